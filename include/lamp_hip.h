@@ -1,0 +1,451 @@
+/*
+ * lamp_hip.h - C ABI of liblamp_hip.so, the MI355X (gfx950) native tensor backend for Lamp.
+ *
+ * This is the drop-in boundary: the functions below are what a JNI adapter for the JVM
+ * package `aten` (the un-vendored dependency io.github.pityka:aten-scala-core, reference
+ * build.sbt:125) would bind, one native per `aten.ATen.*` / `aten.Tensor.*` /
+ * `aten.CudaStream.*` / `aten.NcclComm.*` call that lamp's hot path makes.  Each group cites
+ * the reference call sites (paths relative to the reference root) it replaces.  See
+ * INTEGRATION.md for the JNI stub a maintainer would add.
+ *
+ * Conventions (reference: how lamp uses the handles)
+ *  - every function returns 0 on success, non-zero on failure; lamp_last_error() then holds a
+ *    thread-local message (libtorch raises c10::Error -> JVM exception; the JNI shim does
+ *    the same from this status).  Shape/dtype/device mismatches fail loudly, never corrupt.
+ *  - tensors are opaque handles.  Every tensor returned through an out-parameter is a NEW
+ *    handle the caller owns (also for views, lamp releases views separately:
+ *    lamp-sten/src/main/scala/lamp/device.scala:88-111) and must lamp_tensor_release().
+ *  - `_out` variants write into their first argument, a trailing `_` means in place.
+ *  - scalar types are ATen's scalar-type bytes (lamp-sten/.../STen.scala:726-731):
+ *    0 u8, 1 i8, 2 i16, 3 i32, 4 i64, 5 f16, 6 f32, 7 f64, 11 bool, 15 bf16.
+ *    Compute kernels exist for f32, f64, bf16 (+ i64/i32/u8/bool where indices or masks
+ *    are involved); f16 is storage/cast only.
+ *  - device type 0 = host, 1 = GPU (lamp's "cuda", STen.scala:757-759).  Host tensors are
+ *    staging only (copyFrom/To arrays, pinned buffers): this library has NO CPU compute
+ *    path; handing a host tensor to a compute entry point is an error.
+ *  - kernels launch on the calling thread's current stream of the current device
+ *    (lamp-sten/.../device.scala:119-129, 199-213).
+ */
+#ifndef LAMP_HIP_H
+#define LAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMP_MAX_DIMS 8
+
+typedef struct lamp_tensor lamp_tensor;
+typedef struct lamp_stream lamp_stream;
+typedef struct lamp_comm lamp_comm;
+typedef struct lamp_graph lamp_graph;
+
+#define LAMP_U8 0
+#define LAMP_I8 1
+#define LAMP_I16 2
+#define LAMP_I32 3
+#define LAMP_I64 4
+#define LAMP_F16 5
+#define LAMP_F32 6
+#define LAMP_F64 7
+#define LAMP_BOOL 11
+#define LAMP_BF16 15
+
+#define LAMP_DEVICE_CPU (-1)
+
+/* ------------------------------------------------------------------------------------------
+ * errors / library
+ * ------------------------------------------------------------------------------------------ */
+const char* lamp_last_error(void);
+const char* lamp_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * devices and streams   (aten.Tensor.hasCuda/getNumGPUs, aten.CudaStream.*:
+ * lamp-sten/src/main/scala/lamp/device.scala:178-217, STen.scala:636-639)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_has_gpu(int* out);
+int lamp_get_num_gpus(int* out);
+int lamp_get_device(int* out);                 /* cudaGetDevice */
+int lamp_set_device(int device);               /* cudaSetDevice */
+int lamp_device_synchronize(void);
+int lamp_device_name(char* buf, int buflen);
+int lamp_device_num_cus(int* out);
+int lamp_stream_get_current(int device, lamp_stream** out);      /* getCurrentCUDAStream */
+int lamp_stream_get_default(int device, lamp_stream** out);      /* getDefaultCUDAStream */
+int lamp_stream_get_from_pool(int high_priority, int device, lamp_stream** out); /* getStreamFromPool */
+int lamp_stream_set_current(lamp_stream* s);                     /* setCurrentCUDAStream */
+int lamp_stream_synchronize(lamp_stream* s);
+int lamp_stream_wait_stream(lamp_stream* waiter, lamp_stream* on); /* event record + wait */
+int lamp_stream_release(lamp_stream* s);
+int lamp_stream_native(lamp_stream* s, void** hip_stream_out);
+/* RNG (aten.Tensor.manual_seed*, device.scala:149,170,215; umap.scala:180) */
+int lamp_manual_seed(uint64_t seed);
+/* aten.Tensor.allowtf32: accepted for source compatibility; gfx950 has no reduced precision
+ * f32 MFMA so f32 GEMMs are always exact f32 (example-autoregressivelm/.../main.scala:18) */
+int lamp_allow_tf32(int flag);
+
+/* HIP graph capture of the calling thread's current stream (launch-bound training steps) */
+int lamp_graph_begin_capture(void);
+int lamp_graph_end_capture(lamp_graph** out);
+int lamp_graph_launch(lamp_graph* g);
+int lamp_graph_release(lamp_graph* g);
+
+/* ------------------------------------------------------------------------------------------
+ * allocation registry  (aten.TensorTrace / TensorOptionsTrace:
+ * lamp-sten/src/main/scala/lamp/TensorLogger.scala:13-62,200-201; leak check
+ * lamp-data/src/test/scala/lamp/data/mlp.test.scala:180-188)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_live_tensor_count(int64_t* out);
+int lamp_allocator_stats(int device, int64_t* reserved_bytes, int64_t* in_use_bytes, int64_t* n_device_mallocs);
+int lamp_allocator_trim(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * tensor handles, metadata, host <-> device   (aten.Tensor instance methods used by
+ * STen.scala:845-1000 and TensorHelpers.scala; factories STen.scala:215-330)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_tensor_release(lamp_tensor* t);
+int lamp_tensor_release_all(lamp_tensor** ts, int n);                    /* Tensor.releaseAll */
+int lamp_tensor_retain(const lamp_tensor* t, lamp_tensor** out);
+int lamp_tensor_ndim(const lamp_tensor* t, int* out);
+int lamp_tensor_sizes(const lamp_tensor* t, int64_t* out /* LAMP_MAX_DIMS */);
+int lamp_tensor_strides(const lamp_tensor* t, int64_t* out);
+int lamp_tensor_numel(const lamp_tensor* t, int64_t* out);
+int lamp_tensor_element_size(const lamp_tensor* t, int64_t* out);
+int lamp_tensor_scalar_type(const lamp_tensor* t, int* out);            /* scalarTypeByte */
+int lamp_tensor_device(const lamp_tensor* t, int* out);                 /* -1 host, else GPU index */
+int lamp_tensor_is_contiguous(const lamp_tensor* t, int* out);
+int lamp_tensor_is_pinned(const lamp_tensor* t, int* out);
+int lamp_tensor_data_ptr(const lamp_tensor* t, void** out);
+int lamp_tensor_storage_id(const lamp_tensor* t, uint64_t* out);        /* views share it */
+
+int lamp_empty(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_zeros(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_ones(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_full(lamp_tensor** out, const int64_t* sizes, int ndim, double value, int dtype, int device);
+int lamp_zeros_like(lamp_tensor** out, const lamp_tensor* t);
+int lamp_ones_like(lamp_tensor** out, const lamp_tensor* t);
+int lamp_scalar_tensor(lamp_tensor** out, double value, int dtype, int device);   /* Tensor.scalarDouble */
+int lamp_scalar_tensor_l(lamp_tensor** out, int64_t value, int dtype, int device); /* Tensor.scalarLong */
+int lamp_arange(lamp_tensor** out, double start, double end, double step, int dtype, int device);
+int lamp_eye(lamp_tensor** out, int64_t n, int64_t m, int dtype, int device);
+/* wrap caller-owned memory without copying (from_file / pinned staging / interop) */
+int lamp_from_blob(lamp_tensor** out, void* data, const int64_t* sizes, const int64_t* strides, int ndim,
+                   int dtype, int device);
+/* copyFrom<Type>Array / copyTo<Type>Array (TensorHelpers.scala:44-345): raw bytes of the
+ * tensor's own dtype, row-major.  For GPU tensors these stage through the current stream
+ * and synchronise it. */
+int lamp_copy_from_host(lamp_tensor* dst, const void* src, size_t nbytes);
+int lamp_copy_to_host(const lamp_tensor* src, void* dst, size_t nbytes);
+int lamp_clone(lamp_tensor** out, const lamp_tensor* t);
+int lamp_contiguous(lamp_tensor** out, const lamp_tensor* t);
+int lamp_copy_(lamp_tensor* dst, const lamp_tensor* src, int non_blocking);  /* copyFrom, STen.scala:931-944 */
+/* value.to(options, non_blocking, copy) (device.scala:221-225; STen.scala:1880) */
+int lamp_to(lamp_tensor** out, const lamp_tensor* t, int dtype, int device, int non_blocking, int copy);
+int lamp_cast(lamp_tensor** out, const lamp_tensor* t, int dtype);      /* _cast_Float/Double/Long/... */
+int lamp_pin_memory(lamp_tensor** out, const lamp_tensor* t);
+int lamp_item(const lamp_tensor* t, double* out);                        /* numel==1, syncs */
+
+/* ------------------------------------------------------------------------------------------
+ * views   (ATen.t/transpose/select/slice/narrow/_unsafe_view/reshape/flatten/expand_as/
+ * squeeze/unsqueeze/cat/stack: STen.scala:210-213,956-971,1374-1380,1472-1491,1740,1766-1775;
+ * ops.scala:15-118)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_view(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim);   /* view/_unsafe_view, one -1 allowed */
+int lamp_reshape(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim);
+int lamp_flatten(lamp_tensor** out, const lamp_tensor* t, int64_t start_dim, int64_t end_dim);
+int lamp_transpose(lamp_tensor** out, const lamp_tensor* t, int64_t dim0, int64_t dim1);
+int lamp_t(lamp_tensor** out, const lamp_tensor* t);
+int lamp_select(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t index);
+int lamp_slice(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t end, int64_t step);
+int lamp_narrow(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t length);
+int lamp_expand(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim);
+int lamp_expand_as(lamp_tensor** out, const lamp_tensor* t, const lamp_tensor* other);
+int lamp_squeeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim);   /* dim = INT64_MIN: all */
+int lamp_unsqueeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim);
+int lamp_cat(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim);
+int lamp_cat_out(lamp_tensor* out, lamp_tensor* const* ts, int n, int64_t dim);
+int lamp_stack(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim);
+
+/* ------------------------------------------------------------------------------------------
+ * fills   (fill__0, zero_: STen.scala:1382,1406)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_fill_(lamp_tensor* t, double value);
+int lamp_zero_(lamp_tensor* t);
+
+/* ------------------------------------------------------------------------------------------
+ * element-wise, broadcasting   (ATen.add_0/sub_0/mul_0/div_0 + scalar + _out + in-place,
+ * addcmul_out/addcdiv_out: STen.scala:365-468,1110-1217,1242-1264; ops.scala:511-621)
+ *   out = a + alpha*b  etc.
+ * ------------------------------------------------------------------------------------------ */
+int lamp_add(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, double alpha);
+int lamp_sub(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, double alpha);
+int lamp_mul(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_div(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_add_scalar(lamp_tensor** out, const lamp_tensor* a, double b, double alpha);
+int lamp_sub_scalar(lamp_tensor** out, const lamp_tensor* a, double b, double alpha);
+int lamp_mul_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_div_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_add_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b, double alpha);
+int lamp_sub_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b, double alpha);
+int lamp_mul_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_div_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_add_(lamp_tensor* self, const lamp_tensor* b, double alpha);    /* += */
+int lamp_sub_(lamp_tensor* self, const lamp_tensor* b, double alpha);    /* -= */
+int lamp_mul_(lamp_tensor* self, const lamp_tensor* b);                  /* *= */
+int lamp_div_(lamp_tensor* self, const lamp_tensor* b);                  /* /= */
+int lamp_add_scalar_(lamp_tensor* self, double b, double alpha);
+int lamp_mul_scalar_(lamp_tensor* self, double b);
+int lamp_addcmul_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value);
+int lamp_addcdiv_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value);
+int lamp_maximum(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);   /* max_2, knn/package.scala:28 */
+int lamp_minimum(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_pow_scalar(lamp_tensor** out, const lamp_tensor* a, double exponent);     /* pow_2 */
+int lamp_pow_tensor(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* exponent);
+int lamp_where(lamp_tensor** out, const lamp_tensor* cond, const lamp_tensor* a, const lamp_tensor* b); /* where_0 */
+int lamp_masked_fill(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask, double value);
+/* comparisons -> bool tensors (lt_0/le_0/ne_1/eq/gt/ge: STen.scala:1013-1030,1610-1665) */
+int lamp_lt_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_le_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_gt_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_ge_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_eq_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_ne_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_lt(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_le(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_gt(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_ge(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_eq(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_ne(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_logical_not(lamp_tensor** out, const lamp_tensor* a);
+
+/* unary (STen.scala:1266-1320; activations ops.scala:854-1032).  In-place twins take `_`. */
+int lamp_relu(lamp_tensor** out, const lamp_tensor* a);
+int lamp_relu_(lamp_tensor* a);
+int lamp_leaky_relu(lamp_tensor** out, const lamp_tensor* a, double negative_slope);
+int lamp_gelu(lamp_tensor** out, const lamp_tensor* a);                   /* exact erf form */
+int lamp_gelu_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* self);
+int lamp_sigmoid(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sigmoid_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output);
+int lamp_tanh(lamp_tensor** out, const lamp_tensor* a);
+int lamp_tanh_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output);
+int lamp_hardswish(lamp_tensor** out, const lamp_tensor* a);
+int lamp_hardswish_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* self);
+int lamp_softplus(lamp_tensor** out, const lamp_tensor* a, double beta, double threshold);
+int lamp_softplus_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* self, double beta, double threshold);
+int lamp_exp(lamp_tensor** out, const lamp_tensor* a);
+int lamp_exp_(lamp_tensor* a);
+int lamp_log(lamp_tensor** out, const lamp_tensor* a);
+int lamp_log1p(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sqrt(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sqrt_(lamp_tensor* a);
+int lamp_square(lamp_tensor** out, const lamp_tensor* a);
+int lamp_reciprocal(lamp_tensor** out, const lamp_tensor* a);
+int lamp_reciprocal_(lamp_tensor* a);
+int lamp_neg(lamp_tensor** out, const lamp_tensor* a);
+int lamp_abs(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sign(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sin(lamp_tensor** out, const lamp_tensor* a);
+int lamp_cos(lamp_tensor** out, const lamp_tensor* a);
+int lamp_tan(lamp_tensor** out, const lamp_tensor* a);
+int lamp_atan(lamp_tensor** out, const lamp_tensor* a);
+/* fused forms of lamp's op backward closures (same arithmetic as the ATen call chains they
+ * replace; see DESIGN.md "fused backward closures"):
+ *   relu:  out += p * (x < 0 ? 0 : 1)      ops.scala:918-935 (gradient at x == 0 is 1)
+ *   leaky: out += p * (x < 0 ? slope : 1)  ops.scala:936-953 */
+int lamp_relu_backward_accumulate_(lamp_tensor* out, const lamp_tensor* p, const lamp_tensor* x, double negative_slope);
+
+/* ------------------------------------------------------------------------------------------
+ * reductions   (sum_0/sum_1/mean_1/norm_3/var_mean/argmax/max/min: STen.scala:1336-1352,
+ * 1493-1501,1524-1540,1565-1585,987; TensorHelpers.unbroadcast TensorHelpers.scala:7-41)
+ * ------------------------------------------------------------------------------------------ */
+int lamp_sum_all(lamp_tensor** out, const lamp_tensor* a);
+int lamp_sum_dims(lamp_tensor** out, const lamp_tensor* a, const int64_t* dims, int ndims, int keepdim);
+int lamp_mean_all(lamp_tensor** out, const lamp_tensor* a);
+int lamp_mean_dims(lamp_tensor** out, const lamp_tensor* a, const int64_t* dims, int ndims, int keepdim);
+int lamp_norm2_dims(lamp_tensor** out, const lamp_tensor* a, const int64_t* dims, int ndims, int keepdim);
+int lamp_var_mean_dims(lamp_tensor** var_out, lamp_tensor** mean_out, const lamp_tensor* a, const int64_t* dims,
+                       int ndims, int unbiased, int keepdim);
+int lamp_max_all(lamp_tensor** out, const lamp_tensor* a);
+int lamp_min_all(lamp_tensor** out, const lamp_tensor* a);
+int lamp_argmax(lamp_tensor** out, const lamp_tensor* a, int64_t dim, int keepdim);
+int lamp_unbroadcast(lamp_tensor** out, const lamp_tensor* p, const int64_t* target_sizes, int ndim);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM family   (ATen.mm/bmm/addmm/baddbmm/matmul + aten-scala's custom natives
+ * Tensor.addmm_out_transposed1/2 and Tensor.baddbmm_out_transposed1/2:
+ * STen.scala:391-449,1146,1220-1240; ops.scala:665-724)
+ *   addmm_out_transposed1: out = beta*self + alpha * (a^T . b)
+ *   addmm_out_transposed2: out = beta*self + alpha * (a . b^T)
+ * bf16 -> MFMA 16x16x32 bf16, fp32 accumulate; f32 -> exact f32 MFMA; f64 -> f64 MFMA.
+ * ------------------------------------------------------------------------------------------ */
+int lamp_mm(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_mm_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_bmm(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_bmm_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_matmul(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_addmm(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_addmm_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_baddbmm(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_addmm_out_transposed1(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_addmm_out_transposed2(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_baddbmm_out_transposed1(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+int lamp_baddbmm_out_transposed2(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha);
+/* fused Linear forward: y = x.W + bias[1,out] (lamp-core/.../nn/Linear.scala:19-33 issues
+ * mm then a broadcast add; this is the same arithmetic with the add in the GEMM epilogue) */
+int lamp_linear_bias(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* w, const lamp_tensor* bias_or_null);
+
+/* ------------------------------------------------------------------------------------------
+ * convolution / pooling   (ATen.convolution, convolution_backward(output_mask[3]),
+ * avg_pool2d(+_backward), max_pool2d_with_indices(+_backward): ops.scala:1547-1651,
+ * 1721-1825).  NCHW / NCL contiguous, groups supported, transposed supported.
+ * ------------------------------------------------------------------------------------------ */
+int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* w, const lamp_tensor* bias_or_null,
+                     const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial,
+                     int transposed, const int64_t* output_padding, int64_t groups);
+/* out3 = {grad_input, grad_weight, grad_bias}; entries whose mask is 0 come back NULL */
+int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x,
+                              const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
+                              const int64_t* dilation, int nspatial, int transposed,
+                              const int64_t* output_padding, int64_t groups, const uint8_t mask[3]);
+int lamp_avg_pool2d(lamp_tensor** out, const lamp_tensor* x, int64_t kernel, int64_t stride, int64_t padding,
+                    int ceil_mode, int count_include_pad);
+int lamp_avg_pool2d_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel,
+                             int64_t stride, int64_t padding, int ceil_mode, int count_include_pad);
+int lamp_max_pool2d_with_indices(lamp_tensor** out, lamp_tensor** indices, const lamp_tensor* x, int64_t kernel,
+                                 int64_t stride, int64_t padding, int64_t dilation, int ceil_mode);
+int lamp_max_pool2d_with_indices_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
+                                          int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,
+                                          int ceil_mode, const lamp_tensor* indices);
+
+/* ------------------------------------------------------------------------------------------
+ * normalisation   (ATen.native_batch_norm(+_backward), native_layer_norm(+_backward):
+ * ops.scala:1846-2140).  running_mean/var are updated in place when training
+ * (running_var with the unbiased estimate); stats are computed in f32 for bf16 inputs.
+ * ------------------------------------------------------------------------------------------ */
+int lamp_native_batch_norm(lamp_tensor* out3[3] /* y, save_mean, save_invstd */, const lamp_tensor* x,
+                           const lamp_tensor* weight_or_null, const lamp_tensor* bias_or_null,
+                           lamp_tensor* running_mean_or_null, lamp_tensor* running_var_or_null, int training,
+                           double momentum, double eps);
+int lamp_native_batch_norm_backward(lamp_tensor* out3[3] /* dx, dweight, dbias */, const lamp_tensor* grad_out,
+                                    const lamp_tensor* x, const lamp_tensor* weight_or_null,
+                                    const lamp_tensor* running_mean_or_null, const lamp_tensor* running_var_or_null,
+                                    const lamp_tensor* save_mean_or_null, const lamp_tensor* save_invstd_or_null,
+                                    int training, double eps, const uint8_t mask[3]);
+int lamp_native_layer_norm(lamp_tensor* out3[3] /* y, mean, rstd */, const lamp_tensor* x,
+                           const int64_t* normalized_shape, int nnorm, const lamp_tensor* weight_or_null,
+                           const lamp_tensor* bias_or_null, double eps);
+int lamp_native_layer_norm_backward(lamp_tensor* out3[3] /* dx, dweight, dbias */, const lamp_tensor* grad_out,
+                                    const lamp_tensor* x, const int64_t* normalized_shape, int nnorm,
+                                    const lamp_tensor* mean, const lamp_tensor* rstd,
+                                    const lamp_tensor* weight_or_null, const lamp_tensor* bias_or_null,
+                                    const uint8_t mask[3]);
+
+/* ------------------------------------------------------------------------------------------
+ * softmax / losses   (ATen.log_softmax, _log_softmax_backward_data, nll_loss_forward/backward,
+ * mse_loss(+_backward): ops.scala:955-975,1176-1304; STen.scala:602-616,1509)
+ * reduction: 0 none, 1 mean, 2 sum
+ * ------------------------------------------------------------------------------------------ */
+int lamp_log_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
+int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* output, int64_t dim);
+int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
+int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
+                          const lamp_tensor* target /* i64 [N] */, const lamp_tensor* weight_or_null,
+                          int64_t reduction, int64_t ignore_index);
+int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
+                           const lamp_tensor* target, const lamp_tensor* weight_or_null, int64_t reduction,
+                           int64_t ignore_index, const lamp_tensor* total_weight);
+int lamp_mse_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction);
+int lamp_mse_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
+                           const lamp_tensor* target, int64_t reduction);
+
+/* ------------------------------------------------------------------------------------------
+ * indexing / sampling   (index_select, index_add_0, index, masked_select, repeat_interleave_2,
+ * randint, topk, embedding: ops.scala:179-197; BatchStream.scala:548-549; umap.scala:211-227;
+ * knn/package.scala:55).  Index tensors are i64 and results are bit-exact.
+ * ------------------------------------------------------------------------------------------ */
+int lamp_index_select(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index);
+int lamp_index_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
+int lamp_index_add_(lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
+int lamp_masked_select(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask);   /* syncs (output size) */
+int lamp_repeat_interleave(lamp_tensor** out, const lamp_tensor* a, int64_t repeats, int64_t dim);
+int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted);
+int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes);
+int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tensor* indices);
+int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights);
+/* RNG: Philox4x32-10 counter streams; bit-compat with libtorch streams is not required by any
+ * reference test (SURVEY.md 8b "RNG / globals") */
+int lamp_rand(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_randn(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_normal(lamp_tensor** out, double mean, double std, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_randint(lamp_tensor** out, int64_t low, int64_t high, const int64_t* sizes, int ndim, int dtype, int device);
+int lamp_dropout_(lamp_tensor* self, double p, int training);
+
+/* ------------------------------------------------------------------------------------------
+ * fused multi-tensor optimiser steps   (lamp-core/src/main/scala/lamp/nn/AdamW.scala:101-176,
+ * SGD.scala:46-98, nn/package.scala:72-100).  One launch for all parameter tensors instead
+ * of ~8 ATen calls per tensor; arithmetic order follows the reference line by line.
+ * ------------------------------------------------------------------------------------------ */
+/* sum_i ||g_i||^2 -> out (1 element, dtype of g_0); then g_i *= min(1, theta/sqrt(sum)) */
+int lamp_gradient_clipping_(lamp_tensor* const* grads, int n, double theta);
+/* params/grads/m/v: n tensors each. master_or_null[i] != NULL => mixed precision working copy
+ * (f32) is updated and params[i] receives the down-cast copy (AdamW.scala:48-85,167-169). */
+int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_tensor* const* m,
+                     lamp_tensor* const* v, lamp_tensor* const* master_or_null, int n, const double* lr,
+                     const double* weight_decay, const double* beta1, const double* beta2, double eps,
+                     double schedule_factor, int64_t step_count, int debias);
+int lamp_sgdw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_tensor* const* velocity_or_null,
+                    int n, const double* lr, const double* weight_decay, const double* momentum,
+                    double schedule_factor);
+/* flat bucket helpers for data parallel training: pack n tensors into one
+ * contiguous f32 bucket scaled by `scale`, and unpack with a (device-resident) divisor */
+int lamp_flatten_into_(lamp_tensor* bucket, lamp_tensor* const* ts, int n, double scale);
+int lamp_unflatten_from_(lamp_tensor* const* ts, int n, const lamp_tensor* bucket, int divide_by_last_element);
+
+/* ------------------------------------------------------------------------------------------
+ * scaled dot product attention   (aten _scaled_dot_product_*_attention(+_backward):
+ * STen.scala:501-584; ops.scala:2342-2390).  q,k,v: (B, heads, S, d).
+ * ------------------------------------------------------------------------------------------ */
+int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp, const lamp_tensor* q,
+                                      const lamp_tensor* k, const lamp_tensor* v, int is_causal, double scale);
+int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
+                                               const lamp_tensor* q, const lamp_tensor* k, const lamp_tensor* v,
+                                               const lamp_tensor* out, const lamp_tensor* logsumexp,
+                                               int is_causal, double scale);
+
+/* ------------------------------------------------------------------------------------------
+ * kNN / UMAP fused kernels   (lamp-knn/src/main/scala/lamp/knn/package.scala:21-80;
+ * lamp-umap/src/main/scala/lamp/umap/umap.scala:115-286)
+ * ------------------------------------------------------------------------------------------ */
+/* indices[q,k] (i64) of the k smallest max(0,|q|^2+|x|^2-2q.x) per query row; never
+ * materialises the q x n distance matrix.  distances_or_null receives the k values. */
+int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances_or_null, const lamp_tensor* data,
+                               const lamp_tensor* query, int64_t k);
+/* one fused evaluation of the UMAP layout loss and its gradient w.r.t. locations
+ * (minDist == 0 branch and the capped-exponential branch) - see umap.scala:132-176 */
+int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations,
+                        const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
+                        const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
+                        int balance, double repulsion_strength);
+
+/* ------------------------------------------------------------------------------------------
+ * collectives over RCCL / xGMI   (aten.NcclComm.{get_unique_id, comm_init_rank, broadcast,
+ * reduce, comm_destroy}: STen.scala:629-671,1902-1908; call sites
+ * lamp-data/.../distributed/package.scala:683-731).  all_reduce is the addition the
+ * data-parallel redesign needs (one flat bucket instead of 74 broadcasts + 38 reduces).
+ * ------------------------------------------------------------------------------------------ */
+#define LAMP_UNIQUE_ID_BYTES 128
+int lamp_comm_get_unique_id(uint8_t* id_out /* LAMP_UNIQUE_ID_BYTES */);
+int lamp_comm_init_rank(lamp_comm** out, int nranks, const uint8_t* id, int rank);
+int lamp_comm_broadcast(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int root);
+int lamp_comm_reduce(lamp_tensor* const* inputs, lamp_tensor* output, int root, int op /* 0 = sum */,
+                     lamp_comm* const* comms, int n);
+int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int op);
+int lamp_comm_destroy(lamp_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMP_HIP_H */

@@ -1,0 +1,265 @@
+// Devices, streams, errors, RNG state and HIP-graph capture.
+//
+// Mirrors what lamp expects from aten.CudaStream / aten.Tensor statics
+// (reference: lamp-sten/src/main/scala/lamp/device.scala:119-129,178-217):
+// the current device and the current stream are PER OS THREAD, kernels go to the
+// calling thread's current stream.
+#include "tensor.h"
+
+#include <mutex>
+#include <map>
+
+struct lamp_stream {
+  hipStream_t s = nullptr;
+  int device = 0;
+  bool is_default = false;
+  std::atomic<int> refs{1};
+};
+
+struct lamp_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t stream = nullptr;
+  int device = 0;
+};
+
+namespace lamp {
+
+static thread_local std::string tl_error;
+void set_last_error(const std::string& msg) { tl_error = msg; }
+
+static thread_local int tl_device = 0;
+static thread_local bool tl_device_set = false;
+static thread_local hipStream_t tl_streams[16] = {nullptr};
+static thread_local bool tl_stream_set[16] = {false};
+
+static std::mutex g_mu;
+static int g_num_cus = -1;
+static std::atomic<uint64_t> g_seed{0x5eed1234abcdULL};
+static std::atomic<uint64_t> g_philox_offset{0};
+
+int current_device() {
+  if (!tl_device_set) {
+    // adopt the process default (LOCAL_RANK based selection happens via lamp_set_device)
+    tl_device = 0;
+    tl_device_set = true;
+    hipError_t e = hipSetDevice(0);
+    if (e != hipSuccess) throw Error(std::string("hipSetDevice(0) failed: ") + hipGetErrorString(e) +
+                                     " - no usable MI355X device; this library has no CPU fallback");
+  }
+  return tl_device;
+}
+void set_device(int d) {
+  HIP_CHECK(hipSetDevice(d));
+  tl_device = d;
+  tl_device_set = true;
+}
+hipStream_t current_stream(int device) {
+  LAMP_CHECK(device >= 0 && device < 16, "bad device " << device);
+  if (!tl_stream_set[device]) return nullptr;  // the null (default) stream
+  return tl_streams[device];
+}
+hipStream_t current_stream() { return current_stream(current_device()); }
+
+int num_cus() {
+  if (g_num_cus < 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_num_cus < 0) {
+      hipDeviceProp_t p;
+      hipError_t e = hipGetDeviceProperties(&p, current_device());
+      g_num_cus = (e == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+  }
+  return g_num_cus;
+}
+uint64_t philox_seed() { return g_seed.load(); }
+uint64_t next_philox_offset(uint64_t n) { return g_philox_offset.fetch_add(n); }
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+const char* lamp_last_error(void) { return tl_error.c_str(); }
+const char* lamp_version(void) { return "lamp_hip 0.1 (gfx950)"; }
+
+int lamp_has_gpu(int* out) {
+  LAMP_API_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *out = (e == hipSuccess && n > 0) ? 1 : 0;
+  LAMP_API_END
+}
+int lamp_get_num_gpus(int* out) {
+  LAMP_API_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *out = (e == hipSuccess) ? n : 0;
+  LAMP_API_END
+}
+int lamp_get_device(int* out) {
+  LAMP_API_BEGIN
+  *out = current_device();
+  LAMP_API_END
+}
+int lamp_set_device(int device) {
+  LAMP_API_BEGIN
+  set_device(device);
+  LAMP_API_END
+}
+int lamp_device_synchronize(void) {
+  LAMP_API_BEGIN
+  current_device();
+  HIP_CHECK(hipDeviceSynchronize());
+  LAMP_API_END
+}
+int lamp_device_name(char* buf, int buflen) {
+  LAMP_API_BEGIN
+  hipDeviceProp_t p;
+  HIP_CHECK(hipGetDeviceProperties(&p, current_device()));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  LAMP_API_END
+}
+int lamp_device_num_cus(int* out) {
+  LAMP_API_BEGIN
+  *out = num_cus();
+  LAMP_API_END
+}
+
+int lamp_stream_get_current(int device, lamp_stream** out) {
+  LAMP_API_BEGIN
+  auto* s = new lamp_stream();
+  s->device = device;
+  s->s = current_stream(device);
+  s->is_default = (s->s == nullptr);
+  *out = s;
+  LAMP_API_END
+}
+int lamp_stream_get_default(int device, lamp_stream** out) {
+  LAMP_API_BEGIN
+  auto* s = new lamp_stream();
+  s->device = device;
+  s->s = nullptr;
+  s->is_default = true;
+  *out = s;
+  LAMP_API_END
+}
+
+// a small round-robin pool per device, like c10's getStreamFromPool
+static std::mutex g_pool_mu;
+static std::map<std::pair<int, int>, std::vector<hipStream_t>> g_pool;
+static std::map<std::pair<int, int>, size_t> g_pool_next;
+
+int lamp_stream_get_from_pool(int high_priority, int device, lamp_stream** out) {
+  LAMP_API_BEGIN
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto key = std::make_pair(device, high_priority ? 1 : 0);
+  auto& v = g_pool[key];
+  if (v.empty()) {
+    int prev = current_device();
+    HIP_CHECK(hipSetDevice(device));
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (int i = 0; i < 8; i++) {
+      hipStream_t s;
+      HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : lo));
+      v.push_back(s);
+    }
+    HIP_CHECK(hipSetDevice(prev));
+  }
+  size_t& nx = g_pool_next[key];
+  auto* s = new lamp_stream();
+  s->device = device;
+  s->s = v[nx % v.size()];
+  nx++;
+  *out = s;
+  LAMP_API_END
+}
+int lamp_stream_set_current(lamp_stream* s) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(s, "null stream");
+  tl_streams[s->device] = s->s;
+  tl_stream_set[s->device] = !s->is_default;
+  LAMP_API_END
+}
+int lamp_stream_synchronize(lamp_stream* s) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(s, "null stream");
+  HIP_CHECK(hipStreamSynchronize(s->s));
+  LAMP_API_END
+}
+int lamp_stream_wait_stream(lamp_stream* waiter, lamp_stream* on) {
+  LAMP_API_BEGIN
+  hipEvent_t ev;
+  HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(ev, on->s));
+  HIP_CHECK(hipStreamWaitEvent(waiter->s, ev, 0));
+  HIP_CHECK(hipEventDestroy(ev));
+  LAMP_API_END
+}
+int lamp_stream_release(lamp_stream* s) {
+  LAMP_API_BEGIN
+  delete s;  // pool streams stay alive for the process lifetime
+  LAMP_API_END
+}
+int lamp_stream_native(lamp_stream* s, void** out) {
+  LAMP_API_BEGIN
+  *out = (void*)s->s;
+  LAMP_API_END
+}
+
+int lamp_manual_seed(uint64_t seed) {
+  LAMP_API_BEGIN
+  g_seed.store(seed);
+  g_philox_offset.store(0);
+  LAMP_API_END
+}
+int lamp_allow_tf32(int) { return 0; }
+
+// ---- HIP graphs ------------------------------------------------------------------------------
+int lamp_graph_begin_capture(void) {
+  LAMP_API_BEGIN
+  hipStream_t s = current_stream();
+  LAMP_CHECK(s != nullptr, "graph capture needs a non-default current stream "
+                           "(lamp_stream_get_from_pool + lamp_stream_set_current first)");
+  allocator_begin_capture_pool();
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    allocator_end_capture_pool();
+    HIP_CHECK(e);
+  }
+  LAMP_API_END
+}
+int lamp_graph_end_capture(lamp_graph** out) {
+  LAMP_API_BEGIN
+  hipStream_t s = current_stream();
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  allocator_end_capture_pool();
+  HIP_CHECK(e);
+  auto* lg = new lamp_graph();
+  lg->graph = g;
+  lg->stream = s;
+  lg->device = current_device();
+  HIP_CHECK(hipGraphInstantiate(&lg->exec, g, nullptr, nullptr, 0));
+  *out = lg;
+  LAMP_API_END
+}
+int lamp_graph_launch(lamp_graph* g) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(g && g->exec, "null graph");
+  HIP_CHECK(hipGraphLaunch(g->exec, current_stream()));
+  LAMP_API_END
+}
+int lamp_graph_release(lamp_graph* g) {
+  LAMP_API_BEGIN
+  if (g) {
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+  }
+  LAMP_API_END
+}
+
+}  // extern "C"

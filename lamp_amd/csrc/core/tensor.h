@@ -1,0 +1,205 @@
+// Internal C++ view of the runtime behind include/lamp_hip.h.
+//
+// A lamp_tensor is what lamp's `aten.Tensor` JVM object points at
+// (reference: lamp-sten/src/main/scala/lamp/STen.scala:845 wraps exactly one
+// such native handle): a strided view (sizes/strides/offset, row-major by
+// default, NCHW for images) over a reference-counted storage block that lives
+// either in HBM (hipMalloc'ed through the caching allocator) or in host memory
+// (staging only - there is NO CPU compute path in this library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <sstream>
+
+#include "../../../include/lamp_hip.h"
+
+namespace lamp {
+
+constexpr int kMaxDims = LAMP_MAX_DIMS;
+
+// ATen scalar-type bytes, the values lamp passes around (STen.scala:726-731).
+enum DType : int {
+  kU8 = 0, kI8 = 1, kI16 = 2, kI32 = 3, kI64 = 4, kF16 = 5, kF32 = 6, kF64 = 7, kBool = 11, kBF16 = 15
+};
+
+inline size_t dtype_size(int dt) {
+  switch (dt) {
+    case kU8: case kI8: case kBool: return 1;
+    case kI16: case kF16: case kBF16: return 2;
+    case kI32: case kF32: return 4;
+    case kI64: case kF64: return 8;
+  }
+  throw std::runtime_error("unknown scalar type byte " + std::to_string(dt));
+}
+inline const char* dtype_name(int dt) {
+  switch (dt) {
+    case kU8: return "u8"; case kI8: return "i8"; case kI16: return "i16"; case kI32: return "i32";
+    case kI64: return "i64"; case kF16: return "f16"; case kF32: return "f32"; case kF64: return "f64";
+    case kBool: return "bool"; case kBF16: return "bf16";
+  }
+  return "?";
+}
+inline bool is_float(int dt) { return dt == kF32 || dt == kF64 || dt == kBF16 || dt == kF16; }
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define LAMP_CHECK(cond, ...)                                                     \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      std::ostringstream _os;                                                     \
+      _os << __VA_ARGS__;                                                         \
+      throw ::lamp::Error(std::string(__func__) + ": " + _os.str());              \
+    }                                                                             \
+  } while (0)
+
+#define HIP_CHECK(expr)                                                           \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      throw ::lamp::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e)); \
+    }                                                                             \
+  } while (0)
+
+void set_last_error(const std::string& msg);
+
+// every extern "C" body is wrapped in these: exceptions never cross the C ABI
+// (the JNI shim turns a non-zero status + lamp_last_error() into a JVM exception,
+// which is what lamp's Scope relies on - Scope.scala:394-421).
+#define LAMP_API_BEGIN try {
+#define LAMP_API_END                                                              \
+  return 0;                                                                       \
+  }                                                                               \
+  catch (const std::exception& e) {                                               \
+    ::lamp::set_last_error(e.what());                                             \
+    return 1;                                                                     \
+  }                                                                               \
+  catch (...) {                                                                   \
+    ::lamp::set_last_error("unknown C++ exception");                              \
+    return 1;                                                                     \
+  }
+
+// ---------------------------------------------------------------------------------------------
+struct Storage {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int device = -1;          // -1 = host, >=0 = HIP device ordinal
+  bool pinned = false;      // host only
+  bool owned = true;        // false: wraps caller memory (lamp_tensor_from_blob)
+  void* pool = nullptr;     // allocator block cookie
+  std::atomic<int> refs{1};
+};
+
+}  // namespace lamp
+
+// The opaque handle of the C ABI.
+struct lamp_tensor {
+  lamp::Storage* st = nullptr;
+  int64_t offset = 0;  // in elements
+  int ndim = 0;
+  int64_t sizes[lamp::kMaxDims] = {0};
+  int64_t strides[lamp::kMaxDims] = {0};
+  int dtype = lamp::kF32;
+
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; i++) n *= sizes[i];
+    return n;
+  }
+  int device() const { return st ? st->device : -1; }
+  bool is_device() const { return st && st->device >= 0; }
+  size_t itemsize() const { return lamp::dtype_size(dtype); }
+  void* data() const { return st ? (char*)st->ptr + offset * (int64_t)itemsize() : nullptr; }
+  template <class T> T* ptr() const { return (T*)data(); }
+  bool is_contiguous() const {
+    int64_t expect = 1;
+    for (int i = ndim - 1; i >= 0; i--) {
+      if (sizes[i] == 1) continue;
+      if (strides[i] != expect) return false;
+      expect *= sizes[i];
+    }
+    return true;
+  }
+  std::vector<int64_t> shape() const { return std::vector<int64_t>(sizes, sizes + ndim); }
+  std::string describe() const {
+    std::ostringstream os;
+    os << lamp::dtype_name(dtype) << "[";
+    for (int i = 0; i < ndim; i++) os << (i ? "," : "") << sizes[i];
+    os << "]@" << (is_device() ? "gpu" : "cpu");
+    return os.str();
+  }
+};
+
+namespace lamp {
+
+using Tensor = lamp_tensor;
+
+// ---- allocator (core/allocator.cpp) ----
+void* device_alloc(int device, size_t bytes, void** cookie);
+void device_free(int device, void* ptr, void* cookie);
+void allocator_stats(int device, int64_t* reserved, int64_t* in_use, int64_t* n_malloc);
+void allocator_trim(int device);
+void allocator_begin_capture_pool();
+void allocator_end_capture_pool();
+
+// ---- runtime (core/runtime.cpp) ----
+int current_device();
+void set_device(int d);
+hipStream_t current_stream();           // thread-local current stream of current device
+hipStream_t current_stream(int device);
+int num_cus();
+uint64_t next_philox_offset(uint64_t n);  // advances the generator state by n draws
+uint64_t philox_seed();
+
+// ---- tensor construction (core/tensor.cpp) ----
+Tensor* new_tensor(const int64_t* sizes, int ndim, int dtype, int device);  // uninitialised, contiguous
+inline Tensor* new_tensor(const std::vector<int64_t>& s, int dtype, int device) {
+  return new_tensor(s.data(), (int)s.size(), dtype, device);
+}
+Tensor* new_like(const Tensor* t);  // contiguous, same shape/dtype/device
+Tensor* new_like(const Tensor* t, int dtype);
+Tensor* new_view(const Tensor* base, const int64_t* sizes, const int64_t* strides, int ndim, int64_t offset);
+Tensor* retain(const Tensor* t);  // new handle on the same view
+void release(Tensor* t);
+Tensor* contiguous(const Tensor* t);  // +1 handle; a copy only if needed
+void copy_into(Tensor* dst, const Tensor* src);  // handles dtype conversion, strides, host<->device
+void fill_zero(Tensor* t);
+
+// RAII holder for temporaries inside API functions.
+struct Hold {
+  Tensor* t;
+  explicit Hold(Tensor* t_ = nullptr) : t(t_) {}
+  ~Hold() { if (t) release(t); }
+  Hold(const Hold&) = delete;
+  Hold& operator=(const Hold&) = delete;
+  Hold(Hold&& o) : t(o.t) { o.t = nullptr; }
+  Hold& operator=(Hold&& o) { if (this != &o) { if (t) release(t); t = o.t; o.t = nullptr; } return *this; }
+  Tensor* get() const { return t; }
+  Tensor* operator->() const { return t; }
+  Tensor* take() { Tensor* r = t; t = nullptr; return r; }
+};
+
+inline void check_same_device(const Tensor* a, const Tensor* b) {
+  LAMP_CHECK(a->device() == b->device(), "tensors on different devices: " << a->describe() << " vs " << b->describe());
+}
+inline void check_device_tensor(const Tensor* a, const char* what) {
+  LAMP_CHECK(a != nullptr, what << " is null");
+  LAMP_CHECK(a->is_device(), what << " " << a->describe()
+             << " is a host tensor: this library has no CPU compute path, move it to the GPU first");
+}
+
+inline int grid_for(int64_t work_items, int block, int max_blocks_per_cu = 8) {
+  int64_t g = (work_items + block - 1) / block;
+  int64_t cap = (int64_t)num_cus() * max_blocks_per_cu;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace lamp

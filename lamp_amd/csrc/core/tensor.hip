@@ -1,0 +1,757 @@
+// Tensor handles: creation, release, metadata, views, host<->device copies, strided copy/cast.
+//
+// Replaces the `aten.Tensor` instance surface lamp-sten drives (reference:
+// lamp-sten/src/main/scala/lamp/STen.scala:845-1000, TensorHelpers.scala:44-345,
+// device.scala:62-114,221-225).
+#include "tensor.h"
+#include "strided.h"
+#include "../kernels/device_utils.h"
+
+#include <climits>
+
+namespace lamp {
+
+static std::atomic<int64_t> g_live_tensors{0};
+
+static Storage* new_storage(size_t bytes, int device, bool pinned = false) {
+  Storage* s = new Storage();
+  s->bytes = bytes;
+  s->device = device;
+  s->pinned = pinned;
+  if (device >= 0) {
+    s->ptr = device_alloc(device, bytes, &s->pool);
+  } else if (pinned) {
+    HIP_CHECK(hipHostMalloc(&s->ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  } else {
+    s->ptr = malloc(bytes ? bytes : 1);
+    LAMP_CHECK(s->ptr, "host malloc of " << bytes << " bytes failed");
+  }
+  return s;
+}
+static void storage_unref(Storage* s) {
+  if (!s) return;
+  if (s->refs.fetch_sub(1) == 1) {
+    if (s->owned) {
+      if (s->device >= 0) device_free(s->device, s->ptr, s->pool);
+      else if (s->pinned) (void)hipHostFree(s->ptr);
+      else free(s->ptr);
+    }
+    delete s;
+  }
+}
+
+Tensor* new_tensor(const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_CHECK(ndim >= 0 && ndim <= kMaxDims, "ndim " << ndim << " out of range");
+  Tensor* t = new Tensor();
+  t->ndim = ndim;
+  t->dtype = dtype;
+  int64_t n = 1;
+  for (int i = ndim - 1; i >= 0; i--) {
+    LAMP_CHECK(sizes[i] >= 0, "negative size");
+    t->sizes[i] = sizes[i];
+    t->strides[i] = n;
+    n *= sizes[i];
+  }
+  try {
+    t->st = new_storage((size_t)n * dtype_size(dtype), device);
+  } catch (...) {
+    delete t;
+    throw;
+  }
+  g_live_tensors++;
+  return t;
+}
+Tensor* new_like(const Tensor* t) { return new_tensor(t->sizes, t->ndim, t->dtype, t->device()); }
+Tensor* new_like(const Tensor* t, int dtype) { return new_tensor(t->sizes, t->ndim, dtype, t->device()); }
+
+Tensor* new_view(const Tensor* base, const int64_t* sizes, const int64_t* strides, int ndim, int64_t offset) {
+  LAMP_CHECK(ndim >= 0 && ndim <= kMaxDims, "ndim out of range");
+  Tensor* t = new Tensor();
+  t->st = base->st;
+  base->st->refs.fetch_add(1);
+  t->dtype = base->dtype;
+  t->ndim = ndim;
+  t->offset = offset;
+  for (int i = 0; i < ndim; i++) { t->sizes[i] = sizes[i]; t->strides[i] = strides[i]; }
+  g_live_tensors++;
+  return t;
+}
+Tensor* retain(const Tensor* t) { return new_view(t, t->sizes, t->strides, t->ndim, t->offset); }
+void release(Tensor* t) {
+  if (!t) return;
+  storage_unref(t->st);
+  t->st = nullptr;
+  delete t;
+  g_live_tensors--;
+}
+
+// ---- strided copy with conversion ------------------------------------------------------------
+template <class D, class S>
+__global__ void copy_strided_kernel(D* __restrict__ dst, const S* __restrict__ src, int64_t n, IterArgs it) {
+  using A = acc_t<S>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t off[2];
+    iter_offsets<2>(it, i, off);
+    dst[off[0]] = store_as<D>(load_as<A>(src[off[1]]));
+  }
+}
+template <class D, class S>
+__global__ void copy_contig_kernel(D* __restrict__ dst, const S* __restrict__ src, int64_t n) {
+  using A = acc_t<S>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = store_as<D>(load_as<A>(src[i]));
+}
+
+template <class D> struct conv_helper {
+  template <class S> static void run(Tensor* dst, const Tensor* src, const IterSpace& it, hipStream_t st) {
+    int64_t n = it.numel;
+    if (n == 0) return;
+    int grid = grid_for(n, 256);
+    if (it.all_contiguous) {
+      hipLaunchKernelGGL((copy_contig_kernel<D, S>), dim3(grid), dim3(256), 0, st, dst->ptr<D>(), src->ptr<S>(), n);
+    } else {
+      hipLaunchKernelGGL((copy_strided_kernel<D, S>), dim3(grid), dim3(256), 0, st, dst->ptr<D>(), src->ptr<S>(), n,
+                         to_args(it));
+    }
+    LAMP_LAUNCH_CHECK();
+  }
+};
+
+static void device_copy(Tensor* dst, const Tensor* src) {
+  hipStream_t st = current_stream(dst->device());
+  const Tensor* ops[2] = {dst, src};
+  IterSpace it = make_iter(dst->shape(), ops, 2);
+  if (it.numel == 0) return;
+  if (dst->dtype == src->dtype && it.all_contiguous) {
+    HIP_CHECK(hipMemcpyAsync(dst->data(), src->data(), (size_t)it.numel * dst->itemsize(), hipMemcpyDeviceToDevice, st));
+    return;
+  }
+  LAMP_DISPATCH_ALL(dst->dtype, D, LAMP_DISPATCH_ALL(src->dtype, S, (conv_helper<D>::template run<S>(dst, src, it, st))));
+}
+
+// host side strided/converting copy (staging only; used for host<->host and as the slow path
+// when a host<->device copy needs a layout or dtype change)
+template <class D, class S> static void host_copy_t(Tensor* dst, const Tensor* src, const IterSpace& it) {
+  using A = acc_t<S>;
+  D* d = dst->ptr<D>();
+  const S* s = src->ptr<S>();
+  int64_t idx[kMaxDims] = {0};
+  for (int64_t i = 0; i < it.numel; i++) {
+    int64_t od = 0, os = 0;
+    for (int k = 0; k < it.ndim; k++) { od += idx[k] * it.strides[0][k]; os += idx[k] * it.strides[1][k]; }
+    d[od] = store_as<D>(load_as<A>(s[os]));
+    for (int k = it.ndim - 1; k >= 0; k--) {
+      if (++idx[k] < it.sizes[k]) break;
+      idx[k] = 0;
+    }
+  }
+}
+template <class D> struct host_conv_helper {
+  template <class S> static void run(Tensor* dst, const Tensor* src, const IterSpace& it) { host_copy_t<D, S>(dst, src, it); }
+};
+static void host_copy(Tensor* dst, const Tensor* src) {
+  const Tensor* ops[2] = {dst, src};
+  IterSpace it = make_iter(dst->shape(), ops, 2);
+  if (it.numel == 0) return;
+  if (dst->dtype == src->dtype && it.all_contiguous) {
+    memcpy(dst->data(), src->data(), (size_t)it.numel * dst->itemsize());
+    return;
+  }
+  LAMP_DISPATCH_ALL(dst->dtype, D, LAMP_DISPATCH_ALL(src->dtype, S, (host_conv_helper<D>::template run<S>(dst, src, it))));
+}
+
+void copy_into(Tensor* dst, const Tensor* src) {
+  // src broadcasts into dst
+  bool dd = dst->is_device(), sd = src->is_device();
+  if (dd && sd) {
+    if (dst->device() == src->device()) { device_copy(dst, src); return; }
+    // peer copy: stage through a contiguous same-dtype buffer on the source device
+    Hold sc(contiguous(src));
+    Hold tmp(new_tensor(sc->sizes, sc->ndim, sc->dtype, dst->device()));
+    HIP_CHECK(hipMemcpyPeerAsync(tmp->data(), dst->device(), sc->data(), src->device(),
+                                 (size_t)sc->numel() * sc->itemsize(), current_stream(dst->device())));
+    device_copy(dst, tmp.get());
+    return;
+  }
+  if (!dd && !sd) { host_copy(dst, src); return; }
+  bool simple = dst->dtype == src->dtype && dst->is_contiguous() && src->is_contiguous() && dst->numel() == src->numel();
+  if (dd) {  // host -> device
+    hipStream_t st = current_stream(dst->device());
+    if (simple) {
+      HIP_CHECK(hipMemcpyAsync(dst->data(), src->data(), (size_t)dst->numel() * dst->itemsize(), hipMemcpyHostToDevice, st));
+      if (!src->st->pinned) HIP_CHECK(hipStreamSynchronize(st));
+      return;
+    }
+    Hold sc(contiguous(src));
+    Hold tmp(new_tensor(sc->sizes, sc->ndim, sc->dtype, dst->device()));
+    HIP_CHECK(hipMemcpyAsync(tmp->data(), sc->data(), (size_t)sc->numel() * sc->itemsize(), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    device_copy(dst, tmp.get());
+    return;
+  }
+  // device -> host
+  hipStream_t st = current_stream(src->device());
+  if (simple) {
+    HIP_CHECK(hipMemcpyAsync(dst->data(), src->data(), (size_t)dst->numel() * dst->itemsize(), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return;
+  }
+  Hold tmp(new_tensor(dst->sizes, dst->ndim, dst->dtype, src->device()));
+  device_copy(tmp.get(), src);
+  Hold htmp(new_tensor(dst->sizes, dst->ndim, dst->dtype, -1));
+  HIP_CHECK(hipMemcpyAsync(htmp->data(), tmp->data(), (size_t)tmp->numel() * tmp->itemsize(), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  host_copy(dst, htmp.get());
+}
+
+Tensor* contiguous(const Tensor* t) {
+  if (t->is_contiguous()) return retain(t);
+  Tensor* c = new_like(t);
+  try { copy_into(c, t); } catch (...) { release(c); throw; }
+  return c;
+}
+
+void fill_zero(Tensor* t) {
+  if (t->numel() == 0) return;
+  if (t->is_contiguous()) {
+    if (t->is_device()) HIP_CHECK(hipMemsetAsync(t->data(), 0, (size_t)t->numel() * t->itemsize(), current_stream(t->device())));
+    else memset(t->data(), 0, (size_t)t->numel() * t->itemsize());
+    return;
+  }
+  int64_t one[1] = {1};
+  Hold z(new_tensor(one, 0, t->dtype, t->device()));
+  fill_zero(z.get());
+  copy_into(t, z.get());
+}
+
+// ---- fills -------------------------------------------------------------------------------------
+template <class T> __global__ void fill_kernel(T* p, int64_t n, T v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static void fill_value(Tensor* t, double value) {
+  if (t->numel() == 0) return;
+  if (value == 0.0) { fill_zero(t); return; }
+  if (!t->is_contiguous()) {
+    Hold s(new_tensor(nullptr, 0, t->dtype, t->device()));
+    fill_value(s.get(), value);
+    copy_into(t, s.get());
+    return;
+  }
+  int64_t n = t->numel();
+  if (t->is_device()) {
+    hipStream_t st = current_stream(t->device());
+    LAMP_DISPATCH_ALL(t->dtype, T,
+                      hipLaunchKernelGGL((fill_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, st, t->ptr<T>(), n,
+                                         store_as<T>((acc_t<T>)value)));
+    LAMP_LAUNCH_CHECK();
+  } else {
+    LAMP_DISPATCH_ALL(t->dtype, T, { T v = store_as<T>((acc_t<T>)value); T* p = t->ptr<T>(); for (int64_t i = 0; i < n; i++) p[i] = v; });
+  }
+}
+
+// ---- view helpers ------------------------------------------------------------------------------
+static std::vector<int64_t> infer_size(const int64_t* sizes, int ndim, int64_t numel) {
+  std::vector<int64_t> out(sizes, sizes + ndim);
+  int64_t known = 1;
+  int infer = -1;
+  for (int i = 0; i < ndim; i++) {
+    if (out[i] == -1) { LAMP_CHECK(infer < 0, "only one dimension can be inferred"); infer = i; }
+    else { LAMP_CHECK(out[i] >= 0, "invalid shape dimension " << out[i]); known *= out[i]; }
+  }
+  if (infer >= 0) {
+    LAMP_CHECK(known > 0 && numel % known == 0, "shape is invalid for input of size " << numel);
+    out[infer] = numel / known;
+  } else {
+    LAMP_CHECK(known == numel, "shape is invalid for input of size " << numel);
+  }
+  return out;
+}
+
+// can `t` be viewed with `shape` without a copy? (same algorithm idea as ATen's computeStride)
+static bool compute_view_strides(const Tensor* t, const std::vector<int64_t>& shape, std::vector<int64_t>& out) {
+  out.assign(shape.size(), 0);
+  int64_t numel = t->numel();
+  if (numel == 0) {
+    int64_t s = 1;
+    for (int i = (int)shape.size() - 1; i >= 0; i--) { out[i] = s; s *= std::max<int64_t>(shape[i], 1); }
+    return true;
+  }
+  int view_d = (int)shape.size() - 1;
+  int64_t chunk_base_stride = t->ndim ? t->strides[t->ndim - 1] : 1;
+  int64_t tensor_numel = 1, view_numel = 1;
+  for (int td = t->ndim - 1; td >= 0; td--) {
+    tensor_numel *= t->sizes[td];
+    if (td == 0 || (t->sizes[td - 1] != 1 && t->strides[td - 1] != tensor_numel * chunk_base_stride)) {
+      while (view_d >= 0 && (view_numel < tensor_numel || shape[view_d] == 1)) {
+        out[view_d] = view_numel * chunk_base_stride;
+        view_numel *= shape[view_d];
+        view_d--;
+      }
+      if (view_numel != tensor_numel) return false;
+      if (td > 0) {
+        chunk_base_stride = t->strides[td - 1];
+        tensor_numel = 1;
+        view_numel = 1;
+      }
+    }
+  }
+  if (view_d != -1) {
+    // remaining leading size-1 dims
+    for (; view_d >= 0; view_d--) {
+      if (shape[view_d] != 1) return false;
+      out[view_d] = 0;
+    }
+  }
+  return true;
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+#define NOT_NULL(p) LAMP_CHECK((p) != nullptr, #p " is null")
+
+extern "C" {
+
+int lamp_live_tensor_count(int64_t* out) { *out = g_live_tensors.load(); return 0; }
+
+int lamp_tensor_release(lamp_tensor* t) {
+  LAMP_API_BEGIN
+  release(t);
+  LAMP_API_END
+}
+int lamp_tensor_release_all(lamp_tensor** ts, int n) {
+  LAMP_API_BEGIN
+  for (int i = 0; i < n; i++) release(ts[i]);
+  LAMP_API_END
+}
+int lamp_tensor_retain(const lamp_tensor* t, lamp_tensor** out) {
+  LAMP_API_BEGIN
+  NOT_NULL(t);
+  *out = retain(t);
+  LAMP_API_END
+}
+int lamp_tensor_ndim(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->ndim; LAMP_API_END }
+int lamp_tensor_sizes(const lamp_tensor* t, int64_t* out) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  for (int i = 0; i < t->ndim; i++) out[i] = t->sizes[i];
+  LAMP_API_END
+}
+int lamp_tensor_strides(const lamp_tensor* t, int64_t* out) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  for (int i = 0; i < t->ndim; i++) out[i] = t->strides[i];
+  LAMP_API_END
+}
+int lamp_tensor_numel(const lamp_tensor* t, int64_t* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->numel(); LAMP_API_END }
+int lamp_tensor_element_size(const lamp_tensor* t, int64_t* out) { LAMP_API_BEGIN NOT_NULL(t); *out = (int64_t)t->itemsize(); LAMP_API_END }
+int lamp_tensor_scalar_type(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->dtype; LAMP_API_END }
+int lamp_tensor_device(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->device(); LAMP_API_END }
+int lamp_tensor_is_contiguous(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->is_contiguous(); LAMP_API_END }
+int lamp_tensor_is_pinned(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->st->pinned; LAMP_API_END }
+int lamp_tensor_data_ptr(const lamp_tensor* t, void** out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->data(); LAMP_API_END }
+int lamp_tensor_storage_id(const lamp_tensor* t, uint64_t* out) { LAMP_API_BEGIN NOT_NULL(t); *out = (uint64_t)(uintptr_t)t->st; LAMP_API_END }
+
+int lamp_empty(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN
+  dtype_size(dtype);
+  *out = new_tensor(sizes, ndim, dtype, device);
+  LAMP_API_END
+}
+int lamp_full(lamp_tensor** out, const int64_t* sizes, int ndim, double value, int dtype, int device) {
+  LAMP_API_BEGIN
+  dtype_size(dtype);
+  Hold t(new_tensor(sizes, ndim, dtype, device));
+  fill_value(t.get(), value);
+  *out = t.take();
+  LAMP_API_END
+}
+int lamp_zeros(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {
+  return lamp_full(out, sizes, ndim, 0.0, dtype, device);
+}
+int lamp_ones(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {
+  return lamp_full(out, sizes, ndim, 1.0, dtype, device);
+}
+int lamp_zeros_like(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  Hold r(new_like(t));
+  fill_zero(r.get());
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_ones_like(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  Hold r(new_like(t));
+  fill_value(r.get(), 1.0);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_scalar_tensor(lamp_tensor** out, double value, int dtype, int device) {
+  return lamp_full(out, nullptr, 0, value, dtype, device);
+}
+int lamp_scalar_tensor_l(lamp_tensor** out, int64_t value, int dtype, int device) {
+  LAMP_API_BEGIN
+  Hold h(new_tensor(nullptr, 0, dtype, -1));
+  LAMP_DISPATCH_ALL(dtype, T, *h->ptr<T>() = store_as<T>((acc_t<T>)value));
+  if (device < 0) { *out = h.take(); }
+  else {
+    Hold d(new_tensor(nullptr, 0, dtype, device));
+    copy_into(d.get(), h.get());
+    *out = d.take();
+  }
+  LAMP_API_END
+}
+int lamp_arange(lamp_tensor** out, double start, double end, double step, int dtype, int device) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(step != 0, "step must be non-zero");
+  int64_t n = (int64_t)std::ceil((end - start) / step);
+  if (n < 0) n = 0;
+  int64_t sz[1] = {n};
+  Hold h(new_tensor(sz, 1, dtype, -1));
+  LAMP_DISPATCH_ALL(dtype, T, { T* p = h->ptr<T>(); for (int64_t i = 0; i < n; i++) p[i] = store_as<T>((acc_t<T>)(start + i * step)); });
+  if (device < 0) *out = h.take();
+  else {
+    Hold d(new_tensor(sz, 1, dtype, device));
+    copy_into(d.get(), h.get());
+    *out = d.take();
+  }
+  LAMP_API_END
+}
+int lamp_eye(lamp_tensor** out, int64_t n, int64_t m, int dtype, int device) {
+  LAMP_API_BEGIN
+  int64_t sz[2] = {n, m};
+  Hold h(new_tensor(sz, 2, dtype, -1));
+  fill_zero(h.get());
+  LAMP_DISPATCH_ALL(dtype, T, { T* p = h->ptr<T>(); for (int64_t i = 0; i < std::min(n, m); i++) p[i * m + i] = store_as<T>((acc_t<T>)1); });
+  if (device < 0) *out = h.take();
+  else {
+    Hold d(new_tensor(sz, 2, dtype, device));
+    copy_into(d.get(), h.get());
+    *out = d.take();
+  }
+  LAMP_API_END
+}
+int lamp_from_blob(lamp_tensor** out, void* data, const int64_t* sizes, const int64_t* strides, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(ndim >= 0 && ndim <= kMaxDims, "ndim out of range");
+  Tensor* t = new Tensor();
+  t->st = new Storage();
+  t->st->ptr = data;
+  t->st->device = device;
+  t->st->owned = false;
+  t->dtype = dtype;
+  t->ndim = ndim;
+  int64_t n = 1;
+  for (int i = ndim - 1; i >= 0; i--) {
+    t->sizes[i] = sizes[i];
+    t->strides[i] = strides ? strides[i] : n;
+    n *= sizes[i];
+  }
+  t->st->bytes = (size_t)n * dtype_size(dtype);
+  g_live_tensors++;
+  *out = t;
+  LAMP_API_END
+}
+int lamp_copy_from_host(lamp_tensor* dst, const void* src, size_t nbytes) {
+  LAMP_API_BEGIN NOT_NULL(dst);
+  LAMP_CHECK(nbytes == (size_t)dst->numel() * dst->itemsize(), "byte count " << nbytes << " does not match tensor " << dst->describe());
+  int64_t sz[kMaxDims];
+  for (int i = 0; i < dst->ndim; i++) sz[i] = dst->sizes[i];
+  lamp_tensor* wrap = nullptr;
+  LAMP_CHECK(lamp_from_blob(&wrap, (void*)src, sz, nullptr, dst->ndim, dst->dtype, -1) == 0, lamp_last_error());
+  Hold h(wrap);
+  copy_into(dst, h.get());
+  if (dst->is_device()) HIP_CHECK(hipStreamSynchronize(current_stream(dst->device())));
+  LAMP_API_END
+}
+int lamp_copy_to_host(const lamp_tensor* src, void* dst, size_t nbytes) {
+  LAMP_API_BEGIN NOT_NULL(src);
+  LAMP_CHECK(nbytes == (size_t)src->numel() * src->itemsize(), "byte count " << nbytes << " does not match tensor " << src->describe());
+  int64_t sz[kMaxDims];
+  for (int i = 0; i < src->ndim; i++) sz[i] = src->sizes[i];
+  lamp_tensor* wrap = nullptr;
+  LAMP_CHECK(lamp_from_blob(&wrap, dst, sz, nullptr, src->ndim, src->dtype, -1) == 0, lamp_last_error());
+  Hold h(wrap);
+  copy_into(h.get(), src);
+  LAMP_API_END
+}
+int lamp_clone(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  Hold r(new_like(t));
+  copy_into(r.get(), t);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_contiguous(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  *out = contiguous(t);
+  LAMP_API_END
+}
+int lamp_copy_(lamp_tensor* dst, const lamp_tensor* src, int non_blocking) {
+  LAMP_API_BEGIN NOT_NULL(dst); NOT_NULL(src);
+  copy_into(dst, src);
+  (void)non_blocking;
+  LAMP_API_END
+}
+int lamp_to(lamp_tensor** out, const lamp_tensor* t, int dtype, int device, int non_blocking, int copy) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  (void)non_blocking;
+  dtype_size(dtype);
+  if (!copy && dtype == t->dtype && device == t->device()) { *out = retain(t); }
+  else {
+    Hold r(new_tensor(t->sizes, t->ndim, dtype, device));
+    copy_into(r.get(), t);
+    *out = r.take();
+  }
+  LAMP_API_END
+}
+int lamp_cast(lamp_tensor** out, const lamp_tensor* t, int dtype) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  dtype_size(dtype);
+  if (dtype == t->dtype) { *out = retain(t); }
+  else {
+    Hold r(new_tensor(t->sizes, t->ndim, dtype, t->device()));
+    copy_into(r.get(), t);
+    *out = r.take();
+  }
+  LAMP_API_END
+}
+int lamp_pin_memory(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(!t->is_device(), "pin_memory expects a host tensor");
+  Tensor* r = new Tensor();
+  r->ndim = t->ndim;
+  r->dtype = t->dtype;
+  int64_t n = 1;
+  for (int i = t->ndim - 1; i >= 0; i--) { r->sizes[i] = t->sizes[i]; r->strides[i] = n; n *= t->sizes[i]; }
+  try { r->st = new_storage((size_t)n * dtype_size(t->dtype), -1, true); } catch (...) { delete r; throw; }
+  g_live_tensors++;
+  Hold h(r);
+  copy_into(r, t);
+  *out = h.take();
+  LAMP_API_END
+}
+int lamp_item(const lamp_tensor* t, double* out) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(t->numel() == 1, "item() needs a one element tensor, got " << t->describe());
+  int64_t one[1] = {1};
+  Hold h(new_tensor(one, 0, kF64, -1));
+  Hold flat(new_view(t, one, one, 0, t->offset));
+  copy_into(h.get(), flat.get());
+  *out = *h->ptr<double>();
+  LAMP_API_END
+}
+
+int lamp_fill_(lamp_tensor* t, double value) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  fill_value(t, value);
+  LAMP_API_END
+}
+int lamp_zero_(lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  fill_zero(t);
+  LAMP_API_END
+}
+
+// ---- views -------------------------------------------------------------------------------------
+int lamp_view(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  auto shape = infer_size(sizes, ndim, t->numel());
+  std::vector<int64_t> st;
+  LAMP_CHECK(compute_view_strides(t, shape, st), "view size is not compatible with input tensor's size and stride; use reshape");
+  *out = new_view(t, shape.data(), st.data(), (int)shape.size(), t->offset);
+  LAMP_API_END
+}
+int lamp_reshape(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  auto shape = infer_size(sizes, ndim, t->numel());
+  std::vector<int64_t> st;
+  if (compute_view_strides(t, shape, st)) { *out = new_view(t, shape.data(), st.data(), (int)shape.size(), t->offset); }
+  else {
+    Hold c(contiguous(t));
+    LAMP_CHECK(compute_view_strides(c.get(), shape, st), "internal: reshape of a contiguous tensor failed");
+    *out = new_view(c.get(), shape.data(), st.data(), (int)shape.size(), c->offset);
+  }
+  LAMP_API_END
+}
+int lamp_flatten(lamp_tensor** out, const lamp_tensor* t, int64_t start_dim, int64_t end_dim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  int64_t s = wrap_dim(start_dim, t->ndim), e = wrap_dim(end_dim, t->ndim);
+  LAMP_CHECK(s <= e, "flatten: start_dim after end_dim");
+  std::vector<int64_t> shape;
+  for (int i = 0; i < s; i++) shape.push_back(t->sizes[i]);
+  int64_t m = 1;
+  for (int64_t i = s; i <= e && i < t->ndim; i++) m *= t->sizes[i];
+  shape.push_back(m);
+  for (int i = (int)e + 1; i < t->ndim; i++) shape.push_back(t->sizes[i]);
+  return lamp_reshape(out, t, shape.data(), (int)shape.size());
+  LAMP_API_END
+}
+int lamp_transpose(lamp_tensor** out, const lamp_tensor* t, int64_t dim0, int64_t dim1) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  int64_t a = wrap_dim(dim0, t->ndim), b = wrap_dim(dim1, t->ndim);
+  Tensor* v = retain(t);
+  if (t->ndim > 0) { std::swap(v->sizes[a], v->sizes[b]); std::swap(v->strides[a], v->strides[b]); }
+  *out = v;
+  LAMP_API_END
+}
+int lamp_t(lamp_tensor** out, const lamp_tensor* t) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(t->ndim <= 2, "t() expects a tensor with <= 2 dimensions");
+  if (t->ndim < 2) { *out = retain(t); return 0; }
+  return lamp_transpose(out, t, 0, 1);
+  LAMP_API_END
+}
+int lamp_select(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t index) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(t->ndim > 0, "select on a 0-dim tensor");
+  int64_t d = wrap_dim(dim, t->ndim);
+  int64_t n = t->sizes[d];
+  LAMP_CHECK(index >= -n && index < n, "select: index " << index << " out of range for size " << n);
+  if (index < 0) index += n;
+  int64_t sz[kMaxDims], st[kMaxDims];
+  int k = 0;
+  for (int i = 0; i < t->ndim; i++) if (i != d) { sz[k] = t->sizes[i]; st[k] = t->strides[i]; k++; }
+  *out = new_view(t, sz, st, k, t->offset + index * t->strides[d]);
+  LAMP_API_END
+}
+int lamp_slice(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t end, int64_t step) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(t->ndim > 0, "slice on a 0-dim tensor");
+  LAMP_CHECK(step > 0, "slice step must be positive");
+  int64_t d = wrap_dim(dim, t->ndim);
+  int64_t n = t->sizes[d];
+  if (start < 0) start += n;
+  if (end < 0) end += n;
+  start = std::min(std::max<int64_t>(start, 0), n);
+  end = std::min(std::max<int64_t>(end, start), n);
+  Tensor* v = retain(t);
+  v->offset += start * t->strides[d];
+  v->sizes[d] = (end - start + step - 1) / step;
+  v->strides[d] = t->strides[d] * step;
+  *out = v;
+  LAMP_API_END
+}
+int lamp_narrow(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t length) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  int64_t d = wrap_dim(dim, t->ndim);
+  if (start < 0) start += t->sizes[d];
+  LAMP_CHECK(start >= 0 && length >= 0 && start + length <= t->sizes[d], "narrow: start " << start << " + length " << length << " exceeds size " << t->sizes[d]);
+  return lamp_slice(out, t, d, start, start + length, 1);
+  LAMP_API_END
+}
+int lamp_expand(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(ndim >= t->ndim && ndim <= kMaxDims, "expand: target has fewer dims than the tensor");
+  int64_t sz[kMaxDims], st[kMaxDims];
+  int lead = ndim - t->ndim;
+  for (int i = 0; i < ndim; i++) {
+    int64_t want = sizes[i];
+    if (i < lead) { LAMP_CHECK(want >= 0, "expand: -1 not allowed in a leading new dimension"); sz[i] = want; st[i] = 0; continue; }
+    int64_t have = t->sizes[i - lead];
+    if (want == -1) want = have;
+    if (have == want) { sz[i] = have; st[i] = t->strides[i - lead]; }
+    else { LAMP_CHECK(have == 1, "expand: size " << have << " cannot expand to " << want << " at dim " << i); sz[i] = want; st[i] = 0; }
+  }
+  *out = new_view(t, sz, st, ndim, t->offset);
+  LAMP_API_END
+}
+int lamp_expand_as(lamp_tensor** out, const lamp_tensor* t, const lamp_tensor* other) {
+  LAMP_API_BEGIN NOT_NULL(t); NOT_NULL(other);
+  return lamp_expand(out, t, other->sizes, other->ndim);
+  LAMP_API_END
+}
+int lamp_squeeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  int64_t sz[kMaxDims], st[kMaxDims];
+  int k = 0;
+  if (dim == INT64_MIN) {
+    for (int i = 0; i < t->ndim; i++) if (t->sizes[i] != 1) { sz[k] = t->sizes[i]; st[k] = t->strides[i]; k++; }
+  } else {
+    int64_t d = wrap_dim(dim, t->ndim);
+    for (int i = 0; i < t->ndim; i++) if (!(i == d && t->sizes[i] == 1)) { sz[k] = t->sizes[i]; st[k] = t->strides[i]; k++; }
+  }
+  *out = new_view(t, sz, st, k, t->offset);
+  LAMP_API_END
+}
+int lamp_unsqueeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(t->ndim < kMaxDims, "too many dims");
+  int64_t d = wrap_dim(dim, t->ndim, true);
+  int64_t sz[kMaxDims], st[kMaxDims];
+  int k = 0;
+  for (int i = 0; i <= t->ndim; i++) {
+    if (i == d) { sz[k] = 1; st[k] = (i < t->ndim) ? t->sizes[i] * t->strides[i] : 1; k++; }
+    if (i < t->ndim) { sz[k] = t->sizes[i]; st[k] = t->strides[i]; k++; }
+  }
+  *out = new_view(t, sz, st, k, t->offset);
+  LAMP_API_END
+}
+
+static void cat_into(Tensor* out, lamp_tensor* const* ts, int n, int64_t d) {
+  int64_t pos = 0;
+  for (int i = 0; i < n; i++) {
+    if (ts[i]->ndim == 1 && ts[i]->sizes[0] == 0 && out->ndim != 1) continue;  // legacy empty tensor
+    Tensor* v = retain(out);
+    Hold hv(v);
+    v->offset += pos * out->strides[d];
+    v->sizes[d] = ts[i]->sizes[d];
+    copy_into(v, ts[i]);
+    pos += ts[i]->sizes[d];
+  }
+}
+static std::vector<int64_t> cat_shape(lamp_tensor* const* ts, int n, int64_t dim, int64_t* dout) {
+  LAMP_CHECK(n > 0, "cat of an empty list");
+  const Tensor* ref = nullptr;
+  for (int i = 0; i < n; i++) { LAMP_CHECK(ts[i], "null tensor in list"); if (!(ts[i]->ndim == 1 && ts[i]->sizes[0] == 0)) { ref = ts[i]; break; } }
+  if (!ref) ref = ts[0];
+  int64_t d = wrap_dim(dim, ref->ndim);
+  std::vector<int64_t> shape = ref->shape();
+  int64_t total = 0;
+  for (int i = 0; i < n; i++) {
+    const Tensor* t = ts[i];
+    if (t->ndim == 1 && t->sizes[0] == 0 && ref->ndim != 1) continue;
+    LAMP_CHECK(t->ndim == ref->ndim, "cat: tensors must have the same number of dimensions");
+    LAMP_CHECK(t->dtype == ref->dtype, "cat: dtype mismatch");
+    for (int k = 0; k < t->ndim; k++) if (k != d) LAMP_CHECK(t->sizes[k] == ref->sizes[k], "cat: sizes must match except in dimension " << d);
+    total += t->sizes[d];
+  }
+  shape[d] = total;
+  *dout = d;
+  return shape;
+}
+int lamp_cat(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim) {
+  LAMP_API_BEGIN
+  int64_t d;
+  auto shape = cat_shape(ts, n, dim, &d);
+  Hold r(new_tensor(shape, ts[0]->dtype, ts[0]->device()));
+  cat_into(r.get(), ts, n, d);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_cat_out(lamp_tensor* out, lamp_tensor* const* ts, int n, int64_t dim) {
+  LAMP_API_BEGIN NOT_NULL(out);
+  int64_t d;
+  auto shape = cat_shape(ts, n, dim, &d);
+  LAMP_CHECK(out->shape() == shape, "cat_out: output shape mismatch");
+  cat_into(out, ts, n, d);
+  LAMP_API_END
+}
+int lamp_stack(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(n > 0, "stack of an empty list");
+  int64_t d = wrap_dim(dim, ts[0]->ndim, true);
+  std::vector<lamp_tensor*> us(n);
+  std::vector<Hold> holds;
+  holds.reserve(n);
+  for (int i = 0; i < n; i++) {
+    LAMP_CHECK(ts[i]->shape() == ts[0]->shape(), "stack expects each tensor to be equal size");
+    lamp_tensor* u = nullptr;
+    LAMP_CHECK(lamp_unsqueeze(&u, ts[i], d) == 0, lamp_last_error());
+    holds.emplace_back(u);
+    us[i] = u;
+  }
+  return lamp_cat(out, us.data(), n, d);
+  LAMP_API_END
+}
+
+}  // extern "C"

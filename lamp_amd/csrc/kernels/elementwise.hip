@@ -1,0 +1,471 @@
+// Broadcasting element-wise kernels (HBM-bound: one pass, 16-byte loads/stores per lane on the
+// contiguous path, a generic strided path for views and broadcasts).
+//
+// Replaces the ATen calls behind lamp's arithmetic (reference call sites:
+// lamp-sten/src/main/scala/lamp/STen.scala:365-468 (out variants), 1110-1217 (+,-,*,/ and in
+// place), 1242-1264 (addcmul), 1266-1320 (unary); backward closures in
+// lamp-core/src/main/scala/lamp/autograd/ops.scala:511-621, 754-1032).
+//
+// bf16 math is done in f32 and rounded once on store, f64 stays f64 - the same evaluation
+// ATen's CPU kernels use, so results agree to rounding with the oracle.
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+// ---- kernels -----------------------------------------------------------------------------------
+// contiguous path: every operand has stride 1, or stride 0 (a broadcast one-element operand)
+template <class TO, class TI, int NIN, class F>
+__global__ __launch_bounds__(256) void ew_vec_kernel(TO* __restrict__ out, const TI* in0, const TI* in1, const TI* in2,
+                                                     int64_t n, int bcast_mask, F f) {
+  using A = acc_t<TI>;
+  constexpr int W = 16 / sizeof(TI);
+  const int64_t nvec = n / W;
+  A s0 = A(0), s1 = A(0), s2 = A(0);
+  if (bcast_mask & 1) s0 = load_as<A>(in0[0]);
+  if (NIN > 1 && (bcast_mask & 2)) s1 = load_as<A>(in1[0]);
+  if (NIN > 2 && (bcast_mask & 4)) s2 = load_as<A>(in2[0]);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec<TI, W> v0, v1, v2;
+    if (!(bcast_mask & 1)) v0 = *reinterpret_cast<const Vec<TI, W>*>(in0 + i * W);
+    if (NIN > 1 && !(bcast_mask & 2)) v1 = *reinterpret_cast<const Vec<TI, W>*>(in1 + i * W);
+    if (NIN > 2 && !(bcast_mask & 4)) v2 = *reinterpret_cast<const Vec<TI, W>*>(in2 + i * W);
+    Vec<TO, W> r;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      A a = (bcast_mask & 1) ? s0 : load_as<A>(v0.v[k]);
+      A b = (NIN > 1) ? ((bcast_mask & 2) ? s1 : load_as<A>(v1.v[k])) : A(0);
+      A c = (NIN > 2) ? ((bcast_mask & 4) ? s2 : load_as<A>(v2.v[k])) : A(0);
+      r.v[k] = f.template apply<TO>(a, b, c);
+    }
+    *reinterpret_cast<Vec<TO, W>*>(out + i * W) = r;
+  }
+  // tail
+  const int64_t tail0 = nvec * W;
+  const int64_t t = tail0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) {
+    A a = (bcast_mask & 1) ? s0 : load_as<A>(in0[t]);
+    A b = (NIN > 1) ? ((bcast_mask & 2) ? s1 : load_as<A>(in1[t])) : A(0);
+    A c = (NIN > 2) ? ((bcast_mask & 4) ? s2 : load_as<A>(in2[t])) : A(0);
+    out[t] = f.template apply<TO>(a, b, c);
+  }
+}
+
+template <class TO, class TI, int NIN, class F>
+__global__ __launch_bounds__(256) void ew_strided_kernel(TO* __restrict__ out, const TI* in0, const TI* in1, const TI* in2,
+                                                         int64_t n, IterArgs it, F f) {
+  using A = acc_t<TI>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t off[4];
+    iter_offsets<4>(it, i, off);
+    A a = load_as<A>(in0[off[1]]);
+    A b = (NIN > 1) ? load_as<A>(in1[off[2]]) : A(0);
+    A c = (NIN > 2) ? load_as<A>(in2[off[3]]) : A(0);
+    out[off[0]] = f.template apply<TO>(a, b, c);
+  }
+}
+
+// ---- launcher ----------------------------------------------------------------------------------
+template <class TO, class TI, int NIN, class F>
+void launch_ew(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F f) {
+  const Tensor* ops[4] = {out, a, b ? b : a, c ? c : a};
+  IterSpace it = make_iter(out->shape(), ops, 4);
+  int64_t n = it.numel;
+  if (n == 0) return;
+  hipStream_t st = current_stream(out->device());
+  const TI* p0 = a->ptr<TI>();
+  const TI* p1 = b ? b->ptr<TI>() : nullptr;
+  const TI* p2 = c ? c->ptr<TI>() : nullptr;
+  // vector path eligibility
+  bool vec_ok = it.ndim == 1 && it.strides[0][0] == 1;
+  int mask = 0;
+  if (vec_ok) {
+    for (int o = 1; o <= NIN; o++) {
+      int64_t s = it.strides[o][0];
+      if (s == 0) mask |= 1 << (o - 1);
+      else if (s != 1) vec_ok = false;
+    }
+    auto aligned = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!aligned(out->data())) vec_ok = false;
+    if (!(mask & 1) && !aligned(p0)) vec_ok = false;
+    if (NIN > 1 && !(mask & 2) && !aligned(p1)) vec_ok = false;
+    if (NIN > 2 && !(mask & 4) && !aligned(p2)) vec_ok = false;
+  }
+  if (n == 1) vec_ok = false;
+  if (vec_ok) {
+    constexpr int W = 16 / sizeof(TI);
+    int grid = grid_for((n + W - 1) / W, 256);
+    hipLaunchKernelGGL((ew_vec_kernel<TO, TI, NIN, F>), dim3(grid), dim3(256), 0, st, out->ptr<TO>(), p0, p1, p2, n, mask, f);
+  } else {
+    int grid = grid_for(n, 256);
+    hipLaunchKernelGGL((ew_strided_kernel<TO, TI, NIN, F>), dim3(grid), dim3(256), 0, st, out->ptr<TO>(), p0, p1, p2, n,
+                       to_args(it), f);
+  }
+  LAMP_LAUNCH_CHECK();
+}
+
+// ---- functors ----------------------------------------------------------------------------------
+#define FUNCTOR_BEGIN(NAME) struct NAME { double p0 = 0, p1 = 0; template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+#define FUNCTOR_END } };
+
+template <class A> __device__ __forceinline__ A dexp(A x);
+template <> __device__ __forceinline__ float dexp(float x) { return expf(x); }
+template <> __device__ __forceinline__ double dexp(double x) { return exp(x); }
+template <> __device__ __forceinline__ int64_t dexp(int64_t x) { return (int64_t)exp((double)x); }
+
+#define MATH1(NAME, FF, DF)                                                                       \
+  template <class A> __device__ __forceinline__ A NAME(A x) { return (A)DF((double)x); }          \
+  template <> __device__ __forceinline__ float NAME(float x) { return FF(x); }                    \
+  template <> __device__ __forceinline__ double NAME(double x) { return DF(x); }
+MATH1(m_log, logf, log)
+MATH1(m_log1p, log1pf, log1p)
+MATH1(m_sqrt, sqrtf, sqrt)
+MATH1(m_sin, sinf, sin)
+MATH1(m_cos, cosf, cos)
+MATH1(m_tan, tanf, tan)
+MATH1(m_atan, atanf, atan)
+MATH1(m_tanh, tanhf, tanh)
+MATH1(m_erf, erff, erf)
+MATH1(m_fabs, fabsf, fabs)
+template <class A> __device__ __forceinline__ A m_pow(A x, A y) { return (A)pow((double)x, (double)y); }
+template <> __device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+
+FUNCTOR_BEGIN(FAdd) return store_as<TO>((A)(a + (A)p0 * b)); FUNCTOR_END
+FUNCTOR_BEGIN(FSub) return store_as<TO>((A)(a - (A)p0 * b)); FUNCTOR_END
+FUNCTOR_BEGIN(FMul) return store_as<TO>((A)(a * b)); FUNCTOR_END
+FUNCTOR_BEGIN(FDiv) return store_as<TO>((A)(a / b)); FUNCTOR_END
+FUNCTOR_BEGIN(FMax) return store_as<TO>((A)((a > b || a != a) ? a : b)); FUNCTOR_END
+FUNCTOR_BEGIN(FMin) return store_as<TO>((A)((a < b || a != a) ? a : b)); FUNCTOR_END
+FUNCTOR_BEGIN(FPow) return store_as<TO>(m_pow<A>(a, b)); FUNCTOR_END
+FUNCTOR_BEGIN(FAddS) return store_as<TO>((A)(a + (A)(p0 * p1))); FUNCTOR_END       // a + alpha*scalar (p0 scalar, p1 alpha)
+FUNCTOR_BEGIN(FMulS) return store_as<TO>((A)(a * (A)p0)); FUNCTOR_END
+FUNCTOR_BEGIN(FDivS) return store_as<TO>((A)(a / (A)p0)); FUNCTOR_END
+struct FPowS {
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+    // the special cases ATen's CPU pow kernel takes (exact for 2, 3, 0.5, -1, -2, -0.5)
+    if (p0 == 2.0) return store_as<TO>((A)(a * a));
+    if (p0 == 3.0) return store_as<TO>((A)(a * a * a));
+    if (p0 == 0.5) return store_as<TO>(m_sqrt<A>(a));
+    if (p0 == 1.0) return store_as<TO>(a);
+    if (p0 == -1.0) return store_as<TO>((A)(A(1) / a));
+    if (p0 == -2.0) return store_as<TO>((A)(A(1) / (a * a)));
+    if (p0 == -0.5) return store_as<TO>((A)(A(1) / m_sqrt<A>(a)));
+    return store_as<TO>(m_pow<A>(a, (A)p0));
+  }
+};
+FUNCTOR_BEGIN(FAddcmul) return store_as<TO>((A)(a + (A)p0 * b * c)); FUNCTOR_END
+FUNCTOR_BEGIN(FAddcdiv) return store_as<TO>((A)(a + (A)p0 * b / c)); FUNCTOR_END
+// out(a) += p(b) * (x(c) < 0 ? slope : 1)      ops.scala:918-953
+FUNCTOR_BEGIN(FReluBwdAcc) return store_as<TO>((A)(a + b * ((c < A(0)) ? (A)p0 : A(1)))); FUNCTOR_END
+
+FUNCTOR_BEGIN(FRelu) return store_as<TO>((A)((a < A(0)) ? A(0) : a)); FUNCTOR_END   // NaN propagates like ATen's relu
+FUNCTOR_BEGIN(FLeakyRelu) return store_as<TO>((A)((a > A(0)) ? a : a * (A)p0)); FUNCTOR_END
+FUNCTOR_BEGIN(FGelu) return store_as<TO>((A)(a * A(0.5) * (A(1) + m_erf<A>(a * A(0.70710678118654752440))))); FUNCTOR_END
+struct FGeluBwd {  // (grad, self)
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+    const A kAlpha = A(0.70710678118654752440), kBeta = A(0.39894228040143267794);  // 1/sqrt(2), 1/sqrt(2 pi)
+    A cdf = A(0.5) * (A(1) + m_erf<A>(x * kAlpha));
+    A pdf = kBeta * dexp<A>(x * x * A(-0.5));
+    return store_as<TO>((A)(g * (cdf + x * pdf)));
+  }
+};
+FUNCTOR_BEGIN(FSigmoid) return store_as<TO>((A)(A(1) / (A(1) + dexp<A>(-a)))); FUNCTOR_END
+FUNCTOR_BEGIN(FSigmoidBwd) return store_as<TO>((A)(a * (A(1) - b) * b)); FUNCTOR_END   // (grad, output)
+FUNCTOR_BEGIN(FTanh) return store_as<TO>(m_tanh<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FTanhBwd) return store_as<TO>((A)(a * (A(1) - b * b))); FUNCTOR_END       // (grad, output)
+struct FHardswish {
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A x, A b, A c) const {
+    A t = x + A(3);
+    t = t < A(0) ? A(0) : (t > A(6) ? A(6) : t);
+    return store_as<TO>((A)(x * t / A(6)));
+  }
+};
+struct FHardswishBwd {  // (grad, self)
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+    if (x < A(-3)) return store_as<TO>(A(0));
+    if (x <= A(3)) return store_as<TO>((A)(g * ((x / A(3)) + A(0.5))));
+    return store_as<TO>(g);
+  }
+};
+struct FSoftplus {  // p0 beta, p1 threshold
+  double p0 = 1, p1 = 20;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A x, A b, A c) const {
+    A xb = x * (A)p0;
+    return store_as<TO>((A)((xb > (A)p1) ? x : m_log1p<A>(dexp<A>(xb)) / (A)p0));
+  }
+};
+struct FSoftplusBwd {  // (grad, self)
+  double p0 = 1, p1 = 20;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+    A xb = x * (A)p0;
+    A z = dexp<A>(xb);
+    return store_as<TO>((A)((xb > (A)p1) ? g : g * z / (z + A(1))));
+  }
+};
+FUNCTOR_BEGIN(FExp) return store_as<TO>(dexp<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FLog) return store_as<TO>(m_log<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FLog1p) return store_as<TO>(m_log1p<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FSqrt) return store_as<TO>(m_sqrt<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FSquare) return store_as<TO>((A)(a * a)); FUNCTOR_END
+FUNCTOR_BEGIN(FRecip) return store_as<TO>((A)(A(1) / a)); FUNCTOR_END
+FUNCTOR_BEGIN(FNeg) return store_as<TO>((A)(-a)); FUNCTOR_END
+FUNCTOR_BEGIN(FAbs) return store_as<TO>((A)(a < A(0) ? -a : a)); FUNCTOR_END
+FUNCTOR_BEGIN(FSign) return store_as<TO>((A)((A(0) < a) - (a < A(0)))); FUNCTOR_END
+FUNCTOR_BEGIN(FSin) return store_as<TO>(m_sin<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FCos) return store_as<TO>(m_cos<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FTan) return store_as<TO>(m_tan<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FAtan) return store_as<TO>(m_atan<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FLogicalNot) return (TO)(a == A(0)); FUNCTOR_END
+// comparisons: TO = uint8_t
+FUNCTOR_BEGIN(FLt) return (TO)(a < b); FUNCTOR_END
+FUNCTOR_BEGIN(FLe) return (TO)(a <= b); FUNCTOR_END
+FUNCTOR_BEGIN(FGt) return (TO)(a > b); FUNCTOR_END
+FUNCTOR_BEGIN(FGe) return (TO)(a >= b); FUNCTOR_END
+FUNCTOR_BEGIN(FEq) return (TO)(a == b); FUNCTOR_END
+FUNCTOR_BEGIN(FNe) return (TO)(a != b); FUNCTOR_END
+FUNCTOR_BEGIN(FLtS) return (TO)(a < (A)p0); FUNCTOR_END
+FUNCTOR_BEGIN(FLeS) return (TO)(a <= (A)p0); FUNCTOR_END
+FUNCTOR_BEGIN(FGtS) return (TO)(a > (A)p0); FUNCTOR_END
+FUNCTOR_BEGIN(FGeS) return (TO)(a >= (A)p0); FUNCTOR_END
+FUNCTOR_BEGIN(FEqS) return (TO)(a == (A)p0); FUNCTOR_END
+FUNCTOR_BEGIN(FNeS) return (TO)(a != (A)p0); FUNCTOR_END
+
+// ---- host helpers ------------------------------------------------------------------------------
+static void check_inputs(const Tensor* a, const Tensor* b, const Tensor* c) {
+  check_device_tensor(a, "input");
+  if (b) { check_device_tensor(b, "input"); check_same_device(a, b);
+           LAMP_CHECK(a->dtype == b->dtype, "dtype mismatch: " << a->describe() << " vs " << b->describe()); }
+  if (c) { check_device_tensor(c, "input"); check_same_device(a, c);
+           LAMP_CHECK(a->dtype == c->dtype, "dtype mismatch: " << a->describe() << " vs " << c->describe()); }
+}
+static std::vector<int64_t> out_shape(const Tensor* a, const Tensor* b, const Tensor* c) {
+  std::vector<int64_t> s = a->shape();
+  if (b) s = broadcast_shapes(s, b->shape());
+  if (c) s = broadcast_shapes(s, c->shape());
+  return s;
+}
+
+// same-dtype output; `out` == nullptr allocates
+template <int NIN, class F, bool FLOAT_ONLY>
+Tensor* run_same(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F f) {
+  check_inputs(a, b, c);
+  auto shape = out_shape(a, b, c);
+  Hold owned;
+  if (!out) { owned = Hold(new_tensor(shape, a->dtype, a->device())); out = owned.get(); }
+  else {
+    check_device_tensor(out, "out");
+    LAMP_CHECK(out->shape() == shape, "out " << out->describe() << " does not match the broadcast shape of the inputs");
+    LAMP_CHECK(out->dtype == a->dtype, "out dtype mismatch: " << out->describe() << " vs " << a->describe());
+  }
+  if (FLOAT_ONLY) {
+    LAMP_DISPATCH_FLOAT(a->dtype, T, (launch_ew<T, T, NIN, F>(out, a, b, c, f)));
+  } else {
+    LAMP_DISPATCH_ALL(a->dtype, T, (launch_ew<T, T, NIN, F>(out, a, b, c, f)));
+  }
+  return owned.get() ? owned.take() : out;
+}
+template <int NIN, class F> Tensor* run_bool(const Tensor* a, const Tensor* b, F f) {
+  check_inputs(a, b, nullptr);
+  auto shape = out_shape(a, b, nullptr);
+  Hold out(new_tensor(shape, kBool, a->device()));
+  LAMP_DISPATCH_ALL(a->dtype, T, (launch_ew<uint8_t, T, NIN, F>(out.get(), a, b, nullptr, f)));
+  return out.take();
+}
+
+// ---- where / masked_fill (mixed dtypes: bool condition) ----------------------------------------
+template <class T>
+__global__ void where_kernel(T* out, const uint8_t* cond, const T* a, const T* b, int64_t n, IterArgs it) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t off[4];
+    iter_offsets<4>(it, i, off);
+    out[off[0]] = cond[off[1]] ? a[off[2]] : b[off[3]];
+  }
+}
+template <class T>
+__global__ void masked_fill_kernel(T* out, const T* a, const uint8_t* mask, T value, int64_t n, IterArgs it) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t off[3];
+    iter_offsets<3>(it, i, off);
+    out[off[0]] = mask[off[2]] ? value : a[off[1]];
+  }
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+#define API1(NAME, F, FLOAT_ONLY)                                                                  \
+  int lamp_##NAME(lamp_tensor** out, const lamp_tensor* a) {                                       \
+    LAMP_API_BEGIN *out = run_same<1, F, FLOAT_ONLY>(nullptr, a, nullptr, nullptr, F{}); LAMP_API_END \
+  }
+#define API1_INPLACE(NAME, F, FLOAT_ONLY)                                                          \
+  int lamp_##NAME(lamp_tensor* a) {                                                                \
+    LAMP_API_BEGIN run_same<1, F, FLOAT_ONLY>(a, a, nullptr, nullptr, F{}); LAMP_API_END           \
+  }
+#define API2(NAME, F, FLOAT_ONLY)                                                                  \
+  int lamp_##NAME(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {                 \
+    LAMP_API_BEGIN *out = run_same<2, F, FLOAT_ONLY>(nullptr, a, b, nullptr, F{}); LAMP_API_END    \
+  }
+#define API_CMP(NAME, F)                                                                           \
+  int lamp_##NAME(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {                 \
+    LAMP_API_BEGIN *out = run_bool<2, F>(a, b, F{}); LAMP_API_END                                  \
+  }
+#define API_CMP_S(NAME, F)                                                                         \
+  int lamp_##NAME(lamp_tensor** out, const lamp_tensor* a, double b) {                             \
+    LAMP_API_BEGIN *out = run_bool<1, F>(a, nullptr, F{b, 0}); LAMP_API_END                        \
+  }
+
+extern "C" {
+
+int lamp_add(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, double alpha) {
+  LAMP_API_BEGIN *out = run_same<2, FAdd, false>(nullptr, a, b, nullptr, FAdd{alpha, 0}); LAMP_API_END
+}
+int lamp_sub(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, double alpha) {
+  LAMP_API_BEGIN *out = run_same<2, FSub, false>(nullptr, a, b, nullptr, FSub{alpha, 0}); LAMP_API_END
+}
+API2(mul, FMul, false)
+API2(div, FDiv, false)
+API2(maximum, FMax, false)
+API2(minimum, FMin, false)
+API2(pow_tensor, FPow, true)
+int lamp_add_scalar(lamp_tensor** out, const lamp_tensor* a, double b, double alpha) {
+  LAMP_API_BEGIN *out = run_same<1, FAddS, false>(nullptr, a, nullptr, nullptr, FAddS{b, alpha}); LAMP_API_END
+}
+int lamp_sub_scalar(lamp_tensor** out, const lamp_tensor* a, double b, double alpha) {
+  LAMP_API_BEGIN *out = run_same<1, FAddS, false>(nullptr, a, nullptr, nullptr, FAddS{-b, alpha}); LAMP_API_END
+}
+int lamp_mul_scalar(lamp_tensor** out, const lamp_tensor* a, double b) {
+  LAMP_API_BEGIN *out = run_same<1, FMulS, false>(nullptr, a, nullptr, nullptr, FMulS{b, 0}); LAMP_API_END
+}
+int lamp_div_scalar(lamp_tensor** out, const lamp_tensor* a, double b) {
+  LAMP_API_BEGIN *out = run_same<1, FDivS, false>(nullptr, a, nullptr, nullptr, FDivS{b, 0}); LAMP_API_END
+}
+int lamp_pow_scalar(lamp_tensor** out, const lamp_tensor* a, double e) {
+  LAMP_API_BEGIN *out = run_same<1, FPowS, true>(nullptr, a, nullptr, nullptr, FPowS{e, 0}); LAMP_API_END
+}
+int lamp_add_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b, double alpha) {
+  LAMP_API_BEGIN run_same<2, FAdd, false>(out, a, b, nullptr, FAdd{alpha, 0}); LAMP_API_END
+}
+int lamp_sub_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b, double alpha) {
+  LAMP_API_BEGIN run_same<2, FSub, false>(out, a, b, nullptr, FSub{alpha, 0}); LAMP_API_END
+}
+int lamp_mul_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN run_same<2, FMul, false>(out, a, b, nullptr, FMul{}); LAMP_API_END
+}
+int lamp_div_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN run_same<2, FDiv, false>(out, a, b, nullptr, FDiv{}); LAMP_API_END
+}
+int lamp_add_(lamp_tensor* self, const lamp_tensor* b, double alpha) { return lamp_add_out(self, self, b, alpha); }
+int lamp_sub_(lamp_tensor* self, const lamp_tensor* b, double alpha) { return lamp_sub_out(self, self, b, alpha); }
+int lamp_mul_(lamp_tensor* self, const lamp_tensor* b) { return lamp_mul_out(self, self, b); }
+int lamp_div_(lamp_tensor* self, const lamp_tensor* b) { return lamp_div_out(self, self, b); }
+int lamp_add_scalar_(lamp_tensor* self, double b, double alpha) {
+  LAMP_API_BEGIN run_same<1, FAddS, false>(self, self, nullptr, nullptr, FAddS{b, alpha}); LAMP_API_END
+}
+int lamp_mul_scalar_(lamp_tensor* self, double b) {
+  LAMP_API_BEGIN run_same<1, FMulS, false>(self, self, nullptr, nullptr, FMulS{b, 0}); LAMP_API_END
+}
+int lamp_addcmul_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value) {
+  LAMP_API_BEGIN run_same<3, FAddcmul, false>(out, self, t1, t2, FAddcmul{value, 0}); LAMP_API_END
+}
+int lamp_addcdiv_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value) {
+  LAMP_API_BEGIN run_same<3, FAddcdiv, true>(out, self, t1, t2, FAddcdiv{value, 0}); LAMP_API_END
+}
+int lamp_relu_backward_accumulate_(lamp_tensor* out, const lamp_tensor* p, const lamp_tensor* x, double negative_slope) {
+  LAMP_API_BEGIN run_same<3, FReluBwdAcc, true>(out, out, p, x, FReluBwdAcc{negative_slope, 0}); LAMP_API_END
+}
+
+API1(relu, FRelu, false)
+API1_INPLACE(relu_, FRelu, false)
+int lamp_leaky_relu(lamp_tensor** out, const lamp_tensor* a, double slope) {
+  LAMP_API_BEGIN *out = run_same<1, FLeakyRelu, true>(nullptr, a, nullptr, nullptr, FLeakyRelu{slope, 0}); LAMP_API_END
+}
+API1(gelu, FGelu, true)
+API2(gelu_backward, FGeluBwd, true)
+API1(sigmoid, FSigmoid, true)
+API2(sigmoid_backward, FSigmoidBwd, true)
+API1(tanh, FTanh, true)
+API2(tanh_backward, FTanhBwd, true)
+API1(hardswish, FHardswish, true)
+API2(hardswish_backward, FHardswishBwd, true)
+int lamp_softplus(lamp_tensor** out, const lamp_tensor* a, double beta, double threshold) {
+  LAMP_API_BEGIN *out = run_same<1, FSoftplus, true>(nullptr, a, nullptr, nullptr, FSoftplus{beta, threshold}); LAMP_API_END
+}
+int lamp_softplus_backward(lamp_tensor** out, const lamp_tensor* g, const lamp_tensor* x, double beta, double threshold) {
+  LAMP_API_BEGIN *out = run_same<2, FSoftplusBwd, true>(nullptr, g, x, nullptr, FSoftplusBwd{beta, threshold}); LAMP_API_END
+}
+API1(exp, FExp, true)
+API1_INPLACE(exp_, FExp, true)
+API1(log, FLog, true)
+API1(log1p, FLog1p, true)
+API1(sqrt, FSqrt, true)
+API1_INPLACE(sqrt_, FSqrt, true)
+API1(square, FSquare, false)
+API1(reciprocal, FRecip, true)
+API1_INPLACE(reciprocal_, FRecip, true)
+API1(neg, FNeg, false)
+API1(abs, FAbs, false)
+API1(sign, FSign, false)
+API1(sin, FSin, true)
+API1(cos, FCos, true)
+API1(tan, FTan, true)
+API1(atan, FAtan, true)
+
+API_CMP(lt, FLt)
+API_CMP(le, FLe)
+API_CMP(gt, FGt)
+API_CMP(ge, FGe)
+API_CMP(eq, FEq)
+API_CMP(ne, FNe)
+API_CMP_S(lt_scalar, FLtS)
+API_CMP_S(le_scalar, FLeS)
+API_CMP_S(gt_scalar, FGtS)
+API_CMP_S(ge_scalar, FGeS)
+API_CMP_S(eq_scalar, FEqS)
+API_CMP_S(ne_scalar, FNeS)
+int lamp_logical_not(lamp_tensor** out, const lamp_tensor* a) {
+  LAMP_API_BEGIN *out = run_bool<1, FLogicalNot>(a, nullptr, FLogicalNot{}); LAMP_API_END
+}
+
+int lamp_where(lamp_tensor** out, const lamp_tensor* cond, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN
+  check_device_tensor(cond, "condition"); check_device_tensor(a, "self"); check_device_tensor(b, "other");
+  LAMP_CHECK(cond->dtype == kBool || cond->dtype == kU8, "where expects a bool condition, got " << cond->describe());
+  LAMP_CHECK(a->dtype == b->dtype, "where: dtype mismatch " << a->describe() << " vs " << b->describe());
+  auto shape = broadcast_shapes(broadcast_shapes(cond->shape(), a->shape()), b->shape());
+  Hold r(new_tensor(shape, a->dtype, a->device()));
+  const Tensor* ops[4] = {r.get(), cond, a, b};
+  IterSpace it = make_iter(shape, ops, 4);
+  if (it.numel > 0) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((where_kernel<T>), dim3(grid_for(it.numel, 256)), dim3(256), 0,
+                                                      current_stream(a->device()), r->ptr<T>(), cond->ptr<uint8_t>(),
+                                                      a->ptr<T>(), b->ptr<T>(), it.numel, to_args(it)));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_masked_fill(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask, double value) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(mask, "mask");
+  LAMP_CHECK(mask->dtype == kBool || mask->dtype == kU8, "masked_fill expects a bool mask");
+  auto shape = broadcast_shapes(a->shape(), mask->shape());
+  LAMP_CHECK(shape == a->shape(), "masked_fill: mask must broadcast to self");
+  Hold r(new_tensor(shape, a->dtype, a->device()));
+  const Tensor* ops[3] = {r.get(), a, mask};
+  IterSpace it = make_iter(shape, ops, 3);
+  if (it.numel > 0) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((masked_fill_kernel<T>), dim3(grid_for(it.numel, 256)), dim3(256), 0,
+                                                      current_stream(a->device()), r->ptr<T>(), a->ptr<T>(),
+                                                      mask->ptr<uint8_t>(), store_as<T>((acc_t<T>)value), it.numel, to_args(it)));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,581 @@
+// GEMM family on the gfx950 matrix cores.
+//
+// Replaces ATen.mm / bmm / addmm / baddbmm / matmul and aten-scala's custom natives
+// Tensor.addmm_out_transposed1/2, Tensor.baddbmm_out_transposed1/2 (reference call sites:
+// lamp-sten/src/main/scala/lamp/STen.scala:391-449,1146,1220-1240;
+// lamp-core/src/main/scala/lamp/autograd/ops.scala:665-724 - MatMul/BatchedMatMul forward
+// `mm`, backward dA += p.B^T (transposed2) and dB += A^T.p (transposed1), beta = alpha = 1).
+//
+//   C[m,n] = beta * S[m,n] + alpha * sum_k A(m,k) * B(k,n)
+//
+// All four storage combinations are handled WITHOUT materialising a transpose: an operand
+// whose K index is contiguous in memory is staged as [rows][K] and its MFMA fragments are
+// read with ds_read_b128; an operand whose K index is strided (B of a row-major mm, both
+// operands of A^T.B) is staged in its natural [K][cols] layout (coalesced 16-byte global
+// loads) and its fragments come from the CDNA4 transposing LDS read ds_read_b64_tr_b16.
+//
+// bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate, one rounding to bf16 in the epilogue.
+// f32 : v_mfma_f32_16x16x4_f32 - exact f32 FMA chain (no tf32 on gfx950), parity <= 1e-5.
+// f64 : v_mfma_f64_16x16x4_f64 (the reference's own tests run in double).
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* S;          // beta operand (may alias C, may be null)
+  int64_t M, N, K;
+  int64_t a_rs, a_cs;     // A(m,k) = A[m*a_rs + k*a_cs]; exactly one of them is 1 for the fast path
+  int64_t b_rs, b_cs;     // B(k,n) = B[k*b_rs + n*b_cs]
+  int64_t ldc;            // C(m,n) = C[m*ldc + n]
+  int64_t s_rs, s_cs;     // S(m,n) = S[m*s_rs + n*s_cs] (0 strides broadcast)
+  int64_t a_bs, b_bs, c_bs, s_bs;  // batch strides
+  int batch;
+  int a_vec, b_vec;       // 16-byte vector loads legal for this operand
+  double alpha, beta;
+  int tiles_m, tiles_n;
+};
+
+// ================================================================================================
+// bf16 kernel: 128 x 128 x 64 tile, 256 threads = 4 waves (2 x 2), 64 x 64 per wave
+// ================================================================================================
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+// LDS image of a K-contiguous operand tile: [128 rows][64 k] bf16, 128-byte rows of eight
+// 16-byte chunks, chunk' = chunk ^ (row & 7)  (conflict-free ds_read_b128 for the
+// 16-row x 16-byte fragment read pattern).
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// LDS image of a K-strided operand tile: [64 k][128 cols] bf16, 256-byte rows of eight
+// 32-byte chunks, chunk' = chunk ^ f(k) with f(k) = (k & 3) | ((k >> 3) & 1) << 2 (the rows a
+// 32-lane half touches in one ds_read_b64_tr_b16 land in 8 different chunks).
+__device__ __forceinline__ int ks_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int ks_off(int k, int col8 /* 16-byte chunk index 0..15 */) {
+  return k * 256 + ((((col8 >> 1) ^ ks_swz(k))) << 5) + ((col8 & 1) << 4);
+}
+
+// global -> registers for one 128x64 (or 64x128) operand tile: 4 x 16 bytes per thread
+template <bool KC>
+__device__ __forceinline__ void stage_load(uint4 (&r)[4], const bf16_t* __restrict__ base, int64_t ld, int64_t row0,
+                                           int64_t k0, int64_t rows, int64_t K, int vec_ok, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + i * 256;
+    int64_t gr, gk;     // "row" = M or N index, "k" = K index
+    int64_t addr;
+    bool full;
+    if (KC) {           // [rows][K], K contiguous: 8 chunks per row
+      gr = row0 + (c >> 3);
+      gk = k0 + ((c & 7) << 3);
+      addr = gr * ld + gk;
+      full = (gr < rows) && (gk + 8 <= K);
+    } else {            // [K][rows], row index contiguous: 16 chunks per k
+      gk = k0 + (c >> 4);
+      gr = row0 + ((c & 15) << 3);
+      addr = gk * ld + gr;
+      full = (gk < K) && (gr + 8 <= rows);
+    }
+    if (full && vec_ok) {
+      r[i] = *reinterpret_cast<const uint4*>(base + addr);
+    } else {
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        bool ok = KC ? (gr < rows && gk + j < K) : (gk < K && gr + j < rows);
+        e[j] = ok ? base[addr + j].bits : (unsigned short)0;
+      }
+      r[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+  }
+}
+template <bool KC> __device__ __forceinline__ void stage_store(const uint4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid + i * 256;
+    const int off = KC ? kc_off(c >> 3, c & 7) : ks_off(c >> 4, c & 15);
+    *reinterpret_cast<uint4*>(lds + off) = r[i];
+  }
+}
+
+// fragment for MFMA 16x16x32: lane l needs 8 consecutive k (k = 32*s + 8*(l>>4) + j) of row/col (l & 15)
+template <bool KC> __device__ __forceinline__ bf8_t load_frag(const char* lds, int tile_row0, int s, int lane) {
+  if (KC) {
+    const int row = tile_row0 + (lane & 15);
+    const int chunk = s * 4 + (lane >> 4);
+    s8_t v = *reinterpret_cast<const s8_t*>(lds + kc_off(row, chunk));
+    return __builtin_bit_cast(bf8_t, v);
+  } else {
+    // transposing read: within a 16-lane group lane 4q+p supplies the address of row q, columns 4p..4p+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = s * 32 + g * 8 + q;
+    const int col8 = (tile_row0 >> 3) + (p >> 1);           // 16-byte chunk along the contiguous index
+    const int off0 = ks_off(k, col8) + ((p & 1) << 3);
+    const int off1 = ks_off(k + 4, col8) + ((p & 1) << 3);
+    typedef __attribute__((address_space(3))) s4_t* lds_ptr_t;
+    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(lds + off0));
+    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(lds + off1));
+    s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf8_t, v);
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware tile order: consecutive tiles of one XCD share A row-panels in that XCD's L2
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  // group tiles in column strips of 8 tile rows for L2 reuse of the B panel
+  const int GROUP = 8;
+  const int per_group = GROUP * g.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP;
+  const int gsize = min(g.tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsize;
+  const int tn = (bid % per_group) / gsize;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int bz = blockIdx.z;
+  const bf16_t* A = (const bf16_t*)g.A + bz * g.a_bs;
+  const bf16_t* B = (const bf16_t*)g.B + bz * g.b_bs;
+  const int64_t lda = AKC ? g.a_rs : g.a_cs;
+  const int64_t ldb = BKC ? g.b_cs : g.b_rs;
+
+  // stage layout: [A0][B0][A1][B1]
+#define As_(buf) (smem + (buf) * 2 * TILE_BYTES)
+#define Bs_(buf) (smem + (buf) * 2 * TILE_BYTES + TILE_BYTES)
+
+  f4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (int)((g.K + BK - 1) / BK);
+  uint4 ra[4], rb[4];
+  stage_load<AKC>(ra, A, lda, m0, 0, g.M, g.K, g.a_vec, tid);
+  stage_load<BKC>(rb, B, ldb, n0, 0, g.N, g.K, g.b_vec, tid);
+  stage_store<AKC>(ra, As_(0), tid);
+  stage_store<BKC>(rb, Bs_(0), tid);
+  __syncthreads();
+
+  for (int t = 0; t < nk; t++) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      stage_load<AKC>(ra, A, lda, m0, (int64_t)(t + 1) * BK, g.M, g.K, g.a_vec, tid);
+      stage_load<BKC>(rb, B, ldb, n0, (int64_t)(t + 1) * BK, g.N, g.K, g.b_vec, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      bf8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = load_frag<AKC>(As_(cur), wr * 64 + i * 16, s, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = load_frag<BKC>(Bs_(cur), wc * 64 + j * 16, s, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      stage_store<AKC>(ra, As_(cur ^ 1), tid);
+      stage_store<BKC>(rb, Bs_(cur ^ 1), tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
+  const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t col = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row < g.M && col < g.N) {
+          float v = alpha * acc[i][j][r];
+          if (S) v += beta * (float)S[row * g.s_rs + col * g.s_cs];
+          C[row * g.ldc + col] = bf16_t(v);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// f32 / f64 kernel: 64 x 64 x 16 tile, 256 threads = 4 waves (2 x 2), 32 x 32 per wave,
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64. LDS tiles are k-major [16][64+pad] so a
+// fragment read is one conflict-free 4/8-byte read per lane.
+// ================================================================================================
+template <class T> struct FpTraits;
+template <> struct FpTraits<float> {
+  using acc4 = f4_t;
+  static __device__ __forceinline__ acc4 mfma(float a, float b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+template <> struct FpTraits<double> {
+  using acc4 = d4_t;
+  static __device__ __forceinline__ acc4 mfma(double a, double b, acc4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  // f64 C/D: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+constexpr int FM = 64, FN = 64, FK = 16, FPAD = 4;
+
+template <class T>
+__global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
+  using TR = FpTraits<T>;
+  using acc4 = typename TR::acc4;
+  __shared__ T As[2][FK][FM + FPAD];
+  __shared__ T Bs[2][FK][FN + FPAD];
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int64_t m0 = (int64_t)tm * FM, n0 = (int64_t)tn * FN;
+  const int bz = blockIdx.z;
+  const T* A = (const T*)g.A + bz * g.a_bs;
+  const T* B = (const T*)g.B + bz * g.b_bs;
+
+  acc4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = acc4{0, 0, 0, 0};
+
+  // staging: 64 x 16 = 1024 elements per operand, 4 per thread; thread -> (row, k) chosen so the
+  // global reads are coalesced along whichever index is contiguous
+  const bool a_kc = (g.a_cs == 1), b_kc = (g.b_rs == 1);
+  T ra[4], rb[4];
+  auto load_tile = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int e = tid + i * 256;
+      int ar, ak, bn, bk;
+      if (a_kc) { ar = e >> 4; ak = e & 15; } else { ak = e >> 6; ar = e & 63; }
+      if (b_kc) { bn = e >> 4; bk = e & 15; } else { bk = e >> 6; bn = e & 63; }
+      const int64_t gm = m0 + ar, gka = k0 + ak, gn = n0 + bn, gkb = k0 + bk;
+      ra[i] = (gm < g.M && gka < g.K) ? A[gm * g.a_rs + gka * g.a_cs] : T(0);
+      rb[i] = (gn < g.N && gkb < g.K) ? B[gkb * g.b_rs + gn * g.b_cs] : T(0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int e = tid + i * 256;
+      int ar, ak, bn, bk;
+      if (a_kc) { ar = e >> 4; ak = e & 15; } else { ak = e >> 6; ar = e & 63; }
+      if (b_kc) { bn = e >> 4; bk = e & 15; } else { bk = e >> 6; bn = e & 63; }
+      As[buf][ak][ar] = ra[i];
+      Bs[buf][bk][bn] = rb[i];
+    }
+  };
+
+  const int nk = (int)((g.K + FK - 1) / FK);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    const int cur = t & 1;
+    if (t + 1 < nk) load_tile((int64_t)(t + 1) * FK);
+#pragma unroll
+    for (int s = 0; s < FK / 4; s++) {
+      const int k = s * 4 + (lane >> 4);
+      T fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) fa[i] = As[cur][k][wr * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[j] = Bs[cur][k][wc * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = TR::mfma(fa[i], fb[j], acc[i][j]);
+    }
+    if (t + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  T* C = (T*)g.C + bz * g.c_bs;
+  const T* S = g.S ? (const T*)g.S + bz * g.s_bs : nullptr;
+  const T alpha = (T)g.alpha, beta = (T)g.beta;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int64_t col = n0 + wc * 32 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + wr * 32 + i * 16 + TR::crow(lane, r);
+        if (row < g.M && col < g.N) {
+          T v = alpha * acc[i][j][r];
+          if (S) v += beta * S[row * g.s_rs + col * g.s_cs];
+          C[row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct Operand {
+  const Tensor* t;
+  Hold owned;  // contiguous copy when the strides are not GEMM-friendly
+  int64_t rs, cs, bs;
+};
+
+// a 2-D (or batched 3-D) operand whose (row, col) strides have a unit stride somewhere
+static void prep_operand(Operand& o, const Tensor* t, bool batched) {
+  int nd = t->ndim;
+  o.t = t;
+  int64_t rs = t->strides[nd - 2], cs = t->strides[nd - 1];
+  int64_t rows = t->sizes[nd - 2], cols = t->sizes[nd - 1];
+  bool ok = (cs == 1 && (rs >= cols || rows == 1)) || (rs == 1 && (cs >= rows || cols == 1));
+  if (rows == 1 && cols == 1) ok = true;
+  if (!ok) {
+    o.owned = Hold(new_like(t));
+    copy_into(o.owned.get(), t);
+    o.t = o.owned.get();
+    rs = o.t->strides[nd - 2];
+    cs = o.t->strides[nd - 1];
+  }
+  // normalise degenerate strides so exactly one of them is 1
+  if (cols == 1 && rs == 1 && cs != 1 && rows > 1) { /* column vector stored densely: M-contiguous */ }
+  o.rs = rs;
+  o.cs = cs;
+  o.bs = batched ? o.t->strides[0] : 0;
+}
+
+// transA: use a^T, transB: use b^T.  self may be null (beta ignored) and may alias out.
+static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, const Tensor* b, bool transA, bool transB,
+                          double beta, double alpha, bool batched) {
+  check_device_tensor(out, "out"); check_device_tensor(a, "mat1"); check_device_tensor(b, "mat2");
+  const int nd = batched ? 3 : 2;
+  LAMP_CHECK(a->ndim == nd && b->ndim == nd && out->ndim == nd, "expected " << nd << "-D operands, got " << a->describe() << ", "
+             << b->describe() << " -> " << out->describe());
+  LAMP_CHECK(a->dtype == b->dtype && a->dtype == out->dtype, "dtype mismatch: " << a->describe() << " x " << b->describe()
+             << " -> " << out->describe());
+  check_same_device(a, b); check_same_device(a, out);
+  Operand oa, ob;
+  prep_operand(oa, a, batched);
+  prep_operand(ob, b, batched);
+  const int64_t ar = oa.t->sizes[nd - 2], ac = oa.t->sizes[nd - 1], br = ob.t->sizes[nd - 2], bc = ob.t->sizes[nd - 1];
+  GemmArgs g{};
+  g.M = transA ? ac : ar;
+  g.K = transA ? ar : ac;
+  const int64_t Kb = transB ? bc : br;
+  g.N = transB ? br : bc;
+  LAMP_CHECK(g.K == Kb, "shapes cannot be multiplied: " << a->describe() << (transA ? "^T" : "") << " x " << b->describe() << (transB ? "^T" : ""));
+  LAMP_CHECK(out->sizes[nd - 2] == g.M && out->sizes[nd - 1] == g.N, "out " << out->describe() << " has the wrong shape for " << g.M << "x" << g.N);
+  LAMP_CHECK(out->strides[nd - 1] == 1 || g.N == 1, "out must be row-major");
+  g.batch = batched ? (int)out->sizes[0] : 1;
+  if (batched) LAMP_CHECK(a->sizes[0] == g.batch && b->sizes[0] == g.batch, "batch size mismatch");
+  g.a_rs = transA ? oa.cs : oa.rs;
+  g.a_cs = transA ? oa.rs : oa.cs;
+  g.b_rs = transB ? ob.cs : ob.rs;
+  g.b_cs = transB ? ob.rs : ob.cs;
+  g.a_bs = oa.bs; g.b_bs = ob.bs;
+  g.A = oa.t->data(); g.B = ob.t->data(); g.C = out->data();
+  g.ldc = out->strides[nd - 2];
+  g.c_bs = batched ? out->strides[0] : 0;
+  g.alpha = alpha; g.beta = beta;
+  if (self && beta != 0.0) {
+    check_device_tensor(self, "self");
+    LAMP_CHECK(self->dtype == out->dtype, "self dtype mismatch");
+    // broadcast self to [batch, M, N]
+    std::vector<int64_t> oshape = out->shape();
+    const Tensor* ops[2] = {out, self};
+    LAMP_CHECK(self->ndim <= nd, "self has too many dims");
+    int lead = nd - self->ndim;
+    int64_t st[3] = {0, 0, 0};
+    for (int d = 0; d < nd; d++) {
+      if (d < lead) continue;
+      int64_t sz = self->sizes[d - lead];
+      LAMP_CHECK(sz == oshape[d] || sz == 1, "self " << self->describe() << " does not broadcast to " << out->describe());
+      st[d] = (sz == 1 && oshape[d] != 1) ? 0 : self->strides[d - lead];
+    }
+    g.S = self->data();
+    g.s_rs = st[nd - 2]; g.s_cs = st[nd - 1]; g.s_bs = batched ? st[0] : 0;
+  } else {
+    g.S = nullptr;
+  }
+  if (g.M == 0 || g.N == 0 || g.batch == 0) return;
+  hipStream_t stm = current_stream(out->device());
+  if (g.K == 0) {  // out = beta * self
+    if (g.S) { LAMP_CHECK(lamp_mul_scalar_(out, 0.0) == 0, lamp_last_error()); LAMP_CHECK(lamp_add_(out, self, beta) == 0, lamp_last_error()); }
+    else fill_zero(out);
+    return;
+  }
+  if (a->dtype == kBF16) {
+    const bool akc = (g.a_cs == 1), bkc = (g.b_rs == 1);
+    LAMP_CHECK(akc || g.a_rs == 1, "internal: A has no unit stride");
+    LAMP_CHECK(bkc || g.b_cs == 1, "internal: B has no unit stride");
+    const int64_t lda = akc ? g.a_rs : g.a_cs, ldb = bkc ? g.b_cs : g.b_rs;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    g.a_vec = (lda % 8 == 0) && al16(g.A) && (g.a_bs % 8 == 0);
+    g.b_vec = (ldb % 8 == 0) && al16(g.B) && (g.b_bs % 8 == 0);
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (int)((g.N + BN - 1) / BN);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
+    size_t lds = 4 * TILE_BYTES;
+    if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), lds, stm, g);
+    else if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), lds, stm, g);
+    else if (!akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), lds, stm, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), lds, stm, g);
+  } else if (a->dtype == kF32 || a->dtype == kF64) {
+    g.tiles_m = (int)((g.M + FM - 1) / FM);
+    g.tiles_n = (int)((g.N + FN - 1) / FN);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
+    if (a->dtype == kF32) hipLaunchKernelGGL((gemm_fp_kernel<float>), grid, dim3(256), 0, stm, g);
+    else hipLaunchKernelGGL((gemm_fp_kernel<double>), grid, dim3(256), 0, stm, g);
+  } else {
+    LAMP_CHECK(false, "GEMM supports bf16, f32 and f64, got " << a->describe());
+  }
+  LAMP_LAUNCH_CHECK();
+}
+
+static Tensor* alloc_out(const Tensor* a, const Tensor* b, bool transA, bool transB, bool batched) {
+  const int nd = batched ? 3 : 2;
+  LAMP_CHECK(a->ndim == nd && b->ndim == nd, "expected " << nd << "-D operands, got " << a->describe() << " and " << b->describe());
+  int64_t M = transA ? a->sizes[nd - 1] : a->sizes[nd - 2];
+  int64_t N = transB ? b->sizes[nd - 2] : b->sizes[nd - 1];
+  std::vector<int64_t> s;
+  if (batched) s.push_back(a->sizes[0]);
+  s.push_back(M); s.push_back(N);
+  return new_tensor(s, a->dtype, a->device());
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_mm(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(b, "mat2");
+  Hold r(alloc_out(a, b, false, false, false));
+  gemm_dispatch(r.get(), nullptr, a, b, false, false, 0.0, 1.0, false);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_mm_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN gemm_dispatch(out, nullptr, a, b, false, false, 0.0, 1.0, false); LAMP_API_END
+}
+int lamp_bmm(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(b, "mat2");
+  Hold r(alloc_out(a, b, false, false, true));
+  gemm_dispatch(r.get(), nullptr, a, b, false, false, 0.0, 1.0, true);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_bmm_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN gemm_dispatch(out, nullptr, a, b, false, false, 0.0, 1.0, true); LAMP_API_END
+}
+int lamp_addmm(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "mat1"); check_device_tensor(b, "mat2");
+  Hold r(alloc_out(a, b, false, false, false));
+  gemm_dispatch(r.get(), self, a, b, false, false, beta, alpha, false);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_addmm_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN gemm_dispatch(out, self, a, b, false, false, beta, alpha, false); LAMP_API_END
+}
+int lamp_baddbmm(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "batch1"); check_device_tensor(b, "batch2");
+  Hold r(alloc_out(a, b, false, false, true));
+  gemm_dispatch(r.get(), self, a, b, false, false, beta, alpha, true);
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_addmm_out_transposed1(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN gemm_dispatch(out, self, a, b, true, false, beta, alpha, false); LAMP_API_END
+}
+int lamp_addmm_out_transposed2(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN gemm_dispatch(out, self, a, b, false, true, beta, alpha, false); LAMP_API_END
+}
+int lamp_baddbmm_out_transposed1(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN gemm_dispatch(out, self, a, b, true, false, beta, alpha, true); LAMP_API_END
+}
+int lamp_baddbmm_out_transposed2(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* a, const lamp_tensor* b, double beta, double alpha) {
+  LAMP_API_BEGIN gemm_dispatch(out, self, a, b, false, true, beta, alpha, true); LAMP_API_END
+}
+int lamp_linear_bias(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* w, const lamp_tensor* bias) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "x"); check_device_tensor(w, "w");
+  Hold r(alloc_out(x, w, false, false, false));
+  gemm_dispatch(r.get(), bias, x, w, false, false, bias ? 1.0 : 0.0, 1.0, false);
+  *out = r.take();
+  LAMP_API_END
+}
+// matmul: 1-D/2-D/3-D combinations lamp uses (STen.scala:1223)
+int lamp_matmul(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(b, "other");
+  if (a->ndim == 2 && b->ndim == 2) return lamp_mm(out, a, b);
+  if (a->ndim == 3 && b->ndim == 3) return lamp_bmm(out, a, b);
+  if (a->ndim == 1 && b->ndim == 1) {
+    lamp_tensor *a2 = nullptr, *b2 = nullptr, *r = nullptr;
+    int64_t s1[2] = {1, a->sizes[0]}, s2[2] = {b->sizes[0], 1};
+    LAMP_CHECK(lamp_view(&a2, a, s1, 2) == 0, lamp_last_error()); Hold ha(a2);
+    LAMP_CHECK(lamp_reshape(&b2, b, s2, 2) == 0, lamp_last_error()); Hold hb(b2);
+    LAMP_CHECK(lamp_mm(&r, a2, b2) == 0, lamp_last_error()); Hold hr(r);
+    return lamp_view(out, r, nullptr, 0);
+  }
+  if (a->ndim == 2 && b->ndim == 1) {
+    lamp_tensor *b2 = nullptr, *r = nullptr;
+    int64_t s2[2] = {b->sizes[0], 1};
+    LAMP_CHECK(lamp_reshape(&b2, b, s2, 2) == 0, lamp_last_error()); Hold hb(b2);
+    LAMP_CHECK(lamp_mm(&r, a, b2) == 0, lamp_last_error()); Hold hr(r);
+    int64_t so[1] = {a->sizes[0]};
+    return lamp_view(out, r, so, 1);
+  }
+  if (a->ndim == 1 && b->ndim == 2) {
+    lamp_tensor *a2 = nullptr, *r = nullptr;
+    int64_t s1[2] = {1, a->sizes[0]};
+    LAMP_CHECK(lamp_reshape(&a2, a, s1, 2) == 0, lamp_last_error()); Hold ha(a2);
+    LAMP_CHECK(lamp_mm(&r, a2, b) == 0, lamp_last_error()); Hold hr(r);
+    int64_t so[1] = {b->sizes[1]};
+    return lamp_view(out, r, so, 1);
+  }
+  if (a->ndim == 3 && b->ndim == 2) {  // [B,M,K] x [K,N] -> fold the batch into M
+    lamp_tensor *a2 = nullptr, *r = nullptr;
+    int64_t s1[2] = {a->sizes[0] * a->sizes[1], a->sizes[2]};
+    LAMP_CHECK(lamp_reshape(&a2, a, s1, 2) == 0, lamp_last_error()); Hold ha(a2);
+    LAMP_CHECK(lamp_mm(&r, a2, b) == 0, lamp_last_error()); Hold hr(r);
+    int64_t so[3] = {a->sizes[0], a->sizes[1], b->sizes[1]};
+    return lamp_view(out, r, so, 3);
+  }
+  LAMP_CHECK(false, "matmul: unsupported operand ranks " << a->ndim << " and " << b->ndim);
+  LAMP_API_END
+}
+
+}  // extern "C"
