@@ -1,0 +1,271 @@
+// Convolution (1-D / 2-D, groups, stride, padding, dilation, transposed) forward and backward.
+//
+// Replaces ATen.convolution and ATen.convolution_backward(output_mask[3]) as lamp's single
+// Convolution op calls them (reference: lamp-core/src/main/scala/lamp/autograd/ops.scala:1547-1651;
+// Conv2D module lamp-core/.../nn/Conv2D.scala:8-83; Conv1D and Conv2DTransposed route through the
+// same op with 1-element / transposed=true arguments).
+//
+// Layout NCHW (NCL for 1-D is treated as H = 1), weights [Cout, Cin/g, kh, kw]
+// (transposed: [Cin, Cout/g, kh, kw]).
+//
+// This file holds the general direct kernels (every geometry, f32/f64/bf16, fp32 accumulation for
+// bf16).  The implicit-GEMM MFMA kernels for the wide 3x3 / 1x1 layers of the CIFAR ResNet live
+// in conv_igemm.hip and are selected by conv_dispatch when the geometry qualifies.
+#include "device_utils.h"
+#include "../core/strided.h"
+#include "conv_geom.h"
+
+namespace lamp {
+
+// out[n, co, ho, wo] = bias[co] + sum_{ci, r, s} x[n, ci, ho*sh - ph + r*dh, wo*sw - pw + s*dw] * w[co, ci_l, r, s]
+template <class T>
+__global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+                                                              T* __restrict__ y, ConvGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.N * g.Cout * g.Ho * g.Wo;
+  const int cin_g = (int)(g.Cin / g.groups), cout_g = (int)(g.Cout / g.groups);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % g.Wo);
+    const int ho = (int)((e / g.Wo) % g.Ho);
+    const int co = (int)((e / (g.Wo * g.Ho)) % g.Cout);
+    const int64_t n = e / (g.Wo * g.Ho * g.Cout);
+    const int grp = co / cout_g;
+    A acc = bias ? load_as<A>(bias[co]) : A(0);
+    const T* wp = w + (int64_t)co * cin_g * g.kh * g.kw;
+    for (int cl = 0; cl < cin_g; cl++) {
+      const T* xp = x + ((n * g.Cin + grp * cin_g + cl) * g.H) * g.W;
+      for (int r = 0; r < g.kh; r++) {
+        const int h = ho * g.sh - g.ph + r * g.dh;
+        if (h < 0 || h >= g.H) continue;
+        for (int s = 0; s < g.kw; s++) {
+          const int ww = wo * g.sw - g.pw + s * g.dw;
+          if (ww < 0 || ww >= g.W) continue;
+          acc += load_as<A>(xp[h * g.W + ww]) * load_as<A>(wp[(cl * g.kh + r) * g.kw + s]);
+        }
+      }
+    }
+    y[e] = store_as<T>(acc);
+  }
+}
+
+// dx[n, ci, h, w] = sum_{co in group, r, s} dy[n, co, ho, wo] * w[co, ci_l, r, s],  h = ho*sh - ph + r*dh
+template <class T>
+__global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ w, const T* __restrict__ bias,
+                                                                T* __restrict__ dx, ConvGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.N * g.Cin * g.H * g.W;
+  const int cin_g = (int)(g.Cin / g.groups), cout_g = (int)(g.Cout / g.groups);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wi = (int)(e % g.W);
+    const int hi = (int)((e / g.W) % g.H);
+    const int ci = (int)((e / (g.W * g.H)) % g.Cin);
+    const int64_t n = e / (g.W * g.H * g.Cin);
+    const int grp = ci / cin_g, cl = ci - grp * cin_g;
+    A acc = bias ? load_as<A>(bias[ci]) : A(0);   // bias only used when this kernel runs a transposed forward
+    for (int r = 0; r < g.kh; r++) {
+      const int hn = hi + g.ph - r * g.dh;
+      if (hn < 0 || hn % g.sh != 0) continue;
+      const int ho = hn / g.sh;
+      if (ho >= g.Ho) continue;
+      for (int s = 0; s < g.kw; s++) {
+        const int wn = wi + g.pw - s * g.dw;
+        if (wn < 0 || wn % g.sw != 0) continue;
+        const int wo = wn / g.sw;
+        if (wo >= g.Wo) continue;
+        for (int col = 0; col < cout_g; col++) {
+          const int co = grp * cout_g + col;
+          acc += load_as<A>(dy[((n * g.Cout + co) * g.Ho + ho) * g.Wo + wo]) *
+                 load_as<A>(w[(((int64_t)co * cin_g + cl) * g.kh + r) * g.kw + s]);
+        }
+      }
+    }
+    dx[e] = store_as<T>(acc);
+  }
+}
+
+// dw[co, ci_l, r, s] = sum_{n, ho, wo} dy[n, co, ho, wo] * x[n, ci, ho*sh - ph + r*dh, wo*sw - pw + s*dw]
+// one workgroup per (co, ci_l); up to MAXRS kernel taps kept in registers
+constexpr int MAXRS = 49;
+template <class T, int RS>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dw, ConvGeom g) {
+  using A = acc_t<T>;
+  __shared__ A sm[4];
+  const int cin_g = (int)(g.Cin / g.groups), cout_g = (int)(g.Cout / g.groups);
+  const int co = blockIdx.x / cin_g, cl = blockIdx.x % cin_g;
+  const int grp = co / cout_g;
+  const int ci = grp * cin_g + cl;
+  const int khkw = g.kh * g.kw;
+  A acc[RS];
+#pragma unroll
+  for (int i = 0; i < RS; i++) acc[i] = A(0);
+  const int64_t per = g.Ho * g.Wo, total = g.N * per;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t n = e / per;
+    const int p = (int)(e - n * per);
+    const int ho = p / (int)g.Wo, wo = p - ho * (int)g.Wo;
+    const A gy = load_as<A>(dy[(n * g.Cout + co) * per + p]);
+    const T* xp = x + (n * g.Cin + ci) * g.H * g.W;
+#pragma unroll
+    for (int rs = 0; rs < RS; rs++) {
+      if (rs < khkw) {
+        const int r = rs / g.kw, s = rs - r * g.kw;
+        const int h = ho * g.sh - g.ph + r * g.dh, ww = wo * g.sw - g.pw + s * g.dw;
+        if (h >= 0 && h < g.H && ww >= 0 && ww < g.W) acc[rs] += gy * load_as<A>(xp[h * g.W + ww]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rs = 0; rs < RS; rs++) {
+    if (rs < khkw) {
+      A v = block_sum(acc[rs], sm);
+      if (threadIdx.x == 0) dw[((int64_t)co * cin_g + cl) * khkw + rs] = store_as<T>(v);
+    }
+  }
+}
+
+ConvGeom make_geom(const Tensor* x, const Tensor* w, const int64_t* stride, const int64_t* padding, const int64_t* dilation,
+                   int nspatial, int transposed, const int64_t* output_padding, int64_t groups) {
+  LAMP_CHECK(nspatial == 1 || nspatial == 2, "only 1-D and 2-D convolutions are supported (got " << nspatial << " spatial dims)");
+  LAMP_CHECK(x->ndim == nspatial + 2 && w->ndim == nspatial + 2, "convolution: input " << x->describe() << " / weight " << w->describe()
+             << " do not have " << nspatial + 2 << " dims");
+  LAMP_CHECK(groups >= 1, "groups must be >= 1");
+  ConvGeom g{};
+  g.transposed = transposed;
+  g.groups = groups;
+  const bool two = nspatial == 2;
+  g.sh = two ? (int)stride[0] : 1; g.sw = (int)stride[two ? 1 : 0];
+  g.ph = two ? (int)padding[0] : 0; g.pw = (int)padding[two ? 1 : 0];
+  g.dh = two ? (int)dilation[0] : 1; g.dw = (int)dilation[two ? 1 : 0];
+  g.kh = two ? (int)w->sizes[2] : 1; g.kw = (int)w->sizes[two ? 3 : 2];
+  const int oph = (transposed && output_padding) ? (two ? (int)output_padding[0] : 0) : 0;
+  const int opw = (transposed && output_padding) ? (int)output_padding[two ? 1 : 0] : 0;
+  LAMP_CHECK(g.sh > 0 && g.sw > 0 && g.dh > 0 && g.dw > 0 && g.ph >= 0 && g.pw >= 0, "bad convolution geometry");
+  g.N = x->sizes[0];
+  // In "regular" terms (Cin, H, W) is the side with the larger image for transposed convs.
+  if (!transposed) {
+    g.Cin = x->sizes[1]; g.H = two ? x->sizes[2] : 1; g.W = x->sizes[two ? 3 : 2];
+    g.Cout = w->sizes[0];
+    LAMP_CHECK(w->sizes[1] * groups == g.Cin, "convolution: weight " << w->describe() << " expects " << w->sizes[1] * groups
+               << " input channels, input has " << g.Cin);
+    LAMP_CHECK(g.Cout % groups == 0, "out channels not divisible by groups");
+    g.Ho = (g.H + 2 * g.ph - g.dh * (g.kh - 1) - 1) / g.sh + 1;
+    g.Wo = (g.W + 2 * g.pw - g.dw * (g.kw - 1) - 1) / g.sw + 1;
+    LAMP_CHECK(g.Ho > 0 && g.Wo > 0, "convolution output would be empty");
+  } else {
+    // transposed conv: x plays the role of dy of a regular conv whose input is the (bigger) output
+    g.Cout = x->sizes[1]; g.Ho = two ? x->sizes[2] : 1; g.Wo = x->sizes[two ? 3 : 2];
+    LAMP_CHECK(w->sizes[0] == g.Cout, "transposed convolution: weight " << w->describe() << " expects " << w->sizes[0] << " input channels");
+    g.Cin = w->sizes[1] * groups;
+    g.H = (g.Ho - 1) * g.sh - 2 * g.ph + g.dh * (g.kh - 1) + oph + 1;
+    g.W = (g.Wo - 1) * g.sw - 2 * g.pw + g.dw * (g.kw - 1) + opw + 1;
+    LAMP_CHECK(g.H > 0 && g.W > 0, "transposed convolution output would be empty");
+  }
+  return g;
+}
+
+template <class T> static void launch_fwd(const Tensor* x, const Tensor* w, const Tensor* b, Tensor* y, const ConvGeom& g, hipStream_t st) {
+  const int64_t total = g.N * g.Cout * g.Ho * g.Wo;
+  if (!total) return;
+  hipLaunchKernelGGL((conv_fwd_direct_kernel<T>), dim3(grid_for(total, 256, 16)), dim3(256), 0, st, x->ptr<T>(), w->ptr<T>(),
+                     b ? b->ptr<T>() : (const T*)nullptr, y->ptr<T>(), g);
+  LAMP_LAUNCH_CHECK();
+}
+template <class T> static void launch_dgrad(const Tensor* dy, const Tensor* w, const Tensor* b, Tensor* dx, const ConvGeom& g, hipStream_t st) {
+  const int64_t total = g.N * g.Cin * g.H * g.W;
+  if (!total) return;
+  hipLaunchKernelGGL((conv_dgrad_direct_kernel<T>), dim3(grid_for(total, 256, 16)), dim3(256), 0, st, dy->ptr<T>(), w->ptr<T>(),
+                     b ? b->ptr<T>() : (const T*)nullptr, dx->ptr<T>(), g);
+  LAMP_LAUNCH_CHECK();
+}
+template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  const int64_t blocks = g.Cout * (g.Cin / g.groups);
+  if (!blocks) return;
+  const int khkw = g.kh * g.kw;
+  LAMP_CHECK(khkw <= MAXRS, "kernel window larger than " << MAXRS << " taps is not supported");
+  if (khkw == 1) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
+  else if (khkw <= 9) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
+  else if (khkw <= 25) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 25>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
+  else hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, MAXRS>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
+  LAMP_LAUNCH_CHECK();
+}
+
+// implemented in conv_igemm.hip; return true when they handled the request
+bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
+
+Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* w, const lamp_tensor* bias, const int64_t* stride,
+                     const int64_t* padding, const int64_t* dilation, int nspatial, int transposed, const int64_t* output_padding,
+                     int64_t groups) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(w, "weight");
+  LAMP_CHECK(x->dtype == w->dtype, "convolution: input " << x->describe() << " and weight " << w->describe() << " have different dtypes");
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, transposed, output_padding, groups);
+  const int64_t out_c = transposed ? g.Cin : g.Cout;
+  if (bias) { check_device_tensor(bias, "bias"); LAMP_CHECK(bias->numel() == out_c && bias->dtype == x->dtype, "convolution: bias must have " << out_c << " elements"); }
+  Hold xc(contiguous(x)), wc(contiguous(w));
+  Hold bc(bias ? contiguous(bias) : nullptr);
+  std::vector<int64_t> oshape = {g.N, out_c};
+  if (nspatial == 2) oshape.push_back(transposed ? g.H : g.Ho);
+  oshape.push_back(transposed ? g.W : g.Wo);
+  Hold y(new_tensor(oshape, x->dtype, x->device()));
+  hipStream_t st = current_stream(x->device());
+  if (!transposed) {
+    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
+      LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_fwd<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
+    }
+  } else {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
+  }
+  *out = y.take();
+  LAMP_API_END
+}
+
+int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* w,
+                              const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial, int transposed,
+                              const int64_t* output_padding, int64_t groups, const uint8_t mask[3]) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(w, "weight"); check_device_tensor(grad_out, "grad_out");
+  LAMP_CHECK(x->dtype == w->dtype && grad_out->dtype == x->dtype, "convolution_backward: dtype mismatch");
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, transposed, output_padding, groups);
+  {
+    const int64_t oc = transposed ? g.Cin : g.Cout, oh = transposed ? g.H : g.Ho, ow = transposed ? g.W : g.Wo;
+    LAMP_CHECK(grad_out->ndim == x->ndim && grad_out->sizes[0] == g.N && grad_out->sizes[1] == oc &&
+               grad_out->sizes[grad_out->ndim - 1] == ow && (nspatial == 1 || grad_out->sizes[2] == oh),
+               "convolution_backward: grad_out " << grad_out->describe() << " does not match the forward output shape");
+  }
+  Hold xc(contiguous(x)), wc(contiguous(w)), gc(contiguous(grad_out));
+  hipStream_t st = current_stream(x->device());
+  Hold dx(mask[0] ? new_like(xc.get()) : nullptr);
+  Hold dw(mask[1] ? new_like(wc.get()) : nullptr);
+  Hold db;
+  if (!transposed) {
+    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+      LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
+    }
+    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
+      LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_wgrad<T>(gc.get(), xc.get(), dw.get(), g, st)));
+    }
+  } else {
+    // forward was dgrad(x, w): d/dx is the regular forward conv of grad_out, d/dw swaps the roles of x and grad_out
+    if (dx.get()) { LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_fwd<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st))); }
+    if (dw.get()) { LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_wgrad<T>(xc.get(), gc.get(), dw.get(), g, st))); }
+  }
+  if (mask[2]) {
+    std::vector<int64_t> dims = {0};
+    for (int i = 2; i < grad_out->ndim; i++) dims.push_back(i);
+    db = Hold(reduce_dims(gc.get(), dims.data(), (int)dims.size(), false, 0));
+  }
+  out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  LAMP_API_END
+}
+
+}  // extern "C"

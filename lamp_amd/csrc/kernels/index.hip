@@ -1,0 +1,457 @@
+// Indexing, gathering, scattering, selection and random sampling.
+//
+// Replaces ATen.index_select / index_add / masked_select / repeat_interleave / topk / one_hot /
+// embedding(+_backward) / rand / randn / normal / randint / dropout_ as lamp calls them
+// (reference: lamp-core/src/main/scala/lamp/autograd/ops.scala:179-197 (IndexSelect), 1079-1100
+// (Dropout), 2141-2170 (Embedding); lamp-data/.../BatchStream.scala:548-549;
+// lamp-umap/.../umap.scala:211-227; lamp-knn/.../package.scala:55).
+// Index tensors are int64 and every index-valued result is bit-exact.
+// RNG is Philox4x32-10 keyed by (seed, per-call offset); bit compatibility with libtorch's
+// streams is not required by any reference test.
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+// ---- atomics -------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void atomic_add_t(T* p, T v) { atomicAdd(p, v); }
+template <> __device__ __forceinline__ void atomic_add_t<int64_t>(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+template <> __device__ __forceinline__ void atomic_add_t<uint8_t>(uint8_t* p, uint8_t v) {
+  unsigned int* w = (unsigned int*)((uintptr_t)p & ~(uintptr_t)3);
+  const int sh = ((uintptr_t)p & 3) * 8;
+  unsigned int old = *w, assumed;
+  do {
+    assumed = old;
+    unsigned int b = ((assumed >> sh) + v) & 0xff;
+    old = atomicCAS(w, assumed, (assumed & ~(0xffu << sh)) | (b << sh));
+  } while (old != assumed);
+}
+template <> __device__ __forceinline__ void atomic_add_t<bf16_t>(bf16_t* p, bf16_t v) {
+  unsigned int* w = (unsigned int*)((uintptr_t)p & ~(uintptr_t)3);
+  const int sh = ((uintptr_t)p & 2) * 8;
+  unsigned int old = *w, assumed;
+  do {
+    assumed = old;
+    bf16_t cur; cur.bits = (uint16_t)(assumed >> sh);
+    bf16_t nw((float)cur + (float)v);
+    old = atomicCAS(w, assumed, (assumed & ~(0xffffu << sh)) | ((unsigned int)nw.bits << sh));
+  } while (old != assumed);
+}
+
+// a viewed as [outer, D, inner]
+template <class T>
+__global__ void index_select_kernel(const T* __restrict__ a, const int64_t* __restrict__ index, T* __restrict__ out, int64_t outer,
+                                    int64_t D, int64_t inner, int64_t J) {
+  const int64_t total = outer * J * inner;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % inner, j = (e / inner) % J, o = e / (inner * J);
+    int64_t k = index[j];
+    if (k < 0) k += D;
+    out[e] = (k >= 0 && k < D) ? a[(o * D + k) * inner + i] : T{};
+  }
+}
+template <class T>
+__global__ void index_add_kernel(T* __restrict__ self, const int64_t* __restrict__ index, const T* __restrict__ src, int64_t outer,
+                                 int64_t D, int64_t inner, int64_t J) {
+  const int64_t total = outer * J * inner;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % inner, j = (e / inner) % J, o = e / (inner * J);
+    int64_t k = index[j];
+    if (k < 0) k += D;
+    if (k >= 0 && k < D) atomic_add_t<T>(self + (o * D + k) * inner + i, src[e]);
+  }
+}
+template <class T>
+__global__ void repeat_interleave_kernel(const T* __restrict__ a, T* __restrict__ out, int64_t outer, int64_t D, int64_t inner, int64_t rep) {
+  const int64_t total = outer * D * rep * inner;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % inner, jr = (e / inner) % (D * rep), o = e / (inner * D * rep);
+    out[e] = a[(o * D + jr / rep) * inner + i];
+  }
+}
+template <class T>
+__global__ void one_hot_kernel(const int64_t* __restrict__ a, T* __restrict__ out, int64_t n, int64_t C) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * C; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = (T)((e % C) == a[e / C]);
+}
+
+// ---- masked_select: order-preserving stream compaction -------------------------------------------
+constexpr int MS_ITEMS = 16, MS_BLOCK = 256, MS_TILE = MS_ITEMS * MS_BLOCK;
+__global__ __launch_bounds__(MS_BLOCK) void ms_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int64_t* __restrict__ counts) {
+  __shared__ int64_t sm[4];
+  const int64_t base = (int64_t)blockIdx.x * MS_TILE + threadIdx.x * MS_ITEMS;
+  int64_t c = 0;
+  for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) c++;
+  c = block_sum(c, sm);
+  if (threadIdx.x == 0) counts[blockIdx.x] = c;
+}
+__global__ void ms_scan_kernel(int64_t* counts, int64_t nblocks, int64_t* total) {
+  // single thread exclusive scan - nblocks is n / 4096, at most a few thousand
+  int64_t run = 0;
+  for (int64_t i = 0; i < nblocks; i++) { int64_t c = counts[i]; counts[i] = run; run += c; }
+  *total = run;
+}
+template <class T>
+__global__ __launch_bounds__(MS_BLOCK) void ms_scatter_kernel(const T* __restrict__ a, const uint8_t* __restrict__ mask, int64_t n,
+                                                              const int64_t* __restrict__ offsets, T* __restrict__ out) {
+  __shared__ int sm[MS_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * MS_TILE + threadIdx.x * MS_ITEMS;
+  int c = 0;
+  for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) c++;
+  sm[threadIdx.x] = c;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 256 per-thread counts
+  for (int off = 1; off < MS_BLOCK; off <<= 1) {
+    int v = threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t pos = offsets[blockIdx.x] + sm[threadIdx.x] - c;
+  for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) out[pos++] = a[base + k];
+}
+
+// ---- top-k along the last dim: k rounds of lexicographic (value, index) arg-min/max ---------------
+template <class T>
+__global__ __launch_bounds__(256) void topk_kernel(const T* __restrict__ a, T* __restrict__ vals, int64_t* __restrict__ idxs, int64_t D,
+                                                   int64_t k, int largest) {
+  using A = acc_t<T>;
+  __shared__ A sv[4];
+  __shared__ int64_t si[4];
+  __shared__ A last_v;
+  __shared__ int64_t last_i;
+  const T* row = a + (int64_t)blockIdx.x * D;
+  if (threadIdx.x == 0) { last_v = 0; last_i = -1; }
+  __syncthreads();
+  for (int64_t r = 0; r < k; r++) {
+    const A lv = last_v;
+    const int64_t li = last_i;
+    // best candidate strictly after (lv, li) in the ordering
+    bool has = false;
+    A bv = 0;
+    int64_t bi = -1;
+    for (int64_t d = threadIdx.x; d < D; d += blockDim.x) {
+      A v = load_as<A>(row[d]);
+      if (largest) v = -v;
+      const bool after = (li < 0) || (v > lv) || (v == lv && d > li);
+      if (!after) continue;
+      if (!has || v < bv || (v == bv && d < bi)) { has = true; bv = v; bi = d; }
+    }
+    // wave + block reduction on (bv, bi)
+    for (int off = 32; off > 0; off >>= 1) {
+      const A ov = __shfl_xor(bv, off, 64);
+      const int64_t oi = __shfl_xor(bi, off, 64);
+      const int oh = __shfl_xor((int)has, off, 64);
+      if (oh && (!has || ov < bv || (ov == bv && oi < bi))) { has = true; bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sv[wid] = bv; si[wid] = has ? bi : -1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      A fv = 0; int64_t fi = -1;
+      for (int w = 0; w < (int)(blockDim.x >> 6); w++)
+        if (si[w] >= 0 && (fi < 0 || sv[w] < fv || (sv[w] == fv && si[w] < fi))) { fv = sv[w]; fi = si[w]; }
+      last_v = fv; last_i = fi;
+      vals[(int64_t)blockIdx.x * k + r] = store_as<T>(largest ? -fv : fv);
+      idxs[(int64_t)blockIdx.x * k + r] = fi;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------------------
+struct Philox {
+  uint32_t key[2];
+  uint32_t ctr[4];
+  __device__ Philox(uint64_t seed, uint64_t subsequence, uint64_t offset) {
+    key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32);
+    ctr[0] = (uint32_t)offset; ctr[1] = (uint32_t)(offset >> 32);
+    ctr[2] = (uint32_t)subsequence; ctr[3] = (uint32_t)(subsequence >> 32);
+  }
+  __device__ uint4 next() {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+      c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    if (++ctr[0] == 0) ++ctr[1];
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // 53-bit uniform in [0,1)
+  return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+// mode 0 uniform [0,1), 1 normal(mean,std), 2 randint [low, high), 3 bernoulli keep-mask scaled by 1/(1-p) multiplied into out
+template <class T, int MODE>
+__global__ void rng_kernel(T* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, double p0, double p1) {
+  using A = acc_t<T>;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  Philox ph(seed, (uint64_t)tid, offset);
+  for (int64_t i = tid * 2; i < n; i += (int64_t)gridDim.x * blockDim.x * 2) {
+    const uint4 r = ph.next();
+    double a = u01(r.x, r.y), b = u01(r.z, r.w);
+    double v0, v1;
+    if (MODE == 1) {
+      const double rad = sqrt(-2.0 * log(1.0 - a)), ang = 6.283185307179586476925 * b;
+      v0 = p0 + p1 * rad * cos(ang); v1 = p0 + p1 * rad * sin(ang);
+    } else if (MODE == 2) {
+      v0 = floor(p0 + a * (p1 - p0)); v1 = floor(p0 + b * (p1 - p0));
+    } else if (MODE == 3) {
+      v0 = (a >= p0) ? 1.0 / (1.0 - p0) : 0.0; v1 = (b >= p0) ? 1.0 / (1.0 - p0) : 0.0;
+    } else { v0 = a; v1 = b; }
+    if (MODE == 3) {
+      out[i] = store_as<T>((A)(load_as<A>(out[i]) * (A)v0));
+      if (i + 1 < n) out[i + 1] = store_as<T>((A)(load_as<A>(out[i + 1]) * (A)v1));
+    } else {
+      out[i] = store_as<T>((A)v0);
+      if (i + 1 < n) out[i + 1] = store_as<T>((A)v1);
+    }
+  }
+}
+
+static void split3(const Tensor* a, int64_t dim, int64_t& outer, int64_t& D, int64_t& inner) {
+  const int64_t d = wrap_dim(dim, a->ndim);
+  outer = inner = 1;
+  D = a->ndim ? a->sizes[d] : 1;
+  for (int i = 0; i < d; i++) outer *= a->sizes[i];
+  for (int i = (int)d + 1; i < a->ndim; i++) inner *= a->sizes[i];
+}
+static void check_index(const Tensor* index) {
+  check_device_tensor(index, "index");
+  LAMP_CHECK(index->dtype == kI64, "index must be int64, got " << index->describe());
+  LAMP_CHECK(index->ndim <= 1, "index must be a vector");
+}
+
+template <int MODE> static Tensor* rng_new(const int64_t* sizes, int ndim, int dtype, int device, double p0, double p1) {
+  LAMP_CHECK(device >= 0, "random tensors are generated on the GPU; host generation is not supported");
+  Hold t(new_tensor(sizes, ndim, dtype, device));
+  const int64_t n = t->numel();
+  if (n) {
+    const int grid = grid_for((n + 1) / 2, 256);
+    const uint64_t off = next_philox_offset((uint64_t)((n + 1) / 2 / ((int64_t)grid * 256) + 2));
+    LAMP_DISPATCH_ALL(dtype, T, hipLaunchKernelGGL((rng_kernel<T, MODE>), dim3(grid), dim3(256), 0, current_stream(device), t->ptr<T>(), n,
+                                                   philox_seed(), off, p0, p1));
+    LAMP_LAUNCH_CHECK();
+  }
+  return t.take();
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_index_select(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_index(index);
+  Hold ac(contiguous(a)), ic(contiguous(index));
+  int64_t outer, D, inner;
+  split3(a, dim, outer, D, inner);
+  const int64_t J = index->numel();
+  std::vector<int64_t> oshape = a->shape();
+  if (a->ndim) oshape[wrap_dim(dim, a->ndim)] = J;
+  Hold r(new_tensor(oshape, a->dtype, a->device()));
+  const int64_t total = outer * J * inner;
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((index_select_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                      current_stream(a->device()), ac->ptr<T>(), ic->ptr<int64_t>(), r->ptr<T>(), outer, D, inner, J));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_index_add_(lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self"); check_index(index); check_device_tensor(source, "source");
+  LAMP_CHECK(self->is_contiguous(), "index_add_ needs a contiguous destination");
+  LAMP_CHECK(self->dtype == source->dtype, "index_add: dtype mismatch");
+  int64_t outer, D, inner;
+  split3(self, dim, outer, D, inner);
+  const int64_t J = index->numel();
+  std::vector<int64_t> sshape = self->shape();
+  if (self->ndim) sshape[wrap_dim(dim, self->ndim)] = J;
+  LAMP_CHECK(source->shape() == sshape, "index_add: source " << source->describe() << " has the wrong shape");
+  Hold sc(contiguous(source)), ic(contiguous(index));
+  const int64_t total = outer * J * inner;
+  if (total) {
+    LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((index_add_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                         current_stream(self->device()), self->ptr<T>(), ic->ptr<int64_t>(), sc->ptr<T>(), outer, D, inner, J));
+    LAMP_LAUNCH_CHECK();
+  }
+  LAMP_API_END
+}
+int lamp_index_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self");
+  Hold r(new_like(self));
+  copy_into(r.get(), self);
+  LAMP_CHECK(lamp_index_add_(r.get(), dim, index, source) == 0, lamp_last_error());
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_masked_select(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(mask, "mask");
+  LAMP_CHECK(mask->dtype == kBool || mask->dtype == kU8, "masked_select expects a bool mask");
+  auto shape = broadcast_shapes(a->shape(), mask->shape());
+  Hold ae(new_tensor(shape, a->dtype, a->device())), me(new_tensor(shape, mask->dtype, a->device()));
+  copy_into(ae.get(), a);
+  copy_into(me.get(), mask);
+  const int64_t n = ae->numel();
+  const int64_t nblocks = (n + MS_TILE - 1) / MS_TILE;
+  hipStream_t st = current_stream(a->device());
+  int64_t cs[1] = {nblocks + 1};
+  Hold counts(new_tensor(cs, 1, kI64, a->device()));
+  int64_t total = 0;
+  if (n) {
+    hipLaunchKernelGGL(ms_count_kernel, dim3((unsigned)nblocks), dim3(MS_BLOCK), 0, st, me->ptr<uint8_t>(), n, counts->ptr<int64_t>());
+    hipLaunchKernelGGL(ms_scan_kernel, dim3(1), dim3(1), 0, st, counts->ptr<int64_t>(), nblocks, counts->ptr<int64_t>() + nblocks);
+    LAMP_LAUNCH_CHECK();
+    HIP_CHECK(hipMemcpyAsync(&total, counts->ptr<int64_t>() + nblocks, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  int64_t os[1] = {total};
+  Hold r(new_tensor(os, 1, a->dtype, a->device()));
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((ms_scatter_kernel<T>), dim3((unsigned)nblocks), dim3(MS_BLOCK), 0, st, ae->ptr<T>(),
+                                                      me->ptr<uint8_t>(), n, counts->ptr<int64_t>(), r->ptr<T>()));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_repeat_interleave(lamp_tensor** out, const lamp_tensor* a, int64_t repeats, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(repeats >= 0, "repeats must be non-negative");
+  Hold ac(contiguous(a));
+  int64_t outer, D, inner;
+  split3(a, dim, outer, D, inner);
+  std::vector<int64_t> oshape = a->shape();
+  if (a->ndim) oshape[wrap_dim(dim, a->ndim)] = D * repeats; else oshape = {repeats};
+  Hold r(new_tensor(oshape, a->dtype, a->device()));
+  const int64_t total = r->numel();
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((repeat_interleave_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                      current_stream(a->device()), ac->ptr<T>(), r->ptr<T>(), outer, D, inner, repeats));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted) {
+  LAMP_API_BEGIN
+  (void)sorted;  // results always come back sorted (a legal answer for sorted=false)
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim >= 1, "topk of a 0-dim tensor");
+  const int64_t d = wrap_dim(dim, a->ndim);
+  LAMP_CHECK(k >= 0 && k <= a->sizes[d], "topk: k = " << k << " out of range for dimension of size " << a->sizes[d]);
+  // move `dim` last
+  lamp_tensor* tr = nullptr;
+  LAMP_CHECK(lamp_transpose(&tr, a, d, a->ndim - 1) == 0, lamp_last_error());
+  Hold trh(tr);
+  Hold ac(contiguous(tr));
+  const int64_t D = ac->sizes[ac->ndim - 1];
+  const int64_t rows = D ? ac->numel() / D : 0;
+  std::vector<int64_t> oshape = ac->shape();
+  oshape.back() = k;
+  Hold v(new_tensor(oshape, a->dtype, a->device())), ix(new_tensor(oshape, kI64, a->device()));
+  if (rows && k) {
+    LAMP_DISPATCH_FLOAT(a->dtype, T, hipLaunchKernelGGL((topk_kernel<T>), dim3((unsigned)rows), dim3(256), 0, current_stream(a->device()),
+                                                        ac->ptr<T>(), v->ptr<T>(), ix->ptr<int64_t>(), D, k, largest));
+    LAMP_LAUNCH_CHECK();
+  }
+  lamp_tensor *vo = nullptr, *io = nullptr;
+  LAMP_CHECK(lamp_transpose(&vo, v.get(), d, a->ndim - 1) == 0, lamp_last_error());
+  Hold vh(vo);
+  LAMP_CHECK(lamp_transpose(&io, ix.get(), d, a->ndim - 1) == 0, lamp_last_error());
+  *values = vh.take();
+  *indices = io;
+  LAMP_API_END
+}
+int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->dtype == kI64 && num_classes > 0, "one_hot expects int64 input and a positive class count");
+  Hold ac(contiguous(a));
+  std::vector<int64_t> oshape = a->shape();
+  oshape.push_back(num_classes);
+  Hold r(new_tensor(oshape, kI64, a->device()));
+  const int64_t n = a->numel();
+  if (n) {
+    hipLaunchKernelGGL((one_hot_kernel<int64_t>), dim3(grid_for(n * num_classes, 256)), dim3(256), 0, current_stream(a->device()),
+                       ac->ptr<int64_t>(), r->ptr<int64_t>(), n, num_classes);
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tensor* indices) {
+  LAMP_API_BEGIN
+  check_device_tensor(weight, "weight"); check_device_tensor(indices, "indices");
+  LAMP_CHECK(weight->ndim == 2 && indices->dtype == kI64, "embedding expects a 2-D weight and int64 indices");
+  Hold ic(contiguous(indices));
+  int64_t flat[1] = {ic->numel()};
+  Hold iv(new_view(ic.get(), flat, (int64_t[]){1}, 1, ic->offset));
+  lamp_tensor* sel = nullptr;
+  LAMP_CHECK(lamp_index_select(&sel, weight, 0, iv.get()) == 0, lamp_last_error());
+  Hold sh(sel);
+  std::vector<int64_t> oshape = indices->shape();
+  oshape.push_back(weight->sizes[1]);
+  return lamp_view(out, sel, oshape.data(), (int)oshape.size());
+  LAMP_API_END
+}
+int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights) {
+  LAMP_API_BEGIN
+  check_device_tensor(grad, "grad"); check_device_tensor(indices, "indices");
+  const int64_t E = grad->sizes[grad->ndim - 1];
+  int64_t ws[2] = {num_weights, E};
+  Hold r(new_tensor(ws, 2, grad->dtype, grad->device()));
+  fill_zero(r.get());
+  Hold gc(contiguous(grad)), ic(contiguous(indices));
+  int64_t gs[2] = {ic->numel(), E}, gst[2] = {E, 1}, is_[1] = {ic->numel()}, ist[1] = {1};
+  Hold g2(new_view(gc.get(), gs, gst, 2, gc->offset)), i1(new_view(ic.get(), is_, ist, 1, ic->offset));
+  LAMP_CHECK(lamp_index_add_(r.get(), 0, i1.get(), g2.get()) == 0, lamp_last_error());
+  *out = r.take();
+  LAMP_API_END
+}
+
+int lamp_rand(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN *out = rng_new<0>(sizes, ndim, dtype, device, 0, 1); LAMP_API_END
+}
+int lamp_randn(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN *out = rng_new<1>(sizes, ndim, dtype, device, 0, 1); LAMP_API_END
+}
+int lamp_normal(lamp_tensor** out, double mean, double std, const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN *out = rng_new<1>(sizes, ndim, dtype, device, mean, std); LAMP_API_END
+}
+int lamp_randint(lamp_tensor** out, int64_t low, int64_t high, const int64_t* sizes, int ndim, int dtype, int device) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(high > low, "randint: high must be greater than low");
+  *out = rng_new<2>(sizes, ndim, dtype, device, (double)low, (double)high);
+  LAMP_API_END
+}
+int lamp_dropout_(lamp_tensor* self, double p, int training) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self");
+  LAMP_CHECK(p >= 0 && p <= 1, "dropout probability must be in [0, 1]");
+  if (!training || p == 0.0) return 0;
+  LAMP_CHECK(self->is_contiguous(), "dropout_ needs a contiguous tensor");
+  const int64_t n = self->numel();
+  if (p == 1.0) { fill_zero(self); return 0; }
+  if (n) {
+    const int grid = grid_for((n + 1) / 2, 256);
+    const uint64_t off = next_philox_offset((uint64_t)((n + 1) / 2 / ((int64_t)grid * 256) + 2));
+    LAMP_DISPATCH_FLOAT(self->dtype, T, hipLaunchKernelGGL((rng_kernel<T, 3>), dim3(grid), dim3(256), 0, current_stream(self->device()),
+                                                           self->ptr<T>(), n, philox_seed(), off, p, 0.0));
+    LAMP_LAUNCH_CHECK();
+  }
+  LAMP_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,513 @@
+// Batch norm and layer norm, forward and backward (HBM-bound).
+//
+// Replaces ATen.native_batch_norm / native_batch_norm_backward / native_layer_norm /
+// native_layer_norm_backward as lamp calls them (reference:
+// lamp-core/src/main/scala/lamp/autograd/ops.scala:1846-1955 (BatchNorm, input flattened to
+// [N, F]), 2037-2140 (BatchNorm2D, [N, C, *]), 1956-2032 (LayerNormOp)).
+//
+// Semantics kept from ATen: biased variance for normalisation, running_var updated with the
+// UNBIASED estimate, running stats updated in place with `momentum`, save_invstd = 1/sqrt(var+eps);
+// statistics in f32 for bf16/f32 inputs (f64 for f64) using Welford/Chan merging so that
+// variance never suffers catastrophic cancellation.
+//
+// Layout: x is [N, C, HW] contiguous (HW = 1 for the 2-D case). Pass 1 reduces each channel with
+// one or more workgroups (64-lane shuffle merge + LDS), pass 2 is a coalesced normalise.
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+template <class A> struct Welford {
+  A n, mean, m2;
+};
+template <class A> __device__ __forceinline__ void wf_add(Welford<A>& w, A x) {
+  w.n += A(1);
+  A d = x - w.mean;
+  w.mean += d / w.n;
+  w.m2 += d * (x - w.mean);
+}
+template <class A> __device__ __forceinline__ Welford<A> wf_merge(const Welford<A>& a, const Welford<A>& b) {
+  Welford<A> r;
+  r.n = a.n + b.n;
+  if (r.n == A(0)) { r.mean = 0; r.m2 = 0; return r; }
+  A d = b.mean - a.mean;
+  A f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+template <class A> __device__ __forceinline__ Welford<A> wf_wave(Welford<A> w) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Welford<A> o;
+    o.n = __shfl_xor(w.n, off, 64);
+    o.mean = __shfl_xor(w.mean, off, 64);
+    o.m2 = __shfl_xor(w.m2, off, 64);
+    w = wf_merge(w, o);
+  }
+  return w;
+}
+
+// ---- batch norm statistics: partial[split][c] = Welford over a slice of (n, hw) -----------------
+// big-HW variant: block (c, split); threads walk hw contiguously
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, acc_t<T>* __restrict__ partial, int64_t N, int64_t C,
+                                                       int64_t HW, int nsplit) {
+  using A = acc_t<T>;
+  __shared__ A sm[3][4];
+  const int64_t c = blockIdx.x;
+  const int split = blockIdx.y;
+  Welford<A> w{0, 0, 0};
+  // split over n
+  for (int64_t n = split; n < N; n += nsplit) {
+    const T* p = x + (n * C + c) * HW;
+    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) wf_add(w, load_as<A>(p[i]));
+  }
+  w = wf_wave(w);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wid] = w.n; sm[1][wid] = w.mean; sm[2][wid] = w.m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Welford<A> r{sm[0][0], sm[1][0], sm[2][0]};
+    for (int k = 1; k < (int)(blockDim.x >> 6); k++) r = wf_merge(r, Welford<A>{sm[0][k], sm[1][k], sm[2][k]});
+    A* o = partial + ((int64_t)split * C + c) * 3;
+    o[0] = r.n; o[1] = r.mean; o[2] = r.m2;
+  }
+}
+// small-HW variant (HW < 64, typically 1): thread per channel, coalesced along c when HW == 1
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_col_kernel(const T* __restrict__ x, acc_t<T>* __restrict__ partial, int64_t N,
+                                                           int64_t C, int64_t HW, int nsplit) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int split = blockIdx.y;
+  Welford<A> w{0, 0, 0};
+  for (int64_t n = split; n < N; n += nsplit) {
+    const T* p = x + (n * C + c) * HW;
+    for (int64_t i = 0; i < HW; i++) wf_add(w, load_as<A>(p[i]));
+  }
+  A* o = partial + ((int64_t)split * C + c) * 3;
+  o[0] = w.n; o[1] = w.mean; o[2] = w.m2;
+}
+// finalize: merge splits, write save_mean / save_invstd, update running stats
+template <class T>
+__global__ void bn_finalize_kernel(const acc_t<T>* __restrict__ partial, int64_t C, int nsplit, T* __restrict__ save_mean,
+                                   T* __restrict__ save_invstd, T* running_mean, T* running_var, double momentum, double eps) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  Welford<A> r{0, 0, 0};
+  for (int s = 0; s < nsplit; s++) {
+    const A* p = partial + ((int64_t)s * C + c) * 3;
+    r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
+  }
+  const A var_biased = r.m2 / r.n;
+  const A invstd = A(1) / (A)sqrt((double)(var_biased + (A)eps));
+  save_mean[c] = store_as<T>(r.mean);
+  save_invstd[c] = store_as<T>(invstd);
+  if (running_mean) running_mean[c] = store_as<T>((A)((A)momentum * r.mean + (A)(1 - momentum) * load_as<A>(running_mean[c])));
+  if (running_var) {
+    const A unbiased = r.m2 / (r.n - A(1));
+    running_var[c] = store_as<T>((A)((A)momentum * unbiased + (A)(1 - momentum) * load_as<A>(running_var[c])));
+  }
+}
+// eval mode: mean/invstd from the running statistics
+template <class T>
+__global__ void bn_eval_stats_kernel(const T* running_mean, const T* running_var, T* mean, T* invstd, int64_t C, double eps) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean ? running_mean[c] : store_as<T>(A(0));
+  const A v = running_var ? load_as<A>(running_var[c]) : A(1);
+  invstd[c] = store_as<T>((A)(A(1) / (A)sqrt((double)(v + (A)eps))));
+}
+// y = (x - mean) * invstd * w + b
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ mean,
+                                                       const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
+                                                       int64_t total, int64_t C, int64_t HW) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = (i / HW) % C;
+    const A scale = load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1));
+    const A shift = b ? load_as<A>(b[c]) : A(0);
+    y[i] = store_as<T>((A)((load_as<A>(x[i]) - load_as<A>(mean[c])) * scale + shift));
+  }
+}
+
+// ---- batch norm backward -------------------------------------------------------------------------
+// partial[split][c] = (sum dy, sum dy * (x - mean))
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                            acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit) {
+  using A = acc_t<T>;
+  __shared__ A sm[2][4];
+  const int64_t c = blockIdx.x;
+  const int split = blockIdx.y;
+  const A mu = load_as<A>(mean[c]);
+  A s1 = 0, s2 = 0;
+  for (int64_t n = split; n < N; n += nsplit) {
+    const int64_t base = (n * C + c) * HW;
+    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) {
+      const A g = load_as<A>(dy[base + i]);
+      s1 += g;
+      s2 += g * (load_as<A>(x[base + i]) - mu);
+    }
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A a = 0, b = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) { a += sm[0][k]; b += sm[1][k]; }
+    partial[((int64_t)split * C + c) * 2] = a;
+    partial[((int64_t)split * C + c) * 2 + 1] = b;
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_col_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                                acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int split = blockIdx.y;
+  const A mu = load_as<A>(mean[c]);
+  A s1 = 0, s2 = 0;
+  for (int64_t n = split; n < N; n += nsplit) {
+    const int64_t base = (n * C + c) * HW;
+    for (int64_t i = 0; i < HW; i++) {
+      const A g = load_as<A>(dy[base + i]);
+      s1 += g;
+      s2 += g * (load_as<A>(x[base + i]) - mu);
+    }
+  }
+  partial[((int64_t)split * C + c) * 2] = s1;
+  partial[((int64_t)split * C + c) * 2 + 1] = s2;
+}
+// sums[c] = merged partials; also writes dweight / dbias if requested
+template <class T>
+__global__ void bn_bwd_finalize_kernel(const acc_t<T>* __restrict__ partial, acc_t<T>* __restrict__ sums, int64_t C, int nsplit,
+                                       const T* __restrict__ invstd, T* dweight, T* dbias) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  A a = 0, b = 0;
+  for (int s = 0; s < nsplit; s++) { a += partial[((int64_t)s * C + c) * 2]; b += partial[((int64_t)s * C + c) * 2 + 1]; }
+  sums[c * 2] = a; sums[c * 2 + 1] = b;
+  if (dweight) dweight[c] = store_as<T>((A)(b * load_as<A>(invstd[c])));
+  if (dbias) dbias[c] = store_as<T>(a);
+}
+// training: dx = (dy - sum_dy/M - (x-mean)*invstd^2*sum_dy_xmu/M) * invstd * w ; eval: dx = dy * invstd * w
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                           const T* __restrict__ invstd, const T* __restrict__ w,
+                                                           const acc_t<T>* __restrict__ sums, T* __restrict__ dx, int64_t total, int64_t C,
+                                                           int64_t HW, double inv_m, int training) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = (i / HW) % C;
+    const A is = load_as<A>(invstd[c]);
+    const A wc = w ? load_as<A>(w[c]) : A(1);
+    const A g = load_as<A>(dy[i]);
+    A r;
+    if (training) {
+      const A k = sums[c * 2 + 1] * is * is * (A)inv_m;
+      const A gm = sums[c * 2] * (A)inv_m;
+      r = (g - gm - (load_as<A>(x[i]) - load_as<A>(mean[c])) * k) * is * wc;
+    } else {
+      r = g * is * wc;
+    }
+    dx[i] = store_as<T>(r);
+  }
+}
+
+// ---- layer norm: rows [M, D] ---------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ mean_out,
+                                                     T* __restrict__ rstd_out, const T* __restrict__ w, const T* __restrict__ b, int64_t M,
+                                                     int64_t D, double eps) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= M) return;
+  const T* xp = x + row * D;
+  Welford<A> wf{0, 0, 0};
+  for (int64_t d = lane; d < D; d += 64) wf_add(wf, load_as<A>(xp[d]));
+  wf = wf_wave(wf);
+  const A mu = wf.mean;
+  const A rstd = A(1) / (A)sqrt((double)(wf.m2 / wf.n + (A)eps));
+  if (lane == 0) { mean_out[row] = store_as<T>(mu); rstd_out[row] = store_as<T>(rstd); }
+  T* yp = y + row * D;
+  for (int64_t d = lane; d < D; d += 64) {
+    A v = (load_as<A>(xp[d]) - mu) * rstd;
+    if (w) v *= load_as<A>(w[d]);
+    if (b) v += load_as<A>(b[d]);
+    yp[d] = store_as<T>(v);
+  }
+}
+// dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat))
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                        const T* __restrict__ rstd, const T* __restrict__ w, T* __restrict__ dx, int64_t M,
+                                                        int64_t D) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= M) return;
+  const A mu = load_as<A>(mean[row]), rs = load_as<A>(rstd[row]);
+  const T* xp = x + row * D;
+  const T* gp = dy + row * D;
+  A s1 = 0, s2 = 0;
+  for (int64_t d = lane; d < D; d += 64) {
+    const A gw = load_as<A>(gp[d]) * (w ? load_as<A>(w[d]) : A(1));
+    const A xh = (load_as<A>(xp[d]) - mu) * rs;
+    s1 += gw;
+    s2 += gw * xh;
+  }
+  s1 = wave_sum(s1) / (A)D;
+  s2 = wave_sum(s2) / (A)D;
+  T* op = dx + row * D;
+  for (int64_t d = lane; d < D; d += 64) {
+    const A gw = load_as<A>(gp[d]) * (w ? load_as<A>(w[d]) : A(1));
+    const A xh = (load_as<A>(xp[d]) - mu) * rs;
+    op[d] = store_as<T>((A)(rs * (gw - s1 - xh * s2)));
+  }
+}
+// column sums over rows: dweight[d] = sum_rows dy * xhat ; dbias[d] = sum_rows dy. partial [nsplit][D][2]
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_dwdb_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                          const T* __restrict__ rstd, acc_t<T>* __restrict__ partial, int64_t M, int64_t D,
+                                                          int nsplit) {
+  using A = acc_t<T>;
+  const int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const int split = blockIdx.y;
+  A sw = 0, sb = 0;
+  for (int64_t r = split; r < M; r += nsplit) {
+    const A g = load_as<A>(dy[r * D + d]);
+    sw += g * (load_as<A>(x[r * D + d]) - load_as<A>(mean[r])) * load_as<A>(rstd[r]);
+    sb += g;
+  }
+  partial[((int64_t)split * D + d) * 2] = sw;
+  partial[((int64_t)split * D + d) * 2 + 1] = sb;
+}
+template <class T>
+__global__ void ln_bwd_finalize_kernel(const acc_t<T>* __restrict__ partial, T* dweight, T* dbias, int64_t D, int nsplit) {
+  using A = acc_t<T>;
+  const int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  A a = 0, b = 0;
+  for (int s = 0; s < nsplit; s++) { a += partial[((int64_t)s * D + d) * 2]; b += partial[((int64_t)s * D + d) * 2 + 1]; }
+  if (dweight) dweight[d] = store_as<T>(a);
+  if (dbias) dbias[d] = store_as<T>(b);
+}
+
+template <class A> constexpr int acc_dtype() { return std::is_same<A, double>::value ? kF64 : kF32; }
+
+struct BnGeom { int64_t N, C, HW; };
+static BnGeom bn_geom(const Tensor* x) {
+  LAMP_CHECK(x->ndim >= 2, "batch norm expects at least 2 dims, got " << x->describe());
+  BnGeom g{x->sizes[0], x->sizes[1], 1};
+  for (int i = 2; i < x->ndim; i++) g.HW *= x->sizes[i];
+  return g;
+}
+static int pick_split(int64_t outputs_blocks, int64_t N) {
+  int64_t target = (int64_t)num_cus() * 4;
+  int64_t s = target / std::max<int64_t>(outputs_blocks, 1);
+  s = std::min<int64_t>(s, N);
+  s = std::min<int64_t>(s, 64);
+  return (int)std::max<int64_t>(s, 1);
+}
+static void check_cvec(const Tensor* t, int64_t C, int dtype, const char* what) {
+  if (!t) return;
+  check_device_tensor(t, what);
+  LAMP_CHECK(t->numel() == C && t->dtype == dtype && t->is_contiguous(), what << " must be a contiguous [" << C << "] tensor of the input dtype, got " << t->describe());
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input");
+  BnGeom g = bn_geom(x);
+  check_cvec(weight, g.C, x->dtype, "weight"); check_cvec(bias, g.C, x->dtype, "bias");
+  check_cvec(running_mean, g.C, x->dtype, "running_mean"); check_cvec(running_var, g.C, x->dtype, "running_var");
+  Hold xc(contiguous(x));
+  Hold y(new_like(xc.get()));
+  int64_t cs[1] = {g.C};
+  Hold mean(new_tensor(cs, 1, x->dtype, x->device())), invstd(new_tensor(cs, 1, x->dtype, x->device()));
+  hipStream_t st = current_stream(x->device());
+  const int64_t total = x->numel();
+  LAMP_DISPATCH_FLOAT(x->dtype, T, {
+    using A = acc_t<T>;
+    if (training) {
+      LAMP_CHECK(g.N * g.HW > 0, "batch norm over an empty batch");
+      const bool col = g.HW < 64;
+      const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
+      const int nsplit = pick_split(blocks, g.N);
+      int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
+      Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+      if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+      else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+      LAMP_LAUNCH_CHECK();
+      hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
+                         mean->ptr<T>(), invstd->ptr<T>(), running_mean ? running_mean->ptr<T>() : (T*)nullptr,
+                         running_var ? running_var->ptr<T>() : (T*)nullptr, momentum, eps);
+      LAMP_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL((bn_eval_stats_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st,
+                         running_mean ? running_mean->ptr<T>() : (const T*)nullptr, running_var ? running_var->ptr<T>() : (const T*)nullptr,
+                         mean->ptr<T>(), invstd->ptr<T>(), g.C, eps);
+      LAMP_LAUNCH_CHECK();
+    }
+    if (total > 0) {
+      hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(),
+                         invstd->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr, total,
+                         g.C, g.HW);
+      LAMP_LAUNCH_CHECK();
+    }
+  });
+  if (!training) {
+    // ATen returns empty save tensors in eval mode; keep handles valid but zero-sized semantics are not needed by lamp
+  }
+  out3[0] = y.take(); out3[1] = mean.take(); out3[2] = invstd.take();
+  LAMP_API_END
+}
+
+int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                                    const lamp_tensor* running_mean, const lamp_tensor* running_var, const lamp_tensor* save_mean,
+                                    const lamp_tensor* save_invstd, int training, double eps, const uint8_t mask[3]) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out");
+  LAMP_CHECK(grad_out->shape() == x->shape() && grad_out->dtype == x->dtype, "grad_out " << grad_out->describe() << " does not match input " << x->describe());
+  BnGeom g = bn_geom(x);
+  check_cvec(weight, g.C, x->dtype, "weight");
+  Hold xc(contiguous(x)), gc(contiguous(grad_out));
+  hipStream_t st = current_stream(x->device());
+  int64_t cs[1] = {g.C};
+  Hold mean_h, invstd_h;
+  const Tensor* mean_t = save_mean;
+  const Tensor* invstd_t = save_invstd;
+  if (training) {
+    LAMP_CHECK(save_mean && save_invstd, "training-mode batch norm backward needs save_mean and save_invstd");
+    check_cvec(save_mean, g.C, x->dtype, "save_mean"); check_cvec(save_invstd, g.C, x->dtype, "save_invstd");
+  } else {
+    check_cvec(running_mean, g.C, x->dtype, "running_mean"); check_cvec(running_var, g.C, x->dtype, "running_var");
+    mean_h = Hold(new_tensor(cs, 1, x->dtype, x->device()));
+    invstd_h = Hold(new_tensor(cs, 1, x->dtype, x->device()));
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((bn_eval_stats_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st,
+                                                        running_mean ? running_mean->ptr<T>() : (const T*)nullptr,
+                                                        running_var ? running_var->ptr<T>() : (const T*)nullptr, mean_h->ptr<T>(),
+                                                        invstd_h->ptr<T>(), g.C, eps));
+    LAMP_LAUNCH_CHECK();
+    mean_t = mean_h.get(); invstd_t = invstd_h.get();
+  }
+  Hold dx(mask[0] ? new_like(xc.get()) : nullptr);
+  Hold dw(mask[1] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
+  Hold db(mask[2] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
+  const int64_t total = x->numel();
+  LAMP_DISPATCH_FLOAT(x->dtype, T, {
+    using A = acc_t<T>;
+    const bool col = g.HW < 64;
+    const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
+    const int nsplit = pick_split(blocks, g.N);
+    int64_t ps[1] = {(int64_t)nsplit * g.C * 2};
+    int64_t ss[1] = {g.C * 2};
+    Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device())), sums(new_tensor(ss, 1, acc_dtype<A>(), x->device()));
+    if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+    LAMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
+                       nsplit, invstd_t->ptr<T>(), dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr);
+    LAMP_LAUNCH_CHECK();
+    if (dx.get() && total > 0) {
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(),
+                         invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW,
+                         1.0 / (double)(g.N * g.HW), training);
+      LAMP_LAUNCH_CHECK();
+    }
+  });
+  out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  LAMP_API_END
+}
+
+int lamp_native_layer_norm(lamp_tensor* out3[3], const lamp_tensor* x, const int64_t* normalized_shape, int nnorm,
+                           const lamp_tensor* weight, const lamp_tensor* bias, double eps) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input");
+  LAMP_CHECK(nnorm >= 1 && nnorm <= x->ndim, "bad normalized_shape");
+  int64_t D = 1;
+  for (int i = 0; i < nnorm; i++) {
+    LAMP_CHECK(normalized_shape[i] == x->sizes[x->ndim - nnorm + i], "normalized_shape does not match the trailing input dims");
+    D *= normalized_shape[i];
+  }
+  const int64_t M = D ? x->numel() / D : 0;
+  if (weight) { check_device_tensor(weight, "weight"); LAMP_CHECK(weight->numel() == D && weight->dtype == x->dtype && weight->is_contiguous(), "bad layer norm weight"); }
+  if (bias) { check_device_tensor(bias, "bias"); LAMP_CHECK(bias->numel() == D && bias->dtype == x->dtype && bias->is_contiguous(), "bad layer norm bias"); }
+  Hold xc(contiguous(x));
+  Hold y(new_like(xc.get()));
+  std::vector<int64_t> sshape;
+  for (int i = 0; i < x->ndim; i++) sshape.push_back(i < x->ndim - nnorm ? x->sizes[i] : 1);
+  Hold mean(new_tensor(sshape, x->dtype, x->device())), rstd(new_tensor(sshape, x->dtype, x->device()));
+  if (M > 0) {
+    const int64_t blocks = (M * 64 + 255) / 256;
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, current_stream(x->device()),
+                                                        xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(),
+                                                        weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr,
+                                                        M, D, eps));
+    LAMP_LAUNCH_CHECK();
+  }
+  out3[0] = y.take(); out3[1] = mean.take(); out3[2] = rstd.take();
+  LAMP_API_END
+}
+
+int lamp_native_layer_norm_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const int64_t* normalized_shape,
+                                    int nnorm, const lamp_tensor* mean, const lamp_tensor* rstd, const lamp_tensor* weight,
+                                    const lamp_tensor* bias, const uint8_t mask[3]) {
+  LAMP_API_BEGIN
+  (void)bias;
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out"); check_device_tensor(mean, "mean"); check_device_tensor(rstd, "rstd");
+  LAMP_CHECK(grad_out->shape() == x->shape() && grad_out->dtype == x->dtype, "grad_out does not match input");
+  int64_t D = 1;
+  for (int i = 0; i < nnorm; i++) D *= normalized_shape[i];
+  const int64_t M = D ? x->numel() / D : 0;
+  LAMP_CHECK(mean->numel() == M && rstd->numel() == M, "mean/rstd have the wrong size");
+  Hold xc(contiguous(x)), gc(contiguous(grad_out)), mc(contiguous(mean)), rc(contiguous(rstd));
+  hipStream_t st = current_stream(x->device());
+  Hold dx(mask[0] ? new_like(xc.get()) : nullptr);
+  std::vector<int64_t> wshape(normalized_shape, normalized_shape + nnorm);
+  Hold dw(mask[1] ? new_tensor(wshape, x->dtype, x->device()) : nullptr);
+  Hold db(mask[2] ? new_tensor(wshape, x->dtype, x->device()) : nullptr);
+  LAMP_DISPATCH_FLOAT(x->dtype, T, {
+    using A = acc_t<T>;
+    if (dx.get() && M > 0) {
+      const int64_t blocks = (M * 64 + 255) / 256;
+      hipLaunchKernelGGL((ln_bwd_dx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mc->ptr<T>(), rc->ptr<T>(),
+                         weight ? weight->ptr<T>() : (const T*)nullptr, dx->ptr<T>(), M, D);
+      LAMP_LAUNCH_CHECK();
+    }
+    if (dw.get() || db.get()) {
+      const int64_t blocks = (D + 255) / 256;
+      const int nsplit = pick_split(blocks, std::max<int64_t>(M, 1));
+      int64_t ps[1] = {(int64_t)nsplit * D * 2};
+      Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+      hipLaunchKernelGGL((ln_bwd_dwdb_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mc->ptr<T>(),
+                         rc->ptr<T>(), partial->ptr<A>(), M, D, nsplit);
+      LAMP_LAUNCH_CHECK();
+      hipLaunchKernelGGL((ln_bwd_finalize_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, partial->ptr<A>(),
+                         dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr, D, nsplit);
+      LAMP_LAUNCH_CHECK();
+    }
+  });
+  out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  LAMP_API_END
+}
+
+}  // extern "C"

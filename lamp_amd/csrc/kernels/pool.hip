@@ -1,0 +1,210 @@
+// 2-D pooling, forward and backward.
+//
+// Replaces ATen.avg_pool2d(+_backward) (ceil_mode=false, count_include_pad=true, no divisor
+// override - the only configuration lamp passes) and ATen.max_pool2d_with_indices(+_backward)
+// (reference: lamp-core/src/main/scala/lamp/autograd/ops.scala:1721-1768 MaxPool2D, 1775-1825 AvgPool2D).
+// max-pool indices are int64 flat offsets h*W + w inside each (n, c) plane, first maximum in
+// row-major window order wins, NaN propagates - bit-exact with ATen.
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+struct PoolGeom {
+  int64_t NC, H, W, Ho, Wo;
+  int k, s, p, d;
+  int count_include_pad;
+};
+
+static int64_t pool_out(int64_t in, int k, int s, int p, int d, int ceil_mode) {
+  int64_t num = in + 2 * p - d * (k - 1) - 1 + (ceil_mode ? s - 1 : 0);
+  int64_t o = num / s + 1;
+  if (ceil_mode && (o - 1) * s >= in + p) o--;
+  return o;
+}
+
+template <class T>
+__global__ void avg_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, PoolGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.Ho * g.Wo;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % g.Wo), ho = (int)((e / g.Wo) % g.Ho);
+    const int64_t nc = e / (g.Wo * g.Ho);
+    int hs = ho * g.s - g.p, ws = wo * g.s - g.p;
+    int he = min(hs + g.k, (int)g.H + g.p), we = min(ws + g.k, (int)g.W + g.p);
+    const int pool = (he - hs) * (we - ws);
+    hs = max(hs, 0); ws = max(ws, 0); he = min(he, (int)g.H); we = min(we, (int)g.W);
+    A acc = 0;
+    const T* xp = x + nc * g.H * g.W;
+    for (int h = hs; h < he; h++)
+      for (int w = ws; w < we; w++) acc += load_as<A>(xp[h * g.W + w]);
+    const int div = g.count_include_pad ? pool : (he - hs) * (we - ws);
+    y[e] = store_as<T>((A)(acc / (A)div));
+  }
+}
+template <class T>
+__global__ void avg_pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, PoolGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.H * g.W;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(e % g.W), h = (int)((e / g.W) % g.H);
+    const int64_t nc = e / (g.W * g.H);
+    A acc = 0;
+    // windows [ho*s - p, ho*s - p + k) containing h
+    int ho_lo = (h + g.p - g.k + 1 + g.s - 1) / g.s; if (h + g.p - g.k + 1 < 0) ho_lo = 0;
+    int wo_lo = (w + g.p - g.k + 1 + g.s - 1) / g.s; if (w + g.p - g.k + 1 < 0) wo_lo = 0;
+    const int ho_hi = min((h + g.p) / g.s, (int)g.Ho - 1), wo_hi = min((w + g.p) / g.s, (int)g.Wo - 1);
+    for (int ho = ho_lo; ho <= ho_hi; ho++)
+      for (int wo = wo_lo; wo <= wo_hi; wo++) {
+        int hs = ho * g.s - g.p, ws = wo * g.s - g.p;
+        int he = min(hs + g.k, (int)g.H + g.p), we = min(ws + g.k, (int)g.W + g.p);
+        int div = (he - hs) * (we - ws);
+        if (!g.count_include_pad) { div = (min(he, (int)g.H) - max(hs, 0)) * (min(we, (int)g.W) - max(ws, 0)); }
+        acc += load_as<A>(dy[(nc * g.Ho + ho) * g.Wo + wo]) / (A)div;
+      }
+    dx[e] = store_as<T>(acc);
+  }
+}
+template <class T>
+__global__ void max_pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t* __restrict__ idx, PoolGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.Ho * g.Wo;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % g.Wo), ho = (int)((e / g.Wo) % g.Ho);
+    const int64_t nc = e / (g.Wo * g.Ho);
+    int hs = ho * g.s - g.p, ws = wo * g.s - g.p;
+    const int he = min(hs + (g.k - 1) * g.d + 1, (int)g.H), we = min(ws + (g.k - 1) * g.d + 1, (int)g.W);
+    while (hs < 0) hs += g.d;
+    while (ws < 0) ws += g.d;
+    const T* xp = x + nc * g.H * g.W;
+    A best = -INFINITY;
+    int64_t bi = (int64_t)hs * g.W + ws;
+    for (int h = hs; h < he; h += g.d)
+      for (int w = ws; w < we; w += g.d) {
+        const A v = load_as<A>(xp[h * g.W + w]);
+        if (v > best || v != v) { best = v; bi = (int64_t)h * g.W + w; }
+      }
+    y[e] = store_as<T>(best);
+    idx[e] = bi;
+  }
+}
+// gather form (deterministic, no atomics): input element (h, w) collects every window whose argmax it is
+template <class T>
+__global__ void max_pool_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ idx, T* __restrict__ dx, PoolGeom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.H * g.W;
+  const int span = (g.k - 1) * g.d;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(e % g.W), h = (int)((e / g.W) % g.H);
+    const int64_t nc = e / (g.W * g.H);
+    const int64_t me = (int64_t)h * g.W + w;
+    int ho_lo = (h + g.p - span + g.s - 1) / g.s; if (h + g.p - span < 0) ho_lo = 0;
+    int wo_lo = (w + g.p - span + g.s - 1) / g.s; if (w + g.p - span < 0) wo_lo = 0;
+    const int ho_hi = min((h + g.p) / g.s, (int)g.Ho - 1), wo_hi = min((w + g.p) / g.s, (int)g.Wo - 1);
+    A acc = 0;
+    for (int ho = ho_lo; ho <= ho_hi; ho++)
+      for (int wo = wo_lo; wo <= wo_hi; wo++) {
+        const int64_t o = (nc * g.Ho + ho) * g.Wo + wo;
+        if (idx[o] == me) acc += load_as<A>(dy[o]);
+      }
+    dx[e] = store_as<T>(acc);
+  }
+}
+
+static PoolGeom pool_geom(const Tensor* x, int64_t k, int64_t s, int64_t p, int64_t d, int ceil_mode, int cip) {
+  LAMP_CHECK(x->ndim == 4 || x->ndim == 3, "pooling expects a 3-D or 4-D input, got " << x->describe());
+  LAMP_CHECK(k > 0 && s > 0 && p >= 0 && d > 0 && p <= k / 2 + (k == 1 ? 0 : 0) + k, "bad pooling geometry");
+  PoolGeom g{};
+  const int nd = x->ndim;
+  g.H = x->sizes[nd - 2]; g.W = x->sizes[nd - 1];
+  g.NC = x->numel() / std::max<int64_t>(g.H * g.W, 1);
+  g.k = (int)k; g.s = (int)s; g.p = (int)p; g.d = (int)d;
+  g.count_include_pad = cip;
+  g.Ho = pool_out(g.H, g.k, g.s, g.p, g.d, ceil_mode);
+  g.Wo = pool_out(g.W, g.k, g.s, g.p, g.d, ceil_mode);
+  LAMP_CHECK(g.Ho > 0 && g.Wo > 0, "pooling output would be empty");
+  return g;
+}
+static std::vector<int64_t> pooled_shape(const Tensor* x, const PoolGeom& g) {
+  std::vector<int64_t> s = x->shape();
+  s[s.size() - 2] = g.Ho; s[s.size() - 1] = g.Wo;
+  return s;
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_avg_pool2d(lamp_tensor** out, const lamp_tensor* x, int64_t kernel, int64_t stride, int64_t padding, int ceil_mode,
+                    int count_include_pad) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input");
+  PoolGeom g = pool_geom(x, kernel, stride, padding, 1, ceil_mode, count_include_pad);
+  Hold xc(contiguous(x));
+  Hold y(new_tensor(pooled_shape(x, g), x->dtype, x->device()));
+  const int64_t total = y->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = y.take();
+  LAMP_API_END
+}
+int lamp_avg_pool2d_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel, int64_t stride,
+                             int64_t padding, int ceil_mode, int count_include_pad) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out");
+  PoolGeom g = pool_geom(x, kernel, stride, padding, 1, ceil_mode, count_include_pad);
+  LAMP_CHECK(grad_out->shape() == pooled_shape(x, g) && grad_out->dtype == x->dtype, "avg_pool2d_backward: grad_out " << grad_out->describe() << " has the wrong shape");
+  Hold gc(contiguous(grad_out));
+  Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
+  const int64_t total = dx->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), gc->ptr<T>(), dx->ptr<T>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = dx.take();
+  LAMP_API_END
+}
+int lamp_max_pool2d_with_indices(lamp_tensor** out, lamp_tensor** indices, const lamp_tensor* x, int64_t kernel, int64_t stride,
+                                 int64_t padding, int64_t dilation, int ceil_mode) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input");
+  PoolGeom g = pool_geom(x, kernel, stride, padding, dilation, ceil_mode, 1);
+  Hold xc(contiguous(x));
+  auto os = pooled_shape(x, g);
+  Hold y(new_tensor(os, x->dtype, x->device())), idx(new_tensor(os, kI64, x->device()));
+  const int64_t total = y->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((max_pool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), idx->ptr<int64_t>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = y.take();
+  *indices = idx.take();
+  LAMP_API_END
+}
+int lamp_max_pool2d_with_indices_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel,
+                                          int64_t stride, int64_t padding, int64_t dilation, int ceil_mode, const lamp_tensor* indices) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out"); check_device_tensor(indices, "indices");
+  PoolGeom g = pool_geom(x, kernel, stride, padding, dilation, ceil_mode, 1);
+  LAMP_CHECK(grad_out->shape() == pooled_shape(x, g) && indices->shape() == grad_out->shape() && indices->dtype == kI64 &&
+             grad_out->dtype == x->dtype, "max_pool2d_with_indices_backward: shape/dtype mismatch");
+  Hold gc(contiguous(grad_out)), ic(contiguous(indices));
+  Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
+  const int64_t total = dx->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((max_pool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), gc->ptr<T>(), ic->ptr<int64_t>(), dx->ptr<T>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = dx.take();
+  LAMP_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// log-softmax / softmax / NLL / MSE kernels.
+//
+// Replaces ATen.log_softmax, _log_softmax_backward_data, nll_loss_forward, nll_loss_backward,
+// mse_loss(+_backward) as lamp calls them (reference:
+// lamp-core/src/main/scala/lamp/autograd/ops.scala:955-975 (LogSoftMax), 1176-1206 (MseLoss),
+// 1249-1304 (NllLoss); lamp-core/.../nn/LossFunctions.scala:39-55).
+// One 64-lane wavefront per softmax row (max and sum by lane shuffles), f32 math for bf16/f32.
+// int64 targets are consumed as-is (bit-exact class indices, ignore_index honoured).
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+template <class A> __device__ __forceinline__ A t_exp(A x) { return (A)exp((double)x); }
+template <> __device__ __forceinline__ float t_exp(float x) { return expf(x); }
+template <class A> __device__ __forceinline__ A t_log(A x) { return (A)log((double)x); }
+template <> __device__ __forceinline__ float t_log(float x) { return logf(x); }
+
+// x viewed as [outer, D, inner]; one wave per (outer, inner) pair. LOG: log-softmax else softmax.
+template <class T, bool LOG>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t outer, int64_t D,
+                                                          int64_t inner) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nrows = outer * inner;
+  if (wave >= nrows) return;
+  const int64_t o = wave / inner, i = wave - o * inner;
+  const T* xp = x + o * D * inner + i;
+  T* yp = y + o * D * inner + i;
+  A m = -INFINITY;
+  for (int64_t d = lane; d < D; d += 64) { A v = load_as<A>(xp[d * inner]); m = v > m ? v : m; }
+  m = wave_max(m);
+  A s = 0;
+  for (int64_t d = lane; d < D; d += 64) s += t_exp<A>(load_as<A>(xp[d * inner]) - m);
+  s = wave_sum(s);
+  if (LOG) {
+    const A ls = t_log<A>(s);
+    for (int64_t d = lane; d < D; d += 64) yp[d * inner] = store_as<T>((A)(load_as<A>(xp[d * inner]) - m - ls));
+  } else {
+    const A inv = A(1) / s;
+    for (int64_t d = lane; d < D; d += 64) yp[d * inner] = store_as<T>((A)(t_exp<A>(load_as<A>(xp[d * inner]) - m) * inv));
+  }
+}
+
+// grad_in = grad - exp(output) * sum(grad)
+template <class T>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restrict__ g, const T* __restrict__ out, T* __restrict__ gi,
+                                                              int64_t outer, int64_t D, int64_t inner) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (wave >= outer * inner) return;
+  const int64_t o = wave / inner, i = wave - o * inner;
+  const int64_t base = o * D * inner + i;
+  A s = 0;
+  for (int64_t d = lane; d < D; d += 64) s += load_as<A>(g[base + d * inner]);
+  s = wave_sum(s);
+  for (int64_t d = lane; d < D; d += 64) {
+    const int64_t k = base + d * inner;
+    gi[k] = store_as<T>((A)(load_as<A>(g[k]) - t_exp<A>(load_as<A>(out[k])) * s));
+  }
+}
+
+// ---- NLL ---------------------------------------------------------------------------------------
+// single block: sum_i -w[t_i] x[i, t_i] and sum_i w[t_i] over non-ignored rows
+template <class T>
+__global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restrict__ x, const int64_t* __restrict__ target,
+                                                              const T* __restrict__ w, T* __restrict__ out, T* __restrict__ total_weight,
+                                                              int64_t N, int64_t C, int64_t reduction, int64_t ignore) {
+  using A = acc_t<T>;
+  __shared__ A sm[16];
+  A loss = 0, tw = 0;
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+    const int64_t t = target[i];
+    if (t == ignore) continue;
+    if (t < 0 || t >= C) continue;  // validated on the host for small N; never read out of bounds
+    const A wt = w ? load_as<A>(w[t]) : A(1);
+    loss -= wt * load_as<A>(x[i * C + t]);
+    tw += wt;
+  }
+  loss = block_sum(loss, sm);
+  tw = block_sum(tw, sm);
+  if (threadIdx.x == 0) {
+    *total_weight = store_as<T>(tw);
+    if (reduction == 1) *out = store_as<T>((A)(loss / tw));
+    else *out = store_as<T>(loss);
+  }
+}
+template <class T>
+__global__ void nll_fwd_none_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, const T* __restrict__ w,
+                                    T* __restrict__ out, int64_t N, int64_t C, int64_t ignore) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = target[i];
+    A v = 0;
+    if (t != ignore && t >= 0 && t < C) v = -(w ? load_as<A>(w[t]) : A(1)) * load_as<A>(x[i * C + t]);
+    out[i] = store_as<T>(v);
+  }
+}
+// grad_input[i, c] = (c == t_i && t_i != ignore) ? -w[t_i] * g : 0, g = grad/total_weight (mean), grad (sum), grad[i] (none)
+template <class T>
+__global__ void nll_bwd_kernel(const T* __restrict__ grad, const int64_t* __restrict__ target, const T* __restrict__ w,
+                               const T* __restrict__ total_weight, T* __restrict__ gi, int64_t N, int64_t C, int64_t reduction,
+                               int64_t ignore) {
+  using A = acc_t<T>;
+  const int64_t n = N * C;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / C, c = e - i * C;
+    const int64_t t = target[i];
+    A v = 0;
+    if (c == t && t != ignore) {
+      A g = load_as<A>(reduction == 0 ? grad[i] : grad[0]);
+      if (reduction == 1) g = g / load_as<A>(*total_weight);
+      v = -(w ? load_as<A>(w[t]) : A(1)) * g;
+    }
+    gi[e] = store_as<T>(v);
+  }
+}
+
+// mse backward: out = (x - t) * grad * scale  (grad is a scalar for mean/sum, elementwise for none)
+template <class T>
+__global__ void mse_bwd_kernel(const T* __restrict__ grad, const T* __restrict__ x, const T* __restrict__ t, T* __restrict__ out,
+                               int64_t n, double scale, int grad_scalar) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    A g = load_as<A>(grad_scalar ? grad[0] : grad[i]);
+    out[i] = store_as<T>((A)((A)scale * (load_as<A>(x[i]) - load_as<A>(t[i])) * g));
+  }
+}
+template <class T>
+__global__ void sqdiff_kernel(const T* __restrict__ x, const T* __restrict__ t, T* __restrict__ out, int64_t n) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    A d = load_as<A>(x[i]) - load_as<A>(t[i]);
+    out[i] = store_as<T>((A)(d * d));
+  }
+}
+
+static void split_dim(const Tensor* x, int64_t dim, int64_t& outer, int64_t& D, int64_t& inner) {
+  int64_t d = wrap_dim(dim, x->ndim);
+  outer = 1; inner = 1;
+  D = x->ndim ? x->sizes[d] : 1;
+  for (int i = 0; i < d; i++) outer *= x->sizes[i];
+  for (int i = (int)d + 1; i < x->ndim; i++) inner *= x->sizes[i];
+}
+
+template <bool LOG> static Tensor* softmax_impl(const Tensor* x, int64_t dim) {
+  check_device_tensor(x, "input");
+  Hold xc(contiguous(x));
+  Hold y(new_like(xc.get()));
+  int64_t outer, D, inner;
+  split_dim(x, dim, outer, D, inner);
+  const int64_t rows = outer * inner;
+  if (rows > 0 && D > 0) {
+    const int64_t blocks = (rows * 64 + 255) / 256;
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((softmax_fwd_kernel<T, LOG>), dim3((unsigned)blocks), dim3(256), 0,
+                                                        current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), outer, D, inner));
+    LAMP_LAUNCH_CHECK();
+  }
+  return y.take();
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_log_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim) { LAMP_API_BEGIN *out = softmax_impl<true>(x, dim); LAMP_API_END }
+int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim) { LAMP_API_BEGIN *out = softmax_impl<false>(x, dim); LAMP_API_END }
+
+int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(grad, "grad_output"); check_device_tensor(output, "output");
+  LAMP_CHECK(grad->shape() == output->shape() && grad->dtype == output->dtype, "grad/output mismatch: " << grad->describe() << " vs " << output->describe());
+  Hold gc(contiguous(grad)), oc(contiguous(output));
+  Hold gi(new_like(oc.get()));
+  int64_t outer, D, inner;
+  split_dim(output, dim, outer, D, inner);
+  const int64_t rows = outer * inner;
+  if (rows > 0 && D > 0) {
+    const int64_t blocks = (rows * 64 + 255) / 256;
+    LAMP_DISPATCH_FLOAT(output->dtype, T, hipLaunchKernelGGL((log_softmax_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
+                                                             current_stream(output->device()), gc->ptr<T>(), oc->ptr<T>(),
+                                                             gi->ptr<T>(), outer, D, inner));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = gi.take();
+  LAMP_API_END
+}
+
+static void nll_check(const lamp_tensor* x, const lamp_tensor* target, const lamp_tensor* weight) {
+  check_device_tensor(x, "input"); check_device_tensor(target, "target");
+  LAMP_CHECK(x->ndim == 2, "nll_loss expects a 2-D input (samples x classes), got " << x->describe());
+  LAMP_CHECK(target->ndim == 1 && target->dtype == kI64, "nll_loss expects a 1-D int64 target, got " << target->describe());
+  LAMP_CHECK(target->sizes[0] == x->sizes[0], "nll_loss: batch size mismatch " << x->describe() << " vs " << target->describe());
+  if (weight) {
+    check_device_tensor(weight, "weight");
+    LAMP_CHECK(weight->numel() == x->sizes[1] && weight->dtype == x->dtype, "nll_loss: weight must have " << x->sizes[1] << " elements of the input dtype");
+  }
+}
+
+int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x, const lamp_tensor* target,
+                          const lamp_tensor* weight, int64_t reduction, int64_t ignore_index) {
+  LAMP_API_BEGIN
+  nll_check(x, target, weight);
+  LAMP_CHECK(reduction >= 0 && reduction <= 2, "bad reduction " << reduction);
+  Hold xc(contiguous(x)), tc(contiguous(target));
+  Hold wc(weight ? contiguous(weight) : nullptr);
+  const int64_t N = x->sizes[0], C = x->sizes[1];
+  hipStream_t st = current_stream(x->device());
+  Hold tw(new_tensor(nullptr, 0, x->dtype, x->device()));
+  if (reduction == 0) {
+    int64_t sz[1] = {N};
+    Hold o(new_tensor(sz, 1, x->dtype, x->device()));
+    fill_zero(tw.get());
+    if (N > 0) {
+      LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_none_kernel<T>), dim3(grid_for(N, 256)), dim3(256), 0, st,
+                                                          xc->ptr<T>(), tc->ptr<int64_t>(), wc.get() ? wc->ptr<T>() : (const T*)nullptr,
+                                                          o->ptr<T>(), N, C, ignore_index));
+      LAMP_LAUNCH_CHECK();
+    }
+    *out = o.take();
+  } else {
+    Hold o(new_tensor(nullptr, 0, x->dtype, x->device()));
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_reduce_kernel<T>), dim3(1), dim3(1024), 0, st, xc->ptr<T>(),
+                                                        tc->ptr<int64_t>(), wc.get() ? wc->ptr<T>() : (const T*)nullptr, o->ptr<T>(),
+                                                        tw->ptr<T>(), N, C, reduction, ignore_index));
+    LAMP_LAUNCH_CHECK();
+    *out = o.take();
+  }
+  *total_weight = tw.take();
+  LAMP_API_END
+}
+
+int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* target,
+                           const lamp_tensor* weight, int64_t reduction, int64_t ignore_index, const lamp_tensor* total_weight) {
+  LAMP_API_BEGIN
+  nll_check(x, target, weight);
+  check_device_tensor(grad_out, "grad_output"); check_device_tensor(total_weight, "total_weight");
+  LAMP_CHECK(grad_out->dtype == x->dtype && total_weight->dtype == x->dtype, "nll_loss_backward: dtype mismatch");
+  const int64_t N = x->sizes[0], C = x->sizes[1];
+  if (reduction == 0) LAMP_CHECK(grad_out->numel() == N, "nll_loss_backward: grad_output must have N elements for reduction none");
+  else LAMP_CHECK(grad_out->numel() == 1, "nll_loss_backward: grad_output must be a scalar");
+  Hold gc(contiguous(grad_out)), tc(contiguous(target));
+  Hold wc(weight ? contiguous(weight) : nullptr);
+  Hold gi(new_tensor(x->sizes, 2, x->dtype, x->device()));
+  if (N * C > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_bwd_kernel<T>), dim3(grid_for(N * C, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), gc->ptr<T>(), tc->ptr<int64_t>(),
+                                                        wc.get() ? wc->ptr<T>() : (const T*)nullptr, total_weight->ptr<T>(),
+                                                        gi->ptr<T>(), N, C, reduction, ignore_index));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = gi.take();
+  LAMP_API_END
+}
+
+int lamp_mse_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(target, "target");
+  LAMP_CHECK(x->shape() == target->shape() && x->dtype == target->dtype, "mse_loss: input/target mismatch " << x->describe() << " vs " << target->describe());
+  Hold xc(contiguous(x)), tc(contiguous(target));
+  Hold sq(new_like(xc.get()));
+  const int64_t n = x->numel();
+  if (n > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((sqdiff_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), xc->ptr<T>(), tc->ptr<T>(), sq->ptr<T>(), n));
+    LAMP_LAUNCH_CHECK();
+  }
+  if (reduction == 0) { *out = sq.take(); return 0; }
+  return reduction == 1 ? lamp_mean_all(out, sq.get()) : lamp_sum_all(out, sq.get());
+  LAMP_API_END
+}
+
+int lamp_mse_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(target, "target"); check_device_tensor(grad_out, "grad_output");
+  LAMP_CHECK(x->shape() == target->shape() && x->dtype == target->dtype && grad_out->dtype == x->dtype, "mse_loss_backward: mismatch");
+  const int64_t n = x->numel();
+  int grad_scalar = grad_out->numel() == 1 && n != 1 ? 1 : (grad_out->numel() == 1);
+  if (!grad_scalar) LAMP_CHECK(grad_out->numel() == n, "mse_loss_backward: grad_output has the wrong size");
+  Hold xc(contiguous(x)), tc(contiguous(target)), gc(contiguous(grad_out));
+  Hold gi(new_like(xc.get()));
+  const double scale = reduction == 1 ? 2.0 / (double)n : 2.0;
+  if (n > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((mse_bwd_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), gc->ptr<T>(), xc->ptr<T>(), tc->ptr<T>(),
+                                                        gi->ptr<T>(), n, scale, grad_scalar));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = gi.take();
+  LAMP_API_END
+}
+
+}  // extern "C"

@@ -58,6 +58,12 @@ class STen:
         except Exception:
             pass
 
+    @property
+    def _as_parameter_(self):
+        # lets an STen be passed straight to a C-ABI call; the object (and so the handle) stays
+        # alive for the duration of the call because ctypes holds the argument tuple
+        return C.c_void_p(self.h)
+
     def release(self):
         h, self.h = getattr(self, "h", None), None
         if h:

@@ -1,0 +1,476 @@
+"""Op-level parity: every C-ABI compute entry point vs the same ATen operator on CPU.
+
+The oracle side calls torch.ops.aten.* on CPU tensors (the operators the reference dispatches,
+see oracle/lamp_oracle.py header); the HIP side goes through liblamp_hip.so.  Inputs are
+deterministic closed forms.  Tolerances: bit-exact for index/bool results, <= 1e-5 relative for
+f32 forward (BASELINE.json), 1e-12 for f64, bf16 at bf16 resolution (stated per test).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from lamp_amd import sten as S
+from lamp_amd._capi import lib, i64_array
+from tests.util import DTYPES, FWD_TOL, assert_close, closed_form, to_sten, to_torch
+
+pytestmark = pytest.mark.gpu
+aten = torch.ops.aten
+
+
+def _mask3(a, b, c):
+    return (C.c_uint8 * 3)(a, b, c)
+
+
+def _out3():
+    return (C.c_void_p * 3)()
+
+
+def _wrap3(arr):
+    return [S.STen(arr[i]) if arr[i] else None for i in range(3)]
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+def test_binary_broadcast_and_inplace(gpu, dt):
+    a = closed_form((5, 1, 7), 1, 4.0, dt)
+    b = closed_form((3, 7), 50, 3.0, dt) + 1.6
+    A, B = to_sten(a), to_sten(b)
+    tol = FWD_TOL[dt]
+    assert_close(to_torch(A + B), (a + b).float() if dt == torch.bfloat16 else a + b, tol, "add")
+    assert_close(to_torch(A - B), (a - b).float() if dt == torch.bfloat16 else a - b, tol, "sub")
+    assert_close(to_torch(A * B), (a * b).float() if dt == torch.bfloat16 else a * b, tol, "mul")
+    assert_close(to_torch(A / B), (a / b).float() if dt == torch.bfloat16 else a / b, tol, "div")
+    assert_close(to_torch(A.add(B, 0.25)), aten.add.Tensor(a, b, alpha=0.25).double(), tol, "add alpha")
+    assert_close(to_torch(A * 3.5), aten.mul.Scalar(a, 3.5).double(), tol, "mul scalar")
+    assert_close(to_torch(A + 2.0), aten.add.Scalar(a, 2.0).double(), tol, "add scalar")
+    # in place on a broadcast rhs
+    full = closed_form((3, 7), 9, 1.0, dt)
+    F = to_sten(full)
+    F += to_sten(closed_form((1, 7), 3, 1.0, dt))
+    assert_close(to_torch(F), (full + closed_form((1, 7), 3, 1.0, dt)).double(), tol, "+= broadcast")
+    # addcmul / addcdiv out (AdamW building blocks)
+    t1, t2 = closed_form((3, 7), 11, 2.0, dt), closed_form((3, 7), 13, 2.0, dt) + 1.5
+    O = to_sten(full)
+    S.STen.addcmulOut(O, O, to_sten(t1), to_sten(t2), 0.3)
+    assert_close(to_torch(O), aten.addcmul(full, t1, t2, value=0.3).double(), tol, "addcmul")
+    O = to_sten(full)
+    S.STen.addcdivOut(O, O, to_sten(t1), to_sten(t2), -0.7)
+    assert_close(to_torch(O), aten.addcdiv(full, t1, t2, value=-0.7).double(), tol, "addcdiv")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_unary_functions(gpu, dt):
+    x = closed_form((4, 33), 7, 6.0, dt)
+    X = to_sten(x)
+    tol = FWD_TOL[dt]
+    pos = x.abs() + 0.25
+    P = to_sten(pos)
+    cases = [("relu", X.relu(), aten.relu(x)), ("gelu", X.gelu(), aten.gelu(x)), ("sigmoid", X.sigmoid(), aten.sigmoid(x)),
+             ("tanh", X.tanh(), aten.tanh(x)), ("hardswish", X.hardSwish(), aten.hardswish(x)),
+             ("leaky", X.leakyRelu(0.1), aten.leaky_relu(x, 0.1)), ("softplus", X.softplus(1.0, 20.0), aten.softplus(x, 1.0, 20.0)),
+             ("exp", X.exp(), aten.exp(x)), ("log", P.log(), aten.log(pos)), ("log1p", P.log1p(), aten.log1p(pos)),
+             ("sqrt", P.sqrt(), aten.sqrt(pos)), ("reciprocal", P.reciprocal(), aten.reciprocal(pos)), ("neg", X.neg(), aten.neg(x)),
+             ("abs", X.abs(), aten.abs(x)), ("sign", X.sign(), aten.sign(x)), ("sin", X.sin(), aten.sin(x)), ("cos", X.cos(), aten.cos(x)),
+             ("atan", X.atan(), aten.atan(x)), ("pow2", X.pow(2.0), aten.pow.Tensor_Scalar(x, 2.0)),
+             ("pow0.5", P.pow(0.5), aten.pow.Tensor_Scalar(pos, 0.5)), ("pow1.7", P.pow(1.7), aten.pow.Tensor_Scalar(pos, 1.7))]
+    for name, got, ref in cases:
+        assert_close(to_torch(got), ref.double(), tol * (4 if name in ("exp", "pow1.7", "tan") else 1), name)
+    g = closed_form((4, 33), 99, 2.0, dt)
+    G = to_sten(g)
+    o = C.c_void_p(); lib.lamp_gelu_backward(C.byref(o), G, X)
+    assert_close(to_torch(S.STen(o)), aten.gelu_backward(g, x).double(), tol, "gelu_backward")
+    y = aten.sigmoid(x)
+    o = C.c_void_p(); lib.lamp_sigmoid_backward(C.byref(o), G, to_sten(y))
+    assert_close(to_torch(S.STen(o)), aten.sigmoid_backward(g, y).double(), tol, "sigmoid_backward")
+    y = aten.tanh(x)
+    o = C.c_void_p(); lib.lamp_tanh_backward(C.byref(o), G, to_sten(y))
+    assert_close(to_torch(S.STen(o)), aten.tanh_backward(g, y).double(), tol, "tanh_backward")
+    o = C.c_void_p(); lib.lamp_hardswish_backward(C.byref(o), G, X)
+    assert_close(to_torch(S.STen(o)), aten.hardswish_backward(g, x).double(), tol, "hardswish_backward")
+    # fused relu backward accumulate == lamp's lt/where/addcmul chain, gradient at x == 0 is 1
+    xz = x.clone(); xz[0, :5] = 0
+    out0 = closed_form((4, 33), 5, 1.0, dt)
+    O = to_sten(out0)
+    lib.lamp_relu_backward_accumulate_(O, G, to_sten(xz), 0.0)
+    ref = out0.double() + g.double() * torch.where(xz.double() < 0, 0.0, 1.0)
+    assert_close(to_torch(O), ref, tol, "relu backward accumulate")
+
+
+def test_comparisons_where_are_exact(gpu):
+    a = closed_form((6, 9), 1, 4.0, torch.float32)
+    b = closed_form((6, 9), 4, 4.0, torch.float32)
+    A, B = to_sten(a), to_sten(b)
+    for name, got, ref in [("lt", A.lt(B), a < b), ("le", A.le(B), a <= b), ("gt", A.gt(0.3), a > 0.3), ("ge", A.ge(B), a >= b),
+                           ("eq", A.equ(A), a == a), ("ne", A.ne(B), a != b), ("lt0", A.lt(0.0), a < 0)]:
+        assert np.array_equal(got.to_numpy(), ref.numpy()), name
+    w = S.STen.where(A.lt(0.0), A, B)
+    assert np.array_equal(w.to_numpy(), torch.where(a < 0, a, b).numpy())
+    assert np.array_equal(A.maskedFill(A.gt(0.0), -2.0).to_numpy(), a.masked_fill(a > 0, -2.0).numpy())
+    i = torch.arange(12).reshape(3, 4)
+    I = to_sten(i)
+    assert np.array_equal(I.ne(to_sten(torch.full((3, 4), 5))).to_numpy(), (i != 5).numpy())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_reductions(gpu, dt):
+    x = closed_form((6, 5, 8, 3), 3, 2.0, dt)
+    X = to_sten(x)
+    tol = FWD_TOL[dt] * 4
+    xd = x.double()
+    assert_close(to_torch(X.sum()), xd.sum(), tol * 8, "sum all")
+    for dims, keep in [([0], True), ([3], False), ([0, 2, 3], False), ([1, 3], True), ([0, 2], False), ([1], True), ([0, 1, 2, 3], False)]:
+        assert_close(to_torch(X.sum(dims, keep)), xd.sum(dims, keepdim=keep), tol * 4, f"sum {dims}")
+        assert_close(to_torch(X.mean(dims, keep)), xd.mean(dims, keepdim=keep), tol * 4, f"mean {dims}")
+    assert_close(to_torch(X.norm2([3], True)), torch.linalg.vector_norm(xd, 2, [3], True), tol, "norm2")
+    v, m = X.varAndMean([0, 2], True, True)
+    rv, rm = torch.var_mean(xd, [0, 2], unbiased=True, keepdim=True)
+    assert_close(to_torch(v), rv, tol * 4, "var")
+    assert_close(to_torch(m), rm, tol * 4, "mean")
+    big = closed_form((3, 70001), 5, 2.0, dt)
+    assert_close(to_torch(to_sten(big).sum(1, False)), big.double().sum(1), tol * 8, "long rows")
+    assert_close(to_torch(to_sten(big).sum(0, True)), big.double().sum(0, keepdim=True), tol * 4, "many columns")
+    assert np.array_equal(X.argmax(1, False).to_numpy(), torch.argmax(x.float(), 1).numpy())
+    # unbroadcast (TensorHelpers.scala:7-41)
+    p = closed_form((4, 5, 6), 2, 1.0, dt)
+    assert_close(to_torch(to_sten(p).unbroadcast([1, 6])), p.double().sum((0, 1)).reshape(1, 6), tol * 4, "unbroadcast")
+    assert_close(to_torch(to_sten(p).unbroadcast([5, 1])), p.double().sum((0, 2)).reshape(5, 1), tol * 4, "unbroadcast2")
+
+
+def test_views_share_storage_and_strided_copy(gpu):
+    x = closed_form((4, 6, 5), 0, 1.0, torch.float32)
+    X = to_sten(x)
+    v = X.transpose(0, 2)
+    assert v.storage_id == X.storage_id and v.shape == [5, 6, 4]
+    assert np.array_equal(v.to_numpy(), x.transpose(0, 2).numpy())
+    assert np.array_equal(X.select(1, 2).to_numpy(), x.select(1, 2).numpy())
+    assert np.array_equal(X.slice(2, 1, 5, 2).to_numpy(), x[:, :, 1:5:2].numpy())
+    assert np.array_equal(X.narrow(0, 1, 2).to_numpy(), x.narrow(0, 1, 2).numpy())
+    assert np.array_equal(X.view(24, 5).to_numpy(), x.view(24, 5).numpy())
+    assert np.array_equal(X.view(-1).to_numpy(), x.view(-1).numpy())
+    assert np.array_equal(v.reshape(30, 4).to_numpy(), x.transpose(0, 2).reshape(30, 4).numpy())
+    assert np.array_equal(X.flatten(1).to_numpy(), x.flatten(1).numpy())
+    assert np.array_equal(X.unsqueeze(1).expand([4, 3, 6, 5]).to_numpy(), x.unsqueeze(1).expand(4, 3, 6, 5).numpy())
+    assert np.array_equal(S.STen.cat([X, X.slice(0, 0, 2)], 0).to_numpy(), torch.cat([x, x[:2]], 0).numpy())
+    assert np.array_equal(S.STen.stack([X, X], 1).to_numpy(), torch.stack([x, x], 1).numpy())
+    with pytest.raises(Exception):
+        v.view(20, 6)
+    # writing through a view is visible in the base
+    X.select(0, 0).fill_(7.0)
+    assert (X.to_numpy()[0] == 7.0).all()
+    assert np.array_equal(X.castToDouble().to_numpy(), X.to_numpy().astype(np.float64))
+    assert np.array_equal(to_sten(torch.arange(10)).castToFloat().to_numpy(), np.arange(10, dtype=np.float32))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 3), (64, 64, 64), (130, 70, 45), (256, 384, 192), (1024, 256, 784), (1024, 10, 256), (1, 1, 1)])
+def test_gemm_family(gpu, dt, shape):
+    M, N, K = shape
+    a, b = closed_form((M, K), 1, 2.0, dt), closed_form((K, N), 77, 2.0, dt)
+    A, B = to_sten(a), to_sten(b)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 1.6e-2}[dt]
+    ref = a.double() @ b.double()
+    assert_close(to_torch(A.mm(B)), ref, tol, "mm")
+    # column-major operands through transposed views (no copies needed)
+    assert_close(to_torch(to_sten(a.t().contiguous()).t.mm(to_sten(b.t().contiguous()).t)), ref, tol, "mm of transposed views")
+    out0, p = closed_form((K, N), 5, 1.0, dt), closed_form((M, N), 9, 1.0, dt)
+    O, P = to_sten(out0), to_sten(p)
+    S.STen.addmm_out_transposed1(O, O, A, P, 1.0, 1.0)          # dB += A^T . p   (ops.scala:680-690)
+    assert_close(to_torch(O), out0.double() + a.double().t() @ p.double(), tol * 2, "addmm_out_transposed1")
+    out1 = closed_form((M, K), 6, 1.0, dt)
+    O1 = to_sten(out1)
+    S.STen.addmm_out_transposed2(O1, O1, P, B, 1.0, 1.0)        # dA += p . B^T   (ops.scala:669-679)
+    assert_close(to_torch(O1), out1.double() + p.double() @ b.double().t(), tol * 2, "addmm_out_transposed2")
+    bias = closed_form((1, N), 4, 1.0, dt)
+    assert_close(to_torch(to_sten(bias).addmm(A, B, 0.5, 2.0)), 0.5 * bias.double() + 2.0 * ref, tol * 2, "addmm broadcast self")
+    o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), A, B, to_sten(bias))
+    assert_close(to_torch(S.STen(o)), ref + bias.double(), tol * 2, "linear_bias")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_bmm_family(gpu, dt):
+    a, b = closed_form((3, 33, 65), 1, 2.0, dt), closed_form((3, 65, 17), 5, 2.0, dt)
+    A, B = to_sten(a), to_sten(b)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 1.6e-2}[dt]
+    ref = a.double() @ b.double()
+    assert_close(to_torch(A.bmm(B)), ref, tol, "bmm")
+    p = closed_form((3, 33, 17), 8, 1.0, dt)
+    P = to_sten(p)
+    o1 = closed_form((3, 65, 17), 3, 1.0, dt); O1 = to_sten(o1)
+    S.STen.baddbmm_out_transposed1(O1, O1, A, P, 1.0, 1.0)
+    assert_close(to_torch(O1), o1.double() + a.double().transpose(1, 2) @ p.double(), tol * 2, "baddbmm_t1")
+    o2 = closed_form((3, 33, 65), 2, 1.0, dt); O2 = to_sten(o2)
+    S.STen.baddbmm_out_transposed2(O2, O2, P, B, 1.0, 1.0)
+    assert_close(to_torch(O2), o2.double() + p.double() @ b.double().transpose(1, 2), tol * 2, "baddbmm_t2")
+    assert_close(to_torch(A.matmul(to_sten(b[0]))), a.double() @ b[0].double(), tol, "matmul 3d x 2d")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_log_softmax_and_nll(gpu, dt):
+    x = closed_form((37, 100), 3, 8.0, dt)
+    X = to_sten(x)
+    tol = FWD_TOL[dt]
+    y = aten._log_softmax(x, 1, False)
+    assert_close(to_torch(X.logSoftMax(1)), y.double(), tol * (1 if dt != torch.bfloat16 else 2), "log_softmax")
+    assert_close(to_torch(X.softmax(1)), aten._softmax(x, 1, False).double(), tol, "softmax")
+    x3 = closed_form((4, 7, 5), 3, 4.0, dt)
+    assert_close(to_torch(to_sten(x3).logSoftMax(1)), aten._log_softmax(x3, 1, False).double(), tol * 2, "log_softmax middle dim")
+    g = closed_form((37, 100), 8, 1.0, dt)
+    o = C.c_void_p(); lib.lamp_log_softmax_backward_data(C.byref(o), to_sten(g), to_sten(y), 1)
+    assert_close(to_torch(S.STen(o)), aten._log_softmax_backward_data(g, y, 1, x.dtype).double(), tol * 4, "log_softmax backward")
+    target = (torch.arange(37) * 7) % 100
+    target[5] = -100
+    w = closed_form((100,), 1, 1.0, dt) + 1.0
+    T, W = to_sten(target), to_sten(w)
+    for red in (0, 1, 2):
+        ref, ref_tw = aten.nll_loss_forward(y, target, w, red, -100)
+        o, tw = C.c_void_p(), C.c_void_p()
+        lib.lamp_nll_loss_forward(C.byref(o), C.byref(tw), to_sten(y), T, W, red, -100)
+        O, TW = S.STen(o), S.STen(tw)
+        assert_close(to_torch(O), ref.double(), tol * 4, f"nll forward red={red}")
+        if red:
+            assert_close(to_torch(TW), ref_tw.double(), tol * 4, "total_weight")
+        gy = closed_form(tuple(ref.shape), 2, 1.0, dt) + 1.0
+        gi = C.c_void_p()
+        lib.lamp_nll_loss_backward(C.byref(gi), to_sten(gy), to_sten(y), T, W, red, -100, to_sten(ref_tw))
+        refb = aten.nll_loss_backward(gy, y, target, w, red, -100, ref_tw)
+        assert_close(to_torch(S.STen(gi)), refb.double(), tol * 4, f"nll backward red={red}")
+    t = closed_form((37, 100), 1, 1.0, dt)
+    for red in (0, 1, 2):
+        o = C.c_void_p(); lib.lamp_mse_loss(C.byref(o), X, to_sten(t), red)
+        assert_close(to_torch(S.STen(o)), aten.mse_loss(x, t, red).double(), tol * 8, "mse")
+        gy = torch.ones((), dtype=dt) if red else closed_form((37, 100), 3, 1.0, dt)
+        o = C.c_void_p(); lib.lamp_mse_loss_backward(C.byref(o), to_sten(gy), X, to_sten(t), red)
+        assert_close(to_torch(S.STen(o)), aten.mse_loss_backward(gy, x, t, red).double(), tol * 4, "mse backward")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(16, 6, 8, 8), (4, 100, 8, 8), (64, 10), (1024, 256), (3, 5, 7), (2, 16, 32, 32)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm(gpu, dt, shape, training):
+    x = closed_form(shape, 3, 4.0, dt) + 0.3
+    Cc = shape[1]
+    w, b = closed_form((Cc,), 1, 1.0, dt) + 1.0, closed_form((Cc,), 5, 1.0, dt)
+    rm, rv = closed_form((Cc,), 7, 0.5, dt), closed_form((Cc,), 9, 0.5, dt) + 1.0
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = aten.native_batch_norm(x, w, b, rm_ref, rv_ref, training, 0.1, 1e-5)
+    RM, RV = to_sten(rm), to_sten(rv)
+    out = _out3()
+    lib.lamp_native_batch_norm(out, to_sten(x), to_sten(w), to_sten(b), RM, RV, int(training), 0.1, 1e-5)
+    y, sm, si = _wrap3(out)
+    tol = FWD_TOL[dt] * 4
+    assert_close(to_torch(y), ref[0].double(), tol, "bn y")
+    if training:
+        assert_close(to_torch(sm), ref[1].double(), tol, "save_mean")
+        assert_close(to_torch(si), ref[2].double(), tol, "save_invstd")
+        assert_close(to_torch(RM), rm_ref.double(), tol, "running_mean")
+        assert_close(to_torch(RV), rv_ref.double(), tol, "running_var (unbiased)")
+    gy = closed_form(shape, 11, 2.0, dt)
+    save_mean, save_invstd = (ref[1], ref[2]) if training else (None, None)
+    refb = aten.native_batch_norm_backward(gy, x, w, rm_ref, rv_ref, save_mean, save_invstd, training, 1e-5, [True, True, True])
+    outb = _out3()
+    lib.lamp_native_batch_norm_backward(outb, to_sten(gy), to_sten(x), to_sten(w), to_sten(rm_ref), to_sten(rv_ref),
+                                        to_sten(ref[1]) if training else None, to_sten(ref[2]) if training else None,
+                                        int(training), 1e-5, _mask3(1, 1, 1))
+    dx, dw, db = _wrap3(outb)
+    btol = {torch.float64: 1e-10, torch.float32: 2e-4, torch.bfloat16: 4e-2}[dt]
+    assert_close(to_torch(dx), refb[0].double(), btol, "bn dx")
+    assert_close(to_torch(dw), refb[1].double(), btol, "bn dweight")
+    assert_close(to_torch(db), refb[2].double(), btol, "bn dbias")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("affine", [(True, True), (True, False), (False, False)])
+def test_layer_norm(gpu, dt, affine):
+    x = closed_form((6, 7, 96), 3, 4.0, dt)
+    w = closed_form((96,), 1, 1.0, dt) + 1.0 if affine[0] else None
+    b = closed_form((96,), 5, 1.0, dt) if affine[1] else None
+    ref = aten.native_layer_norm(x, [96], w, b, 1e-5)
+    out = _out3()
+    lib.lamp_native_layer_norm(out, to_sten(x), i64_array([96]), 1, to_sten(w) if w is not None else None,
+                               to_sten(b) if b is not None else None, 1e-5)
+    y, mean, rstd = _wrap3(out)
+    tol = FWD_TOL[dt] * 4
+    assert_close(to_torch(y), ref[0].double(), tol, "ln y")
+    assert_close(to_torch(mean), ref[1].double(), tol, "ln mean")
+    assert_close(to_torch(rstd), ref[2].double(), tol, "ln rstd")
+    gy = closed_form((6, 7, 96), 13, 2.0, dt)
+    refb = aten.native_layer_norm_backward(gy, x, [96], ref[1], ref[2], w, b, [True, w is not None, b is not None])
+    outb = _out3()
+    lib.lamp_native_layer_norm_backward(outb, to_sten(gy), to_sten(x), i64_array([96]), 1, to_sten(ref[1]), to_sten(ref[2]),
+                                        to_sten(w) if w is not None else None, to_sten(b) if b is not None else None,
+                                        _mask3(1, int(w is not None), int(b is not None)))
+    dx, dw, db = _wrap3(outb)
+    btol = {torch.float64: 1e-10, torch.float32: 2e-4, torch.bfloat16: 4e-2}[dt]
+    assert_close(to_torch(dx), refb[0].double(), btol, "ln dx")
+    if w is not None:
+        assert_close(to_torch(dw), refb[1].double(), btol, "ln dweight")
+    if b is not None:
+        assert_close(to_torch(db), refb[2].double(), btol, "ln dbias")
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, k, stride, pad, dil, groups)
+    (2, 3, 32, 32, 6, 5, 1, 2, 1, 1),      # resnet stem
+    (2, 6, 32, 32, 6, 3, 2, 1, 1, 1),      # res1.r1
+    (2, 6, 32, 32, 6, 1, 2, 0, 1, 1),      # res1.l
+    (2, 16, 8, 8, 128, 3, 1, 1, 1, 1),     # res3.r1
+    (2, 128, 8, 8, 128, 3, 1, 1, 1, 1),    # res3.r2
+    (2, 128, 8, 8, 100, 3, 1, 1, 1, 1),    # res4.r1
+    (2, 100, 8, 8, 100, 3, 1, 1, 1, 1),    # res4.r2
+    (2, 128, 8, 8, 100, 1, 1, 0, 1, 1),    # res4.l
+    (3, 4, 9, 7, 6, 3, 2, 1, 2, 2),        # odd sizes, dilation, groups
+    (1, 2, 3, 3, 1, 3, 1, 0, 1, 1),        # reference KAT geometry (autograd.test.scala:2043)
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_convolution_forward_backward(gpu, dt, case):
+    N, Cin, H, W, Cout, k, s, p, d, groups = case
+    x = closed_form((N, Cin, H, W), 3, 2.0, dt)
+    w = closed_form((Cout, Cin // groups, k, k), 17, 1.0, dt)
+    b = closed_form((Cout,), 5, 1.0, dt)
+    args = ([s, s], [p, p], [d, d], False, [0, 0], groups)
+    ref = aten.convolution(x, w, b, *args)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([s, s]), i64_array([p, p]), i64_array([d, d]), 2, 0,
+                         i64_array([0, 0]), groups)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 1.6e-2}[dt]
+    assert_close(to_torch(S.STen(o)), ref.double(), tol, "conv forward")
+    gy = closed_form(tuple(ref.shape), 23, 1.0, dt)
+    refb = aten.convolution_backward(gy, x, w, [Cout], *args, [True, True, True])
+    out = _out3()
+    lib.lamp_convolution_backward(out, to_sten(gy), to_sten(x), to_sten(w), i64_array([s, s]), i64_array([p, p]), i64_array([d, d]), 2, 0,
+                                  i64_array([0, 0]), groups, _mask3(1, 1, 1))
+    dx, dw, db = _wrap3(out)
+    btol = {torch.float64: 1e-10, torch.float32: 1e-4, torch.bfloat16: 3e-2}[dt]
+    assert_close(to_torch(dx), refb[0].double(), btol, "conv dgrad")
+    assert_close(to_torch(dw), refb[1].double(), btol, "conv wgrad")
+    assert_close(to_torch(db), refb[2].double(), btol, "conv bias grad")
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_conv1d_and_transposed(gpu, dt):
+    x = closed_form((2, 3, 11), 3, 2.0, dt)
+    w = closed_form((4, 3, 3), 17, 1.0, dt)
+    b = closed_form((4,), 5, 1.0, dt)
+    args = ([2], [1], [1], False, [0], 1)
+    ref = aten.convolution(x, w, b, *args)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([2]), i64_array([1]), i64_array([1]), 1, 0, i64_array([0]), 1)
+    assert_close(to_torch(S.STen(o)), ref.double(), FWD_TOL[dt], "conv1d")
+    # transposed 2-D
+    xt = closed_form((2, 4, 5, 5), 3, 2.0, dt)
+    wt = closed_form((4, 3, 3, 3), 7, 1.0, dt)
+    bt = closed_form((3,), 2, 1.0, dt)
+    targs = ([2, 2], [1, 1], [1, 1], True, [1, 1], 1)
+    reft = aten.convolution(xt, wt, bt, *targs)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), to_sten(xt), to_sten(wt), to_sten(bt), i64_array([2, 2]), i64_array([1, 1]), i64_array([1, 1]), 2, 1,
+                         i64_array([1, 1]), 1)
+    assert_close(to_torch(S.STen(o)), reft.double(), FWD_TOL[dt], "transposed conv")
+    gy = closed_form(tuple(reft.shape), 23, 1.0, dt)
+    refb = aten.convolution_backward(gy, xt, wt, [3], *targs, [True, True, True])
+    out = _out3()
+    lib.lamp_convolution_backward(out, to_sten(gy), to_sten(xt), to_sten(wt), i64_array([2, 2]), i64_array([1, 1]), i64_array([1, 1]), 2, 1,
+                                  i64_array([1, 1]), 1, _mask3(1, 1, 1))
+    dx, dw, db = _wrap3(out)
+    assert_close(to_torch(dx), refb[0].double(), 1e-4, "transposed dgrad")
+    assert_close(to_torch(dw), refb[1].double(), 1e-4, "transposed wgrad")
+    assert_close(to_torch(db), refb[2].double(), 1e-4, "transposed bias grad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_pooling(gpu, dt):
+    x = closed_form((3, 5, 8, 8), 3, 2.0, dt)
+    X = to_sten(x)
+    tol = FWD_TOL[dt]
+    for (k, s, p) in [(8, 1, 0), (2, 2, 0), (3, 2, 1)]:
+        ref = aten.avg_pool2d(x, [k], [s], [p], False, True, None)
+        o = C.c_void_p(); lib.lamp_avg_pool2d(C.byref(o), X, k, s, p, 0, 1)
+        assert_close(to_torch(S.STen(o)), ref.double(), tol * 2, "avg_pool2d")
+        gy = closed_form(tuple(ref.shape), 9, 1.0, dt)
+        refb = aten.avg_pool2d_backward(gy, x, [k], [s], [p], False, True, None)
+        o = C.c_void_p(); lib.lamp_avg_pool2d_backward(C.byref(o), to_sten(gy), X, k, s, p, 0, 1)
+        assert_close(to_torch(S.STen(o)), refb.double(), tol * 2, "avg_pool2d backward")
+    for (k, s, p, d) in [(2, 2, 0, 1), (3, 2, 1, 1), (3, 1, 1, 2)]:
+        ref, idx = aten.max_pool2d_with_indices(x, [k], [s], [p], [d], False)
+        o, i = C.c_void_p(), C.c_void_p()
+        lib.lamp_max_pool2d_with_indices(C.byref(o), C.byref(i), X, k, s, p, d, 0)
+        O, I = S.STen(o), S.STen(i)
+        assert_close(to_torch(O), ref.double(), 0.0, "max_pool values (exact)")
+        assert np.array_equal(I.to_numpy(), idx.numpy()), "max_pool indices must be bit-exact"
+        gy = closed_form(tuple(ref.shape), 9, 1.0, dt)
+        refb = aten.max_pool2d_with_indices_backward(gy, x, [k], [s], [p], [d], False, idx)
+        o = C.c_void_p(); lib.lamp_max_pool2d_with_indices_backward(C.byref(o), to_sten(gy), X, k, s, p, d, 0, I)
+        assert_close(to_torch(S.STen(o)), refb.double(), tol * 2, "max_pool backward")
+
+
+def test_index_ops_bit_exact(gpu):
+    x = closed_form((50, 3), 3, 2.0, torch.float64)
+    idx = (torch.arange(120) * 7) % 50
+    X, I = to_sten(x), to_sten(idx)
+    assert np.array_equal(X.indexSelect(0, I).to_numpy(), x.index_select(0, idx).numpy())
+    assert np.array_equal(X.indexSelect(1, to_sten(torch.tensor([2, 0]))).to_numpy(), x.index_select(1, torch.tensor([2, 0])).numpy())
+    src = closed_form((120, 3), 9, 1.0, torch.float64)
+    got = X.indexAdd(0, I, to_sten(src)).to_numpy()
+    np.testing.assert_allclose(got, x.index_add(0, idx, src).numpy(), rtol=1e-13, atol=1e-13)
+    m = x > 0.1
+    assert np.array_equal(X.maskedSelect(to_sten(m)).to_numpy(), x.masked_select(m).numpy())
+    big = closed_form((100001,), 1, 2.0, torch.float32)
+    mb = big > 0
+    assert np.array_equal(to_sten(big).maskedSelect(to_sten(mb)).to_numpy(), big.masked_select(mb).numpy())
+    assert np.array_equal(I.repeatInterleave(5, 0).to_numpy(), idx.repeat_interleave(5, 0).numpy())
+    assert np.array_equal(I.oneHot(50).to_numpy(), torch.nn.functional.one_hot(idx, 50).numpy())
+    d = closed_form((7, 1000), 5, 2.0, torch.float32)
+    v, ix = to_sten(d).topk(10, 1, False, False)
+    rv, rix = aten.topk(d, 10, 1, False, True)
+    assert np.array_equal(np.sort(ix.to_numpy(), 1), np.sort(rix.numpy(), 1)), "top-k index sets"
+    assert np.array_equal(np.sort(v.to_numpy(), 1), np.sort(rv.numpy(), 1))
+    v, ix = to_sten(d).topk(3, 1, True, True)
+    rv, rix = aten.topk(d, 3, 1, True, True)
+    assert np.array_equal(v.to_numpy(), rv.numpy())
+
+
+def test_rng_statistics(gpu):
+    lib.lamp_manual_seed(42)
+    u = S.STen.rand([200000], S.F32).to_numpy()
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3 and abs(u.var() - 1 / 12) < 5e-3
+    n = S.STen.normal(1.0, 2.0, [200000], S.F64).to_numpy()
+    assert abs(n.mean() - 1.0) < 2e-2 and abs(n.std() - 2.0) < 2e-2
+    r = S.STen.randint(0, 7, [100000]).to_numpy()
+    assert r.min() == 0 and r.max() == 6 and r.dtype == np.int64
+    lib.lamp_manual_seed(42)
+    u2 = S.STen.rand([200000], S.F32).to_numpy()
+    assert np.array_equal(u, u2), "same seed, same stream"
+    ones = S.STen.ones([100000], S.F32)
+    ones.dropout_(0.25, True)
+    o = ones.to_numpy()
+    assert set(np.unique(o)).issubset({0.0, np.float32(1 / 0.75)}) and abs((o == 0).mean() - 0.25) < 1e-2
+
+
+def test_errors_are_loud(gpu):
+    a = to_sten(closed_form((3, 4), 0, 1.0, torch.float32))
+    b = to_sten(closed_form((5, 4), 0, 1.0, torch.float32))
+    with pytest.raises(Exception, match="broadcast"):
+        a + b
+    with pytest.raises(Exception, match="multiplied"):
+        a.mm(b)
+    with pytest.raises(Exception, match="dtype"):
+        a + to_sten(closed_form((3, 4), 0, 1.0, torch.float64))
+    host = S.STen.zeros([3, 4], S.F32, device=S.CPU)
+    with pytest.raises(Exception, match="no CPU compute"):
+        host.relu()
+
+
+def test_allocation_registry(gpu):
+    import gc
+    gc.collect()
+    n0 = S.live_tensor_count()
+    t = [S.STen.zeros([128, 128]) for _ in range(10)]
+    assert S.live_tensor_count() == n0 + 10
+    del t
+    gc.collect()
+    assert S.live_tensor_count() == n0
