@@ -1,0 +1,99 @@
+/*
+ * lamp_host.h - C ABI of the host-side mirror of lamp-core's autograd / nn / optimiser layer.
+ *
+ * In the reference this layer is Scala running on the JVM ABOVE the JNI boundary
+ * (lamp-core/src/main/scala/lamp/autograd/{autograd,ops}.scala, lamp/nn/*.scala,
+ * lamp-data/.../distributed/package.scala); it only sequences aten.* calls.  No JVM exists in
+ * the build environment, so the same sequencing logic is restated in C++ over lamp_hip.h and
+ * exported here so that the parity tests and bench.py can drive the exact op sequences the
+ * reference would issue.  A JVM deployment does not need this header: lamp-core itself runs
+ * unchanged on top of lamp_hip.h.
+ *
+ * Same conventions as lamp_hip.h: int status, lamp_last_error(), out-params own +1 handle.
+ */
+#ifndef LAMP_HOST_H
+#define LAMP_HOST_H
+
+#include "lamp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lamp_var lamp_var;             /* lamp.autograd.Variable (autograd.scala:176) */
+typedef struct lamp_module lamp_module;       /* lamp.nn.GenericModule (Module.scala:272) */
+typedef struct lamp_optimizer lamp_optimizer; /* lamp.nn.Optimizer (Optimizer.scala:5) */
+typedef struct lamp_model lamp_model;         /* lamp.nn.SupervisedModel (SupervisedModel.scala:151) */
+
+/* ---- variables (autograd/package.scala:60-78; autograd.scala:176-282) ---- */
+int lamp_var_const(lamp_var** out, const lamp_tensor* value);
+int lamp_var_param(lamp_var** out, const lamp_tensor* value);
+int lamp_var_value(const lamp_var* v, lamp_tensor** out);
+int lamp_var_grad(const lamp_var* v, lamp_tensor** out);          /* *out = NULL when needsGrad is false */
+int lamp_var_needs_grad(const lamp_var* v, int* out);
+int lamp_var_zero_grad(lamp_var* v);
+int lamp_var_backprop(lamp_var* v);                               /* Variable.backprop */
+int lamp_var_wengert_size(const lamp_var* v, int64_t* out);       /* length of the topological order */
+int lamp_var_release(lamp_var* v);
+
+/* One entry point for every Op case class of ops.scala, selected by its Scala name
+ * ("MatMul", "Add", "Relu", "Convolution", "BatchNorm2D", "NllLoss", ...):
+ *   vars    - Variable inputs in the order of the case class parameters (NULL for absent options)
+ *   tensors - plain tensor arguments (targets, weights, running statistics)
+ *   d / i   - double / long scalar arguments in declaration order */
+int lamp_op_apply(lamp_var** out, const char* name, lamp_var* const* vars, int nvars, lamp_tensor* const* tensors, int ntensors,
+                  const double* d, int nd, const int64_t* i, int ni);
+
+/* ---- modules (lamp/nn) ---- */
+int lamp_module_linear(lamp_module** out, int64_t in, int64_t outf, int dtype, int device, int bias);
+int lamp_module_conv2d(lamp_module** out, int64_t in_channels, int64_t out_channels, int64_t kernel, int dtype, int device, int bias,
+                       int64_t stride, int64_t padding, int64_t dilation, int64_t groups);
+int lamp_module_batch_norm(lamp_module** out, int64_t features, int dtype, int device, int two_d);
+int lamp_module_layer_norm(lamp_module** out, const int64_t* shape, int nshape, int dtype, int device, int scale, int bias);
+int lamp_module_dropout(lamp_module** out, double p);
+int lamp_module_fun(lamp_module** out, const char* name, double a, double b);
+int lamp_module_sequential(lamp_module** out, lamp_module* const* mods, int n);
+int lamp_module_residual(lamp_module** out, lamp_module* right, lamp_module* left_or_null);
+int lamp_module_mlp(lamp_module** out, int64_t in, int64_t outf, const int64_t* hidden, int nhidden, int dtype, int device, double dropout,
+                    int last_non_linearity, const char* activation, int norm, int bias);
+/* Cnn.resnet (example-cifar100/src/main/scala/lamp/example/cifar/cnn.scala:89-137) */
+int lamp_module_resnet(lamp_module** out, int64_t num_classes, double dropout, int dtype, int device);
+int lamp_module_forward(lamp_module* m, lamp_var* x, lamp_var** out);
+int lamp_module_num_state(lamp_module* m, int64_t* out);
+int lamp_module_state(lamp_module* m, int64_t index, lamp_var** out);   /* state in lamp's order (params and consts) */
+int lamp_module_set_training(lamp_module* m, int training);              /* asTraining / asEval */
+int lamp_module_zero_grad(lamp_module* m);
+int lamp_module_release(lamp_module* m);
+
+/* ---- optimisers (nn/AdamW.scala, nn/SGD.scala); clip < 0 means None ---- */
+int lamp_optimizer_adamw(lamp_optimizer** out, lamp_tensor* const* params, int n, double weight_decay, double learning_rate, double beta1,
+                         double beta2, double eps, double clip, int debias, int mixed_precision);
+int lamp_optimizer_sgdw(lamp_optimizer** out, lamp_tensor* const* params, int n, double learning_rate, double weight_decay,
+                        double momentum /* < 0: none */, double clip);
+int lamp_optimizer_step(lamp_optimizer* o, lamp_tensor* const* gradients /* NULL entries = None */, int n, double schedule_factor);
+int lamp_optimizer_num_state(lamp_optimizer* o, int64_t* out);
+int lamp_optimizer_state(lamp_optimizer* o, int64_t index, lamp_tensor** out);
+int lamp_optimizer_release(lamp_optimizer* o);
+/* nn/package.scala:72-100 */
+int lamp_gradient_clipping_in_place(lamp_tensor* const* gradients, int n, double theta);
+
+/* ---- supervised model + training steps ---- */
+/* loss_kind 0: LossFunctions.NLL(numClasses, classWeights, reduction, ignore) ; 1: MSE ; 2: Identity */
+int lamp_model_create(lamp_model** out, lamp_module* module, int loss_kind, const lamp_tensor* class_weights_or_null, int64_t reduction,
+                      int64_t ignore_index);
+/* SupervisedModel.addTotalLossAndReturnGradientsAndNumExamples (SupervisedModel.scala:190-211):
+ * forward, loss, zero grads, backprop; acc += loss * n. Gradients are left in the parameters' grad buffers. */
+int lamp_model_gradients(lamp_model* m, const lamp_tensor* samples, const lamp_tensor* target, lamp_tensor* acc_or_null, int zero_grad,
+                         int64_t* num_examples);
+int lamp_model_forward_loss(lamp_model* m, const lamp_tensor* samples, const lamp_tensor* target, lamp_tensor* acc_or_null,
+                            int64_t* num_examples);
+/* one full step = gradients + (optional RCCL exchange) + optimizer.step, as IOLoops.oneEpoch's processBatch
+ * (lamp-data/.../IOLoops.scala:621-658) or distributed oneBatch (distributed/package.scala:733-759) */
+int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm_or_null, const lamp_tensor* samples, const lamp_tensor* target,
+                          lamp_tensor* acc_or_null, int64_t* num_examples);
+int lamp_model_release(lamp_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMP_HOST_H */

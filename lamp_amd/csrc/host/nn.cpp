@@ -1,0 +1,232 @@
+// lamp.nn over the C ABI - see nn.h for the reference map.
+#include "nn.h"
+
+namespace lamp {
+namespace host {
+
+// ---- Linear (nn/Linear.scala:19-33, init :45-66) -------------------------------------------------
+Mod Linear::make(int64_t in, int64_t out, int dtype, int device, bool bias) {
+  Var w = make_param(ops::normal(0.0, std::sqrt(2.0 / (double)(in + out)), {in, out}, dtype, device));
+  Var b = bias ? make_param(ops::zeros({1, out}, dtype, device)) : nullptr;
+  return std::make_shared<Linear>(w, b);
+}
+Var Linear::forward(const Var& x) {
+  Var v;
+  if (x->value.ndim() == 2) v = F::mm(x, weights);
+  else {  // mm1: view(-1, last).mm(w).view(shape.dropRight(1) :+ -1)
+    auto shape = x->shape();
+    Var x2 = F::view(x, {-1, shape.back()});
+    Var y = F::mm(x2, weights);
+    shape.back() = -1;
+    v = F::view(y, shape);
+  }
+  return bias ? F::add(bias, v) : v;   // bias.map(_ + v)
+}
+
+// ---- Conv2D (nn/Conv2D.scala:22-34, init :51-82) --------------------------------------------------
+Mod Conv2D::make(int64_t inC, int64_t outC, int64_t k, int dtype, int device, bool bias, int64_t stride, int64_t padding, int64_t dilation,
+                 int64_t groups) {
+  auto m = std::make_shared<Conv2D>();
+  m->weights = make_param(ops::normal(0.0, std::sqrt(2.0 / (double)(outC + inC)), {outC, inC / groups, k, k}, dtype, device));
+  Ten b = ops::zeros({outC}, dtype, device);
+  m->bias = bias ? make_param(b) : make_const(b);
+  m->stride = stride; m->padding = padding; m->dilation = dilation; m->groups = groups;
+  return m;
+}
+Var Conv2D::forward(const Var& x) {
+  return F::convolution(x, weights, bias, {stride, stride}, {padding, padding}, {dilation, dilation}, false, {0, 0}, groups);
+}
+
+// ---- BatchNorm / BatchNorm2D (init: weight N(0, 0.01), bias 0, running mean 0, running var 0) ----
+Mod BatchNorm::make(int64_t features, int dtype, int device, bool two_d) {
+  auto m = std::make_shared<BatchNorm>();
+  m->weight = make_param(ops::normal(0.0, 0.01, {features}, dtype, device));
+  m->bias = make_param(ops::zeros({features}, dtype, device));
+  m->runningMean = make_const(ops::zeros({features}, dtype, device));
+  m->runningVar = make_const(ops::zeros({features}, dtype, device));
+  m->two_d = two_d;
+  return m;
+}
+Var BatchNorm::forward(const Var& x) {
+  return two_d ? F::batch_norm_2d(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps)
+               : F::batch_norm(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
+}
+Mod LayerNorm::make(const std::vector<int64_t>& shape, int dtype, int device, bool scale, bool bias) {
+  auto m = std::make_shared<LayerNorm>();
+  m->normalizedShape = shape;
+  if (scale) m->scale = make_param(ops::ones(shape, dtype, device));
+  if (bias) m->bias = make_param(ops::zeros(shape, dtype, device));
+  return m;
+}
+
+Mod make_fun(const std::string& name, double a, double b) {
+  if (name == "relu") return std::make_shared<Fun>([](const Var& x) { return F::relu(x); });
+  if (name == "gelu") return std::make_shared<Fun>([](const Var& x) { return F::gelu(x); });
+  if (name == "sigmoid") return std::make_shared<Fun>([](const Var& x) { return F::sigmoid(x); });
+  if (name == "tanh") return std::make_shared<Fun>([](const Var& x) { return F::tanh(x); });
+  if (name == "hardswish") return std::make_shared<Fun>([](const Var& x) { return F::hardswish(x); });
+  if (name == "swish1") return std::make_shared<Fun>([](const Var& x) { return F::mult(x, F::sigmoid(x)); });
+  if (name == "logsoftmax") return std::make_shared<Fun>([a](const Var& x) { return F::log_softmax(x, (int64_t)a); });
+  if (name == "avgpool2d") return std::make_shared<Fun>([a, b](const Var& x) { return F::avg_pool2d(x, (int64_t)a, (int64_t)b, 0); });
+  if (name == "maxpool2d") return std::make_shared<Fun>([a, b](const Var& x) { return F::max_pool2d(x, (int64_t)a, (int64_t)b, 0, 1); });
+  if (name == "flatten_last") return std::make_shared<Fun>([a](const Var& x) { return F::flatten(x, x->value.ndim() - (int64_t)a, -1); });
+  LAMP_CHECK(false, "unknown Fun module '" << name << "'");
+  return nullptr;
+}
+
+// ---- Residual.make / Cnn.resnet (cnn.scala:33-137) -------------------------------------------------
+Mod residual_make(int64_t inC, int64_t outC, int dtype, int device, double dropout, int64_t stride) {
+  std::vector<Mod> right = {
+      Conv2D::make(inC, outC, 3, dtype, device, false, stride, 1, 1, 1), BatchNorm::make(outC, dtype, device, true), make_fun("relu"),
+      std::make_shared<Dropout>(dropout, true), Conv2D::make(outC, outC, 3, dtype, device, false, 1, 1, 1, 1),
+      BatchNorm::make(outC, dtype, device, true)};
+  Mod left;
+  if (!(inC == outC && stride == 1)) {
+    left = std::make_shared<Sequential>(std::vector<Mod>{Conv2D::make(inC, outC, 1, dtype, device, false, stride, 0, 1, 1),
+                                                         BatchNorm::make(outC, dtype, device, true)});
+  }
+  return std::make_shared<Sequential>(std::vector<Mod>{std::make_shared<Residual>(std::make_shared<Sequential>(right), left),
+                                                       make_fun("relu"), std::make_shared<Dropout>(dropout, true)});
+}
+Mod cnn_resnet(int64_t numClasses, double dropout, int dtype, int device) {
+  return std::make_shared<Sequential>(std::vector<Mod>{
+      Conv2D::make(3, 6, 5, dtype, device, false, 1, 2, 1, 1),
+      std::make_shared<Sequential>(std::vector<Mod>{residual_make(6, 6, dtype, device, dropout, 2), residual_make(6, 16, dtype, device, dropout, 2),
+                                                    residual_make(16, 128, dtype, device, dropout, 1),
+                                                    residual_make(128, numClasses, dtype, device, dropout, 1)}),
+      make_fun("avgpool2d", 8, 1), make_fun("flatten_last", 3), make_fun("logsoftmax", 1)});
+}
+
+// ---- MLP.apply (nn/MLP.scala:40-167) -------------------------------------------------------------
+Mod mlp(int64_t in, int64_t out, const std::vector<int64_t>& hidden, int dtype, int device, double dropout, bool lastNonLinearity,
+        const std::string& activation, int norm, bool bias) {
+  // hasBias: LayerNorm(bias=true) and BatchNorm disable the Linear bias (MLP.scala:85-88)
+  const bool hasBias = (norm == 1 || norm == 2) ? false : bias;
+  auto make_norm = [&](int64_t dim) -> std::vector<Mod> {
+    if (norm == 1) return {BatchNorm::make(dim, dtype, device, false)};
+    if (norm == 2) return {LayerNorm::make({dim}, dtype, device, true, true)};
+    return {};
+  };
+  auto block = [&](int64_t i, int64_t o, bool nonlin) {
+    std::vector<Mod> m = {Linear::make(i, o, dtype, device, hasBias)};
+    for (auto& n : make_norm(o)) m.push_back(n);
+    if (nonlin) { m.push_back(make_fun(activation)); m.push_back(std::make_shared<Dropout>(dropout, true)); }
+    return std::make_shared<Sequential>(m);
+  };
+  std::vector<Mod> layers;
+  int64_t prev = in;
+  for (int64_t h : hidden) { layers.push_back(block(prev, h, true)); prev = h; }
+  layers.push_back(block(prev, out, lastNonLinearity));
+  return std::make_shared<Sequential>(layers);
+}
+
+// ---- AdamW (nn/AdamW.scala) -----------------------------------------------------------------------
+static bool is_low_precision(int dt) { return dt == kF16 || dt == kBF16; }
+AdamW::AdamW(const std::vector<Ten>& params, double wd, double lr, double b1, double b2, double eps_, bool has_clip_, double clip_,
+             bool debias_, bool mixed)
+    : parameters(params), weightDecay(wd), learningRate(lr), beta1(b1), beta2(b2), eps(eps_), has_clip(has_clip_), clip(clip_),
+      debias(debias_), mixedPrecision(mixed) {
+  for (auto& p : parameters) {
+    const bool up = mixedPrecision && is_low_precision(p.dtype());
+    workingCopy.push_back(up ? ops::cast(p, kF32) : Ten());
+    Ten z = ops::zeros_like(p);
+    mt.push_back(up ? ops::cast(z, kF32) : z);
+    vt.push_back(up ? ops::cast(z, kF32) : ops::zeros_like(p));
+  }
+  stepCountSTen = ops::scalar(0.0, kF64, parameters.empty() ? 0 : parameters[0].device());
+}
+std::vector<Ten> AdamW::state() {
+  std::vector<Ten> s = {stepCountSTen};
+  for (auto& t : mt) s.push_back(t);
+  for (auto& t : vt) s.push_back(t);
+  for (auto& t : workingCopy) if (t.defined()) s.push_back(t);
+  return s;
+}
+void AdamW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
+  LAMP_CHECK(gradients.size() == parameters.size(), "AdamW.step: got " << gradients.size() << " gradients for " << parameters.size() << " parameters");
+  std::vector<lamp_tensor*> p, g, m, v, w;
+  for (size_t i = 0; i < parameters.size(); i++) {
+    if (!gradients[i].defined()) continue;
+    p.push_back(parameters[i].h()); g.push_back(gradients[i].h()); m.push_back(mt[i].h()); v.push_back(vt[i].h());
+    w.push_back(workingCopy[i].h());
+  }
+  if (has_clip && !g.empty()) HCALL(lamp_gradient_clipping_(g.data(), (int)g.size(), clip));
+  stepCount += 1;
+  HCALL(lamp_add_scalar_(stepCountSTen.h(), 1.0, 1.0));
+  const int n = (int)p.size();
+  std::vector<double> lr(n, learningRate), wd(n, weightDecay), b1(n, beta1), b2(n, beta2);
+  HCALL(lamp_adamw_step_(p.data(), g.data(), m.data(), v.data(), w.data(), n, lr.data(), wd.data(), b1.data(), b2.data(), eps, scheduleFactor,
+                         stepCount, debias));
+}
+
+SGDW::SGDW(const std::vector<Ten>& params, double lr, double wd, bool has_m, double mom, bool has_clip_, double clip_)
+    : parameters(params), learningRate(lr), weightDecay(wd), momentum(mom), has_momentum(has_m), has_clip(has_clip_), clip(clip_) {
+  if (has_momentum) for (auto& p : parameters) velocity.push_back(ops::zeros_like(p));
+}
+void SGDW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
+  LAMP_CHECK(gradients.size() == parameters.size(), "SGDW.step: gradient count mismatch");
+  std::vector<lamp_tensor*> p, g, v;
+  for (size_t i = 0; i < parameters.size(); i++) {
+    if (!gradients[i].defined()) continue;
+    p.push_back(parameters[i].h()); g.push_back(gradients[i].h());
+    v.push_back(has_momentum ? velocity[i].h() : nullptr);
+  }
+  if (has_clip && !g.empty()) HCALL(lamp_gradient_clipping_(g.data(), (int)g.size(), clip));
+  const int n = (int)p.size();
+  std::vector<double> lr(n, learningRate), wd(n, weightDecay), mom(n, momentum);
+  HCALL(lamp_sgdw_step_(p.data(), g.data(), v.data(), n, lr.data(), wd.data(), mom.data(), scheduleFactor));
+}
+
+// ---- SupervisedModel -------------------------------------------------------------------------------
+std::pair<Var, int64_t> SupervisedModel::loss(const Var& output, const Ten& target) {
+  if (loss_kind == 0) return {F::nll_loss(output, target, classWeights, reduction, ignore), output->value.size(0)};
+  if (loss_kind == 1) return {F::mse_loss(output, target, 1), output->value.size(0)};
+  return {output, target.size(0)};
+}
+int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten& samples, const Ten& target, const Ten& acc, bool zeroGrad,
+                                                                      std::vector<Ten>* gradients) {
+  Var output = module->forward(make_const(samples));          // BatchStream emits const(features) (BatchStream.scala:562)
+  auto ln = loss(output, target);
+  std::vector<Ten> g = module->gradients(ln.first, zeroGrad);
+  if (acc.defined()) {                                         // acc += (loss.value * numInstances.toDouble)
+    Ten scaled = ops::mul_scalar(ln.first->value, (double)ln.second);
+    ops::add_(acc, ops::reshape(scaled, acc.shape()));
+  }
+  if (gradients) *gradients = g;
+  return ln.second;
+}
+int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, const Ten& target, const Ten& acc) {
+  Var output = module->forward(make_const(samples));
+  auto ln = loss(output, target);
+  if (acc.defined()) {
+    Ten scaled = ops::mul_scalar(ln.first->value, (double)ln.second);
+    ops::add_(acc, ops::reshape(scaled, acc.shape()));
+  }
+  return ln.second;
+}
+
+// ---- data parallel step ------------------------------------------------------------------------------
+int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc) {
+  std::vector<Ten> grads;
+  const int64_t n = model.addTotalLossAndReturnGradientsAndNumExamples(samples, target, acc, true, &grads);
+  if (comm) {
+    // averageGradients (distributed/package.scala:690-719): g *= n ; reduce(n) ; reduce(g) ; g /= sum n.
+    // Here: one flat f32 bucket [n*g_0 | n*g_1 | ... | n], one all-reduce, every rank divides by the summed n.
+    std::vector<lamp_tensor*> gh;
+    int64_t total = 0;
+    for (auto& g : grads) { gh.push_back(g.h()); total += g.numel(); }
+    if (!bucket.defined() || bucket.numel() != total + 1) bucket = ops::zeros({total + 1}, kF32, grads[0].device());
+    HCALL(lamp_flatten_into_(bucket.h(), gh.data(), (int)gh.size(), (double)n));
+    Ten last = ops::slice(bucket, 0, total, total + 1, 1);
+    ops::fill_(last, (double)n);
+    lamp_tensor* bt[1] = {bucket.h()};
+    lamp_comm* cm[1] = {comm};
+    HCALL(lamp_comm_all_reduce(bt, cm, 1, 0));
+    HCALL(lamp_unflatten_from_(gh.data(), (int)gh.size(), bucket.h(), 1));
+  }
+  opt.step(grads, 1.0);
+  return n;
+}
+
+}  // namespace host
+}  // namespace lamp

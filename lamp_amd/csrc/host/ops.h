@@ -1,0 +1,60 @@
+// lamp's autograd operators (lamp-core/src/main/scala/lamp/autograd/ops.scala) over the C ABI.
+#pragma once
+#include "autograd.h"
+
+namespace lamp {
+namespace host {
+namespace F {
+
+Var transpose(const Var& a, int64_t d1 = 0, int64_t d2 = 1);
+Var view(const Var& a, const std::vector<int64_t>& shape);
+Var reshape(const Var& a, const std::vector<int64_t>& shape);
+Var flatten(const Var& a, int64_t start, int64_t end = -1);
+Var concatenate(const std::vector<Var>& as, int64_t dim);
+Var add(const Var& a, const Var& b);
+Var const_add(const Var& a, double b);
+Var minus(const Var& a, const Var& b);
+Var const_mult(const Var& a, double b);
+Var mult(const Var& a, const Var& b);
+Var div(const Var& a, const Var& b);
+Var sum(const Var& a, const std::vector<int64_t>& dim = {}, bool keepDim = false);
+Var mean(const Var& a, const std::vector<int64_t>& dim, bool keepDim = true);
+Var norm2(const Var& a, const std::vector<int64_t>& dim, bool keepDim);
+Var mm(const Var& a, const Var& b);
+Var bmm(const Var& a, const Var& b);
+Var exp(const Var& a);
+Var log(const Var& a);
+Var log1p(const Var& a);
+Var sin(const Var& a);
+Var cos(const Var& a);
+Var tanh(const Var& a);
+Var pow_const(const Var& a, double e);
+Var relu(const Var& a);
+Var leaky_relu(const Var& a, double slope);
+Var gelu(const Var& a);
+Var sigmoid(const Var& a);
+Var hardswish(const Var& a);
+Var softplus(const Var& a, double beta, double threshold);
+Var log_softmax(const Var& a, int64_t dim);
+Var dropout(const Var& a, double prob, bool train);
+Var nll_loss(const Var& input, const Ten& target, const Ten& weights, int64_t reduction = 1, int64_t ignore = -100);
+Var mse_loss(const Var& input, const Ten& target, int64_t reduction = 1);
+Var index_select(const Var& input, int64_t dim, const Var& index);
+Var euclidean_distance(const Var& a, const Var& b, int64_t dim);
+Var capped_shifted_negative_exponential(const Var& a, double shift);
+Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
+                const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
+                const std::vector<int64_t>& outputPadding, int64_t groups);
+Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding);
+Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation);
+Var batch_norm(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,
+               double momentum, double eps);
+Var batch_norm_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,
+                  double momentum, double eps);
+Var layer_norm(const Var& input, const Var& weight /*nullable*/, const Var& bias /*nullable*/, const std::vector<int64_t>& normalizedShape,
+               double eps);
+Var embedding(const Var& input, const Var& weight);
+
+}  // namespace F
+}  // namespace host
+}  // namespace lamp

@@ -1,0 +1,185 @@
+"""HIP path vs the reference's known-answer tests and vs the oracle, through the host C ABI.
+
+1. Every KAT of tests/kats.py (the reference's own `testGradientAndValue` cases) runs on the GPU in
+   float64 with the reference's acceptance rule: value to 4 decimals, autograd gradient == central
+   finite difference to 4 decimals.
+2. Optimiser KATs (exact AdamW/SGDW values, gradient clipping).
+3. Composite parity vs the oracle on deterministic closed-form inputs: MLP step (BASELINE config 1),
+   CIFAR ResNet step, several optimiser steps; f32 forward <= 1e-5, gradients <= 1e-3 (BASELINE.json).
+"""
+import numpy as np
+import pytest
+import torch
+
+from lamp_amd import autograd as A
+from lamp_amd import nn
+from lamp_amd import sten as S
+from oracle import lamp_oracle as O
+from tests import kats
+from tests.backends import HipBackend, OracleBackend
+from tests.util import assert_close, to_sten, to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(kats.CASES))
+def test_reference_kat_on_gpu(gpu, name):
+    B = HipBackend()
+    value, grad = kats.run_case(B, name)
+    assert round(value, 4) == round(kats.EXPECTED[name], 4), (name, value, kats.EXPECTED[name])
+    fd = kats.finite_difference(B, name)
+    assert np.array_equal(np.round(grad, 4) + 0.0, np.round(fd, 4) + 0.0), (name, grad, fd)
+    # and bitwise-close to the oracle in float64
+    ovalue, ograd = kats.run_case(OracleBackend(), name)
+    assert abs(value - ovalue) <= 1e-12 * max(1.0, abs(ovalue))
+    np.testing.assert_allclose(grad, ograd, rtol=1e-10, atol=1e-12)
+
+
+def test_adamw_kats_on_gpu(gpu):
+    g = kats.GOLDEN["adamw"]
+    for key in ("no_weight_decay", "weight_decay"):
+        p = S.STen.from_numpy(np.array([g["init"]]), dtype=S.F64)
+        grad = S.STen.from_numpy(np.array([g["gradients"]]), dtype=S.F64)
+        opt = nn.AdamW([p], weightDecay=g[key]["weightDecay"], learningRate=g["learningRate"], beta1=g["beta1"], beta2=g["beta2"])
+        for step in ("step1", "step2"):
+            opt.step([grad], 1.0)
+            np.testing.assert_allclose(p.to_numpy()[0], g[key][step], rtol=1e-14, atol=0)
+            assert np.array_equal(np.round(p.to_numpy()[0], 10), np.round(g[key][step], 10))
+        assert opt.state[0].to_numpy() == 2.0          # stepCount scalar is state()[0] (AdamW.scala:97)
+    # mixed precision (bf16 parameters, f32 working copy): same trajectory as the oracle
+    p0 = torch.tensor([g["init"]], dtype=torch.float64).bfloat16()
+    gr = torch.tensor([g["gradients"]], dtype=torch.float64).bfloat16()
+    po = p0.clone()
+    oo = O.AdamW([po], weightDecay=1e-5, learningRate=0.1, beta1=0.999, beta2=0.9, mixedPrecision=True)
+    ph, gh = to_sten(p0), to_sten(gr)
+    oh = nn.AdamW([ph], weightDecay=1e-5, learningRate=0.1, beta1=0.999, beta2=0.9, mixedPrecision=True)
+    for _ in range(3):
+        oo.step([gr], 1.0); oh.step([gh], 1.0)
+        assert np.array_equal(ph.to_numpy(), po.float().numpy()), "bf16 parameters must round identically"
+
+
+def test_sgd_and_clipping_kats_on_gpu(gpu):
+    g = kats.GOLDEN["sgd"]
+    for key in ("noop", "no_momentum_no_wd", "no_momentum"):
+        p = S.STen.ones([1, 2], S.F64)
+        nn.SGDW([p], g[key]["lr"], g[key]["wd"]).step([S.STen.from_numpy(np.array([g[key]["grad"]]))], 1.0)
+        np.testing.assert_allclose(p.to_numpy()[0], g[key]["expect"], rtol=0, atol=1e-15)
+    p = S.STen.ones([1, 2], S.F64)
+    opt = nn.SGDW([p], 1.0, 0.1)
+    grad = S.STen.from_numpy(np.array([g["two_steps"]["grad"]]))
+    opt.step([grad], 1.0)
+    assert np.array_equal(np.round(p.to_numpy()[0], 4), np.round(g["two_steps"]["step1"], 4))
+    opt.step([grad], 1.0)
+    assert np.array_equal(np.round(p.to_numpy()[0], 4), np.round(g["two_steps"]["step2"], 4))
+    # momentum variant vs oracle
+    po = torch.ones(1, 2, dtype=torch.float64); ph = S.STen.ones([1, 2], S.F64)
+    oo, oh = O.SGDW([po], 0.5, 0.01, momentum=0.9), nn.SGDW([ph], 0.5, 0.01, momentum=0.9)
+    gt = torch.tensor([[0.5, 0.75]], dtype=torch.float64)
+    for _ in range(3):
+        oo.step([gt], 1.0); oh.step([to_sten(gt)], 1.0)
+    np.testing.assert_allclose(ph.to_numpy(), po.numpy(), rtol=1e-14)
+    c = kats.GOLDEN["gradient_clipping"]
+    ts = [S.STen.ones(s, S.F64) for s in c["shapes"]]
+    nn.gradientClippingInPlace(ts, c["theta"])
+    assert np.array_equal(np.round(ts[0].to_numpy().reshape(-1), 4), np.round(np.full(6, c["expect"]), 4))
+    np.testing.assert_allclose(ts[1].to_numpy().reshape(-1), np.full(2, c["expect"]), rtol=1e-14)
+
+
+def test_semantic_traps_on_gpu(gpu):
+    x = A.param(S.STen.from_numpy(np.array([[0.0, -1.0, 2.0]])))
+    x.relu().sum().backprop()
+    assert x.partialDerivative.to_numpy().tolist() == [[1.0, 0.0, 1.0]]          # gradient at 0 is 1
+    x = A.param(S.STen.ones([2, 2], S.F64))
+    (x + x).sum().backprop()
+    assert x.partialDerivative.to_numpy().tolist() == [[2.0, 2.0], [2.0, 2.0]]   # accumulate contract
+    c = A.const(S.STen.ones([2, 2], S.F64))
+    assert c.partialDerivative is None and not c.needsGrad
+    # Linear = mm then broadcast add of a [1, out] bias; BN running_var starts at 0
+    m = nn.BatchNorm2D(3, S.F64)
+    st = m.state
+    assert [v.needsGrad for v in st] == [True, True, False, False]
+    assert st[3].value.to_numpy().tolist() == [0.0, 0.0, 0.0]
+    lin = nn.Linear(4, 3, S.F64)
+    assert lin.state[1].shape == [1, 3]
+
+
+def _load_from_oracle(hip_module, oracle_module, dtype):
+    hip_module.load([S.STen.from_numpy(v.value.detach().double().numpy(), dtype=dtype) for v in oracle_module.state()])
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_mlp_step_matches_oracle(gpu, dt):
+    """BASELINE config 1: MLP(784 -> 256 -> 10, BatchNorm, relu, dropout 0) -> logSoftMax -> NLL(ones), B = 1024."""
+    ldt = S.F64 if dt == torch.float64 else S.F32
+    om = O.Sequential(O.mlp(784, 10, [256], dt), O.Fun(lambda v: v.logSoftMax(1)))
+    hm = nn.Sequential(nn.MLP(784, 10, [256], ldt), nn.Fun("logsoftmax", 1))
+    _load_from_oracle(hm, om, ldt)
+    x = O.closed_form(1024 * 784, 0, 1.0, dt).reshape(1024, 784)
+    target = torch.arange(1024) % 10
+    cw = torch.ones(10, dtype=dt)
+    oloss, ograds = O.training_step(om, O.nll_loss(10, cw), x, target, None)
+    model = nn.SupervisedModel(hm, nn.SupervisedModel.NLL, to_sten(cw))
+    acc = S.STen.zeros([1], ldt)
+    n, hgrads = model.addTotalLossAndReturnGradientsAndNumExamples(to_sten(x), to_sten(target), acc)
+    assert n == 1024
+    ftol, btol = (1e-11, 1e-9) if dt == torch.float64 else (1e-5, 1e-3)
+    assert_close(to_torch(acc) / 1024.0, oloss.double().reshape(1), ftol, "loss")
+    assert len(hgrads) == len(ograds) == 6
+    for i, (hg, og) in enumerate(zip(hgrads, ograds)):
+        assert_close(to_torch(hg), og.double(), btol, f"gradient {i}")
+    # running statistics were updated identically
+    for hv, ov in zip(hm.state, om.state()):
+        assert_close(to_torch(hv.value), ov.value.double(), ftol * 10, "state after step")
+
+
+@pytest.mark.parametrize("dt,B", [(torch.float64, 4), (torch.float32, 16)])
+def test_resnet_training_steps_match_oracle(gpu, dt, B):
+    """Cnn.resnet(100) forward + backprop + AdamW, 2 steps, closed-form weights and batch."""
+    ldt = S.F64 if dt == torch.float64 else S.F32
+    om = O.resnet(100, dt)
+    hm = nn.resnet(100, 0.0, ldt)
+    assert len(hm.state) == len(om.state()) == 74 and len(hm.parameters) == 37
+    _load_from_oracle(hm, om, ldt)
+    x = O.closed_form(B * 3 * 32 * 32, 5, 1.0, dt).reshape(B, 3, 32, 32)
+    target = (torch.arange(B) * 7) % 100
+    cw = torch.ones(100, dtype=dt)
+    oopt = O.AdamW([p.value for p in om.parameters()], weightDecay=0.0, learningRate=1e-3, beta1=0.9, beta2=0.95)
+    hopt = nn.AdamW([p.value for p in hm.parameters], weightDecay=0.0, learningRate=1e-3, beta1=0.9, beta2=0.95)
+    model = nn.SupervisedModel(hm, nn.SupervisedModel.NLL, to_sten(cw))
+    X, T = to_sten(x), to_sten(target)
+    ftol, btol = (1e-10, 1e-8) if dt == torch.float64 else (1e-5, 1e-3)
+    for step in range(2):
+        oloss, ograds = O.training_step(om, O.nll_loss(100, cw), x, target, None)
+        acc = S.STen.zeros([1], ldt)
+        n, hgrads = model.addTotalLossAndReturnGradientsAndNumExamples(X, T, acc)
+        assert_close(to_torch(acc) / B, oloss.double().reshape(1), ftol, f"loss step {step}")
+        for i, (hg, og) in enumerate(zip(hgrads, ograds)):
+            assert_close(to_torch(hg), og.double(), btol, f"step {step} gradient {i} shape {list(og.shape)}")
+        oopt.step(ograds, 1.0)
+        hopt.step(hgrads, 1.0)
+        for i, (hv, ov) in enumerate(zip(hm.state, om.state())):
+            assert_close(to_torch(hv.value), ov.value.double(), btol, f"step {step} state {i}")
+    # eval mode uses the running statistics
+    hm.asEval()
+    for mod in om.mods[1].mods:
+        pass
+    out_h = hm.forward(A.const(X)).value
+    assert out_h.shape == [B, 100]
+
+
+def test_train_step_entry_point(gpu):
+    """lamp_model_train_step == gradients + optimizer.step (single process, no communicator)."""
+    hm1, hm2 = nn.resnet(100, 0.0, S.F32), nn.resnet(100, 0.0, S.F32)
+    hm2.load([v.value for v in hm1.state])
+    x = to_sten(O.closed_form(8 * 3 * 32 * 32, 5, 1.0, torch.float32).reshape(8, 3, 32, 32))
+    t = to_sten((torch.arange(8) * 3) % 100)
+    cw = S.STen.ones([100], S.F32)
+    m1, m2 = nn.SupervisedModel(hm1, 0, cw), nn.SupervisedModel(hm2, 0, cw)
+    o1 = nn.AdamW_factory(0.0)([p.value for p in hm1.parameters])
+    o2 = nn.AdamW_factory(0.0)([p.value for p in hm2.parameters])
+    for _ in range(2):
+        n, g = m1.addTotalLossAndReturnGradientsAndNumExamples(x, t, None)
+        o1.step(g, 1.0)
+        assert m2.train_step(o2, x, t) == 8
+    for a, b in zip(hm1.state, hm2.state):
+        assert np.array_equal(a.value.to_numpy(), b.value.to_numpy())
