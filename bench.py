@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py - training-step throughput of the lamp hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic batch: Cnn.resnet(100) forward + backprop +
+AdamW on a device-resident batch of B = 2048 CIFAR-shaped images per GPU (BASELINE.json config 3/4;
+example-cifar100/src/main/scala/lamp/example/cifar/cnn.scala:89-137, run_cifar.sh:7), bf16 parameters
+and activations with fp32 working copies in AdamW (AdamW.scala:48-85).  With N > 1 every rank computes
+local gradients, one flat fp32 bucket is all-reduced over RCCL/xGMI, every rank applies the same step
+(weak scaling: B per GPU fixed).  One JSON line is printed by rank 0.
+
+Other workloads (parity-test configurations, not the headline line): --workload gemm | mlp.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp"])
+    ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
+    return ap.parse_args()
+
+
+def closed_form_np(n, salt=0, scale=1.0):
+    import numpy as np
+    i = np.arange(n, dtype=np.int64) + salt
+    return ((((i * 7919) % 1009).astype(np.float64) / 1009.0) - 0.5) * scale
+
+
+def kernel_report(lib):
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, n, ms, flops, byts = line.split()
+        rows.append({"tag": tag, "launches": int(n), "total_ms": float(ms), "flops": float(flops), "bytes": float(byts)})
+    return rows
+
+
+def roofline_of(rows):
+    """roofline object for the kernel class that took the most time in the timed region."""
+    if not rows:
+        return None
+    d = max(rows, key=lambda r: r["total_ms"])
+    avg_s = d["total_ms"] / d["launches"] / 1e3
+    ai = d["flops"] / max(d["bytes"], 1.0)
+    if d["flops"] > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
+        peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_BF16_TFLOPS
+        ach = d["flops"] / avg_s / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "kernel": d["tag"], "launches": d["launches"], "avg_us": avg_s * 1e6}
+    ach = d["bytes"] / avg_s / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "kernel": d["tag"], "launches": d["launches"], "avg_us": avg_s * 1e6}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    # CPU baseline first, in a child process, on rank 0 at N = 1 only (before this process touches the GPU)
+    cpu_baseline = None
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        try:
+            wl = {"resnet": "resnet", "gemm": "gemm", "mlp": "mlp"}[a.workload]
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--budget-s", "15"],
+                                 capture_output=True, text=True, timeout=600)
+            cpu_baseline = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # the baseline is informative; never fail the GPU measurement because of it
+            cpu_baseline = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+
+    from lamp_amd._capi import lib          # HIP library before torch (binds the system ROCm runtime)
+    lib.load()
+    lib.lamp_set_device(local_rank)
+    from lamp_amd import nn, sten as S
+    import numpy as np
+
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only (uid exchange, barrier, max)
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            lib.lamp_comm_get_unique_id(uid)
+        import torch
+        t = torch.tensor(list(uid), dtype=torch.uint8)
+        dist.broadcast(t, 0)
+        uid = (C.c_uint8 * 128)(*t.tolist())
+        ch = C.c_void_p()
+        lib.lamp_comm_init_rank(C.byref(ch), world, uid, rank)              # RCCL communicator (data plane, xGMI)
+        comm = ch
+
+    def barrier():
+        lib.lamp_device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    dtype = S.BF16 if a.dtype == "bf16" else S.F32
+    result_extra = {}
+    if a.workload == "resnet":
+        B = a.batch
+        lib.lamp_manual_seed(1234)                                   # same initial weights on every rank
+        model_mod = nn.resnet(100, 0.0, dtype, local_rank)
+        x = S.STen.from_numpy(closed_form_np(B * 3 * 32 * 32, 5 + rank * 7919).reshape(B, 3, 32, 32).astype(np.float32), local_rank, dtype)
+        target = S.STen.from_numpy(((np.arange(B) * 7 + rank) % 100).astype(np.int64), local_rank)
+        cw = S.STen.ones([100], dtype, local_rank)
+        model = nn.SupervisedModel(model_mod, nn.SupervisedModel.NLL, cw)
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3, mixedPrecision=(a.dtype == "bf16"))([p.value for p in model_mod.parameters])
+        acc = S.STen.zeros([1], dtype, local_rank)
+        step = lambda: model.train_step(opt, x, target, acc, comm)
+        units_per_step = B
+        metric, unit = "training-step samples/sec", "samples/s"
+        config = {"workload": "example-cifar100 Cnn.resnet(100) training step (fwd+backprop+AdamW), synthetic CIFAR batch",
+                  "per_gpu_batch": B, "global_batch": B * a.gpus, "parallelism": f"dp{a.gpus}" if a.gpus > 1 else "single",
+                  "optimizer": "AdamW lr 1e-3 wd 0 beta2 0.95" + (" mixedPrecision" if a.dtype == "bf16" else "")}
+    elif a.workload == "gemm":
+        n = 4096
+        A_ = S.STen.from_numpy((closed_form_np(n * n, 1, 2.0)).reshape(n, n).astype(np.float32), local_rank, dtype)
+        W_ = S.STen.from_numpy((closed_form_np(n * n, 77, 2.0)).reshape(n, n).astype(np.float32), local_rank, dtype)
+        bias = S.STen.from_numpy(closed_form_np(n, 3, 1.0).reshape(1, n).astype(np.float32), local_rank, dtype)
+        P_ = S.STen.ones([n, n], dtype, local_rank)
+        dW, dX = S.STen.zeros([n, n], dtype, local_rank), S.STen.zeros([n, n], dtype, local_rank)
+        out_h = C.c_void_p()
+
+        def step():
+            o = C.c_void_p()
+            lib.lamp_linear_bias(C.byref(o), A_, W_, bias)                   # y = x.W + b
+            y = S.STen(o)
+            S.STen.addmm_out_transposed1(dW, dW, A_, P_, 1.0, 1.0)          # dW += x^T p
+            S.STen.addmm_out_transposed2(dX, dX, P_, W_, 1.0, 1.0)          # dX += p W^T
+            return y
+        units_per_step = 3 * 2.0 * n ** 3 / 1e12
+        metric, unit = "4096x4096 addmm fwd+bwd", "TFLOP/s"
+        config = {"workload": "lamp Linear(4096,4096,bias) on x[4096,4096]: fwd addmm + dW (A^T.p) + dX (p.W^T)", "parallelism": "replicas"}
+    else:
+        B = 1024
+        model_mod = nn.Sequential(nn.MLP(784, 10, [256], S.F32, local_rank), nn.Fun("logsoftmax", 1))
+        x = S.STen.from_numpy(closed_form_np(B * 784).reshape(B, 784).astype(np.float32), local_rank)
+        target = S.STen.from_numpy((np.arange(B) % 10).astype(np.int64), local_rank)
+        model = nn.SupervisedModel(model_mod, 0, S.STen.ones([10], S.F32, local_rank))
+        acc = S.STen.zeros([1], S.F32, local_rank)
+        step = lambda: model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
+        units_per_step = B
+        metric, unit = "MLP fwd+bwd samples/sec", "samples/s"
+        config = {"workload": "MLP 784-256-10 fwd+bwd fp32 batch 1024", "parallelism": "replicas"}
+        a.dtype = "f32"
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    lib.lamp_kernel_timer_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.lamp_kernel_timer_enable(0)
+    rows = kernel_report(lib)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        value = units_per_step * a.gpus * a.steps / elapsed
+        roof = roofline_of(rows)
+        line = {"metric": metric, "value": value, "unit": unit, "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": a.dtype, "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu_baseline}
+        if a.workload == "resnet":
+            # whole-step figures against SURVEY.md 8(d): 153.3 MFLOP and ~1.4 MB algorithmic HBM bytes per sample per step
+            per_gpu = value / a.gpus
+            line["step_roofline"] = {"algorithmic_tflops": per_gpu * 153.3e6 / 1e12, "frac_bf16_mfma_peak": per_gpu * 153.3e6 / 1e12 / PEAK_BF16_TFLOPS,
+                                     "algorithmic_GBps": per_gpu * 1.4e6 / 1e9, "frac_hbm_peak": per_gpu * 1.4e6 / 1e9 / PEAK_HBM_GBS}
+        top = sorted(rows, key=lambda r: -r["total_ms"])[:8]
+        line["kernel_classes"] = [{"tag": r["tag"], "launches_per_step": r["launches"] / a.steps, "ms_per_step": r["total_ms"] / a.steps} for r in top]
+        print(json.dumps(line))
+    if comm is not None:
+        lib.lamp_comm_destroy(comm)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,12 @@ int lamp_manual_seed(uint64_t seed);
  * f32 MFMA so f32 GEMMs are always exact f32 (example-autoregressivelm/.../main.scala:18) */
 int lamp_allow_tf32(int flag);
 
+/* per-kernel-class HIP-event timing for the roofline line of bench.py: when enabled every tagged
+ * launch is bracketed by two events on its own stream; the report has one line per tag:
+ * "tag launches total_ms algorithmic_flops_per_launch algorithmic_bytes_per_launch" */
+int lamp_kernel_timer_enable(int on);
+int lamp_kernel_timer_report(char* buf, int buflen);
+
 /* HIP graph capture of the calling thread's current stream (launch-bound training steps) */
 int lamp_graph_begin_capture(void);
 int lamp_graph_end_capture(lamp_graph** out);

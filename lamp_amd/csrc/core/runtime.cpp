@@ -75,9 +75,64 @@ int num_cus() {
 uint64_t philox_seed() { return g_seed.load(); }
 uint64_t next_philox_offset(uint64_t n) { return g_philox_offset.fetch_add(n); }
 
+// ---- kernel timers ------------------------------------------------------------------------------
+namespace {
+struct TimerEntry { std::string tag; double flops, bytes; hipEvent_t a, b; };
+std::mutex g_timer_mu;
+std::vector<TimerEntry*> g_timer_entries;
+std::atomic<int> g_timer_on{0};
+}  // namespace
+
+KernelTimer::KernelTimer(const char* tag, double flops, double bytes, hipStream_t st) : slot(nullptr), stream(st) {
+  if (!g_timer_on.load(std::memory_order_relaxed)) return;
+  auto* e = new TimerEntry{tag, flops, bytes, nullptr, nullptr};
+  if (hipEventCreate(&e->a) != hipSuccess || hipEventCreate(&e->b) != hipSuccess) { delete e; return; }
+  (void)hipEventRecord(e->a, st);
+  slot = e;
+}
+KernelTimer::~KernelTimer() {
+  if (!slot) return;
+  auto* e = (TimerEntry*)slot;
+  (void)hipEventRecord(e->b, stream);
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  g_timer_entries.push_back(e);
+}
+
 }  // namespace lamp
 
 using namespace lamp;
+
+extern "C" int lamp_kernel_timer_enable(int on) {
+  g_timer_on.store(on);
+  return 0;
+}
+// writes lines "tag count total_ms flops_per_launch bytes_per_launch\n" and clears the log
+extern "C" int lamp_kernel_timer_report(char* buf, int buflen) {
+  LAMP_API_BEGIN
+  std::vector<TimerEntry*> es;
+  { std::lock_guard<std::mutex> lk(g_timer_mu); es.swap(g_timer_entries); }
+  struct Agg { int64_t n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto* e : es) {
+    (void)hipEventSynchronize(e->b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->a, e->b) == hipSuccess) {
+      auto& a = agg[e->tag];
+      a.n++; a.ms += ms; a.flops += e->flops; a.bytes += e->bytes;
+    }
+    (void)hipEventDestroy(e->a); (void)hipEventDestroy(e->b);
+    delete e;
+  }
+  std::string out;
+  for (auto& kv : agg) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %lld %.6f %.6e %.6e\n", kv.first.c_str(), (long long)kv.second.n, kv.second.ms,
+             kv.second.flops / kv.second.n, kv.second.bytes / kv.second.n);
+    out += line;
+  }
+  snprintf(buf, buflen, "%s", out.c_str());
+  LAMP_API_END
+}
 
 extern "C" {
 

@@ -171,6 +171,17 @@ Tensor* contiguous(const Tensor* t);  // +1 handle; a copy only if needed
 void copy_into(Tensor* dst, const Tensor* src);  // handles dtype conversion, strides, host<->device
 void fill_zero(Tensor* t);
 
+// ---- per-kernel-class timing with HIP events (bench.py roofline section) ----------------------
+// Disabled unless lamp_kernel_timer_enable(1): then every tagged launch site records a pair of
+// events on ITS stream; lamp_kernel_timer_report() sums elapsed times per tag together with the
+// algorithmic flops / bytes the launcher declared.
+struct KernelTimer {
+  KernelTimer(const char* tag, double flops, double bytes, hipStream_t stream);
+  ~KernelTimer();
+  void* slot;
+  hipStream_t stream;
+};
+
 // RAII holder for temporaries inside API functions.
 struct Hold {
   Tensor* t;

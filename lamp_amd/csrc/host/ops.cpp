@@ -436,15 +436,28 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
   lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
   HCALL(lamp_native_batch_norm(o3, x.h(), weight->value.h(), bias->value.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
   Ten out(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]), wv = weight->value;
+  // The reference calls native_batch_norm_backward once per requested derivative (ops.scala:1901,1924,
+  // 2086,2107); both calls reduce the same two per-channel sums.  Here the first closure that runs asks
+  // for dx AND dweight in one call and parks dweight for the other closure - identical arithmetic, one
+  // reduction pass over (dy, x) instead of two.
+  auto cache = std::make_shared<std::pair<Ten, Ten>>();   // (dweight, the incoming gradient it was computed for)
+  const bool both = input->needsGrad() && weight->needsGrad();
   auto back = [=](int which) {
     return [=](const Ten& p, const Ten& o) {
+      if (which == 1 && cache->first.defined() && cache->second.h() == p.h()) {
+        ops::add_(o, ops::reshape(cache->first, o.shape()));
+        cache->first = Ten(); cache->second = Ten();
+        return;
+      }
       Ten fp = two_d ? p : ops::flatten(p, 1, p.ndim() - 1);
       lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
-      uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1), 0};
+      const bool want_both = both && which == 0;
+      uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1 || want_both), 0};
       HCALL(lamp_native_batch_norm_backward(r3, fp.h(), x.h(), wv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(),
                                             training, eps, mask));
-      Ten r(r3[which]);
-      ops::add_(o, ops::reshape(r, o.shape()));
+      Ten r0(r3[0]), r1(r3[1]);
+      if (want_both) { cache->first = r1; cache->second = p; }
+      ops::add_(o, ops::reshape(which == 0 ? r0 : r1, o.shape()));
     };
   };
   op->params.push_back({input, back(0)});

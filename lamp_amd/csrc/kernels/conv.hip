@@ -123,6 +123,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const T* __restr
   }
 }
 
+// wgrad for the narrow layers (3..16 channels, large images): the reduction runs over N*Ho*Wo
+// pixels and the result is tiny, so parallelise over IMAGES: a workgroup stages one image of x and
+// dy in LDS (as the accumulation type), every thread owns one filter tap (co, ci, r, s) [or a pixel
+// slice of it when there are fewer taps than threads] and walks the image; per-workgroup partial
+// filters go to a workspace and are summed by conv_wgrad_reduce_kernel (deterministic order).
+template <class T>
+__global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const T* __restrict__ dy, const T* __restrict__ x, acc_t<T>* __restrict__ partial,
+                                                             ConvGeom g, int O, int PS, int images_per_block) {
+  using A = acc_t<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  A* xs = reinterpret_cast<A*>(smem_raw);                     // [Cin][H][W]
+  A* ds = xs + g.Cin * g.H * g.W;                             // [Cout][Ho][Wo]
+  A* accs = ds + g.Cout * g.Ho * g.Wo;                        // [O]
+  const int tid = threadIdx.x;
+  const int cin_g = (int)(g.Cin / g.groups), cout_g = (int)(g.Cout / g.groups);
+  const int khkw = g.kh * g.kw;
+  for (int o = tid; o < O; o += blockDim.x) accs[o] = A(0);
+  const int64_t n0 = (int64_t)blockIdx.x * images_per_block;
+  const int64_t n1 = min(n0 + images_per_block, g.N);
+  const int xsz = (int)(g.Cin * g.H * g.W), dsz = (int)(g.Cout * g.Ho * g.Wo);
+  const int KO = (O + 255) / 256;                              // taps per thread when O > 256
+  for (int64_t n = n0; n < n1; n++) {
+    __syncthreads();
+    const T* xp = x + n * xsz;
+    const T* dp = dy + n * dsz;
+    for (int i = tid; i < xsz; i += blockDim.x) xs[i] = load_as<A>(xp[i]);
+    for (int i = tid; i < dsz; i += blockDim.x) ds[i] = load_as<A>(dp[i]);
+    __syncthreads();
+    for (int k = 0; k < KO; k++) {
+      int o, slice;
+      if (O >= 256) { o = tid + k * 256; slice = 0; }
+      else { o = tid % O; slice = tid / O; }
+      if (o >= O || slice >= PS) continue;
+      const int rs = o % khkw, cl = (o / khkw) % cin_g, co = o / (khkw * cin_g);
+      const int r = rs / g.kw, s = rs - r * g.kw;
+      const int ci = (co / cout_g) * cin_g + cl;
+      const A* xc = xs + ci * g.H * g.W;
+      const A* dc = ds + co * g.Ho * g.Wo;
+      // valid output range for this tap (no per-pixel bounds checks in the inner loop)
+      const int off_h = r * g.dh - g.ph, off_w = s * g.dw - g.pw;
+      int ho_lo = off_h < 0 ? (-off_h + g.sh - 1) / g.sh : 0;
+      int wo_lo = off_w < 0 ? (-off_w + g.sw - 1) / g.sw : 0;
+      int ho_hi = (int)min<int64_t>(g.Ho, (g.H - 1 - off_h) / g.sh + 1);
+      int wo_hi = (int)min<int64_t>(g.Wo, (g.W - 1 - off_w) / g.sw + 1);
+      if (g.H - 1 - off_h < 0) ho_hi = 0;
+      if (g.W - 1 - off_w < 0) wo_hi = 0;
+      A acc = A(0);
+      for (int ho = ho_lo + slice; ho < ho_hi; ho += PS) {
+        const A* xr = xc + (ho * g.sh + off_h) * g.W + off_w;
+        const A* dr = dc + ho * g.Wo;
+        for (int wo = wo_lo; wo < wo_hi; wo++) acc += dr[wo] * xr[wo * g.sw];
+      }
+      if (PS > 1) atomicAdd(&accs[o], acc);
+      else accs[o] += acc;
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < O; o += blockDim.x) partial[(int64_t)blockIdx.x * O + o] = accs[o];
+}
+template <class T>
+__global__ void conv_wgrad_reduce_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
+  using A = acc_t<T>;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
+    A a = 0;
+    for (int b = 0; b < nblocks; b++) a += partial[(int64_t)b * O + o];
+    dw[o] = store_as<T>(a);
+  }
+}
+
 ConvGeom make_geom(const Tensor* x, const Tensor* w, const int64_t* stride, const int64_t* padding, const int64_t* dilation,
                    int nspatial, int transposed, const int64_t* output_padding, int64_t groups) {
   LAMP_CHECK(nspatial == 1 || nspatial == 2, "only 1-D and 2-D convolutions are supported (got " << nspatial << " spatial dims)");
@@ -166,6 +235,7 @@ ConvGeom make_geom(const Tensor* x, const Tensor* w, const int64_t* stride, cons
 template <class T> static void launch_fwd(const Tensor* x, const Tensor* w, const Tensor* b, Tensor* y, const ConvGeom& g, hipStream_t st) {
   const int64_t total = g.N * g.Cout * g.Ho * g.Wo;
   if (!total) return;
+  KernelTimer kt("conv_fwd_direct", conv_flops(g), conv_bytes(g, sizeof(T)), st);
   hipLaunchKernelGGL((conv_fwd_direct_kernel<T>), dim3(grid_for(total, 256, 16)), dim3(256), 0, st, x->ptr<T>(), w->ptr<T>(),
                      b ? b->ptr<T>() : (const T*)nullptr, y->ptr<T>(), g);
   LAMP_LAUNCH_CHECK();
@@ -173,6 +243,7 @@ template <class T> static void launch_fwd(const Tensor* x, const Tensor* w, cons
 template <class T> static void launch_dgrad(const Tensor* dy, const Tensor* w, const Tensor* b, Tensor* dx, const ConvGeom& g, hipStream_t st) {
   const int64_t total = g.N * g.Cin * g.H * g.W;
   if (!total) return;
+  KernelTimer kt("conv_dgrad_direct", conv_flops(g), conv_bytes(g, sizeof(T)), st);
   hipLaunchKernelGGL((conv_dgrad_direct_kernel<T>), dim3(grid_for(total, 256, 16)), dim3(256), 0, st, dy->ptr<T>(), w->ptr<T>(),
                      b ? b->ptr<T>() : (const T*)nullptr, dx->ptr<T>(), g);
   LAMP_LAUNCH_CHECK();
@@ -181,7 +252,34 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
   const int64_t blocks = g.Cout * (g.Cin / g.groups);
   if (!blocks) return;
   const int khkw = g.kh * g.kw;
+  {
+    using A = acc_t<T>;
+    const int64_t O = blocks * khkw;
+    const size_t lds = (size_t)(g.Cin * g.H * g.W + g.Cout * g.Ho * g.Wo + O) * sizeof(A);
+    if (lds <= 150 * 1024 && O <= 8192) {
+      const int nb = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * 2);
+      const int ipb = (int)((g.N + nb - 1) / nb);
+      const int nblocks = (int)((g.N + ipb - 1) / ipb);
+      const int PS = O >= 256 ? 1 : (int)(256 / O);
+      int64_t ps[1] = {(int64_t)nblocks * O};
+      Hold partial(new_tensor(ps, 1, std::is_same<A, double>::value ? kF64 : kF32, dy->device()));
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      {
+        KernelTimer kt("conv_wgrad_lds", conv_flops(g), conv_bytes(g, sizeof(T)), st);
+        hipLaunchKernelGGL((conv_wgrad_lds_kernel<T>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<A>(), g, (int)O, PS, ipb);
+        LAMP_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL((conv_wgrad_reduce_kernel<T>), dim3(grid_for(O, 256)), dim3(256), 0, st, partial->ptr<A>(), dw->ptr<T>(), (int)O, nblocks);
+      LAMP_LAUNCH_CHECK();
+      return;
+    }
+  }
   LAMP_CHECK(khkw <= MAXRS, "kernel window larger than " << MAXRS << " taps is not supported");
+  KernelTimer kt("conv_wgrad_direct", conv_flops(g), conv_bytes(g, sizeof(T)), st);
   if (khkw == 1) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
   else if (khkw <= 9) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);
   else if (khkw <= 25) hipLaunchKernelGGL((conv_wgrad_direct_kernel<T, 25>), dim3((unsigned)blocks), dim3(256), 0, st, dy->ptr<T>(), x->ptr<T>(), dw->ptr<T>(), g);

@@ -92,6 +92,7 @@ void launch_ew(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F
     if (NIN > 2 && !(mask & 4) && !aligned(p2)) vec_ok = false;
   }
   if (n == 1) vec_ok = false;
+  KernelTimer kt("elementwise", 0, (double)n * (NIN * sizeof(TI) + sizeof(TO)), st);
   if (vec_ok) {
     constexpr int W = 16 / sizeof(TI);
     int grid = grid_for((n + W - 1) / W, 256);

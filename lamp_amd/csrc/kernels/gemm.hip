@@ -430,6 +430,9 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     else fill_zero(out);
     return;
   }
+  const double g_flops = 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch;
+  const double g_bytes = ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * (g.S ? 2 : 1)) * g.batch * (double)dtype_size(a->dtype);
+  KernelTimer kt(a->dtype == kBF16 ? "gemm_bf16" : (a->dtype == kF32 ? "gemm_f32" : "gemm_f64"), g_flops, g_bytes, stm);
   if (a->dtype == kBF16) {
     const bool akc = (g.a_cs == 1), bkc = (g.b_rs == 1);
     LAMP_CHECK(akc || g.a_rs == 1, "internal: A has no unit stride");

@@ -49,20 +49,42 @@ template <class A> __device__ __forceinline__ Welford<A> wf_wave(Welford<A> w) {
 }
 
 // ---- batch norm statistics: partial[split][c] = Welford over a slice of (n, hw) -----------------
-// big-HW variant: block (c, split); threads walk hw contiguously
+// big-HW variant: block (c, split). The channel's N*HW elements are walked as 16-byte packets
+// (HW % W == 0) by all threads of all splits; each thread keeps a SHIFTED sum / sum of squares
+// (shift = its first element, so no catastrophic cancellation) which is converted to a Welford
+// triple and Chan-merged across lanes, waves and splits.
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, acc_t<T>* __restrict__ partial, int64_t N, int64_t C,
-                                                       int64_t HW, int nsplit) {
+                                                       int64_t HW, int nsplit, int vec) {
   using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
   __shared__ A sm[3][4];
   const int64_t c = blockIdx.x;
   const int split = blockIdx.y;
-  Welford<A> w{0, 0, 0};
-  // split over n
-  for (int64_t n = split; n < N; n += nsplit) {
-    const T* p = x + (n * C + c) * HW;
-    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) wf_add(w, load_as<A>(p[i]));
+  A cnt = 0, s1 = 0, s2 = 0, shift = 0;
+  bool first = true;
+  if (vec) {
+    const int64_t vpp = HW / W;                 // packets per (n, c) plane
+    const int64_t total = N * vpp;
+    for (int64_t i = (int64_t)split * blockDim.x + threadIdx.x; i < total; i += (int64_t)nsplit * blockDim.x) {
+      const int64_t n = i / vpp, v = i - n * vpp;
+      const Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + (n * C + c) * HW + v * W);
+      if (first) { shift = load_as<A>(pk.v[0]); first = false; }
+#pragma unroll
+      for (int k = 0; k < W; k++) { const A d = load_as<A>(pk.v[k]) - shift; s1 += d; s2 += d * d; }
+      cnt += A(W);
+    }
+  } else {
+    const int64_t total = N * HW;
+    for (int64_t i = (int64_t)split * blockDim.x + threadIdx.x; i < total; i += (int64_t)nsplit * blockDim.x) {
+      const int64_t n = i / HW, v = i - n * HW;
+      const A val = load_as<A>(x[(n * C + c) * HW + v]);
+      if (first) { shift = val; first = false; }
+      const A d = val - shift;
+      s1 += d; s2 += d * d; cnt += A(1);
+    }
   }
+  Welford<A> w{cnt, cnt > A(0) ? shift + s1 / cnt : A(0), cnt > A(0) ? s2 - s1 * s1 / cnt : A(0)};
   w = wf_wave(w);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { sm[0][wid] = w.n; sm[1][wid] = w.mean; sm[2][wid] = w.m2; }
@@ -122,12 +144,29 @@ __global__ void bn_eval_stats_kernel(const T* running_mean, const T* running_var
   const A v = running_var ? load_as<A>(running_var[c]) : A(1);
   invstd[c] = store_as<T>((A)(A(1) / (A)sqrt((double)(v + (A)eps))));
 }
-// y = (x - mean) * invstd * w + b
+// y = (x - mean) * invstd * w + b      (16-byte packets when HW % W == 0: one channel per packet)
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ mean,
                                                        const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
-                                                       int64_t total, int64_t C, int64_t HW) {
+                                                       int64_t total, int64_t C, int64_t HW, int vec) {
   using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  if (vec) {
+    const int64_t vpp = HW / W, nv = total / W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t c = (i / vpp) % C;
+      const A scale = load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1));
+      const A shift = (b ? load_as<A>(b[c]) : A(0)) - load_as<A>(mean[c]) * scale;
+      const A mu = load_as<A>(mean[c]);
+      const A bb = b ? load_as<A>(b[c]) : A(0);
+      Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + i * W);
+      (void)shift;
+#pragma unroll
+      for (int k = 0; k < W; k++) pk.v[k] = store_as<T>((A)((load_as<A>(pk.v[k]) - mu) * scale + bb));
+      *reinterpret_cast<Vec<T, W>*>(y + i * W) = pk;
+    }
+    return;
+  }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = (i / HW) % C;
     const A scale = load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1));
@@ -140,19 +179,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 // partial[split][c] = (sum dy, sum dy * (x - mean))
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
-                                                            acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit) {
+                                                            acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit, int vec) {
   using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
   __shared__ A sm[2][4];
   const int64_t c = blockIdx.x;
   const int split = blockIdx.y;
   const A mu = load_as<A>(mean[c]);
   A s1 = 0, s2 = 0;
-  for (int64_t n = split; n < N; n += nsplit) {
-    const int64_t base = (n * C + c) * HW;
-    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) {
-      const A g = load_as<A>(dy[base + i]);
-      s1 += g;
-      s2 += g * (load_as<A>(x[base + i]) - mu);
+  if (vec) {
+    const int64_t vpp = HW / W, total = N * vpp;
+    for (int64_t i = (int64_t)split * blockDim.x + threadIdx.x; i < total; i += (int64_t)nsplit * blockDim.x) {
+      const int64_t n = i / vpp, v = i - n * vpp;
+      const int64_t base = (n * C + c) * HW + v * W;
+      const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + base);
+      const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + base);
+#pragma unroll
+      for (int k = 0; k < W; k++) { const A gg = load_as<A>(g.v[k]); s1 += gg; s2 += gg * (load_as<A>(xv.v[k]) - mu); }
+    }
+  } else {
+    const int64_t total = N * HW;
+    for (int64_t i = (int64_t)split * blockDim.x + threadIdx.x; i < total; i += (int64_t)nsplit * blockDim.x) {
+      const int64_t n = i / HW, v = i - n * HW;
+      const int64_t base = (n * C + c) * HW + v;
+      const A gg = load_as<A>(dy[base]);
+      s1 += gg; s2 += gg * (load_as<A>(x[base]) - mu);
     }
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -204,8 +255,30 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
                                                            const T* __restrict__ invstd, const T* __restrict__ w,
                                                            const acc_t<T>* __restrict__ sums, T* __restrict__ dx, int64_t total, int64_t C,
-                                                           int64_t HW, double inv_m, int training) {
+                                                           int64_t HW, double inv_m, int training, int vec) {
   using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  if (vec) {
+    const int64_t vpp = HW / W, nv = total / W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t c = (i / vpp) % C;
+      const A is = load_as<A>(invstd[c]);
+      const A wc = w ? load_as<A>(w[c]) : A(1);
+      const A mu = load_as<A>(mean[c]);
+      const A k = training ? sums[c * 2 + 1] * is * is * (A)inv_m : A(0);
+      const A gm = training ? sums[c * 2] * (A)inv_m : A(0);
+      const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + i * W);
+      const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + i * W);
+      Vec<T, W> r;
+#pragma unroll
+      for (int q = 0; q < W; q++) {
+        const A gg = load_as<A>(g.v[q]);
+        r.v[q] = store_as<T>(training ? (A)((gg - gm - (load_as<A>(xv.v[q]) - mu) * k) * is * wc) : (A)(gg * is * wc));
+      }
+      *reinterpret_cast<Vec<T, W>*>(dx + i * W) = r;
+    }
+    return;
+  }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = (i / HW) % C;
     const A is = load_as<A>(invstd[c]);
@@ -317,7 +390,7 @@ static int pick_split(int64_t outputs_blocks, int64_t N) {
   int64_t target = (int64_t)num_cus() * 4;
   int64_t s = target / std::max<int64_t>(outputs_blocks, 1);
   s = std::min<int64_t>(s, N);
-  s = std::min<int64_t>(s, 64);
+  s = std::min<int64_t>(s, 256);
   return (int)std::max<int64_t>(s, 1);
 }
 static void check_cvec(const Tensor* t, int64_t C, int dtype, const char* what) {
@@ -347,6 +420,7 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
+    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)y->data()) & 15) == 0;
     if (training) {
       LAMP_CHECK(g.N * g.HW > 0, "batch norm over an empty batch");
       const bool col = g.HW < 64;
@@ -354,8 +428,9 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
       const int nsplit = pick_split(blocks, g.N);
       int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
       Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+      KernelTimer kt("bn_fwd_stats", 0, (double)total * sizeof(T), st);
       if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-      else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+      else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
       LAMP_LAUNCH_CHECK();
       hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
                          mean->ptr<T>(), invstd->ptr<T>(), running_mean ? running_mean->ptr<T>() : (T*)nullptr,
@@ -368,9 +443,10 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
       LAMP_LAUNCH_CHECK();
     }
     if (total > 0) {
+      KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
       hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(),
                          invstd->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr, total,
-                         g.C, g.HW);
+                         g.C, g.HW, vec);
       LAMP_LAUNCH_CHECK();
     }
   });
@@ -415,22 +491,25 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
+    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr)) & 15) == 0;
     const bool col = g.HW < 64;
     const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
     const int nsplit = pick_split(blocks, g.N);
     int64_t ps[1] = {(int64_t)nsplit * g.C * 2};
     int64_t ss[1] = {g.C * 2};
     Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device())), sums(new_tensor(ss, 1, acc_dtype<A>(), x->device()));
+    KernelTimer kt1("bn_bwd_reduce", 0, 2.0 * (double)total * sizeof(T), st);
     if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
     LAMP_LAUNCH_CHECK();
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
                        nsplit, invstd_t->ptr<T>(), dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr);
     LAMP_LAUNCH_CHECK();
     if (dx.get() && total > 0) {
+      KernelTimer kt2("bn_bwd_apply", 0, 3.0 * (double)total * sizeof(T), st);
       hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(),
                          invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW,
-                         1.0 / (double)(g.N * g.HW), training);
+                         1.0 / (double)(g.N * g.HW), training, vec);
       LAMP_LAUNCH_CHECK();
     }
   });

@@ -320,6 +320,9 @@ CONV_CASES = [
     (2, 128, 8, 8, 100, 3, 1, 1, 1, 1),    # res4.r1
     (2, 100, 8, 8, 100, 3, 1, 1, 1, 1),    # res4.r2
     (2, 128, 8, 8, 100, 1, 1, 0, 1, 1),    # res4.l
+    (5, 100, 8, 8, 128, 3, 1, 1, 1, 1),    # odd batch on the implicit-GEMM path
+    (7, 16, 8, 8, 128, 1, 1, 0, 1, 1),     # res3.l (1x1)
+    (70, 128, 8, 8, 128, 3, 1, 1, 1, 1),   # several image splits in wgrad
     (3, 4, 9, 7, 6, 3, 2, 1, 2, 2),        # odd sizes, dilation, groups
     (1, 2, 3, 3, 1, 3, 1, 0, 1, 1),        # reference KAT geometry (autograd.test.scala:2043)
 ]
