@@ -429,12 +429,17 @@ int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_
  * materialises the q x n distance matrix.  distances_or_null receives the k values. */
 int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances_or_null, const lamp_tensor* data,
                                const lamp_tensor* query, int64_t k);
-/* one fused evaluation of the UMAP layout loss and its gradient w.r.t. locations
- * (minDist == 0 branch and the capped-exponential branch) - see umap.scala:132-176 */
+/* one fused evaluation of the UMAP layout loss (umap.scala:132-176) and of its gradient w.r.t.
+ * `locations`, accumulated into grad_accum:
+ *   loss = -(attractions / sum(b) + repulsions * repulsion_strength / |index3|)        (balance != 0)
+ *   grad_accum += sum_k term_weights[k] * scatter_k(dloss/dlocations_k),  k = index1..index4.
+ * term_weights reproduces how lamp's IndexSelect backward (`out += out.indexAdd(..)`, ops.scala:186-191)
+ * accumulates the four gathers into one buffer: {1, 2, 4, 8} in the reference's traversal order;
+ * pass {1, 1, 1, 1} for the mathematical gradient. */
 int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations,
                         const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
                         const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
-                        int balance, double repulsion_strength);
+                        int balance, double repulsion_strength, const double* term_weights);
 
 /* ------------------------------------------------------------------------------------------
  * collectives over RCCL / xGMI   (aten.NcclComm.{get_unique_id, comm_init_rank, broadcast,

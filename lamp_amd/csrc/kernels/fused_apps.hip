@@ -1,0 +1,323 @@
+// kNN graph, UMAP layout loss/gradient and scaled-dot-product attention.
+//
+// kNN   : lamp-knn/src/main/scala/lamp/knn/package.scala:21-80 - D = max(0, |q|^2 + |x|^2^T - 2 q.x^T),
+//         k smallest per row; here the data set is walked in column chunks so the q x n distance
+//         matrix is never materialised (per chunk: MFMA GEMM -> fused distance epilogue -> per-row
+//         top-k; chunk winners are merged by a final top-k).  Index results are exact.
+// UMAP  : lamp-umap/src/main/scala/lamp/umap/umap.scala:132-176 (loss) - one fused kernel evaluates
+//         the loss and scatter-adds its gradient into the locations' gradient (f64 atomics).
+// SDPA  : lamp-sten/.../STen.scala:501-584, ops.scala:2342-2390; CPU semantics are the composed
+//         softmax(Q K^T * scale + mask) V of Transformer.scala:784-804 (the fused op has no CPU
+//         known-answer test in the reference: parity is pinned to the composed form).
+#include "device_utils.h"
+#include "../core/strided.h"
+
+namespace lamp {
+
+Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
+
+// dist[i, j] = max(0, qn[i] + dn[j] - 2 * outer[i, j])   (same operation order as the reference chain)
+template <class T>
+__global__ void knn_dist_kernel(T* __restrict__ outer, const T* __restrict__ qn, const T* __restrict__ dn, int64_t Q, int64_t Nc) {
+  using A = acc_t<T>;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < Q * Nc; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / Nc, j = e - i * Nc;
+    const A o2 = load_as<A>(store_as<T>((A)(load_as<A>(outer[e]) * A(2))));
+    const A s = load_as<A>(store_as<T>((A)(load_as<A>(qn[i]) + load_as<A>(dn[j]))));
+    const A v = s - o2;
+    outer[e] = store_as<T>(v > A(0) ? v : A(0));
+  }
+}
+// out[i, j] = src[i, idx[i, j]] (+ column offset table for index merging)
+template <class T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, int64_t rows, int64_t k, int64_t srccols) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < rows * k; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / k;
+    out[e] = src[i * srccols + idx[e]];
+  }
+}
+__global__ void add_offset_kernel(int64_t* __restrict__ idx, int64_t n, int64_t offset) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) idx[e] += offset;
+}
+
+// ---- UMAP ------------------------------------------------------------------------------------------------
+// one thread per pair; pairs [0, E1) are attractive (index1, index2, b), pairs [E1, E1 + E2) repulsive (index3, index4)
+template <class T>
+__global__ __launch_bounds__(256) void umap_pairs_kernel(const T* __restrict__ loc, int64_t D, const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
+                                                         const T* __restrict__ b, int64_t E1, const int64_t* __restrict__ i3, const int64_t* __restrict__ i4,
+                                                         int64_t E2, const T* __restrict__ bsum, double min_dist, int balance, double strength,
+                                                         double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc) {
+  __shared__ double sm[4];
+  double local = 0.0;
+  const double attr_scale = balance ? 1.0 / (double)bsum[0] : 1.0;
+  const double rep_scale = balance ? strength / (double)E2 : 1.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E1 + E2; e += (int64_t)gridDim.x * blockDim.x) {
+    const bool attr = e < E1;
+    const int64_t a = attr ? i1[e] : i3[e - E1], c = attr ? i2[e] : i4[e - E1];
+    double d2 = 0.0;
+    for (int64_t k = 0; k < D; k++) { const double df = (double)loc[a * D + k] - (double)loc[c * D + k]; d2 += df * df; }
+    const double d = sqrt(d2);
+    double dl_dd;   // d loss / d distance for this pair
+    if (attr) {
+      const double bb = (double)b[e];
+      if (min_dist == 0.0) { local += bb * d * attr_scale; dl_dd = bb * attr_scale; }                    // -( -(b d) ) / sum b
+      else {
+        const double f = d <= min_dist ? 1.0 : exp(min_dist - d);
+        local += -bb * log(f) * attr_scale;
+        dl_dd = d <= min_dist ? 0.0 : bb * attr_scale;
+      }
+    } else {
+      if (min_dist == 0.0) {
+        const double ex = exp(-d);
+        local += -rep_scale * log1p(-ex);
+        dl_dd = -rep_scale * ex / (1.0 - ex);
+      } else {
+        const double f = d <= min_dist ? 1.0 : exp(min_dist - d);
+        local += -rep_scale * log1p(-f + 1e-6);
+        dl_dd = d <= min_dist ? 0.0 : -rep_scale * f / (1.0 + 1e-6 - f);
+      }
+    }
+    const double wa = attr ? w1 : w3, wc = attr ? w2 : w4;
+    for (int64_t k = 0; k < D; k++) {
+      const double unit = ((double)loc[a * D + k] - (double)loc[c * D + k]) / d;   // diff / norm (NaN at d == 0, as in the reference)
+      atomicAdd(&grad[a * D + k], (T)(wa * dl_dd * unit));
+      atomicAdd(&grad[c * D + k], (T)(-wc * dl_dd * unit));
+    }
+  }
+  local = block_sum(local, sm);
+  if (threadIdx.x == 0) atomicAdd(loss_acc, local);
+}
+template <class T> __global__ void cast_scalar_kernel(const double* in, T* out) { *out = (T)(*in); }
+
+// ---- attention helpers ---------------------------------------------------------------------------------------
+// scores[b, i, j] = scale * scores[b, i, j] (+ -inf above the diagonal); lse[b, i] = logsumexp_j; p = exp(s - lse)
+template <class T>
+__global__ __launch_bounds__(256) void sdpa_softmax_kernel(T* __restrict__ s, T* __restrict__ lse, int64_t rows, int64_t Sq, int64_t Sk, double scale, int causal) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int64_t i = row % Sq;
+  T* p = s + row * Sk;
+  const int64_t lim = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+  A m = -INFINITY;
+  for (int64_t j = lane; j < lim; j += 64) { const A v = load_as<A>(p[j]) * (A)scale; m = v > m ? v : m; }
+  m = wave_max(m);
+  A sum = 0;
+  for (int64_t j = lane; j < lim; j += 64) sum += (A)exp((double)(load_as<A>(p[j]) * (A)scale - m));
+  sum = wave_sum(sum);
+  const A l = m + (A)log((double)sum);
+  if (lane == 0) lse[row] = store_as<T>(l);
+  for (int64_t j = lane; j < Sk; j += 64) p[j] = store_as<T>(j < lim ? (A)exp((double)(load_as<A>(p[j]) * (A)scale - l)) : A(0));
+}
+// ds = p * (dp - rowsum(dp * p)) * scale   (in place on dp)
+template <class T>
+__global__ __launch_bounds__(256) void sdpa_softmax_bwd_kernel(T* __restrict__ dp, const T* __restrict__ p, int64_t rows, int64_t Sk, double scale) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  A dot = 0;
+  for (int64_t j = lane; j < Sk; j += 64) dot += load_as<A>(dp[row * Sk + j]) * load_as<A>(p[row * Sk + j]);
+  dot = wave_sum(dot);
+  for (int64_t j = lane; j < Sk; j += 64) {
+    const int64_t e = row * Sk + j;
+    dp[e] = store_as<T>((A)(load_as<A>(p[e]) * (load_as<A>(dp[e]) - dot) * (A)scale));
+  }
+}
+
+static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
+  lamp_tensor* o = nullptr;
+  LAMP_CHECK(fn(&o, a) == 0, lamp_last_error());
+  return Hold(o);
+}
+
+}  // namespace lamp
+
+using namespace lamp;
+
+extern "C" {
+
+int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, const lamp_tensor* data, const lamp_tensor* query, int64_t k) {
+  LAMP_API_BEGIN
+  check_device_tensor(data, "data"); check_device_tensor(query, "query");
+  LAMP_CHECK(data->ndim == 2 && query->ndim == 2 && data->sizes[1] == query->sizes[1] && data->dtype == query->dtype,
+             "knn: data " << data->describe() << " and query " << query->describe() << " must be 2-D with equal width and dtype");
+  const int64_t N = data->sizes[0], Q = query->sizes[0], dim = data->sizes[1];
+  LAMP_CHECK(k >= 1 && k <= N, "knn: k = " << k << " out of range for " << N << " points");
+  Hold dc(contiguous(data)), qc(contiguous(query));
+  hipStream_t st = current_stream(data->device());
+  // squared norms: (v * v).rowSum
+  Hold d2(call1(lamp_square, dc.get())), q2(call1(lamp_square, qc.get()));
+  int64_t one = 1;
+  Hold dn(reduce_dims(d2.get(), &one, 1, true, 0)), qn(reduce_dims(q2.get(), &one, 1, true, 0));
+  d2 = Hold(); q2 = Hold();
+  // column chunk so that the Q x chunk block stays around 256 MB
+  int64_t chunk = std::max<int64_t>(k, std::min<int64_t>(N, (int64_t)(256ll << 20) / (int64_t)(std::max<int64_t>(Q, 1) * data->itemsize())));
+  chunk = std::max<int64_t>(chunk, std::min<int64_t>(N, 1024));
+  const int64_t nchunks = (N + chunk - 1) / chunk;
+  std::vector<Hold> cand_v, cand_i;
+  for (int64_t c = 0; c < nchunks; c++) {
+    const int64_t lo = c * chunk, len = std::min(chunk, N - lo);
+    lamp_tensor *dsl = nullptr, *dnsl = nullptr;
+    LAMP_CHECK(lamp_narrow(&dsl, dc.get(), 0, lo, len) == 0, lamp_last_error()); Hold hd(dsl);
+    LAMP_CHECK(lamp_narrow(&dnsl, dn.get(), 0, lo, len) == 0, lamp_last_error()); Hold hdn(dnsl);
+    int64_t os[2] = {Q, len};
+    Hold outer(new_tensor(os, 2, data->dtype, data->device()));
+    LAMP_CHECK(lamp_addmm_out_transposed2(outer.get(), outer.get(), qc.get(), dsl, 0.0, 1.0) == 0, lamp_last_error());   // q . x^T
+    if (Q * len > 0) {
+      LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_dist_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
+                                                             outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
+      LAMP_LAUNCH_CHECK();
+    }
+    const int64_t kk = std::min(k, len);
+    lamp_tensor *tv = nullptr, *ti = nullptr;
+    LAMP_CHECK(lamp_topk(&tv, &ti, outer.get(), kk, 1, 0, 1) == 0, lamp_last_error());
+    Hold hv(tv), hi(ti);
+    Hold ic(contiguous(ti));
+    if (lo) { hipLaunchKernelGGL(add_offset_kernel, dim3(grid_for(Q * kk, 256)), dim3(256), 0, st, ic->ptr<int64_t>(), Q * kk, lo); LAMP_LAUNCH_CHECK(); }
+    cand_v.emplace_back(contiguous(tv));
+    cand_i.emplace_back(ic.take());
+  }
+  Hold best_v, best_i;
+  if (nchunks == 1) { best_v = std::move(cand_v[0]); best_i = std::move(cand_i[0]); }
+  else {
+    std::vector<lamp_tensor*> vs, is;
+    for (auto& h : cand_v) vs.push_back(h.get());
+    for (auto& h : cand_i) is.push_back(h.get());
+    lamp_tensor *allv = nullptr, *alli = nullptr;
+    LAMP_CHECK(lamp_cat(&allv, vs.data(), (int)vs.size(), 1) == 0, lamp_last_error()); Hold hav(allv);
+    LAMP_CHECK(lamp_cat(&alli, is.data(), (int)is.size(), 1) == 0, lamp_last_error()); Hold hai(alli);
+    lamp_tensor *tv = nullptr, *ti = nullptr;
+    LAMP_CHECK(lamp_topk(&tv, &ti, allv, k, 1, 0, 1) == 0, lamp_last_error());
+    Hold hv(tv), hi(ti);
+    Hold pos(contiguous(ti));
+    int64_t os[2] = {Q, k};
+    Hold gi(new_tensor(os, 2, kI64, data->device()));
+    hipLaunchKernelGGL((gather_rows_kernel<int64_t>), dim3(grid_for(Q * k, 256)), dim3(256), 0, st, alli->ptr<int64_t>(), pos->ptr<int64_t>(),
+                       gi->ptr<int64_t>(), Q, k, alli->sizes[1]);
+    LAMP_LAUNCH_CHECK();
+    best_v = Hold(contiguous(tv));
+    best_i = std::move(gi);
+  }
+  *indices = best_i.take();
+  if (distances) *distances = best_v.take();
+  LAMP_API_END
+}
+
+int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
+                        const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
+                        double repulsion_strength, const double* term_weights) {
+  LAMP_API_BEGIN
+  check_device_tensor(locations, "locations"); check_device_tensor(grad_accum, "grad_accum");
+  check_device_tensor(index1, "index1"); check_device_tensor(index2, "index2"); check_device_tensor(index3, "index3"); check_device_tensor(index4, "index4");
+  check_device_tensor(b, "b");
+  LAMP_CHECK(locations->ndim == 2 && locations->is_contiguous() && grad_accum->is_contiguous() && grad_accum->shape() == locations->shape() &&
+             grad_accum->dtype == locations->dtype, "umap: locations/grad must be contiguous [n, dim] tensors of one dtype");
+  LAMP_CHECK(locations->dtype == kF64 || locations->dtype == kF32, "umap layout runs in f64 (reference) or f32");
+  for (const lamp_tensor* ix : {index1, index2, index3, index4}) LAMP_CHECK(ix->dtype == kI64 && ix->ndim == 1 && ix->is_contiguous(), "umap: indices must be contiguous int64 vectors");
+  const int64_t E1 = index1->numel(), E2 = index3->numel();
+  LAMP_CHECK(index2->numel() == E1 && b->numel() == E1 && index4->numel() == E2 && b->dtype == locations->dtype && b->is_contiguous(), "umap: edge list size mismatch");
+  hipStream_t st = current_stream(locations->device());
+  Hold bsum(reduce_dims(b, nullptr, 0, false, 0));
+  int64_t one[1] = {1};
+  Hold acc(new_tensor(one, 1, kF64, locations->device()));
+  fill_zero(acc.get());
+  Hold out(new_tensor(nullptr, 0, locations->dtype, locations->device()));
+  const double w[4] = {term_weights ? term_weights[0] : 1.0, term_weights ? term_weights[1] : 1.0, term_weights ? term_weights[2] : 1.0,
+                       term_weights ? term_weights[3] : 1.0};
+  if (locations->dtype == kF64) {
+    hipLaunchKernelGGL((umap_pairs_kernel<double>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<double>(), locations->sizes[1],
+                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
+                       bsum->ptr<double>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>());
+    hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
+  } else {
+    hipLaunchKernelGGL((umap_pairs_kernel<float>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<float>(), locations->sizes[1],
+                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
+                       bsum->ptr<float>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>());
+    hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
+  }
+  LAMP_LAUNCH_CHECK();
+  *loss = out.take();
+  LAMP_API_END
+}
+
+// q, k, v: (B, heads, S, d).  out: (B, heads, Sq, d), logsumexp: (B, heads, Sq)
+int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp, const lamp_tensor* q, const lamp_tensor* k, const lamp_tensor* v,
+                                      int is_causal, double scale) {
+  LAMP_API_BEGIN
+  check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value");
+  LAMP_CHECK(q->ndim == 4 && k->ndim == 4 && v->ndim == 4, "attention expects (B, heads, S, d) tensors");
+  LAMP_CHECK(q->dtype == k->dtype && q->dtype == v->dtype, "attention: dtype mismatch");
+  const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
+  LAMP_CHECK(k->sizes[0] == B && k->sizes[1] == H && k->sizes[3] == D && v->sizes[0] == B && v->sizes[1] == H && v->sizes[2] == Sk, "attention: shape mismatch");
+  if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
+  Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v));
+  int64_t qs[3] = {B * H, Sq, D}, ks[3] = {B * H, Sk, D}, vs[3] = {B * H, Sk, Dv};
+  lamp_tensor *q3 = nullptr, *k3 = nullptr, *v3 = nullptr;
+  LAMP_CHECK(lamp_view(&q3, qc.get(), qs, 3) == 0, lamp_last_error()); Hold hq(q3);
+  LAMP_CHECK(lamp_view(&k3, kc.get(), ks, 3) == 0, lamp_last_error()); Hold hk(k3);
+  LAMP_CHECK(lamp_view(&v3, vc.get(), vs, 3) == 0, lamp_last_error()); Hold hv(v3);
+  int64_t ss[3] = {B * H, Sq, Sk};
+  Hold scores(new_tensor(ss, 3, q->dtype, q->device()));
+  LAMP_CHECK(lamp_baddbmm_out_transposed2(scores.get(), scores.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
+  int64_t ls[3] = {B, H, Sq};
+  Hold lse(new_tensor(ls, 3, q->dtype, q->device()));
+  const int64_t rows = B * H * Sq;
+  if (rows) {
+    LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0,
+                                                        current_stream(q->device()), scores->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, scale, is_causal));
+    LAMP_LAUNCH_CHECK();
+  }
+  lamp_tensor* o3 = nullptr;
+  LAMP_CHECK(lamp_bmm(&o3, scores.get(), v3) == 0, lamp_last_error()); Hold ho(o3);
+  int64_t os[4] = {B, H, Sq, Dv};
+  LAMP_CHECK(lamp_view(out, o3, os, 4) == 0, lamp_last_error());
+  *logsumexp = lse.take();
+  LAMP_API_END
+}
+
+int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* q, const lamp_tensor* k,
+                                               const lamp_tensor* v, const lamp_tensor* out, const lamp_tensor* logsumexp, int is_causal, double scale) {
+  LAMP_API_BEGIN
+  (void)out; (void)logsumexp;   // P is recomputed from q and k (same numerics as the forward)
+  check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value"); check_device_tensor(grad_out, "grad_out");
+  const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
+  if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
+  Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v)), gc(contiguous(grad_out));
+  int64_t qs[3] = {B * H, Sq, D}, ks[3] = {B * H, Sk, D}, vs[3] = {B * H, Sk, Dv}, gs[3] = {B * H, Sq, Dv};
+  lamp_tensor *q3 = nullptr, *k3 = nullptr, *v3 = nullptr, *g3 = nullptr;
+  LAMP_CHECK(lamp_view(&q3, qc.get(), qs, 3) == 0, lamp_last_error()); Hold hq(q3);
+  LAMP_CHECK(lamp_view(&k3, kc.get(), ks, 3) == 0, lamp_last_error()); Hold hk(k3);
+  LAMP_CHECK(lamp_view(&v3, vc.get(), vs, 3) == 0, lamp_last_error()); Hold hv(v3);
+  LAMP_CHECK(lamp_view(&g3, gc.get(), gs, 3) == 0, lamp_last_error()); Hold hg(g3);
+  int64_t ss[3] = {B * H, Sq, Sk}, ls[1] = {B * H * Sq};
+  Hold p(new_tensor(ss, 3, q->dtype, q->device())), lse(new_tensor(ls, 1, q->dtype, q->device()));
+  LAMP_CHECK(lamp_baddbmm_out_transposed2(p.get(), p.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
+  const int64_t rows = B * H * Sq;
+  hipStream_t st = current_stream(q->device());
+  if (rows) {
+    LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st,
+                                                        p->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, scale, is_causal));
+    LAMP_LAUNCH_CHECK();
+  }
+  // dV = P^T dO ; dP = dO V^T ; dS = P (dP - rowsum(dP P)) scale ; dQ = dS K ; dK = dS^T Q
+  Hold dv(new_tensor(vs, 3, q->dtype, q->device())), dp(new_tensor(ss, 3, q->dtype, q->device()));
+  LAMP_CHECK(lamp_baddbmm_out_transposed1(dv.get(), dv.get(), p.get(), g3, 0.0, 1.0) == 0, lamp_last_error());
+  LAMP_CHECK(lamp_baddbmm_out_transposed2(dp.get(), dp.get(), g3, v3, 0.0, 1.0) == 0, lamp_last_error());
+  if (rows) {
+    LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_bwd_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st,
+                                                        dp->ptr<T>(), p->ptr<T>(), rows, Sk, scale));
+    LAMP_LAUNCH_CHECK();
+  }
+  lamp_tensor* dq3 = nullptr;
+  LAMP_CHECK(lamp_bmm(&dq3, dp.get(), k3) == 0, lamp_last_error()); Hold hdq(dq3);
+  Hold dk(new_tensor(ks, 3, q->dtype, q->device()));
+  LAMP_CHECK(lamp_baddbmm_out_transposed1(dk.get(), dk.get(), dp.get(), q3, 0.0, 1.0) == 0, lamp_last_error());
+  LAMP_CHECK(lamp_view(&out3[0], dq3, q->sizes, 4) == 0, lamp_last_error());
+  LAMP_CHECK(lamp_view(&out3[1], dk.get(), k->sizes, 4) == 0, lamp_last_error());
+  LAMP_CHECK(lamp_view(&out3[2], dv.get(), v->sizes, 4) == 0, lamp_last_error());
+  LAMP_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""kNN, UMAP and attention entry points vs the oracle (lamp-knn, lamp-umap, Transformer composed attention)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from lamp_amd import autograd as A
+from lamp_amd import nn
+from lamp_amd import sten as S
+from lamp_amd._capi import lib, f64_array
+from oracle import lamp_oracle as O
+from tests.util import assert_close, to_sten, to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _points(n, d, dtype):
+    # 16 separated clusters + uniform jitter from a seeded generator: neighbour distances differ by far more
+    # than the rounding noise of |q|^2 + |x|^2 - 2 q.x, so the k-NN SETS are well defined (no ties)
+    g = torch.Generator().manual_seed(12345)
+    jitter = torch.rand(n, d, generator=g, dtype=torch.float64)
+    centers = (torch.arange(n) % 16).double().reshape(n, 1) * 3.0
+    return (jitter + centers).to(dtype)
+
+
+def _well_separated_queries(data64, candidates, k, gap):
+    """keep the query rows whose k-th and (k+1)-th neighbour distances differ by more than `gap` (in f64), so that the
+    k-NN SET is decided by the data and not by the rounding noise of the |q|^2 + |x|^2 - 2 q.x form."""
+    d = O.squared_euclidean_distance(data64[candidates], data64)
+    v, _ = torch.topk(d, k + 1, 1, largest=False, sorted=True)
+    return candidates[(v[:, k] - v[:, k - 1]) > gap]
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_knn_matches_reference_algorithm(gpu, dt):
+    data64 = _points(3000, 16, torch.float64)
+    rows = _well_separated_queries(data64, torch.arange(400), 10, 2e-2)
+    assert len(rows) > 100
+    data, query = data64.to(dt), data64[rows].to(dt)
+    ref = O.knn_minibatched(data, query, 10, 100)
+    i, d = C.c_void_p(), C.c_void_p()
+    lib.lamp_knn_squared_euclidean(C.byref(i), C.byref(d), to_sten(data), to_sten(query), 10)
+    I, D = S.STen(i), S.STen(d)
+    got = I.to_numpy()
+    assert got.dtype == np.int64 and got.shape == (len(rows), 10)
+    assert np.array_equal(np.sort(got, 1), np.sort(ref.numpy(), 1)), "neighbour index sets must be exact"
+    assert (np.sort(got, 1) == rows.numpy()[:, None]).any(1).all(), "self is among the neighbours (umap.scala:327-329)"
+    # |q|^2 + |x|^2 - 2 q.x cancels catastrophically in f32 (|q|^2 ~ 3e4 here, in the reference as well), so the values are
+    # checked against the exact f64 distances with the error bound of that formula: a few ulp of |q|^2
+    exact = torch.gather(O.squared_euclidean_distance(data64[rows], data64), 1, torch.from_numpy(got))
+    bound = (2e-2 if dt == torch.float32 else 1e-9)
+    assert (to_torch(D).double() - exact).abs().max().item() <= bound, "distances"
+
+
+def test_knn_chunked_merge(gpu):
+    # several column chunks: 40000 points do not fit the per-call distance block for 512 queries
+    data64 = _points(40000, 8, torch.float64)
+    rows = _well_separated_queries(data64, torch.arange(0, 40000, 37)[:700], 5, 1e-2)[:512]
+    assert len(rows) > 100
+    data, query = data64.float(), data64[rows].float()
+    ref = O.knn_minibatched(data, query, 5, 128)
+    i = C.c_void_p()
+    lib.lamp_knn_squared_euclidean(C.byref(i), None, to_sten(data), to_sten(query), 5)
+    assert np.array_equal(np.sort(S.STen(i).to_numpy(), 1), np.sort(ref.numpy(), 1))
+
+
+@pytest.mark.parametrize("min_dist", [0.0, 0.3])
+def test_umap_fused_loss_and_gradient(gpu, min_dist):
+    n, e1, e2 = 200, 700, 3000
+    loc = _points(n, 2, torch.float64) * 0.1
+    g = torch.Generator().manual_seed(0)
+    i1 = torch.randint(0, n, (e1,), generator=g); i2 = (i1 + 1 + torch.randint(0, n - 1, (e1,), generator=g)) % n
+    i3 = torch.randint(0, n, (e2,), generator=g); i4 = (i3 + 1 + torch.randint(0, n - 1, (e2,), generator=g)) % n
+    b = torch.rand(e1, generator=g, dtype=torch.float64)
+    lv = O.param(loc.clone())
+    L = O.umap_loss(lv, i1, i2, i3, i4, b, minDist=min_dist)
+    L.backprop()
+    # the reference accumulates the four IndexSelect backwards as out = 2*out + scatter: weights 1, 2, 4, 8
+    grad = S.STen.zeros([n, 2], S.F64)
+    lo = C.c_void_p()
+    lib.lamp_umap_loss_grad(C.byref(lo), grad, to_sten(loc), to_sten(i1), to_sten(i2), to_sten(b), to_sten(i3), to_sten(i4), min_dist, 1, 1.0,
+                            f64_array([1.0, 2.0, 4.0, 8.0]))
+    assert_close(to_torch(S.STen(lo)).reshape(()), L.value.double().reshape(()), 1e-12, "loss")
+    assert_close(to_torch(grad), lv.grad.double(), 1e-10, "gradient (reference accumulation order)")
+    # and the op-by-op HIP path agrees with both
+    hv = A.param(to_sten(loc))
+    from tests.test_apps_helpers import hip_umap_loss
+    HL = hip_umap_loss(hv, to_sten(i1), to_sten(i2), to_sten(i3), to_sten(i4), to_sten(b), min_dist)
+    HL.backprop()
+    assert_close(to_torch(HL.value).reshape(()), L.value.double().reshape(()), 1e-12, "op-by-op loss")
+    assert_close(to_torch(hv.partialDerivative), lv.grad.double(), 1e-10, "op-by-op gradient")
+
+
+def test_umap_layout_iterations_follow_the_oracle(gpu):
+    """umap.scala:238-283: zeroGrad, backprop, AdamW(lr 0.1, wd 0, clip 1, beta2 0.95).step - 5 iterations."""
+    n, e1, e2 = 120, 400, 2000
+    loc0 = _points(n, 2, torch.float64) * 0.05
+    g = torch.Generator().manual_seed(1)
+    i1 = torch.randint(0, n, (e1,), generator=g); i2 = (i1 + 1 + torch.randint(0, n - 1, (e1,), generator=g)) % n
+    i3 = torch.randint(0, n, (e2,), generator=g); i4 = (i3 + 1 + torch.randint(0, n - 1, (e2,), generator=g)) % n
+    b = torch.rand(e1, generator=g, dtype=torch.float64)
+    lo = O.param(loc0.clone())
+    oopt = O.AdamW([lo.value], 0.0, 0.1, 0.9, 0.95, clip=1.0)
+    H = to_sten(loc0)
+    hopt = nn.AdamW([H], 0.0, 0.1, 0.9, 0.95, clip=1.0)
+    grad = S.STen.zeros([n, 2], S.F64)
+    I1, I2, I3, I4, Bt = (to_sten(t) for t in (i1, i2, i3, i4, b))
+    for _ in range(5):
+        lo.zeroGrad()
+        L = O.umap_loss(lo, i1, i2, i3, i4, b)
+        L.backprop()
+        oopt.step([lo.grad], 1.0)
+        grad.zero_()
+        out = C.c_void_p()
+        lib.lamp_umap_loss_grad(C.byref(out), grad, H, I1, I2, Bt, I3, I4, 0.0, 1, 1.0, f64_array([1.0, 2.0, 4.0, 8.0]))
+        hopt.step([grad], 1.0)
+        assert_close(to_torch(S.STen(out)).reshape(()), L.value.double().reshape(()), 1e-9, "loss along the trajectory")
+    assert_close(to_torch(H), lo.value.double(), 1e-8, "layout after 5 iterations")
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_matches_composed_softmax(gpu, dt, causal):
+    Bz, H, Sq, D = 2, 3, 40, 16
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt) for _ in range(3))
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    scores = qd @ kd.transpose(-1, -2) / np.sqrt(D)
+    if causal:
+        scores = scores.masked_fill(torch.triu(torch.ones(Sq, Sq, dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(scores, -1) @ vd
+    lse_ref = torch.logsumexp(scores, -1)
+    o, l = C.c_void_p(), C.c_void_p()
+    lib.lamp_scaled_dot_product_attention(C.byref(o), C.byref(l), to_sten(q), to_sten(k), to_sten(v), int(causal), 0.0)
+    Ot, Lt = S.STen(o), S.STen(l)
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 3e-2}[dt]
+    assert_close(to_torch(Ot), ref.detach(), tol, "attention output")
+    assert_close(to_torch(Lt), lse_ref.detach(), tol, "logsumexp")
+    go = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt)
+    ref.backward(go.double())
+    out3 = (C.c_void_p * 3)()
+    lib.lamp_scaled_dot_product_attention_backward(out3, to_sten(go), to_sten(q), to_sten(k), to_sten(v), Ot, Lt, int(causal), 0.0)
+    btol = {torch.float64: 1e-10, torch.float32: 1e-3, torch.bfloat16: 6e-2}[dt]
+    for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
+        assert_close(to_torch(S.STen(h)), r, btol, name)
