@@ -102,19 +102,9 @@ def main():
     dist = None
     comm = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only (uid exchange, barrier, max)
-        uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            lib.lamp_comm_get_unique_id(uid)
-        import torch
-        t = torch.tensor(list(uid), dtype=torch.uint8)
-        dist.broadcast(t, 0)
-        uid = (C.c_uint8 * 128)(*t.tolist())
-        ch = C.c_void_p()
-        lib.lamp_comm_init_rank(C.byref(ch), world, uid, rank)              # RCCL communicator (data plane, xGMI)
-        comm = ch
+        from lamp_amd import distributed as D
+        dist = D.init_control_plane()            # gloo: control plane only (unique id, barrier, max of times)
+        comm = D.rccl_communicator(dist)         # RCCL communicator: the data plane over xGMI
 
     def barrier():
         lib.lamp_device_synchronize()

@@ -1,0 +1,69 @@
+"""Host-side logic of the data-parallel loop (one process per GPU).
+
+Reference: lamp-data/src/main/scala/lamp/data/distributed/package.scala:171-445 (drive/follow: rank 0 creates the NCCL
+unique id and hands it to the followers over the control plane, everybody calls ncclCommInitRank), :690-719
+(averageGradients) and lamp-data/.../BatchStream.scala:378-402 (everyNth sharding).  The control plane here is a gloo
+process group (the reference uses cats-effect queues or Akka TCP); the data plane is RCCL through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Sequence, Tuple
+
+
+def env_rank() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_control_plane():
+    """gloo process group from the torchrun environment (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
+    import torch.distributed as dist
+    rank, _, world = env_rank()
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def exchange_unique_id(dist, make_id) -> bytes:
+    """rank 0 calls make_id() (128 bytes, lamp_comm_get_unique_id) and broadcasts it - DistributedCommunicationRoot.onUniqueIdReady /
+    NonRoot.join in the reference (DistributedCommunication.scala:15-62)."""
+    import torch
+    t = torch.zeros(128, dtype=torch.uint8)
+    if dist.get_rank() == 0:
+        raw = bytes(make_id())
+        assert len(raw) == 128
+        t = torch.tensor(list(raw), dtype=torch.uint8)
+    dist.broadcast(t, 0)
+    return bytes(t.tolist())
+
+
+def rccl_communicator(dist):
+    """RCCL communicator for this rank (blocking until the clique is complete, like ncclInitComm - STen.scala:629-641)."""
+    from ._capi import lib
+
+    def make():
+        buf = (C.c_uint8 * 128)()
+        lib.lamp_comm_get_unique_id(buf)
+        return bytes(buf)
+    uid = exchange_unique_id(dist, make)
+    h = C.c_void_p()
+    lib.lamp_comm_init_rank(C.byref(h), dist.get_world_size(), (C.c_uint8 * 128)(*uid), dist.get_rank())
+    return h
+
+
+def bucket_layout(numels: Sequence[int]) -> Tuple[List[int], int]:
+    """offsets of each gradient inside the flat fp32 bucket; the bucket has one extra trailing element for numExamples."""
+    offs, o = [], 0
+    for n in numels:
+        offs.append(o)
+        o += int(n)
+    return offs, o + 1
+
+
+def every_nth(num_batches: int, n: int, offset: int) -> List[int]:
+    """BatchStream.everyNth(n, offset): rank `offset` of `n` takes minibatches offset, offset+n, ... (BatchStream.scala:378-402).
+    All ranks must see the same number of batches or the clique deadlocks (distributed/package.scala:613-616): the tail that does
+    not fill a full round is dropped."""
+    full = (num_batches // n) * n
+    return list(range(offset, full, n))

@@ -1,0 +1,84 @@
+"""N > 1 logic on CPU: two gloo processes run the exchange protocol of the data-parallel step.
+
+What runs here is the host logic (rendezvous, bucket layout, example-weighted averaging contract, sharding); the device
+kernels of the same step (lamp_flatten_into_ / lamp_comm_all_reduce / lamp_unflatten_from_) are covered on the GPU in
+test_flat_bucket_and_single_rank_collectives (world size 1 communicator).
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from lamp_amd import distributed as D
+from oracle import lamp_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    dist = D.init_control_plane()
+    # 1. unique id rendezvous: every rank ends up with root's 128 bytes
+    uid = D.exchange_unique_id(dist, lambda: bytes(range(128)))
+    assert uid == bytes(range(128))
+    # 2. one data-parallel exchange: local gradients of a small model on this rank's shard, flat bucket, all-reduce(sum), / sum n
+    torch.manual_seed(0)
+    m = O.Sequential(O.mlp(12, 3, [8], torch.float64), O.Fun(lambda v: v.logSoftMax(1)))
+    n_r = [5, 3][rank]                                        # uneven shards: the weighting matters
+    x = O.closed_form(8 * 12, 0, 1.0, torch.float64).reshape(8, 12)[sum([5, 3][:rank]):][:n_r]
+    t = (torch.arange(8) % 3)[sum([5, 3][:rank]):][:n_r]
+    _, grads = O.training_step(m, O.nll_loss(3, torch.ones(3, dtype=torch.float64)), x, t, None)
+    offs, total = D.bucket_layout([g.numel() for g in grads])
+    bucket = torch.zeros(total, dtype=torch.float32)
+    for g, o in zip(grads, offs):                              # lamp_flatten_into_(bucket, grads, scale = n_r)
+        bucket[o:o + g.numel()] = (g.reshape(-1) * n_r).float()
+    bucket[-1] = n_r
+    dist.all_reduce(bucket)                                    # lamp_comm_all_reduce
+    avg = [(bucket[o:o + g.numel()] / bucket[-1]).reshape(g.shape) for g, o in zip(grads, offs)]   # lamp_unflatten_from_
+    torch.save({"grads": grads, "avg": avg, "n": n_r}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    ref = O.average_gradients([r0["grads"], r1["grads"]], [r0["n"], r1["n"]])      # distributed/package.scala:690-719
+    for a0, a1, r in zip(r0["avg"], r1["avg"], ref):
+        assert torch.equal(a0, a1), "every rank must hold the same averaged gradient"
+        assert torch.allclose(a0.double(), r, rtol=1e-6, atol=1e-7)
+
+
+def test_every_nth_sharding():
+    assert D.every_nth(10, 4, 1) == [1, 5]            # two full rounds; the tail (8, 9) is dropped on every rank
+    shards = [D.every_nth(12, 3, r) for r in range(3)]
+    assert sorted(sum(shards, [])) == list(range(12)) and len({len(s) for s in shards}) == 1
+    assert D.bucket_layout([4, 6, 2]) == ([0, 4, 10], 13)
+
+
+@pytest.mark.gpu
+def test_flat_bucket_and_single_rank_collectives(gpu):
+    from lamp_amd import sten as S
+    from lamp_amd._capi import lib, handle_array
+    g = [S.STen.from_numpy(np.arange(6, dtype=np.float32).reshape(2, 3)), S.STen.from_numpy(np.ones(4, dtype=np.float32) * 2)]
+    offs, total = D.bucket_layout([t.numel for t in g])
+    bucket = S.STen.zeros([total], S.F32)
+    lib.lamp_flatten_into_(bucket, handle_array([t.h for t in g]), 2, 3.0)
+    bucket.slice(0, total - 1, total).fill_(3.0)
+    uid = (C.c_uint8 * 128)(); lib.lamp_comm_get_unique_id(uid)
+    comm = C.c_void_p(); lib.lamp_comm_init_rank(C.byref(comm), 1, uid, 0)
+    lib.lamp_comm_all_reduce(handle_array([bucket.h]), handle_array([comm]), 1, 0)
+    lib.lamp_comm_broadcast(handle_array([bucket.h]), handle_array([comm]), 1, 0)
+    lib.lamp_comm_reduce(handle_array([bucket.h]), bucket, 0, 0, handle_array([comm]), 1)
+    assert np.allclose(bucket.to_numpy(), np.concatenate([np.arange(6) * 3.0, np.ones(4) * 6.0, [3.0]]))
+    out = [S.STen.zeros([2, 3]), S.STen.zeros([4])]
+    lib.lamp_unflatten_from_(handle_array([t.h for t in out]), 2, bucket, 1)
+    assert np.allclose(out[0].to_numpy(), np.arange(6).reshape(2, 3)) and np.allclose(out[1].to_numpy(), 2.0)
+    lib.lamp_comm_destroy(comm)
