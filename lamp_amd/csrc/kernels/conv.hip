@@ -182,14 +182,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const T* __restrict
   __syncthreads();
   for (int o = tid; o < O; o += blockDim.x) partial[(int64_t)blockIdx.x * O + o] = accs[o];
 }
+// one wavefront per filter tap: lanes stride over the per-workgroup partials (coalescing across taps is not
+// needed, the partial buffer is a few MB and L2 resident), fixed summation order => deterministic
 template <class T>
-__global__ void conv_wgrad_reduce_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
   using A = acc_t<T>;
-  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < O; o += gridDim.x * blockDim.x) {
-    A a = 0;
-    for (int b = 0; b < nblocks; b++) a += partial[(int64_t)b * O + o];
-    dw[o] = store_as<T>(a);
-  }
+  const int lane = threadIdx.x & 63;
+  const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (o >= O) return;
+  A a = 0;
+  for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * O + o];
+  a = wave_sum(a);
+  if (lane == 0) dw[o] = store_as<T>(a);
 }
 
 ConvGeom make_geom(const Tensor* x, const Tensor* w, const int64_t* stride, const int64_t* padding, const int64_t* dilation,
@@ -273,7 +277,7 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
         hipLaunchKernelGGL((conv_wgrad_lds_kernel<T>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<A>(), g, (int)O, PS, ipb);
         LAMP_LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL((conv_wgrad_reduce_kernel<T>), dim3(grid_for(O, 256)), dim3(256), 0, st, partial->ptr<A>(), dw->ptr<T>(), (int)O, nblocks);
+      hipLaunchKernelGGL((conv_wgrad_reduce_kernel<T>), dim3((unsigned)((O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), dw->ptr<T>(), (int)O, nblocks);
       LAMP_LAUNCH_CHECK();
       return;
     }
@@ -291,6 +295,10 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
 bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
+// implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
+bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
 
@@ -317,7 +325,7 @@ int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
   Hold y(new_tensor(oshape, x->dtype, x->device()));
   hipStream_t st = current_stream(x->device());
   if (!transposed) {
-    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
+    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !small_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_fwd<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
     }
   } else {
@@ -346,10 +354,10 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
   Hold dw(mask[1] ? new_like(wc.get()) : nullptr);
   Hold db;
   if (!transposed) {
-    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
     }
-    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
+    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !small_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_wgrad<T>(gc.get(), xc.get(), dw.get(), g, st)));
     }
   } else {

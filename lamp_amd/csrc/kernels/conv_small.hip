@@ -1,0 +1,280 @@
+// Direct convolution for the NARROW layers of the CIFAR ResNet (3..16 channels on 32x32 / 16x16 maps:
+// stem 3->6 5x5, res1 6->6, res2 6->16 incl. the strided 3x3 and 1x1 projections; reference workload
+// example-cifar100/.../cnn.scala:89-131, op ops.scala:1547-1651).  MFMA tiles would be > 90 % padding here, the
+// layers are bound by activation traffic, so: one workgroup per image, the image staged ONCE in LDS (fp32, zero
+// halo, so no bounds checks), one thread per output pixel accumulating ALL output channels in registers, weights
+// read through the scalar cache (wave-uniform indices -> s_load, used as SGPR operands of v_fmac).
+//   fprop : y[n, :, ho, wo]  = b + sum_{ci,r,s} x[n, ci, ho*sh - p + r, wo*sw - p + s] * w[:, ci, r, s]
+//   dgrad : dx[n, :, h, w]   = sum_{co,r,s}   dy[n, co, (h + p - r)/sh, (w + p - s)/sw] * w[co, :, r, s]
+#include "device_utils.h"
+#include "conv_geom.h"
+
+namespace lamp {
+
+// weights as fp32 in "k-major" order so that the innermost (unrolled) loop over the register-blocked
+// channel reads consecutive scalars:  fprop wf[(ci, r, s)][co],  dgrad wf[(co, r, s)][ci]
+template <class T>
+__global__ void cs_pack_kernel(const T* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int kh, int kw, int CB, int dgrad) {
+  const int total = (dgrad ? Cout : Cin) * kh * kw * CB;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int c = e % CB, krs = e / CB;
+    const int s = krs % kw, r = (krs / kw) % kh, k = krs / (kw * kh);
+    float v = 0.f;
+    if (!dgrad) { if (c < Cout) v = load_as<float>(w[((c * Cin + k) * kh + r) * kw + s]); }
+    else { if (c < Cin) v = load_as<float>(w[((k * Cin + c) * kh + r) * kw + s]); }
+    wf[e] = v;
+  }
+}
+
+// CB = register block over output channels (8 or 16)
+template <class T, int CB>
+__global__ __launch_bounds__(256) void cs_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wf, const T* __restrict__ bias,
+                                                     T* __restrict__ y, ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* xs = reinterpret_cast<float*>(smem_raw);            // [Cin][Hp][Wp], zero halo
+  const int Hp = (int)g.H + 2 * g.ph, Wp = (int)g.W + 2 * g.pw;
+  const int Cin = (int)g.Cin, Cout = (int)g.Cout, H = (int)g.H, W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  for (int i = tid; i < Cin * Hp * Wp; i += blockDim.x) xs[i] = 0.f;
+  __syncthreads();
+  const T* xp = x + n * Cin * H * W;
+  for (int i = tid; i < Cin * H * W; i += blockDim.x) {
+    const int w_ = i % W, h_ = (i / W) % H, c_ = i / (W * H);
+    xs[(c_ * Hp + h_ + g.ph) * Wp + w_ + g.pw] = load_as<float>(xp[i]);
+  }
+  __syncthreads();
+  T* yp = y + n * Cout * Ho * Wo;
+  for (int p = tid; p < Ho * Wo; p += blockDim.x) {
+    const int ho = p / Wo, wo = p - ho * Wo;
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) acc[c] = 0.f;
+    const float* xb = xs + (ho * g.sh) * Wp + wo * g.sw;
+    const float* wk = wf;
+    for (int ci = 0; ci < Cin; ci++) {
+      for (int r = 0; r < g.kh; r++) {
+        const float* xr = xb + (ci * Hp + r) * Wp;
+        for (int s = 0; s < g.kw; s++) {
+          const float xv = xr[s];
+#pragma unroll
+          for (int c = 0; c < CB; c++) acc[c] = fmaf(xv, wk[c], acc[c]);
+          wk += CB;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+      if (c < Cout) yp[c * Ho * Wo + p] = store_as<T>(acc[c] + (bias ? load_as<float>(bias[c]) : 0.f));
+  }
+}
+
+// CB = register block over INPUT channels (the outputs of dgrad)
+template <class T, int CB>
+__global__ __launch_bounds__(256) void cs_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ wf, T* __restrict__ dx, ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* ds = reinterpret_cast<float*>(smem_raw);            // [Cout][Ho][Wo]
+  const int Cin = (int)g.Cin, Cout = (int)g.Cout, H = (int)g.H, W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const T* dp = dy + n * Cout * Ho * Wo;
+  for (int i = tid; i < Cout * Ho * Wo; i += blockDim.x) ds[i] = load_as<float>(dp[i]);
+  __syncthreads();
+  T* xp = dx + n * Cin * H * W;
+  for (int p = tid; p < H * W; p += blockDim.x) {
+    const int h = p / W, w = p - h * W;
+    float acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++) acc[c] = 0.f;
+    const float* wk = wf;
+    for (int co = 0; co < Cout; co++) {
+      for (int r = 0; r < g.kh; r++) {
+        const int hn = h + g.ph - r;
+        const int ho = hn / g.sh;
+        const bool hv = hn >= 0 && (hn - ho * g.sh) == 0 && ho < Ho;
+        for (int s = 0; s < g.kw; s++) {
+          const int wn = w + g.pw - s;
+          const int wo = wn / g.sw;
+          const bool v = hv && wn >= 0 && (wn - wo * g.sw) == 0 && wo < Wo;
+          const float gv = v ? ds[(co * Ho + ho) * Wo + wo] : 0.f;
+#pragma unroll
+          for (int c = 0; c < CB; c++) acc[c] = fmaf(gv, wk[c], acc[c]);
+          wk += CB;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+      if (c < Cin) xp[c * H * W + p] = store_as<T>(acc[c]);
+  }
+}
+
+static bool cs_qualifies(const ConvGeom& g, bool dgrad) {
+  if (g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
+  if (g.Cin > 16 || g.Cout > 16) return false;
+  const int64_t lds = dgrad ? g.Cout * g.Ho * g.Wo * 4 : g.Cin * (g.H + 2 * g.ph) * (g.W + 2 * g.pw) * 4;
+  if (lds > 64 * 1024) return false;
+  if (g.N < 1) return false;
+  return true;
+}
+
+template <class T> static bool cs_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+  if (!cs_qualifies(g, dgrad)) return false;
+  const int cb_ch = (int)(dgrad ? g.Cin : g.Cout);
+  const int CB = cb_ch <= 8 ? 8 : 16;
+  const int64_t nk = (dgrad ? g.Cout : g.Cin) * g.kh * g.kw * CB;
+  int64_t ps[1] = {nk};
+  Hold wf(new_tensor(ps, 1, kF32, in->device()));
+  hipLaunchKernelGGL((cs_pack_kernel<T>), dim3(grid_for(nk, 256)), dim3(256), 0, st, w->ptr<T>(), wf->ptr<float>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw,
+                     CB, dgrad ? 1 : 0);
+  LAMP_LAUNCH_CHECK();
+  const size_t lds = dgrad ? (size_t)(g.Cout * g.Ho * g.Wo * 4) : (size_t)(g.Cin * (g.H + 2 * g.ph) * (g.W + 2 * g.pw) * 4);
+  const int64_t px = dgrad ? g.H * g.W : g.Ho * g.Wo;
+  const int block = px >= 256 ? 256 : (px >= 128 ? 128 : 64);
+  KernelTimer kt(dgrad ? "conv_dgrad_small" : "conv_fwd_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
+  if (!dgrad) {
+    if (CB == 8) hipLaunchKernelGGL((cs_fwd_kernel<T, 8>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<float>(), bias ? bias->ptr<T>() : (const T*)nullptr, out->ptr<T>(), g);
+    else hipLaunchKernelGGL((cs_fwd_kernel<T, 16>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<float>(), bias ? bias->ptr<T>() : (const T*)nullptr, out->ptr<T>(), g);
+  } else {
+    if (CB == 8) hipLaunchKernelGGL((cs_dgrad_kernel<T, 8>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<float>(), out->ptr<T>(), g);
+    else hipLaunchKernelGGL((cs_dgrad_kernel<T, 16>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<float>(), out->ptr<T>(), g);
+  }
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+
+// wgrad: dw[co, ci, r, s] = sum_{n, ho, wo} dy[n, co, ho, wo] * x[n, ci, ho*sh - p + r, wo*sw - p + s].
+// A workgroup walks a range of images (x with zero halo and dy staged in LDS as fp32). A thread owns one
+// (ci, r) pair and a slice of the output rows and keeps a CB x KW register block of partial filter taps
+// (all output channels x all horizontal taps): per output pixel CB + KW LDS reads feed CB*KW FMAs.
+// Slices are combined with LDS atomics, workgroups through a partial buffer + deterministic reduce.
+template <class T, int CB, int KW>
+__global__ __launch_bounds__(256) void cs_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ partial, ConvGeom g,
+                                                       int PS, int images_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int Hp = (int)g.H + 2 * g.ph, Wp = (int)g.W + 2 * g.pw + KW;   // + KW: slack so the last taps never read past the row
+  const int Cin = (int)g.Cin, Cout = (int)g.Cout, H = (int)g.H, W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+  float* xs = reinterpret_cast<float*>(smem_raw);             // [Cin][Hp][Wp]
+  float* ds = xs + Cin * Hp * Wp;                              // [CB][Ho][Wo] (rows >= Cout zero)
+  float* accs = ds + CB * Ho * Wo;                             // [PS][Cout][Cin][kh][KW] per-slice partials
+  const int O = Cout * Cin * g.kh * KW;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Cin * Hp * Wp; i += blockDim.x) xs[i] = 0.f;
+  for (int i = tid; i < CB * Ho * Wo; i += blockDim.x) ds[i] = 0.f;
+  const int ntask = Cin * g.kh;
+  const int task = tid % ntask, slice = tid / ntask;
+  const bool active = slice < PS;
+  const int ci = task / g.kh, r = task - ci * g.kh;
+  float acc[CB][KW];
+#pragma unroll
+  for (int c = 0; c < CB; c++)
+#pragma unroll
+    for (int s = 0; s < KW; s++) acc[c][s] = 0.f;
+  const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min(n0 + images_per_block, g.N);
+  for (int64_t n = n0; n < n1; n++) {
+    __syncthreads();
+    const T* xp = x + n * Cin * H * W;
+    const T* dp = dy + n * Cout * Ho * Wo;
+    for (int i = tid; i < Cin * H * W; i += blockDim.x) {
+      const int w_ = i % W, h_ = (i / W) % H, c_ = i / (W * H);
+      xs[(c_ * Hp + h_ + g.ph) * Wp + w_ + g.pw] = load_as<float>(xp[i]);
+    }
+    for (int i = tid; i < Cout * Ho * Wo; i += blockDim.x) ds[i] = load_as<float>(dp[i]);
+    __syncthreads();
+    if (active) {
+      for (int ho = slice; ho < Ho; ho += PS) {
+        const float* xr = xs + (ci * Hp + ho * g.sh + r) * Wp;
+        const float* dr = ds + ho * Wo;
+        for (int wo = 0; wo < Wo; wo++) {
+          float xv[KW];
+#pragma unroll
+          for (int s = 0; s < KW; s++) xv[s] = xr[wo * g.sw + s];
+#pragma unroll
+          for (int c = 0; c < CB; c++) {
+            const float gv = dr[c * Ho * Wo + wo];
+#pragma unroll
+            for (int s = 0; s < KW; s++) acc[c][s] = fmaf(gv, xv[s], acc[c][s]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+      if (c < Cout)
+#pragma unroll
+        for (int s = 0; s < KW; s++) accs[slice * O + ((c * Cin + ci) * g.kh + r) * KW + s] = acc[c][s];
+  }
+  __syncthreads();
+  // fixed-order sum over the row slices: bitwise reproducible
+  for (int i = tid; i < O; i += blockDim.x) {
+    float a = 0.f;
+    for (int sl = 0; sl < PS; sl++) a += accs[sl * O + i];
+    partial[(int64_t)blockIdx.x * O + i] = a;
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void cs_wgrad_reduce_kernel(const float* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (o >= O) return;
+  float a = 0.f;
+  for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * O + o];
+  a = wave_sum(a);
+  if (lane == 0) dw[o] = store_as<T>(a);
+}
+
+template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  if (g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
+  if (g.Cin > 16 || g.Cout > 16 || g.kh != g.kw || !(g.kw == 1 || g.kw == 3 || g.kw == 5)) return false;
+  const int ntask = (int)g.Cin * g.kh;
+  if (ntask > 256 || g.N < 1) return false;
+  const int CB = g.Cout <= 8 ? 8 : 16, KW = g.kw;
+  const int Hp = (int)g.H + 2 * g.ph, Wp = (int)g.W + 2 * g.pw + KW;
+  const int O = (int)(g.Cout * g.Cin * g.kh * KW);
+  const int PS = std::min<int>(256 / ntask, (int)g.Ho);
+  const size_t lds = (size_t)(g.Cin * Hp * Wp + CB * g.Ho * g.Wo + (int64_t)PS * O) * 4;
+  if (lds > 150 * 1024) return false;
+  const int nb = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * 2);
+  const int ipb = (int)((g.N + nb - 1) / nb);
+  const int nblocks = (int)((g.N + ipb - 1) / ipb);
+  int64_t ps[1] = {(int64_t)nblocks * O};
+  Hold partial(new_tensor(ps, 1, kF32, dy->device()));
+  {
+    KernelTimer kt("conv_wgrad_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
+#define CS_WG(CBv, KWv)                                                                                                              \
+  do {                                                                                                                               \
+    static bool attr = false;                                                                                                        \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)cs_wgrad_kernel<T, CBv, KWv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((cs_wgrad_kernel<T, CBv, KWv>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<float>(), g, PS, ipb); \
+  } while (0)
+    if (CB == 8 && KW == 1) CS_WG(8, 1); else if (CB == 8 && KW == 3) CS_WG(8, 3); else if (CB == 8 && KW == 5) CS_WG(8, 5);
+    else if (CB == 16 && KW == 1) CS_WG(16, 1); else if (CB == 16 && KW == 3) CS_WG(16, 3); else CS_WG(16, 5);
+#undef CS_WG
+    LAMP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL((cs_wgrad_reduce_kernel<T>), dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<T>(), O, nblocks);
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  if (x->dtype == kBF16) return cs_wgrad_run<bf16_t>(dy, x, dw, g, st);
+  if (x->dtype == kF32) return cs_wgrad_run<float>(dy, x, dw, g, st);
+  return false;
+}
+
+// f32 accumulation is only parity-safe for bf16/f32 inputs; f64 stays on the generic direct kernels
+bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
+  if (x->dtype == kBF16) return cs_run<bf16_t>(x, w, bias, y, g, false, st);
+  if (x->dtype == kF32) return cs_run<float>(x, w, bias, y, g, false, st);
+  return false;
+}
+bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
+  if (dy->dtype == kBF16) return cs_run<bf16_t>(dy, w, nullptr, dx, g, true, st);
+  if (dy->dtype == kF32) return cs_run<float>(dy, w, nullptr, dx, g, true, st);
+  return false;
+}
+
+}  // namespace lamp

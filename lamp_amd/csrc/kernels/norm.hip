@@ -112,18 +112,22 @@ __global__ __launch_bounds__(256) void bn_stats_col_kernel(const T* __restrict__
   A* o = partial + ((int64_t)split * C + c) * 3;
   o[0] = w.n; o[1] = w.mean; o[2] = w.m2;
 }
-// finalize: merge splits, write save_mean / save_invstd, update running stats
+// finalize: one wavefront per channel merges the split partials (Chan), lane 0 writes save_mean / save_invstd and
+// updates the running statistics
 template <class T>
-__global__ void bn_finalize_kernel(const acc_t<T>* __restrict__ partial, int64_t C, int nsplit, T* __restrict__ save_mean,
-                                   T* __restrict__ save_invstd, T* running_mean, T* running_var, double momentum, double eps) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const acc_t<T>* __restrict__ partial, int64_t C, int nsplit, T* __restrict__ save_mean,
+                                                          T* __restrict__ save_invstd, T* running_mean, T* running_var, double momentum, double eps) {
   using A = acc_t<T>;
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (c >= C) return;
   Welford<A> r{0, 0, 0};
-  for (int s = 0; s < nsplit; s++) {
+  for (int s = lane; s < nsplit; s += 64) {
     const A* p = partial + ((int64_t)s * C + c) * 3;
     r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
   }
+  r = wf_wave(r);
+  if (lane != 0) return;
   const A var_biased = r.m2 / r.n;
   const A invstd = A(1) / (A)sqrt((double)(var_biased + (A)eps));
   save_mean[c] = store_as<T>(r.mean);
@@ -237,15 +241,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_col_kernel(const T* __restr
   partial[((int64_t)split * C + c) * 2] = s1;
   partial[((int64_t)split * C + c) * 2 + 1] = s2;
 }
-// sums[c] = merged partials; also writes dweight / dbias if requested
+// sums[c] = merged partials (one wavefront per channel); also writes dweight / dbias if requested
 template <class T>
-__global__ void bn_bwd_finalize_kernel(const acc_t<T>* __restrict__ partial, acc_t<T>* __restrict__ sums, int64_t C, int nsplit,
-                                       const T* __restrict__ invstd, T* dweight, T* dbias) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const acc_t<T>* __restrict__ partial, acc_t<T>* __restrict__ sums, int64_t C, int nsplit,
+                                                              const T* __restrict__ invstd, T* dweight, T* dbias) {
   using A = acc_t<T>;
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (c >= C) return;
   A a = 0, b = 0;
-  for (int s = 0; s < nsplit; s++) { a += partial[((int64_t)s * C + c) * 2]; b += partial[((int64_t)s * C + c) * 2 + 1]; }
+  for (int s = lane; s < nsplit; s += 64) { a += partial[((int64_t)s * C + c) * 2]; b += partial[((int64_t)s * C + c) * 2 + 1]; }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane != 0) return;
   sums[c * 2] = a; sums[c * 2 + 1] = b;
   if (dweight) dweight[c] = store_as<T>((A)(b * load_as<A>(invstd[c])));
   if (dbias) dbias[c] = store_as<T>(a);
@@ -432,7 +439,7 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
       if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
       else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
       LAMP_LAUNCH_CHECK();
-      hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
+      hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
                          mean->ptr<T>(), invstd->ptr<T>(), running_mean ? running_mean->ptr<T>() : (T*)nullptr,
                          running_var ? running_var->ptr<T>() : (T*)nullptr, momentum, eps);
       LAMP_LAUNCH_CHECK();
@@ -502,7 +509,7 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
     if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
     LAMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
                        nsplit, invstd_t->ptr<T>(), dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr);
     LAMP_LAUNCH_CHECK();
     if (dx.get() && total > 0) {
