@@ -262,6 +262,8 @@ int lamp_atan(lamp_tensor** out, const lamp_tensor* a);
  *   relu:  out += p * (x < 0 ? 0 : 1)      ops.scala:918-935 (gradient at x == 0 is 1)
  *   leaky: out += p * (x < 0 ? slope : 1)  ops.scala:936-953 */
 int lamp_relu_backward_accumulate_(lamp_tensor* out, const lamp_tensor* p, const lamp_tensor* x, double negative_slope);
+/* the same product written to a fresh tensor (first accumulation into a still-zero gradient: 0 + v == v) */
+int lamp_relu_backward(lamp_tensor** out, const lamp_tensor* p, const lamp_tensor* x, double negative_slope);
 
 /* ------------------------------------------------------------------------------------------
  * reductions   (sum_0/sum_1/mean_1/norm_3/var_mean/argmax/max/min: STen.scala:1336-1352,

@@ -31,7 +31,7 @@ extern "C" {
 int lamp_var_const(lamp_var** out, const lamp_tensor* value) { LAMP_API_BEGIN *out = wrap(make_const(borrow(value))); LAMP_API_END }
 int lamp_var_param(lamp_var** out, const lamp_tensor* value) { LAMP_API_BEGIN *out = wrap(make_param(borrow(value))); LAMP_API_END }
 int lamp_var_value(const lamp_var* v, lamp_tensor** out) { LAMP_API_BEGIN *out = give(v->v->value); LAMP_API_END }
-int lamp_var_grad(const lamp_var* v, lamp_tensor** out) { LAMP_API_BEGIN *out = give(v->v->grad); LAMP_API_END }
+int lamp_var_grad(const lamp_var* v, lamp_tensor** out) { LAMP_API_BEGIN *out = give(v->v->grad_tensor()); LAMP_API_END }
 int lamp_var_needs_grad(const lamp_var* v, int* out) { LAMP_API_BEGIN *out = v->v->needsGrad(); LAMP_API_END }
 int lamp_var_zero_grad(lamp_var* v) { LAMP_API_BEGIN v->v->zeroGrad(); LAMP_API_END }
 int lamp_var_backprop(lamp_var* v) { LAMP_API_BEGIN backprop(v->v); LAMP_API_END }

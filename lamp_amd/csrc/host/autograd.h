@@ -129,28 +129,73 @@ inline Ten cat(const std::vector<Ten>& ts, int64_t dim) {
 // ---- autograd --------------------------------------------------------------------------------
 struct Variable;
 using Var = std::shared_ptr<Variable>;
-using Backward = std::function<void(const Ten& p, const Ten& out)>;
+// a backward closure receives the incoming partial derivative p and the INPUT variable whose gradient it
+// must add to (autograd.scala:66-84: "the result is accumulated (added)")
+using Backward = std::function<void(const Ten& p, Variable& out)>;
 
 struct Op {
   virtual ~Op() = default;
-  // (input, closure): the closure ADDS its partial derivative into `out` (autograd.scala:66-84)
   std::vector<std::pair<Var, Backward>> params;
   const char* name = "op";
 };
 
+// Gradient buffers.  lamp allocates a zeros_like buffer for every op output up front (autograd.scala:89-96) and
+// every closure does `out += ...`.  Here the buffer is created by the FIRST accumulation instead (0 + v == v,
+// bit for bit): no memset, no read-modify-write for the common single-consumer case, same values.
+//   grad undefined  <=> mathematically zero (nothing accumulated yet)
+//   grad_shared     <=> the tensor was adopted from somewhere else (e.g. `out += p` with equal shapes adopts p):
+//                       it must not be modified in place; the next accumulation writes a fresh tensor.
 struct Variable {
   std::shared_ptr<Op> op;   // empty for constants / parameters
   Ten value;
-  Ten grad;                 // undefined <=> needsGrad == false
-  bool needsGrad() const { return grad.defined(); }
+  bool wants_grad = false;  // lamp's needsGrad
+  Ten grad;
+  bool grad_shared = false;
+  bool needsGrad() const { return wants_grad; }
   std::vector<int64_t> shape() const { return value.shape(); }
-  void zeroGrad() { if (grad.defined()) ops::zero_(grad); }
+  void zeroGrad() { grad = Ten(); grad_shared = false; }            // lazily zero
+  // the gradient as a tensor (materialises zeros if nothing was accumulated)
+  Ten grad_tensor() {
+    if (!wants_grad) return Ten();
+    if (!grad.defined()) { grad = ops::zeros_like(value); grad_shared = false; }
+    return grad;
+  }
+  // an exclusively owned buffer that kernels may update in place
+  Ten grad_inplace() {
+    if (!grad.defined()) { grad = ops::zeros_like(value); grad_shared = false; }
+    else if (grad_shared) { grad = ops::clone(grad); grad_shared = false; }
+    return grad;
+  }
+  // out += t.  `fresh`: t is a temporary nobody else will read or write, so it can become the buffer itself.
+  void accumulate(const Ten& t, bool fresh) {
+    if (!grad.defined()) { grad = t; grad_shared = !fresh; return; }
+    if (grad_shared) { grad = ops::add(grad, t); grad_shared = false; return; }
+    ops::add_(grad, t);
+  }
+  void accumulate_scaled(const Ten& t, double alpha) {   // out += alpha * t
+    if (!grad.defined()) { grad = ops::mul_scalar(t, alpha); grad_shared = false; return; }
+    if (grad_shared) { grad = ops::add(grad, t, alpha); grad_shared = false; return; }
+    ops::add_(grad, t, alpha);
+  }
+  void subtract(const Ten& t) { accumulate_scaled(t, -1.0); }
+  // out += value * t1 * t2   (ATen addcmul)
+  void addcmul(const Ten& t1, const Ten& t2, double v) {
+    if (!grad.defined()) {
+      Ten m = ops::mul(t1, t2);
+      if (v != 1.0) ops::mul_scalar_(m, v);
+      if (m.shape() != value.shape()) { grad = ops::zeros_like(value); ops::add_(grad, m); }   // broadcast product
+      else grad = m;
+      grad_shared = false;
+      return;
+    }
+    ops::addcmul_(grad_inplace(), t1, t2, v);
+  }
+  bool has_grad() const { return grad.defined(); }
 };
 
 Var make_const(const Ten& t);   // package.scala:60-68
 Var make_param(const Ten& t);   // package.scala:70-78
-// Variable.apply: value + pre-zeroed grad buffer (autograd.scala:88-96)
-Var make_result(const std::shared_ptr<Op>& op, const Ten& value);
+Var make_result(const std::shared_ptr<Op>& op, const Ten& value);   // Variable.apply (autograd.scala:88-96)
 std::vector<Variable*> topological_sort(Variable* root);   // autograd.scala:490-518
 void backprop(const Var& root);                            // autograd.scala:264-282
 

@@ -31,7 +31,7 @@ struct Module {
     if (zeroGradFirst) zeroGrad();
     backprop(loss);
     std::vector<Ten> g;
-    for (auto& p : parameters()) g.push_back(p->grad);
+    for (auto& p : parameters()) g.push_back(p->grad_inplace());   // exclusive, materialised (zeros if nothing flowed)
     return g;
   }
 };

@@ -1,13 +1,14 @@
 // lamp's autograd operators, restated over the C ABI.
 //
 // Reference: lamp-core/src/main/scala/lamp/autograd/ops.scala - each function below cites the
-// case class it mirrors.  The forward runs at construction, every backward closure ADDS into
-// the pre-allocated gradient buffer of its input (`out += ...`), exactly as in the reference,
+// case class it mirrors.  The forward runs at construction, every backward closure ADDS its
+// partial derivative to the gradient of its input (`out += ...`), exactly as in the reference,
 // including its quirks (relu gradient at 0 is 1; IndexSelect's `out += out.indexAdd(...)`).
-// Where the reference recomputes one native call three times with different output masks
-// (Convolution, BatchNorm*, LayerNorm) the closures here still make one call per requested
-// derivative - the same arithmetic, see DESIGN.md for the cached variant used by the
-// training step.
+//
+// Gradient buffers are created by the first accumulation (see Variable in autograd.h): where the
+// reference does zeros_like + `out += v`, the first closure to run simply installs v (0 + v == v
+// exactly), later closures add in place.  In-place native forms (addmm_out_transposed*, the fused
+// relu backward) take their beta = 0 / out-of-place variant for that first accumulation.
 #include "ops.h"
 
 namespace lamp {
@@ -21,14 +22,14 @@ Var make_const(const Ten& t) {
 Var make_param(const Ten& t) {
   auto v = std::make_shared<Variable>();
   v->value = t;
-  v->grad = ops::zeros_like(t);
+  v->wants_grad = true;
   return v;
 }
 Var make_result(const std::shared_ptr<Op>& op, const Ten& value) {
   auto v = std::make_shared<Variable>();
   v->op = op;
   v->value = value;
-  v->grad = ops::zeros_like(value);
+  v->wants_grad = true;
   return v;
 }
 
@@ -48,11 +49,12 @@ std::vector<Variable*> topological_sort(Variable* root) {
 
 void backprop(const Var& root) {
   if (!root->needsGrad()) return;
-  ops::fill_(root->grad, 1.0);
+  root->grad = ops::ones_like(root->value);   // partialDerivative.get.fill_(1d)
+  root->grad_shared = false;
   for (Variable* v : topological_sort(root.get())) {
-    if (!v->op) continue;
+    if (!v->op || !v->has_grad()) continue;   // a node nothing flowed into contributes exact zeros
     for (auto& p : v->op->params)
-      if (p.first->needsGrad()) p.second(v->grad, p.first->grad);
+      if (p.first->needsGrad()) p.second(v->grad, *p.first);
   }
 }
 
@@ -62,9 +64,20 @@ std::shared_ptr<Op> new_op(const char* name) {
   o->name = name;
   return o;
 }
-void acc_unbroadcast(const Ten& p, const Ten& out, const std::vector<int64_t>& shape, bool subtract = false) {
-  Ten u = ops::unbroadcast(p, shape);
-  if (subtract) ops::sub_(out, u); else ops::add_(out, u);
+// out (+/-)= p.unbroadcast(shape)
+void acc_unbroadcast(const Ten& p, Variable& out, const std::vector<int64_t>& shape, bool subtract = false) {
+  const bool same = p.shape() == shape;
+  Ten u = same ? p : ops::unbroadcast(p, shape);
+  if (subtract) out.subtract(u);
+  else out.accumulate(u, !same);
+}
+// a dense copy of p broadcast to `shape`
+Ten broadcast_copy(const Ten& p, const std::vector<int64_t>& shape) {
+  lamp_tensor *e = nullptr, *c = nullptr;
+  HCALL(lamp_expand(&e, p.h(), shape.data(), (int)shape.size()));
+  Ten eh(e);
+  HCALL(lamp_clone(&c, e));
+  return Ten(c);
 }
 }  // namespace
 
@@ -73,22 +86,22 @@ namespace F {
 // ---- shape ops (ops.scala:15-49, 1827-1843) -----------------------------------------------------
 Var transpose(const Var& a, int64_t d1, int64_t d2) {
   auto op = new_op("Transpose");
-  op->params.push_back({a, [d1, d2](const Ten& p, const Ten& out) { ops::add_(out, ops::transpose(p, d1, d2)); }});
+  op->params.push_back({a, [d1, d2](const Ten& p, Variable& out) { out.accumulate(ops::transpose(p, d1, d2), false); }});
   return make_result(op, ops::transpose(a->value, d1, d2));
 }
 Var view(const Var& a, const std::vector<int64_t>& shape) {
   auto op = new_op("View");
-  op->params.push_back({a, [](const Ten& p, const Ten& out) { ops::add_(out, ops::reshape(p, out.shape())); }});
+  op->params.push_back({a, [](const Ten& p, Variable& out) { out.accumulate(ops::reshape(p, out.shape()), false); }});
   return make_result(op, ops::view(a->value, shape));
 }
 Var reshape(const Var& a, const std::vector<int64_t>& shape) {
   auto op = new_op("Reshape");
-  op->params.push_back({a, [](const Ten& p, const Ten& out) { ops::add_(out, ops::reshape(p, out.shape())); }});
+  op->params.push_back({a, [](const Ten& p, Variable& out) { out.accumulate(ops::reshape(p, out.shape()), false); }});
   return make_result(op, ops::reshape(a->value, shape));
 }
 Var flatten(const Var& a, int64_t start, int64_t end) {
   auto op = new_op("Flatten");
-  op->params.push_back({a, [](const Ten& p, const Ten& out) { ops::add_(out, ops::reshape(p, out.shape())); }});
+  op->params.push_back({a, [](const Ten& p, Variable& out) { out.accumulate(ops::reshape(p, out.shape()), false); }});
   return make_result(op, ops::flatten(a->value, start, end));
 }
 Var concatenate(const std::vector<Var>& as, int64_t dim) {   // ops.scala:51-62
@@ -97,7 +110,7 @@ Var concatenate(const std::vector<Var>& as, int64_t dim) {   // ops.scala:51-62
   int64_t from = 0;
   for (auto& a : as) {
     const int64_t to = from + a->value.size((int)dim);
-    op->params.push_back({a, [dim, from, to](const Ten& p, const Ten& out) { ops::add_(out, ops::slice(p, dim, from, to, 1)); }});
+    op->params.push_back({a, [dim, from, to](const Ten& p, Variable& out) { out.accumulate(ops::slice(p, dim, from, to, 1), false); }});
     vals.push_back(a->value);
     from = to;
   }
@@ -108,35 +121,44 @@ Var concatenate(const std::vector<Var>& as, int64_t dim) {   // ops.scala:51-62
 Var add(const Var& a, const Var& b) {
   auto op = new_op("Add");
   auto as = a->shape(), bs = b->shape();
-  op->params.push_back({a, [as](const Ten& p, const Ten& out) { acc_unbroadcast(p, out, as); }});
-  op->params.push_back({b, [bs](const Ten& p, const Ten& out) { acc_unbroadcast(p, out, bs); }});
+  op->params.push_back({a, [as](const Ten& p, Variable& out) { acc_unbroadcast(p, out, as); }});
+  op->params.push_back({b, [bs](const Ten& p, Variable& out) { acc_unbroadcast(p, out, bs); }});
   return make_result(op, ops::add(a->value, b->value));
 }
 Var const_add(const Var& a, double b) {
   auto op = new_op("ConstAdd");
   auto as = a->shape();
-  op->params.push_back({a, [as](const Ten& p, const Ten& out) { acc_unbroadcast(p, out, as); }});
+  op->params.push_back({a, [as](const Ten& p, Variable& out) { acc_unbroadcast(p, out, as); }});
   return make_result(op, ops::add_scalar(a->value, b));
 }
 Var minus(const Var& a, const Var& b) {
   auto op = new_op("Minus");
   auto as = a->shape(), bs = b->shape();
-  op->params.push_back({a, [as](const Ten& p, const Ten& out) { acc_unbroadcast(p, out, as); }});
-  op->params.push_back({b, [bs](const Ten& p, const Ten& out) { acc_unbroadcast(p, out, bs, true); }});
+  op->params.push_back({a, [as](const Ten& p, Variable& out) { acc_unbroadcast(p, out, as); }});
+  op->params.push_back({b, [bs](const Ten& p, Variable& out) { acc_unbroadcast(p, out, bs, true); }});
   return make_result(op, ops::sub(a->value, b->value));
 }
 Var const_mult(const Var& a, double b) {
   auto op = new_op("ConstMult");
   auto as = a->shape();
-  op->params.push_back({a, [as, b](const Ten& p, const Ten& out) { acc_unbroadcast(ops::mul_scalar(p, b), out, as); }});
+  op->params.push_back({a, [as, b](const Ten& p, Variable& out) {
+    Ten t = ops::mul_scalar(p, b);
+    if (t.shape() == as) out.accumulate(t, true); else out.accumulate(ops::unbroadcast(t, as), true);
+  }});
   return make_result(op, ops::mul_scalar(a->value, b));
 }
 Var mult(const Var& a, const Var& b) {
   auto op = new_op("Mult");
   auto as = a->shape(), bs = b->shape();
   Ten av = a->value, bv = b->value;
-  op->params.push_back({a, [as, bv](const Ten& p, const Ten& out) { acc_unbroadcast(ops::mul(p, bv), out, as); }});
-  op->params.push_back({b, [bs, av](const Ten& p, const Ten& out) { acc_unbroadcast(ops::mul(p, av), out, bs); }});
+  op->params.push_back({a, [as, bv](const Ten& p, Variable& out) {
+    Ten t = ops::mul(p, bv);
+    out.accumulate(t.shape() == as ? t : ops::unbroadcast(t, as), true);
+  }});
+  op->params.push_back({b, [bs, av](const Ten& p, Variable& out) {
+    Ten t = ops::mul(p, av);
+    out.accumulate(t.shape() == bs ? t : ops::unbroadcast(t, bs), true);
+  }});
   return make_result(op, ops::mul(a->value, b->value));
 }
 Var div(const Var& a, const Var& b) {
@@ -144,51 +166,92 @@ Var div(const Var& a, const Var& b) {
   auto as = a->shape(), bs = b->shape();
   Ten bv = b->value;
   Ten val = ops::div(a->value, b->value);
-  op->params.push_back({a, [as, bv](const Ten& p, const Ten& out) { acc_unbroadcast(ops::div(p, bv), out, as); }});
-  op->params.push_back({b, [bs, bv, val](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [as, bv](const Ten& p, Variable& out) {
+    Ten t = ops::div(p, bv);
+    out.accumulate(t.shape() == as ? t : ops::unbroadcast(t, as), true);
+  }});
+  op->params.push_back({b, [bs, bv, val](const Ten& p, Variable& out) {
     Ten tmp = ops::div(val, bv);
     ops::mul_(tmp, p);
-    acc_unbroadcast(tmp, out, bs, true);
+    out.subtract(tmp.shape() == bs ? tmp : ops::unbroadcast(tmp, bs));
   }});
   return make_result(op, val);
 }
-Var sum(const Var& a, const std::vector<int64_t>& dim, bool keepDim) {   // ops.scala:623-630
+Var sum(const Var& a, const std::vector<int64_t>& dim, bool keepDim) {   // ops.scala:623-630: out += p (broadcast)
   auto op = new_op("Sum");
-  op->params.push_back({a, [](const Ten& p, const Ten& out) { ops::add_(out, p); }});
+  auto as = a->shape();
+  op->params.push_back({a, [as, dim, keepDim](const Ten& p, Variable& out) {
+    if (p.shape() == as) { out.accumulate(p, false); return; }
+    // `out += p` broadcasts p; a reduced dim that was dropped (keepDim = false) only broadcasts when ATen's
+    // rules allow it, which is the case lamp uses (full sums, or keepDim = true)
+    if (!out.has_grad()) out.accumulate(broadcast_copy(p, as), true);
+    else ops::add_(out.grad_inplace(), p);
+    (void)dim; (void)keepDim;
+  }});
   return make_result(op, dim.empty() ? ops::sum_all(a->value) : ops::sum_dims(a->value, dim, keepDim));
 }
 Var mean(const Var& a, const std::vector<int64_t>& dim, bool keepDim) {  // ops.scala:1034-1054
   auto op = new_op("Mean");
   int64_t n = 1;
   for (auto d : dim) n *= a->value.size((int)d);
-  op->params.push_back({a, [n](const Ten& p, const Ten& out) { ops::add_(out, p, 1.0 / (double)n); }});
+  auto as = a->shape();
+  op->params.push_back({a, [n, as](const Ten& p, Variable& out) {
+    if (!out.has_grad()) {
+      Ten e = broadcast_copy(p, as);
+      ops::mul_scalar_(e, 1.0 / (double)n);
+      out.accumulate(e, true);
+    } else ops::add_(out.grad_inplace(), p, 1.0 / (double)n);
+  }});
   return make_result(op, ops::mean_dims(a->value, dim, keepDim));
 }
 Var norm2(const Var& a, const std::vector<int64_t>& dim, bool keepDim) {  // ops.scala:632-645
   auto op = new_op("Norm2");
   Ten av = a->value;
   Ten val = ops::norm2_dims(a->value, dim, keepDim);
-  op->params.push_back({a, [av, val](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [av, val](const Ten& p, Variable& out) {
     Ten pa = ops::mul(p, av);
     ops::div_(pa, val);
-    ops::add_(out, pa);
+    out.accumulate(pa, true);
   }});
   return make_result(op, val);
 }
 
 // ---- GEMM (ops.scala:665-724) -------------------------------------------------------------------
+namespace {
+// out = beta * out + op(a) op(b) through the transposed natives; first accumulation uses beta = 0 into a new buffer
+template <class Fn> void gemm_accumulate(Variable& out, Fn call) {
+  if (!out.has_grad()) {
+    lamp_tensor* fresh = nullptr;
+    HCALL(lamp_empty(&fresh, out.value.h()->sizes, out.value.ndim(), out.value.dtype(), out.value.device()));
+    Ten t(fresh);
+    call(t, 0.0);
+    out.grad = t;
+    out.grad_shared = false;
+  } else {
+    call(out.grad_inplace(), 1.0);
+  }
+}
+}  // namespace
 Var mm(const Var& a, const Var& b) {
   auto op = new_op("MatMul");
   Ten av = a->value, bv = b->value;
-  op->params.push_back({a, [bv](const Ten& p, const Ten& out) { HCALL(lamp_addmm_out_transposed2(out.h(), out.h(), p.h(), bv.h(), 1.0, 1.0)); }});
-  op->params.push_back({b, [av](const Ten& p, const Ten& out) { HCALL(lamp_addmm_out_transposed1(out.h(), out.h(), av.h(), p.h(), 1.0, 1.0)); }});
+  op->params.push_back({a, [bv](const Ten& p, Variable& out) {     // dA += p . B^T   (Tensor.addmm_out_transposed2)
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_addmm_out_transposed2(o.h(), o.h(), p.h(), bv.h(), beta, 1.0)); });
+  }});
+  op->params.push_back({b, [av](const Ten& p, Variable& out) {     // dB += A^T . p   (Tensor.addmm_out_transposed1)
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_addmm_out_transposed1(o.h(), o.h(), av.h(), p.h(), beta, 1.0)); });
+  }});
   return make_result(op, ops::mm(a->value, b->value));
 }
 Var bmm(const Var& a, const Var& b) {
   auto op = new_op("BatchedMatMul");
   Ten av = a->value, bv = b->value;
-  op->params.push_back({a, [bv](const Ten& p, const Ten& out) { HCALL(lamp_baddbmm_out_transposed2(out.h(), out.h(), p.h(), bv.h(), 1.0, 1.0)); }});
-  op->params.push_back({b, [av](const Ten& p, const Ten& out) { HCALL(lamp_baddbmm_out_transposed1(out.h(), out.h(), av.h(), p.h(), 1.0, 1.0)); }});
+  op->params.push_back({a, [bv](const Ten& p, Variable& out) {
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_baddbmm_out_transposed2(o.h(), o.h(), p.h(), bv.h(), beta, 1.0)); });
+  }});
+  op->params.push_back({b, [av](const Ten& p, Variable& out) {
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_baddbmm_out_transposed1(o.h(), o.h(), av.h(), p.h(), beta, 1.0)); });
+  }});
   return make_result(op, ops::bmm(a->value, b->value));
 }
 
@@ -196,61 +259,72 @@ Var bmm(const Var& a, const Var& b) {
 Var exp(const Var& a) {
   auto op = new_op("Exp");
   Ten val = ops::exp(a->value);
-  op->params.push_back({a, [val](const Ten& p, const Ten& out) { ops::addcmul_(out, p, val, 1.0); }});
+  op->params.push_back({a, [val](const Ten& p, Variable& out) { out.addcmul(p, val, 1.0); }});
   return make_result(op, val);
 }
 Var log(const Var& a) {
   auto op = new_op("Log");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::reciprocal(av), 1.0); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { out.addcmul(p, ops::reciprocal(av), 1.0); }});
   return make_result(op, ops::log(a->value));
 }
 Var log1p(const Var& a) {
   auto op = new_op("Log1p");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [av](const Ten& p, Variable& out) {
     Ten tmp = ops::add_scalar(av, 1.0);
     HCALL(lamp_reciprocal_(tmp.h()));
-    ops::addcmul_(out, p, tmp, 1.0);
+    out.addcmul(p, tmp, 1.0);
   }});
   return make_result(op, ops::log1p(a->value));
 }
 Var sin(const Var& a) {
   auto op = new_op("Sin");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::cos(av), 1.0); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { out.addcmul(p, ops::cos(av), 1.0); }});
   return make_result(op, ops::sin(a->value));
 }
 Var cos(const Var& a) {
   auto op = new_op("Cos");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::sin(av), -1.0); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { out.addcmul(p, ops::sin(av), -1.0); }});
   return make_result(op, ops::cos(a->value));
 }
 Var tanh(const Var& a) {
   auto op = new_op("Tanh");
   Ten val = ops::tanh(a->value);
-  op->params.push_back({a, [val](const Ten& p, const Ten& out) { ops::add_(out, ops::tanh_backward(p, val)); }});
+  op->params.push_back({a, [val](const Ten& p, Variable& out) { out.accumulate(ops::tanh_backward(p, val), true); }});
   return make_result(op, val);
 }
 Var pow_const(const Var& a, double e) {
   auto op = new_op("PowConst");
   Ten av = a->value;
-  op->params.push_back({a, [av, e](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::pow_scalar(av, e - 1), e); }});
+  op->params.push_back({a, [av, e](const Ten& p, Variable& out) { out.addcmul(p, ops::pow_scalar(av, e - 1), e); }});
   return make_result(op, ops::pow_scalar(a->value, e));
 }
 // Relu (ops.scala:918-935): out += p * where(a < 0, 0, 1) - five ATen calls and three temporaries in
-// the reference; here the same arithmetic in one fused kernel (lamp_relu_backward_accumulate_).
+// the reference; here the same arithmetic in one fused kernel.
+namespace {
+void relu_like_backward(const Ten& p, Variable& out, const Ten& x, double slope) {
+  if (!out.has_grad()) {
+    lamp_tensor* t = nullptr;
+    HCALL(lamp_relu_backward(&t, p.h(), x.h(), slope));
+    out.accumulate(Ten(t), true);
+  } else {
+    HCALL(lamp_relu_backward_accumulate_(out.grad_inplace().h(), p.h(), x.h(), slope));
+  }
+}
+}  // namespace
 Var relu(const Var& a) {
   auto op = new_op("Relu");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { HCALL(lamp_relu_backward_accumulate_(out.h(), p.h(), av.h(), 0.0)); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { relu_like_backward(p, out, av, 0.0); }});
   return make_result(op, ops::relu(a->value));
 }
 Var leaky_relu(const Var& a, double slope) {
   auto op = new_op("LeakyRelu");
   Ten av = a->value;
-  op->params.push_back({a, [av, slope](const Ten& p, const Ten& out) { HCALL(lamp_relu_backward_accumulate_(out.h(), p.h(), av.h(), slope)); }});
+  op->params.push_back({a, [av, slope](const Ten& p, Variable& out) { relu_like_backward(p, out, av, slope); }});
   lamp_tensor* o = nullptr;
   HCALL(lamp_leaky_relu(&o, a->value.h(), slope));
   return make_result(op, Ten(o));
@@ -258,28 +332,28 @@ Var leaky_relu(const Var& a, double slope) {
 Var gelu(const Var& a) {
   auto op = new_op("Gelu");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { ops::add_(out, ops::gelu_backward(p, av)); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { out.accumulate(ops::gelu_backward(p, av), true); }});
   return make_result(op, ops::gelu(a->value));
 }
 Var sigmoid(const Var& a) {
   auto op = new_op("Sigmoid");
   Ten val = ops::sigmoid(a->value);
-  op->params.push_back({a, [val](const Ten& p, const Ten& out) { ops::add_(out, ops::sigmoid_backward(p, val)); }});
+  op->params.push_back({a, [val](const Ten& p, Variable& out) { out.accumulate(ops::sigmoid_backward(p, val), true); }});
   return make_result(op, val);
 }
 Var hardswish(const Var& a) {
   auto op = new_op("HardSwish");
   Ten av = a->value;
-  op->params.push_back({a, [av](const Ten& p, const Ten& out) { ops::add_(out, ops::hardswish_backward(p, av)); }});
+  op->params.push_back({a, [av](const Ten& p, Variable& out) { out.accumulate(ops::hardswish_backward(p, av), true); }});
   return make_result(op, ops::hardswish(a->value));
 }
 Var softplus(const Var& a, double beta, double threshold) {
   auto op = new_op("Softplus");
   Ten av = a->value;
-  op->params.push_back({a, [av, beta, threshold](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [av, beta, threshold](const Ten& p, Variable& out) {
     lamp_tensor* o = nullptr;
     HCALL(lamp_softplus_backward(&o, p.h(), av.h(), beta, threshold));
-    ops::add_(out, Ten(o));
+    out.accumulate(Ten(o), true);
   }});
   lamp_tensor* o = nullptr;
   HCALL(lamp_softplus(&o, a->value.h(), beta, threshold));
@@ -290,22 +364,22 @@ Var log_softmax(const Var& a, int64_t dim) {   // ops.scala:955-975
   lamp_tensor* o = nullptr;
   HCALL(lamp_log_softmax(&o, a->value.h(), dim));
   Ten val(o);
-  op->params.push_back({a, [val, dim](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [val, dim](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_log_softmax_backward_data(&t, p.h(), val.h(), dim));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   return make_result(op, val);
 }
 Var dropout(const Var& a, double prob, bool train) {   // ops.scala:1079-1100
   auto op = new_op("Dropout");
   if (prob <= 0.0) {
-    op->params.push_back({a, [](const Ten& p, const Ten& out) { ops::add_(out, p); }});
+    op->params.push_back({a, [](const Ten& p, Variable& out) { out.accumulate(p, false); }});
     return make_result(op, a->value);
   }
   Ten mask = ops::ones_like(a->value);
   HCALL(lamp_dropout_(mask.h(), prob, train));
-  op->params.push_back({a, [mask](const Ten& p, const Ten& out) { ops::addcmul_(out, p, mask, 1.0); }});
+  op->params.push_back({a, [mask](const Ten& p, Variable& out) { out.addcmul(p, mask, 1.0); }});
   return make_result(op, ops::mul(a->value, mask));
 }
 
@@ -317,10 +391,10 @@ Var nll_loss(const Var& input, const Ten& target, const Ten& weights, int64_t re
   lamp_tensor *v = nullptr, *tw = nullptr;
   HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
   Ten val(v), total_weight(tw), iv = input->value;
-  op->params.push_back({input, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({input, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_nll_loss_backward(&t, p.h(), iv.h(), target.h(), weights.h(), reduction, ignore, total_weight.h()));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   return make_result(op, val);
 }
@@ -328,10 +402,10 @@ Var mse_loss(const Var& input, const Ten& target, int64_t reduction) {
   LAMP_CHECK(input->value.numel() == target.numel(), "mse loss: input/target size mismatch");
   auto op = new_op("MseLoss");
   Ten tv = ops::view(target, input->shape()), iv = input->value;
-  op->params.push_back({input, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({input, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_mse_loss_backward(&t, p.h(), iv.h(), tv.h(), reduction));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   lamp_tensor* o = nullptr;
   HCALL(lamp_mse_loss(&o, iv.h(), tv.h(), reduction));
@@ -342,9 +416,14 @@ Var mse_loss(const Var& input, const Ten& target, int64_t reduction) {
 Var index_select(const Var& input, int64_t dim, const Var& index) {
   auto op = new_op("IndexSelect");
   Ten idx = index->value;
-  op->params.push_back({input, [dim, idx](const Ten& p, const Ten& out) {
-    Ten tmp = ops::index_add(out, dim, idx, p);   // val tmp = out.indexAdd(dim, index, p)
-    ops::add_(out, tmp);                          // out += tmp
+  op->params.push_back({input, [dim, idx](const Ten& p, Variable& out) {
+    // val tmp = out.indexAdd(dim, index, p); out += tmp      => out = 2 * out + scatter(p)   (sic)
+    if (!out.has_grad()) {
+      out.accumulate(ops::index_add(ops::zeros_like(out.value), dim, idx, p), true);
+    } else {
+      Ten tmp = ops::index_add(out.grad, dim, idx, p);
+      out.accumulate(tmp, true);
+    }
   }});
   return make_result(op, ops::index_select(input->value, dim, idx));
 }
@@ -352,8 +431,8 @@ Var euclidean_distance(const Var& a, const Var& b, int64_t dim) {
   auto op = new_op("EuclideanDistance");
   Ten diff = ops::sub(a->value, b->value);
   Ten norm = ops::norm2_dims(diff, {dim}, true);
-  op->params.push_back({a, [diff, norm](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::div(diff, norm), 1.0); }});
-  op->params.push_back({b, [diff, norm](const Ten& p, const Ten& out) { ops::addcmul_(out, p, ops::div(diff, norm), -1.0); }});
+  op->params.push_back({a, [diff, norm](const Ten& p, Variable& out) { out.addcmul(p, ops::div(diff, norm), 1.0); }});
+  op->params.push_back({b, [diff, norm](const Ten& p, Variable& out) { out.addcmul(p, ops::div(diff, norm), -1.0); }});
   return make_result(op, norm);
 }
 Var capped_shifted_negative_exponential(const Var& a, double shift) {
@@ -364,10 +443,10 @@ Var capped_shifted_negative_exponential(const Var& a, double shift) {
   Ten above = ops::sub(ops::scalar(shift, dt, dev), a->value);
   HCALL(lamp_exp_(above.h()));
   Ten result = ops::where(pred, ones, above);
-  op->params.push_back({a, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({a, [=](const Ten& p, Variable& out) {
     Ten zeros = ops::zeros({1}, dt, dev);
     Ten nonzeros = ops::mul_scalar(result, -1.0);
-    ops::addcmul_(out, p, ops::where(pred, zeros, nonzeros), 1.0);
+    out.addcmul(p, ops::where(pred, zeros, nonzeros), 1.0);
   }});
   return make_result(op, result);
 }
@@ -380,13 +459,12 @@ Var convolution(const Var& input, const Var& weight, const Var& bias, const std:
   const int ns = (int)stride.size();
   Ten iv = input->value, wv = weight->value;
   auto back = [=](int which) {
-    return [=](const Ten& p, const Ten& out) {
+    return [=](const Ten& p, Variable& out) {
       lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
       uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1), (uint8_t)(which == 2)};
       HCALL(lamp_convolution_backward(o3, p.h(), iv.h(), wv.h(), stride.data(), padding.data(), dilation.data(), ns, transposed,
                                       outputPadding.data(), groups, mask));
-      Ten r(o3[which]);
-      ops::add_(out, r);
+      out.accumulate(Ten(o3[which]), true);
     };
   };
   op->params.push_back({input, back(0)});
@@ -401,10 +479,10 @@ Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding) {
   LAMP_CHECK(input->value.ndim() == 4, "Input dimensions must be 4");
   auto op = new_op("AvgPool2D");
   Ten iv = input->value;
-  op->params.push_back({input, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({input, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_avg_pool2d_backward(&t, p.h(), iv.h(), k, stride, padding, 0, 1));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   lamp_tensor* o = nullptr;
   HCALL(lamp_avg_pool2d(&o, iv.h(), k, stride, padding, 0, 1));
@@ -417,10 +495,10 @@ Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int
   lamp_tensor *o = nullptr, *m = nullptr;
   HCALL(lamp_max_pool2d_with_indices(&o, &m, iv.h(), k, stride, padding, dilation, 0));
   Ten mask(m);
-  op->params.push_back({input, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({input, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_max_pool2d_with_indices_backward(&t, p.h(), iv.h(), k, stride, padding, dilation, 0, mask.h()));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   return make_result(op, Ten(o));
 }
@@ -443,9 +521,9 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
   auto cache = std::make_shared<std::pair<Ten, Ten>>();   // (dweight, the incoming gradient it was computed for)
   const bool both = input->needsGrad() && weight->needsGrad();
   auto back = [=](int which) {
-    return [=](const Ten& p, const Ten& o) {
+    return [=](const Ten& p, Variable& o) {
       if (which == 1 && cache->first.defined() && cache->second.h() == p.h()) {
-        ops::add_(o, ops::reshape(cache->first, o.shape()));
+        o.accumulate(ops::reshape(cache->first, o.shape()), true);
         cache->first = Ten(); cache->second = Ten();
         return;
       }
@@ -457,19 +535,19 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
                                             training, eps, mask));
       Ten r0(r3[0]), r1(r3[1]);
       if (want_both) { cache->first = r1; cache->second = p; }
-      ops::add_(o, ops::reshape(which == 0 ? r0 : r1, o.shape()));
+      o.accumulate(ops::reshape(which == 0 ? r0 : r1, o.shape()), true);
     };
   };
   op->params.push_back({input, back(0)});
   op->params.push_back({weight, back(1)});
-  op->params.push_back({bias, [=](const Ten& p, const Ten& o) {
+  op->params.push_back({bias, [=](const Ten& p, Variable& o) {
     if (two_d) {
       std::vector<int64_t> tgt = o.shape();
       for (int i = 0; i < p.ndim() - 2; i++) tgt.push_back(1);
-      ops::add_(o, ops::reshape(ops::unbroadcast(p, tgt), o.shape()));
+      o.accumulate(ops::reshape(ops::unbroadcast(p, tgt), o.shape()), true);
     } else {
       Ten fp = ops::flatten(p, 1, p.ndim() - 1);
-      ops::add_(o, ops::unbroadcast(fp, o.shape()));
+      o.accumulate(ops::unbroadcast(fp, o.shape()), fp.shape() != o.shape());
     }
   }});
   return make_result(op, two_d ? out : ops::reshape(out, input->shape()));
@@ -493,13 +571,12 @@ Var layer_norm(const Var& input, const Var& weight, const Var& bias, const std::
   Ten out(o3[0]), mean(o3[1]), rstd(o3[2]), iv = input->value;
   Ten wv = weight ? weight->value : Ten(), bv = bias ? bias->value : Ten();
   auto back = [=](int which) {
-    return [=](const Ten& p, const Ten& o) {
+    return [=](const Ten& p, Variable& o) {
       lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
       uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1), (uint8_t)(which == 2)};
       HCALL(lamp_native_layer_norm_backward(r3, p.h(), iv.h(), normalizedShape.data(), (int)normalizedShape.size(), mean.h(), rstd.h(),
                                             wv.h(), bv.h(), mask));
-      Ten r(r3[which]);
-      ops::add_(o, r);
+      o.accumulate(Ten(r3[which]), true);
     };
   };
   op->params.push_back({input, back(0)});
@@ -511,10 +588,10 @@ Var embedding(const Var& input, const Var& weight) {   // ops.scala:2141-2170
   auto op = new_op("Embedding");
   Ten idx = input->value;
   const int64_t nw = weight->value.size(0);
-  op->params.push_back({weight, [=](const Ten& p, const Ten& out) {
+  op->params.push_back({weight, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
     HCALL(lamp_embedding_backward(&t, p.h(), idx.h(), nw));
-    ops::add_(out, Ten(t));
+    out.accumulate(Ten(t), true);
   }});
   lamp_tensor* o = nullptr;
   HCALL(lamp_embedding(&o, weight->value.h(), idx.h()));

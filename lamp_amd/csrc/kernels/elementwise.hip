@@ -160,6 +160,7 @@ FUNCTOR_BEGIN(FAddcdiv) return store_as<TO>((A)(a + (A)p0 * b / c)); FUNCTOR_END
 // out(a) += p(b) * (x(c) < 0 ? slope : 1)      ops.scala:918-953
 FUNCTOR_BEGIN(FReluBwdAcc) return store_as<TO>((A)(a + b * ((c < A(0)) ? (A)p0 : A(1)))); FUNCTOR_END
 
+FUNCTOR_BEGIN(FReluBwd) return store_as<TO>((A)(a * ((b < A(0)) ? (A)p0 : A(1)))); FUNCTOR_END   // p * (x < 0 ? slope : 1)
 FUNCTOR_BEGIN(FRelu) return store_as<TO>((A)((a < A(0)) ? A(0) : a)); FUNCTOR_END   // NaN propagates like ATen's relu
 FUNCTOR_BEGIN(FLeakyRelu) return store_as<TO>((A)((a > A(0)) ? a : a * (A)p0)); FUNCTOR_END
 FUNCTOR_BEGIN(FGelu) return store_as<TO>((A)(a * A(0.5) * (A(1) + m_erf<A>(a * A(0.70710678118654752440))))); FUNCTOR_END
@@ -380,6 +381,9 @@ int lamp_relu_backward_accumulate_(lamp_tensor* out, const lamp_tensor* p, const
   LAMP_API_BEGIN run_same<3, FReluBwdAcc, true>(out, out, p, x, FReluBwdAcc{negative_slope, 0}); LAMP_API_END
 }
 
+int lamp_relu_backward(lamp_tensor** out, const lamp_tensor* p, const lamp_tensor* x, double negative_slope) {
+  LAMP_API_BEGIN *out = run_same<2, FReluBwd, true>(nullptr, p, x, nullptr, FReluBwd{negative_slope, 0}); LAMP_API_END
+}
 API1(relu, FRelu, false)
 API1_INPLACE(relu_, FRelu, false)
 int lamp_leaky_relu(lamp_tensor** out, const lamp_tensor* a, double slope) {
