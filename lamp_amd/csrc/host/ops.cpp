@@ -515,32 +515,40 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
   HCALL(lamp_native_batch_norm(o3, x.h(), weight->value.h(), bias->value.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
   Ten out(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]), wv = weight->value;
   // The reference calls native_batch_norm_backward once per requested derivative (ops.scala:1901,1924,
-  // 2086,2107); both calls reduce the same two per-channel sums.  Here the first closure that runs asks
-  // for dx AND dweight in one call and parks dweight for the other closure - identical arithmetic, one
-  // reduction pass over (dy, x) instead of two.
-  auto cache = std::make_shared<std::pair<Ten, Ten>>();   // (dweight, the incoming gradient it was computed for)
-  const bool both = input->needsGrad() && weight->needsGrad();
+  // 2086,2107) and sums p again for the bias; all three reduce the same per-channel sums.  Here the input
+  // closure (it runs first) asks for dx, dweight AND dbias in one call and parks the latter two for the
+  // sibling closures - identical arithmetic, one reduction pass over (dy, x) instead of three.
+  struct Cache { Ten dweight, dbias, p; };                 // results parked for the sibling closures + the gradient they belong to
+  auto cache = std::make_shared<Cache>();
+  const bool want_w = weight->needsGrad(), want_b = bias->needsGrad();
   auto back = [=](int which) {
     return [=](const Ten& p, Variable& o) {
-      if (which == 1 && cache->first.defined() && cache->second.h() == p.h()) {
-        o.accumulate(ops::reshape(cache->first, o.shape()), true);
-        cache->first = Ten(); cache->second = Ten();
+      if (which == 1 && cache->dweight.defined() && cache->p.h() == p.h()) {
+        o.accumulate(ops::reshape(cache->dweight, o.shape()), true);
+        cache->dweight = Ten();
         return;
       }
       Ten fp = two_d ? p : ops::flatten(p, 1, p.ndim() - 1);
       lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
-      const bool want_both = both && which == 0;
-      uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1 || want_both), 0};
+      const bool first = which == 0;   // the input closure runs first and shares its reduction pass with weight and bias
+      uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1 || (first && want_w)), (uint8_t)(first && want_b)};
       HCALL(lamp_native_batch_norm_backward(r3, fp.h(), x.h(), wv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(),
                                             training, eps, mask));
-      Ten r0(r3[0]), r1(r3[1]);
-      if (want_both) { cache->first = r1; cache->second = p; }
+      Ten r0(r3[0]), r1(r3[1]), r2(r3[2]);
+      if (first) { cache->dweight = r1; cache->dbias = r2; cache->p = p; }
       o.accumulate(ops::reshape(which == 0 ? r0 : r1, o.shape()), true);
     };
   };
   op->params.push_back({input, back(0)});
   op->params.push_back({weight, back(1)});
+  // bias gradient = sum of p over every dim but the channel one (ops.scala:1944-1953, 2126-2138: unbroadcast + view);
+  // that sum is also a by-product of native_batch_norm_backward's reduction, so it is taken from there when available
   op->params.push_back({bias, [=](const Ten& p, Variable& o) {
+    if (cache->dbias.defined() && cache->p.h() == p.h()) {
+      o.accumulate(ops::reshape(cache->dbias, o.shape()), true);
+      cache->dbias = Ten(); cache->p = Ten();
+      return;
+    }
     if (two_d) {
       std::vector<int64_t> tgt = o.shape();
       for (int i = 0; i < p.ndim() - 2; i++) tgt.push_back(1);

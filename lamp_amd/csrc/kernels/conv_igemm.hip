@@ -276,14 +276,120 @@ __global__ __launch_bounds__(256) void ig_wgrad8_kernel(const bf16_t* __restrict
         out[co * IG_M + ci] = acc[i][j][rr];
       }
 }
-// dw[co][ci][r][s] = sum_split partial[split][rs][co][ci]
+// dw[co][ci][r][s] = sum_split partial[split][rs][co][ci]; threads run along ci (the contiguous index of the partials)
 __global__ void ig_wgrad_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int RS, int nsplit) {
-  const int total = CO * CI * RS;
+  const int total = RS * CO * CI;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int rs = e % RS, ci = (e / RS) % CI, co = e / (RS * CI);
+    const int ci = e % CI, co = (e / CI) % CO, rs = e / (CI * CO);
     float a = 0.f;
     for (int sp = 0; sp < nsplit; sp++) a += partial[((int64_t)(sp * RS + rs) * IG_M + co) * IG_M + ci];
-    dw[e] = bf16_t(a);
+    dw[((int64_t)co * CI + ci) * RS + rs] = bf16_t(a);
+  }
+}
+
+// ---- wgrad v2: all taps in one workgroup ----------------------------------------------------------------
+// Workgroup = (32-channel slice of Cin, image range); it owns dW[all taps][128 co][32 ci] in registers (9 x 4 MFMA
+// tiles per wave).  Per image: dY[128 co][64 px] is staged K-contiguous (swizzled 128-B rows) and X[32 ci][8x8] is
+// staged as THREE horizontally shifted copies with a zero row above and below ([s][ci][10 rows][8 px], 176-B channel
+// stride => conflict-free ds_read_b128), so the B fragment of tap (r, s) for image rows 4ks..4ks+3 is one aligned
+// 16-byte read.  A fragments are shared by the 9 taps: 26 LDS reads feed 72 MFMAs per wave and image.
+constexpr int WG_CI = 32;                         // input channels per workgroup
+constexpr int WG_XCH = 176;                       // bytes per channel in one shifted copy (11 x 16)
+constexpr int WG_XCOPY = WG_CI * WG_XCH;          // 5632
+constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies (+ pad to keep stages 16-B aligned) = 33,792
+template <int KS>
+__global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                          int N, int CO, int CI, int CIP, int images_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int ci0 = tile * WG_CI;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
+  // zero both stages once: the padding rows of the shifted copies are never written again
+  for (int o = tid * 16; o < 2 * WG_STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const int xci = tid >> 3, xh = tid & 7;          // this thread's (channel, image row) of the X tile
+  auto load_x = [&](int n) -> uint4 {
+    if (ci0 + xci < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto store_x = [&](char* stage, uint4 v) {
+    char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
+    if (KS == 1) { *reinterpret_cast<uint4*>(xb) = v; return; }
+    // copy s holds out[w] = in[w + s - 1]
+    *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
+    *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
+    *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
+  };
+
+  f4v acc[RS][4];
+#pragma unroll
+  for (int t = 0; t < RS; t++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rx;
+  if (nbeg < nend) {
+    ig_stage_load_rows(ra, dy + (int64_t)nbeg * CO * 64, 64, 0, CO, 64, tid);
+    rx = load_x(nbeg);
+    ig_stage_store_rows(ra, smem, tid);
+    store_x(smem, rx);
+  }
+  __syncthreads();
+  for (int n = nbeg; n < nend; n++) {
+    const int cur = (n - nbeg) & 1;
+    if (n + 1 < nend) {
+      ig_stage_load_rows(ra, dy + (int64_t)(n + 1) * CO * 64, 64, 0, CO, 64, tid);
+      rx = load_x(n + 1);
+    }
+    const char* st = smem + cur * WG_STAGE;
+    const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf8v fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(st, wr * 64 + i * 16, ks, lane);
+      const int h = 4 * ks + (lane >> 4);
+#pragma unroll
+      for (int t = 0; t < RS; t++) {
+        const int r = t / KS, s = t % KS;
+        s8v v = *reinterpret_cast<const s8v*>(xl + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
+        const bf8v fb = __builtin_bit_cast(bf8v, v);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i], 0, 0, 0);
+      }
+    }
+    if (n + 1 < nend) {
+      char* nx = smem + (cur ^ 1) * WG_STAGE;
+      ig_stage_store_rows(ra, nx, tid);
+      store_x(nx, rx);
+    }
+    __syncthreads();
+  }
+  // partial[(split * RS + t)][co][CIP]
+#pragma unroll
+  for (int t = 0; t < RS; t++) {
+    float* out = partial + (int64_t)(split * RS + t) * IG_M * CIP;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+        out[co * CIP + ci] = acc[t][i][rr];
+      }
+  }
+}
+__global__ void ig_wgrad_reduce_v2_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int CIP, int RS, int nsplit) {
+  const int total = RS * CO * CI;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ci = e % CI, co = (e / CI) % CO, rs = e / (CI * CO);
+    float a = 0.f;
+    for (int sp = 0; sp < nsplit; sp++) a += partial[((int64_t)(sp * RS + rs) * IG_M + co) * CIP + ci];
+    dw[((int64_t)co * CI + ci) * RS + rs] = bf16_t(a);
   }
 }
 
@@ -339,7 +445,38 @@ bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvG
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
   if (!ig_qualifies(g, x->dtype)) return false;
   const int KS = g.kh, RS = KS * KS;
-  // enough workgroups to fill 256 CUs: RS taps x nsplit image ranges
+  {
+    // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
+    const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
+    const int CIP = ntile * WG_CI;
+    int target = std::max(1, (num_cus() * 2) / ntile);               // ~2 workgroups per CU
+    int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
+    if (ips < 8 && g.N >= 8) ips = 8;
+    const int nsplit = (int)((g.N + ips - 1) / ips);
+    int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
+    Hold partial(new_tensor(ps, 1, kF32, x->device()));
+    const size_t lds = 2 * WG_STAGE;
+    {
+      KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
+      static bool a3 = false, a1 = false;
+      if (KS == 3) {
+        if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_wgrad8v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
+        hipLaunchKernelGGL((ig_wgrad8v2_kernel<3>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
+                           (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
+      } else {
+        if (!a1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_wgrad8v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
+        hipLaunchKernelGGL((ig_wgrad8v2_kernel<1>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
+                           (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
+      }
+      LAMP_LAUNCH_CHECK();
+    }
+    const int total = (int)(g.Cout * g.Cin * RS);
+    hipLaunchKernelGGL(ig_wgrad_reduce_v2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), (int)g.Cout,
+                       (int)g.Cin, CIP, RS, nsplit);
+    LAMP_LAUNCH_CHECK();
+    return true;
+  }
+  // (v1, kept for reference: one tap per workgroup) enough workgroups to fill 256 CUs: RS taps x nsplit image ranges
   int target_splits = (2 * num_cus() + RS - 1) / RS;
   int ips = (int)std::max<int64_t>(1, (g.N + target_splits - 1) / target_splits);
   if (ips < 8 && g.N >= 8) ips = 8;

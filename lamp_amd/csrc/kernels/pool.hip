@@ -111,6 +111,26 @@ __global__ void max_pool_bwd_kernel(const T* __restrict__ dy, const int64_t* __r
   }
 }
 
+// global average pooling (window == whole plane, the tail of Cnn.resnet: AvgPool2D(k = 8) on 8x8 maps):
+// one wavefront per (n, c) plane, coalesced reads, shuffle reduction; backward is a broadcast
+template <class T>
+__global__ __launch_bounds__(256) void avg_pool_global_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int hw) {
+  using A = acc_t<T>;
+  const int lane = threadIdx.x & 63;
+  const int64_t pl = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (pl >= planes) return;
+  A s = 0;
+  for (int i = lane; i < hw; i += 64) s += load_as<A>(x[pl * hw + i]);
+  s = wave_sum(s);
+  if (lane == 0) y[pl] = store_as<T>((A)(s / (A)hw));
+}
+template <class T>
+__global__ void avg_pool_global_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t total, int hw) {
+  using A = acc_t<T>;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    dx[e] = store_as<T>((A)(load_as<A>(dy[e / hw]) / (A)hw));
+}
+
 static PoolGeom pool_geom(const Tensor* x, int64_t k, int64_t s, int64_t p, int64_t d, int ceil_mode, int cip) {
   LAMP_CHECK(x->ndim == 4 || x->ndim == 3, "pooling expects a 3-D or 4-D input, got " << x->describe());
   LAMP_CHECK(k > 0 && s > 0 && p >= 0 && d > 0 && p <= k / 2 + (k == 1 ? 0 : 0) + k, "bad pooling geometry");
@@ -145,7 +165,12 @@ int lamp_avg_pool2d(lamp_tensor** out, const lamp_tensor* x, int64_t kernel, int
   Hold xc(contiguous(x));
   Hold y(new_tensor(pooled_shape(x, g), x->dtype, x->device()));
   const int64_t total = y->numel();
-  if (total) {
+  const bool global = (g.k == g.H && g.k == g.W && g.p == 0 && g.Ho == 1 && g.Wo == 1);
+  if (total && global) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_global_fwd_kernel<T>), dim3((unsigned)((g.NC * 64 + 255) / 256)), dim3(256), 0,
+                                                        current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), g.NC, (int)(g.H * g.W)));
+    LAMP_LAUNCH_CHECK();
+  } else if (total) {
     LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
                                                         current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), g));
     LAMP_LAUNCH_CHECK();
@@ -162,7 +187,12 @@ int lamp_avg_pool2d_backward(lamp_tensor** out, const lamp_tensor* grad_out, con
   Hold gc(contiguous(grad_out));
   Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
   const int64_t total = dx->numel();
-  if (total) {
+  const bool global = (g.k == g.H && g.k == g.W && g.p == 0 && g.Ho == 1 && g.Wo == 1);
+  if (total && global) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_global_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(x->device()), gc->ptr<T>(), dx->ptr<T>(), total, (int)(g.H * g.W)));
+    LAMP_LAUNCH_CHECK();
+  } else if (total) {
     LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((avg_pool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
                                                         current_stream(x->device()), gc->ptr<T>(), dx->ptr<T>(), g));
     LAMP_LAUNCH_CHECK();
