@@ -85,31 +85,35 @@ __global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __r
 
 // ---- fprop / dgrad -----------------------------------------------------------------------------------
 // x [N][CI][64], wp [RS][128][KP], y [N][CO][64].  KP = padded K per tap (32, 64 or 128).
-template <int KS>
-__global__ __launch_bounds__(256) void ig_conv8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                       bf16_t* __restrict__ y, int N, int CI, int KP, int CO) {
+template <int KS, int NW>
+__global__ __launch_bounds__(NW * 128) void ig_conv8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
+                                                            bf16_t* __restrict__ y, int N, int CI, int KP, int CO) {
+  // NW images per workgroup, 2 * NW waves: wave (wr, wc) owns output channels [64 wr, 64 wr + 64) of image wc.
+  // One weight stage feeds NW images, so a wider workgroup halves the L2 weight traffic and the barriers per MFMA.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
+  constexpr int NT = NW * 128;
+  constexpr int LPT = 1024 / NT;            // 16-byte weight chunks per thread and stage
   const int RB = KP * 2;                    // bytes per pixel row of the channel-last image
   const int XIMG = 100 * RB;                // one padded 10x10 image
-  char* Xl = smem;                          // [2][100][KP]
-  char* Wl = smem + 2 * XIMG;               // 2 x IG_WTILE
+  char* Xl = smem;                          // [NW][100][KP]
+  char* Wl = smem + NW * XIMG;              // 2 x IG_WTILE
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int n0 = blockIdx.x * 2;
+  const int wr = wid / NW, wc = wid % NW;
+  const int n0 = blockIdx.x * NW;
   const int cmask = (KP >> 3) - 1;
 
   // zero the image tiles (borders and padded channels must read as 0)
-  for (int o = tid * 16; o < 2 * XIMG; o += 256 * 16) *reinterpret_cast<uint4*>(Xl + o) = make_uint4(0, 0, 0, 0);
+  for (int o = tid * 16; o < NW * XIMG; o += NT * 16) *reinterpret_cast<uint4*>(Xl + o) = make_uint4(0, 0, 0, 0);
   __syncthreads();
   // NCHW -> channel-last: one 16-byte global load = one image row (8 pixels) of one channel
-  for (int img = 0; img < 2; img++) {
+  for (int img = 0; img < NW; img++) {
     const int n = n0 + img;
     if (n >= N) break;
     const bf16_t* xp = x + (int64_t)n * CI * 64;
     char* xi = Xl + img * XIMG;
-    for (int e = tid; e < CI * 8; e += 256) {
+    for (int e = tid; e < CI * 8; e += NT) {
       const int ci = e >> 3, h = e & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(xp + ci * 64 + h * 8);
       const unsigned int words[4] = {v.x, v.y, v.z, v.w};
@@ -132,9 +136,24 @@ __global__ __launch_bounds__(256) void ig_conv8_kernel(const bf16_t* __restrict_
   const int KW = KP < 64 ? KP : 64;         // k per stage
   const int CC = KP / KW;                   // chunks per tap
   const int T = RS * CC;
-  uint4 rw[4];
-  ig_stage_load_rows(rw, wp, KP, 0, IG_M, KP, tid);
-  ig_stage_store_rows(rw, Wl, tid);
+  uint4 rw[LPT];
+  auto stage_load = [&](const bf16_t* base, int k0) {
+#pragma unroll
+    for (int i = 0; i < LPT; i++) {
+      const int c = tid + i * NT;
+      const int gr = c >> 3, gk = k0 + ((c & 7) << 3);
+      rw[i] = (gk + 8 <= KP) ? *reinterpret_cast<const uint4*>(base + gr * KP + gk) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage_store = [&](char* lds) {
+#pragma unroll
+    for (int i = 0; i < LPT; i++) {
+      const int c = tid + i * NT;
+      *reinterpret_cast<uint4*>(lds + ig_kc_off(c >> 3, c & 7)) = rw[i];
+    }
+  };
+  stage_load(wp, 0);
+  stage_store(Wl);
   __syncthreads();
 
   // per-lane pixel of each of this wave's 4 n-tiles (image wc, image rows 2j, 2j+1)
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void ig_conv8_kernel(const bf16_t* __restrict_
     const int rs = t / CC, cc = t - rs * CC;
     if (t + 1 < T) {
       const int rs1 = (t + 1) / CC, cc1 = (t + 1) - rs1 * CC;
-      ig_stage_load_rows(rw, wp + (int64_t)rs1 * IG_M * KP, KP, (int64_t)cc1 * KW, IG_M, KP, tid);
+      stage_load(wp + (int64_t)rs1 * IG_M * KP, cc1 * KW);
     }
     const int r = rs / KS, s = rs - r * KS;
     const char* wl = Wl + cur * IG_WTILE;
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(256) void ig_conv8_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < T) ig_stage_store_rows(rw, Wl + (cur ^ 1) * IG_WTILE, tid);
+    if (t + 1 < T) stage_store(Wl + (cur ^ 1) * IG_WTILE);
     __syncthreads();
   }
 
@@ -415,20 +434,24 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   hipLaunchKernelGGL(ig_pack_weights_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wp->ptr<bf16_t>(), (int)g.Cout,
                      (int)g.Cin, KS, KP, dgrad ? 1 : 0);
   LAMP_LAUNCH_CHECK();
-  const size_t lds = (size_t)2 * 100 * KP * 2 + 2 * IG_WTILE;
-  const int blocks = (int)((g.N + 1) / 2);
+  const int NW = g.N >= 1024 ? 4 : 2;        // images per workgroup (keep >= 256 workgroups before widening)
+  const size_t lds = (size_t)NW * 100 * KP * 2 + 2 * IG_WTILE;
+  const int blocks = (int)((g.N + NW - 1) / NW);
   KernelTimer kt(dgrad ? "conv_dgrad_igemm" : "conv_fwd_igemm", conv_flops(g), conv_bytes(g, 2), st);
-  if (KS == 3) {
-    static bool attr3 = false;
-    if (!attr3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr3 = true; }
-    hipLaunchKernelGGL((ig_conv8_kernel<3>), dim3(blocks), dim3(256), lds, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(),
-                       bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
-  } else {
-    static bool attr1 = false;
-    if (!attr1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
-    hipLaunchKernelGGL((ig_conv8_kernel<1>), dim3(blocks), dim3(256), lds, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(),
-                       bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
-  }
+  const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+#define IG_LAUNCH(KS_, NW_)                                                                                                        \
+  do {                                                                                                                             \
+    static bool attr = false;                                                                                                      \
+    if (!attr) {                                                                                                                   \
+      HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8_kernel<KS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr = true;                                                                                                                 \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((ig_conv8_kernel<KS_, NW_>), dim3(blocks), dim3(NW_ * 128), lds, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(), bp, \
+                       out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);                                                                  \
+  } while (0)
+  if (KS == 3) { if (NW == 4) IG_LAUNCH(3, 4); else IG_LAUNCH(3, 2); }
+  else { if (NW == 4) IG_LAUNCH(1, 4); else IG_LAUNCH(1, 2); }
+#undef IG_LAUNCH
   LAMP_LAUNCH_CHECK();
 }
 
