@@ -402,13 +402,36 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
       }
   }
 }
-__global__ void ig_wgrad_reduce_v2_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int CIP, int RS, int nsplit) {
-  const int total = RS * CO * CI;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int ci = e % CI, co = (e / CI) % CO, rs = e / (CI * CO);
-    float a = 0.f;
-    for (int sp = 0; sp < nsplit; sp++) a += partial[((int64_t)(sp * RS + rs) * IG_M + co) * CIP + ci];
-    dw[((int64_t)co * CI + ci) * RS + rs] = bf16_t(a);
+// Split reduction: thread (q, sg) sums float4 column q of this block over the splits sg, sg+8, ... (independent 16-byte
+// loads in flight), the 8 split groups are then combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void ig_wgrad_reduce_v2_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int CIP, int RS,
+                                                                 int nsplit) {
+  __shared__ float4 red[8][32];
+  const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int64_t per_split = (int64_t)RS * IG_M * CIP / 4;   // float4 elements of one split
+  const int64_t col = (int64_t)blockIdx.x * 32 + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < per_split) {
+    const float4* p4 = reinterpret_cast<const float4*>(partial) + col;
+#pragma unroll 4
+    for (int sp = sg; sp < nsplit; sp += 8) {
+      const float4 v = p4[(int64_t)sp * per_split];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[sg][q] = a;
+  __syncthreads();
+  if (sg == 0 && col < per_split) {
+#pragma unroll
+    for (int g = 1; g < 8; g++) { const float4 v = red[g][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    const int c4 = CIP / 4;
+    const int ci = (int)(col % c4) * 4, co = (int)((col / c4) % IG_M), rs = (int)(col / ((int64_t)c4 * IG_M));
+    if (co < CO) {
+      const float r[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (ci + k < CI) dw[((int64_t)co * CI + ci + k) * RS + rs] = bf16_t(r[k]);
+    }
   }
 }
 
@@ -472,7 +495,8 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
     const int CIP = ntile * WG_CI;
-    int target = std::max(1, (num_cus() * 2) / ntile);               // ~2 workgroups per CU
+    static const int wgs_per_cu = [] { const char* e = getenv("LAMP_WGRAD_WGS_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();
+    int target = std::max(1, (num_cus() * wgs_per_cu) / ntile);      // ~2 workgroups per CU
     int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
     if (ips < 8 && g.N >= 8) ips = 8;
     const int nsplit = (int)((g.N + ips - 1) / ips);
@@ -493,8 +517,8 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
       }
       LAMP_LAUNCH_CHECK();
     }
-    const int total = (int)(g.Cout * g.Cin * RS);
-    hipLaunchKernelGGL(ig_wgrad_reduce_v2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), (int)g.Cout,
+    const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
+    hipLaunchKernelGGL(ig_wgrad_reduce_v2_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), (int)g.Cout,
                        (int)g.Cin, CIP, RS, nsplit);
     LAMP_LAUNCH_CHECK();
     return true;
