@@ -296,6 +296,9 @@ bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor
 bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 // implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
+bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
 bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
@@ -325,7 +328,8 @@ int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
   Hold y(new_tensor(oshape, x->dtype, x->device()));
   hipStream_t st = current_stream(x->device());
   if (!transposed) {
-    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !small_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
+    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !narrow_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) &&
+        !small_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_fwd<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
     }
   } else {
@@ -354,10 +358,12 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
   Hold dw(mask[1] ? new_like(wc.get()) : nullptr);
   Hold db;
   if (!transposed) {
-    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) &&
+        !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
     }
-    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !small_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
+    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !narrow_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) &&
+        !small_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_wgrad<T>(gc.get(), xc.get(), dw.get(), g, st)));
     }
   } else {

@@ -1,0 +1,382 @@
+// Matrix-core convolution for the NARROW bf16 layers of the CIFAR ResNet (3..16 channels on 32x32 / 16x16 / 8x8
+// maps: stem 3->6 5x5, res1 6->6 (stride 2), res2 6->16 (stride 2) and their 1x1 projections; reference
+// workload example-cifar100/.../cnn.scala:89-131, op ops.scala:1547-1651).
+//
+// These layers are bound by activation traffic (a few FLOPs per byte), but a scalar-FMA direct convolution
+// still needs ~100 VALU instructions per output pixel and ends up 3-10x above the HBM time.  Here the
+// multiply-accumulates go to v_mfma_f32_16x16x32_bf16 with a formulation that needs NO im2col gather:
+//
+//   fprop / dgrad:   D[pixel][co] = sum_{(c, r)} sum_{j = 0..7} X[c][ho*sh + r][wo*sw + j] * Wk[(c, r)][j][co]
+//     the K dimension is (channel, filter row) x an 8-wide window of the image row; Wk is the filter row
+//     zero-padded from kw to 8 taps.  The A fragment of a lane (8 consecutive k of one pixel) is then 16
+//     CONTIGUOUS bytes of the LDS image, one ds_read_b128 at 2-byte alignment (gfx950 has unaligned DS
+//     access), the B fragments (packed weights) live in registers for the whole kernel.  The padding costs
+//     MFMA work only, of which there is plenty to spare.  dgrad = fprop over the stride-dilated dy image
+//     (zeros inserted while staging) with the filter mirrored and Cin/Cout swapped.
+//   wgrad:           D[co][(ci, r, s)] = sum_{pixels} dY[co][p] * X[ci][ho*sh - ph + r][wo*sw - pw + s]
+//     K runs over output pixels (8 consecutive pixels of a row per lane): A = 16 aligned bytes of dY,
+//     B = 16 contiguous bytes of the shifted image row (stride 2: of its even / odd column plane).
+//
+// One workgroup stages one image (or a few 8x8 ones) in LDS with coalesced 16-byte loads and walks a strided
+// range of images; every kernel reads each activation once and writes each result once.
+// Accumulation is fp32 in a fixed order: results are bitwise reproducible.
+#include "device_utils.h"
+#include "conv_geom.h"
+
+namespace lamp {
+
+typedef short nv_s8 __attribute__((ext_vector_type(8)));
+typedef nv_s8 __attribute__((aligned(2))) nv_s8_u;      // 16-byte LDS read at 2-byte alignment
+typedef __bf16 nv_bf8 __attribute__((ext_vector_type(8)));
+typedef float nv_f4 __attribute__((ext_vector_type(4)));
+
+struct NcvGeom {
+  int N, C, CO;          // images, loop (K-side) channels, output channels
+  int H, W;              // staged tensor [C][H][W]
+  int Hs, Ws;            // LDS image [C][Hs][Ws]
+  int top, left, dil;    // staged pixel (a, b) lands at (top + a*dil, left + b*dil)
+  int Ho, Wo;            // output map
+  int sh, sw, wx;        // window of output (ho, wo), filter row r: LDS row ho*sh + r, columns wo*sw + wx + [0, 8)
+  int kh;
+};
+
+constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligned rows for the vector copy
+
+// wpk[kstep][lane][8]: lane = co + 16*g, pair (c, r) = 4*kstep + g, element j = filter column (zero for j >= kw)
+//   fprop: W[co][c][r][j]            dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j]
+__global__ void ncv_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int kh, int kw, int nk, int dgrad) {
+  const int total = nk * 64 * 8;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
+    const int co = lane & 15, pair = ks * 4 + (lane >> 4);
+    const int c = pair / kh, r = pair - c * kh;
+    bf16_t v; v.bits = 0;
+    if (j < kw) {
+      if (!dgrad) { if (co < Cout && c < Cin) v = w[((co * Cin + c) * kh + r) * kw + j]; }
+      else { if (co < Cin && c < Cout) v = w[((c * Cin + co) * kh + (kh - 1 - r)) * kw + (kw - 1 - j)]; }
+    }
+    wpk[e] = v;
+  }
+}
+
+__device__ __forceinline__ void ncv_stage(unsigned short* xs, const bf16_t* __restrict__ sp, const NcvGeom& q, int tid, int nthreads) {
+  if (q.dil == 1) {
+    const int rc = q.W >> 3, total = q.C * q.H * rc;
+    for (int i = tid; i < total; i += nthreads) {
+      const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
+      const uint4 v = *reinterpret_cast<const uint4*>(sp + (c * q.H + a) * q.W + b * 8);
+      *reinterpret_cast<uint4*>(xs + (c * q.Hs + q.top + a) * q.Ws + q.left + b * 8) = v;
+    }
+  } else {
+    const int total = q.C * q.H * q.W;
+    for (int i = tid; i < total; i += nthreads) {
+      const int b = i % q.W, a = (i / q.W) % q.H, c = i / (q.W * q.H);
+      xs[(c * q.Hs + q.top + a * q.dil) * q.Ws + q.left + b * q.dil] = sp[i].bits;
+    }
+  }
+}
+
+template <int NK>
+__global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk, const bf16_t* __restrict__ bias,
+                                                      bf16_t* __restrict__ dst, NcvGeom q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int co = lane & 15;
+  nv_bf8 wfr[NK];
+  int koff[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ks++) {
+    wfr[ks] = __builtin_bit_cast(nv_bf8, *reinterpret_cast<const nv_s8*>(wpk + (ks * 64 + lane) * 8));
+    int pair = ks * 4 + (lane >> 4);
+    if (pair >= q.C * q.kh) pair = 0;                    // padded k: weights are zero, any valid address will do
+    const int c = pair / q.kh, r = pair - c * q.kh;
+    koff[ks] = (c * q.Hs + r) * q.Ws * 2;
+  }
+  const float bv = (bias && co < q.CO) ? (float)bias[co] : 0.f;
+  const int HoWo = q.Ho * q.Wo, ntiles = (HoWo + 15) >> 4;
+  const int img_elems = q.C * q.Hs * q.Ws;
+  for (int o = tid * 8; o < img_elems; o += 256 * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);   // img_elems % 8 == 0
+  bool first = true;
+  for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
+    __syncthreads();                                     // zero fill / previous image's reads are done
+    ncv_stage(xs, src + (int64_t)n * q.C * q.H * q.W, q, tid, 256);
+    __syncthreads();
+    first = false;
+    bf16_t* yp = dst + (int64_t)n * q.CO * HoWo;
+    for (int tile = wid; tile < ntiles; tile += 4) {
+      const int p = min(tile * 16 + (lane & 15), HoWo - 1);
+      const int ho = p / q.Wo, wo = p - ho * q.Wo;
+      const char* base = smem + ((ho * q.sh) * q.Ws + wo * q.sw + q.wx) * 2;
+      nv_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK; ks++) {
+        const nv_s8 a = *reinterpret_cast<const nv_s8_u*>(base + koff[ks]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, a), wfr[ks], acc, 0, 0, 0);
+      }
+      // D: column = output channel (lane & 15), rows = 4 consecutive pixels
+      const int p4 = tile * 16 + (lane >> 4) * 4;
+      if (co < q.CO && p4 < HoWo) {
+        const bf16_t o0(acc[0] + bv), o1(acc[1] + bv), o2(acc[2] + bv), o3(acc[3] + bv);
+        uint2 pk;
+        pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+        pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+        *reinterpret_cast<uint2*>(yp + co * HoWo + p4) = pk;
+      }
+    }
+  }
+  (void)first;
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------------------
+struct NcvWGeom {
+  int N, Cin, Cout, H, W, Ho, Wo;
+  int kh, kw, ph, pw;
+  int Hs, Ws;            // SW == 1: LDS x image [Cin][Hs][Ws]; SW == 2: [Cin][Hs][2 parities][Ws]
+  int ncol;              // Cin * kh * kw
+  int IG;                // images staged per round
+};
+constexpr int NCV_OFF2 = 4;   // stride 2: column w lives at plane (w & 1), position (w >> 1) + NCV_OFF2
+
+template <int NT, int SW>
+__global__ __launch_bounds__(256) void ncv_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial, NcvWGeom q,
+                                                        int images_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int HoWo = q.Ho * q.Wo;
+  const int ximg = q.Cin * q.Hs * q.Ws * (SW == 2 ? 2 : 1);        // elements per staged image
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);      // [IG][ximg]
+  unsigned short* ds = xs + q.IG * ximg;                             // [IG][16][HoWo]  (rows >= Cout stay zero)
+  float* red = reinterpret_cast<float*>(ds + q.IG * 16 * HoWo);      // [4 waves][16][NT * 16]
+  {
+    const int tot = q.IG * (ximg + 16 * HoWo);                       // multiple of 8 (host guarantees)
+    for (int o = tid * 8; o < tot; o += 256 * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);
+  }
+  // per-lane column (ci, r, s) of each n-tile -> byte offset of its shifted row inside a staged image
+  int coff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    int cidx = nt * 16 + (lane & 15);
+    if (cidx >= q.ncol) cidx = 0;                                     // padded columns: computed, never written
+    const int s = cidx % q.kw, r = (cidx / q.kw) % q.kh, ci = cidx / (q.kw * q.kh);
+    if (SW == 1) coff[nt] = ((ci * q.Hs + r) * q.Ws + s - q.pw + NCV_LEFT) * 2;
+    else {
+      const int t = s - q.pw, par = t & 1, half = (t - par) >> 1;
+      coff[nt] = (((ci * q.Hs + r) * 2 + par) * q.Ws + half + NCV_OFF2) * 2;
+    }
+  }
+  nv_f4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) acc[nt] = nv_f4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min<int64_t>(n0 + images_per_block, q.N);
+  const int chunks_per_img = HoWo >> 5;
+  for (int64_t nb = n0; nb < n1; nb += q.IG) {
+    const int ig = (int)min<int64_t>(q.IG, n1 - nb);
+    __syncthreads();
+    for (int im = 0; im < ig; im++) {
+      const bf16_t* xp = x + (nb + im) * q.Cin * q.H * q.W;
+      unsigned short* xi = xs + im * ximg;
+      const int rc = q.W >> 3, total = q.Cin * q.H * rc;
+      for (int i = tid; i < total; i += 256) {
+        const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
+        const uint4 v = *reinterpret_cast<const uint4*>(xp + (c * q.H + a) * q.W + b * 8);
+        if (SW == 1) {
+          *reinterpret_cast<uint4*>(xi + (c * q.Hs + q.ph + a) * q.Ws + NCV_LEFT + b * 8) = v;
+        } else {
+          // de-interleave even / odd columns
+          uint2 ev, od;
+          ev.x = (v.x & 0xffffu) | (v.y << 16); ev.y = (v.z & 0xffffu) | (v.w << 16);
+          od.x = (v.x >> 16) | (v.y & 0xffff0000u); od.y = (v.z >> 16) | (v.w & 0xffff0000u);
+          unsigned short* row = xi + ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFF2 + b * 4;
+          *reinterpret_cast<uint2*>(row) = ev;
+          *reinterpret_cast<uint2*>(row + q.Ws) = od;
+        }
+      }
+      const bf16_t* dp = dy + (nb + im) * q.Cout * HoWo;
+      unsigned short* di = ds + im * 16 * HoWo;
+      const int dtot = q.Cout * HoWo >> 3;
+      for (int i = tid; i < dtot; i += 256) *reinterpret_cast<uint4*>(di + i * 8) = *reinterpret_cast<const uint4*>(dp + i * 8);
+    }
+    __syncthreads();
+    const int nchunks = ig * chunks_per_img;
+    for (int ch = wid; ch < nchunks; ch += 4) {
+      const int pg = ch * 32 + (lane >> 4) * 8;                      // this lane's 8 consecutive output pixels
+      const int im = pg / HoWo, pp = pg - im * HoWo;
+      const int ho = pp / q.Wo, wo0 = pp - ho * q.Wo;
+      const nv_s8 a = *reinterpret_cast<const nv_s8*>(ds + (im * 16 + (lane & 15)) * HoWo + pp);
+      const char* xb = reinterpret_cast<const char*>(xs + im * ximg) +
+                       (SW == 1 ? (ho * q.Ws + wo0) * 2 : ((ho * 2) * 2 * q.Ws + wo0) * 2);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const nv_s8 b = *reinterpret_cast<const nv_s8_u*>(xb + coff[nt]);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, a), __builtin_bit_cast(nv_bf8, b), acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  // D: column = (ci, r, s) index, rows = 4 output channels; combine the 4 waves in a fixed order
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) red[(wid * 16 + (lane >> 4) * 4 + rr) * (NT * 16) + nt * 16 + (lane & 15)] = acc[nt][rr];
+  __syncthreads();
+  const int O = q.Cout * q.ncol;
+  for (int i = tid; i < O; i += 256) {
+    const int co = i / q.ncol, cidx = i - co * q.ncol;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) a += red[(w * 16 + co) * (NT * 16) + cidx];
+    partial[(int64_t)blockIdx.x * O + i] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void ncv_wgrad_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int O, int nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
+  if (o >= O) return;
+  float a = 0.f;
+  for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * O + o];
+  a = wave_sum(a);
+  if (lane == 0) dw[o] = bf16_t(a);
+}
+
+// ---- host ------------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static bool ncv_common(const ConvGeom& g, int dtype) {
+  if (dtype != kBF16) return false;
+  if (g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
+  if (g.Cin > 16 || g.Cout > 16 || g.N < 1) return false;
+  if (g.sh != g.sw || g.sh < 1 || g.sh > 2) return false;
+  if (g.kw > 8 || g.ph > g.kh - 1 || g.pw > g.kw - 1 || g.pw > 8) return false;
+  return true;
+}
+
+template <int NK>
+static void ncv_launch(const bf16_t* src, const bf16_t* wpk, const bf16_t* bias, bf16_t* dst, const NcvGeom& q, int blocks, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((ncv_fwd_kernel<NK>), dim3(blocks), dim3(256), lds, st, src, wpk, bias, dst, q);
+}
+
+static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+  if (!ncv_common(g, in->dtype)) return false;
+  NcvGeom q;
+  q.N = (int)g.N; q.kh = g.kh;
+  if (!dgrad) {
+    if (g.W % 8 != 0) return false;
+    q.C = (int)g.Cin; q.CO = (int)g.Cout; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
+    q.top = g.ph; q.left = NCV_LEFT;
+    q.Ho = (int)g.Ho; q.Wo = (int)g.Wo; q.sh = g.sh; q.sw = g.sw; q.wx = NCV_LEFT - g.pw;
+    q.Hs = std::max((int)g.H + 2 * g.ph, (q.Ho - 1) * g.sh + g.kh);
+    q.Ws = round_up(std::max(NCV_LEFT + (int)g.W, (q.Wo - 1) * g.sw + q.wx + 8), 8);
+  } else {
+    // dx = stride-1 correlation of the dilated dy image with the mirrored filter, padding k-1-p
+    const int pt = g.kh - 1 - g.ph, pl = g.kw - 1 - g.pw;
+    q.C = (int)g.Cout; q.CO = (int)g.Cin; q.H = (int)g.Ho; q.W = (int)g.Wo; q.dil = g.sh;
+    if (q.dil == 1 && q.W % 8 != 0) return false;
+    q.top = pt; q.left = NCV_LEFT;
+    q.Ho = (int)g.H; q.Wo = (int)g.W; q.sh = 1; q.sw = 1; q.wx = NCV_LEFT - pl;
+    q.Hs = std::max(pt + ((int)g.Ho - 1) * g.sh + 1, (int)g.H + g.kh - 1);
+    q.Ws = round_up(std::max(NCV_LEFT + ((int)g.Wo - 1) * g.sw + 1, (int)g.W - 1 + q.wx + 8), 8);
+  }
+  if ((q.Ho * q.Wo) % 4 != 0) return false;
+  const int pairs = q.C * q.kh;
+  const int nk_real = (pairs + 3) / 4;
+  static const int nk_opts[] = {1, 2, 4, 5, 8, 12};
+  int NK = 0;
+  for (int o : nk_opts) if (o >= nk_real) { NK = o; break; }
+  if (!NK) return false;
+  const size_t lds = (size_t)q.C * q.Hs * q.Ws * 2;
+  if (lds > 64 * 1024) return false;
+  int64_t ps[1] = {(int64_t)NK * 64 * 8};
+  Hold wpk(new_tensor(ps, 1, kBF16, in->device()));
+  hipLaunchKernelGGL(ncv_pack_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wpk->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh,
+                     g.kw, NK, dgrad ? 1 : 0);
+  LAMP_LAUNCH_CHECK();
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
+  const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
+  KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
+  const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+  switch (NK) {
+    case 1: ncv_launch<1>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 4: ncv_launch<4>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 5: ncv_launch<5>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    default: ncv_launch<12>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+  }
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+
+bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
+  return ncv_run(x, w, bias, y, g, false, st);
+}
+bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
+  return ncv_run(dy, w, nullptr, dx, g, true, st);
+}
+
+template <int NT, int SW>
+static void ncv_wg_launch(const bf16_t* dy, const bf16_t* x, float* partial, const NcvWGeom& q, int ipb, int blocks, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)ncv_wgrad_kernel<NT, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  hipLaunchKernelGGL((ncv_wgrad_kernel<NT, SW>), dim3(blocks), dim3(256), lds, st, dy, x, partial, q, ipb);
+}
+
+bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  if (!ncv_common(g, x->dtype)) return false;
+  if (g.W % 8 != 0 || g.Wo % 8 != 0 || (g.Ho * g.Wo) % 32 != 0) return false;
+  NcvWGeom q;
+  q.N = (int)g.N; q.Cin = (int)g.Cin; q.Cout = (int)g.Cout; q.H = (int)g.H; q.W = (int)g.W; q.Ho = (int)g.Ho; q.Wo = (int)g.Wo;
+  q.kh = g.kh; q.kw = g.kw; q.ph = g.ph; q.pw = g.pw;
+  q.ncol = (int)g.Cin * g.kh * g.kw;
+  const int SW = g.sh;
+  q.Hs = std::max((int)g.H + 2 * g.ph, ((int)g.Ho - 1) * g.sh + g.kh);
+  if (SW == 1) q.Ws = round_up(std::max(NCV_LEFT + (int)g.W, (int)g.Wo - 1 + g.kw - 1 - g.pw + NCV_LEFT + 1), 8);
+  else {
+    const int half_max = (g.kw - 1 - g.pw) >> 1;
+    q.Ws = round_up(std::max((int)g.W / 2, (int)g.Wo + half_max) + NCV_OFF2 + 1, 8);
+  }
+  const int HoWo = (int)(g.Ho * g.Wo);
+  q.IG = std::max(1, 256 / HoWo);                                    // >= 8 chunks of 32 pixels per round
+  const int nt_real = (q.ncol + 15) / 16;
+  static const int nt_opts[] = {1, 2, 4, 5, 9};
+  int NT = 0;
+  for (int o : nt_opts) if (o >= nt_real) { NT = o; break; }
+  if (!NT) return false;
+  const int ximg = q.Cin * q.Hs * q.Ws * (SW == 2 ? 2 : 1);
+  if ((q.IG * (ximg + 16 * HoWo)) % 8 != 0) return false;
+  const size_t lds = (size_t)q.IG * (ximg + 16 * HoWo) * 2 + (size_t)4 * 16 * NT * 16 * 4;
+  if (lds > 150 * 1024) return false;
+  const int O = q.Cout * q.ncol;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds));
+  const int64_t rounds = (g.N + q.IG - 1) / q.IG;
+  const int nb = (int)std::min<int64_t>(rounds, (int64_t)num_cus() * per_cu);
+  const int ipb = (int)((rounds + nb - 1) / nb) * q.IG;
+  const int nblocks = (int)((g.N + ipb - 1) / ipb);
+  int64_t ps[1] = {(int64_t)nblocks * O};
+  Hold partial(new_tensor(ps, 1, kF32, dy->device()));
+  {
+    KernelTimer kt("conv_wgrad_narrow", conv_flops(g), conv_bytes(g, 2), st);
+    const bf16_t* dp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
+#define NCV_WG(NTv)                                                                                          \
+  do {                                                                                                       \
+    if (SW == 1) ncv_wg_launch<NTv, 1>(dp, xp, pp, q, ipb, nblocks, lds, st);                                \
+    else ncv_wg_launch<NTv, 2>(dp, xp, pp, q, ipb, nblocks, lds, st);                                        \
+  } while (0)
+    switch (NT) {
+      case 1: NCV_WG(1); break;
+      case 2: NCV_WG(2); break;
+      case 4: NCV_WG(4); break;
+      case 5: NCV_WG(5); break;
+      default: NCV_WG(9); break;
+    }
+#undef NCV_WG
+    LAMP_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(ncv_wgrad_reduce_kernel, dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), O,
+                     nblocks);
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+
+}  // namespace lamp

@@ -315,6 +315,11 @@ CONV_CASES = [
     (2, 3, 32, 32, 6, 5, 1, 2, 1, 1),      # resnet stem
     (2, 6, 32, 32, 6, 3, 2, 1, 1, 1),      # res1.r1
     (2, 6, 32, 32, 6, 1, 2, 0, 1, 1),      # res1.l
+    (3, 6, 16, 16, 6, 3, 1, 1, 1, 1),      # res1.r2
+    (5, 6, 16, 16, 16, 3, 2, 1, 1, 1),     # res2.r1 (8x8 outputs: several images per wgrad round, ragged last round)
+    (5, 6, 16, 16, 16, 1, 2, 0, 1, 1),     # res2.l
+    (2100, 6, 16, 16, 6, 3, 2, 1, 1, 1),   # more images than workgroups on the narrow matrix-core path
+    (2, 5, 16, 24, 7, 3, 1, 0, 1, 1),      # narrow path, no padding, non-square map
     (2, 16, 8, 8, 128, 3, 1, 1, 1, 1),     # res3.r1
     (2, 128, 8, 8, 128, 3, 1, 1, 1, 1),    # res3.r2
     (2, 128, 8, 8, 100, 3, 1, 1, 1, 1),    # res4.r1
