@@ -128,6 +128,94 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
   (void)first;
 }
 
+// Aligned-window variant.  An unaligned ds_read_b128 runs at ~1/11 of the aligned rate on gfx950
+// (scripts/microbench/lds_unaligned.hip), and the windows of neighbouring pixels start 2 (stride 1) or 4 bytes
+// apart.  So one MFMA tile takes 16 pixels whose windows have the SAME phase inside a 16-byte segment: columns
+// cg*P + d with a fixed d (P = 8 / stride phases), from TR = 16 / (Wo / P) image rows.  The P tiles d = 0..P-1 of
+// such a "super-tile" (TR full output rows) read the SAME two or three aligned segments per lane, which are loaded
+// once and funnel-shifted in registers by a compile-time amount; a lane ends up holding P consecutive output
+// pixels per accumulator register, stored as one 16- or 8-byte write.
+//   PH0 = (window origin wx) & 7.
+template <int NK, int SW, int PH0>
+__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk, const bf16_t* __restrict__ bias,
+                                                       bf16_t* __restrict__ dst, NcvGeom q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
+  constexpr int P = 8 / SW;
+  constexpr int NSEG = (PH0 + (P - 1) * SW + 7) < 16 ? 2 : 3;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
+  const int co = lane & 15;
+  const int ncg = q.Wo / P, TR = 16 / ncg;
+  nv_bf8 wfr[NK];
+  int koff[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ks++) {
+    wfr[ks] = __builtin_bit_cast(nv_bf8, *reinterpret_cast<const nv_s8*>(wpk + (ks * 64 + lane) * 8));
+    int pair = ks * 4 + (lane >> 4);
+    if (pair >= q.C * q.kh) pair = 0;
+    const int c = pair / q.kh, r = pair - c * q.kh;
+    koff[ks] = (c * q.Hs + r) * q.Ws * 2;
+  }
+  const float bv = (bias && co < q.CO) ? (float)bias[co] : 0.f;
+  const int HoWo = q.Ho * q.Wo, nsuper = q.Ho / TR;
+  const int img_elems = q.C * q.Hs * q.Ws;
+  for (int o = tid * 8; o < img_elems; o += nthreads * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);
+  // A-side lane -> (row within the super-tile, column group)
+  const int a_tr = (lane & 15) / ncg, a_cg = (lane & 15) - a_tr * ncg;
+  const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
+  for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
+    __syncthreads();
+    ncv_stage(xs, src + (int64_t)n * q.C * q.H * q.W, q, tid, nthreads);
+    __syncthreads();
+    bf16_t* yp = dst + (int64_t)n * q.CO * HoWo;
+    for (int st = wid; st < nsuper; st += nwaves) {
+      const int h0 = st * TR;
+      const char* base = smem + a_off + h0 * q.sh * q.Ws * 2;
+      nv_f4 acc[P];
+#pragma unroll
+      for (int d = 0; d < P; d++) acc[d] = nv_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK; ks++) {
+        unsigned int sg[NSEG * 4 + 1];
+#pragma unroll
+        for (int e = 0; e < NSEG; e++) {
+          const uint4 v = *reinterpret_cast<const uint4*>(base + koff[ks] + e * 16);
+          sg[e * 4 + 0] = v.x; sg[e * 4 + 1] = v.y; sg[e * 4 + 2] = v.z; sg[e * 4 + 3] = v.w;
+        }
+        sg[NSEG * 4] = 0;
+#pragma unroll
+        for (int d = 0; d < P; d++) {
+          constexpr int dummy = 0; (void)dummy;
+          const int o = PH0 + d * SW;                      // compile-time after unrolling
+          const int dq = o >> 1;
+          unsigned int f[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) f[j] = (o & 1) ? __builtin_amdgcn_alignbit(sg[dq + j + 1], sg[dq + j], 16) : sg[dq + j];
+          typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+          const u4v fv = {f[0], f[1], f[2], f[3]};
+          acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, fv), wfr[ks], acc[d], 0, 0, 0);
+        }
+      }
+      if (co < q.CO) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int i = (lane >> 4) * 4 + rr;
+          const int tr = i / ncg, cg = i - tr * ncg;
+          bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
+          unsigned int pk[P / 2];
+#pragma unroll
+          for (int d = 0; d < P; d += 2) {
+            const bf16_t lo(acc[d][rr] + bv), hi(acc[d + 1][rr] + bv);
+            pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+          }
+          if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
+          else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+        }
+      }
+    }
+  }
+}
+
 // ---- wgrad ---------------------------------------------------------------------------------------------
 struct NcvWGeom {
   int N, Cin, Cout, H, W, Ho, Wo;
@@ -279,6 +367,13 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     q.Ws = round_up(std::max(NCV_LEFT + ((int)g.Wo - 1) * g.sw + 1, (int)g.W - 1 + q.wx + 8), 8);
   }
   if ((q.Ho * q.Wo) % 4 != 0) return false;
+  // aligned-window kernel: Wo a multiple of the P = 8/stride phases, 16 pixels = TR full-phase rows
+  const int P = 8 / q.sw, ph0 = q.wx & 7;
+  bool aligned = q.Wo % P == 0 && (ph0 == 0 || ph0 == 6 || ph0 == 7);
+  int ncg = aligned ? q.Wo / P : 0;
+  if (aligned && !(ncg == 2 || ncg == 4 || ncg == 8 || ncg == 16)) aligned = false;
+  if (aligned && q.Ho % (16 / ncg) != 0) aligned = false;
+  if (aligned) q.Ws = round_up(std::max(q.Ws, q.Wo * q.sw + (q.wx - ph0) + 16), 8);
   const int pairs = q.C * q.kh;
   const int nk_real = (pairs + 3) / 4;
   static const int nk_opts[] = {1, 2, 4, 5, 8, 12};
@@ -296,6 +391,31 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
   KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
   const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+  if (aligned) {
+    const int nsuper = q.Ho / (16 / ncg);
+    const int threads = 64 * std::min(4, nsuper);
+    const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
+    if (NK2 != NK) {   // repack with the padded k-step count
+      int64_t ps2[1] = {(int64_t)NK2 * 64 * 8};
+      wpk = Hold(new_tensor(ps2, 1, kBF16, in->device()));
+      hipLaunchKernelGGL(ncv_pack_kernel, dim3(grid_for(ps2[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wpk->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin,
+                         g.kh, g.kw, NK2, dgrad ? 1 : 0);
+    }
+#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q)
+#define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
+#define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
+    switch (NK2) {
+      case 2: NCV_F2_SW(2); break;
+      case 4: NCV_F2_SW(4); break;
+      case 5: NCV_F2_SW(5); break;
+      default: NCV_F2_SW(12); break;
+    }
+#undef NCV_F2_SW
+#undef NCV_F2_PH
+#undef NCV_F2
+    LAMP_LAUNCH_CHECK();
+    return true;
+  }
   switch (NK) {
     case 1: ncv_launch<1>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
     case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
