@@ -92,6 +92,10 @@ int lamp_allow_tf32(int flag);
  * "tag launches total_ms algorithmic_flops_per_launch algorithmic_bytes_per_launch" */
 int lamp_kernel_timer_enable(int on);
 int lamp_kernel_timer_report(char* buf, int buflen);
+/* time only launches with this tag (NULL or "" = all); set while the timers are disabled */
+int lamp_kernel_timer_filter(const char* tag);
+/* median elapsed time of an (event, empty kernel, event) bracket on the current stream, microseconds */
+int lamp_kernel_timer_calibrate(double* out_us);
 
 /* HIP graph capture of the calling thread's current stream (launch-bound training steps) */
 int lamp_graph_begin_capture(void);

@@ -80,13 +80,25 @@ namespace {
 struct TimerEntry { std::string tag; double flops, bytes; hipEvent_t a, b; };
 std::mutex g_timer_mu;
 std::vector<TimerEntry*> g_timer_entries;
+std::vector<hipEvent_t> g_event_pool;      // recycled events: creation is the expensive part of a timed launch
 std::atomic<int> g_timer_on{0};
+std::string g_timer_filter;                // empty = every tagged launch, else only this tag (read under g_timer_on transitions)
+hipEvent_t pooled_event() {
+  {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 }  // namespace
 
 KernelTimer::KernelTimer(const char* tag, double flops, double bytes, hipStream_t st) : slot(nullptr), stream(st) {
   if (!g_timer_on.load(std::memory_order_relaxed)) return;
-  auto* e = new TimerEntry{tag, flops, bytes, nullptr, nullptr};
-  if (hipEventCreate(&e->a) != hipSuccess || hipEventCreate(&e->b) != hipSuccess) { delete e; return; }
+  if (!g_timer_filter.empty() && g_timer_filter != tag) return;
+  auto* e = new TimerEntry{tag, flops, bytes, pooled_event(), pooled_event()};
+  if (!e->a || !e->b) { delete e; return; }
   (void)hipEventRecord(e->a, st);
   slot = e;
 }
@@ -106,6 +118,11 @@ extern "C" int lamp_kernel_timer_enable(int on) {
   g_timer_on.store(on);
   return 0;
 }
+// restrict timing to one tag (NULL or "" = all tags); call while the timers are disabled
+extern "C" int lamp_kernel_timer_filter(const char* tag) {
+  g_timer_filter = tag ? tag : "";
+  return 0;
+}
 // writes lines "tag count total_ms flops_per_launch bytes_per_launch\n" and clears the log
 extern "C" int lamp_kernel_timer_report(char* buf, int buflen) {
   LAMP_API_BEGIN
@@ -120,7 +137,7 @@ extern "C" int lamp_kernel_timer_report(char* buf, int buflen) {
       auto& a = agg[e->tag];
       a.n++; a.ms += ms; a.flops += e->flops; a.bytes += e->bytes;
     }
-    (void)hipEventDestroy(e->a); (void)hipEventDestroy(e->b);
+    { std::lock_guard<std::mutex> lk(g_timer_mu); g_event_pool.push_back(e->a); g_event_pool.push_back(e->b); }
     delete e;
   }
   std::string out;

@@ -311,6 +311,8 @@ using namespace lamp;
 
 #define NOT_NULL(p) LAMP_CHECK((p) != nullptr, #p " is null")
 
+__global__ void timer_null_kernel(int* p) { if (p) *p = 0; }
+
 extern "C" {
 
 int lamp_live_tensor_count(int64_t* out) { *out = g_live_tensors.load(); return 0; }
@@ -751,6 +753,31 @@ int lamp_stack(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim) {
     us[i] = u;
   }
   return lamp_cat(out, us.data(), n, d);
+  LAMP_API_END
+}
+
+// Event-bracket overhead of the kernel timers: median elapsed time of (event, empty kernel, event) on the current
+// stream, in microseconds.  bench.py subtracts it from every timed launch (a bracket costs several us of packet
+// processing that a rocprofv3 kernel trace does not see).
+int lamp_kernel_timer_calibrate(double* out_us) {
+  LAMP_API_BEGIN
+  NOT_NULL(out_us);
+  hipStream_t st = current_stream();
+  const int R = 33;
+  std::vector<hipEvent_t> ev(2 * R);
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  for (int w = 0; w < 4; w++) hipLaunchKernelGGL(timer_null_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr);
+  for (int i = 0; i < R; i++) {
+    HIP_CHECK(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(timer_null_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr);
+    HIP_CHECK(hipEventRecord(ev[2 * i + 1], st));
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<float> ms(R);
+  for (int i = 0; i < R; i++) HIP_CHECK(hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(ms.begin(), ms.end());
+  *out_us = (double)ms[R / 2] * 1e3;
   LAMP_API_END
 }
 

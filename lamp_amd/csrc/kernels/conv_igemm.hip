@@ -460,7 +460,8 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   const int NW = g.N >= 1024 ? 4 : 2;        // images per workgroup (keep >= 256 workgroups before widening)
   const size_t lds = (size_t)NW * 100 * KP * 2 + 2 * IG_WTILE;
   const int blocks = (int)((g.N + NW - 1) / NW);
-  KernelTimer kt(dgrad ? "conv_dgrad_igemm" : "conv_fwd_igemm", conv_flops(g), conv_bytes(g, 2), st);
+  // fprop and dgrad are the SAME kernel (ig_conv8_kernel), so they share one timer class
+  KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
   const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
 #define IG_LAUNCH(KS_, NW_)                                                                                                        \
   do {                                                                                                                             \

@@ -505,9 +505,11 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
     int64_t ps[1] = {(int64_t)nsplit * g.C * 2};
     int64_t ss[1] = {g.C * 2};
     Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device())), sums(new_tensor(ss, 1, acc_dtype<A>(), x->device()));
-    KernelTimer kt1("bn_bwd_reduce", 0, 2.0 * (double)total * sizeof(T), st);
-    if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+    {
+      KernelTimer kt1("bn_bwd_reduce", 0, 2.0 * (double)total * sizeof(T), st);
+      if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+    }
     LAMP_LAUNCH_CHECK();
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
                        nsplit, invstd_t->ptr<T>(), dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr);
