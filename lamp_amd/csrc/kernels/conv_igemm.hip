@@ -7,16 +7,20 @@
 // dilation 1, groups 1, Cin <= 128, Cout <= 128.  Everything else stays on the direct kernels.
 //
 // fprop and dgrad share ONE kernel (dgrad = fprop of dy with the weights transposed and the taps
-// mirrored):   Out[co][p] = sum_{r,s,ci} Wp[rs][co][ci] * X[ci][p + (r,s) - pad]
-//   M = output channels (128 per workgroup, zero padded), N = 128 pixels = two images,
-//   K = taps * Cin; v_mfma_f32_16x16x32_bf16, fp32 accumulation.
-//   * the two input images live in LDS channel-LAST ([10x10 padded pixel][ci]) so that a B fragment
+// mirrored):   Out[p][co] = sum_{r,s,ci} X[ci][p + (r,s) - pad] * Wp[rs][co][ci]
+//   M = pixels (256 = four images per workgroup), N = output channels (128, zero padded),
+//   K = taps * Cin; v_mfma_f32_16x16x32_bf16, fp32 accumulation; 8 waves, wave tile 64 px x 64 co.
+//   * the input images live in LDS channel-LAST ([10x10 padded pixel][ci]) so that a pixel fragment
 //     (8 consecutive ci of one shifted pixel) is one ds_read_b128; the NCHW -> channel-last
-//     transposition happens once per image while staging (coalesced 16-byte global loads).
-//   * weights are pre-packed by a tiny kernel to [tap][co][ci] (ci contiguous) and streamed
-//     through a double-buffered LDS tile, one (tap, 64-channel chunk) per stage.
+//     transposition is an 8x8 register transpose per thread between coalesced 16-byte global loads
+//     and 16-byte LDS writes.
+//   * weights are pre-packed by a tiny kernel to [tap][co][ci] (ci contiguous) and streamed by LDS-DMA
+//     (global_load_lds_dwordx4) through a three-slot ring, one (tap, 64-channel chunk) per stage.
 //   * both LDS images are XOR-swizzled on 16-byte chunks so every fragment read is conflict-free
-//     (see the lane -> pixel permutation in px_of_col).
+//     (see the lane -> pixel permutation in px_of_col); the same permutation makes a lane's four
+//     accumulator rows four consecutive pixels, so the epilogue stores 8 bytes per lane.
+//   * the two waves of every SIMD run the READ and MFMA phases of a stage in ping-pong (raw s_barrier,
+//     counted vmcnt), see the main loop.
 // wgrad is a plain NT GEMM per tap, dW[rs][co][ci] = sum_{n,p} dY[n][co][p] * Xshift_rs[n][ci][p]:
 //   the K dimension runs over pixels of many images; the tap shift is applied while staging X
 //   (row select + a 16-bit funnel shift inside the 16-byte row), partial sums of the image
@@ -98,31 +102,52 @@ __global__ __launch_bounds__(NW * 128) void ig_conv8_kernel(const bf16_t* __rest
   const int RB = KP * 2;                    // bytes per pixel row of the channel-last image
   const int XIMG = 100 * RB;                // one padded 10x10 image
   char* Xl = smem;                          // [NW][100][KP]
-  char* Wl = smem + NW * XIMG;              // 2 x IG_WTILE
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  char* Wl = smem + NW * XIMG;              // 3 x IG_WTILE (ring)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: guards raw s_barriers below
   const int wr = wid / NW, wc = wid % NW;
   const int n0 = blockIdx.x * NW;
   const int cmask = (KP >> 3) - 1;
 
-  // zero the image tiles (borders and padded channels must read as 0)
-  for (int o = tid * 16; o < NW * XIMG; o += NT * 16) *reinterpret_cast<uint4*>(Xl + o) = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-  // NCHW -> channel-last: one 16-byte global load = one image row (8 pixels) of one channel
-  for (int img = 0; img < NW; img++) {
-    const int n = n0 + img;
-    if (n >= N) break;
-    const bf16_t* xp = x + (int64_t)n * CI * 64;
-    char* xi = Xl + img * XIMG;
-    for (int e = tid; e < CI * 8; e += NT) {
-      const int ci = e >> 3, h = e & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(xp + ci * 64 + h * 8);
-      const unsigned int words[4] = {v.x, v.y, v.z, v.w};
+  // halo pixels of the padded 10x10 images must read as 0 (a 1x1 kernel never leaves the interior)
+  if (KS > 1) {
+    const int cpp = RB >> 4;                                   // 16-byte chunks per pixel
+    for (int o = tid; o < NW * 36 * cpp; o += NT) {
+      const int ch = o % cpp, hidx = (o / cpp) % 36, img = o / (cpp * 36);
+      int hp, wpx;
+      if (hidx < 10) { hp = 0; wpx = hidx; }
+      else if (hidx < 20) { hp = 9; wpx = hidx - 10; }
+      else { hp = 1 + ((hidx - 20) >> 1); wpx = ((hidx - 20) & 1) * 9; }
+      *reinterpret_cast<uint4*>(Xl + img * XIMG + (hp * 10 + wpx) * RB + (ch << 4)) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // NCHW -> channel-last.  A thread takes 8 channels x one image row: eight coalesced 16-byte loads (8 pixels of one
+  // channel each), an 8x8 transposition of the 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one
+  // pixel each).  Lanes run along the channel groups, so the 8 lanes of a ds_write_b128 group hit 8 different chunks.
+  {
+    const int ncgp = KP >> 3;
+    for (int e = tid; e < NW * 8 * ncgp; e += NT) {
+      const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
+      const int n = n0 + img;
+      unsigned int w[8][4];
 #pragma unroll
-      for (int wq = 0; wq < 8; wq++) {
-        const unsigned short el = (unsigned short)(words[wq >> 1] >> ((wq & 1) * 16));
-        const int hp = h + 1, wpx = wq + 1;
-        const int off = (hp * 10 + wpx) * RB + ((((ci >> 3) ^ x_swz(hp, wpx, cmask))) << 4) + ((ci & 7) << 1);
-        *reinterpret_cast<unsigned short*>(xi + off) = el;
+      for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < CI && n < N) v = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+        w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+      }
+      char* xi = Xl + img * XIMG;
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        unsigned int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned int lo = w[2 * j][p >> 1], hi = w[2 * j + 1][p >> 1];
+          d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        const int hp = h + 1, wpx = p + 1;
+        *reinterpret_cast<uint4*>(xi + (hp * 10 + wpx) * RB + ((cg ^ x_swz(hp, wpx, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
   }
@@ -133,79 +158,124 @@ __global__ __launch_bounds__(NW * 128) void ig_conv8_kernel(const bf16_t* __rest
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-  const int KW = KP < 64 ? KP : 64;         // k per stage
+  constexpr int KW = 64;                    // k per stage (KP is 64 or 128)
   const int CC = KP / KW;                   // chunks per tap
   const int T = RS * CC;
-  uint4 rw[LPT];
-  auto stage_load = [&](const bf16_t* base, int k0) {
+  // Weight stages arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of THREE
+  // slots, two stages ahead of their use.  The DMA destination is lane-linear (wave base + lane * 16), so the XOR swizzle
+  // of the tile is applied to the per-lane SOURCE address; ig_kc_off() applies the same involution on the read side.
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  typedef const __attribute__((address_space(1))) char glb_char_t;
+  auto stage_dma = [&](int t, int slot) {
+    const int rs1 = t / CC, cc1 = t - rs1 * CC;
+    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
 #pragma unroll
     for (int i = 0; i < LPT; i++) {
-      const int c = tid + i * NT;
-      const int gr = c >> 3, gk = k0 + ((c & 7) << 3);
-      rw[i] = (gk + 8 <= KP) ? *reinterpret_cast<const uint4*>(base + gr * KP + gk) : make_uint4(0, 0, 0, 0);
+      const int piece = wid * LPT + i;                 // 1 KiB piece of the 16 KiB slot written by this wave-instruction
+      const int p = piece * 64 + lane;                 // 16-byte position inside the slot
+      const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * IG_WTILE + piece * 1024), 16, 0, 0);
     }
   };
-  auto stage_store = [&](char* lds) {
-#pragma unroll
-    for (int i = 0; i < LPT; i++) {
-      const int c = tid + i * NT;
-      *reinterpret_cast<uint4*>(lds + ig_kc_off(c >> 3, c & 7)) = rw[i];
-    }
-  };
-  stage_load(wp, 0);
-  stage_store(Wl);
-  __syncthreads();
+  stage_dma(0, 0);
+  if (T > 1) stage_dma(1, 1);
 
-  // per-lane pixel of each of this wave's 4 n-tiles (image wc, image rows 2j, 2j+1)
+  // B-fragment addresses.  For tap (r, s) and n-tile j a lane reads pixel (2j + rowsel + r, wpix + s) of image wc, chunk
+  // (k-chunk ^ swizzle).  k-chunk = uniform part (cc, ks: bits 2..) ^ lane part (lane >> 4: bits 0..1), and XOR is
+  // bitwise, so everything except the uniform part is folded into ONE precomputed byte offset per (tap, j); the hot loop
+  // then needs a single v_xor per ds_read instead of ~10 integer instructions.
   int rowsel, wpix;
   px_of_col(lane & 15, rowsel, wpix);
-  const char* ximg = Xl + wc * XIMG;
-
-  for (int t = 0; t < T; t++) {
-    const int cur = t & 1;
-    const int rs = t / CC, cc = t - rs * CC;
-    if (t + 1 < T) {
-      const int rs1 = (t + 1) / CC, cc1 = (t + 1) - rs1 * CC;
-      stage_load(wp + (int64_t)rs1 * IG_M * KP, cc1 * KW);
-    }
-    const int r = rs / KS, s = rs - r * KS;
-    const char* wl = Wl + cur * IG_WTILE;
-    const int ksteps = KW >> 5;
-#pragma unroll 2
-    for (int ks = 0; ks < ksteps; ks++) {
-      bf8v fa[4], fb[4];
+  int pre[RS][4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(wl, wr * 64 + i * 16, ks, lane);
-      const int chunk = cc * (KW >> 3) + ks * 4 + (lane >> 4);
+  for (int rs = 0; rs < RS; rs++) {
+    const int r = rs / KS, s = rs - r * KS;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int hp = 2 * j + rowsel + r + (1 - PAD), wpx = wpix + s + (1 - PAD);
+      pre[rs][j] = wc * XIMG + (hp * 10 + wpx) * RB + ((((lane >> 4) & cmask) ^ x_swz(hp, wpx, cmask)) << 4);
+    }
+  }
+  // A-fragment (weight tile) addresses: row = wr*64 + i*16 + (lane & 15), chunk = (ks*4 + (lane >> 4)) ^ (row & 7)
+  const int a_row = (wr * 64 + (lane & 15)) * 128;
+  const int a_ch0 = ((lane >> 4) ^ (lane & 7)) << 4, a_ch1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // image tiles and weight stages 0, 1 are in LDS
+
+  // Two-phase ping-pong.  A stage is a READ phase (16 ds_read_b128: both k-steps' fragments, plus the DMA of stage t+2)
+  // and an MFMA phase (32 MFMAs), each closed by a raw s_barrier.  The waves with wr == 1 - the second wave of every
+  // SIMD - run one phase behind the waves with wr == 0, so while one wave of a SIMD feeds the matrix core the other one
+  // reads LDS.  Ordering of the DMA ring (slot = stage % 3):
+  //   * DMA(t+2) is issued in READ(t); its slot was last read in READ(t-1), and every read is retired (lgkmcnt(0))
+  //     before the barrier that closes its phase;
+  //   * each wave retires its own DMA(t+1) with a counted vmcnt before the barrier closing READ(t) (DMA(t+2) stays in
+  //     flight), which for both groups is passed before anyone starts READ(t+1).
+  bf8v fa0[4], fb0[4], fa1[4], fb1[4];
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // measured in one process: 8 % faster than no stagger, 13 % than odd/even
+  int t = 0, slot = 0;                               // slot = t % 3
+#pragma unroll
+  for (int rs = 0; rs < RS; rs++) {
+    for (int cc = 0; cc < CC; cc++, t++) {
+      const char* wl = Wl + slot * IG_WTILE + a_row;
+      const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      // ---- READ(t)
+      if (t + 2 < T) stage_dma(t + 2, slot2);
+      const int u = ((cc * (KW >> 3)) & cmask) << 4;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
+        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int hp = 2 * j + rowsel + r + (1 - PAD), wpx = wpix + s + (1 - PAD);
-        const int off = (hp * 10 + wpx) * RB + ((chunk ^ x_swz(hp, wpx, cmask)) << 4);
-        s8v v = *reinterpret_cast<const s8v*>(ximg + off);
-        fb[j] = __builtin_bit_cast(bf8v, v);
+        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u)));
+        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u ^ (4 << 4))));
       }
+      if (t + 2 < T) {
+        if (LPT == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- MFMA(t)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      slot = slot1;
     }
-    if (t + 1 < T) stage_store(Wl + (cur ^ 1) * IG_WTILE);
-    __syncthreads();
   }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
 
-  // epilogue: D rows = output channel, D cols = pixels
+  // epilogue.  The pixels are the A operand, so D rows = pixels and D cols = output channels: a lane holds, per (i, j),
+  // output channel i*16 + (lane & 15) and the four MFMA rows 4q..4q+3 (q = lane >> 4), which px_of_col maps to four
+  // CONSECUTIVE pixels of one image row -> one 8-byte store.
   const int n = n0 + wc;
   if (n < N) {
     bf16_t* yp = y + (int64_t)n * CO * 64;
+    const int q = lane >> 4;
+    const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+      const int co = wr * 64 + i * 16 + (lane & 15);
+      if (co < CO) {
+        const float b = bias ? (float)bias[co] : 0.f;
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr;
-        if (co < CO) {
-          const float b = bias ? (float)bias[co] : 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; j++) yp[co * 64 + (2 * j + rowsel) * 8 + wpix] = bf16_t(acc[i][j][rr] + b);
+        for (int j = 0; j < 4; j++) {
+          const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+          uint2 pk;
+          pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+          pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+          *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
         }
       }
     }
@@ -446,7 +516,7 @@ static bool ig_qualifies(const ConvGeom& g, int dtype) {
   if (g.N < 1) return false;
   return true;
 }
-static int pad_k(int64_t c) { return c <= 32 ? 32 : (c <= 64 ? 64 : 128); }
+static int pad_k(int64_t c) { return c <= 64 ? 64 : 128; }
 
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
   const int KS = g.kh, RS = KS * KS;
@@ -458,7 +528,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
                      (int)g.Cin, KS, KP, dgrad ? 1 : 0);
   LAMP_LAUNCH_CHECK();
   const int NW = g.N >= 1024 ? 4 : 2;        // images per workgroup (keep >= 256 workgroups before widening)
-  const size_t lds = (size_t)NW * 100 * KP * 2 + 2 * IG_WTILE;
+  const size_t lds = (size_t)NW * 100 * KP * 2 + 3 * IG_WTILE;
   const int blocks = (int)((g.N + NW - 1) / NW);
   // fprop and dgrad are the SAME kernel (ig_conv8_kernel), so they share one timer class
   KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
