@@ -222,6 +222,294 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 // ================================================================================================
+// bf16 large-tile kernel for aligned shapes (M % 256 == 0, N % 128 == 0, K % 64 == 0):
+// 256 x 128 x 64 tile, 512 threads = 8 waves (4 x 2), 64 x 64 per wave.
+//   * operand tiles arrive by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a ring of THREE
+//     stages, two K-steps ahead of their use; the LDS images are the same swizzled images as above, with
+//     the swizzle applied to the per-lane SOURCE address (the DMA destination is lane-linear);
+//   * a K-step is a READ phase (all 16 fragments of the step + the DMA of step t+2) and an MFMA phase
+//     (32 MFMAs), each closed by a raw s_barrier; waves 4-7 (the second wave of every SIMD) run one phase
+//     behind waves 0-3, so the matrix core and the LDS pipe of a SIMD are busy at the same time;
+//   * DMA ordering: each wave retires its own DMA(t+1) with a counted vmcnt before the barrier closing
+//     READ(t) (DMA(t+2) stays in flight); DMA(t+2) reuses the slot last read in READ(t-1), whose reads
+//     were retired (lgkmcnt(0)) before the barrier closing that phase;
+//   * the B fragment is the MFMA's first operand: D rows = n, D cols = m, so a lane's four accumulator
+//     registers are four CONSECUTIVE columns of C and the epilogue stores 8 bytes per lane.
+// ================================================================================================
+constexpr int PM = 256, PN = 128, PK = 64;
+constexpr int P_A_BYTES = PM * PK * 2, P_B_BYTES = PN * PK * 2, P_SLOT = P_A_BYTES + P_B_BYTES;   // 32 + 16 KiB
+
+__device__ __forceinline__ int ks_off_p(int k, int col8, int pitch) { return k * pitch + ((((col8 >> 1) ^ ks_swz(k))) << 5) + ((col8 & 1) << 4); }
+
+typedef __attribute__((address_space(3))) char pp_lds_t;
+typedef const __attribute__((address_space(1))) char pp_glb_t;
+
+// one operand tile of one K-step: ROWS x 64, global -> LDS by DMA; 1 KiB pieces, ROWS / 64 pieces per wave
+template <bool KC, int ROWS>
+__device__ __forceinline__ void pp_stage_dma(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, char* img, int wid, int lane) {
+  constexpr int PPW = ROWS * PK * 2 / 1024 / 8;
+#pragma unroll
+  for (int i = 0; i < PPW; i++) {
+    const int piece = wid * PPW + i;
+    const int p = piece * 64 + lane;                       // 16-byte position inside the image
+    const bf16_t* src;
+    if (KC) {                                              // image [ROWS][8 chunks], chunk' = chunk ^ (row & 7)
+      const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
+      src = base + (row0 + row) * ld + k0 + chunk * 8;
+    } else {                                               // image [64 k][ROWS / 8 chunks], 32-byte pairs XOR ks_swz(k)
+      constexpr int CPR = ROWS / 8;
+      const int k = p / CPR, c = p % CPR;
+      const int col8 = ((((c >> 1) ^ ks_swz(k))) << 1) | (c & 1);
+      src = base + (k0 + k) * ld + row0 + col8 * 8;
+    }
+    __builtin_amdgcn_global_load_lds((pp_glb_t*)src, (pp_lds_t*)(img + piece * 1024), 16, 0, 0);
+  }
+}
+template <bool KC, int ROWS> __device__ __forceinline__ bf8_t pp_frag(const char* img, int tile_row0, int s, int lane) {
+  if (KC) {
+    s8_t v = *reinterpret_cast<const s8_t*>(img + kc_off(tile_row0 + (lane & 15), s * 4 + (lane >> 4)));
+    return __builtin_bit_cast(bf8_t, v);
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = s * 32 + g * 8 + q;
+    const int col8 = (tile_row0 >> 3) + (p >> 1);
+    typedef __attribute__((address_space(3))) s4_t* lds_ptr_t;
+    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + ks_off_p(k, col8, ROWS * 2) + ((p & 1) << 3)));
+    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + ks_off_p(k + 4, col8, ROWS * 2) + ((p & 1) << 3)));
+    s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf8_t, v);
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int GROUP = 4;                                      // column strips of 4 tile rows (1024 rows of A) per L2
+  const int per_group = GROUP * g.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP;
+  const int gsize = min(g.tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsize;
+  const int tn = (bid % per_group) / gsize;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: guards raw s_barriers
+  const int wr = wid >> 1, wc = wid & 1;                      // 4 x 2 waves, 64 x 64 each
+  const int64_t m0 = (int64_t)tm * PM, n0 = (int64_t)tn * PN;
+  const int bz = blockIdx.z;
+  const bf16_t* A = (const bf16_t*)g.A + bz * g.a_bs;
+  const bf16_t* B = (const bf16_t*)g.B + bz * g.b_bs;
+  const int64_t lda = AKC ? g.a_rs : g.a_cs;
+  const int64_t ldb = BKC ? g.b_cs : g.b_rs;
+
+  f4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (int)(g.K / PK);
+  auto dma = [&](int t, int slot) {
+    char* sb = smem + slot * P_SLOT;
+    pp_stage_dma<AKC, PM>(A, lda, m0, (int64_t)t * PK, sb, wid, lane);
+    pp_stage_dma<BKC, PN>(B, ldb, n0, (int64_t)t * PK, sb + P_A_BYTES, wid, lane);
+  };
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int grp = wid >> 2;                                  // waves w and w + 4 share a SIMD
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  bf8_t fa0[4], fa1[4], fb0[4], fb1[4];
+  int slot = 0;
+  for (int t = 0; t < nk; t++) {
+    const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+    const char* as = smem + slot * P_SLOT;
+    const char* bs = as + P_A_BYTES;
+    // ---- READ(t)
+    if (t + 2 < nk) dma(t + 2, slot2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa0[i] = pp_frag<AKC, PM>(as, wr * 64 + i * 16, 0, lane);
+      fa1[i] = pp_frag<AKC, PM>(as, wr * 64 + i * 16, 1, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      fb0[j] = pp_frag<BKC, PN>(bs, wc * 64 + j * 16, 0, lane);
+      fb1[j] = pp_frag<BKC, PN>(bs, wc * 64 + j * 16, 1, lane);
+    }
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- MFMA(t)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    slot = slot1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  // epilogue: D rows = n (four consecutive per lane), D cols = m (lane & 15)
+  bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
+  const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int64_t row = m0 + wr * 64 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        v[r] = alpha * acc[i][j][r];
+        if (S) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+      }
+      const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
+      uint2 pk;
+      pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+      pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+      *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
+    }
+  }
+}
+
+// ================================================================================================
+// bf16 256 x 256 x 64 kernel (M % 256 == 0, N % 256 == 0, K % 64 == 0, >= 200 tiles): 8 waves (2 x 4), 128 x 64 per wave.
+// At 4096^3 the 256 x 128 kernel above moves ~9 TB/s from L2 into the CUs and stops there; the square 256 tile halves the
+// bytes per FLOP (128 FLOP/B).  LDS holds TWO 64 KiB stages, so the DMA of stage t+1 is issued one stage ahead, by every
+// wave in its first READ phase of stage t, and retired (vmcnt(0)) before the barrier that closes the LAST phase of stage t.
+// A stage is four phases, READ(k-step 0) / MFMA / READ(k-step 1) / MFMA, each closed by a raw s_barrier, with waves 4-7
+// running one phase behind waves 0-3 (ping-pong on every SIMD).  In units of phases, stage t occupies 4t..4t+3 for group 0
+// and 4t+1..4t+4 for group 1:
+//   * slot (t+1)&1 held stage t-1, last read by group 1 in phase 4t-1; group 0 issues DMA(t+1) in phase 4t, group 1 in 4t+1;
+//   * both groups retire their DMA(t+1) before the barrier closing phase 4t+3 (group 0: end of its second MFMA phase,
+//     group 1: end of its second READ phase); the first read of stage t+1 is in phase 4t+4.
+// ================================================================================================
+constexpr int QM = 256, QN = 256;
+constexpr int Q_IMG = QM * PK * 2, Q_SLOT = 2 * Q_IMG;     // 32 KiB per operand image, 64 KiB per stage
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int GROUP = 4;
+  const int per_group = GROUP * g.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP;
+  const int gsize = min(g.tiles_m - first_m, GROUP);
+  const int tm = first_m + (bid % per_group) % gsize;
+  const int tn = (bid % per_group) / gsize;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;                      // 2 x 4 waves, 128 x 64 each; wr is also the ping-pong group
+  const int64_t m0 = (int64_t)tm * QM, n0 = (int64_t)tn * QN;
+  const int bz = blockIdx.z;
+  const bf16_t* A = (const bf16_t*)g.A + bz * g.a_bs;
+  const bf16_t* B = (const bf16_t*)g.B + bz * g.b_bs;
+  const int64_t lda = AKC ? g.a_rs : g.a_cs;
+  const int64_t ldb = BKC ? g.b_cs : g.b_rs;
+
+  f4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (int)(g.K / PK);
+  auto dma = [&](int t, int slot) {
+    char* sb = smem + slot * Q_SLOT;
+    pp_stage_dma<AKC, QM>(A, lda, m0, (int64_t)t * PK, sb, wid, lane);
+    pp_stage_dma<BKC, QN>(B, ldb, n0, (int64_t)t * PK, sb + Q_IMG, wid, lane);
+  };
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf8_t fa[8], fb[4];
+#define Q_READ(S_)                                                                                     \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) fa[i] = pp_frag<AKC, QM>(as, wr * 128 + i * 16, S_, lane); \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) fb[j] = pp_frag<BKC, QN>(bs, wc * 64 + j * 16, S_, lane);  \
+  } while (0)
+#define Q_MFMA()                                                                                       \
+  do {                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; i++)                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);      \
+    __builtin_amdgcn_s_setprio(0);                                                                     \
+  } while (0)
+  for (int t = 0; t < nk; t++) {
+    const char* as = smem + (t & 1) * Q_SLOT;
+    const char* bs = as + Q_IMG;
+    // READ k-step 0 (+ DMA of the next stage)
+    if (t + 1 < nk) dma(t + 1, (t + 1) & 1);
+    Q_READ(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Q_MFMA();
+    __builtin_amdgcn_s_barrier();
+    // READ k-step 1
+    Q_READ(1);
+    if (wr == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Q_MFMA();
+    if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef Q_READ
+#undef Q_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
+  const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int64_t row = m0 + wr * 128 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        v[r] = alpha * acc[i][j][r];
+        if (S) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+      }
+      const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
+      uint2 pk;
+      pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+      pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+      *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
+    }
+  }
+}
+
+// ================================================================================================
 // f32 / f64 kernel: 64 x 64 x 16 tile, 256 threads = 4 waves (2 x 2), 32 x 32 per wave,
 // v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64. LDS tiles are k-major [16][64+pad] so a
 // fragment read is one conflict-free 4/8-byte read per lane.
@@ -441,6 +729,48 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     g.a_vec = (lda % 8 == 0) && al16(g.A) && (g.a_bs % 8 == 0);
     g.b_vec = (ldb % 8 == 0) && al16(g.B) && (g.b_bs % 8 == 0);
+    // aligned, large problems: 256 x 128 LDS-DMA / ping-pong kernel
+    const bool big = g.a_vec && g.b_vec && g.M % PM == 0 && g.N % PN == 0 && g.K % PK == 0 && (g.ldc % 4 == 0) &&
+                     (((uintptr_t)g.C & 7) == 0) && (g.c_bs % 4 == 0) && (g.M / PM) * (g.N / PN) * g.batch >= 128;
+    const bool big2 = big && g.N % QN == 0 && (g.M / QM) * (g.N / QN) * g.batch >= 200;
+    if (big2) {
+      g.tiles_m = (int)(g.M / QM);
+      g.tiles_n = (int)(g.N / QN);
+      dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
+      const size_t lds = 2 * Q_SLOT;
+#define PP2_LAUNCH(A_, B_)                                                                                                      \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp2_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((gemm_bf16_pp2_kernel<A_, B_>), grid, dim3(512), lds, stm, g);                                           \
+  } while (0)
+      if (akc && !bkc) PP2_LAUNCH(true, false);
+      else if (akc && bkc) PP2_LAUNCH(true, true);
+      else if (!akc && !bkc) PP2_LAUNCH(false, false);
+      else PP2_LAUNCH(false, true);
+#undef PP2_LAUNCH
+      LAMP_LAUNCH_CHECK();
+      return;
+    }
+    if (big) {
+      g.tiles_m = (int)(g.M / PM);
+      g.tiles_n = (int)(g.N / PN);
+      dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
+      const size_t lds = 3 * P_SLOT;
+#define PP_LAUNCH(A_, B_)                                                                                                       \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_, B_>), grid, dim3(512), lds, stm, g);                                            \
+  } while (0)
+      if (akc && !bkc) PP_LAUNCH(true, false);
+      else if (akc && bkc) PP_LAUNCH(true, true);
+      else if (!akc && !bkc) PP_LAUNCH(false, false);
+      else PP_LAUNCH(false, true);
+#undef PP_LAUNCH
+      LAMP_LAUNCH_CHECK();
+      return;
+    }
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
     dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);

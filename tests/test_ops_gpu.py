@@ -164,7 +164,8 @@ def test_views_share_storage_and_strided_copy(gpu):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 3, 3), (64, 64, 64), (130, 70, 45), (256, 384, 192), (1024, 256, 784), (1024, 10, 256), (1, 1, 1)])
+@pytest.mark.parametrize("shape", [(2, 3, 3), (64, 64, 64), (130, 70, 45), (256, 384, 192), (1024, 256, 784), (1024, 10, 256), (1, 1, 1),
+                                   (2048, 2048, 2048)])   # aligned and large: the 256x128 LDS-DMA kernel, all four operand layouts
 def test_gemm_family(gpu, dt, shape):
     M, N, K = shape
     a, b = closed_form((M, K), 1, 2.0, dt), closed_form((K, N), 77, 2.0, dt)
@@ -186,6 +187,29 @@ def test_gemm_family(gpu, dt, shape):
     assert_close(to_torch(to_sten(bias).addmm(A, B, 0.5, 2.0)), 0.5 * bias.double() + 2.0 * ref, tol * 2, "addmm broadcast self")
     o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), A, B, to_sten(bias))
     assert_close(to_torch(S.STen(o)), ref + bias.double(), tol * 2, "linear_bias")
+
+
+@pytest.mark.parametrize("K", [128, 192])
+def test_gemm_256_tile_all_layouts(gpu, K):
+    """the 256 x 256 LDS-DMA kernel (>= 200 tiles): all four operand layouts, even and odd stage counts"""
+    dt, n = torch.bfloat16, 4096
+    a, b = closed_form((n, K), 1, 2.0, dt), closed_form((K, n), 77, 2.0, dt)
+    A, B = to_sten(a), to_sten(b)
+    ref = a.double() @ b.double()
+    assert_close(to_torch(A.mm(B)), ref, 1.6e-2, "mm")
+    assert_close(to_torch(to_sten(a.t().contiguous()).t.mm(to_sten(b.t().contiguous()).t)), ref, 1.6e-2, "mm of transposed views")
+    at, p = closed_form((K, n), 3, 2.0, dt), closed_form((K, n), 9, 1.0, dt)          # out[n, n] += at^T . p
+    o0 = closed_form((n, n), 5, 1.0, dt)
+    O = to_sten(o0)
+    S.STen.addmm_out_transposed1(O, O, to_sten(at), to_sten(p), 1.0, 1.0)
+    assert_close(to_torch(O), o0.double() + at.double().t() @ p.double(), 3.2e-2, "addmm_out_transposed1")
+    p2, b2 = closed_form((n, K), 11, 1.0, dt), closed_form((n, K), 13, 2.0, dt)        # out[n, n] += p2 . b2^T
+    O1 = to_sten(o0)
+    S.STen.addmm_out_transposed2(O1, O1, to_sten(p2), to_sten(b2), 1.0, 1.0)
+    assert_close(to_torch(O1), o0.double() + p2.double() @ b2.double().t(), 3.2e-2, "addmm_out_transposed2")
+    bias = closed_form((1, n), 4, 1.0, dt)
+    o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), A, B, to_sten(bias))
+    assert_close(to_torch(S.STen(o)), ref + bias.double(), 3.2e-2, "linear_bias")
 
 
 @pytest.mark.parametrize("dt", DTYPES)
