@@ -17,6 +17,7 @@
 // bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate, one rounding to bf16 in the epilogue.
 // f32 : v_mfma_f32_16x16x4_f32 - exact f32 FMA chain (no tf32 on gfx950), parity <= 1e-5.
 // f64 : v_mfma_f64_16x16x4_f64 (the reference's own tests run in double).
+#include <cstring>
 #include "device_utils.h"
 #include "../core/strided.h"
 
