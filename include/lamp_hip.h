@@ -346,6 +346,21 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3] /* dx, dweight, dbias *
                                     const lamp_tensor* running_mean_or_null, const lamp_tensor* running_var_or_null,
                                     const lamp_tensor* save_mean_or_null, const lamp_tensor* save_invstd_or_null,
                                     int training, double eps, const uint8_t mask[3]);
+/* Fused forms of the pair lamp's networks chain everywhere, BatchNorm -> relu (cnn.scala:36-40,
+ * MLP.scala:98-120): y = relu(native_batch_norm(x)), rounded to the element type between the two exactly
+ * as the unfused pair is, so the results are identical; the backward recomputes the relu mask from x
+ * (grad passes where the normalised value is >= 0, ops.scala:918-953) and saves the three elementwise
+ * passes of relu / relu-backward.  Not ATen natives: optional extensions in the style of aten-scala's
+ * addmm_out_transposed. */
+int lamp_native_batch_norm_relu(lamp_tensor* out3[3] /* y, save_mean, save_invstd */, const lamp_tensor* x,
+                                const lamp_tensor* weight_or_null, const lamp_tensor* bias_or_null,
+                                lamp_tensor* running_mean_or_null, lamp_tensor* running_var_or_null, int training,
+                                double momentum, double eps);
+int lamp_native_batch_norm_relu_backward(lamp_tensor* out3[3] /* dx, dweight, dbias */, const lamp_tensor* grad_out,
+                                         const lamp_tensor* x, const lamp_tensor* weight_or_null, const lamp_tensor* bias_or_null,
+                                         const lamp_tensor* running_mean_or_null, const lamp_tensor* running_var_or_null,
+                                         const lamp_tensor* save_mean_or_null, const lamp_tensor* save_invstd_or_null,
+                                         int training, double eps, const uint8_t mask[3]);
 int lamp_native_layer_norm(lamp_tensor* out3[3] /* y, mean, rstd */, const lamp_tensor* x,
                            const int64_t* normalized_shape, int nnorm, const lamp_tensor* weight_or_null,
                            const lamp_tensor* bias_or_null, double eps);

@@ -51,6 +51,28 @@ Var BatchNorm::forward(const Var& x) {
   return two_d ? F::batch_norm_2d(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps)
                : F::batch_norm(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
 }
+bool BatchNorm::can_fuse_relu(const Var& x) const { return two_d && F::batch_norm_relu_2d_supported(x); }
+Var BatchNorm::forward_relu(const Var& x) {
+  return F::batch_norm_relu_2d(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
+}
+// The reference's Sequential is a plain fold (nn/Sequential.scala).  The one rewrite done here: BatchNorm2D directly followed by
+// Fun(relu) runs as the fused op (same values, three elementwise passes fewer).
+Var Sequential::forward(const Var& x) {
+  Var v = x;
+  for (size_t i = 0; i < mods.size(); i++) {
+    if (i + 1 < mods.size()) {
+      auto* bn = dynamic_cast<BatchNorm*>(mods[i].get());
+      auto* fn = dynamic_cast<Fun*>(mods[i + 1].get());
+      if (bn && fn && fn->tag == "relu" && bn->can_fuse_relu(v)) {
+        v = bn->forward_relu(v);
+        i++;
+        continue;
+      }
+    }
+    v = mods[i]->forward(v);
+  }
+  return v;
+}
 Mod LayerNorm::make(const std::vector<int64_t>& shape, int dtype, int device, bool scale, bool bias) {
   auto m = std::make_shared<LayerNorm>();
   m->normalizedShape = shape;
@@ -60,7 +82,7 @@ Mod LayerNorm::make(const std::vector<int64_t>& shape, int dtype, int device, bo
 }
 
 Mod make_fun(const std::string& name, double a, double b) {
-  if (name == "relu") return std::make_shared<Fun>([](const Var& x) { return F::relu(x); });
+  if (name == "relu") return std::make_shared<Fun>([](const Var& x) { return F::relu(x); }, "relu");
   if (name == "gelu") return std::make_shared<Fun>([](const Var& x) { return F::gelu(x); });
   if (name == "sigmoid") return std::make_shared<Fun>([](const Var& x) { return F::sigmoid(x); });
   if (name == "tanh") return std::make_shared<Fun>([](const Var& x) { return F::tanh(x); });

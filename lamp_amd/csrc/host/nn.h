@@ -59,6 +59,8 @@ struct BatchNorm : Module {     // nn/BatchNorm.scala:7-88 and nn/BatchNorm2D.sc
   static Mod make(int64_t features, int dtype, int device, bool two_d);
   void collect_state(std::vector<Var>& o) override { o.push_back(weight); o.push_back(bias); o.push_back(runningMean); o.push_back(runningVar); }
   Var forward(const Var& x) override;
+  bool can_fuse_relu(const Var& x) const;       // BatchNorm2D on maps of >= 64 elements
+  Var forward_relu(const Var& x);                // relu(forward(x)) as one fused op, identical values
   void set_training(bool t) override { training = t; }
 };
 struct LayerNorm : Module {     // nn/LayerNorm.scala:8-57
@@ -78,7 +80,8 @@ struct Dropout : Module {       // nn/Dropout.scala:6-8 (skips the op when p <= 
 };
 struct Fun : Module {           // nn `Fun(scope => input => ...)`
   std::function<Var(const Var&)> f;
-  explicit Fun(std::function<Var(const Var&)> f_) : f(std::move(f_)) {}
+  std::string tag;              // "relu" for the plain relu: lets Sequential fuse BatchNorm2D -> relu
+  explicit Fun(std::function<Var(const Var&)> f_, std::string tag_ = "") : f(std::move(f_)), tag(std::move(tag_)) {}
   void collect_state(std::vector<Var>&) override {}
   Var forward(const Var& x) override { return f(x); }
 };
@@ -86,7 +89,7 @@ struct Sequential : Module {
   std::vector<Mod> mods;
   explicit Sequential(std::vector<Mod> m) : mods(std::move(m)) {}
   void collect_state(std::vector<Var>& o) override { for (auto& m : mods) m->collect_state(o); }
-  Var forward(const Var& x) override { Var v = x; for (auto& m : mods) v = m->forward(v); return v; }
+  Var forward(const Var& x) override;
   void set_training(bool t) override { for (auto& m : mods) m->set_training(t); }
 };
 struct Residual : Module {      // cnn.scala:11-21

@@ -505,15 +505,22 @@ Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int
 
 // ---- normalisation (ops.scala:1846-2140) --------------------------------------------------------
 static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, const Var& weight, const Var& bias, const Ten& runningMean,
-                           const Ten& runningVar, bool training, double momentum, double eps, bool two_d) {
+                           const Ten& runningVar, bool training, double momentum, double eps, bool two_d, bool relu = false) {
   auto op = new_op(name);
   const std::vector<int64_t> expected = {x.size(1)};
   LAMP_CHECK(weight->shape() == expected, "Expected [" << expected[0] << "] got weight shape of " << weight->value.h()->describe());
   LAMP_CHECK(bias->shape() == expected, "Expected [" << expected[0] << "] got bias shape of " << bias->value.h()->describe());
   LAMP_CHECK(runningMean.shape() == expected && runningVar.shape() == expected, "running statistics have the wrong shape");
   lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
-  HCALL(lamp_native_batch_norm(o3, x.h(), weight->value.h(), bias->value.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
-  Ten out(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]), wv = weight->value;
+  if (relu) HCALL(lamp_native_batch_norm_relu(o3, x.h(), weight->value.h(), bias->value.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
+  else HCALL(lamp_native_batch_norm(o3, x.h(), weight->value.h(), bias->value.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
+  Ten out(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]), wv = weight->value, bv = bias->value;
+  // one backward call; with relu fused the gradient mask is recomputed from x inside the kernels
+  auto bn_backward = [=](lamp_tensor* r3[3], const Ten& fp, const uint8_t mask[3]) {
+    if (relu) HCALL(lamp_native_batch_norm_relu_backward(r3, fp.h(), x.h(), wv.h(), bv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(),
+                                                         training, eps, mask));
+    else HCALL(lamp_native_batch_norm_backward(r3, fp.h(), x.h(), wv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(), training, eps, mask));
+  };
   // The reference calls native_batch_norm_backward once per requested derivative (ops.scala:1901,1924,
   // 2086,2107) and sums p again for the bias; all three reduce the same per-channel sums.  Here the input
   // closure (it runs first) asks for dx, dweight AND dbias in one call and parks the latter two for the
@@ -532,8 +539,7 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
       lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
       const bool first = which == 0;   // the input closure runs first and shares its reduction pass with weight and bias
       uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1 || (first && want_w)), (uint8_t)(first && want_b)};
-      HCALL(lamp_native_batch_norm_backward(r3, fp.h(), x.h(), wv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(),
-                                            training, eps, mask));
+      bn_backward(r3, fp, mask);
       Ten r0(r3[0]), r1(r3[1]), r2(r3[2]);
       if (first) { cache->dweight = r1; cache->dbias = r2; cache->p = p; }
       o.accumulate(ops::reshape(which == 0 ? r0 : r1, o.shape()), true);
@@ -547,6 +553,14 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
     if (cache->dbias.defined() && cache->p.h() == p.h()) {
       o.accumulate(ops::reshape(cache->dbias, o.shape()), true);
       cache->dbias = Ten(); cache->p = Ten();
+      return;
+    }
+    if (relu) {                                              // the bias gradient is the sum of the MASKED p
+      lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
+      const uint8_t mask[3] = {0, 0, 1};
+      bn_backward(r3, p, mask);
+      Ten r0(r3[0]), r1(r3[1]), r2(r3[2]);
+      o.accumulate(ops::reshape(r2, o.shape()), true);
       return;
     }
     if (two_d) {
@@ -569,6 +583,20 @@ Var batch_norm_2d(const Var& input, const Var& weight, const Var& bias, const Te
                   double momentum, double eps) {
   LAMP_CHECK(input->value.ndim() >= 3, "Expected 3D or 4D tensor");
   return batch_norm_impl("BatchNorm2D", input, input->value, weight, bias, runningMean, runningVar, training, momentum, eps, true);
+}
+// relu(batch_norm_2d(x)) as ONE op (the BatchNorm2D -> Fun(relu) pair of cnn.scala:36-40): identical values, the relu and
+// relu-backward passes folded into the normalisation kernels.  Maps of fewer than 64 elements take the unfused pair.
+bool batch_norm_relu_2d_supported(const Var& input) {
+  const int nd = input->value.ndim();
+  if (nd < 3) return false;
+  int64_t hw = 1;
+  for (int d = 2; d < nd; d++) hw *= input->value.size(d);
+  return hw >= 64;
+}
+Var batch_norm_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,
+                       double momentum, double eps) {
+  LAMP_CHECK(input->value.ndim() >= 3, "Expected 3D or 4D tensor");
+  return batch_norm_impl("BatchNorm2DRelu", input, input->value, weight, bias, runningMean, runningVar, training, momentum, eps, true, true);
 }
 Var layer_norm(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& normalizedShape, double eps) {
   auto op = new_op("LayerNormOp");

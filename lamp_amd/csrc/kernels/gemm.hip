@@ -369,6 +369,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
   bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
   const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
   const float alpha = (float)g.alpha, beta = (float)g.beta;
+  const bool s_vec = S && g.s_cs == 1 && (g.s_rs % 4 == 0) && (((uintptr_t)S & 7) == 0);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int64_t row = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -377,9 +378,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
       const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        v[r] = alpha * acc[i][j][r];
-        if (S) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+      for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][r];
+      if (S) {
+        if (s_vec) {                                       // beta operand contiguous along n: one 8-byte load
+          const uint2 sv = *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
+          bf16_t e0, e1, e2, e3;
+          e0.bits = (unsigned short)(sv.x & 0xffffu); e1.bits = (unsigned short)(sv.x >> 16);
+          e2.bits = (unsigned short)(sv.y & 0xffffu); e3.bits = (unsigned short)(sv.y >> 16);
+          v[0] += beta * (float)e0; v[1] += beta * (float)e1; v[2] += beta * (float)e2; v[3] += beta * (float)e3;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+        }
       }
       const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
       uint2 pk;
@@ -489,6 +499,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
   bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
   const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
   const float alpha = (float)g.alpha, beta = (float)g.beta;
+  const bool s_vec = S && g.s_cs == 1 && (g.s_rs % 4 == 0) && (((uintptr_t)S & 7) == 0);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int64_t row = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -497,9 +508,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
       const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        v[r] = alpha * acc[i][j][r];
-        if (S) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+      for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][r];
+      if (S) {
+        if (s_vec) {                                       // beta operand contiguous along n: one 8-byte load
+          const uint2 sv = *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
+          bf16_t e0, e1, e2, e3;
+          e0.bits = (unsigned short)(sv.x & 0xffffu); e1.bits = (unsigned short)(sv.x >> 16);
+          e2.bits = (unsigned short)(sv.y & 0xffffu); e3.bits = (unsigned short)(sv.y >> 16);
+          v[0] += beta * (float)e0; v[1] += beta * (float)e1; v[2] += beta * (float)e2; v[3] += beta * (float)e3;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] += beta * (float)S[row * g.s_rs + (col + r) * g.s_cs];
+        }
       }
       const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
       uint2 pk;

@@ -148,11 +148,17 @@ __global__ void bn_eval_stats_kernel(const T* running_mean, const T* running_var
   const A v = running_var ? load_as<A>(running_var[c]) : A(1);
   invstd[c] = store_as<T>((A)(A(1) / (A)sqrt((double)(v + (A)eps))));
 }
-// y = (x - mean) * invstd * w + b      (16-byte packets when HW % W == 0: one channel per packet)
+// the normalised value, ONE expression shared by the forward kernel and by the backward kernels that recompute it for
+// the fused relu mask (an explicit fma so that every kernel rounds identically)
+template <class A> __device__ __forceinline__ A bn_affine(A x, A mu, A scale, A bb);
+template <> __device__ __forceinline__ float bn_affine<float>(float x, float mu, float scale, float bb) { return __builtin_fmaf(x - mu, scale, bb); }
+template <> __device__ __forceinline__ double bn_affine<double>(double x, double mu, double scale, double bb) { return __builtin_fma(x - mu, scale, bb); }
+// y = (x - mean) * invstd * w + b      (16-byte packets when HW % W == 0: one channel per packet); relu: y = max(y, 0)
+// applied to the ROUNDED value, as the separate relu kernel would
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ mean,
                                                        const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
-                                                       int64_t total, int64_t C, int64_t HW, int vec) {
+                                                       int64_t total, int64_t C, int64_t HW, int vec, int relu) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   if (vec) {
@@ -160,13 +166,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
       const int64_t c = (i / vpp) % C;
       const A scale = load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1));
-      const A shift = (b ? load_as<A>(b[c]) : A(0)) - load_as<A>(mean[c]) * scale;
       const A mu = load_as<A>(mean[c]);
       const A bb = b ? load_as<A>(b[c]) : A(0);
       Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + i * W);
-      (void)shift;
 #pragma unroll
-      for (int k = 0; k < W; k++) pk.v[k] = store_as<T>((A)((load_as<A>(pk.v[k]) - mu) * scale + bb));
+      for (int k = 0; k < W; k++) {
+        T v = store_as<T>(bn_affine<A>(load_as<A>(pk.v[k]), mu, scale, bb));
+        if (relu && load_as<A>(v) < A(0)) v = store_as<T>(A(0));
+        pk.v[k] = v;
+      }
       *reinterpret_cast<Vec<T, W>*>(y + i * W) = pk;
     }
     return;
@@ -174,22 +182,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = (i / HW) % C;
     const A scale = load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1));
-    const A shift = b ? load_as<A>(b[c]) : A(0);
-    y[i] = store_as<T>((A)((load_as<A>(x[i]) - load_as<A>(mean[c])) * scale + shift));
+    const A bb = b ? load_as<A>(b[c]) : A(0);
+    T v = store_as<T>(bn_affine<A>(load_as<A>(x[i]), load_as<A>(mean[c]), scale, bb));
+    if (relu && load_as<A>(v) < A(0)) v = store_as<T>(A(0));
+    y[i] = v;
   }
 }
 
 // ---- batch norm backward -------------------------------------------------------------------------
 // partial[split][c] = (sum dy, sum dy * (x - mean))
+// relu != 0: dy is the gradient of relu(bn(x)); it is masked where the (recomputed, rounded) normalised value is < 0
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
-                                                            acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit, int vec) {
+                                                            acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit, int vec,
+                                                            int relu, const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A sm[2][4];
   const int64_t c = blockIdx.x;
   const int split = blockIdx.y;
   const A mu = load_as<A>(mean[c]);
+  const A scale = relu ? load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1)) : A(0);
+  const A bb = (relu && b) ? load_as<A>(b[c]) : A(0);
   A s1 = 0, s2 = 0;
   if (vec) {
     const int64_t vpp = HW / W, total = N * vpp;
@@ -199,15 +213,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + base);
       const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + base);
 #pragma unroll
-      for (int k = 0; k < W; k++) { const A gg = load_as<A>(g.v[k]); s1 += gg; s2 += gg * (load_as<A>(xv.v[k]) - mu); }
+      for (int k = 0; k < W; k++) {
+        A gg = load_as<A>(g.v[k]);
+        const A xx = load_as<A>(xv.v[k]);
+        if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+        s1 += gg; s2 += gg * (xx - mu);
+      }
     }
   } else {
     const int64_t total = N * HW;
     for (int64_t i = (int64_t)split * blockDim.x + threadIdx.x; i < total; i += (int64_t)nsplit * blockDim.x) {
       const int64_t n = i / HW, v = i - n * HW;
       const int64_t base = (n * C + c) * HW + v;
-      const A gg = load_as<A>(dy[base]);
-      s1 += gg; s2 += gg * (load_as<A>(x[base]) - mu);
+      A gg = load_as<A>(dy[base]);
+      const A xx = load_as<A>(x[base]);
+      if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+      s1 += gg; s2 += gg * (xx - mu);
     }
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -215,10 +236,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    A a = 0, b = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); k++) { a += sm[0][k]; b += sm[1][k]; }
+    A a = 0, bsum = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) { a += sm[0][k]; bsum += sm[1][k]; }
     partial[((int64_t)split * C + c) * 2] = a;
-    partial[((int64_t)split * C + c) * 2 + 1] = b;
+    partial[((int64_t)split * C + c) * 2 + 1] = bsum;
   }
 }
 template <class T>
@@ -262,7 +283,7 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
                                                            const T* __restrict__ invstd, const T* __restrict__ w,
                                                            const acc_t<T>* __restrict__ sums, T* __restrict__ dx, int64_t total, int64_t C,
-                                                           int64_t HW, double inv_m, int training, int vec) {
+                                                           int64_t HW, double inv_m, int training, int vec, int relu, const T* __restrict__ b) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   if (vec) {
@@ -274,13 +295,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const A mu = load_as<A>(mean[c]);
       const A k = training ? sums[c * 2 + 1] * is * is * (A)inv_m : A(0);
       const A gm = training ? sums[c * 2] * (A)inv_m : A(0);
+      const A scale = is * wc, bb = (relu && b) ? load_as<A>(b[c]) : A(0);
       const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + i * W);
       const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + i * W);
       Vec<T, W> r;
 #pragma unroll
       for (int q = 0; q < W; q++) {
-        const A gg = load_as<A>(g.v[q]);
-        r.v[q] = store_as<T>(training ? (A)((gg - gm - (load_as<A>(xv.v[q]) - mu) * k) * is * wc) : (A)(gg * is * wc));
+        A gg = load_as<A>(g.v[q]);
+        const A xx = load_as<A>(xv.v[q]);
+        if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+        r.v[q] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
       }
       *reinterpret_cast<Vec<T, W>*>(dx + i * W) = r;
     }
@@ -290,12 +314,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int64_t c = (i / HW) % C;
     const A is = load_as<A>(invstd[c]);
     const A wc = w ? load_as<A>(w[c]) : A(1);
-    const A g = load_as<A>(dy[i]);
+    const A mu = load_as<A>(mean[c]);
+    A g = load_as<A>(dy[i]);
+    const A xx = load_as<A>(x[i]);
+    if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, is * wc, b ? load_as<A>(b[c]) : A(0)))) < A(0)) g = A(0);
     A r;
     if (training) {
       const A k = sums[c * 2 + 1] * is * is * (A)inv_m;
       const A gm = sums[c * 2] * (A)inv_m;
-      r = (g - gm - (load_as<A>(x[i]) - load_as<A>(mean[c])) * k) * is * wc;
+      r = (g - gm - (xx - mu) * k) * is * wc;
     } else {
       r = g * is * wc;
     }
@@ -412,8 +439,8 @@ using namespace lamp;
 
 extern "C" {
 
-int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
-                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps) {
+static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input");
   BnGeom g = bn_geom(x);
@@ -453,7 +480,7 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
       KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
       hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(),
                          invstd->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr, total,
-                         g.C, g.HW, vec);
+                         g.C, g.HW, vec, relu);
       LAMP_LAUNCH_CHECK();
     }
   });
@@ -463,15 +490,28 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   out3[0] = y.take(); out3[1] = mean.take(); out3[2] = invstd.take();
   LAMP_API_END
 }
+int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps) {
+  return bn_forward_impl(out3, x, weight, bias, running_mean, running_var, training, momentum, eps, 0);
+}
+int lamp_native_batch_norm_relu(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                                lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps) {
+  return bn_forward_impl(out3, x, weight, bias, running_mean, running_var, training, momentum, eps, 1);
+}
 
-int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
-                                    const lamp_tensor* running_mean, const lamp_tensor* running_var, const lamp_tensor* save_mean,
-                                    const lamp_tensor* save_invstd, int training, double eps, const uint8_t mask[3]) {
+static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                            const lamp_tensor* bias, const lamp_tensor* running_mean, const lamp_tensor* running_var,
+                            const lamp_tensor* save_mean, const lamp_tensor* save_invstd, int training, double eps, const uint8_t mask[3],
+                            int relu) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out");
   LAMP_CHECK(grad_out->shape() == x->shape() && grad_out->dtype == x->dtype, "grad_out " << grad_out->describe() << " does not match input " << x->describe());
   BnGeom g = bn_geom(x);
   check_cvec(weight, g.C, x->dtype, "weight");
+  if (relu) {
+    check_cvec(bias, g.C, x->dtype, "bias");
+    LAMP_CHECK(g.HW >= 64, "the fused batch-norm-relu backward exists for maps of at least 64 elements, got " << x->describe());
+  }
   Hold xc(contiguous(x)), gc(contiguous(grad_out));
   hipStream_t st = current_stream(x->device());
   int64_t cs[1] = {g.C};
@@ -508,7 +548,8 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
     {
       KernelTimer kt1("bn_bwd_reduce", 0, 2.0 * (double)total * sizeof(T), st);
       if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec,
+                              relu, invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr);
     }
     LAMP_LAUNCH_CHECK();
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
@@ -518,12 +559,23 @@ int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
       KernelTimer kt2("bn_bwd_apply", 0, 3.0 * (double)total * sizeof(T), st);
       hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(),
                          invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW,
-                         1.0 / (double)(g.N * g.HW), training, vec);
+                         1.0 / (double)(g.N * g.HW), training, vec, relu, bias ? bias->ptr<T>() : (const T*)nullptr);
       LAMP_LAUNCH_CHECK();
     }
   });
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
   LAMP_API_END
+}
+int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                                    const lamp_tensor* running_mean, const lamp_tensor* running_var, const lamp_tensor* save_mean,
+                                    const lamp_tensor* save_invstd, int training, double eps, const uint8_t mask[3]) {
+  return bn_backward_impl(out3, grad_out, x, weight, nullptr, running_mean, running_var, save_mean, save_invstd, training, eps, mask, 0);
+}
+int lamp_native_batch_norm_relu_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                                         const lamp_tensor* bias, const lamp_tensor* running_mean, const lamp_tensor* running_var,
+                                         const lamp_tensor* save_mean, const lamp_tensor* save_invstd, int training, double eps,
+                                         const uint8_t mask[3]) {
+  return bn_backward_impl(out3, grad_out, x, weight, bias, running_mean, running_var, save_mean, save_invstd, training, eps, mask, 1);
 }
 
 int lamp_native_layer_norm(lamp_tensor* out3[3], const lamp_tensor* x, const int64_t* normalized_shape, int nnorm,

@@ -305,6 +305,40 @@ def test_batch_norm(gpu, dt, shape, training):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(6, 5, 8, 8), (4, 16, 16, 16), (3, 7, 9, 9)])
+def test_batch_norm_relu_fused_equals_unfused_pair(gpu, dt, shape, training):
+    """lamp_native_batch_norm_relu(+_backward) must be BITWISE the pair native_batch_norm -> relu (and its backward)"""
+    x = closed_form(shape, 3, 4.0, dt) + 0.3
+    Cc = shape[1]
+    w, b = closed_form((Cc,), 1, 1.0, dt) + 1.0, closed_form((Cc,), 5, 1.0, dt)
+    rm, rv = closed_form((Cc,), 7, 0.5, dt), closed_form((Cc,), 9, 0.5, dt) + 1.0
+    X, Wt, Bt = to_sten(x), to_sten(w), to_sten(b)
+    out_u, out_f = _out3(), _out3()
+    RMu, RVu, RMf, RVf = to_sten(rm), to_sten(rv), to_sten(rm), to_sten(rv)
+    lib.lamp_native_batch_norm(out_u, X, Wt, Bt, RMu, RVu, int(training), 0.1, 1e-5)
+    lib.lamp_native_batch_norm_relu(out_f, X, Wt, Bt, RMf, RVf, int(training), 0.1, 1e-5)
+    yu, smu, siu = _wrap3(out_u)
+    yf, smf, sif = _wrap3(out_f)
+    assert np.array_equal(yu.relu().to_numpy(), yf.to_numpy())
+    assert np.array_equal(RMu.to_numpy(), RMf.to_numpy()) and np.array_equal(RVu.to_numpy(), RVf.to_numpy())
+    # against the oracle as well
+    ref = torch.relu(aten.native_batch_norm(x, w, b, rm.clone(), rv.clone(), training, 0.1, 1e-5)[0])
+    assert_close(to_torch(yf), ref.double(), FWD_TOL[dt] * 4, "fused bn+relu")
+    gy = closed_form(shape, 11, 2.0, dt)
+    GY = to_sten(gy)
+    gm = C.c_void_p()
+    lib.lamp_relu_backward(C.byref(gm), GY, yu, 0.0)
+    outb_u, outb_f = _out3(), _out3()
+    sm = smu if training else None
+    si = siu if training else None
+    lib.lamp_native_batch_norm_backward(outb_u, S.STen(gm), X, Wt, RMu, RVu, sm, si, int(training), 1e-5, _mask3(1, 1, 1))
+    lib.lamp_native_batch_norm_relu_backward(outb_f, GY, X, Wt, Bt, RMu, RVu, sm, si, int(training), 1e-5, _mask3(1, 1, 1))
+    for u, f, what in zip(_wrap3(outb_u), _wrap3(outb_f), ("dx", "dweight", "dbias")):
+        assert np.array_equal(u.to_numpy(), f.to_numpy()), what
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("affine", [(True, True), (True, False), (False, False)])
 def test_layer_norm(gpu, dt, affine):
     x = closed_form((6, 7, 96), 3, 4.0, dt)
