@@ -122,7 +122,9 @@ def main():
 
     dist = None
     comm = None
-    if world > 1:
+    # LAMP_BENCH_FORCE_COMM=1 (under torch.distributed.run with one process) drives the complete multi-rank code path -
+    # gloo control plane, unique-id exchange, RCCL communicator, two-bucket overlapped exchange - on a single GPU
+    if world > 1 or (os.environ.get("LAMP_BENCH_FORCE_COMM") == "1" and "RANK" in os.environ):
         from lamp_amd import distributed as D
         dist = D.init_control_plane()            # gloo: control plane only (unique id, barrier, max of times)
         comm = D.rccl_communicator(dist)         # RCCL communicator: the data plane over xGMI

@@ -198,6 +198,7 @@ Var make_param(const Ten& t);   // package.scala:70-78
 Var make_result(const std::shared_ptr<Op>& op, const Ten& value);   // Variable.apply (autograd.scala:88-96)
 std::vector<Variable*> topological_sort(Variable* root);   // autograd.scala:490-518
 void backprop(const Var& root);                            // autograd.scala:264-282
+void backprop(const Var& root, const std::function<void(Variable*)>& after_node);
 
 }  // namespace host
 }  // namespace lamp

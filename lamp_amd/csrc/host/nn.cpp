@@ -1,5 +1,6 @@
 // lamp.nn over the C ABI - see nn.h for the reference map.
 #include "nn.h"
+#include <unordered_map>
 
 namespace lamp {
 namespace host {
@@ -228,24 +229,84 @@ int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, co
 }
 
 // ---- data parallel step ------------------------------------------------------------------------------
+DataParallel::~DataParallel() { if (comm_stream) lamp_stream_release(comm_stream); }
+
 int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc) {
-  std::vector<Ten> grads;
-  const int64_t n = model.addTotalLossAndReturnGradientsAndNumExamples(samples, target, acc, true, &grads);
-  if (comm) {
-    // averageGradients (distributed/package.scala:690-719): g *= n ; reduce(n) ; reduce(g) ; g /= sum n.
-    // Here: one flat f32 bucket [n*g_0 | n*g_1 | ... | n], one all-reduce, every rank divides by the summed n.
-    std::vector<lamp_tensor*> gh;
-    int64_t total = 0;
-    for (auto& g : grads) { gh.push_back(g.h()); total += g.numel(); }
-    if (!bucket.defined() || bucket.numel() != total + 1) bucket = ops::zeros({total + 1}, kF32, grads[0].device());
-    HCALL(lamp_flatten_into_(bucket.h(), gh.data(), (int)gh.size(), (double)n));
-    Ten last = ops::slice(bucket, 0, total, total + 1, 1);
-    ops::fill_(last, (double)n);
+  if (!comm) {
+    std::vector<Ten> grads;
+    const int64_t n = model.addTotalLossAndReturnGradientsAndNumExamples(samples, target, acc, true, &grads);
+    opt.step(grads, 1.0);
+    return n;
+  }
+  // averageGradients (distributed/package.scala:690-719): g *= n ; reduce(n) ; reduce(g) ; g /= sum n.
+  // Here: flat f32 buckets [n*g_i ... | n], one all-reduce each, every rank divides by the summed n.
+  std::vector<Var> params = model.module->parameters();
+  LAMP_CHECK(!params.empty(), "data-parallel step on a model without parameters");
+  const int device = params[0]->value.device();
+  int64_t total = 0;
+  for (auto& p : params) total += p->value.numel();
+  size_t split = params.size();                     // params[split..) = deep bucket
+  for (int64_t tail = 0; split > 0 && tail * 10 < total * 9;) tail += params[--split]->value.numel();
+
+  for (auto& p : params) p->zeroGrad();
+  Var output = model.module->forward(make_const(samples));
+  auto ln = model.loss(output, target);
+  const int64_t n = ln.second;
+
+  lamp_stream* cur = nullptr;
+  HCALL(lamp_stream_get_current(device, &cur));
+  if (!comm_stream) HCALL(lamp_stream_get_from_pool(1, device, &comm_stream));
+
+  auto exchange = [&](size_t lo, size_t hi, Ten& bucket, std::vector<Ten>& grads, std::vector<lamp_tensor*>& gh) {
+    int64_t cnt = 0;
+    for (size_t i = lo; i < hi; i++) {
+      grads.push_back(params[i]->grad_inplace());  // materialised (zeros if nothing flowed)
+      gh.push_back(grads.back().h());
+      cnt += grads.back().numel();
+    }
+    if (!bucket.defined() || bucket.numel() != cnt + 1) bucket = ops::zeros({cnt + 1}, kF32, device);
+    HCALL(lamp_stream_wait_stream(comm_stream, cur));              // the gradients are complete on the compute stream
+    HCALL(lamp_stream_set_current(comm_stream));
+    if (!gh.empty()) HCALL(lamp_flatten_into_(bucket.h(), gh.data(), (int)gh.size(), (double)n));
+    ops::fill_(ops::slice(bucket, 0, cnt, cnt + 1, 1), (double)n);
     lamp_tensor* bt[1] = {bucket.h()};
     lamp_comm* cm[1] = {comm};
     HCALL(lamp_comm_all_reduce(bt, cm, 1, 0));
-    HCALL(lamp_unflatten_from_(gh.data(), (int)gh.size(), bucket.h(), 1));
+    HCALL(lamp_stream_set_current(cur));
+  };
+
+  // gradients of a parameter are final once every op that consumes it has run its backward
+  std::unordered_map<Variable*, int> uses;
+  for (size_t i = split; i < params.size(); i++) uses[params[i].get()] = 0;
+  for (Variable* v : topological_sort(ln.first.get()))
+    if (v->op)
+      for (auto& p : v->op->params) { auto it = uses.find(p.first.get()); if (it != uses.end()) it->second++; }
+  int64_t pending = 0;
+  for (auto& kv : uses) if (kv.second > 0) pending++;
+  std::vector<Ten> g_deep, g_rest;
+  std::vector<lamp_tensor*> h_deep, h_rest;
+  bool deep_sent = false;
+  auto send_deep = [&]() { exchange(split, params.size(), bucket_deep, g_deep, h_deep); deep_sent = true; };
+  if (pending == 0 && split < params.size()) send_deep();
+  backprop(ln.first, [&](Variable* v) {
+    if (deep_sent || !v->op) return;
+    for (auto& p : v->op->params) {
+      auto it = uses.find(p.first.get());
+      if (it != uses.end() && it->second > 0 && --it->second == 0 && --pending == 0) { send_deep(); return; }
+    }
+  });
+  if (!deep_sent) send_deep();
+  exchange(0, split, bucket_rest, g_rest, h_rest);
+  if (acc.defined()) {                                           // acc += (loss.value * numInstances.toDouble)
+    Ten scaled = ops::mul_scalar(ln.first->value, (double)n);
+    ops::add_(acc, ops::reshape(scaled, acc.shape()));
   }
+  HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both reduced buckets are visible to the compute stream
+  if (!h_deep.empty()) HCALL(lamp_unflatten_from_(h_deep.data(), (int)h_deep.size(), bucket_deep.h(), 1));
+  if (!h_rest.empty()) HCALL(lamp_unflatten_from_(h_rest.data(), (int)h_rest.size(), bucket_rest.h(), 1));
+  lamp_stream_release(cur);
+  std::vector<Ten> grads(g_rest);
+  grads.insert(grads.end(), g_deep.begin(), g_deep.end());
   opt.step(grads, 1.0);
   return n;
 }

@@ -150,10 +150,16 @@ struct SupervisedModel {
 
 // one data-parallel step: local gradients, example-weighted all-reduce of ONE flat f32 bucket
 // (numExamples appended as the last element), identical optimiser step on every rank.
+// The exchange runs on a second stream in TWO buckets: the parameters of the deep layers (the tail of the parameter list
+// that holds >= 90 % of the elements; their gradients are complete first) are packed and all-reduced while backward
+// continues through the shallow layers, the rest follows after backward.  Every rank issues the same two collectives in the
+// same order.
 struct DataParallel {
   lamp_comm* comm = nullptr;    // null => single process (no exchange)
-  Ten bucket;                   // f32 [sum numel + 1]
+  Ten bucket_deep, bucket_rest; // f32 [sum numel + 1] each, last element = numExamples
+  lamp_stream* comm_stream = nullptr;
   int64_t step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc);
+  ~DataParallel();
 };
 
 }  // namespace host

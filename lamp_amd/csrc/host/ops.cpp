@@ -47,14 +47,19 @@ std::vector<Variable*> topological_sort(Variable* root) {
   return std::vector<Variable*>(order.rbegin(), order.rend());
 }
 
-void backprop(const Var& root) {
+void backprop(const Var& root) { backprop(root, nullptr); }
+// `after` runs once per visited node, after the node's backward closures (also for nodes nothing flowed into): the
+// data-parallel step uses it to start the gradient exchange of the deep layers while the shallow ones are still in backward
+void backprop(const Var& root, const std::function<void(Variable*)>& after) {
   if (!root->needsGrad()) return;
   root->grad = ops::ones_like(root->value);   // partialDerivative.get.fill_(1d)
   root->grad_shared = false;
   for (Variable* v : topological_sort(root.get())) {
-    if (!v->op || !v->has_grad()) continue;   // a node nothing flowed into contributes exact zeros
-    for (auto& p : v->op->params)
-      if (p.first->needsGrad()) p.second(v->grad, *p.first);
+    if (v->op && v->has_grad()) {             // a node nothing flowed into contributes exact zeros
+      for (auto& p : v->op->params)
+        if (p.first->needsGrad()) p.second(v->grad, *p.first);
+    }
+    if (after) after(v);
   }
 }
 

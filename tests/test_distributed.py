@@ -2,7 +2,8 @@
 
 What runs here is the host logic (rendezvous, bucket layout, example-weighted averaging contract, sharding); the device
 kernels of the same step (lamp_flatten_into_ / lamp_comm_all_reduce / lamp_unflatten_from_) are covered on the GPU in
-test_flat_bucket_and_single_rank_collectives (world size 1 communicator).
+test_flat_bucket_and_single_rank_collectives, and the complete overlapped two-bucket step (second stream, events, AdamW) in
+test_overlapped_data_parallel_step_single_rank (world size 1 communicator).
 """
 import ctypes as C
 import os
@@ -82,3 +83,37 @@ def test_flat_bucket_and_single_rank_collectives(gpu):
     lib.lamp_unflatten_from_(handle_array([t.h for t in out]), 2, bucket, 1)
     assert np.allclose(out[0].to_numpy(), np.arange(6).reshape(2, 3)) and np.allclose(out[1].to_numpy(), 2.0)
     lib.lamp_comm_destroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_overlapped_data_parallel_step_single_rank(gpu, dtype_name):
+    """lamp_model_train_step with a world-size-1 RCCL communicator runs the whole two-bucket / second-stream exchange
+    (pack * n, all-reduce, / sum n, AdamW).  With one rank the averaged gradient is the local one, so three steps must
+    land on the parameters of the plain step (n = 64 is a power of two: *n and /n are exact)."""
+    from lamp_amd import sten as S, nn
+    from lamp_amd._capi import lib
+    dt = S.F32 if dtype_name == "f32" else S.BF16
+    B = 64
+    x = S.STen.from_numpy((np.arange(B * 3 * 32 * 32) * 7919 % 1009 / 1009.0 - 0.5).reshape(B, 3, 32, 32).astype(np.float32), 0, dt)
+    target = S.STen.from_numpy((np.arange(B) * 7 % 100).astype(np.int64), 0)
+    uid = (C.c_uint8 * 128)(); lib.lamp_comm_get_unique_id(uid)
+    comm = C.c_void_p(); lib.lamp_comm_init_rank(C.byref(comm), 1, uid, 0)
+
+    def run(use_comm):
+        lib.lamp_manual_seed(99)
+        mod = nn.resnet(100, 0.0, dt, 0)
+        model = nn.SupervisedModel(mod, nn.SupervisedModel.NLL, S.STen.ones([100], dt, 0))
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3, mixedPrecision=(dt == S.BF16))([p.value for p in mod.parameters])
+        acc = S.STen.zeros([1], dt, 0)
+        for _ in range(3):
+            assert model.train_step(opt, x, target, acc, comm if use_comm else None) == B
+        lib.lamp_device_synchronize()
+        return [s.value.castToDouble().to_numpy() for s in mod.state], acc.castToDouble().to_numpy()
+
+    plain, acc0 = run(False)
+    dp, acc1 = run(True)
+    lib.lamp_comm_destroy(comm)
+    assert np.array_equal(acc0, acc1)
+    for a, b in zip(plain, dp):
+        assert np.array_equal(a, b), "single-rank data-parallel step must reproduce the plain step bit for bit"
