@@ -144,3 +144,50 @@ def test_attention_matches_composed_softmax(gpu, dt, causal):
     btol = {torch.float64: 1e-10, torch.float32: 1e-3, torch.bfloat16: 6e-2}[dt]
     for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
         assert_close(to_torch(S.STen(h)), r, btol, name)
+
+
+def test_knn_and_umap_at_full_size_properties(gpu):
+    """BASELINE config 5 at its full size (1M x 128 f32 points, k = 10): size-independent properties instead of an oracle.
+    kNN (262,144 query rows against all 1M points): the query itself is a neighbour at distance ~0, indices are in range and
+    distinct per row, and no sampled non-neighbour is closer than the k-th neighbour.  UMAP layout (1M points, 10M attractive
+    + 50M repulsive pairs): with unit term weights every pair pushes its two end points with opposite forces, so the
+    gradient sums to zero over the points."""
+    n, d, k, nq = 1_000_000, 128, 10, 262_144
+    rng = np.random.default_rng(5)
+    pts = rng.random((n, d), dtype=np.float32) + (np.arange(n) % 16)[:, None].astype(np.float32)
+    data = S.STen.from_numpy(pts, 0, S.F32)
+    rows = np.sort(rng.choice(n, nq, replace=False))
+    query = S.STen.from_numpy(pts[rows], 0, S.F32)
+    i, dd = C.c_void_p(), C.c_void_p()
+    lib.lamp_knn_squared_euclidean(C.byref(i), C.byref(dd), data, query, k)
+    idx, dist = S.STen(i).to_numpy(), S.STen(dd).to_numpy()
+    assert idx.shape == (nq, k) and idx.min() >= 0 and idx.max() < n
+    assert (idx == rows[:, None]).any(1).all(), "self is among the neighbours"
+    assert (np.sort(idx, 1)[:, 1:] != np.sort(idx, 1)[:, :-1]).all(), "neighbours are distinct"
+    # |q|^2 + |x|^2 - 2qx in f32 with |x|^2 ~ 1e4: absolute error of a few 1e-3
+    self_pos = (idx == rows[:, None]).argmax(1)
+    assert np.abs(dist[np.arange(nq), self_pos]).max() < 5e-2
+    probe = rng.integers(0, n, nq)
+    sample = rng.choice(nq, 4096, replace=False)
+    exact = ((pts[rows[sample]].astype(np.float64) - pts[probe[sample]].astype(np.float64)) ** 2).sum(1)
+    kth = dist[sample].max(1).astype(np.float64)
+    in_set = (idx[sample] == probe[sample, None]).any(1)
+    assert (in_set | (exact >= kth - 5e-2)).all(), "a non-neighbour is never closer than the k-th neighbour"
+
+    # UMAP layout step on the full edge list shape
+    ne = n * k
+    loc = S.STen.from_numpy(rng.random((n, 2)), 0, S.F64)
+    a1 = np.repeat(np.arange(n, dtype=np.int64), k)
+    a3 = rng.integers(0, n, ne * 5).astype(np.int64)
+    i1 = S.STen.from_numpy(a1, 0)
+    i2 = S.STen.from_numpy((a1 + 1 + rng.integers(0, n - 1, ne)) % n, 0)             # never a self pair (log 0)
+    b = S.STen.from_numpy(rng.random(ne), 0, S.F64)
+    i3 = S.STen.from_numpy(a3, 0)
+    i4 = S.STen.from_numpy((a3 + 1 + rng.integers(0, n - 1, ne * 5)) % n, 0)
+    grad = S.STen.zeros([n, 2], S.F64, 0)
+    w = (C.c_double * 4)(1.0, 1.0, 1.0, 1.0)
+    o = C.c_void_p()
+    lib.lamp_umap_loss_grad(C.byref(o), grad, loc, i1, i2, b, i3, i4, 0.1, 1, 1.0, w)
+    g = grad.to_numpy()
+    assert np.isfinite(g).all() and np.isfinite(S.STen(o).to_numpy()).all()
+    assert np.abs(g.sum(0)).max() <= 1e-9 * np.abs(g).sum(), "pairwise forces cancel"
