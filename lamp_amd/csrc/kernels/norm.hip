@@ -189,6 +189,76 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// Channel-aligned normalise with the finalize folded in (training mode, maps of >= 64 elements): workgroup (c, slice).
+// Its first wavefront merges the channel's split partials exactly as bn_finalize_kernel does (same order, so every
+// workgroup of the channel gets bitwise the same mean / invstd), slice 0 also writes save_mean / save_invstd and updates the
+// running statistics; then the workgroup normalises its slice of the channel.  One launch less per batch norm, and no
+// cross-workgroup hand-off (the partials are complete at the kernel boundary).
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x, T* __restrict__ y, const acc_t<T>* __restrict__ partial, int nsplit,
+                                                        T* __restrict__ save_mean, T* __restrict__ save_invstd, T* running_mean, T* running_var,
+                                                        double momentum, double eps, const T* __restrict__ w, const T* __restrict__ b, int64_t N,
+                                                        int64_t C, int64_t HW, int nblk, int vec, int relu) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  __shared__ A stat[2];
+  const int64_t c = blockIdx.x;
+  const int slice = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    Welford<A> r{0, 0, 0};
+    for (int s = lane; s < nsplit; s += 64) {
+      const A* p = partial + ((int64_t)s * C + c) * 3;
+      r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
+    }
+    r = wf_wave(r);
+    if (lane == 0) {
+      const A var_biased = r.m2 / r.n;
+      const A invstd = A(1) / (A)sqrt((double)(var_biased + (A)eps));
+      const T m_t = store_as<T>(r.mean), is_t = store_as<T>(invstd);
+      stat[0] = load_as<A>(m_t);                       // the normalisation uses the values as they are saved (rounded to T)
+      stat[1] = load_as<A>(is_t);
+      if (slice == 0) {
+        save_mean[c] = m_t;
+        save_invstd[c] = is_t;
+        if (running_mean) running_mean[c] = store_as<T>((A)((A)momentum * r.mean + (A)(1 - momentum) * load_as<A>(running_mean[c])));
+        if (running_var) {
+          const A unbiased = r.m2 / (r.n - A(1));
+          running_var[c] = store_as<T>((A)((A)momentum * unbiased + (A)(1 - momentum) * load_as<A>(running_var[c])));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const A mu = stat[0];
+  const A scale = stat[1] * (w ? load_as<A>(w[c]) : A(1));
+  const A bb = b ? load_as<A>(b[c]) : A(0);
+  if (vec) {
+    const int64_t vpp = HW / W, total = N * vpp;
+    for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+      const int64_t n = i / vpp, v = i - n * vpp;
+      const int64_t base = (n * C + c) * HW + v * W;
+      Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + base);
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        T o = store_as<T>(bn_affine<A>(load_as<A>(pk.v[k]), mu, scale, bb));
+        if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
+        pk.v[k] = o;
+      }
+      *reinterpret_cast<Vec<T, W>*>(y + base) = pk;
+    }
+  } else {
+    const int64_t total = N * HW;
+    for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+      const int64_t n = i / HW, v = i - n * HW;
+      const int64_t base = (n * C + c) * HW + v;
+      T o = store_as<T>(bn_affine<A>(load_as<A>(x[base]), mu, scale, bb));
+      if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
+      y[base] = o;
+    }
+  }
+}
+
 // ---- batch norm backward -------------------------------------------------------------------------
 // partial[split][c] = (sum dy, sum dy * (x - mean))
 // relu != 0: dy is the gradient of relu(bn(x)); it is masked where the (recomputed, rounded) normalised value is < 0
@@ -330,6 +400,70 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// Channel-aligned dx with the finalize folded in: workgroup (c, slice) sums the channel's split partials in the fixed order of
+// bn_bwd_finalize_kernel, slice 0 writes dweight / dbias, then (do_apply) the workgroup writes its slice of dx.
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                            const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
+                                                            const acc_t<T>* __restrict__ partial, int nsplit, T* dweight, T* dbias,
+                                                            T* __restrict__ dx, int64_t N, int64_t C, int64_t HW, int nblk, double inv_m,
+                                                            int training, int vec, int relu, int do_apply) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  __shared__ A stat[2];
+  const int64_t c = blockIdx.x;
+  const int slice = blockIdx.y;
+  const A is = load_as<A>(invstd[c]);
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    A a = 0, bs = 0;
+    for (int s = lane; s < nsplit; s += 64) { a += partial[((int64_t)s * C + c) * 2]; bs += partial[((int64_t)s * C + c) * 2 + 1]; }
+    a = wave_sum(a); bs = wave_sum(bs);
+    if (lane == 0) {
+      stat[0] = a; stat[1] = bs;
+      if (slice == 0) {
+        if (dweight) dweight[c] = store_as<T>((A)(bs * is));
+        if (dbias) dbias[c] = store_as<T>(a);
+      }
+    }
+  }
+  if (!do_apply) return;
+  __syncthreads();
+  const A wc = w ? load_as<A>(w[c]) : A(1);
+  const A mu = load_as<A>(mean[c]);
+  const A k = training ? stat[1] * is * is * (A)inv_m : A(0);
+  const A gm = training ? stat[0] * (A)inv_m : A(0);
+  const A scale = is * wc, bb = (relu && b) ? load_as<A>(b[c]) : A(0);
+  if (vec) {
+    const int64_t vpp = HW / W, total = N * vpp;
+    for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+      const int64_t n = i / vpp, v = i - n * vpp;
+      const int64_t base = (n * C + c) * HW + v * W;
+      const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + base);
+      const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + base);
+      Vec<T, W> r;
+#pragma unroll
+      for (int q = 0; q < W; q++) {
+        A gg = load_as<A>(g.v[q]);
+        const A xx = load_as<A>(xv.v[q]);
+        if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+        r.v[q] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
+      }
+      *reinterpret_cast<Vec<T, W>*>(dx + base) = r;
+    }
+  } else {
+    const int64_t total = N * HW;
+    for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+      const int64_t n = i / HW, v = i - n * HW;
+      const int64_t base = (n * C + c) * HW + v;
+      A gg = load_as<A>(dy[base]);
+      const A xx = load_as<A>(x[base]);
+      if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+      dx[base] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
+    }
+  }
+}
+
 // ---- layer norm: rows [M, D] ---------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ mean_out,
@@ -462,26 +596,45 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
       const int nsplit = pick_split(blocks, g.N);
       int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
       Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
-      KernelTimer kt("bn_fwd_stats", 0, (double)total * sizeof(T), st);
-      if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-      else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
-      LAMP_LAUNCH_CHECK();
-      hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
-                         mean->ptr<T>(), invstd->ptr<T>(), running_mean ? running_mean->ptr<T>() : (T*)nullptr,
-                         running_var ? running_var->ptr<T>() : (T*)nullptr, momentum, eps);
-      LAMP_LAUNCH_CHECK();
+      T* rm = running_mean ? running_mean->ptr<T>() : (T*)nullptr;
+      T* rv = running_var ? running_var->ptr<T>() : (T*)nullptr;
+      const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
+      const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+      {
+        KernelTimer kt("bn_fwd_stats", 0, (double)total * sizeof(T), st);
+        if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+        else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+        LAMP_LAUNCH_CHECK();
+      }
+      if (!col && total > 0) {
+        // finalize folded into the channel-aligned normalise
+        KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
+        hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), partial->ptr<A>(), nsplit,
+                           mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit, vec, relu);
+        LAMP_LAUNCH_CHECK();
+      } else {
+        hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
+                           mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps);
+        LAMP_LAUNCH_CHECK();
+        if (total > 0) {
+          KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
+          hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(), invstd->ptr<T>(),
+                             wp, bp, total, g.C, g.HW, vec, relu);
+          LAMP_LAUNCH_CHECK();
+        }
+      }
     } else {
       hipLaunchKernelGGL((bn_eval_stats_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st,
                          running_mean ? running_mean->ptr<T>() : (const T*)nullptr, running_var ? running_var->ptr<T>() : (const T*)nullptr,
                          mean->ptr<T>(), invstd->ptr<T>(), g.C, eps);
       LAMP_LAUNCH_CHECK();
-    }
-    if (total > 0) {
-      KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
-      hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(),
-                         invstd->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr, total,
-                         g.C, g.HW, vec, relu);
-      LAMP_LAUNCH_CHECK();
+      if (total > 0) {
+        KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
+        hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(),
+                           invstd->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr, total,
+                           g.C, g.HW, vec, relu);
+        LAMP_LAUNCH_CHECK();
+      }
     }
   });
   if (!training) {
@@ -552,15 +705,29 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
                               relu, invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr);
     }
     LAMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
-                       nsplit, invstd_t->ptr<T>(), dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr);
-    LAMP_LAUNCH_CHECK();
-    if (dx.get() && total > 0) {
+    T* dwp = dw.get() ? dw->ptr<T>() : (T*)nullptr;
+    T* dbp = db.get() ? db->ptr<T>() : (T*)nullptr;
+    const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
+    const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+    if (!col) {
+      // finalize folded into the channel-aligned dx kernel (one slice and no element loop when only dweight / dbias are wanted)
+      const int do_apply = (dx.get() && total > 0) ? 1 : 0;
+      const int nblk = do_apply ? nsplit : 1;
       KernelTimer kt2("bn_bwd_apply", 0, 3.0 * (double)total * sizeof(T), st);
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(),
-                         invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW,
-                         1.0 / (double)(g.N * g.HW), training, vec, relu, bias ? bias->ptr<T>() : (const T*)nullptr);
+      hipLaunchKernelGGL((bn_bwd_apply2_kernel<T>), dim3((unsigned)g.C, nblk), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), invstd_t->ptr<T>(),
+                         wp, bp, partial->ptr<A>(), nsplit, dwp, dbp, do_apply ? dx->ptr<T>() : (T*)nullptr, g.N, g.C, g.HW, nblk,
+                         1.0 / (double)(g.N * g.HW), training, vec, relu, do_apply);
       LAMP_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
+                         nsplit, invstd_t->ptr<T>(), dwp, dbp);
+      LAMP_LAUNCH_CHECK();
+      if (dx.get() && total > 0) {
+        KernelTimer kt2("bn_bwd_apply", 0, 3.0 * (double)total * sizeof(T), st);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(),
+                           invstd_t->ptr<T>(), wp, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW, 1.0 / (double)(g.N * g.HW), training, vec, relu, bp);
+        LAMP_LAUNCH_CHECK();
+      }
     }
   });
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
