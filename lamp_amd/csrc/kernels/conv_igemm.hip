@@ -566,8 +566,8 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
     const int CIP = ntile * WG_CI;
-    static const int wgs_per_cu = [] { const char* e = getenv("LAMP_WGRAD_WGS_PER_CU"); return e ? std::max(1, atoi(e)) : 2; }();
-    int target = std::max(1, (num_cus() * wgs_per_cu) / ntile);      // ~2 workgroups per CU
+    static const int wgs_per_cu = [] { const char* e = getenv("LAMP_WGRAD_WGS_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();
+    int target = std::max(1, (num_cus() * wgs_per_cu) / ntile);      // one workgroup per CU: half the partial-sum traffic of two, same speed
     int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
     if (ips < 8 && g.N >= 8) ips = 8;
     const int nsplit = (int)((g.N + ips - 1) / ips);

@@ -42,21 +42,27 @@ struct NcvGeom {
 
 constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligned rows for the vector copy
 
-// wpk[kstep][lane][8]: lane = co + 16*g, pair (c, r) = 4*kstep + g, element j = filter column (zero for j >= kw)
-//   fprop: W[co][c][r][j]            dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j]
-__global__ void ncv_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int kh, int kw, int nk, int dgrad) {
-  const int total = nk * 64 * 8;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int j = e & 7, lane = (e >> 3) & 63, ks = e >> 9;
-    const int co = lane & 15, pair = ks * 4 + (lane >> 4);
-    const int c = pair / kh, r = pair - c * kh;
-    bf16_t v; v.bits = 0;
-    if (j < kw) {
-      if (!dgrad) { if (co < Cout && c < Cin) v = w[((co * Cin + c) * kh + r) * kw + j]; }
-      else { if (co < Cin && c < Cout) v = w[((c * Cin + co) * kh + (kh - 1 - r)) * kw + (kw - 1 - j)]; }
+// Weight fragments are gathered by every lane straight from the filter tensor (a few hundred elements, L2 resident): no pack
+// kernel, no packed copy.  Fragment of k-step ks for lane = co + 16*g: pair (c, r) = 4*ks + g, element j = filter column
+// (zero for j >= kw);   fprop: W[co][c][r][j]      dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j]
+struct NcvW {
+  const bf16_t* w;
+  int Cout, Cin, kh, kw, dgrad;
+};
+__device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
+  const int co = lane & 15, pair = ks * 4 + (lane >> 4);
+  const int c = pair / wq.kh, r = pair - c * wq.kh;
+  nv_s8 v;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    unsigned short e = 0;
+    if (j < wq.kw) {
+      if (!wq.dgrad) { if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + j].bits; }
+      else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - j)].bits; }
     }
-    wpk[e] = v;
+    v[j] = (short)e;
   }
+  return __builtin_bit_cast(nv_bf8, v);
 }
 
 __device__ __forceinline__ void ncv_stage(unsigned short* xs, const bf16_t* __restrict__ sp, const NcvGeom& q, int tid, int nthreads) {
@@ -77,7 +83,7 @@ __device__ __forceinline__ void ncv_stage(unsigned short* xs, const bf16_t* __re
 }
 
 template <int NK>
-__global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk, const bf16_t* __restrict__ bias,
+__global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__ src, NcvW wq, const bf16_t* __restrict__ bias,
                                                       bf16_t* __restrict__ dst, NcvGeom q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
   int koff[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ks++) {
-    wfr[ks] = __builtin_bit_cast(nv_bf8, *reinterpret_cast<const nv_s8*>(wpk + (ks * 64 + lane) * 8));
+    wfr[ks] = ncv_weight_frag(wq, ks, lane);
     int pair = ks * 4 + (lane >> 4);
     if (pair >= q.C * q.kh) pair = 0;                    // padded k: weights are zero, any valid address will do
     const int c = pair / q.kh, r = pair - c * q.kh;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
 // pixels per accumulator register, stored as one 16- or 8-byte write.
 //   PH0 = (window origin wx) & 7.
 template <int NK, int SW, int PH0>
-__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wpk, const bf16_t* __restrict__ bias,
+__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, NcvW wq, const bf16_t* __restrict__ bias,
                                                        bf16_t* __restrict__ dst, NcvGeom q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   int koff[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ks++) {
-    wfr[ks] = __builtin_bit_cast(nv_bf8, *reinterpret_cast<const nv_s8*>(wpk + (ks * 64 + lane) * 8));
+    wfr[ks] = ncv_weight_frag(wq, ks, lane);
     int pair = ks * 4 + (lane >> 4);
     if (pair >= q.C * q.kh) pair = 0;
     const int c = pair / q.kh, r = pair - c * q.kh;
@@ -341,8 +347,8 @@ static bool ncv_common(const ConvGeom& g, int dtype) {
 }
 
 template <int NK>
-static void ncv_launch(const bf16_t* src, const bf16_t* wpk, const bf16_t* bias, bf16_t* dst, const NcvGeom& q, int blocks, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((ncv_fwd_kernel<NK>), dim3(blocks), dim3(256), lds, st, src, wpk, bias, dst, q);
+static void ncv_launch(const bf16_t* src, const NcvW& wq, const bf16_t* bias, bf16_t* dst, const NcvGeom& q, int blocks, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((ncv_fwd_kernel<NK>), dim3(blocks), dim3(256), lds, st, src, wq, bias, dst, q);
 }
 
 static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
@@ -382,12 +388,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   if (!NK) return false;
   const size_t lds = (size_t)q.C * q.Hs * q.Ws * 2;
   if (lds > 64 * 1024) return false;
-  int64_t ps[1] = {(int64_t)NK * 64 * 8};
-  Hold wpk(new_tensor(ps, 1, kBF16, in->device()));
-  hipLaunchKernelGGL(ncv_pack_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wpk->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh,
-                     g.kw, NK, dgrad ? 1 : 0);
-  LAMP_LAUNCH_CHECK();
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
+  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0};
+  static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2 (each workgroup gathers its weight fragments once)
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
   const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
   KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
   const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
@@ -395,13 +398,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     const int nsuper = q.Ho / (16 / ncg);
     const int threads = 64 * std::min(4, nsuper);
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
-    if (NK2 != NK) {   // repack with the padded k-step count
-      int64_t ps2[1] = {(int64_t)NK2 * 64 * 8};
-      wpk = Hold(new_tensor(ps2, 1, kBF16, in->device()));
-      hipLaunchKernelGGL(ncv_pack_kernel, dim3(grid_for(ps2[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wpk->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin,
-                         g.kh, g.kw, NK2, dgrad ? 1 : 0);
-    }
-#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q)
+#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q)
 #define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
 #define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
     switch (NK2) {
@@ -417,12 +414,12 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     return true;
   }
   switch (NK) {
-    case 1: ncv_launch<1>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 4: ncv_launch<4>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 5: ncv_launch<5>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    default: ncv_launch<12>(in->ptr<bf16_t>(), wpk->ptr<bf16_t>(), bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 1: ncv_launch<1>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 2: ncv_launch<2>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 4: ncv_launch<4>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 5: ncv_launch<5>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    default: ncv_launch<12>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
   }
   LAMP_LAUNCH_CHECK();
   return true;
