@@ -324,6 +324,149 @@ __global__ __launch_bounds__(256) void ncv_wgrad_kernel(const bf16_t* __restrict
   }
 }
 
+// Aligned-read wgrad.  The MFMA columns of one tile are 16 (ci, r) pairs at ONE filter column s, so the window shift s - pw is
+// the same for the whole wave: per (32-pixel chunk, pair tile) a lane reads two or three ALIGNED 16-byte segments of its image
+// row and cuts the KW shifted fragments out of them with compile-time funnel shifts (an unaligned ds_read_b128 costs 11 aligned
+// ones, see ncv_fwd2_kernel).  Stride 2: even / odd column planes, filter column s reads plane (s - pw) & 1 at offset
+// (s - pw) >> 1 in {-1, 0} (KW <= 3).  acc[pair tile][s] holds dW[co][(ci, r)][s].
+constexpr int NCV_OFFA = 8;   // column origin of the staged rows (both strides): 16-byte aligned segments
+template <int KW, int PW, int SW, int NPT>
+__global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial, NcvWGeom q,
+                                                         int images_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int HoWo = q.Ho * q.Wo;
+  const int ximg = q.Cin * q.Hs * q.Ws * (SW == 2 ? 2 : 1);
+  unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* ds = xs + q.IG * ximg;
+  constexpr int NCOLT = NPT * KW * 16;                               // accumulator columns per output channel
+  float* red = reinterpret_cast<float*>(ds + q.IG * 16 * HoWo);      // [4 waves][16][NCOLT]
+  {
+    const int tot = q.IG * (ximg + 16 * HoWo);
+    for (int o = tid * 8; o < tot; o += 256 * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);
+  }
+  // per-lane row offset (bytes) of pair tile pt: pair = pt*16 + (lane & 15) -> (ci, r)
+  const int npairs = q.Cin * q.kh;
+  int poff[NPT];
+#pragma unroll
+  for (int pt = 0; pt < NPT; pt++) {
+    int pair = pt * 16 + (lane & 15);
+    if (pair >= npairs) pair = 0;                                    // padded columns: computed, never written
+    const int ci = pair / q.kh, r = pair - ci * q.kh;
+    poff[pt] = (SW == 1 ? (ci * q.Hs + r) * q.Ws : (ci * q.Hs + r) * 2 * q.Ws) * 2;
+  }
+  nv_f4 acc[NPT][KW];
+#pragma unroll
+  for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+    for (int s = 0; s < KW; s++) acc[pt][s] = nv_f4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min<int64_t>(n0 + images_per_block, q.N);
+  const int chunks_per_img = HoWo >> 5;
+  for (int64_t nb = n0; nb < n1; nb += q.IG) {
+    const int ig = (int)min<int64_t>(q.IG, n1 - nb);
+    __syncthreads();
+    for (int im = 0; im < ig; im++) {
+      const bf16_t* xp = x + (nb + im) * q.Cin * q.H * q.W;
+      unsigned short* xi = xs + im * ximg;
+      const int rc = q.W >> 3, total = q.Cin * q.H * rc;
+      for (int i = tid; i < total; i += 256) {
+        const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
+        const uint4 v = *reinterpret_cast<const uint4*>(xp + (c * q.H + a) * q.W + b * 8);
+        if (SW == 1) {
+          *reinterpret_cast<uint4*>(xi + (c * q.Hs + q.ph + a) * q.Ws + NCV_OFFA + b * 8) = v;
+        } else {
+          uint2 ev, od;
+          ev.x = (v.x & 0xffffu) | (v.y << 16); ev.y = (v.z & 0xffffu) | (v.w << 16);
+          od.x = (v.x >> 16) | (v.y & 0xffff0000u); od.y = (v.z >> 16) | (v.w & 0xffff0000u);
+          unsigned short* row = xi + ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFFA + b * 4;
+          *reinterpret_cast<uint2*>(row) = ev;
+          *reinterpret_cast<uint2*>(row + q.Ws) = od;
+        }
+      }
+      const bf16_t* dp = dy + (nb + im) * q.Cout * HoWo;
+      unsigned short* di = ds + im * 16 * HoWo;
+      const int dtot = q.Cout * HoWo >> 3;
+      for (int i = tid; i < dtot; i += 256) *reinterpret_cast<uint4*>(di + i * 8) = *reinterpret_cast<const uint4*>(dp + i * 8);
+    }
+    __syncthreads();
+    const int nchunks = ig * chunks_per_img;
+    for (int ch = wid; ch < nchunks; ch += 4) {
+      const int pg = ch * 32 + (lane >> 4) * 8;
+      const int im = pg / HoWo, pp = pg - im * HoWo;
+      const int ho = pp / q.Wo, wo0 = pp - ho * q.Wo;
+      const nv_s8 a = *reinterpret_cast<const nv_s8*>(ds + (im * 16 + (lane & 15)) * HoWo + pp);
+      const nv_bf8 af = __builtin_bit_cast(nv_bf8, a);
+      // byte address of element column (wo0 + NCV_OFFA - 8) of this lane's group row: segment -1
+      const char* xb = reinterpret_cast<const char*>(xs + im * ximg) +
+                       (SW == 1 ? (ho * q.Ws + wo0 + NCV_OFFA - 8) * 2 : ((ho * 2) * 2 * q.Ws + wo0 + NCV_OFFA - 8) * 2);
+#pragma unroll
+      for (int pt = 0; pt < NPT; pt++) {
+        const char* rowp = xb + poff[pt];
+        if (SW == 1) {
+          // 24 elements around the aligned window: [seg-1 | seg0 | seg+1]
+          constexpr bool need_m = PW > 0, need_p = (KW - 1 - PW) > 0;
+          unsigned int sg[13];
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          const uint4 v0 = need_m ? *reinterpret_cast<const uint4*>(rowp) : z;
+          const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + 16);
+          const uint4 v2 = need_p ? *reinterpret_cast<const uint4*>(rowp + 32) : z;
+          sg[0] = v0.x; sg[1] = v0.y; sg[2] = v0.z; sg[3] = v0.w; sg[4] = v1.x; sg[5] = v1.y; sg[6] = v1.z; sg[7] = v1.w;
+          sg[8] = v2.x; sg[9] = v2.y; sg[10] = v2.z; sg[11] = v2.w; sg[12] = 0;
+#pragma unroll
+          for (int s = 0; s < KW; s++) {
+            const int o = 8 + s - PW;                              // compile-time element offset of the window
+            const int dq = o >> 1;
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            u4v f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = (o & 1) ? __builtin_amdgcn_alignbit(sg[dq + j + 1], sg[dq + j], 16) : sg[dq + j];
+            acc[pt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(nv_bf8, f), acc[pt][s], 0, 0, 0);
+          }
+        } else {
+          // per parity plane: [seg-1 | seg0]; filter column s -> plane (s - PW) & 1, element offset 8 + ((s - PW) >> 1)
+          unsigned int sg[2][9];
+#pragma unroll
+          for (int par = 0; par < 2; par++) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(rowp + par * q.Ws * 2);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + par * q.Ws * 2 + 16);
+            sg[par][0] = v0.x; sg[par][1] = v0.y; sg[par][2] = v0.z; sg[par][3] = v0.w;
+            sg[par][4] = v1.x; sg[par][5] = v1.y; sg[par][6] = v1.z; sg[par][7] = v1.w; sg[par][8] = 0;
+          }
+#pragma unroll
+          for (int s = 0; s < KW; s++) {
+            const int t = s - PW, par = t & 1, half = (t - par) >> 1;   // compile time
+            const int o = 8 + half, dq = o >> 1;
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            u4v f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[j] = (o & 1) ? __builtin_amdgcn_alignbit(sg[par][dq + j + 1], sg[par][dq + j], 16) : sg[par][dq + j];
+            acc[pt][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(nv_bf8, f), acc[pt][s], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D: column = pair within the tile, rows = 4 output channels; combine the 4 waves in a fixed order
+#pragma unroll
+  for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+    for (int s = 0; s < KW; s++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) red[(wid * 16 + (lane >> 4) * 4 + rr) * NCOLT + (pt * KW + s) * 16 + (lane & 15)] = acc[pt][s][rr];
+  __syncthreads();
+  const int O = q.Cout * q.ncol;
+  for (int i = tid; i < O; i += 256) {
+    const int co = i / q.ncol, cidx = i - co * q.ncol;              // cidx = (ci*kh + r)*kw + s
+    const int pair = cidx / KW, s = cidx - pair * KW;
+    const int col = ((pair >> 4) * KW + s) * 16 + (pair & 15);
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) a += red[(w * 16 + co) * NCOLT + col];
+    partial[(int64_t)blockIdx.x * O + i] = a;
+  }
+}
+
 __global__ __launch_bounds__(256) void ncv_wgrad_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int O, int nblocks) {
   const int lane = threadIdx.x & 63;
   const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
@@ -455,6 +598,53 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
   }
   const int HoWo = (int)(g.Ho * g.Wo);
   q.IG = std::max(1, 256 / HoWo);                                    // >= 8 chunks of 32 pixels per round
+  // aligned-read kernel for the filter shapes of the CIFAR ResNet
+  const int npt = (int)((g.Cin * g.kh + 15) / 16);
+  const bool aligned = g.kh == g.kw && npt <= 3 &&
+                       ((g.kw == 5 && g.pw == 2 && SW == 1) || (g.kw == 3 && g.pw == 1) || (g.kw == 1 && g.pw == 0));
+  if (aligned) {
+    if (SW == 1) q.Ws = round_up(NCV_OFFA + std::max((int)g.W, (int)g.Wo + 8) + 8, 8);
+    else q.Ws = round_up(NCV_OFFA + std::max((int)g.W / 2, (int)g.Wo) + 8, 8);
+    const int ximg2 = q.Cin * q.Hs * q.Ws * (SW == 2 ? 2 : 1);
+    const int ncolt = npt * g.kw * 16;
+    const size_t lds2 = (size_t)q.IG * (ximg2 + 16 * HoWo) * 2 + (size_t)4 * 16 * ncolt * 4;
+    if (lds2 <= 150 * 1024) {
+      const int O = q.Cout * q.ncol;
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds2));
+      const int64_t rounds = (g.N + q.IG - 1) / q.IG;
+      const int nb = (int)std::min<int64_t>(rounds, (int64_t)num_cus() * per_cu);
+      const int ipb = (int)((rounds + nb - 1) / nb) * q.IG;
+      const int nblocks = (int)((g.N + ipb - 1) / ipb);
+      int64_t ps[1] = {(int64_t)nblocks * O};
+      Hold partial(new_tensor(ps, 1, kF32, dy->device()));
+      {
+        KernelTimer kt("conv_wgrad_narrow", conv_flops(g), conv_bytes(g, 2), st);
+        const bf16_t* dp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
+#define NCV_WG2(KWv, PWv, SWv, NPTv)                                                                                                   \
+  do {                                                                                                                                 \
+    static bool attr = false;                                                                                                          \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>), dim3(nblocks), dim3(256), lds2, st, dp, xp, pp, q, ipb);               \
+  } while (0)
+#define NCV_WG2_NPT(KWv, PWv, SWv) do { if (npt == 1) NCV_WG2(KWv, PWv, SWv, 1); else if (npt == 2) NCV_WG2(KWv, PWv, SWv, 2); else NCV_WG2(KWv, PWv, SWv, 3); } while (0)
+        if (g.kw == 5) NCV_WG2_NPT(5, 2, 1);
+        else if (g.kw == 3 && SW == 1) NCV_WG2_NPT(3, 1, 1);
+        else if (g.kw == 3) NCV_WG2_NPT(3, 1, 2);
+        else if (SW == 1) NCV_WG2_NPT(1, 0, 1);
+        else NCV_WG2_NPT(1, 0, 2);
+#undef NCV_WG2_NPT
+#undef NCV_WG2
+        LAMP_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL(ncv_wgrad_reduce_kernel, dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), O,
+                         nblocks);
+      LAMP_LAUNCH_CHECK();
+      return true;
+    }
+    // does not fit: restore the geometry of the generic kernel
+    if (SW == 1) q.Ws = round_up(std::max(NCV_LEFT + (int)g.W, (int)g.Wo - 1 + g.kw - 1 - g.pw + NCV_LEFT + 1), 8);
+    else { const int half_max = (g.kw - 1 - g.pw) >> 1; q.Ws = round_up(std::max((int)g.W / 2, (int)g.Wo + half_max) + NCV_OFF2 + 1, 8); }
+  }
   const int nt_real = (q.ncol + 15) / 16;
   static const int nt_opts[] = {1, 2, 4, 5, 9};
   int NT = 0;
