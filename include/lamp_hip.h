@@ -361,6 +361,18 @@ int lamp_native_batch_norm_relu_backward(lamp_tensor* out3[3] /* dx, dweight, db
                                          const lamp_tensor* running_mean_or_null, const lamp_tensor* running_var_or_null,
                                          const lamp_tensor* save_mean_or_null, const lamp_tensor* save_invstd_or_null,
                                          int training, double eps, const uint8_t mask[3]);
+/* relu(native_batch_norm(x) + addend): the tail of lamp's residual block (cnn.scala:11-21,36-46: BatchNorm2D of the right
+ * branch, Residual's add, Fun(relu)), each intermediate rounded as the three separate ops round it.  Training mode, maps of
+ * >= 64 elements.  The backward returns the four gradients (mask[3] = d addend, which is the relu-masked grad_out). */
+int lamp_native_batch_norm_add_relu(lamp_tensor* out3[3] /* y, save_mean, save_invstd */, const lamp_tensor* x,
+                                    const lamp_tensor* addend, const lamp_tensor* weight_or_null, const lamp_tensor* bias_or_null,
+                                    lamp_tensor* running_mean_or_null, lamp_tensor* running_var_or_null, int training,
+                                    double momentum, double eps);
+int lamp_native_batch_norm_add_relu_backward(lamp_tensor* out4[4] /* dx, dweight, dbias, daddend */, const lamp_tensor* grad_out,
+                                             const lamp_tensor* x, const lamp_tensor* addend, const lamp_tensor* weight_or_null,
+                                             const lamp_tensor* bias_or_null, const lamp_tensor* running_mean_or_null,
+                                             const lamp_tensor* running_var_or_null, const lamp_tensor* save_mean_or_null,
+                                             const lamp_tensor* save_invstd_or_null, int training, double eps, const uint8_t mask[4]);
 int lamp_native_layer_norm(lamp_tensor* out3[3] /* y, mean, rstd */, const lamp_tensor* x,
                            const int64_t* normalized_shape, int nnorm, const lamp_tensor* weight_or_null,
                            const lamp_tensor* bias_or_null, double eps);

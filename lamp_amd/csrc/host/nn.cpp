@@ -56,6 +56,27 @@ bool BatchNorm::can_fuse_relu(const Var& x) const { return two_d && F::batch_nor
 Var BatchNorm::forward_relu(const Var& x) {
   return F::batch_norm_relu_2d(x, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
 }
+bool BatchNorm::can_fuse_add_relu(const Var& x) const { return training && can_fuse_relu(x); }
+Var BatchNorm::forward_add_relu(const Var& x, const Var& addend) {
+  return F::batch_norm_add_relu_2d(x, addend, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
+}
+Var Residual::forward_relu(const Var& x) {
+  auto* seq = dynamic_cast<Sequential*>(right.get());
+  BatchNorm* bn = (seq && !seq->mods.empty()) ? dynamic_cast<BatchNorm*>(seq->mods.back().get()) : nullptr;
+  if (bn) {
+    // right branch up to (not including) its last batch norm, with the usual BatchNorm -> relu rewrite inside
+    Sequential head(std::vector<Mod>(seq->mods.begin(), seq->mods.end() - 1));
+    Var v = head.forward(x);
+    if (bn->can_fuse_add_relu(v)) {
+      Var l = left ? left->forward(x) : x;
+      if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);
+      return F::relu(F::add(bn->forward(v), l));
+    }
+    Var l = left ? left->forward(x) : x;
+    return F::relu(F::add(bn->forward(v), l));
+  }
+  return F::relu(forward(x));
+}
 // The reference's Sequential is a plain fold (nn/Sequential.scala).  The one rewrite done here: BatchNorm2D directly followed by
 // Fun(relu) runs as the fused op (same values, three elementwise passes fewer).
 Var Sequential::forward(const Var& x) {
@@ -66,6 +87,12 @@ Var Sequential::forward(const Var& x) {
       auto* fn = dynamic_cast<Fun*>(mods[i + 1].get());
       if (bn && fn && fn->tag == "relu" && bn->can_fuse_relu(v)) {
         v = bn->forward_relu(v);
+        i++;
+        continue;
+      }
+      auto* res = dynamic_cast<Residual*>(mods[i].get());
+      if (res && fn && fn->tag == "relu") {
+        v = res->forward_relu(v);
         i++;
         continue;
       }

@@ -61,6 +61,8 @@ struct BatchNorm : Module {     // nn/BatchNorm.scala:7-88 and nn/BatchNorm2D.sc
   Var forward(const Var& x) override;
   bool can_fuse_relu(const Var& x) const;       // BatchNorm2D on maps of >= 64 elements
   Var forward_relu(const Var& x);                // relu(forward(x)) as one fused op, identical values
+  bool can_fuse_add_relu(const Var& x) const;   // additionally: training mode
+  Var forward_add_relu(const Var& x, const Var& addend);   // relu(forward(x) + addend) as one fused op
   void set_training(bool t) override { training = t; }
 };
 struct LayerNorm : Module {     // nn/LayerNorm.scala:8-57
@@ -101,6 +103,9 @@ struct Residual : Module {      // cnn.scala:11-21
     Var l = left ? left->forward(x) : x;
     return F::add(r, l);
   }
+  // relu(forward(x)); when the right branch is a Sequential ending in a fusable BatchNorm2D the add and the relu run inside
+  // its normalise kernel (identical values)
+  Var forward_relu(const Var& x);
   void set_training(bool t) override { right->set_training(t); if (left) left->set_training(t); }
 };
 

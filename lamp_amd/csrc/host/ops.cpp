@@ -603,6 +603,49 @@ Var batch_norm_relu_2d(const Var& input, const Var& weight, const Var& bias, con
   LAMP_CHECK(input->value.ndim() >= 3, "Expected 3D or 4D tensor");
   return batch_norm_impl("BatchNorm2DRelu", input, input->value, weight, bias, runningMean, runningVar, training, momentum, eps, true, true);
 }
+// relu(batch_norm_2d(x) + addend) as ONE op: the tail of lamp's residual block (cnn.scala:11-21: `right(x) + left(x)` where
+// right ends in BatchNorm2D, followed by Fun(relu) in Cnn.residual, cnn.scala:36-46).  Values are those of the three ops
+// (every intermediate is rounded as they round it); the backward hands the relu-masked gradient to the addend and the batch
+// norm gradients to x / weight / bias from one fused pass.
+Var batch_norm_add_relu_2d(const Var& input, const Var& addend, const Var& weight, const Var& bias, const Ten& runningMean,
+                           const Ten& runningVar, bool training, double momentum, double eps) {
+  auto op = new_op("BatchNorm2DAddRelu");
+  const Ten x = input->value, av = addend->value, wv = weight->value, bv = bias->value;
+  const std::vector<int64_t> expected = {x.size(1)};
+  LAMP_CHECK(weight->shape() == expected && bias->shape() == expected, "batch norm weight / bias have the wrong shape");
+  LAMP_CHECK(runningMean.shape() == expected && runningVar.shape() == expected, "running statistics have the wrong shape");
+  lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
+  HCALL(lamp_native_batch_norm_add_relu(o3, x.h(), av.h(), wv.h(), bv.h(), runningMean.h(), runningVar.h(), training, momentum, eps));
+  Ten out(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]);
+  struct Cache { Ten g[4]; Ten p; };                       // dx, dweight, dbias, daddend of one backward call, and the p they belong to
+  auto cache = std::make_shared<Cache>();
+  const bool want[4] = {input->needsGrad(), weight->needsGrad(), bias->needsGrad(), addend->needsGrad()};
+  auto back = [=](int which) {
+    return [=](const Ten& p, Variable& o) {
+      if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
+        // first closure of this backward pass: one call for every gradient that will be asked for
+        uint8_t mask[4] = {(uint8_t)want[0], (uint8_t)want[1], (uint8_t)want[2], (uint8_t)want[3]};
+        mask[which] = 1;
+        lamp_tensor* r4[4] = {nullptr, nullptr, nullptr, nullptr};
+        HCALL(lamp_native_batch_norm_add_relu_backward(r4, p.h(), x.h(), av.h(), wv.h(), bv.h(), runningMean.h(), runningVar.h(), saveMean.h(),
+                                                       saveInvstd.h(), training, eps, mask));
+        for (int i = 0; i < 4; i++) cache->g[i] = r4[i] ? Ten(r4[i]) : Ten();
+        cache->p = p;
+      }
+      Ten g = cache->g[which];
+      cache->g[which] = Ten();
+      bool any = false;
+      for (int i = 0; i < 4; i++) any = any || cache->g[i].defined();
+      if (!any) cache->p = Ten();
+      o.accumulate(ops::reshape(g, o.shape()), true);
+    };
+  };
+  op->params.push_back({input, back(0)});
+  op->params.push_back({weight, back(1)});
+  op->params.push_back({bias, back(2)});
+  op->params.push_back({addend, back(3)});
+  return make_result(op, out);
+}
 Var layer_norm(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& normalizedShape, double eps) {
   auto op = new_op("LayerNormOp");
   lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};

@@ -54,6 +54,8 @@ Var batch_norm_2d(const Var& input, const Var& weight, const Var& bias, const Te
 bool batch_norm_relu_2d_supported(const Var& input);
 Var batch_norm_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,
                        double momentum, double eps);
+Var batch_norm_add_relu_2d(const Var& input, const Var& addend, const Var& weight, const Var& bias, const Ten& runningMean,
+                           const Ten& runningVar, bool training, double momentum, double eps);
 Var layer_norm(const Var& input, const Var& weight /*nullable*/, const Var& bias /*nullable*/, const std::vector<int64_t>& normalizedShape,
                double eps);
 Var embedding(const Var& input, const Var& weight);

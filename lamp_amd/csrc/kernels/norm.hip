@@ -198,7 +198,7 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x, T* __restrict__ y, const acc_t<T>* __restrict__ partial, int nsplit,
                                                         T* __restrict__ save_mean, T* __restrict__ save_invstd, T* running_mean, T* running_var,
                                                         double momentum, double eps, const T* __restrict__ w, const T* __restrict__ b, int64_t N,
-                                                        int64_t C, int64_t HW, int nblk, int vec, int relu) {
+                                                        int64_t C, int64_t HW, int nblk, int vec, int relu, const T* __restrict__ addend) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A stat[2];
@@ -239,9 +239,12 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
       const int64_t n = i / vpp, v = i - n * vpp;
       const int64_t base = (n * C + c) * HW + v * W;
       Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + base);
+      Vec<T, W> ad;
+      if (addend) ad = *reinterpret_cast<const Vec<T, W>*>(addend + base);
 #pragma unroll
       for (int k = 0; k < W; k++) {
         T o = store_as<T>(bn_affine<A>(load_as<A>(pk.v[k]), mu, scale, bb));
+        if (addend) o = store_as<T>((A)(load_as<A>(o) + load_as<A>(ad.v[k])));     // the residual add, rounded as the add kernel rounds
         if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
         pk.v[k] = o;
       }
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
       const int64_t n = i / HW, v = i - n * HW;
       const int64_t base = (n * C + c) * HW + v;
       T o = store_as<T>(bn_affine<A>(load_as<A>(x[base]), mu, scale, bb));
+      if (addend) o = store_as<T>((A)(load_as<A>(o) + load_as<A>(addend[base])));
       if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
       y[base] = o;
     }
@@ -265,7 +269,8 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
                                                             acc_t<T>* __restrict__ partial, int64_t N, int64_t C, int64_t HW, int nsplit, int vec,
-                                                            int relu, const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b) {
+                                                            int relu, const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
+                                                            const T* __restrict__ addend) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A sm[2][4];
@@ -282,11 +287,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const int64_t base = (n * C + c) * HW + v * W;
       const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + base);
       const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + base);
+      Vec<T, W> ad;
+      if (addend) ad = *reinterpret_cast<const Vec<T, W>*>(addend + base);
 #pragma unroll
       for (int k = 0; k < W; k++) {
         A gg = load_as<A>(g.v[k]);
         const A xx = load_as<A>(xv.v[k]);
-        if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+        if (relu) {
+          T pre = store_as<T>(bn_affine<A>(xx, mu, scale, bb));
+          if (addend) pre = store_as<T>((A)(load_as<A>(pre) + load_as<A>(ad.v[k])));
+          if (load_as<A>(pre) < A(0)) gg = A(0);
+        }
         s1 += gg; s2 += gg * (xx - mu);
       }
     }
@@ -297,7 +308,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const int64_t base = (n * C + c) * HW + v;
       A gg = load_as<A>(dy[base]);
       const A xx = load_as<A>(x[base]);
-      if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+      if (relu) {
+        T pre = store_as<T>(bn_affine<A>(xx, mu, scale, bb));
+        if (addend) pre = store_as<T>((A)(load_as<A>(pre) + load_as<A>(addend[base])));
+        if (load_as<A>(pre) < A(0)) gg = A(0);
+      }
       s1 += gg; s2 += gg * (xx - mu);
     }
   }
@@ -407,7 +422,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
                                                             const T* __restrict__ invstd, const T* __restrict__ w, const T* __restrict__ b,
                                                             const acc_t<T>* __restrict__ partial, int nsplit, T* dweight, T* dbias,
                                                             T* __restrict__ dx, int64_t N, int64_t C, int64_t HW, int nblk, double inv_m,
-                                                            int training, int vec, int relu, int do_apply) {
+                                                            int training, int vec, int relu, int do_apply, const T* __restrict__ addend,
+                                                            T* __restrict__ dadd) {
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A stat[2];
@@ -441,15 +457,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
       const int64_t base = (n * C + c) * HW + v * W;
       const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + base);
       const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + base);
-      Vec<T, W> r;
+      Vec<T, W> ad, r, gm_out;
+      if (addend) ad = *reinterpret_cast<const Vec<T, W>*>(addend + base);
 #pragma unroll
       for (int q = 0; q < W; q++) {
         A gg = load_as<A>(g.v[q]);
         const A xx = load_as<A>(xv.v[q]);
-        if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
+        if (relu) {
+          T pre = store_as<T>(bn_affine<A>(xx, mu, scale, bb));
+          if (addend) pre = store_as<T>((A)(load_as<A>(pre) + load_as<A>(ad.v[q])));
+          if (load_as<A>(pre) < A(0)) gg = A(0);
+        }
+        gm_out.v[q] = store_as<T>(gg);                      // dy or 0: exact
         r.v[q] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
       }
-      *reinterpret_cast<Vec<T, W>*>(dx + base) = r;
+      if (dx) *reinterpret_cast<Vec<T, W>*>(dx + base) = r;
+      if (dadd) *reinterpret_cast<Vec<T, W>*>(dadd + base) = gm_out;
     }
   } else {
     const int64_t total = N * HW;
@@ -458,8 +481,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
       const int64_t base = (n * C + c) * HW + v;
       A gg = load_as<A>(dy[base]);
       const A xx = load_as<A>(x[base]);
-      if (relu && load_as<A>(store_as<T>(bn_affine<A>(xx, mu, scale, bb))) < A(0)) gg = A(0);
-      dx[base] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
+      if (relu) {
+        T pre = store_as<T>(bn_affine<A>(xx, mu, scale, bb));
+        if (addend) pre = store_as<T>((A)(load_as<A>(pre) + load_as<A>(addend[base])));
+        if (load_as<A>(pre) < A(0)) gg = A(0);
+      }
+      if (dx) dx[base] = store_as<T>(training ? (A)((gg - gm - (xx - mu) * k) * is * wc) : (A)(gg * is * wc));
+      if (dadd) dadd[base] = store_as<T>(gg);
     }
   }
 }
@@ -574,10 +602,18 @@ using namespace lamp;
 extern "C" {
 
 static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
-                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu) {
+                           lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu,
+                           const lamp_tensor* addend = nullptr) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input");
   BnGeom g = bn_geom(x);
+  Hold addc;
+  if (addend) {
+    check_device_tensor(addend, "addend");
+    LAMP_CHECK(relu && training && g.HW >= 64, "the fused batch-norm-add-relu exists in training mode for maps of at least 64 elements");
+    LAMP_CHECK(addend->shape() == x->shape() && addend->dtype == x->dtype, "addend " << addend->describe() << " does not match input " << x->describe());
+    addc = Hold(contiguous(addend));
+  }
   check_cvec(weight, g.C, x->dtype, "weight"); check_cvec(bias, g.C, x->dtype, "bias");
   check_cvec(running_mean, g.C, x->dtype, "running_mean"); check_cvec(running_var, g.C, x->dtype, "running_var");
   Hold xc(contiguous(x));
@@ -610,7 +646,8 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
         // finalize folded into the channel-aligned normalise
         KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
         hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), partial->ptr<A>(), nsplit,
-                           mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit, vec, relu);
+                           mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit,
+                           (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr);
         LAMP_LAUNCH_CHECK();
       } else {
         hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
@@ -655,7 +692,7 @@ int lamp_native_batch_norm_relu(lamp_tensor* out3[3], const lamp_tensor* x, cons
 static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
                             const lamp_tensor* bias, const lamp_tensor* running_mean, const lamp_tensor* running_var,
                             const lamp_tensor* save_mean, const lamp_tensor* save_invstd, int training, double eps, const uint8_t mask[3],
-                            int relu) {
+                            int relu, const lamp_tensor* addend = nullptr, lamp_tensor** daddend_out = nullptr) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out");
   LAMP_CHECK(grad_out->shape() == x->shape() && grad_out->dtype == x->dtype, "grad_out " << grad_out->describe() << " does not match input " << x->describe());
@@ -666,6 +703,14 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
     LAMP_CHECK(g.HW >= 64, "the fused batch-norm-relu backward exists for maps of at least 64 elements, got " << x->describe());
   }
   Hold xc(contiguous(x)), gc(contiguous(grad_out));
+  Hold addc, dadd;
+  if (addend) {
+    check_device_tensor(addend, "addend");
+    LAMP_CHECK(relu && training, "the fused batch-norm-add-relu backward exists in training mode");
+    LAMP_CHECK(addend->shape() == x->shape() && addend->dtype == x->dtype, "addend " << addend->describe() << " does not match input " << x->describe());
+    addc = Hold(contiguous(addend));
+    if (daddend_out) dadd = Hold(new_like(xc.get()));
+  }
   hipStream_t st = current_stream(x->device());
   int64_t cs[1] = {g.C};
   Hold mean_h, invstd_h;
@@ -691,7 +736,8 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
-    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr)) & 15) == 0;
+    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr) |
+                                                          (uintptr_t)(addc.get() ? addc->data() : nullptr) | (uintptr_t)(dadd.get() ? dadd->data() : nullptr)) & 15) == 0;
     const bool col = g.HW < 64;
     const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
     const int nsplit = pick_split(blocks, g.N);
@@ -702,7 +748,8 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
       KernelTimer kt1("bn_bwd_reduce", 0, 2.0 * (double)total * sizeof(T), st);
       if (col) hipLaunchKernelGGL((bn_bwd_reduce_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
       else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec,
-                              relu, invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr);
+                              relu, invstd_t->ptr<T>(), weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr,
+                              addc.get() ? addc->ptr<T>() : (const T*)nullptr);
     }
     LAMP_LAUNCH_CHECK();
     T* dwp = dw.get() ? dw->ptr<T>() : (T*)nullptr;
@@ -711,12 +758,13 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
     const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
     if (!col) {
       // finalize folded into the channel-aligned dx kernel (one slice and no element loop when only dweight / dbias are wanted)
-      const int do_apply = (dx.get() && total > 0) ? 1 : 0;
+      const int do_apply = ((dx.get() || dadd.get()) && total > 0) ? 1 : 0;
       const int nblk = do_apply ? nsplit : 1;
       KernelTimer kt2("bn_bwd_apply", 0, 3.0 * (double)total * sizeof(T), st);
       hipLaunchKernelGGL((bn_bwd_apply2_kernel<T>), dim3((unsigned)g.C, nblk), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mean_t->ptr<T>(), invstd_t->ptr<T>(),
-                         wp, bp, partial->ptr<A>(), nsplit, dwp, dbp, do_apply ? dx->ptr<T>() : (T*)nullptr, g.N, g.C, g.HW, nblk,
-                         1.0 / (double)(g.N * g.HW), training, vec, relu, do_apply);
+                         wp, bp, partial->ptr<A>(), nsplit, dwp, dbp, dx.get() ? dx->ptr<T>() : (T*)nullptr, g.N, g.C, g.HW, nblk,
+                         1.0 / (double)(g.N * g.HW), training, vec, relu, do_apply, addc.get() ? addc->ptr<T>() : (const T*)nullptr,
+                         dadd.get() ? dadd->ptr<T>() : (T*)nullptr);
       LAMP_LAUNCH_CHECK();
     } else {
       hipLaunchKernelGGL((bn_bwd_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), sums->ptr<A>(), g.C,
@@ -731,6 +779,7 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
     }
   });
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  if (daddend_out) *daddend_out = dadd.take();
   LAMP_API_END
 }
 int lamp_native_batch_norm_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
@@ -743,6 +792,22 @@ int lamp_native_batch_norm_relu_backward(lamp_tensor* out3[3], const lamp_tensor
                                          const lamp_tensor* save_mean, const lamp_tensor* save_invstd, int training, double eps,
                                          const uint8_t mask[3]) {
   return bn_backward_impl(out3, grad_out, x, weight, bias, running_mean, running_var, save_mean, save_invstd, training, eps, mask, 1);
+}
+
+int lamp_native_batch_norm_add_relu(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* addend, const lamp_tensor* weight,
+                                    const lamp_tensor* bias, lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum,
+                                    double eps) {
+  if (!addend) { ::lamp::set_last_error("lamp_native_batch_norm_add_relu: addend is null"); return 1; }
+  return bn_forward_impl(out3, x, weight, bias, running_mean, running_var, training, momentum, eps, 1, addend);
+}
+int lamp_native_batch_norm_add_relu_backward(lamp_tensor* out4[4], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* addend,
+                                             const lamp_tensor* weight, const lamp_tensor* bias, const lamp_tensor* running_mean,
+                                             const lamp_tensor* running_var, const lamp_tensor* save_mean, const lamp_tensor* save_invstd,
+                                             int training, double eps, const uint8_t mask[4]) {
+  if (!addend) { ::lamp::set_last_error("lamp_native_batch_norm_add_relu_backward: addend is null"); return 1; }
+  out4[3] = nullptr;
+  return bn_backward_impl(out4, grad_out, x, weight, bias, running_mean, running_var, save_mean, save_invstd, training, eps, mask, 1, addend,
+                          mask[3] ? &out4[3] : nullptr);
 }
 
 int lamp_native_layer_norm(lamp_tensor* out3[3], const lamp_tensor* x, const int64_t* normalized_shape, int nnorm,

@@ -339,6 +339,41 @@ def test_batch_norm_relu_fused_equals_unfused_pair(gpu, dt, shape, training):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(6, 5, 8, 8), (4, 16, 16, 16), (3, 7, 9, 9)])
+def test_batch_norm_add_relu_fused_equals_unfused_chain(gpu, dt, shape):
+    """lamp_native_batch_norm_add_relu(+_backward) must be BITWISE the chain native_batch_norm -> add -> relu and its backward"""
+    x = closed_form(shape, 3, 4.0, dt) + 0.3
+    addend = closed_form(shape, 29, 3.0, dt)
+    Cc = shape[1]
+    w, b = closed_form((Cc,), 1, 1.0, dt) + 1.0, closed_form((Cc,), 5, 1.0, dt)
+    rm, rv = closed_form((Cc,), 7, 0.5, dt), closed_form((Cc,), 9, 0.5, dt) + 1.0
+    X, AD, Wt, Bt = to_sten(x), to_sten(addend), to_sten(w), to_sten(b)
+    out_u, out_f = _out3(), _out3()
+    RMu, RVu, RMf, RVf = to_sten(rm), to_sten(rv), to_sten(rm), to_sten(rv)
+    lib.lamp_native_batch_norm(out_u, X, Wt, Bt, RMu, RVu, 1, 0.1, 1e-5)
+    lib.lamp_native_batch_norm_add_relu(out_f, X, AD, Wt, Bt, RMf, RVf, 1, 0.1, 1e-5)
+    yu, smu, siu = _wrap3(out_u)
+    yf, smf, sif = _wrap3(out_f)
+    su = yu + AD                                            # the residual add, rounded to the element type
+    assert np.array_equal(su.relu().to_numpy(), yf.to_numpy())
+    assert np.array_equal(RMu.to_numpy(), RMf.to_numpy()) and np.array_equal(RVu.to_numpy(), RVf.to_numpy())
+    ref = torch.relu((aten.native_batch_norm(x, w, b, rm.clone(), rv.clone(), True, 0.1, 1e-5)[0] + addend))
+    assert_close(to_torch(yf), ref.double(), FWD_TOL[dt] * 4, "fused bn+add+relu")
+    gy = closed_form(shape, 11, 2.0, dt)
+    GY = to_sten(gy)
+    gm = C.c_void_p()
+    lib.lamp_relu_backward(C.byref(gm), GY, su, 0.0)
+    G = S.STen(gm)
+    outb_u = _out3()
+    lib.lamp_native_batch_norm_backward(outb_u, G, X, Wt, RMu, RVu, smu, siu, 1, 1e-5, _mask3(1, 1, 1))
+    out4 = (C.c_void_p * 4)()
+    lib.lamp_native_batch_norm_add_relu_backward(out4, GY, X, AD, Wt, Bt, RMu, RVu, smu, siu, 1, 1e-5, (C.c_uint8 * 4)(1, 1, 1, 1))
+    fused = [S.STen(out4[i]) for i in range(4)]
+    for u, f, what in zip(list(_wrap3(outb_u)) + [G], fused, ("dx", "dweight", "dbias", "daddend")):
+        assert np.array_equal(u.to_numpy(), f.to_numpy()), what
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("affine", [(True, True), (True, False), (False, False)])
 def test_layer_norm(gpu, dt, affine):
     x = closed_form((6, 7, 96), 3, 4.0, dt)
