@@ -20,13 +20,13 @@ CLASSES = [  # kernel-name regex -> bench.py timer class
     (r"ig_wgrad8v2_kernel", "conv_wgrad_igemm"),
     (r"ig_wgrad_reduce_v2_kernel", "conv_wgrad_igemm_reduce"),
     (r"ncv_fwd", "conv_narrow_fprop_dgrad"),
-    (r"ncv_wgrad_kernel", "conv_wgrad_narrow"),
+    (r"ncv_wgrad2?_kernel", "conv_wgrad_narrow"),
     (r"bn_stats_kernel", "bn_fwd_stats"),
-    (r"bn_apply_kernel", "bn_fwd_apply"),
+    (r"bn_apply2?_kernel", "bn_fwd_apply"),
     (r"bn_bwd_reduce_kernel", "bn_bwd_reduce"),
-    (r"bn_bwd_apply_kernel", "bn_bwd_apply"),
+    (r"bn_bwd_apply2?_kernel", "bn_bwd_apply"),
     (r"ew_vec_kernel", "elementwise"),
-    (r"gemm_bf16_kernel", "gemm_bf16"),
+    (r"gemm_bf16", "gemm_bf16"),
 ]
 
 
