@@ -14,6 +14,8 @@
 
 namespace lamp {
 
+void knn_distance_block(Tensor* out, const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn);   // gemm.hip
+
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
 
 // dist[i, j] = max(0, qn[i] + dn[j] - 2 * outer[i, j])   (same operation order as the reference chain)
@@ -164,11 +166,17 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
     LAMP_CHECK(lamp_narrow(&dnsl, dn.get(), 0, lo, len) == 0, lamp_last_error()); Hold hdn(dnsl);
     int64_t os[2] = {Q, len};
     Hold outer(new_tensor(os, 2, data->dtype, data->device()));
-    LAMP_CHECK(lamp_addmm_out_transposed2(outer.get(), outer.get(), qc.get(), dsl, 0.0, 1.0) == 0, lamp_last_error());   // q . x^T
-    if (Q * len > 0) {
-      LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_dist_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
-                                                             outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
-      LAMP_LAUNCH_CHECK();
+    if (data->dtype == kF32 || data->dtype == kF64) {
+      // distance block in the GEMM epilogue: the q x chunk block is written once and never re-read before the top-k
+      Hold hdnc(contiguous(dnsl));
+      knn_distance_block(outer.get(), qc.get(), dsl, qn.get(), hdnc.get());
+    } else {
+      LAMP_CHECK(lamp_addmm_out_transposed2(outer.get(), outer.get(), qc.get(), dsl, 0.0, 1.0) == 0, lamp_last_error());   // q . x^T
+      if (Q * len > 0) {
+        LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_dist_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
+                                                               outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
+        LAMP_LAUNCH_CHECK();
+      }
     }
     const int64_t kk = std::min(k, len);
     lamp_tensor *tv = nullptr, *ti = nullptr;

@@ -44,6 +44,9 @@ struct GemmArgs {
   int a_vec, b_vec;       // 16-byte vector loads legal for this operand
   double alpha, beta;
   int tiles_m, tiles_n;
+  // optional kNN epilogue of the f32/f64 kernel: C = max(0, (knn_q[m] + knn_d[n]) - 2 * C)   (knn/package.scala:21-30)
+  const void* knn_q;
+  const void* knn_d;
 };
 
 // ================================================================================================
@@ -642,6 +645,12 @@ __global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
         if (row < g.M && col < g.N) {
           T v = alpha * acc[i][j][r];
           if (S) v += beta * S[row * g.s_rs + col * g.s_cs];
+          if (g.knn_q) {       // the operation order of the separate distance kernel: (qn + dn) - 2 * outer, clamped at 0
+            const T o2 = v * T(2);
+            const T sn = ((const T*)g.knn_q)[row] + ((const T*)g.knn_d)[col];
+            const T dd = sn - o2;
+            v = dd > T(0) ? dd : T(0);
+          }
           C[row * g.ldc + col] = v;
         }
       }
@@ -681,7 +690,7 @@ static void prep_operand(Operand& o, const Tensor* t, bool batched) {
 
 // transA: use a^T, transB: use b^T.  self may be null (beta ignored) and may alias out.
 static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, const Tensor* b, bool transA, bool transB,
-                          double beta, double alpha, bool batched) {
+                          double beta, double alpha, bool batched, const Tensor* knn_q = nullptr, const Tensor* knn_d = nullptr) {
   check_device_tensor(out, "out"); check_device_tensor(a, "mat1"); check_device_tensor(b, "mat2");
   const int nd = batched ? 3 : 2;
   LAMP_CHECK(a->ndim == nd && b->ndim == nd && out->ndim == nd, "expected " << nd << "-D operands, got " << a->describe() << ", "
@@ -694,6 +703,10 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
   prep_operand(ob, b, batched);
   const int64_t ar = oa.t->sizes[nd - 2], ac = oa.t->sizes[nd - 1], br = ob.t->sizes[nd - 2], bc = ob.t->sizes[nd - 1];
   GemmArgs g{};
+  if (knn_q) {
+    LAMP_CHECK(a->dtype == kF32 || a->dtype == kF64, "the fused kNN epilogue exists for f32 / f64");
+    g.knn_q = knn_q->data(); g.knn_d = knn_d->data();
+  }
   g.M = transA ? ac : ar;
   g.K = transA ? ar : ac;
   const int64_t Kb = transB ? bc : br;
@@ -810,6 +823,13 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     LAMP_CHECK(false, "GEMM supports bf16, f32 and f64, got " << a->describe());
   }
   LAMP_LAUNCH_CHECK();
+}
+
+// out[i, j] = max(0, qn[i] + dn[j] - 2 * q[i, :] . x[j, :])  in one kernel (f32 / f64): the kNN distance block
+void knn_distance_block(Tensor* out, const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn) {
+  LAMP_CHECK(qn->is_contiguous() && dn->is_contiguous() && qn->numel() == q->sizes[0] && dn->numel() == x->sizes[0] && qn->dtype == q->dtype &&
+             dn->dtype == q->dtype, "knn_distance_block: bad norm vectors");
+  gemm_dispatch(out, nullptr, q, x, false, true, 0.0, 1.0, false, qn, dn);
 }
 
 static Tensor* alloc_out(const Tensor* a, const Tensor* b, bool transA, bool transB, bool batched) {
