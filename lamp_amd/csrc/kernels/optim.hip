@@ -13,7 +13,7 @@
 
 namespace lamp {
 
-constexpr int MT_MAX = 32;       // tensors per launch
+constexpr int MT_MAX = 40;       // tensors per launch (the descriptor is a by-value kernel argument: 3.4 KB of the 4 KB limit; the ResNet has 37)
 constexpr int MT_CHUNK = 4096;   // elements per workgroup
 
 struct MultiArgs {
@@ -25,6 +25,8 @@ struct MultiArgs {
   double s[4];                   // scalars
   int flags;
 };
+
+static_assert(sizeof(MultiArgs) <= 4096, "MultiArgs is passed by value: HIP kernel arguments are limited to 4 KB");
 
 __device__ __forceinline__ int mt_find(const MultiArgs& a, int blk) {
   int t = 0;
