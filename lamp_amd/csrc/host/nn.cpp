@@ -186,6 +186,7 @@ AdamW::AdamW(const std::vector<Ten>& params, double wd, double lr, double b1, do
   stepCountSTen = ops::scalar(0.0, kF64, parameters.empty() ? 0 : parameters[0].device());
 }
 std::vector<Ten> AdamW::state() {
+  ops::fill_(stepCountSTen, (double)stepCount);
   std::vector<Ten> s = {stepCountSTen};
   for (auto& t : mt) s.push_back(t);
   for (auto& t : vt) s.push_back(t);
@@ -201,8 +202,7 @@ void AdamW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
     w.push_back(workingCopy[i].h());
   }
   if (has_clip && !g.empty()) HCALL(lamp_gradient_clipping_(g.data(), (int)g.size(), clip));
-  stepCount += 1;
-  HCALL(lamp_add_scalar_(stepCountSTen.h(), 1.0, 1.0));
+  stepCount += 1;               // stepCountSTen (state()[0]) is brought up to date when the state is asked for: one launch less per step
   const int n = (int)p.size();
   std::vector<double> lr(n, learningRate), wd(n, weightDecay), b1(n, beta1), b2(n, beta2);
   HCALL(lamp_adamw_step_(p.data(), g.data(), m.data(), v.data(), w.data(), n, lr.data(), wd.data(), b1.data(), b2.data(), eps, scheduleFactor,
@@ -239,8 +239,7 @@ int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten&
   auto ln = loss(output, target);
   std::vector<Ten> g = module->gradients(ln.first, zeroGrad);
   if (acc.defined()) {                                         // acc += (loss.value * numInstances.toDouble)
-    Ten scaled = ops::mul_scalar(ln.first->value, (double)ln.second);
-    ops::add_(acc, ops::reshape(scaled, acc.shape()));
+    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
   }
   if (gradients) *gradients = g;
   return ln.second;
@@ -249,8 +248,7 @@ int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, co
   Var output = module->forward(make_const(samples));
   auto ln = loss(output, target);
   if (acc.defined()) {
-    Ten scaled = ops::mul_scalar(ln.first->value, (double)ln.second);
-    ops::add_(acc, ops::reshape(scaled, acc.shape()));
+    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
   }
   return ln.second;
 }
@@ -325,8 +323,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   if (!deep_sent) send_deep();
   exchange(0, split, bucket_rest, g_rest, h_rest);
   if (acc.defined()) {                                           // acc += (loss.value * numInstances.toDouble)
-    Ten scaled = ops::mul_scalar(ln.first->value, (double)n);
-    ops::add_(acc, ops::reshape(scaled, acc.shape()));
+    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)n);
   }
   HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both reduced buckets are visible to the compute stream
   if (!h_deep.empty()) HCALL(lamp_unflatten_from_(h_deep.data(), (int)h_deep.size(), bucket_deep.h(), 1));
