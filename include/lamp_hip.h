@@ -469,6 +469,11 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances_or
  * term_weights reproduces how lamp's IndexSelect backward (`out += out.indexAdd(..)`, ops.scala:186-191)
  * accumulates the four gathers into one buffer: {1, 2, 4, 8} in the reference's traversal order;
  * pass {1, 1, 1, 1} for the mathematical gradient. */
+/* Umap.edgeWeights (umap.scala:50-113, JVM double loops in the reference): per point the smallest positive kNN
+ * distance rho and the bisection for sigma (Umap.binarySearch, umap.scala:14-48), then for every neighbour j != i
+ * the fuzzy union b = w_ij + w_ji - w_ij*w_ji.  knn_distances [n,k] f64, knn [n,k] i64 -> out [m,3] f64 rows (i, j, b) in
+ * the reference's emission order. */
+int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, const lamp_tensor* knn);
 int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations,
                         const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
                         const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,

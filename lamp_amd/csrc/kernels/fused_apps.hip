@@ -134,6 +134,45 @@ static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a)
   return Hold(o);
 }
 
+// ---- UMAP edge weights (umap.scala:14-113) ------------------------------------------------------------------------------
+// rho_i = smallest positive kNN distance of point i; sigma_i = the reference's bisection (binarySearch: start 1, double while
+// the upper bound is infinite, stop at |f - log2 k| < 1e-6 or after 1000 steps) of f(s) = sum_d exp(-max(0, d - rho_i) / s).
+__global__ void umap_rho_sigma_kernel(const double* __restrict__ dist, double* __restrict__ rho, double* __restrict__ sigma, int64_t n, int k) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {   // grid_for caps the grid
+    const double* d = dist + i * k;
+    double r = INFINITY;
+    for (int j = 0; j < k; j++) if (d[j] > 0.0 && d[j] < r) r = d[j];
+    const double target = log((double)k) / log(2.0);
+    double lo = 0.0, hi = INFINITY, mid = 1.0;
+    for (int it = 0; it <= 1000; it++) {
+      double f = 0.0;
+      for (int j = 0; j < k; j++) f += exp((-1.0 * fmax(0.0, d[j] - r)) / mid);
+      if (fabs(f - target) < 1e-6) break;
+      if (f > target) { hi = mid; mid = (lo + mid) * 0.5; }
+      else { lo = mid; mid = isinf(hi) ? mid * 2.0 : (hi + mid) * 0.5; }
+    }
+    rho[i] = r;
+    sigma[i] = mid;
+  }
+}
+// one thread per (i, jidx): b = w_ij + w_ji - w_ij * w_ji with w_ji looked up in j's neighbour list (0 if i is not in it)
+__global__ void umap_edge_b_kernel(const double* __restrict__ dist, const int64_t* __restrict__ knn, const double* __restrict__ rho,
+                                   const double* __restrict__ sigma, double* __restrict__ oi, double* __restrict__ oj, double* __restrict__ ob,
+                                   uint8_t* __restrict__ keep, int64_t n, int k) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * k; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / k;
+    const int64_t j = knn[e];
+    oi[e] = (double)i; oj[e] = (double)j;
+    if (j == i || j < 0 || j >= n) { keep[e] = 0; ob[e] = 0.0; continue; }
+    const double wij = exp((-1.0 * fmax(0.0, dist[e] - rho[i])) / sigma[i]);
+    double wji = 0.0;
+    for (int l = 0; l < k; l++)
+      if (knn[j * k + l] == i) { wji = exp((-1.0 * fmax(0.0, dist[j * k + l] - rho[j])) / sigma[j]); break; }
+    ob[e] = wij + wji - wij * wji;
+    keep[e] = 1;
+  }
+}
+
 }  // namespace lamp
 
 using namespace lamp;
@@ -210,6 +249,40 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   }
   *indices = best_i.take();
   if (distances) *distances = best_v.take();
+  LAMP_API_END
+}
+
+/* rows (i, j, b) for every neighbour j != i of every point i, in the reference's emission order (umap.scala:50-113) */
+int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, const lamp_tensor* knn) {
+  LAMP_API_BEGIN
+  check_device_tensor(knn_distances, "knn_distances"); check_device_tensor(knn, "knn");
+  LAMP_CHECK(knn_distances->ndim == 2 && knn->ndim == 2 && knn_distances->shape() == knn->shape() && knn_distances->dtype == kF64 && knn->dtype == kI64,
+             "umap edge weights: expected [n, k] f64 distances and i64 indices, got " << knn_distances->describe() << " and " << knn->describe());
+  const int64_t n = knn->sizes[0];
+  const int k = (int)knn->sizes[1];
+  LAMP_CHECK(k >= 1, "umap edge weights: k must be positive");
+  Hold dc(contiguous(knn_distances)), kc(contiguous(knn));
+  hipStream_t st = current_stream(knn->device());
+  int64_t ns[1] = {n}, es[1] = {n * k};
+  Hold rho(new_tensor(ns, 1, kF64, knn->device())), sigma(new_tensor(ns, 1, kF64, knn->device()));
+  Hold oi(new_tensor(es, 1, kF64, knn->device())), oj(new_tensor(es, 1, kF64, knn->device())), ob(new_tensor(es, 1, kF64, knn->device()));
+  Hold keep(new_tensor(es, 1, kBool, knn->device()));
+  if (n > 0) {
+    hipLaunchKernelGGL(umap_rho_sigma_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, dc->ptr<double>(), rho->ptr<double>(), sigma->ptr<double>(), n, k);
+    LAMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(umap_edge_b_kernel, dim3(grid_for(n * k, 256)), dim3(256), 0, st, dc->ptr<double>(), kc->ptr<int64_t>(), rho->ptr<double>(),
+                       sigma->ptr<double>(), oi->ptr<double>(), oj->ptr<double>(), ob->ptr<double>(), keep->ptr<uint8_t>(), n, k);
+    LAMP_LAUNCH_CHECK();
+  }
+  // order-preserving compaction of the three columns, then [m, 3]
+  lamp_tensor* cols[3] = {nullptr, nullptr, nullptr};
+  const Tensor* src[3] = {oi.get(), oj.get(), ob.get()};
+  std::vector<Hold> held;
+  for (int c = 0; c < 3; c++) {
+    LAMP_CHECK(lamp_masked_select(&cols[c], src[c], keep.get()) == 0, lamp_last_error());
+    held.emplace_back(cols[c]);
+  }
+  return lamp_stack(out, cols, 3, 1);
   LAMP_API_END
 }
 

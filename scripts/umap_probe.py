@@ -47,3 +47,17 @@ lib.lamp_device_synchronize()
 dt = (time.perf_counter() - t0) / R
 pairs = ne * 6
 print(f"UMAP loss+grad points={nq} pairs={pairs}: {dt*1e3:.3f} ms/iteration  {pairs/dt/1e9:.2f} Gpairs/s  {pairs*(2*2*8+2*2*8)/dt/1e9:.0f} GB/s gather+scatter")
+
+# edge weights (umap.scala:50-113) on a 1M x 10 neighbour table
+ne_pts = 1_000_000
+kd = np.sort(rng.random((ne_pts, k)), axis=1); kd[:, 0] = 0.0
+ki = rng.integers(0, ne_pts, (ne_pts, k)).astype(np.int64); ki[:, 0] = np.arange(ne_pts)
+KD, KI = S.STen.from_numpy(kd, 0, S.F64), S.STen.from_numpy(ki, 0)
+def ew():
+    o = C.c_void_p(); lib.lamp_umap_edge_weights(C.byref(o), KD, KI); return S.STen(o)
+ew(); lib.lamp_device_synchronize()
+t0 = time.perf_counter(); R = 5
+for _ in range(R): out = ew()
+lib.lamp_device_synchronize()
+dt = (time.perf_counter() - t0) / R
+print(f"UMAP edge weights n={ne_pts} k={k}: {dt*1e3:.2f} ms ({out.shape[0]} edges)")

@@ -1,6 +1,8 @@
 """kNN, UMAP and attention entry points vs the oracle (lamp-knn, lamp-umap, Transformer composed attention)."""
 import ctypes as C
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -191,3 +193,59 @@ def test_knn_and_umap_at_full_size_properties(gpu):
     g = grad.to_numpy()
     assert np.isfinite(g).all() and np.isfinite(S.STen(o).to_numpy()).all()
     assert np.abs(g.sum(0)).max() <= 1e-9 * np.abs(g).sum(), "pairwise forces cancel"
+
+    # UMAP edge weights on a 1M x 10 neighbour table (self in column 0): every non-self neighbour yields one row, rows are in
+    # emission order, and sampled rows agree with the oracle's rho / bisection / fuzzy union computed for those rows only
+    kd = np.sort(rng.random((n, k)), axis=1); kd[:, 0] = 0.0
+    ki = rng.integers(0, n, (n, k)).astype(np.int64); ki[:, 0] = np.arange(n)
+    o = C.c_void_p()
+    lib.lamp_umap_edge_weights(C.byref(o), S.STen.from_numpy(kd, 0, S.F64), S.STen.from_numpy(ki, 0))
+    ew = S.STen(o).to_numpy()
+    keep = ki != np.arange(n)[:, None]
+    assert ew.shape == (int(keep.sum()), 3)
+    assert np.array_equal(ew[:, 0], np.repeat(np.arange(n), k)[keep.reshape(-1)].astype(np.float64))
+    assert np.array_equal(ew[:, 1], ki[keep].astype(np.float64))
+    assert (ew[:, 2] >= 0).all() and (ew[:, 2] <= 1 + 1e-12).all()
+    log2k = math.log(k) / math.log(2.0)
+
+    def rho_sigma(row):
+        r = min(d for d in kd[row] if d > 0)
+        return r, O._binary_search(log2k, lambda s_: sum(math.exp((-1 * max(0.0, d - r)) / s_) for d in kd[row]))
+    flat_pos = np.flatnonzero(keep.reshape(-1))
+    for e in rng.choice(len(flat_pos), 200, replace=False):
+        i, jidx = divmod(int(flat_pos[e]), k)
+        j = int(ki[i, jidx])
+        ri, si = rho_sigma(i)
+        wij = math.exp((-1 * max(0.0, kd[i, jidx] - ri)) / si)
+        wji = 0.0
+        hits = np.flatnonzero(ki[j] == i)
+        if len(hits):
+            rj, sj = rho_sigma(j)
+            wji = math.exp((-1 * max(0.0, kd[j, hits[0]] - rj)) / sj)
+        assert abs(ew[e, 2] - (wij + wji - wij * wji)) < 1e-9
+
+
+def test_umap_edge_weights_reference_kat_and_oracle(gpu):
+    """lamp_umap_edge_weights vs the reference's KAT (umap.test.scala:10-53, the oracle is pinned to it in test_oracle_kat.py)
+    and vs the oracle on a 600-point kNN graph (rho / bisection sigma / fuzzy union, rows in emission order)."""
+    data = torch.tensor([[1.0, 4.0], [2.0, 5.0], [3.0, 6.0]], dtype=torch.float64)
+    knn = O.knn_minibatched(data, data, 3, 100)
+    d2 = O.squared_euclidean_distance(data, data)
+    knn = torch.stack([row[torch.argsort(d2[i][row], stable=True)] for i, row in enumerate(knn)])
+    dist = torch.tensor([[float(torch.linalg.vector_norm(data[i] - data[j])) for j in knn[i]] for i in range(3)], dtype=torch.float64)
+    o = C.c_void_p()
+    lib.lamp_umap_edge_weights(C.byref(o), to_sten(dist), to_sten(knn))
+    got = S.STen(o).to_numpy()
+    exp = np.array([(0., 1., 1.), (0., 2., 0.), (1., 0., 1.), (1., 2., 1.), (2., 1., 1.), (2., 0., 0.)])
+    assert got.shape == exp.shape and np.array_equal(got[:, :2], exp[:, :2]) and np.allclose(got[:, 2], exp[:, 2], atol=1e-6), got
+
+    pts = _points(600, 5, torch.float64)
+    idx = O.knn_minibatched(pts, pts, 8, 100)
+    dd = torch.stack([torch.linalg.vector_norm(pts[i] - pts[idx[i]], dim=1) for i in range(600)])
+    rows = np.array(O.edge_weights(dd.tolist(), idx.tolist()))
+    o = C.c_void_p()
+    lib.lamp_umap_edge_weights(C.byref(o), to_sten(dd), to_sten(idx))
+    got = S.STen(o).to_numpy()
+    assert got.shape == rows.shape
+    assert np.array_equal(got[:, :2], rows[:, :2]), "edge list (i, j) and its order"
+    assert np.abs(got[:, 2] - rows[:, 2]).max() < 1e-9
