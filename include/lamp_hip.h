@@ -469,6 +469,9 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances_or
  * term_weights reproduces how lamp's IndexSelect backward (`out += out.indexAdd(..)`, ops.scala:186-191)
  * accumulates the four gathers into one buffer: {1, 2, 4, 8} in the reference's traversal order;
  * pass {1, 1, 1, 1} for the mathematical gradient. */
+/* knnDistances of Umap.umap (umap.scala:382-402, a JVM loop in the reference): out[i, j] = exact f64 Euclidean distance
+ * between data row i and data row indices[i, j], summed left to right over the columns.  out is [n, k] f64. */
+int lamp_knn_row_distances(lamp_tensor** out, const lamp_tensor* data, const lamp_tensor* indices);
 /* Umap.edgeWeights (umap.scala:50-113, JVM double loops in the reference): per point the smallest positive kNN
  * distance rho and the bisection for sigma (Umap.binarySearch, umap.scala:14-48), then for every neighbour j != i
  * the fuzzy union b = w_ij + w_ji - w_ij*w_ji.  knn_distances [n,k] f64, knn [n,k] i64 -> out [m,3] f64 rows (i, j, b) in

@@ -173,6 +173,21 @@ __global__ void umap_edge_b_kernel(const double* __restrict__ dist, const int64_
   }
 }
 
+// knnDistances of Umap.umap (umap.scala:382-402): the exact f64 Euclidean distance between row i and each of its neighbours,
+// summed in the reference's order (left to right over the columns)
+template <class T>
+__global__ void knn_row_distance_kernel(const T* __restrict__ data, const int64_t* __restrict__ idx, double* __restrict__ out, int64_t n, int64_t k,
+                                        int64_t d) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * k; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / k, j = idx[e];
+    const T* a = data + i * d;
+    const T* b = data + j * d;
+    double s = 0.0;
+    for (int64_t c = 0; c < d; c++) { const double t = (double)load_as<acc_t<T>>(a[c]) - (double)load_as<acc_t<T>>(b[c]); s += t * t; }
+    out[e] = sqrt(s);
+  }
+}
+
 }  // namespace lamp
 
 using namespace lamp;
@@ -252,6 +267,23 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   LAMP_API_END
 }
 
+int lamp_knn_row_distances(lamp_tensor** out, const lamp_tensor* data, const lamp_tensor* indices) {
+  LAMP_API_BEGIN
+  check_device_tensor(data, "data"); check_device_tensor(indices, "indices");
+  LAMP_CHECK(data->ndim == 2 && indices->ndim == 2 && indices->dtype == kI64 && indices->sizes[0] == data->sizes[0],
+             "knn row distances: expected data [n, d] and i64 indices [n, k], got " << data->describe() << " and " << indices->describe());
+  Hold dc(contiguous(data)), ic(contiguous(indices));
+  const int64_t n = indices->sizes[0], k = indices->sizes[1], d = data->sizes[1];
+  int64_t os[2] = {n, k};
+  Hold r(new_tensor(os, 2, kF64, data->device()));
+  if (n * k > 0) {
+    LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_row_distance_kernel<T>), dim3(grid_for(n * k, 256)), dim3(256), 0, current_stream(data->device()),
+                                                           dc->ptr<T>(), ic->ptr<int64_t>(), r->ptr<double>(), n, k, d));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
 /* rows (i, j, b) for every neighbour j != i of every point i, in the reference's emission order (umap.scala:50-113) */
 int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, const lamp_tensor* knn) {
   LAMP_API_BEGIN

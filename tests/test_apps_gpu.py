@@ -249,3 +249,40 @@ def test_umap_edge_weights_reference_kat_and_oracle(gpu):
     assert got.shape == rows.shape
     assert np.array_equal(got[:, :2], rows[:, :2]), "edge list (i, j) and its order"
     assert np.abs(got[:, 2] - rows[:, 2]).max() < 1e-9
+
+
+def test_umap_pipeline_end_to_end(gpu):
+    """lamp_amd.umap.umap mirrors Umap.umap: with 0 iterations the graph b equals the oracle's edge weights on the oracle's kNN
+    (exact f64 distances); with iterations the loss goes down, runs are reproducible for a seed, and graph neighbours end up much
+    closer in the layout than random pairs."""
+    from lamp_amd import umap as U
+    rng = np.random.default_rng(3)
+    centers = np.array([[0.0] * 6, [8.0] * 6, [-8.0, 8.0, -8.0, 8.0, -8.0, 8.0]])
+    data = np.concatenate([c + rng.standard_normal((60, 6)) * 0.5 for c in centers])
+    t = torch.from_numpy(data)
+    idx = O.knn_minibatched(t, t, 6, 50)
+    d2 = O.squared_euclidean_distance(t, t)
+    idx = torch.stack([row[torch.argsort(d2[i][row], stable=True)] for i, row in enumerate(idx)])
+    dist = torch.stack([torch.linalg.vector_norm(t[i] - t[idx[i]], dim=1) for i in range(len(t))])
+    ref_rows = {(int(a), int(b)): w for a, b, w in O.edge_weights(dist.tolist(), idx.tolist())}
+    layout0, b, _ = U.umap(data, k=6, iterations=0, randomSeed=7)
+    got = b.to_numpy()
+    assert len(got) == len(ref_rows)
+    for i, j, w in got:
+        assert abs(ref_rows[(int(i), int(j))] - w) < 1e-9
+    assert layout0.shape == [180, 2]
+
+    losses = []
+    layout, b2, last = U.umap(data, k=6, iterations=150, lr=0.1, randomSeed=7, log=lambda s: losses.append(float(s.split(",")[-1].strip(" )"))))
+    layout_again, _, last_again = U.umap(data, k=6, iterations=150, lr=0.1, randomSeed=7)
+    # same seed, same samples; the f64 atomic scatter-adds of the gradient are summed in a run-dependent order (as index_add is
+    # on any GPU), so agreement is to rounding, not bitwise
+    assert np.abs(layout.to_numpy() - layout_again.to_numpy()).max() < 1e-3 and abs(last - last_again) < 1e-4 * max(1.0, abs(last)), \
+        (np.abs(layout.to_numpy() - layout_again.to_numpy()).max(), last, last_again)
+    assert len(losses) == 150 and np.mean(losses[-10:]) < 0.8 * np.mean(losses[:10]), "the loss (negated objective, umap.scala:163-175) goes down"
+    L = layout.to_numpy()
+    e = b2.to_numpy()
+    edge_len = np.linalg.norm(L[e[:, 0].astype(int)] - L[e[:, 1].astype(int)], axis=1).mean()
+    ri, rj = rng.integers(0, 180, 4000), rng.integers(0, 180, 4000)
+    rand_len = np.linalg.norm(L[ri] - L[rj], axis=1).mean()
+    assert edge_len < 0.5 * rand_len, (edge_len, rand_len)      # graph neighbours end up close, random pairs do not
