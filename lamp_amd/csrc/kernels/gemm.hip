@@ -658,6 +658,133 @@ __global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
 }
 
 // ================================================================================================
+// f32 kernel for larger problems: 128 x 128 x 16 tile, 4 waves (2 x 2, 64 x 64 each), 16-byte global loads along whichever
+// index of an operand is contiguous, k-major LDS tiles [16][128 + 16] (the +16 puts the four k rows a fragment read touches on
+// disjoint bank ranges), v_mfma_f32_16x16x4_f32: the same exact f32 FMA chain per output as the 64 x 64 kernel, twice the
+// FLOP per byte staged.  Needs 16-byte aligned operands with leading dimensions that are multiples of 4.
+// ================================================================================================
+constexpr int GM = 128, GN = 128, GK = 16, GPAD = 16;
+
+__global__ __launch_bounds__(256) void gemm_f32_big_kernel(GemmArgs g) {
+  __shared__ float As[2][GK][GM + GPAD];
+  __shared__ float Bs[2][GK][GN + GPAD];
+  const int ntiles = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int64_t m0 = (int64_t)tm * GM, n0 = (int64_t)tn * GN;
+  const int bz = blockIdx.z;
+  const float* A = (const float*)g.A + bz * g.a_bs;
+  const float* B = (const float*)g.B + bz * g.b_bs;
+  const bool a_kc = (g.a_cs == 1), b_kc = (g.b_rs == 1);
+  const int64_t lda = a_kc ? g.a_rs : g.a_cs, ldb = b_kc ? g.b_cs : g.b_rs;
+
+  f4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  // staging: 128 x 16 floats per operand = 512 packets of 4, two per thread
+  float4 ra[2], rb[2];
+  auto load_op = [&](float4 (&r)[2], const float* P, bool kc, int64_t ld, int64_t r0, int64_t rows, int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kc) {                                   // [rows][K]: packet = 4 consecutive k of one row
+        const int64_t row = r0 + (c >> 2), k = k0 + ((c & 3) << 2);
+        if (row < rows) {
+          if (k + 4 <= g.K) v = *reinterpret_cast<const float4*>(P + row * ld + k);
+          else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4; j++) if (k + j < g.K) e[j] = P[row * ld + k + j]; v = make_float4(e[0], e[1], e[2], e[3]); }
+        }
+      } else {                                    // [K][rows]: packet = 4 consecutive rows of one k
+        const int64_t k = k0 + (c >> 5), row = r0 + ((c & 31) << 2);
+        if (k < g.K) {
+          if (row + 4 <= rows) v = *reinterpret_cast<const float4*>(P + k * ld + row);
+          else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4; j++) if (row + j < rows) e[j] = P[k * ld + row + j]; v = make_float4(e[0], e[1], e[2], e[3]); }
+        }
+      }
+      r[i] = v;
+    }
+  };
+  auto store_op = [&](const float4 (&r)[2], float (*T)[GM + GPAD], bool kc) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + i * 256;
+      if (kc) {
+        const int row = c >> 2, k = (c & 3) << 2;
+        T[k][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
+      } else {
+        const int k = c >> 5, row = (c & 31) << 2;
+        *reinterpret_cast<float4*>(&T[k][row]) = r[i];
+      }
+    }
+  };
+
+  const int nk = (int)((g.K + GK - 1) / GK);
+  load_op(ra, A, a_kc, lda, m0, g.M, 0);
+  load_op(rb, B, b_kc, ldb, n0, g.N, 0);
+  store_op(ra, As[0], a_kc);
+  store_op(rb, Bs[0], b_kc);
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      load_op(ra, A, a_kc, lda, m0, g.M, (int64_t)(t + 1) * GK);
+      load_op(rb, B, b_kc, ldb, n0, g.N, (int64_t)(t + 1) * GK);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < GK / 4; s4++) {
+      const int k = s4 * 4 + (lane >> 4);
+      float fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fa[i] = As[cur][k][wr * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = Bs[cur][k][wc * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      store_op(ra, As[cur ^ 1], a_kc);
+      store_op(rb, Bs[cur ^ 1], b_kc);
+    }
+    __syncthreads();
+  }
+  float* C = (float*)g.C + bz * g.c_bs;
+  const float* S = g.S ? (const float*)g.S + bz * g.s_bs : nullptr;
+  const float alpha = (float)g.alpha, beta = (float)g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t col = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (row < g.M && col < g.N) {
+          float v = alpha * acc[i][j][r];
+          if (S) v += beta * S[row * g.s_rs + col * g.s_cs];
+          if (g.knn_q) {
+            const float o2 = v * 2.f;
+            const float sn = ((const float*)g.knn_q)[row] + ((const float*)g.knn_d)[col];
+            const float dd = sn - o2;
+            v = dd > 0.f ? dd : 0.f;
+          }
+          C[row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 struct Operand {
@@ -817,7 +944,15 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     g.tiles_m = (int)((g.M + FM - 1) / FM);
     g.tiles_n = (int)((g.N + FN - 1) / FN);
     dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
-    if (a->dtype == kF32) hipLaunchKernelGGL((gemm_fp_kernel<float>), grid, dim3(256), 0, stm, g);
+    const bool a_kc32 = (g.a_cs == 1), b_kc32 = (g.b_rs == 1);
+    const int64_t lda32 = a_kc32 ? g.a_rs : g.a_cs, ldb32 = b_kc32 ? g.b_cs : g.b_rs;
+    const bool big32 = a->dtype == kF32 && (lda32 % 4 == 0) && (ldb32 % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 &&
+                       (g.a_bs % 4 == 0) && (g.b_bs % 4 == 0) && ((g.M + GM - 1) / GM) * ((g.N + GN - 1) / GN) * g.batch >= 128;
+    if (big32) {
+      g.tiles_m = (int)((g.M + GM - 1) / GM);
+      g.tiles_n = (int)((g.N + GN - 1) / GN);
+      hipLaunchKernelGGL(gemm_f32_big_kernel, dim3(g.tiles_m * g.tiles_n, 1, g.batch), dim3(256), 0, stm, g);
+    } else if (a->dtype == kF32) hipLaunchKernelGGL((gemm_fp_kernel<float>), grid, dim3(256), 0, stm, g);
     else hipLaunchKernelGGL((gemm_fp_kernel<double>), grid, dim3(256), 0, stm, g);
   } else {
     LAMP_CHECK(false, "GEMM supports bf16, f32 and f64, got " << a->describe());
