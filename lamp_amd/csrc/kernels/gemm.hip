@@ -277,13 +277,25 @@ template <bool KC, int ROWS> __device__ __forceinline__ bf8_t pp_frag(const char
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int k = s * 32 + g * 8 + q;
     const int col8 = (tile_row0 >> 3) + (p >> 1);
-    typedef __attribute__((address_space(3))) s4_t* lds_ptr_t;
-    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + ks_off_p(k, col8, ROWS * 2) + ((p & 1) << 3)));
-    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + ks_off_p(k + 4, col8, ROWS * 2) + ((p & 1) << 3)));
+    // Inline asm, not __builtin_amdgcn_ds_read_tr16_b64: hipcc cannot tell that the builtin's read does not alias the LDS-DMA
+    // in flight and drains it with s_waitcnt vmcnt(0) in front of the first transposing read of every phase, which serialises the
+    // weight stream with the compute (measured: 1.07 vs 1.36 PFLOP/s against the all-ds_read_b128 layout).  The results are
+    // made visible to the compiler's users by pp_frag_fence() below.
+    s4_t lo, hi;
+    const unsigned a0 = (unsigned)(uintptr_t)(img + ks_off_p(k, col8, ROWS * 2) + ((p & 1) << 3));
+    const unsigned a1 = (unsigned)(uintptr_t)(img + ks_off_p(k + 4, col8, ROWS * 2) + ((p & 1) << 3));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
     s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf8_t, v);
   }
 }
+
+// s_waitcnt lgkmcnt(0) (optionally with a vmcnt) that "produces" the fragments: consumers of asm-issued LDS reads cannot be
+// scheduled above it
+#define PP_FENCE4(WAIT, F) asm volatile(WAIT : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) : : "memory")
+#define PP_FENCE8(WAIT, F) \
+  asm volatile(WAIT : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]) : : "memory")
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
@@ -349,8 +361,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
       fb0[j] = pp_frag<BKC, PN>(bs, wc * 64 + j * 16, 0, lane);
       fb1[j] = pp_frag<BKC, PN>(bs, wc * 64 + j * 16, 1, lane);
     }
-    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (t + 2 < nk) PP_FENCE4("s_waitcnt vmcnt(6) lgkmcnt(0)", fa0);
+    else PP_FENCE4("s_waitcnt vmcnt(0) lgkmcnt(0)", fa0);
+    PP_FENCE4("", fa1); PP_FENCE4("", fb0); PP_FENCE4("", fb1);
     __builtin_amdgcn_s_barrier();
     // ---- MFMA(t)
     __builtin_amdgcn_s_setprio(1);
@@ -482,14 +495,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
     // READ k-step 0 (+ DMA of the next stage)
     if (t + 1 < nk) dma(t + 1, (t + 1) & 1);
     Q_READ(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_FENCE8("s_waitcnt lgkmcnt(0)", fa); PP_FENCE4("", fb);
     __builtin_amdgcn_s_barrier();
     Q_MFMA();
     __builtin_amdgcn_s_barrier();
     // READ k-step 1
     Q_READ(1);
-    if (wr == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (wr == 1) PP_FENCE8("s_waitcnt vmcnt(0) lgkmcnt(0)", fa);
+    else PP_FENCE8("s_waitcnt lgkmcnt(0)", fa);
+    PP_FENCE4("", fb);
     __builtin_amdgcn_s_barrier();
     Q_MFMA();
     if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
