@@ -304,6 +304,24 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
   const int n0 = blockIdx.x * NW;
   const int cmask = (KP >> 3) - 1;
 
+  // the first weight stage is requested before the image loads: both latencies overlap
+  constexpr int KW = 64;
+  const int CC = KP / KW;
+  const int T = RS * CC;
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  typedef const __attribute__((address_space(1))) char glb_char_t;
+  auto stage_dma = [&](int t, int slot) {
+    const int rs1 = t / CC, cc1 = t - rs1 * CC;
+    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
+#pragma unroll
+    for (int i = 0; i < LPT; i++) {
+      const int piece = wid * LPT + i;
+      const int p = piece * 64 + lane;
+      const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * IG_WTILE + piece * 1024), 16, 0, 0);
+    }
+  };
+  stage_dma(0, 0);
   if (tid * 16 < RB) *reinterpret_cast<uint4*>(Xl + ZOFF + tid * 16) = make_uint4(0, 0, 0, 0);
   {
     const int ncgp = KP >> 3;
@@ -338,23 +356,6 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int KW = 64;
-  const int CC = KP / KW;
-  const int T = RS * CC;
-  typedef __attribute__((address_space(3))) char lds_char_t;
-  typedef const __attribute__((address_space(1))) char glb_char_t;
-  auto stage_dma = [&](int t, int slot) {
-    const int rs1 = t / CC, cc1 = t - rs1 * CC;
-    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
-#pragma unroll
-    for (int i = 0; i < LPT; i++) {
-      const int piece = wid * LPT + i;
-      const int p = piece * 64 + lane;
-      const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * IG_WTILE + piece * 1024), 16, 0, 0);
-    }
-  };
-  stage_dma(0, 0);
 
   int rowsel, wpix;
   px_of_col(lane & 15, rowsel, wpix);
