@@ -94,6 +94,12 @@ struct Storage {
   bool owned = true;        // false: wraps caller memory (lamp_tensor_from_blob)
   void* pool = nullptr;     // allocator block cookie
   std::atomic<int> refs{1};
+  // Bumped whenever a MUTABLE pointer into the storage is handed out (data() / ptr<T>() on a non-const handle): every kernel
+  // that writes a tensor has to go through one of those, so "version unchanged" proves "contents unchanged" - the packed-weight
+  // cache of the implicit-GEMM convolutions relies on it.  Spurious bumps (a mutable pointer used for reading) only cost a miss.
+  std::atomic<uint64_t> version{0};
+  uint64_t uid = next_uid();    // never reused (a freed Storage's address can be)
+  static uint64_t next_uid() { static std::atomic<uint64_t> c{1}; return c.fetch_add(1, std::memory_order_relaxed); }
 };
 
 }  // namespace lamp
@@ -115,8 +121,11 @@ struct lamp_tensor {
   int device() const { return st ? st->device : -1; }
   bool is_device() const { return st && st->device >= 0; }
   size_t itemsize() const { return lamp::dtype_size(dtype); }
-  void* data() const { return st ? (char*)st->ptr + offset * (int64_t)itemsize() : nullptr; }
-  template <class T> T* ptr() const { return (T*)data(); }
+  void* raw() const { return st ? (char*)st->ptr + offset * (int64_t)itemsize() : nullptr; }   // no version bump: read-only uses
+  void* data() { if (st) st->version.fetch_add(1, std::memory_order_relaxed); return raw(); }
+  const void* data() const { return raw(); }
+  template <class T> T* ptr() { return (T*)data(); }
+  template <class T> const T* ptr() const { return (const T*)raw(); }
   bool is_contiguous() const {
     int64_t expect = 1;
     for (int i = ndim - 1; i >= 0; i--) {

@@ -350,7 +350,8 @@ int lamp_tensor_scalar_type(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT
 int lamp_tensor_device(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->device(); LAMP_API_END }
 int lamp_tensor_is_contiguous(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->is_contiguous(); LAMP_API_END }
 int lamp_tensor_is_pinned(const lamp_tensor* t, int* out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->st->pinned; LAMP_API_END }
-int lamp_tensor_data_ptr(const lamp_tensor* t, void** out) { LAMP_API_BEGIN NOT_NULL(t); *out = t->data(); LAMP_API_END }
+// the caller receives a MUTABLE pointer: counts as a write for the storage version
+int lamp_tensor_data_ptr(const lamp_tensor* t, void** out) { LAMP_API_BEGIN NOT_NULL(t); *out = const_cast<lamp_tensor*>(t)->data(); LAMP_API_END }
 int lamp_tensor_storage_id(const lamp_tensor* t, uint64_t* out) { LAMP_API_BEGIN NOT_NULL(t); *out = (uint64_t)(uintptr_t)t->st; LAMP_API_END }
 
 int lamp_empty(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device) {

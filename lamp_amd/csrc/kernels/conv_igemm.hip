@@ -25,6 +25,9 @@
 //   the K dimension runs over pixels of many images; the tap shift is applied while staging X
 //   (row select + a 16-bit funnel shift inside the 16-byte row), partial sums of the image
 //   splits go to an fp32 workspace and a small kernel reduces them into dW[co][ci][r][s].
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "device_utils.h"
 #include "conv_geom.h"
 
@@ -74,16 +77,19 @@ __device__ __forceinline__ int x_swz(int hp, int wp, int nchunk_mask) { return (
 // ---- weight packing ---------------------------------------------------------------------------------
 // fprop: wp[rs][co][ci] = W[co][ci][r][s]            (rows = Cout, k = Cin)
 // dgrad: wp[rs][ci][co] = W[co][ci][kh-1-r][kw-1-s]  (rows = Cin,  k = Cout)
-__global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KS, int KP, int dgrad) {
+// one launch writes BOTH layouts: [fprop image (KPf) | dgrad image (KPd)]
+__global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KS, int KPf, int KPd) {
   const int RS = KS * KS;
-  const int total = RS * IG_M * KP;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const int dgrad = e0 >= nf;
+    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
     const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
     const int r = rs / KS, s = rs % KS;
     bf16_t v; v.bits = 0;
     if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
     else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
-    wp[e] = v;
+    wp[e0] = v;
   }
 }
 
@@ -670,15 +676,69 @@ static bool ig_qualifies(const ConvGeom& g, int dtype) {
 }
 static int pad_k(int64_t c) { return c <= 64 ? 64 : 128; }
 
+// Both packed layouts of a weight tensor (fprop and dgrad) are produced by ONE launch and cached per (weight storage, view,
+// stream) while the storage's version is unchanged: every kernel that writes a tensor obtains a mutable pointer through
+// Tensor::data()/ptr<T>(), which bumps the version (core/tensor.h), so "same version" proves "same contents".  In a training
+// step the weights change once (the optimiser), so each convolution packs once per step instead of once per fprop and once
+// per dgrad; with frozen weights (evaluation, gradient accumulation) nothing is repacked at all.  Storages that wrap caller
+// memory (lamp_tensor_from_blob) are never cached.  LAMP_PACK_CACHE=0 disables the cache.
+namespace {
+struct PackKey {
+  uint64_t uid; int64_t offset; int KS, Cout, Cin; hipStream_t st;
+  bool operator<(const PackKey& o) const { return std::tie(uid, offset, KS, Cout, Cin, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.st); }
+};
+struct PackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+std::mutex g_pack_mu;
+std::map<PackKey, PackVal> g_pack_cache;
+uint64_t g_pack_tick = 0;
+}  // namespace
+
+static int pad_k(int64_t c);
+// returns a +1 handle on the buffer [fprop image | dgrad image]; *dgrad_offset = element offset of the second image
+static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStream_t st, int64_t* dgrad_offset) {
+  const int RS = KS * KS;
+  const int KPf = pad_k(g.Cin), KPd = pad_k(g.Cout);
+  const int64_t nf = (int64_t)RS * IG_M * KPf, nd = (int64_t)RS * IG_M * KPd;
+  *dgrad_offset = nf;
+  static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
+  const bool cacheable = cache_on && w->st->owned;
+  const PackKey key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, st};
+  const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    auto it = g_pack_cache.find(key);
+    if (it != g_pack_cache.end() && it->second.version == ver) {
+      it->second.tick = ++g_pack_tick;
+      return retain(it->second.packed);
+    }
+  }
+  int64_t ps[1] = {nf + nd};
+  Hold wp(new_tensor(ps, 1, kBF16, w->device()));
+  hipLaunchKernelGGL(ig_pack_weights_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wp->ptr<bf16_t>(), (int)g.Cout,
+                     (int)g.Cin, KS, KPf, KPd);
+  LAMP_LAUNCH_CHECK();
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    auto it = g_pack_cache.find(key);
+    if (it != g_pack_cache.end()) { release(it->second.packed); g_pack_cache.erase(it); }
+    if (g_pack_cache.size() >= 256) {           // evict the least recently used entry
+      auto victim = g_pack_cache.begin();
+      for (auto i = g_pack_cache.begin(); i != g_pack_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
+      release(victim->second.packed);
+      g_pack_cache.erase(victim);
+    }
+    g_pack_cache[key] = PackVal{ver, retain(wp.get()), ++g_pack_tick};
+  }
+  return wp.take();
+}
+
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
   const int KS = g.kh, RS = KS * KS;
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
-  int64_t ps[1] = {(int64_t)RS * IG_M * KP};
-  Hold wp(new_tensor(ps, 1, kBF16, in->device()));
-  hipLaunchKernelGGL(ig_pack_weights_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wp->ptr<bf16_t>(), (int)g.Cout,
-                     (int)g.Cin, KS, KP, dgrad ? 1 : 0);
-  LAMP_LAUNCH_CHECK();
+  int64_t dgrad_off = 0;
+  Hold wpk(packed_weights(w, g, KS, st, &dgrad_off));
+  const bf16_t* wpp = static_cast<const Tensor*>(wpk.get())->ptr<bf16_t>() + (dgrad ? dgrad_off : 0);
   {
     const char* variant = getenv("LAMP_IG_VARIANT");
     if (!(variant && variant[0] == 'a')) {   // default: two co-resident workgroups per CU (A/B on one device: 7 % faster per launch)
@@ -689,10 +749,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       static bool a3 = false, a1 = false;
       if (KS == 3) {
         if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
-        hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(), bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
       } else {
         if (!a1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
-        hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(), bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
       }
       LAMP_LAUNCH_CHECK();
       return;
@@ -711,7 +771,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8_kernel<KS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       attr = true;                                                                                                                 \
     }                                                                                                                              \
-    hipLaunchKernelGGL((ig_conv8_kernel<KS_, NW_>), dim3(blocks), dim3(NW_ * 128), lds, st, in->ptr<bf16_t>(), wp->ptr<bf16_t>(), bp, \
+    hipLaunchKernelGGL((ig_conv8_kernel<KS_, NW_>), dim3(blocks), dim3(NW_ * 128), lds, st, in->ptr<bf16_t>(), wpp, bp, \
                        out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);                                                                  \
   } while (0)
   if (KS == 3) { if (NW == 4) IG_LAUNCH(3, 4); else IG_LAUNCH(3, 2); }

@@ -575,3 +575,44 @@ def test_allocation_registry(gpu):
     del t
     gc.collect()
     assert S.live_tensor_count() == n0
+
+
+def test_igemm_pack_cache_sees_every_weight_write(gpu):
+    """The implicit-GEMM convolutions cache their packed weights per storage version.  Every way of changing the weights must
+    invalidate it: in-place arithmetic, copy_, a write through a view, a host upload, the optimiser."""
+    from lamp_amd import nn as NN
+    dt = torch.bfloat16
+    x = closed_form((4, 128, 8, 8), 3, 2.0, dt)
+    w0 = closed_form((128, 128, 3, 3), 17, 1.0, dt)
+    b = torch.zeros(128, dtype=dt)
+    X, Bt = to_sten(x), to_sten(b)
+    W = to_sten(w0)
+
+    def conv(Wt):
+        o = C.c_void_p()
+        lib.lamp_convolution(C.byref(o), X, Wt, Bt, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
+        return to_torch(S.STen(o))
+
+    def check(w_now, what):
+        ref = aten.convolution(x, w_now, b, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        assert_close(conv(W), ref.double(), 1.6e-2, what)
+
+    check(w0, "first call")
+    check(w0, "cached call")
+    lib.lamp_mul_scalar_(W, 0.5)
+    check(to_torch(W).to(dt), "after mul_scalar_")
+    w1 = closed_form((128, 128, 3, 3), 5, 1.0, dt)
+    lib.lamp_copy_(W, to_sten(w1), 0)
+    check(w1, "after copy_")
+    W.select(0, 3).fill_(0.25)                              # write through a view of the same storage
+    w2 = w1.clone(); w2[3] = 0.25
+    check(w2, "after a view write")
+    w3 = closed_form((128, 128, 3, 3), 9, 1.0, dt)
+    W2 = to_sten(w3)                                        # a different tensor with different contents
+    ref3 = aten.convolution(x, w3, b, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    assert_close(conv(W2), ref3.double(), 1.6e-2, "another weight tensor")
+    # the optimiser: one SGD step changes W, the next convolution must use the new values
+    g = S.STen.ones([128, 128, 3, 3], S.BF16, 0)
+    opt = NN.SGDW([W], 0.5, 0.0)
+    opt.step([g], 1.0)
+    check(to_torch(W).to(dt), "after the optimiser step")
