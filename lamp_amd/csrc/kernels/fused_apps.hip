@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void sdpa_softmax_bwd_kernel(T* __restrict__ d
   }
 }
 
+bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
+                         int64_t Dv, int is_causal, double scale, hipStream_t st);   // attention.hip
+
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;
   LAMP_CHECK(fn(&o, a) == 0, lamp_last_error());
@@ -371,12 +374,21 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
   LAMP_CHECK(lamp_view(&q3, qc.get(), qs, 3) == 0, lamp_last_error()); Hold hq(q3);
   LAMP_CHECK(lamp_view(&k3, kc.get(), ks, 3) == 0, lamp_last_error()); Hold hk(k3);
   LAMP_CHECK(lamp_view(&v3, vc.get(), vs, 3) == 0, lamp_last_error()); Hold hv(v3);
-  int64_t ss[3] = {B * H, Sq, Sk};
-  Hold scores(new_tensor(ss, 3, q->dtype, q->device()));
-  LAMP_CHECK(lamp_baddbmm_out_transposed2(scores.get(), scores.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
   int64_t ls[3] = {B, H, Sq};
   Hold lse(new_tensor(ls, 3, q->dtype, q->device()));
   const int64_t rows = B * H * Sq;
+  if (rows && Sk) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate
+    int64_t os4[4] = {B, H, Sq, Dv};
+    Hold fo(new_tensor(os4, 4, q->dtype, q->device()));
+    if (flash_attention_fwd(q3, k3, v3, fo.get(), lse.get(), B * H, Sq, Sk, D, Dv, is_causal, scale, current_stream(q->device()))) {
+      *out = fo.take();
+      *logsumexp = lse.take();
+      return 0;
+    }
+  }
+  int64_t ss[3] = {B * H, Sq, Sk};
+  Hold scores(new_tensor(ss, 3, q->dtype, q->device()));
+  LAMP_CHECK(lamp_baddbmm_out_transposed2(scores.get(), scores.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
   if (rows) {
     LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0,
                                                         current_stream(q->device()), scores->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, scale, is_causal));

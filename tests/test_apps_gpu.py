@@ -148,6 +148,39 @@ def test_attention_matches_composed_softmax(gpu, dt, causal):
         assert_close(to_torch(S.STen(h)), r, btol, name)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 200, 200, 64), (1, 2, 130, 333, 128), (2, 2, 64, 64, 128), (1, 1, 1, 70, 64), (1, 2, 257, 96, 64)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_flash_attention_bf16(gpu, shape, causal):
+    """bf16 with head dim 64 / 128 takes the fused flash kernel (attention.hip): ragged Sq / Sk, Sq != Sk, causal masks that
+    leave whole key tiles unused.  Checked against an f64 softmax(QK^T)V of the same bf16-rounded inputs."""
+    Bz, H, Sq, Sk, D = shape
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(torch.bfloat16)
+    k, v = (torch.randn(Bz, H, Sk, D, generator=g, dtype=torch.float64).to(torch.bfloat16) for _ in range(2))
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    scores = qd @ kd.transpose(-1, -2) / np.sqrt(D)
+    if causal:
+        scores = scores.masked_fill(torch.triu(torch.ones(Sq, Sk, dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(scores, -1) @ vd
+    lse_ref = torch.logsumexp(scores, -1)
+    lib.lamp_kernel_timer_enable(1)
+    o, l = C.c_void_p(), C.c_void_p()
+    lib.lamp_scaled_dot_product_attention(C.byref(o), C.byref(l), to_sten(q), to_sten(k), to_sten(v), int(causal), 0.0)
+    Ot, Lt = S.STen(o), S.STen(l)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    assert b"sdpa_flash_fwd" in buf.value, "the fused kernel did not run"
+    assert_close(to_torch(Ot), ref.detach(), 2e-2, "attention output")
+    assert_close(to_torch(Lt), lse_ref.detach(), 2e-2, "logsumexp")
+    go = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(torch.bfloat16)
+    ref.backward(go.double())
+    out3 = (C.c_void_p * 3)()
+    lib.lamp_scaled_dot_product_attention_backward(out3, to_sten(go), to_sten(q), to_sten(k), to_sten(v), Ot, Lt, int(causal), 0.0)
+    for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
+        assert_close(to_torch(S.STen(h)), r, 6e-2, name)
+
+
 def test_knn_and_umap_at_full_size_properties(gpu):
     """BASELINE config 5 at its full size (1M x 128 f32 points, k = 10): size-independent properties instead of an oracle.
     kNN (262,144 query rows against all 1M points): the query itself is a neighbour at distance ~0, indices are in range and
