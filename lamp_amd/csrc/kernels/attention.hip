@@ -69,6 +69,10 @@ __device__ __forceinline__ float at_sum_x16_x32(float x) {
   return a + b;
 }
 
+__device__ __forceinline__ float at_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float at_fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float at_add1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <int DH>
 __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 bf16_t* __restrict__ o, bf16_t* __restrict__ lse, int Sq, int Sk, float scale, int causal) {
@@ -206,22 +210,29 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
 #pragma unroll
           for (int r = 0; r < 4; r++) s[t][mt][r] = (mt * 16 + r < lim) ? s[t][mt][r] : -INFINITY;
       }
-      float m_loc = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+      // v_max3 from asm: hipcc puts a canonicalising v_max in front of every fmaxf on an MFMA result
+      float m_loc = at_max3(s[t][0][0], s[t][0][1], s[t][0][2]);
+      m_loc = at_max3(m_loc, s[t][0][3], s[t][1][0]);
 #pragma unroll
-      for (int mt = 1; mt < 4; mt++) m_loc = fmaxf(fmaxf(fmaxf(m_loc, s[t][mt][0]), s[t][mt][1]), fmaxf(s[t][mt][2], s[t][mt][3]));
+      for (int mt = 1; mt < 4; mt++) {
+        m_loc = at_max3(m_loc, s[t][mt][1], s[t][mt][2]);
+        if (mt < 3) m_loc = at_max3(m_loc, s[t][mt][3], s[t][mt + 1][0]); else m_loc = at_max3(m_loc, s[t][mt][3], s[t][mt][3]);
+      }
       m_loc = at_max_x16_x32(m_loc) * c2;       // c2 > 0: max commutes with the scaling
-      const float m_new = fmaxf(m_run[t], m_loc);
+      // deferred max: the reference point moves only for a jump of 2^8 (p stays below 2^8: harmless in f32 / bf16), so the
+      // rescale of O is rare; -inf + 8 < anything finite starts it
+      const float m_new = (m_loc > m_run[t] + 8.f) ? m_loc : m_run[t];
       const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;   // rows with no visible key yet: every p is exp2(-inf) = 0
       const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_sub);
-      const at_f4 c2v = {c2, c2, c2, c2}, msv = {-m_sub, -m_sub, -m_sub, -m_sub};
       at_f4 psum = {0.f, 0.f, 0.f, 0.f};
+      // single-issue f32 ops (asm): hipcc would pack them into v_pk_*_f32, which costs more beside MFMAs than it saves
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++) {
-        const at_f4 e = __builtin_elementwise_fma(s[t][mt], c2v, msv);
+      for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) s[t][mt][r] = __builtin_amdgcn_exp2f(e[r]);
-        psum += s[t][mt];
-      }
+        for (int r = 0; r < 4; r++) {
+          s[t][mt][r] = __builtin_amdgcn_exp2f(at_fma1(s[t][mt][r], c2, -m_sub));
+          psum[r] = at_add1(psum[r], s[t][mt][r]);
+        }
       l_run[t] = l_run[t] * alpha + ((psum[0] + psum[1]) + (psum[2] + psum[3]));
       m_run[t] = m_new;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
@@ -279,9 +290,9 @@ bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
   if (!enabled) return false;
   if (q->dtype != kBF16 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
   if ((((uintptr_t)q->data() | (uintptr_t)k->data() | (uintptr_t)v->data() | (uintptr_t)out->data()) & 15) != 0) return false;
+  KernelTimer kt("sdpa_flash_fwd", 4.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 2.0 * Sk) * D * 2, st);
   const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
   const size_t lds = (size_t)4 * AT_BK * D * 2;
-  KernelTimer kt("sdpa_flash_fwd", 4.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 2.0 * Sk) * D * 2, st);
   if (D == 128) {
     static bool attr = false;
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
