@@ -2,7 +2,7 @@
  * lamp_host.h - C ABI of the host-side mirror of lamp-core's autograd / nn / optimiser layer.
  *
  * In the reference this layer is Scala running on the JVM ABOVE the JNI boundary
- * (lamp-core/src/main/scala/lamp/autograd/{autograd,ops}.scala, lamp/nn/*.scala,
+ * (lamp-core/src/main/scala/lamp/autograd/{autograd,ops}.scala, lamp/nn (all files),
  * lamp-data/.../distributed/package.scala); it only sequences aten.* calls.  No JVM exists in
  * the build environment, so the same sequencing logic is restated in C++ over lamp_hip.h and
  * exported here so that the parity tests and bench.py can drive the exact op sequences the
@@ -73,6 +73,8 @@ int lamp_optimizer_sgdw(lamp_optimizer** out, lamp_tensor* const* params, int n,
 int lamp_optimizer_step(lamp_optimizer* o, lamp_tensor* const* gradients /* NULL entries = None */, int n, double schedule_factor);
 int lamp_optimizer_num_state(lamp_optimizer* o, int64_t* out);
 int lamp_optimizer_state(lamp_optimizer* o, int64_t index, lamp_tensor** out);
+/* Optimizer.load (AdamW.scala:87-93, SGD.scala:38-42): copyFrom into the state tensors in order; AdamW re-reads its step count */
+int lamp_optimizer_load(lamp_optimizer* o, lamp_tensor* const* tensors, int n);
 int lamp_optimizer_release(lamp_optimizer* o);
 /* nn/package.scala:72-100 */
 int lamp_gradient_clipping_in_place(lamp_tensor* const* gradients, int n, double theta);
@@ -92,6 +94,35 @@ int lamp_model_forward_loss(lamp_model* m, const lamp_tensor* samples, const lam
 int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm_or_null, const lamp_tensor* samples, const lamp_tensor* target,
                           lamp_tensor* acc_or_null, int64_t* num_examples);
 int lamp_model_release(lamp_model* m);
+
+/* ---- tensor-list files and checkpoints (lamp-data Writer.scala:14-190, Reader.scala:17-95, schemas.scala:30-56) ----
+ * A list of tensors is a JSON descriptor {"tensors":[{"dims","dataType","byteOffset","byteLength"}...],"location",
+ * "byteOffset","byteLength"} at `path` plus the raw little-endian blob `path`.data (every tensor padded to a multiple
+ * of 8 bytes); `location` is relative to the descriptor unless absolute.  Files written here are readable by the
+ * reference's Reader and the other way round. */
+int lamp_write_tensors_into_file(lamp_tensor* const* tensors, int64_t n, const char* path);    /* Writer.writeTensorsIntoFile */
+int lamp_tensor_list_length(const char* path, int64_t* n);
+/* Reader.readTensorsFromFile(file, device, pin) with STen.tensorsFromFile's checks (STen.scala:157-168); device -1 = host */
+int lamp_read_tensors_from_file(lamp_tensor** out /* capacity */, int64_t capacity, int64_t* n_read, const char* path, int device, int pin);
+int lamp_module_write_checkpoint(lamp_module* m, const char* path);     /* Writer.writeCheckpoint: module.state in order */
+int lamp_module_load_from_file(lamp_module* m, const char* path);       /* Reader.loadFromFile: copyFrom per state tensor */
+
+/* Cifar.loadImageFile (example-cifar100/.../cifar100.scala:29-56): records of 3074 bytes (coarse label, fine label,
+ * 3x32x32 pixels); labels = i64 fine labels [n], images = [n, 3, 32, 32] cast to `dtype` (raw 0..255 values). */
+int lamp_cifar_load_image_file(lamp_tensor** labels, lamp_tensor** images, const char* path, int64_t num_images, int dtype, int device);
+
+/* ---- BatchStream.minibatchesFromFull (BatchStream.scala:528-592) + everyNth (:378-400) ----
+ * `order` is the shuffled row order (the caller owns the RNG: scala.util.Random.shuffle on the JVM); it is cut into groups of
+ * minibatch_size; drop_last removes the LAST group whether or not it is full, as the reference does.  The data set lives in
+ * HBM and a minibatch is one gather on the device.  next: *x = NULL at EndStream. */
+typedef struct lamp_batch_stream lamp_batch_stream;
+int lamp_batch_stream_from_full(lamp_batch_stream** out, const lamp_tensor* features, const lamp_tensor* target, const int64_t* order, int64_t n,
+                                int64_t minibatch_size, int drop_last, int device);
+int lamp_batch_stream_every_nth(lamp_batch_stream* s, int64_t n, int64_t offset);
+int lamp_batch_stream_num_batches(const lamp_batch_stream* s, int64_t* out);
+int lamp_batch_stream_next(lamp_batch_stream* s, lamp_tensor** x, lamp_tensor** target);
+int lamp_batch_stream_reset(lamp_batch_stream* s);
+int lamp_batch_stream_release(lamp_batch_stream* s);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,6 @@
 using namespace lamp;
 using namespace lamp::host;
 
-struct lamp_module { Mod m; };
 struct lamp_optimizer { std::shared_ptr<Optimizer> o; };
 struct lamp_model {
   SupervisedModel model;
@@ -181,6 +180,13 @@ int lamp_optimizer_state(lamp_optimizer* o, int64_t index, lamp_tensor** out) {
   auto s = o->o->state();
   LAMP_CHECK(index >= 0 && index < (int64_t)s.size(), "optimizer state index out of range");
   *out = give(s[index]);
+  LAMP_API_END
+}
+int lamp_optimizer_load(lamp_optimizer* o, lamp_tensor* const* tensors, int n) {
+  LAMP_API_BEGIN
+  std::vector<Ten> ts;
+  for (int i = 0; i < n; i++) { LAMP_CHECK(tensors[i], "Optimizer.load: NULL tensor"); ts.push_back(borrow(tensors[i])); }
+  o->o->load(ts);
   LAMP_API_END
 }
 int lamp_optimizer_release(lamp_optimizer* o) { LAMP_API_BEGIN delete o; LAMP_API_END }

@@ -193,6 +193,14 @@ std::vector<Ten> AdamW::state() {
   for (auto& t : workingCopy) if (t.defined()) s.push_back(t);
   return s;
 }
+void AdamW::load(const std::vector<Ten>& tensors) {
+  Optimizer::load(tensors);
+  if (!tensors.empty()) {   // stepCount = stepCountSTen.toDoubleArray(0).toLong
+    double v = 0;
+    HCALL(lamp_item(stepCountSTen.h(), &v));
+    stepCount = (int64_t)v;
+  }
+}
 void AdamW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
   LAMP_CHECK(gradients.size() == parameters.size(), "AdamW.step: got " << gradients.size() << " gradients for " << parameters.size() << " parameters");
   std::vector<lamp_tensor*> p, g, m, v, w;

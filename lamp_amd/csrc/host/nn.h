@@ -121,6 +121,11 @@ struct Optimizer {
   virtual ~Optimizer() = default;
   virtual void step(const std::vector<Ten>& gradients, double scheduleFactor) = 0;   // gradient may be undefined (None)
   virtual std::vector<Ten> state() = 0;
+  // Optimizer.load: copyFrom into every state tensor in order (AdamW.scala:87-93, SGD.scala:38-42)
+  virtual void load(const std::vector<Ten>& tensors) {
+    std::vector<Ten> st = state();
+    for (size_t i = 0; i < st.size() && i < tensors.size(); i++) ops::copy_(st[i], tensors[i]);
+  }
 };
 struct AdamW : Optimizer {      // nn/AdamW.scala:29-177
   std::vector<Ten> parameters, mt, vt, workingCopy;   // workingCopy[i] undefined when not mixed precision
@@ -132,6 +137,7 @@ struct AdamW : Optimizer {      // nn/AdamW.scala:29-177
         bool debias, bool mixed);
   void step(const std::vector<Ten>& gradients, double scheduleFactor) override;
   std::vector<Ten> state() override;
+  void load(const std::vector<Ten>& tensors) override;   // also restores stepCount from state()[0]
 };
 struct SGDW : Optimizer {       // nn/SGD.scala:19-99
   std::vector<Ten> parameters, velocity;
@@ -169,3 +175,5 @@ struct DataParallel {
 
 }  // namespace host
 }  // namespace lamp
+
+struct lamp_module { lamp::host::Mod m; };   // the C handle of lamp_host.h

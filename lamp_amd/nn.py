@@ -103,6 +103,10 @@ class Optimizer:
         hs = handle_array([g.h if g is not None else None for g in gradients])
         lib.lamp_optimizer_step(self.h, hs, len(gradients), float(scheduleFactor))
 
+    def load(self, tensors: Sequence[STen]):
+        """Optimizer.load (AdamW.scala:87-93): copy into the state tensors in order, restore the step count."""
+        lib.lamp_optimizer_load(self.h, handle_array([t.h for t in tensors]), len(tensors))
+
     @property
     def state(self) -> List[STen]:
         n = C.c_int64(); lib.lamp_optimizer_num_state(self.h, C.byref(n))

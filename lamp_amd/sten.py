@@ -18,7 +18,7 @@ from ._capi import lib, LampError, i64_array, f64_array, handle_array
 U8, I8, I16, I32, I64, F16, F32, F64, BOOL, BF16 = 0, 1, 2, 3, 4, 5, 6, 7, 11, 15
 _NP = {U8: np.uint8, I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, F32: np.float32, F64: np.float64,
        BOOL: np.bool_, BF16: np.uint16, F16: np.float16}
-_FROM_NP = {np.dtype(np.uint8): U8, np.dtype(np.int32): I32, np.dtype(np.int64): I64, np.dtype(np.float32): F32,
+_FROM_NP = {np.dtype(np.uint8): U8, np.dtype(np.int8): I8, np.dtype(np.int16): I16, np.dtype(np.int32): I32, np.dtype(np.int64): I64, np.dtype(np.float32): F32,
             np.dtype(np.float64): F64, np.dtype(np.bool_): BOOL, np.dtype(np.float16): F16}
 
 CPU = -1

@@ -1,0 +1,246 @@
+"""lamp-data rows: tensor-list files / checkpoints (Writer.scala, Reader.scala), Cifar.loadImageFile, BatchStream.
+
+CPU tests follow lamp-data/src/test/scala/lamp/data/ReadWrite.test.scala ("io empty", "io empty 2") on host tensors, and
+pin the descriptor text to the format the reference documents (Writer.scala:14-38, schemas.scala:30-56).  GPU tests follow
+"checkpoint modules" and batchstream.test.scala.  The JVM is not available here: byte-level agreement with a file written by
+the reference itself is unpinned; the descriptor grammar and blob layout are taken from the reference's specification."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lamp_amd import data as D, sten as S
+from lamp_amd._capi import LampError
+
+
+def _host(a, dtype=None):
+    return S.STen.from_numpy(np.asarray(a), device=S.CPU, dtype=dtype)
+
+
+def _reference_list():
+    """the tensors of ReadWrite.test.scala 'io empty' (ones(23,23) f64 / f32 / i64, empties, ones(3,3), i8, bf16)"""
+    return [_host(np.ones((23, 23))), _host(np.ones((23, 23), np.float32)), _host(np.ones((23, 23), np.int64)),
+            _host(np.zeros((0,))), _host(np.zeros((0, 0), np.float32)), _host(np.zeros((0,), np.int64)), _host(np.ones((3, 3))),
+            _host(np.ones((23,), np.int8)), _host(np.ones((23,), np.float32), dtype=S.BF16)]
+
+
+@pytest.mark.parametrize("pin", [False, pytest.param(True, marks=pytest.mark.gpu)])   # pinned memory needs the HIP runtime's device
+def test_io_round_trip_reference_list(tmp_path, pin):
+    ts = _reference_list()
+    f = str(tmp_path / "list")
+    D.writeTensorsIntoFile(ts, f)
+    back = D.readTensorsFromFile(f, S.CPU, pin)
+    assert len(back) == len(ts)
+    for a, b in zip(ts, back):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert np.array_equal(a.to_numpy(), b.to_numpy())
+
+
+def test_io_empty_2(tmp_path):
+    ts = [_host(np.zeros((0,))), _host(np.zeros((0, 0), np.float32)), _host(np.zeros((0,), np.int64))]
+    f = str(tmp_path / "e")
+    D.writeTensorsIntoFile(ts, f)
+    assert os.path.getsize(f + ".data") == 0
+    back = D.readTensorsFromFile(f, S.CPU, False)
+    assert [b.shape for b in back] == [[0], [0, 0], [0]] and [b.dtype for b in back] == [S.F64, S.F32, S.I64]
+    D.writeTensorsIntoFile([], f)
+    assert D.readTensorsFromFile(f, S.CPU, False) == []
+
+
+def test_descriptor_and_blob_layout(tmp_path):
+    """Known answer: the descriptor text (field order of the case classes, compact) and the blob bytes with 8-byte padding."""
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)          # 24 B
+    b = np.array([1, -2, 3], dtype=np.int8)                   # 3 B + 5 pad
+    c = np.array([7], dtype=np.int64)                         # 8 B
+    d = np.array([1.0, -2.5, 3.25], dtype=np.float32)         # bf16: 6 B + 2 pad
+    f = str(tmp_path / "ck")
+    D.writeTensorsIntoFile([_host(a), _host(b), _host(c), _host(d, dtype=S.BF16)], f)
+    text = open(f).read()
+    assert text == ('{"tensors":[{"dims":[2,3],"dataType":6,"byteOffset":0,"byteLength":24},'
+                    '{"dims":[3],"dataType":1,"byteOffset":24,"byteLength":3},'
+                    '{"dims":[1],"dataType":4,"byteOffset":32,"byteLength":8},'
+                    '{"dims":[3],"dataType":15,"byteOffset":40,"byteLength":6}],'
+                    '"location":"ck.data","byteOffset":0,"byteLength":48}')
+    blob = open(f + ".data", "rb").read()
+    bf = (np.array([1.0, -2.5, 3.25], np.float32).view(np.uint32) >> 16).astype("<u2").tobytes()
+    assert blob == a.astype("<f4").tobytes() + b.tobytes() + b"\0" * 5 + c.astype("<i8").tobytes() + bf + b"\0" * 2
+
+
+def test_reader_accepts_foreign_descriptor_and_checks_it(tmp_path):
+    """A descriptor as another writer may produce it: whitespace, reordered and unknown fields, absolute location, padding gaps;
+    and the reference's assertions (8-byte aligned tensor offsets, bounds, 4096-aligned list offset)."""
+    blob = str(tmp_path / "w.bin")
+    x = np.arange(5, dtype=np.float64)
+    with open(blob, "wb") as fh:
+        fh.write(b"\xff" * 16 + x.tobytes() + b"\0" * 8 + np.int64(9).tobytes())
+    desc = {"byteLength": 72, "byteOffset": 0, "location": blob, "extra": {"k": [1, 2, {"z": None}]},
+            "tensors": [{"byteLength": 40, "byteOffset": 16, "dataType": 7, "dims": [5], "note": "x"},
+                        {"dims": [], "dataType": 4, "byteOffset": 64, "byteLength": 8}]}
+    f = str(tmp_path / "w.json")
+    json.dump(desc, open(f, "w"), indent=2)
+    got = D.readTensorsFromFile(f)
+    assert np.array_equal(got[0].to_numpy(), x) and got[1].shape == [] and int(got[1].to_numpy()) == 9
+    for patch, msg in (({"byteOffset": 100}, "multiple of 4096"), ({"byteLength": 48}, "out of bound")):
+        json.dump({**desc, **patch}, open(f, "w"))
+        with pytest.raises(LampError, match=msg):
+            D.readTensorsFromFile(f)
+    bad = json.loads(json.dumps(desc)); bad["tensors"][0]["byteOffset"] = 12
+    json.dump(bad, open(f, "w"))
+    with pytest.raises(LampError, match="aligned to 8"):
+        D.readTensorsFromFile(f)
+    bad = json.loads(json.dumps(desc)); bad["tensors"][0]["dims"] = [4]
+    json.dump(bad, open(f, "w"))
+    with pytest.raises(LampError, match="do not match byteLength"):
+        D.readTensorsFromFile(f)
+    with pytest.raises(LampError, match="cannot open"):
+        D.readTensorsFromFile(str(tmp_path / "missing"))
+
+
+def test_java_random_known_answers():
+    """java.util.Random's published behaviour: new Random(42).nextInt(10) sequence starts 0, 3, 8, 4, 0, 5, 5, 8, 9, 3 (widely
+    quoted) and new Random(0).nextInt() & power-of-two bounds follow the documented LCG."""
+    r = D.JavaRandom(42)
+    assert [r.nextInt(10) for _ in range(10)] == [0, 3, 8, 4, 0, 5, 5, 8, 9, 3]
+    r = D.JavaRandom(0)
+    assert [r.nextInt(16) for _ in range(4)] == [(16 * v) >> 31 for v in _lcg31(0, 4)]
+    p = D.JavaRandom(7).shuffle(list(range(100)))
+    assert sorted(p) == list(range(100)) and p != list(range(100))
+
+
+def _lcg31(seed, n):
+    s = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+    out = []
+    for _ in range(n):
+        s = (s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        out.append(s >> 17)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_checkpoint_modules_float_and_mixed(gpu, tmp_path):
+    """ReadWrite.test.scala 'checkpoint modules - float' / '- mixed': write, load into a fresh module, states identical."""
+    from lamp_amd import nn
+    for dt2 in (S.F32, S.F64):
+        net = nn.Sequential(nn.Linear(5, 5, S.F32), nn.Linear(5, 5, dt2))
+        f = str(tmp_path / f"ck{dt2}")
+        D.writeCheckpoint(f, net)
+        net2 = nn.Sequential(nn.Linear(5, 5, S.F32), nn.Linear(5, 5, dt2))
+        assert any(not np.array_equal(a.value.to_numpy(), b.value.to_numpy()) for a, b in zip(net.state, net2.state))
+        D.loadFromFile(net2, f)
+        for a, b in zip(net.state, net2.state):
+            assert a.value.dtype == b.value.dtype and np.array_equal(a.value.to_numpy(), b.value.to_numpy())
+    # the file is an ordinary tensor list: readable straight onto the device, bf16 ResNet state included
+    net = nn.resnet(100, 0.0, S.BF16)
+    f = str(tmp_path / "resnet")
+    D.writeCheckpoint(f, net)
+    back = D.readTensorsFromFile(f, 0, True)
+    st = net.state
+    assert len(back) == len(st)
+    for a, b in zip(st, back):
+        assert b.device == 0 and a.value.shape == b.shape and np.array_equal(a.value.to_numpy(), b.to_numpy())
+    with pytest.raises(LampError, match="holds"):
+        D.loadFromFile(nn.Sequential(net, nn.Linear(3, 3)), f)
+
+
+@pytest.mark.gpu
+def test_cifar_records(gpu, tmp_path):
+    rng = np.random.default_rng(1)
+    n = 257
+    rec = rng.integers(0, 256, (n, 3074), dtype=np.uint8)
+    rec[:, 1] = rng.integers(0, 100, n)
+    f = str(tmp_path / "train.bin")
+    with open(f, "wb") as fh:
+        fh.write(rec.tobytes() + b"tail")                       # trailing bytes are ignored: length = numImages * 3074
+    for dt, npdt in ((S.F32, np.float32), (S.F64, np.float64), (S.BF16, np.float32)):
+        lab, img = D.loadImageFile(f, n, dt, 0)
+        assert lab.dtype == S.I64 and np.array_equal(lab.to_numpy(), rec[:, 1].astype(np.int64))
+        assert img.shape == [n, 3, 32, 32] and img.dtype == dt
+        assert np.array_equal(img.to_numpy(), rec[:, 2:].reshape(n, 3, 32, 32).astype(npdt))   # 0..255 are exact in bf16
+    with pytest.raises(LampError, match="fewer than"):
+        D.loadImageFile(f, n + 1, S.F32, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_resident", [False, True])
+def test_minibatches_from_full(gpu, host_resident):
+    """batchstream.test.scala: every row is served exactly once per epoch in the given order, groups of minibatchSize, dropLast
+    drops the LAST group (full or not), everyNth(n, k) keeps batches i % n == k."""
+    n, mb = 103, 10
+    x = np.arange(n * 6, dtype=np.float32).reshape(n, 2, 3)
+    y = np.arange(n, dtype=np.int64) * 7
+    dev = S.CPU if host_resident else 0
+    fx, fy = S.STen.from_numpy(x, dev), S.STen.from_numpy(y, dev)
+    order = D.JavaRandom(123).shuffle(list(range(n)))
+    for drop in (False, True):
+        st = D.BatchStream.minibatchesFromFull(mb, drop, fx, fy, order=order)
+        groups = [order[i:i + mb] for i in range(0, n, mb)]
+        if drop:
+            groups = groups[:-1]
+        assert st.numBatches == len(groups)
+        for epoch in range(2):
+            got = list(st)
+            assert len(got) == len(groups)
+            for (bx, by), g in zip(got, groups):
+                assert bx.device == 0 and np.array_equal(bx.to_numpy(), x[g]) and np.array_equal(by.to_numpy(), y[g])
+            assert st.nextBatch() is None
+            st.reset()
+    # a full last group is dropped too
+    st = D.BatchStream.minibatchesFromFull(10, True, fx, fy, order=order[:100])
+    assert st.numBatches == 9
+    # everyNth: the shards of a 3-rank job partition the batches
+    seen = []
+    for r in range(3):
+        st = D.BatchStream.minibatchesFromFull(mb, False, fx, fy, order=order).everyNth(3, r)
+        idx = [i for i in range(11) if i % 3 == r]
+        assert st.numBatches == len(idx)
+        for (bx, by), i in zip(st, idx):
+            assert np.array_equal(by.to_numpy(), y[order[i * mb:(i + 1) * mb]])
+            seen.append(i)
+    assert sorted(seen) == list(range(11))
+    with pytest.raises(LampError, match="out of range"):
+        D.BatchStream.minibatchesFromFull(mb, False, fx, fy, order=[0, n])
+
+
+@pytest.mark.gpu
+def test_training_from_stream_and_resume(gpu, tmp_path):
+    """End to end: CIFAR-style records -> device-resident stream -> a few training steps -> checkpoint -> a fresh model loaded
+    from it continues bit-identically to the original."""
+    import ctypes as C
+    from lamp_amd import nn
+    from lamp_amd._capi import lib
+    rng = np.random.default_rng(3)
+    n = 64
+    rec = rng.integers(0, 256, (n, 3074), dtype=np.uint8)
+    rec[:, 1] = np.arange(n) % 100
+    f = str(tmp_path / "c.bin")
+    open(f, "wb").write(rec.tobytes())
+    lab, img = D.loadImageFile(f, n, S.F32, 0)
+
+    def make():
+        lib.lamp_manual_seed(5)
+        net = nn.resnet(100, 0.0, S.F32)
+        model = nn.SupervisedModel(net, nn.SupervisedModel.NLL, S.STen.ones([100], S.F32, 0))
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3)([p.value for p in net.parameters])
+        return net, model, opt
+
+    def run(model, opt, order):
+        st = D.BatchStream.minibatchesFromFull(16, False, img, lab, order=order)
+        for bx, by in st:
+            model.train_step(opt, bx, by)
+
+    net, model, opt = make()
+    run(model, opt, list(range(n)))
+    ck = str(tmp_path / "ck")
+    D.writeCheckpoint(ck, net)
+    ock = str(tmp_path / "ock")
+    D.writeTensorsIntoFile(opt.state, ock)
+    net2, model2, opt2 = make()
+    D.loadFromFile(net2, ck)
+    opt2.load(D.readTensorsFromFile(ock, 0))
+    order2 = list(reversed(range(n)))
+    run(model, opt, order2)
+    run(model2, opt2, order2)
+    for a, b in zip(net.state, net2.state):
+        assert np.array_equal(a.value.to_numpy(), b.value.to_numpy())
