@@ -45,6 +45,7 @@ template <int DH> __device__ __forceinline__ int at_v_off(int key, int col8) {
 // drains it (s_waitcnt vmcnt(0)) in front of the first read of every tile, which exposes the whole K / V prefetch.  The
 // fences below are the s_waitcnt that "produce" the registers for the compiler's scheduler.
 template <int OFF> __device__ __forceinline__ void at_read128(at_s8& d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void at_read128f(at_f4& d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void at_read_tr(at_s4& d, unsigned a) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
 #define AT_FENCE2(WAIT, F) asm volatile(WAIT : "+v"(F[0]), "+v"(F[1]) : : "memory")
 #define AT_FENCE4(WAIT, F) asm volatile(WAIT : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) : : "memory")
@@ -69,13 +70,22 @@ __device__ __forceinline__ float at_sum_x16_x32(float x) {
   return a + b;
 }
 
+// Inline-asm VALU ops are invisible to hipcc's hazard recogniser: an asm instruction that reads an MFMA result too early gets stale
+// data (no hardware interlock).  These "settle" fences sit between the MFMAs and their first asm consumer: they depend on the
+// accumulators (so they are scheduled after the MFMAs) and spend the required wait states (11 for an 8-pass MFMA).
+#define AT_SETTLE "s_nop 7\n\ts_nop 7"
+__device__ __forceinline__ void at_settle2(at_f4& a, at_f4& b) { asm volatile(AT_SETTLE : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void at_settle4(at_f4& a, at_f4& b, at_f4& c, at_f4& d) { asm volatile(AT_SETTLE : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void at_settle8(at_f4& a, at_f4& b, at_f4& c, at_f4& d, at_f4& e, at_f4& f, at_f4& g, at_f4& h) {
+  asm volatile(AT_SETTLE : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
 __device__ __forceinline__ float at_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float at_fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float at_add1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                                bf16_t* __restrict__ o, bf16_t* __restrict__ lse, int Sq, int Sk, float scale, int causal) {
+                                                                bf16_t* __restrict__ o, float* __restrict__ lse, int Sq, int Sk, float scale, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DH / 32;                 // k-steps of the S^T product
   constexpr int DT = DH / 16;                 // 16-row tiles of O^T
@@ -196,6 +206,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
 #pragma unroll
         for (int t = 0; t < AT_QT; t++) s[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, kf[mt & 1][ks]), qf[t][ks], s[t][mt], 0, 0, 0);
     });
+    static_assert(AT_QT == 2, "the settle fence below lists the score tiles of two query tiles");
+    at_settle8(s[0][0], s[0][1], s[0][2], s[0][3], s[1][0], s[1][1], s[1][2], s[1][3]);
     // ---- online softmax: a lane owns 16 keys of each of its queries
     const bool need_mask = (kt * AT_BK + AT_BK > Sk) || (causal && kt * AT_BK + AT_BK - 1 > qw0);
     at_bf8 pf[AT_QT][2];
@@ -279,16 +291,16 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
       pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
       *reinterpret_cast<uint2*>(op + dt * 16 + g * 4) = pk;
     }
-    if (g == 0) lse[bh * (int64_t)Sq + qi[t]] = bf16_t(l_tot > 0.f ? (m_run[t] + __log2f(l_tot)) * 0.69314718055994530942f : -INFINITY);
+    if (g == 0) lse[bh * (int64_t)Sq + qi[t]] = l_tot > 0.f ? (m_run[t] + __log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
   }
 }
 
-// q, k, v: contiguous [BH, S, D] bf16.  Returns false when the shape is not covered (the caller composes the op instead).
+// q, k, v: contiguous [BH, S, D] bf16; lse: f32 [BH, Sq] (as ATen's logsumexp).  Returns false when the shape is not covered (the caller composes the op instead).
 bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
                          int64_t Dv, int is_causal, double scale, hipStream_t st) {
   static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
-  if (q->dtype != kBF16 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
+  if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
   if ((((uintptr_t)q->data() | (uintptr_t)k->data() | (uintptr_t)v->data() | (uintptr_t)out->data()) & 15) != 0) return false;
   KernelTimer kt("sdpa_flash_fwd", 4.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 2.0 * Sk) * D * 2, st);
   const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
@@ -297,12 +309,419 @@ bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
     static bool attr = false;
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((sdpa_flash_fwd_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), out->ptr<bf16_t>(),
-                       lse->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal);
   } else {
     hipLaunchKernelGGL((sdpa_flash_fwd_kernel<64>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), out->ptr<bf16_t>(),
-                       lse->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal);
   }
   LAMP_LAUNCH_CHECK();
+  return true;
+}
+
+// =====================================================================================================================
+// Backward (flash form): P is recomputed from Q, K and the forward's logsumexp; nothing of size S x S is stored.
+//   D_i  = sum_d dO[i][d] O[i][d]                               (sdpa_bwd_dsum_kernel, f32 [BH, Sq])
+//   dQ   = scale * (P o (dO V^T - D)) K                         (sdpa_flash_bwd_dq_kernel: workgroup = 128 queries, streams K / V)
+//   dK^T = scale * Q^T (P o (dO V^T - D)),  dV^T = dO^T P       (sdpa_flash_bwd_dkv_kernel: workgroup owns keys, streams Q / dO)
+// S and dP are computed in both kernels (7 instead of 5 matrix products per tile pair) so that neither needs a sum across
+// workgroups: no atomics, results independent of the schedule.
+// Every LDS tile is a [64 rows][DH] row-major image with the 32-byte-pair swizzle of at_v_off: it serves both the row reads
+// (ds_read_b128: rows x 8 consecutive d) and the transposing reads (ds_read_b64_tr_b16: d x 8 rows) without bank conflicts.
+// As in the forward, each product is oriented so that the contraction index of the NEXT product is the in-lane dimension of
+// this one's result: the dq kernel computes S^T / dP^T (lane = one query, 4 keys per tile), the dkv kernel S / dP (lane = one
+// key, 4 queries per tile), and the packed bf16 probabilities feed the next MFMA's B operand with no cross-lane traffic.
+// =====================================================================================================================
+template <int DH> __device__ __forceinline__ void at_dma_rows(const bf16_t* base, int row0, int nrows, char* lds, int wid, int lane) {
+  constexpr int VP = AT_BK * DH * 2 / 1024, CPR = DH / 8;
+#pragma unroll
+  for (int i = 0; i < VP / 4; i++) {
+    const int piece = wid * (VP / 4) + i;
+    const int pp = piece * 64 + lane;
+    const int row = pp / CPR, c = pp % CPR;
+    const int col8 = ((((c >> 1) ^ (row & (DH / 16 - 1)))) << 1) | (c & 1);
+    int r = row0 + row; r = r < nrows ? r : nrows - 1;
+    __builtin_amdgcn_global_load_lds((at_glb_t*)(base + (int64_t)r * DH + col8 * 8), (at_lds_t*)(lds + piece * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void sdpa_bwd_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ o, float* __restrict__ dsum, int64_t rows, int D) {
+  // 16 lanes per row, 8-element packets
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  float acc = 0.f;
+  if (row < rows) {
+    for (int c = l * 8; c < D; c += 128) {
+      const at_s8 a = *reinterpret_cast<const at_s8*>(dO + row * D + c), b = *reinterpret_cast<const at_s8*>(o + row * D + c);
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc += __uint_as_float((unsigned)(unsigned short)a[j] << 16) * __uint_as_float((unsigned)(unsigned short)b[j] << 16);
+    }
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (row < rows && l == 0) dsum[row] = acc;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                   const bf16_t* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                                   bf16_t* __restrict__ dq, int Sq, int Sk, float scale, int causal) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = DH / 32, DT = DH / 16, KIMG = AT_BK * DH * 2, PITCH = DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const int64_t bh = blockIdx.y;
+  const int q0 = (causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * AT_BQ;
+  const bf16_t* qp = q + bh * (int64_t)Sq * DH;
+  const bf16_t* dop = dO + bh * (int64_t)Sq * DH;
+  const bf16_t* kp = k + bh * (int64_t)Sk * DH;
+  const bf16_t* vp = v + bh * (int64_t)Sk * DH;
+  char* Kl = smem;                            // [2][KIMG]
+  char* Vl = smem + 2 * KIMG;                 // [2][KIMG]
+
+  const int qw0 = q0 + wid * (16 * AT_QT);
+  int qi[AT_QT];
+  at_bf8 qf[AT_QT][KS], dof[AT_QT][KS];
+  float lse2[AT_QT], dsm[AT_QT];
+#pragma unroll
+  for (int t = 0; t < AT_QT; t++) {
+    qi[t] = qw0 + t * 16 + (lane & 15);
+    const int qrow = qi[t] < Sq ? qi[t] : Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      qf[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(qp + (int64_t)qrow * DH + ks * 32 + g * 8));
+      dof[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(dop + (int64_t)qrow * DH + ks * 32 + g * 8));
+    }
+    lse2[t] = lse[bh * (int64_t)Sq + qrow] * 1.44269504088896340736f;
+    dsm[t] = dsum[bh * (int64_t)Sq + qrow];
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned rbase[KS], tbase[DT];               // row-read / transposing-read byte addresses in tile 0 of K
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) { rbase[ks] = lds0 + at_v_off<DH>(lane & 15, ks * 4 + g); asm volatile("" : "+v"(rbase[ks])); }
+  {
+    const int qq = (lane >> 2) & 3, pc = lane & 3;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) { tbase[dt] = lds0 + at_v_off<DH>(4 * g + qq, dt * 2 + (pc >> 1)) + ((pc & 1) << 3); asm volatile("" : "+v"(tbase[dt])); }
+  }
+  at_f4 acc[AT_QT][DT];
+#pragma unroll
+  for (int t = 0; t < AT_QT; t++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) acc[t][dt] = at_f4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = scale * 1.44269504088896340736f;
+
+  int nkt = (Sk + AT_BK - 1) / AT_BK;
+  if (causal) { const int last_q = min(q0 + AT_BQ, Sq) - 1; nkt = min(nkt, last_q / AT_BK + 1); }
+  if (nkt > 0) { at_dma_rows<DH>(kp, 0, Sk, Kl, wid, lane); at_dma_rows<DH>(vp, 0, Sk, Vl, wid, lane); }
+  for (int kt = 0; kt < nkt; kt++) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) { at_dma_rows<DH>(kp, (kt + 1) * AT_BK, Sk, Kl + (buf ^ 1) * KIMG, wid, lane); at_dma_rows<DH>(vp, (kt + 1) * AT_BK, Sk, Vl + (buf ^ 1) * KIMG, wid, lane); }
+    if (causal && kt * AT_BK > qw0 + 16 * AT_QT - 1) continue;
+    const unsigned koff = buf * KIMG, voff = 2 * KIMG + buf * KIMG;
+    const bool need_mask = (kt * AT_BK + AT_BK > Sk) || (causal && kt * AT_BK + AT_BK - 1 > qw0);
+    int lim[AT_QT];
+#pragma unroll
+    for (int t = 0; t < AT_QT; t++) lim[t] = (causal ? min(Sk, qi[t] + 1) : Sk) - kt * AT_BK - 4 * g;
+    // the 64 keys are processed as two halves of 32 (one k-step of the dQ product each): keeps 32 instead of 64 score registers live
+    at_static_for<0, 2>([&](auto tpc) {
+      constexpr int tp = decltype(tpc)::value;
+      at_f4 s[AT_QT][2], dp[AT_QT][2];
+      at_s8 fr[2][KS];
+      auto r_issue = [&](auto mtc, unsigned off, at_s8* dst) {
+        constexpr int mt = decltype(mtc)::value;
+        at_static_for<0, KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; at_read128<mt * 16 * PITCH>(dst[ks], rbase[ks] + off); });
+      };
+      // ---- S^T = K Q^T and dP^T = V dO^T for key tiles 2 tp, 2 tp + 1: 4 fragment sets stream through two register buffers
+      r_issue(std::integral_constant<int, 2 * tp>{}, koff, fr[0]);
+      at_static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, h = i & 1;
+        if constexpr (i == 0) r_issue(std::integral_constant<int, 2 * tp + 1>{}, koff, fr[1]);
+        if constexpr (i == 1) r_issue(std::integral_constant<int, 2 * tp>{}, voff, fr[0]);
+        if constexpr (i == 2) r_issue(std::integral_constant<int, 2 * tp + 1>{}, voff, fr[1]);
+        if constexpr (KS == 4) { if constexpr (i < 3) AT_FENCE4("s_waitcnt lgkmcnt(4)", fr[i & 1]); else AT_FENCE4("s_waitcnt lgkmcnt(0)", fr[i & 1]); }
+        else                   { if constexpr (i < 3) AT_FENCE2("s_waitcnt lgkmcnt(2)", fr[i & 1]); else AT_FENCE2("s_waitcnt lgkmcnt(0)", fr[i & 1]); }
+#pragma unroll
+        for (int t = 0; t < AT_QT; t++) { if constexpr (i < 2) s[t][h] = at_f4{0.f, 0.f, 0.f, 0.f}; else dp[t][h] = at_f4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int t = 0; t < AT_QT; t++) {
+            if constexpr (i < 2) s[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, fr[i & 1][ks]), qf[t][ks], s[t][h], 0, 0, 0);
+            else dp[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, fr[i & 1][ks]), dof[t][ks], dp[t][h], 0, 0, 0);
+          }
+      });
+      at_settle4(s[0][0], s[0][1], s[1][0], s[1][1]);
+      // ---- K^T fragments of these 32 keys fly during the elementwise part
+      at_s4 klo[DT], khi[DT];
+      at_static_for<0, DT>([&](auto dtc) {
+        constexpr int dt = decltype(dtc)::value;
+        at_read_tr<tp * 32 * PITCH>(klo[dt], tbase[dt] + koff);
+        at_read_tr<tp * 32 * PITCH + 16 * PITCH>(khi[dt], tbase[dt] + koff);
+      });
+      // ---- dS^T = P^T o (dP^T - D) * scale
+      at_bf8 dsf[AT_QT];
+#pragma unroll
+      for (int t = 0; t < AT_QT; t++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float p = __builtin_amdgcn_exp2f(at_fma1(s[t][h][r], c2, -lse2[t]));
+            if (need_mask) p = ((2 * tp + h) * 16 + r < lim[t]) ? p : 0.f;
+            dsf[t][4 * h + r] = (__bf16)(p * (dp[t][h][r] - dsm[t]) * scale);
+          }
+      }
+      // ---- dQ^T += K^T dS^T
+      if constexpr (DT == 8) { AT_FENCE8("s_waitcnt lgkmcnt(0)", klo); AT_FENCE8("", khi); }
+      else                   { AT_FENCE4("s_waitcnt lgkmcnt(0)", klo); AT_FENCE4("", khi); }
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const at_s4 lo = klo[dt], hi = khi[dt];
+        const at_s8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int t = 0; t < AT_QT; t++) acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, x), dsf[t], acc[t][dt], 0, 0, 0);
+      }
+    });
+  }
+#pragma unroll
+  for (int t = 0; t < AT_QT; t++) {
+    if (qi[t] >= Sq) continue;
+    bf16_t* op = dq + (bh * (int64_t)Sq + qi[t]) * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      const bf16_t o0(acc[t][dt][0]), o1(acc[t][dt][1]), o2(acc[t][dt][2]), o3(acc[t][dt][3]);
+      uint2 pk;
+      pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+      pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+      *reinterpret_cast<uint2*>(op + dt * 16 + g * 4) = pk;
+    }
+  }
+}
+
+// dK, dV: a wave owns NK key tiles of 16 (its K / V fragments stay in registers), the workgroup streams Q / dO / lse / D in
+// 64-query tiles and consumes them 32 queries at a time (one MFMA k-step of the dK / dV products).
+template <int DH, int NK>
+__global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                                 bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int Sq, int Sk, float scale, int causal) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = DH / 32, DT = DH / 16, KIMG = AT_BK * DH * 2, PITCH = DH * 2;
+  constexpr int BKW = 4 * 16 * NK;             // keys per workgroup
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const int64_t bh = blockIdx.y;
+  const int k0 = blockIdx.x * BKW;
+  const bf16_t* qp = q + bh * (int64_t)Sq * DH;
+  const bf16_t* dop = dO + bh * (int64_t)Sq * DH;
+  const bf16_t* kp = k + bh * (int64_t)Sk * DH;
+  const bf16_t* vp = v + bh * (int64_t)Sk * DH;
+  const float* lsep = lse + bh * (int64_t)Sq;
+  const float* dsp = dsum + bh * (int64_t)Sq;
+  char* Ql = smem;                            // [2][KIMG]
+  char* Ol = smem + 2 * KIMG;                 // [2][KIMG]  (dO)
+  char* Sl = smem + 4 * KIMG;                 // [2][2][64] f32: lse, D of the tile's 64 queries
+
+  const int kw0 = k0 + wid * (16 * NK);
+  int ki[NK];
+  at_bf8 kfr[NK][KS], vfr[NK][KS];
+#pragma unroll
+  for (int u = 0; u < NK; u++) {
+    ki[u] = kw0 + u * 16 + (lane & 15);
+    const int krow = ki[u] < Sk ? ki[u] : Sk - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      kfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(kp + (int64_t)krow * DH + ks * 32 + g * 8));
+      vfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(vp + (int64_t)krow * DH + ks * 32 + g * 8));
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned rbase[KS], tbase[DT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) { rbase[ks] = lds0 + at_v_off<DH>(lane & 15, ks * 4 + g); asm volatile("" : "+v"(rbase[ks])); }
+  {
+    const int qq = (lane >> 2) & 3, pc = lane & 3;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) { tbase[dt] = lds0 + at_v_off<DH>(4 * g + qq, dt * 2 + (pc >> 1)) + ((pc & 1) << 3); asm volatile("" : "+v"(tbase[dt])); }
+  }
+  at_f4 acck[NK][DT], accv[NK][DT];
+#pragma unroll
+  for (int u = 0; u < NK; u++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) { acck[u][dt] = at_f4{0.f, 0.f, 0.f, 0.f}; accv[u][dt] = at_f4{0.f, 0.f, 0.f, 0.f}; }
+  const float c2 = scale * 1.44269504088896340736f;
+
+  const int nqt = (Sq + AT_BK - 1) / AT_BK;
+  const int qt0 = causal ? min(k0 / AT_BK, nqt) : 0;    // queries before the block's first key see none of its keys
+  auto dma_stats = [&](int qt, int buf) {     // wave 0: lse, wave 1: D; one 4-byte element per lane
+    if (wid < 2) {
+      int r = qt * AT_BK + lane; r = r < Sq ? r : Sq - 1;
+      __builtin_amdgcn_global_load_lds((at_glb_t*)((wid == 0 ? lsep : dsp) + r), (at_lds_t*)(Sl + buf * 512 + wid * 256), 4, 0, 0);
+    }
+  };
+  const unsigned sbase = lds0 + 4 * KIMG + 16 * g;   // + buf * 512 + array * 256 + m * 64
+  if (qt0 < nqt) { at_dma_rows<DH>(qp, qt0 * AT_BK, Sq, Ql, wid, lane); at_dma_rows<DH>(dop, qt0 * AT_BK, Sq, Ol, wid, lane); dma_stats(qt0, 0); }
+  for (int qt = qt0; qt < nqt; qt++) {
+    const int buf = (qt - qt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (qt + 1 < nqt) {
+      at_dma_rows<DH>(qp, (qt + 1) * AT_BK, Sq, Ql + (buf ^ 1) * KIMG, wid, lane);
+      at_dma_rows<DH>(dop, (qt + 1) * AT_BK, Sq, Ol + (buf ^ 1) * KIMG, wid, lane);
+      dma_stats(qt + 1, buf ^ 1);
+    }
+    const unsigned qoff = buf * KIMG, ooff = 2 * KIMG + buf * KIMG;
+    // the lane's rows of a 16-query tile are 4 g .. 4 g + 3: its lse / D values are one 16-byte LDS read per tile
+    at_f4 lq[4], dq_[4];
+    at_static_for<0, 4>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      at_read128f<m * 64>(lq[m], sbase + buf * 512);
+      at_read128f<256 + m * 64>(dq_[m], sbase + buf * 512);
+    });
+    AT_FENCE4("s_waitcnt lgkmcnt(0)", lq); AT_FENCE4("", dq_);
+#pragma unroll
+    for (int m = 0; m < 4; m++) lq[m] *= 1.44269504088896340736f;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {      // 32 queries: tiles m = 2 half, 2 half + 1
+      at_f4 s[2][NK], dp[2][NK];
+      // ---- S = Q K^T, dP = dO V^T (A = rows of the Q / dO tile, B = the wave's resident K / V fragments)
+      at_static_for<0, 2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        const int m = 2 * half + h;
+        at_s8 fq[KS], fo[KS];
+        at_static_for<0, KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; at_read128<0>(fq[ks], rbase[ks] + qoff + m * 16 * PITCH); });
+        at_static_for<0, KS>([&](auto ksc) { constexpr int ks = decltype(ksc)::value; at_read128<0>(fo[ks], rbase[ks] + ooff + m * 16 * PITCH); });
+        if constexpr (KS == 4) { AT_FENCE4("s_waitcnt lgkmcnt(4)", fq); } else { AT_FENCE2("s_waitcnt lgkmcnt(2)", fq); }
+#pragma unroll
+        for (int u = 0; u < NK; u++) {
+          s[h][u] = at_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) s[h][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, fq[ks]), kfr[u][ks], s[h][u], 0, 0, 0);
+        }
+        if constexpr (KS == 4) { AT_FENCE4("s_waitcnt lgkmcnt(0)", fo); } else { AT_FENCE2("s_waitcnt lgkmcnt(0)", fo); }
+#pragma unroll
+        for (int u = 0; u < NK; u++) {
+          dp[h][u] = at_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) dp[h][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, fo[ks]), vfr[u][ks], dp[h][u], 0, 0, 0);
+        }
+      });
+      if constexpr (NK == 1) at_settle2(s[0][0], s[1][0]); else at_settle4(s[0][0], s[0][NK - 1], s[1][0], s[1][NK - 1]);
+      // ---- transposed dO fragments fly during the elementwise part
+      at_s4 tlo[DT], thi[DT];
+      auto t_issue = [&](unsigned off) {
+        at_static_for<0, DT>([&](auto dtc) {
+          constexpr int dt = decltype(dtc)::value;
+          at_read_tr<0>(tlo[dt], tbase[dt] + off + half * 32 * PITCH);
+          at_read_tr<16 * PITCH>(thi[dt], tbase[dt] + off + half * 32 * PITCH);
+        });
+      };
+      auto t_fence = [&]() {
+        if constexpr (DT == 8) { AT_FENCE8("s_waitcnt lgkmcnt(0)", tlo); AT_FENCE8("", thi); }
+        else                   { AT_FENCE4("s_waitcnt lgkmcnt(0)", tlo); AT_FENCE4("", thi); }
+      };
+      t_issue(ooff);
+      // ---- P and dS for the lane's key (column) and 8 queries; both become B operands: k-slot (g, j) <-> query 16 (j >> 2) + 4 g + (j & 3)
+      at_bf8 pb[NK], dsb[NK];
+#pragma unroll
+      for (int u = 0; u < NK; u++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int m = 2 * half + h;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int qidx = qt * AT_BK + m * 16 + 4 * g + r;
+            const bool ok = qidx < Sq && ki[u] < Sk && (!causal || ki[u] <= qidx);
+            const float p = ok ? __builtin_amdgcn_exp2f(at_fma1(s[h][u][r], c2, -lq[m][r])) : 0.f;
+            pb[u][4 * h + r] = (__bf16)p;
+            dsb[u][4 * h + r] = (__bf16)(p * (dp[h][u][r] - dq_[m][r]) * scale);
+          }
+        }
+      }
+      // ---- dV^T += dO^T P ; dK^T += Q^T dS
+      t_fence();
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const at_s8 x = {tlo[dt][0], tlo[dt][1], tlo[dt][2], tlo[dt][3], thi[dt][0], thi[dt][1], thi[dt][2], thi[dt][3]};
+#pragma unroll
+        for (int u = 0; u < NK; u++) accv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, x), pb[u], accv[u][dt], 0, 0, 0);
+      }
+      t_issue(qoff);
+      t_fence();
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const at_s8 x = {tlo[dt][0], tlo[dt][1], tlo[dt][2], tlo[dt][3], thi[dt][0], thi[dt][1], thi[dt][2], thi[dt][3]};
+#pragma unroll
+        for (int u = 0; u < NK; u++) acck[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf8, x), dsb[u], acck[u][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NK; u++) {
+    if (ki[u] >= Sk) continue;
+    bf16_t* okp = dk + (bh * (int64_t)Sk + ki[u]) * DH;
+    bf16_t* ovp = dv + (bh * (int64_t)Sk + ki[u]) * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      {
+        const bf16_t o0(acck[u][dt][0]), o1(acck[u][dt][1]), o2(acck[u][dt][2]), o3(acck[u][dt][3]);
+        uint2 pk; pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16); pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+        *reinterpret_cast<uint2*>(okp + dt * 16 + g * 4) = pk;
+      }
+      {
+        const bf16_t o0(accv[u][dt][0]), o1(accv[u][dt][1]), o2(accv[u][dt][2]), o3(accv[u][dt][3]);
+        uint2 pk; pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16); pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+        *reinterpret_cast<uint2*>(ovp + dt * 16 + g * 4) = pk;
+      }
+    }
+  }
+}
+
+// dq, dk, dv <- grad_out, q, k, v, out, lse (f32).  Returns false when the shape is not covered.
+bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
+                         Tensor* dv, Tensor* dsum /* f32 [BH * Sq] scratch */, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal,
+                         double scale, hipStream_t st) {
+  static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
+  if (!enabled) return false;
+  if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
+  const int64_t rows = BH * Sq;
+  hipLaunchKernelGGL(sdpa_bwd_dsum_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, go->ptr<bf16_t>(), out->ptr<bf16_t>(), dsum->ptr<float>(),
+                     rows, (int)D);
+  const size_t lds = (size_t)4 * AT_BK * D * 2 + 1024;
+  {
+    KernelTimer kt("sdpa_flash_bwd_dq", 6.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (3.0 * Sq + 2.0 * Sk) * D * 2, st);
+    const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
+    if (D == 128) {
+      static bool attr = false;
+      if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      hipLaunchKernelGGL((sdpa_flash_bwd_dq_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
+                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+    } else {
+      hipLaunchKernelGGL((sdpa_flash_bwd_dq_kernel<64>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
+                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+    }
+    LAMP_LAUNCH_CHECK();
+  }
+  {
+    KernelTimer kt("sdpa_flash_bwd_dkv", 8.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 4.0 * Sk) * D * 2, st);
+    if (D == 128) {
+      constexpr int NK = 1;
+      static bool attr = false;
+      if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_bwd_dkv_kernel<128, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      const dim3 grid((unsigned)((Sk + 64 * NK - 1) / (64 * NK)), (unsigned)BH);
+      hipLaunchKernelGGL((sdpa_flash_bwd_dkv_kernel<128, NK>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
+                         lse->ptr<float>(), dsum->ptr<float>(), dk->ptr<bf16_t>(), dv->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+    } else {
+      constexpr int NK = 2;
+      const dim3 grid((unsigned)((Sk + 64 * NK - 1) / (64 * NK)), (unsigned)BH);
+      hipLaunchKernelGGL((sdpa_flash_bwd_dkv_kernel<64, NK>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
+                         lse->ptr<float>(), dsum->ptr<float>(), dk->ptr<bf16_t>(), dv->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+    }
+    LAMP_LAUNCH_CHECK();
+  }
   return true;
 }
 

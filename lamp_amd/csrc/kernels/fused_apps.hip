@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void sdpa_softmax_bwd_kernel(T* __restrict__ d
 
 bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
                          int64_t Dv, int is_causal, double scale, hipStream_t st);   // attention.hip
+bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
+                         Tensor* dv, Tensor* dsum, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
 
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;
@@ -377,12 +379,12 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
   int64_t ls[3] = {B, H, Sq};
   Hold lse(new_tensor(ls, 3, q->dtype, q->device()));
   const int64_t rows = B * H * Sq;
-  if (rows && Sk) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate
+  if (rows && Sk && q->dtype == kBF16) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate; logsumexp is f32 as in ATen
     int64_t os4[4] = {B, H, Sq, Dv};
-    Hold fo(new_tensor(os4, 4, q->dtype, q->device()));
-    if (flash_attention_fwd(q3, k3, v3, fo.get(), lse.get(), B * H, Sq, Sk, D, Dv, is_causal, scale, current_stream(q->device()))) {
+    Hold fo(new_tensor(os4, 4, q->dtype, q->device())), lse32(new_tensor(ls, 3, kF32, q->device()));
+    if (flash_attention_fwd(q3, k3, v3, fo.get(), lse32.get(), B * H, Sq, Sk, D, Dv, is_causal, scale, current_stream(q->device()))) {
       *out = fo.take();
-      *logsumexp = lse.take();
+      *logsumexp = lse32.take();
       return 0;
     }
   }
@@ -405,11 +407,24 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
 int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* q, const lamp_tensor* k,
                                                const lamp_tensor* v, const lamp_tensor* out, const lamp_tensor* logsumexp, int is_causal, double scale) {
   LAMP_API_BEGIN
-  (void)out; (void)logsumexp;   // P is recomputed from q and k (same numerics as the forward)
   check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value"); check_device_tensor(grad_out, "grad_out");
   const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
   if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
   Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v)), gc(contiguous(grad_out));
+  // flash form: needs the forward's output and its f32 logsumexp (what the fused forward returns)
+  if (q->dtype == kBF16 && out && logsumexp && logsumexp->dtype == kF32 && out->dtype == kBF16 && B * H * Sq > 0 && Sk > 0 && grad_out->dtype == kBF16 &&
+      logsumexp->numel() == B * H * Sq && out->numel() == B * H * Sq * Dv) {
+    Hold oc(contiguous(out)), lc(contiguous(logsumexp));
+    int64_t n1[1] = {B * H * Sq};
+    Hold dsum(new_tensor(n1, 1, kF32, q->device()));
+    Hold fdq(new_tensor(q->sizes, 4, kBF16, q->device())), fdk(new_tensor(k->sizes, 4, kBF16, q->device())), fdv(new_tensor(v->sizes, 4, kBF16, q->device()));
+    if (flash_attention_bwd(gc.get(), qc.get(), kc.get(), vc.get(), oc.get(), lc.get(), fdq.get(), fdk.get(), fdv.get(), dsum.get(), B * H, Sq, Sk, D, Dv,
+                            is_causal, scale, current_stream(q->device()))) {
+      out3[0] = fdq.take(); out3[1] = fdk.take(); out3[2] = fdv.take();
+      return 0;
+    }
+  }
+  // composed: P is recomputed from q and k (same numerics as the composed forward)
   int64_t qs[3] = {B * H, Sq, D}, ks[3] = {B * H, Sk, D}, vs[3] = {B * H, Sk, Dv}, gs[3] = {B * H, Sq, Dv};
   lamp_tensor *q3 = nullptr, *k3 = nullptr, *v3 = nullptr, *g3 = nullptr;
   LAMP_CHECK(lamp_view(&q3, qc.get(), qs, 3) == 0, lamp_last_error()); Hold hq(q3);

@@ -176,9 +176,14 @@ def test_flash_attention_bf16(gpu, shape, causal):
     go = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(torch.bfloat16)
     ref.backward(go.double())
     out3 = (C.c_void_p * 3)()
+    lib.lamp_kernel_timer_enable(1)
     lib.lamp_scaled_dot_product_attention_backward(out3, to_sten(go), to_sten(q), to_sten(k), to_sten(v), Ot, Lt, int(causal), 0.0)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    assert b"sdpa_flash_bwd_dq" in buf.value and b"sdpa_flash_bwd_dkv" in buf.value, "the fused backward did not run"
+    assert Lt.dtype == S.F32
     for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
-        assert_close(to_torch(S.STen(h)), r, 6e-2, name)
+        assert_close(to_torch(S.STen(h)), r, 3e-2, name)
 
 
 def test_knn_and_umap_at_full_size_properties(gpu):
