@@ -456,6 +456,35 @@ Var capped_shifted_negative_exponential(const Var& a, double shift) {
   return make_result(op, result);
 }
 
+// ScaledDotProductAttention (ops.scala:2342-2390): joinedBackward - one backward call yields the three gradients.  Here the first
+// closure that runs makes the call and parks the other two results for its siblings (same p), as batch norm does above.
+Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal) {
+  auto op = new_op("ScaledDotProductAttention");
+  lamp_tensor *o = nullptr, *l = nullptr;
+  HCALL(lamp_scaled_dot_product_attention(&o, &l, query->value.h(), key->value.h(), value->value.h(), isCausal, 0.0));
+  Ten out(o), lse(l);
+  struct Cache { Ten g[3]; Ten p; };
+  auto cache = std::make_shared<Cache>();
+  const Ten qv = query->value, kv = key->value, vv = value->value;
+  auto back = [=](int which) {
+    return [=](const Ten& p, Variable& acc) {
+      if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
+        lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
+        HCALL(lamp_scaled_dot_product_attention_backward(r3, p.h(), qv.h(), kv.h(), vv.h(), out.h(), lse.h(), isCausal, 0.0));
+        for (int i = 0; i < 3; i++) cache->g[i] = Ten(r3[i]);
+        cache->p = p;
+      }
+      acc.accumulate(cache->g[which], true);
+      cache->g[which] = Ten();
+      if (!cache->g[0].defined() && !cache->g[1].defined() && !cache->g[2].defined()) cache->p = Ten();
+    };
+  };
+  op->params.push_back({query, back(0)});
+  op->params.push_back({key, back(1)});
+  op->params.push_back({value, back(2)});
+  return make_result(op, out);
+}
+
 // ---- convolution / pooling (ops.scala:1547-1825) ------------------------------------------------
 Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                 const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,

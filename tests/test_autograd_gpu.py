@@ -183,3 +183,26 @@ def test_train_step_entry_point(gpu):
         assert m2.train_step(o2, x, t) == 8
     for a, b in zip(hm1.state, hm2.state):
         assert np.array_equal(a.value.to_numpy(), b.value.to_numpy())
+
+
+@pytest.mark.parametrize("dt,D,tol", [(torch.float32, 16, 1e-4), (torch.bfloat16, 64, 4e-2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_scaled_dot_product_attention_op(gpu, dt, D, tol, causal):
+    """The ScaledDotProductAttention op (ops.scala:2342-2390): one backward call feeds the three parents; a parent used twice
+    (q is also the value here) accumulates both contributions.  f32 takes the composed kernels, bf16 with head dim 64 the fused ones."""
+    g = torch.Generator().manual_seed(9)
+    Bz, H, Sq = 2, 2, 70
+    q0, k0 = (torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt) for _ in range(2))
+    w0 = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt)
+    qd, kd = (t.double().clone().requires_grad_(True) for t in (q0, k0))
+    sc = qd @ kd.transpose(-1, -2) / np.sqrt(D)
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(Sq, Sq, dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(sc, -1) @ qd
+    (ref * w0.double()).sum().backward()
+    q, k = A.param(to_sten(q0)), A.param(to_sten(k0))
+    out = q.scaledDotProductAttention(k, q, causal)
+    assert_close(to_torch(out.value), ref.detach(), tol, "attention output")
+    (out * A.const(to_sten(w0))).sum().backprop()
+    assert_close(to_torch(q.partialDerivative), qd.grad, tol, "dq (+ dv: q is also the value)")
+    assert_close(to_torch(k.partialDerivative), kd.grad, tol, "dk")
