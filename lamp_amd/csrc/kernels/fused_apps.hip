@@ -133,6 +133,9 @@ bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
 bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
                          Tensor* dv, Tensor* dsum, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
 
+bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
+               int64_t k, hipStream_t st);   // knn_fused.hip
+
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;
   LAMP_CHECK(fn(&o, a) == 0, lamp_last_error());
@@ -213,6 +216,17 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   int64_t one = 1;
   Hold dn(reduce_dims(d2.get(), &one, 1, true, 0)), qn(reduce_dims(q2.get(), &one, 1, true, 0));
   d2 = Hold(); q2 = Hold();
+  // f32, 64 / 128 features, k <= 16: top-k fused into the distance GEMM, no distance block at all (knn_fused.hip)
+  if (Q > 0) {
+    int64_t os[2] = {Q, k};
+    Hold fi(new_tensor(os, 2, kI64, data->device())), fv(new_tensor(os, 2, data->dtype, data->device()));
+    Hold dnc(contiguous(dn.get())), qnc(contiguous(qn.get()));
+    if (knn_fused(qc.get(), dc.get(), qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, dim, k, st)) {
+      *indices = fi.take();
+      if (distances) *distances = fv.take();
+      return 0;
+    }
+  }
   // column chunk so that the Q x chunk block stays around 256 MB
   int64_t chunk = std::max<int64_t>(k, std::min<int64_t>(N, (int64_t)(256ll << 20) / (int64_t)(std::max<int64_t>(Q, 1) * data->itemsize())));
   chunk = std::max<int64_t>(chunk, std::min<int64_t>(N, 1024));

@@ -21,3 +21,19 @@ graph_s = t1 - t0
 it_ms = ((t2 - t1) - graph_s) / iters * 1e3
 print(f"umap n={n}: host->device + kNN graph + distances + edge weights {graph_s:.2f} s ({b.shape[0]} edges); layout {it_ms:.1f} ms/iteration "
       f"-> 500 iterations {graph_s + 0.5 * it_ms:.1f} s total; final loss {loss:.4f}")
+
+# per-kernel-class breakdown of the layout iterations
+import ctypes as C
+knn = U.knn_search(*(lambda X: (X, X))(__import__("lamp_amd").sten.STen.from_numpy(data.astype(np.float32), 0)), 10)
+X64 = __import__("lamp_amd").sten.STen.from_numpy(data, 0)
+d = C.c_void_p(); lib.lamp_knn_row_distances(C.byref(d), X64, knn)
+ew = U.edge_weights(__import__("lamp_amd").sten.STen(d), knn)
+lib.lamp_kernel_timer_enable(1)
+U.optimize(ew, n, 0.1, 10, 0.0, 5, 42, True, 1.0, 0, 2)
+buf = C.create_string_buffer(1 << 16)
+lib.lamp_kernel_timer_report(buf, len(buf))
+lib.lamp_kernel_timer_enable(0)
+rows = [l.split() for l in buf.value.decode().splitlines()]
+rows.sort(key=lambda r: -float(r[2]))
+for tag, cnt, ms, fl, by in rows[:12]:
+    print(f"   {tag:28s} launches/iter {int(cnt) / 10:6.1f}  ms/iter {float(ms) / 10:8.3f}")
