@@ -96,67 +96,35 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const float* __restri
   for (int j = 0; j < NJ; j++) { bbase[j] = lds0 + c16 * ROWB + ((((4 * j + g) ^ c16)) << 4); asm volatile("" : "+v"(bbase[j])); }
 
   const int nit = (N + KF_BC - 1) / KF_BC;
-  float dnc[4], dnn[4];
+  float dnc[4], dnn[4], dno[4];                // column norms of the tile being multiplied / the next one / the one being filtered
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++) { int col = 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; }
-  dma_tile(0, 0);
-  for (int it = 0; it < nit; it++) {
-    const int buf = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  for (int ct = 0; ct < 4; ct++) { int col = 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; dno[ct] = 0.f; }
+  kf_f4 old[2][4];                             // dot products of the previous tile: filtered while this tile multiplies
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) dnc[ct] = dnn[ct];
-    if (it + 1 < nit) {
-      dma_tile(it + 1, buf ^ 1);
+  for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) { int col = (it + 1) * KF_BC + 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; }
-    }
-    // ---- 32 x 64 dot products
-    kf_f4 acc[2][4];
+    for (int ct = 0; ct < 4; ct++) old[t][ct] = kf_f4{0.f, 0.f, 0.f, 0.f};
+  int col0_old = N;                            // no valid column: the first pass filters nothing
+
+  // distances of one accumulator tile in the reference's operation order: (|q|^2 + |x|^2) - 2 q.x, then the clamp
+  auto dist4 = [&](const kf_f4& a, int t, float dnv, float* v) {
 #pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[t][ct] = kf_f4{0.f, 0.f, 0.f, 0.f};
-    const unsigned boff = buf * TILE;
-    kf_f4 bf[2][4];
-    auto b_issue = [&](auto jc, kf_f4* dst) {
-      constexpr int j = decltype(jc)::value;
-      kf_read128<0 * 16 * ROWB>(dst[0], bbase[j] + boff);
-      kf_read128<1 * 16 * ROWB>(dst[1], bbase[j] + boff);
-      kf_read128<2 * 16 * ROWB>(dst[2], bbase[j] + boff);
-      kf_read128<3 * 16 * ROWB>(dst[3], bbase[j] + boff);
-    };
-    b_issue(std::integral_constant<int, 0>{}, bf[0]);
-    kf_static_for<0, NJ>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (j + 1 < NJ) { b_issue(std::integral_constant<int, j + 1>{}, bf[(j + 1) & 1]); KF_FENCE4("s_waitcnt lgkmcnt(4)", bf[j & 1]); }
-      else KF_FENCE4("s_waitcnt lgkmcnt(0)", bf[j & 1]);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-          for (int t = 0; t < 2; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[t][j][i], bf[j & 1][ct][i], acc[t][ct], 0, 0, 0);
-    });
-    // ---- distances and selection
-    const int col0 = it * KF_BC;
+    for (int r = 0; r < 4; r++) { const float d = (qnr[t][r] + dnv) - 2.f * a[r]; v[r] = d > 0.f ? d : 0.f; }
+  };
+  // slow path (probability ~ k / points seen per candidate): append the passing candidates of every accumulator tile to the
+  // wave's buffer (ballot + prefix count) and let lane r insert the entries of row r into that row's sorted list
+  auto select_tile = [&](const kf_f4 (&a)[2][4], const float* dnv, int c0) {
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
-        const int col = col0 + 16 * ct + c16;
+        const int col = c0 + 16 * ct + c16;
         float v[4];
+        dist4(a[t][ct], t, dnv[ct], v);
         bool pass[4], any = false;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float s = qnr[t][r] + dnc[ct];          // the reference's operation order: (|q|^2 + |x|^2) - 2 q.x, then the clamp
-          const float d = s - 2.f * acc[t][ct][r];
-          v[r] = d > 0.f ? d : 0.f;
-          pass[r] = col < N && v[r] < thr[t][r];
-          any |= pass[r];
-        }
+        for (int r = 0; r < 4; r++) { pass[r] = col < N && v[r] < thr[t][r]; any |= pass[r]; }
         if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
-        // append: ballot + prefix count, the buffer is private to the wave
         int cnt = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -168,7 +136,6 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const float* __restri
           cnt += __builtin_popcountll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // lane r inserts the entries of row r, in buffer order
         if (lane < 32) {
           float* lv = ws->lv[lane];
           int* li = ws->li[lane];
@@ -189,7 +156,74 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const float* __restri
 #pragma unroll
           for (int r = 0; r < 4; r++) thr[tt][r] = ws->thr[16 * tt + 4 * g + r];
       }
+  };
+  // branch-free test "does any candidate of the tile beat its row's k-th best": plain VALU work the scheduler can place
+  // between the MFMAs of the next tile
+  auto any_pass = [&](const kf_f4 (&a)[2][4], const float* dnv, int c0) {
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        float v[4];
+        dist4(a[t][ct], t, dnv[ct], v);
+        const bool in = c0 + 16 * ct + c16 < N;
+#pragma unroll
+        for (int r = 0; r < 4; r++) any |= in && v[r] < thr[t][r];
+      }
+    return any;
+  };
+
+  dma_tile(0, 0);
+  for (int it = 0; it < nit; it++) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) dnc[ct] = dnn[ct];
+    if (it + 1 < nit) {
+      dma_tile(it + 1, buf ^ 1);
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) { int col = (it + 1) * KF_BC + 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; }
+    }
+    // ---- 32 x 64 dot products of tile `it`, with the filter of tile `it - 1` in the same basic block
+    kf_f4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[t][ct] = kf_f4{0.f, 0.f, 0.f, 0.f};
+    const unsigned boff = buf * TILE;
+    kf_f4 bf[2][4];
+    auto b_issue = [&](auto jc, kf_f4* dst) {
+      constexpr int j = decltype(jc)::value;
+      kf_read128<0 * 16 * ROWB>(dst[0], bbase[j] + boff);
+      kf_read128<1 * 16 * ROWB>(dst[1], bbase[j] + boff);
+      kf_read128<2 * 16 * ROWB>(dst[2], bbase[j] + boff);
+      kf_read128<3 * 16 * ROWB>(dst[3], bbase[j] + boff);
+    };
+    b_issue(std::integral_constant<int, 0>{}, bf[0]);
+    const bool hit = any_pass(old, dno, col0_old);
+    kf_static_for<0, NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < NJ) { b_issue(std::integral_constant<int, j + 1>{}, bf[(j + 1) & 1]); KF_FENCE4("s_waitcnt lgkmcnt(4)", bf[j & 1]); }
+      else KF_FENCE4("s_waitcnt lgkmcnt(0)", bf[j & 1]);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+          for (int t = 0; t < 2; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[t][j][i], bf[j & 1][ct][i], acc[t][ct], 0, 0, 0);
+    });
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) select_tile(old, dno, col0_old);
+    col0_old = it * KF_BC;
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) dno[ct] = dnc[ct];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) old[t][ct] = acc[t][ct];
   }
+  select_tile(old, dno, col0_old);
   // ---- results: row lane of the wave
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < 32 && q0 + lane < Q) {
