@@ -89,6 +89,77 @@ __global__ __launch_bounds__(256) void umap_pairs_kernel(const T* __restrict__ l
   local = block_sum(local, sm);
   if (threadIdx.x == 0) atomicAdd(loss_acc, local);
 }
+// 2-D layouts (the default numDim): a lane pair per pair of points, one lane per coordinate.
+// Float atomics execute at the memory side as 64-byte requests, ~20 G requests/s chip-wide, and that rate - not bytes - bounds
+// this kernel: the generic kernel above issues 4 requests per pair.  Here (1) the x and y adds of a point leave in ONE wave
+// instruction from adjacent lanes (same 64-byte line: one request), and (2) the contributions to the FIRST point of a pair are
+// summed across the wave before the atomic: the edge list is sorted by that index (runs of ~k attractive and ~k * negatives
+// repulsive pairs per point), so a segmented scan leaves one atomic per run.  ~1.1 requests per pair instead of 4.
+// The distance and the loss terms are computed exactly as above (d^2 = dx^2 + dy^2 in that order on both lanes).
+template <class T>
+__global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ loc, const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
+                                                          const T* __restrict__ b, int64_t E1, const int64_t* __restrict__ i3, const int64_t* __restrict__ i4,
+                                                          int64_t E2, const T* __restrict__ bsum, double min_dist, int balance, double strength,
+                                                          double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc) {
+  __shared__ double sm[4];
+  double local = 0.0;
+  const double attr_scale = balance ? 1.0 / (double)bsum[0] : 1.0;
+  const double rep_scale = balance ? strength / (double)E2 : 1.0;
+  const int lane = threadIdx.x & 63, dim = threadIdx.x & 1;
+  const int64_t E = E1 + E2;
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 1);
+  const int64_t rounds = (E + stride - 1) / stride;                // the same trip count for every lane: the loop body shuffles
+  int64_t e = blockIdx.x * (int64_t)(blockDim.x >> 1) + (threadIdx.x >> 1);
+  for (int64_t it = 0; it < rounds; it++, e += stride) {
+    const bool valid = e < E;
+    const int64_t ee = valid ? e : E - 1;
+    const bool attr = ee < E1;
+    const int64_t a = attr ? i1[ee] : i3[ee - E1], c = attr ? i2[ee] : i4[ee - E1];
+    const double diff = (double)loc[a * 2 + dim] - (double)loc[c * 2 + dim];
+    const double sq = diff * diff, sq_o = __shfl_xor(sq, 1, 64);
+    const double d2 = dim == 0 ? (0.0 + sq) + sq_o : (0.0 + sq_o) + sq;
+    const double d = sqrt(d2);
+    double dl_dd, term;
+    if (attr) {
+      const double bb = (double)b[ee];
+      if (min_dist == 0.0) { term = bb * d * attr_scale; dl_dd = bb * attr_scale; }
+      else {
+        const double f = d <= min_dist ? 1.0 : exp(min_dist - d);
+        term = -bb * log(f) * attr_scale;
+        dl_dd = d <= min_dist ? 0.0 : bb * attr_scale;
+      }
+    } else {
+      if (min_dist == 0.0) {
+        const double ex = exp(-d);
+        term = -rep_scale * log1p(-ex);
+        dl_dd = -rep_scale * ex / (1.0 - ex);
+      } else {
+        const double f = d <= min_dist ? 1.0 : exp(min_dist - d);
+        term = -rep_scale * log1p(-f + 1e-6);
+        dl_dd = d <= min_dist ? 0.0 : -rep_scale * f / (1.0 + 1e-6 - f);
+      }
+    }
+    if (valid && dim == 0) local += term;
+    const double unit = diff / d;                                   // NaN at d == 0, as in the reference
+    const double wa = attr ? w1 : w3, wc = attr ? w2 : w4;
+    T ga = valid ? (T)(wa * dl_dd * unit) : T(0);
+    const T gc = (T)(-wc * dl_dd * unit);
+    if (valid) atomicAdd(&grad[c * 2 + dim], gc);
+    // segmented inclusive scan over the pairs of the wave that share the first point (lane distance 2 per pair)
+    const int64_t akey = valid ? a : -1 - (int64_t)lane;            // invalid lanes never merge
+    const int64_t aprev = __shfl_up(akey, 2, 64), anext = __shfl_down(akey, 2, 64);
+    int closed = lane < 2 || aprev != akey;                         // the run's first pair is already included in the sum
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) {
+      const T up = __shfl_up(ga, off, 64);
+      const int cup = __shfl_up(closed, off, 64);
+      if (lane >= off && !closed) { ga += up; closed = cup; }
+    }
+    if (valid && (lane >= 62 || anext != akey)) atomicAdd(&grad[a * 2 + dim], ga);
+  }
+  local = block_sum(local, sm);
+  if (threadIdx.x == 0) atomicAdd(loss_acc, local);
+}
 template <class T> __global__ void cast_scalar_kernel(const double* in, T* out) { *out = (T)(*in); }
 
 // ---- attention helpers ---------------------------------------------------------------------------------------
@@ -358,7 +429,20 @@ int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_
   Hold out(new_tensor(nullptr, 0, locations->dtype, locations->device()));
   const double w[4] = {term_weights ? term_weights[0] : 1.0, term_weights ? term_weights[1] : 1.0, term_weights ? term_weights[2] : 1.0,
                        term_weights ? term_weights[3] : 1.0};
-  if (locations->dtype == kF64) {
+  static const bool pairs2 = [] { const char* e = getenv("LAMP_UMAP_PAIRS2"); return !(e && e[0] == '0'); }();
+  if (pairs2 && locations->sizes[1] == 2 && E1 + E2 > 0) {
+    if (locations->dtype == kF64) {
+      hipLaunchKernelGGL((umap_pairs2_kernel<double>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<double>(), index1->ptr<int64_t>(),
+                         index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<double>(), min_dist, balance,
+                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>());
+      hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
+    } else {
+      hipLaunchKernelGGL((umap_pairs2_kernel<float>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<float>(), index1->ptr<int64_t>(),
+                         index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<float>(), min_dist, balance,
+                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>());
+      hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
+    }
+  } else if (locations->dtype == kF64) {
     hipLaunchKernelGGL((umap_pairs_kernel<double>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<double>(), locations->sizes[1],
                        index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
                        bsum->ptr<double>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>());
