@@ -481,6 +481,13 @@ int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_
                         const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
                         const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
                         int balance, double repulsion_strength, const double* term_weights);
+/* Same, with the reference's `mask = i.ne(j); i.maskedSelect(mask); j.maskedSelect(mask)` (umap.scala:221-227) folded in:
+ * negative pairs with index3[e] == index4[e] are ignored and the repulsion is normalised by the number of pairs kept
+ * (counted on the device).  Saves the two 45M-element compactions per iteration at 1M points. */
+int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations,
+                                  const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
+                                  const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
+                                  int balance, double repulsion_strength, const double* term_weights);
 
 /* ------------------------------------------------------------------------------------------
  * collectives over RCCL / xGMI   (aten.NcclComm.{get_unique_id, comm_init_rank, broadcast,

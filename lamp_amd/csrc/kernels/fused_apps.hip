@@ -48,14 +48,15 @@ template <class T>
 __global__ __launch_bounds__(256) void umap_pairs_kernel(const T* __restrict__ loc, int64_t D, const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
                                                          const T* __restrict__ b, int64_t E1, const int64_t* __restrict__ i3, const int64_t* __restrict__ i4,
                                                          int64_t E2, const T* __restrict__ bsum, double min_dist, int balance, double strength,
-                                                         double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc) {
+                                                         double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc, const int64_t* __restrict__ e2_kept, int skip_self) {
   __shared__ double sm[4];
   double local = 0.0;
   const double attr_scale = balance ? 1.0 / (double)bsum[0] : 1.0;
-  const double rep_scale = balance ? strength / (double)E2 : 1.0;
+  const double rep_scale = balance ? strength / (double)(e2_kept ? *e2_kept : E2) : 1.0;   // E2 counts the pairs that are kept
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E1 + E2; e += (int64_t)gridDim.x * blockDim.x) {
     const bool attr = e < E1;
     const int64_t a = attr ? i1[e] : i3[e - E1], c = attr ? i2[e] : i4[e - E1];
+    if (skip_self && !attr && a == c) continue;                      // the reference drops these pairs before the loss (umap.scala:221-227)
     double d2 = 0.0;
     for (int64_t k = 0; k < D; k++) { const double df = (double)loc[a * D + k] - (double)loc[c * D + k]; d2 += df * df; }
     const double d = sqrt(d2);
@@ -100,21 +101,21 @@ template <class T>
 __global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ loc, const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
                                                           const T* __restrict__ b, int64_t E1, const int64_t* __restrict__ i3, const int64_t* __restrict__ i4,
                                                           int64_t E2, const T* __restrict__ bsum, double min_dist, int balance, double strength,
-                                                          double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc) {
+                                                          double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc, const int64_t* __restrict__ e2_kept, int skip_self) {
   __shared__ double sm[4];
   double local = 0.0;
   const double attr_scale = balance ? 1.0 / (double)bsum[0] : 1.0;
-  const double rep_scale = balance ? strength / (double)E2 : 1.0;
+  const double rep_scale = balance ? strength / (double)(e2_kept ? *e2_kept : E2) : 1.0;   // E2 counts the pairs that are kept
   const int lane = threadIdx.x & 63, dim = threadIdx.x & 1;
   const int64_t E = E1 + E2;
   const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 1);
   const int64_t rounds = (E + stride - 1) / stride;                // the same trip count for every lane: the loop body shuffles
   int64_t e = blockIdx.x * (int64_t)(blockDim.x >> 1) + (threadIdx.x >> 1);
   for (int64_t it = 0; it < rounds; it++, e += stride) {
-    const bool valid = e < E;
-    const int64_t ee = valid ? e : E - 1;
+    const int64_t ee = e < E ? e : E - 1;
     const bool attr = ee < E1;
     const int64_t a = attr ? i1[ee] : i3[ee - E1], c = attr ? i2[ee] : i4[ee - E1];
+    const bool valid = e < E && !(skip_self && !attr && a == c);    // the reference drops negative pairs that hit themselves
     const double diff = (double)loc[a * 2 + dim] - (double)loc[c * 2 + dim];
     const double sq = diff * diff, sq_o = __shfl_xor(sq, 1, 64);
     const double d2 = dim == 0 ? (0.0 + sq) + sq_o : (0.0 + sq_o) + sq;
@@ -161,6 +162,13 @@ __global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ 
   if (threadIdx.x == 0) atomicAdd(loss_acc, local);
 }
 template <class T> __global__ void cast_scalar_kernel(const double* in, T* out) { *out = (T)(*in); }
+__global__ __launch_bounds__(256) void count_ne_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t n, int64_t* __restrict__ out) {
+  __shared__ double sm[4];
+  double local = 0.0;   // exact below 2^53
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) local += a[e] != b[e] ? 1.0 : 0.0;
+  local = block_sum(local, sm);
+  if (threadIdx.x == 0 && local != 0.0) atomicAdd((unsigned long long*)out, (unsigned long long)local);
+}
 
 // ---- attention helpers ---------------------------------------------------------------------------------------
 // scores[b, i, j] = scale * scores[b, i, j] (+ -inf above the diagonal); lse[b, i] = logsumexp_j; p = exp(s - lse)
@@ -408,10 +416,10 @@ int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, 
   LAMP_API_END
 }
 
-int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
-                        const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
-                        double repulsion_strength, const double* term_weights) {
-  LAMP_API_BEGIN
+}  // extern "C"
+static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
+                                const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
+                                double repulsion_strength, const double* term_weights, int skip_self) {
   check_device_tensor(locations, "locations"); check_device_tensor(grad_accum, "grad_accum");
   check_device_tensor(index1, "index1"); check_device_tensor(index2, "index2"); check_device_tensor(index3, "index3"); check_device_tensor(index4, "index4");
   check_device_tensor(b, "b");
@@ -427,6 +435,13 @@ int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_
   Hold acc(new_tensor(one, 1, kF64, locations->device()));
   fill_zero(acc.get());
   Hold out(new_tensor(nullptr, 0, locations->dtype, locations->device()));
+  Hold kept;                                   // number of negative pairs that do not hit themselves (device scalar; no host sync)
+  if (skip_self) {
+    kept = Hold(new_tensor(one, 1, kI64, locations->device()));
+    fill_zero(kept.get());
+    if (E2 > 0) { hipLaunchKernelGGL(count_ne_kernel, dim3(grid_for(E2, 256)), dim3(256), 0, st, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, kept->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
+  }
+  const int64_t* keptp = skip_self ? kept->ptr<int64_t>() : nullptr;
   const double w[4] = {term_weights ? term_weights[0] : 1.0, term_weights ? term_weights[1] : 1.0, term_weights ? term_weights[2] : 1.0,
                        term_weights ? term_weights[3] : 1.0};
   static const bool pairs2 = [] { const char* e = getenv("LAMP_UMAP_PAIRS2"); return !(e && e[0] == '0'); }();
@@ -434,27 +449,41 @@ int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_
     if (locations->dtype == kF64) {
       hipLaunchKernelGGL((umap_pairs2_kernel<double>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<double>(), index1->ptr<int64_t>(),
                          index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<double>(), min_dist, balance,
-                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>());
+                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>(), keptp, skip_self);
       hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
     } else {
       hipLaunchKernelGGL((umap_pairs2_kernel<float>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<float>(), index1->ptr<int64_t>(),
                          index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<float>(), min_dist, balance,
-                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>());
+                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>(), keptp, skip_self);
       hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
     }
   } else if (locations->dtype == kF64) {
     hipLaunchKernelGGL((umap_pairs_kernel<double>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<double>(), locations->sizes[1],
                        index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
-                       bsum->ptr<double>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>());
+                       bsum->ptr<double>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>(), keptp, skip_self);
     hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
   } else {
     hipLaunchKernelGGL((umap_pairs_kernel<float>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<float>(), locations->sizes[1],
                        index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
-                       bsum->ptr<float>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>());
+                       bsum->ptr<float>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>(), keptp, skip_self);
     hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
   }
   LAMP_LAUNCH_CHECK();
   *loss = out.take();
+}
+extern "C" {
+int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
+                        const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
+                        double repulsion_strength, const double* term_weights) {
+  LAMP_API_BEGIN
+  umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, index3, index4, min_dist, balance, repulsion_strength, term_weights, 0);
+  LAMP_API_END
+}
+int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1,
+                                  const lamp_tensor* index2, const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
+                                  int balance, double repulsion_strength, const double* term_weights) {
+  LAMP_API_BEGIN
+  umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, index3, index4, min_dist, balance, repulsion_strength, term_weights, 1);
   LAMP_API_END
 }
 

@@ -229,6 +229,28 @@ def test_flash_attention_bf16(gpu, shape, causal):
         assert_close(to_torch(S.STen(h)), r, 3e-2, name)
 
 
+def test_umap_skip_self_equals_masked_pairs(gpu):
+    """lamp_umap_loss_grad_skip_self folds `mask = i.ne(j); i.maskedSelect(mask); j.maskedSelect(mask)` (umap.scala:221-227) into
+    the kernel: same loss and gradient as the explicit compaction, for 2-D (lane-pair kernel) and 3-D (generic kernel) layouts."""
+    rng = np.random.default_rng(4)
+    n, e1, e2 = 300, 1500, 6000
+    for dim in (2, 3):
+        loc = S.STen.from_numpy(rng.random((n, dim)), 0, S.F64)
+        a1 = np.sort(rng.integers(0, n, e1)); a2 = (a1 + 1 + rng.integers(0, n - 1, e1)) % n
+        a3 = np.repeat(a1, 4)[:e2]; a4 = rng.integers(0, n, e2); a4[::7] = a3[::7]          # every 7th negative hits itself
+        b = S.STen.from_numpy(rng.random(e1), 0, S.F64)
+        w = f64_array([1.0, 2.0, 4.0, 8.0])
+        keep = a3 != a4
+        res = []
+        for fn, i3, i4 in ((lib.lamp_umap_loss_grad, a3[keep], a4[keep]), (lib.lamp_umap_loss_grad_skip_self, a3, a4)):
+            g = S.STen.zeros([n, dim], S.F64)
+            lo = C.c_void_p()
+            fn(C.byref(lo), g, loc, S.STen.from_numpy(a1, 0), S.STen.from_numpy(a2, 0), b, S.STen.from_numpy(i3, 0), S.STen.from_numpy(i4, 0), 0.0, 1, 1.5, w)
+            res.append((float(S.STen(lo).to_numpy()), g.to_numpy()))
+        assert abs(res[0][0] - res[1][0]) <= 1e-12 * abs(res[0][0])
+        assert np.abs(res[0][1] - res[1][1]).max() <= 1e-12 * np.abs(res[0][1]).max()
+
+
 def test_knn_and_umap_at_full_size_properties(gpu):
     """BASELINE config 5 at its full size (1M x 128 f32 points, k = 10): size-independent properties instead of an oracle.
     kNN (262,144 query rows against all 1M points): the query itself is a neighbour at distance ~0, indices are in range and
