@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): full GPU test suite, bench line, rocprofv3 kernel stats, the two PMC passes and the secondary probes.
+# Everything judged is written under gpurun_out/refresh/ and copied into profiles/ by hand afterwards.
+set -u
+R=$PWD; O=$R/gpurun_out/refresh; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
+python bench.py > $O/bench.log 2>$O/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/ks -o k --output-format csv -- python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline > /tmp/ks.log 2>&1
+cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+python3 $R/scripts/trace_step.py $(find /tmp/ks -name "*kernel_trace.csv" | head -1) > $O/last_step_breakdown.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pw.log 2>&1
+python3 $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv" | head -1) $(find /tmp/pw -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+cd $R
+{ python scripts/attn_probe.py 8 16 4096 128 0; python scripts/attn_probe.py 8 16 4096 128 1; python scripts/attn_probe.py 8 16 4096 64 0; } > $O/attention_probe.txt 2>&1
+python scripts/umap_full_probe.py 1000000 40 2>&1 | grep "umap n" > $O/umap_probe.txt
+python scripts/gemm_ab.py > $O/gemm_ab.txt 2>&1 || true
+cat $O/pytest_gpu.txt; tail -c 600 $O/bench.log; cat $O/pmc_traffic.txt | head -12; cat $O/umap_probe.txt
