@@ -440,6 +440,165 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
   }
 }
 
+// Variant for at most 64 output channels (every igemm layer of the CIFAR ResNet): as ig_conv8b_kernel, but
+//  * a weight stage holds only the 64 real rows (8 KiB), so no wave multiplies zero rows: waves = 2 images x 2 halves of 32 channels;
+//  * FOUR weight slots, stages requested three ahead behind a counted vmcnt (variant b has one stage in flight and pays an L2 round
+//    trip per stage);
+//  * 16 + 0.1 + 32 KiB of LDS: three workgroups fit a CU.
+template <int KS>
+__global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int NW = 2, NT = 256, LPT = 2;
+  constexpr int WT = 64 * 64 * 2, NSLOT = 4;   // one weight stage: 64 rows x 64 k
+  const int RB = KP * 2;
+  const int XIMG = 64 * RB;                 // 8x8 pixels, no halo
+  char* Xl = smem;                          // [2][64][KP] + one zero pixel
+  const int ZOFF = NW * XIMG;
+  char* Wl = smem + NW * XIMG + RB;         // NSLOT x WT
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int n0 = blockIdx.x * NW;
+  const int cmask = (KP >> 3) - 1;
+
+  // the first weight stage is requested before the image loads: both latencies overlap
+  constexpr int KW = 64;
+  const int CC = KP / KW;
+  const int T = RS * CC;
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  typedef const __attribute__((address_space(1))) char glb_char_t;
+  auto stage_dma = [&](int t, int slot) {
+    const int rs1 = t / CC, cc1 = t - rs1 * CC;
+    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
+#pragma unroll
+    for (int i = 0; i < LPT; i++) {
+      const int piece = wid * LPT + i;
+      const int p = piece * 64 + lane;
+      const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * WT + piece * 1024), 16, 0, 0);
+    }
+  };
+  stage_dma(0, 0);
+  if (1 < T) stage_dma(1, 1);
+  if (2 < T) stage_dma(2, 2);
+  if (tid * 16 < RB) *reinterpret_cast<uint4*>(Xl + ZOFF + tid * 16) = make_uint4(0, 0, 0, 0);
+  {
+    const int ncgp = KP >> 3;
+    for (int e = tid; e < NW * 8 * ncgp; e += NT) {
+      const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
+      const int n = n0 + img;
+      unsigned int w[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < CI && n < N) v = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+        w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+      }
+      char* xi = Xl + img * XIMG;
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        unsigned int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned int lo = w[2 * j][p >> 1], hi = w[2 * j + 1][p >> 1];
+          d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ x_swz(h + 1, p + 1, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+
+  f4v acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+
+  int rowsel, wpix;
+  px_of_col(lane & 15, rowsel, wpix);
+  int pre[RS][4];
+#pragma unroll
+  for (int rs = 0; rs < RS; rs++) {
+    const int r = rs / KS, s = rs - r * KS;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int h = 2 * j + rowsel + r - PAD, w = wpix + s - PAD;
+      const bool inside = h >= 0 && h < 8 && w >= 0 && w < 8;
+      pre[rs][j] = inside ? wc * XIMG + (h * 8 + w) * RB + ((((lane >> 4) & cmask) ^ x_swz(h + 1, w + 1, cmask)) << 4)
+                          : ZOFF + (((lane >> 4) & cmask) << 4);
+    }
+  }
+  const int a_row = (wr * 32 + (lane & 15)) * 128;
+  const int a_ch0 = ((lane >> 4) ^ (lane & 7)) << 4, a_ch1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf8v fa0[2], fb0[4], fa1[2], fb1[4];
+  int t = 0;
+#pragma unroll
+  for (int rs = 0; rs < RS; rs++) {
+    for (int cc = 0; cc < CC; cc++, t++) {
+      const char* wl = Wl + (t & 3) * WT + a_row;
+      if (t + 3 < T) stage_dma(t + 3, (t + 3) & 3);
+      const int u = ((cc * (KW >> 3)) & cmask) << 4;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
+        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u)));
+        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u ^ (4 << 4))));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      // stage t + 1 must have landed; stages t + 2 and t + 3 (LPT loads each) may stay in flight
+      if (t + 3 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  const int n = n0 + wc;
+  if (n < N) {
+    bf16_t* yp = y + (int64_t)n * CO * 64;
+    const int q = lane >> 4;
+    const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int co = wr * 32 + i * 16 + (lane & 15);
+      if (co < CO) {
+        const float b = bias ? (float)bias[co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+          uint2 pk;
+          pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+          pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+          *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
+        }
+      }
+    }
+  }
+}
+
 // ---- wgrad --------------------------------------------------------------------------------------------
 // partial[(split * RS + rs)][128][128] (fp32) = sum over the split's images of dY[n] (128 x 64) . Xshift_rs[n]^T (64 x 128)
 template <int KS>
@@ -742,10 +901,23 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   {
     const char* variant = getenv("LAMP_IG_VARIANT");
     if (!(variant && variant[0] == 'a')) {   // default: two co-resident workgroups per CU (A/B on one device: 7 % faster per launch)
-      const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
       const int blocksb = (int)((g.N + 1) / 2);
       KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
       const bf16_t* bpb = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+      if (CO <= 64 && !(variant && variant[0] == 'b')) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
+        const size_t ldsc = (size_t)2 * 64 * KP * 2 + KP * 2 + 4 * (64 * 64 * 2);
+        static bool c3 = false, c1 = false;
+        if (KS == 3) {
+          if (!c3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c3 = true; }
+          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        } else {
+          if (!c1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c1 = true; }
+          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        }
+        LAMP_LAUNCH_CHECK();
+        return;
+      }
+      const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
       static bool a3 = false, a1 = false;
       if (KS == 3) {
         if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
