@@ -10,7 +10,7 @@ and activations with fp32 working copies in AdamW (AdamW.scala:48-85).  With N >
 local gradients, one flat fp32 bucket is all-reduced over RCCL/xGMI, every rank applies the same step
 (weak scaling: B per GPU fixed).  One JSON line is printed by rank 0.
 
-Other workloads (parity-test configurations, not the headline line): --workload gemm | mlp.
+Other workloads (parity-test configurations and secondary probes, not the headline line): --workload gemm | mlp | knn | attention | umap.
 """
 import argparse
 import ctypes as C
@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp"])
+    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,7 +105,7 @@ def main():
 
     # CPU baseline first, in a child process, on rank 0 at N = 1 only (before this process touches the GPU)
     cpu_baseline = None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and a.workload in ("resnet", "gemm", "mlp"):   # secondary probes have no CPU leg
         try:
             wl = {"resnet": "resnet", "gemm": "gemm", "mlp": "mlp"}[a.workload]
             out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--budget-s", "15"],
@@ -171,6 +171,57 @@ def main():
         units_per_step = 3 * 2.0 * n ** 3 / 1e12
         metric, unit = "4096x4096 addmm fwd+bwd", "TFLOP/s"
         config = {"workload": "lamp Linear(4096,4096,bias) on x[4096,4096]: fwd addmm + dW (A^T.p) + dX (p.W^T)", "parallelism": "replicas"}
+    elif a.workload == "knn":
+        # BASELINE config 5, first half: brute-force kNN graph, 131072 query rows per step against 1M x 128 f32 points, k = 10
+        n, nq, d, k = 1_000_000, 131_072, 128, 10
+        rng = np.random.default_rng(0)
+        pts = rng.random((n, d), dtype=np.float32) + (np.arange(n) % 16)[:, None].astype(np.float32)
+        X = S.STen.from_numpy(pts, local_rank, S.F32)
+        Qs = X.slice(0, rank * nq % (n - nq), rank * nq % (n - nq) + nq)
+
+        def step():
+            i = C.c_void_p()
+            lib.lamp_knn_squared_euclidean(C.byref(i), None, X, Qs, k)
+            return S.STen(i)
+        units_per_step = nq
+        metric, unit = "kNN queries/sec (1M x 128 f32 points, k = 10)", "queries/s"
+        config = {"workload": "lamp.knn.knnSearch squared Euclidean, 131072 queries x 1M points x 128 features, k = 10 (top-k fused into the f32 MFMA GEMM)",
+                  "parallelism": "query rows sharded" if a.gpus > 1 else "single"}
+        a.dtype = "f32"
+    elif a.workload == "attention":
+        # ScaledDotProductAttention forward + backward, bf16, B 8 x 16 heads x S 4096 x d 128, non-causal
+        Bz, H, Sq, D = 8, 16, 4096, 128
+        rng = np.random.default_rng(0)
+        q_, k_, v_, g_ = (S.STen.from_numpy(rng.standard_normal((Bz, H, Sq, D), dtype=np.float32), local_rank, S.BF16) for _ in range(4))
+
+        def step():
+            o, l = C.c_void_p(), C.c_void_p()
+            lib.lamp_scaled_dot_product_attention(C.byref(o), C.byref(l), q_, k_, v_, 0, 0.0)
+            O_, L_ = S.STen(o), S.STen(l)
+            out3 = (C.c_void_p * 3)()
+            lib.lamp_scaled_dot_product_attention_backward(out3, g_, q_, k_, v_, O_, L_, 0, 0.0)
+            return [S.STen(h) for h in out3]
+        units_per_step = 14.0 * Bz * H * Sq * Sq * D / 1e12      # 4 fwd + 10 bwd model flops per (query, key, feature)
+        metric, unit = "attention fwd+bwd (model flops)", "TFLOP/s"
+        config = {"workload": "ScaledDotProductAttention fwd + bwd, bf16, batch 8 x 16 heads x 4096 x 128, non-causal", "parallelism": "replicas"}
+    elif a.workload == "umap":
+        # BASELINE config 5, second half: one layout iteration of Umap.optimize at 1M points (9M edges, 5 negatives per edge, f64)
+        from lamp_amd import umap as U
+        n, kk = 1_000_000, 10
+        rng = np.random.default_rng(0)
+        knn_idx = (np.arange(n)[:, None] + 1 + rng.integers(0, n - 1, (n, kk))) % n
+        knn_idx[:, 0] = np.arange(n)
+        knn_dist = np.sort(rng.random((n, kk)), 1); knn_dist[:, 0] = 0.0
+        ew = U.edge_weights(S.STen.from_numpy(knn_dist, local_rank, S.F64), S.STen.from_numpy(knn_idx.astype(np.int64), local_rank))
+        state = {}
+
+        def step():
+            state["r"] = U.optimize(ew, n, 0.1, 1, 0.0, 5, 42 + len(state), True, 1.0, local_rank, 2)
+        units_per_step = 1
+        metric, unit = "UMAP layout iterations/sec (1M points)", "iterations/s"
+        config = {"workload": "Umap.optimize, 1 iteration per step: 1M points, ~9M edges, 5 negatives per edge, f64, AdamW; includes the per-call "
+                              "initial layout (rand) that a 500-iteration run pays once", "parallelism": "replicas"}
+        a.dtype = "f64"
     else:
         B = 1024
         model_mod = nn.Sequential(nn.MLP(784, 10, [256], S.F32, local_rank), nn.Fun("logsoftmax", 1))

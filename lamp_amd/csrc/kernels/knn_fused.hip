@@ -242,7 +242,7 @@ bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
   const dim3 grid((unsigned)((Q + KF_BQ - 1) / KF_BQ));
   const size_t lds = (size_t)2 * KF_BC * dim * 4 + 4 * sizeof(KfWaveState);
-  KernelTimer kt("knn_fused", 2.0 * (double)Q * N * dim, ((double)Q + N) * dim * 4, st);
+  KernelTimer kt("knn_fused_f32", 2.0 * (double)Q * N * dim, ((double)Q + N) * dim * 4, st);
 #define KF_LAUNCH(D)                                                                                                                       \
   do {                                                                                                                                     \
     static bool attr = false;                                                                                                              \

@@ -85,7 +85,7 @@ def test_knn_fused_topk(gpu, n, nq, d, k):
     buf = C.create_string_buffer(1 << 16)
     lib.lamp_kernel_timer_report(buf, len(buf))
     lib.lamp_kernel_timer_enable(0)
-    assert b"knn_fused" in buf.value, "the fused kernel did not run"
+    assert b"knn_fused_f32" in buf.value, "the fused kernel did not run"
     got, dist = S.STen(i).to_numpy(), S.STen(dd).to_numpy()
     assert got.shape == (len(rows), k) and got.dtype == np.int64
     assert np.array_equal(np.sort(got, 1), np.sort(ref.numpy(), 1)), "neighbour index sets must be exact"
