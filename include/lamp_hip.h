@@ -502,6 +502,9 @@ int lamp_comm_broadcast(lamp_tensor* const* tensors, lamp_comm* const* comms, in
 int lamp_comm_reduce(lamp_tensor* const* inputs, lamp_tensor* output, int root, int op /* 0 = sum */,
                      lamp_comm* const* comms, int n);
 int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int op);
+/* out = concatenation over ranks of `in` (ncclAllGather): the exchange step of row-sharded work, e.g. the kNN graph whose
+ * query rows are split over the ranks (lamp-knn has no multi-GPU form) */
+int lamp_comm_all_gather(lamp_tensor* out, const lamp_tensor* in, lamp_comm* comm);
 int lamp_comm_destroy(lamp_comm* c);
 
 #ifdef __cplusplus

@@ -123,6 +123,18 @@ int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, i
   LAMP_API_END
 }
 
+// out[rank * numel(in) ...] = in of that rank (ncclAllGather): the exchange step of row-sharded work (kNN graph)
+int lamp_comm_all_gather(lamp_tensor* out, const lamp_tensor* in, lamp_comm* comm) {
+  LAMP_API_BEGIN
+  check_comm_tensor(out, comm);
+  check_comm_tensor(in, comm);
+  int nranks = 0;
+  NCCL_CHECK(ncclCommCount(comm->comm, &nranks));
+  LAMP_CHECK(out->dtype == in->dtype && out->numel() == in->numel() * nranks, "all_gather: out must hold nranks x in elements of the same dtype");
+  NCCL_CHECK(ncclAllGather(in->data(), out->data(), (size_t)in->numel(), nccl_type(in->dtype), comm->comm, current_stream(comm->device)));
+  LAMP_API_END
+}
+
 int lamp_comm_destroy(lamp_comm* c) {
   LAMP_API_BEGIN
   if (c) {

@@ -67,3 +67,41 @@ def every_nth(num_batches: int, n: int, offset: int) -> List[int]:
     not fill a full round is dropped."""
     full = (num_batches // n) * n
     return list(range(offset, full, n))
+
+
+def row_shard(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """rows [lo, hi) of rank `rank` when n rows are split into `world` equal blocks (the last ones padded: every rank owns
+    ceil(n / world) rows so that the all-gather has equal contributions)."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def knn_search_sharded(features, k: int, comm, world: int, rank: int):
+    """kNN graph of `features` against itself with the QUERY ROWS split over the ranks (independent row blocks, the data
+    set replicated in every GPU's HBM, one all-gather of the [n / world, k] index blocks at the end).  Returns the full [n, k] i64
+    index tensor on every rank.  lamp-knn itself is single-device (knn/package.scala:60-121)."""
+    from . import sten as S
+    from . import umap as U
+    from ._capi import lib
+    n = features.shape[0]
+    per = (n + world - 1) // world
+    lo, hi = row_shard(n, world, rank)
+    # every rank contributes exactly `per` rows: short or empty blocks query the last rows again (dropped after the gather)
+    qlo = max(min(lo, n - per), 0) if per <= n else 0
+    mine = U.knn_search(features, features.slice(0, qlo, min(qlo + per, n)), k)
+    if mine.shape[0] < per:                                            # n < per * 1: tiny inputs
+        mine = S.STen.cat([mine] + [mine.slice(0, 0, 1)] * (per - mine.shape[0]), 0)
+    if world == 1 or comm is None:
+        return mine.slice(0, 0, n)
+    out = S.STen.zeros([world * per, k], S.I64, features.device)
+    lib.lamp_comm_all_gather(out, mine.contiguous(), comm)
+    # block r holds the rows [qlo_r, qlo_r + per); only the last block can be shifted: put the rows back in order
+    parts = []
+    for r in range(world):
+        rlo, rhi = row_shard(n, world, r)
+        if rhi <= rlo:
+            continue
+        rq = max(min(rlo, n - per), 0)
+        parts.append(out.slice(0, r * per + (rlo - rq), r * per + (rlo - rq) + (rhi - rlo)))
+    return parts[0] if len(parts) == 1 else S.STen.cat(parts, 0)

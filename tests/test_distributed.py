@@ -117,3 +117,59 @@ def test_overlapped_data_parallel_step_single_rank(gpu, dtype_name):
     assert np.array_equal(acc0, acc1)
     for a, b in zip(plain, dp):
         assert np.array_equal(a, b), "single-rank data-parallel step must reproduce the plain step bit for bit"
+
+
+def test_row_shards_cover_every_row_once():
+    """host logic of the row-sharded kNN graph: the per-rank blocks partition the rows, and the fixed-size contributions
+    of the all-gather (short / empty last blocks re-query the tail rows) can always be cut back to exactly those blocks."""
+    for n in (1, 7, 64, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            per = (n + world - 1) // world
+            seen = []
+            for r in range(world):
+                lo, hi = D.row_shard(n, world, r)
+                assert 0 <= lo <= hi <= n and hi - lo <= per
+                seen += list(range(lo, hi))
+                if hi > lo and per <= n:
+                    q = max(min(lo, n - per), 0)                 # first row this rank really queries
+                    assert q <= lo and q + per >= hi, "the shifted block still contains the rank's rows"
+            assert seen == list(range(n))
+
+
+@pytest.mark.gpu
+def test_sharded_knn_single_rank_and_all_gather(gpu):
+    """world size 1: the sharded driver returns the plain graph; lamp_comm_all_gather on a 1-rank RCCL communicator copies."""
+    from lamp_amd import sten as S, umap as U
+    from lamp_amd._capi import lib
+    rng = np.random.default_rng(3)
+    X = S.STen.from_numpy(rng.random((500, 64), dtype=np.float32), 0)
+    ref = U.knn_search(X, X, 5).to_numpy()
+    assert np.array_equal(D.knn_search_sharded(X, 5, None, 1, 0).to_numpy(), ref)
+    buf = (C.c_uint8 * 128)()
+    lib.lamp_comm_get_unique_id(buf)
+    h = C.c_void_p()
+    lib.lamp_comm_init_rank(C.byref(h), 1, buf, 0)
+    try:
+        got = D.knn_search_sharded(X, 5, h, 1, 0).to_numpy()
+        assert np.array_equal(got, ref)
+        src = S.STen.from_numpy(np.arange(12, dtype=np.int64).reshape(3, 4), 0)
+        dst = S.STen.zeros([3, 4], S.I64, 0)
+        lib.lamp_comm_all_gather(dst, src, h)
+        assert np.array_equal(dst.to_numpy(), src.to_numpy())
+        # the reassembly for several ranks, driven with the single-process pieces a 3-rank job would produce
+        n, world, k = 500, 3, 5
+        per = (n + world - 1) // world
+        blocks = []
+        for r in range(world):
+            lo, hi = D.row_shard(n, world, r)
+            q = max(min(lo, n - per), 0)
+            blocks.append(U.knn_search(X, X.slice(0, q, q + per), k).to_numpy())
+        gathered = np.concatenate(blocks, 0)
+        parts = []
+        for r in range(world):
+            lo, hi = D.row_shard(n, world, r)
+            q = max(min(lo, n - per), 0)
+            parts.append(gathered[r * per + (lo - q): r * per + (lo - q) + (hi - lo)])
+        assert np.array_equal(np.concatenate(parts, 0), ref)
+    finally:
+        lib.lamp_comm_destroy(h)
