@@ -305,6 +305,9 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
     lamp_tensor* bt[1] = {bucket.h()};
     lamp_comm* cm[1] = {comm};
     HCALL(lamp_comm_all_reduce(bt, cm, 1, 0));
+    // averaged gradients back into the parameters' grad buffers, still on the exchange stream: for the deep bucket this overlaps
+    // the rest of backward instead of queueing behind it
+    if (!gh.empty()) HCALL(lamp_unflatten_from_(gh.data(), (int)gh.size(), bucket.h(), 1));
     HCALL(lamp_stream_set_current(cur));
   };
 
@@ -333,9 +336,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   if (acc.defined()) {                                           // acc += (loss.value * numInstances.toDouble)
     ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)n);
   }
-  HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both reduced buckets are visible to the compute stream
-  if (!h_deep.empty()) HCALL(lamp_unflatten_from_(h_deep.data(), (int)h_deep.size(), bucket_deep.h(), 1));
-  if (!h_rest.empty()) HCALL(lamp_unflatten_from_(h_rest.data(), (int)h_rest.size(), bucket_rest.h(), 1));
+  HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both averaged gradient sets are visible to the compute stream
   lamp_stream_release(cur);
   std::vector<Ten> grads(g_rest);
   grads.insert(grads.end(), g_deep.begin(), g_deep.end());
