@@ -32,4 +32,4 @@ buf = C.create_string_buffer(1 << 16); lib.lamp_kernel_timer_report(buf, len(buf
 tag, n, ms, _, _ = buf.value.decode().split()
 dt = (float(ms) / int(n)) * 1e-3 - cal.value * 1e-6
 fl = 2.0 * N * 64 * Cin * Cout * k * k
-print(f"dbg={os.environ.get('LAMP_IG_DBG','0')} conv {Cin}->{Cout} k{k}: {dt*1e6:.1f} us/kernel (events - bracket), {fl/dt/1e12:.0f} TF/s")
+print(f"variant={os.environ.get('LAMP_IG_VARIANT','default')} conv {Cin}->{Cout} k{k}: {dt*1e6:.1f} us/kernel (events - bracket), {fl/dt/1e12:.0f} TF/s")
