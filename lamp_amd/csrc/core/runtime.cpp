@@ -335,3 +335,38 @@ int lamp_graph_release(lamp_graph* g) {
 }
 
 }  // extern "C"
+
+// ---- convolution -> batch-norm statistics hand-off ------------------------------------------------------------------------
+namespace lamp {
+namespace {
+struct ConvStatsEntry { uint64_t uid = 0, version = 0; int64_t offset = 0, C = 0; lamp_tensor* partial = nullptr; int P = 0; };
+constexpr int kConvStatsRing = 32;
+ConvStatsEntry g_conv_stats[kConvStatsRing];
+int g_conv_stats_next = 0;
+std::mutex g_conv_stats_mu;
+}  // namespace
+
+void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P) {
+  std::lock_guard<std::mutex> lock(g_conv_stats_mu);
+  ConvStatsEntry& e = g_conv_stats[g_conv_stats_next];
+  g_conv_stats_next = (g_conv_stats_next + 1) % kConvStatsRing;
+  if (e.partial) lamp_tensor_release(e.partial);
+  e.uid = y->st->uid; e.version = y->st->version.load(std::memory_order_relaxed); e.offset = y->offset; e.C = y->sizes[1];
+  e.partial = nullptr; e.P = P;
+  lamp_tensor_retain(partial, &e.partial);
+}
+
+lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P) {
+  if (!x || !x->st) return nullptr;
+  std::lock_guard<std::mutex> lock(g_conv_stats_mu);
+  for (auto& e : g_conv_stats) {
+    if (e.partial && e.uid == x->st->uid && e.offset == x->offset && e.C == C && e.version == x->st->version.load(std::memory_order_relaxed)) {
+      lamp_tensor* r = nullptr;
+      lamp_tensor_retain(e.partial, &r);
+      *P = e.P;
+      return r;
+    }
+  }
+  return nullptr;
+}
+}  // namespace lamp

@@ -163,6 +163,11 @@ void set_device(int d);
 hipStream_t current_stream();           // thread-local current stream of current device
 hipStream_t current_stream(int device);
 int num_cus();
+// Batch-norm statistics computed by a convolution's epilogue: Welford triples [P][C][3] (f32) over P disjoint slices of the output,
+// keyed by the output's storage (uid, offset) and valid while its version is unchanged.  The batch norm that consumes the tensor
+// picks them up instead of re-reading it (norm.hip).  A small ring: the consumer runs right after the producer.
+void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P);
+lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P);   // +1 handle or nullptr
 uint64_t next_philox_offset(uint64_t n);  // advances the generator state by n draws
 uint64_t philox_seed();
 

@@ -288,13 +288,31 @@ __global__ __launch_bounds__(NW * 128) void ig_conv8_kernel(const bf16_t* __rest
   }
 }
 
+// Welford triple (count, mean, M2) of the 16 output values a lane holds for one output channel, merged over the four lanes that share
+// the channel (xor 16, 32): the statistics of the wave's 64 pixels of that channel, from the bf16-ROUNDED values the batch norm reads.
+__device__ __forceinline__ void ig_stats_merge(float& n, float& mean, float& m2, float n2, float mean2, float m22) {
+  const float nt = n + n2, d = mean2 - mean, f = n2 / nt;
+  mean = mean + d * f;
+  m2 = m2 + m22 + d * d * n * f;
+  n = nt;
+}
+__device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, float& mean, float& m2) {
+  const float sh = v[0];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { const float d = v[k] - sh; s1 += d; s2 += d * d; }
+  n = 16.f; mean = sh + s1 * (1.f / 16.f); m2 = s2 - s1 * s1 * (1.f / 16.f);
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) ig_stats_merge(n, mean, m2, __shfl_xor(n, off, 64), __shfl_xor(mean, off, 64), __shfl_xor(m2, off, 64));
+}
+
 // DEFAULT variant, TWO co-resident workgroups per CU (LAMP_IG_VARIANT=a selects the 4-image kernel above): two images and four waves per
 // workgroup, the images WITHOUT halo (taps outside the image read a shared zero pixel), two weight slots: 32 + 0.25 + 32 KiB of
 // LDS.  The two workgroups of a CU are independent, so the prologue / epilogue of one overlaps the main loop of the other and
 // their READ / MFMA phases interleave without an explicit stagger.
 template <int KS>
 __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -425,16 +443,24 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int co = wr * 64 + i * 16 + (lane & 15);
-      if (co < CO) {
-        const float b = bias ? (float)bias[co] : 0.f;
+      const float b = (bias && co < CO) ? (float)bias[co] : 0.f;
+      float vals[16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+      for (int j = 0; j < 4; j++) {
+        const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+        if (co < CO) {
           uint2 pk;
           pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
           pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
           *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
         }
+        vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
+        vals[4 * j + 2] = __uint_as_float((unsigned)o2.bits << 16); vals[4 * j + 3] = __uint_as_float((unsigned)o3.bits << 16);
+      }
+      if (stats) {                              // one partial per image: the batch norm that follows merges them (norm.hip)
+        float wn, wm, w2;
+        ig_stats_wave(vals, wn, wm, w2);
+        if (q == 0 && co < CO) { float* sp = stats + ((int64_t)co * N + n) * 3; /* [channel][image][3] */ sp[0] = wn; sp[1] = wm; sp[2] = w2; }
       }
     }
   }
@@ -447,7 +473,7 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
 //  * 16 + 0.1 + 32 KiB of LDS: three workgroups fit a CU.
 template <int KS>
 __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -584,16 +610,24 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int co = wr * 32 + i * 16 + (lane & 15);
-      if (co < CO) {
-        const float b = bias ? (float)bias[co] : 0.f;
+      const float b = (bias && co < CO) ? (float)bias[co] : 0.f;
+      float vals[16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+      for (int j = 0; j < 4; j++) {
+        const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+        if (co < CO) {
           uint2 pk;
           pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
           pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
           *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
         }
+        vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
+        vals[4 * j + 2] = __uint_as_float((unsigned)o2.bits << 16); vals[4 * j + 3] = __uint_as_float((unsigned)o3.bits << 16);
+      }
+      if (stats) {                              // one partial per image: the batch norm that follows merges them (norm.hip)
+        float wn, wm, w2;
+        ig_stats_wave(vals, wn, wm, w2);
+        if (q == 0 && co < CO) { float* sp = stats + ((int64_t)co * N + n) * 3; /* [channel][image][3] */ sp[0] = wn; sp[1] = wm; sp[2] = w2; }
       }
     }
   }
@@ -902,6 +936,16 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
     const char* variant = getenv("LAMP_IG_VARIANT");
     if (!(variant && variant[0] == 'a')) {   // default: two co-resident workgroups per CU (A/B on one device: 7 % faster per launch)
       const int blocksb = (int)((g.N + 1) / 2);
+      // fprop: per-image batch-norm statistics of the output from the epilogue (LAMP_CONV_BN_STATS=0 turns the hand-off off)
+      static const bool bn_stats = [] { const char* e = getenv("LAMP_CONV_BN_STATS"); return !(e && e[0] == '0'); }();
+      Hold statt;
+      float* statp = nullptr;
+      if (bn_stats && !dgrad && g.N >= 2) {
+        int64_t ps[1] = {(int64_t)g.N * CO * 3};
+        statt = Hold(new_tensor(ps, 1, kF32, in->device()));
+        statp = statt->ptr<float>();
+      }
+      struct Publish { Hold& t; const Tensor* y; int P; ~Publish() { if (t.get()) conv_stats_publish(y, t.get(), P); } } publish{statt, out, (int)g.N};
       KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
       const bf16_t* bpb = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
       if (CO <= 64 && !(variant && variant[0] == 'b')) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
@@ -909,10 +953,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         static bool c3 = false, c1 = false;
         if (KS == 3) {
           if (!c3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c3 = true; }
-          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
         } else {
           if (!c1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c1 = true; }
-          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
         }
         LAMP_LAUNCH_CHECK();
         return;
@@ -921,10 +965,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       static bool a3 = false, a1 = false;
       if (KS == 3) {
         if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
-        hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
       } else {
         if (!a1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
-        hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO);
+        hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
       }
       LAMP_LAUNCH_CHECK();
       return;

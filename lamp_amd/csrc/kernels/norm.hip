@@ -13,6 +13,7 @@
 // Layout: x is [N, C, HW] contiguous (HW = 1 for the 2-D case). Pass 1 reduces each channel with
 // one or more workgroups (64-lane shuffle merge + LDS), pass 2 is a coalesced normalise.
 #include "device_utils.h"
+#include <type_traits>
 #include "../core/strided.h"
 
 namespace lamp {
@@ -202,16 +203,40 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A stat[2];
+  __shared__ A wpart[4][3];
   const int64_t c = blockIdx.x;
   const int slice = blockIdx.y;
+  // nsplit > 0: partial[s][c] (the statistics kernel); nsplit < 0: partial[c][s] with -nsplit entries (a convolution's per-image
+  // statistics, merged here by the whole workgroup in a fixed order)
+  const int np = nsplit < 0 ? -nsplit : nsplit;
+  if (nsplit < 0) {
+    // EQUAL-count triples (n0, mean_s, m2_s): with shift = mean_0,  mean = shift + S1 / np,  m2 = sum m2_s + n0 (S2 - S1^2 / np)
+    // where S1 = sum (mean_s - shift), S2 = sum (mean_s - shift)^2: no division per partial, fixed summation order
+    const A* pc = partial + (int64_t)c * np * 3;
+    const A shift = pc[1];
+    A s1 = 0, s2 = 0, sm = 0;
+    for (int s = threadIdx.x; s < np; s += blockDim.x) { const A d = pc[s * 3 + 1] - shift; s1 += d; s2 += d * d; sm += pc[s * 3 + 2]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) { wpart[threadIdx.x >> 6][0] = s1; wpart[threadIdx.x >> 6][1] = s2; wpart[threadIdx.x >> 6][2] = sm; }
+    __syncthreads();
+  }
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     Welford<A> r{0, 0, 0};
-    for (int s = lane; s < nsplit; s += 64) {
-      const A* p = partial + ((int64_t)s * C + c) * 3;
-      r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
+    if (nsplit < 0) {
+      A s1 = 0, s2 = 0, sm = 0;
+      for (int k = 0; k < (int)(blockDim.x >> 6); k++) { s1 += wpart[k][0]; s2 += wpart[k][1]; sm += wpart[k][2]; }
+      const A n0 = partial[(int64_t)c * np * 3], shift = partial[(int64_t)c * np * 3 + 1];
+      r.n = n0 * (A)np;
+      r.mean = shift + s1 / (A)np;
+      r.m2 = sm + n0 * (s2 - s1 * s1 / (A)np);
+    } else {
+      for (int s = lane; s < np; s += 64) {
+        const A* p = nsplit < 0 ? partial + ((int64_t)c * np + s) * 3 : partial + ((int64_t)s * C + c) * 3;
+        r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
+      }
+      r = wf_wave(r);
     }
-    r = wf_wave(r);
     if (lane == 0) {
       const A var_biased = r.m2 / r.n;
       const A invstd = A(1) / (A)sqrt((double)(var_biased + (A)eps));
@@ -624,28 +649,37 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
-    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)y->data()) & 15) == 0;
+    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->raw() | (uintptr_t)y->raw()) & 15) == 0;
     if (training) {
       LAMP_CHECK(g.N * g.HW > 0, "batch norm over an empty batch");
       const bool col = g.HW < 64;
       const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
       const int nsplit = pick_split(blocks, g.N);
-      int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
-      Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+      // statistics handed over by the convolution that produced x (its epilogue computed per-image Welford triples): no stats pass
+      int npart = nsplit;
+      Hold partial;
+      if (!col && std::is_same<A, float>::value) partial = Hold(conv_stats_lookup(xc.get(), g.C, &npart));
+      const bool have_stats = partial.get() != nullptr;
+      if (!have_stats) {
+        npart = nsplit;
+        int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
+        partial = Hold(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+      }
       T* rm = running_mean ? running_mean->ptr<T>() : (T*)nullptr;
       T* rv = running_var ? running_var->ptr<T>() : (T*)nullptr;
       const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
       const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
-      {
+      if (!have_stats) {
         KernelTimer kt("bn_fwd_stats", 0, (double)total * sizeof(T), st);
-        if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
-        else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+        if (col) hipLaunchKernelGGL((bn_stats_col_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit);
+        else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
         LAMP_LAUNCH_CHECK();
       }
       if (!col && total > 0) {
         // finalize folded into the channel-aligned normalise
         KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
-        hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), partial->ptr<A>(), nsplit,
+        hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), y->ptr<T>(),
+                           static_cast<const Tensor*>(partial.get())->ptr<A>(), have_stats ? -npart : npart,
                            mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit,
                            (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr);
         LAMP_LAUNCH_CHECK();

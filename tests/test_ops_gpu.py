@@ -616,3 +616,48 @@ def test_igemm_pack_cache_sees_every_weight_write(gpu):
     opt = NN.SGDW([W], 0.5, 0.0)
     opt.step([g], 1.0)
     check(to_torch(W).to(dt), "after the optimiser step")
+
+
+@pytest.mark.parametrize("cin,cout,k", [(128, 128, 3), (64, 64, 3), (32, 64, 1), (128, 100, 3)])
+def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k):
+    """A bf16 8x8 convolution on the implicit-GEMM path leaves per-image Welford triples of its output for the batch norm that
+    consumes it (conv_stats_publish / conv_stats_lookup): that batch norm launches no statistics kernel, and its outputs are those
+    of a batch norm run on a COPY of the tensor (different storage: no hand-off) up to the merge order of the partial statistics.
+    Writing into the tensor invalidates the hand-off."""
+    dt = torch.bfloat16
+    N = 64
+    x = closed_form((N, cin, 8, 8), 3, 2.0, dt)
+    w = closed_form((cout, cin, k, k), 17, 0.2, dt)
+    bias = closed_form((cout,), 5, 1.0, dt)
+    g, b = closed_form((cout,), 1, 1.0, dt) + 1.0, closed_form((cout,), 9, 1.0, dt)
+    rm, rv = closed_form((cout,), 7, 0.5, dt), closed_form((cout,), 11, 0.5, dt) + 1.0
+    o = C.c_void_p()
+    p_ = (k - 1) // 2
+    lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(bias), i64_array([1, 1]), i64_array([p_, p_]), i64_array([1, 1]), 2, 0,
+                         i64_array([0, 0]), 1)
+    Y = S.STen(o)
+    Ycopy = Y.clone()
+
+    def bn(t):
+        out = _out3()
+        RM, RV = to_sten(rm), to_sten(rv)
+        lib.lamp_kernel_timer_enable(1)
+        lib.lamp_native_batch_norm_relu(out, t, to_sten(g), to_sten(b), RM, RV, 1, 0.1, 1e-5)
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        lib.lamp_kernel_timer_enable(0)
+        return _wrap3(out), RM, RV, buf.value
+
+    (y1, m1, i1), RM1, RV1, rep1 = bn(Y)
+    (y2, m2, i2), RM2, RV2, rep2 = bn(Ycopy)
+    assert b"bn_fwd_stats" not in rep1, "the statistics pass ran although the convolution had published them"
+    assert b"bn_fwd_stats" in rep2
+    assert_close(to_torch(m1), to_torch(m2), 1e-2, "save_mean")          # bf16-rounded values: equal up to one rounding step
+    assert_close(to_torch(i1), to_torch(i2), 1e-2, "save_invstd")
+    assert_close(to_torch(y1), to_torch(y2), 2e-2, "normalised output")
+    assert_close(to_torch(RV1), to_torch(RV2), 1e-2, "running_var")
+    ref = torch.relu(aten.native_batch_norm(to_torch(Ycopy).to(dt), g, b, rm.clone(), rv.clone(), True, 0.1, 1e-5)[0])
+    assert_close(to_torch(y1), ref.double(), FWD_TOL[dt] * 4, "against the oracle")
+    lib.lamp_mul_(Y, Y.onesLike())                                           # any write through the handle bumps the storage version
+    _, _, _, rep3 = bn(Y)
+    assert b"bn_fwd_stats" in rep3, "stale statistics were used after the tensor had been written"
