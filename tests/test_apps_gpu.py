@@ -67,17 +67,18 @@ def test_knn_chunked_merge(gpu):
     assert np.array_equal(np.sort(S.STen(i).to_numpy(), 1), np.sort(ref.numpy(), 1))
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n,nq,d,k", [(3000, 400, 128, 10), (777, 257, 64, 16), (64, 130, 128, 1), (20000, 33, 128, 10), (100, 100, 64, 7)])
-def test_knn_fused_topk(gpu, n, nq, d, k):
+def test_knn_fused_topk(gpu, n, nq, d, k, dt):
     """f32 with 64 / 128 features and k <= 16 takes knn_fused.hip (top-k inside the distance GEMM): ragged tile counts, fewer
     points than one tile, k = 1 and k = 16, against the reference algorithm of the oracle on well separated rows."""
     # clusters 0.25 apart: |x|^2 stays below 3e3, so the f32 form |q|^2 + |x|^2 - 2 q.x is good to ~1e-3 and rows whose k-th and
     # (k+1)-th neighbours differ by 2e-2 have a k-NN SET decided by the data
     g = torch.Generator().manual_seed(777)
     data64 = torch.rand(n, d, generator=g, dtype=torch.float64) + (torch.arange(n) % 16).double().reshape(n, 1) * 0.25
-    rows = _well_separated_queries(data64, torch.arange(0, n, max(n // nq, 1))[:nq], k, 2e-2)
+    rows = _well_separated_queries(data64, torch.arange(0, n, max(n // nq, 1))[:nq], k, 2e-2 if dt == torch.float32 else 1e-9)
     assert len(rows) >= min(nq, n) // 4
-    data, query = data64.float(), data64[rows].float()
+    data, query = data64.to(dt), data64[rows].to(dt)
     ref = O.knn_minibatched(data, query, k, 100)
     lib.lamp_kernel_timer_enable(1)
     i, dd = C.c_void_p(), C.c_void_p()
@@ -85,20 +86,21 @@ def test_knn_fused_topk(gpu, n, nq, d, k):
     buf = C.create_string_buffer(1 << 16)
     lib.lamp_kernel_timer_report(buf, len(buf))
     lib.lamp_kernel_timer_enable(0)
-    assert b"knn_fused_f32" in buf.value, "the fused kernel did not run"
+    assert (b"knn_fused_f32" if dt == torch.float32 else b"knn_fused_f64") in buf.value, "the fused kernel did not run"
     got, dist = S.STen(i).to_numpy(), S.STen(dd).to_numpy()
     assert got.shape == (len(rows), k) and got.dtype == np.int64
     assert np.array_equal(np.sort(got, 1), np.sort(ref.numpy(), 1)), "neighbour index sets must be exact"
     assert (np.diff(dist, axis=1) >= 0).all(), "neighbours come sorted by distance"
     exact = torch.gather(O.squared_euclidean_distance(data64[rows], data64), 1, torch.from_numpy(got))
-    assert (torch.from_numpy(dist).double() - exact).abs().max().item() <= 5e-3
+    assert (torch.from_numpy(dist).double() - exact).abs().max().item() <= (5e-3 if dt == torch.float32 else 1e-9)
 
 
-def test_knn_fused_ties_take_the_lower_index(gpu):
+@pytest.mark.parametrize("npdt", [np.float32, np.float64])
+def test_knn_fused_ties_take_the_lower_index(gpu, npdt):
     """Exact duplicates have bit-identical distances: the lower index wins, inside one tile, across tiles and at the k-th place."""
     rng = np.random.default_rng(2)
-    base = rng.random((50, 128), dtype=np.float32)
-    data = np.concatenate([base, base, base[:25], rng.random((200, 128), dtype=np.float32) + 3.0])   # copies at +50 and +100
+    base = rng.random((50, 128)).astype(npdt)
+    data = np.concatenate([base, base, base[:25], rng.random((200, 128)).astype(npdt) + 3.0])   # copies at +50 and +100
     query = base[:40]
     i, dd = C.c_void_p(), C.c_void_p()
     lib.lamp_knn_squared_euclidean(C.byref(i), C.byref(dd), S.STen.from_numpy(data, 0), S.STen.from_numpy(query, 0), 2)
