@@ -295,12 +295,30 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   int64_t one = 1;
   Hold dn(reduce_dims(d2.get(), &one, 1, true, 0)), qn(reduce_dims(q2.get(), &one, 1, true, 0));
   d2 = Hold(); q2 = Hold();
-  // f32, 64 / 128 features, k <= 16: top-k fused into the distance GEMM, no distance block at all (knn_fused.hip)
-  if (Q > 0) {
+  // f32 / f64, up to 128 features, k <= 16: top-k fused into the distance GEMM, no distance block at all (knn_fused.hip).  Widths
+  // other than 64 / 128 are zero-padded to the next of the two (distances unchanged: the padding adds 0 to norms and dot products)
+  if (Q > 0 && (data->dtype == kF32 || data->dtype == kF64) && dim <= 128 && k <= 16) {
+    const int64_t pdim = dim <= 64 ? 64 : 128;
+    Hold dpad, qpad;
+    const Tensor *dsrc = dc.get(), *qsrc = qc.get();
+    if (pdim != dim) {
+      auto pad = [&](const Tensor* t, int64_t rows) {
+        int64_t ps[2] = {rows, pdim};
+        Hold z(new_tensor(ps, 2, t->dtype, t->device()));
+        fill_zero(z.get());
+        lamp_tensor* view = nullptr;
+        LAMP_CHECK(lamp_narrow(&view, z.get(), 1, 0, dim) == 0, lamp_last_error());
+        Hold hv(view);
+        LAMP_CHECK(lamp_copy_(view, t, 1) == 0, lamp_last_error());
+        return z;
+      };
+      dpad = pad(dc.get(), N); qpad = pad(qc.get(), Q);
+      dsrc = dpad.get(); qsrc = qpad.get();
+    }
     int64_t os[2] = {Q, k};
     Hold fi(new_tensor(os, 2, kI64, data->device())), fv(new_tensor(os, 2, data->dtype, data->device()));
     Hold dnc(contiguous(dn.get())), qnc(contiguous(qn.get()));
-    if (knn_fused(qc.get(), dc.get(), qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, dim, k, st)) {
+    if (knn_fused(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st)) {
       *indices = fi.take();
       if (distances) *distances = fv.take();
       return 0;

@@ -56,15 +56,39 @@ def test_knn_matches_reference_algorithm(gpu, dt):
 
 
 def test_knn_chunked_merge(gpu):
-    # several column chunks: 40000 points do not fit the per-call distance block for 512 queries
+    # k = 17 is beyond the fused kernel (k <= 16): column-chunked GEMM + top-k + merge of the per-chunk winners; 40000 points do
+    # not fit the per-call distance block for 512 queries, so several chunks are merged
     data64 = _points(40000, 8, torch.float64)
-    rows = _well_separated_queries(data64, torch.arange(0, 40000, 37)[:700], 5, 1e-2)[:512]
+    rows = _well_separated_queries(data64, torch.arange(0, 40000, 13)[:3000], 17, 1e-2)[:512]
     assert len(rows) > 100
     data, query = data64.float(), data64[rows].float()
-    ref = O.knn_minibatched(data, query, 5, 128)
+    ref = O.knn_minibatched(data, query, 17, 128)
+    lib.lamp_kernel_timer_enable(1)
     i = C.c_void_p()
-    lib.lamp_knn_squared_euclidean(C.byref(i), None, to_sten(data), to_sten(query), 5)
+    lib.lamp_knn_squared_euclidean(C.byref(i), None, to_sten(data), to_sten(query), 17)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    assert b"knn_fused" not in buf.value
     assert np.array_equal(np.sort(S.STen(i).to_numpy(), 1), np.sort(ref.numpy(), 1))
+
+
+def test_knn_narrow_widths_are_padded_onto_the_fused_kernel(gpu):
+    """feature widths other than 64 / 128 (here 8, 50, 100) are zero-padded: same neighbours as the reference algorithm"""
+    for d in (8, 50, 100):
+        g = torch.Generator().manual_seed(d)
+        data64 = torch.rand(2000, d, generator=g, dtype=torch.float64) + (torch.arange(2000) % 16).double().reshape(2000, 1) * 0.25
+        rows = _well_separated_queries(data64, torch.arange(0, 2000, 5), 10, 1e-2)
+        assert len(rows) > 50
+        ref = O.knn_minibatched(data64.float(), data64[rows].float(), 10, 100)
+        lib.lamp_kernel_timer_enable(1)
+        i = C.c_void_p()
+        lib.lamp_knn_squared_euclidean(C.byref(i), None, to_sten(data64.float()), to_sten(data64[rows].float()), 10)
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        lib.lamp_kernel_timer_enable(0)
+        assert b"knn_fused_f32" in buf.value
+        assert np.array_equal(np.sort(S.STen(i).to_numpy(), 1), np.sort(ref.numpy(), 1))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
