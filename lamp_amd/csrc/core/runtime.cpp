@@ -339,7 +339,8 @@ int lamp_graph_release(lamp_graph* g) {
 // ---- convolution -> batch-norm statistics hand-off ------------------------------------------------------------------------
 namespace lamp {
 namespace {
-struct ConvStatsEntry { uint64_t uid = 0, version = 0; int64_t offset = 0, C = 0; lamp_tensor* partial = nullptr; int P = 0; };
+struct ConvStatsEntry { uint64_t uid = 0, version = 0; int64_t offset = 0, N = 0, C = 0, HW = 0; lamp_tensor* partial = nullptr; int P = 0; };
+inline int64_t spatial_of(const lamp_tensor* t) { int64_t hw = 1; for (int i = 2; i < t->ndim; i++) hw *= t->sizes[i]; return hw; }
 constexpr int kConvStatsRing = 32;
 ConvStatsEntry g_conv_stats[kConvStatsRing];
 int g_conv_stats_next = 0;
@@ -351,7 +352,8 @@ void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P) {
   ConvStatsEntry& e = g_conv_stats[g_conv_stats_next];
   g_conv_stats_next = (g_conv_stats_next + 1) % kConvStatsRing;
   if (e.partial) lamp_tensor_release(e.partial);
-  e.uid = y->st->uid; e.version = y->st->version.load(std::memory_order_relaxed); e.offset = y->offset; e.C = y->sizes[1];
+  e.uid = y->st->uid; e.version = y->st->version.load(std::memory_order_relaxed); e.offset = y->offset;
+  e.N = y->sizes[0]; e.C = y->sizes[1]; e.HW = spatial_of(y);
   e.partial = nullptr; e.P = P;
   lamp_tensor_retain(partial, &e.partial);
 }
@@ -360,7 +362,9 @@ lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P) {
   if (!x || !x->st) return nullptr;
   std::lock_guard<std::mutex> lock(g_conv_stats_mu);
   for (auto& e : g_conv_stats) {
-    if (e.partial && e.uid == x->st->uid && e.offset == x->offset && e.C == C && e.version == x->st->version.load(std::memory_order_relaxed)) {
+    // the whole tensor the convolution wrote, unchanged since: same storage, offset, shape and version, and dense
+    if (e.partial && e.uid == x->st->uid && e.offset == x->offset && x->ndim >= 3 && e.N == x->sizes[0] && e.C == C && x->sizes[1] == C &&
+        e.HW == spatial_of(x) && x->is_contiguous() && e.version == x->st->version.load(std::memory_order_relaxed)) {
       lamp_tensor* r = nullptr;
       lamp_tensor_retain(e.partial, &r);
       *P = e.P;

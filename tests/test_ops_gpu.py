@@ -658,6 +658,9 @@ def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k)
     assert_close(to_torch(RV1), to_torch(RV2), 1e-2, "running_var")
     ref = torch.relu(aten.native_batch_norm(to_torch(Ycopy).to(dt), g, b, rm.clone(), rv.clone(), True, 0.1, 1e-5)[0])
     assert_close(to_torch(y1), ref.double(), FWD_TOL[dt] * 4, "against the oracle")
+    half = Y.slice(0, 0, N // 2)                                             # a batch slice shares storage, offset and version: no hand-off
+    _, _, _, rep_half = bn(half)
+    assert b"bn_fwd_stats" in rep_half, "the statistics of the whole batch were used for a slice of it"
     lib.lamp_mul_(Y, Y.onesLike())                                           # any write through the handle bumps the storage version
     _, _, _, rep3 = bn(Y)
     assert b"bn_fwd_stats" in rep3, "stale statistics were used after the tensor had been written"
