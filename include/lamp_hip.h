@@ -462,6 +462,9 @@ int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_
  * materialises the q x n distance matrix.  distances_or_null receives the k values. */
 int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances_or_null, const lamp_tensor* data,
                                const lamp_tensor* query, int64_t k);
+/* the same search under lamp.knn.JaccardDistance (package.scala:16-19, 32-44): 1 - q.x / ((sum q + sum x) - q.x) */
+int lamp_knn_jaccard(lamp_tensor** indices, lamp_tensor** distances_or_null, const lamp_tensor* data,
+                     const lamp_tensor* query, int64_t k);
 /* one fused evaluation of the UMAP layout loss (umap.scala:132-176) and of its gradient w.r.t.
  * `locations`, accumulated into grad_accum:
  *   loss = -(attractions / sum(b) + repulsions * repulsion_strength / |index3|)        (balance != 0)

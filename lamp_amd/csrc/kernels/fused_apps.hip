@@ -30,6 +30,19 @@ __global__ void knn_dist_kernel(T* __restrict__ outer, const T* __restrict__ qn,
     outer[e] = store_as<T>(v > A(0) ? v : A(0));
   }
 }
+// Jaccard: dist[i, j] = 1 - outer / ((qn[i] + dn[j]) - outer)   (knn/package.scala:32-44, same operation order)
+template <class T>
+__global__ void knn_jaccard_kernel(T* __restrict__ outer, const T* __restrict__ qn, const T* __restrict__ dn, int64_t Q, int64_t Nc) {
+  using A = acc_t<T>;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < Q * Nc; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / Nc, j = e - i * Nc;
+    const A o = load_as<A>(outer[e]);
+    const A s = load_as<A>(store_as<T>((A)(load_as<A>(qn[i]) + load_as<A>(dn[j]))));
+    const A den = load_as<A>(store_as<T>((A)(s - o)));
+    const A sim = load_as<A>(store_as<T>((A)(o / den)));
+    outer[e] = store_as<T>((A)(A(1) - sim));
+  }
+}
 // out[i, j] = src[i, idx[i, j]] (+ column offset table for index merging)
 template <class T>
 __global__ void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, T* __restrict__ out, int64_t rows, int64_t k, int64_t srccols) {
@@ -213,7 +226,7 @@ bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, con
                          Tensor* dv, Tensor* dsum, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
-               int64_t k, hipStream_t st);   // knn_fused.hip
+               int64_t k, hipStream_t st, int kind);   // knn_fused.hip
 
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;
@@ -281,8 +294,8 @@ using namespace lamp;
 
 extern "C" {
 
-int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, const lamp_tensor* data, const lamp_tensor* query, int64_t k) {
-  LAMP_API_BEGIN
+}  // extern "C"
+static void knn_impl(lamp_tensor** indices, lamp_tensor** distances, const lamp_tensor* data, const lamp_tensor* query, int64_t k, int kind) {
   check_device_tensor(data, "data"); check_device_tensor(query, "query");
   LAMP_CHECK(data->ndim == 2 && query->ndim == 2 && data->sizes[1] == query->sizes[1] && data->dtype == query->dtype,
              "knn: data " << data->describe() << " and query " << query->describe() << " must be 2-D with equal width and dtype");
@@ -290,11 +303,15 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   LAMP_CHECK(k >= 1 && k <= N, "knn: k = " << k << " out of range for " << N << " points");
   Hold dc(contiguous(data)), qc(contiguous(query));
   hipStream_t st = current_stream(data->device());
-  // squared norms: (v * v).rowSum
-  Hold d2(call1(lamp_square, dc.get())), q2(call1(lamp_square, qc.get()));
+  // Euclidean: squared norms (v * v).rowSum; Jaccard: v.rowSum
   int64_t one = 1;
-  Hold dn(reduce_dims(d2.get(), &one, 1, true, 0)), qn(reduce_dims(q2.get(), &one, 1, true, 0));
-  d2 = Hold(); q2 = Hold();
+  Hold dn, qn;
+  if (kind == 0) {
+    Hold d2(call1(lamp_square, dc.get())), q2(call1(lamp_square, qc.get()));
+    dn = Hold(reduce_dims(d2.get(), &one, 1, true, 0)); qn = Hold(reduce_dims(q2.get(), &one, 1, true, 0));
+  } else {
+    dn = Hold(reduce_dims(dc.get(), &one, 1, true, 0)); qn = Hold(reduce_dims(qc.get(), &one, 1, true, 0));
+  }
   // f32 / f64, up to 128 features, k <= 16: top-k fused into the distance GEMM, no distance block at all (knn_fused.hip).  Widths
   // other than 64 / 128 are zero-padded to the next of the two (distances unchanged: the padding adds 0 to norms and dot products)
   if (Q > 0 && (data->dtype == kF32 || data->dtype == kF64) && dim <= 128 && k <= 16) {
@@ -318,10 +335,10 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
     int64_t os[2] = {Q, k};
     Hold fi(new_tensor(os, 2, kI64, data->device())), fv(new_tensor(os, 2, data->dtype, data->device()));
     Hold dnc(contiguous(dn.get())), qnc(contiguous(qn.get()));
-    if (knn_fused(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st)) {
+    if (knn_fused(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st, kind)) {
       *indices = fi.take();
       if (distances) *distances = fv.take();
-      return 0;
+      return;
     }
   }
   // column chunk so that the Q x chunk block stays around 256 MB
@@ -336,15 +353,20 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
     LAMP_CHECK(lamp_narrow(&dnsl, dn.get(), 0, lo, len) == 0, lamp_last_error()); Hold hdn(dnsl);
     int64_t os[2] = {Q, len};
     Hold outer(new_tensor(os, 2, data->dtype, data->device()));
-    if (data->dtype == kF32 || data->dtype == kF64) {
+    if (kind == 0 && (data->dtype == kF32 || data->dtype == kF64)) {
       // distance block in the GEMM epilogue: the q x chunk block is written once and never re-read before the top-k
       Hold hdnc(contiguous(dnsl));
       knn_distance_block(outer.get(), qc.get(), dsl, qn.get(), hdnc.get());
     } else {
       LAMP_CHECK(lamp_addmm_out_transposed2(outer.get(), outer.get(), qc.get(), dsl, 0.0, 1.0) == 0, lamp_last_error());   // q . x^T
       if (Q * len > 0) {
-        LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_dist_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
-                                                               outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
+        if (kind == 0) {
+          LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_dist_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
+                                                                 outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
+        } else {
+          LAMP_DISPATCH_FLOAT(data->dtype, T, hipLaunchKernelGGL((knn_jaccard_kernel<T>), dim3(grid_for(Q * len, 256)), dim3(256), 0, st,
+                                                                 outer->ptr<T>(), qn->ptr<T>(), hdn->ptr<T>(), Q, len));
+        }
         LAMP_LAUNCH_CHECK();
       }
     }
@@ -380,6 +402,16 @@ int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, c
   }
   *indices = best_i.take();
   if (distances) *distances = best_v.take();
+}
+extern "C" {
+int lamp_knn_squared_euclidean(lamp_tensor** indices, lamp_tensor** distances, const lamp_tensor* data, const lamp_tensor* query, int64_t k) {
+  LAMP_API_BEGIN
+  knn_impl(indices, distances, data, query, k, 0);
+  LAMP_API_END
+}
+int lamp_knn_jaccard(lamp_tensor** indices, lamp_tensor** distances, const lamp_tensor* data, const lamp_tensor* query, int64_t k) {
+  LAMP_API_BEGIN
+  knn_impl(indices, distances, data, query, k, 1);
   LAMP_API_END
 }
 

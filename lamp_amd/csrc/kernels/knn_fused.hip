@@ -57,7 +57,7 @@ template <class T> struct KfWaveState {
   int cr[KF_CAND];
 };
 
-template <class T, int DIM>
+template <class T, int DIM, int KIND>   // KIND 0: squared Euclidean (qn, dn = squared norms), 1: Jaccard (qn, dn = row sums)
 __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__ q, const T* __restrict__ x, const T* __restrict__ qn,
                                                            const T* __restrict__ dn, int64_t* __restrict__ out_idx, T* __restrict__ out_val,
                                                            int Q, int N, int k) {
@@ -129,9 +129,13 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
   int col0_old = N;                            // no valid column: the first pass filters nothing
 
   // distances of one accumulator tile in the reference's operation order: (|q|^2 + |x|^2) - 2 q.x, then the clamp
+  // Jaccard (knn/package.scala:32-44): 1 - q.x / ((sum q + sum x) - q.x), 0 / 0 -> NaN, which no threshold test ever passes
   auto dist4 = [&](const acc_t& a, int t, T dnv, T* v) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) { const T d = (qnr[t][r] + dnv) - T(2) * a[r]; v[r] = d > T(0) ? d : T(0); }
+    for (int r = 0; r < 4; r++) {
+      if constexpr (KIND == 0) { const T d = (qnr[t][r] + dnv) - T(2) * a[r]; v[r] = d > T(0) ? d : T(0); }
+      else { const T den = (qnr[t][r] + dnv) - a[r]; v[r] = T(1) - a[r] / den; }
+    }
   };
   // slow path (probability ~ k / points seen per candidate): append the passing candidates of every accumulator tile to the
   // wave's buffer (ballot + prefix count) and let lane r insert the entries of row r into that row's sorted list
@@ -260,26 +264,28 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
 }
 
 // indices [Q, k] i64, values [Q, k] of the data's dtype; qn [Q], dn [N] squared norms.  Returns false when the shape is not covered.
-template <class T, int D>
+template <class T, int D, int KIND>
 static void knn_fused_launch(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
                              hipStream_t st) {
   static bool attr = false;
-  if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)knn_fused_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)knn_fused_kernel<T, D, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
   const dim3 grid((unsigned)((Q + KF_BQ - 1) / KF_BQ));
   const size_t lds = (size_t)2 * KfTraits<T>::BC * D * sizeof(T) + 4 * sizeof(KfWaveState<T>);
-  hipLaunchKernelGGL((knn_fused_kernel<T, D>), grid, dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(), idx->ptr<int64_t>(), val->ptr<T>(),
+  hipLaunchKernelGGL((knn_fused_kernel<T, D, KIND>), grid, dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(), idx->ptr<int64_t>(), val->ptr<T>(),
                      (int)Q, (int)N, (int)k);
 }
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
-               int64_t k, hipStream_t st) {
+               int64_t k, hipStream_t st, int kind) {
   static const bool enabled = [] { const char* e = getenv("LAMP_KNN_FUSED"); return !(e && e[0] == '0'); }();
   const bool f32 = q->dtype == kF32, f64 = q->dtype == kF64;
   if (!enabled || !(f32 || f64) || !(dim == 64 || dim == 128) || k < 1 || k > KF_KMAX || N > 0x7fffff00 || Q > 0x7fffff00 || N < k || Q < 1) return false;
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
   KernelTimer kt(f32 ? "knn_fused_f32" : "knn_fused_f64", 2.0 * (double)Q * N * dim, ((double)Q + N) * dim * (f32 ? 4 : 8), st);
-  if (f32) { if (dim == 128) knn_fused_launch<float, 128>(q, x, qn, dn, idx, val, Q, N, k, st); else knn_fused_launch<float, 64>(q, x, qn, dn, idx, val, Q, N, k, st); }
-  else     { if (dim == 128) knn_fused_launch<double, 128>(q, x, qn, dn, idx, val, Q, N, k, st); else knn_fused_launch<double, 64>(q, x, qn, dn, idx, val, Q, N, k, st); }
+#define KF_GO(TT, DD) do { if (kind == 0) knn_fused_launch<TT, DD, 0>(q, x, qn, dn, idx, val, Q, N, k, st); else knn_fused_launch<TT, DD, 1>(q, x, qn, dn, idx, val, Q, N, k, st); } while (0)
+  if (f32) { if (dim == 128) KF_GO(float, 128); else KF_GO(float, 64); }
+  else     { if (dim == 128) KF_GO(double, 128); else KF_GO(double, 64); }
+#undef KF_GO
   LAMP_LAUNCH_CHECK();
   return true;
 }

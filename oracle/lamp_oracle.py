@@ -743,10 +743,19 @@ def squared_euclidean_distance(v1: torch.Tensor, v2: torch.Tensor) -> torch.Tens
     return aten.maximum(n1 + n2.t() - outer * 2, torch.zeros(1, dtype=v1.dtype))
 
 
-def knn_minibatched(d: torch.Tensor, query: torch.Tensor, k: int, minibatch: int) -> torch.Tensor:
+def jaccard_distance(v1: torch.Tensor, v2: torch.Tensor) -> torch.Tensor:    # package.scala:32-44
+    outer = aten.mm(v1, v2.t())
+    n1 = aten.sum.dim_IntList(v1, [1], True)
+    n2 = aten.sum.dim_IntList(v2, [1], True)
+    denom = n1 + n2.t() - outer
+    sim = outer / denom
+    return torch.ones(1, dtype=sim.dtype) - sim
+
+
+def knn_minibatched(d: torch.Tensor, query: torch.Tensor, k: int, minibatch: int, distance=None) -> torch.Tensor:
     outs = []
     for s in range(0, query.shape[0], minibatch):
-        dist = squared_euclidean_distance(query[s:s + minibatch], d)
+        dist = (distance or squared_euclidean_distance)(query[s:s + minibatch], d)
         _, idx = aten.topk(dist, k, 1, False, False)
         outs.append(idx)
     return torch.cat(outs, 0)

@@ -136,6 +136,32 @@ def test_knn_fused_ties_take_the_lower_index(gpu, npdt):
     assert np.array_equal(got3[:25, 2], np.arange(25) + 100)
 
 
+@pytest.mark.parametrize("d,k", [(128, 5), (40, 3), (200, 4)])
+def test_knn_jaccard_and_host_api(gpu, d, k):
+    """lamp.knn.JaccardDistance on binary feature vectors (fused kernel for d <= 128, composed blocks above) against the reference
+    algorithm, and the host-side API (knnSearch / classification / regression) of lamp_amd.knn."""
+    from lamp_amd import knn as K
+    g = torch.Generator().manual_seed(3)
+    n = 1500
+    data = (torch.rand(n, d, generator=g) < 0.3).double()
+    data[:, 0] = 1.0                                                  # no empty rows (0 / 0)
+    dist = O.jaccard_distance(data, data)
+    v, _ = torch.topk(dist, k + 1, 1, largest=False, sorted=True)
+    rows = torch.arange(n)[(v[:, k] - v[:, k - 1]) > 1e-6][:400]      # the k-NN set is decided by the data
+    assert len(rows) > 50
+    ref = O.knn_minibatched(data, data[rows], k, 100, O.jaccard_distance).numpy()
+    for precision, dt in (("f64", np.float64), ("f32", np.float32)):
+        got = K.knnSearch(data.numpy(), data[rows].numpy(), k, K.JaccardDistance, 0, precision, 100)
+        assert got.dtype == np.int32 and np.array_equal(np.sort(got, 1), np.sort(ref, 1)), precision
+    # Euclidean through the same API + the host post-processing
+    labels = (np.arange(n) % 3).astype(np.int64)
+    idx = K.knnSearch(data.numpy(), data[:10].numpy(), 4, K.SquaredEuclideanDistance, 0, "f64")
+    cls = K.classification(labels, idx, 3, False)
+    assert cls.shape == (10, 3) and np.allclose(cls.sum(1), 1.0)
+    assert np.allclose(K.regression(labels.astype(np.float64), idx), labels[idx].mean(1))
+    assert np.allclose(K.classification(labels, idx, 3, True), np.log(cls + 1e-6))
+
+
 @pytest.mark.parametrize("min_dist", [0.0, 0.3])
 def test_umap_fused_loss_and_gradient(gpu, min_dist):
     n, e1, e2 = 200, 700, 3000
