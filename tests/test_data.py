@@ -244,3 +244,58 @@ def test_training_from_stream_and_resume(gpu, tmp_path):
     run(model2, opt2, order2)
     for a, b in zip(net.state, net2.state):
         assert np.array_equal(a.value.to_numpy(), b.value.to_numpy())
+
+
+@pytest.mark.gpu
+def test_one_epoch_loops(gpu):
+    """IOLoops.oneEpoch / validationOneEpoch: the epoch loop equals the hand-written per-batch loop; accumulating gradients over N
+    batches steps once per N batches with the summed gradient; validation runs in eval mode and leaves the parameters alone."""
+    from lamp_amd import nn, loops
+    from lamp_amd._capi import lib
+    rng = np.random.default_rng(0)
+    n = 96
+    x = S.STen.from_numpy(rng.standard_normal((n, 20)).astype(np.float32), 0)
+    y = S.STen.from_numpy((np.arange(n) % 4).astype(np.int64), 0)
+
+    def make():
+        lib.lamp_manual_seed(11)
+        net = nn.Sequential(nn.MLP(20, 4, [16], S.F32, 0), nn.Fun("logsoftmax", 1))
+        model = nn.SupervisedModel(net, nn.SupervisedModel.NLL, S.STen.ones([4], S.F32, 0))
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-2)([p.value for p in net.parameters])
+        return net, model, opt
+
+    order = list(range(n))
+    # (1) epoch loop == manual loop
+    net1, model1, opt1 = make()
+    st1 = D.BatchStream.minibatchesFromFull(16, False, x, y, order=order)
+    logs = []
+    l1 = loops.oneEpoch(0, model1, opt1, st1, logger=logs.append)
+    assert logs and "Avg training loss in epoch 0 over 96 examples" in logs[0]
+    net2, model2, opt2 = make()
+    acc = S.STen.zeros([1], S.F32, 0)
+    tot = 0
+    for bx, by in D.BatchStream.minibatchesFromFull(16, False, x, y, order=order):
+        tot += model2.train_step(opt2, bx, by, acc)
+    assert tot == n and abs(l1 - float(acc.to_numpy()[0]) / n) < 1e-7
+    for a, b in zip(net1.state, net2.state):
+        assert np.array_equal(a.value.to_numpy(), b.value.to_numpy())
+    # (2) accumulation over 2 batches of 16 == one step on the summed gradients of the two batches
+    net3, model3, opt3 = make()
+    st3 = D.BatchStream.minibatchesFromFull(16, False, x, y, order=order[:32])
+    loops.oneEpoch(0, model3, opt3, st3, accumulateGradientOverNBatches=2)
+    net4, model4, opt4 = make()
+    net4.zeroGrad()
+    grads = None
+    for bx, by in D.BatchStream.minibatchesFromFull(16, False, x, y, order=order[:32]):
+        _, grads = model4.addTotalLossAndReturnGradientsAndNumExamples(bx, by, None, False)
+    opt4.step(grads, 1.0)
+    for a, b in zip(net3.state, net4.state):
+        assert np.allclose(a.value.to_numpy(), b.value.to_numpy(), rtol=0, atol=1e-7)
+    # (3) validation: eval mode (batch norm uses its running statistics), parameters untouched, mode restored
+    before = [v.value.to_numpy().copy() for v in net1.state]
+    vl = loops.validationOneEpoch(model1, D.BatchStream.minibatchesFromFull(32, False, x, y, order=order))
+    assert np.isfinite(vl) and all(np.array_equal(a, v.value.to_numpy()) for a, v in zip(before, net1.state))
+    # a learning-rate factor of 0 leaves the parameters where they are (the schedule factor reaches the optimizer)
+    loops.oneEpoch(1, model1, opt1, st1, learningRateScheduleFactor=0.0)
+    changed = [not np.array_equal(a, v.value.to_numpy()) for a, v in zip(before, net1.state) if v.needsGrad]
+    assert not any(changed)
