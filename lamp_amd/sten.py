@@ -396,3 +396,37 @@ def synchronize():
 
 def live_tensor_count() -> int:
     n = C.c_int64(); lib.lamp_live_tensor_count(C.byref(n)); return n.value
+
+
+# ---- Device.toBatched / BufferPair (lamp-sten/src/main/scala/lamp/device.scala:48-114, :236-249) --------------------------------
+class BufferPair:
+    """a (pinned) host source buffer and a device destination buffer of `size` elements"""
+
+    def __init__(self, source: STen, destination: STen):
+        self.source, self.destination = source, destination
+
+    @staticmethod
+    def allocate(size: int, device: int, dtype: int = F32) -> "BufferPair":
+        o = _out(); lib.lamp_empty(C.byref(o), i64_array([size]), 1, dtype, CPU)
+        host = STen(o)
+        p = _out(); lib.lamp_pin_memory(C.byref(p), host)
+        d = _out(); lib.lamp_empty(C.byref(d), i64_array([size]), 1, dtype, device)
+        return BufferPair(STen(p), STen(d))
+
+
+def toBatched(tensors: Sequence[STen], buffers: BufferPair) -> list:
+    """Device.toBatched: the tensors (one dtype, on the source buffer's device) are concatenated into the host buffer, cross the bus
+    in ONE copy and are split into clones on the destination device - the same ATen call sequence as the reference (view, slice,
+    cat_out, copyFrom, narrow, view, clone)."""
+    views = [t.view(-1) for t in tensors]
+    sizes = [v.numel for v in views]
+    total = sum(sizes)
+    host_slice = buffers.source.slice(0, 0, total)
+    lib.lamp_cat_out(host_slice, handle_array([v.h for v in views]), len(views), 0)
+    buffers.destination.slice(0, 0, total).copyFrom(host_slice, True)
+    dev = buffers.destination.slice(0, 0, total)
+    out, off = [], 0
+    for t, n in zip(tensors, sizes):
+        out.append(dev.narrow(0, off, n).view(*t.shape).cloneTensor())
+        off += n
+    return out

@@ -299,3 +299,27 @@ def test_one_epoch_loops(gpu):
     loops.oneEpoch(1, model1, opt1, st1, learningRateScheduleFactor=0.0)
     changed = [not np.array_equal(a, v.value.to_numpy()) for a, v in zip(before, net1.state) if v.needsGrad]
     assert not any(changed)
+
+
+def test_host_staging_cat_out_without_gpu():
+    """the host half of Device.toBatched (device.scala:80-92): flat views concatenated into a slice of the staging buffer"""
+    from lamp_amd._capi import lib, handle_array
+    a, b = _host(np.arange(6, dtype=np.float32).reshape(2, 3)), _host(np.arange(4, dtype=np.float32) + 10)
+    buf = _host(np.zeros(16, np.float32))
+    va, vb, dst = a.view(-1), b.view(-1), buf.slice(0, 0, 10)      # keep the handles alive across the call
+    lib.lamp_cat_out(dst, handle_array([va.h, vb.h]), 2, 0)
+    assert np.array_equal(buf.to_numpy(), np.concatenate([np.arange(6), np.arange(4) + 10, np.zeros(6)]).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_to_batched(gpu):
+    """Device.toBatched: several host tensors reach the device through one pinned buffer and one copy"""
+    rng = np.random.default_rng(0)
+    arrs = [rng.standard_normal(s).astype(np.float32) for s in ((3, 4), (5,), (2, 2, 2), (1,))]
+    bufs = S.BufferPair.allocate(64, 0, S.F32)
+    out = S.toBatched([_host(a) for a in arrs], bufs)
+    for a, t in zip(arrs, out):
+        assert t.device == 0 and t.shape == list(a.shape) and np.array_equal(t.to_numpy(), a)
+    out2 = S.toBatched([_host(a + 1) for a in arrs], bufs)          # the buffers are reused; earlier results are clones
+    for a, t, t2 in zip(arrs, out, out2):
+        assert np.array_equal(t.to_numpy(), a) and np.array_equal(t2.to_numpy(), a + 1)
