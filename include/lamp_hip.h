@@ -492,8 +492,18 @@ int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, c
                                   const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
                                   int balance, double repulsion_strength, const double* term_weights);
 
+/* The layout with its EDGE LIST sharded over ranks (lamp-umap is single-device): every rank evaluates its slice of the
+ * attractive edges and its own negatives under GLOBAL normalisers - bsum (sum of b over all ranks, one element of b's dtype) and
+ * kept (all-reduced lamp_count_ne of the negatives, one int64) - and the caller all-reduces gradient and loss. */
+int lamp_count_ne(lamp_tensor** out /* int64 [1] on the device */, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_umap_loss_grad_sharded(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations,
+                                const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
+                                const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
+                                int balance, double repulsion_strength, const double* term_weights,
+                                const lamp_tensor* bsum_global, const lamp_tensor* kept_global);
+
 /* ------------------------------------------------------------------------------------------
- * collectives over RCCL / xGMI   (aten.NcclComm.{get_unique_id, comm_init_rank, broadcast,
+ * collectives over RCCL / xGMI  (aten.NcclComm.{get_unique_id, comm_init_rank, broadcast,
  * reduce, comm_destroy}: STen.scala:629-671,1902-1908; call sites
  * lamp-data/.../distributed/package.scala:683-731).  all_reduce is the addition the
  * data-parallel redesign needs (one flat bucket instead of 74 broadcasts + 38 reduces).

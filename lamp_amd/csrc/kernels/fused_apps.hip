@@ -469,7 +469,8 @@ int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, 
 }  // extern "C"
 static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
                                 const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
-                                double repulsion_strength, const double* term_weights, int skip_self) {
+                                double repulsion_strength, const double* term_weights, int skip_self,
+                                const lamp_tensor* bsum_global = nullptr, const lamp_tensor* kept_global = nullptr) {
   check_device_tensor(locations, "locations"); check_device_tensor(grad_accum, "grad_accum");
   check_device_tensor(index1, "index1"); check_device_tensor(index2, "index2"); check_device_tensor(index3, "index3"); check_device_tensor(index4, "index4");
   check_device_tensor(b, "b");
@@ -480,18 +481,26 @@ static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, con
   const int64_t E1 = index1->numel(), E2 = index3->numel();
   LAMP_CHECK(index2->numel() == E1 && b->numel() == E1 && index4->numel() == E2 && b->dtype == locations->dtype && b->is_contiguous(), "umap: edge list size mismatch");
   hipStream_t st = current_stream(locations->device());
-  Hold bsum(reduce_dims(b, nullptr, 0, false, 0));
+  // sharded edge lists (one slice per rank): the normalisers are the GLOBAL sum of b and count of kept negatives, handed in
+  Hold bsum;
+  if (bsum_global) {
+    check_device_tensor(bsum_global, "bsum"); LAMP_CHECK(bsum_global->dtype == b->dtype && bsum_global->numel() == 1, "umap: bsum must be one element of b's dtype");
+    lamp_tensor* r = nullptr; LAMP_CHECK(lamp_tensor_retain(bsum_global, &r) == 0, lamp_last_error()); bsum = Hold(r);
+  } else bsum = Hold(reduce_dims(b, nullptr, 0, false, 0));
   int64_t one[1] = {1};
   Hold acc(new_tensor(one, 1, kF64, locations->device()));
   fill_zero(acc.get());
   Hold out(new_tensor(nullptr, 0, locations->dtype, locations->device()));
   Hold kept;                                   // number of negative pairs that do not hit themselves (device scalar; no host sync)
-  if (skip_self) {
+  if (kept_global) {
+    check_device_tensor(kept_global, "kept"); LAMP_CHECK(kept_global->dtype == kI64 && kept_global->numel() == 1, "umap: kept must be one int64");
+    lamp_tensor* r = nullptr; LAMP_CHECK(lamp_tensor_retain(kept_global, &r) == 0, lamp_last_error()); kept = Hold(r);
+  } else if (skip_self) {
     kept = Hold(new_tensor(one, 1, kI64, locations->device()));
     fill_zero(kept.get());
     if (E2 > 0) { hipLaunchKernelGGL(count_ne_kernel, dim3(grid_for(E2, 256)), dim3(256), 0, st, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, kept->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
   }
-  const int64_t* keptp = skip_self ? kept->ptr<int64_t>() : nullptr;
+  const int64_t* keptp = kept.get() ? static_cast<const Tensor*>(kept.get())->ptr<int64_t>() : nullptr;
   const double w[4] = {term_weights ? term_weights[0] : 1.0, term_weights ? term_weights[1] : 1.0, term_weights ? term_weights[2] : 1.0,
                        term_weights ? term_weights[3] : 1.0};
   static const bool pairs2 = [] { const char* e = getenv("LAMP_UMAP_PAIRS2"); return !(e && e[0] == '0'); }();
@@ -527,6 +536,30 @@ int lamp_umap_loss_grad(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_
                         double repulsion_strength, const double* term_weights) {
   LAMP_API_BEGIN
   umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, index3, index4, min_dist, balance, repulsion_strength, term_weights, 0);
+  LAMP_API_END
+}
+// building blocks of the layout with the EDGE LIST sharded over ranks: number of pairs a != b as a device scalar, and
+// the loss / gradient of a slice of the pairs under global normalisers; the caller all-reduces the count, the gradient and the loss
+int lamp_count_ne(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "a"); check_device_tensor(b, "b");
+  LAMP_CHECK(a->dtype == kI64 && b->dtype == kI64 && a->is_contiguous() && b->is_contiguous() && a->numel() == b->numel(), "count_ne: two contiguous int64 tensors of one size");
+  int64_t one[1] = {1};
+  Hold r(new_tensor(one, 1, kI64, a->device()));
+  fill_zero(r.get());
+  const int64_t n = a->numel();
+  if (n > 0) { hipLaunchKernelGGL(count_ne_kernel, dim3(grid_for(n, 256)), dim3(256), 0, current_stream(a->device()), a->ptr<int64_t>(), b->ptr<int64_t>(), n, r->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_umap_loss_grad_sharded(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1,
+                                const lamp_tensor* index2, const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
+                                int balance, double repulsion_strength, const double* term_weights, const lamp_tensor* bsum_global,
+                                const lamp_tensor* kept_global) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(bsum_global && kept_global, "umap sharded: the global normalisers are required");
+  umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, index3, index4, min_dist, balance, repulsion_strength, term_weights, 1, bsum_global,
+                      kept_global);
   LAMP_API_END
 }
 int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1,

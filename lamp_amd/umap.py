@@ -84,6 +84,53 @@ def optimize(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDis
     return locations, last
 
 
+def optimize_sharded(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDist: float, negativeSampleSize: int, randomSeed: int,
+                     balanceAttractionsAndRepulsions: bool, repulsionStrength: float, device: int, numDim: int, comm, world: int, rank: int,
+                     log=None) -> Tuple[S.STen, float]:
+    """Umap.optimize with the edge list sharded over `world` ranks (lamp-umap itself is single-device): rank r takes
+    every world-th edge and draws the negatives of its own edges; the normalisers (sum of b, number of kept negatives) are made
+    global with two small all-reduces, the [n, numDim] gradient (16 MB f64 at 1M points) and the loss with one each per iteration;
+    every rank applies the same AdamW step, so the layouts stay bit-identical across ranks.  world == 1 reproduces `optimize`."""
+    def all_reduce(t):
+        if comm is not None and world > 1:
+            lib.lamp_comm_all_reduce((C.c_void_p * 1)(t.h), (C.c_void_p * 1)(comm), 1, 0)
+
+    lib.lamp_manual_seed(int(randomSeed))
+    locations = S.STen.rand([total, numDim], S.F64, device)                 # same seed, same initial layout on every rank
+    if world > 1:
+        lib.lamp_manual_seed(int(randomSeed) + 7919 * (rank + 1))           # but different negatives
+    sel = S.STen.from_numpy(np.arange(rank, edgeWeights.shape[0], world, dtype=np.int64), device)
+    index1 = edgeWeights.select(1, 0).castToLong().indexSelect(0, sel)
+    index2 = edgeWeights.select(1, 1).castToLong().indexSelect(0, sel)
+    b = edgeWeights.select(1, 2).contiguous().indexSelect(0, sel)
+    bsum = b.sum().view(1)
+    all_reduce(bsum)
+    opt = nn.AdamW_factory(weightDecay=0.0, learningRate=lr, clip=1.0)([locations])
+    grad = S.STen.zeros([total, numDim], S.F64, device)
+    weights = f64_array([1.0, 2.0, 4.0, 8.0])
+    last = 0.0
+    for it in range(int(iterations)):
+        ii = index1.repeatInterleave(int(negativeSampleSize), 0)
+        jj = S.STen.randint(0, total - 1, [ii.shape[0]], S.I64, device)
+        kept = C.c_void_p()
+        lib.lamp_count_ne(C.byref(kept), ii, jj)
+        kept = S.STen(kept)
+        all_reduce(kept)
+        grad.zero_()
+        out = C.c_void_p()
+        lib.lamp_umap_loss_grad_sharded(C.byref(out), grad, locations, index1, index2, b, ii, jj, float(minDist), int(bool(balanceAttractionsAndRepulsions)),
+                                        float(repulsionStrength), weights, bsum, kept)
+        loss = S.STen(out).view(1)
+        all_reduce(grad)
+        if log is not None or it == int(iterations) - 1:
+            all_reduce(loss)
+            last = float(loss.to_numpy().reshape(-1)[0])
+            if log is not None:
+                log(f"loss in epoch: {(it, last)}")
+        opt.step([grad], 1.0)
+    return locations, last
+
+
 def umapCustomKnn(knn: S.STen, knnDistances: S.STen, device: int = 0, numDim: int = 2, lr: float = 0.1, iterations: int = 500,
                   minDist: float = 0.0, negativeSampleSize: int = 5, randomSeed: int = 42, balanceAttractionsAndRepulsions: bool = True,
                   repulsionStrength: float = 1.0, positiveSamples: Optional[int] = None, log=None):

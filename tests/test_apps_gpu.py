@@ -303,6 +303,48 @@ def test_umap_skip_self_equals_masked_pairs(gpu):
         assert np.abs(res[0][1] - res[1][1]).max() <= 1e-12 * np.abs(res[0][1]).max()
 
 
+def test_umap_sharded_layout_building_blocks(gpu):
+    """Edge list split over ranks: the sum over the shards of lamp_umap_loss_grad_sharded (global normalisers handed in) equals the
+    unsharded loss / gradient; with one rank optimize_sharded reproduces optimize."""
+    from lamp_amd import umap as U
+    rng = np.random.default_rng(8)
+    n, e1 = 400, 2400
+    loc = S.STen.from_numpy(rng.random((n, 2)), 0, S.F64)
+    a1 = np.sort(rng.integers(0, n, e1)); a2 = (a1 + 1 + rng.integers(0, n - 1, e1)) % n
+    bb = rng.random(e1)
+    a3 = np.repeat(a1, 3); a4 = rng.integers(0, n, a3.shape[0]); a4[::11] = a3[::11]
+    w = f64_array([1.0, 2.0, 4.0, 8.0])
+    T = lambda a, dt=None: S.STen.from_numpy(a, 0, dt)
+    g_all = S.STen.zeros([n, 2], S.F64)
+    lo = C.c_void_p()
+    lib.lamp_umap_loss_grad_skip_self(C.byref(lo), g_all, loc, T(a1), T(a2), T(bb, S.F64), T(a3), T(a4), 0.0, 1, 1.0, w)
+    loss_all = float(S.STen(lo).to_numpy())
+    kept = C.c_void_p()
+    lib.lamp_count_ne(C.byref(kept), T(a3), T(a4))
+    kept = S.STen(kept)
+    assert int(kept.to_numpy()[0]) == int((a3 != a4).sum())
+    bsum = T(np.array([bb.sum()]), S.F64)
+    world = 3
+    g_sum, loss_sum = np.zeros((n, 2)), 0.0
+    for r in range(world):
+        e = np.arange(r, e1, world)
+        neg = np.concatenate([np.arange(3 * i, 3 * i + 3) for i in e])
+        g = S.STen.zeros([n, 2], S.F64)
+        lo = C.c_void_p()
+        lib.lamp_umap_loss_grad_sharded(C.byref(lo), g, loc, T(a1[e]), T(a2[e]), T(bb[e], S.F64), T(a3[neg]), T(a4[neg]), 0.0, 1, 1.0, w, bsum, kept)
+        g_sum += g.to_numpy(); loss_sum += float(S.STen(lo).to_numpy())
+    assert abs(loss_sum - loss_all) <= 1e-11 * abs(loss_all)
+    assert np.abs(g_sum - g_all.to_numpy()).max() <= 1e-11 * np.abs(g_all.to_numpy()).max()
+    # one rank: the sharded driver is the plain one
+    knn_idx = (np.arange(n)[:, None] + 1 + rng.integers(0, n - 1, (n, 6))) % n
+    knn_idx[:, 0] = np.arange(n)
+    dist = np.sort(rng.random((n, 6)), 1); dist[:, 0] = 0.0
+    ew = U.edge_weights(T(dist, S.F64), T(knn_idx.astype(np.int64)))
+    l1, v1 = U.optimize(ew, n, 0.1, 5, 0.0, 5, 42, True, 1.0, 0, 2)
+    l2, v2 = U.optimize_sharded(ew, n, 0.1, 5, 0.0, 5, 42, True, 1.0, 0, 2, None, 1, 0)
+    assert abs(v1 - v2) <= 1e-9 * abs(v1) and np.abs(l1.to_numpy() - l2.to_numpy()).max() <= 1e-9
+
+
 def test_knn_and_umap_at_full_size_properties(gpu):
     """BASELINE config 5 at its full size (1M x 128 f32 points, k = 10): size-independent properties instead of an oracle.
     kNN (262,144 query rows against all 1M points): the query itself is a neighbour at distance ~0, indices are in range and
