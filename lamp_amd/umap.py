@@ -23,7 +23,7 @@ import numpy as np
 
 from . import nn
 from . import sten as S
-from ._capi import lib, f64_array
+from ._capi import lib, f64_array, handle_array
 
 
 def knn_search(features: S.STen, query: S.STen, k: int, minibatchSize: int = 1000) -> S.STen:
@@ -92,8 +92,8 @@ def optimize_sharded(edgeWeights: S.STen, total: int, lr: float, iterations: int
     global with two small all-reduces, the [n, numDim] gradient (16 MB f64 at 1M points) and the loss with one each per iteration;
     every rank applies the same AdamW step, so the layouts stay bit-identical across ranks.  world == 1 reproduces `optimize`."""
     def all_reduce(t):
-        if comm is not None and world > 1:
-            lib.lamp_comm_all_reduce((C.c_void_p * 1)(t.h), (C.c_void_p * 1)(comm), 1, 0)
+        if comm is not None:
+            lib.lamp_comm_all_reduce(handle_array([t.h]), handle_array([comm.value if isinstance(comm, C.c_void_p) else comm]), 1, 0)
 
     lib.lamp_manual_seed(int(randomSeed))
     locations = S.STen.rand([total, numDim], S.F64, device)                 # same seed, same initial layout on every rank

@@ -152,6 +152,12 @@ def test_sharded_knn_single_rank_and_all_gather(gpu):
     try:
         got = D.knn_search_sharded(X, 5, h, 1, 0).to_numpy()
         assert np.array_equal(got, ref)
+        # the sharded UMAP layout driver through a real (1-rank) communicator: its all-reduces run and change nothing
+        dist = np.sort(rng.random((500, 5)), 1); dist[:, 0] = 0.0
+        ew = U.edge_weights(S.STen.from_numpy(dist, 0, S.F64), S.STen.from_numpy(ref.astype(np.int64), 0))
+        l1, v1 = U.optimize(ew, 500, 0.1, 4, 0.0, 5, 42, True, 1.0, 0, 2)
+        l2, v2 = U.optimize_sharded(ew, 500, 0.1, 4, 0.0, 5, 42, True, 1.0, 0, 2, h, 1, 0)
+        assert abs(v1 - v2) <= 1e-9 * abs(v1) and np.abs(l1.to_numpy() - l2.to_numpy()).max() <= 1e-9
         src = S.STen.from_numpy(np.arange(12, dtype=np.int64).reshape(3, 4), 0)
         dst = S.STen.zeros([3, 4], S.I64, 0)
         lib.lamp_comm_all_gather(dst, src, h)
