@@ -598,6 +598,136 @@ __global__ void ln_bwd_finalize_kernel(const acc_t<T>* __restrict__ partial, T* 
   if (dbias) dbias[d] = store_as<T>(b);
 }
 
+// ---- vectorised layer norm: a wavefront per row, the row held in registers as up to MAXP 16-byte packets per lane -------------
+// (the scalar kernels above re-read the row and pay a division per element in their Welford update: 1.1-1.7 TB/s on 16384 x 4096
+// bf16).  Two passes over the REGISTERS: mean, then the centred sum of squares.
+template <class T, int MAXP>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ mean_out,
+                                                         T* __restrict__ rstd_out, const T* __restrict__ w, const T* __restrict__ b, int64_t M,
+                                                         int64_t D, double eps) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= M) return;
+  const int npk = (int)(D / W);
+  const Vec<T, W>* xp = reinterpret_cast<const Vec<T, W>*>(x + row * D);
+  Vec<T, W> pk[MAXP];
+  A s = 0;
+#pragma unroll
+  for (int i = 0; i < MAXP; i++) {
+    const int p = lane + 64 * i;
+    if (p < npk) {
+      pk[i] = xp[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) s += load_as<A>(pk[i].v[k]);
+    }
+  }
+  const A mu = wave_sum(s) / (A)D;
+  A q = 0;
+#pragma unroll
+  for (int i = 0; i < MAXP; i++)
+    if (lane + 64 * i < npk) {
+#pragma unroll
+      for (int k = 0; k < W; k++) { const A d = load_as<A>(pk[i].v[k]) - mu; q += d * d; }
+    }
+  const A rstd = A(1) / (A)sqrt((double)(wave_sum(q) / (A)D + (A)eps));
+  if (lane == 0) { mean_out[row] = store_as<T>(mu); rstd_out[row] = store_as<T>(rstd); }
+  Vec<T, W>* yp = reinterpret_cast<Vec<T, W>*>(y + row * D);
+#pragma unroll
+  for (int i = 0; i < MAXP; i++) {
+    const int p = lane + 64 * i;
+    if (p < npk) {
+      Vec<T, W> wv, bv, o;
+      if (w) wv = reinterpret_cast<const Vec<T, W>*>(w)[p];
+      if (b) bv = reinterpret_cast<const Vec<T, W>*>(b)[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        A v = (load_as<A>(pk[i].v[k]) - mu) * rstd;
+        if (w) v *= load_as<A>(wv.v[k]);
+        if (b) v += load_as<A>(bv.v[k]);
+        o.v[k] = store_as<T>(v);
+      }
+      yp[p] = o;
+    }
+  }
+}
+template <class T, int MAXP>
+__global__ __launch_bounds__(256) void ln_bwd_dx_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                            const T* __restrict__ rstd, const T* __restrict__ w, T* __restrict__ dx, int64_t M,
+                                                            int64_t D) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= M) return;
+  const int npk = (int)(D / W);
+  const A mu = load_as<A>(mean[row]), rs = load_as<A>(rstd[row]);
+  const Vec<T, W>* xp = reinterpret_cast<const Vec<T, W>*>(x + row * D);
+  const Vec<T, W>* gp = reinterpret_cast<const Vec<T, W>*>(dy + row * D);
+  Vec<T, W> px[MAXP], pg[MAXP];                // x, then x-hat is recomputed; g * w kept in pg's slots as T would lose bits: recompute
+  A s1 = 0, s2 = 0;
+#pragma unroll
+  for (int i = 0; i < MAXP; i++) {
+    const int p = lane + 64 * i;
+    if (p < npk) {
+      px[i] = xp[p]; pg[i] = gp[p];
+      Vec<T, W> wv;
+      if (w) wv = reinterpret_cast<const Vec<T, W>*>(w)[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const A gw = load_as<A>(pg[i].v[k]) * (w ? load_as<A>(wv.v[k]) : A(1));
+        const A xh = (load_as<A>(px[i].v[k]) - mu) * rs;
+        s1 += gw; s2 += gw * xh;
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (A)D;
+  s2 = wave_sum(s2) / (A)D;
+  Vec<T, W>* op = reinterpret_cast<Vec<T, W>*>(dx + row * D);
+#pragma unroll
+  for (int i = 0; i < MAXP; i++) {
+    const int p = lane + 64 * i;
+    if (p < npk) {
+      Vec<T, W> wv, o;
+      if (w) wv = reinterpret_cast<const Vec<T, W>*>(w)[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        const A gw = load_as<A>(pg[i].v[k]) * (w ? load_as<A>(wv.v[k]) : A(1));
+        const A xh = (load_as<A>(px[i].v[k]) - mu) * rs;
+        o.v[k] = store_as<T>((A)(rs * (gw - s1 - xh * s2)));
+      }
+      op[p] = o;
+    }
+  }
+}
+// dweight / dbias partial sums: a thread owns W consecutive columns (16-byte loads), a block row-split `split` of nsplit
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_dwdb_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean,
+                                                              const T* __restrict__ rstd, acc_t<T>* __restrict__ partial, int64_t M, int64_t D,
+                                                              int nsplit) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  const int64_t pcol = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // packet column
+  if (pcol * W >= D) return;
+  const int split = blockIdx.y;
+  A sw[W], sb[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) { sw[k] = 0; sb[k] = 0; }
+  for (int64_t r = split; r < M; r += nsplit) {
+    const Vec<T, W> g = *reinterpret_cast<const Vec<T, W>*>(dy + r * D + pcol * W);
+    const Vec<T, W> xv = *reinterpret_cast<const Vec<T, W>*>(x + r * D + pcol * W);
+    const A mu = load_as<A>(mean[r]), rs = load_as<A>(rstd[r]);
+#pragma unroll
+    for (int k = 0; k < W; k++) { const A gg = load_as<A>(g.v[k]); sw[k] += gg * (load_as<A>(xv.v[k]) - mu) * rs; sb[k] += gg; }
+  }
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    partial[((int64_t)split * D + pcol * W + k) * 2] = sw[k];
+    partial[((int64_t)split * D + pcol * W + k) * 2 + 1] = sb[k];
+  }
+}
+
 template <class A> constexpr int acc_dtype() { return std::is_same<A, double>::value ? kF64 : kF32; }
 
 struct BnGeom { int64_t N, C, HW; };
@@ -864,10 +994,20 @@ int lamp_native_layer_norm(lamp_tensor* out3[3], const lamp_tensor* x, const int
   Hold mean(new_tensor(sshape, x->dtype, x->device())), rstd(new_tensor(sshape, x->dtype, x->device()));
   if (M > 0) {
     const int64_t blocks = (M * 64 + 255) / 256;
-    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, current_stream(x->device()),
-                                                        xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(),
-                                                        weight ? weight->ptr<T>() : (const T*)nullptr, bias ? bias->ptr<T>() : (const T*)nullptr,
-                                                        M, D, eps));
+    hipStream_t st = current_stream(x->device());
+    LAMP_DISPATCH_FLOAT(x->dtype, T, {
+      constexpr int W = 16 / sizeof(T);
+      const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
+      const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+      const int64_t npk = D / W;
+      const bool vec = D % W == 0 && npk <= 64 * 8 && (((uintptr_t)xc->raw() | (uintptr_t)y->raw() | (uintptr_t)wp | (uintptr_t)bp) & 15) == 0;
+      const T* xp = static_cast<const Tensor*>(xc.get())->ptr<T>();
+      if (!vec) hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(), wp, bp, M, D, eps);
+      else if (npk <= 64) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(), wp, bp, M, D, eps);
+      else if (npk <= 128) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(), wp, bp, M, D, eps);
+      else if (npk <= 256) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(), wp, bp, M, D, eps);
+      else hipLaunchKernelGGL((ln_fwd_vec_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), mean->ptr<T>(), rstd->ptr<T>(), wp, bp, M, D, eps);
+    });
     LAMP_LAUNCH_CHECK();
   }
   out3[0] = y.take(); out3[1] = mean.take(); out3[2] = rstd.take();
@@ -893,23 +1033,38 @@ int lamp_native_layer_norm_backward(lamp_tensor* out3[3], const lamp_tensor* gra
   Hold db(mask[2] ? new_tensor(wshape, x->dtype, x->device()) : nullptr);
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
+    constexpr int W = 16 / sizeof(T);
+    const T* xp = static_cast<const Tensor*>(xc.get())->ptr<T>();
+    const T* gp = static_cast<const Tensor*>(gc.get())->ptr<T>();
+    const T* mp = static_cast<const Tensor*>(mc.get())->ptr<T>();
+    const T* rp = static_cast<const Tensor*>(rc.get())->ptr<T>();
+    const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
+    const int64_t npk = D / W;
+    const bool al = D % W == 0 && (((uintptr_t)xp | (uintptr_t)gp | (uintptr_t)wp) & 15) == 0;
     if (dx.get() && M > 0) {
       const int64_t blocks = (M * 64 + 255) / 256;
-      hipLaunchKernelGGL((ln_bwd_dx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mc->ptr<T>(), rc->ptr<T>(),
-                         weight ? weight->ptr<T>() : (const T*)nullptr, dx->ptr<T>(), M, D);
+      const bool vec = al && npk <= 64 * 8 && ((uintptr_t)dx->raw() & 15) == 0;
+      if (!vec) hipLaunchKernelGGL((ln_bwd_dx_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, gp, xp, mp, rp, wp, dx->ptr<T>(), M, D);
+      else if (npk <= 64) hipLaunchKernelGGL((ln_bwd_dx_vec_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, gp, xp, mp, rp, wp, dx->ptr<T>(), M, D);
+      else if (npk <= 128) hipLaunchKernelGGL((ln_bwd_dx_vec_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, gp, xp, mp, rp, wp, dx->ptr<T>(), M, D);
+      else if (npk <= 256) hipLaunchKernelGGL((ln_bwd_dx_vec_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, gp, xp, mp, rp, wp, dx->ptr<T>(), M, D);
+      else hipLaunchKernelGGL((ln_bwd_dx_vec_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), 0, st, gp, xp, mp, rp, wp, dx->ptr<T>(), M, D);
       LAMP_LAUNCH_CHECK();
     }
     if (dw.get() || db.get()) {
-      const int64_t blocks = (D + 255) / 256;
+      const int64_t blocks = al ? (npk + 255) / 256 : (D + 255) / 256;
       const int nsplit = pick_split(blocks, std::max<int64_t>(M, 1));
       int64_t ps[1] = {(int64_t)nsplit * D * 2};
       Hold partial(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
-      hipLaunchKernelGGL((ln_bwd_dwdb_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gc->ptr<T>(), xc->ptr<T>(), mc->ptr<T>(),
-                         rc->ptr<T>(), partial->ptr<A>(), M, D, nsplit);
+      if (al) hipLaunchKernelGGL((ln_bwd_dwdb_vec_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gp, xp, mp, rp, partial->ptr<A>(), M, D, nsplit);
+      else hipLaunchKernelGGL((ln_bwd_dwdb_kernel<T>), dim3((unsigned)blocks, nsplit), dim3(256), 0, st, gp, xp, mp, rp, partial->ptr<A>(), M, D, nsplit);
       LAMP_LAUNCH_CHECK();
+      {
+      const int64_t blocks = (D + 255) / 256;
       hipLaunchKernelGGL((ln_bwd_finalize_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, partial->ptr<A>(),
                          dw.get() ? dw->ptr<T>() : (T*)nullptr, db.get() ? db->ptr<T>() : (T*)nullptr, D, nsplit);
       LAMP_LAUNCH_CHECK();
+      }
     }
   });
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
