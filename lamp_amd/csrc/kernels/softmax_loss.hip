@@ -43,6 +43,98 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// contiguous rows (inner == 1), D a multiple of the packet width: 16-byte loads; rows of up to 64 * MAXP packets stay in registers
+// (one read of x), longer ones (LM vocabularies) are streamed three times with vector loads (MAXP == 0)
+template <class T, bool LOG, int MAXP>
+__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t D) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  constexpr int NP = MAXP > 0 ? MAXP : 1;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int64_t npk = D / W;
+  const Vec<T, W>* xp = reinterpret_cast<const Vec<T, W>*>(x + row * D);
+  Vec<T, W>* yp = reinterpret_cast<Vec<T, W>*>(y + row * D);
+  Vec<T, W> pk[NP];
+  A m = -INFINITY;
+  if (MAXP > 0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+      if (lane + 64 * i < npk) {
+        pk[i] = xp[lane + 64 * i];
+#pragma unroll
+        for (int k = 0; k < W; k++) { const A v = load_as<A>(pk[i].v[k]); m = v > m ? v : m; }
+      }
+  } else {
+    for (int64_t p = lane; p < npk; p += 64) {
+      const Vec<T, W> t = xp[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) { const A v = load_as<A>(t.v[k]); m = v > m ? v : m; }
+    }
+  }
+  m = wave_max(m);
+  A s = 0;
+  if (MAXP > 0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+      if (lane + 64 * i < npk) {
+#pragma unroll
+        for (int k = 0; k < W; k++) s += t_exp<A>(load_as<A>(pk[i].v[k]) - m);
+      }
+  } else {
+    for (int64_t p = lane; p < npk; p += 64) {
+      const Vec<T, W> t = xp[p];
+#pragma unroll
+      for (int k = 0; k < W; k++) s += t_exp<A>(load_as<A>(t.v[k]) - m);
+    }
+  }
+  s = wave_sum(s);
+  const A ls = LOG ? t_log<A>(s) : A(0), inv = LOG ? A(0) : A(1) / s;
+  auto emit = [&](const Vec<T, W>& t, int64_t p) {
+    Vec<T, W> o;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const A v = load_as<A>(t.v[k]);
+      o.v[k] = LOG ? store_as<T>((A)(v - m - ls)) : store_as<T>((A)(t_exp<A>(v - m) * inv));
+    }
+    yp[p] = o;
+  };
+  if (MAXP > 0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) if (lane + 64 * i < npk) emit(pk[i], lane + 64 * i);
+  } else {
+    for (int64_t p = lane; p < npk; p += 64) emit(xp[p], p);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void log_softmax_bwd_vec_kernel(const T* __restrict__ g, const T* __restrict__ out, T* __restrict__ gi, int64_t rows,
+                                                                  int64_t D) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int64_t npk = D / W;
+  const Vec<T, W>* gp = reinterpret_cast<const Vec<T, W>*>(g + row * D);
+  const Vec<T, W>* op = reinterpret_cast<const Vec<T, W>*>(out + row * D);
+  Vec<T, W>* ip = reinterpret_cast<Vec<T, W>*>(gi + row * D);
+  A s = 0;
+  for (int64_t p = lane; p < npk; p += 64) {
+    const Vec<T, W> t = gp[p];
+#pragma unroll
+    for (int k = 0; k < W; k++) s += load_as<A>(t.v[k]);
+  }
+  s = wave_sum(s);
+  for (int64_t p = lane; p < npk; p += 64) {
+    const Vec<T, W> t = gp[p], o = op[p];
+    Vec<T, W> r;
+#pragma unroll
+    for (int k = 0; k < W; k++) r.v[k] = store_as<T>((A)(load_as<A>(t.v[k]) - t_exp<A>(load_as<A>(o.v[k])) * s));
+    ip[p] = r;
+  }
+}
+
 // grad_in = grad - exp(output) * sum(grad)
 template <class T>
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restrict__ g, const T* __restrict__ out, T* __restrict__ gi,
@@ -154,8 +246,19 @@ template <bool LOG> static Tensor* softmax_impl(const Tensor* x, int64_t dim) {
   const int64_t rows = outer * inner;
   if (rows > 0 && D > 0) {
     const int64_t blocks = (rows * 64 + 255) / 256;
-    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((softmax_fwd_kernel<T, LOG>), dim3((unsigned)blocks), dim3(256), 0,
-                                                        current_stream(x->device()), xc->ptr<T>(), y->ptr<T>(), outer, D, inner));
+    hipStream_t st = current_stream(x->device());
+    LAMP_DISPATCH_FLOAT(x->dtype, T, {
+      constexpr int W = 16 / sizeof(T);
+      const T* xp = static_cast<const Tensor*>(xc.get())->ptr<T>();
+      const int64_t npk = D / W;
+      const bool vec = inner == 1 && D % W == 0 && D >= 64 * W / 2 && (((uintptr_t)xp | (uintptr_t)y->raw()) & 15) == 0;
+      if (!vec) hipLaunchKernelGGL((softmax_fwd_kernel<T, LOG>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), outer, D, inner);
+      else if (npk <= 64) hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, LOG, 1>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), rows, D);
+      else if (npk <= 128) hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, LOG, 2>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), rows, D);
+      else if (npk <= 256) hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, LOG, 4>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), rows, D);
+      else if (npk <= 512) hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, LOG, 8>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), rows, D);
+      else hipLaunchKernelGGL((softmax_fwd_vec_kernel<T, LOG, 0>), dim3((unsigned)blocks), dim3(256), 0, st, xp, y->ptr<T>(), rows, D);
+    });
     LAMP_LAUNCH_CHECK();
   }
   return y.take();
@@ -181,9 +284,14 @@ int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad, c
   const int64_t rows = outer * inner;
   if (rows > 0 && D > 0) {
     const int64_t blocks = (rows * 64 + 255) / 256;
-    LAMP_DISPATCH_FLOAT(output->dtype, T, hipLaunchKernelGGL((log_softmax_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
-                                                             current_stream(output->device()), gc->ptr<T>(), oc->ptr<T>(),
-                                                             gi->ptr<T>(), outer, D, inner));
+    LAMP_DISPATCH_FLOAT(output->dtype, T, {
+      constexpr int W = 16 / sizeof(T);
+      const T* gp = static_cast<const Tensor*>(gc.get())->ptr<T>();
+      const T* op = static_cast<const Tensor*>(oc.get())->ptr<T>();
+      const bool vec = inner == 1 && D % W == 0 && D >= 64 * W / 2 && (((uintptr_t)gp | (uintptr_t)op | (uintptr_t)gi->raw()) & 15) == 0;
+      if (vec) hipLaunchKernelGGL((log_softmax_bwd_vec_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, current_stream(output->device()), gp, op, gi->ptr<T>(), rows, D);
+      else hipLaunchKernelGGL((log_softmax_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, current_stream(output->device()), gp, op, gi->ptr<T>(), outer, D, inner);
+    });
     LAMP_LAUNCH_CHECK();
   }
   *out = gi.take();

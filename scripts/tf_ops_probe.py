@@ -31,14 +31,20 @@ def gelu_b():
     o = C.c_void_p(); lib.lamp_gelu_backward(C.byref(o), g, x); return S.STen(o)
 def lsm():
     o = C.c_void_p(); lib.lamp_log_softmax(C.byref(o), x, 1); return S.STen(o)
+nb = R * D * 2
 V, E, T = 50304, 768, 65536
 emb = S.STen.from_numpy(rng.standard_normal((V, E), dtype=np.float32), 0, S.BF16)
 idx = S.STen.from_numpy(rng.integers(0, V, T).astype(np.int64), 0)
 def embed():
     o = C.c_void_p(); lib.lamp_embedding(C.byref(o), emb, idx); return S.STen(o)
 
-nb = R * D * 2
-for name, fn, byts in (("layer_norm fwd", ln_fwd, 2 * nb), ("layer_norm bwd", ln_bwd, 3 * nb), ("gelu fwd", gelu, 2 * nb), ("gelu bwd", gelu_b, 3 * nb),
+Vb = S.STen.from_numpy(rng.standard_normal((4096, V), dtype=np.float32), 0, S.BF16)
+def lsm_vocab():
+    o = C.c_void_p(); lib.lamp_log_softmax(C.byref(o), Vb, 1); return S.STen(o)
+LSo = lsm(); 
+def lsm_b():
+    o = C.c_void_p(); lib.lamp_log_softmax_backward_data(C.byref(o), g, LSo, 1); return S.STen(o)
+for name, fn, byts in (("log_softmax fwd (4096 x 50304)", lsm_vocab, 2 * 4096 * V * 2), ("log_softmax bwd (rows of 4096)", lsm_b, 3 * nb), ("layer_norm fwd", ln_fwd, 2 * nb), ("layer_norm bwd", ln_bwd, 3 * nb), ("gelu fwd", gelu, 2 * nb), ("gelu bwd", gelu_b, 3 * nb),
                        ("log_softmax fwd (rows of 4096)", lsm, 2 * nb), ("embedding 65536 x 768", embed, 2 * T * E * 2)):
     dt = timeit(fn)
     print(f"{name:34s} {dt * 1e6:9.1f} us  {byts / dt / 1e9:8.0f} GB/s")
