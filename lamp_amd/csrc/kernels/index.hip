@@ -50,6 +50,19 @@ __global__ void index_select_kernel(const T* __restrict__ a, const int64_t* __re
     out[e] = (k >= 0 && k < D) ? a[(o * D + k) * inner + i] : T{};
   }
 }
+// row gather (dim 0 of a contiguous tensor, rows a multiple of 16 bytes): 16-byte packets, no 64-bit divisions per element -
+// embeddings, the minibatch gather of the device-resident data set, UMAP's index selects of [n, d] tables
+__global__ __launch_bounds__(256) void index_select_rows_vec_kernel(const uint4* __restrict__ a, const int64_t* __restrict__ index, uint4* __restrict__ out,
+                                                                    int64_t D, int ppr /* packets per row */, int64_t J) {
+  const int64_t total = J * ppr;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / ppr;
+    const int p = (int)(e - j * ppr);
+    int64_t k = index[j];
+    if (k < 0) k += D;
+    out[e] = (k >= 0 && k < D) ? a[k * ppr + p] : make_uint4(0, 0, 0, 0);
+  }
+}
 template <class T>
 __global__ void index_add_kernel(T* __restrict__ self, const int64_t* __restrict__ index, const T* __restrict__ src, int64_t outer,
                                  int64_t D, int64_t inner, int64_t J) {
@@ -390,8 +403,16 @@ int lamp_index_select(lamp_tensor** out, const lamp_tensor* a, int64_t dim, cons
   Hold r(new_tensor(oshape, a->dtype, a->device()));
   const int64_t total = outer * J * inner;
   if (total) {
-    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((index_select_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
-                                                      current_stream(a->device()), ac->ptr<T>(), ic->ptr<int64_t>(), r->ptr<T>(), outer, D, inner, J));
+    const int64_t row_bytes = inner * (int64_t)a->itemsize();
+    const void* ap = static_cast<const Tensor*>(ac.get())->raw();
+    if (outer == 1 && row_bytes % 16 == 0 && row_bytes / 16 < (1 << 30) && (((uintptr_t)ap | (uintptr_t)r->raw()) & 15) == 0) {
+      const int ppr = (int)(row_bytes / 16);
+      hipLaunchKernelGGL(index_select_rows_vec_kernel, dim3(grid_for(J * ppr, 256)), dim3(256), 0, current_stream(a->device()), (const uint4*)ap,
+                         static_cast<const Tensor*>(ic.get())->ptr<int64_t>(), (uint4*)r->data(), D, ppr, J);
+    } else {
+      LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((index_select_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                        current_stream(a->device()), ac->ptr<T>(), ic->ptr<int64_t>(), r->ptr<T>(), outer, D, inner, J));
+    }
     LAMP_LAUNCH_CHECK();
   }
   *out = r.take();
