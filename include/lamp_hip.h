@@ -413,7 +413,9 @@ int lamp_repeat_interleave(lamp_tensor** out, const lamp_tensor* a, int64_t repe
 int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted);
 int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes);
 int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tensor* indices);
-int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights);
+/* ATen embedding_backward(grad, indices, num_weights, padding_idx, false, false): rows equal to padding_idx get no gradient;
+ * lamp always passes padding_idx = 0 (ops.scala:2150-2158) */
+int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights, int64_t padding_idx);
 /* RNG: Philox4x32-10 counter streams; bit-compat with libtorch streams is not required by any
  * reference test (SURVEY.md 8b "RNG / globals") */
 int lamp_rand(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);

@@ -58,6 +58,39 @@ int lamp_module_mlp(lamp_module** out, int64_t in, int64_t outf, const int64_t* 
                     int last_non_linearity, const char* activation, int norm, int bias);
 /* Cnn.resnet (example-cifar100/src/main/scala/lamp/example/cifar/cnn.scala:89-137) */
 int lamp_module_resnet(lamp_module** out, int64_t num_classes, double dropout, int dtype, int device);
+/* ---- transformer family and the autoregressive language model (lamp-core nn/Transformer.scala, nn/Embedding.scala,
+ * nn/languagemodel/lm.scala).  State order = the reference's `state`; the layer norms inside the blocks carry no scale / bias
+ * (LayerNorm.apply defaults).  Modules whose input is a tuple / case class are called through lamp_module_forward_multi. */
+int lamp_module_embedding(lamp_module** out, int64_t classes, int64_t dimensions, int dtype, int device);            /* Embedding.scala:35-48 */
+int lamp_module_multihead_attention(lamp_module** out, int64_t dQ, int64_t dK, int64_t dV, int64_t hidden_per_head, int64_t outf, double dropout,
+                                    int64_t num_heads, int dtype, int device, int linearized, int causal_mask);      /* Transformer.scala:619-641; vars (q, k, v), tensors (maxLength?) */
+int lamp_module_transformer_encoder_block(lamp_module** out, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                          int64_t mlp_hidden, int64_t outf, double dropout, int dtype, int device, int linearized, int gpt_order,
+                                          int causal_mask);                                                            /* :492-530; vars (x), tensors (maxLength?) */
+int lamp_module_transformer_encoder(lamp_module** out, int64_t num_blocks, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                    int64_t mlp_hidden, double dropout, int dtype, int device, int linearized, int gpt_order, int causal_mask); /* :76-102 */
+int lamp_module_transformer_decoder_block(lamp_module** out, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                          int64_t mlp_hidden, int64_t outf, double dropout, int dtype, int device, int linearized,
+                                          int decoder_decoder_causal_mask, int encoder_decoder_causal_mask);          /* :384-432; vars (decoderInput, encoderOutput), tensors (maxLength?) */
+int lamp_module_transformer(lamp_module** out, int64_t num_blocks, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                            int64_t mlp_hidden, double dropout, int dtype, int device, int linearized, int encoder_causal_mask,
+                            int decoder_decoder_causal_mask, int encoder_decoder_causal_mask); /* :330-365; vars (decoderInput, encoderInput), tensors (decoderMaxLength?, encoderMaxLength?) */
+int lamp_positional_embedding_vaswani(lamp_tensor** out, int64_t sequence_length, int64_t dimension, int dtype, int device); /* :1022-1045 */
+int lamp_module_transformer_embedding(lamp_module** out, lamp_module* embedding, int add_positional_embedding,
+                                      const lamp_tensor* positional_embedding);                                        /* :1105-1125 */
+int lamp_module_language_model(lamp_module** out, int64_t max_length, int64_t vocabulary_size, int64_t num_blocks, int64_t embedding_dim,
+                               int64_t attention_hidden_per_head, int64_t attention_num_heads, int64_t encoder_mlp_hidden, double dropout, int dtype,
+                               int device, int linearized);                      /* lm.scala:194-232; vars (tokens), tensors (maxLength?, positions?) -> logits */
+int lamp_module_language_model_loss(lamp_module** out, int64_t max_length, int64_t vocabulary_size, int64_t num_blocks, int64_t embedding_dim,
+                                    int64_t attention_hidden_per_head, int64_t attention_num_heads, int64_t encoder_mlp_hidden, double dropout,
+                                    int64_t pad_token, int dtype, int device, int linearized); /* lm.scala:63-91; vars (tokens), tensors (target, maxLength?, positions?) -> loss */
+/* LanguageModelOutput(encoded, languageModelLogits) (lm.scala:146-188); either output pointer may be NULL */
+int lamp_language_model_forward(lamp_module* m, lamp_var* tokens, const lamp_tensor* max_length_or_null, const lamp_tensor* positions_or_null,
+                                lamp_var** encoded, lamp_var** logits);
+int lamp_sequence_mask(lamp_var** out, const lamp_tensor* max_length, lamp_var* maskable, double fill);   /* MultiheadAttention.sequenceMask :667-749 */
+int lamp_masked_softmax(lamp_var** out, lamp_var* input, const lamp_tensor* max_length);                  /* MultiheadAttention.maskedSoftmax :751-762 */
+/* GenericModule[A, B].forward for a tuple / case-class A: its Variables and its plain tensors in the reference's order; a NULL tensor = None */
+int lamp_module_forward_multi(lamp_module* m, lamp_var* const* vars, int nvars, const lamp_tensor* const* tensors, int ntensors, lamp_var** out);
 int lamp_module_forward(lamp_module* m, lamp_var* x, lamp_var** out);
 int lamp_module_num_state(lamp_module* m, int64_t* out);
 int lamp_module_state(lamp_module* m, int64_t index, lamp_var** out);   /* state in lamp's order (params and consts) */

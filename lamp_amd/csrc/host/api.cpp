@@ -1,5 +1,6 @@
 // extern "C" surface of the host layer (include/lamp_host.h).
 #include "nn.h"
+#include "transformer.h"
 #include "../../../include/lamp_host.h"
 
 #include <cstring>
@@ -95,6 +96,7 @@ int lamp_op_apply(lamp_var** out, const char* name, lamp_var* const* vars, int n
   else if (n == "BatchNorm2D") r = F::batch_norm_2d(V(0), V(1), V(2), T(0), T(1), I(0) != 0, D(0), D(1));
   else if (n == "LayerNormOp") r = F::layer_norm(V(0), V(1), V(2), IV(0, ni), D(0));
   else if (n == "Embedding") r = F::embedding(V(0), V(1));
+  else if (n == "MaskFill") r = F::mask_fill(V(0), T(0), D(0));                       // tensors = [mask], d = [fill]
   else LAMP_CHECK(false, "unknown Op '" << n << "'");
   *out = wrap(r);
   LAMP_API_END
@@ -134,6 +136,101 @@ int lamp_module_mlp(lamp_module** out, int64_t in, int64_t outf, const int64_t* 
 }
 int lamp_module_resnet(lamp_module** out, int64_t num_classes, double dropout, int dtype, int device) {
   LAMP_API_BEGIN *out = wrapm(cnn_resnet(num_classes, dropout, dtype, device)); LAMP_API_END
+}
+// ---- transformer family (Transformer.scala, lm.scala) -----------------------------------------------------
+int lamp_module_embedding(lamp_module** out, int64_t classes, int64_t dimensions, int dtype, int device) {
+  LAMP_API_BEGIN *out = wrapm(Embedding::make(classes, dimensions, dtype, device)); LAMP_API_END
+}
+int lamp_module_multihead_attention(lamp_module** out, int64_t dQ, int64_t dK, int64_t dV, int64_t hidden_per_head, int64_t outf, double dropout,
+                                    int64_t num_heads, int dtype, int device, int linearized, int causal_mask) {
+  LAMP_API_BEGIN *out = wrapm(MultiheadAttention::make(dQ, dK, dV, hidden_per_head, outf, dropout, num_heads, dtype, device, linearized, causal_mask)); LAMP_API_END
+}
+int lamp_module_transformer_encoder_block(lamp_module** out, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                          int64_t mlp_hidden, int64_t outf, double dropout, int dtype, int device, int linearized, int gpt_order,
+                                          int causal_mask) {
+  LAMP_API_BEGIN
+  *out = wrapm(TransformerEncoderBlock::make(in, attention_hidden_per_head, attention_num_heads, mlp_hidden, outf, dropout, dtype, device, linearized,
+                                             gpt_order, causal_mask));
+  LAMP_API_END
+}
+int lamp_module_transformer_encoder(lamp_module** out, int64_t num_blocks, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                    int64_t mlp_hidden, double dropout, int dtype, int device, int linearized, int gpt_order, int causal_mask) {
+  LAMP_API_BEGIN
+  *out = wrapm(TransformerEncoder::make(num_blocks, in, attention_hidden_per_head, attention_num_heads, mlp_hidden, dropout, dtype, device, linearized,
+                                        gpt_order, causal_mask));
+  LAMP_API_END
+}
+int lamp_module_transformer_decoder_block(lamp_module** out, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                                          int64_t mlp_hidden, int64_t outf, double dropout, int dtype, int device, int linearized,
+                                          int decoder_decoder_causal_mask, int encoder_decoder_causal_mask) {
+  LAMP_API_BEGIN
+  *out = wrapm(TransformerDecoderBlock::make(in, attention_hidden_per_head, attention_num_heads, mlp_hidden, outf, dropout, dtype, device, linearized,
+                                             decoder_decoder_causal_mask, encoder_decoder_causal_mask));
+  LAMP_API_END
+}
+int lamp_module_transformer(lamp_module** out, int64_t num_blocks, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
+                            int64_t mlp_hidden, double dropout, int dtype, int device, int linearized, int encoder_causal_mask,
+                            int decoder_decoder_causal_mask, int encoder_decoder_causal_mask) {
+  LAMP_API_BEGIN
+  *out = wrapm(Transformer::make(num_blocks, in, attention_hidden_per_head, attention_num_heads, mlp_hidden, dropout, dtype, device, linearized,
+                                 encoder_causal_mask, decoder_decoder_causal_mask, encoder_decoder_causal_mask));
+  LAMP_API_END
+}
+int lamp_positional_embedding_vaswani(lamp_tensor** out, int64_t sequence_length, int64_t dimension, int dtype, int device) {
+  LAMP_API_BEGIN *out = give(positional_embedding_vaswani(sequence_length, dimension, dtype, device)); LAMP_API_END
+}
+int lamp_module_transformer_embedding(lamp_module** out, lamp_module* embedding, int add_positional_embedding, const lamp_tensor* positional_embedding) {
+  LAMP_API_BEGIN
+  auto e = std::dynamic_pointer_cast<Embedding>(embedding->m);
+  LAMP_CHECK(e, "TransformerEmbedding: `embedding` must be an Embedding module");
+  auto m = std::make_shared<TransformerEmbedding>();
+  m->embedding = e;
+  m->addPositionalEmbedding = add_positional_embedding;
+  m->positionalEmbedding = make_const(borrow(positional_embedding));
+  *out = wrapm(m);
+  LAMP_API_END
+}
+int lamp_module_language_model(lamp_module** out, int64_t max_length, int64_t vocabulary_size, int64_t num_blocks, int64_t embedding_dim,
+                               int64_t attention_hidden_per_head, int64_t attention_num_heads, int64_t encoder_mlp_hidden, double dropout, int dtype,
+                               int device, int linearized) {
+  LAMP_API_BEGIN
+  *out = wrapm(LanguageModelModule::make(max_length, vocabulary_size, num_blocks, embedding_dim, attention_hidden_per_head, attention_num_heads,
+                                         encoder_mlp_hidden, dropout, dtype, device, linearized));
+  LAMP_API_END
+}
+int lamp_module_language_model_loss(lamp_module** out, int64_t max_length, int64_t vocabulary_size, int64_t num_blocks, int64_t embedding_dim,
+                                    int64_t attention_hidden_per_head, int64_t attention_num_heads, int64_t encoder_mlp_hidden, double dropout,
+                                    int64_t pad_token, int dtype, int device, int linearized) {
+  LAMP_API_BEGIN
+  *out = wrapm(LanguageModelLoss::make(max_length, vocabulary_size, num_blocks, embedding_dim, attention_hidden_per_head, attention_num_heads,
+                                       encoder_mlp_hidden, dropout, pad_token, dtype, device, linearized));
+  LAMP_API_END
+}
+int lamp_language_model_forward(lamp_module* m, lamp_var* tokens, const lamp_tensor* max_length, const lamp_tensor* positions, lamp_var** encoded,
+                                lamp_var** logits) {
+  LAMP_API_BEGIN
+  auto lm = std::dynamic_pointer_cast<LanguageModelModule>(m->m);
+  if (!lm) if (auto l = std::dynamic_pointer_cast<LanguageModelLoss>(m->m)) lm = l->languageModel;
+  LAMP_CHECK(lm, "lamp_language_model_forward: not a LanguageModelModule / LanguageModelLoss");
+  auto r = lm->run(tokens->v, max_length ? borrow(max_length) : Ten(), positions ? borrow(positions) : Ten());
+  if (encoded) *encoded = wrap(r.first);
+  if (logits) *logits = wrap(r.second);
+  LAMP_API_END
+}
+int lamp_sequence_mask(lamp_var** out, const lamp_tensor* max_length, lamp_var* maskable, double fill) {
+  LAMP_API_BEGIN *out = wrap(MultiheadAttention::sequenceMask(borrow(max_length), maskable->v, fill)); LAMP_API_END
+}
+int lamp_masked_softmax(lamp_var** out, lamp_var* input, const lamp_tensor* max_length) {
+  LAMP_API_BEGIN *out = wrap(MultiheadAttention::maskedSoftmax(input->v, borrow(max_length))); LAMP_API_END
+}
+int lamp_module_forward_multi(lamp_module* m, lamp_var* const* vars, int nvars, const lamp_tensor* const* tensors, int ntensors, lamp_var** out) {
+  LAMP_API_BEGIN
+  std::vector<Var> xs;
+  for (int i = 0; i < nvars; i++) { LAMP_CHECK(vars[i], "forward_multi: NULL variable"); xs.push_back(vars[i]->v); }
+  std::vector<Ten> aux;
+  for (int i = 0; i < ntensors; i++) aux.push_back(tensors[i] ? borrow(tensors[i]) : Ten());
+  *out = wrap(m->m->forward_multi(xs, aux));
+  LAMP_API_END
 }
 int lamp_module_forward(lamp_module* m, lamp_var* x, lamp_var** out) { LAMP_API_BEGIN *out = wrap(m->m->forward(x->v)); LAMP_API_END }
 int lamp_module_num_state(lamp_module* m, int64_t* out) { LAMP_API_BEGIN *out = (int64_t)m->m->state().size(); LAMP_API_END }

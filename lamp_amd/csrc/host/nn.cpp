@@ -236,6 +236,12 @@ void SGDW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
 }
 
 // ---- SupervisedModel -------------------------------------------------------------------------------
+// With LossFunctions.Identity the loss is computed inside the module (LanguageModelLoss, lm.scala:44-59): its input case class
+// carries the target, which reaches the module as forward_multi's first extra tensor.  Single-input modules ignore it.
+static Var run_module(SupervisedModel& m, const Ten& samples, const Ten& target) {
+  if (m.loss_kind == 2) return m.module->forward_multi({make_const(samples)}, {target});
+  return m.module->forward(make_const(samples));
+}
 std::pair<Var, int64_t> SupervisedModel::loss(const Var& output, const Ten& target) {
   if (loss_kind == 0) return {F::nll_loss(output, target, classWeights, reduction, ignore), output->value.size(0)};
   if (loss_kind == 1) return {F::mse_loss(output, target, 1), output->value.size(0)};
@@ -243,7 +249,7 @@ std::pair<Var, int64_t> SupervisedModel::loss(const Var& output, const Ten& targ
 }
 int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten& samples, const Ten& target, const Ten& acc, bool zeroGrad,
                                                                       std::vector<Ten>* gradients) {
-  Var output = module->forward(make_const(samples));          // BatchStream emits const(features) (BatchStream.scala:562)
+  Var output = run_module(*this, samples, target);            // BatchStream emits const(features) (BatchStream.scala:562)
   auto ln = loss(output, target);
   std::vector<Ten> g = module->gradients(ln.first, zeroGrad);
   if (acc.defined()) {                                         // acc += (loss.value * numInstances.toDouble)
@@ -253,7 +259,7 @@ int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten&
   return ln.second;
 }
 int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, const Ten& target, const Ten& acc) {
-  Var output = module->forward(make_const(samples));
+  Var output = run_module(*this, samples, target);
   auto ln = loss(output, target);
   if (acc.defined()) {
     ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
@@ -282,7 +288,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   for (int64_t tail = 0; split > 0 && tail * 10 < total * 9;) tail += params[--split]->value.numel();
 
   for (auto& p : params) p->zeroGrad();
-  Var output = model.module->forward(make_const(samples));
+  Var output = run_module(model, samples, target);
   auto ln = model.loss(output, target);
   const int64_t n = ln.second;
 

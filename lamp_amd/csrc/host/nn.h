@@ -18,6 +18,9 @@ struct Module {
   // every state tensor in lamp's order, parameters (needsGrad) and constants alike (Module.scala:272-318)
   virtual void collect_state(std::vector<Var>& out) = 0;
   virtual Var forward(const Var& x) = 0;
+  // GenericModule[A, B] with a tuple / case-class input (Transformer.scala, lm.scala): the Variables and the plain tensors of A in
+  // the reference's order; an Option that is None is an undefined Ten.  Single-input modules ignore the extras.
+  virtual Var forward_multi(const std::vector<Var>& xs, const std::vector<Ten>& aux) { (void)aux; return forward(xs.at(0)); }
   virtual void set_training(bool) {}   // TrainingMode.asEval / asTraining
   std::vector<Var> state() { std::vector<Var> s; collect_state(s); return s; }
   std::vector<Var> parameters() {

@@ -432,6 +432,17 @@ Var index_select(const Var& input, int64_t dim, const Var& index) {
   }});
   return make_result(op, ops::index_select(input->value, dim, idx));
 }
+Var mask_fill(const Var& input, const Ten& mask, double fill) {   // ops.scala:148-159
+  auto op = new_op("MaskFill");
+  op->params.push_back({input, [mask](const Ten& p, Variable& out) {
+    lamp_tensor* t = nullptr;
+    HCALL(lamp_masked_fill(&t, p.h(), mask.h(), 0.0));
+    out.accumulate(Ten(t), true);
+  }});
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_masked_fill(&o, input->value.h(), mask.h(), fill));
+  return make_result(op, Ten(o));
+}
 Var euclidean_distance(const Var& a, const Var& b, int64_t dim) {
   auto op = new_op("EuclideanDistance");
   Ten diff = ops::sub(a->value, b->value);
@@ -703,7 +714,7 @@ Var embedding(const Var& input, const Var& weight) {   // ops.scala:2141-2170
   const int64_t nw = weight->value.size(0);
   op->params.push_back({weight, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;
-    HCALL(lamp_embedding_backward(&t, p.h(), idx.h(), nw));
+    HCALL(lamp_embedding_backward(&t, p.h(), idx.h(), nw, /*padding_idx, as the reference passes it*/ 0));
     out.accumulate(Ten(t), true);
   }});
   lamp_tensor* o = nullptr;

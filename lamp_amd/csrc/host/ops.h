@@ -40,6 +40,7 @@ Var dropout(const Var& a, double prob, bool train);
 Var nll_loss(const Var& input, const Ten& target, const Ten& weights, int64_t reduction = 1, int64_t ignore = -100);
 Var mse_loss(const Var& input, const Ten& target, int64_t reduction = 1);
 Var index_select(const Var& input, int64_t dim, const Var& index);
+Var mask_fill(const Var& input, const Ten& mask, double fill);   // MaskFill (ops.scala:148-159)
 Var euclidean_distance(const Var& a, const Var& b, int64_t dim);
 Var capped_shifted_negative_exponential(const Var& a, double shift);
 Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal);   // attentionBias: not supported (None)

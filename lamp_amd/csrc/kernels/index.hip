@@ -63,6 +63,38 @@ __global__ __launch_bounds__(256) void index_select_rows_vec_kernel(const uint4*
     out[e] = (k >= 0 && k < D) ? a[k * ppr + p] : make_uint4(0, 0, 0, 0);
   }
 }
+// embedding_dense_backward for tables of moderate height: one workgroup per (weight row, 256 columns) walks the index list in
+// chunks of 256 (one ballot per wave), and adds the matching gradient rows in ascending token order into an f32 / f64 accumulator -
+// no atomics, no zero fill, run-to-run identical, rounded once.  Rows equal to padding_idx receive no gradient (ATen).
+template <class T>
+__global__ __launch_bounds__(256) void embedding_backward_scan_kernel(const T* __restrict__ grad, const int64_t* __restrict__ idx, T* __restrict__ out,
+                                                                      int64_t N, int64_t E, int64_t padding_idx) {
+  using A = acc_t<T>;
+  const int64_t k = blockIdx.x;
+  const int64_t col = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  __shared__ unsigned long long masks[4];
+  A acc = 0;
+  if (k != padding_idx) {
+    for (int64_t base = 0; base < N; base += 256) {
+      const int64_t n = base + threadIdx.x;
+      const unsigned long long b = __ballot(n < N && idx[n] == k);
+      if ((threadIdx.x & 63) == 0) masks[threadIdx.x >> 6] = b;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        unsigned long long m = masks[w];
+        while (m) {
+          const int bit = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          if (col < E) acc += load_as<A>(grad[(base + w * 64 + bit) * E + col]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (col < E) out[k * E + col] = store_as<T>(acc);
+}
+
 template <class T>
 __global__ void index_add_kernel(T* __restrict__ self, const int64_t* __restrict__ index, const T* __restrict__ src, int64_t outer,
                                  int64_t D, int64_t inner, int64_t J) {
@@ -564,17 +596,33 @@ int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tens
   return lamp_view(out, sel, oshape.data(), (int)oshape.size());
   LAMP_API_END
 }
-int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights) {
+int lamp_embedding_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* indices, int64_t num_weights, int64_t padding_idx) {
   LAMP_API_BEGIN
   check_device_tensor(grad, "grad"); check_device_tensor(indices, "indices");
+  LAMP_CHECK(indices->dtype == kI64, "embedding_backward: indices must be long");
   const int64_t E = grad->sizes[grad->ndim - 1];
   int64_t ws[2] = {num_weights, E};
   Hold r(new_tensor(ws, 2, grad->dtype, grad->device()));
-  fill_zero(r.get());
   Hold gc(contiguous(grad)), ic(contiguous(indices));
-  int64_t gs[2] = {ic->numel(), E}, gst[2] = {E, 1}, is_[1] = {ic->numel()}, ist[1] = {1};
-  Hold g2(new_view(gc.get(), gs, gst, 2, gc->offset)), i1(new_view(ic.get(), is_, ist, 1, ic->offset));
-  LAMP_CHECK(lamp_index_add_(r.get(), 0, i1.get(), g2.get()) == 0, lamp_last_error());
+  const int64_t N = ic->numel();
+  LAMP_CHECK(gc->numel() == N * E, "embedding_backward: grad " << grad->describe() << " does not match indices " << indices->describe());
+  const bool floating = grad->dtype == kF32 || grad->dtype == kF64 || grad->dtype == kBF16;
+  if (floating && num_weights > 0 && E > 0 && num_weights <= 65535 * 16 && (double)num_weights * (double)N <= (double)(1ll << 28)) {
+    LAMP_DISPATCH_FLOAT(grad->dtype, T, hipLaunchKernelGGL((embedding_backward_scan_kernel<T>), dim3((unsigned)num_weights, (unsigned)((E + 255) / 256)),
+                                                           dim3(256), 0, current_stream(grad->device()), gc->ptr<T>(), ic->ptr<int64_t>(), r->ptr<T>(), N, E,
+                                                           padding_idx));
+    LAMP_LAUNCH_CHECK();
+  } else {
+    fill_zero(r.get());
+    int64_t gs[2] = {N, E}, gst[2] = {E, 1}, is_[1] = {N}, ist[1] = {1};
+    Hold g2(new_view(gc.get(), gs, gst, 2, gc->offset)), i1(new_view(ic.get(), is_, ist, 1, ic->offset));
+    LAMP_CHECK(lamp_index_add_(r.get(), 0, i1.get(), g2.get()) == 0, lamp_last_error());
+    if (padding_idx >= 0 && padding_idx < num_weights) {   // the row only ever received the gradients of the padding tokens
+      int64_t rs[1] = {E}, rst[1] = {1};
+      Hold row(new_view(r.get(), rs, rst, 1, r->offset + padding_idx * E));
+      fill_zero(row.get());
+    }
+  }
   *out = r.take();
   LAMP_API_END
 }
