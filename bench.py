@@ -10,7 +10,7 @@ and activations with fp32 working copies in AdamW (AdamW.scala:48-85).  With N >
 local gradients, one flat fp32 bucket is all-reduced over RCCL/xGMI, every rank applies the same step
 (weak scaling: B per GPU fixed).  One JSON line is printed by rank 0.
 
-Other workloads (parity-test configurations and secondary probes, not the headline line): --workload gemm | mlp | knn | attention | umap.
+Other workloads (parity-test configurations and secondary probes, not the headline line): --workload gemm | mlp | knn | attention | umap | lm.
 """
 import argparse
 import ctypes as C
@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap"])
+    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "lm"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +152,30 @@ def main():
         config = {"workload": "example-cifar100 Cnn.resnet(100) training step (fwd+backprop+AdamW), synthetic CIFAR batch",
                   "per_gpu_batch": B, "global_batch": B * a.gpus, "parallelism": f"dp{a.gpus}" if a.gpus > 1 else "single",
                   "optimizer": "AdamW lr 1e-3 wd 0 beta2 0.95" + (" mixedPrecision" if a.dtype == "bf16" else "")}
+    elif a.workload == "lm":
+        # example-autoregressivelm (model.scala:9-37, train.scala:40-66): byte-level GPT, 12 blocks x 768 x 12 heads, context 384,
+        # bf16 parameters + mixed-precision AdamW (weight decay on the attention / MLP matrices only, clip 1), DP over the ranks
+        from lamp_amd import transformer as TR
+        B = a.batch if a.batch != 2048 else 64
+        ctx, vocab, dim, heads, blocks = 384, 256, 768, 12, 12
+        lib.lamp_manual_seed(1234)
+        net = TR.LanguageModelLoss(ctx, vocab, blocks, dim, dim // heads, heads, dim * 4, 0.0, -1000, dtype, local_rank)
+        toks = ((np.arange(B * (ctx + 1), dtype=np.int64) * 2654435761 + rank * 97) >> 7) % vocab
+        toks = toks.reshape(B, ctx + 1)
+        x = S.STen.from_numpy(np.ascontiguousarray(toks[:, :-1]), local_rank)
+        target = S.STen.from_numpy(np.ascontiguousarray(toks[:, 1:]), local_rank)
+        model = nn.SupervisedModel(net, nn.SupervisedModel.IDENTITY)
+        params = net.parameters
+        # state order per block: wQ wK wV wO w1 w2 b1 b2 scale1 scale2 after the two embeddings; decay on the six matrices
+        wd = [0.0, 0.0] + [0.1 if i % 10 < 6 else 0.0 for i in range(10 * blocks)]
+        opt = nn.AdamW_tagged([p.value for p in params], wd, 1e-4, 0.9, 0.95, clip=1.0, mixedPrecision=(a.dtype == "bf16"))
+        acc = S.STen.zeros([1], dtype, local_rank)
+        step = lambda: model.train_step(opt, x, target, acc, comm)
+        units_per_step = B * ctx
+        metric, unit = "language-model training tokens/sec", "tokens/s"
+        config = {"workload": "example-autoregressivelm LanguageModelLoss training step (12 x 768 x 12 heads, context 384, vocabulary 256), synthetic tokens",
+                  "per_gpu_batch": B, "global_batch": B * a.gpus, "parallelism": f"dp{a.gpus}" if a.gpus > 1 else "single",
+                  "optimizer": "AdamW lr 1e-4 wd 0.1 (matrices) beta2 0.95 clip 1" + (" mixedPrecision" if a.dtype == "bf16" else "")}
     elif a.workload == "gemm":
         n = 4096
         A_ = S.STen.from_numpy((closed_form_np(n * n, 1, 2.0)).reshape(n, n).astype(np.float32), local_rank, dtype)
@@ -292,7 +316,7 @@ def main():
             line["step_roofline"] = {"algorithmic_tflops": per_gpu * 153.3e6 / 1e12, "frac_bf16_mfma_peak": per_gpu * 153.3e6 / 1e12 / PEAK_BF16_TFLOPS,
                                      "algorithmic_GBps": per_gpu * 1.4e6 / 1e9, "frac_hbm_peak": per_gpu * 1.4e6 / 1e9 / PEAK_HBM_GBS}
         line["host_enqueue_ms_per_step"] = enqueue / a.steps * 1e3
-        top = sorted(class_rows, key=lambda r: -r["total_ms"])[:10]
+        top = sorted(class_rows, key=lambda r: -r["total_ms"])[:int(os.environ.get("LAMP_BENCH_TOP", "10"))]
         line["kernel_classes"] = [{"tag": r["tag"], "launches_per_step": r["launches"] / PROFILE_STEPS, "ms_per_step": r["total_ms"] / PROFILE_STEPS}
                                   for r in top]
         print(json.dumps(line))

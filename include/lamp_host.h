@@ -101,6 +101,10 @@ int lamp_module_release(lamp_module* m);
 /* ---- optimisers (nn/AdamW.scala, nn/SGD.scala); clip < 0 means None ---- */
 int lamp_optimizer_adamw(lamp_optimizer** out, lamp_tensor* const* params, int n, double weight_decay, double learning_rate, double beta1,
                          double beta2, double eps, double clip, int debias, int mixed_precision);
+/* AdamW with OptimizedHyperparameter = PTag => Double resolved per parameter (AdamW.scala:29-47, train.scala:48-66 of
+ * example-autoregressivelm: weight decay on the attention / MLP matrices only): arrays of n values */
+int lamp_optimizer_adamw_tagged(lamp_optimizer** out, lamp_tensor* const* params, int n, const double* weight_decay, const double* learning_rate,
+                                const double* beta1, const double* beta2, double eps, double clip, int debias, int mixed_precision);
 int lamp_optimizer_sgdw(lamp_optimizer** out, lamp_tensor* const* params, int n, double learning_rate, double weight_decay,
                         double momentum /* < 0: none */, double clip);
 int lamp_optimizer_step(lamp_optimizer* o, lamp_tensor* const* gradients /* NULL entries = None */, int n, double schedule_factor);

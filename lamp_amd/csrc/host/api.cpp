@@ -256,6 +256,19 @@ int lamp_optimizer_adamw(lamp_optimizer** out, lamp_tensor* const* params, int n
   *out = o;
   LAMP_API_END
 }
+int lamp_optimizer_adamw_tagged(lamp_optimizer** out, lamp_tensor* const* params, int n, const double* wd, const double* lr, const double* b1,
+                                const double* b2, double eps, double clip, int debias, int mixed) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(wd && lr && b1 && b2, "lamp_optimizer_adamw_tagged: one value per parameter for every hyperparameter");
+  std::vector<Ten> ps;
+  for (int i = 0; i < n; i++) ps.push_back(borrow(params[i]));
+  auto a = std::make_shared<AdamW>(ps, 0.0, 0.0, 0.0, 0.0, eps, clip >= 0, clip, debias, mixed);
+  a->weightDecayPer.assign(wd, wd + n); a->learningRatePer.assign(lr, lr + n); a->beta1Per.assign(b1, b1 + n); a->beta2Per.assign(b2, b2 + n);
+  auto* o = new lamp_optimizer();
+  o->o = a;
+  *out = o;
+  LAMP_API_END
+}
 int lamp_optimizer_sgdw(lamp_optimizer** out, lamp_tensor* const* params, int n, double lr, double wd, double momentum, double clip) {
   LAMP_API_BEGIN
   std::vector<Ten> ps;

@@ -204,15 +204,18 @@ void AdamW::load(const std::vector<Ten>& tensors) {
 void AdamW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
   LAMP_CHECK(gradients.size() == parameters.size(), "AdamW.step: got " << gradients.size() << " gradients for " << parameters.size() << " parameters");
   std::vector<lamp_tensor*> p, g, m, v, w;
+  std::vector<double> lr, wd, b1, b2;
+  auto pick = [](const std::vector<double>& per, double all, size_t i) { return per.empty() ? all : per[i]; };
   for (size_t i = 0; i < parameters.size(); i++) {
     if (!gradients[i].defined()) continue;
     p.push_back(parameters[i].h()); g.push_back(gradients[i].h()); m.push_back(mt[i].h()); v.push_back(vt[i].h());
     w.push_back(workingCopy[i].h());
+    lr.push_back(pick(learningRatePer, learningRate, i)); wd.push_back(pick(weightDecayPer, weightDecay, i));
+    b1.push_back(pick(beta1Per, beta1, i)); b2.push_back(pick(beta2Per, beta2, i));
   }
   if (has_clip && !g.empty()) HCALL(lamp_gradient_clipping_(g.data(), (int)g.size(), clip));
   stepCount += 1;               // stepCountSTen (state()[0]) is brought up to date when the state is asked for: one launch less per step
   const int n = (int)p.size();
-  std::vector<double> lr(n, learningRate), wd(n, weightDecay), b1(n, beta1), b2(n, beta2);
   HCALL(lamp_adamw_step_(p.data(), g.data(), m.data(), v.data(), w.data(), n, lr.data(), wd.data(), b1.data(), b2.data(), eps, scheduleFactor,
                          stepCount, debias));
 }

@@ -134,6 +134,8 @@ struct AdamW : Optimizer {      // nn/AdamW.scala:29-177
   std::vector<Ten> parameters, mt, vt, workingCopy;   // workingCopy[i] undefined when not mixed precision
   double weightDecay, learningRate, beta1, beta2, eps;
   bool has_clip; double clip; bool debias, mixedPrecision;
+  // OptimizedHyperparameter = PTag => Double (Optimizer.scala / AdamW.scala:29-47): when non-empty, one value per parameter
+  std::vector<double> weightDecayPer, learningRatePer, beta1Per, beta2Per;
   int64_t stepCount = 0;
   Ten stepCountSTen;            // f64 scalar, state()[0] (AdamW.scala:97)
   AdamW(const std::vector<Ten>& params, double wd, double lr, double b1, double b2, double eps, bool has_clip, double clip,

@@ -51,6 +51,36 @@ __global__ __launch_bounds__(256) void ew_vec_kernel(TO* __restrict__ out, const
   }
 }
 
+// [R, N] iteration with a contiguous output where every input is dense, a row vector broadcast over the rows (bias / scale of a
+// token batch) or one element: 16-byte packets, the row vector re-read from L2.  kind: 2 bits per input (0 dense, 1 row vector, 2 scalar)
+template <class TO, class TI, int NIN, class F>
+__global__ __launch_bounds__(256) void ew_rowvec_kernel(TO* __restrict__ out, const TI* in0, const TI* in1, const TI* in2, int64_t npk, int ppr,
+                                                        int kind, F f) {
+  using A = acc_t<TI>;
+  constexpr int W = 16 / sizeof(TI);
+  const int k0 = kind & 3, k1 = (kind >> 2) & 3, k2 = (kind >> 4) & 3;
+  A s0 = A(0), s1 = A(0), s2 = A(0);
+  if (k0 == 2) s0 = load_as<A>(in0[0]);
+  if (NIN > 1 && k1 == 2) s1 = load_as<A>(in1[0]);
+  if (NIN > 2 && k2 == 2) s2 = load_as<A>(in2[0]);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npk; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cp = i % ppr;
+    Vec<TI, W> v0, v1, v2;
+    if (k0 != 2) v0 = *reinterpret_cast<const Vec<TI, W>*>(in0 + (k0 == 0 ? i : cp) * W);
+    if (NIN > 1 && k1 != 2) v1 = *reinterpret_cast<const Vec<TI, W>*>(in1 + (k1 == 0 ? i : cp) * W);
+    if (NIN > 2 && k2 != 2) v2 = *reinterpret_cast<const Vec<TI, W>*>(in2 + (k2 == 0 ? i : cp) * W);
+    Vec<TO, W> r;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      A a = k0 == 2 ? s0 : load_as<A>(v0.v[k]);
+      A b = (NIN > 1) ? (k1 == 2 ? s1 : load_as<A>(v1.v[k])) : A(0);
+      A c = (NIN > 2) ? (k2 == 2 ? s2 : load_as<A>(v2.v[k])) : A(0);
+      r.v[k] = f.template apply<TO>(a, b, c);
+    }
+    *reinterpret_cast<Vec<TO, W>*>(out + i * W) = r;
+  }
+}
+
 template <class TO, class TI, int NIN, class F>
 __global__ __launch_bounds__(256) void ew_strided_kernel(TO* __restrict__ out, const TI* in0, const TI* in1, const TI* in2,
                                                          int64_t n, IterArgs it, F f) {
@@ -92,8 +122,31 @@ void launch_ew(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F
     if (NIN > 2 && !(mask & 4) && !aligned(p2)) vec_ok = false;
   }
   if (n == 1) vec_ok = false;
+  // row-vector broadcast over a dense [R, N] output
+  bool row_ok = false;
+  int kind = 0;
+  constexpr int WV = 16 / sizeof(TI);
+  if (!vec_ok && sizeof(TO) == sizeof(TI) && it.ndim == 2 && it.strides[0][1] == 1 && it.strides[0][0] == it.sizes[1] && it.sizes[1] % WV == 0 &&
+      it.sizes[1] / WV < (1ll << 31)) {
+    row_ok = ((uintptr_t)out->data() & 15) == 0;
+    const void* ps[3] = {p0, p1, p2};
+    for (int o = 1; o <= NIN && row_ok; o++) {
+      const int64_t s0 = it.strides[o][0], s1 = it.strides[o][1];
+      int kd;
+      if (s0 == it.sizes[1] && s1 == 1) kd = 0;
+      else if (s0 == 0 && s1 == 1) kd = 1;
+      else if (s0 == 0 && s1 == 0) kd = 2;
+      else { row_ok = false; break; }
+      if (kd != 2 && ((uintptr_t)ps[o - 1] & 15) != 0) row_ok = false;
+      kind |= kd << (2 * (o - 1));
+    }
+  }
   KernelTimer kt("elementwise", 0, (double)n * (NIN * sizeof(TI) + sizeof(TO)), st);
-  if (vec_ok) {
+  if (row_ok) {
+    const int64_t npk = n / WV;
+    hipLaunchKernelGGL((ew_rowvec_kernel<TO, TI, NIN, F>), dim3(grid_for(npk, 256)), dim3(256), 0, st, out->ptr<TO>(), p0, p1, p2, npk,
+                       (int)(it.sizes[1] / WV), kind, f);
+  } else if (vec_ok) {
     constexpr int W = 16 / sizeof(TI);
     int grid = grid_for((n + W - 1) / W, 256);
     hipLaunchKernelGGL((ew_vec_kernel<TO, TI, NIN, F>), dim3(grid), dim3(256), 0, st, out->ptr<TO>(), p0, p1, p2, n, mask, f);

@@ -18,6 +18,10 @@
 // f32 : v_mfma_f32_16x16x4_f32 - exact f32 FMA chain (no tf32 on gfx950), parity <= 1e-5.
 // f64 : v_mfma_f64_16x16x4_f64 (the reference's own tests run in double).
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
 #include "device_utils.h"
 #include "../core/strided.h"
 
@@ -47,6 +51,9 @@ struct GemmArgs {
   // optional kNN epilogue of the f32/f64 kernel: C = max(0, (knn_q[m] + knn_d[n]) - 2 * C)   (knn/package.scala:21-30)
   const void* knn_q;
   const void* knn_d;
+  // split-K (bf16 256 x 256 kernel): blockIdx.z walks K chunks (a_bs / b_bs = one chunk along K) and the raw f32 accumulators go to
+  // C = float[split][M][N]; gemm_splitk_reduce_kernel sums the slices and applies alpha / beta
+  int split_f32;
 };
 
 // ================================================================================================
@@ -513,6 +520,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
 #undef Q_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
 
+  if (g.split_f32) {
+    float* W = (float*)g.C + bz * g.c_bs;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int64_t row = m0 + wr * 128 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<f4_t*>(W + row * g.ldc + col) = acc[i][j];
+      }
+    }
+    return;
+  }
   bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
   const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
   const float alpha = (float)g.alpha, beta = (float)g.beta;
@@ -544,6 +564,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
       pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
       *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
     }
+  }
+}
+
+// split-K epilogue: C[m][n] = alpha * sum_s W[s][m][n] + beta * S[m][n], four columns per thread (N % 4 == 0), slices summed in order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ W, int split, int64_t M, int64_t N, bf16_t* __restrict__ C,
+                                                                 int64_t ldc, const bf16_t* __restrict__ S, int64_t s_rs, int64_t s_cs, float alpha, float beta) {
+  const int64_t total = M * N / 4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    f4_t a = *reinterpret_cast<const f4_t*>(W + e * 4);
+    for (int s = 1; s < split; s++) a += *reinterpret_cast<const f4_t*>(W + (int64_t)s * M * N + e * 4);
+    const int64_t row = (e * 4) / N, col = (e * 4) % N;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      v[r] = alpha * a[r];
+      if (S) v[r] += beta * (float)S[row * s_rs + (col + r) * s_cs];
+    }
+    const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
+    bf16_t* c = C + row * ldc + col;
+    c[0] = o0; c[1] = o1; c[2] = o2; c[3] = o3;
   }
 }
 
@@ -895,7 +935,19 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
   }
   const double g_flops = 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch;
   const double g_bytes = ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * (g.S ? 2 : 1)) * g.batch * (double)dtype_size(a->dtype);
-  KernelTimer kt(a->dtype == kBF16 ? "gemm_bf16" : (a->dtype == kF32 ? "gemm_f32" : "gemm_f64"), g_flops, g_bytes, stm);
+  const char* kt_tag = a->dtype == kBF16 ? "gemm_bf16" : (a->dtype == kF32 ? "gemm_f32" : "gemm_f64");
+  static const bool shape_tags = getenv("LAMP_GEMM_SHAPE_TAGS") != nullptr;   // profiling aid: one timer class per shape and layout
+  if (shape_tags) {
+    static std::mutex mu;
+    static std::map<std::string, std::unique_ptr<std::string>> interned;
+    std::ostringstream os;
+    os << kt_tag << "[" << g.batch << "x" << g.M << "x" << g.N << "x" << g.K << (g.a_cs == 1 ? ",Akc" : ",Amc") << (g.b_rs == 1 ? ",Bkc" : ",Bnc") << "]";
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = interned[os.str()];
+    if (!e) e.reset(new std::string(os.str()));
+    kt_tag = e->c_str();
+  }
+  KernelTimer kt(kt_tag, g_flops, g_bytes, stm);
   if (a->dtype == kBF16) {
     const bool akc = (g.a_cs == 1), bkc = (g.b_rs == 1);
     LAMP_CHECK(akc || g.a_rs == 1, "internal: A has no unit stride");
@@ -908,6 +960,40 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     const bool big = g.a_vec && g.b_vec && g.M % PM == 0 && g.N % PN == 0 && g.K % PK == 0 && (g.ldc % 4 == 0) &&
                      (((uintptr_t)g.C & 7) == 0) && (g.c_bs % 4 == 0) && (g.M / PM) * (g.N / PN) * g.batch >= 128;
     const bool big2 = big && g.N % QN == 0 && (g.M / QM) * (g.N / QN) * g.batch >= 200;
+    // few output tiles over a long K (the weight gradients x^T . p of a token batch): split K over blockIdx.z
+    static const bool allow_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
+    if (allow_split && !big2 && g.batch == 1 && g.a_vec && g.b_vec && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 2048) {
+      const int64_t tiles = (g.M / QM) * (g.N / QN), nk_total = g.K / PK;
+      int split = 1;
+      for (int64_t d = 2; d <= nk_total / 4; d++)
+        if (nk_total % d == 0) { split = (int)d; if (tiles * d >= 224) break; }
+      if (split > 1 && tiles * split >= 64) {
+        Hold ws(new_tensor({(int64_t)split, g.M, g.N}, kF32, out->device()));
+        GemmArgs h = g;
+        h.K = g.K / split;
+        h.a_bs = h.K * g.a_cs; h.b_bs = h.K * g.b_rs;
+        h.C = ws->data(); h.ldc = g.N; h.c_bs = g.M * g.N; h.S = nullptr; h.split_f32 = 1;
+        h.tiles_m = (int)(g.M / QM); h.tiles_n = (int)(g.N / QN);
+        dim3 grid(h.tiles_m * h.tiles_n, 1, split);
+        const size_t lds = 2 * Q_SLOT;
+#define PP2S_LAUNCH(A_, B_)                                                                                                     \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp2_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((gemm_bf16_pp2_kernel<A_, B_>), grid, dim3(512), lds, stm, h);                                           \
+  } while (0)
+        if (akc && !bkc) PP2S_LAUNCH(true, false);
+        else if (akc && bkc) PP2S_LAUNCH(true, true);
+        else if (!akc && !bkc) PP2S_LAUNCH(false, false);
+        else PP2S_LAUNCH(false, true);
+#undef PP2S_LAUNCH
+        LAMP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(grid_for(g.M * g.N / 4, 256)), dim3(256), 0, stm, (const float*)ws->data(), split, g.M, g.N,
+                           (bf16_t*)g.C, g.ldc, (const bf16_t*)g.S, g.s_rs, g.s_cs, (float)g.alpha, (float)g.beta);
+        LAMP_LAUNCH_CHECK();
+        return;
+      }
+    }
     if (big2) {
       g.tiles_m = (int)(g.M / QM);
       g.tiles_n = (int)(g.N / QN);

@@ -87,6 +87,77 @@ __global__ __launch_bounds__(256) void reduce_column_kernel(const T* __restrict_
   partial[blockIdx.y * nout + o] = acc;
 }
 
+// column reduction of a dense [K0, R1, K1] input in 16-byte packets: a workgroup covers 32 packets of columns x 8 row lanes, every
+// row lane walks its share of the row chunk, the lanes are combined through LDS in a fixed order (run-to-run identical)
+template <class T, int OP>
+__global__ __launch_bounds__(256) void reduce_column_vec_kernel(const T* __restrict__ in, acc_t<T>* __restrict__ partial, RGeom g) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  __shared__ A sm[8][32 * W + 1];
+  const int cp = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t ppr = g.K1 / W;                                  // packets per row
+  const int64_t pk = (int64_t)blockIdx.x * 32 + cp;
+  const int64_t k0 = blockIdx.z;
+  const int64_t chunk = (g.R1 + g.nsplit - 1) / g.nsplit;
+  const int64_t begin = blockIdx.y * chunk;
+  const int64_t end = begin + chunk < g.R1 ? begin + chunk : g.R1;
+  A acc[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) acc[k] = r_init<OP, A>();
+  if (pk < ppr) {
+    const T* base = in + k0 * g.R1 * g.K1 + pk * W;
+    int64_t r = begin + rl;
+    for (; r + 24 < end; r += 32) {                               // four independent loads in flight
+      Vec<T, W> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const Vec<T, W>*>(base + (r + 8 * u) * g.K1);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int k = 0; k < W; k++) acc[k] = r_comb<OP, A>(acc[k], r_elem<OP, A>(load_as<A>(v[u].v[k])));
+    }
+    for (; r < end; r += 8) {
+      const Vec<T, W> v = *reinterpret_cast<const Vec<T, W>*>(base + r * g.K1);
+#pragma unroll
+      for (int k = 0; k < W; k++) acc[k] = r_comb<OP, A>(acc[k], r_elem<OP, A>(load_as<A>(v.v[k])));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < W; k++) sm[rl][cp * W + k] = acc[k];
+  __syncthreads();
+  const int64_t nout = g.K0 * g.K1;
+  for (int c = threadIdx.x; c < 32 * W; c += 256) {
+    const int64_t col = (int64_t)blockIdx.x * 32 * W + c;
+    if (col < g.K1) {
+      A a = sm[0][c];
+#pragma unroll
+      for (int l = 1; l < 8; l++) a = r_comb<OP, A>(a, sm[l][c]);
+      partial[blockIdx.y * nout + k0 * g.K1 + col] = a;
+    }
+  }
+}
+
+// finalize of many partials: 64 outputs x 4 split lanes per workgroup
+template <class T, int OP>
+__global__ __launch_bounds__(256) void reduce_finalize_wide_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ out, int64_t nout, int64_t nsplit,
+                                                                   double scale, int do_sqrt) {
+  using A = acc_t<T>;
+  __shared__ A sm[4][64];
+  const int oc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t o = (int64_t)blockIdx.x * 64 + oc;
+  A r = r_init<OP, A>();
+  if (o < nout)
+    for (int64_t s = sl; s < nsplit; s += 4) r = r_comb<OP, A>(r, partial[s * nout + o]);
+  sm[sl][oc] = r;
+  __syncthreads();
+  if (sl == 0 && o < nout) {
+    r = r_comb<OP, A>(r_comb<OP, A>(sm[0][oc], sm[1][oc]), r_comb<OP, A>(sm[2][oc], sm[3][oc]));
+    if (OP == kSum || OP == kSumSq) r = (A)(r * (A)scale);
+    if (do_sqrt) r = (A)sqrt((double)r);
+    out[o] = store_as<T>(r);
+  }
+}
+
 // finalize: combine nsplit partials, apply scale / sqrt, cast
 template <class T, int OP>
 __global__ void reduce_finalize_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ out, int64_t nout, int64_t nsplit,
@@ -188,6 +259,7 @@ static void reduce_typed(const Tensor* ac, Tensor* out, const DimPlan& p, double
   int64_t nsplit = 1;
   if (column) {
     int64_t blocks = (nout + 255) / 256;
+    if (sizeof(T) <= 8 && g.K1 % (16 / sizeof(T)) == 0 && g.R1 >= 64) blocks = ((g.K1 / (16 / sizeof(T)) + 31) / 32) * g.K0;
     if (blocks < target_blocks && g.R1 >= 256) nsplit = std::min<int64_t>(std::min<int64_t>(target_blocks / blocks, g.R1 / 64), 256);
   } else {
     int64_t total = g.R1 * g.R2;
@@ -197,7 +269,13 @@ static void reduce_typed(const Tensor* ac, Tensor* out, const DimPlan& p, double
   g.nsplit = nsplit;
   int64_t psz[1] = {nsplit * nout};
   Hold partial(new_tensor(psz, 1, std::is_same<A, double>::value ? kF64 : (std::is_same<A, float>::value ? kF32 : kI64), ac->device()));
-  if (column) {
+  constexpr int WV = 16 / sizeof(T);
+  const bool column_vec = column && sizeof(T) <= 8 && g.K1 % WV == 0 && ((uintptr_t)ac->data() & 15) == 0 && g.K0 <= 65535 && g.R1 >= 64;
+  if (column_vec) {
+    const int64_t bx = (g.K1 / WV + 31) / 32;
+    dim3 grid((unsigned)bx, (unsigned)nsplit, (unsigned)g.K0);
+    hipLaunchKernelGGL((reduce_column_vec_kernel<T, OP>), grid, dim3(256), 0, st, ac->ptr<T>(), partial->ptr<A>(), g);
+  } else if (column) {
     dim3 grid((unsigned)((nout + 255) / 256), (unsigned)nsplit);
     hipLaunchKernelGGL((reduce_column_kernel<T, OP>), grid, dim3(256), 0, st, ac->ptr<T>(), partial->ptr<A>(), g);
   } else {
@@ -208,8 +286,12 @@ static void reduce_typed(const Tensor* ac, Tensor* out, const DimPlan& p, double
     hipLaunchKernelGGL((reduce_block_kernel<T, OP>), grid, dim3(block), 0, st, ac->ptr<T>(), partial->ptr<A>(), g);
   }
   LAMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL((reduce_finalize_kernel<T, OP>), dim3(grid_for(nout, 256)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
-                     nout, nsplit, scale, do_sqrt);
+  if (nsplit >= 16 && nout < 65536)
+    hipLaunchKernelGGL((reduce_finalize_wide_kernel<T, OP>), dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
+                       nout, nsplit, scale, do_sqrt);
+  else
+    hipLaunchKernelGGL((reduce_finalize_kernel<T, OP>), dim3(grid_for(nout, 256)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
+                       nout, nsplit, scale, do_sqrt);
   LAMP_LAUNCH_CHECK();
 }
 

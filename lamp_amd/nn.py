@@ -126,6 +126,20 @@ def AdamW(parameters: Sequence[STen], weightDecay, learningRate=0.001, beta1=0.9
     return opt
 
 
+def AdamW_tagged(parameters: Sequence[STen], weightDecay: Sequence[float], learningRate, beta1=0.9, beta2=0.999, eps=1e-8, clip=None, debias=True,
+                 mixedPrecision=False) -> Optimizer:
+    """AdamW whose hyperparameters are functions of the parameter tag (AdamW.scala:29-47): one value per parameter (scalars are repeated)."""
+    from ._capi import f64_array
+    n = len(parameters)
+    per = lambda v: f64_array([float(x) for x in v] if hasattr(v, "__len__") else [float(v)] * n)
+    o = C.c_void_p()
+    lib.lamp_optimizer_adamw_tagged(C.byref(o), handle_array([p.h for p in parameters]), n, per(weightDecay), per(learningRate), per(beta1), per(beta2),
+                                    float(eps), -1.0 if clip is None else float(clip), int(debias), int(mixedPrecision))
+    opt = Optimizer(o)
+    opt._keep = list(parameters)
+    return opt
+
+
 def AdamW_factory(weightDecay, learningRate=0.001, beta1=0.9, beta2=0.95, eps=1e-8, clip=None, debias=True, mixedPrecision=False):
     """AdamW.factory: note beta2 = 0.95 (AdamW.scala:12)."""
     return lambda params: AdamW(params, weightDecay, learningRate, beta1, beta2, eps, clip, debias, mixedPrecision)

@@ -212,6 +212,24 @@ def test_gemm_256_tile_all_layouts(gpu, K):
     assert_close(to_torch(S.STen(o)), ref + bias.double(), 3.2e-2, "linear_bias")
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 12288), (256, 768, 6144), (768, 3072, 4096), (512, 256, 2048)])
+def test_gemm_split_k(gpu, M, N, K):
+    """few output tiles over a long K (weight gradients of a token batch): K split over blockIdx.z, f32 slices summed by the reduce
+    kernel - all operand layouts, beta operand, and the same answer as the unsplit kernel up to bf16 rounding of one result"""
+    dt = torch.bfloat16
+    xt, p = closed_form((K, M), 3, 2.0, dt), closed_form((K, N), 9, 2.0, dt)
+    ref = xt.double().t() @ p.double()
+    got = to_torch(to_sten(xt).t.mm(to_sten(p)))                       # x^T . p: A m-contiguous, B n-contiguous
+    assert_close(got, ref, 8e-3, "x^T . p")
+    a, b = closed_form((M, K), 5, 2.0, dt), closed_form((N, K), 6, 2.0, dt)
+    assert_close(to_torch(to_sten(a).mm(to_sten(b).t)), a.double() @ b.double().t(), 8e-3, "a . b^T")
+    assert_close(to_torch(to_sten(a).mm(to_sten(b.t().contiguous()))), a.double() @ b.double().t(), 8e-3, "a . b")
+    o0 = closed_form((M, N), 7, float(K) ** 0.5, dt)
+    O = to_sten(o0)
+    S.STen.addmm_out_transposed1(O, O, to_sten(xt), to_sten(p), 1.0, 1.0)
+    assert_close(to_torch(O), o0.double() + ref, 1.6e-2, "out += x^T . p")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_bmm_family(gpu, dt):
     a, b = closed_form((3, 33, 65), 1, 2.0, dt), closed_form((3, 65, 17), 5, 2.0, dt)
