@@ -964,9 +964,20 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     static const bool allow_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
     if (allow_split && !big2 && g.batch == 1 && g.a_vec && g.b_vec && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 2048) {
       const int64_t tiles = (g.M / QM) * (g.N / QN), nk_total = g.K / PK;
+      // one workgroup per CU.  Cost of a split d in us: rounds x k-steps per chunk x ~1.7 us (one 256 x 256 x 64 stage at the
+      // kernel's ~4.9 TFLOP/s per CU) + writing and re-reading d f32 slices at ~4 TB/s
+      const int64_t cus = num_cus();
+      auto cost = [&](int64_t d) {
+        const int64_t wgs = tiles * d;
+        return (double)((wgs + cus - 1) / cus) * (double)(nk_total / d) * 1.7 + (d > 1 ? (double)d * (double)g.M * (double)g.N * 8.0 / 4.0e6 : 0.0);
+      };
       int split = 1;
-      for (int64_t d = 2; d <= nk_total / 4; d++)
-        if (nk_total % d == 0) { split = (int)d; if (tiles * d >= 224) break; }
+      double best = cost(1);
+      for (int64_t d = 2; d <= nk_total / 4; d++) {
+        if (nk_total % d) continue;
+        const double c = cost(d);
+        if (c < best * 0.97) { best = c; split = (int)d; }
+      }
       if (split > 1 && tiles * split >= 64) {
         Hold ws(new_tensor({(int64_t)split, g.M, g.N}, kF32, out->device()));
         GemmArgs h = g;
