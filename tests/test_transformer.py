@@ -322,3 +322,24 @@ def test_language_model_training_steps_with_identity_loss(gpu):
             assert_close(to_torch(hv.value), ov.value.double(), 2e-4, f"state {i} after step {step}")
     assert abs(float(acc.to_numpy()[0]) - 4 * sum(losses)) <= 1e-4 * 4 * sum(losses)
     assert losses[1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_language_model_bf16_flash_path_matches_f32_oracle(gpu):
+    """bf16 with head width 64: the fused branch runs the flash kernels (attention.hip) on the (batch, sequence, heads, d) views; the loss
+    and every gradient agree with the f32 oracle on the same bf16-rounded weights at bf16 resolution"""
+    A, nn, S, TR = _hip()
+    vocab, ctx, dim, heads, blocks, pad = 32, 16, 128, 2, 2, -1000
+    om = _oracle_lm(vocab, ctx, dim, heads, blocks, torch.float32, pad)
+    for v in om.state():                                   # weights of a trained-model magnitude, representable in bf16
+        v.value.copy_((v.value * (4.0 / v.value.shape[-1] ** 0.5)).bfloat16().float())
+    hm = TR.LanguageModelLoss(ctx, vocab, blocks, dim, dim // heads, heads, dim * 4, 0.0, pad, S.BF16, 0)
+    _load(hm, om, S, torch.bfloat16)
+    tokens = (torch.arange(4 * ctx).view(4, ctx) * 7 + 3) % vocab
+    target = (tokens * 5 + 1) % vocab
+    oloss = om.loss(tokens, target)
+    hloss = hm.forward(A.const(to_sten(tokens)), to_sten(target))
+    assert_close(to_torch(hloss.value).reshape(()).double(), oloss.value.double(), 2e-2, "loss")
+    hg = hm.gradients(hloss); og = om.gradients(oloss)
+    for i, (a, b) in enumerate(zip(hg, og)):
+        assert_close(to_torch(a).double(), b.double(), 6e-2, f"gradient {i}")
