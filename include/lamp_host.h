@@ -130,6 +130,13 @@ int lamp_model_forward_loss(lamp_model* m, const lamp_tensor* samples, const lam
  * (lamp-data/.../IOLoops.scala:621-658) or distributed oneBatch (distributed/package.scala:733-759) */
 int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm_or_null, const lamp_tensor* samples, const lamp_tensor* target,
                           lamp_tensor* acc_or_null, int64_t* num_examples);
+/* Single-process data parallel, DataParallel.driveSynchronousLoop's `synchronousStep` (lamp-data DataParallel.scala:195-311): the main
+ * model (with the optimiser) and `nreplicas` replicas on other GPUs; arrays of nreplicas + 1 entries, main first.  Copies the main
+ * state to the replicas, computes every model's gradients on its own host thread, and - when `step` - averages the gradients weighted
+ * by the example counts into the main model and steps the optimiser.  Returns the examples of all models. */
+int lamp_data_parallel_step(lamp_model* main_model, lamp_optimizer* o, lamp_model* const* replicas, int nreplicas, const lamp_tensor* const* samples,
+                            const lamp_tensor* const* targets, lamp_tensor* const* accs_or_null, int zero_grad, int step, double schedule_factor,
+                            int64_t* num_examples);
 int lamp_model_release(lamp_model* m);
 
 /* ---- tensor-list files and checkpoints (lamp-data Writer.scala:14-190, Reader.scala:17-95, schemas.scala:30-56) ----

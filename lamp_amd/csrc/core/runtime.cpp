@@ -7,6 +7,7 @@
 #include "tensor.h"
 
 #include <mutex>
+#include <set>
 #include <map>
 
 struct lamp_stream {
@@ -71,6 +72,17 @@ int num_cus() {
     }
   }
   return g_num_cus;
+}
+// kernels that use more than 64 KiB of dynamic LDS opt in once per (function, device): the attribute belongs to the device's copy of
+// the code object, and one process may drive several GPUs (single-process data parallel, one host thread per GPU)
+void allow_big_lds(const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({fn, dev})) return;
+  HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  done.insert({fn, dev});
 }
 uint64_t philox_seed() { return g_seed.load(); }
 uint64_t next_philox_offset(uint64_t n) { return g_philox_offset.fetch_add(n); }

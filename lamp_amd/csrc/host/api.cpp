@@ -339,6 +339,20 @@ int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, con
   *num_examples = m->dp.step(m->model, *o->o, borrow(samples), borrow(target), acc ? borrow(acc) : Ten());
   LAMP_API_END
 }
+int lamp_data_parallel_step(lamp_model* main_model, lamp_optimizer* o, lamp_model* const* replicas, int nreplicas, const lamp_tensor* const* samples,
+                            const lamp_tensor* const* targets, lamp_tensor* const* accs, int zero_grad, int step, double schedule_factor,
+                            int64_t* num_examples) {
+  LAMP_API_BEGIN
+  std::vector<SupervisedModel*> reps;
+  for (int i = 0; i < nreplicas; i++) { LAMP_CHECK(replicas[i], "NULL replica"); reps.push_back(&replicas[i]->model); }
+  std::vector<Ten> xs, ts, as;
+  for (int i = 0; i <= nreplicas; i++) {
+    LAMP_CHECK(samples[i] && targets[i], "NULL batch");
+    xs.push_back(borrow(samples[i])); ts.push_back(borrow(targets[i])); as.push_back(accs && accs[i] ? borrow(accs[i]) : Ten());
+  }
+  *num_examples = data_parallel_synchronous_step(main_model->model, *o->o, reps, xs, ts, as, zero_grad, step, schedule_factor);
+  LAMP_API_END
+}
 int lamp_model_release(lamp_model* m) { LAMP_API_BEGIN delete m; LAMP_API_END }
 
 }  // extern "C"

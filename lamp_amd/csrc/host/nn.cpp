@@ -1,5 +1,6 @@
 // lamp.nn over the C ABI - see nn.h for the reference map.
 #include "nn.h"
+#include <thread>
 #include <unordered_map>
 
 namespace lamp {
@@ -268,6 +269,65 @@ int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, co
     ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
   }
   return ln.second;
+}
+
+// ---- single-process data parallel (DataParallel.scala:195-311) ---------------------------------------------
+int64_t data_parallel_synchronous_step(SupervisedModel& main, Optimizer& opt, const std::vector<SupervisedModel*>& replicas,
+                                       const std::vector<Ten>& samples, const std::vector<Ten>& targets, const std::vector<Ten>& accs,
+                                       bool zeroGrad, bool step, double scheduleFactor) {
+  const size_t n = replicas.size() + 1;
+  LAMP_CHECK(samples.size() == n && targets.size() == n && accs.size() == n, "assertion failed: batch.size == models.size + 1 (DataParallel.scala:207-208)");
+  std::vector<SupervisedModel*> models = {&main};
+  for (auto* r : replicas) models.push_back(r);
+  std::vector<Var> mainState = main.module->state();
+  LAMP_CHECK(!mainState.empty(), "data parallel step on a model without state");
+  const int mainDevice = mainState[0]->value.device();
+  int callerDevice = 0;
+  HCALL(lamp_get_device(&callerDevice));
+  HCALL(lamp_set_device(mainDevice));
+  HCALL(lamp_device_synchronize());          // the previous optimiser step is complete before the replicas read the state
+
+  std::vector<int64_t> examples(n, 0);
+  std::vector<std::vector<Ten>> grads(n);
+  std::vector<std::string> errors(n);
+  auto work = [&](size_t i) {
+    try {
+      std::vector<Var> st = models[i]->module->state();
+      LAMP_CHECK(st.size() == mainState.size(), "replica " << i << " has " << st.size() << " state tensors, the main model " << mainState.size());
+      const int dev = st[0]->value.device();
+      HCALL(lamp_set_device(dev));
+      if (i > 0)                              // copyStateFromMain (:224-247)
+        for (size_t k = 0; k < st.size(); k++) ops::copy_(st[k]->value, mainState[k]->value);
+      examples[i] = models[i]->addTotalLossAndReturnGradientsAndNumExamples(samples[i], targets[i], accs[i], zeroGrad, &grads[i]);
+      if (step)                               // gradTensor *= numExample (:273-281)
+        for (auto& g : grads[i]) if (g.defined()) ops::mul_scalar_(g, (double)examples[i]);
+      HCALL(lamp_device_synchronize());
+    } catch (const std::exception& e) { errors[i] = e.what(); if (errors[i].empty()) errors[i] = "unknown error"; }
+  };
+  std::vector<std::thread> threads;
+  for (size_t i = 1; i < n; i++) threads.emplace_back(work, i);
+  work(0);
+  for (auto& t : threads) t.join();
+  HCALL(lamp_set_device(mainDevice));
+  for (size_t i = 0; i < n; i++) LAMP_CHECK(errors[i].empty(), "data parallel model " << i << ": " << errors[i]);
+  int64_t total = 0;
+  for (auto e : examples) total += e;
+  if (step) {                                 // averageGradientsIntoMain (:262-306) then stepOptimizer
+    for (size_t i = 1; i < n; i++) {
+      LAMP_CHECK(grads[i].size() == grads[0].size(), "assertion failed: grads.size == gradMain.size");
+      for (size_t k = 0; k < grads[0].size(); k++) {
+        LAMP_CHECK(grads[i][k].defined() == grads[0][k].defined(), "assertion failed: source.isEmpty == main.isEmpty");
+        if (!grads[0][k].defined()) continue;
+        lamp_tensor* onMain = nullptr;          // main.device.to(source)
+        HCALL(lamp_to(&onMain, grads[i][k].h(), grads[i][k].dtype(), mainDevice, 1, 1));
+        ops::add_(grads[0][k], Ten(onMain));
+      }
+    }
+    for (auto& g : grads[0]) if (g.defined()) ops::mul_scalar_(g, 1.0 / (double)total);
+    opt.step(grads[0], scheduleFactor);
+  }
+  HCALL(lamp_set_device(callerDevice));
+  return total;
 }
 
 // ---- data parallel step ------------------------------------------------------------------------------

@@ -178,6 +178,15 @@ struct DataParallel {
   ~DataParallel();
 };
 
+// Single-process data parallel (lamp-data DataParallel.scala:195-311, `synchronousStep`): the main model + optimiser live on one
+// GPU, every other GPU holds a replica.  Per step: the main state is copied to the replicas, every model computes its gradients on
+// its own batch from its own host thread (current device and stream are per thread), the gradients are weighted by their example
+// counts, copied to the main GPU and summed there, divided by the total, and the optimiser steps the main model.
+// samples / targets / accs are ordered main first.  Returns the number of examples of all models.
+int64_t data_parallel_synchronous_step(SupervisedModel& main, Optimizer& opt, const std::vector<SupervisedModel*>& replicas,
+                                       const std::vector<Ten>& samples, const std::vector<Ten>& targets, const std::vector<Ten>& accs,
+                                       bool zeroGrad, bool step, double scheduleFactor);
+
 }  // namespace host
 }  // namespace lamp
 

@@ -324,7 +324,7 @@ bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
   const size_t lds = (size_t)4 * AT_BK * D * 2;
   if (D == 128) {
     static bool attr = false;
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    allow_big_lds((const void*)sdpa_flash_fwd_kernel<128>);
     hipLaunchKernelGGL((sdpa_flash_fwd_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), out->ptr<bf16_t>(),
                        lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal);
   } else {
@@ -719,7 +719,7 @@ bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, con
     const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
     if (D == 128) {
       static bool attr = false;
-      if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      allow_big_lds((const void*)sdpa_flash_bwd_dq_kernel<128>);
       hipLaunchKernelGGL((sdpa_flash_bwd_dq_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
                          lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
     } else {
@@ -732,7 +732,7 @@ bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, con
     KernelTimer kt("sdpa_flash_bwd_dkv", 8.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 4.0 * Sk) * D * 2, st);
 #define AT_DKV(DHV, NKV)                                                                                                                             \
   do {                                                                                                                                               \
-    HIP_CHECK(hipFuncSetAttribute((const void*)sdpa_flash_bwd_dkv_kernel<DHV, NKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
+    allow_big_lds((const void*)sdpa_flash_bwd_dkv_kernel<DHV, NKV>);        \
     const dim3 grid((unsigned)((Sk + 64 * NKV - 1) / (64 * NKV)), (unsigned)BH);                                                                     \
     hipLaunchKernelGGL((sdpa_flash_bwd_dkv_kernel<DHV, NKV>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(),        \
                        go->ptr<bf16_t>(), lse->ptr<float>(), dsum->ptr<float>(), dk->ptr<bf16_t>(), dv->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, \

@@ -267,11 +267,7 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
       const int PS = O >= 256 ? 1 : (int)(256 / O);
       int64_t ps[1] = {(int64_t)nblocks * O};
       Hold partial(new_tensor(ps, 1, std::is_same<A, double>::value ? kF64 : kF32, dy->device()));
-      static bool attr_set = false;
-      if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-      }
+      allow_big_lds((const void*)conv_wgrad_lds_kernel<T>);
       {
         KernelTimer kt("conv_wgrad_lds", conv_flops(g), conv_bytes(g, sizeof(T)), st);
         hipLaunchKernelGGL((conv_wgrad_lds_kernel<T>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<A>(), g, (int)O, PS, ipb);

@@ -952,10 +952,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         const size_t ldsc = (size_t)2 * 64 * KP * 2 + KP * 2 + 4 * (64 * 64 * 2);
         static bool c3 = false, c1 = false;
         if (KS == 3) {
-          if (!c3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c3 = true; }
+          allow_big_lds((const void*)ig_conv8c_kernel<3>);
           hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
         } else {
-          if (!c1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c1 = true; }
+          allow_big_lds((const void*)ig_conv8c_kernel<1>);
           hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
         }
         LAMP_LAUNCH_CHECK();
@@ -964,10 +964,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
       static bool a3 = false, a1 = false;
       if (KS == 3) {
-        if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
+        allow_big_lds((const void*)ig_conv8b_kernel<3>);
         hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
       } else {
-        if (!a1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8b_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
+        allow_big_lds((const void*)ig_conv8b_kernel<1>);
         hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
       }
       LAMP_LAUNCH_CHECK();
@@ -984,7 +984,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   do {                                                                                                                             \
     static bool attr = false;                                                                                                      \
     if (!attr) {                                                                                                                   \
-      HIP_CHECK(hipFuncSetAttribute((const void*)ig_conv8_kernel<KS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      allow_big_lds((const void*)ig_conv8_kernel<KS_, NW_>); \
       attr = true;                                                                                                                 \
     }                                                                                                                              \
     hipLaunchKernelGGL((ig_conv8_kernel<KS_, NW_>), dim3(blocks), dim3(NW_ * 128), lds, st, in->ptr<bf16_t>(), wpp, bp, \
@@ -1025,11 +1025,11 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
       static bool a3 = false, a1 = false;
       if (KS == 3) {
-        if (!a3) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_wgrad8v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a3 = true; }
+        allow_big_lds((const void*)ig_wgrad8v2_kernel<3>);
         hipLaunchKernelGGL((ig_wgrad8v2_kernel<3>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
                            (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
       } else {
-        if (!a1) { HIP_CHECK(hipFuncSetAttribute((const void*)ig_wgrad8v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
+        allow_big_lds((const void*)ig_wgrad8v2_kernel<1>);
         hipLaunchKernelGGL((ig_wgrad8v2_kernel<1>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
                            (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
       }

@@ -578,7 +578,7 @@ bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const Conv
 template <int NT, int SW>
 static void ncv_wg_launch(const bf16_t* dy, const bf16_t* x, float* partial, const NcvWGeom& q, int ipb, int blocks, size_t lds, hipStream_t st) {
   static bool attr = false;
-  if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)ncv_wgrad_kernel<NT, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  allow_big_lds((const void*)ncv_wgrad_kernel<NT, SW>);
   hipLaunchKernelGGL((ncv_wgrad_kernel<NT, SW>), dim3(blocks), dim3(256), lds, st, dy, x, partial, q, ipb);
 }
 
@@ -623,7 +623,7 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
 #define NCV_WG2(KWv, PWv, SWv, NPTv)                                                                                                   \
   do {                                                                                                                                 \
     static bool attr = false;                                                                                                          \
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    allow_big_lds((const void*)ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>); \
     hipLaunchKernelGGL((ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>), dim3(nblocks), dim3(256), lds2, st, dp, xp, pp, q, ipb);               \
   } while (0)
 #define NCV_WG2_NPT(KWv, PWv, SWv) do { if (npt == 1) NCV_WG2(KWv, PWv, SWv, 1); else if (npt == 2) NCV_WG2(KWv, PWv, SWv, 2); else NCV_WG2(KWv, PWv, SWv, 3); } while (0)

@@ -247,7 +247,7 @@ template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, T
 #define CS_WG(CBv, KWv)                                                                                                              \
   do {                                                                                                                               \
     static bool attr = false;                                                                                                        \
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)cs_wgrad_kernel<T, CBv, KWv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    allow_big_lds((const void*)cs_wgrad_kernel<T, CBv, KWv>); \
     hipLaunchKernelGGL((cs_wgrad_kernel<T, CBv, KWv>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<float>(), g, PS, ipb); \
   } while (0)
     if (CB == 8 && KW == 1) CS_WG(8, 1); else if (CB == 8 && KW == 3) CS_WG(8, 3); else if (CB == 8 && KW == 5) CS_WG(8, 5);

@@ -990,7 +990,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
 #define PP2S_LAUNCH(A_, B_)                                                                                                     \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp2_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    allow_big_lds((const void*)gemm_bf16_pp2_kernel<A_, B_>); \
     hipLaunchKernelGGL((gemm_bf16_pp2_kernel<A_, B_>), grid, dim3(512), lds, stm, h);                                           \
   } while (0)
         if (akc && !bkc) PP2S_LAUNCH(true, false);
@@ -1013,7 +1013,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
 #define PP2_LAUNCH(A_, B_)                                                                                                      \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp2_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    allow_big_lds((const void*)gemm_bf16_pp2_kernel<A_, B_>); \
     hipLaunchKernelGGL((gemm_bf16_pp2_kernel<A_, B_>), grid, dim3(512), lds, stm, g);                                           \
   } while (0)
       if (akc && !bkc) PP2_LAUNCH(true, false);
@@ -1032,7 +1032,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
 #define PP_LAUNCH(A_, B_)                                                                                                       \
   do {                                                                                                                          \
     static bool attr = false;                                                                                                   \
-    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    allow_big_lds((const void*)gemm_bf16_pp_kernel<A_, B_>); \
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_, B_>), grid, dim3(512), lds, stm, g);                                            \
   } while (0)
       if (akc && !bkc) PP_LAUNCH(true, false);

@@ -268,7 +268,7 @@ template <class T, int D, int KIND>
 static void knn_fused_launch(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
                              hipStream_t st) {
   static bool attr = false;
-  if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void*)knn_fused_kernel<T, D, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+  allow_big_lds((const void*)knn_fused_kernel<T, D, KIND>);
   const dim3 grid((unsigned)((Q + KF_BQ - 1) / KF_BQ));
   const size_t lds = (size_t)2 * KfTraits<T>::BC * D * sizeof(T) + 4 * sizeof(KfWaveState<T>);
   hipLaunchKernelGGL((knn_fused_kernel<T, D, KIND>), grid, dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(), idx->ptr<int64_t>(), val->ptr<T>(),

@@ -193,3 +193,18 @@ class SupervisedModel:
         n = C.c_int64()
         lib.lamp_model_train_step(self.h, optimizer.h, comm, samples.h, target.h, acc.h if acc is not None else None, C.byref(n))
         return n.value
+
+
+def dataParallelSynchronousStep(mainModel: SupervisedModel, optimizer: Optimizer, models: Sequence[SupervisedModel], batches, accs=None,
+                                zeroGrad=True, step=True, scheduleFactor=1.0) -> int:
+    """DataParallel.driveSynchronousLoop's synchronousStep (lamp-data DataParallel.scala:195-311): one process, the main model + optimiser
+    on one GPU and one replica per other GPU.  `batches` = [(samples, target)] and `accs` = [loss accumulator] per model, main first."""
+    n = len(models) + 1
+    assert len(batches) == n, "assertion failed: batch.size == models.size + 1"
+    arr = lambda hs: (C.c_void_p * n)(*hs)
+    num = C.c_int64()
+    lib.lamp_data_parallel_step(mainModel.h, optimizer.h, handle_array([m.h for m in models]) if models else None, len(models),
+                                arr([b[0].h for b in batches]), arr([b[1].h for b in batches]),
+                                arr([(a.h if a is not None else None) for a in accs]) if accs is not None else None,
+                                int(zeroGrad), int(step), float(scheduleFactor), C.byref(num))
+    return num.value

@@ -13,7 +13,7 @@ python3 $R/scripts/trace_step.py $(find /tmp/ks -name "*kernel_trace.csv" | head
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pw.log 2>&1
 python3 $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv" | head -1) $(find /tmp/pw -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
-for w in knn attention umap; do
+for w in knn attention umap lm; do
   rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o k --output-format csv -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > /tmp/ks_$w.log 2>&1
   cp $(find /tmp/ks_$w -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$w.csv
   grep -o '{"metric.*' /tmp/ks_$w.log | tail -1 > $O/bench_$w.log
@@ -22,4 +22,6 @@ cd $R
 { python scripts/attn_probe.py 8 16 4096 128 0; python scripts/attn_probe.py 8 16 4096 128 1; python scripts/attn_probe.py 8 16 4096 64 0; } > $O/attention_probe.txt 2>&1
 python scripts/umap_full_probe.py 1000000 40 2>&1 | grep "umap n" > $O/umap_probe.txt
 python scripts/gemm_ab.py > $O/gemm_ab.txt 2>&1 || true
+python scripts/tf_ops_probe.py > $O/tf_ops_probe.txt 2>&1 || true
+python scripts/kstats_top.py /tmp/ks_lm 40 5 > $O/lm_kernels.txt 2>&1 || true
 cat $O/pytest_gpu.txt; tail -c 600 $O/bench.log; cat $O/pmc_traffic.txt | head -12; cat $O/umap_probe.txt

@@ -179,3 +179,53 @@ def test_sharded_knn_single_rank_and_all_gather(gpu):
         assert np.array_equal(np.concatenate(parts, 0), ref)
     finally:
         lib.lamp_comm_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_single_process_data_parallel_step(gpu, accumulate):
+    """DataParallel.synchronousStep (lamp-data DataParallel.scala:195-311) with the main model and two replicas (all on the one GPU of
+    the test box: same host threads, copies, weighting and reduction as with one GPU each): replicas receive the main state, the
+    example-weighted mean gradient and the AdamW step equal the oracle's, the loss accumulators are per model."""
+    from lamp_amd import nn, sten as S
+    from tests.util import to_sten, to_torch, assert_close, closed_form
+    dt = torch.float64
+    def oracle_model(): return O.Sequential(O.mlp(12, 3, [8], dt), O.Fun(lambda v: v.logSoftMax(1)))
+    def hip_model(): return nn.Sequential(nn.MLP(12, 3, [8], S.F64), nn.Fun("logsoftmax", 1))
+    om = oracle_model()
+    hmods = [hip_model() for _ in range(3)]
+    hmods[0].load([to_sten(v.value) for v in om.state()])            # replicas start with different (random) weights
+    cw = torch.ones(3, dtype=dt)
+    models = [nn.SupervisedModel(m, nn.SupervisedModel.NLL, to_sten(cw)) for m in hmods]
+    hopt = nn.AdamW([p.value for p in hmods[0].parameters], weightDecay=0.01, learningRate=1e-2)
+    oopt = O.AdamW([p.value for p in om.parameters()], weightDecay=0.01, learningRate=1e-2)
+    sizes = [5, 3, 7]
+    accs = [S.STen.zeros([1], S.F64) for _ in range(3)]
+    expected_acc = [0.0, 0.0, 0.0]
+    for it in range(2 * accumulate):
+        xs = [closed_form((n, 12), 100 * it + 10 * i, 2.0, dt) for i, n in enumerate(sizes)]
+        ts = [(torch.arange(n) + i + it) % 3 for i, n in enumerate(sizes)]
+        zero, step = it % accumulate == 0, it % accumulate == accumulate - 1
+        total = nn.dataParallelSynchronousStep(models[0], hopt, models[1:], [(to_sten(x), to_sten(t)) for x, t in zip(xs, ts)], accs,
+                                               zeroGrad=zero, step=step)
+        assert total == sum(sizes)
+        # oracle: every model holds the main state; gradients accumulate over `accumulate` batches per model, then the reference's
+        # in-place `grad *= n` of the last batch, sum over models, / total of the last batch
+        if zero:
+            per_model = [None] * 3
+        for i in range(3):
+            loss = om.forward(O.const(xs[i])).nllLoss(ts[i], cw, 1, -100)
+            expected_acc[i] += loss.value.item() * sizes[i]
+            g = [x.clone() for x in om.gradients(loss)]
+            per_model[i] = g if per_model[i] is None else [a + b for a, b in zip(per_model[i], g)]
+        # the replicas now hold the state the main model had at the start of this step
+        for r in hmods[1:]:
+            for hv, ov in zip(r.parameters, om.parameters()):        # (the batch-norm running statistics move with every forward)
+                assert_close(to_torch(hv.value), ov.value, 1e-12, "replica parameters = main parameters")
+        if step:
+            avg = [sum(per_model[i][k] * sizes[i] for i in range(3)) / sum(sizes) for k in range(len(per_model[0]))]
+            oopt.step(avg, 1.0)
+            for hv, ov in zip(hmods[0].parameters, om.parameters()):
+                assert_close(to_torch(hv.value), ov.value, 1e-10, "main parameters after the step")
+    for a, e in zip(accs, expected_acc):
+        assert abs(float(a.to_numpy()[0]) - e) <= 1e-9 * abs(e)
