@@ -206,3 +206,49 @@ def test_scaled_dot_product_attention_op(gpu, dt, D, tol, causal):
     (out * A.const(to_sten(w0))).sum().backprop()
     assert_close(to_torch(q.partialDerivative), qd.grad, tol, "dq (+ dv: q is also the value)")
     assert_close(to_torch(k.partialDerivative), kd.grad, tol, "dk")
+
+
+def test_hip_graph_replays_the_gradient_computation(gpu):
+    """launch-bound steps: forward + backprop captured once into a HIP graph (lamp_graph_*), replayed on new batches written into the
+    captured input buffer; gradients and the loss accumulator equal the eager ones, the optimiser runs eagerly between replays"""
+    import ctypes as C
+    from lamp_amd._capi import lib
+    dt, ldt = torch.float32, S.F32
+    om = O.Sequential(O.mlp(48, 5, [32], dt), O.Fun(lambda v: v.logSoftMax(1)))
+    def fresh():
+        m = nn.Sequential(nn.MLP(48, 5, [32], ldt), nn.Fun("logsoftmax", 1)); _load_from_oracle(m, om, ldt); return m
+    cw = to_sten(torch.ones(5, dtype=dt))
+    batches = [(O.closed_form(64 * 48, 11 * i, 1.0, dt).reshape(64, 48), (torch.arange(64) + i) % 5) for i in range(3)]
+    # eager reference: three AdamW steps
+    em = fresh(); emodel = nn.SupervisedModel(em, nn.SupervisedModel.NLL, cw)
+    eopt = nn.AdamW([p.value for p in em.parameters], weightDecay=0.0, learningRate=1e-2)
+    eacc = S.STen.zeros([1], ldt)
+    for x, t in batches:
+        emodel.train_step(eopt, to_sten(x), to_sten(t), eacc)
+    # captured: same three steps, gradients from graph replays
+    st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(st)); lib.lamp_stream_set_current(st)
+    try:
+        gm = fresh(); gmodel = nn.SupervisedModel(gm, nn.SupervisedModel.NLL, cw)
+        gopt = nn.AdamW([p.value for p in gm.parameters], weightDecay=0.0, learningRate=1e-2)
+        gacc = S.STen.zeros([1], ldt)
+        x_buf, t_buf = to_sten(batches[0][0]), to_sten(batches[0][1])
+        scratch = S.STen.zeros([1], ldt)
+        gmodel.addTotalLossAndReturnGradientsAndNumExamples(x_buf, t_buf, scratch)       # eager warm-up (attributes, caches)
+        for v, ov in zip(gm.state, om.state()):                                            # undo the running-statistics update
+            v.value.copyFrom(to_sten(ov.value))
+        lib.lamp_graph_begin_capture()
+        n, grads = gmodel.addTotalLossAndReturnGradientsAndNumExamples(x_buf, t_buf, gacc)
+        g = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(g))
+        assert n == 64
+        for x, t in batches:
+            x_buf.copyFrom(to_sten(x)); t_buf.copyFrom(to_sten(t))
+            lib.lamp_graph_launch(g)
+            gopt.step(grads, 1.0)
+        lib.lamp_device_synchronize()
+        for a, b in zip(gm.state, em.state):
+            assert_close(to_torch(a.value), to_torch(b.value).double(), 1e-6, "state after three captured steps")
+        assert_close(to_torch(gacc), to_torch(eacc).double(), 1e-6, "loss accumulator")
+        lib.lamp_graph_release(g)
+    finally:
+        d = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(d)); lib.lamp_stream_set_current(d)
+        lib.lamp_stream_release(st); lib.lamp_stream_release(d)
