@@ -225,6 +225,10 @@ void fill_zero(Tensor* t) {
 }
 
 // ---- fills -------------------------------------------------------------------------------------
+template <class T> __global__ void arange_kernel(T* p, int64_t n, double start, double step) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = store_as<T>((acc_t<T>)(start + (double)i * step));
+}
 template <class T> __global__ void fill_kernel(T* p, int64_t n, T v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -409,14 +413,18 @@ int lamp_arange(lamp_tensor** out, double start, double end, double step, int dt
   int64_t n = (int64_t)std::ceil((end - start) / step);
   if (n < 0) n = 0;
   int64_t sz[1] = {n};
+  if (device >= 0) {   // filled on the device with the same f64 expression (no staging copy: legal inside a graph capture)
+    Hold d(new_tensor(sz, 1, dtype, device));
+    if (n) {
+      LAMP_DISPATCH_ALL(dtype, T, hipLaunchKernelGGL((arange_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(device), d->ptr<T>(), n, start, step));
+      LAMP_LAUNCH_CHECK();
+    }
+    *out = d.take();
+    return 0;
+  }
   Hold h(new_tensor(sz, 1, dtype, -1));
   LAMP_DISPATCH_ALL(dtype, T, { T* p = h->ptr<T>(); for (int64_t i = 0; i < n; i++) p[i] = store_as<T>((acc_t<T>)(start + i * step)); });
-  if (device < 0) *out = h.take();
-  else {
-    Hold d(new_tensor(sz, 1, dtype, device));
-    copy_into(d.get(), h.get());
-    *out = d.take();
-  }
+  *out = h.take();
   LAMP_API_END
 }
 int lamp_eye(lamp_tensor** out, int64_t n, int64_t m, int dtype, int device) {
