@@ -248,6 +248,24 @@ Var mm(const Var& a, const Var& b) {
   }});
   return make_result(op, ops::mm(a->value, b->value));
 }
+// x.mm(w) + bias as one GEMM whose epilogue adds the row vector (bf16: the product is rounded before the addition, so the values are
+// bitwise those of the two-operator chain); the three closures are those of MatMul and of Add's broadcast operand
+Var linear_bias(const Var& x, const Var& w, const Var& bias) {
+  LAMP_CHECK(x->value.ndim() == 2 && w->value.ndim() == 2, "linear_bias: 2-D operands");
+  auto op = new_op("MatMulAdd");
+  Ten xv = x->value, wv = w->value;
+  auto bs = bias->shape();
+  op->params.push_back({x, [wv](const Ten& p, Variable& out) {
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_addmm_out_transposed2(o.h(), o.h(), p.h(), wv.h(), beta, 1.0)); });
+  }});
+  op->params.push_back({w, [xv](const Ten& p, Variable& out) {
+    gemm_accumulate(out, [&](const Ten& o, double beta) { HCALL(lamp_addmm_out_transposed1(o.h(), o.h(), xv.h(), p.h(), beta, 1.0)); });
+  }});
+  op->params.push_back({bias, [bs](const Ten& p, Variable& out) { out.accumulate(p.shape() == bs ? p : ops::unbroadcast(p, bs), p.shape() != bs); }});
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_linear_bias(&o, xv.h(), wv.h(), bias->value.h()));
+  return make_result(op, Ten(o));
+}
 Var bmm(const Var& a, const Var& b) {
   auto op = new_op("BatchedMatMul");
   Ten av = a->value, bv = b->value;

@@ -22,6 +22,7 @@ Var mean(const Var& a, const std::vector<int64_t>& dim, bool keepDim = true);
 Var norm2(const Var& a, const std::vector<int64_t>& dim, bool keepDim);
 Var mm(const Var& a, const Var& b);
 Var bmm(const Var& a, const Var& b);
+Var linear_bias(const Var& x, const Var& w, const Var& bias);   // x.mm(w) + bias[1, n] in one launch, values of the chain
 Var exp(const Var& a);
 Var log(const Var& a);
 Var log1p(const Var& a);

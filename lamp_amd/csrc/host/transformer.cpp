@@ -15,6 +15,16 @@ Var mm1(const Var& a, const Var& b, bool reshape_first = false) {
   shape.back() = -1;
   return F::view(F::mm(a2, b), shape);
 }
+// mm1(a, w) + b with the bias folded into the GEMM epilogue (same values as the chain, see F::linear_bias)
+Var mm1_bias(const Var& a, const Var& w, const Var& b) {
+  static const bool fused = !(getenv("LAMP_LINEAR_BIAS_FUSED") && atoi(getenv("LAMP_LINEAR_BIAS_FUSED")) == 0);
+  const auto bsh = b->shape();
+  if (!fused || bsh.size() != 2 || bsh[0] != 1 || bsh[1] != w->value.size(1)) return F::add(mm1(a, w), b);
+  auto shape = a->shape();
+  Var a2 = F::view(a, {-1, shape.back()});
+  shape.back() = -1;
+  return F::view(F::linear_bias(a2, w, b), shape);
+}
 Ten arange_like(int64_t start, int64_t end, const Ten& options) {
   lamp_tensor* o = nullptr;
   HCALL(lamp_arange(&o, (double)start, (double)end, 1.0, options.dtype(), options.device()));
@@ -178,12 +188,12 @@ Var TransformerEncoderBlock::block(const Var& input, const Ten& maxLength) {   /
     Var a1 = layerNorm1->forward(F::dropout(input, dropout, train));
     Var a2 = F::add(F::mult(attention->attend(a1, a1, a1, maxLength), scale1), input);
     Var a3 = layerNorm2->forward(F::dropout(a2, dropout, train));
-    Var a4 = F::add(F::mult(F::add(mm1(F::gelu(F::add(mm1(a3, w1), b1)), w2), b2), scale2), a2);
+    Var a4 = F::add(F::mult(mm1_bias(F::gelu(mm1_bias(a3, w1, b1)), w2, b2), scale2), a2);
     return a4;
   }
   Var a1 = attention->attend(input, input, input, maxLength);
   Var a2 = layerNorm1->forward(F::add(F::dropout(a1, dropout, train), input));
-  Var a3 = F::add(mm1(F::gelu(F::add(mm1(a2, w1), b1)), w2), b2);
+  Var a3 = mm1_bias(F::gelu(mm1_bias(a2, w1, b1)), w2, b2);
   return layerNorm2->forward(F::add(F::dropout(a3, dropout, train), a3));   // a3.dropout + a3 (sic, :255)
 }
 std::shared_ptr<TransformerEncoder> TransformerEncoder::make(int64_t numBlocks, int64_t in, int64_t attentionHiddenPerHeadDim, int64_t attentionNumHeads,
@@ -224,7 +234,7 @@ Var TransformerDecoderBlock::block(const Var& decoderInput, const Var& encoderOu
   Var a4 = layerNorm3->forward(F::dropout(encoderOutput, dropout, train));
   Var a5 = F::add(a2, attentionEncoderDecoder->attend(a3, a4, a4, Ten()));
   Var a6 = layerNorm4->forward(F::dropout(a5, dropout, train));
-  return F::add(F::add(mm1(F::gelu(F::add(mm1(a6, w1), b1)), w2), b2), a5);
+  return F::add(mm1_bias(F::gelu(mm1_bias(a6, w1, b1)), w2, b2), a5);
 }
 std::shared_ptr<Transformer> Transformer::make(int64_t numBlocks, int64_t in, int64_t attentionHiddenPerHeadDim, int64_t attentionNumHeads,
                                                int64_t mlpHiddenDim, double dropout, int dtype, int device, bool linearized, bool encoderCausalMask,

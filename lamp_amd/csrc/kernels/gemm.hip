@@ -54,6 +54,8 @@ struct GemmArgs {
   // split-K (bf16 256 x 256 kernel): blockIdx.z walks K chunks (a_bs / b_bs = one chunk along K) and the raw f32 accumulators go to
   // C = float[split][M][N]; gemm_splitk_reduce_kernel sums the slices and applies alpha / beta
   int split_f32;
+  // bf16: round alpha * acc to bf16 before the beta operand is added - bitwise the chain `mm` then `add` that lamp's Linear issues
+  int round_first;
 };
 
 // ================================================================================================
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         const int64_t row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (row < g.M && col < g.N) {
           float v = alpha * acc[i][j][r];
+          if (g.round_first) v = (float)bf16_t(v);
           if (S) v += beta * (float)S[row * g.s_rs + col * g.s_cs];
           C[row * g.ldc + col] = bf16_t(v);
         }
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
       const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][r];
+      for (int r = 0; r < 4; r++) { v[r] = alpha * acc[i][j][r]; if (g.round_first) v[r] = (float)bf16_t(v[r]); }
       if (S) {
         if (s_vec) {                                       // beta operand contiguous along n: one 8-byte load
           const uint2 sv = *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
       const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[r] = alpha * acc[i][j][r];
+      for (int r = 0; r < 4; r++) { v[r] = alpha * acc[i][j][r]; if (g.round_first) v[r] = (float)bf16_t(v[r]); }
       if (S) {
         if (s_vec) {                                       // beta operand contiguous along n: one 8-byte load
           const uint2 sv = *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
 
 // split-K epilogue: C[m][n] = alpha * sum_s W[s][m][n] + beta * S[m][n], four columns per thread (N % 4 == 0), slices summed in order
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ W, int split, int64_t M, int64_t N, bf16_t* __restrict__ C,
-                                                                 int64_t ldc, const bf16_t* __restrict__ S, int64_t s_rs, int64_t s_cs, float alpha, float beta) {
+                                                                 int64_t ldc, const bf16_t* __restrict__ S, int64_t s_rs, int64_t s_cs, float alpha, float beta, int round_first) {
   const int64_t total = M * N / 4;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     f4_t a = *reinterpret_cast<const f4_t*>(W + e * 4);
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       v[r] = alpha * a[r];
+      if (round_first) v[r] = (float)bf16_t(v[r]);
       if (S) v[r] += beta * (float)S[row * s_rs + (col + r) * s_cs];
     }
     const bf16_t o0(v[0]), o1(v[1]), o2(v[2]), o3(v[3]);
@@ -871,7 +875,7 @@ static void prep_operand(Operand& o, const Tensor* t, bool batched) {
 
 // transA: use a^T, transB: use b^T.  self may be null (beta ignored) and may alias out.
 static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, const Tensor* b, bool transA, bool transB,
-                          double beta, double alpha, bool batched, const Tensor* knn_q = nullptr, const Tensor* knn_d = nullptr) {
+                          double beta, double alpha, bool batched, const Tensor* knn_q = nullptr, const Tensor* knn_d = nullptr, bool round_first = false) {
   check_device_tensor(out, "out"); check_device_tensor(a, "mat1"); check_device_tensor(b, "mat2");
   const int nd = batched ? 3 : 2;
   LAMP_CHECK(a->ndim == nd && b->ndim == nd && out->ndim == nd, "expected " << nd << "-D operands, got " << a->describe() << ", "
@@ -884,6 +888,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
   prep_operand(ob, b, batched);
   const int64_t ar = oa.t->sizes[nd - 2], ac = oa.t->sizes[nd - 1], br = ob.t->sizes[nd - 2], bc = ob.t->sizes[nd - 1];
   GemmArgs g{};
+  g.round_first = round_first ? 1 : 0;
   if (knn_q) {
     LAMP_CHECK(a->dtype == kF32 || a->dtype == kF64, "the fused kNN epilogue exists for f32 / f64");
     g.knn_q = knn_q->data(); g.knn_d = knn_d->data();
@@ -1000,7 +1005,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
 #undef PP2S_LAUNCH
         LAMP_LAUNCH_CHECK();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(grid_for(g.M * g.N / 4, 256)), dim3(256), 0, stm, (const float*)ws->data(), split, g.M, g.N,
-                           (bf16_t*)g.C, g.ldc, (const bf16_t*)g.S, g.s_rs, g.s_cs, (float)g.alpha, (float)g.beta);
+                           (bf16_t*)g.C, g.ldc, (const bf16_t*)g.S, g.s_rs, g.s_cs, (float)g.alpha, (float)g.beta, g.round_first);
         LAMP_LAUNCH_CHECK();
         return;
       }
@@ -1152,7 +1157,7 @@ int lamp_linear_bias(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
   LAMP_API_BEGIN
   check_device_tensor(x, "x"); check_device_tensor(w, "w");
   Hold r(alloc_out(x, w, false, false, false));
-  gemm_dispatch(r.get(), bias, x, w, false, false, bias ? 1.0 : 0.0, 1.0, false);
+  gemm_dispatch(r.get(), bias, x, w, false, false, bias ? 1.0 : 0.0, 1.0, false, nullptr, nullptr, /*round_first: x.mm(w) + bias, rounded as the chain*/ true);
   *out = r.take();
   LAMP_API_END
 }

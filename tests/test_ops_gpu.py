@@ -230,6 +230,20 @@ def test_gemm_split_k(gpu, M, N, K):
     assert_close(to_torch(O), o0.double() + ref, 1.6e-2, "out += x^T . p")
 
 
+@pytest.mark.parametrize("M,N,K", [(96, 40, 72), (512, 1024, 768), (4096, 4096, 512), (256, 256, 4096)])
+def test_linear_bias_is_bitwise_the_mm_add_chain(gpu, M, N, K):
+    """lamp's Linear and the transformer MLP issue x.mm(w) + bias; lamp_linear_bias adds the row vector in the GEMM epilogue after
+    rounding the product to bf16, which makes it bit for bit the two-operator chain (every bf16 kernel incl. the split-K reduce)"""
+    dt = torch.bfloat16
+    x, w, b = closed_form((M, K), 1, 2.0, dt), closed_form((K, N), 2, 2.0, dt), closed_form((1, N), 3, 8.0, dt)
+    X, W, B = to_sten(x), to_sten(w), to_sten(b)
+    o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), X, W, B)
+    fused = S.STen(o).to_numpy()
+    chain = (X.mm(W) + B).to_numpy()
+    assert np.array_equal(fused, chain)
+    assert_close(torch.from_numpy(fused), x.double() @ w.double() + b.double(), 1.6e-2, "value")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_bmm_family(gpu, dt):
     a, b = closed_form((3, 33, 65), 1, 2.0, dt), closed_form((3, 65, 17), 5, 2.0, dt)
