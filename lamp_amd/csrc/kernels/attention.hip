@@ -313,8 +313,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
 }
 
 // q, k, v: contiguous [BH, S, D] bf16; lse: f32 [BH, Sq] (as ATen's logsumexp).  Returns false when the shape is not covered (the caller composes the op instead).
+bool small_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
+                         int64_t Dv, int is_causal, double scale, hipStream_t st);   // attention_small.hip: S <= 16, d = 64
+bool small_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
+                         Tensor* dv, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
+
 bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
                          int64_t Dv, int is_causal, double scale, hipStream_t st) {
+  if (small_attention_fwd(q, k, v, out, lse, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
   static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
   if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
@@ -707,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
 bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
                          Tensor* dv, Tensor* dsum /* f32 [BH * Sq] scratch */, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal,
                          double scale, hipStream_t st) {
+  if (small_attention_bwd(go, q, k, v, out, lse, dq, dk, dv, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
   static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
   if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;

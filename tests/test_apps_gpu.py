@@ -281,6 +281,38 @@ def test_flash_attention_bf16(gpu, shape, causal):
         assert_close(to_torch(S.STen(h)), r, 3e-2, name)
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 12), (2, 5, 16), (1, 9, 1), (2, 3, 5)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_short_sequence_attention_bf16(gpu, shape, causal):
+    """S <= 16 with head width 64 (the problems lamp's MultiheadAttention actually hands the fused operator: one per token, over the
+    head axis) take the wave-per-problem kernels of attention_small.hip; output, logsumexp and the three gradients against f64."""
+    Bz, H, Sq = shape
+    D = 64
+    g = torch.Generator().manual_seed(5)
+    q, k, v, go = (torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(torch.bfloat16) for _ in range(4))
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    scores = qd @ kd.transpose(-1, -2) / np.sqrt(D)
+    if causal:
+        scores = scores.masked_fill(torch.triu(torch.ones(Sq, Sq, dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(scores, -1) @ vd
+    lse_ref = torch.logsumexp(scores, -1)
+    ref.backward(go.double())
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_enable(1)
+    o, l = C.c_void_p(), C.c_void_p()
+    lib.lamp_scaled_dot_product_attention(C.byref(o), C.byref(l), to_sten(q), to_sten(k), to_sten(v), int(causal), 0.0)
+    Ot, Lt = S.STen(o), S.STen(l)
+    out3 = (C.c_void_p * 3)()
+    lib.lamp_scaled_dot_product_attention_backward(out3, to_sten(go), to_sten(q), to_sten(k), to_sten(v), Ot, Lt, int(causal), 0.0)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    assert b"sdpa_small_fwd" in buf.value and b"sdpa_small_bwd" in buf.value, "the short-sequence kernels did not run"
+    assert_close(to_torch(Ot), ref.detach(), 1e-2, "attention output")
+    assert_close(to_torch(Lt), lse_ref.detach(), 1e-5, "logsumexp")
+    for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
+        assert_close(to_torch(S.STen(h)), r, 1e-2, name)
+
+
 def test_umap_skip_self_equals_masked_pairs(gpu):
     """lamp_umap_loss_grad_skip_self folds `mask = i.ne(j); i.maskedSelect(mask); j.maskedSelect(mask)` (umap.scala:221-227) into
     the kernel: same loss and gradient as the explicit compaction, for 2-D (lane-pair kernel) and 3-D (generic kernel) layouts."""
