@@ -72,21 +72,26 @@ __device__ __forceinline__ void sa_store16(bf16_t* dst, const float (&acc)[16]) 
 __device__ __forceinline__ float sa_group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float sa_group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
 
+// LDS per wavefront bounds the resident waves (160 KB per CU): forward 7.2 KB -> 20 waves, backward 9.3 KB -> 16 waves
+struct SaLdsFwd {
+  uint4 q[SA_S * 8], k[SA_S * 8], v[SA_S * 8];                // [S][64] bf16 images
+  float p[SA_S][SA_S + 1];
+};
 struct SaLds {
   uint4 q[SA_S * 8], k[SA_S * 8], v[SA_S * 8], g[SA_S * 8];   // [S][64] bf16 images (g = dout)
-  float p[SA_S][SA_S + 1], ds[SA_S][SA_S + 1];
+  float p[SA_S][SA_S + 1];                                     // P, then dS
 };
 }  // namespace
 
 __global__ __launch_bounds__(64 * SA_WAVES) void sdpa_small_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int64_t nprob, int S, float scale,
                                                                       int causal) {
-  __shared__ SaLds lds[SA_WAVES];
+  __shared__ SaLdsFwd lds[SA_WAVES];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t prob = (int64_t)blockIdx.x * SA_WAVES + wid;
   const bool live = prob < nprob;
   const int64_t base = (live ? prob : 0) * S * SA_D;
-  SaLds& L = lds[wid];
+  SaLdsFwd& L = lds[wid];
   const int i = lane & 15, g = lane >> 4;
   if (live) {
     sa_stage(Q + base, L.q, S, lane);
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(64 * SA_WAVES) void sdpa_small_bwd_kernel(const bf1
   unsigned qa[32], ga[32];
   sa_load_row(L.q + (row ? i : 0) * 8, qa);
   sa_load_row(L.g + (row ? i : 0) * 8, ga);
+  float dsv[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int j = g + 4 * c;
@@ -169,26 +175,33 @@ __global__ __launch_bounds__(64 * SA_WAVES) void sdpa_small_bwd_kernel(const bf1
       ds = p * (sa_dot(ga, L.v + j * 8) - Di) * scale;
     }
     L.p[i][j] = p;
-    L.ds[i][j] = ds;
+    dsv[c] = ds;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float acc[16];
-  // dQ[i] = sum_j dS[i][j] K[j]
-#pragma unroll
-  for (int t = 0; t < 16; t++) acc[t] = 0.f;
-  for (int j = 0; j < S; j++) sa_axpy16(acc, L.ds[i][j], L.k + j * 8, g);
-  if (row) sa_store16(dQ + base + (int64_t)i * SA_D + g * 16, acc);
-  // dK[j] = sum_i dS[i][j] Q[i]   (this lane: key j = lane & 15)
-#pragma unroll
-  for (int t = 0; t < 16; t++) acc[t] = 0.f;
-  for (int r = 0; r < S; r++) sa_axpy16(acc, L.ds[r][i], L.q + r * 8, g);
-  if (row) sa_store16(dK + base + (int64_t)i * SA_D + g * 16, acc);
-  // dV[j] = sum_i P[i][j] dO[i]
+  // dV[j] = sum_i P[i][j] dO[i]   (this lane: key j = lane & 15)
 #pragma unroll
   for (int t = 0; t < 16; t++) acc[t] = 0.f;
   for (int r = 0; r < S; r++) sa_axpy16(acc, L.p[r][i], L.g + r * 8, g);
   if (row) sa_store16(dV + base + (int64_t)i * SA_D + g * 16, acc);
+  // the block now holds dS
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < 4; c++) L.p[i][g + 4 * c] = dsv[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // dQ[i] = sum_j dS[i][j] K[j]
+#pragma unroll
+  for (int t = 0; t < 16; t++) acc[t] = 0.f;
+  for (int j = 0; j < S; j++) sa_axpy16(acc, L.p[i][j], L.k + j * 8, g);
+  if (row) sa_store16(dQ + base + (int64_t)i * SA_D + g * 16, acc);
+  // dK[j] = sum_i dS[i][j] Q[i]
+#pragma unroll
+  for (int t = 0; t < 16; t++) acc[t] = 0.f;
+  for (int r = 0; r < S; r++) sa_axpy16(acc, L.p[r][i], L.q + r * 8, g);
+  if (row) sa_store16(dK + base + (int64_t)i * SA_D + g * 16, acc);
 }
 
 static bool small_attention_enabled() {
