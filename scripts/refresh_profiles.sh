@@ -23,5 +23,5 @@ cd $R
 python scripts/umap_full_probe.py 1000000 40 2>&1 | grep "umap n" > $O/umap_probe.txt
 python scripts/gemm_ab.py > $O/gemm_ab.txt 2>&1 || true
 python scripts/tf_ops_probe.py > $O/tf_ops_probe.txt 2>&1 || true
-python scripts/kstats_top.py /tmp/ks_lm 40 5 > $O/lm_kernels.txt 2>&1 || true
+python scripts/kstats_top.py /tmp/ks_lm 40 6 > $O/lm_kernels.txt 2>&1 || true
 cat $O/pytest_gpu.txt; tail -c 600 $O/bench.log; cat $O/pmc_traffic.txt | head -12; cat $O/umap_probe.txt
