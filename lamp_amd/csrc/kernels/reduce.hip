@@ -137,21 +137,25 @@ __global__ __launch_bounds__(256) void reduce_column_vec_kernel(const T* __restr
   }
 }
 
-// finalize of many partials: 64 outputs x 4 split lanes per workgroup
+// finalize of many partials: 16 outputs x 16 split lanes per workgroup, lanes combined through LDS in a fixed order
 template <class T, int OP>
 __global__ __launch_bounds__(256) void reduce_finalize_wide_kernel(const acc_t<T>* __restrict__ partial, T* __restrict__ out, int64_t nout, int64_t nsplit,
                                                                    double scale, int do_sqrt) {
   using A = acc_t<T>;
-  __shared__ A sm[4][64];
-  const int oc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int64_t o = (int64_t)blockIdx.x * 64 + oc;
+  __shared__ A sm[16][17];
+  const int oc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t o = (int64_t)blockIdx.x * 16 + oc;
   A r = r_init<OP, A>();
-  if (o < nout)
-    for (int64_t s = sl; s < nsplit; s += 4) r = r_comb<OP, A>(r, partial[s * nout + o]);
+  if (o < nout) {
+#pragma unroll 4
+    for (int64_t s = sl; s < nsplit; s += 16) r = r_comb<OP, A>(r, partial[s * nout + o]);
+  }
   sm[sl][oc] = r;
   __syncthreads();
   if (sl == 0 && o < nout) {
-    r = r_comb<OP, A>(r_comb<OP, A>(sm[0][oc], sm[1][oc]), r_comb<OP, A>(sm[2][oc], sm[3][oc]));
+    r = sm[0][oc];
+#pragma unroll
+    for (int l = 1; l < 16; l++) r = r_comb<OP, A>(r, sm[l][oc]);
     if (OP == kSum || OP == kSumSq) r = (A)(r * (A)scale);
     if (do_sqrt) r = (A)sqrt((double)r);
     out[o] = store_as<T>(r);
@@ -287,7 +291,7 @@ static void reduce_typed(const Tensor* ac, Tensor* out, const DimPlan& p, double
   }
   LAMP_LAUNCH_CHECK();
   if (nsplit >= 16 && nout < 65536)
-    hipLaunchKernelGGL((reduce_finalize_wide_kernel<T, OP>), dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
+    hipLaunchKernelGGL((reduce_finalize_wide_kernel<T, OP>), dim3((unsigned)((nout + 15) / 16)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
                        nout, nsplit, scale, do_sqrt);
   else
     hipLaunchKernelGGL((reduce_finalize_kernel<T, OP>), dim3(grid_for(nout, 256)), dim3(256), 0, st, partial->ptr<A>(), out->ptr<T>(),
