@@ -18,6 +18,7 @@
 // f32 : v_mfma_f32_16x16x4_f32 - exact f32 FMA chain (no tf32 on gfx950), parity <= 1e-5.
 // f64 : v_mfma_f64_16x16x4_f64 (the reference's own tests run in double).
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -954,6 +955,8 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
   }
   KernelTimer kt(kt_tag, g_flops, g_bytes, stm);
   if (a->dtype == kBF16) {
+    const int out_device = out->device();
+    std::function<void(GemmArgs)> run = [&](GemmArgs g) {
     const bool akc = (g.a_cs == 1), bkc = (g.b_rs == 1);
     LAMP_CHECK(akc || g.a_rs == 1, "internal: A has no unit stride");
     LAMP_CHECK(bkc || g.b_cs == 1, "internal: B has no unit stride");
@@ -967,7 +970,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     const bool big2 = big && g.N % QN == 0 && (g.M / QM) * (g.N / QN) * g.batch >= 200;
     // few output tiles over a long K (the weight gradients x^T . p of a token batch): split K over blockIdx.z
     static const bool allow_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
-    if (allow_split && !big2 && g.batch == 1 && g.a_vec && g.b_vec && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 2048) {
+    if (allow_split && !big2 && g.batch == 1 && g.a_vec && g.b_vec && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 512) {
       const int64_t tiles = (g.M / QM) * (g.N / QN), nk_total = g.K / PK;
       // one workgroup per CU.  Cost of a split d in us: rounds x k-steps per chunk x ~1.7 us (one 256 x 256 x 64 stage at the
       // kernel's ~4.9 TFLOP/s per CU) + writing and re-reading d f32 slices at ~4 TB/s
@@ -984,7 +987,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
         if (c < best * 0.97) { best = c; split = (int)d; }
       }
       if (split > 1 && tiles * split >= 64) {
-        Hold ws(new_tensor({(int64_t)split, g.M, g.N}, kF32, out->device()));
+        Hold ws(new_tensor({(int64_t)split, g.M, g.N}, kF32, out_device));
         GemmArgs h = g;
         h.K = g.K / split;
         h.a_bs = h.K * g.a_cs; h.b_bs = h.K * g.b_rs;
@@ -1056,6 +1059,32 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     else if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), lds, stm, g);
     else if (!akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), lds, stm, g);
     else hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), lds, stm, g);
+    LAMP_LAUNCH_CHECK();
+    };
+    // The 256 x 256 kernel runs one workgroup per CU, so a tile count just above a multiple of the CU count costs a whole extra round
+    // (288 tiles: 155 us, 255 tiles: 101 us at K = 3072).  When the last round would be less than a quarter full, the rows of that
+    // remainder become a second product, which the split-K path spreads over the idle CUs.
+    static const bool tail_split = !(getenv("LAMP_GEMM_TAIL_SPLIT") && atoi(getenv("LAMP_GEMM_TAIL_SPLIT")) == 0);
+    const int64_t cus = num_cus();
+    if (tail_split && g.batch == 1 && !g.knn_q && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 2048) {   // shorter K: the second launch costs more than the round
+      const int64_t tn = g.N / QN, t2 = (g.M / QM) * tn, rem = t2 % cus;
+      if (t2 > cus && rem > 0 && rem * 4 <= cus) {
+        const int64_t rem_rows = (rem + tn - 1) / tn, M2 = rem_rows * QM, M1 = g.M - M2;
+        if (M1 > 0 && (M1 / QM) * tn >= 200) {
+          GemmArgs g1 = g, g2 = g;
+          g1.M = M1;
+          g2.M = M2;
+          g2.A = (const char*)g.A + M1 * g.a_rs * (int64_t)sizeof(bf16_t);
+          g2.C = (char*)g.C + M1 * g.ldc * (int64_t)sizeof(bf16_t);
+          if (g.S) g2.S = (const char*)g.S + M1 * g.s_rs * (int64_t)sizeof(bf16_t);
+          run(g1);
+          run(g2);
+          return;
+        }
+      }
+    }
+    run(g);
+    return;
   } else if (a->dtype == kF32 || a->dtype == kF64) {
     g.tiles_m = (int)((g.M + FM - 1) / FM);
     g.tiles_n = (int)((g.N + FN - 1) / FN);

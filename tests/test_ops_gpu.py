@@ -212,10 +212,11 @@ def test_gemm_256_tile_all_layouts(gpu, K):
     assert_close(to_torch(S.STen(o)), ref + bias.double(), 3.2e-2, "linear_bias")
 
 
-@pytest.mark.parametrize("M,N,K", [(768, 768, 12288), (256, 768, 6144), (768, 3072, 4096), (512, 256, 2048)])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 12288), (256, 768, 6144), (768, 3072, 4096), (512, 256, 2048), (24576, 768, 2048), (22016, 768, 768)])
 def test_gemm_split_k(gpu, M, N, K):
     """few output tiles over a long K (weight gradients of a token batch): K split over blockIdx.z, f32 slices summed by the reduce
-    kernel - all operand layouts, beta operand, and the same answer as the unsplit kernel up to bf16 rounding of one result"""
+    kernel - all operand layouts, beta operand, and the same answer as the unsplit kernel up to bf16 rounding of one result.  The two
+    tall shapes are 288 / 258 tiles of 256 x 256: the rows of the nearly empty last round run as a second, K-split product."""
     dt = torch.bfloat16
     xt, p = closed_form((K, M), 3, 2.0, dt), closed_form((K, N), 9, 2.0, dt)
     ref = xt.double().t() @ p.double()
