@@ -209,6 +209,9 @@ int lamp_div_(lamp_tensor* self, const lamp_tensor* b);                  /* /= *
 int lamp_add_scalar_(lamp_tensor* self, double b, double alpha);
 int lamp_mul_scalar_(lamp_tensor* self, double b);
 int lamp_addcmul_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value);
+/* a * b + c in one pass, the product rounded to the tensor type before the addition: the values of lamp's chain `(a * b) + c`
+ * (Transformer.scala:244-247: attention * scale + input) */
+int lamp_mul_add(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, const lamp_tensor* c);
 int lamp_addcdiv_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value);
 int lamp_maximum(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);   /* max_2, knn/package.scala:28 */
 int lamp_minimum(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);

@@ -166,6 +166,24 @@ Var mult(const Var& a, const Var& b) {
   }});
   return make_result(op, ops::mul(a->value, b->value));
 }
+// (a * b) + c as one kernel with the values of the two-operator chain; the closures are Mult's and Add's
+Var mult_add(const Var& a, const Var& b, const Var& c) {
+  auto op = new_op("MultAdd");
+  auto as = a->shape(), bs = b->shape(), cs = c->shape();
+  Ten av = a->value, bv = b->value;
+  op->params.push_back({a, [as, bv](const Ten& p, Variable& out) {
+    Ten t = ops::mul(p, bv);
+    out.accumulate(t.shape() == as ? t : ops::unbroadcast(t, as), true);
+  }});
+  op->params.push_back({b, [bs, av](const Ten& p, Variable& out) {
+    Ten t = ops::mul(p, av);
+    out.accumulate(t.shape() == bs ? t : ops::unbroadcast(t, bs), true);
+  }});
+  op->params.push_back({c, [cs](const Ten& p, Variable& out) { out.accumulate(p.shape() == cs ? p : ops::unbroadcast(p, cs), p.shape() != cs); }});
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_mul_add(&o, av.h(), bv.h(), c->value.h()));
+  return make_result(op, Ten(o));
+}
 Var div(const Var& a, const Var& b) {
   auto op = new_op("Div");
   auto as = a->shape(), bs = b->shape();

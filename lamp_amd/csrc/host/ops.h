@@ -16,6 +16,7 @@ Var const_add(const Var& a, double b);
 Var minus(const Var& a, const Var& b);
 Var const_mult(const Var& a, double b);
 Var mult(const Var& a, const Var& b);
+Var mult_add(const Var& a, const Var& b, const Var& c);   // (a * b) + c in one launch, values of the chain
 Var div(const Var& a, const Var& b);
 Var sum(const Var& a, const std::vector<int64_t>& dim = {}, bool keepDim = false);
 Var mean(const Var& a, const std::vector<int64_t>& dim, bool keepDim = true);

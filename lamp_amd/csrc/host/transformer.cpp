@@ -25,6 +25,12 @@ Var mm1_bias(const Var& a, const Var& w, const Var& b) {
   shape.back() = -1;
   return F::view(F::linear_bias(a2, w, b), shape);
 }
+// x * scale + residual (Transformer.scala:244-247) in one pass with the values of the chain
+Var mult_add(const Var& x, const Var& scale, const Var& residual) {
+  static const bool fused = !(getenv("LAMP_MULT_ADD_FUSED") && atoi(getenv("LAMP_MULT_ADD_FUSED")) == 0);
+  if (!fused || x->value.dtype() != scale->value.dtype() || x->value.dtype() != residual->value.dtype()) return F::add(F::mult(x, scale), residual);
+  return F::mult_add(x, scale, residual);
+}
 Ten arange_like(int64_t start, int64_t end, const Ten& options) {
   lamp_tensor* o = nullptr;
   HCALL(lamp_arange(&o, (double)start, (double)end, 1.0, options.dtype(), options.device()));
@@ -186,9 +192,9 @@ void TransformerEncoderBlock::collect_state(std::vector<Var>& o) {   // :227-235
 Var TransformerEncoderBlock::block(const Var& input, const Ten& maxLength) {   // :237-258
   if (gptOrder) {
     Var a1 = layerNorm1->forward(F::dropout(input, dropout, train));
-    Var a2 = F::add(F::mult(attention->attend(a1, a1, a1, maxLength), scale1), input);
+    Var a2 = mult_add(attention->attend(a1, a1, a1, maxLength), scale1, input);
     Var a3 = layerNorm2->forward(F::dropout(a2, dropout, train));
-    Var a4 = F::add(F::mult(mm1_bias(F::gelu(mm1_bias(a3, w1, b1)), w2, b2), scale2), a2);
+    Var a4 = mult_add(mm1_bias(F::gelu(mm1_bias(a3, w1, b1)), w2, b2), scale2, a2);
     return a4;
   }
   Var a1 = attention->attend(input, input, input, maxLength);

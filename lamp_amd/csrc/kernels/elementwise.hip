@@ -209,6 +209,15 @@ struct FPowS {
   }
 };
 FUNCTOR_BEGIN(FAddcmul) return store_as<TO>((A)(a + (A)p0 * b * c)); FUNCTOR_END
+// (a * b) + c with the product rounded to the tensor type first: bit for bit the chain Mult then Add (no fma contraction)
+struct FMulAdd {
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+#pragma clang fp contract(off)
+    const A prod = load_as<A>(store_as<TO>((A)(a * b)));
+    return store_as<TO>((A)(prod + c));
+  }
+};
 FUNCTOR_BEGIN(FAddcdiv) return store_as<TO>((A)(a + (A)p0 * b / c)); FUNCTOR_END
 // out(a) += p(b) * (x(c) < 0 ? slope : 1)      ops.scala:918-953
 FUNCTOR_BEGIN(FReluBwdAcc) return store_as<TO>((A)(a + b * ((c < A(0)) ? (A)p0 : A(1)))); FUNCTOR_END
@@ -426,6 +435,9 @@ int lamp_mul_scalar_(lamp_tensor* self, double b) {
 }
 int lamp_addcmul_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value) {
   LAMP_API_BEGIN run_same<3, FAddcmul, false>(out, self, t1, t2, FAddcmul{value, 0}); LAMP_API_END
+}
+int lamp_mul_add(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, const lamp_tensor* c) {
+  LAMP_API_BEGIN *out = run_same<3, FMulAdd, true>(nullptr, a, b, c, FMulAdd{}); LAMP_API_END
 }
 int lamp_addcdiv_out(lamp_tensor* out, const lamp_tensor* self, const lamp_tensor* t1, const lamp_tensor* t2, double value) {
   LAMP_API_BEGIN run_same<3, FAddcdiv, true>(out, self, t1, t2, FAddcdiv{value, 0}); LAMP_API_END

@@ -246,6 +246,17 @@ def test_linear_bias_is_bitwise_the_mm_add_chain(gpu, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_mul_add_is_bitwise_the_mult_add_chain(gpu, dt):
+    """lamp_mul_add = (a * b) + c with the product rounded first: bit for bit the two elementwise operators it replaces (dense,
+    row-vector broadcast and scalar operands)"""
+    a, c = closed_form((96, 136), 1, 3.0, dt), closed_form((96, 136), 2, 3.0, dt)
+    for b in (closed_form((136,), 3, 2.0, dt), closed_form((96, 136), 4, 2.0, dt), closed_form((1,), 5, 2.0, dt)):
+        A, B, Cc = to_sten(a), to_sten(b), to_sten(c)
+        o = C.c_void_p(); lib.lamp_mul_add(C.byref(o), A, B, Cc)
+        assert np.array_equal(S.STen(o).to_numpy(), ((A * B) + Cc).to_numpy())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_bmm_family(gpu, dt):
     a, b = closed_form((3, 33, 65), 1, 2.0, dt), closed_form((3, 65, 17), 5, 2.0, dt)
     A, B = to_sten(a), to_sten(b)
