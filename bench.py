@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - training-step throughput of the lamp hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU.  Started under a launcher (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this process IS one rank.  Started bare, it spawns the N rank processes itself BEFORE anything touches the GPU, forwards
+rank 0's line and exits non-zero unless all N ranks joined ONE RCCL communicator (`rccl_ranks` in the line = ncclCommCount).
 
 A "step" is one pass of the hot path over one synthetic batch: Cnn.resnet(100) forward + backprop +
 AdamW on a device-resident batch of B = 2048 CIFAR-shaped images per GPU (BASELINE.json config 3/4;
@@ -39,7 +43,48 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
+    ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous of the N ranks only (no GPU work): prints {\"dry_launch\": true, \"ranks\": N}")
+    ap.add_argument("--min-window-s", type=float, default=0.5, help="repeat the K-step timed window until this much time is covered; the median window is reported")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """bare `python bench.py --gpus N`: become the launcher.  N children (fresh interpreters, this process never initialises HIP), one
+    per GPU, with the environment a torch.distributed.run launch would give them; rank 0's stdout is forwarded.  Exit code 0 only if
+    every rank exits 0."""
+    import socket
+    import tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    rdzv = os.path.join(tempfile.gettempdir(), f"lamp_rdzv_{os.getpid()}_{port}.json")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LAMP_RDZV_FILE=rdzv, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0:
+                    rc = rc or code or 1
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for o in alive:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+        try:
+            os.unlink(rdzv)
+        except OSError:
+            pass
+    return rc
 
 
 def closed_form_np(n, salt=0, scale=1.0):
@@ -74,35 +119,55 @@ def pmc_traffic(tag):
     return cls["traffic_bytes"], os.path.relpath(files[-1], ROOT)
 
 
-def roofline_of(rows, bracket_ms=0.0):
-    """roofline object for the kernel class that took the most time (the only class timed in the timed region)."""
+def roofline_of(rows):
+    """roofline object for the kernel class that took the most time.  avg_us is the plain HIP-event bracket around every launch of
+    the class (recorded on the launch's own stream in an UNTIMED pass after the timed region); nothing is subtracted: an (event,
+    kernel, event) bracket reads 1 - 2 us longer than the rocprofv3 kernel trace of the same launch, so `frac` errs low."""
     if not rows:
         return None
     d = max(rows, key=lambda r: r["total_ms"])
     avg_s = d["total_ms"] / d["launches"] / 1e3
-    extra = {"kernel": d["tag"], "launches": d["launches"], "avg_us": avg_s * 1e6,
-             "avg_us_event_raw": d.get("raw_total_ms", d["total_ms"]) / d["launches"] * 1e3, "event_bracket_us": bracket_ms * 1e3}
+    extra = {"kernel": d["tag"], "launches": d["launches"], "avg_us": avg_s * 1e6, "timing": "hip events per launch, untimed pass, uncorrected"}
     traffic = pmc_traffic(d["tag"])
     if traffic is not None:
         extra["traffic_source"] = traffic[1]
-        extra["algorithmic_bytes"] = d["bytes"]
+    flops, byts = d["flops"], d["bytes"]            # per launch (lamp_kernel_timer_report averages the launchers' declarations)
+    extra["algorithmic_bytes"] = byts
+    extra["algorithmic_flops"] = flops
     traffic = traffic[0] if traffic is not None else None
-    ai = d["flops"] / max(d["bytes"], 1.0)
-    if d["flops"] > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
+    ai = flops / max(byts, 1.0)
+    if flops > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
         peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_BF16_TFLOPS
-        ach = d["flops"] / avg_s / 1e12
+        ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **extra}
-    ach = d["bytes"] / avg_s / 1e9
+    ach = byts / avg_s / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic, **extra}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))             # launcher: never touches the GPU itself
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    if a.dry_launch:
+        # the launch + rendezvous path without a GPU: every rank joins the control plane, receives rank 0's 128 id bytes, and the
+        # collectives the timing protocol uses (barrier, max over ranks) run once
+        from lamp_amd import distributed as D
+        cp = D.init_control_plane(timeout=60.0)
+        uid = D.exchange_unique_id(cp, lambda: bytes((7 * i + 1) % 256 for i in range(128)))
+        assert uid == bytes((7 * i + 1) % 256 for i in range(128))
+        ranks = cp.all_gather(rank)
+        slowest = cp.all_reduce_max(float(rank))
+        cp.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "ranks": len(ranks), "rank_list": ranks, "max_rank": slowest, "n_gpus": a.gpus}))
+        cp.close()
+        return
 
     # CPU baseline first, in a child process, on rank 0 at N = 1 only (before this process touches the GPU)
     cpu_baseline = None
@@ -115,20 +180,28 @@ def main():
         except Exception as e:  # the baseline is informative; never fail the GPU measurement because of it
             cpu_baseline = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
-    from lamp_amd._capi import lib          # HIP library before torch (binds the system ROCm runtime)
+    from lamp_amd._capi import lib
     lib.load()
+    ngpu = C.c_int(0)
+    lib.lamp_get_num_gpus(C.byref(ngpu))
+    if local_rank >= ngpu.value:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ngpu.value} GPU(s)")
     lib.lamp_set_device(local_rank)
     from lamp_amd import nn, sten as S
     import numpy as np
 
     dist = None
     comm = None
-    # LAMP_BENCH_FORCE_COMM=1 (under torch.distributed.run with one process) drives the complete multi-rank code path -
-    # gloo control plane, unique-id exchange, RCCL communicator, two-bucket overlapped exchange - on a single GPU
+    rccl_ranks = 1
+    # LAMP_BENCH_FORCE_COMM=1 (with RANK=0 WORLD_SIZE=1 in the environment) drives the complete multi-rank code path - control plane,
+    # unique-id exchange, RCCL communicator, two-bucket overlapped exchange - on a single GPU
     if world > 1 or (os.environ.get("LAMP_BENCH_FORCE_COMM") == "1" and "RANK" in os.environ):
         from lamp_amd import distributed as D
-        dist = D.init_control_plane()            # gloo: control plane only (unique id, barrier, max of times)
+        dist = D.init_control_plane()            # TCP control plane: unique id, barrier, max of times - no tensor library
         comm = D.rccl_communicator(dist)         # RCCL communicator: the data plane over xGMI
+        rccl_ranks = D.comm_count(comm)
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks, --gpus says {a.gpus}: refusing to report")
 
     def barrier():
         lib.lamp_device_synchronize()
@@ -277,7 +350,32 @@ def main():
         config["hip_graph"] = "forward + backprop captured, optimiser eager"
     for _ in range(a.warmup):
         step()
-    # untimed classification pass: every tagged launch bracketed by HIP events -> per-class table and the dominant class
+    # ---- timed region: EXACTLY K steps between barrier + device synchronize on both sides, no instrumentation inside (kernel timers
+    # off).  A K-step window shorter than --min-window-s is repeated and the MEDIAN window reported (every window is a complete
+    # measurement by the contract; 20 ResNet steps are 30 ms, which one scheduling hiccup of the host distorts).
+    lib.lamp_kernel_timer_enable(0)
+    windows, enqueues = [], []
+    total = 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        enq = time.perf_counter() - t0            # host time to issue the steps (the device may still be running)
+        barrier()
+        w = time.perf_counter() - t0
+        if dist is not None:
+            w = dist.all_reduce_max(w)             # MAX over ranks; the same value on every rank, so all ranks stop together
+        windows.append(w); enqueues.append(enq)
+        total += w
+        if total >= a.min_window_s or len(windows) >= 200:
+            break
+    order = sorted(range(len(windows)), key=lambda k: windows[k])
+    mid = order[len(order) // 2]
+    elapsed, enqueue = windows[mid], enqueues[mid]
+
+    # ---- untimed passes for the roofline object (after the measurement, so they cannot disturb it)
+    # 1. classification: every tagged launch bracketed by HIP events (on the stream it is launched on) -> per-class table
     PROFILE_STEPS = 2
     barrier()
     lib.lamp_kernel_timer_filter(None)
@@ -287,45 +385,29 @@ def main():
     barrier()
     lib.lamp_kernel_timer_enable(0)
     class_rows = kernel_report(lib)
-    # an (event, kernel, event) bracket costs a few us of packet processing that the kernel itself does not:
-    # calibrate it with an empty kernel and take it off every timed launch (rocprofv3 kernel traces agree with
-    # the corrected figure, see profiles/)
-    cal = C.c_double(0.0)
-    lib.lamp_kernel_timer_calibrate(C.byref(cal))
-    bracket_ms = cal.value / 1e3
-    for r in class_rows:
-        r["raw_total_ms"] = r["total_ms"]
-        r["total_ms"] = max(r["total_ms"] - r["launches"] * bracket_ms, 0.05 * r["total_ms"])
     dominant = max(class_rows, key=lambda r: r["total_ms"])["tag"] if class_rows else None
-    # timed region: only the dominant class carries events (two per launch), so the step time is not inflated by the
-    # instrumentation of the other ~200 launches
-    lib.lamp_kernel_timer_filter(dominant.encode() if dominant else None)
-    barrier()
-    lib.lamp_kernel_timer_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    enqueue = time.perf_counter() - t0        # host time to issue the steps (the device may still be running)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.lamp_kernel_timer_enable(0)
-    lib.lamp_kernel_timer_filter(None)
-    rows = kernel_report(lib)
-    for r in rows:
-        r["raw_total_ms"] = r["total_ms"]
-        r["total_ms"] = max(r["total_ms"] - r["launches"] * bracket_ms, 0.05 * r["total_ms"])
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    # 2. the dominant class alone (events on ~10 launches per step instead of ~100: the kernels around it run as in the timed region)
+    rows = []
+    if dominant:
+        lib.lamp_kernel_timer_filter(dominant.encode())
+        lib.lamp_kernel_timer_enable(1)
+        for _ in range(max(PROFILE_STEPS, min(a.steps, 10))):
+            step()
+        barrier()
+        lib.lamp_kernel_timer_enable(0)
+        lib.lamp_kernel_timer_filter(None)
+        rows = kernel_report(lib)
 
     if rank == 0:
         value = units_per_step * a.gpus * a.steps / elapsed
-        roof = roofline_of(rows, bracket_ms)
+        roof = roofline_of(rows)
         line = {"metric": metric, "value": value, "unit": unit, "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": a.dtype, "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu_baseline}
+                "dtype": a.dtype, "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu_baseline,
+                "rccl_ranks": rccl_ranks,
+                "timed_windows": {"count": len(windows), "steps_each": a.steps, "reported": "median",
+                                  "min_ms_per_step": min(windows) / a.steps * 1e3, "max_ms_per_step": max(windows) / a.steps * 1e3}}
+        line.update(result_extra)
         if a.workload == "resnet":
             # whole-step figures against SURVEY.md 8(d): 153.3 MFLOP and ~1.4 MB algorithmic HBM bytes per sample per step
             per_gpu = value / a.gpus
@@ -335,11 +417,12 @@ def main():
         top = sorted(class_rows, key=lambda r: -r["total_ms"])[:int(os.environ.get("LAMP_BENCH_TOP", "10"))]
         line["kernel_classes"] = [{"tag": r["tag"], "launches_per_step": r["launches"] / PROFILE_STEPS, "ms_per_step": r["total_ms"] / PROFILE_STEPS}
                                   for r in top]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if comm is not None:
         lib.lamp_comm_destroy(comm)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.close()
 
 
 if __name__ == "__main__":

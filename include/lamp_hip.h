@@ -80,6 +80,10 @@ int lamp_stream_set_current(lamp_stream* s);                     /* setCurrentCU
 int lamp_stream_synchronize(lamp_stream* s);
 int lamp_stream_wait_stream(lamp_stream* waiter, lamp_stream* on); /* event record + wait */
 int lamp_stream_release(lamp_stream* s);
+/* the tensor's storage is also used by work on `s` (NULL = the caller's current stream): the caching allocator will not hand the
+ * block out again before that work is done.  Needed whenever a tensor allocated under one current stream is consumed under another
+ * (Device.withOtherStream, device.scala:199-213). */
+int lamp_tensor_record_stream(const lamp_tensor* t, lamp_stream* s_or_null);
 int lamp_stream_native(lamp_stream* s, void** hip_stream_out);
 /* RNG (aten.Tensor.manual_seed*, device.scala:149,170,215; umap.scala:180) */
 int lamp_manual_seed(uint64_t seed);
@@ -111,6 +115,8 @@ int lamp_graph_release(lamp_graph* g);
 int lamp_live_tensor_count(int64_t* out);
 int lamp_allocator_stats(int device, int64_t* reserved_bytes, int64_t* in_use_bytes, int64_t* n_device_mallocs);
 int lamp_allocator_trim(int device);
+/* how many frees had to wait for another stream (record_stream'ed blocks) since start-up */
+int lamp_allocator_deferred_frees(int device, int64_t* out);
 
 /* ------------------------------------------------------------------------------------------
  * tensor handles, metadata, host <-> device   (aten.Tensor instance methods used by
@@ -203,6 +209,9 @@ int lamp_sub_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b, d
 int lamp_mul_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
 int lamp_div_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b);
 int lamp_add_(lamp_tensor* self, const lamp_tensor* b, double alpha);    /* += */
+/* acc += scale * x for acc and x of different floating types (sum taken in f64): lamp's loss accumulators are f64 scalars
+ * whatever the model type (IOLoops.scala:715 `STen.scalarDouble(0, options)`, SupervisedModel.scala:207) */
+int lamp_add_scaled_mixed_(lamp_tensor* acc, const lamp_tensor* x, double scale);
 int lamp_sub_(lamp_tensor* self, const lamp_tensor* b, double alpha);    /* -= */
 int lamp_mul_(lamp_tensor* self, const lamp_tensor* b);                  /* *= */
 int lamp_div_(lamp_tensor* self, const lamp_tensor* b);                  /* /= */
@@ -517,9 +526,13 @@ int lamp_umap_loss_grad_sharded(lamp_tensor** loss, lamp_tensor* grad_accum, con
 int lamp_comm_get_unique_id(uint8_t* id_out /* LAMP_UNIQUE_ID_BYTES */);
 int lamp_comm_init_rank(lamp_comm** out, int nranks, const uint8_t* id, int rank);
 int lamp_comm_broadcast(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int root);
-int lamp_comm_reduce(lamp_tensor* const* inputs, lamp_tensor* output, int root, int op /* 0 = sum */,
+int lamp_comm_reduce(lamp_tensor* const* inputs, lamp_tensor* output, int root, int op /* ncclRedOp_t: 0 sum, 1 prod, 2 max, 3 min */,
                      lamp_comm* const* comms, int n);
 int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int op);
+/* ncclCommCount / ncclCommUserRank: what RCCL itself says about the clique (bench.py prints rccl_ranks from this and refuses
+ * to report an N-GPU figure unless it equals N) */
+int lamp_comm_count(const lamp_comm* c, int* nranks_out);
+int lamp_comm_user_rank(const lamp_comm* c, int* rank_out);
 /* out = concatenation over ranks of `in` (ncclAllGather): the exchange step of row-sharded work, e.g. the kNN graph whose
  * query rows are split over the ranks (lamp-knn has no multi-GPU form) */
 int lamp_comm_all_gather(lamp_tensor* out, const lamp_tensor* in, lamp_comm* comm);

@@ -130,6 +130,13 @@ int lamp_model_forward_loss(lamp_model* m, const lamp_tensor* samples, const lam
  * (lamp-data/.../IOLoops.scala:621-658) or distributed oneBatch (distributed/package.scala:733-759) */
 int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm_or_null, const lamp_tensor* samples, const lamp_tensor* target,
                           lamp_tensor* acc_or_null, int64_t* num_examples);
+/* the same with the learning-rate schedule factor of the epoch (IOLoops.scala:621-658 `learningRateScheduleFactor`) */
+int lamp_model_train_step_scheduled(lamp_model* m, lamp_optimizer* o, lamp_comm* comm_or_null, const lamp_tensor* samples,
+                                    const lamp_tensor* target, lamp_tensor* acc_or_null, double schedule_factor, int64_t* num_examples);
+/* broadcast of module.state (parameters and batch-norm running statistics) and the optimiser state from `root` to every rank
+ * (distributed/package.scala:683-688).  lamp_model_train_step does it by itself before the first step over a communicator; call it
+ * again before validation / checkpoints to make rank `root`'s non-parameter state the state of every rank. */
+int lamp_model_sync_state(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, int root);
 /* Single-process data parallel, DataParallel.driveSynchronousLoop's `synchronousStep` (lamp-data DataParallel.scala:195-311): the main
  * model (with the optimiser) and `nreplicas` replicas on other GPUs; arrays of nreplicas + 1 entries, main first.  Copies the main
  * state to the replicas, computes every model's gradients on its own host thread, and - when `step` - averages the gradients weighted

@@ -39,10 +39,23 @@ ncclDataType_t nccl_type(int dt) {
   }
   throw lamp::Error(std::string("dtype not supported by RCCL: ") + lamp::dtype_name(dt));
 }
-ncclRedOp_t nccl_op(int op) {
-  LAMP_CHECK(op == 0, "only op 0 (sum) is used by lamp and supported here, got " << op);
-  return ncclSum;
+ncclRedOp_t nccl_op(int op) {   // ncclRedOp_t numbering, which is what aten.NcclComm.reduce passes through (lamp itself only uses 0)
+  switch (op) {
+    case 0: return ncclSum;
+    case 1: return ncclProd;
+    case 2: return ncclMax;
+    case 3: return ncclMin;
+  }
+  throw lamp::Error("reduction op " + std::to_string(op) + " is not one of 0 sum / 1 prod / 2 max / 3 min");
 }
+// ncclGroupStart / ncclGroupEnd as a scope: an error thrown between the two must not leave the group open (every later RCCL call
+// of the thread would queue into it for ever)
+struct GroupGuard {
+  bool open = false;
+  explicit GroupGuard(int n) { if (n > 1) { NCCL_CHECK(ncclGroupStart()); open = true; } }
+  void end() { if (open) { open = false; NCCL_CHECK(ncclGroupEnd()); } }
+  ~GroupGuard() { if (open) (void)ncclGroupEnd(); }
+};
 void check_comm_tensor(const lamp_tensor* t, const lamp_comm* c) {
   lamp::check_device_tensor(t, "tensor");
   LAMP_CHECK(c && c->comm, "null communicator");
@@ -85,41 +98,44 @@ int lamp_comm_init_rank(lamp_comm** out, int nranks, const uint8_t* id, int rank
 
 int lamp_comm_broadcast(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int root) {
   LAMP_API_BEGIN
-  if (n > 1) NCCL_CHECK(ncclGroupStart());
+  for (int i = 0; i < n; i++) check_comm_tensor(tensors[i], comms[i]);
+  GroupGuard group(n);
   for (int i = 0; i < n; i++) {
-    check_comm_tensor(tensors[i], comms[i]);
     NCCL_CHECK(ncclBroadcast(tensors[i]->data(), tensors[i]->data(), (size_t)tensors[i]->numel(), nccl_type(tensors[i]->dtype), root,
                              comms[i]->comm, current_stream(comms[i]->device)));
   }
-  if (n > 1) NCCL_CHECK(ncclGroupEnd());
+  group.end();
   LAMP_API_END
 }
 
 int lamp_comm_reduce(lamp_tensor* const* inputs, lamp_tensor* output, int root, int op, lamp_comm* const* comms, int n) {
   LAMP_API_BEGIN
-  if (n > 1) NCCL_CHECK(ncclGroupStart());
+  const ncclRedOp_t rop = nccl_op(op);
   for (int i = 0; i < n; i++) {
     check_comm_tensor(inputs[i], comms[i]);
-    void* recv = (comms[i]->rank == root && output) ? output->data() : inputs[i]->data();
-    if (comms[i]->rank == root && output) {
+    if (comms[i]->rank == root && output)
       LAMP_CHECK(output->numel() == inputs[i]->numel() && output->dtype == inputs[i]->dtype && output->is_contiguous(), "reduce: output does not match the input");
-    }
-    NCCL_CHECK(ncclReduce(inputs[i]->data(), recv, (size_t)inputs[i]->numel(), nccl_type(inputs[i]->dtype), nccl_op(op), root,
+  }
+  GroupGuard group(n);
+  for (int i = 0; i < n; i++) {
+    void* recv = (comms[i]->rank == root && output) ? output->data() : inputs[i]->data();
+    NCCL_CHECK(ncclReduce(inputs[i]->data(), recv, (size_t)inputs[i]->numel(), nccl_type(inputs[i]->dtype), rop, root,
                           comms[i]->comm, current_stream(comms[i]->device)));
   }
-  if (n > 1) NCCL_CHECK(ncclGroupEnd());
+  group.end();
   LAMP_API_END
 }
 
 int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, int n, int op) {
   LAMP_API_BEGIN
-  if (n > 1) NCCL_CHECK(ncclGroupStart());
+  const ncclRedOp_t rop = nccl_op(op);
+  for (int i = 0; i < n; i++) check_comm_tensor(tensors[i], comms[i]);
+  GroupGuard group(n);
   for (int i = 0; i < n; i++) {
-    check_comm_tensor(tensors[i], comms[i]);
-    NCCL_CHECK(ncclAllReduce(tensors[i]->data(), tensors[i]->data(), (size_t)tensors[i]->numel(), nccl_type(tensors[i]->dtype), nccl_op(op),
+    NCCL_CHECK(ncclAllReduce(tensors[i]->data(), tensors[i]->data(), (size_t)tensors[i]->numel(), nccl_type(tensors[i]->dtype), rop,
                              comms[i]->comm, current_stream(comms[i]->device)));
   }
-  if (n > 1) NCCL_CHECK(ncclGroupEnd());
+  group.end();
   LAMP_API_END
 }
 
@@ -132,6 +148,21 @@ int lamp_comm_all_gather(lamp_tensor* out, const lamp_tensor* in, lamp_comm* com
   NCCL_CHECK(ncclCommCount(comm->comm, &nranks));
   LAMP_CHECK(out->dtype == in->dtype && out->numel() == in->numel() * nranks, "all_gather: out must hold nranks x in elements of the same dtype");
   NCCL_CHECK(ncclAllGather(in->data(), out->data(), (size_t)in->numel(), nccl_type(in->dtype), comm->comm, current_stream(comm->device)));
+  LAMP_API_END
+}
+
+// ranks RCCL itself counts in the communicator / this rank's index in it (ncclCommCount, ncclCommUserRank): launchers use it to
+// prove that an "N GPU" job really is N ranks
+int lamp_comm_count(const lamp_comm* c, int* nranks_out) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(c && c->comm, "null communicator");
+  NCCL_CHECK(ncclCommCount(c->comm, nranks_out));
+  LAMP_API_END
+}
+int lamp_comm_user_rank(const lamp_comm* c, int* rank_out) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(c && c->comm, "null communicator");
+  NCCL_CHECK(ncclCommUserRank(c->comm, rank_out));
   LAMP_API_END
 }
 

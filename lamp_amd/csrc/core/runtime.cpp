@@ -87,6 +87,40 @@ void allow_big_lds(const void* fn) {
 uint64_t philox_seed() { return g_seed.load(); }
 uint64_t next_philox_offset(uint64_t n) { return g_philox_offset.fetch_add(n); }
 
+// ---- device-side assertions ---------------------------------------------------------------------
+// ATen raises a device assert when nll_loss meets a class index outside [0, C); silently skipping the row would train on a subset
+// with a shrunken total_weight.  Kernels report such conditions into one host-mapped word per device; the library looks at it at
+// every point where the host waits for the device anyway (item, copy to host, synchronize) and raises there.
+namespace {
+std::mutex g_assert_mu;
+int* g_assert_words = nullptr;     // [16], pinned + mapped + coherent: the device writes, the host reads without a copy
+const char* assert_text(int code) {
+  switch (code) {
+    case kAssertNllTarget: return "nll_loss: a target class index is outside [0, numClasses) and is not ignore_index";
+    case kAssertIndexRange: return "index out of range";
+  }
+  return "device-side assertion";
+}
+}  // namespace
+int* device_assert_word(int device) {
+  std::lock_guard<std::mutex> lk(g_assert_mu);
+  if (!g_assert_words) {
+    void* p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
+    memset(p, 0, 16 * sizeof(int));
+    g_assert_words = (int*)p;
+  }
+  return g_assert_words + device;
+}
+void check_device_asserts(int device) {
+  if (!g_assert_words) return;
+  volatile int* w = g_assert_words + device;
+  const int code = *w;
+  if (code == 0) return;
+  *w = 0;
+  throw Error(std::string("device-side assertion failed: ") + assert_text(code));
+}
+
 // ---- kernel timers ------------------------------------------------------------------------------
 namespace {
 struct TimerEntry { std::string tag; double flops, bytes; hipEvent_t a, b; };
@@ -194,8 +228,9 @@ int lamp_set_device(int device) {
 }
 int lamp_device_synchronize(void) {
   LAMP_API_BEGIN
-  current_device();
+  const int dev = current_device();
   HIP_CHECK(hipDeviceSynchronize());
+  check_device_asserts(dev);
   LAMP_API_END
 }
 int lamp_device_name(char* buf, int buflen) {
@@ -271,6 +306,7 @@ int lamp_stream_synchronize(lamp_stream* s) {
   LAMP_API_BEGIN
   LAMP_CHECK(s, "null stream");
   HIP_CHECK(hipStreamSynchronize(s->s));
+  check_device_asserts(s->device);
   LAMP_API_END
 }
 int lamp_stream_wait_stream(lamp_stream* waiter, lamp_stream* on) {
@@ -280,6 +316,17 @@ int lamp_stream_wait_stream(lamp_stream* waiter, lamp_stream* on) {
   HIP_CHECK(hipEventRecord(ev, on->s));
   HIP_CHECK(hipStreamWaitEvent(waiter->s, ev, 0));
   HIP_CHECK(hipEventDestroy(ev));
+  LAMP_API_END
+}
+// `t`'s storage is (also) in use by work queued on `s` (NULL: the calling thread's current stream of t's device): when the last
+// handle is released the block is not recycled before that work has finished (at::Tensor::record_stream; lamp consumes tensors
+// allocated inside `withOtherStream` on the default stream, device.scala:199-213)
+int lamp_tensor_record_stream(const lamp_tensor* t, lamp_stream* s) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(t, "null tensor");
+  if (!t->is_device()) return 0;
+  if (s) record_stream(t, s->device, s->s);
+  else record_stream(t, t->device(), current_stream(t->device()));
   LAMP_API_END
 }
 int lamp_stream_release(lamp_stream* s) {

@@ -152,6 +152,11 @@ using Tensor = lamp_tensor;
 // ---- allocator (core/allocator.cpp) ----
 void* device_alloc(int device, size_t bytes, void** cookie);
 void device_free(int device, void* ptr, void* cookie);
+void device_record_stream(int device, void* cookie, int stream_device, hipStream_t stream);   // block is in use on that stream too
+inline void record_stream(const lamp_tensor* t, int stream_device, hipStream_t stream) {
+  if (t && t->st && t->st->device >= 0 && t->st->owned) device_record_stream(t->st->device, t->st->pool, stream_device, stream);
+}
+int64_t allocator_deferred_frees(int device);
 void allocator_stats(int device, int64_t* reserved, int64_t* in_use, int64_t* n_malloc);
 void allocator_trim(int device);
 void allocator_begin_capture_pool();
@@ -169,6 +174,10 @@ void allow_big_lds(const void* kernel);   // opt a kernel into 160 KiB of dynami
 // picks them up instead of re-reading it (norm.hip).  A small ring: the consumer runs right after the producer.
 void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P);
 lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P);   // +1 handle or nullptr
+// device-side assertions (runtime.cpp): a kernel stores a code into *device_assert_word(dev); the next host wait raises
+enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2 };
+int* device_assert_word(int device);
+void check_device_asserts(int device);
 uint64_t next_philox_offset(uint64_t n);  // advances the generator state by n draws
 uint64_t philox_seed();
 

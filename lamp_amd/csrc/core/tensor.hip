@@ -168,8 +168,24 @@ void copy_into(Tensor* dst, const Tensor* src) {
     // peer copy: stage through a contiguous same-dtype buffer on the source device
     Hold sc(contiguous(src));
     Hold tmp(new_tensor(sc->sizes, sc->ndim, sc->dtype, dst->device()));
+    // the copy runs on the DESTINATION device's stream: it must see what the source device's stream has written (src itself, or
+    // the contiguous staging copy just queued there), and the staging block must not be recycled on its own stream while the copy
+    // is still reading it
+    hipStream_t dstream = current_stream(dst->device()), sstream = current_stream(src->device());
+    {
+      const int prev = current_device();
+      HIP_CHECK(hipSetDevice(src->device()));
+      hipEvent_t ev = nullptr;
+      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(ev, sstream));
+      HIP_CHECK(hipSetDevice(dst->device()));
+      HIP_CHECK(hipStreamWaitEvent(dstream, ev, 0));
+      HIP_CHECK(hipEventDestroy(ev));
+      HIP_CHECK(hipSetDevice(prev));
+    }
+    record_stream(sc.get(), dst->device(), dstream);
     HIP_CHECK(hipMemcpyPeerAsync(tmp->data(), dst->device(), sc->data(), src->device(),
-                                 (size_t)sc->numel() * sc->itemsize(), current_stream(dst->device())));
+                                 (size_t)sc->numel() * sc->itemsize(), dstream));
     device_copy(dst, tmp.get());
     return;
   }
@@ -483,6 +499,7 @@ int lamp_copy_to_host(const lamp_tensor* src, void* dst, size_t nbytes) {
   LAMP_CHECK(lamp_from_blob(&wrap, dst, sz, nullptr, src->ndim, src->dtype, -1) == 0, lamp_last_error());
   Hold h(wrap);
   copy_into(h.get(), src);
+  if (src->is_device()) check_device_asserts(src->device());
   LAMP_API_END
 }
 int lamp_clone(lamp_tensor** out, const lamp_tensor* t) {
@@ -548,6 +565,7 @@ int lamp_item(const lamp_tensor* t, double* out) {
   Hold h(new_tensor(one, 0, kF64, -1));
   Hold flat(new_view(t, one, one, 0, t->offset));
   copy_into(h.get(), flat.get());
+  if (t->is_device()) check_device_asserts(t->device());
   *out = *h->ptr<double>();
   LAMP_API_END
 }

@@ -339,6 +339,20 @@ int lamp_model_train_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, con
   *num_examples = m->dp.step(m->model, *o->o, borrow(samples), borrow(target), acc ? borrow(acc) : Ten());
   LAMP_API_END
 }
+int lamp_model_train_step_scheduled(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, const lamp_tensor* samples, const lamp_tensor* target,
+                                    lamp_tensor* acc, double schedule_factor, int64_t* num_examples) {
+  LAMP_API_BEGIN
+  m->dp.comm = comm;
+  *num_examples = m->dp.step(m->model, *o->o, borrow(samples), borrow(target), acc ? borrow(acc) : Ten(), schedule_factor);
+  LAMP_API_END
+}
+int lamp_model_sync_state(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, int root) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(comm, "NULL communicator");
+  m->dp.comm = comm;
+  m->dp.sync_state(m->model, *o->o, root);
+  LAMP_API_END
+}
 int lamp_data_parallel_step(lamp_model* main_model, lamp_optimizer* o, lamp_model* const* replicas, int nreplicas, const lamp_tensor* const* samples,
                             const lamp_tensor* const* targets, lamp_tensor* const* accs, int zero_grad, int step, double schedule_factor,
                             int64_t* num_examples) {

@@ -202,6 +202,11 @@ void AdamW::load(const std::vector<Ten>& tensors) {
     stepCount = (int64_t)v;
   }
 }
+void AdamW::counters_from_state() {
+  double v = 0;
+  HCALL(lamp_item(stepCountSTen.h(), &v));
+  stepCount = (int64_t)v;
+}
 void AdamW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
   LAMP_CHECK(gradients.size() == parameters.size(), "AdamW.step: got " << gradients.size() << " gradients for " << parameters.size() << " parameters");
   std::vector<lamp_tensor*> p, g, m, v, w;
@@ -242,6 +247,13 @@ void SGDW::step(const std::vector<Ten>& gradients, double scheduleFactor) {
 // ---- SupervisedModel -------------------------------------------------------------------------------
 // With LossFunctions.Identity the loss is computed inside the module (LanguageModelLoss, lm.scala:44-59): its input case class
 // carries the target, which reaches the module as forward_multi's first extra tensor.  Single-input modules ignore it.
+// acc += (loss.value * numInstances.toDouble) (SupervisedModel.scala:207): one launch.  The reference's accumulator is an f64 scalar
+// (IOLoops.scala:715, distributed/package.scala:631) whatever the model's type; same-type accumulators keep the plain add.
+static void accumulate_loss(const Ten& acc, const Ten& loss, int64_t n) {
+  if (!acc.defined()) return;
+  if (acc.dtype() == loss.dtype()) ops::add_(acc, ops::reshape(loss, acc.shape()), (double)n);
+  else HCALL(lamp_add_scaled_mixed_(acc.h(), loss.h(), (double)n));
+}
 static Var run_module(SupervisedModel& m, const Ten& samples, const Ten& target) {
   if (m.loss_kind == 2) return m.module->forward_multi({make_const(samples)}, {target});
   return m.module->forward(make_const(samples));
@@ -256,18 +268,14 @@ int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten&
   Var output = run_module(*this, samples, target);            // BatchStream emits const(features) (BatchStream.scala:562)
   auto ln = loss(output, target);
   std::vector<Ten> g = module->gradients(ln.first, zeroGrad);
-  if (acc.defined()) {                                         // acc += (loss.value * numInstances.toDouble)
-    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
-  }
+  accumulate_loss(acc, ln.first->value, ln.second);
   if (gradients) *gradients = g;
   return ln.second;
 }
 int64_t SupervisedModel::addTotalLossAndReturnNumExamples(const Ten& samples, const Ten& target, const Ten& acc) {
   Var output = run_module(*this, samples, target);
   auto ln = loss(output, target);
-  if (acc.defined()) {
-    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)ln.second);   // one fused a += n * loss
-  }
+  accumulate_loss(acc, ln.first->value, ln.second);
   return ln.second;
 }
 
@@ -333,13 +341,48 @@ int64_t data_parallel_synchronous_step(SupervisedModel& main, Optimizer& opt, co
 // ---- data parallel step ------------------------------------------------------------------------------
 DataParallel::~DataParallel() { if (comm_stream) lamp_stream_release(comm_stream); }
 
-int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc) {
+namespace {
+// the thread's current stream is switched to the exchange stream for a few calls: an error in between (RCCL failure, a gradient that
+// is not contiguous) must not leave the thread on the high-priority stream, nor leak the handle of the compute stream
+struct StreamScope {
+  lamp_stream* prev = nullptr;
+  explicit StreamScope(int device) { HCALL(lamp_stream_get_current(device, &prev)); }
+  void enter(lamp_stream* s) { HCALL(lamp_stream_set_current(s)); }
+  void leave() { HCALL(lamp_stream_set_current(prev)); }
+  ~StreamScope() { if (prev) { lamp_stream_set_current(prev); lamp_stream_release(prev); } }
+};
+}  // namespace
+
+void DataParallel::sync_state(SupervisedModel& model, Optimizer& opt, int root) {
+  LAMP_CHECK(comm, "sync_state needs a communicator");
+  std::vector<lamp_tensor*> ts;
+  std::vector<Ten> keep;
+  for (auto& v : model.module->state()) { keep.push_back(v->value); }
+  for (auto& t : opt.state()) if (t.defined()) keep.push_back(t);
+  for (auto& t : keep) {
+    LAMP_CHECK(t.h()->is_contiguous(), "state tensor " << t.h()->describe() << " is not contiguous");
+    ts.push_back(t.h());
+  }
+  // groups of <= 64 tensors per ncclGroup (one communicator, many buffers)
+  for (size_t lo = 0; lo < ts.size(); lo += 64) {
+    const int n = (int)std::min<size_t>(64, ts.size() - lo);
+    std::vector<lamp_comm*> cm(n, comm);
+    HCALL(lamp_comm_broadcast(ts.data() + lo, cm.data(), n, root));
+  }
+  opt.counters_from_state();  // AdamW's step count follows the broadcast state()[0]
+  synced_with = comm;
+}
+
+int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc, double scheduleFactor) {
   if (!comm) {
     std::vector<Ten> grads;
     const int64_t n = model.addTotalLossAndReturnGradientsAndNumExamples(samples, target, acc, true, &grads);
-    opt.step(grads, 1.0);
+    opt.step(grads, scheduleFactor);
     return n;
   }
+  // replicas must start from one state: ranks that initialised differently (checkpoint read on rank 0 only, different seeds) would
+  // otherwise train divergent models without any error
+  if (synced_with != comm) sync_state(model, opt, 0);
   // averageGradients (distributed/package.scala:690-719): g *= n ; reduce(n) ; reduce(g) ; g /= sum n.
   // Here: flat f32 buckets [n*g_i ... | n], one all-reduce each, every rank divides by the summed n.
   std::vector<Var> params = model.module->parameters();
@@ -355,8 +398,8 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   auto ln = model.loss(output, target);
   const int64_t n = ln.second;
 
-  lamp_stream* cur = nullptr;
-  HCALL(lamp_stream_get_current(device, &cur));
+  StreamScope scope(device);
+  lamp_stream* const cur = scope.prev;
   if (!comm_stream) HCALL(lamp_stream_get_from_pool(1, device, &comm_stream));
 
   auto exchange = [&](size_t lo, size_t hi, Ten& bucket, std::vector<Ten>& grads, std::vector<lamp_tensor*>& gh) {
@@ -367,8 +410,11 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
       cnt += grads.back().numel();
     }
     if (!bucket.defined() || bucket.numel() != cnt + 1) bucket = ops::zeros({cnt + 1}, kF32, device);
+    // gradients and bucket were allocated under the compute stream and are now used on the exchange stream
+    HCALL(lamp_tensor_record_stream(bucket.h(), comm_stream));
+    for (auto* g : gh) HCALL(lamp_tensor_record_stream(g, comm_stream));
     HCALL(lamp_stream_wait_stream(comm_stream, cur));              // the gradients are complete on the compute stream
-    HCALL(lamp_stream_set_current(comm_stream));
+    scope.enter(comm_stream);
     if (!gh.empty()) HCALL(lamp_flatten_into_(bucket.h(), gh.data(), (int)gh.size(), (double)n));
     ops::fill_(ops::slice(bucket, 0, cnt, cnt + 1, 1), (double)n);
     lamp_tensor* bt[1] = {bucket.h()};
@@ -377,7 +423,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
     // averaged gradients back into the parameters' grad buffers, still on the exchange stream: for the deep bucket this overlaps
     // the rest of backward instead of queueing behind it
     if (!gh.empty()) HCALL(lamp_unflatten_from_(gh.data(), (int)gh.size(), bucket.h(), 1));
-    HCALL(lamp_stream_set_current(cur));
+    scope.leave();
   };
 
   // gradients of a parameter are final once every op that consumes it has run its backward
@@ -402,14 +448,11 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   });
   if (!deep_sent) send_deep();
   exchange(0, split, bucket_rest, g_rest, h_rest);
-  if (acc.defined()) {                                           // acc += (loss.value * numInstances.toDouble)
-    ops::add_(acc, ops::reshape(ln.first->value, acc.shape()), (double)n);
-  }
+  accumulate_loss(acc, ln.first->value, n);
   HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both averaged gradient sets are visible to the compute stream
-  lamp_stream_release(cur);
   std::vector<Ten> grads(g_rest);
   grads.insert(grads.end(), g_deep.begin(), g_deep.end());
-  opt.step(grads, 1.0);
+  opt.step(grads, scheduleFactor);
   return n;
 }
 

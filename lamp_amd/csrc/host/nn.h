@@ -129,6 +129,9 @@ struct Optimizer {
     std::vector<Ten> st = state();
     for (size_t i = 0; i < st.size() && i < tensors.size(); i++) ops::copy_(st[i], tensors[i]);
   }
+  // host-side counters that mirror a state tensor (AdamW's step count) re-read from it after the state tensors were overwritten
+  // in place (broadcast from another rank)
+  virtual void counters_from_state() {}
 };
 struct AdamW : Optimizer {      // nn/AdamW.scala:29-177
   std::vector<Ten> parameters, mt, vt, workingCopy;   // workingCopy[i] undefined when not mixed precision
@@ -143,6 +146,7 @@ struct AdamW : Optimizer {      // nn/AdamW.scala:29-177
   void step(const std::vector<Ten>& gradients, double scheduleFactor) override;
   std::vector<Ten> state() override;
   void load(const std::vector<Ten>& tensors) override;   // also restores stepCount from state()[0]
+  void counters_from_state() override;
 };
 struct SGDW : Optimizer {       // nn/SGD.scala:19-99
   std::vector<Ten> parameters, velocity;
@@ -174,7 +178,12 @@ struct DataParallel {
   lamp_comm* comm = nullptr;    // null => single process (no exchange)
   Ten bucket_deep, bucket_rest; // f32 [sum numel + 1] each, last element = numExamples
   lamp_stream* comm_stream = nullptr;
-  int64_t step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc);
+  lamp_comm* synced_with = nullptr;   // communicator the replicas were last made identical over
+  int64_t step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc, double scheduleFactor = 1.0);
+  // broadcast(root): module.state (parameters AND batch-norm running statistics) and the optimiser state from rank `root` to every
+  // rank (distributed/package.scala:683-688 does this before every batch; here the replicas step identically, so once before the
+  // first step - and whenever the caller wants the non-parameter state of rank 0 everywhere: validation, checkpoints)
+  void sync_state(SupervisedModel& model, Optimizer& opt, int root = 0);
   ~DataParallel();
 };
 

@@ -358,6 +358,15 @@ __global__ void masked_fill_kernel(T* out, const T* a, const uint8_t* mask, T va
   }
 }
 
+// acc[i] += scale * x[i] with acc and x of DIFFERENT floating types, the product and sum taken in f64: the epoch-loss accumulator of
+// the training loops is an f64 scalar whatever the model's type (`STen.scalarDouble(0, options)`, IOLoops.scala:715;
+// `acc += loss * numInstances`, SupervisedModel.scala:207).  A bf16 accumulator would round every batch to 8 bits.
+template <class TA, class TX>
+__global__ void add_scaled_mixed_kernel(TA* __restrict__ acc, const TX* __restrict__ x, double scale, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc[i] = store_as<TA>((acc_t<TA>)(load_as<double>(acc[i]) + scale * load_as<double>(x[i])));
+}
+
 }  // namespace lamp
 
 using namespace lamp;
@@ -424,6 +433,19 @@ int lamp_div_out(lamp_tensor* out, const lamp_tensor* a, const lamp_tensor* b) {
   LAMP_API_BEGIN run_same<2, FDiv, false>(out, a, b, nullptr, FDiv{}); LAMP_API_END
 }
 int lamp_add_(lamp_tensor* self, const lamp_tensor* b, double alpha) { return lamp_add_out(self, self, b, alpha); }
+int lamp_add_scaled_mixed_(lamp_tensor* acc, const lamp_tensor* x, double scale) {
+  LAMP_API_BEGIN
+  check_device_tensor(acc, "acc"); check_device_tensor(x, "x"); check_same_device(acc, x);
+  LAMP_CHECK(acc->numel() == x->numel() && acc->is_contiguous() && x->is_contiguous(),
+             "acc " << acc->describe() << " and x " << x->describe() << " must be contiguous with the same number of elements");
+  const int64_t n = acc->numel();
+  if (n == 0) return 0;
+  hipStream_t st = current_stream(acc->device());
+  LAMP_DISPATCH_FLOAT(acc->dtype, TA, LAMP_DISPATCH_FLOAT(x->dtype, TX,
+      hipLaunchKernelGGL((add_scaled_mixed_kernel<TA, TX>), dim3(grid_for(n, 256)), dim3(256), 0, st, acc->ptr<TA>(), x->ptr<TX>(), scale, n)));
+  LAMP_LAUNCH_CHECK();
+  LAMP_API_END
+}
 int lamp_sub_(lamp_tensor* self, const lamp_tensor* b, double alpha) { return lamp_sub_out(self, self, b, alpha); }
 int lamp_mul_(lamp_tensor* self, const lamp_tensor* b) { return lamp_mul_out(self, self, b); }
 int lamp_div_(lamp_tensor* self, const lamp_tensor* b) { return lamp_div_out(self, self, b); }

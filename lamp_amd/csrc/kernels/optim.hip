@@ -191,6 +191,36 @@ static void check_list(lamp_tensor* const* ts, int n, const char* what, int dtyp
 
 using namespace lamp;
 
+// The bucket layout on HOST tensors (same offsets, same f32 arithmetic: bucket = scale * g rounded to f32, g = bucket / last as f32):
+// a control-plane process can pack / unpack gradients that live in host memory - the exchange protocol of the data-parallel step
+// is testable between CPU-only ranks, and host-resident replicas (lamp's CPU device) can take part in an exchange.
+template <class T>
+static void host_flatten(float* bucket, lamp_tensor* const* ts, int n, const std::vector<int64_t>& offs, double scale) {
+  const float sc = (float)scale;
+  for (int i = 0; i < n; i++) {
+    const T* src = ts[i]->ptr<T>();
+    float* dst = bucket + offs[i];
+    for (int64_t k = 0, e = ts[i]->numel(); k < e; k++) dst[k] = sc * load_as<float>(src[k]);
+  }
+}
+template <class T>
+static void host_unflatten(lamp_tensor* const* ts, int n, const float* bucket, const std::vector<int64_t>& offs, int64_t last) {
+  const float div = last >= 0 ? bucket[last] : 1.0f;
+  for (int i = 0; i < n; i++) {
+    T* dst = ts[i]->ptr<T>();
+    const float* src = bucket + offs[i];
+    for (int64_t k = 0, e = ts[i]->numel(); k < e; k++) dst[k] = store_as<T>((acc_t<T>)(src[k] / div));
+  }
+}
+static bool all_host(const lamp_tensor* bucket, lamp_tensor* const* ts, int n) {
+  if (bucket->is_device()) return false;
+  for (int i = 0; i < n; i++) {
+    LAMP_CHECK(ts[i] && !ts[i]->is_device(), "host bucket with a device tensor in the list");
+    LAMP_CHECK(ts[i]->is_contiguous() && ts[i]->dtype == ts[0]->dtype, "host bucket: tensors must be contiguous and of one dtype");
+  }
+  return true;
+}
+
 extern "C" {
 
 int lamp_gradient_clipping_(lamp_tensor* const* grads, int n, double theta) {
@@ -308,15 +338,20 @@ int lamp_sgdw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_
 
 int lamp_flatten_into_(lamp_tensor* bucket, lamp_tensor* const* ts, int n, double scale) {
   LAMP_API_BEGIN
-  check_device_tensor(bucket, "bucket");
+  LAMP_CHECK(bucket, "bucket is null");
   LAMP_CHECK(bucket->dtype == kF32 && bucket->is_contiguous(), "the gradient bucket must be a contiguous f32 tensor");
   if (n == 0) return 0;
-  const int dtype = ts[0]->dtype, dev = bucket->device();
-  check_list(ts, n, "tensors", dtype, dev);
   std::vector<int64_t> numels(n), offs(n);
   int64_t off = 0;
-  for (int i = 0; i < n; i++) { numels[i] = ts[i]->numel(); offs[i] = off; off += numels[i]; }
+  for (int i = 0; i < n; i++) { LAMP_CHECK(ts[i], "null tensor in the list"); numels[i] = ts[i]->numel(); offs[i] = off; off += numels[i]; }
   LAMP_CHECK(off <= bucket->numel(), "bucket too small: " << bucket->numel() << " < " << off);
+  if (all_host(bucket, ts, n)) {
+    LAMP_DISPATCH_FLOAT(ts[0]->dtype, T, host_flatten<T>(bucket->ptr<float>(), ts, n, offs, scale));
+    return 0;
+  }
+  check_device_tensor(bucket, "bucket");
+  const int dtype = ts[0]->dtype, dev = bucket->device();
+  check_list(ts, n, "tensors", dtype, dev);
   hipStream_t st = current_stream(dev);
   LAMP_DISPATCH_FLOAT(dtype, T, for_each_group(n, numels.data(),
       [&](MultiArgs& a, int t, int gi) { a.p[0][t] = ts[gi]->data(); a.h[0][t] = (double)offs[gi]; a.s[0] = scale; },
@@ -327,16 +362,21 @@ int lamp_flatten_into_(lamp_tensor* bucket, lamp_tensor* const* ts, int n, doubl
 
 int lamp_unflatten_from_(lamp_tensor* const* ts, int n, const lamp_tensor* bucket, int divide_by_last_element) {
   LAMP_API_BEGIN
-  check_device_tensor(bucket, "bucket");
+  LAMP_CHECK(bucket, "bucket is null");
   LAMP_CHECK(bucket->dtype == kF32 && bucket->is_contiguous(), "the gradient bucket must be a contiguous f32 tensor");
   if (n == 0) return 0;
-  const int dtype = ts[0]->dtype, dev = bucket->device();
-  check_list(ts, n, "tensors", dtype, dev);
   std::vector<int64_t> numels(n), offs(n);
   int64_t off = 0;
-  for (int i = 0; i < n; i++) { numels[i] = ts[i]->numel(); offs[i] = off; off += numels[i]; }
+  for (int i = 0; i < n; i++) { LAMP_CHECK(ts[i], "null tensor in the list"); numels[i] = ts[i]->numel(); offs[i] = off; off += numels[i]; }
   LAMP_CHECK(off <= bucket->numel(), "bucket too small");
   const int64_t last = divide_by_last_element ? bucket->numel() - 1 : -1;
+  if (all_host(bucket, ts, n)) {
+    LAMP_DISPATCH_FLOAT(ts[0]->dtype, T, host_unflatten<T>(ts, n, bucket->ptr<float>(), offs, last));
+    return 0;
+  }
+  check_device_tensor(bucket, "bucket");
+  const int dtype = ts[0]->dtype, dev = bucket->device();
+  check_list(ts, n, "tensors", dtype, dev);
   hipStream_t st = current_stream(dev);
   LAMP_DISPATCH_FLOAT(dtype, T, for_each_group(n, numels.data(),
       [&](MultiArgs& a, int t, int gi) { a.p[0][t] = ts[gi]->data(); a.h[0][t] = (double)offs[gi]; },

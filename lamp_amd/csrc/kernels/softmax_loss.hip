@@ -159,14 +159,14 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restric
 template <class T>
 __global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restrict__ x, const int64_t* __restrict__ target,
                                                               const T* __restrict__ w, T* __restrict__ out, T* __restrict__ total_weight,
-                                                              int64_t N, int64_t C, int64_t reduction, int64_t ignore) {
+                                                              int64_t N, int64_t C, int64_t reduction, int64_t ignore, int* __restrict__ assert_word) {
   using A = acc_t<T>;
   __shared__ A sm[16];
   A loss = 0, tw = 0;
   for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
     const int64_t t = target[i];
     if (t == ignore) continue;
-    if (t < 0 || t >= C) continue;  // validated on the host for small N; never read out of bounds
+    if (t < 0 || t >= C) { *(volatile int*)assert_word = kAssertNllTarget; continue; }  // never read out of bounds; the host raises at its next wait
     const A wt = w ? load_as<A>(w[t]) : A(1);
     loss -= wt * load_as<A>(x[i * C + t]);
     tw += wt;
@@ -181,11 +181,12 @@ __global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restric
 }
 template <class T>
 __global__ void nll_fwd_none_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, const T* __restrict__ w,
-                                    T* __restrict__ out, int64_t N, int64_t C, int64_t ignore) {
+                                    T* __restrict__ out, int64_t N, int64_t C, int64_t ignore, int* __restrict__ assert_word) {
   using A = acc_t<T>;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = target[i];
     A v = 0;
+    if (t != ignore && (t < 0 || t >= C)) *(volatile int*)assert_word = kAssertNllTarget;
     if (t != ignore && t >= 0 && t < C) v = -(w ? load_as<A>(w[t]) : A(1)) * load_as<A>(x[i * C + t]);
     out[i] = store_as<T>(v);
   }
@@ -319,6 +320,7 @@ int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const l
   const int64_t N = x->sizes[0], C = x->sizes[1];
   hipStream_t st = current_stream(x->device());
   Hold tw(new_tensor(nullptr, 0, x->dtype, x->device()));
+  int* aw = device_assert_word(x->device());
   if (reduction == 0) {
     int64_t sz[1] = {N};
     Hold o(new_tensor(sz, 1, x->dtype, x->device()));
@@ -326,7 +328,7 @@ int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const l
     if (N > 0) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_none_kernel<T>), dim3(grid_for(N, 256)), dim3(256), 0, st,
                                                           xc->ptr<T>(), tc->ptr<int64_t>(), wc.get() ? wc->ptr<T>() : (const T*)nullptr,
-                                                          o->ptr<T>(), N, C, ignore_index));
+                                                          o->ptr<T>(), N, C, ignore_index, aw));
       LAMP_LAUNCH_CHECK();
     }
     *out = o.take();
@@ -334,7 +336,7 @@ int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const l
     Hold o(new_tensor(nullptr, 0, x->dtype, x->device()));
     LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_reduce_kernel<T>), dim3(1), dim3(1024), 0, st, xc->ptr<T>(),
                                                         tc->ptr<int64_t>(), wc.get() ? wc->ptr<T>() : (const T*)nullptr, o->ptr<T>(),
-                                                        tw->ptr<T>(), N, C, reduction, ignore_index));
+                                                        tw->ptr<T>(), N, C, reduction, ignore_index, aw));
     LAMP_LAUNCH_CHECK();
     *out = o.take();
   }

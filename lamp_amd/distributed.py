@@ -2,43 +2,201 @@
 
 Reference: lamp-data/src/main/scala/lamp/data/distributed/package.scala:171-445 (drive/follow: rank 0 creates the NCCL
 unique id and hands it to the followers over the control plane, everybody calls ncclCommInitRank), :690-719
-(averageGradients) and lamp-data/.../BatchStream.scala:378-402 (everyNth sharding).  The control plane here is a gloo
-process group (the reference uses cats-effect queues or Akka TCP); the data plane is RCCL through the C ABI.
+(averageGradients) and lamp-data/.../BatchStream.scala:378-402 (everyNth sharding).  The control plane here is a small TCP
+rendezvous (the reference uses cats-effect queues or Akka TCP); the data plane is RCCL through the C ABI.  No torch import.
 """
 from __future__ import annotations
 
 import ctypes as C
+import json
+import math
 import os
-from typing import List, Sequence, Tuple
+import socket
+import struct
+import tempfile
+import time
+from typing import List, Optional, Sequence, Tuple
 
 
 def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_control_plane():
-    """gloo process group from the torchrun environment (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
-    import torch.distributed as dist
+# ---- control plane -----------------------------------------------------------------------------------------------------------
+# The reference hands the NCCL unique id from the root to the followers over its own control plane (cats-effect queues inside one
+# JVM, or Akka TCP between hosts: DistributedCommunication.scala:15-62, AkkaDistributedCommunication.scala:59-68).  Here that is a
+# few lines of TCP on the loop-back / cluster interface: rank 0 listens, every other rank keeps one connection to it, and each
+# collective of the control plane is one message up and one reply down.  No tensor library is involved; the data plane is RCCL.
+
+def _send_msg(sock: socket.socket, obj) -> None:
+    raw = json.dumps(obj).encode()
+    sock.sendall(struct.pack("<I", len(raw)) + raw)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control plane: peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock: socket.socket):
+    (n,) = struct.unpack("<I", _recv_exact(sock, 4))
+    return json.loads(_recv_exact(sock, n).decode())
+
+
+def rendezvous_file() -> str:
+    """Where rank 0 publishes the port it listens on.  All ranks of one launch share MASTER_ADDR / MASTER_PORT and - being children
+    of one launcher (torch.distributed.run's agent or bench.py's own spawner) - the parent pid, which keeps two launches apart even
+    when they are given the same MASTER_PORT.  LAMP_RDZV_FILE overrides (multi-node: a path on a shared file system)."""
+    if os.environ.get("LAMP_RDZV_FILE"):
+        return os.environ["LAMP_RDZV_FILE"]
+    key = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    return os.path.join(tempfile.gettempdir(), f"lamp_rdzv_{key}.json")
+
+
+class ControlPlane:
+    """rank 0 = server, ranks 1.. = clients; collectives: barrier, broadcast_bytes, all_reduce_max, all_gather."""
+
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 0, rdzv: Optional[str] = None, timeout: float = 600.0):
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.peers: List[Optional[socket.socket]] = [None] * world       # rank 0 only
+        self.up: Optional[socket.socket] = None                        # ranks > 0: connection to rank 0
+        self._rdzv_written = None
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            nonce = os.urandom(8).hex()
+            if rdzv:
+                tmp = f"{rdzv}.{os.getpid()}.tmp"
+                with open(tmp, "w") as f:
+                    json.dump({"port": srv.getsockname()[1], "nonce": nonce}, f)
+                os.replace(tmp, rdzv)                                  # atomic: readers see nothing or the whole record
+                self._rdzv_written = rdzv
+            try:
+                joined = 0
+                while joined < world - 1:
+                    c, _ = srv.accept()
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    hello = _recv_msg(c)
+                    r = int(hello["rank"])
+                    if hello.get("world") != world or not (0 < r < world) or self.peers[r] is not None or (rdzv and hello.get("nonce") != nonce):
+                        _send_msg(c, {"ok": False, "why": f"rank {r} of world {hello.get('world')} does not belong to this launch (world {world})"})
+                        c.close()
+                        continue
+                    _send_msg(c, {"ok": True})
+                    self.peers[r] = c
+                    joined += 1
+            finally:
+                srv.close()
+        else:
+            deadline = time.monotonic() + timeout
+            last = None
+            while True:
+                try:
+                    if rdzv:
+                        with open(rdzv) as f:
+                            rec = json.load(f)
+                        cport, nonce = int(rec["port"]), rec["nonce"]
+                    else:
+                        cport, nonce = port, None
+                    s = socket.create_connection((addr, cport), timeout=5.0)
+                    s.settimeout(timeout)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send_msg(s, {"rank": rank, "world": world, "nonce": nonce})
+                    ans = _recv_msg(s)
+                    if not ans.get("ok"):
+                        s.close()
+                        raise ConnectionError(ans.get("why", "refused"))
+                    self.up = s
+                    break
+                except (OSError, ValueError, KeyError, ConnectionError) as e:   # not published yet / stale record / not listening yet
+                    last = e
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"control plane: rank {rank} could not reach rank 0 within {timeout:.0f} s ({last})")
+                    time.sleep(0.05)
+
+    # torch.distributed-flavoured accessors so call sites read the same
+    def get_rank(self) -> int: return self.rank
+    def get_world_size(self) -> int: return self.world
+
+    def _round(self, mine, combine):
+        """one message up from every rank, `combine(list_by_rank)` on rank 0, the result down to every rank"""
+        if self.world == 1:
+            return combine([mine])
+        if self.rank == 0:
+            vals = [mine] + [_recv_msg(self.peers[r]) for r in range(1, self.world)]
+            out = combine(vals)
+            for r in range(1, self.world):
+                _send_msg(self.peers[r], out)
+            return out
+        _send_msg(self.up, mine)
+        return _recv_msg(self.up)
+
+    def barrier(self) -> None:
+        self._round(None, lambda v: None)
+
+    def broadcast_bytes(self, data: Optional[bytes], root: int = 0) -> bytes:
+        return bytes.fromhex(self._round(data.hex() if (self.rank == root and data is not None) else None, lambda v: v[root]))
+
+    def all_reduce_max(self, x: float) -> float:
+        return float(self._round(float(x), max))
+
+    def all_reduce_sum(self, x: float) -> float:
+        return float(self._round(float(x), lambda v: math.fsum(v)))
+
+    def all_gather(self, obj) -> list:
+        return self._round(obj, list)
+
+    def close(self) -> None:
+        for s in self.peers + [self.up]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self.peers, self.up = [None] * self.world, None
+        if self._rdzv_written:
+            try:
+                os.unlink(self._rdzv_written)
+            except OSError:
+                pass
+            self._rdzv_written = None
+
+    destroy_process_group = close
+
+
+def init_control_plane(timeout: float = 600.0) -> ControlPlane:
+    """Control plane from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT - torch.distributed.run and
+    bench.py's own spawner both set them).  MASTER_PORT itself belongs to the launcher (torchrun's store listens there), so rank 0
+    binds an ephemeral port and publishes it in `rendezvous_file()`; LAMP_CONTROL_PORT pins the port instead."""
     rank, _, world = env_rank()
-    if not dist.is_initialized():
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    return dist
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("LAMP_CONTROL_PORT"):
+        return ControlPlane(rank, world, addr, int(os.environ["LAMP_CONTROL_PORT"]), None, timeout)
+    return ControlPlane(rank, world, addr, 0, rendezvous_file(), timeout)
 
 
-def exchange_unique_id(dist, make_id) -> bytes:
+def exchange_unique_id(cp, make_id) -> bytes:
     """rank 0 calls make_id() (128 bytes, lamp_comm_get_unique_id) and broadcasts it - DistributedCommunicationRoot.onUniqueIdReady /
     NonRoot.join in the reference (DistributedCommunication.scala:15-62)."""
-    import torch
-    t = torch.zeros(128, dtype=torch.uint8)
-    if dist.get_rank() == 0:
+    raw = None
+    if cp.get_rank() == 0:
         raw = bytes(make_id())
         assert len(raw) == 128
-        t = torch.tensor(list(raw), dtype=torch.uint8)
-    dist.broadcast(t, 0)
-    return bytes(t.tolist())
+    return cp.broadcast_bytes(raw, 0)
 
 
-def rccl_communicator(dist):
+def rccl_communicator(cp):
     """RCCL communicator for this rank (blocking until the clique is complete, like ncclInitComm - STen.scala:629-641)."""
     from ._capi import lib
 
@@ -46,10 +204,19 @@ def rccl_communicator(dist):
         buf = (C.c_uint8 * 128)()
         lib.lamp_comm_get_unique_id(buf)
         return bytes(buf)
-    uid = exchange_unique_id(dist, make)
+    uid = exchange_unique_id(cp, make)
     h = C.c_void_p()
-    lib.lamp_comm_init_rank(C.byref(h), dist.get_world_size(), (C.c_uint8 * 128)(*uid), dist.get_rank())
+    lib.lamp_comm_init_rank(C.byref(h), cp.get_world_size(), (C.c_uint8 * 128)(*uid), cp.get_rank())
     return h
+
+
+def comm_count(comm) -> int:
+    """ncclCommCount of a communicator: the number of ranks RCCL itself sees (bench.py refuses to print a line when it differs
+    from --gpus)."""
+    from ._capi import lib
+    n = C.c_int(0)
+    lib.lamp_comm_count(comm, C.byref(n))
+    return n.value
 
 
 def bucket_layout(numels: Sequence[int]) -> Tuple[List[int], int]:

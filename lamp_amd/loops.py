@@ -26,7 +26,7 @@ def oneEpoch(epochCount: int, model: SupervisedModel, optimizer: Optimizer, trai
              comm=None) -> float:
     """One pass over `trainBatches`; returns the average training loss (sum of loss * numInstances over the batches / instances)."""
     first = model.module.state[0].value
-    lossAcc = S.STen.zeros([1], first.dtype, first.device)
+    lossAcc = S.STen.zeros([1], S.F64, first.device)        # STen.scalarDouble(0, options): f64 whatever the model type (IOLoops.scala:715)
     numInstances, batchCount = 0, 0
     t1 = time.perf_counter()
     trainBatches.reset()
@@ -34,14 +34,7 @@ def oneEpoch(epochCount: int, model: SupervisedModel, optimizer: Optimizer, trai
         model.module.zeroGrad()
     for sample, target in trainBatches:
         if accumulateGradientOverNBatches <= 1:
-            if comm is None and learningRateScheduleFactor == 1.0:
-                n = model.train_step(optimizer, sample, target, lossAcc, None)
-            elif comm is not None:
-                assert learningRateScheduleFactor == 1.0, "the fused data-parallel step applies the optimizer with factor 1"
-                n = model.train_step(optimizer, sample, target, lossAcc, comm)
-            else:
-                n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(sample, target, lossAcc, True)
-                optimizer.step(grads, learningRateScheduleFactor)
+            n = model.train_step(optimizer, sample, target, lossAcc, comm, learningRateScheduleFactor)
         else:
             assert comm is None, "gradient accumulation is a single-process option in the reference (IOLoops.oneEpoch)"
             n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(sample, target, lossAcc, False)
@@ -64,7 +57,7 @@ def validationOneEpoch(model: SupervisedModel, validationBatches: BatchStream, e
                        logger: Optional[Callable[[str], None]] = None) -> float:
     """Average validation loss with the module in eval mode (restored to training mode afterwards, as `model.asEval` is a copy there)."""
     first = model.module.state[0].value
-    totalLoss = S.STen.zeros([1], first.dtype, first.device)
+    totalLoss = S.STen.zeros([1], S.F64, first.device)      # f64 accumulator (IOLoops.scala:809)
     totalExamples = 0
     model.module.asEval()
     try:

@@ -188,11 +188,20 @@ class SupervisedModel:
         lib.lamp_model_forward_loss(self.h, samples.h, target.h, acc.h if acc is not None else None, C.byref(n))
         return n.value
 
-    def train_step(self, optimizer: Optimizer, samples: STen, target: STen, acc: Optional[STen] = None, comm=None) -> int:
+    def train_step(self, optimizer: Optimizer, samples: STen, target: STen, acc: Optional[STen] = None, comm=None,
+                   scheduleFactor: float = 1.0) -> int:
         """one batch of IOLoops.oneEpoch / distributed oneBatch: gradients (+ all-reduce) + optimizer.step."""
         n = C.c_int64()
-        lib.lamp_model_train_step(self.h, optimizer.h, comm, samples.h, target.h, acc.h if acc is not None else None, C.byref(n))
+        if scheduleFactor == 1.0:
+            lib.lamp_model_train_step(self.h, optimizer.h, comm, samples.h, target.h, acc.h if acc is not None else None, C.byref(n))
+        else:
+            lib.lamp_model_train_step_scheduled(self.h, optimizer.h, comm, samples.h, target.h, acc.h if acc is not None else None,
+                                                float(scheduleFactor), C.byref(n))
         return n.value
+
+    def sync_state(self, optimizer: Optimizer, comm, root: int = 0) -> None:
+        """distributed `broadcast` (distributed/package.scala:683-688): rank `root`'s module + optimiser state on every rank."""
+        lib.lamp_model_sync_state(self.h, optimizer.h, comm, int(root))
 
 
 def dataParallelSynchronousStep(mainModel: SupervisedModel, optimizer: Optimizer, models: Sequence[SupervisedModel], batches, accs=None,

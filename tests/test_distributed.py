@@ -1,13 +1,21 @@
-"""N > 1 logic on CPU: two gloo processes run the exchange protocol of the data-parallel step.
+"""N > 1 logic on CPU.
 
-What runs here is the host logic (rendezvous, bucket layout, example-weighted averaging contract, sharding); the device
-kernels of the same step (lamp_flatten_into_ / lamp_comm_all_reduce / lamp_unflatten_from_) are covered on the GPU in
-test_flat_bucket_and_single_rank_collectives, and the complete overlapped two-bucket step (second stream, events, AdamW) in
-test_overlapped_data_parallel_step_single_rank (world size 1 communicator).
+* two gloo processes run the exchange of the data-parallel step with the PRODUCT's bucket code: every rank packs its oracle
+  gradients with lamp_flatten_into_ (host tensors, scale = local example count, example count appended), gloo all-reduces the
+  bucket, lamp_unflatten_from_ divides by the summed count - compared with the oracle's averageGradients;
+* the TCP control plane of lamp_amd.distributed (unique-id hand-over, barrier, max over ranks) between two processes;
+* bench.py's own launcher: `--gpus 2 --dry-launch` starts two ranks that rendezvous, and a real `--gpus 2` run on a box
+  without two GPUs exits non-zero instead of printing a line.
+
+The device kernels of the same step are covered on the GPU in test_flat_bucket_and_single_rank_collectives, and the complete
+overlapped two-bucket step (second stream, events, AdamW) in test_overlapped_data_parallel_step_single_rank (world size 1).
 """
 import ctypes as C
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -17,31 +25,43 @@ import torch.multiprocessing as mp
 from lamp_amd import distributed as D
 from oracle import lamp_oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from lamp_amd import sten as S
+    from lamp_amd._capi import lib, handle_array
+    lib.load()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
-    dist = D.init_control_plane()
-    # 1. unique id rendezvous: every rank ends up with root's 128 bytes
-    uid = D.exchange_unique_id(dist, lambda: bytes(range(128)))
-    assert uid == bytes(range(128))
-    # 2. one data-parallel exchange: local gradients of a small model on this rank's shard, flat bucket, all-reduce(sum), / sum n
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # local gradients of a small model on this rank's shard (uneven shards: the weighting matters)
     torch.manual_seed(0)
     m = O.Sequential(O.mlp(12, 3, [8], torch.float64), O.Fun(lambda v: v.logSoftMax(1)))
-    n_r = [5, 3][rank]                                        # uneven shards: the weighting matters
+    n_r = [5, 3][rank]
     x = O.closed_form(8 * 12, 0, 1.0, torch.float64).reshape(8, 12)[sum([5, 3][:rank]):][:n_r]
     t = (torch.arange(8) % 3)[sum([5, 3][:rank]):][:n_r]
     _, grads = O.training_step(m, O.nll_loss(3, torch.ones(3, dtype=torch.float64)), x, t, None)
+    # the product's bucket code on host tensors: averageGradients (distributed/package.scala:690-719) as
+    # bucket = [n_r * g ... | n_r] -> all-reduce(sum) -> g = bucket / bucket[last]
+    hg = [S.STen.from_numpy(g.numpy(), S.CPU) for g in grads]
     offs, total = D.bucket_layout([g.numel() for g in grads])
-    bucket = torch.zeros(total, dtype=torch.float32)
-    for g, o in zip(grads, offs):                              # lamp_flatten_into_(bucket, grads, scale = n_r)
-        bucket[o:o + g.numel()] = (g.reshape(-1) * n_r).float()
-    bucket[-1] = n_r
-    dist.all_reduce(bucket)                                    # lamp_comm_all_reduce
-    avg = [(bucket[o:o + g.numel()] / bucket[-1]).reshape(g.shape) for g, o in zip(grads, offs)]   # lamp_unflatten_from_
+    bucket = S.STen.zeros([total], S.F32, S.CPU)
+    lib.lamp_flatten_into_(bucket, handle_array([g.h for g in hg]), len(hg), float(n_r))
+    packed = bucket.to_numpy().copy()
+    for g, o in zip(grads, offs):                              # the layout bucket_layout describes is the one the library writes
+        assert np.array_equal(packed[o:o + g.numel()], (g.reshape(-1).float() * float(n_r)).numpy())   # f32(scale) * f32(g), as the device kernel
+    packed[-1] = n_r
+    tb = torch.from_numpy(packed)
+    dist.all_reduce(tb)                                        # lamp_comm_all_reduce on the GPU path
+    summed = S.STen.from_numpy(tb.numpy(), S.CPU)
+    outs = [S.STen.zeros(list(g.shape), S.F64, S.CPU) for g in grads]
+    lib.lamp_unflatten_from_(handle_array([o.h for o in outs]), len(outs), summed, 1)
+    avg = [torch.from_numpy(o.to_numpy()) for o in outs]
     torch.save({"grads": grads, "avg": avg, "n": n_r}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -55,6 +75,95 @@ def test_two_rank_gradient_exchange(tmp_path):
     for a0, a1, r in zip(r0["avg"], r1["avg"], ref):
         assert torch.equal(a0, a1), "every rank must hold the same averaged gradient"
         assert torch.allclose(a0.double(), r, rtol=1e-6, atol=1e-7)
+
+
+_CP_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+from lamp_amd import distributed as D
+cp = D.init_control_plane(timeout=30.0)
+r = cp.get_rank()
+uid = D.exchange_unique_id(cp, lambda: bytes(range(128)))
+assert uid == bytes(range(128)), "every rank ends up with root's 128 bytes"
+assert cp.all_reduce_max(1.0 + r) == float(cp.get_world_size())
+assert cp.all_reduce_sum(0.5) == 0.5 * cp.get_world_size()
+assert cp.all_gather({"rank": r}) == [{"rank": k} for k in range(cp.get_world_size())]
+for _ in range(50):
+    cp.barrier()
+assert cp.broadcast_bytes(b"xyz" if r == 1 else None, root=1) == b"xyz"
+cp.close()
+print("ok", r)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tcp_control_plane(tmp_path, world):
+    """rank 0 publishes its port in the rendezvous file, the others find it; unique-id hand-over, barrier, max, gather."""
+    rdzv = str(tmp_path / "rdzv.json")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="1", LAMP_RDZV_FILE=rdzv)
+        procs.append(subprocess.Popen([sys.executable, "-c", _CP_SCRIPT, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for r, p_ in enumerate(procs):
+        out, err = p_.communicate(timeout=120)
+        assert p_.returncode == 0, err
+        assert out.strip() == f"ok {r}"
+    assert not os.path.exists(rdzv), "rank 0 removes the rendezvous record when it closes"
+
+
+def test_control_plane_rejects_a_rank_of_another_launch(tmp_path):
+    """a process that connects with the wrong world size / nonce is turned away and the clique still completes"""
+    import threading
+    rdzv = str(tmp_path / "r.json")
+    box = {}
+    th = threading.Thread(target=lambda: box.setdefault("cp", D.ControlPlane(0, 2, "127.0.0.1", 0, rdzv, 30.0)))
+    th.start()
+    import time
+    while not os.path.exists(rdzv):
+        time.sleep(0.01)
+    rec = json.load(open(rdzv))
+    s = socket.create_connection(("127.0.0.1", rec["port"]))
+    D._send_msg(s, {"rank": 1, "world": 5, "nonce": rec["nonce"]})
+    assert D._recv_msg(s)["ok"] is False
+    s.close()
+    good = D.ControlPlane(1, 2, "127.0.0.1", 0, rdzv, 30.0)
+    th.join(30)
+    assert box["cp"].peers[1] is not None
+    good.close(); box["cp"].close()
+
+
+def test_bench_dry_launch_two_ranks():
+    """`python bench.py --gpus 2` started bare becomes the launcher: two rank processes with the torchrun environment rendezvous."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line == {"dry_launch": True, "ranks": 2, "rank_list": [0, 1], "max_rank": 1.0, "n_gpus": 2}
+
+
+def test_bench_under_a_launcher_checks_the_world_size():
+    """inside a launcher's environment bench.py is ONE rank, and --gpus must agree with WORLD_SIZE"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def _visible_gpus():
+    n = C.c_int(0)
+    from lamp_amd._capi import lib
+    lib.load()
+    lib.lamp_get_num_gpus(C.byref(n))
+    return n.value
+
+
+def test_bench_multi_gpu_refuses_to_fabricate():
+    """a bare `--gpus 2` on a box with fewer than two GPUs must exit non-zero and print no result line (round 1 printed 2 x the
+    single-GPU figure)"""
+    if _visible_gpus() >= 2:
+        pytest.skip("this box really has two GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not any(l.startswith("{") for l in out.stdout.splitlines()), out.stdout
 
 
 def test_every_nth_sharding():
@@ -229,3 +338,78 @@ def test_single_process_data_parallel_step(gpu, accumulate):
                 assert_close(to_torch(hv.value), ov.value, 1e-10, "main parameters after the step")
     for a, e in zip(accs, expected_acc):
         assert abs(float(a.to_numpy()[0]) - e) <= 1e-9 * abs(e)
+
+
+@pytest.mark.gpu
+def test_state_broadcast_and_schedule_factor_single_rank(gpu):
+    """distributed `broadcast` (distributed/package.scala:683-688) as lamp_model_sync_state, and the schedule factor of the fused
+    data-parallel step: with one rank the broadcast changes nothing (incl. AdamW's step count, which travels as state()[0]) and
+    lamp_model_train_step_scheduled(comm, factor) lands on the parameters of gradients + optimizer.step(factor)."""
+    from lamp_amd import sten as S, nn
+    from lamp_amd._capi import lib
+    B = 32
+    x = S.STen.from_numpy((np.arange(B * 3 * 32 * 32) * 7919 % 1009 / 1009.0 - 0.5).reshape(B, 3, 32, 32).astype(np.float32), 0, S.F32)
+    target = S.STen.from_numpy((np.arange(B) * 7 % 100).astype(np.int64), 0)
+    uid = (C.c_uint8 * 128)(); lib.lamp_comm_get_unique_id(uid)
+    comm = C.c_void_p(); lib.lamp_comm_init_rank(C.byref(comm), 1, uid, 0)
+    n = C.c_int(0); lib.lamp_comm_count(comm, C.byref(n)); assert n.value == 1
+    r = C.c_int(-1); lib.lamp_comm_user_rank(comm, C.byref(r)); assert r.value == 0
+
+    def run(use_comm):
+        lib.lamp_manual_seed(7)
+        mod = nn.resnet(100, 0.0, S.F32, 0)
+        model = nn.SupervisedModel(mod, nn.SupervisedModel.NLL, S.STen.ones([100], S.F32, 0))
+        opt = nn.AdamW_factory(weightDecay=0.01, learningRate=1e-3)([p.value for p in mod.parameters])
+        acc = S.STen.zeros([1], S.F64, 0)
+        for k, f in enumerate((1.0, 0.5, 0.25)):
+            if use_comm:
+                if k == 1:
+                    model.sync_state(opt, comm, 0)
+                assert model.train_step(opt, x, target, acc, comm, f) == B
+            else:
+                _, g = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
+                opt.step(g, f)
+        lib.lamp_device_synchronize()
+        return [s.value.to_numpy() for s in mod.state], acc.to_numpy(), opt.state[0].to_numpy()
+
+    plain, acc0, sc0 = run(False)
+    dp, acc1, sc1 = run(True)
+    lib.lamp_comm_destroy(comm)
+    assert sc0 == sc1 == 3.0
+    assert np.array_equal(acc0, acc1)
+    for a, b in zip(plain, dp):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_allocator_defers_reuse_of_blocks_another_stream_still_uses(gpu):
+    """A tensor allocated under the compute stream and consumed on a second stream (lamp's withOtherStream, the gradient exchange):
+    after lamp_tensor_record_stream its block is not recycled while the other stream's work is pending.  Stress: the side stream is
+    kept busy with a long dependent chain reading `src`; `src` is released and the compute stream immediately allocates and overwrites
+    same-sized tensors; the side stream's result must still be computed from the original contents."""
+    from lamp_amd import sten as S
+    from lamp_amd._capi import lib
+    side = C.c_void_p(); lib.lamp_stream_get_from_pool(1, 0, C.byref(side))
+    cur = C.c_void_p(); lib.lamp_stream_get_current(0, C.byref(cur))
+    d0 = C.c_int64(0); lib.lamp_allocator_deferred_frees(0, C.byref(d0))
+    n = 1 << 22
+    for trial in range(8):
+        src = S.STen.full([n], float(trial + 1), S.F32, 0)
+        lib.lamp_stream_wait_stream(side, cur)                       # the fill is complete before the side stream reads
+        lib.lamp_tensor_record_stream(src, side)
+        lib.lamp_stream_set_current(side)
+        try:
+            t = src * 1.0
+            for _ in range(40):                                      # a long chain on the side stream, all reading src
+                t = t * 0.5 + src * 0.5
+        finally:
+            lib.lamp_stream_set_current(cur)
+        src.release()                                                # freed while the side stream still reads it
+        junk = [S.STen.full([n], -1e30, S.F32, 0) for _ in range(4)]  # would land in src's block without the deferral
+        lib.lamp_stream_synchronize(side)
+        got = t.to_numpy()
+        assert np.all(got == np.float32(trial + 1)), f"trial {trial}: the side stream read recycled memory ({got[:4]})"
+        del junk
+    d1 = C.c_int64(0); lib.lamp_allocator_deferred_frees(0, C.byref(d1))
+    assert d1.value - d0.value >= 8
+    lib.lamp_stream_release(side); lib.lamp_stream_release(cur)

@@ -196,20 +196,46 @@ def test_gemm_256_tile_all_layouts(gpu, K):
     a, b = closed_form((n, K), 1, 2.0, dt), closed_form((K, n), 77, 2.0, dt)
     A, B = to_sten(a), to_sten(b)
     ref = a.double() @ b.double()
-    assert_close(to_torch(A.mm(B)), ref, 1.6e-2, "mm")
-    assert_close(to_torch(to_sten(a.t().contiguous()).t.mm(to_sten(b.t().contiguous()).t)), ref, 1.6e-2, "mm of transposed views")
+    assert_close(to_torch(A.mm(B)), ref, 2.0 ** -7, "mm")
+    assert_close(to_torch(to_sten(a.t().contiguous()).t.mm(to_sten(b.t().contiguous()).t)), ref, 2.0 ** -7, "mm of transposed views")
     at, p = closed_form((K, n), 3, 2.0, dt), closed_form((K, n), 9, 1.0, dt)          # out[n, n] += at^T . p
     o0 = closed_form((n, n), 5, 1.0, dt)
     O = to_sten(o0)
     S.STen.addmm_out_transposed1(O, O, to_sten(at), to_sten(p), 1.0, 1.0)
-    assert_close(to_torch(O), o0.double() + at.double().t() @ p.double(), 3.2e-2, "addmm_out_transposed1")
+    assert_close(to_torch(O), o0.double() + at.double().t() @ p.double(), 2.0 ** -7, "addmm_out_transposed1")
     p2, b2 = closed_form((n, K), 11, 1.0, dt), closed_form((n, K), 13, 2.0, dt)        # out[n, n] += p2 . b2^T
     O1 = to_sten(o0)
     S.STen.addmm_out_transposed2(O1, O1, to_sten(p2), to_sten(b2), 1.0, 1.0)
-    assert_close(to_torch(O1), o0.double() + p2.double() @ b2.double().t(), 3.2e-2, "addmm_out_transposed2")
+    assert_close(to_torch(O1), o0.double() + p2.double() @ b2.double().t(), 2.0 ** -7, "addmm_out_transposed2")
     bias = closed_form((1, n), 4, 1.0, dt)
     o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), A, B, to_sten(bias))
-    assert_close(to_torch(S.STen(o)), ref + bias.double(), 3.2e-2, "linear_bias")
+    assert_close(to_torch(S.STen(o)), ref + bias.double(), 2.0 ** -7, "linear_bias")
+
+
+def test_gemm_4096_cube_is_the_benchmarked_linear(gpu):
+    """BASELINE.json config 2 at full size: lamp `Linear(4096, 4096, bias)` on x[4096, 4096] in bf16 - y = x.W + b, dW += x^T.p,
+    dX += p.W^T with beta = 1 into non-zero accumulators (MatMul's backward closures, ops.scala:665-695) - against f64 on 192
+    sampled rows of each result (all 4096 columns), per element at rtol 2^-7: one bf16 rounding of an f32-accumulated sum."""
+    dt, n = torch.bfloat16, 4096
+    x, w = closed_form((n, n), 1, 2.0, dt), closed_form((n, n), 77, 2.0, dt)
+    b, p = closed_form((1, n), 3, 1.0, dt), closed_form((n, n), 9, 1.0, dt)
+    dw0, dx0 = closed_form((n, n), 5, 8.0, dt), closed_form((n, n), 6, 8.0, dt)
+    X, W, Bv, P = to_sten(x), to_sten(w), to_sten(b), to_sten(p)
+    o = C.c_void_p(); lib.lamp_linear_bias(C.byref(o), X, W, Bv)
+    Y = S.STen(o)
+    dW, dX = to_sten(dw0), to_sten(dx0)
+    S.STen.addmm_out_transposed1(dW, dW, X, P, 1.0, 1.0)             # dW += x^T . p
+    S.STen.addmm_out_transposed2(dX, dX, P, W, 1.0, 1.0)             # dX += p . W^T
+    rows = torch.tensor(sorted(set(((torch.arange(192) * 2654435761) % n).tolist())))
+    xd, wd, pd = x.double(), w.double(), p.double()
+    y, dw, dx = to_torch(Y), to_torch(dW), to_torch(dX)
+    assert_close(y[rows], xd[rows] @ wd + b.double(), 2.0 ** -7, "y = x.W + b")
+    assert_close(dw[rows], dw0.double()[rows] + xd[:, rows].t() @ pd, 2.0 ** -7, "dW += x^T.p")
+    assert_close(dx[rows], dx0.double()[rows] + pd[rows] @ wd.t(), 2.0 ** -7, "dX += p.W^T")
+    # f32 at the same size: <= 1e-5 per element (BASELINE.json's forward bar)
+    xf, wf = x.float(), w.float()
+    yf = to_torch(to_sten(xf).mm(to_sten(wf)))
+    assert_close(yf[rows], xd[rows] @ wd, 1e-5, "f32 x.W")
 
 
 @pytest.mark.parametrize("M,N,K", [(768, 768, 12288), (256, 768, 6144), (768, 3072, 4096), (512, 256, 2048), (24576, 768, 2048), (22016, 768, 768)])
@@ -311,6 +337,27 @@ def test_log_softmax_and_nll(gpu, dt):
         gy = torch.ones((), dtype=dt) if red else closed_form((37, 100), 3, 1.0, dt)
         o = C.c_void_p(); lib.lamp_mse_loss_backward(C.byref(o), to_sten(gy), X, to_sten(t), red)
         assert_close(to_torch(S.STen(o)), aten.mse_loss_backward(gy, x, t, red).double(), tol * 4, "mse backward")
+
+
+def test_nll_target_out_of_range_raises_at_the_next_host_wait(gpu):
+    """ATen raises a device assert for a class index outside [0, C) that is not ignore_index (the reference calls
+    ATen.nll_loss_forward, ops.scala:1249-1304).  Here the kernel reports it and the next host wait (item / copy to host /
+    synchronize) raises a LampError - a label or vocabulary mismatch must not train silently on a subset of the rows."""
+    from lamp_amd._capi import LampError
+    x = to_sten(aten._log_softmax(closed_form((8, 5), 3, 2.0, torch.float32), 1, False))
+    for bad, red in ((5, 1), (-1, 2), (7, 0)):
+        target = torch.arange(8) % 5
+        target[3] = bad
+        o, tw = C.c_void_p(), C.c_void_p()
+        lib.lamp_nll_loss_forward(C.byref(o), C.byref(tw), x, to_sten(target), None, red, -100)     # the launch itself succeeds
+        with pytest.raises(LampError, match="nll_loss: a target class index is outside"):
+            S.STen(o).to_numpy()
+        S.STen(tw).release()
+    # the flag is cleared by the raise: a valid call afterwards is clean
+    o, tw = C.c_void_p(), C.c_void_p()
+    lib.lamp_nll_loss_forward(C.byref(o), C.byref(tw), x, to_sten(torch.arange(8) % 5), None, 1, -100)
+    assert np.isfinite(S.STen(o).item())
+    lib.lamp_device_synchronize()
 
 
 @pytest.mark.parametrize("dt", DTYPES)
