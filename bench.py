@@ -248,6 +248,8 @@ def main():
         units_per_step = B * ctx
         metric, unit = "language-model training tokens/sec", "tokens/s"
         config = {"workload": "example-autoregressivelm LanguageModelLoss training step (12 x 768 x 12 heads, context 384, vocabulary 256), synthetic tokens",
+                  "attention": ("as written for CUDA: (batch, sequence, heads, d) views read as (batch, heads, sequence, d)" if os.environ.get("LAMP_ATTENTION_AS_WRITTEN_FOR_CUDA") == "1"
+                                else "reference CPU semantics: causal per-head attention over the 384 positions (flash kernels on strided views)"),
                   "per_gpu_batch": B, "global_batch": B * a.gpus, "parallelism": f"dp{a.gpus}" if a.gpus > 1 else "single",
                   "optimizer": "AdamW lr 1e-4 wd 0.1 (matrices) beta2 0.95 clip 1" + (" mixedPrecision" if a.dtype == "bf16" else "")}
     elif a.workload == "gemm":

@@ -64,6 +64,12 @@ int lamp_module_resnet(lamp_module** out, int64_t num_classes, double dropout, i
 int lamp_module_embedding(lamp_module** out, int64_t classes, int64_t dimensions, int dtype, int device);            /* Embedding.scala:35-48 */
 int lamp_module_multihead_attention(lamp_module** out, int64_t dQ, int64_t dK, int64_t dV, int64_t hidden_per_head, int64_t outf, double dropout,
                                     int64_t num_heads, int dtype, int device, int linearized, int causal_mask);      /* Transformer.scala:619-641; vars (q, k, v), tensors (maxLength?) */
+/* What the fused-operator branch of MultiheadAttention.multiheadAttention (Transformer.scala:946-962) computes.  0 (default): the
+ * arithmetic of the reference's ATen CPU path (its composed branch, :963-1001): per-head attention over the sequence; the flash
+ * kernels read (batch, heads, sequence, d) views of the projections in place.  1: the call as written for CUDA - (batch, sequence,
+ * heads, d) views handed to an operator that reads dimension 1 as heads (attention over the heads of each token).  Process-wide;
+ * returns the previous value in *previous_or_null.  Environment default: LAMP_ATTENTION_AS_WRITTEN_FOR_CUDA=1. */
+int lamp_attention_fused_call_as_written(int on, int* previous_or_null);
 int lamp_module_transformer_encoder_block(lamp_module** out, int64_t in, int64_t attention_hidden_per_head, int64_t attention_num_heads,
                                           int64_t mlp_hidden, int64_t outf, double dropout, int dtype, int device, int linearized, int gpt_order,
                                           int causal_mask);                                                            /* :492-530; vars (x), tensors (maxLength?) */

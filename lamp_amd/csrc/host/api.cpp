@@ -367,6 +367,13 @@ int lamp_data_parallel_step(lamp_model* main_model, lamp_optimizer* o, lamp_mode
   *num_examples = data_parallel_synchronous_step(main_model->model, *o->o, reps, xs, ts, as, zero_grad, step, schedule_factor);
   LAMP_API_END
 }
+int lamp_attention_fused_call_as_written(int on, int* previous) {
+  LAMP_API_BEGIN
+  bool& f = MultiheadAttention::fused_call_as_written();
+  if (previous) *previous = f ? 1 : 0;
+  f = on != 0;
+  LAMP_API_END
+}
 int lamp_model_release(lamp_model* m) { LAMP_API_BEGIN delete m; LAMP_API_END }
 
 }  // extern "C"

@@ -124,6 +124,10 @@ Var MultiheadAttention::linearizedAttention(const Var& q, const Var& k, const Va
   Var denom = F::bmm(qF, tmp2);
   return F::div(enumerator, F::const_add(denom, 1e-5));
 }
+bool& MultiheadAttention::fused_call_as_written() {
+  static bool v = [] { const char* e = getenv("LAMP_ATTENTION_AS_WRITTEN_FOR_CUDA"); return e && e[0] == '1'; }();
+  return v;
+}
 Var MultiheadAttention::multiheadAttention(const Var& query, const Var& keys, const Var& values, const Ten& maxLength, double dropout,
                                            bool trainDropout, const Var& wQuery, const Var& wKeys, const Var& wValues, const Var& wOutput,
                                            int64_t numHeads, bool linearized, bool causalMask) {   // :889-1006
@@ -142,14 +146,28 @@ Var MultiheadAttention::multiheadAttention(const Var& query, const Var& keys, co
   Var q1 = mm1(query, wQuery, true), k1 = mm1(keys, wKeys, true), v1 = mm1(values, wValues, true);
   const int64_t nQ = q1->value.size(1), nK = k1->value.size(1), nV = v1->value.size(1), nB = q1->value.size(0);
   const bool aligned = nQ % 8 == 0 && nK % 8 == 0 && nV % 8 == 0;
-  // isCuda is always true behind this library
-  const bool useEfficientAttentionKernel = aligned && nQ == nK && !linearized && (causalMask || !maxLength.defined()) && (dropout == 0.0 || !trainDropout);
   Var attention;
-  if (useEfficientAttentionKernel) {
-    // The reference hands the fused operator views shaped (batch, sequence, heads, d) (:930-945); the operator reads dimension 1 as
-    // the heads and dimension 2 as the sequence.  The call is reproduced as it is.
-    attention = F::flatten(F::scaled_dot_product_attention(F::view(q1, {nB, nQ, numHeads, -1}), F::view(k1, {nB, nQ, numHeads, -1}),
-                                                           F::view(v1, {nB, nQ, numHeads, -1}), causalMask), 2, 3);
+  if (fused_call_as_written()) {
+    // opt-in: the reference's CUDA branch literally.  isCuda is always true behind this library
+    const bool useEfficientAttentionKernel = aligned && nQ == nK && !linearized && (causalMask || !maxLength.defined()) && (dropout == 0.0 || !trainDropout);
+    if (useEfficientAttentionKernel) {
+      // (batch, sequence, heads, d) views (:930-945); the operator reads dimension 1 as the heads and dimension 2 as the sequence
+      attention = F::flatten(F::scaled_dot_product_attention(F::view(q1, {nB, nQ, numHeads, -1}), F::view(k1, {nB, nQ, numHeads, -1}),
+                                                             F::view(v1, {nB, nQ, numHeads, -1}), causalMask), 2, 3);
+      return mm1(attention, wOutput, true);
+    }
+  }
+  // Default: the arithmetic of the composed branch, which is what the reference's CPU path always runs.  With a causal mask and no
+  // explicit lengths that branch is softmax(Q K^T / sqrt(d) + causal mask) V per (batch, head) - exactly the fused operator on
+  // (batch, heads, sequence, d) operands, so the flash kernels take strided views of the projections (no transposeIn copies) and
+  // hand back a (batch, heads, sequence, d) view of (batch, sequence, heads, d) storage (transposeOut is free).  Every other case
+  // (no mask: raw scores without softmax, :797-801; explicit maxLength; linearized; active dropout) runs composed as written.
+  const bool fusedEqualsComposed = causalMask && !maxLength.defined() && nQ == nK && !linearized && (dropout == 0.0 || !trainDropout) &&
+                                   q1->value.dtype() == kBF16;
+  if (fusedEqualsComposed) {
+    auto heads_first = [&](const Var& x, int64_t n) { return F::transpose(F::view(x, {nB, n, numHeads, -1}), 1, 2); };   // (B, H, S, d) view
+    Var o = F::scaled_dot_product_attention(heads_first(q1, nQ), heads_first(k1, nK), heads_first(v1, nV), true);
+    attention = F::flatten(F::transpose(o, 1, 2), 2, 3);
   } else {
     Var q1t = transposeIn(q1, numHeads), k1t = transposeIn(k1, numHeads), v1t = transposeIn(v1, numHeads);
     Ten maxLengthRepeated;

@@ -32,6 +32,12 @@ struct MultiheadAttention : Module {        // Transformer.scala:572-616; state 
   Var forward_multi(const std::vector<Var>& xs, const std::vector<Ten>& aux) override;
   void set_training(bool) override {}       // TrainingMode.identity (Transformer.scala:644-645)
 
+  // Which arithmetic the fused-operator branch of multiheadAttention (Transformer.scala:946-962) stands for:
+  //   false (default) - the meaning of the reference's ATen CPU path, i.e. of its composed branch (:963-1001): every head attends
+  //                     over the sequence.  The fused kernels get (batch, heads, sequence, d) VIEWS of the projections;
+  //   true            - the call exactly as written for CUDA: (batch, sequence, heads, d) views handed to an operator that reads
+  //                     dimension 1 as the heads - attention over the HEADS of each token (SURVEY 8a-17's layout hazard).
+  static bool& fused_call_as_written();
   // companion object (Transformer.scala:667-1008)
   static Var sequenceMask(const Ten& maxLength, const Var& maskable, double fill);
   static Var maskedSoftmax(const Var& input, const Ten& maxLength);

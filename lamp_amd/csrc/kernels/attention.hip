@@ -89,6 +89,11 @@ __device__ __forceinline__ float at_add1(float a, float b) { float r; asm("v_add
 // before, but the LAST workgroups of the launch are now the lightest ones of every head instead of whole heads (the tail of a
 // launch with only ~8 workgroup generations was 15 % of it).
 constexpr int AT_CH = 16;
+// Where row `r` of (batch b, head h) starts, in elements: b * sb + h * sh + r * sr.  Contiguous (B, heads, S, d): {S d heads, S d, d};
+// a (B, heads, S, d) VIEW of projections stored (B, S, heads, d) - what lamp's multi-head attention holds after `mm1` + `view`
+// (Transformer.scala:925-945) - : {S heads d, d, heads d}.  The kernels read and write such views in place: no transposed copies.
+struct AtLay { int64_t sb, sh, sr; };
+__device__ __forceinline__ int64_t at_base(const AtLay& l, int bh, int H) { const int b = bh / H, h = bh - b * H; return b * l.sb + h * l.sh; }
 __device__ __forceinline__ void at_block_of(int causal, int& bh, int& qb) {
   const int nqb = gridDim.x, BH = gridDim.y;
   if (!causal) { bh = blockIdx.y; qb = blockIdx.x; return; }
@@ -101,7 +106,8 @@ __device__ __forceinline__ void at_block_of(int causal, int& bh, int& qb) {
 
 template <int DH>
 __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                                bf16_t* __restrict__ o, float* __restrict__ lse, int Sq, int Sk, float scale, int causal) {
+                                                                bf16_t* __restrict__ o, float* __restrict__ lse, int Sq, int Sk, float scale, int causal,
+                                                                int H, AtLay lq, AtLay lk, AtLay lv, AtLay lo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DH / 32;                 // k-steps of the S^T product
   constexpr int DT = DH / 16;                 // 16-row tiles of O^T
@@ -114,9 +120,9 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
   at_block_of(causal, bh_, qb_);                // causal: the query blocks with the most keys go first
   const int64_t bh = bh_;
   const int q0 = qb_ * AT_BQ;
-  const bf16_t* qp = q + bh * (int64_t)Sq * DH;
-  const bf16_t* kp = k + bh * (int64_t)Sk * DH;
-  const bf16_t* vp = v + bh * (int64_t)Sk * DH;
+  const bf16_t* qp = q + at_base(lq, bh_, H);
+  const bf16_t* kp = k + at_base(lk, bh_, H);
+  const bf16_t* vp = v + at_base(lv, bh_, H);
   char* Vl = smem;                            // [2][KIMG]  (first: the immediate offsets of its reads stay below 64 KiB)
   char* Kl = smem + 2 * KIMG;                 // [2][KIMG]
 
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
     qi[t] = qw0 + t * 16 + (lane & 15);
     const int qrow = qi[t] < Sq ? qi[t] : Sq - 1;
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) qf[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(qp + (int64_t)qrow * DH + ks * 32 + g * 8));
+    for (int ks = 0; ks < KS; ks++) qf[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(qp + (int64_t)qrow * lq.sr + ks * 32 + g * 8));
   }
 
   auto dma_tile = [&](int kt, int buf) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
       const int sub = piece >> 3, pp = (piece & 7) * 64 + lane;
       const int row = pp >> 3, chunk = (pp & 7) ^ (row & 7);
       int key = key0 + row; key = key < Sk ? key : Sk - 1;
-      __builtin_amdgcn_global_load_lds((at_glb_t*)(kp + (int64_t)key * DH + sub * 64 + chunk * 8), (at_lds_t*)(Kl + buf * KIMG + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((at_glb_t*)(kp + (int64_t)key * lk.sr + sub * 64 + chunk * 8), (at_lds_t*)(Kl + buf * KIMG + piece * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < VP / 4; i++) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
       const int row = pp / CPR, c = pp % CPR;
       const int col8 = ((((c >> 1) ^ (row & (DH / 16 - 1)))) << 1) | (c & 1);
       int key = key0 + row; key = key < Sk ? key : Sk - 1;
-      __builtin_amdgcn_global_load_lds((at_glb_t*)(vp + (int64_t)key * DH + col8 * 8), (at_lds_t*)(Vl + buf * KIMG + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((at_glb_t*)(vp + (int64_t)key * lv.sr + col8 * 8), (at_lds_t*)(Vl + buf * KIMG + piece * 1024), 16, 0, 0);
     }
   };
 
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_fwd_kernel(const bf16_t* __
     const float l_tot = at_sum_x16_x32(l_run[t]);
     if (qi[t] >= Sq) continue;
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    bf16_t* op = o + (bh * (int64_t)Sq + qi[t]) * DH;
+    bf16_t* op = o + at_base(lo, bh_, H) + (int64_t)qi[t] * lo.sr;
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) {
       const bf16_t o0(acc_o[t][dt][0] * inv), o1(acc_o[t][dt][1] * inv), o2(acc_o[t][dt][2] * inv), o3(acc_o[t][dt][3] * inv);
@@ -318,24 +324,48 @@ bool small_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
 bool small_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
                          Tensor* dv, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
 
-bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
-                         int64_t Dv, int is_causal, double scale, hipStream_t st) {
-  if (small_attention_fwd(q, k, v, out, lse, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
+// 4-D (B, heads, S, d) tensor whose rows are d contiguous elements: contiguous tensors and (B, heads, S, d) views of (B, S, heads, d)
+// storage alike.  16-byte packets need every stride to be a multiple of 8 elements and an aligned base.
+bool at_layout_of(const Tensor* t, AtLay* l) {
+  if (t->ndim != 4 || (t->sizes[3] != 1 && t->strides[3] != 1)) return false;
+  l->sb = t->sizes[0] > 1 ? t->strides[0] : 0;
+  l->sh = t->sizes[1] > 1 ? t->strides[1] : 0;
+  l->sr = t->sizes[2] > 1 ? t->strides[2] : t->sizes[3];
+  if ((l->sb | l->sh | l->sr) & 7) return false;
+  return (((uintptr_t)t->raw()) & 15) == 0;
+}
+// result buffer for a (B, heads, S, d) operator whose input `like` has that shape: laid out as `like` is - a view over
+// (B, S, heads, d) storage when `like` is one (so that lamp's transpose(1, 2) + flatten back to (B, S, heads * d) is free)
+Tensor* at_new_like_layout(const Tensor* like, int64_t B, int64_t H, int64_t S, int64_t D, int dtype) {
+  const bool permuted = like->ndim == 4 && H > 1 && S > 1 && like->strides[1] < like->strides[2];
+  if (!permuted) { int64_t sz[4] = {B, H, S, D}; return new_tensor(sz, 4, dtype, like->device()); }
+  int64_t sz[4] = {B, S, H, D};
+  Hold buf(new_tensor(sz, 4, dtype, like->device()));
+  int64_t vs[4] = {B, H, S, D}, vst[4] = {S * H * D, D, H * D, 1};
+  return new_view(buf.get(), vs, vst, 4, buf->offset);
+}
+
+// q, k, v, out: (B, heads, S, d) bf16 in any AtLay layout; lse: contiguous f32 [B, heads, Sq] (as ATen's logsumexp).
+// Returns false when the shape / layout is not covered (the caller composes the op instead).
+bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int is_causal, double scale, hipStream_t st) {
+  const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3], BH = B * H;
+  if (q->is_contiguous() && k->is_contiguous() && v->is_contiguous() && out->is_contiguous() &&
+      small_attention_fwd(q, k, v, out, lse, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
   static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
   if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
-  if ((((uintptr_t)q->data() | (uintptr_t)k->data() | (uintptr_t)v->data() | (uintptr_t)out->data()) & 15) != 0) return false;
+  AtLay lq, lk, lv, lo;
+  if (!at_layout_of(q, &lq) || !at_layout_of(k, &lk) || !at_layout_of(v, &lv) || !at_layout_of(out, &lo) || !lse->is_contiguous()) return false;
   KernelTimer kt("sdpa_flash_fwd", 4.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 2.0 * Sk) * D * 2, st);
   const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
   const size_t lds = (size_t)4 * AT_BK * D * 2;
   if (D == 128) {
-    static bool attr = false;
     allow_big_lds((const void*)sdpa_flash_fwd_kernel<128>);
     hipLaunchKernelGGL((sdpa_flash_fwd_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), out->ptr<bf16_t>(),
-                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal, (int)H, lq, lk, lv, lo);
   } else {
     hipLaunchKernelGGL((sdpa_flash_fwd_kernel<64>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), out->ptr<bf16_t>(),
-                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                       lse->ptr<float>(), (int)Sq, (int)Sk, (float)scale, is_causal, (int)H, lq, lk, lv, lo);
   }
   LAMP_LAUNCH_CHECK();
   return true;
@@ -354,7 +384,7 @@ bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tens
 // this one's result: the dq kernel computes S^T / dP^T (lane = one query, 4 keys per tile), the dkv kernel S / dP (lane = one
 // key, 4 queries per tile), and the packed bf16 probabilities feed the next MFMA's B operand with no cross-lane traffic.
 // =====================================================================================================================
-template <int DH> __device__ __forceinline__ void at_dma_rows(const bf16_t* base, int row0, int nrows, char* lds, int wid, int lane) {
+template <int DH> __device__ __forceinline__ void at_dma_rows(const bf16_t* base, int64_t sr, int row0, int nrows, char* lds, int wid, int lane) {
   constexpr int VP = AT_BK * DH * 2 / 1024, CPR = DH / 8;
 #pragma unroll
   for (int i = 0; i < VP / 4; i++) {
@@ -363,18 +393,22 @@ template <int DH> __device__ __forceinline__ void at_dma_rows(const bf16_t* base
     const int row = pp / CPR, c = pp % CPR;
     const int col8 = ((((c >> 1) ^ (row & (DH / 16 - 1)))) << 1) | (c & 1);
     int r = row0 + row; r = r < nrows ? r : nrows - 1;
-    __builtin_amdgcn_global_load_lds((at_glb_t*)(base + (int64_t)r * DH + col8 * 8), (at_lds_t*)(lds + piece * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((at_glb_t*)(base + (int64_t)r * sr + col8 * 8), (at_lds_t*)(lds + piece * 1024), 16, 0, 0);
   }
 }
 
-__global__ __launch_bounds__(256) void sdpa_bwd_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ o, float* __restrict__ dsum, int64_t rows, int D) {
+__global__ __launch_bounds__(256) void sdpa_bwd_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ o, float* __restrict__ dsum, int64_t rows, int D,
+                                                            int Sq, int H, AtLay lg, AtLay lo) {
   // 16 lanes per row, 8-element packets
   const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
   const int l = threadIdx.x & 15;
   float acc = 0.f;
   if (row < rows) {
+    const int bh = (int)(row / Sq), r = (int)(row - (int64_t)bh * Sq);
+    const bf16_t* gp = dO + at_base(lg, bh, H) + (int64_t)r * lg.sr;
+    const bf16_t* op = o + at_base(lo, bh, H) + (int64_t)r * lo.sr;
     for (int c = l * 8; c < D; c += 128) {
-      const at_s8 a = *reinterpret_cast<const at_s8*>(dO + row * D + c), b = *reinterpret_cast<const at_s8*>(o + row * D + c);
+      const at_s8 a = *reinterpret_cast<const at_s8*>(gp + c), b = *reinterpret_cast<const at_s8*>(op + c);
 #pragma unroll
       for (int j = 0; j < 8; j++) acc += __uint_as_float((unsigned)(unsigned short)a[j] << 16) * __uint_as_float((unsigned)(unsigned short)b[j] << 16);
     }
@@ -387,7 +421,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dsum_kernel(const bf16_t* __rest
 template <int DH>
 __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                    const bf16_t* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                                   bf16_t* __restrict__ dq, int Sq, int Sk, float scale, int causal) {
+                                                                   bf16_t* __restrict__ dq, int Sq, int Sk, float scale, int causal,
+                                                                   int H, AtLay lq, AtLay lk, AtLay lv, AtLay lg, AtLay ldq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DH / 32, DT = DH / 16, KIMG = AT_BK * DH * 2, PITCH = DH * 2;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -397,10 +432,10 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t*
   at_block_of(causal, bh_, qb_);
   const int64_t bh = bh_;
   const int q0 = qb_ * AT_BQ;
-  const bf16_t* qp = q + bh * (int64_t)Sq * DH;
-  const bf16_t* dop = dO + bh * (int64_t)Sq * DH;
-  const bf16_t* kp = k + bh * (int64_t)Sk * DH;
-  const bf16_t* vp = v + bh * (int64_t)Sk * DH;
+  const bf16_t* qp = q + at_base(lq, bh_, H);
+  const bf16_t* dop = dO + at_base(lg, bh_, H);
+  const bf16_t* kp = k + at_base(lk, bh_, H);
+  const bf16_t* vp = v + at_base(lv, bh_, H);
   char* Kl = smem;                            // [2][KIMG]
   char* Vl = smem + 2 * KIMG;                 // [2][KIMG]
 
@@ -414,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t*
     const int qrow = qi[t] < Sq ? qi[t] : Sq - 1;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      qf[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(qp + (int64_t)qrow * DH + ks * 32 + g * 8));
-      dof[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(dop + (int64_t)qrow * DH + ks * 32 + g * 8));
+      qf[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(qp + (int64_t)qrow * lq.sr + ks * 32 + g * 8));
+      dof[t][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(dop + (int64_t)qrow * lg.sr + ks * 32 + g * 8));
     }
     lse2[t] = lse[bh * (int64_t)Sq + qrow] * 1.44269504088896340736f;
     dsm[t] = dsum[bh * (int64_t)Sq + qrow];
@@ -438,12 +473,12 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t*
 
   int nkt = (Sk + AT_BK - 1) / AT_BK;
   if (causal) { const int last_q = min(q0 + AT_BQ, Sq) - 1; nkt = min(nkt, last_q / AT_BK + 1); }
-  if (nkt > 0) { at_dma_rows<DH>(kp, 0, Sk, Kl, wid, lane); at_dma_rows<DH>(vp, 0, Sk, Vl, wid, lane); }
+  if (nkt > 0) { at_dma_rows<DH>(kp, lk.sr, 0, Sk, Kl, wid, lane); at_dma_rows<DH>(vp, lv.sr, 0, Sk, Vl, wid, lane); }
   for (int kt = 0; kt < nkt; kt++) {
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) { at_dma_rows<DH>(kp, (kt + 1) * AT_BK, Sk, Kl + (buf ^ 1) * KIMG, wid, lane); at_dma_rows<DH>(vp, (kt + 1) * AT_BK, Sk, Vl + (buf ^ 1) * KIMG, wid, lane); }
+    if (kt + 1 < nkt) { at_dma_rows<DH>(kp, lk.sr, (kt + 1) * AT_BK, Sk, Kl + (buf ^ 1) * KIMG, wid, lane); at_dma_rows<DH>(vp, lv.sr, (kt + 1) * AT_BK, Sk, Vl + (buf ^ 1) * KIMG, wid, lane); }
     if (causal && kt * AT_BK > qw0 + 16 * AT_QT - 1) continue;
     const unsigned koff = buf * KIMG, voff = 2 * KIMG + buf * KIMG;
     const bool need_mask = (kt * AT_BK + AT_BK > Sk) || (causal && kt * AT_BK + AT_BK - 1 > qw0);
@@ -514,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t*
 #pragma unroll
   for (int t = 0; t < AT_QT; t++) {
     if (qi[t] >= Sq) continue;
-    bf16_t* op = dq + (bh * (int64_t)Sq + qi[t]) * DH;
+    bf16_t* op = dq + at_base(ldq, bh_, H) + (int64_t)qi[t] * ldq.sr;
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) {
       const bf16_t o0(acc[t][dt][0]), o1(acc[t][dt][1]), o2(acc[t][dt][2]), o3(acc[t][dt][3]);
@@ -531,7 +566,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dq_kernel(const bf16_t*
 template <int DH, int NK>
 __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                                 bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int Sq, int Sk, float scale, int causal) {
+                                                                 bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int Sq, int Sk, float scale, int causal,
+                                                                 int H, AtLay lq, AtLay lk, AtLay lv, AtLay lg, AtLay ldk, AtLay ldv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DH / 32, DT = DH / 16, KIMG = AT_BK * DH * 2, PITCH = DH * 2;
   constexpr int BKW = 4 * 16 * NK;             // keys per workgroup
@@ -539,11 +575,12 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const int64_t bh = blockIdx.y;
+  const int bh_ = blockIdx.y;
   const int k0 = blockIdx.x * BKW;
-  const bf16_t* qp = q + bh * (int64_t)Sq * DH;
-  const bf16_t* dop = dO + bh * (int64_t)Sq * DH;
-  const bf16_t* kp = k + bh * (int64_t)Sk * DH;
-  const bf16_t* vp = v + bh * (int64_t)Sk * DH;
+  const bf16_t* qp = q + at_base(lq, bh_, H);
+  const bf16_t* dop = dO + at_base(lg, bh_, H);
+  const bf16_t* kp = k + at_base(lk, bh_, H);
+  const bf16_t* vp = v + at_base(lv, bh_, H);
   const float* lsep = lse + bh * (int64_t)Sq;
   const float* dsp = dsum + bh * (int64_t)Sq;
   char* Ql = smem;                            // [2][KIMG]
@@ -559,8 +596,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
     const int krow = ki[u] < Sk ? ki[u] : Sk - 1;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      kfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(kp + (int64_t)krow * DH + ks * 32 + g * 8));
-      vfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(vp + (int64_t)krow * DH + ks * 32 + g * 8));
+      kfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(kp + (int64_t)krow * lk.sr + ks * 32 + g * 8));
+      vfr[u][ks] = __builtin_bit_cast(at_bf8, *reinterpret_cast<const at_s8*>(vp + (int64_t)krow * lv.sr + ks * 32 + g * 8));
     }
   }
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -588,14 +625,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
     }
   };
   const unsigned sbase = lds0 + 4 * KIMG + 16 * g;   // + buf * 512 + array * 256 + m * 64
-  if (qt0 < nqt) { at_dma_rows<DH>(qp, qt0 * AT_BK, Sq, Ql, wid, lane); at_dma_rows<DH>(dop, qt0 * AT_BK, Sq, Ol, wid, lane); dma_stats(qt0, 0); }
+  if (qt0 < nqt) { at_dma_rows<DH>(qp, lq.sr, qt0 * AT_BK, Sq, Ql, wid, lane); at_dma_rows<DH>(dop, lg.sr, qt0 * AT_BK, Sq, Ol, wid, lane); dma_stats(qt0, 0); }
   for (int qt = qt0; qt < nqt; qt++) {
     const int buf = (qt - qt0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (qt + 1 < nqt) {
-      at_dma_rows<DH>(qp, (qt + 1) * AT_BK, Sq, Ql + (buf ^ 1) * KIMG, wid, lane);
-      at_dma_rows<DH>(dop, (qt + 1) * AT_BK, Sq, Ol + (buf ^ 1) * KIMG, wid, lane);
+      at_dma_rows<DH>(qp, lq.sr, (qt + 1) * AT_BK, Sq, Ql + (buf ^ 1) * KIMG, wid, lane);
+      at_dma_rows<DH>(dop, lg.sr, (qt + 1) * AT_BK, Sq, Ol + (buf ^ 1) * KIMG, wid, lane);
       dma_stats(qt + 1, buf ^ 1);
     }
     const unsigned qoff = buf * KIMG, ooff = 2 * KIMG + buf * KIMG;
@@ -691,8 +728,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
 #pragma unroll
   for (int u = 0; u < NK; u++) {
     if (ki[u] >= Sk) continue;
-    bf16_t* okp = dk + (bh * (int64_t)Sk + ki[u]) * DH;
-    bf16_t* ovp = dv + (bh * (int64_t)Sk + ki[u]) * DH;
+    bf16_t* okp = dk + at_base(ldk, bh_, H) + (int64_t)ki[u] * ldk.sr;
+    bf16_t* ovp = dv + at_base(ldv, bh_, H) + (int64_t)ki[u] * ldv.sr;
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) {
       {
@@ -711,27 +748,32 @@ __global__ __launch_bounds__(256, 2) void sdpa_flash_bwd_dkv_kernel(const bf16_t
 
 // dq, dk, dv <- grad_out, q, k, v, out, lse (f32).  Returns false when the shape is not covered.
 bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
-                         Tensor* dv, Tensor* dsum /* f32 [BH * Sq] scratch */, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal,
-                         double scale, hipStream_t st) {
-  if (small_attention_bwd(go, q, k, v, out, lse, dq, dk, dv, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
+                         Tensor* dv, Tensor* dsum /* f32 [BH * Sq] scratch */, int is_causal, double scale, hipStream_t st) {
+  const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3], BH = B * H;
+  const Tensor* all[9] = {go, q, k, v, out, lse, dq, dk, dv};
+  bool contig = true;
+  for (auto* t : all) contig = contig && t->is_contiguous();
+  if (contig && small_attention_bwd(go, q, k, v, out, lse, dq, dk, dv, BH, Sq, Sk, D, Dv, is_causal, scale, st)) return true;
   static const bool enabled = [] { const char* e = getenv("LAMP_FLASH_ATTENTION"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
   if (q->dtype != kBF16 || lse->dtype != kF32 || D != Dv || !(D == 64 || D == 128) || Sq < 1 || Sk < 1 || Sq > (1 << 30) || Sk > (1 << 30)) return false;
+  AtLay lq, lk, lv, lg, lo, ldq, ldk, ldv;
+  if (!at_layout_of(q, &lq) || !at_layout_of(k, &lk) || !at_layout_of(v, &lv) || !at_layout_of(go, &lg) || !at_layout_of(out, &lo) ||
+      !at_layout_of(dq, &ldq) || !at_layout_of(dk, &ldk) || !at_layout_of(dv, &ldv) || !lse->is_contiguous()) return false;
   const int64_t rows = BH * Sq;
   hipLaunchKernelGGL(sdpa_bwd_dsum_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, go->ptr<bf16_t>(), out->ptr<bf16_t>(), dsum->ptr<float>(),
-                     rows, (int)D);
+                     rows, (int)D, (int)Sq, (int)H, lg, lo);
   const size_t lds = (size_t)4 * AT_BK * D * 2 + 1024;
   {
     KernelTimer kt("sdpa_flash_bwd_dq", 6.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (3.0 * Sq + 2.0 * Sk) * D * 2, st);
     const dim3 grid((unsigned)((Sq + AT_BQ - 1) / AT_BQ), (unsigned)BH);
     if (D == 128) {
-      static bool attr = false;
       allow_big_lds((const void*)sdpa_flash_bwd_dq_kernel<128>);
       hipLaunchKernelGGL((sdpa_flash_bwd_dq_kernel<128>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
-                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal, (int)H, lq, lk, lv, lg, ldq);
     } else {
       hipLaunchKernelGGL((sdpa_flash_bwd_dq_kernel<64>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(), go->ptr<bf16_t>(),
-                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal);
+                         lse->ptr<float>(), dsum->ptr<float>(), dq->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, is_causal, (int)H, lq, lk, lv, lg, ldq);
     }
     LAMP_LAUNCH_CHECK();
   }
@@ -739,11 +781,11 @@ bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, con
     KernelTimer kt("sdpa_flash_bwd_dkv", 8.0 * (double)BH * Sq * Sk * D * (is_causal ? 0.5 : 1.0), (double)BH * (2.0 * Sq + 4.0 * Sk) * D * 2, st);
 #define AT_DKV(DHV, NKV)                                                                                                                             \
   do {                                                                                                                                               \
-    allow_big_lds((const void*)sdpa_flash_bwd_dkv_kernel<DHV, NKV>);        \
+    allow_big_lds((const void*)sdpa_flash_bwd_dkv_kernel<DHV, NKV>);                                                                                 \
     const dim3 grid((unsigned)((Sk + 64 * NKV - 1) / (64 * NKV)), (unsigned)BH);                                                                     \
     hipLaunchKernelGGL((sdpa_flash_bwd_dkv_kernel<DHV, NKV>), grid, dim3(256), lds, st, q->ptr<bf16_t>(), k->ptr<bf16_t>(), v->ptr<bf16_t>(),        \
                        go->ptr<bf16_t>(), lse->ptr<float>(), dsum->ptr<float>(), dk->ptr<bf16_t>(), dv->ptr<bf16_t>(), (int)Sq, (int)Sk, (float)scale, \
-                       is_causal);                                                                                                                   \
+                       is_causal, (int)H, lq, lk, lv, lg, ldk, ldv);                                                                                 \
   } while (0)
     // keys per wave, measured (B 8, h 16, S 4096): 32 keys need one wave per SIMD at d = 128 (3.45 vs 2.53 ms for 16 keys at two
     // waves per SIMD); at d = 64, 32 keys win without a causal mask (1.35 vs 1.46 ms) and lose with one (1.28 vs 1.04 ms)

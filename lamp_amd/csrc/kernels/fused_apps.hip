@@ -220,10 +220,11 @@ __global__ __launch_bounds__(256) void sdpa_softmax_bwd_kernel(T* __restrict__ d
   }
 }
 
-bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int64_t BH, int64_t Sq, int64_t Sk, int64_t D,
-                         int64_t Dv, int is_causal, double scale, hipStream_t st);   // attention.hip
+// attention.hip: (B, heads, S, d) bf16 tensors in any row-contiguous layout (contiguous, or views of (B, S, heads, d) storage)
+bool flash_attention_fwd(const Tensor* q, const Tensor* k, const Tensor* v, Tensor* out, Tensor* lse, int is_causal, double scale, hipStream_t st);
 bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, const Tensor* v, const Tensor* out, const Tensor* lse, Tensor* dq, Tensor* dk,
-                         Tensor* dv, Tensor* dsum, int64_t BH, int64_t Sq, int64_t Sk, int64_t D, int64_t Dv, int is_causal, double scale, hipStream_t st);
+                         Tensor* dv, Tensor* dsum, int is_causal, double scale, hipStream_t st);
+Tensor* at_new_like_layout(const Tensor* like, int64_t B, int64_t H, int64_t S, int64_t D, int dtype);
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
                int64_t k, hipStream_t st, int kind);   // knn_fused.hip
@@ -580,24 +581,25 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
   const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
   LAMP_CHECK(k->sizes[0] == B && k->sizes[1] == H && k->sizes[3] == D && v->sizes[0] == B && v->sizes[1] == H && v->sizes[2] == Sk, "attention: shape mismatch");
   if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
+  int64_t ls[3] = {B, H, Sq};
+  const int64_t rows = B * H * Sq;
+  if (rows && Sk && q->dtype == kBF16) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate; logsumexp is f32 as in ATen
+    // strided operands are read in place; the result takes q's layout, so a (B, heads, S, d) view of (B, S, heads, d) projections
+    // comes back as such a view (lamp's transposeOut is then free)
+    Hold fo(at_new_like_layout(q, B, H, Sq, Dv, q->dtype)), lse32(new_tensor(ls, 3, kF32, q->device()));
+    if (flash_attention_fwd(q, k, v, fo.get(), lse32.get(), is_causal, scale, current_stream(q->device()))) {
+      *out = fo.take();
+      *logsumexp = lse32.take();
+      return 0;
+    }
+  }
   Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v));
   int64_t qs[3] = {B * H, Sq, D}, ks[3] = {B * H, Sk, D}, vs[3] = {B * H, Sk, Dv};
   lamp_tensor *q3 = nullptr, *k3 = nullptr, *v3 = nullptr;
   LAMP_CHECK(lamp_view(&q3, qc.get(), qs, 3) == 0, lamp_last_error()); Hold hq(q3);
   LAMP_CHECK(lamp_view(&k3, kc.get(), ks, 3) == 0, lamp_last_error()); Hold hk(k3);
   LAMP_CHECK(lamp_view(&v3, vc.get(), vs, 3) == 0, lamp_last_error()); Hold hv(v3);
-  int64_t ls[3] = {B, H, Sq};
   Hold lse(new_tensor(ls, 3, q->dtype, q->device()));
-  const int64_t rows = B * H * Sq;
-  if (rows && Sk && q->dtype == kBF16) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate; logsumexp is f32 as in ATen
-    int64_t os4[4] = {B, H, Sq, Dv};
-    Hold fo(new_tensor(os4, 4, q->dtype, q->device())), lse32(new_tensor(ls, 3, kF32, q->device()));
-    if (flash_attention_fwd(q3, k3, v3, fo.get(), lse32.get(), B * H, Sq, Sk, D, Dv, is_causal, scale, current_stream(q->device()))) {
-      *out = fo.take();
-      *logsumexp = lse32.take();
-      return 0;
-    }
-  }
   int64_t ss[3] = {B * H, Sq, Sk};
   Hold scores(new_tensor(ss, 3, q->dtype, q->device()));
   LAMP_CHECK(lamp_baddbmm_out_transposed2(scores.get(), scores.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
@@ -620,20 +622,27 @@ int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_
   check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value"); check_device_tensor(grad_out, "grad_out");
   const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
   if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
-  Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v)), gc(contiguous(grad_out));
-  // flash form: needs the forward's output and its f32 logsumexp (what the fused forward returns)
+  // flash form: needs the forward's output and its f32 logsumexp (what the fused forward returns); operands are read in place in
+  // whatever row-contiguous layout they have, each gradient takes the layout of its operand
   if (q->dtype == kBF16 && out && logsumexp && logsumexp->dtype == kF32 && out->dtype == kBF16 && B * H * Sq > 0 && Sk > 0 && grad_out->dtype == kBF16 &&
-      logsumexp->numel() == B * H * Sq && out->numel() == B * H * Sq * Dv) {
-    Hold oc(contiguous(out)), lc(contiguous(logsumexp));
+      logsumexp->numel() == B * H * Sq && out->numel() == B * H * Sq * Dv && out->ndim == 4 && grad_out->ndim == 4) {
+    Hold lc(contiguous(logsumexp));
     int64_t n1[1] = {B * H * Sq};
     Hold dsum(new_tensor(n1, 1, kF32, q->device()));
-    Hold fdq(new_tensor(q->sizes, 4, kBF16, q->device())), fdk(new_tensor(k->sizes, 4, kBF16, q->device())), fdv(new_tensor(v->sizes, 4, kBF16, q->device()));
-    if (flash_attention_bwd(gc.get(), qc.get(), kc.get(), vc.get(), oc.get(), lc.get(), fdq.get(), fdk.get(), fdv.get(), dsum.get(), B * H, Sq, Sk, D, Dv,
-                            is_causal, scale, current_stream(q->device()))) {
+    Hold fdq(at_new_like_layout(q, B, H, Sq, D, kBF16)), fdk(at_new_like_layout(k, B, H, Sk, D, kBF16)), fdv(at_new_like_layout(v, B, H, Sk, Dv, kBF16));
+    if (flash_attention_bwd(grad_out, q, k, v, out, lc.get(), fdq.get(), fdk.get(), fdv.get(), dsum.get(), is_causal, scale, current_stream(q->device()))) {
+      out3[0] = fdq.take(); out3[1] = fdk.take(); out3[2] = fdv.take();
+      return 0;
+    }
+    // a gradient with an odd layout (e.g. expanded): retry on a dense copy before giving the fused form up
+    Hold gc2(contiguous(grad_out)), oc2(contiguous(out));
+    if ((gc2.get()->raw() != grad_out->raw() || oc2.get()->raw() != out->raw()) &&
+        flash_attention_bwd(gc2.get(), q, k, v, oc2.get(), lc.get(), fdq.get(), fdk.get(), fdv.get(), dsum.get(), is_causal, scale, current_stream(q->device()))) {
       out3[0] = fdq.take(); out3[1] = fdk.take(); out3[2] = fdv.take();
       return 0;
     }
   }
+  Hold qc(contiguous(q)), kc(contiguous(k)), vc(contiguous(v)), gc(contiguous(grad_out));
   // composed: P is recomputed from q and k (same numerics as the composed forward)
   int64_t qs[3] = {B * H, Sq, D}, ks[3] = {B * H, Sk, D}, vs[3] = {B * H, Sk, Dv}, gs[3] = {B * H, Sq, Dv};
   lamp_tensor *q3 = nullptr, *k3 = nullptr, *v3 = nullptr, *g3 = nullptr;

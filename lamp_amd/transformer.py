@@ -43,6 +43,12 @@ class MultiheadAttention(_Multi):
         return _forward_multi(self, vs, [maxLength])
 
     @staticmethod
+    def fusedCallAsWritten(on: bool) -> bool:
+        """process-wide switch (see lamp_attention_fused_call_as_written in include/lamp_host.h); returns the previous setting.
+        Default False: the fused branch computes what the reference's CPU path computes (per-head attention over the sequence)."""
+        prev = C.c_int(0); lib.lamp_attention_fused_call_as_written(int(bool(on)), C.byref(prev)); return bool(prev.value)
+
+    @staticmethod
     def sequenceMask(maxLength: STen, maskable: Variable, fill: float) -> Variable:
         o = C.c_void_p(); lib.lamp_sequence_mask(C.byref(o), maxLength.h, maskable.h, float(fill)); return Variable(o)
     sequenceMaskValidLength1D = sequenceMask

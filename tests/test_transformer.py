@@ -90,9 +90,10 @@ def _rand_params(shapes, dt, salt=0, scale=1.0):
     return [O.param(closed_form(s, salt + 17 * i, scale, dt)) for i, s in enumerate(shapes)]
 
 
-def _oracle_mha(dq, hidden, heads, out, dt, linearized, causal, salt=0):
+def _oracle_mha(dq, hidden, heads, out, dt, linearized, causal, salt=0, is_cuda=False):
+    """is_cuda=False (default): the composed branch = the reference's ATen CPU path, the parity target of the HIP library's default mode"""
     wq, wk, wv, wo = _rand_params([(dq, hidden * heads), (dq, hidden * heads), (dq, hidden * heads), (hidden * heads, out)], dt, salt, 1.0)
-    return T.MultiheadAttention(wq, wk, wv, wo, heads, linearized, causal, is_cuda=True)
+    return T.MultiheadAttention(wq, wk, wv, wo, heads, linearized, causal, is_cuda=is_cuda)
 
 
 def _oracle_encoder_block(in_, hidden, heads, mlp, dt, linearized, gpt, causal, salt=0):
@@ -152,17 +153,23 @@ def test_reference_transformer_encoder_test_on_gpu(gpu, linearized):
         assert np.array_equal(np.round(to_torch(a).numpy(), 6) + 0.0, np.round(b.numpy(), 6) + 0.0)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
-@pytest.mark.parametrize("case", ["plain", "maxlen2d", "causal", "linearized", "linearized_maxlen", "fused", "fused_causal", "cross"])
-def test_multihead_attention_matches_oracle(gpu, dt, case):
+@pytest.fixture
+def as_written_for_cuda():
+    """opt-in mode of the HIP library: the fused call exactly as the reference writes it for CUDA (dimension 1 read as heads)"""
+    from lamp_amd import transformer as TR
+    prev = TR.MultiheadAttention.fusedCallAsWritten(True)
+    yield
+    TR.MultiheadAttention.fusedCallAsWritten(prev)
+
+
+def _mha_case(dt, case, is_cuda):
     A, nn, S, TR = _hip()
     B, Sq, heads, hidden, dq, out = 3, 6, 4, 8, 10, 5
     linearized = case.startswith("linearized")
     causal = case in ("causal", "fused_causal")
     if case.startswith("fused"):
-        Sq = 16                                     # aligned: the fused branch with its (batch, sequence, heads, d) views
-    om = _oracle_mha(dq, hidden, heads, out, dt, linearized, causal)
+        Sq = 16                                     # aligned sequence: the gate of the fused branch (Transformer.scala:946-951)
+    om = _oracle_mha(dq, hidden, heads, out, dt, linearized, causal, is_cuda=is_cuda)
     hm = TR.MultiheadAttention(dq, dq, dq, hidden, out, 0.0, heads, _lamp_dtype(S, dt), 0, linearized, causal)
     _load(hm, om, S, dt)
     q = closed_form((B, Sq, dq), 5, 2.0, dt)
@@ -182,6 +189,65 @@ def test_multihead_attention_matches_oracle(gpu, dt, case):
         assert_close(to_torch(a.partialDerivative), b.grad.double(), BWD_TOL[dt], name)
     for i, (a, b) in enumerate(zip(hm.parameters, om.parameters())):
         assert_close(to_torch(a.partialDerivative), b.grad.double(), BWD_TOL[dt], f"weight {i}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+@pytest.mark.parametrize("case", ["plain", "maxlen2d", "causal", "linearized", "linearized_maxlen", "fused", "fused_causal", "cross"])
+def test_multihead_attention_matches_oracle(gpu, dt, case):
+    """default mode = the composed branch of the reference's CPU path, also for aligned sequences ("fused*": per-head attention over
+    the 16 positions; without a mask the raw scores, :797-801)"""
+    _mha_case(dt, case, is_cuda=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+@pytest.mark.parametrize("case", ["fused", "fused_causal", "causal", "plain"])
+def test_multihead_attention_as_written_for_cuda(gpu, as_written_for_cuda, dt, case):
+    """opt-in: the fused call with (batch, sequence, heads, d) views read as (batch, heads, sequence, d) - what the reference's CUDA
+    branch hands to ATen (test_oracle_fused_branch_reads_dim1_as_heads states what that computes)"""
+    _mha_case(dt, case, is_cuda=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Sq,heads,hidden", [(384, 12, 64), (200, 3, 64), (128, 2, 128), (16, 4, 64)])
+def test_multihead_attention_bf16_flash_path_has_cpu_semantics(gpu, Sq, heads, hidden):
+    """bf16, head width 64 / 128, causal: the default mode runs the flash kernels on strided (batch, heads, sequence, d) views of the
+    projections (no transposed copies) and must agree with the composed f32 oracle - per-head attention over the SEQUENCE - at bf16
+    resolution; the kernel classes that ran are checked, and the as-written-for-CUDA reading of the same call differs measurably."""
+    import ctypes as C
+    from lamp_amd._capi import lib
+    A, nn, S, TR = _hip()
+    B, dq, out = 2, 64, 48
+    om = _oracle_mha(dq, hidden, heads, out, torch.float32, False, True)
+    for v in om.state():
+        v.value.copy_((v.value * (2.0 / v.value.shape[0] ** 0.5)).bfloat16().float())
+    hm = TR.MultiheadAttention(dq, dq, dq, hidden, out, 0.0, heads, S.BF16, 0, False, True)
+    _load(hm, om, S, torch.bfloat16)
+    x = closed_form((B, Sq, dq), 5, 2.0, torch.bfloat16)
+    xv = O.param(x.float())
+    oout = om.forward(xv)
+    hx = A.param(to_sten(x))
+    lib.lamp_kernel_timer_filter(None); lib.lamp_kernel_timer_enable(1)
+    hout = hm.forward(hx)
+    c = closed_form(tuple(oout.shape), 31, 1.0, torch.bfloat16)
+    (hout * A.const(to_sten(c))).sum().backprop()
+    lib.lamp_kernel_timer_enable(0)
+    buf = C.create_string_buffer(1 << 16); lib.lamp_kernel_timer_report(buf, len(buf))
+    ran = {l.split()[0] for l in buf.value.decode().splitlines()}
+    assert {"sdpa_flash_fwd", "sdpa_flash_bwd_dq", "sdpa_flash_bwd_dkv"} <= ran, ran
+    (oout * O.const(c.float())).sum().backprop()
+    assert_close(to_torch(hout.value), oout.value.double(), 2.0 ** -6, "forward")
+    assert_close(to_torch(hx.partialDerivative), xv.grad.double(), 2.0 ** -4, "dx")
+    for i, (a, b) in enumerate(zip(hm.parameters, om.parameters())):
+        assert_close(to_torch(a.partialDerivative), b.grad.double(), 2.0 ** -4, f"weight {i}")
+    if Sq % 8 == 0:
+        prev = TR.MultiheadAttention.fusedCallAsWritten(True)
+        try:
+            other = to_torch(hm.forward(A.const(to_sten(x))).value)
+        finally:
+            TR.MultiheadAttention.fusedCallAsWritten(prev)
+        assert (other.double() - oout.value.double()).abs().max() > 0.05 * oout.value.abs().max(), "the two readings must differ"
 
 
 @pytest.mark.gpu
@@ -326,8 +392,9 @@ def test_language_model_training_steps_with_identity_loss(gpu):
 
 @pytest.mark.gpu
 def test_language_model_bf16_flash_path_matches_f32_oracle(gpu):
-    """bf16 with head width 64: the fused branch runs the flash kernels (attention.hip) on the (batch, sequence, heads, d) views; the loss
-    and every gradient agree with the f32 oracle on the same bf16-rounded weights at bf16 resolution"""
+    """bf16 with head width 64: causal attention runs the flash kernels (attention.hip) on (batch, heads, sequence, d) views of the
+    projections - per-head attention over the sequence, the arithmetic of the reference's CPU path; the loss and every gradient agree
+    with the composed f32 oracle on the same bf16-rounded weights at bf16 resolution"""
     A, nn, S, TR = _hip()
     vocab, ctx, dim, heads, blocks, pad = 32, 16, 128, 2, 2, -1000
     om = _oracle_lm(vocab, ctx, dim, heads, blocks, torch.float32, pad)
