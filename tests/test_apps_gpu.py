@@ -278,7 +278,7 @@ def test_flash_attention_bf16(gpu, shape, causal):
     assert b"sdpa_flash_bwd_dq" in buf.value and b"sdpa_flash_bwd_dkv" in buf.value, "the fused backward did not run"
     assert Lt.dtype == S.F32
     for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
-        assert_close(to_torch(S.STen(h)), r, 4e-2, name)     # sums over S of bf16-rounded P / dS: the error scales with sqrt(S) * 2^-9 * |terms|, not with the element
+        assert_close(to_torch(S.STen(h)), r, 2e-2, name, scale="max")     # sums over S of bf16-rounded P / dS: the error scales with sqrt(S) * 2^-9 * |terms|, not with the element
 
 
 @pytest.mark.parametrize("shape", [(3, 37, 12), (2, 5, 16), (1, 9, 1), (2, 3, 5)])
@@ -310,7 +310,7 @@ def test_short_sequence_attention_bf16(gpu, shape, causal):
     assert_close(to_torch(Ot), ref.detach(), 1e-2, "attention output")
     assert_close(to_torch(Lt), lse_ref.detach(), 1e-5, "logsumexp")
     for name, h, r in zip(("dq", "dk", "dv"), out3, (qd.grad, kd.grad, vd.grad)):
-        assert_close(to_torch(S.STen(h)), r, 1e-2, name)
+        assert_close(to_torch(S.STen(h)), r, 1e-2, name, scale="max")     # dS is rounded to bf16 before the dq / dk products
 
 
 def test_umap_skip_self_equals_masked_pairs(gpu):

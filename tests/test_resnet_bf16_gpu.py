@@ -13,10 +13,13 @@ are run on the same bf16-rounded weights and batch: ATen-CPU f32 (the truth both
 (the reference's own arithmetic at this precision) and the HIP path.  Required, per tensor:
 
   * loss: |hip - f32| <= 2^-7 |f32|  (one bf16 rounding of a value of ~4.6 is 2^-9 relative; the class scores are bf16)
-  * every one of the 37 gradients:  ||hip - f32||_2 <= 1.25 * ||cpu_bf16 - f32||_2 + 2^-8 ||f32||_2
-    - the HIP path is as close to the f32 truth as the reference's bf16 path is (it is usually closer: f32 accumulation inside
-    the fused kernels), and never further than a quarter more;
-  * parameters after two AdamW steps (mixed precision: f32 working copies): the update p2 - p0 obeys the same inequality.
+  * the 37 gradients taken together (one concatenated vector):  ||hip - f32||_2 <= 1.25 * ||cpu_bf16 - f32||_2
+    - the HIP path is as close to the f32 truth as the reference's own bf16 arithmetic is (measured on MI355X: 1.07 x at B = 256,
+    0.89 x at B = 2048; scripts/resnet_bf16_ratios.py prints the table);
+  * every single gradient tensor:  ||hip - f32||_2 <= 2 * ||cpu_bf16 - f32||_2 + 2^-8 ||f32||_2 - the two bf16 paths are two
+    realisations of the same rounding noise, whose per-tensor norms scatter between 0.4 x and 1.7 x of each other (a 6-element
+    batch-norm gradient is one draw); a kernel that drops or mis-scales a term is off by the gradient's own norm, 3 - 20 x more;
+  * parameters after two AdamW steps (mixed precision: f32 working copies): the update p2 - p0 obeys the same inequalities.
 """
 import ctypes as C
 
@@ -82,23 +85,27 @@ def test_bf16_resnet_step_tracks_the_f32_truth_like_the_cpu_bf16_path(gpu, B, st
         lh = float(to_torch(acc)[0]) / B
         assert abs(lh - float(lf)) <= 2.0 ** -7 * abs(float(lf)), f"step {step}: loss {lh} vs f32 {float(lf)} (cpu bf16 {float(lb)})"
         assert len(hg) == len(gf) == 37
-        worst = 0.0
+        th = tb = 0.0
         for i, (h, b, f) in enumerate(zip(hg, gb, gf)):
             eh, eb, nf = _l2(to_torch(h), f), _l2(b.float(), f), float(f.double().norm())
-            worst = max(worst, eh / max(eb, 1e-30))
-            assert eh <= 1.25 * eb + 2.0 ** -8 * nf, (f"step {step} gradient {i} {list(f.shape)}: ||hip - f32|| = {eh:.4e} but the ATen-CPU bf16 "
-                                                    f"path is at {eb:.4e} (||f32|| = {nf:.4e})")
+            th += eh * eh; tb += eb * eb
+            assert eh <= 2.0 * eb + 2.0 ** -8 * nf, (f"step {step} gradient {i} {list(f.shape)}: ||hip - f32|| = {eh:.4e} but the ATen-CPU bf16 "
+                                                   f"path is at {eb:.4e} (||f32|| = {nf:.4e})")
             assert bool(torch.isfinite(to_torch(h)).all())
+        assert th ** 0.5 <= 1.25 * tb ** 0.5, f"step {step}: all gradients: ||hip - f32|| = {th ** 0.5:.4e}, ATen-CPU bf16 at {tb ** 0.5:.4e}"
         bopt.step(gb, 1.0); fopt.step(gf, 1.0); hopt.step(hg, 1.0)
+    th = tb = 0.0
     for i, (hp, bp, fp, q) in enumerate(zip(hm.parameters, ob.parameters(), of.parameters(), p0)):
         uh, ub, uf = to_torch(hp.value).float() - q, bp.value.float() - q, fp.value.float() - q
         eh, eb, nf = _l2(uh, uf), _l2(ub, uf), float(uf.double().norm())
-        assert eh <= 1.25 * eb + 2.0 ** -6 * nf, f"parameter {i} {list(q.shape)} after {steps} AdamW steps: update error {eh:.4e} vs cpu-bf16 {eb:.4e} (||update|| {nf:.4e})"
+        th += eh * eh; tb += eb * eb
+        assert eh <= 2.0 * eb + 2.0 ** -6 * nf, f"parameter {i} {list(q.shape)} after {steps} AdamW steps: update error {eh:.4e} vs cpu-bf16 {eb:.4e} (||update|| {nf:.4e})"
+    assert th ** 0.5 <= 1.25 * tb ** 0.5, f"all parameter updates: ||hip - f32|| = {th ** 0.5:.4e}, ATen-CPU bf16 at {tb ** 0.5:.4e}"
     # batch-norm running statistics moved identically (f32-accurate statistics of bf16 activations)
     for hv, bv, fv in zip(hm.state, ob.state(), of.state()):
         if hv.value.shape == fv.value.shape and fv.value.ndim == 1:
             eh, eb, nf = _l2(to_torch(hv.value), fv.value), _l2(bv.value.float(), fv.value), float(fv.value.double().norm())
-            assert eh <= 1.25 * eb + 2.0 ** -6 * nf + 1e-6
+            assert eh <= 2.0 * eb + 2.0 ** -6 * nf + 1e-6
 
 
 def test_bf16_epoch_loss_accumulates_in_f64(gpu):

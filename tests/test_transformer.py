@@ -237,10 +237,11 @@ def test_multihead_attention_bf16_flash_path_has_cpu_semantics(gpu, Sq, heads, h
     ran = {l.split()[0] for l in buf.value.decode().splitlines()}
     assert {"sdpa_flash_fwd", "sdpa_flash_bwd_dq", "sdpa_flash_bwd_dkv"} <= ran, ran
     (oout * O.const(c.float())).sum().backprop()
-    assert_close(to_torch(hout.value), oout.value.double(), 2.0 ** -6, "forward")
-    assert_close(to_torch(hx.partialDerivative), xv.grad.double(), 2.0 ** -4, "dx")
+    # four bf16 stages (projections, attention, output projection): chained roundings -> scale="max"
+    assert_close(to_torch(hout.value), oout.value.double(), 2.0 ** -6, "forward", scale="max")
+    assert_close(to_torch(hx.partialDerivative), xv.grad.double(), 2.0 ** -5, "dx", scale="max")
     for i, (a, b) in enumerate(zip(hm.parameters, om.parameters())):
-        assert_close(to_torch(a.partialDerivative), b.grad.double(), 2.0 ** -4, f"weight {i}")
+        assert_close(to_torch(a.partialDerivative), b.grad.double(), 2.0 ** -5, f"weight {i}", scale="max")
     if Sq % 8 == 0:
         prev = TR.MultiheadAttention.fusedCallAsWritten(True)
         try:
@@ -409,4 +410,4 @@ def test_language_model_bf16_flash_path_matches_f32_oracle(gpu):
     assert_close(to_torch(hloss.value).reshape(()).double(), oloss.value.double(), 2e-2, "loss")
     hg = hm.gradients(hloss); og = om.gradients(oloss)
     for i, (a, b) in enumerate(zip(hg, og)):
-        assert_close(to_torch(a).double(), b.double(), 6e-2, f"gradient {i}")
+        assert_close(to_torch(a).double(), b.double(), 3e-2, f"gradient {i}", scale="max")     # a whole network in bf16: chained roundings
