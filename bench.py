@@ -39,10 +39,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "lm"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
-    ap.add_argument("--graph", action="store_true", help="resnet / lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager)")
+    ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="resnet: issue the step eagerly instead of replaying forward + backprop from a HIP graph")
     ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous of the N ranks only (no GPU work): prints {\"dry_launch\": true, \"ranks\": N}")
     ap.add_argument("--min-window-s", type=float, default=0.5, help="repeat the K-step timed window until this much time is covered; the median window is reported")
     return ap.parse_args()
@@ -336,9 +336,15 @@ def main():
         a.dtype = "f32"
 
     graph = None
-    if a.graph and a.workload in ("resnet", "lm") and comm is None:
-        # launch-bound steps: forward + backprop are captured once (after one eager step has set attributes and filled caches) and
-        # replayed; the optimiser (whose step count is a host value) stays eager
+    step_eager = step
+    use_graph = comm is None and not a.no_graph and ((a.workload == "resnet") or (a.graph and a.workload == "lm"))
+    if use_graph:
+        # The ResNet step is ~110 short launches: issued one by one the host needs ~0.5 ms of a 1.5 ms step and the device idles ~10 %
+        # between kernels.  Forward + backprop are captured once into a HIP graph (after one eager step has set attributes and filled
+        # the caches) and replayed per step - the same kernels on the same buffers, launched back to back; the optimiser (its step count
+        # is a host value) stays eager.  --no-graph measures the eager step; the untimed roofline passes always run eagerly, because
+        # HIP events cannot bracket the kernels of a replayed graph.
+        lib.lamp_device_synchronize()            # weights / optimiser state were written on the null stream
         st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, local_rank, C.byref(st)); lib.lamp_stream_set_current(st)
         step()
         lib.lamp_device_synchronize()
@@ -349,7 +355,7 @@ def main():
             lib.lamp_graph_launch(graph)
             opt.step(captured_grads, 1.0)
             return units_per_step
-        config["hip_graph"] = "forward + backprop captured, optimiser eager"
+        config["hip_graph"] = "forward + backprop replayed from a HIP graph, optimiser eager (--no-graph: eager step)"
     for _ in range(a.warmup):
         step()
     # ---- timed region: EXACTLY K steps between barrier + device synchronize on both sides, no instrumentation inside (kernel timers
@@ -383,7 +389,7 @@ def main():
     lib.lamp_kernel_timer_filter(None)
     lib.lamp_kernel_timer_enable(1)
     for _ in range(PROFILE_STEPS):
-        step()
+        step_eager()
     barrier()
     lib.lamp_kernel_timer_enable(0)
     class_rows = kernel_report(lib)
@@ -394,7 +400,7 @@ def main():
         lib.lamp_kernel_timer_filter(dominant.encode())
         lib.lamp_kernel_timer_enable(1)
         for _ in range(max(PROFILE_STEPS, min(a.steps, 10))):
-            step()
+            step_eager()
         barrier()
         lib.lamp_kernel_timer_enable(0)
         lib.lamp_kernel_timer_filter(None)
