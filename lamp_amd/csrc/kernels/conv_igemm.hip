@@ -633,6 +633,197 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
   }
 }
 
+// Variant for MORE than 64 output channels at large batch (the 128- and 100-channel layers of res3 / res4: 80 % of the network's FLOPs):
+// ONE workgroup per CU, eight images and eight waves, wave w = image w x ALL output channels (64 pixels x 128 channels, 128 f32
+// accumulators per lane).
+//  * One weight stage now feeds eight images instead of two: the weights - 295 KB per 3x3 layer, re-streamed from L2 by every
+//    workgroup - cost 75 MB of L2 -> LDS traffic per launch instead of 302 MB (ig_conv8b at B = 2048: 105 FLOP per byte ingested
+//    against the ~32 B/clk a CU takes from L2; here 4x that).
+//  * A wave reads 8 weight fragments + 4 pixel fragments per 32 MFMAs (ig_conv8b: 16): the LDS array is busy 37 % of the matrix time.
+//  * Weight stages are 128 rows x 32 k (8 KiB, one LDS-DMA piece per wave) in a three-slot ring requested two stages ahead; 64-byte
+//    rows, 16-byte chunk c of row r at c ^ ((4 - (r >> 2)) & 3): the four 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS)
+//    each see 16 different slots.
+//  * K runs input-channel chunk OUTER, tap inner, and only over the chunks that hold real channels (a 16-channel input is one
+//    chunk, not two 64-deep stages of mostly zeros).
+//  * READ / MFMA phases in ping-pong between the two waves of a SIMD (waves 4-7 one phase behind), as in ig_conv8_kernel.
+//  * Epilogue: the accumulators go through the (now free) LDS as [channel][64 pixels] rows and leave as 16-byte stores, eight lanes
+//    per 128-byte row: full cache lines instead of 8-byte pieces (ig_conv8b writes 1.5x its algorithmic bytes to HBM).
+template <int KS, int NCT, int KP>
+__global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
+                                                        bf16_t* __restrict__ y, int N, int CI, int CO, float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int NI = 8, NT = 512;
+  constexpr int WT = 128 * 32 * 2, NSLOT = 3;   // one weight stage: 128 rows x 32 k
+  constexpr int RB = KP * 2;                // bytes per pixel of the channel-last image
+  constexpr int XIMG = 64 * RB;             // 8x8 pixels, no halo
+  constexpr int cmask = (KP >> 3) - 1;
+  char* Wl = smem;                          // NSLOT x WT
+  char* Xl = smem + NSLOT * WT;             // [8][64][KP]; taps outside the image read whatever lies 9 pixels before / after it (the
+                                            // weight ring, a neighbour image, 9 spare pixels at the end) and are zeroed in registers
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = image of this wave
+  const int grp = wid >> 2;                 // second wave of its SIMD: runs one phase behind
+  const int n0 = blockIdx.x * NI;
+  const int KC = (CI + 31) >> 5;            // 32-channel chunks that hold real channels
+  const int T = RS * KC;
+
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  typedef const __attribute__((address_space(1))) char glb_char_t;
+  // stage (kc, rs): rows = output channels, k = input channels [32 kc, 32 kc + 32) of tap rs; one 1 KiB piece (16 rows) per wave
+  const int d_row = wid * 16 + (lane >> 2);
+  const int d_src = d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3);
+  auto stage_dma = [&](int kc1, int rs1, int slot) {
+    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
+    __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+  };
+  stage_dma(0, 0, 0);
+  if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+  {
+    constexpr int ncgp = KP >> 3;
+    for (int e = tid; e < NI * 8 * ncgp; e += NT) {
+      const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
+      const int n = n0 + img;
+      unsigned int w[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = cg * 8 + k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < CI && n < N) v = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+        w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+      }
+      char* xi = Xl + img * XIMG;
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        unsigned int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned int lo = w[2 * j][p >> 1], hi = w[2 * j + 1][p >> 1];
+          d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ x_swz(h + 1, p + 1, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+    }
+  }
+
+  f4v acc[NCT][4];
+#pragma unroll
+  for (int i = 0; i < NCT; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  // Pixel-fragment addresses.  Tap (r, s), pixel tile j: pixel (2j + rowsel + r - PAD, wpix + s - PAD) of this wave's image, 16-byte
+  // chunk (k-chunk ^ x_swz(pixel)).  Everything that depends on (r, s, j) linearly - ((r * 8 + s) + 16 j) * RB - is a compile-time
+  // immediate of the ds_read; the swizzle depends only on the PARITY of the row (rowsel + r) and on the column (wpix + s), so
+  // 2 x KS byte offsets per lane cover all taps and tiles (36 precomputed addresses spilled at 128 accumulators).  Pixels outside the
+  // image are read from wherever the address lands (always inside the allocation) and the fragment is zeroed in registers.
+  int rowsel, wpix;
+  px_of_col(lane & 15, rowsel, wpix);
+  const int p0 = wid * XIMG + ((rowsel - PAD) * 8 + (wpix - PAD)) * RB;
+  int va[2][KS];
+#pragma unroll
+  for (int par = 0; par < 2; par++)
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int hp1 = (rowsel + par + 1 - PAD) & 1, wp1 = (wpix + s + 1 - PAD) & 7;     // x_swz(h + 1, w + 1): parity of the row, column
+      va[par][s] = p0 + (((((lane >> 4) & cmask) ^ (((hp1 << 3) | wp1) & cmask))) << 4);
+    }
+  const bool col_lo = wpix == 0, col_hi = wpix == 7, row_lo = rowsel == 0, row_hi = rowsel == 1;
+  // weight fragment of output-channel tile i: row 16 i + (lane & 15), chunk (lane >> 4) ^ swizzle(row)
+  const int a_off = (lane & 15) * 64 + ((((lane >> 4) ^ ((4 - ((lane >> 2) & 3)) & 3)) & 3) << 4);
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // images and weight stages 0, 1 are in LDS
+
+  // Two-phase ping-pong, ring discipline as in ig_conv8_kernel: DMA(t+2) is issued in READ(t) into the slot last read in READ(t-1)
+  // (every read is retired before the barrier closing its phase); each wave retires its own piece of DMA(t+1) before the barrier
+  // closing READ(t), which both groups pass before anyone starts READ(t+1).
+  bf8v fa[NCT], fb[4];
+  const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  int t = 0, slot = 0;
+  for (int kc = 0; kc < KC; kc++) {
+    const int u = ((kc * 4) & cmask) << 4;
+#pragma unroll
+    for (int rs = 0; rs < RS; rs++, t++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int r = rs / KS, s = rs - r * KS;
+      const char* wl = Wl + slot * WT + a_off;
+      const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      // ---- READ(t)
+      if (t + 2 < T) stage_dma(kc + (rs + 2) / RS, (rs + 2) % RS, slot2);
+#pragma unroll
+      for (int i = 0; i < NCT; i++) fa[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 1024));
+      const char* xb = Xl + (va[r & 1][s] ^ u);
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s) + 16 * j) * RB));
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (KS == 3) {                                   // taps that fall outside the 8x8 image contribute zeros
+        const bool colout = (s == 0 && col_lo) || (s == 2 && col_hi);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool out = colout || (r == 0 && j == 0 && row_lo) || (r == 2 && j == 3 && row_hi);
+          if (s != 1 || (r == 0 && j == 0) || (r == 2 && j == 3)) fb[j] = out ? zero8 : fb[j];
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      // ---- MFMA(t)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NCT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      slot = slot1;
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();          // every READ phase of every wave is over: LDS is free
+
+  // epilogue: + bias, round to bf16, batch-norm statistics from the rounded values (as ig_conv8b), then [channel][64 pixels] rows
+  // in this wave's 16 KiB of LDS (8-byte slot s of row c at s ^ ((c & 7) << 1): the 16 channels of a store spread over the banks and
+  // 16-byte chunks stay whole) and out as 16-byte stores
+  const int n = n0 + wid;
+  char* El = smem + wid * 16384;
+  const int q = lane >> 4;
+  const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
+#pragma unroll
+  for (int i = 0; i < NCT; i++) {
+    const int co = i * 16 + (lane & 15);
+    const float b = (bias && co < CO) ? (float)bias[co] : 0.f;
+    float vals[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
+      uint2 pk;
+      pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+      pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+      const int sl = (2 * j + qrow) * 2 + (qw >> 2);
+      *reinterpret_cast<uint2*>(El + co * 128 + ((sl ^ ((co & 7) << 1)) << 3)) = pk;
+      vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
+      vals[4 * j + 2] = __uint_as_float((unsigned)o2.bits << 16); vals[4 * j + 3] = __uint_as_float((unsigned)o3.bits << 16);
+    }
+    if (stats) {                              // one partial per image: the batch norm that follows merges them (norm.hip)
+      float wn, wm, w2;
+      ig_stats_wave(vals, wn, wm, w2);
+      if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = wn; sp[1] = wm; sp[2] = w2; }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the region is private to this wave
+  if (n < N) {
+    bf16_t* yp = y + (int64_t)n * CO * 64;
+#pragma unroll
+    for (int it = 0; it < NCT * 2; it++) {
+      const int idx = it * 64 + lane;
+      const int co = idx >> 3, c = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(El + co * 128 + ((c ^ (co & 7)) << 4));
+      if (co < CO) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
+    }
+  }
+}
+
 // ---- wgrad --------------------------------------------------------------------------------------------
 // partial[(split * RS + rs)][128][128] (fp32) = sum over the split's images of dY[n] (128 x 64) . Xshift_rs[n]^T (64 x 128)
 template <int KS>
@@ -948,6 +1139,26 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       struct Publish { Hold& t; const Tensor* y; int P; ~Publish() { if (t.get()) conv_stats_publish(y, t.get(), P); } } publish{statt, out, (int)g.N};
       KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
       const bf16_t* bpb = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+      // more than 64 output channels and enough images to give every CU a workgroup of eight: one workgroup per CU, wave = image x all
+      // channels (LAMP_IG_VARIANT=d forces it for any batch, =b keeps the two-image kernel)
+      const bool force_d = variant && variant[0] == 'd';
+      if (CO > 64 && !(variant && variant[0] == 'b') && (force_d || g.N >= 4 * (int64_t)num_cus())) {
+        const int blocksd = (int)((g.N + 7) / 8);
+        const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)8 * 64 * KP * 2 + 9 * KP * 2, (size_t)8 * 16384);
+#define IG_LAUNCH_D(KS_, NCT_, KP_)                                                                                                         \
+  do {                                                                                                                                      \
+    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_, KP_>);                                                                          \
+    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_, KP_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb,                \
+                       out->ptr<bf16_t>(), (int)g.N, CI, CO, statp);                                                                       \
+  } while (0)
+#define IG_LAUNCH_D2(KS_, NCT_) do { if (KP == 64) IG_LAUNCH_D(KS_, NCT_, 64); else IG_LAUNCH_D(KS_, NCT_, 128); } while (0)
+        if (KS == 3) { if (CO <= 112) IG_LAUNCH_D2(3, 7); else IG_LAUNCH_D2(3, 8); }
+        else { if (CO <= 112) IG_LAUNCH_D2(1, 7); else IG_LAUNCH_D2(1, 8); }
+#undef IG_LAUNCH_D2
+#undef IG_LAUNCH_D
+        LAMP_LAUNCH_CHECK();
+        return;
+      }
       if (CO <= 64 && !(variant && variant[0] == 'b')) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
         const size_t ldsc = (size_t)2 * 64 * KP * 2 + KP * 2 + 4 * (64 * 64 * 2);
         static bool c3 = false, c1 = false;

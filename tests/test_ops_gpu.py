@@ -543,6 +543,61 @@ def test_convolution_forward_backward(gpu, dt, case):
     assert_close(to_torch(db), refb[2].double(), btol, "conv bias grad")
 
 
+@pytest.mark.parametrize("case", [(16, 128, 128, 3), (13, 128, 100, 3), (9, 100, 100, 3), (24, 16, 128, 3), (11, 128, 100, 1), (8, 16, 128, 1),
+                                  (3, 100, 128, 3), (1100, 128, 128, 3)])
+def test_igemm_eight_image_kernel(gpu, case, monkeypatch):
+    """ig_conv8d_kernel (one workgroup per CU, eight images, wave = image x all output channels; the default for > 64 output channels
+    once the batch gives every CU a workgroup): forced on small and ragged batches (N not a multiple of 8, N < 8), fprop with bias and
+    dgrad against ATen and against the two-image kernel (same products in f32, summed channel-chunk outer instead of tap outer: equal up
+    to one bf16 rounding), and the batch-norm statistics it publishes equal to a statistics pass over its output."""
+    import os
+    N, Cin, Cout, k = case
+    dt = torch.bfloat16
+    x = closed_form((N, Cin, 8, 8), 3, 2.0, dt)
+    w = closed_form((Cout, Cin, k, k), 17, 1.0, dt)
+    b = closed_form((Cout,), 5, 1.0, dt)
+    p = (k - 1) // 2
+    args = ([1, 1], [p, p], [1, 1], False, [0, 0], 1)
+    gy = closed_form((N, Cout, 8, 8), 23, 1.0, dt)
+
+    def run(variant):
+        monkeypatch.setenv("LAMP_IG_VARIANT", variant)
+        o = C.c_void_p()
+        lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                             i64_array([0, 0]), 1)
+        out = _out3()
+        lib.lamp_convolution_backward(out, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                                      i64_array([0, 0]), 1, _mask3(1, 0, 0))
+        return S.STen(o), _wrap3(out)[0]
+
+    yd, dxd = run("d")
+    yb, dxb = run("b")
+    monkeypatch.delenv("LAMP_IG_VARIANT")
+    ref = aten.convolution(x, w, b, *args)
+    refb = aten.convolution_backward(gy, x, w, [Cout], *args, [True, False, False])
+    assert_close(to_torch(yd), ref.double(), 2.0 ** -7, "conv forward (8-image kernel)")
+    assert_close(to_torch(dxd), refb[0].double(), 2.0 ** -7, "conv dgrad (8-image kernel)")
+    assert_close(to_torch(yd), to_torch(yb).double(), 2.0 ** -7, "fprop: 8-image kernel vs 2-image kernel")     # one bf16 ulp
+    assert_close(to_torch(dxd), to_torch(dxb).double(), 2.0 ** -7, "dgrad: 8-image kernel vs 2-image kernel")
+    if N >= 2:
+        # the statistics hand-off: a training-mode batch norm directly on the convolution's output takes the epilogue's partials
+        monkeypatch.setenv("LAMP_IG_VARIANT", "d")
+        o = C.c_void_p()
+        lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                             i64_array([0, 0]), 1)
+        Y = S.STen(o)
+        g, bb = closed_form((Cout,), 7, 1.0, dt) + 1.0, closed_form((Cout,), 9, 1.0, dt)
+        out = _out3()
+        lib.lamp_native_batch_norm(out, Y, to_sten(g), to_sten(bb), to_sten(torch.zeros(Cout, dtype=dt)), to_sten(torch.ones(Cout, dtype=dt)), 1, 0.1, 1e-5)
+        yn, mean, invstd = _wrap3(out)
+        # reference statistics in f32 of the bf16 values the convolution stored; save_mean / save_invstd come back in bf16
+        rn = aten.native_batch_norm(to_torch(Y).float(), g.float(), bb.float(), torch.zeros(Cout), torch.ones(Cout), True, 0.1, 1e-5)
+        assert_close(to_torch(mean), rn[1].double(), 2.0 ** -8, "save_mean from the epilogue's partials")
+        assert_close(to_torch(invstd), rn[2].double(), 2.0 ** -8, "save_invstd from the epilogue's partials")
+        assert_close(to_torch(yn), rn[0].double(), 2.0 ** -7, "batch norm on the hand-off statistics")
+        monkeypatch.delenv("LAMP_IG_VARIANT")
+
+
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
 def test_conv1d_and_transposed(gpu, dt):
     x = closed_form((2, 3, 11), 3, 2.0, dt)
