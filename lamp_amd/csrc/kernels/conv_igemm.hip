@@ -636,32 +636,48 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
 // Variant for MORE than 64 output channels at large batch (the 128- and 100-channel layers of res3 / res4: 80 % of the network's FLOPs):
 // ONE workgroup per CU, eight images and eight waves, wave w = image w x ALL output channels (64 pixels x 128 channels, 128 f32
 // accumulators per lane).
-//  * One weight stage now feeds eight images instead of two: the weights - 295 KB per 3x3 layer, re-streamed from L2 by every
-//    workgroup - cost 75 MB of L2 -> LDS traffic per launch instead of 302 MB (ig_conv8b at B = 2048: 105 FLOP per byte ingested
-//    against the ~32 B/clk a CU takes from L2; here 4x that).
+//  * One weight stage feeds eight images instead of two: the weights - 295 KB per 3x3 layer, re-streamed from L2 by every workgroup -
+//    cost 75 MB of L2 -> LDS traffic per launch instead of 302 MB (ig_conv8b at B = 2048: 105 FLOP per byte ingested against the
+//    ~32 B/clk a CU takes from L2; here 4x that).
 //  * A wave reads 8 weight fragments + 4 pixel fragments per 32 MFMAs (ig_conv8b: 16): the LDS array is busy 37 % of the matrix time.
 //  * Weight stages are 128 rows x 32 k (8 KiB, one LDS-DMA piece per wave) in a three-slot ring requested two stages ahead; 64-byte
 //    rows, 16-byte chunk c of row r at c ^ ((4 - (r >> 2)) & 3): the four 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS)
 //    each see 16 different slots.
-//  * K runs input-channel chunk OUTER, tap inner, and only over the chunks that hold real channels (a 16-channel input is one
-//    chunk, not two 64-deep stages of mostly zeros).
+//  * K runs input-channel chunk OUTER, tap inner, only over the chunks that hold real channels (a 16-channel input is one chunk, not
+//    two 64-deep stages of mostly zeros); the images sit in LDS as [chunk][image][pixel][32 channels] (64-byte pixel rows).
+//  * Measured with in-kernel stamps (scripts/conv_stamp_probe.py, 128 -> 128 3x3, B = 2048; cycles per workgroup): prologue 12.2k
+//    (an HBM burst of every CU at once: 11 B/clk/CU), main loop 41.7k (36 stages x 1158; 1024 = matrix pipe alone), epilogue 6.5k +
+//    stores 4k.  Tried and dropped: fetching chunk kc + 1 of the wave's own image during chunk kc (two 32-channel chunks in LDS,
+//    four-slot ring, the loads queued behind the ring's requests so the in-order vmcnt waits leave them three stages to land): the
+//    prologue fell to 4.7k but every round stalled the barrier-coupled waves on HBM latency - main loop 54.7k, 71k in total vs 65k.
 //  * READ / MFMA phases in ping-pong between the two waves of a SIMD (waves 4-7 one phase behind), as in ig_conv8_kernel.
 //  * Epilogue: the accumulators go through the (now free) LDS as [channel][64 pixels] rows and leave as 16-byte stores, eight lanes
 //    per 128-byte row: full cache lines instead of 8-byte pieces (ig_conv8b writes 1.5x its algorithmic bytes to HBM).
-template <int KS, int NCT, int KP>
+#ifdef IG8D_STAMP
+__device__ unsigned long long ig8d_stamps[8 * 512];
+#define IG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) ig8d_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define IG_STAMP(k) do { } while (0)
+#endif
+// swizzle of the 64-byte pixel rows: 16-byte chunk c of pixel (h, w) at c ^ (((h & 1) << 1) | ((w >> 2) & 1)); with bank(16-byte slot) =
+// (4 (w & 3) + chunk') mod 16 the 16 pixels of an MFMA tile (two rows x eight columns) read 16 different slots
+__device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | ((w >> 2) & 1); }
+
+template <int KS, int NCT>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int CO, float* __restrict__ stats) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int NI = 8, NT = 512;
   constexpr int WT = 128 * 32 * 2, NSLOT = 3;   // one weight stage: 128 rows x 32 k
-  constexpr int RB = KP * 2;                // bytes per pixel of the channel-last image
-  constexpr int XIMG = 64 * RB;             // 8x8 pixels, no halo
-  constexpr int cmask = (KP >> 3) - 1;
+  constexpr int RB = 64;                    // bytes per pixel of one 32-channel chunk
+  constexpr int XIMG = 64 * RB;             // one chunk of one image: 4 KiB
+  constexpr int XBUF = NI * XIMG;           // one chunk of the workgroup's eight images
   char* Wl = smem;                          // NSLOT x WT
-  char* Xl = smem + NSLOT * WT;             // [8][64][KP]; taps outside the image read whatever lies 9 pixels before / after it (the
-                                            // weight ring, a neighbour image, 9 spare pixels at the end) and are zeroed in registers
+  char* Xl = smem + NSLOT * WT;             // [chunk][8 images][64 pixels][32 channels].  Taps outside the image read whatever lies up
+                                            // to 9 pixels before / after it (weight ring, neighbour image, spare bytes at the end) and
+                                            // are zeroed in registers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = image of this wave
   const int grp = wid >> 2;                 // second wave of its SIMD: runs one phase behind
@@ -678,35 +694,36 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
     __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
   };
+  IG_STAMP(0);
   stage_dma(0, 0, 0);
   if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+  IG_STAMP(1);
+  // NCHW -> [pixel][32 channels].  A thread takes 8 channels x one image row: eight coalesced 16-byte loads, an 8x8 transposition of the
+  // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).
   {
-    constexpr int ncgp = KP >> 3;
-    for (int e = tid; e < NI * 8 * ncgp; e += NT) {
-      const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
+    for (int e = tid; e < NI * 8 * 4 * KC; e += NT) {
+      const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7, ch = e >> 8;
       const int n = n0 + img;
-      unsigned int w[8][4];
+      uint4 rw[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        const int c = cg * 8 + k;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < CI && n < N) v = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
-        w[k][0] = v.x; w[k][1] = v.y; w[k][2] = v.z; w[k][3] = v.w;
+        const int c = ch * 32 + cg * 8 + k;
+        rw[k] = make_uint4(0, 0, 0, 0);
+        if (c < CI && n < N) rw[k] = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
       }
-      char* xi = Xl + img * XIMG;
+      char* xi = Xl + ch * XBUF + img * XIMG;
 #pragma unroll
       for (int p = 0; p < 8; p++) {
         unsigned int d[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const unsigned int lo = w[2 * j][p >> 1], hi = w[2 * j + 1][p >> 1];
+          const unsigned int lo = (&rw[2 * j].x)[p >> 1], hi = (&rw[2 * j + 1].x)[p >> 1];
           d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
         }
-        *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ x_swz(h + 1, p + 1, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ ig8d_swz(h, p)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
   }
-
   f4v acc[NCT][4];
 #pragma unroll
   for (int i = 0; i < NCT; i++)
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
   // Pixel-fragment addresses.  Tap (r, s), pixel tile j: pixel (2j + rowsel + r - PAD, wpix + s - PAD) of this wave's image, 16-byte
-  // chunk (k-chunk ^ x_swz(pixel)).  Everything that depends on (r, s, j) linearly - ((r * 8 + s) + 16 j) * RB - is a compile-time
+  // chunk (lane >> 4) ^ swizzle(pixel).  Everything that depends on (r, s, j) linearly - ((r * 8 + s) + 16 j) * RB - is a compile-time
   // immediate of the ds_read; the swizzle depends only on the PARITY of the row (rowsel + r) and on the column (wpix + s), so
   // 2 x KS byte offsets per lane cover all taps and tiles (36 precomputed addresses spilled at 128 accumulators).  Pixels outside the
   // image are read from wherever the address lands (always inside the allocation) and the fragment is zeroed in registers.
@@ -725,16 +742,15 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int par = 0; par < 2; par++)
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const int hp1 = (rowsel + par + 1 - PAD) & 1, wp1 = (wpix + s + 1 - PAD) & 7;     // x_swz(h + 1, w + 1): parity of the row, column
-      va[par][s] = p0 + (((((lane >> 4) & cmask) ^ (((hp1 << 3) | wp1) & cmask))) << 4);
-    }
+    for (int s = 0; s < KS; s++)
+      va[par][s] = p0 + (((lane >> 4) ^ ig8d_swz(rowsel + par - PAD, wpix + s - PAD)) << 4);
   const bool col_lo = wpix == 0, col_hi = wpix == 7, row_lo = rowsel == 0, row_hi = rowsel == 1;
   // weight fragment of output-channel tile i: row 16 i + (lane & 15), chunk (lane >> 4) ^ swizzle(row)
   const int a_off = (lane & 15) * 64 + ((((lane >> 4) ^ ((4 - ((lane >> 2) & 3)) & 3)) & 3) << 4);
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // images and weight stages 0, 1 are in LDS
+  IG_STAMP(2);
 
   // Two-phase ping-pong, ring discipline as in ig_conv8_kernel: DMA(t+2) is issued in READ(t) into the slot last read in READ(t-1)
   // (every read is retired before the barrier closing its phase); each wave retires its own piece of DMA(t+1) before the barrier
@@ -744,10 +760,9 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int t = 0, slot = 0;
   for (int kc = 0; kc < KC; kc++) {
-    const int u = ((kc * 4) & cmask) << 4;
+    const char* xk = Xl + kc * XBUF;
 #pragma unroll
     for (int rs = 0; rs < RS; rs++, t++) {
-      constexpr int dummy = 0; (void)dummy;
       const int r = rs / KS, s = rs - r * KS;
       const char* wl = Wl + slot * WT + a_off;
       const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       if (t + 2 < T) stage_dma(kc + (rs + 2) / RS, (rs + 2) % RS, slot2);
 #pragma unroll
       for (int i = 0; i < NCT; i++) fa[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 1024));
-      const char* xb = Xl + (va[r & 1][s] ^ u);
+      const char* xb = xk + va[r & 1][s];
 #pragma unroll
       for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s) + 16 * j) * RB));
       if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
@@ -781,6 +796,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();          // every READ phase of every wave is over: LDS is free
+  IG_STAMP(3);
 
   // epilogue: + bias, round to bf16, batch-norm statistics from the rounded values (as ig_conv8b), then [channel][64 pixels] rows
   // in this wave's 16 KiB of LDS (8-byte slot s of row c at s ^ ((c & 7) << 1): the 16 channels of a store spread over the banks and
@@ -789,29 +805,68 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   char* El = smem + wid * 16384;
   const int q = lane >> 4;
   const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
+  // 8 waves x 8 tiles of epilogue arithmetic is pure vector-issue time (measured: 10.7k of the kernel's 69k cycles with the per-value
+  // Welford form): the statistics use packed f32 math on shifted sums, merge the four lanes of a channel without divisions (equal
+  // counts: the same values as ig_stats_merge gives), and are skipped altogether when nobody asked for them (dgrad)
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  // every tile's bias value requested up front: one memory round trip instead of one per tile (a load inside the tile loop also made
+  // every tile wait for the previous tile's statistics stores: vmcnt counts loads and stores in one queue)
+  unsigned short braw[NCT];
 #pragma unroll
   for (int i = 0; i < NCT; i++) {
     const int co = i * 16 + (lane & 15);
-    const float b = (bias && co < CO) ? (float)bias[co] : 0.f;
-    float vals[16];
+    braw[i] = (bias && co < CO) ? bias[co].bits : (unsigned short)0;
+  }
+#pragma unroll
+  for (int i = 0; i < NCT; i++) {
+    const int co = i * 16 + (lane & 15);
+    const float b = __uint_as_float((unsigned)braw[i] << 16);
+    uint2 pk[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const bf16_t o0(acc[i][j][0] + b), o1(acc[i][j][1] + b), o2(acc[i][j][2] + b), o3(acc[i][j][3] + b);
-      uint2 pk;
-      pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
-      pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+      // two values per v_cvt_pk_bf16_f32 (round to nearest even, as the scalar cast)
+      typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+      const f2v lo = {acc[i][j][0] + b, acc[i][j][1] + b}, hi = {acc[i][j][2] + b, acc[i][j][3] + b};
+      pk[j].x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2v));
+      pk[j].y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2v));
       const int sl = (2 * j + qrow) * 2 + (qw >> 2);
-      *reinterpret_cast<uint2*>(El + co * 128 + ((sl ^ ((co & 7) << 1)) << 3)) = pk;
-      vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
-      vals[4 * j + 2] = __uint_as_float((unsigned)o2.bits << 16); vals[4 * j + 3] = __uint_as_float((unsigned)o3.bits << 16);
+      *reinterpret_cast<uint2*>(El + co * 128 + ((sl ^ ((co & 7) << 1)) << 3)) = pk[j];
     }
     if (stats) {                              // one partial per image: the batch norm that follows merges them (norm.hip)
-      float wn, wm, w2;
-      ig_stats_wave(vals, wn, wm, w2);
-      if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = wn; sp[1] = wm; sp[2] = w2; }
+      // the 16 bf16-ROUNDED values of this lane as f32 pairs (low half << 16, high half masked), shifted by the first one
+      const float sh = __uint_as_float(pk[0].x << 16);
+      const f2v sh2 = {sh, sh};
+      f2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f2v va = {__uint_as_float(pk[j].x << 16), __uint_as_float(pk[j].x & 0xffff0000u)};
+        const f2v vb = {__uint_as_float(pk[j].y << 16), __uint_as_float(pk[j].y & 0xffff0000u)};
+        const f2v da = va - sh2, db = vb - sh2;
+        s1 += da; s2 = __builtin_elementwise_fma(da, da, s2);
+        s1 += db; s2 = __builtin_elementwise_fma(db, db, s2);
+      }
+      const float t1 = s1[0] + s1[1], t2 = s2[0] + s2[1];
+      float mean = sh + t1 * (1.f / 16.f), m2 = t2 - t1 * t1 * (1.f / 16.f);
+      // merge over the four lanes that hold the channel (xor 16, 32): equal counts n, so mean' = mean + d / 2, M2' = M2a + M2b + d^2 n / 2
+      // (v_permlane16/32_swap leave {own, partner} in {a, b} in an order that depends on the lane: the merge is written on (a, b);
+      // lanes may differ in the last bit, only lane q == 0 publishes)
+      {
+        float ma = mean, mb = mean, qa = m2, qb = m2;
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+        const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 8.f;
+      }
+      {
+        float ma = mean, mb = mean, qa = m2, qb = m2;
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+        const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 16.f;
+      }
+      if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = mean; sp[2] = m2; }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the region is private to this wave
+  IG_STAMP(4);
   if (n < N) {
     bf16_t* yp = y + (int64_t)n * CO * 64;
 #pragma unroll
@@ -822,7 +877,15 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       if (co < CO) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
     }
   }
+  IG_STAMP(5);
+#ifdef IG8D_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IG_STAMP(6);
+#endif
 }
+#ifdef IG8D_STAMP
+extern "C" int lamp_debug_ig8d_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ig8d_stamps), sizeof(ig8d_stamps)) == hipSuccess ? 0 : 1; }
+#endif
 
 // ---- wgrad --------------------------------------------------------------------------------------------
 // partial[(split * RS + rs)][128][128] (fp32) = sum over the split's images of dY[n] (128 x 64) . Xshift_rs[n]^T (64 x 128)
@@ -1144,17 +1207,17 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       const bool force_d = variant && variant[0] == 'd';
       if (CO > 64 && !(variant && variant[0] == 'b') && (force_d || g.N >= 4 * (int64_t)num_cus())) {
         const int blocksd = (int)((g.N + 7) / 8);
-        const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)8 * 64 * KP * 2 + 9 * KP * 2, (size_t)8 * 16384);
-#define IG_LAUNCH_D(KS_, NCT_, KP_)                                                                                                         \
+        // 3 weight slots + the 32-channel image chunks (+ 9 spare pixels behind them for the taps of a 3x3 kernel) - and at least the
+        // 8 x 16 KiB the epilogue stages the output through
+        const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)((CI + 31) / 32) * 8 * 4096 + (KS == 3 ? 9 * 64 : 0), (size_t)8 * 16384);
+#define IG_LAUNCH_D(KS_, NCT_)                                                                                                              \
   do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_, KP_>);                                                                          \
-    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_, KP_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb,                \
-                       out->ptr<bf16_t>(), (int)g.N, CI, CO, statp);                                                                       \
+    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
+    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
+                       (int)g.N, CI, KP, CO, statp);                                                                                       \
   } while (0)
-#define IG_LAUNCH_D2(KS_, NCT_) do { if (KP == 64) IG_LAUNCH_D(KS_, NCT_, 64); else IG_LAUNCH_D(KS_, NCT_, 128); } while (0)
-        if (KS == 3) { if (CO <= 112) IG_LAUNCH_D2(3, 7); else IG_LAUNCH_D2(3, 8); }
-        else { if (CO <= 112) IG_LAUNCH_D2(1, 7); else IG_LAUNCH_D2(1, 8); }
-#undef IG_LAUNCH_D2
+        if (KS == 3) { if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
+        else { if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
 #undef IG_LAUNCH_D
         LAMP_LAUNCH_CHECK();
         return;

@@ -19,7 +19,8 @@ are run on the same bf16-rounded weights and batch: ATen-CPU f32 (the truth both
   * every single gradient tensor:  ||hip - f32||_2 <= 2 * ||cpu_bf16 - f32||_2 + 2^-8 ||f32||_2 - the two bf16 paths are two
     realisations of the same rounding noise, whose per-tensor norms scatter between 0.4 x and 1.7 x of each other (a 6-element
     batch-norm gradient is one draw); a kernel that drops or mis-scales a term is off by the gradient's own norm, 3 - 20 x more;
-  * parameters after two AdamW steps (mixed precision: f32 working copies): the update p2 - p0 obeys the same inequalities.
+  * parameters after two AdamW steps (mixed precision: f32 working copies): the updates p2 - p0 of all tensors together obey the
+    1.25 x inequality (per tensor only a sanity bound: a sign flip of one near-zero gradient is 2 lr).
 """
 import ctypes as C
 
@@ -99,7 +100,10 @@ def test_bf16_resnet_step_tracks_the_f32_truth_like_the_cpu_bf16_path(gpu, B, st
         uh, ub, uf = to_torch(hp.value).float() - q, bp.value.float() - q, fp.value.float() - q
         eh, eb, nf = _l2(uh, uf), _l2(ub, uf), float(uf.double().norm())
         th += eh * eh; tb += eb * eb
-        assert eh <= 2.0 * eb + 2.0 ** -6 * nf, f"parameter {i} {list(q.shape)} after {steps} AdamW steps: update error {eh:.4e} vs cpu-bf16 {eb:.4e} (||update|| {nf:.4e})"
+        # per tensor only a sanity bound: the first AdamW steps move every element by ~lr * sign(g), so ONE near-zero gradient whose sign the
+        # two bf16 paths round differently is an error of 2 lr in a tensor whose whole update has norm lr * sqrt(numel) (a [16] batch-norm
+        # bias: 35 % per flipped element); the aggregate below is the criterion
+        assert eh <= 2.0 * eb + 0.5 * nf, f"parameter {i} {list(q.shape)} after {steps} AdamW steps: update error {eh:.4e} vs cpu-bf16 {eb:.4e} (||update|| {nf:.4e})"
     assert th ** 0.5 <= 1.25 * tb ** 0.5, f"all parameter updates: ||hip - f32|| = {th ** 0.5:.4e}, ATen-CPU bf16 at {tb ** 0.5:.4e}"
     # batch-norm running statistics moved identically (f32-accurate statistics of bf16 activations)
     for hv, bv, fv in zip(hm.state, ob.state(), of.state()):
