@@ -343,6 +343,12 @@ int lamp_max_pool2d_with_indices(lamp_tensor** out, lamp_tensor** indices, const
 int lamp_max_pool2d_with_indices_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
                                           int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,
                                           int ceil_mode, const lamp_tensor* indices);
+/* max_pool1d_with_indices over [N, C, L] (MaxPool1D, ops.scala:1658-1715); indices are positions along L */
+int lamp_max_pool1d_with_indices(lamp_tensor** out, lamp_tensor** indices, const lamp_tensor* x, int64_t kernel,
+                                 int64_t stride, int64_t padding, int64_t dilation, int ceil_mode);
+int lamp_max_pool1d_with_indices_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
+                                          int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,
+                                          int ceil_mode, const lamp_tensor* indices);
 
 /* ------------------------------------------------------------------------------------------
  * normalisation   (ATen.native_batch_norm(+_backward), native_layer_norm(+_backward):
@@ -411,6 +417,13 @@ int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const
 int lamp_mse_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction);
 int lamp_mse_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
                            const lamp_tensor* target, int64_t reduction);
+/* smooth_l1_loss_0 / smooth_l1_loss_backward_0 and binary_cross_entropy_with_logits (SmoothL1Loss, BinaryCrossEntropyWithLogitsLoss:
+ * ops.scala:1207-1247, 1309-1367); reduction 0 none / 1 mean / 2 sum; pos_weight may be NULL */
+int lamp_smooth_l1_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction, double beta);
+int lamp_smooth_l1_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* target,
+                                 int64_t reduction, double beta);
+int lamp_binary_cross_entropy_with_logits(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target,
+                                          const lamp_tensor* pos_weight_or_null, int64_t reduction);
 
 /* ------------------------------------------------------------------------------------------
  * indexing / sampling   (index_select, index_add_0, index, masked_select, repeat_interleave_2,
@@ -422,6 +435,13 @@ int lamp_index_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, cons
 int lamp_index_add_(lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
 int lamp_masked_select(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask);   /* syncs (output size) */
 int lamp_repeat_interleave(lamp_tensor** out, const lamp_tensor* a, int64_t repeats, int64_t dim);
+int lamp_repeat_interleave_tensor(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* repeats /* i64[size(dim)] */, int64_t dim); /* syncs */
+/* masked_scatter / gather / scatter_add / index_fill: the ATen calls behind lamp's MaskSelect, ElementWiseMinimum / Maximum, ScatterAdd and
+ * IndexFill closures (ops.scala:133-177, 410-434, 2287-2340).  An index outside the tensor raises at the next host wait. */
+int lamp_masked_scatter(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* mask, const lamp_tensor* source);
+int lamp_gather(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index);
+int lamp_scatter_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src);
+int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value);
 int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted);
 int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes);
 int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tensor* indices);

@@ -103,6 +103,31 @@ class Variable:
     def nllLoss(self, target: STen, weights: STen, reduction=1, ignore=-100):
         return apply_op("NllLoss", [self], tensors=[target, weights], i=[reduction, ignore])
     def mseLoss(self, target: STen, reduction=1): return apply_op("MseLoss", [self], tensors=[target], i=[reduction])
+    # the rest of Variable's methods (autograd.scala:296-486) over ops2.cpp
+    def select(self, dim, index): return apply_op("Select", [self], i=[dim, index])
+    def slice(self, dim, start, end, step): return apply_op("Slice", [self], i=[dim, start, end, step])
+    def assign(self, other): return apply_op("Assign", [self, other])
+    def maskFill(self, mask, fill): return apply_op("MaskFill", [self], tensors=[mask.value], d=[fill])
+    def maskSelect(self, mask): return apply_op("MaskSelect", [self, mask])
+    def cast(self, scalarTypeByte): return apply_op("CastToPrecision", [self], i=[scalarTypeByte])
+    def scatterAdd(self, index, dim, maxIndex): return apply_op("ScatterAdd", [self, index], i=[dim, maxIndex])
+    def indexAdd(self, index, dim, maxIndex): return apply_op("IndexAdd", [self, index], i=[dim, maxIndex])
+    def indexAddFromSource(self, index, dim, source): return apply_op("IndexAddToTarget", [self, source, index], i=[dim])
+    def indexFill(self, index, dim, fillValue): return apply_op("IndexFill", [self, index], d=[fillValue], i=[dim])
+    def expandAs(self, other: STen): return apply_op("ExpandAs", [self], tensors=[other])
+    def expand(self, shape): return apply_op("Expand", [self], i=list(shape))
+    def tan(self): return apply_op("Tan", [self])
+    def atan(self): return apply_op("ArcTan", [self])
+    def powv(self, exponent): return apply_op("Pow", [self, exponent])
+    def minimum(self, other): return apply_op("ElementWiseMinimum", [self, other])
+    def maximum(self, other): return apply_op("ElementWiseMaximum", [self, other])
+    def crossEntropy(self, other): return (self * other).rowSum() * -1.0            # autograd.scala:391-392
+    def squaredFrobenius(self): return apply_op("SquaredFrobeniusMatrixNorm", [self])
+    def variance(self, dim): return apply_op("Variance", [self], i=list(dim))
+    def repeatInterleave(self, repeats, dim): return apply_op("RepeatInterleave", [self, repeats], i=[dim])
+    def smoothL1Loss(self, target: STen, reduction=1, beta=1.0): return apply_op("SmoothL1Loss", [self], tensors=[target], d=[beta], i=[reduction])
+    def binaryCrossEntropyWithLogitsLoss(self, target: STen, posWeights: Optional[STen] = None, reduction=1):
+        return apply_op("BinaryCrossEntropyWithLogitsLoss", [self], tensors=[target] + ([posWeights] if posWeights is not None else []), i=[reduction])
 
 
 def const(t: STen) -> Variable:
@@ -147,4 +172,8 @@ def LayerNormOp(input, weight, bias, normalizedShape, eps):
 
 
 def CappedShiftedNegativeExponential(a, shift): return apply_op("CappedShiftedNegativeExponential", [a], d=[shift])
+def Stack(inputs, dim): return apply_op("Stack", list(inputs), i=[dim])
+def Where(condition: STen, trueBranch, falseBranch): return apply_op("Where", [trueBranch, falseBranch], tensors=[condition])
+def WeightNorm(v, g, dim): return apply_op("WeightNorm", [v, g], i=[dim])
+def MaxPool1D(input, kernelSize, stride=1, padding=0, dilation=1): return apply_op("MaxPool1D", [input], i=[kernelSize, stride, padding, dilation])
 def Embedding(input, weight): return apply_op("Embedding", [input, weight])

@@ -97,6 +97,31 @@ int lamp_op_apply(lamp_var** out, const char* name, lamp_var* const* vars, int n
   else if (n == "LayerNormOp") r = F::layer_norm(V(0), V(1), V(2), IV(0, ni), D(0));
   else if (n == "Embedding") r = F::embedding(V(0), V(1));
   else if (n == "MaskFill") r = F::mask_fill(V(0), T(0), D(0));                       // tensors = [mask], d = [fill]
+  else if (n == "Stack") { std::vector<Var> as; for (int k = 0; k < nvars; k++) as.push_back(V(k)); r = F::stack(as, I(0)); }
+  else if (n == "Select") r = F::select(V(0), I(0), I(1));
+  else if (n == "Slice") r = F::slice(V(0), I(0), I(1), I(2), I(3));
+  else if (n == "MaskSelect") r = F::mask_select(V(0), V(1));
+  else if (n == "IndexFill") r = F::index_fill(V(0), I(0), V(1), D(0));
+  else if (n == "Where") r = F::where(T(0), V(0), V(1));                               // tensors = [condition]
+  else if (n == "Assign") r = F::assign(V(0), V(1));                                   // (abandon, keep)
+  else if (n == "CastToPrecision") r = F::cast_to_precision(V(0), (int)I(0));          // i = [scalar type byte]
+  else if (n == "ScatterAdd") r = F::scatter_add(V(0), V(1), I(0), I(1));              // i = [dim, maxIndex]
+  else if (n == "IndexAdd") r = F::index_add(V(0), V(1), I(0), I(1));
+  else if (n == "IndexAddToTarget") r = F::index_add_to_target(V(0), V(1), V(2), I(0)); // (target, src, index)
+  else if (n == "RepeatInterleave") r = F::repeat_interleave(V(0), V(1), I(0));
+  else if (n == "ExpandAs") r = F::expand_as(V(0), T(0));
+  else if (n == "Expand") r = F::expand(V(0), IV(0, ni));
+  else if (n == "Tan") r = F::tan(V(0));
+  else if (n == "ArcTan") r = F::atan(V(0));
+  else if (n == "Pow") r = F::pow(V(0), V(1));
+  else if (n == "ElementWiseMinimum") r = F::minimum(V(0), V(1));
+  else if (n == "ElementWiseMaximum") r = F::maximum(V(0), V(1));
+  else if (n == "Variance") r = F::variance(V(0), IV(0, ni));
+  else if (n == "SquaredFrobeniusMatrixNorm") r = F::squared_frobenius(V(0));
+  else if (n == "WeightNorm") r = F::weight_norm(V(0), V(1), I(0));
+  else if (n == "SmoothL1Loss") r = F::smooth_l1_loss(V(0), T(0), I(0), D(0));         // tensors = [target], i = [reduction], d = [beta]
+  else if (n == "BinaryCrossEntropyWithLogitsLoss") r = F::binary_cross_entropy_with_logits(V(0), T(0), ntensors > 1 && tensors[1] ? T(1) : Ten(), I(0));
+  else if (n == "MaxPool1D") r = F::max_pool1d(V(0), I(0), I(1), I(2), I(3));
   else LAMP_CHECK(false, "unknown Op '" << n << "'");
   *out = wrap(r);
   LAMP_API_END

@@ -64,6 +64,33 @@ Var layer_norm(const Var& input, const Var& weight /*nullable*/, const Var& bias
                double eps);
 Var embedding(const Var& input, const Var& weight);
 
+// ops2.cpp: the rest of the operators the reference's gradient suite exercises (ops.scala line numbers there)
+Var stack(const std::vector<Var>& as, int64_t dim);
+Var select(const Var& a, int64_t dim, int64_t index);
+Var slice(const Var& a, int64_t dim, int64_t start, int64_t end, int64_t step);
+Var mask_select(const Var& input, const Var& mask);
+Var index_fill(const Var& input, int64_t dim, const Var& index, double fill);
+Var where(const Ten& condition, const Var& trueBranch, const Var& falseBranch);
+Var assign(const Var& abandon, const Var& keep);
+Var cast_to_precision(const Var& a, int dtype);
+Var scatter_add(const Var& src, const Var& index, int64_t dim, int64_t maxIndex);
+Var index_add(const Var& src, const Var& index, int64_t dim, int64_t maxIndex);
+Var index_add_to_target(const Var& target, const Var& src, const Var& index, int64_t dim);
+Var repeat_interleave(const Var& self, const Var& repeats, int64_t dim);
+Var expand_as(const Var& a, const Ten& as);
+Var expand(const Var& a, const std::vector<int64_t>& shape);
+Var tan(const Var& a);
+Var atan(const Var& a);
+Var pow(const Var& a, const Var& exponent);
+Var minimum(const Var& a, const Var& b);
+Var maximum(const Var& a, const Var& b);
+Var variance(const Var& a, const std::vector<int64_t>& dim);
+Var squared_frobenius(const Var& a);
+Var weight_norm(const Var& v, const Var& g, int64_t dim);
+Var smooth_l1_loss(const Var& input, const Ten& target, int64_t reduction, double beta);
+Var binary_cross_entropy_with_logits(const Var& input, const Ten& target, const Ten& posWeights /* may be undefined */, int64_t reduction);
+Var max_pool1d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation);
+
 }  // namespace F
 }  // namespace host
 }  // namespace lamp

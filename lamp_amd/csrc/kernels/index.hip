@@ -156,6 +156,72 @@ __global__ __launch_bounds__(MS_BLOCK) void ms_scatter_kernel(const T* __restric
   for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) out[pos++] = a[base + k];
 }
 
+// masked_scatter: out = self with the positions where mask is true replaced by CONSECUTIVE elements of source (row-major order of the
+// true positions) - ATen's masked_scatter, which lamp's MaskSelect / ElementWiseMinimum / ElementWiseMaximum backward closures use
+// (ops.scala:133-146, 2287-2340).  Same two-level scan as masked_select.
+template <class T>
+__global__ __launch_bounds__(MS_BLOCK) void ms_masked_scatter_kernel(T* __restrict__ out, const uint8_t* __restrict__ mask, int64_t n,
+                                                                     const int64_t* __restrict__ offsets, const T* __restrict__ src, int64_t nsrc) {
+  __shared__ int sm[MS_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * MS_TILE + threadIdx.x * MS_ITEMS;
+  int c = 0;
+  for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) c++;
+  sm[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < MS_BLOCK; off <<= 1) {
+    int v = threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t pos = offsets[blockIdx.x] + sm[threadIdx.x] - c;
+  for (int k = 0; k < MS_ITEMS; k++) if (base + k < n && mask[base + k]) { if (pos < nsrc) out[base + k] = src[pos]; pos++; }
+}
+
+// gather / scatter_add along `dim` for tensors of one rank: coordinates of an element of `index` with the coordinate along dim
+// replaced by the index value address the other tensor (ATen gather / scatter_add; lamp's ScatterAdd op, ops.scala:410-434)
+struct GsGeom { int ndim; int dim; int64_t isz[kMaxDims]; int64_t istr[kMaxDims]; int64_t astr[kMaxDims]; int64_t bstr[kMaxDims]; int64_t dlim; };
+template <class T, bool SCATTER>
+__global__ void gather_scatter_kernel(T* __restrict__ a /* gather: out ; scatter: self */, const int64_t* __restrict__ index, const T* __restrict__ b /* gather: input ; scatter: src */,
+                                      int64_t n, GsGeom g, int* __restrict__ assert_word) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e, io = 0, ao = 0, bo = 0;
+    for (int d = g.ndim - 1; d >= 0; d--) {
+      const int64_t c = r % g.isz[d]; r /= g.isz[d];
+      io += c * g.istr[d];
+      if (d != g.dim) { ao += c * g.astr[d]; bo += c * g.bstr[d]; }
+      else { if (SCATTER) bo += c * g.bstr[d]; else ao += c * g.astr[d]; }
+    }
+    const int64_t t = index[io];
+    if (t < 0 || t >= g.dlim) { *(volatile int*)assert_word = kAssertIndexRange; continue; }
+    if (SCATTER) atomic_add_t<T>(a + ao + t * g.astr[g.dim], b[bo]);
+    else a[ao] = b[bo + t * g.bstr[g.dim]];
+  }
+}
+// index_fill along dim (IndexFill op, ops.scala:160-177)
+template <class T>
+__global__ void index_fill_kernel(T* __restrict__ out, const int64_t* __restrict__ index, int64_t nidx, int64_t outer, int64_t D, int64_t inner, T value) {
+  const int64_t total = outer * nidx * inner;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t in = e % inner, k = (e / inner) % nidx, o = e / (inner * nidx);
+    const int64_t t = index[k];
+    if (t >= 0 && t < D) out[(o * D + t) * inner + in] = value;
+  }
+}
+// repeat_interleave with one count per slice (ATen repeat_interleave.self_Tensor; RepeatInterleave op, ops.scala:484-509): `starts` is
+// the exclusive prefix sum of the counts
+template <class T>
+__global__ void repeat_interleave_tensor_kernel(const T* __restrict__ a, T* __restrict__ out, const int64_t* __restrict__ starts, int64_t outer, int64_t D,
+                                                int64_t inner, int64_t Dout) {
+  const int64_t total = outer * Dout * inner;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t in = e % inner, j = (e / inner) % Dout, o = e / (inner * Dout);
+    int64_t lo = 0, hi = D - 1;                      // largest d with starts[d] <= j
+    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (starts[mid] <= j) lo = mid; else hi = mid - 1; }
+    out[e] = a[(o * D + lo) * inner + in];
+  }
+}
+
 // ---- top-k along the last dim, k <= 64: one wavefront per row, threshold + compaction ------------------------------------
 // (the kNN graph spends its time here: one call per distance block, rows of ~2048 candidates, k = 10)
 //   pass 1: every lane takes the minimum of its strided share of the row; a 64-lane bitonic sort of those minima gives
@@ -524,6 +590,119 @@ int lamp_repeat_interleave(lamp_tensor** out, const lamp_tensor* a, int64_t repe
   if (total) {
     LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((repeat_interleave_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
                                                       current_stream(a->device()), ac->ptr<T>(), r->ptr<T>(), outer, D, inner, repeats));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_masked_scatter(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* mask, const lamp_tensor* source) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self"); check_device_tensor(mask, "mask"); check_device_tensor(source, "source");
+  LAMP_CHECK(mask->dtype == kBool || mask->dtype == kU8, "masked_scatter expects a bool mask");
+  LAMP_CHECK(source->dtype == self->dtype, "masked_scatter: source dtype " << source->describe() << " differs from self " << self->describe());
+  Hold r(new_tensor(self->shape(), self->dtype, self->device())), me(new_tensor(self->shape(), mask->dtype, self->device()));
+  copy_into(r.get(), self);
+  copy_into(me.get(), mask);                      // mask broadcasts to self
+  Hold sc(contiguous(source));
+  const int64_t n = r->numel();
+  if (n) {
+    const int64_t nblocks = (n + MS_TILE - 1) / MS_TILE;
+    hipStream_t st = current_stream(self->device());
+    int64_t cs[1] = {nblocks + 1};
+    Hold counts(new_tensor(cs, 1, kI64, self->device()));
+    hipLaunchKernelGGL(ms_count_kernel, dim3((unsigned)nblocks), dim3(MS_BLOCK), 0, st, me->ptr<uint8_t>(), n, counts->ptr<int64_t>());
+    hipLaunchKernelGGL(ms_scan_kernel, dim3(1), dim3(1), 0, st, counts->ptr<int64_t>(), nblocks, counts->ptr<int64_t>() + nblocks);
+    LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((ms_masked_scatter_kernel<T>), dim3((unsigned)nblocks), dim3(MS_BLOCK), 0, st, r->ptr<T>(),
+                                                         me->ptr<uint8_t>(), n, counts->ptr<int64_t>(), sc->ptr<T>(), sc->numel()));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+static GsGeom gs_geom(const Tensor* a, const Tensor* index, const Tensor* b, int64_t dim, bool scatter) {
+  LAMP_CHECK(index->dtype == kI64, "index must be int64, got " << index->describe());
+  LAMP_CHECK(a->ndim == index->ndim && b->ndim == index->ndim && index->ndim >= 1, "gather / scatter_add: self, index and source must have one rank");
+  GsGeom g;
+  g.ndim = index->ndim;
+  g.dim = (int)wrap_dim(dim, index->ndim);
+  for (int d = 0; d < g.ndim; d++) {
+    g.isz[d] = index->sizes[d]; g.istr[d] = index->strides[d]; g.astr[d] = a->strides[d]; g.bstr[d] = b->strides[d];
+    if (d != g.dim) LAMP_CHECK(index->sizes[d] <= a->sizes[d] && index->sizes[d] <= b->sizes[d], "gather / scatter_add: index is larger than the tensors along dim " << d);
+  }
+  g.dlim = scatter ? a->sizes[g.dim] : b->sizes[g.dim];
+  if (scatter) LAMP_CHECK(index->sizes[g.dim] <= b->sizes[g.dim], "scatter_add: index is longer than src along dim");
+  return g;
+}
+int lamp_gather(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(index, "index");
+  Hold r(new_tensor(index->shape(), a->dtype, a->device()));
+  const GsGeom g = gs_geom(r.get(), index, a, dim, false);
+  const int64_t n = index->numel();
+  if (n) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((gather_scatter_kernel<T, false>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(a->device()),
+                                                      r->ptr<T>(), index->ptr<int64_t>(), a->ptr<T>(), n, g, device_assert_word(a->device())));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_scatter_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self"); check_device_tensor(index, "index"); check_device_tensor(src, "src");
+  LAMP_CHECK(self->dtype == src->dtype, "scatter_add: dtype mismatch");
+  Hold r(new_tensor(self->shape(), self->dtype, self->device()));
+  copy_into(r.get(), self);
+  const GsGeom g = gs_geom(r.get(), index, src, dim, true);
+  const int64_t n = index->numel();
+  if (n) {
+    LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((gather_scatter_kernel<T, true>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(self->device()),
+                                                         r->ptr<T>(), index->ptr<int64_t>(), src->ptr<T>(), n, g, device_assert_word(self->device())));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_index(index);
+  Hold r(new_tensor(a->shape(), a->dtype, a->device()));
+  copy_into(r.get(), a);
+  Hold ic(contiguous(index));
+  int64_t outer, D, inner;
+  split3(a, dim, outer, D, inner);
+  const int64_t total = outer * ic->numel() * inner;
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((index_fill_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, current_stream(a->device()), r->ptr<T>(),
+                                                      ic->ptr<int64_t>(), ic->numel(), outer, D, inner, store_as<T>((acc_t<T>)value)));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_repeat_interleave_tensor(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* repeats, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_index(repeats);
+  int64_t outer, D, inner;
+  split3(a, dim, outer, D, inner);
+  LAMP_CHECK(repeats->numel() == D, "repeat_interleave: " << repeats->numel() << " counts for " << D << " slices");
+  // the output size is the sum of the counts: one small device -> host copy (as ATen)
+  std::vector<int64_t> rep((size_t)D), starts((size_t)D);
+  Hold rc(contiguous(repeats));
+  if (D) LAMP_CHECK(lamp_copy_to_host(rc.get(), rep.data(), (size_t)D * 8) == 0, lamp_last_error());
+  int64_t Dout = 0;
+  for (int64_t d = 0; d < D; d++) { LAMP_CHECK(rep[d] >= 0, "repeats must be non-negative"); starts[d] = Dout; Dout += rep[d]; }
+  int64_t dd[1] = {D};
+  Hold st_t(new_tensor(dd, 1, kI64, a->device()));
+  if (D) LAMP_CHECK(lamp_copy_from_host(st_t.get(), starts.data(), (size_t)D * 8) == 0, lamp_last_error());
+  Hold ac(contiguous(a));
+  std::vector<int64_t> oshape = a->shape();
+  if (a->ndim) oshape[wrap_dim(dim, a->ndim)] = Dout; else oshape = {Dout};
+  Hold r(new_tensor(oshape, a->dtype, a->device()));
+  const int64_t total = r->numel();
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((repeat_interleave_tensor_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                                      current_stream(a->device()), ac->ptr<T>(), r->ptr<T>(), st_t->ptr<int64_t>(), outer, D, inner, Dout));
     LAMP_LAUNCH_CHECK();
   }
   *out = r.take();

@@ -188,6 +188,56 @@ static std::vector<int64_t> pooled_shape(const Tensor* x, const PoolGeom& g) {
   return s;
 }
 
+// ---- 1-D max pooling over [N, C, L] (ATen max_pool1d_with_indices; MaxPool1D op, ops.scala:1658-1715) ------------------------------
+// indices are positions along L (what the reference's backward index_adds with); ties and NaN as ATen: the first maximum, NaN wins
+struct Pool1Geom { int64_t NC, L, Lo; int k, s, p, d; };
+template <class T>
+__global__ void max_pool1d_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t* __restrict__ idx, Pool1Geom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.Lo;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lo = e % g.Lo, nc = e / g.Lo;
+    const T* xp = x + nc * g.L;
+    int64_t best = -1;
+    A bv = 0;
+    for (int j = 0; j < g.k; j++) {
+      const int64_t l = lo * g.s - g.p + (int64_t)j * g.d;
+      if (l < 0 || l >= g.L) continue;
+      const A v = load_as<A>(xp[l]);
+      if (best < 0 || v > bv || v != v) { if (!(best >= 0 && bv != bv)) { bv = v; best = l; } }
+    }
+    y[e] = store_as<T>(bv);
+    idx[e] = best < 0 ? 0 : best;
+  }
+}
+// gather form (deterministic): input position l collects the gradients of every window whose maximum it was
+template <class T>
+__global__ void max_pool1d_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ idx, T* __restrict__ dx, Pool1Geom g) {
+  using A = acc_t<T>;
+  const int64_t total = g.NC * g.L;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t l = e % g.L, nc = e / g.L;
+    A acc = 0;
+    // windows lo with lo * s - p <= l <= lo * s - p + (k - 1) d
+    int64_t lo_min = (l + g.p - (int64_t)(g.k - 1) * g.d + g.s - 1) / g.s;
+    if (l + g.p - (int64_t)(g.k - 1) * g.d < 0) lo_min = 0;
+    const int64_t lo_max = min((l + g.p) / g.s, g.Lo - 1);
+    for (int64_t lo = lo_min; lo <= lo_max; lo++)
+      if (idx[nc * g.Lo + lo] == l) acc += load_as<A>(dy[nc * g.Lo + lo]);
+    dx[e] = store_as<T>(acc);
+  }
+}
+static Pool1Geom pool1_geom(const Tensor* x, int64_t kernel, int64_t stride, int64_t padding, int64_t dilation, int ceil_mode) {
+  LAMP_CHECK(x->ndim == 3, "assertion failed: Input dimensions must be 3 (MaxPool1D), got " << x->describe());
+  LAMP_CHECK(kernel >= 1 && stride >= 1 && padding >= 0 && dilation >= 1 && padding * 2 <= kernel, "max_pool1d: bad kernel / stride / padding / dilation");
+  Pool1Geom g;
+  g.NC = x->sizes[0] * x->sizes[1]; g.L = x->sizes[2];
+  g.k = (int)kernel; g.s = (int)stride; g.p = (int)padding; g.d = (int)dilation;
+  g.Lo = pool_out(g.L, g.k, g.s, g.p, g.d, ceil_mode);
+  LAMP_CHECK(g.Lo >= 1, "max_pool1d: output would be empty");
+  return g;
+}
+
 }  // namespace lamp
 
 using namespace lamp;
@@ -281,6 +331,43 @@ int lamp_max_pool2d_with_indices_backward(lamp_tensor** out, const lamp_tensor* 
   if (total) {
     LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((max_pool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
                                                         current_stream(x->device()), gc->ptr<T>(), ic->ptr<int64_t>(), dx->ptr<T>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = dx.take();
+  LAMP_API_END
+}
+
+int lamp_max_pool1d_with_indices(lamp_tensor** out, lamp_tensor** indices, const lamp_tensor* x, int64_t kernel, int64_t stride, int64_t padding,
+                                 int64_t dilation, int ceil_mode) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input");
+  const Pool1Geom g = pool1_geom(x, kernel, stride, padding, dilation, ceil_mode);
+  Hold xc(contiguous(x));
+  int64_t os[3] = {x->sizes[0], x->sizes[1], g.Lo};
+  Hold y(new_tensor(os, 3, x->dtype, x->device())), idx(new_tensor(os, 3, kI64, x->device()));
+  const int64_t total = y->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((max_pool1d_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, current_stream(x->device()),
+                                                        xc->ptr<T>(), y->ptr<T>(), idx->ptr<int64_t>(), g));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = y.take();
+  *indices = idx.take();
+  LAMP_API_END
+}
+int lamp_max_pool1d_with_indices_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel, int64_t stride,
+                                          int64_t padding, int64_t dilation, int ceil_mode, const lamp_tensor* indices) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out"); check_device_tensor(indices, "indices");
+  const Pool1Geom g = pool1_geom(x, kernel, stride, padding, dilation, ceil_mode);
+  LAMP_CHECK(grad_out->ndim == 3 && grad_out->sizes[2] == g.Lo && indices->shape() == grad_out->shape() && indices->dtype == kI64 && grad_out->dtype == x->dtype,
+             "max_pool1d_with_indices_backward: shape/dtype mismatch");
+  Hold gc(contiguous(grad_out)), ic(contiguous(indices));
+  Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
+  const int64_t total = dx->numel();
+  if (total) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((max_pool1d_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, current_stream(x->device()),
+                                                        gc->ptr<T>(), ic->ptr<int64_t>(), dx->ptr<T>(), g));
     LAMP_LAUNCH_CHECK();
   }
   *out = dx.take();

@@ -13,6 +13,8 @@ namespace lamp {
 
 template <class A> __device__ __forceinline__ A t_exp(A x) { return (A)exp((double)x); }
 template <> __device__ __forceinline__ float t_exp(float x) { return expf(x); }
+template <class A> __device__ __forceinline__ A t_log1p(A x) { return (A)log1p((double)x); }
+template <> __device__ __forceinline__ float t_log1p(float x) { return log1pf(x); }
 template <class A> __device__ __forceinline__ A t_log(A x) { return (A)log((double)x); }
 template <> __device__ __forceinline__ float t_log(float x) { return logf(x); }
 
@@ -211,6 +213,43 @@ __global__ void nll_bwd_kernel(const T* __restrict__ grad, const int64_t* __rest
   }
 }
 
+// smooth_l1 (ATen smooth_l1_loss: |d| < beta ? 0.5 d^2 / beta : |d| - 0.5 beta; beta = 0: l1) and its derivative wrt the input
+template <class T>
+__global__ void smooth_l1_kernel(const T* __restrict__ x, const T* __restrict__ t, T* __restrict__ out, int64_t n, double beta) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const A d = load_as<A>(x[i]) - load_as<A>(t[i]);
+    const A z = d < A(0) ? -d : d;
+    out[i] = store_as<T>((A)(z < (A)beta ? A(0.5) * z * z / (A)beta : z - A(0.5) * (A)beta));
+  }
+}
+template <class T>
+__global__ void smooth_l1_bwd_kernel(const T* __restrict__ grad, const T* __restrict__ x, const T* __restrict__ t, T* __restrict__ out, int64_t n,
+                                     double beta, double norm, int grad_scalar) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const A g = load_as<A>(grad_scalar ? grad[0] : grad[i]);
+    const A d = load_as<A>(x[i]) - load_as<A>(t[i]);
+    A r;
+    if (d <= -(A)beta) r = -(A)norm * g;
+    else if (d >= (A)beta) r = (A)norm * g;
+    else r = (A)norm * d * g / (A)beta;
+    out[i] = store_as<T>(r);
+  }
+}
+// binary_cross_entropy_with_logits (ATen): loss = (1 - y) x + (1 + (pw - 1) y) (log1p(exp(-|x|)) + max(-x, 0)); pw broadcasts over x
+template <class T>
+__global__ void bce_logits_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ pw, T* __restrict__ out, int64_t n, int64_t pw_n) {
+  using A = acc_t<T>;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const A xv = load_as<A>(x[i]), yv = load_as<A>(y[i]);
+    const A ax = xv < A(0) ? -xv : xv, nx = -xv > A(0) ? -xv : A(0);
+    const A lse = t_log1p<A>(t_exp<A>(-ax)) + nx;
+    const A w = pw ? A(1) + (load_as<A>(pw[i % pw_n]) - A(1)) * yv : A(1);
+    out[i] = store_as<T>((A)((A(1) - yv) * xv + w * lse));
+  }
+}
+
 // mse backward: out = (x - t) * grad * scale  (grad is a scalar for mean/sum, elementwise for none)
 template <class T>
 __global__ void mse_bwd_kernel(const T* __restrict__ grad, const T* __restrict__ x, const T* __restrict__ t, T* __restrict__ out,
@@ -381,6 +420,73 @@ int lamp_mse_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* ta
   }
   if (reduction == 0) { *out = sq.take(); return 0; }
   return reduction == 1 ? lamp_mean_all(out, sq.get()) : lamp_sum_all(out, sq.get());
+  LAMP_API_END
+}
+
+int lamp_smooth_l1_loss(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction, double beta) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(target, "target");
+  LAMP_CHECK(x->shape() == target->shape() && x->dtype == target->dtype, "smooth_l1_loss: input/target mismatch " << x->describe() << " vs " << target->describe());
+  LAMP_CHECK(beta >= 0, "smooth_l1_loss: negative beta");
+  Hold xc(contiguous(x)), tc(contiguous(target));
+  Hold el(new_like(xc.get()));
+  const int64_t n = x->numel();
+  if (n > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((smooth_l1_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(x->device()), xc->ptr<T>(),
+                                                        tc->ptr<T>(), el->ptr<T>(), n, beta));
+    LAMP_LAUNCH_CHECK();
+  }
+  if (reduction == 0) { *out = el.take(); return 0; }
+  return reduction == 1 ? lamp_mean_all(out, el.get()) : lamp_sum_all(out, el.get());
+  LAMP_API_END
+}
+int lamp_smooth_l1_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* target, int64_t reduction, double beta) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(target, "target"); check_device_tensor(grad_out, "grad_output");
+  LAMP_CHECK(x->shape() == target->shape() && x->dtype == target->dtype && grad_out->dtype == x->dtype, "smooth_l1_loss_backward: mismatch");
+  const int64_t n = x->numel();
+  const int grad_scalar = grad_out->numel() == 1;
+  if (!grad_scalar) LAMP_CHECK(grad_out->numel() == n, "smooth_l1_loss_backward: grad_output has the wrong size");
+  Hold xc(contiguous(x)), tc(contiguous(target)), gc(contiguous(grad_out));
+  Hold gi(new_like(xc.get()));
+  const double norm = reduction == 1 ? 1.0 / (double)n : 1.0;
+  if (n > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((smooth_l1_bwd_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(x->device()),
+                                                        gc->ptr<T>(), xc->ptr<T>(), tc->ptr<T>(), gi->ptr<T>(), n, beta, norm, grad_scalar));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = gi.take();
+  LAMP_API_END
+}
+int lamp_binary_cross_entropy_with_logits(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* target, const lamp_tensor* pos_weight, int64_t reduction) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(target, "target");
+  LAMP_CHECK(x->shape() == target->shape() && x->dtype == target->dtype, "binary_cross_entropy_with_logits: input/target mismatch");
+  Hold xc(contiguous(x)), tc(contiguous(target));
+  Hold pc;
+  int64_t pw_n = 1;
+  if (pos_weight) {
+    check_device_tensor(pos_weight, "pos_weight");
+    LAMP_CHECK(pos_weight->dtype == x->dtype, "binary_cross_entropy_with_logits: pos_weight dtype");
+    // pos_weight broadcasts against the trailing dims of the input: it is dense over the last numel(pos_weight) elements of every row
+    auto bs = broadcast_shapes(x->shape(), pos_weight->shape());
+    LAMP_CHECK(bs == x->shape(), "binary_cross_entropy_with_logits: pos_weight does not broadcast to the input");
+    int lead = 0;
+    while (lead < pos_weight->ndim && pos_weight->sizes[lead] == 1) lead++;
+    for (int d = lead; d < pos_weight->ndim; d++)
+      LAMP_CHECK(pos_weight->sizes[d] == x->sizes[x->ndim - pos_weight->ndim + d], "binary_cross_entropy_with_logits: pos_weight must cover whole trailing dims");
+    pc = Hold(contiguous(pos_weight));
+    pw_n = pos_weight->numel();
+  }
+  Hold el(new_like(xc.get()));
+  const int64_t n = x->numel();
+  if (n > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((bce_logits_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(x->device()), xc->ptr<T>(),
+                                                        tc->ptr<T>(), pc.get() ? static_cast<const Tensor*>(pc.get())->ptr<T>() : (const T*)nullptr, el->ptr<T>(), n, pw_n));
+    LAMP_LAUNCH_CHECK();
+  }
+  if (reduction == 0) { *out = el.take(); return 0; }
+  return reduction == 1 ? lamp_mean_all(out, el.get()) : lamp_sum_all(out, el.get());
   LAMP_API_END
 }
 

@@ -376,6 +376,322 @@ class CappedShiftedNegativeExponential(Op):
         self.value = Variable(result, self)
 
 
+# ---- the rest of the operators the reference's gradient suite exercises (autograd.test.scala) ---------
+# Each closure issues the ATen calls of the Scala closure, in its order - quirks included (named where they are).
+class Stack(Op):            # ops.scala:64-72
+    def __init__(self, a: Sequence[Variable], dim):
+        self.params = [(v, (lambda idx: lambda p, out: out.add_(aten.select.int(p, dim, idx)))(i)) for i, v in enumerate(a)]
+        self.value = Variable(aten.stack([v.value for v in a], dim), self)
+
+
+class Concatenate(Op):      # ops.scala:51-62
+    def __init__(self, a: Sequence[Variable], dim):
+        self.params, start = [], 0
+        for v in a:
+            end = start + v.value.shape[dim]
+            self.params.append((v, (lambda s, e: lambda p, out: out.add_(aten.slice.Tensor(p, dim, s, e, 1)))(start, end)))
+            start = end
+        self.value = Variable(aten.cat([v.value for v in a], dim), self)
+
+
+class Reshape(Op):          # ops.scala:40-49
+    def __init__(self, a, shape):
+        self.params = [(a, lambda p, out: out.add_(aten.reshape(p, list(out.shape))))]
+        self.value = Variable(aten.reshape(a.value, list(shape)), self)
+
+
+class Select(Op):           # ops.scala:74-95
+    def __init__(self, a, dim, index):
+        def da(p, out):
+            tmp = torch.zeros(list(out.shape), dtype=a.value.dtype)
+            scalar = torch.tensor(index, dtype=torch.int64)
+            pshape = list(p.shape)
+            p2 = p.view(pshape[:dim] + [1] + pshape[dim:])
+            out.add_(aten.index_add(tmp, dim, scalar.reshape(1), p2))
+        self.params = [(a, da)]
+        self.value = Variable(aten.select.int(a.value, dim, index), self)
+
+
+class Slice(Op):            # ops.scala:96-119
+    def __init__(self, a, dim, start, end, step):
+        def da(p, out):
+            tmp = torch.zeros(list(out.shape), dtype=a.value.dtype)
+            out.add_(aten.index_add(tmp, dim, torch.arange(start, end, step, dtype=torch.int64), p))
+        self.params = [(a, da)]
+        self.value = Variable(aten.slice.Tensor(a.value, dim, start, end, step), self)
+
+
+class MaskFill(Op):         # ops.scala:148-159
+    def __init__(self, inp, mask: Variable, fill):
+        self.params = [(inp, lambda p, out: out.add_(aten.masked_fill.Scalar(p, mask.value, 0.0)))]
+        self.value = Variable(aten.masked_fill.Scalar(inp.value, mask.value, fill), self)
+
+
+class MaskSelect(Op):       # ops.scala:133-146
+    def __init__(self, inp, mask: Variable):
+        self.params = [(inp, lambda p, out: out.add_(aten.masked_scatter(torch.zeros_like(out), mask.value, p)))]
+        self.value = Variable(aten.masked_select(inp.value, mask.value), self)
+
+
+class IndexFill(Op):        # ops.scala:160-177
+    def __init__(self, inp, dim, index: Variable, fill):
+        self.params = [(inp, lambda p, out: out.add_(aten.index_fill.int_Scalar(p, dim, index.value, 0.0)))]
+        self.value = Variable(aten.index_fill.int_Scalar(inp.value, dim, index.value, fill), self)
+
+
+class Where(Op):            # ops.scala:198-229
+    def __init__(self, condition: torch.Tensor, t: Variable, f: Variable):
+        def dt(p, out):
+            out.addcmul_(p, aten.where.self(condition, torch.ones_like(t.value), torch.zeros_like(f.value)), value=1.0)
+
+        def df(p, out):
+            out.addcmul_(p, aten.where.self(condition, torch.zeros_like(t.value), torch.ones_like(f.value)), value=1.0)
+        self.params = [(t, dt), (f, df)]
+        self.value = Variable(aten.where.self(condition, t.value, f.value), self)
+
+
+class Assign(Op):           # ops.scala:242-249
+    def __init__(self, abandon, keep):
+        self.params = [(abandon, lambda p, out: None), (keep, lambda p, out: out.add_(p))]
+        self.value = Variable(keep.value, self)
+
+
+class CastToPrecision(Op):  # ops.scala:260-288: the same precision returns the variable itself
+    def __init__(self, a, dtype):
+        self.params = [(a, lambda p, out: out.add_(p.to(a.value.dtype)))]
+        self.value = a if a.value.dtype == dtype else Variable(a.value.to(dtype), self)
+
+
+class ScatterAdd(Op):       # ops.scala:410-434
+    def __init__(self, src, index: Variable, dim, maxIndex):
+        assert src.value.shape[dim] == index.value.shape[dim]
+        self.params = [(src, lambda p, out: out.add_(aten.gather(p, dim, index.value)))]
+        shape = list(src.value.shape)
+        shape[dim] = maxIndex
+        self.value = Variable(aten.scatter_add(torch.zeros(shape, dtype=src.value.dtype), dim, index.value, src.value), self)
+
+
+class IndexAdd(Op):         # ops.scala:436-460
+    def __init__(self, src, index: Variable, dim, maxIndex):
+        self.params = [(src, lambda p, out: out.add_(aten.index_select(p, dim, index.value)))]
+        shape = list(src.value.shape)
+        shape[dim] = maxIndex
+        self.value = Variable(aten.index_add(torch.zeros(shape, dtype=src.value.dtype), dim, index.value, src.value), self)
+
+
+class IndexAddToTarget(Op):  # ops.scala:462-482
+    def __init__(self, target, src, index: Variable, dim):
+        self.params = [(src, lambda p, out: out.add_(aten.index_select(p, dim, index.value))), (target, lambda p, out: out.add_(p))]
+        self.value = Variable(aten.index_add(target.value, dim, index.value, src.value), self)
+
+
+class RepeatInterleave(Op):  # ops.scala:484-509: the closure scatters back along dimension 0 whatever `dim` was
+    def __init__(self, a, repeats: Variable, dim):
+        def da(p, out):
+            plain = torch.arange(0, a.value.shape[0], 1, dtype=torch.int64)
+            rep = aten.repeat_interleave.self_Tensor(plain, repeats.value, 0)
+            out.add_(aten.index_add(torch.zeros_like(out), 0, rep, p))
+        self.params = [(a, da)]
+        self.value = Variable(aten.repeat_interleave.self_Tensor(a.value, repeats.value, dim), self)
+
+
+class ExpandAs(Op):         # ops.scala:647-653
+    def __init__(self, a, other: torch.Tensor):
+        self.params = [(a, lambda p, out: out.add_(unbroadcast(p, a.shape)))]
+        self.value = Variable(aten.expand_as(a.value, other), self)
+
+
+class Sin(Op):              # ops.scala:819-829
+    def __init__(self, a):
+        self.params = [(a, lambda p, out: out.addcmul_(p, aten.cos(a.value), value=1.0))]
+        self.value = Variable(aten.sin(a.value), self)
+
+
+class Cos(Op):              # ops.scala:830-840
+    def __init__(self, a):
+        def da(p, out):
+            tmp = aten.sin(a.value)
+            out.addcmul_(p, tmp, value=-1.0)
+        self.params = [(a, da)]
+        self.value = Variable(aten.cos(a.value), self)
+
+
+class Tan(Op):              # ops.scala:841-853
+    def __init__(self, a):
+        def da(p, out):
+            tmp1 = aten.pow.Tensor_Scalar(self.value.value, 2.0)
+            tmp1 += torch.ones(1, dtype=a.value.dtype)
+            out.addcmul_(p, tmp1, value=1.0)
+        self.params = [(a, da)]
+        self.value = Variable(aten.tan(a.value), self)
+
+
+class ArcTan(Op):           # ops.scala:864-878
+    def __init__(self, a):
+        def da(p, out):
+            tmp1 = aten.pow.Tensor_Scalar(a.value, 2.0)
+            tmp1 += torch.ones(1, dtype=a.value.dtype)
+            tmp1.reciprocal_()
+            out.addcmul_(p, tmp1, value=1.0)
+        self.params = [(a, da)]
+        self.value = Variable(aten.atan(a.value), self)
+
+
+class Pow(Op):              # ops.scala:890-916: the exponent is read as ONE host number; its gradient is p.unbroadcast([out.head or 1, 1]) * SUM(a^e log a)
+    def __init__(self, a, exponent: Variable):
+        def da(p, out):
+            e = float(exponent.value.reshape(-1)[0])
+            out.addcmul_(p, aten.pow.Tensor_Scalar(a.value, e - 1), value=e)
+
+        def de(p, out):
+            e = float(exponent.value.reshape(-1)[0])
+            tmp3 = aten.pow.Tensor_Scalar(a.value, e) * aten.log(a.value)
+            p2 = unbroadcast(p, [1 if out.dim() == 0 else out.shape[0], 1])
+            out.addcmul_(p2, aten.sum(tmp3), value=1.0)
+        self.params = [(a, da), (exponent, de)]
+        self.value = Variable(aten.pow.Tensor_Tensor(a.value, exponent.value), self)
+
+
+class Softplus(Op):         # ops.scala:989-1003
+    def __init__(self, a, beta, threshold):
+        self.params = [(a, lambda p, out: out.add_(aten.softplus_backward(p, a.value, beta, threshold)))]
+        self.value = Variable(aten.softplus(a.value, beta, threshold), self)
+
+
+class ElementWiseMinMax(Op):  # ops.scala:2287-2340: masked_scatter consumes p IN ORDER (not the elements under the mask)
+    def __init__(self, a, b, is_min):
+        val = aten.minimum(a.value, b.value) if is_min else aten.maximum(a.value, b.value)
+        mask = aten.eq.Tensor(a.value, val)
+        maskneg = aten.logical_not(mask)
+        self.params = [(a, lambda p, out: out.add_(aten.masked_scatter(torch.zeros_like(out), mask, p))),
+                       (b, lambda p, out: out.add_(aten.masked_scatter(torch.zeros_like(out), maskneg, p)))]
+        self.value = Variable(val, self)
+
+
+class Variance(Op):         # ops.scala:1055-1077: 2 / (SUM of the reduced sizes - 1), as written
+    def __init__(self, a, dim):
+        v, m = aten.var_mean.correction(a.value, dim, correction=1, keepdim=True)
+        n = sum(a.value.shape[d] for d in dim) - 1
+        self.params = [(a, lambda p, out: out.addcmul_(p, a.value - m, value=2.0 / n))]
+        self.value = Variable(v, self)
+
+
+class SquaredFrobeniusMatrixNorm(Op):  # ops.scala:1369-1383
+    def __init__(self, a):
+        self.params = [(a, lambda p, out: out.addcmul_(p, a.value, value=2.0))]
+        fr = aten.linalg_vector_norm(a.value, 2.0, [-2, -1], False)
+        self.value = Variable(aten.pow.Tensor_Scalar(fr, 2.0), self)
+
+
+class WeightNorm(Op):       # ops.scala:1103-1160 (arXiv 1602.07868 eq. 2 and 3)
+    def __init__(self, v, g, dim):
+        assert v.value.dim() == 2 and list(g.value.shape) == [1, v.value.shape[1]]
+        norm = aten.norm.ScalarOpt_dim(v.value, 2.0, [dim], False)
+
+        def gradg(p):
+            tmp1 = aten.sum.dim_IntList(p * v.value, [0], False)
+            return tmp1 / norm
+
+        def dv(p, out):
+            tmp3 = (g.value / norm) * p
+            tmp2 = g.value * gradg(p)
+            tmp2 = tmp2 / norm
+            tmp2 = tmp2 / norm
+            tmp4 = tmp2 * v.value
+            out.add_(tmp3 - tmp4)
+        self.params = [(v, dv), (g, lambda p, out: out.add_(gradg(p)))]
+        self.value = Variable((v.value * g.value) / norm, self)
+
+
+class SmoothL1Loss(Op):     # ops.scala:1207-1247
+    def __init__(self, inp, target, reduction=1, beta=1.0):
+        assert inp.value.numel() == target.numel()
+        tv = target.view(inp.value.shape)
+        self.params = [(inp, lambda p, out: out.add_(aten.smooth_l1_loss_backward(p, inp.value, tv, reduction, beta)))]
+        self.value = Variable(aten.smooth_l1_loss(inp.value, tv, reduction, beta), self)
+
+
+class BinaryCrossEntropyWithLogitsLoss(Op):  # ops.scala:1309-1367
+    def __init__(self, inp, target, posWeights=None, reduction=1):
+        assert list(inp.value.shape) == list(target.shape)
+
+        def da(p, out):
+            if posWeights is not None:
+                t = posWeights * target
+                t2 = t + 1.0
+                t2 -= target
+                t2 *= aten.sigmoid(inp.value)
+                t2 -= t
+            else:
+                t2 = aten.sigmoid(inp.value)
+                t2 -= target
+            t2 *= p
+            if reduction == 1:
+                t2 *= 1.0 / inp.value.numel()
+            out.add_(t2)
+        self.params = [(inp, da)]
+        self.value = Variable(aten.binary_cross_entropy_with_logits(inp.value, target, None, posWeights, reduction), self)
+
+
+class MaxPool1D(Op):        # ops.scala:1658-1715
+    def __init__(self, inp, k, stride=1, padding=0, dilation=1):
+        assert inp.value.dim() == 3
+        out, mask = aten.max_pool1d_with_indices(inp.value, [k], [stride], [padding], [dilation], False)
+
+        def da(p, o):
+            zeros = torch.zeros_like(o)
+            pf, mf, zf = p.flatten(0, 1), mask.flatten(0, 1), zeros.flatten(0, 1)
+            added = [aten.index_add(zf[i], 0, mf[i], pf[i]) for i in range(pf.shape[0])]
+            o.add_(aten._unsafe_view(aten.cat(added, 0), list(o.shape)))
+        self.params = [(inp, da)]
+        self.value = Variable(out, self)
+
+
+class Embedding(Op):        # ops.scala:2141-2185: embedding_backward with padding_idx = 0 (row 0 never receives a gradient)
+    def __init__(self, inp: Variable, weight: Variable):
+        def dw(p, out):
+            out.add_(aten.embedding_backward(p, inp.value, weight.value.shape[0], 0, False, False))
+        self.params = [(weight, dw)]
+        self.value = Variable(aten.embedding(weight.value, inp.value), self)
+
+
+def _more_variable_methods():
+    V = Variable
+    V.t = lambda self: Transpose(self, 0, 1).value
+    V.reshape = lambda self, shape: Reshape(self, shape).value
+    V.cat = lambda self, other, dim: Concatenate([self, other], dim).value
+    V.select = lambda self, dim, index: Select(self, dim, index).value
+    V.slice = lambda self, dim, start, end, step: Slice(self, dim, start, end, step).value
+    V.assign = lambda self, other: Assign(self, other).value
+    V.maskFill = lambda self, mask, fill: MaskFill(self, mask, fill).value
+    V.maskSelect = lambda self, mask: MaskSelect(self, mask).value
+    V.cast = lambda self, dtype: CastToPrecision(self, dtype).value
+    V.scatterAdd = lambda self, index, dim, maxIndex: ScatterAdd(self, index, dim, maxIndex).value
+    V.indexAdd = lambda self, index, dim, maxIndex: IndexAdd(self, index, dim, maxIndex).value
+    V.indexAddFromSource = lambda self, index, dim, source: IndexAddToTarget(self, source, index, dim).value
+    V.indexFill = lambda self, index, dim, fill: IndexFill(self, dim, index, fill).value
+    V.expandAs = lambda self, other: ExpandAs(self, other).value
+    V.rowSum = lambda self: self.sum([1], True)
+    V.colSum = lambda self: self.sum([0], True)
+    V.sin = lambda self: Sin(self).value
+    V.cos = lambda self: Cos(self).value
+    V.tan = lambda self: Tan(self).value
+    V.atan = lambda self: ArcTan(self).value
+    V.pow = lambda self, e: PowConst(self, e).value
+    V.powv = lambda self, e: Pow(self, e).value
+    V.softplus = lambda self, beta, threshold: Softplus(self, beta, threshold).value
+    V.minimum = lambda self, o: ElementWiseMinMax(self, o, True).value
+    V.maximum = lambda self, o: ElementWiseMinMax(self, o, False).value
+    V.crossEntropy = lambda self, other: (self * other).rowSum() * -1.0          # autograd.scala:391-392
+    V.squaredFrobenius = lambda self: SquaredFrobeniusMatrixNorm(self).value
+    V.variance = lambda self, dim: Variance(self, dim).value
+    V.repeatInterleave = lambda self, repeats, dim: RepeatInterleave(self, repeats, dim).value
+    V.mseLoss = lambda self, target, reduction=1: MseLoss(self, target, reduction).value
+    V.smoothL1Loss = lambda self, target, reduction=1, beta=1.0: SmoothL1Loss(self, target, reduction, beta).value
+    V.binaryCrossEntropyWithLogitsLoss = lambda self, target, posWeights=None, reduction=1: BinaryCrossEntropyWithLogitsLoss(self, target, posWeights, reduction).value
+    V.flattenLastDimensions = lambda self, dims: self.flatten(self.value.dim() - dims, -1)
+
+
 # ---- convolution / pooling (ops.scala:1547-1825) --------------------------------------------------
 class Convolution(Op):
     def __init__(self, inp, weight, bias, stride, padding, dilation, transposed, outputPadding, groups):
@@ -829,3 +1145,6 @@ def umap_loss(locations: Variable, index1, index2, index3, index4, b: torch.Tens
     if balance:
         return (attractions / bv.sum() + repulsions * (repulsionStrength / l3.shape[0])) * (-1.0)
     return (attractions + repulsions) * (-1.0)
+
+
+_more_variable_methods()

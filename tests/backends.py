@@ -28,6 +28,16 @@ class OracleBackend(Backend):
     def layer_norm(self, x, w, b, shape, eps): return self.O.LayerNormOp(x, w, b, shape, eps).value
     def avg_pool2d(self, x, k, s, p): return self.O.AvgPool2D(x, k, s, p).value
     def max_pool2d(self, x, k, s, p, d): return self.O.MaxPool2D(x, k, s, p, d).value
+    def max_pool1d(self, x, k, s, p, d): return self.O.MaxPool1D(x, k, s, p, d).value
+    def stack(self, xs, dim): return self.O.Stack(xs, dim).value
+    def where(self, cond, a, b): return self.O.Where(cond, a, b).value
+    def weight_norm(self, v, g, dim): return self.O.WeightNorm(v, g, dim).value
+    def embedding(self, inp, weight): return self.O.Embedding(inp, weight).value
+    def capped_exp(self, x, shift): return self.O.CappedShiftedNegativeExponential(x, shift).value
+    def cast_single(self, x): return x.cast(torch.float32)
+    def eq_scalar(self, t, v): return torch.ops.aten.eq.Scalar(t, v)
+    def const_bool(self, t): return self.O.const(t)
+    def param_transposed01(self, a): return self.O.param(self._t(a).transpose(0, 1))
 
 
 # give the oracle Variable the few method spellings the KATs use (lamp's names)
@@ -68,3 +78,13 @@ class HipBackend(Backend):
     def layer_norm(self, x, w, b, shape, eps): return self.A.LayerNormOp(x, w, b, shape, eps)
     def avg_pool2d(self, x, k, s, p): return self.A.AvgPool2D(x, k, s, p)
     def max_pool2d(self, x, k, s, p, d): return self.A.MaxPool2D(x, k, s, p, d)
+    def max_pool1d(self, x, k, s, p, d): return self.A.MaxPool1D(x, k, s, p, d)
+    def stack(self, xs, dim): return self.A.Stack(xs, dim)
+    def where(self, cond, a, b): return self.A.Where(cond, a, b)
+    def weight_norm(self, v, g, dim): return self.A.WeightNorm(v, g, dim)
+    def embedding(self, inp, weight): return self.A.Embedding(inp, weight)
+    def capped_exp(self, x, shift): return self.A.CappedShiftedNegativeExponential(x, shift)
+    def cast_single(self, x): return x.cast(self.S.F32)
+    def eq_scalar(self, t, v): return t.equ(v)
+    def const_bool(self, t): return self.A.const(t)
+    def param_transposed01(self, a): return self.A.param(self._t(a).transpose(0, 1))
