@@ -36,7 +36,17 @@ struct alignas(2) bf16_t {
   }
 };
 
+// f16 (IEEE half) storage type: lamp's HalfPrecision (STen.scala:726-731 scalar-type byte 5; AdamW's mixed-precision KAT runs on it,
+// adamw.test.scala:96-127).  Arithmetic happens in f32 (acc_t), the conversions are the hardware's round-to-nearest-even casts.
+struct alignas(2) f16_t {
+  uint16_t bits;
+  f16_t() = default;
+  __host__ __device__ explicit f16_t(float f) { _Float16 h = (_Float16)f; bits = __builtin_bit_cast(uint16_t, h); }
+  __host__ __device__ explicit operator float() const { return (float)__builtin_bit_cast(_Float16, bits); }
+};
+
 template <class T> struct acc_type { using type = T; };
+template <> struct acc_type<f16_t> { using type = float; };
 template <> struct acc_type<bf16_t> { using type = float; };
 template <> struct acc_type<float> { using type = float; };
 template <> struct acc_type<double> { using type = double; };
@@ -50,7 +60,14 @@ template <> __host__ __device__ inline float load_as<float, bf16_t>(const bf16_t
 template <> __host__ __device__ inline double load_as<double, bf16_t>(const bf16_t& v) { return (double)(float)v; }
 template <> __host__ __device__ inline int64_t load_as<int64_t, bf16_t>(const bf16_t& v) { return (int64_t)(float)v; }
 
+template <> __host__ __device__ inline float load_as<float, f16_t>(const f16_t& v) { return (float)v; }
+template <> __host__ __device__ inline double load_as<double, f16_t>(const f16_t& v) { return (double)(float)v; }
+template <> __host__ __device__ inline int64_t load_as<int64_t, f16_t>(const f16_t& v) { return (int64_t)(float)v; }
+
 template <class T, class A> __host__ __device__ inline T store_as(A v) { return (T)v; }
+template <> __host__ __device__ inline f16_t store_as<f16_t, float>(float v) { return f16_t(v); }
+template <> __host__ __device__ inline f16_t store_as<f16_t, double>(double v) { return f16_t((float)v); }
+template <> __host__ __device__ inline f16_t store_as<f16_t, int64_t>(int64_t v) { return f16_t((float)v); }
 template <> __host__ __device__ inline bf16_t store_as<bf16_t, float>(float v) { return bf16_t(v); }
 template <> __host__ __device__ inline bf16_t store_as<bf16_t, double>(double v) { return bf16_t((float)v); }
 template <> __host__ __device__ inline bf16_t store_as<bf16_t, int64_t>(int64_t v) { return bf16_t((float)v); }
@@ -67,6 +84,7 @@ template <class T> constexpr int vec_width() { return 16 / sizeof(T); }
     case ::lamp::kF32: { using T = float; __VA_ARGS__; } break;                                   \
     case ::lamp::kF64: { using T = double; __VA_ARGS__; } break;                                  \
     case ::lamp::kBF16: { using T = ::lamp::bf16_t; __VA_ARGS__; } break;                         \
+    case ::lamp::kF16: { using T = ::lamp::f16_t; __VA_ARGS__; } break;                           \
     default: throw ::lamp::Error(std::string(__func__) + ": unsupported floating dtype " +        \
                                  ::lamp::dtype_name(DT));                                         \
   }
@@ -76,6 +94,7 @@ template <class T> constexpr int vec_width() { return 16 / sizeof(T); }
     case ::lamp::kF32: { using T = float; __VA_ARGS__; } break;                                   \
     case ::lamp::kF64: { using T = double; __VA_ARGS__; } break;                                  \
     case ::lamp::kBF16: { using T = ::lamp::bf16_t; __VA_ARGS__; } break;                         \
+    case ::lamp::kF16: { using T = ::lamp::f16_t; __VA_ARGS__; } break;                           \
     case ::lamp::kI64: { using T = int64_t; __VA_ARGS__; } break;                                 \
     case ::lamp::kI32: { using T = int32_t; __VA_ARGS__; } break;                                 \
     case ::lamp::kU8: case ::lamp::kBool: { using T = uint8_t; __VA_ARGS__; } break;              \

@@ -142,7 +142,15 @@ template <bool KC> __device__ __forceinline__ bf8_t load_frag(const char* lds, i
   }
 }
 
-template <bool AKC, bool BKC>
+// E = bf16_t or f16_t: the two 16-bit floating types share the staging (bit patterns) and the fragment layout; only the MFMA opcode
+// (v_mfma_f32_16x16x32_bf16 / _f16) and the epilogue's rounding differ
+template <class E> __device__ __forceinline__ f4_t mfma16(bf8_t a, bf8_t b, f4_t c);
+template <> __device__ __forceinline__ f4_t mfma16<bf16_t>(bf8_t a, bf8_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+template <> __device__ __forceinline__ f4_t mfma16<f16_t>(bf8_t a, bf8_t b, f4_t c) {
+  typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+template <bool AKC, bool BKC, class E = bf16_t>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware tile order: consecutive tiles of one XCD share A row-panels in that XCD's L2
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma16<E>(fa[i], fb[j], acc[i][j]);
     }
     if (t + 1 < nk) {
       stage_store<AKC>(ra, As_(cur ^ 1), tid);
@@ -214,8 +222,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   }
 
   // epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-  bf16_t* C = (bf16_t*)g.C + bz * g.c_bs;
-  const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
+  E* C = (E*)g.C + bz * g.c_bs;
+  const E* S = g.S ? (const E*)g.S + bz * g.s_bs : nullptr;
   const float alpha = (float)g.alpha, beta = (float)g.beta;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -227,9 +235,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         const int64_t row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (row < g.M && col < g.N) {
           float v = alpha * acc[i][j][r];
-          if (g.round_first) v = (float)bf16_t(v);
+          if (g.round_first) v = (float)E(v);
           if (S) v += beta * (float)S[row * g.s_rs + col * g.s_cs];
-          C[row * g.ldc + col] = bf16_t(v);
+          C[row * g.ldc + col] = E(v);
         }
       }
     }
@@ -941,7 +949,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
   }
   const double g_flops = 2.0 * (double)g.M * (double)g.N * (double)g.K * g.batch;
   const double g_bytes = ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * (g.S ? 2 : 1)) * g.batch * (double)dtype_size(a->dtype);
-  const char* kt_tag = a->dtype == kBF16 ? "gemm_bf16" : (a->dtype == kF32 ? "gemm_f32" : "gemm_f64");
+  const char* kt_tag = a->dtype == kBF16 ? "gemm_bf16" : (a->dtype == kF16 ? "gemm_f16" : (a->dtype == kF32 ? "gemm_f32" : "gemm_f64"));
   static const bool shape_tags = getenv("LAMP_GEMM_SHAPE_TAGS") != nullptr;   // profiling aid: one timer class per shape and layout
   if (shape_tags) {
     static std::mutex mu;
@@ -1085,6 +1093,23 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     }
     run(g);
     return;
+  } else if (a->dtype == kF16) {
+    // half precision: the 128 x 128 x 64 register-staged kernel (every shape, bounds checked) on v_mfma_f32_16x16x32_f16
+    const bool akc = (g.a_cs == 1), bkc = (g.b_rs == 1);
+    LAMP_CHECK(akc || g.a_rs == 1, "internal: A has no unit stride");
+    LAMP_CHECK(bkc || g.b_cs == 1, "internal: B has no unit stride");
+    const int64_t lda = akc ? g.a_rs : g.a_cs, ldb = bkc ? g.b_cs : g.b_rs;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    g.a_vec = (lda % 8 == 0) && al16(g.A) && (g.a_bs % 8 == 0);
+    g.b_vec = (ldb % 8 == 0) && al16(g.B) && (g.b_bs % 8 == 0);
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (int)((g.N + BN - 1) / BN);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, g.batch);
+    const size_t lds = 4 * TILE_BYTES;
+    if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false, f16_t>), grid, dim3(256), lds, stm, g);
+    else if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, f16_t>), grid, dim3(256), lds, stm, g);
+    else if (!akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, f16_t>), grid, dim3(256), lds, stm, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, true, f16_t>), grid, dim3(256), lds, stm, g);
   } else if (a->dtype == kF32 || a->dtype == kF64) {
     g.tiles_m = (int)((g.M + FM - 1) / FM);
     g.tiles_n = (int)((g.N + FN - 1) / FN);
@@ -1100,7 +1125,7 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     } else if (a->dtype == kF32) hipLaunchKernelGGL((gemm_fp_kernel<float>), grid, dim3(256), 0, stm, g);
     else hipLaunchKernelGGL((gemm_fp_kernel<double>), grid, dim3(256), 0, stm, g);
   } else {
-    LAMP_CHECK(false, "GEMM supports bf16, f32 and f64, got " << a->describe());
+    LAMP_CHECK(false, "GEMM supports bf16, f16, f32 and f64, got " << a->describe());
   }
   LAMP_LAUNCH_CHECK();
 }

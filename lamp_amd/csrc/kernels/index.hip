@@ -38,6 +38,18 @@ template <> __device__ __forceinline__ void atomic_add_t<bf16_t>(bf16_t* p, bf16
   } while (old != assumed);
 }
 
+template <> __device__ __forceinline__ void atomic_add_t<f16_t>(f16_t* p, f16_t v) {
+  unsigned int* w = (unsigned int*)((uintptr_t)p & ~(uintptr_t)3);
+  const int sh = ((uintptr_t)p & 2) * 8;
+  unsigned int old = *w, assumed;
+  do {
+    assumed = old;
+    f16_t cur; cur.bits = (uint16_t)(assumed >> sh);
+    f16_t nw((float)cur + (float)v);
+    old = atomicCAS(w, assumed, (assumed & ~(0xffffu << sh)) | ((unsigned int)nw.bits << sh));
+  } while (old != assumed);
+}
+
 // a viewed as [outer, D, inner]
 template <class T>
 __global__ void index_select_kernel(const T* __restrict__ a, const int64_t* __restrict__ index, T* __restrict__ out, int64_t outer,

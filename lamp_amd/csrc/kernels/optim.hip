@@ -261,8 +261,8 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
   const int dev = params[0]->device();
   hipStream_t st = current_stream(dev);
   // group tensors by (state dtype, grad dtype) so that each launch is homogeneous
-  for (int pass_state : {kF32, kF64, kBF16}) {
-    for (int pass_grad : {kF32, kF64, kBF16}) {
+  for (int pass_state : {kF32, kF64, kBF16, kF16}) {
+    for (int pass_grad : {kF32, kF64, kBF16, kF16}) {
       std::vector<int> sel;
       for (int i = 0; i < n; i++) {
         check_device_tensor(params[i], "parameter"); check_device_tensor(grads[i], "gradient");
@@ -303,6 +303,8 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
       else if (pass_state == kF64 && pass_grad == kF64) ADAMW_LAUNCH(double, double);
       else if (pass_state == kF32 && pass_grad == kBF16) ADAMW_LAUNCH(float, bf16_t);
       else if (pass_state == kBF16 && pass_grad == kBF16) ADAMW_LAUNCH(bf16_t, bf16_t);
+      else if (pass_state == kF32 && pass_grad == kF16) ADAMW_LAUNCH(float, f16_t);      // mixed precision on half parameters (adamw.test.scala:96-127)
+      else if (pass_state == kF16 && pass_grad == kF16) ADAMW_LAUNCH(f16_t, f16_t);
       else LAMP_CHECK(false, "adamw: unsupported (state, gradient) dtype pair " << dtype_name(pass_state) << "/" << dtype_name(pass_grad));
 #undef ADAMW_LAUNCH
       LAMP_LAUNCH_CHECK();

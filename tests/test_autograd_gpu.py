@@ -59,6 +59,51 @@ def test_adamw_kats_on_gpu(gpu):
         assert np.array_equal(ph.to_numpy(), po.float().numpy()), "bf16 parameters must round identically"
 
 
+def test_fp16_mixed_precision_adamw_kat_on_gpu(gpu):
+    """adamw.test.scala:96-127: half-precision parameters and gradients, f32 working copy and moments: the exact values of the
+    reference after one and two steps (0.89990234375 -> 0.79931640625), computed by the fused kernel on f16 tensors."""
+    g = kats.GOLDEN["adamw"]
+    h = g["half_mixed"]
+    p = S.STen.from_numpy(np.array([g["init"]], dtype=np.float16), dtype=S.F16)
+    grad = S.STen.from_numpy(np.array([g["gradients"]], dtype=np.float16), dtype=S.F16)
+    opt = nn.AdamW([p], weightDecay=h["weightDecay"], learningRate=g["learningRate"], beta1=g["beta1"], beta2=g["beta2"], mixedPrecision=True)
+    opt.step([grad], 1.0)
+    assert p.to_numpy().astype(np.float64)[0].tolist() == h["step1"]
+    opt.step([grad], 1.0)
+    assert p.to_numpy().astype(np.float64)[0].tolist() == h["step2"]
+    assert [t.dtype for t in opt.state[1:]] == [S.F32] * (len(opt.state) - 1), "moments and working copy are f32"
+
+
+@pytest.mark.parametrize("dt", [torch.float16])
+def test_half_precision_compute(gpu, dt):
+    """f16 (lamp's HalfPrecision, scalar type byte 5) is a compute type of the library: casts, element-wise arithmetic, reductions,
+    mm / bmm on the f16 matrix cores, softmax - against ATen on CPU at f16 resolution (2^-10 per element)."""
+    from tests.util import closed_form
+    a, b = closed_form((37, 64), 3, 2.0, dt), closed_form((37, 64), 5, 2.0, dt)
+    A_, B_ = to_sten(a), to_sten(b)
+    assert A_.dtype == S.F16
+    tol = 2.0 ** -10
+    assert_close(to_torch(A_ + B_), (a + b).double(), tol, "add")
+    assert_close(to_torch(A_ * B_), (a * b).double(), tol, "mul")
+    assert_close(to_torch(A_.castToFloat()), a.float().double(), 0.0, "f16 -> f32 is exact")
+    assert_close(to_torch(to_sten(a.float()).castToType(S.F16)), a.double(), 0.0, "f32 -> f16 round trip")
+    assert_close(to_torch(A_.exp()), a.float().exp().half().double(), tol * 2, "exp")
+    assert_close(to_torch(A_.sum([1], False)), a.float().sum(1).half().double(), tol * 2, "row sums (f32 accumulation)")
+    w = closed_form((64, 48), 9, 1.0, dt)
+    assert_close(to_torch(A_.mm(to_sten(w))), (a.double() @ w.double()), tol * 2, "mm")
+    assert_close(to_torch(A_.t.mm(to_sten(b))), (a.double().t() @ b.double()), tol * 2, "mm, transposed operand")
+    x3, y3 = closed_form((5, 20, 16), 1, 1.0, dt), closed_form((5, 16, 24), 2, 1.0, dt)
+    assert_close(to_torch(to_sten(x3).bmm(to_sten(y3))), x3.double() @ y3.double(), tol * 2, "bmm")
+    assert_close(to_torch(A_.logSoftMax(1)), torch.log_softmax(a.float(), 1).double(), tol * 4, "log_softmax")
+    # gradients flow in f16 through the host operators
+    pa, pw = A.param(A_), A.param(to_sten(w))
+    pa.mm(pw).relu().sum().backprop()
+    ref_a, ref_w = a.double().requires_grad_(True), w.double().requires_grad_(True)
+    (ref_a @ ref_w).relu().sum().backward()
+    assert_close(to_torch(pa.partialDerivative), ref_a.grad, tol * 4, "dA", scale="max")
+    assert_close(to_torch(pw.partialDerivative), ref_w.grad, tol * 4, "dW", scale="max")
+
+
 def test_sgd_and_clipping_kats_on_gpu(gpu):
     g = kats.GOLDEN["sgd"]
     for key in ("noop", "no_momentum_no_wd", "no_momentum"):

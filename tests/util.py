@@ -5,7 +5,7 @@ import torch
 from lamp_amd import sten as S
 
 TORCH2LAMP = {torch.float32: S.F32, torch.float64: S.F64, torch.bfloat16: S.BF16, torch.int64: S.I64, torch.bool: S.BOOL,
-              torch.int32: S.I32, torch.uint8: S.U8}
+              torch.int32: S.I32, torch.uint8: S.U8, torch.float16: S.F16}
 DTYPES = [torch.float64, torch.float32, torch.bfloat16]
 # forward tolerance per dtype: f32 <= 1e-5 is BASELINE.json's bar; bf16 has 8 bits of mantissa: rtol 2^-7 per element
 FWD_TOL = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 2.0 ** -7}
