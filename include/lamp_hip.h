@@ -113,6 +113,15 @@ int lamp_graph_release(lamp_graph* g);
  * lamp-data/src/test/scala/lamp/data/mlp.test.scala:180-188)
  * ------------------------------------------------------------------------------------------ */
 int lamp_live_tensor_count(int64_t* out);
+/* aten.TensorTrace (TensorLogger.scala:13-62): records of the handles created while the trace is on */
+#define LAMP_TRACE_RECORD 14   /* int64 per record: id, birth ns, scalar type, device (-1 host), ndim, sizes[8], bytes */
+int lamp_tensor_trace_enable(int on);
+int lamp_tensor_trace_list(int64_t* records_or_null, int64_t capacity, int64_t* count);   /* count = live traced handles (may exceed capacity) */
+/* Tensor.from_file / tensors_from_file (STen.scala:115-194): read-only mmap of [offset, offset + length) of a file (offset a multiple of
+ * 4096, mlock when pin) cut into n one-dimensional HOST tensors (types[i], byte offsets[i] aligned to 8, byte lengths[i]) that share the
+ * mapping; it is unmapped with the last handle. */
+int lamp_tensors_from_file(lamp_tensor** outs, const char* path, int64_t offset, int64_t length, int pin, const int64_t* types,
+                           const int64_t* offsets, const int64_t* lengths, int n);
 int lamp_allocator_stats(int device, int64_t* reserved_bytes, int64_t* in_use_bytes, int64_t* n_device_mallocs);
 int lamp_allocator_trim(int device);
 /* how many frees had to wait for another stream (record_stream'ed blocks) since start-up */
@@ -273,6 +282,38 @@ int lamp_sin(lamp_tensor** out, const lamp_tensor* a);
 int lamp_cos(lamp_tensor** out, const lamp_tensor* a);
 int lamp_tan(lamp_tensor** out, const lamp_tensor* a);
 int lamp_atan(lamp_tensor** out, const lamp_tensor* a);
+/* the remaining element-wise members of the aten surface lamp-sten binds (STen.scala:1200-1700): math, in-place forms, logicals */
+int lamp_acos(lamp_tensor** out, const lamp_tensor* a);
+int lamp_asin(lamp_tensor** out, const lamp_tensor* a);
+int lamp_ceil(lamp_tensor** out, const lamp_tensor* a);
+int lamp_floor(lamp_tensor** out, const lamp_tensor* a);
+int lamp_round(lamp_tensor** out, const lamp_tensor* a);      /* half to even, as ATen */
+int lamp_expm1(lamp_tensor** out, const lamp_tensor* a);
+int lamp_log10(lamp_tensor** out, const lamp_tensor* a);
+int lamp_atan2(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_remainder(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);   /* sign of the divisor */
+int lamp_remainder_scalar(lamp_tensor** out, const lamp_tensor* a, double b);
+int lamp_nan_to_num(lamp_tensor** out, const lamp_tensor* a, double nan);            /* infinities -> largest finite values */
+int lamp_abs_(lamp_tensor* a);
+int lamp_acos_(lamp_tensor* a);
+int lamp_asin_(lamp_tensor* a);
+int lamp_atan_(lamp_tensor* a);
+int lamp_ceil_(lamp_tensor* a);
+int lamp_floor_(lamp_tensor* a);
+int lamp_cos_(lamp_tensor* a);
+int lamp_sin_(lamp_tensor* a);
+int lamp_tan_(lamp_tensor* a);
+int lamp_tanh_(lamp_tensor* a);
+int lamp_sigmoid_(lamp_tensor* a);
+int lamp_log_(lamp_tensor* a);
+int lamp_log1p_(lamp_tensor* a);
+int lamp_square_(lamp_tensor* a);
+int lamp_leaky_relu_(lamp_tensor* a, double slope);
+int lamp_logical_and(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_logical_or(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_logical_xor(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b);
+int lamp_isnan(lamp_tensor** out, const lamp_tensor* a);
+int lamp_isfinite(lamp_tensor** out, const lamp_tensor* a);
 /* fused forms of lamp's op backward closures (same arithmetic as the ATen call chains they
  * replace; see DESIGN.md "fused backward closures"):
  *   relu:  out += p * (x < 0 ? 0 : 1)      ops.scala:918-935 (gradient at x == 0 is 1)

@@ -8,10 +8,40 @@
 #include "../kernels/device_utils.h"
 
 #include <climits>
+#include <chrono>
+#include <mutex>
+#include <unordered_map>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace lamp {
 
 static std::atomic<int64_t> g_live_tensors{0};
+
+// ---- live-handle registry (aten.TensorTrace: TensorLogger.scala:13-62) -----------------------------------------------------------
+// lamp's leak detector enables the trace, lists the live tensors periodically (shape, type, device, birth time; the stack trace is
+// captured on the JVM side) and its tests assert that nothing is alive after a scope closes (mlp.test.scala:180-188).  The count is
+// always maintained; the per-handle records only while the trace is on (a mutex + map operation per handle otherwise).
+static std::atomic<int> g_trace_on{0};
+static std::mutex g_trace_mu;
+static std::unordered_map<const Tensor*, int64_t> g_trace;   // handle -> birth (ns, steady clock)
+static inline void track(const Tensor* t) {
+  g_live_tensors++;
+  if (g_trace_on.load(std::memory_order_relaxed)) {
+    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace[t] = now;
+  }
+}
+static inline void untrack(const Tensor* t) {
+  g_live_tensors--;
+  if (g_trace_on.load(std::memory_order_relaxed) || !g_trace.empty()) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.erase(t);
+  }
+}
 
 static Storage* new_storage(size_t bytes, int device, bool pinned = false) {
   Storage* s = new Storage();
@@ -31,7 +61,9 @@ static Storage* new_storage(size_t bytes, int device, bool pinned = false) {
 static void storage_unref(Storage* s) {
   if (!s) return;
   if (s->refs.fetch_sub(1) == 1) {
-    if (s->owned) {
+    if (s->map_base) {
+      (void)munmap(s->map_base, s->map_len);
+    } else if (s->owned) {
       if (s->device >= 0) device_free(s->device, s->ptr, s->pool);
       else if (s->pinned) (void)hipHostFree(s->ptr);
       else free(s->ptr);
@@ -58,7 +90,7 @@ Tensor* new_tensor(const int64_t* sizes, int ndim, int dtype, int device) {
     delete t;
     throw;
   }
-  g_live_tensors++;
+  track(t);
   return t;
 }
 Tensor* new_like(const Tensor* t) { return new_tensor(t->sizes, t->ndim, t->dtype, t->device()); }
@@ -73,16 +105,16 @@ Tensor* new_view(const Tensor* base, const int64_t* sizes, const int64_t* stride
   t->ndim = ndim;
   t->offset = offset;
   for (int i = 0; i < ndim; i++) { t->sizes[i] = sizes[i]; t->strides[i] = strides[i]; }
-  g_live_tensors++;
+  track(t);
   return t;
 }
 Tensor* retain(const Tensor* t) { return new_view(t, t->sizes, t->strides, t->ndim, t->offset); }
 void release(Tensor* t) {
   if (!t) return;
+  untrack(t);
   storage_unref(t->st);
   t->st = nullptr;
   delete t;
-  g_live_tensors--;
 }
 
 // ---- strided copy with conversion ------------------------------------------------------------
@@ -337,6 +369,75 @@ extern "C" {
 
 int lamp_live_tensor_count(int64_t* out) { *out = g_live_tensors.load(); return 0; }
 
+// TensorTrace.enable / disable / list
+int lamp_tensor_trace_enable(int on) {
+  LAMP_API_BEGIN
+  g_trace_on.store(on ? 1 : 0);
+  if (!on) { std::lock_guard<std::mutex> lk(g_trace_mu); g_trace.clear(); }
+  LAMP_API_END
+}
+// one record of LAMP_TRACE_RECORD int64 per live handle created since the trace was enabled:
+//   [0] handle id, [1] birth (ns, monotonic clock), [2] scalar type byte, [3] device (-1 host), [4] ndim, [5..12] sizes, [13] bytes of the view
+int lamp_tensor_trace_list(int64_t* records, int64_t capacity, int64_t* count) {
+  LAMP_API_BEGIN
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  int64_t k = 0;
+  for (auto& kv : g_trace) {
+    if (records && k < capacity) {
+      const Tensor* t = kv.first;
+      int64_t* r = records + k * LAMP_TRACE_RECORD;
+      r[0] = (int64_t)(intptr_t)t; r[1] = kv.second; r[2] = t->dtype; r[3] = t->device(); r[4] = t->ndim;
+      for (int d = 0; d < 8; d++) r[5 + d] = d < t->ndim ? t->sizes[d] : 0;
+      r[13] = t->numel() * (int64_t)t->itemsize();
+    }
+    k++;
+  }
+  *count = k;
+  LAMP_API_END
+}
+
+// Tensor.from_file / tensors_from_file (STen.scala:115-194): the byte range [offset, offset + length) of `path` is mmap'ed (read-only,
+// private; mlock'ed when pin) and n one-dimensional host tensors are cut from it at (types[i], offsets[i], lengths[i] bytes).  Nothing is
+// copied: checkpoints and data sets reach the GPU with one lamp_to per tensor straight from the page cache.
+int lamp_tensors_from_file(lamp_tensor** outs, const char* path, int64_t offset, int64_t length, int pin, const int64_t* types,
+                           const int64_t* offsets, const int64_t* lengths, int n) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(path && outs, "null argument");
+  LAMP_CHECK(offset % 4096 == 0, "Offset must be multiple of 4096. Got " << offset << ". Tried to create tensor from " << path << ".");
+  LAMP_CHECK(length >= 0, "negative length");
+  for (int i = 0; i < n; i++) {
+    LAMP_CHECK(offsets[i] % 8 == 0, "Some tensor offsets within the list is not aligned to 8");
+    LAMP_CHECK(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] + lengths[i] <= length, "Some tensor offset +length is out of bounds");
+    LAMP_CHECK(lengths[i] % (int64_t)dtype_size((int)types[i]) == 0, "tensor " << i << ": byte length " << lengths[i] << " is not a multiple of the element size");
+  }
+  Storage* st = nullptr;
+  if (length > 0) {
+    const int fd = open(path, O_RDONLY);
+    LAMP_CHECK(fd >= 0, "cannot open " << path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < offset + length) { close(fd); LAMP_CHECK(false, path << " is shorter than offset + length = " << offset + length); }
+    void* base = mmap(nullptr, (size_t)length, PROT_READ, MAP_PRIVATE, fd, (off_t)offset);
+    close(fd);
+    LAMP_CHECK(base != MAP_FAILED, "mmap of " << path << " failed");
+    if (pin) (void)mlock(base, (size_t)length);
+    st = new Storage();
+    st->ptr = base; st->bytes = (size_t)length; st->device = -1; st->owned = false; st->map_base = base; st->map_len = (size_t)length;
+  }
+  for (int i = 0; i < n; i++) {
+    Tensor* t = new Tensor();
+    t->dtype = (int)types[i];
+    t->ndim = 1;
+    t->sizes[0] = lengths[i] / (int64_t)dtype_size((int)types[i]);
+    t->strides[0] = 1;
+    if (st) { t->st = st; if (i > 0) st->refs.fetch_add(1); t->offset = offsets[i] / (int64_t)dtype_size((int)types[i]); }
+    else { t->st = new Storage(); t->st->ptr = malloc(1); t->st->device = -1; }
+    track(t);
+    outs[i] = t;
+  }
+  if (st && n == 0) storage_unref(st);
+  LAMP_API_END
+}
+
 int lamp_tensor_release(lamp_tensor* t) {
   LAMP_API_BEGIN
   release(t);
@@ -474,7 +575,7 @@ int lamp_from_blob(lamp_tensor** out, void* data, const int64_t* sizes, const in
     n *= sizes[i];
   }
   t->st->bytes = (size_t)n * dtype_size(dtype);
-  g_live_tensors++;
+  track(t);
   *out = t;
   LAMP_API_END
 }
@@ -552,7 +653,7 @@ int lamp_pin_memory(lamp_tensor** out, const lamp_tensor* t) {
   int64_t n = 1;
   for (int i = t->ndim - 1; i >= 0; i--) { r->sizes[i] = t->sizes[i]; r->strides[i] = n; n *= t->sizes[i]; }
   try { r->st = new_storage((size_t)n * dtype_size(t->dtype), -1, true); } catch (...) { delete r; throw; }
-  g_live_tensors++;
+  track(r);
   Hold h(r);
   copy_into(r, t);
   *out = h.take();

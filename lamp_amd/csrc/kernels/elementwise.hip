@@ -181,6 +181,19 @@ MATH1(m_atan, atanf, atan)
 MATH1(m_tanh, tanhf, tanh)
 MATH1(m_erf, erff, erf)
 MATH1(m_fabs, fabsf, fabs)
+MATH1(m_acos, acosf, acos)
+MATH1(m_asin, asinf, asin)
+MATH1(m_ceil, ceilf, ceil)
+MATH1(m_floor, floorf, floor)
+MATH1(m_rint, rintf, rint)
+MATH1(m_expm1, expm1f, expm1)
+MATH1(m_log10, log10f, log10)
+template <class A> __device__ __forceinline__ A m_atan2(A y, A x) { return (A)atan2((double)y, (double)x); }
+template <> __device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+template <class A> __device__ __forceinline__ A m_fmod(A x, A y) { return (A)fmod((double)x, (double)y); }
+template <> __device__ __forceinline__ float m_fmod(float x, float y) { return fmodf(x, y); }
+// ATen remainder: the result takes the sign of the divisor (Python's %)
+template <class A> __device__ __forceinline__ A m_remainder(A a, A b) { A r = m_fmod<A>(a, b); if (r != A(0) && ((r < A(0)) != (b < A(0)))) r += b; return r; }
 template <class A> __device__ __forceinline__ A m_pow(A x, A y) { return (A)pow((double)x, (double)y); }
 template <> __device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
 
@@ -284,6 +297,29 @@ FUNCTOR_BEGIN(FCos) return store_as<TO>(m_cos<A>(a)); FUNCTOR_END
 FUNCTOR_BEGIN(FTan) return store_as<TO>(m_tan<A>(a)); FUNCTOR_END
 FUNCTOR_BEGIN(FAtan) return store_as<TO>(m_atan<A>(a)); FUNCTOR_END
 FUNCTOR_BEGIN(FLogicalNot) return (TO)(a == A(0)); FUNCTOR_END
+FUNCTOR_BEGIN(FAcos) return store_as<TO>(m_acos<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FAsin) return store_as<TO>(m_asin<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FCeil) return store_as<TO>(m_ceil<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FFloor) return store_as<TO>(m_floor<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FRound) return store_as<TO>(m_rint<A>(a)); FUNCTOR_END                // ATen round: half to even
+FUNCTOR_BEGIN(FExpm1) return store_as<TO>(m_expm1<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FLog10) return store_as<TO>(m_log10<A>(a)); FUNCTOR_END
+FUNCTOR_BEGIN(FAtan2) return store_as<TO>(m_atan2<A>(a, b)); FUNCTOR_END
+FUNCTOR_BEGIN(FRemainder) return store_as<TO>(m_remainder<A>(a, b)); FUNCTOR_END
+FUNCTOR_BEGIN(FRemainderS) return store_as<TO>(m_remainder<A>(a, (A)p0)); FUNCTOR_END
+FUNCTOR_BEGIN(FLogicalAnd) return (TO)((a != A(0)) && (b != A(0))); FUNCTOR_END
+FUNCTOR_BEGIN(FLogicalOr) return (TO)((a != A(0)) || (b != A(0))); FUNCTOR_END
+FUNCTOR_BEGIN(FLogicalXor) return (TO)((a != A(0)) != (b != A(0))); FUNCTOR_END
+FUNCTOR_BEGIN(FIsNan) return (TO)(a != a); FUNCTOR_END
+FUNCTOR_BEGIN(FIsFinite) return (TO)((a - a) == A(0)); FUNCTOR_END
+struct FNanToNum {   // nan_to_num(nan, posinf, neginf): p0 = nan replacement; infinities -> largest finite values of the type (ATen defaults)
+  double p0 = 0, p1 = 0;
+  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+    if (a != a) return store_as<TO>((A)p0);
+    if ((a - a) != A(0)) { const A big = sizeof(TO) == 8 ? (A)1.7976931348623157e308 : (sizeof(TO) == 4 ? (A)3.4028234663852886e38 : (A)p1); return store_as<TO>(a > A(0) ? big : -big); }
+    return store_as<TO>(a);
+  }
+};
 // comparisons: TO = uint8_t
 FUNCTOR_BEGIN(FLt) return (TO)(a < b); FUNCTOR_END
 FUNCTOR_BEGIN(FLe) return (TO)(a <= b); FUNCTOR_END
@@ -506,6 +542,47 @@ API1(sin, FSin, true)
 API1(cos, FCos, true)
 API1(tan, FTan, true)
 API1(atan, FAtan, true)
+API1(acos, FAcos, true)
+API1(asin, FAsin, true)
+API1(ceil, FCeil, true)
+API1(floor, FFloor, true)
+API1(round, FRound, true)
+API1(expm1, FExpm1, true)
+API1(log10, FLog10, true)
+API2(atan2, FAtan2, true)
+API2(remainder, FRemainder, false)
+int lamp_remainder_scalar(lamp_tensor** out, const lamp_tensor* a, double b) {
+  LAMP_API_BEGIN *out = run_same<1, FRemainderS, false>(nullptr, a, nullptr, nullptr, FRemainderS{b, 0}); LAMP_API_END
+}
+int lamp_nan_to_num(lamp_tensor** out, const lamp_tensor* a, double nan) {
+  LAMP_API_BEGIN
+  const double big16 = a->dtype == kBF16 ? 3.3895313892515355e38 : 65504.0;   // largest finite bf16 / f16
+  *out = run_same<1, FNanToNum, true>(nullptr, a, nullptr, nullptr, FNanToNum{nan, big16});
+  LAMP_API_END
+}
+// in-place forms (ATen's trailing underscore: STen's `_`-suffixed methods, STen.scala:1200-1700)
+API1_INPLACE(abs_, FAbs, false)
+API1_INPLACE(acos_, FAcos, true)
+API1_INPLACE(asin_, FAsin, true)
+API1_INPLACE(atan_, FAtan, true)
+API1_INPLACE(ceil_, FCeil, true)
+API1_INPLACE(floor_, FFloor, true)
+API1_INPLACE(cos_, FCos, true)
+API1_INPLACE(sin_, FSin, true)
+API1_INPLACE(tan_, FTan, true)
+API1_INPLACE(tanh_, FTanh, true)
+API1_INPLACE(sigmoid_, FSigmoid, true)
+API1_INPLACE(log_, FLog, true)
+API1_INPLACE(log1p_, FLog1p, true)
+API1_INPLACE(square_, FSquare, false)
+int lamp_leaky_relu_(lamp_tensor* a, double slope) {
+  LAMP_API_BEGIN run_same<1, FLeakyRelu, true>(a, a, nullptr, nullptr, FLeakyRelu{slope, 0}); LAMP_API_END
+}
+API_CMP(logical_and, FLogicalAnd)
+API_CMP(logical_or, FLogicalOr)
+API_CMP(logical_xor, FLogicalXor)
+int lamp_isnan(lamp_tensor** out, const lamp_tensor* a) { LAMP_API_BEGIN *out = run_bool<1, FIsNan>(a, nullptr, FIsNan{}); LAMP_API_END }
+int lamp_isfinite(lamp_tensor** out, const lamp_tensor* a) { LAMP_API_BEGIN *out = run_bool<1, FIsFinite>(a, nullptr, FIsFinite{}); LAMP_API_END }
 
 API_CMP(lt, FLt)
 API_CMP(le, FLe)
