@@ -18,11 +18,17 @@
  *  - `_out` variants write into their first argument, a trailing `_` means in place.
  *  - scalar types are ATen's scalar-type bytes (lamp-sten/.../STen.scala:726-731):
  *    0 u8, 1 i8, 2 i16, 3 i32, 4 i64, 5 f16, 6 f32, 7 f64, 11 bool, 15 bf16.
- *    Compute kernels exist for f32, f64, bf16 (+ i64/i32/u8/bool where indices or masks
- *    are involved); f16 is storage/cast only.
- *  - device type 0 = host, 1 = GPU (lamp's "cuda", STen.scala:757-759).  Host tensors are
- *    staging only (copyFrom/To arrays, pinned buffers): this library has NO CPU compute
- *    path; handing a host tensor to a compute entry point is an error.
+ *    Compute kernels exist for f32, f64, bf16 and f16 (+ i64/i32/u8/bool where indices or
+ *    masks are involved).
+ *  - device type 0 = host, 1 = GPU (lamp's "cuda", STen.scala:757-759).  This is a GPU
+ *    backend: there is no CPU FALLBACK - a GPU tensor never computes on the host and nothing
+ *    runs when no MI355X is visible.  Tensors that LIVE in host memory (lamp's `CPU` device,
+ *    device.scala:138: arrays in and out, pinned staging, mmap'ed files, scalars, index lists)
+ *    support what lamp does with them around the hot path, where they live: construction,
+ *    views, copy / cast, element-wise arithmetic and functions, comparisons, sum / mean /
+ *    norm / max / min, mm (f32 / f64), the gradient-bucket pack / unpack.  Every other entry
+ *    point (convolution, norms, softmax, losses, attention, optimisers, index ops ...) needs
+ *    device tensors and says so.
  *  - kernels launch on the calling thread's current stream of the current device
  *    (lamp-sten/.../device.scala:119-129, 199-213).
  */

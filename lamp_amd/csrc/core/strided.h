@@ -101,7 +101,7 @@ inline IterArgs to_args(const IterSpace& it) {
 }
 
 template <int NOPS>
-__device__ __forceinline__ void iter_offsets(const IterArgs& a, int64_t linear, int64_t (&off)[NOPS]) {
+__host__ __device__ __forceinline__ void iter_offsets(const IterArgs& a, int64_t linear, int64_t (&off)[NOPS]) {
 #pragma unroll
   for (int o = 0; o < NOPS; o++) off[o] = 0;
   for (int d = a.ndim - 1; d >= 0; d--) {

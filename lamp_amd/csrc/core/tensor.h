@@ -5,7 +5,8 @@
 // such native handle): a strided view (sizes/strides/offset, row-major by
 // default, NCHW for images) over a reference-counted storage block that lives
 // either in HBM (hipMalloc'ed through the caching allocator) or in host memory
-// (staging only - there is NO CPU compute path in this library).
+// (lamp's CPU device: staging, views, casts, element-wise / reduction / mm arithmetic where the tensor lives - see the note on device
+// types in include/lamp_hip.h; there is no CPU fallback for GPU tensors).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -228,7 +229,7 @@ inline void check_same_device(const Tensor* a, const Tensor* b) {
 inline void check_device_tensor(const Tensor* a, const char* what) {
   LAMP_CHECK(a != nullptr, what << " is null");
   LAMP_CHECK(a->is_device(), what << " " << a->describe()
-             << " is a host tensor: this library has no CPU compute path, move it to the GPU first");
+             << " is a host tensor: this operator exists only as a GPU kernel, move the tensor to the GPU first");
 }
 
 inline int grid_for(int64_t work_items, int block, int max_blocks_per_cu = 8) {

@@ -102,6 +102,26 @@ void launch_ew(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F
   IterSpace it = make_iter(out->shape(), ops, 4);
   int64_t n = it.numel;
   if (n == 0) return;
+  if (!out->is_device()) {
+    // lamp's CPU device (device.scala:138): tensors that live in host memory compute where they live, with the functors the kernels
+    // use - one scalar loop over the broadcast index space.  (A staging-speed path for the small host tensors lamp creates - scalars,
+    // class weights, index lists, test fixtures; models run on the GPU.)
+    TO* po = out->ptr<TO>();
+    const TI* h0 = a->ptr<TI>();
+    const TI* h1 = b ? b->ptr<TI>() : nullptr;
+    const TI* h2 = c ? c->ptr<TI>() : nullptr;
+    const IterArgs ia = to_args(it);
+    using A = acc_t<TI>;
+    for (int64_t i = 0; i < n; i++) {
+      int64_t off[4];
+      iter_offsets<4>(ia, i, off);
+      const A av = load_as<A>(h0[off[1]]);
+      const A bv = (NIN > 1) ? load_as<A>(h1[off[2]]) : A(0);
+      const A cv = (NIN > 2) ? load_as<A>(h2[off[3]]) : A(0);
+      po[off[0]] = f.template apply<TO>(av, bv, cv);
+    }
+    return;
+  }
   hipStream_t st = current_stream(out->device());
   const TI* p0 = a->ptr<TI>();
   const TI* p1 = b ? b->ptr<TI>() : nullptr;
@@ -159,18 +179,18 @@ void launch_ew(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c, F
 }
 
 // ---- functors ----------------------------------------------------------------------------------
-#define FUNCTOR_BEGIN(NAME) struct NAME { double p0 = 0, p1 = 0; template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+#define FUNCTOR_BEGIN(NAME) struct NAME { double p0 = 0, p1 = 0; template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A a, A b, A c) const {
 #define FUNCTOR_END } };
 
-template <class A> __device__ __forceinline__ A dexp(A x);
-template <> __device__ __forceinline__ float dexp(float x) { return expf(x); }
-template <> __device__ __forceinline__ double dexp(double x) { return exp(x); }
-template <> __device__ __forceinline__ int64_t dexp(int64_t x) { return (int64_t)exp((double)x); }
+template <class A> __host__ __device__ __forceinline__ A dexp(A x);
+template <> __host__ __device__ __forceinline__ float dexp(float x) { return expf(x); }
+template <> __host__ __device__ __forceinline__ double dexp(double x) { return exp(x); }
+template <> __host__ __device__ __forceinline__ int64_t dexp(int64_t x) { return (int64_t)exp((double)x); }
 
 #define MATH1(NAME, FF, DF)                                                                       \
-  template <class A> __device__ __forceinline__ A NAME(A x) { return (A)DF((double)x); }          \
-  template <> __device__ __forceinline__ float NAME(float x) { return FF(x); }                    \
-  template <> __device__ __forceinline__ double NAME(double x) { return DF(x); }
+  template <class A> __host__ __device__ __forceinline__ A NAME(A x) { return (A)DF((double)x); }          \
+  template <> __host__ __device__ __forceinline__ float NAME(float x) { return FF(x); }                    \
+  template <> __host__ __device__ __forceinline__ double NAME(double x) { return DF(x); }
 MATH1(m_log, logf, log)
 MATH1(m_log1p, log1pf, log1p)
 MATH1(m_sqrt, sqrtf, sqrt)
@@ -188,14 +208,14 @@ MATH1(m_floor, floorf, floor)
 MATH1(m_rint, rintf, rint)
 MATH1(m_expm1, expm1f, expm1)
 MATH1(m_log10, log10f, log10)
-template <class A> __device__ __forceinline__ A m_atan2(A y, A x) { return (A)atan2((double)y, (double)x); }
-template <> __device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
-template <class A> __device__ __forceinline__ A m_fmod(A x, A y) { return (A)fmod((double)x, (double)y); }
-template <> __device__ __forceinline__ float m_fmod(float x, float y) { return fmodf(x, y); }
+template <class A> __host__ __device__ __forceinline__ A m_atan2(A y, A x) { return (A)atan2((double)y, (double)x); }
+template <> __host__ __device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+template <class A> __host__ __device__ __forceinline__ A m_fmod(A x, A y) { return (A)fmod((double)x, (double)y); }
+template <> __host__ __device__ __forceinline__ float m_fmod(float x, float y) { return fmodf(x, y); }
 // ATen remainder: the result takes the sign of the divisor (Python's %)
-template <class A> __device__ __forceinline__ A m_remainder(A a, A b) { A r = m_fmod<A>(a, b); if (r != A(0) && ((r < A(0)) != (b < A(0)))) r += b; return r; }
-template <class A> __device__ __forceinline__ A m_pow(A x, A y) { return (A)pow((double)x, (double)y); }
-template <> __device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+template <class A> __host__ __device__ __forceinline__ A m_remainder(A a, A b) { A r = m_fmod<A>(a, b); if (r != A(0) && ((r < A(0)) != (b < A(0)))) r += b; return r; }
+template <class A> __host__ __device__ __forceinline__ A m_pow(A x, A y) { return (A)pow((double)x, (double)y); }
+template <> __host__ __device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
 
 FUNCTOR_BEGIN(FAdd) return store_as<TO>((A)(a + (A)p0 * b)); FUNCTOR_END
 FUNCTOR_BEGIN(FSub) return store_as<TO>((A)(a - (A)p0 * b)); FUNCTOR_END
@@ -209,7 +229,7 @@ FUNCTOR_BEGIN(FMulS) return store_as<TO>((A)(a * (A)p0)); FUNCTOR_END
 FUNCTOR_BEGIN(FDivS) return store_as<TO>((A)(a / (A)p0)); FUNCTOR_END
 struct FPowS {
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A a, A b, A c) const {
     // the special cases ATen's CPU pow kernel takes (exact for 2, 3, 0.5, -1, -2, -0.5)
     if (p0 == 2.0) return store_as<TO>((A)(a * a));
     if (p0 == 3.0) return store_as<TO>((A)(a * a * a));
@@ -225,7 +245,7 @@ FUNCTOR_BEGIN(FAddcmul) return store_as<TO>((A)(a + (A)p0 * b * c)); FUNCTOR_END
 // (a * b) + c with the product rounded to the tensor type first: bit for bit the chain Mult then Add (no fma contraction)
 struct FMulAdd {
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A a, A b, A c) const {
 #pragma clang fp contract(off)
     const A prod = load_as<A>(store_as<TO>((A)(a * b)));
     return store_as<TO>((A)(prod + c));
@@ -241,7 +261,7 @@ FUNCTOR_BEGIN(FLeakyRelu) return store_as<TO>((A)((a > A(0)) ? a : a * (A)p0)); 
 FUNCTOR_BEGIN(FGelu) return store_as<TO>((A)(a * A(0.5) * (A(1) + m_erf<A>(a * A(0.70710678118654752440))))); FUNCTOR_END
 struct FGeluBwd {  // (grad, self)
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A g, A x, A c) const {
     const A kAlpha = A(0.70710678118654752440), kBeta = A(0.39894228040143267794);  // 1/sqrt(2), 1/sqrt(2 pi)
     A cdf = A(0.5) * (A(1) + m_erf<A>(x * kAlpha));
     A pdf = kBeta * dexp<A>(x * x * A(-0.5));
@@ -254,7 +274,7 @@ FUNCTOR_BEGIN(FTanh) return store_as<TO>(m_tanh<A>(a)); FUNCTOR_END
 FUNCTOR_BEGIN(FTanhBwd) return store_as<TO>((A)(a * (A(1) - b * b))); FUNCTOR_END       // (grad, output)
 struct FHardswish {
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A x, A b, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A x, A b, A c) const {
     A t = x + A(3);
     t = t < A(0) ? A(0) : (t > A(6) ? A(6) : t);
     return store_as<TO>((A)(x * t / A(6)));
@@ -262,7 +282,7 @@ struct FHardswish {
 };
 struct FHardswishBwd {  // (grad, self)
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A g, A x, A c) const {
     if (x < A(-3)) return store_as<TO>(A(0));
     if (x <= A(3)) return store_as<TO>((A)(g * ((x / A(3)) + A(0.5))));
     return store_as<TO>(g);
@@ -270,14 +290,14 @@ struct FHardswishBwd {  // (grad, self)
 };
 struct FSoftplus {  // p0 beta, p1 threshold
   double p0 = 1, p1 = 20;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A x, A b, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A x, A b, A c) const {
     A xb = x * (A)p0;
     return store_as<TO>((A)((xb > (A)p1) ? x : m_log1p<A>(dexp<A>(xb)) / (A)p0));
   }
 };
 struct FSoftplusBwd {  // (grad, self)
   double p0 = 1, p1 = 20;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A g, A x, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A g, A x, A c) const {
     A xb = x * (A)p0;
     A z = dexp<A>(xb);
     return store_as<TO>((A)((xb > (A)p1) ? g : g * z / (z + A(1))));
@@ -314,7 +334,7 @@ FUNCTOR_BEGIN(FIsNan) return (TO)(a != a); FUNCTOR_END
 FUNCTOR_BEGIN(FIsFinite) return (TO)((a - a) == A(0)); FUNCTOR_END
 struct FNanToNum {   // nan_to_num(nan, posinf, neginf): p0 = nan replacement; infinities -> largest finite values of the type (ATen defaults)
   double p0 = 0, p1 = 0;
-  template <class TO, class A> __device__ __forceinline__ TO apply(A a, A b, A c) const {
+  template <class TO, class A> __host__ __device__ __forceinline__ TO apply(A a, A b, A c) const {
     if (a != a) return store_as<TO>((A)p0);
     if ((a - a) != A(0)) { const A big = sizeof(TO) == 8 ? (A)1.7976931348623157e308 : (sizeof(TO) == 4 ? (A)3.4028234663852886e38 : (A)p1); return store_as<TO>(a > A(0) ? big : -big); }
     return store_as<TO>(a);
@@ -336,6 +356,14 @@ FUNCTOR_BEGIN(FNeS) return (TO)(a != (A)p0); FUNCTOR_END
 
 // ---- host helpers ------------------------------------------------------------------------------
 static void check_inputs(const Tensor* a, const Tensor* b, const Tensor* c) {
+  LAMP_CHECK(a != nullptr, "input is null");
+  if (!a->is_device()) {     // all operands on the host: lamp's CPU device (see launch_ew)
+    if (b) { LAMP_CHECK(!b->is_device(), "tensors on different devices: " << a->describe() << " vs " << b->describe());
+             LAMP_CHECK(a->dtype == b->dtype, "dtype mismatch: " << a->describe() << " vs " << b->describe()); }
+    if (c) { LAMP_CHECK(!c->is_device(), "tensors on different devices: " << a->describe() << " vs " << c->describe());
+             LAMP_CHECK(a->dtype == c->dtype, "dtype mismatch: " << a->describe() << " vs " << c->describe()); }
+    return;
+  }
   check_device_tensor(a, "input");
   if (b) { check_device_tensor(b, "input"); check_same_device(a, b);
            LAMP_CHECK(a->dtype == b->dtype, "dtype mismatch: " << a->describe() << " vs " << b->describe()); }
@@ -357,7 +385,7 @@ Tensor* run_same(Tensor* out, const Tensor* a, const Tensor* b, const Tensor* c,
   Hold owned;
   if (!out) { owned = Hold(new_tensor(shape, a->dtype, a->device())); out = owned.get(); }
   else {
-    check_device_tensor(out, "out");
+    LAMP_CHECK(out->is_device() == a->is_device() && (!out->is_device() || out->device() == a->device()), "out " << out->describe() << " is not on the device of the inputs");
     LAMP_CHECK(out->shape() == shape, "out " << out->describe() << " does not match the broadcast shape of the inputs");
     LAMP_CHECK(out->dtype == a->dtype, "out dtype mismatch: " << out->describe() << " vs " << a->describe());
   }

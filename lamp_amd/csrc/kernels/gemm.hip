@@ -1154,8 +1154,30 @@ using namespace lamp;
 
 extern "C" {
 
+// lamp's CPU device: mm of tensors that live in host memory (f32 / f64; f64 accumulation, i-k-j loop) - fixtures and small host
+// side products; models multiply on the GPU
+static Tensor* host_mm(const Tensor* a, const Tensor* b) {
+  LAMP_CHECK(a->ndim == 2 && b->ndim == 2 && a->sizes[1] == b->sizes[0] && a->dtype == b->dtype, "mm: shapes " << a->describe() << " x " << b->describe());
+  LAMP_CHECK(a->dtype == kF32 || a->dtype == kF64, "host mm supports f32 and f64, got " << a->describe());
+  const int64_t M = a->sizes[0], K = a->sizes[1], N = b->sizes[1];
+  int64_t os[2] = {M, N};
+  Hold r(new_tensor(os, 2, a->dtype, -1));
+  std::vector<double> row((size_t)N);
+  for (int64_t i = 0; i < M; i++) {
+    std::fill(row.begin(), row.end(), 0.0);
+    for (int64_t k = 0; k < K; k++) {
+      const double av = a->dtype == kF32 ? (double)a->ptr<float>()[i * a->strides[0] + k * a->strides[1]] : a->ptr<double>()[i * a->strides[0] + k * a->strides[1]];
+      for (int64_t j = 0; j < N; j++)
+        row[j] += av * (b->dtype == kF32 ? (double)b->ptr<float>()[k * b->strides[0] + j * b->strides[1]] : b->ptr<double>()[k * b->strides[0] + j * b->strides[1]]);
+    }
+    for (int64_t j = 0; j < N; j++) { if (a->dtype == kF32) r->ptr<float>()[i * N + j] = (float)row[j]; else r->ptr<double>()[i * N + j] = row[j]; }
+  }
+  return r.take();
+}
+
 int lamp_mm(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b) {
   LAMP_API_BEGIN
+  if (a && b && !a->is_device() && !b->is_device()) { *out = host_mm(a, b); return 0; }
   check_device_tensor(a, "self"); check_device_tensor(b, "mat2");
   Hold r(alloc_out(a, b, false, false, false));
   gemm_dispatch(r.get(), nullptr, a, b, false, false, 0.0, 1.0, false);

@@ -299,8 +299,50 @@ static void reduce_typed(const Tensor* ac, Tensor* out, const DimPlan& p, double
   LAMP_LAUNCH_CHECK();
 }
 
+// lamp's CPU device: the reductions of tensors that live in host memory, as one scalar loop (sums in f64 / i64; row-major order)
+template <class T>
+static void host_reduce(const Tensor* ac, Tensor* out, const DimPlan& p, int op, double scale) {
+  using A = acc_t<T>;
+  const int nd = ac->ndim;
+  const int64_t n = ac->numel();
+  std::vector<int64_t> ostride(nd, 0);                 // stride of every input dim in the (keepdim) output
+  { int64_t run = 1; for (int d = nd - 1; d >= 0; d--) if (!p.reduced[d]) { ostride[d] = run; run *= ac->sizes[d]; } }
+  const int64_t nout = std::max<int64_t>(p.nout, 1);
+  std::vector<double> accd(std::is_integral<A>::value ? 0 : nout, (op == 3) ? -INFINITY : (op == 4 ? INFINITY : 0.0));
+  std::vector<int64_t> acci(std::is_integral<A>::value ? nout : 0, 0);
+  const T* src = ac->ptr<T>();
+  std::vector<int64_t> idx(nd, 0);
+  for (int64_t e = 0; e < n; e++) {
+    int64_t o = 0;
+    for (int d = 0; d < nd; d++) o += idx[d] * ostride[d];
+    if (std::is_integral<A>::value) acci[o] += (int64_t)load_as<A>(src[e]);
+    else {
+      const double v = (double)load_as<A>(src[e]);
+      if (op == 0 || op == 1) accd[o] += v;
+      else if (op == 2 || op == 5) accd[o] += v * v;
+      else if (op == 3) { if (v > accd[o] || v != v) accd[o] = v; }
+      else if (op == 4) { if (v < accd[o] || v != v) accd[o] = v; }
+    }
+    for (int d = nd - 1; d >= 0; d--) { if (++idx[d] < ac->sizes[d]) break; idx[d] = 0; }
+  }
+  T* dst = out->ptr<T>();
+  for (int64_t o = 0; o < nout; o++) {
+    if (std::is_integral<A>::value) dst[o] = store_as<T>((A)(op == 1 ? (double)acci[o] * scale : (double)acci[o]));
+    else { double r = accd[o]; if (op == 1) r *= scale; if (op == 2) r = std::sqrt(r); dst[o] = store_as<T>((A)r); }
+  }
+}
+
 // op: 0 sum, 1 mean, 2 norm2, 3 max, 4 min, 5 sumsq
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op) {
+  LAMP_CHECK(a != nullptr, "input is null");
+  if (!a->is_device()) {
+    DimPlan hp = plan_dims(a, dims, ndims);
+    Hold hac(contiguous(a));
+    Hold hout(new_tensor(keepdim ? hp.out_keep : hp.out_nokeep, a->dtype, -1));
+    const double hscale = op == 1 ? (hp.nred ? 1.0 / (double)hp.nred : NAN) : 1.0;
+    LAMP_DISPATCH_ALL(a->dtype, T, (host_reduce<T>(hac.get(), hout.get(), hp, op, hscale)));
+    return hout.take();
+  }
   check_device_tensor(a, "input");
   DimPlan p = plan_dims(a, dims, ndims);
   Hold ac(contiguous(a));
