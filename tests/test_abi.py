@@ -33,7 +33,7 @@ def test_errors_surface_as_exceptions_without_gpu():
         _capi.lib.lamp_tensor_ndim(None, C.byref(n))
 
 
-def test_host_tensors_are_staging_only():
+def test_host_tensors_stage_and_gpu_only_operators_refuse_them():
     import numpy as np
     from lamp_amd import sten as S
     a = np.arange(12, dtype=np.float32).reshape(3, 4)
@@ -42,5 +42,6 @@ def test_host_tensors_are_staging_only():
     assert np.array_equal(t.to_numpy(), a)
     assert np.array_equal(t.transpose(0, 1).to_numpy(), a.T)          # views + host strided copy work
     assert np.array_equal(t.castToDouble().to_numpy(), a.astype(np.float64))
-    with pytest.raises(_capi.LampError, match="no CPU compute"):
-        t.relu()                                                        # but there is no CPU compute path
+    assert np.array_equal(t.relu().to_numpy(), np.maximum(a, 0))        # lamp's CPU device: element-wise where the tensor lives
+    with pytest.raises(_capi.LampError, match="exists only as a GPU kernel"):
+        t.logSoftMax(1)                                                 # everything else is a GPU kernel and says so
