@@ -534,6 +534,14 @@ int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_
                                                const lamp_tensor* q, const lamp_tensor* k, const lamp_tensor* v,
                                                const lamp_tensor* out, const lamp_tensor* logsumexp,
                                                int is_causal, double scale);
+/* the same with ScaledDotProductAttention's optional additive `attentionBias` (ops.scala:2342-2390; it receives no gradient): broadcasts
+ * against (B, heads, Sq, Sk); NULL = none */
+int lamp_scaled_dot_product_attention_bias(lamp_tensor** out, lamp_tensor** logsumexp, const lamp_tensor* q, const lamp_tensor* k,
+                                           const lamp_tensor* v, const lamp_tensor* attn_bias_or_null, int is_causal, double scale);
+int lamp_scaled_dot_product_attention_bias_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* q,
+                                                    const lamp_tensor* k, const lamp_tensor* v, const lamp_tensor* out,
+                                                    const lamp_tensor* logsumexp, const lamp_tensor* attn_bias_or_null, int is_causal,
+                                                    double scale);
 
 /* ------------------------------------------------------------------------------------------
  * kNN / UMAP fused kernels   (lamp-knn/src/main/scala/lamp/knn/package.scala:21-80;

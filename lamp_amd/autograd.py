@@ -97,9 +97,9 @@ class Variable:
     def logSoftMax(self, dim): return apply_op("LogSoftMax", [self], i=[dim])
     def indexSelect(self, dim, index): return apply_op("IndexSelect", [self, index], i=[dim])
     def euclideanDistance(self, b, dim): return apply_op("EuclideanDistance", [self, b], i=[dim])
-    def scaledDotProductAttention(self, key, value, isCausal=False):
-        """ScaledDotProductAttention(query, key, value, attentionBias = None, isCausal) - ops.scala:2342-2390."""
-        return apply_op("ScaledDotProductAttention", [self, key, value], i=[int(isCausal)])
+    def scaledDotProductAttention(self, key, value, isCausal=False, attentionBias: Optional[STen] = None):
+        """ScaledDotProductAttention(query, key, value, attentionBias, isCausal) - ops.scala:2342-2390."""
+        return apply_op("ScaledDotProductAttention", [self, key, value], tensors=[attentionBias] if attentionBias is not None else [], i=[int(isCausal)])
     def nllLoss(self, target: STen, weights: STen, reduction=1, ignore=-100):
         return apply_op("NllLoss", [self], tensors=[target, weights], i=[reduction, ignore])
     def mseLoss(self, target: STen, reduction=1): return apply_op("MseLoss", [self], tensors=[target], i=[reduction])

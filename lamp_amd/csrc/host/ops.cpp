@@ -11,6 +11,8 @@
 // relu backward) take their beta = 0 / out-of-place variant for that first accumulation.
 #include "ops.h"
 
+#include <unordered_set>
+
 namespace lamp {
 namespace host {
 
@@ -34,16 +36,25 @@ Var make_result(const std::shared_ptr<Op>& op, const Ten& value) {
 }
 
 std::vector<Variable*> topological_sort(Variable* root) {
-  std::vector<Variable*> order;  // children first; reversed at the end => root first
-  std::vector<Variable*> marks;
-  std::function<void(Variable*)> visit = [&](Variable* n) {
-    for (auto* m : marks) if (m == n) return;
-    if (n->op) for (auto& p : n->op->params) visit(p.first.get());
-    marks.push_back(n);
+  // children first; reversed at the end => root first.  Marks in a hash set and an explicit stack: the language model's graph has a few
+  // thousand nodes and chains deeper than a recursion should go (a linear mark search made the sort quadratic).
+  std::vector<Variable*> order;
+  std::unordered_set<Variable*> marks;
+  struct Frame { Variable* n; size_t next; };
+  std::vector<Frame> stack;
+  if (marks.insert(root).second) stack.push_back({root, 0});
+  while (!stack.empty()) {
+    Frame& f = stack.back();
+    Variable* n = f.n;
+    const size_t np = n->op ? n->op->params.size() : 0;
+    if (f.next < np) {
+      Variable* c = n->op->params[f.next++].first.get();
+      if (marks.insert(c).second) stack.push_back({c, 0});   // (may invalidate f: not used afterwards)
+      continue;
+    }
     order.push_back(n);
-  };
-  // the mark lookup above is linear; graphs of the hot path have a few hundred nodes
-  visit(root);
+    stack.pop_back();
+  }
   return std::vector<Variable*>(order.rbegin(), order.rend());
 }
 
@@ -505,10 +516,11 @@ Var capped_shifted_negative_exponential(const Var& a, double shift) {
 
 // ScaledDotProductAttention (ops.scala:2342-2390): joinedBackward - one backward call yields the three gradients.  Here the first
 // closure that runs makes the call and parks the other two results for its siblings (same p), as batch norm does above.
-Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal) {
+Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal, const Ten& attentionBias) {
   auto op = new_op("ScaledDotProductAttention");
   lamp_tensor *o = nullptr, *l = nullptr;
-  HCALL(lamp_scaled_dot_product_attention(&o, &l, query->value.h(), key->value.h(), value->value.h(), isCausal, 0.0));
+  lamp_tensor* const bias = attentionBias.defined() ? attentionBias.h() : nullptr;      // Option[STen]: no gradient flows into it
+  HCALL(lamp_scaled_dot_product_attention_bias(&o, &l, query->value.h(), key->value.h(), value->value.h(), bias, isCausal, 0.0));
   Ten out(o), lse(l);
   struct Cache { Ten g[3]; Ten p; };
   auto cache = std::make_shared<Cache>();
@@ -517,7 +529,8 @@ Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& va
     return [=](const Ten& p, Variable& acc) {
       if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
         lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
-        HCALL(lamp_scaled_dot_product_attention_backward(r3, p.h(), qv.h(), kv.h(), vv.h(), out.h(), lse.h(), isCausal, 0.0));
+        HCALL(lamp_scaled_dot_product_attention_bias_backward(r3, p.h(), qv.h(), kv.h(), vv.h(), out.h(), lse.h(), attentionBias.defined() ? attentionBias.h() : nullptr,
+                                                              isCausal, 0.0));
         for (int i = 0; i < 3; i++) cache->g[i] = Ten(r3[i]);
         cache->p = p;
       }

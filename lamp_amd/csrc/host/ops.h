@@ -45,7 +45,7 @@ Var index_select(const Var& input, int64_t dim, const Var& index);
 Var mask_fill(const Var& input, const Ten& mask, double fill);   // MaskFill (ops.scala:148-159)
 Var euclidean_distance(const Var& a, const Var& b, int64_t dim);
 Var capped_shifted_negative_exponential(const Var& a, double shift);
-Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal);   // attentionBias: not supported (None)
+Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal, const Ten& attentionBias = Ten());
 Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                 const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
                 const std::vector<int64_t>& outputPadding, int64_t groups);

@@ -226,6 +226,16 @@ bool flash_attention_bwd(const Tensor* go, const Tensor* q, const Tensor* k, con
                          Tensor* dv, Tensor* dsum, int is_causal, double scale, hipStream_t st);
 Tensor* at_new_like_layout(const Tensor* like, int64_t B, int64_t H, int64_t S, int64_t D, int dtype);
 
+// scores[B*H, Sq, Sk] = scores * scale + bias (bias broadcast against (B, heads, Sq, Sk)) in place
+static void sdpa_add_bias(Tensor* scores, const Tensor* bias, int64_t B, int64_t H, int64_t Sq, int64_t Sk, double scale) {
+  int64_t s4[4] = {B, H, Sq, Sk};
+  lamp_tensor* v4 = nullptr;
+  LAMP_CHECK(lamp_view(&v4, scores, s4, 4) == 0, lamp_last_error());
+  Hold h4(v4);
+  LAMP_CHECK(lamp_mul_scalar_(v4, scale) == 0, lamp_last_error());
+  LAMP_CHECK(lamp_add_(v4, bias, 1.0) == 0, lamp_last_error());
+}
+
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
                int64_t k, hipStream_t st, int kind);   // knn_fused.hip
 
@@ -574,6 +584,13 @@ int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, c
 // q, k, v: (B, heads, S, d).  out: (B, heads, Sq, d), logsumexp: (B, heads, Sq)
 int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp, const lamp_tensor* q, const lamp_tensor* k, const lamp_tensor* v,
                                       int is_causal, double scale) {
+  return lamp_scaled_dot_product_attention_bias(out, logsumexp, q, k, v, nullptr, is_causal, scale);
+}
+// softmax(q k^T * scale + attn_bias (+ causal mask)) v.  attn_bias (ScaledDotProductAttention's `attentionBias: Option[STen]`,
+// ops.scala:2342-2390; no gradient flows into it) broadcasts against (B, heads, Sq, Sk); with a bias the composed kernels run (the
+// flash kernels take the mask-free and causal forms).
+int lamp_scaled_dot_product_attention_bias(lamp_tensor** out, lamp_tensor** logsumexp, const lamp_tensor* q, const lamp_tensor* k, const lamp_tensor* v,
+                                           const lamp_tensor* attn_bias, int is_causal, double scale) {
   LAMP_API_BEGIN
   check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value");
   LAMP_CHECK(q->ndim == 4 && k->ndim == 4 && v->ndim == 4, "attention expects (B, heads, S, d) tensors");
@@ -583,7 +600,12 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
   if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
   int64_t ls[3] = {B, H, Sq};
   const int64_t rows = B * H * Sq;
-  if (rows && Sk && q->dtype == kBF16) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate; logsumexp is f32 as in ATen
+  if (attn_bias) {
+    check_device_tensor(attn_bias, "attn_bias");
+    LAMP_CHECK(attn_bias->dtype == q->dtype, "attention: attn_bias dtype " << attn_bias->describe() << " differs from the query's");
+    LAMP_CHECK(broadcast_shapes({B, H, Sq, Sk}, attn_bias->shape()) == (std::vector<int64_t>{B, H, Sq, Sk}), "attention: attn_bias does not broadcast to (B, heads, Sq, Sk)");
+  }
+  if (rows && Sk && q->dtype == kBF16 && !attn_bias) {   // fused flash form (bf16, head dim 64 / 128): no S x S intermediate; logsumexp is f32 as in ATen
     // strided operands are read in place; the result takes q's layout, so a (B, heads, S, d) view of (B, S, heads, d) projections
     // comes back as such a view (lamp's transposeOut is then free)
     Hold fo(at_new_like_layout(q, B, H, Sq, Dv, q->dtype)), lse32(new_tensor(ls, 3, kF32, q->device()));
@@ -603,9 +625,14 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
   int64_t ss[3] = {B * H, Sq, Sk};
   Hold scores(new_tensor(ss, 3, q->dtype, q->device()));
   LAMP_CHECK(lamp_baddbmm_out_transposed2(scores.get(), scores.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
+  double sm_scale = scale;
+  if (attn_bias && rows && Sk) {            // scores = q k^T * scale + bias, then the row softmax with scale 1
+    sdpa_add_bias(scores.get(), attn_bias, B, H, Sq, Sk, scale);
+    sm_scale = 1.0;
+  }
   if (rows) {
     LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0,
-                                                        current_stream(q->device()), scores->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, scale, is_causal));
+                                                        current_stream(q->device()), scores->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, sm_scale, is_causal));
     LAMP_LAUNCH_CHECK();
   }
   lamp_tensor* o3 = nullptr;
@@ -618,13 +645,19 @@ int lamp_scaled_dot_product_attention(lamp_tensor** out, lamp_tensor** logsumexp
 
 int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* q, const lamp_tensor* k,
                                                const lamp_tensor* v, const lamp_tensor* out, const lamp_tensor* logsumexp, int is_causal, double scale) {
+  return lamp_scaled_dot_product_attention_bias_backward(out3, grad_out, q, k, v, out, logsumexp, nullptr, is_causal, scale);
+}
+int lamp_scaled_dot_product_attention_bias_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* q, const lamp_tensor* k,
+                                                    const lamp_tensor* v, const lamp_tensor* out, const lamp_tensor* logsumexp, const lamp_tensor* attn_bias,
+                                                    int is_causal, double scale) {
   LAMP_API_BEGIN
   check_device_tensor(q, "query"); check_device_tensor(k, "key"); check_device_tensor(v, "value"); check_device_tensor(grad_out, "grad_out");
   const int64_t B = q->sizes[0], H = q->sizes[1], Sq = q->sizes[2], D = q->sizes[3], Sk = k->sizes[2], Dv = v->sizes[3];
   if (scale <= 0) scale = 1.0 / std::sqrt((double)D);
   // flash form: needs the forward's output and its f32 logsumexp (what the fused forward returns); operands are read in place in
   // whatever row-contiguous layout they have, each gradient takes the layout of its operand
-  if (q->dtype == kBF16 && out && logsumexp && logsumexp->dtype == kF32 && out->dtype == kBF16 && B * H * Sq > 0 && Sk > 0 && grad_out->dtype == kBF16 &&
+  if (attn_bias) check_device_tensor(attn_bias, "attn_bias");
+  if (!attn_bias && q->dtype == kBF16 && out && logsumexp && logsumexp->dtype == kF32 && out->dtype == kBF16 && B * H * Sq > 0 && Sk > 0 && grad_out->dtype == kBF16 &&
       logsumexp->numel() == B * H * Sq && out->numel() == B * H * Sq * Dv && out->ndim == 4 && grad_out->ndim == 4) {
     Hold lc(contiguous(logsumexp));
     int64_t n1[1] = {B * H * Sq};
@@ -655,9 +688,11 @@ int lamp_scaled_dot_product_attention_backward(lamp_tensor* out3[3], const lamp_
   LAMP_CHECK(lamp_baddbmm_out_transposed2(p.get(), p.get(), q3, k3, 0.0, 1.0) == 0, lamp_last_error());
   const int64_t rows = B * H * Sq;
   hipStream_t st = current_stream(q->device());
+  double sm_scale = scale;
+  if (attn_bias && rows && Sk) { sdpa_add_bias(p.get(), attn_bias, B, H, Sq, Sk, scale); sm_scale = 1.0; }
   if (rows) {
     LAMP_DISPATCH_FLOAT(q->dtype, T, hipLaunchKernelGGL((sdpa_softmax_kernel<T>), dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st,
-                                                        p->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, scale, is_causal));
+                                                        p->ptr<T>(), lse->ptr<T>(), rows, Sq, Sk, sm_scale, is_causal));
     LAMP_LAUNCH_CHECK();
   }
   // dV = P^T dO ; dP = dO V^T ; dS = P (dP - rowsum(dP P)) scale ; dQ = dS K ; dK = dS^T Q

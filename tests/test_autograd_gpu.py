@@ -254,6 +254,30 @@ def test_scaled_dot_product_attention_op(gpu, dt, D, tol, causal):
     assert_close(to_torch(k.partialDerivative), kd.grad, tol, "dk")
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_scaled_dot_product_attention_with_attention_bias(gpu, dt, tol, causal):
+    """attentionBias: Option[STen] of ScaledDotProductAttention (ops.scala:2342-2390): softmax(q k^T / sqrt(d) + bias (+ causal mask)) v;
+    the bias is a plain tensor (no gradient), here a (1, heads, Sq, Sk) table broadcast over the batch - e.g. relative-position biases"""
+    g = torch.Generator().manual_seed(11)
+    Bz, H, Sq, D = 2, 3, 40, 64
+    q0, k0, v0 = (torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt) for _ in range(3))
+    bias0 = (torch.randn(1, H, Sq, Sq, generator=g, dtype=torch.float64) * 2).to(dt)
+    w0 = torch.randn(Bz, H, Sq, D, generator=g, dtype=torch.float64).to(dt)
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q0, k0, v0))
+    sc = qd @ kd.transpose(-1, -2) / np.sqrt(D) + bias0.double()
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(Sq, Sq, dtype=torch.bool), 1), float("-inf"))
+    ref = torch.softmax(sc, -1) @ vd
+    (ref * w0.double()).sum().backward()
+    q, k, v = A.param(to_sten(q0)), A.param(to_sten(k0)), A.param(to_sten(v0))
+    out = q.scaledDotProductAttention(k, v, causal, to_sten(bias0))
+    assert_close(to_torch(out.value), ref.detach(), tol, "attention output", scale="max")
+    (out * A.const(to_sten(w0))).sum().backprop()
+    for name, a, b in (("dq", q, qd), ("dk", k, kd), ("dv", v, vd)):
+        assert_close(to_torch(a.partialDerivative), b.grad, tol, name, scale="max")
+
+
 def test_hip_graph_replays_the_gradient_computation(gpu):
     """launch-bound steps: forward + backprop captured once into a HIP graph (lamp_graph_*), replayed on new batches written into the
     captured input buffer; gradients and the loss accumulator equal the eager ones, the optimiser runs eagerly between replays"""
