@@ -93,6 +93,29 @@ __global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __r
   }
 }
 
+// the same for up to IG_PACK_MAX weight tensors in ONE launch (blockIdx.y = tensor): the optimiser re-packs every weight it has just
+// updated (igemm_repack_cached), so a training step pays one pack launch instead of one per convolution layer
+constexpr int IG_PACK_MAX = 16;
+struct PackMany { const bf16_t* w[IG_PACK_MAX]; bf16_t* wp[IG_PACK_MAX]; int Cout[IG_PACK_MAX], Cin[IG_PACK_MAX], KS[IG_PACK_MAX], KPf[IG_PACK_MAX], KPd[IG_PACK_MAX]; };
+__global__ void ig_pack_weights_many_kernel(PackMany a) {
+  const int t = blockIdx.y;
+  const bf16_t* __restrict__ w = a.w[t];
+  bf16_t* __restrict__ wp = a.wp[t];
+  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], KPf = a.KPf[t], KPd = a.KPd[t];
+  const int RS = KS * KS;
+  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const int dgrad = e0 >= nf;
+    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
+    const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
+    const int r = rs / KS, s = rs % KS;
+    bf16_t v; v.bits = 0;
+    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
+    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
+    wp[e0] = v;
+  }
+}
+
 // ---- fprop / dgrad -----------------------------------------------------------------------------------
 // x [N][CI][64], wp [RS][128][KP], y [N][CO][64].  KP = padded K per tap (32, 64 or 128).
 template <int KS, int NW>
@@ -1177,6 +1200,45 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
     g_pack_cache[key] = PackVal{ver, retain(wp.get()), ++g_pack_tick};
   }
   return wp.take();
+}
+
+// Called by the optimisers right after they have written the parameters: every parameter whose packed images are cached (i.e. that an
+// implicit-GEMM convolution used before, on this stream) is packed again now, all of them in one launch, and the cache entries are
+// moved to the new storage version - the next step's convolutions find them fresh.  Values are exactly those a lazy pack at first use
+// would produce (same kernel body, same weights).  LAMP_PACK_AFTER_STEP=0 restores the lazy packs.
+void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_PACK_AFTER_STEP"); return !(e && e[0] == '0'); }();
+  if (!on) return;
+  PackMany a;
+  int cnt = 0, maxtotal = 0;
+  std::vector<std::pair<PackKey, uint64_t>> done;       // (entry, storage version its image now corresponds to)
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  for (int i = 0; i < n && cnt < IG_PACK_MAX; i++) {
+    const Tensor* w = params[i];
+    if (!w || !w->is_device() || w->dtype != kBF16 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
+    for (auto& kv : g_pack_cache) {
+      if (kv.first.uid != w->st->uid || kv.first.offset != w->offset || kv.first.st != st) continue;
+      if (kv.first.Cout != (int)w->sizes[0] || kv.first.Cin != (int)w->sizes[1] || kv.first.KS != (int)w->sizes[2]) continue;
+      const int KS = kv.first.KS, RS = KS * KS, KPf = pad_k(kv.first.Cin), KPd = pad_k(kv.first.Cout);
+      const int total = RS * IG_M * (KPf + KPd);
+      if (kv.second.packed->numel() != total) continue;
+      a.w[cnt] = w->ptr<bf16_t>(); a.Cout[cnt] = kv.first.Cout; a.Cin[cnt] = kv.first.Cin; a.KS[cnt] = KS; a.KPf[cnt] = KPf; a.KPd[cnt] = KPd;
+      // IN PLACE: the entry belongs to this stream, so every convolution that read the old image is ordered before this launch - and a
+      // HIP graph captured earlier keeps reading the same address (bench.py replays forward + backprop around the eager optimiser)
+      a.wp[cnt] = static_cast<bf16_t*>(kv.second.packed->raw());
+      done.push_back({kv.first, w->st->version.load(std::memory_order_relaxed)});
+      maxtotal = std::max(maxtotal, total);
+      cnt++;
+      break;
+    }
+  }
+  if (cnt == 0) return;
+  hipLaunchKernelGGL(ig_pack_weights_many_kernel, dim3((unsigned)std::min(64, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
+  LAMP_LAUNCH_CHECK();
+  for (auto& d : done) {
+    auto it = g_pack_cache.find(d.first);
+    if (it != g_pack_cache.end()) { it->second.version = d.second; it->second.tick = ++g_pack_tick; }
+  }
 }
 
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
