@@ -141,6 +141,14 @@ def roofline_of(rows):
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **extra}
     ach = byts / avg_s / 1e9
+    if d["tag"] == "umap_pairs2":
+        # the layout kernel is bound by memory-side float atomics (64-byte requests, ~20 G/s chip-wide measured), not by bytes: its
+        # launcher declares the UNMERGED request count (two per pair) in the flops slot; the kernel merges runs before issuing them
+        extra["algorithmic_flops"] = 0.0
+        extra["atomic_requests_unmerged"] = flops
+        extra["unmerged_atomic_request_rate_Gps"] = flops / avg_s / 1e9
+        extra["note"] = ("bound by memory-side f64 atomics (~20 G requests/s chip-wide on this part, measured): the byte fraction below "
+                         "understates the kernel; the rate above counts two requests per pair, of which the segmented scan merges ~45 %")
     return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic, **extra}
 
 

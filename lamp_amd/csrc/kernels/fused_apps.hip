@@ -516,6 +516,11 @@ static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, con
                        term_weights ? term_weights[3] : 1.0};
   static const bool pairs2 = [] { const char* e = getenv("LAMP_UMAP_PAIRS2"); return !(e && e[0] == '0'); }();
   if (pairs2 && locations->sizes[1] == 2 && E1 + E2 > 0) {
+    // algorithmic traffic per pair: two int64 indices, two 2-D points gathered, b for the attractive pairs, and the read-modify-write of
+    // two gradient points.  The `flops` slot carries the number of memory-side atomic requests if nothing were merged (two per pair,
+    // x and y of a point share a 64-byte line): bench.py divides by the duration for the atomic-request rate.
+    const double esz = (double)dtype_size(locations->dtype);
+    KernelTimer kt("umap_pairs2", 2.0 * (double)(E1 + E2), (double)(E1 + E2) * (16.0 + 4.0 * esz + 8.0 * esz) + (double)E1 * esz, st);
     if (locations->dtype == kF64) {
       hipLaunchKernelGGL((umap_pairs2_kernel<double>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<double>(), index1->ptr<int64_t>(),
                          index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<double>(), min_dist, balance,

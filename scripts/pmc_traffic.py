@@ -16,7 +16,7 @@ import re
 import sys
 
 CLASSES = [  # kernel-name regex -> bench.py timer class
-    (r"ig_conv8b?_kernel", "conv_igemm_fprop_dgrad"),
+    (r"ig_conv8[a-d]?_kernel", "conv_igemm_fprop_dgrad"),
     (r"ig_wgrad8v2_kernel", "conv_wgrad_igemm"),
     (r"ig_wgrad_reduce_v2_kernel", "conv_wgrad_igemm_reduce"),
     (r"ncv_fwd", "conv_narrow_fprop_dgrad"),
