@@ -77,6 +77,12 @@ int lamp_get_num_gpus(int* out);
 int lamp_get_device(int* out);                 /* cudaGetDevice */
 int lamp_set_device(int device);               /* cudaSetDevice */
 int lamp_device_synchronize(void);
+/* Work the library may defer so that it can be batched (today: the reductions of the bf16 convolutions' weight-gradient partial sums,
+ * one launch for all layers of a backward pass) runs at the latest when a pointer into the affected tensor is requested - results
+ * never depend on it.  This call runs it NOW on the streams it was registered on: the host autograd calls it at the end of
+ * backprop (Variable.backprop, autograd.scala:212-260) so that the whole batch lands in one launch; lamp_device_synchronize and
+ * lamp_stream_synchronize include it. */
+int lamp_flush_deferred(void);
 int lamp_device_name(char* buf, int buflen);
 int lamp_device_num_cus(int* out);
 int lamp_stream_get_current(int device, lamp_stream** out);      /* getCurrentCUDAStream */

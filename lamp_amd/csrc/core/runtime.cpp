@@ -226,8 +226,14 @@ int lamp_set_device(int device) {
   set_device(device);
   LAMP_API_END
 }
+int lamp_flush_deferred(void) {
+  LAMP_API_BEGIN
+  flush_deferred();
+  LAMP_API_END
+}
 int lamp_device_synchronize(void) {
   LAMP_API_BEGIN
+  flush_deferred();
   const int dev = current_device();
   HIP_CHECK(hipDeviceSynchronize());
   check_device_asserts(dev);
@@ -305,6 +311,7 @@ int lamp_stream_set_current(lamp_stream* s) {
 int lamp_stream_synchronize(lamp_stream* s) {
   LAMP_API_BEGIN
   LAMP_CHECK(s, "null stream");
+  flush_deferred();
   HIP_CHECK(hipStreamSynchronize(s->s));
   check_device_asserts(s->device);
   LAMP_API_END

@@ -103,7 +103,13 @@ struct Storage {
   std::atomic<uint64_t> version{0};
   uint64_t uid = next_uid();    // never reused (a freed Storage's address can be)
   static uint64_t next_uid() { static std::atomic<uint64_t> c{1}; return c.fetch_add(1, std::memory_order_relaxed); }
+  // Set while a deferred kernel still has to produce the contents (kernels/wgrad_reduce.hip: the reductions of a backward pass's
+  // weight-gradient partial sums run batched in one launch).  Every pointer into the storage goes through lamp_tensor::raw(), which
+  // resolves the deferral first - so nobody can observe the tensor before it is complete.
+  std::atomic<uint32_t> pending{0};
 };
+void resolve_deferred(Storage* st);   // runs every pending deferred kernel now (on the streams they were registered on)
+void flush_deferred();                // the same, called at the natural batching points (end of backprop, lamp_flush_deferred)
 
 }  // namespace lamp
 
@@ -124,7 +130,11 @@ struct lamp_tensor {
   int device() const { return st ? st->device : -1; }
   bool is_device() const { return st && st->device >= 0; }
   size_t itemsize() const { return lamp::dtype_size(dtype); }
-  void* raw() const { return st ? (char*)st->ptr + offset * (int64_t)itemsize() : nullptr; }   // no version bump: read-only uses
+  void* raw() const {                                                                            // no version bump: read-only uses
+    if (!st) return nullptr;
+    if (st->pending.load(std::memory_order_acquire)) lamp::resolve_deferred(st);
+    return (char*)st->ptr + offset * (int64_t)itemsize();
+  }
   void* data() { if (st) st->version.fetch_add(1, std::memory_order_relaxed); return raw(); }
   const void* data() const { return raw(); }
   template <class T> T* ptr() { return (T*)data(); }

@@ -72,6 +72,7 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     }
     if (after) after(v);
   }
+  HCALL(lamp_flush_deferred());               // the convolutions' weight-gradient reductions of this pass, in one launch
 }
 
 namespace {

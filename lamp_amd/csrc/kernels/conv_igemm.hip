@@ -30,6 +30,7 @@
 #include <tuple>
 #include "device_utils.h"
 #include "conv_geom.h"
+#include "wgrad_reduce.h"
 
 namespace lamp {
 
@@ -1100,38 +1101,7 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
       }
   }
 }
-// Split reduction: thread (q, sg) sums float4 column q of this block over the splits sg, sg+8, ... (independent 16-byte
-// loads in flight), the 8 split groups are then combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void ig_wgrad_reduce_v2_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int CIP, int RS,
-                                                                 int nsplit) {
-  __shared__ float4 red[8][32];
-  const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int64_t per_split = (int64_t)RS * IG_M * CIP / 4;   // float4 elements of one split
-  const int64_t col = (int64_t)blockIdx.x * 32 + q;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < per_split) {
-    const float4* p4 = reinterpret_cast<const float4*>(partial) + col;
-#pragma unroll 4
-    for (int sp = sg; sp < nsplit; sp += 8) {
-      const float4 v = p4[(int64_t)sp * per_split];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-  }
-  red[sg][q] = a;
-  __syncthreads();
-  if (sg == 0 && col < per_split) {
-#pragma unroll
-    for (int g = 1; g < 8; g++) { const float4 v = red[g][q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-    const int c4 = CIP / 4;
-    const int ci = (int)(col % c4) * 4, co = (int)((col / c4) % IG_M), rs = (int)(col / ((int64_t)c4 * IG_M));
-    if (co < CO) {
-      const float r[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (ci + k < CI) dw[((int64_t)co * CI + ci + k) * RS + rs] = bf16_t(r[k]);
-    }
-  }
-}
+// (the reduction of the v2 partial sums lives in wgrad_reduce.h: it runs batched with the other layers' reductions)
 
 // ---- host ---------------------------------------------------------------------------------------------
 static bool ig_qualifies(const ConvGeom& g, int dtype) {
@@ -1372,9 +1342,9 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
       LAMP_LAUNCH_CHECK();
     }
     const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
-    hipLaunchKernelGGL(ig_wgrad_reduce_v2_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), (int)g.Cout,
-                       (int)g.Cin, CIP, RS, nsplit);
-    LAMP_LAUNCH_CHECK();
+    WgradReduceArgs ra{};
+    ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
+    wgrad_reduce_enqueue(ra, partial.get(), dw, st);
     return true;
   }
   // (v1, kept for reference: one tap per workgroup) enough workgroups to fill 256 CUs: RS taps x nsplit image ranges

@@ -22,6 +22,11 @@
 // Accumulation is fp32 in a fixed order: results are bitwise reproducible.
 #include "device_utils.h"
 #include "conv_geom.h"
+#include "wgrad_reduce.h"
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace lamp {
 
@@ -38,13 +43,19 @@ struct NcvGeom {
   int Ho, Wo;            // output map
   int sh, sw, wx;        // window of output (ho, wo), filter row r: LDS row ho*sh + r, columns wo*sw + wx + [0, 8)
   int kh;
+  int kh_inv;            // 65536 / kh + 1: pair / kh == (pair * kh_inv) >> 16 for pair < 4096 (no integer division in the prologue)
+  int pf;                // the image fits the register prefetch (W % 8 == 0 and at most NCV_PF 16-byte packets per thread)
 };
 
 constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligned rows for the vector copy
 
-// Weight fragments are gathered by every lane straight from the filter tensor (a few hundred elements, L2 resident): no pack
-// kernel, no packed copy.  Fragment of k-step ks for lane = co + 16*g: pair (c, r) = 4*ks + g, element j = filter column
-// (zero for j >= kw);   fprop: W[co][c][r][j]      dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j]
+// Weight fragments.  Fragment of k-step ks for lane = co + 16*g: pair (c, r) = 4*ks + g, element j = filter column (zero for
+// j >= kw);   fprop: W[co][c][r][j]      dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j].
+// They are packed ONCE per weight version into a [NCV_NKMAX][64 lanes][8] image (12 KiB; ncv_pack_kernel, cached per
+// (storage, view, stream, direction) like the implicit-GEMM images and re-packed in one launch by the optimiser step), so a
+// workgroup's prologue is NK 16-byte loads per lane.  Gathering them per lane from the filter tensor (8 two-byte loads and two
+// integer divisions per k-step) took 5.5 - 6.5 k of the ~22 k cycles a workgroup lives (scripts/ncv_stamp_probe.py).
+constexpr int NCV_NKMAX = 12;
 struct NcvW {
   const bf16_t* w;
   int Cout, Cin, kh, kw, dgrad;
@@ -63,6 +74,48 @@ __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int la
     v[j] = (short)e;
   }
   return __builtin_bit_cast(nv_bf8, v);
+}
+constexpr int NCV_PACK_MAX = 16;
+struct NcvPackMany {
+  NcvW w[NCV_PACK_MAX];
+  nv_bf8* dst[NCV_PACK_MAX];
+};
+// grid (3, entries) x 256 threads: thread = (k-step, lane) of one fragment image
+__global__ __launch_bounds__(256) void ncv_pack_kernel(NcvPackMany a) {
+  const int t = blockIdx.x * 256 + threadIdx.x, e = blockIdx.y;
+  if (t >= NCV_NKMAX * 64) return;
+  a.dst[e][t] = ncv_weight_frag(a.w[e], t >> 6, t & 63);
+}
+
+// Image staging in two halves, so that the NEXT image's global loads are in flight while the current one is multiplied:
+// the image [C][H][W] is read as consecutive 16-byte packets (W % 8 == 0) into NCV_PF registers per thread ...
+constexpr int NCV_PF = 4;
+struct NcvPre { uint4 v[NCV_PF]; };
+__device__ __forceinline__ void ncv_stage_load(NcvPre& r, const bf16_t* __restrict__ sp, const NcvGeom& q, int tid, int nthreads) {
+  const int total = (q.C * q.H * q.W) >> 3;
+#pragma unroll
+  for (int k = 0; k < NCV_PF; k++) {
+    const int i = tid + k * nthreads;
+    if (i < total) r.v[k] = *reinterpret_cast<const uint4*>(sp + i * 8);
+  }
+}
+// ... and written to the LDS image [C][Hs][Ws] at (top + a*dil, left + b*dil) once the previous image's reads are done
+__device__ __forceinline__ void ncv_stage_store(unsigned short* xs, const NcvPre& r, const NcvGeom& q, int tid, int nthreads) {
+  const int rc = q.W >> 3, total = q.C * q.H * rc;
+#pragma unroll
+  for (int k = 0; k < NCV_PF; k++) {
+    const int i = tid + k * nthreads;
+    if (i < total) {
+      const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
+      if (q.dil == 1) *reinterpret_cast<uint4*>(xs + (c * q.Hs + q.top + a) * q.Ws + q.left + b * 8) = r.v[k];
+      else {
+        unsigned short* d = xs + (c * q.Hs + q.top + a * q.dil) * q.Ws + q.left + b * 8 * q.dil;
+        const unsigned int u[4] = {r.v[k].x, r.v[k].y, r.v[k].z, r.v[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { d[(2 * j) * q.dil] = (unsigned short)(u[j] & 0xffffu); d[(2 * j + 1) * q.dil] = (unsigned short)(u[j] >> 16); }
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ void ncv_stage(unsigned short* xs, const bf16_t* __restrict__ sp, const NcvGeom& q, int tid, int nthreads) {
@@ -83,7 +136,7 @@ __device__ __forceinline__ void ncv_stage(unsigned short* xs, const bf16_t* __re
 }
 
 template <int NK>
-__global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__ src, NcvW wq, const bf16_t* __restrict__ bias,
+__global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
                                                       bf16_t* __restrict__ dst, NcvGeom q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
@@ -93,10 +146,10 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
   int koff[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ks++) {
-    wfr[ks] = ncv_weight_frag(wq, ks, lane);
+    wfr[ks] = wpk[ks * 64 + lane];
     int pair = ks * 4 + (lane >> 4);
     if (pair >= q.C * q.kh) pair = 0;                    // padded k: weights are zero, any valid address will do
-    const int c = pair / q.kh, r = pair - c * q.kh;
+    const int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
     koff[ks] = (c * q.Hs + r) * q.Ws * 2;
   }
   const float bv = (bias && co < q.CO) ? (float)bias[co] : 0.f;
@@ -142,11 +195,21 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
 // once and funnel-shifted in registers by a compile-time amount; a lane ends up holding P consecutive output
 // pixels per accumulator register, stored as one 16- or 8-byte write.
 //   PH0 = (window origin wx) & 7.
+// -DNCV_STAMP (diagnostic builds only; scripts/ncv_stamp_probe.py): s_memtime stamps of thread 0 of the first 1024 workgroups
+#ifdef NCV_STAMP
+__device__ unsigned long long ncv_stamps[1024 * 8];
+#define NCV_STAMP_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) ncv_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NCV_STAMP_ONCE(k) do { if (n == (int)blockIdx.x) NCV_STAMP_AT(k); } while (0)
+#else
+#define NCV_STAMP_AT(k) do { } while (0)
+#define NCV_STAMP_ONCE(k) do { } while (0)
+#endif
 template <int NK, int SW, int PH0>
-__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, NcvW wq, const bf16_t* __restrict__ bias,
+__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
                                                        bf16_t* __restrict__ dst, NcvGeom q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
+  NCV_STAMP_AT(0);
   constexpr int P = 8 / SW;
   constexpr int NSEG = (PH0 + (P - 1) * SW + 7) < 16 ? 2 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -156,23 +219,34 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   int koff[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ks++) {
-    wfr[ks] = ncv_weight_frag(wq, ks, lane);
+    wfr[ks] = wpk[ks * 64 + lane];
     int pair = ks * 4 + (lane >> 4);
     if (pair >= q.C * q.kh) pair = 0;
-    const int c = pair / q.kh, r = pair - c * q.kh;
+    const int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
     koff[ks] = (c * q.Hs + r) * q.Ws * 2;
   }
   const float bv = (bias && co < q.CO) ? (float)bias[co] : 0.f;
+#ifdef NCV_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  NCV_STAMP_AT(1);
+#endif
   const int HoWo = q.Ho * q.Wo, nsuper = q.Ho / TR;
   const int img_elems = q.C * q.Hs * q.Ws;
   for (int o = tid * 8; o < img_elems; o += nthreads * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);
   // A-side lane -> (row within the super-tile, column group)
   const int a_tr = (lane & 15) / ncg, a_cg = (lane & 15) - a_tr * ncg;
   const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
+  const int64_t img_in = (int64_t)q.C * q.H * q.W;
+  NcvPre pre;
+  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, src + blockIdx.x * img_in, q, tid, nthreads);
   for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
+    __syncthreads();                                     // zero fill / the previous image's reads are done
+    NCV_STAMP_ONCE(2);
+    if (q.pf) ncv_stage_store(xs, pre, q, tid, nthreads);
+    else ncv_stage(xs, src + n * img_in, q, tid, nthreads);
     __syncthreads();
-    ncv_stage(xs, src + (int64_t)n * q.C * q.H * q.W, q, tid, nthreads);
-    __syncthreads();
+    NCV_STAMP_ONCE(3);
+    if (q.pf && n + (int)gridDim.x < q.N) ncv_stage_load(pre, src + (n + (int)gridDim.x) * img_in, q, tid, nthreads);   // in flight during the MFMAs
     bf16_t* yp = dst + (int64_t)n * q.CO * HoWo;
     for (int st = wid; st < nsuper; st += nwaves) {
       const int h0 = st * TR;
@@ -219,8 +293,17 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
         }
       }
     }
+    NCV_STAMP_ONCE(4);
   }
+#ifdef NCV_STAMP
+  NCV_STAMP_AT(5);
+  __builtin_amdgcn_s_waitcnt(0);
+  NCV_STAMP_AT(6);
+#endif
 }
+#ifdef NCV_STAMP
+extern "C" int lamp_debug_ncv_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ncv_stamps), sizeof(ncv_stamps)) == hipSuccess ? 0 : 1; }
+#endif
 
 // ---- wgrad ---------------------------------------------------------------------------------------------
 struct NcvWGeom {
@@ -467,15 +550,7 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void ncv_wgrad_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int O, int nblocks) {
-  const int lane = threadIdx.x & 63;
-  const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
-  if (o >= O) return;
-  float a = 0.f;
-  for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * O + o];
-  a = wave_sum(a);
-  if (lane == 0) dw[o] = bf16_t(a);
-}
+// (the reduction of the per-block partial sums lives in wgrad_reduce.h: it runs batched with the other layers' reductions)
 
 // ---- host ------------------------------------------------------------------------------------------------
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -490,14 +565,105 @@ static bool ncv_common(const ConvGeom& g, int dtype) {
 }
 
 template <int NK>
-static void ncv_launch(const bf16_t* src, const NcvW& wq, const bf16_t* bias, bf16_t* dst, const NcvGeom& q, int blocks, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((ncv_fwd_kernel<NK>), dim3(blocks), dim3(256), lds, st, src, wq, bias, dst, q);
+static void ncv_launch(const bf16_t* src, const nv_bf8* wpk, const bf16_t* bias, bf16_t* dst, const NcvGeom& q, int blocks, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((ncv_fwd_kernel<NK>), dim3(blocks), dim3(256), lds, st, src, wpk, bias, dst, q);
+}
+
+// ---- packed weight-fragment images, cached per (storage uid, view, geometry, direction, stream) and storage version: the same scheme
+// as the implicit-GEMM images (conv_igemm.hip, "packed-weight cache"); LAMP_PACK_CACHE=0 disables it.
+namespace {
+struct NcvPackKey {
+  uint64_t uid; int64_t offset; int Cout, Cin, kh, kw, dgrad; hipStream_t st;
+  bool operator<(const NcvPackKey& o) const {
+    return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, st) < std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.st);
+  }
+};
+struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+std::mutex g_ncv_mu;
+std::map<NcvPackKey, NcvPackVal> g_ncv_cache;
+uint64_t g_ncv_tick = 0;
+constexpr int64_t NCV_PACK_ELEMS = (int64_t)NCV_NKMAX * 64 * 8;
+}  // namespace
+
+static void ncv_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) {
+  hipLaunchKernelGGL(ncv_pack_kernel, dim3((NCV_NKMAX * 64 + 255) / 256, (unsigned)cnt), dim3(256), 0, st, a);
+  LAMP_LAUNCH_CHECK();
+}
+
+// returns a +1 handle on the fragment image of `w` for this direction
+static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st) {
+  static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
+  const bool cacheable = cache_on && w->st->owned;
+  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, st};
+  const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_ncv_mu);
+    auto it = g_ncv_cache.find(key);
+    if (it != g_ncv_cache.end() && it->second.version == ver) {
+      it->second.tick = ++g_ncv_tick;
+      return retain(it->second.packed);
+    }
+  }
+  int64_t ps[1] = {NCV_PACK_ELEMS};
+  Hold wp(new_tensor(ps, 1, kBF16, w->device()));
+  NcvPackMany a;
+  a.w[0] = wq; a.dst[0] = reinterpret_cast<nv_bf8*>(wp->ptr<bf16_t>());
+  ncv_pack_launch(a, 1, st);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_ncv_mu);
+    auto it = g_ncv_cache.find(key);
+    if (it != g_ncv_cache.end()) { release(it->second.packed); g_ncv_cache.erase(it); }
+    if (g_ncv_cache.size() >= 256) {           // evict the least recently used entry
+      auto victim = g_ncv_cache.begin();
+      for (auto i = g_ncv_cache.begin(); i != g_ncv_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
+      release(victim->second.packed);
+      g_ncv_cache.erase(victim);
+    }
+    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick};
+  }
+  return wp.take();
+}
+
+// Called by the optimisers right after they have written the parameters (next to igemm_repack_cached): every cached fragment image of
+// these parameters on this stream is packed again IN PLACE (a captured HIP graph keeps the address), all of them in one launch.
+void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_PACK_AFTER_STEP"); return !(e && e[0] == '0'); }();
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_ncv_mu);
+  if (g_ncv_cache.empty()) return;
+  NcvPackMany a;
+  int cnt = 0;
+  std::vector<std::pair<NcvPackKey, uint64_t>> done;
+  auto flush = [&] {
+    if (cnt == 0) return;
+    ncv_pack_launch(a, cnt, st);
+    cnt = 0;
+  };
+  for (int i = 0; i < n; i++) {
+    const Tensor* w = params[i];
+    if (!w || !w->is_device() || w->dtype != kBF16 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
+    if (w->sizes[0] > 16 || w->sizes[1] > 16) continue;
+    for (auto& kv : g_ncv_cache) {
+      const NcvPackKey& k = kv.first;
+      if (k.uid != w->st->uid || k.offset != w->offset || k.st != st) continue;
+      if (k.Cout != (int)w->sizes[0] || k.Cin != (int)w->sizes[1] || k.kh != (int)w->sizes[2] || k.kw != (int)w->sizes[3]) continue;
+      a.w[cnt] = NcvW{w->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad};
+      a.dst[cnt] = static_cast<nv_bf8*>(kv.second.packed->raw());
+      done.push_back({k, w->st->version.load(std::memory_order_relaxed)});
+      if (++cnt == NCV_PACK_MAX) flush();
+    }
+  }
+  flush();
+  for (auto& d : done) {
+    auto it = g_ncv_cache.find(d.first);
+    if (it != g_ncv_cache.end()) { it->second.version = d.second; it->second.tick = ++g_ncv_tick; }
+  }
 }
 
 static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
   if (!ncv_common(g, in->dtype)) return false;
   NcvGeom q;
-  q.N = (int)g.N; q.kh = g.kh;
+  q.N = (int)g.N; q.kh = g.kh; q.pf = 0; q.kh_inv = 65536 / g.kh + 1;
   if (!dgrad) {
     if (g.W % 8 != 0) return false;
     q.C = (int)g.Cin; q.CO = (int)g.Cout; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
@@ -532,6 +698,8 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   const size_t lds = (size_t)q.C * q.Hs * q.Ws * 2;
   if (lds > 64 * 1024) return false;
   const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0};
+  Hold wpk_h(ncv_packed_weights(w, wq, st));
+  const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
   static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2 (each workgroup gathers its weight fragments once)
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
   const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
@@ -540,8 +708,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   if (aligned) {
     const int nsuper = q.Ho / (16 / ncg);
     const int threads = 64 * std::min(4, nsuper);
+    q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
-#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q)
+#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q)
 #define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
 #define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
     switch (NK2) {
@@ -557,12 +726,12 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     return true;
   }
   switch (NK) {
-    case 1: ncv_launch<1>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 2: ncv_launch<2>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 4: ncv_launch<4>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 5: ncv_launch<5>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    default: ncv_launch<12>(in->ptr<bf16_t>(), wq, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 1: ncv_launch<1>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 4: ncv_launch<4>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 5: ncv_launch<5>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    default: ncv_launch<12>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
   }
   LAMP_LAUNCH_CHECK();
   return true;
@@ -636,9 +805,9 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
 #undef NCV_WG2
         LAMP_LAUNCH_CHECK();
       }
-      hipLaunchKernelGGL(ncv_wgrad_reduce_kernel, dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), O,
-                         nblocks);
-      LAMP_LAUNCH_CHECK();
+      WgradReduceArgs ra{};
+      ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
+      wgrad_reduce_enqueue(ra, partial.get(), dw, st);
       return true;
     }
     // does not fit: restore the geometry of the generic kernel
@@ -680,9 +849,9 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
 #undef NCV_WG
     LAMP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(ncv_wgrad_reduce_kernel, dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), O,
-                     nblocks);
-  LAMP_LAUNCH_CHECK();
+  WgradReduceArgs ra{};
+  ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
+  wgrad_reduce_enqueue(ra, partial.get(), dw, st);
   return true;
 }
 

@@ -14,6 +14,7 @@
 namespace lamp {
 
 void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   // conv_igemm.hip
+void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);  // conv_narrow.hip
 
 constexpr int MT_MAX = 40;       // tensors per launch (the descriptor is a by-value kernel argument: 3.4 KB of the 4 KB limit; the ResNet has 37)
 constexpr int MT_CHUNK = 4096;   // elements per workgroup
@@ -313,6 +314,7 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
     }
   }
   igemm_repack_cached(params, n, st);     // the convolution weights' packed images follow the update in one launch (conv_igemm.hip)
+  narrow_repack_cached(params, n, st);
   LAMP_API_END
 }
 
@@ -339,6 +341,7 @@ int lamp_sgdw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_
       [&](MultiArgs& a, int blk) { hipLaunchKernelGGL((sgdw_kernel<T>), dim3(blk), dim3(256), 0, st, a); }));
   LAMP_LAUNCH_CHECK();
   igemm_repack_cached(params, n, st);
+  narrow_repack_cached(params, n, st);
   LAMP_API_END
 }
 

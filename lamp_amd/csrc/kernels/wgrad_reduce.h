@@ -1,0 +1,68 @@
+// The second half of the bf16 convolutions' weight gradients: f32 partial sums per image range -> one rounded bf16 tensor, summed in
+// a fixed order (deterministic).  The two bodies below are used by (a) the per-layer kernels of conv_igemm.hip / conv_narrow.hip and
+// (b) the multi-tensor kernel of wgrad_reduce.hip, which runs ALL reductions a backward pass has registered in one launch:
+// the ResNet step had 13 of these ~5 us launches, each at the ~4.5 us launch floor.
+#pragma once
+#include "device_utils.h"
+
+namespace lamp {
+
+struct WgradReduceArgs {
+  int kind;                 // 0: implicit GEMM v2 layout [split][tap][128][CIP], 1: narrow layout [block][O]
+  const float* partial;
+  bf16_t* dw;
+  int CO, CI, CIP, RS;      // kind 0
+  int nsplit;               // kind 0: image ranges; kind 1: blocks
+  int O;                    // kind 1: outputs
+  int blocks;               // workgroups (256 threads) this reduction needs
+};
+
+// kind 0.  Thread (q, sg) sums float4 column q of this block over the splits sg, sg+8, ... (independent 16-byte loads in flight), the 8
+// split groups are then combined through LDS in a fixed order.
+__device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int block, float4 (*red)[32]) {
+  constexpr int M = 128;    // IG_M
+  const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int64_t per_split = (int64_t)a.RS * M * a.CIP / 4;   // float4 elements of one split
+  const int64_t col = (int64_t)block * 32 + q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < per_split) {
+    const float4* p4 = reinterpret_cast<const float4*>(a.partial) + col;
+#pragma unroll 4
+    for (int sp = sg; sp < a.nsplit; sp += 8) {
+      const float4 v = p4[(int64_t)sp * per_split];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[sg][q] = s;
+  __syncthreads();
+  if (sg == 0 && col < per_split) {
+#pragma unroll
+    for (int g = 1; g < 8; g++) { const float4 v = red[g][q]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    const int c4 = a.CIP / 4;
+    const int ci = (int)(col % c4) * 4, co = (int)((col / c4) % M), rs = (int)(col / ((int64_t)c4 * M));
+    if (co < a.CO) {
+      const float r[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (ci + k < a.CI) a.dw[((int64_t)co * a.CI + ci + k) * a.RS + rs] = bf16_t(r[k]);
+    }
+  }
+}
+
+// kind 1.  Wave per output element, lanes over the blocks, butterfly sum.
+__device__ __forceinline__ void wgrad_reduce_narrow(const WgradReduceArgs& a, int block) {
+  const int lane = threadIdx.x & 63;
+  const int o = (int)(((int64_t)block * 256 + threadIdx.x) >> 6);
+  if (o >= a.O) return;
+  float s = 0.f;
+  for (int b = lane; b < a.nsplit; b += 64) s += a.partial[(int64_t)b * a.O + o];
+  s = wave_sum(s);
+  if (lane == 0) a.dw[o] = bf16_t(s);
+}
+
+// Registers the reduction (wgrad_reduce.hip): it runs with every other pending one at the next flush_deferred() - the end of
+// backprop - or the moment anything asks for a pointer into dw's storage (Tensor::raw()), whichever comes first.
+// LAMP_DEFER_WGRAD_REDUCE=0: launch it now.
+void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_tensor* dw, hipStream_t st);
+
+}  // namespace lamp

@@ -52,4 +52,4 @@ lib.lamp_kernel_timer_enable(0)
 for line in buf.value.decode().splitlines():
     tag_, n, ms, flops, byts = line.split()
     if "sdpa" in tag_ or "gemm" in tag_:
-        print(f"   {tag_:24s} n={n} avg {float(ms) / int(n) * 1e3:9.1f} us  {float(flops) / max(float(ms), 1e-9) / 1e9:8.1f} TFLOP/s")
+        print(f"   {tag_:24s} n={n} avg {float(ms) / int(n) * 1e3:9.1f} us  {float(flops) * int(n) / max(float(ms), 1e-9) / 1e9:8.1f} TFLOP/s executed (flops column is per launch)")

@@ -18,7 +18,7 @@ import sys
 CLASSES = [  # kernel-name regex -> bench.py timer class
     (r"ig_conv8[a-d]?_kernel", "conv_igemm_fprop_dgrad"),
     (r"ig_wgrad8v2_kernel", "conv_wgrad_igemm"),
-    (r"ig_wgrad_reduce_v2_kernel", "conv_wgrad_igemm_reduce"),
+    (r"ig_wgrad_reduce_v2_kernel|wgrad_reduce_many_kernel", "conv_wgrad_reduce"),
     (r"ncv_fwd", "conv_narrow_fprop_dgrad"),
     (r"ncv_wgrad2?_kernel", "conv_wgrad_narrow"),
     (r"bn_stats_kernel", "bn_fwd_stats"),

@@ -2,10 +2,9 @@
 # Runs on the GPU box (gpurun): full GPU test suite, bench line, rocprofv3 kernel stats, the two PMC passes and the secondary probes.
 # Everything judged is written under gpurun_out/refresh/ and copied into profiles/ by hand afterwards.
 set -u
-R=$PWD; O=$R/gpurun_out/refresh; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/refresh; mkdir -p $O; RND=${RND:-r02}
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
-python bench.py > $O/bench.log 2>$O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/ks -o k --output-format csv -- python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline > /tmp/ks.log 2>&1
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
@@ -13,6 +12,8 @@ python3 $R/scripts/trace_step.py $(find /tmp/ks -name "*kernel_trace.csv" | head
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > /tmp/pw.log 2>&1
 python3 $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv" | head -1) $(find /tmp/pw -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+cp $O/pmc_traffic.json $R/profiles/${RND}_pmc_traffic.json   # the bench line below reads its roofline.traffic from this run's passes
+cd $R; python bench.py > $O/bench.log 2>$O/bench.err; cd /tmp
 for w in gemm knn attention umap lm; do
   rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o k --output-format csv -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > /tmp/ks_$w.log 2>&1
   cp $(find /tmp/ks_$w -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$w.csv

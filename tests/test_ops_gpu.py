@@ -708,8 +708,11 @@ def test_errors_are_loud(gpu):
     with pytest.raises(Exception, match="dtype"):
         a + to_sten(closed_form((3, 4), 0, 1.0, torch.float64))
     host = S.STen.zeros([3, 4], S.F32, device=S.CPU)
-    with pytest.raises(Exception, match="no CPU compute"):
-        host.relu()
+    assert host.relu().device == S.CPU                      # lamp's CPU device: element-wise where the tensor lives (tests/test_cpu_device.py)
+    with pytest.raises(Exception, match="exists only as a GPU kernel"):
+        host.logSoftMax(1)
+    with pytest.raises(Exception, match="device"):
+        a + host                                               # no silent transfer between devices
 
 
 def test_allocation_registry(gpu):
