@@ -84,6 +84,23 @@ void allow_big_lds(const void* fn) {
   HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done.insert({fn, dev});
 }
+// co-resident workgroups per CU of (kernel, threads, dynamic LDS) on the current device, as the runtime computes it from the code
+// object's register / LDS use.  Launchers that size a persistent grid as CUs x workgroups-per-CU ask here instead of assuming: a
+// grid one workgroup per CU too large runs a second, nearly empty round.
+int kernel_occupancy(const void* fn, int threads, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t, int>, int> cache;
+  const int dev = current_device();
+  const auto key = std::make_tuple(fn, threads, lds, dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds));
+  n = std::max(1, n);
+  cache[key] = n;
+  return n;
+}
 uint64_t philox_seed() { return g_seed.load(); }
 uint64_t next_philox_offset(uint64_t n) { return g_philox_offset.fetch_add(n); }
 

@@ -181,6 +181,7 @@ void set_device(int d);
 hipStream_t current_stream();           // thread-local current stream of current device
 hipStream_t current_stream(int device);
 int num_cus();
+int kernel_occupancy(const void* kernel, int threads, size_t dynamic_lds);   // co-resident workgroups per CU (cached)
 void allow_big_lds(const void* kernel);   // opt a kernel into 160 KiB of dynamic LDS on the current device (once per device)
 // Batch-norm statistics computed by a convolution's epilogue: Welford triples [P][C][3] (f32) over P disjoint slices of the output,
 // keyed by the output's storage (uid, offset) and valid while its version is unchanged.  The batch norm that consumes the tensor

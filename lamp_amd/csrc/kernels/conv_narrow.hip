@@ -87,33 +87,39 @@ __global__ __launch_bounds__(256) void ncv_pack_kernel(NcvPackMany a) {
   a.dst[e][t] = ncv_weight_frag(a.w[e], t >> 6, t & 63);
 }
 
-// Image staging in two halves, so that the NEXT image's global loads are in flight while the current one is multiplied:
-// the image [C][H][W] is read as consecutive 16-byte packets (W % 8 == 0) into NCV_PF registers per thread ...
+// Image staging in two halves, so that the NEXT image's global loads are in flight while the current one is multiplied: the image
+// [C][H][W] is read as consecutive 16-byte packets (W % 8 == 0), packet tid + k * nthreads into register k of the thread, and
+// written to the LDS image [C][Hs][Ws] at (top + a*dil, left + b*dil) once the previous image's reads are done.  A thread handles
+// the same packets of every image, so their LDS destinations are computed once (ncv_stage_plan): -1 = no packet.
 constexpr int NCV_PF = 4;
 struct NcvPre { uint4 v[NCV_PF]; };
-__device__ __forceinline__ void ncv_stage_load(NcvPre& r, const bf16_t* __restrict__ sp, const NcvGeom& q, int tid, int nthreads) {
-  const int total = (q.C * q.H * q.W) >> 3;
-#pragma unroll
-  for (int k = 0; k < NCV_PF; k++) {
-    const int i = tid + k * nthreads;
-    if (i < total) r.v[k] = *reinterpret_cast<const uint4*>(sp + i * 8);
-  }
-}
-// ... and written to the LDS image [C][Hs][Ws] at (top + a*dil, left + b*dil) once the previous image's reads are done
-__device__ __forceinline__ void ncv_stage_store(unsigned short* xs, const NcvPre& r, const NcvGeom& q, int tid, int nthreads) {
+struct NcvPlan { int dst[NCV_PF]; };
+__device__ __forceinline__ NcvPlan ncv_stage_plan(const NcvGeom& q, int tid, int nthreads) {
+  NcvPlan pl;
   const int rc = q.W >> 3, total = q.C * q.H * rc;
 #pragma unroll
   for (int k = 0; k < NCV_PF; k++) {
     const int i = tid + k * nthreads;
-    if (i < total) {
-      const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
-      if (q.dil == 1) *reinterpret_cast<uint4*>(xs + (c * q.Hs + q.top + a) * q.Ws + q.left + b * 8) = r.v[k];
-      else {
-        unsigned short* d = xs + (c * q.Hs + q.top + a * q.dil) * q.Ws + q.left + b * 8 * q.dil;
-        const unsigned int u[4] = {r.v[k].x, r.v[k].y, r.v[k].z, r.v[k].w};
+    const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
+    pl.dst[k] = (q.pf && i < total) ? (c * q.Hs + q.top + a * q.dil) * q.Ws + q.left + b * 8 * q.dil : -1;
+  }
+  return pl;
+}
+__device__ __forceinline__ void ncv_stage_load(NcvPre& r, const NcvPlan& pl, const bf16_t* __restrict__ sp, int tid, int nthreads) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { d[(2 * j) * q.dil] = (unsigned short)(u[j] & 0xffffu); d[(2 * j + 1) * q.dil] = (unsigned short)(u[j] >> 16); }
-      }
+  for (int k = 0; k < NCV_PF; k++)
+    if (pl.dst[k] >= 0) r.v[k] = *reinterpret_cast<const uint4*>(sp + (tid + k * nthreads) * 8);
+}
+__device__ __forceinline__ void ncv_stage_store(unsigned short* xs, const NcvPre& r, const NcvPlan& pl, int dil) {
+#pragma unroll
+  for (int k = 0; k < NCV_PF; k++) {
+    if (pl.dst[k] < 0) continue;
+    if (dil == 1) *reinterpret_cast<uint4*>(xs + pl.dst[k]) = r.v[k];
+    else {
+      unsigned short* d = xs + pl.dst[k];
+      const unsigned int u[4] = {r.v[k].x, r.v[k].y, r.v[k].z, r.v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) { d[(2 * j) * dil] = (unsigned short)(u[j] & 0xffffu); d[(2 * j + 1) * dil] = (unsigned short)(u[j] >> 16); }
     }
   }
 }
@@ -238,15 +244,16 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
   const int64_t img_in = (int64_t)q.C * q.H * q.W;
   NcvPre pre;
-  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, src + blockIdx.x * img_in, q, tid, nthreads);
+  const NcvPlan plan = ncv_stage_plan(q, tid, nthreads);
+  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, plan, src + blockIdx.x * img_in, tid, nthreads);
   for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
     __syncthreads();                                     // zero fill / the previous image's reads are done
     NCV_STAMP_ONCE(2);
-    if (q.pf) ncv_stage_store(xs, pre, q, tid, nthreads);
+    if (q.pf) ncv_stage_store(xs, pre, plan, q.dil);
     else ncv_stage(xs, src + n * img_in, q, tid, nthreads);
     __syncthreads();
     NCV_STAMP_ONCE(3);
-    if (q.pf && n + (int)gridDim.x < q.N) ncv_stage_load(pre, src + (n + (int)gridDim.x) * img_in, q, tid, nthreads);   // in flight during the MFMAs
+    if (q.pf && n + (int)gridDim.x < q.N) ncv_stage_load(pre, plan, src + (n + (int)gridDim.x) * img_in, tid, nthreads);   // in flight during the MFMAs
     bf16_t* yp = dst + (int64_t)n * q.CO * HoWo;
     for (int st = wid; st < nsuper; st += nwaves) {
       const int h0 = st * TR;
@@ -413,6 +420,7 @@ __global__ __launch_bounds__(256) void ncv_wgrad_kernel(const bf16_t* __restrict
 // ones, see ncv_fwd2_kernel).  Stride 2: even / odd column planes, filter column s reads plane (s - pw) & 1 at offset
 // (s - pw) >> 1 in {-1, 0} (KW <= 3).  acc[pair tile][s] holds dW[co][(ci, r)][s].
 constexpr int NCV_OFFA = 8;   // column origin of the staged rows (both strides): 16-byte aligned segments
+constexpr int NCV_WPF = 6;    // 16-byte packets per thread the image-group prefetch holds
 template <int KW, int PW, int SW, int NPT>
 __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial, NcvWGeom q,
                                                          int images_per_block) {
@@ -446,33 +454,79 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
 
   const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min<int64_t>(n0 + images_per_block, q.N);
   const int chunks_per_img = HoWo >> 5;
+  // Staging in two halves (as in ncv_fwd2_kernel): the x and dy packets of the NEXT image group are loaded into registers while this
+  // group is multiplied, and written to LDS after the barrier.  A group is [image][x packets | dy packets] of 16 bytes.
+  const int xpk = (q.Cin * q.H * q.W) >> 3, dpk = (q.Cout * HoWo) >> 3, per = xpk + dpk;
+  const int rc = q.W >> 3;
+  // a thread handles the same packets of every group: source offsets (elements, from the group's first image) and LDS destinations
+  // (elements from xs) are computed once; meta = image index within the group, or -1 (no packet)
+  const bool pf = q.IG * per <= NCV_WPF * 256;
+  uint4 pre[NCV_WPF];
+  int p_src[NCV_WPF], p_dst[NCV_WPF], p_im[NCV_WPF];
+#pragma unroll
+  for (int k = 0; k < NCV_WPF; k++) {
+    const int idx = tid + k * 256;
+    const int im = idx / per, j = idx - im * per;
+    p_im[k] = (pf && im < q.IG) ? im : -1;
+    if (j < xpk) {
+      const int b = j % rc, a = (j / rc) % q.H, c = j / (rc * q.H);
+      p_src[k] = im * q.Cin * q.H * q.W + j * 8;
+      p_dst[k] = im * ximg + (SW == 1 ? (c * q.Hs + q.ph + a) * q.Ws + NCV_OFFA + b * 8 : ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFFA + b * 4);
+    } else {
+      p_src[k] = -(im * q.Cout * HoWo + (j - xpk) * 8) - 1;          // negative: a dy packet
+      p_dst[k] = q.IG * ximg + im * 16 * HoWo + (j - xpk) * 8;
+    }
+  }
+  auto pre_load = [&](int64_t nb, int ig) {
+    const bf16_t* xg = x + nb * q.Cin * q.H * q.W;
+    const bf16_t* dg = dy + nb * q.Cout * HoWo;
+#pragma unroll
+    for (int k = 0; k < NCV_WPF; k++)
+      if (p_im[k] >= 0 && p_im[k] < ig) {
+        const bf16_t* sp = p_src[k] >= 0 ? xg + p_src[k] : dg + (-p_src[k] - 1);
+        pre[k] = *reinterpret_cast<const uint4*>(sp);
+      }
+  };
+  auto stage_x = [&](unsigned short* dst, const uint4 v) {
+    if (SW == 1) {
+      *reinterpret_cast<uint4*>(dst) = v;
+    } else {
+      uint2 ev, od;
+      ev.x = (v.x & 0xffffu) | (v.y << 16); ev.y = (v.z & 0xffffu) | (v.w << 16);
+      od.x = (v.x >> 16) | (v.y & 0xffff0000u); od.y = (v.z >> 16) | (v.w & 0xffff0000u);
+      *reinterpret_cast<uint2*>(dst) = ev;
+      *reinterpret_cast<uint2*>(dst + q.Ws) = od;
+    }
+  };
+  auto pre_store = [&](int ig) {
+#pragma unroll
+    for (int k = 0; k < NCV_WPF; k++) {
+      if (p_im[k] < 0 || p_im[k] >= ig) continue;
+      const uint4 v = pre[k];
+      if (SW == 1 || p_src[k] < 0) *reinterpret_cast<uint4*>(xs + p_dst[k]) = v;      // stride 1 rows and dy packets: one 16-byte write
+      else stage_x(xs + p_dst[k], v);
+    }
+  };
+  auto x_dst = [&](unsigned short* xi, int j) {
+    const int b = j % rc, a = (j / rc) % q.H, c = j / (rc * q.H);
+    return xi + (SW == 1 ? (c * q.Hs + q.ph + a) * q.Ws + NCV_OFFA + b * 8 : ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFFA + b * 4);
+  };
+
+  if (pf && n0 < n1) pre_load(n0, (int)min<int64_t>(q.IG, n1 - n0));
   for (int64_t nb = n0; nb < n1; nb += q.IG) {
     const int ig = (int)min<int64_t>(q.IG, n1 - nb);
     __syncthreads();
-    for (int im = 0; im < ig; im++) {
+    if (pf) pre_store(ig);
+    else for (int im = 0; im < ig; im++) {
       const bf16_t* xp = x + (nb + im) * q.Cin * q.H * q.W;
       unsigned short* xi = xs + im * ximg;
-      const int rc = q.W >> 3, total = q.Cin * q.H * rc;
-      for (int i = tid; i < total; i += 256) {
-        const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
-        const uint4 v = *reinterpret_cast<const uint4*>(xp + (c * q.H + a) * q.W + b * 8);
-        if (SW == 1) {
-          *reinterpret_cast<uint4*>(xi + (c * q.Hs + q.ph + a) * q.Ws + NCV_OFFA + b * 8) = v;
-        } else {
-          uint2 ev, od;
-          ev.x = (v.x & 0xffffu) | (v.y << 16); ev.y = (v.z & 0xffffu) | (v.w << 16);
-          od.x = (v.x >> 16) | (v.y & 0xffff0000u); od.y = (v.z >> 16) | (v.w & 0xffff0000u);
-          unsigned short* row = xi + ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFFA + b * 4;
-          *reinterpret_cast<uint2*>(row) = ev;
-          *reinterpret_cast<uint2*>(row + q.Ws) = od;
-        }
-      }
+      for (int i = tid; i < xpk; i += 256) stage_x(x_dst(xi, i), *reinterpret_cast<const uint4*>(xp + i * 8));
       const bf16_t* dp = dy + (nb + im) * q.Cout * HoWo;
       unsigned short* di = ds + im * 16 * HoWo;
-      const int dtot = q.Cout * HoWo >> 3;
-      for (int i = tid; i < dtot; i += 256) *reinterpret_cast<uint4*>(di + i * 8) = *reinterpret_cast<const uint4*>(dp + i * 8);
+      for (int i = tid; i < dpk; i += 256) *reinterpret_cast<uint4*>(di + i * 8) = *reinterpret_cast<const uint4*>(dp + i * 8);
     }
     __syncthreads();
+    if (pf && nb + q.IG < n1) pre_load(nb + q.IG, (int)min<int64_t>(q.IG, n1 - nb - q.IG));      // in flight during the MFMAs
     const int nchunks = ig * chunks_per_img;
     for (int ch = wid; ch < nchunks; ch += 4) {
       const int pg = ch * 32 + (lane >> 4) * 8;
@@ -700,17 +754,16 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0};
   Hold wpk_h(ncv_packed_weights(w, wq, st));
   const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
-  static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2 (each workgroup gathers its weight fragments once)
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
-  const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
-  KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
+  static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2
+  const int lds_per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
   const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
   if (aligned) {
     const int nsuper = q.Ho / (16 / ncg);
     const int threads = 64 * std::min(4, nsuper);
     q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
-#define NCV_F2(NKv, SWv, PHv) hipLaunchKernelGGL((ncv_fwd2_kernel<NKv, SWv, PHv>), dim3(blocks), dim3(threads), lds, st, in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q)
+    const void* kfn = nullptr;
+#define NCV_F2(NKv, SWv, PHv) kfn = (const void*)ncv_fwd2_kernel<NKv, SWv, PHv>
 #define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
 #define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
     switch (NK2) {
@@ -722,9 +775,19 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
 #undef NCV_F2_SW
 #undef NCV_F2_PH
 #undef NCV_F2
+    // persistent grid: as many workgroups as are really co-resident (registers and LDS), each walks a strided range of images
+    const int per_cu = std::min(lds_per_cu, kernel_occupancy(kfn, threads, lds));
+    const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
+    KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
+    const bf16_t* srcp = in->ptr<bf16_t>();
+    bf16_t* dstp = out->ptr<bf16_t>();
+    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q};
+    HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
     return true;
   }
+  const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * lds_per_cu);
+  KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
   switch (NK) {
     case 1: ncv_launch<1>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
     case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
@@ -779,7 +842,18 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
     const size_t lds2 = (size_t)q.IG * (ximg2 + 16 * HoWo) * 2 + (size_t)4 * 16 * ncolt * 4;
     if (lds2 <= 150 * 1024) {
       const int O = q.Cout * q.ncol;
-      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds2));
+      const void* kfn = nullptr;
+#define NCV_WG2(KWv, PWv, SWv, NPTv) kfn = (const void*)ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>
+#define NCV_WG2_NPT(KWv, PWv, SWv) do { if (npt == 1) NCV_WG2(KWv, PWv, SWv, 1); else if (npt == 2) NCV_WG2(KWv, PWv, SWv, 2); else NCV_WG2(KWv, PWv, SWv, 3); } while (0)
+      if (g.kw == 5) NCV_WG2_NPT(5, 2, 1);
+      else if (g.kw == 3 && SW == 1) NCV_WG2_NPT(3, 1, 1);
+      else if (g.kw == 3) NCV_WG2_NPT(3, 1, 2);
+      else if (SW == 1) NCV_WG2_NPT(1, 0, 1);
+      else NCV_WG2_NPT(1, 0, 2);
+#undef NCV_WG2_NPT
+#undef NCV_WG2
+      allow_big_lds(kfn);
+      const int per_cu = std::min((int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds2)), kernel_occupancy(kfn, 256, lds2));
       const int64_t rounds = (g.N + q.IG - 1) / q.IG;
       const int nb = (int)std::min<int64_t>(rounds, (int64_t)num_cus() * per_cu);
       const int ipb = (int)((rounds + nb - 1) / nb) * q.IG;
@@ -789,20 +863,9 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
       {
         KernelTimer kt("conv_wgrad_narrow", conv_flops(g), conv_bytes(g, 2), st);
         const bf16_t* dp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
-#define NCV_WG2(KWv, PWv, SWv, NPTv)                                                                                                   \
-  do {                                                                                                                                 \
-    static bool attr = false;                                                                                                          \
-    allow_big_lds((const void*)ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>); \
-    hipLaunchKernelGGL((ncv_wgrad2_kernel<KWv, PWv, SWv, NPTv>), dim3(nblocks), dim3(256), lds2, st, dp, xp, pp, q, ipb);               \
-  } while (0)
-#define NCV_WG2_NPT(KWv, PWv, SWv) do { if (npt == 1) NCV_WG2(KWv, PWv, SWv, 1); else if (npt == 2) NCV_WG2(KWv, PWv, SWv, 2); else NCV_WG2(KWv, PWv, SWv, 3); } while (0)
-        if (g.kw == 5) NCV_WG2_NPT(5, 2, 1);
-        else if (g.kw == 3 && SW == 1) NCV_WG2_NPT(3, 1, 1);
-        else if (g.kw == 3) NCV_WG2_NPT(3, 1, 2);
-        else if (SW == 1) NCV_WG2_NPT(1, 0, 1);
-        else NCV_WG2_NPT(1, 0, 2);
-#undef NCV_WG2_NPT
-#undef NCV_WG2
+        int ipb_arg = ipb;
+        void* args[] = {(void*)&dp, (void*)&xp, (void*)&pp, (void*)&q, (void*)&ipb_arg};
+        HIP_CHECK(hipLaunchKernel(kfn, dim3(nblocks), dim3(256), args, lds2, st));
         LAMP_LAUNCH_CHECK();
       }
       WgradReduceArgs ra{};
