@@ -56,20 +56,26 @@ constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligne
 // workgroup's prologue is NK 16-byte loads per lane.  Gathering them per lane from the filter tensor (8 two-byte loads and two
 // integer divisions per k-step) took 5.5 - 6.5 k of the ~22 k cycles a workgroup lives (scripts/ncv_stamp_probe.py).
 constexpr int NCV_NKMAX = 12;
+// ns = 2 ("two-shift" images, for at most 8 output channels and kw + sw <= 8): MFMA column n = 8*s + co carries the filter of
+// channel co moved s*sw taps to the right inside the 8-wide window, i.e. ONE MFMA produces the output pixels of two neighbouring
+// window phases - half the MFMAs (and half the funnel shifts) per output pixel; the 6-channel layers used 6 of 16 columns before.
 struct NcvW {
   const bf16_t* w;
   int Cout, Cin, kh, kw, dgrad;
+  int ns, sw;            // shifts per MFMA (1 or 2) and the window stride between them
 };
 __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
-  const int co = lane & 15, pair = ks * 4 + (lane >> 4);
+  const int n = lane & 15, pair = ks * 4 + (lane >> 4);
+  const int co = wq.ns == 2 ? (n & 7) : n, shift = wq.ns == 2 ? (n >> 3) * wq.sw : 0;
   const int c = pair / wq.kh, r = pair - c * wq.kh;
   nv_s8 v;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     unsigned short e = 0;
-    if (j < wq.kw) {
-      if (!wq.dgrad) { if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + j].bits; }
-      else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - j)].bits; }
+    const int t = j - shift;                  // filter column
+    if (t >= 0 && t < wq.kw) {
+      if (!wq.dgrad) { if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + t].bits; }
+      else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - t)].bits; }
     }
     v[j] = (short)e;
   }
@@ -210,16 +216,18 @@ __device__ unsigned long long ncv_stamps[1024 * 8];
 #define NCV_STAMP_AT(k) do { } while (0)
 #define NCV_STAMP_ONCE(k) do { } while (0)
 #endif
-template <int NK, int SW, int PH0>
+//   NS = shifts per MFMA (see NcvW): NS = 2 halves the P window phases an MFMA has to be issued for.
+template <int NK, int SW, int PH0, int NS>
 __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
                                                        bf16_t* __restrict__ dst, NcvGeom q) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
   NCV_STAMP_AT(0);
   constexpr int P = 8 / SW;
-  constexpr int NSEG = (PH0 + (P - 1) * SW + 7) < 16 ? 2 : 3;
+  constexpr int ND = P / NS;                               // accumulators (MFMAs per k-step) of a super-tile
+  constexpr int NSEG = (PH0 + (ND - 1) * NS * SW + 7) < 16 ? 2 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
-  const int co = lane & 15;
+  const int co = NS == 2 ? (lane & 7) : (lane & 15);
   const int ncg = q.Wo / P, TR = 16 / ncg;
   nv_bf8 wfr[NK];
   int koff[NK];
@@ -258,9 +266,9 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
     for (int st = wid; st < nsuper; st += nwaves) {
       const int h0 = st * TR;
       const char* base = smem + a_off + h0 * q.sh * q.Ws * 2;
-      nv_f4 acc[P];
+      nv_f4 acc[ND];
 #pragma unroll
-      for (int d = 0; d < P; d++) acc[d] = nv_f4{0.f, 0.f, 0.f, 0.f};
+      for (int d = 0; d < ND; d++) acc[d] = nv_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NK; ks++) {
         unsigned int sg[NSEG * 4 + 1];
@@ -271,9 +279,8 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
         }
         sg[NSEG * 4] = 0;
 #pragma unroll
-        for (int d = 0; d < P; d++) {
-          constexpr int dummy = 0; (void)dummy;
-          const int o = PH0 + d * SW;                      // compile-time after unrolling
+        for (int d = 0; d < ND; d++) {
+          const int o = PH0 + d * NS * SW;                 // compile-time after unrolling: window origin of phase d * NS
           const int dq = o >> 1;
           unsigned int f[4];
 #pragma unroll
@@ -283,20 +290,51 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
           acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, fv), wfr[ks], acc[d], 0, 0, 0);
         }
       }
-      if (co < q.CO) {
+      if (NS == 1) {
+        if (co < q.CO) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int i = (lane >> 4) * 4 + rr;
-          const int tr = i / ncg, cg = i - tr * ncg;
-          bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
-          unsigned int pk[P / 2];
+          for (int rr = 0; rr < 4; rr++) {
+            const int i = (lane >> 4) * 4 + rr;
+            const int tr = i / ncg, cg = i - tr * ncg;
+            bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
+            unsigned int pk[P / 2];
 #pragma unroll
-          for (int d = 0; d < P; d += 2) {
-            const bf16_t lo(acc[d][rr] + bv), hi(acc[d + 1][rr] + bv);
-            pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+            for (int d = 0; d < P; d += 2) {
+              const bf16_t lo(acc[d % ND][rr] + bv), hi(acc[(d + 1) % ND][rr] + bv);
+              pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+            }
+            if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
+            else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
           }
-          if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
-          else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+        }
+      } else {
+        // lane (s, co, g) holds phases 2d + s of rows 4g .. 4g+3; its partner lane ^ 8 holds the other parity.  The s = 0 lane
+        // completes rows 4g, 4g+1 and the s = 1 lane rows 4g+2, 4g+3: each sends the two rows it does not store.
+        const int sft = (lane >> 3) & 1;
+        unsigned int keep[2][ND], got[2][ND];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int d = 0; d < ND; d++) {
+            const bf16_t mine(acc[d][sft * 2 + h] + bv), theirs(acc[d][(1 - sft) * 2 + h] + bv);    // rows this lane stores / sends
+            keep[h][d] = mine.bits;
+            got[h][d] = (unsigned)__shfl_xor((int)theirs.bits, 8, 64);
+          }
+        if (co < q.CO) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int i = (lane >> 4) * 4 + sft * 2 + h;
+            const int tr = i / ncg, cg = i - tr * ncg;
+            bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
+            unsigned int pk[ND];
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+              const unsigned int even = sft ? got[h][d] : keep[h][d], odd = sft ? keep[h][d] : got[h][d];
+              pk[d] = even | (odd << 16);
+            }
+            if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % ND], pk[3 % ND]);
+            else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+          }
         }
       }
     }
@@ -627,9 +665,9 @@ static void ncv_launch(const bf16_t* src, const nv_bf8* wpk, const bf16_t* bias,
 // as the implicit-GEMM images (conv_igemm.hip, "packed-weight cache"); LAMP_PACK_CACHE=0 disables it.
 namespace {
 struct NcvPackKey {
-  uint64_t uid; int64_t offset; int Cout, Cin, kh, kw, dgrad; hipStream_t st;
+  uint64_t uid; int64_t offset; int Cout, Cin, kh, kw, dgrad, ns, sw; hipStream_t st;
   bool operator<(const NcvPackKey& o) const {
-    return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, st) < std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.st);
+    return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, ns, sw, st) < std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.ns, o.sw, o.st);
   }
 };
 struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; };
@@ -648,7 +686,7 @@ static void ncv_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) {
 static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st) {
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
   const bool cacheable = cache_on && w->st->owned;
-  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, st};
+  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns, wq.sw, st};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
   if (cacheable) {
     std::lock_guard<std::mutex> lk(g_ncv_mu);
@@ -701,7 +739,7 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
       const NcvPackKey& k = kv.first;
       if (k.uid != w->st->uid || k.offset != w->offset || k.st != st) continue;
       if (k.Cout != (int)w->sizes[0] || k.Cin != (int)w->sizes[1] || k.kh != (int)w->sizes[2] || k.kw != (int)w->sizes[3]) continue;
-      a.w[cnt] = NcvW{w->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad};
+      a.w[cnt] = NcvW{w->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw};
       a.dst[cnt] = static_cast<nv_bf8*>(kv.second.packed->raw());
       done.push_back({k, w->st->version.load(std::memory_order_relaxed)});
       if (++cnt == NCV_PACK_MAX) flush();
@@ -751,7 +789,10 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   if (!NK) return false;
   const size_t lds = (size_t)q.C * q.Hs * q.Ws * 2;
   if (lds > 64 * 1024) return false;
-  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0};
+  // two output phases per MFMA where the columns allow it (see NcvW)
+  static const bool two_shift_on = [] { const char* e = getenv("LAMP_NCV_TWO_SHIFT"); return !(e && e[0] == '0'); }();
+  const int NS = (two_shift_on && aligned && q.CO <= 8 && g.kw + q.sw <= 8) ? 2 : 1;
+  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw};
   Hold wpk_h(ncv_packed_weights(w, wq, st));
   const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
   static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2
@@ -763,7 +804,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
     const void* kfn = nullptr;
-#define NCV_F2(NKv, SWv, PHv) kfn = (const void*)ncv_fwd2_kernel<NKv, SWv, PHv>
+#define NCV_F2(NKv, SWv, PHv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1>
 #define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
 #define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
     switch (NK2) {

@@ -726,45 +726,91 @@ def test_allocation_registry(gpu):
     assert S.live_tensor_count() == n0
 
 
-def test_igemm_pack_cache_sees_every_weight_write(gpu):
-    """The implicit-GEMM convolutions cache their packed weights per storage version.  Every way of changing the weights must
-    invalidate it: in-place arithmetic, copy_, a write through a view, a host upload, the optimiser."""
+@pytest.mark.parametrize("cin,cout,hw,stride", [(128, 128, 8, 1), (6, 6, 16, 1), (6, 16, 16, 2), (3, 6, 32, 1)])
+def test_igemm_pack_cache_sees_every_weight_write(gpu, cin, cout, hw, stride):
+    """The implicit-GEMM and the narrow convolutions cache their packed weights (fprop and dgrad images) per storage version.
+    Every way of changing the weights must invalidate them: in-place arithmetic, copy_, a write through a view, a host upload,
+    the optimiser (which re-packs the cached images itself, in place)."""
     from lamp_amd import nn as NN
     dt = torch.bfloat16
-    x = closed_form((4, 128, 8, 8), 3, 2.0, dt)
-    w0 = closed_form((128, 128, 3, 3), 17, 1.0, dt)
-    b = torch.zeros(128, dtype=dt)
+    k = 5 if cin == 3 else 3
+    pad = k // 2
+    x = closed_form((4, cin, hw, hw), 3, 2.0, dt)
+    w0 = closed_form((cout, cin, k, k), 17, 1.0, dt)
+    b = torch.zeros(cout, dtype=dt)
     X, Bt = to_sten(x), to_sten(b)
     W = to_sten(w0)
+    ho = (hw + 2 * pad - k) // stride + 1
+    gy = closed_form((4, cout, ho, ho), 23, 1.0, dt)
+    GY = to_sten(gy)
 
     def conv(Wt):
         o = C.c_void_p()
-        lib.lamp_convolution(C.byref(o), X, Wt, Bt, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
+        lib.lamp_convolution(C.byref(o), X, Wt, Bt, i64_array([stride, stride]), i64_array([pad, pad]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
         return to_torch(S.STen(o))
 
+    def dgrad(Wt):
+        out3 = (C.c_void_p * 3)()
+        mask = (C.c_uint8 * 3)(1, 0, 0)
+        lib.lamp_convolution_backward(out3, GY, X, Wt, i64_array([stride, stride]), i64_array([pad, pad]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1, mask)
+        return to_torch(S.STen(out3[0]))
+
     def check(w_now, what):
-        ref = aten.convolution(x, w_now, b, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        ref = aten.convolution(x, w_now, b, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
         assert_close(conv(W), ref.double(), 1.6e-2, what)
+        gx = aten.convolution_backward(gy.float(), x.float(), w_now.float(), [0], [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        assert_close(dgrad(W), gx.double(), 1.6e-2, what + " (dgrad)")
 
     check(w0, "first call")
     check(w0, "cached call")
     lib.lamp_mul_scalar_(W, 0.5)
     check(to_torch(W).to(dt), "after mul_scalar_")
-    w1 = closed_form((128, 128, 3, 3), 5, 1.0, dt)
+    w1 = closed_form((cout, cin, k, k), 5, 1.0, dt)
     lib.lamp_copy_(W, to_sten(w1), 0)
     check(w1, "after copy_")
     W.select(0, 3).fill_(0.25)                              # write through a view of the same storage
     w2 = w1.clone(); w2[3] = 0.25
     check(w2, "after a view write")
-    w3 = closed_form((128, 128, 3, 3), 9, 1.0, dt)
+    w3 = closed_form((cout, cin, k, k), 9, 1.0, dt)
     W2 = to_sten(w3)                                        # a different tensor with different contents
-    ref3 = aten.convolution(x, w3, b, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    ref3 = aten.convolution(x, w3, b, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
     assert_close(conv(W2), ref3.double(), 1.6e-2, "another weight tensor")
     # the optimiser: one SGD step changes W, the next convolution must use the new values
-    g = S.STen.ones([128, 128, 3, 3], S.BF16, 0)
+    g = S.STen.ones([cout, cin, k, k], S.BF16, 0)
     opt = NN.SGDW([W], 0.5, 0.0)
     opt.step([g], 1.0)
     check(to_torch(W).to(dt), "after the optimiser step")
+    opt.step([g], 1.0)
+    check(to_torch(W).to(dt), "after a second optimiser step (images re-packed in place)")
+
+
+def test_weight_gradient_reductions_are_deferred_and_batched(gpu):
+    """The reductions of the bf16 convolutions' weight-gradient partial sums are registered and run in ONE launch at
+    lamp_flush_deferred (end of backprop) or when anything asks for the tensor (here: the copy to the host).  Results are those of
+    ATen within bf16 tolerance and identical whether a flush came first or the access triggered it."""
+    dt = torch.bfloat16
+    cases = [(128, 128, 8, 3), (6, 6, 16, 3), (16, 128, 8, 1)]
+    refs, got_access, got_flush = [], [], []
+    for rnd in range(2):
+        handles = []
+        for (cin, cout, hw, k) in cases:
+            x = closed_form((8, cin, hw, hw), 3, 2.0, dt)
+            w = closed_form((cout, cin, k, k), 17, 1.0, dt)
+            gy = closed_form((8, cout, hw, hw), 23, 1.0, dt)
+            out3 = (C.c_void_p * 3)()
+            mask = (C.c_uint8 * 3)(0, 1, 0)
+            lib.lamp_convolution_backward(out3, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([k // 2, k // 2]), i64_array([1, 1]), 2, 0,
+                                          i64_array([0, 0]), 1, mask)
+            handles.append(S.STen(out3[1]))
+            if rnd == 0:
+                refs.append(aten.convolution_backward(gy.float(), x.float(), w.float(), [0], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                      [False, True, False])[1])
+        if rnd == 1:
+            lib.lamp_flush_deferred()
+        (got_flush if rnd == 1 else got_access).extend(to_torch(h) for h in handles)
+    for r, a, f in zip(refs, got_access, got_flush):
+        assert_close(a, r.double(), 1.6e-2, "deferred weight gradient")
+        assert torch.equal(a, f)
 
 
 @pytest.mark.parametrize("cin,cout,k", [(128, 128, 3), (64, 64, 3), (32, 64, 1), (128, 100, 3)])
