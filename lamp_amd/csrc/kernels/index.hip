@@ -9,6 +9,7 @@
 // RNG is Philox4x32-10 keyed by (seed, per-call offset); bit compatibility with libtorch's
 // streams is not required by any reference test.
 #include "device_utils.h"
+#include <cstring>
 #include "../core/strided.h"
 
 namespace lamp {
@@ -503,6 +504,29 @@ extern "C" {
 
 int lamp_index_select(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index) {
   LAMP_API_BEGIN
+  if (a && !a->is_device()) {
+    // lamp's CPU device: BatchStream gathers a minibatch of the host-resident data set into its pinned buffer
+    // (BatchStream.scala:540-573): a row copy per index on the host
+    LAMP_CHECK(index && !index->is_device() && index->dtype == kI64 && index->ndim <= 1, "index_select on a host tensor needs a host int64 index vector");
+    Hold ac(contiguous(a)), ic(contiguous(index));
+    int64_t outer, D, inner;
+    split3(a, dim, outer, D, inner);
+    const int64_t J = index->numel();
+    std::vector<int64_t> oshape = a->shape();
+    if (a->ndim) oshape[wrap_dim(dim, a->ndim)] = J;
+    Hold r(new_tensor(oshape, a->dtype, -1));
+    const size_t row = (size_t)inner * a->itemsize();
+    const char* src = static_cast<const char*>(static_cast<const Tensor*>(ac.get())->raw());
+    char* dst = static_cast<char*>(r->data());
+    const int64_t* ix = static_cast<const Tensor*>(ic.get())->ptr<int64_t>();
+    for (int64_t o = 0; o < outer; o++)
+      for (int64_t j = 0; j < J; j++) {
+        LAMP_CHECK(ix[j] >= 0 && ix[j] < D, "index_select: index " << ix[j] << " out of range for a dimension of size " << D);
+        memcpy(dst + ((size_t)o * J + j) * row, src + ((size_t)o * D + ix[j]) * row, row);
+      }
+    *out = r.take();
+    return 0;
+  }
   check_device_tensor(a, "self"); check_index(index);
   Hold ac(contiguous(a)), ic(contiguous(index));
   int64_t outer, D, inner;

@@ -69,3 +69,20 @@ def test_host_and_device_tensors_do_not_mix_and_gpu_only_ops_say_so():
         lib.lamp_convolution(C.byref(o), a, w, None, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
     with pytest.raises(LampError, match="host tensor"):
         lib.lamp_log_softmax(C.byref(o), a, 1)
+
+
+def test_host_index_select_gathers_a_minibatch():
+    """BatchStream.minibatchesFromFull gathers rows of the host-resident data set into its pinned buffer (BatchStream.scala:540-573)"""
+    import numpy as np
+    from lamp_amd import sten as S
+    from lamp_amd import _capi
+    a = np.arange(5 * 3 * 4, dtype=np.float32).reshape(5, 3, 4)
+    idx = np.array([4, 0, 0, 2], dtype=np.int64)
+    t, ix = S.STen.from_numpy(a, device=S.CPU), S.STen.from_numpy(idx, device=S.CPU)
+    assert np.array_equal(t.indexSelect(0, ix).to_numpy(), a[idx])
+    ix1 = S.STen.from_numpy(np.array([2, 1], dtype=np.int64), device=S.CPU)
+    assert np.array_equal(t.indexSelect(1, ix1).to_numpy(), a[:, [2, 1]])
+    assert np.array_equal(t.transpose(0, 1).indexSelect(0, ix1).to_numpy(), a.transpose(1, 0, 2)[[2, 1]])
+    bad = S.STen.from_numpy(np.array([5], dtype=np.int64), device=S.CPU)
+    with pytest.raises(_capi.LampError, match="out of range"):
+        t.indexSelect(0, bad)
