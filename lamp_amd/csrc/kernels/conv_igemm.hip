@@ -715,8 +715,10 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   const int d_row = wid * 16 + (lane >> 2);
   const int d_src = d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3);
   auto stage_dma = [&](int kc1, int rs1, int slot) {
-    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
-    __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+    if (wid < NCT) {                          // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
+      const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+    }
   };
   IG_STAMP(0);
   stage_dma(0, 0, 0);
@@ -1237,7 +1239,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       // more than 64 output channels and enough images to give every CU a workgroup of eight: one workgroup per CU, wave = image x all
       // channels (LAMP_IG_VARIANT=d forces it for any batch, =b keeps the two-image kernel)
       const bool force_d = variant && variant[0] == 'd';
-      if (CO > 64 && !(variant && variant[0] == 'b') && (force_d || g.N >= 4 * (int64_t)num_cus())) {
+      // ... and for narrow outputs too (NCT = 1 / 4 channel tiles per wave): the 16-channel layers of the ResNet (128 -> 16 dgrad,
+      // 16 -> 16) spent 16 - 30 us in the 64-row kernel multiplying padding; here they are bound by their image reads (LAMP_IG_SMALL_D=0: off)
+      static const bool small_d = [] { const char* e = getenv("LAMP_IG_SMALL_D"); return !(e && e[0] == '0'); }();
+      if ((CO > 64 || small_d) && !(variant && variant[0] == 'b') && (force_d || g.N >= 4 * (int64_t)num_cus())) {
         const int blocksd = (int)((g.N + 7) / 8);
         // 3 weight slots + the 32-channel image chunks (+ 9 spare pixels behind them for the taps of a 3x3 kernel) - and at least the
         // 8 x 16 KiB the epilogue stages the output through
@@ -1248,8 +1253,8 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
     hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
                        (int)g.N, CI, KP, CO, statp);                                                                                       \
   } while (0)
-        if (KS == 3) { if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
-        else { if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
+        if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
+        else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
 #undef IG_LAUNCH_D
         LAMP_LAUNCH_CHECK();
         return;
