@@ -1017,9 +1017,10 @@ constexpr int WG_CI = 32;                         // input channels per workgrou
 constexpr int WG_XCH = 176;                       // bytes per channel in one shifted copy (11 x 16)
 constexpr int WG_XCOPY = WG_CI * WG_XCH;          // 5632
 constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies (+ pad to keep stages 16-B aligned) = 33,792
-template <int KS>
+// NARROW: some 16-channel tiles hold only padding and are not written (see tile_active)
+template <int KS, bool NARROW>
 __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                          int N, int CO, int CI, int CIP, int images_per_split) {
+                                                          int N, int CO, int CI, int CIP, int images_per_split, int COP) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -1051,6 +1052,14 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
   for (int t = 0; t < RS; t++)
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+  // Narrow layers (at most 64 output or 16 input channels): output-channel tiles at or beyond COP = round16(CO) and the second
+  // 16-column half when CIP = 16 hold only padding - they are not written, and the partial sums are [COP][CIP] per tap instead of
+  // [128][32] (16 -> 16: 2.4 MB of partials per launch instead of 37.7 MB).  They ARE still multiplied: uniform branches inside the
+  // MFMA chain made the kernel 25 - 50 % slower (measured), and skipping the tiles did not make the narrow layers faster either
+  const bool col_active = ci0 + wc * 16 < CIP;
+  bool tile_active[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) tile_active[i] = col_active && (wr * 64 + i * 16 < COP);
 
   uint4 ra[4], rx;
   if (nbeg < nend) {
@@ -1090,16 +1099,18 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     }
     __syncthreads();
   }
-  // partial[(split * RS + t)][co][CIP]
+  // partial[(split * RS + t)][COP][CIP]
 #pragma unroll
   for (int t = 0; t < RS; t++) {
-    float* out = partial + (int64_t)(split * RS + t) * IG_M * CIP;
+    float* out = partial + (int64_t)(split * RS + t) * COP * CIP;
 #pragma unroll
     for (int i = 0; i < 4; i++)
+      if (!NARROW || tile_active[i]) {
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
-        out[co * CIP + ci] = acc[t][i][rr];
+        for (int rr = 0; rr < 4; rr++) {
+          const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+          out[co * CIP + ci] = acc[t][i][rr];
+        }
       }
   }
 }
@@ -1323,32 +1334,33 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
   {
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
-    const int CIP = ntile * WG_CI;
+    const int CIP = g.Cin <= 16 ? 16 : ntile * WG_CI;             // columns of a partial-sum tile (see tile_active in the kernel)
+    const bool narrow = g.Cout <= 64 || g.Cin <= 16;               // the NARROW instantiation (branches in the MFMA chain) only where it pays
+    const int COP = narrow ? (int)((g.Cout + 15) / 16) * 16 : IG_M;  // rows
     static const int wgs_per_cu = [] { const char* e = getenv("LAMP_WGRAD_WGS_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();
-    int target = std::max(1, (num_cus() * wgs_per_cu) / ntile);      // one workgroup per CU: half the partial-sum traffic of two, same speed
+    // one workgroup per CU: half the partial-sum traffic of two, same speed
+    static const int narrow_per_cu = [] { const char* e = getenv("LAMP_WGRAD_NARROW_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();   // measured: 2 and 3 are 1 % slower on the step
+    int target = std::max(1, (num_cus() * (narrow ? narrow_per_cu : wgs_per_cu)) / ntile);
     int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
     if (ips < 8 && g.N >= 8) ips = 8;
     const int nsplit = (int)((g.N + ips - 1) / ips);
-    int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
+    int64_t ps[1] = {(int64_t)nsplit * RS * COP * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
     const size_t lds = 2 * WG_STAGE;
     {
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      static bool a3 = false, a1 = false;
-      if (KS == 3) {
-        allow_big_lds((const void*)ig_wgrad8v2_kernel<3>);
-        hipLaunchKernelGGL((ig_wgrad8v2_kernel<3>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
-                           (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
-      } else {
-        allow_big_lds((const void*)ig_wgrad8v2_kernel<1>);
-        hipLaunchKernelGGL((ig_wgrad8v2_kernel<1>), dim3(ntile, nsplit), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(),
-                           (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips);
-      }
+      const void* kfn = KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true> : (const void*)ig_wgrad8v2_kernel<3, false>)
+                                : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true> : (const void*)ig_wgrad8v2_kernel<1, false>);
+      allow_big_lds(kfn);
+      const bf16_t* dyp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
+      int a_N = (int)g.N, a_CO = (int)g.Cout, a_CI = (int)g.Cin, a_CIP = CIP, a_ips = ips, a_COP = COP;
+      void* args[] = {(void*)&dyp, (void*)&xp, (void*)&pp, (void*)&a_N, (void*)&a_CO, (void*)&a_CI, (void*)&a_CIP, (void*)&a_ips, (void*)&a_COP};
+      HIP_CHECK(hipLaunchKernel(kfn, dim3(ntile, nsplit), dim3(256), args, lds, st));
       LAMP_LAUNCH_CHECK();
     }
-    const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
+    const int64_t cols = (int64_t)RS * COP * CIP / 4;
     WgradReduceArgs ra{};
-    ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
+    ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = COP; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
     return true;
   }

@@ -8,10 +8,10 @@
 namespace lamp {
 
 struct WgradReduceArgs {
-  int kind;                 // 0: implicit GEMM v2 layout [split][tap][128][CIP], 1: narrow layout [block][O]
+  int kind;                 // 0: implicit GEMM v2 layout [split][tap][COP][CIP], 1: narrow layout [block][O]
   const float* partial;
   bf16_t* dw;
-  int CO, CI, CIP, RS;      // kind 0
+  int CO, CI, CIP, COP, RS; // kind 0 (COP x CIP = the padded tile the kernel wrote per tap)
   int nsplit;               // kind 0: image ranges; kind 1: blocks
   int O;                    // kind 1: outputs
   int blocks;               // workgroups (256 threads) this reduction needs
@@ -20,7 +20,7 @@ struct WgradReduceArgs {
 // kind 0.  Thread (q, sg) sums float4 column q of this block over the splits sg, sg+8, ... (independent 16-byte loads in flight), the 8
 // split groups are then combined through LDS in a fixed order.
 __device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int block, float4 (*red)[32]) {
-  constexpr int M = 128;    // IG_M
+  const int M = a.COP;
   const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int64_t per_split = (int64_t)a.RS * M * a.CIP / 4;   // float4 elements of one split
   const int64_t col = (int64_t)block * 32 + q;
