@@ -161,6 +161,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when a communicator
+    # is created): from here on file descriptor 1 is stderr, and the line goes out through a private duplicate of the original stdout.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     if a.dry_launch:
         # the launch + rendezvous path without a GPU: every rank joins the control plane, receives rank 0's 128 id bytes, and the
@@ -173,7 +178,7 @@ def main():
         slowest = cp.all_reduce_max(float(rank))
         cp.barrier()
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "ranks": len(ranks), "rank_list": ranks, "max_rank": slowest, "n_gpus": a.gpus}))
+            print(json.dumps({"dry_launch": True, "ranks": len(ranks), "rank_list": ranks, "max_rank": slowest, "n_gpus": a.gpus}), file=line_out, flush=True)
         cp.close()
         return
 
@@ -364,6 +369,11 @@ def main():
             opt.step(captured_grads, 1.0)
             return units_per_step
         config["hip_graph"] = "forward + backprop replayed from a HIP graph, optimiser eager (--no-graph: eager step)"
+    if comm is not None and a.workload in ("resnet", "lm"):
+        # what a data-parallel run does before its first batch: rank 0's module + optimiser state on every rank (the replicas are already
+        # identical here - same seed - so this changes no value; it puts the broadcast path on the wire before the measurement)
+        model.sync_state(opt, comm, 0)
+        config["dp_state_sync"] = "module + optimiser state broadcast from rank 0 before the first step"
     for _ in range(a.warmup):
         step()
     # ---- timed region: EXACTLY K steps between barrier + device synchronize on both sides, no instrumentation inside (kernel timers
@@ -433,7 +443,7 @@ def main():
         top = sorted(class_rows, key=lambda r: -r["total_ms"])[:int(os.environ.get("LAMP_BENCH_TOP", "10"))]
         line["kernel_classes"] = [{"tag": r["tag"], "launches_per_step": r["launches"] / PROFILE_STEPS, "ms_per_step": r["total_ms"] / PROFILE_STEPS}
                                   for r in top]
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
     if comm is not None:
         lib.lamp_comm_destroy(comm)
     if dist is not None:
