@@ -1018,28 +1018,32 @@ constexpr int WG_XCH = 176;                       // bytes per channel in one sh
 constexpr int WG_XCOPY = WG_CI * WG_XCH;          // 5632
 constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies (+ pad to keep stages 16-B aligned) = 33,792
 // NARROW: some 16-channel tiles hold only padding and are not written (see tile_active)
-template <int KS, bool NARROW>
+// CIT = 32-channel slices of Cin one workgroup owns.  3x3: 1 (144 accumulator registers for the nine taps of one slice).  1x1: up to 4 -
+// the whole Cin - so that dY is read ONCE instead of once per slice (128 -> 100: 139 -> 60 MB per launch, 33 -> ~15 us).
+template <int KS, bool NARROW, int CIT>
 __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                           int N, int CO, int CI, int CIP, int images_per_split, int COP) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   const int tile = blockIdx.x, split = blockIdx.y;
-  const int ci0 = tile * WG_CI;
+  const int ci0 = tile * WG_CI * CIT;
+  constexpr int STAGE = IG_WTILE + (CIT > 1 ? CIT * WG_XCOPY : 3 * WG_XCOPY) + 512;   // dY tile + X copies; host: 2 * this
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
   // zero both stages once: the padding rows of the shifted copies are never written again
-  for (int o = tid * 16; o < 2 * WG_STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+  for (int o = tid * 16; o < 2 * STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
-  const int xci = tid >> 3, xh = tid & 7;          // this thread's (channel, image row) of the X tile
-  auto load_x = [&](int n) -> uint4 {
-    if (ci0 + xci < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
+  const int xci = tid >> 3, xh = tid & 7;          // this thread's (channel within a slice, image row) of the X tile
+  auto load_x = [&](int n, int ct) -> uint4 {
+    const int c = ci0 + ct * WG_CI + xci;
+    if (c < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + xh * 8);
     return make_uint4(0, 0, 0, 0);
   };
-  auto store_x = [&](char* stage, uint4 v) {
-    char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
+  auto store_x = [&](char* stage, uint4 v, int ct) {
+    char* xb = stage + IG_WTILE + (ct * WG_CI + xci) * WG_XCH + (xh + 1) * 16;
     if (KS == 1) { *reinterpret_cast<uint4*>(xb) = v; return; }
     // copy s holds out[w] = in[w + s - 1]
     *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
@@ -1047,11 +1051,13 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
   };
 
-  f4v acc[RS][4];
+  f4v acc[CIT][RS][4];
 #pragma unroll
-  for (int t = 0; t < RS; t++)
+  for (int ct = 0; ct < CIT; ct++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc[t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RS; t++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[ct][t][i] = f4v{0.f, 0.f, 0.f, 0.f};
   // Narrow layers (at most 64 output or 16 input channels): output-channel tiles at or beyond COP = round16(CO) and the second
   // 16-column half when CIP = 16 hold only padding - they are not written, and the partial sums are [COP][CIP] per tap instead of
   // [128][32] (16 -> 16: 2.4 MB of partials per launch instead of 37.7 MB).  They ARE still multiplied: uniform branches inside the
@@ -1061,21 +1067,24 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 #pragma unroll
   for (int i = 0; i < 4; i++) tile_active[i] = col_active && (wr * 64 + i * 16 < COP);
 
-  uint4 ra[4], rx;
+  uint4 ra[4], rx[CIT];
   if (nbeg < nend) {
     ig_stage_load_rows(ra, dy + (int64_t)nbeg * CO * 64, 64, 0, CO, 64, tid);
-    rx = load_x(nbeg);
+#pragma unroll
+    for (int ct = 0; ct < CIT; ct++) rx[ct] = load_x(nbeg, ct);
     ig_stage_store_rows(ra, smem, tid);
-    store_x(smem, rx);
+#pragma unroll
+    for (int ct = 0; ct < CIT; ct++) store_x(smem, rx[ct], ct);
   }
   __syncthreads();
   for (int n = nbeg; n < nend; n++) {
     const int cur = (n - nbeg) & 1;
     if (n + 1 < nend) {
       ig_stage_load_rows(ra, dy + (int64_t)(n + 1) * CO * 64, 64, 0, CO, 64, tid);
-      rx = load_x(n + 1);
+#pragma unroll
+      for (int ct = 0; ct < CIT; ct++) rx[ct] = load_x(n + 1, ct);
     }
-    const char* st = smem + cur * WG_STAGE;
+    const char* st = smem + cur * STAGE;
     const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -1084,18 +1093,21 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
       for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(st, wr * 64 + i * 16, ks, lane);
       const int h = 4 * ks + (lane >> 4);
 #pragma unroll
-      for (int t = 0; t < RS; t++) {
-        const int r = t / KS, s = t % KS;
-        s8v v = *reinterpret_cast<const s8v*>(xl + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
-        const bf8v fb = __builtin_bit_cast(bf8v, v);
+      for (int ct = 0; ct < CIT; ct++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i], 0, 0, 0);
-      }
+        for (int t = 0; t < RS; t++) {
+          const int r = t / KS, s = t % KS;
+          s8v v = *reinterpret_cast<const s8v*>(xl + ct * WG_CI * WG_XCH + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
+          const bf8v fb = __builtin_bit_cast(bf8v, v);
+#pragma unroll
+          for (int i = 0; i < 4; i++) acc[ct][t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][t][i], 0, 0, 0);
+        }
     }
     if (n + 1 < nend) {
-      char* nx = smem + (cur ^ 1) * WG_STAGE;
+      char* nx = smem + (cur ^ 1) * STAGE;
       ig_stage_store_rows(ra, nx, tid);
-      store_x(nx, rx);
+#pragma unroll
+      for (int ct = 0; ct < CIT; ct++) store_x(nx, rx[ct], ct);
     }
     __syncthreads();
   }
@@ -1104,14 +1116,16 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
   for (int t = 0; t < RS; t++) {
     float* out = partial + (int64_t)(split * RS + t) * COP * CIP;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (!NARROW || tile_active[i]) {
+    for (int ct = 0; ct < CIT; ct++)
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
-          out[co * CIP + ci] = acc[t][i][rr];
+      for (int i = 0; i < 4; i++)
+        if (!NARROW || tile_active[i]) {
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + ct * WG_CI + wc * 16 + (lane & 15);
+            out[co * CIP + ci] = acc[ct][t][i][rr];
+          }
         }
-      }
   }
 }
 // (the reduction of the v2 partial sums lives in wgrad_reduce.h: it runs batched with the other layers' reductions)
@@ -1333,8 +1347,10 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
   const int KS = g.kh, RS = KS * KS;
   {
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
-    const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
-    const int CIP = g.Cin <= 16 ? 16 : ntile * WG_CI;             // columns of a partial-sum tile (see tile_active in the kernel)
+    // 1x1 with more than one slice of Cin: one workgroup owns all of them (CIT = 4), dY is read once
+    const bool all_ci = KS == 1 && g.Cin > WG_CI;
+    const int ntile = all_ci ? 1 : (int)((g.Cin + WG_CI - 1) / WG_CI);
+    const int CIP = g.Cin <= 16 ? 16 : (all_ci ? 4 : ntile) * WG_CI;   // columns of a partial-sum tile (see tile_active in the kernel)
     const bool narrow = g.Cout <= 64 || g.Cin <= 16;               // the NARROW instantiation (branches in the MFMA chain) only where it pays
     const int COP = narrow ? (int)((g.Cout + 15) / 16) * 16 : IG_M;  // rows
     static const int wgs_per_cu = [] { const char* e = getenv("LAMP_WGRAD_WGS_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();
@@ -1346,11 +1362,12 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     const int nsplit = (int)((g.N + ips - 1) / ips);
     int64_t ps[1] = {(int64_t)nsplit * RS * COP * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
-    const size_t lds = 2 * WG_STAGE;
+    const size_t lds = all_ci ? 2 * (size_t)(IG_WTILE + 4 * WG_XCOPY + 512) : 2 * (size_t)WG_STAGE;
     {
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      const void* kfn = KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true> : (const void*)ig_wgrad8v2_kernel<3, false>)
-                                : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true> : (const void*)ig_wgrad8v2_kernel<1, false>);
+      const void* kfn = KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1> : (const void*)ig_wgrad8v2_kernel<3, false, 1>)
+                      : all_ci  ? (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 4> : (const void*)ig_wgrad8v2_kernel<1, false, 4>)
+                                : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 1> : (const void*)ig_wgrad8v2_kernel<1, false, 1>);
       allow_big_lds(kfn);
       const bf16_t* dyp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
       int a_N = (int)g.N, a_CO = (int)g.Cout, a_CI = (int)g.Cin, a_CIP = CIP, a_ips = ips, a_COP = COP;
