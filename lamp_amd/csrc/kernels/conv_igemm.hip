@@ -1022,11 +1022,20 @@ constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies 
 // the whole Cin - so that dY is read ONCE instead of once per slice (128 -> 100: 139 -> 60 MB per launch, 33 -> ~15 us).
 template <int KS, bool NARROW, int CIT>
 __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                          int N, int CO, int CI, int CIP, int images_per_split, int COP) {
+                                                          int N, int CO, int CI, int CIP, int images_per_split, int COP, int ntile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
-  const int tile = blockIdx.x, split = blockIdx.y;
+  // XCD-aware mapping: the ntile workgroups that read the SAME images' dY (one per Cin slice) get block ids that are equal modulo 8 -
+  // workgroups are dealt round-robin over the 8 XCDs - so they share one XCD's L2: dY comes from HBM once and from L2 ntile - 1
+  // times (3x3, 128 channels: 167 -> 67 MB of HBM reads per launch; the kernel was bound by those reads, not by the matrix cores)
+  const int nsplit = gridDim.x / ntile;
+  int tile, split;
+  {
+    const int b = blockIdx.x;
+    if ((nsplit & 7) == 0) { const int xcd = b & 7, slot = b >> 3; tile = slot % ntile; split = xcd + 8 * (slot / ntile); }
+    else { tile = b % ntile; split = b / ntile; }
+  }
   const int ci0 = tile * WG_CI * CIT;
   constexpr int STAGE = IG_WTILE + (CIT > 1 ? CIT * WG_XCOPY : 3 * WG_XCOPY) + 512;   // dY tile + X copies; host: 2 * this
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1370,9 +1379,9 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
                                 : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 1> : (const void*)ig_wgrad8v2_kernel<1, false, 1>);
       allow_big_lds(kfn);
       const bf16_t* dyp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
-      int a_N = (int)g.N, a_CO = (int)g.Cout, a_CI = (int)g.Cin, a_CIP = CIP, a_ips = ips, a_COP = COP;
-      void* args[] = {(void*)&dyp, (void*)&xp, (void*)&pp, (void*)&a_N, (void*)&a_CO, (void*)&a_CI, (void*)&a_CIP, (void*)&a_ips, (void*)&a_COP};
-      HIP_CHECK(hipLaunchKernel(kfn, dim3(ntile, nsplit), dim3(256), args, lds, st));
+      int a_N = (int)g.N, a_CO = (int)g.Cout, a_CI = (int)g.Cin, a_CIP = CIP, a_ips = ips, a_COP = COP, a_ntile = ntile;
+      void* args[] = {(void*)&dyp, (void*)&xp, (void*)&pp, (void*)&a_N, (void*)&a_CO, (void*)&a_CI, (void*)&a_CIP, (void*)&a_ips, (void*)&a_COP, (void*)&a_ntile};
+      HIP_CHECK(hipLaunchKernel(kfn, dim3(ntile * nsplit), dim3(256), args, lds, st));
       LAMP_LAUNCH_CHECK();
     }
     const int64_t cols = (int64_t)RS * COP * CIP / 4;
