@@ -1137,6 +1137,134 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
         }
   }
 }
+// ---- wgrad, 3x3, wide layers: eight waves per workgroup -------------------------------------------------------------------------
+// ig_wgrad8v2_kernel<3> runs ONE wave per SIMD (144 accumulator + ~100 other registers per lane, and the compiler fills the rest of
+// the file): rocprofv3 shows the matrix pipe 40 % busy, the waves 34 % of their time in s_waitcnt and the rest at the per-image
+// barrier, with nobody to fill the gaps; two workgroups per CU cannot co-reside (registers).  Here the same 128 co x 32 ci x 9 taps
+// tile is owned by EIGHT waves (32 co x 16 ci each: 72 accumulator registers, launch bound 512 => two waves per SIMD) that overlap
+// each other's stalls.  The X fragments are read by four instead of two waves (LDS reads per image 104 -> 176 KB, still under the
+// MFMA time); image ranges, partial sums and their reduction are exactly those of the v2 kernel.
+// (A 128 co x 64 ci tile per workgroup - dY read half as often - was 10 us faster on the class but doubles the partial sums for
+// a fixed number of workgroups: +15 us on the step through the reduction; removed.)
+__global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = 3, RS = 9, PAD = 1;
+  const int nsplit = gridDim.x / ntile;
+  int tile, split;
+  {                                                           // XCD-aware: the tiles of one image range share an L2 (see ig_wgrad8v2_kernel)
+    const int b = blockIdx.x;
+    if ((nsplit & 7) == 0) { const int xcd = b & 7, slot = b >> 3; tile = slot % ntile; split = xcd + 8 * (slot / ntile); }
+    else { tile = b % ntile; split = b / ntile; }
+  }
+  const int ci0 = tile * WG_CI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wid >> 1, wc = wid & 1;                      // 32-channel block of co, 16-channel half of ci
+  const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
+  for (int o = tid * 16; o < 4 * WG_STAGE; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
+  __syncthreads();
+
+  const bool xthread = tid < 256;
+  const int xci = (tid & 255) >> 3, xh = tid & 7;             // (channel, image row) of the X tile: threads 0..255
+  auto load_x = [&](int n) -> uint4 {
+    if (xthread && ci0 + xci < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto store_x = [&](char* stage, uint4 v) {                  // copy s holds out[w] = in[w + s - 1]
+    if (!xthread) return;
+    char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
+    *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
+    *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
+    *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
+  };
+  // dY tile [128 co][64 px]: 1024 16-byte packets, two per thread
+  auto load_dy = [&](uint4 (&r)[2], int n) {
+    const bf16_t* base = dy + (int64_t)n * CO * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + i * 512, gr = c >> 3;
+      r[i] = gr < CO ? *reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3)) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_dy = [&](const uint4 (&r)[2], char* stage) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int c = tid + i * 512; *reinterpret_cast<uint4*>(stage + ig_kc_off(c >> 3, c & 7)) = r[i]; }
+  };
+
+  f4v acc[RS][2];
+#pragma unroll
+  for (int t = 0; t < RS; t++)
+#pragma unroll
+    for (int i = 0; i < 2; i++) acc[t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  // Image PAIRS: an LDS stage holds two images, and per pair the loop is
+  //     LDS-store the NEXT pair (its registers were requested one pair ago)  ->  request the pair after that  ->  multiply THIS pair  ->  barrier
+  // so the LDS stores and the global-load latency run under the MFMAs of two images and there is one barrier per two images.
+  // In-kernel s_memtime stamps of the one-image-per-barrier loop (a temporary diagnostic build) showed 2519 cycles per image:
+  // 1060 multiplying (the matrix pipe's share), 546 storing, 482 at the barrier, 430 issuing loads - every wave in the same phase
+  // at the same time, so the matrix pipe idled 58 % of the loop.  (The barrier is a raw s_barrier behind lgkmcnt(0): __syncthreads()
+  // would drain vmcnt and with it the prefetch.)
+  auto compute = [&](const char* st) {
+    const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf8v fa[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) fa[i] = ig_frag_rows(st, wq * 32 + i * 16, ks, lane);
+      const int h = 4 * ks + (lane >> 4);
+#pragma unroll
+      for (int t = 0; t < RS; t++) {
+        const int r = t / KS, s = t % KS;
+        s8v v = *reinterpret_cast<const s8v*>(xl + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
+        const bf8v fb = __builtin_bit_cast(bf8v, v);
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i], 0, 0, 0);
+      }
+    }
+  };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+  // images at or beyond nend load as zeros (an odd image count: the missing partner contributes nothing)
+  auto load_pair = [&](uint4 (&ra_)[2][2], uint4 (&rx_)[2], int n) {
+#pragma unroll
+    for (int im = 0; im < 2; im++) {
+      if (n + im < nend) { load_dy(ra_[im], n + im); rx_[im] = load_x(n + im); }
+      else { ra_[im][0] = ra_[im][1] = make_uint4(0, 0, 0, 0); rx_[im] = make_uint4(0, 0, 0, 0); }
+    }
+  };
+  auto store_pair = [&](const uint4 (&ra_)[2][2], const uint4 (&rx_)[2], char* stage) {
+#pragma unroll
+    for (int im = 0; im < 2; im++) { store_dy(ra_[im], stage + im * WG_STAGE); store_x(stage + im * WG_STAGE, rx_[im]); }
+  };
+  uint4 ra[2][2], rx[2];
+  if (nbeg < nend) {
+    load_pair(ra, rx, nbeg);
+    store_pair(ra, rx, smem);
+    if (nbeg + 2 < nend) load_pair(ra, rx, nbeg + 2);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int n = nbeg; n < nend; n += 2, cur ^= 1) {
+    char* st = smem + cur * (2 * WG_STAGE);
+    if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * WG_STAGE));      // nobody reads that stage since the last barrier
+    if (n + 4 < nend) load_pair(ra, rx, n + 4);
+    compute(st);
+    compute(st + WG_STAGE);
+    lds_barrier();
+  }
+  // partial[(split * RS + t)][128][CIP]
+#pragma unroll
+  for (int t = 0; t < RS; t++) {
+    float* out = partial + (int64_t)(split * RS + t) * IG_M * CIP;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int co = wq * 32 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+        out[co * CIP + ci] = acc[t][i][rr];
+      }
+  }
+}
 // (the reduction of the v2 partial sums lives in wgrad_reduce.h: it runs batched with the other layers' reductions)
 
 // ---- host ---------------------------------------------------------------------------------------------
@@ -1354,6 +1482,31 @@ bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvG
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
   if (!ig_qualifies(g, x->dtype)) return false;
   const int KS = g.kh, RS = KS * KS;
+  static const bool wide_on = [] { const char* e = getenv("LAMP_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+  if (wide_on && KS == 3 && g.Cin > WG_CI && g.Cout > 64) {
+    // eight-wave kernel: the v2 decomposition (32-channel slice of Cin, image range) with two waves per SIMD
+    const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
+    const int CIP = ntile * WG_CI;
+    int target = std::max(1, num_cus() / ntile);
+    int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
+    if (ips < 8 && g.N >= 8) ips = 8;
+    const int nsplit = (int)((g.N + ips - 1) / ips);
+    int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
+    Hold partial(new_tensor(ps, 1, kF32, x->device()));
+    const size_t lds = 4 * (size_t)WG_STAGE;
+    {
+      KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
+      allow_big_lds((const void*)ig_wgrad8h_kernel);
+      hipLaunchKernelGGL(ig_wgrad8h_kernel, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
+                         (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+      LAMP_LAUNCH_CHECK();
+    }
+    const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
+    WgradReduceArgs ra{};
+    ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = IG_M; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
+    wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+    return true;
+  }
   {
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     // 1x1 with more than one slice of Cin: one workgroup owns all of them (CIT = 4), dY is read once
