@@ -689,7 +689,7 @@ __device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | 
 
 template <int KS, int NCT>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -888,7 +888,25 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
         asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
         const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 16.f;
       }
-      if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = mean; sp[2] = m2; }
+      if (stats_per_wg) {                       // one triple per WORKGROUP (host: N % 8 == 0): the eight images' triples meet in LDS below
+        if (q == 0) { float2* sl = reinterpret_cast<float2*>(smem + 8 * 16384) + wid * 128 + co; *sl = make_float2(mean, m2); }
+      } else if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = mean; sp[2] = m2; }
+    }
+  }
+  if (stats && stats_per_wg) {
+    // The batch norm that reads this output merges the partial statistics of a channel in every one of its workgroups: with one triple
+    // per image that merge (2048 x 12 bytes per channel) was as much load traffic as the workgroup's slice of the activation.  Eight
+    // equal-count triples -> one of count 512: shift = mean_0, mean = shift + S1 / 8, M2 = sum M2_s + 64 (S2 - S1^2 / 8), fixed order.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < NCT * 16 && tid < CO) {
+      const float2* sl = reinterpret_cast<const float2*>(smem + 8 * 16384) + tid;
+      const float shift = sl[0].x;
+      float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) { const float2 v = sl[w * 128]; const float d = v.x - shift; s1 += d; s2 += d * d; sm += v.y; }
+      float* sp = stats + ((int64_t)tid * gridDim.x + blockIdx.x) * 3;
+      sp[0] = 512.f; sp[1] = shift + s1 * 0.125f; sp[2] = sm + 64.f * (s2 - s1 * s1 * 0.125f);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the region is private to this wave
@@ -1408,12 +1426,15 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         const int blocksd = (int)((g.N + 7) / 8);
         // 3 weight slots + the 32-channel image chunks (+ 9 spare pixels behind them for the taps of a 3x3 kernel) - and at least the
         // 8 x 16 KiB the epilogue stages the output through
-        const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)((CI + 31) / 32) * 8 * 4096 + (KS == 3 ? 9 * 64 : 0), (size_t)8 * 16384);
+        // (+ 8 KiB behind the epilogue's staging area: the eight images' statistics of every channel, merged per workgroup)
+        const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)((CI + 31) / 32) * 8 * 4096 + (KS == 3 ? 9 * 64 : 0), (size_t)8 * 16384 + 8 * 128 * 8);
+        const int per_wg = (statp && g.N % 8 == 0) ? 1 : 0;
+        if (per_wg) publish.P = blocksd;
 #define IG_LAUNCH_D(KS_, NCT_)                                                                                                              \
   do {                                                                                                                                      \
     allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
     hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp);                                                                                       \
+                       (int)g.N, CI, KP, CO, statp, per_wg);                                                                               \
   } while (0)
         if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
         else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }

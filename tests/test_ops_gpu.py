@@ -813,14 +813,14 @@ def test_weight_gradient_reductions_are_deferred_and_batched(gpu):
         assert torch.equal(a, f)
 
 
-@pytest.mark.parametrize("cin,cout,k", [(128, 128, 3), (64, 64, 3), (32, 64, 1), (128, 100, 3)])
-def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k):
+@pytest.mark.parametrize("cin,cout,k,N", [(128, 128, 3, 64), (64, 64, 3, 64), (32, 64, 1, 64), (128, 100, 3, 64),
+                                         (128, 128, 3, 1024), (16, 16, 3, 1024), (128, 100, 1, 1024)])   # N = 1024: the eight-image kernel, one triple per workgroup
+def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k, N):
     """A bf16 8x8 convolution on the implicit-GEMM path leaves per-image Welford triples of its output for the batch norm that
     consumes it (conv_stats_publish / conv_stats_lookup): that batch norm launches no statistics kernel, and its outputs are those
     of a batch norm run on a COPY of the tensor (different storage: no hand-off) up to the merge order of the partial statistics.
     Writing into the tensor invalidates the hand-off."""
     dt = torch.bfloat16
-    N = 64
     x = closed_form((N, cin, 8, 8), 3, 2.0, dt)
     w = closed_form((cout, cin, k, k), 17, 0.2, dt)
     bias = closed_form((cout,), 5, 1.0, dt)
