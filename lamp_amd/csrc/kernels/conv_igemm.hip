@@ -1385,7 +1385,7 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
     }
   }
   if (cnt == 0) return;
-  hipLaunchKernelGGL(ig_pack_weights_many_kernel, dim3((unsigned)std::min(64, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ig_pack_weights_many_kernel, dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
   LAMP_LAUNCH_CHECK();
   for (auto& d : done) {
     auto it = g_pack_cache.find(d.first);
