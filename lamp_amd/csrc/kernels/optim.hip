@@ -17,7 +17,7 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   /
 void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);  // conv_narrow.hip
 
 constexpr int MT_MAX = 40;       // tensors per launch (the descriptor is a by-value kernel argument: 3.4 KB of the 4 KB limit; the ResNet has 37)
-constexpr int MT_CHUNK = 4096;   // elements per workgroup
+constexpr int MT_CHUNK = 1024;   // elements per workgroup (4096: the ResNet's 392 k parameters made ~130 workgroups for 256 CUs - 15 us per AdamW launch)
 
 struct MultiArgs {
   int n;
