@@ -975,7 +975,15 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     // aligned, large problems: 256 x 128 LDS-DMA / ping-pong kernel
     const bool big = g.a_vec && g.b_vec && g.M % PM == 0 && g.N % PN == 0 && g.K % PK == 0 && (g.ldc % 4 == 0) &&
                      (((uintptr_t)g.C & 7) == 0) && (g.c_bs % 4 == 0) && (g.M / PM) * (g.N / PN) * g.batch >= 128;
-    const bool big2 = big && g.N % QN == 0 && (g.M / QM) * (g.N / QN) * g.batch >= 200;
+    bool big2 = big && g.N % QN == 0 && (g.M / QM) * (g.N / QN) * g.batch >= 200;
+    if (big && !big2 && g.batch == 1 && g.M % QM == 0 && g.N % QN == 0) {
+      // fewer than 200 tiles of 256 x 256: still the better choice when the 256 x 128 kernel would need a second, mostly empty round
+      // (rounds x k-steps x ~1.7 / ~1.2 us per 64-deep k-step; 3072 x 3072 x 768: 288 half tiles = 2 rounds, 144 full tiles = 1: 34 -> 25 us)
+      const int64_t cusn = num_cus(), nk = g.K / PK;
+      const double c2 = (double)(((g.M / QM) * (g.N / QN) + cusn - 1) / cusn) * (double)nk * 1.7;
+      const double c1 = (double)(((g.M / PM) * (g.N / PN) + cusn - 1) / cusn) * (double)nk * 1.2;
+      if (c2 < c1) big2 = true;
+    }
     // few output tiles over a long K (the weight gradients x^T . p of a token batch): split K over blockIdx.z
     static const bool allow_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
     if (allow_split && !big2 && g.batch == 1 && g.a_vec && g.b_vec && g.M % QM == 0 && g.N % QN == 0 && g.K % PK == 0 && g.K >= 512) {
@@ -994,6 +1002,12 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
         const double c = cost(d);
         if (c < best * 0.97) { best = c; split = (int)d; }
       }
+      // ... against the 128 x 128 kernel without a split (two workgroups per CU, ~1.1 us per 64-deep k-step, ~5 us fixed): with a short K
+      // and enough 128 x 128 tiles it beats the split, whose second launch and f32 slices cost ~9 us beyond the model above
+      // (3072 x 768 x 768, the attention projections of a 3072-token batch: 29.6 -> 18.8 us)
+      const int64_t t128 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+      const double c128 = (double)((t128 + 2 * cus - 1) / (2 * cus)) * (double)nk_total * 1.1 + 5.0;
+      if (split > 1 && !big && c128 < best + 9.0) split = 1;
       if (split > 1 && tiles * split >= 64) {
         Hold ws(new_tensor({(int64_t)split, g.M, g.N}, kF32, out_device));
         GemmArgs h = g;
