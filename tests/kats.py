@@ -156,7 +156,48 @@ ndx6 = np.arange(1.0, 7.0)
 ndx18 = ar18.copy()
 
 
+def _module_cases(c):
+    """composite module KATs of nn.test.scala that are stated with deterministic parameters (the others draw theirs from libtorch's
+    RNG): `testGradientAndValue(id)(input, module, expected)` - value of module.forward(input).sum to 1e-6, gradients of the module's
+    parameters against central differences to 4 decimals.  One case per checked parameter."""
+    eye3 = np.eye(3)
+
+    def linear0(which):
+        def f(B, m):
+            w = B.param(m if which == 0 else np.ones((3, 1)))
+            b = B.param(m if which == 1 else np.ones(1))
+            return (B.const(mat2x3).mm(w) + b).sum(), (w, b)[which]
+        return f
+    c["nn Linear 0 - wrt weight"] = (np.ones((3, 1)), linear0(0))
+    c["nn Linear 0 - wrt bias"] = (np.ones(1), linear0(1))
+
+    def logistic2(which):
+        def f(B, m):
+            w = B.param(m if which == 0 else np.ones((2, 3)))
+            b = B.param(m if which == 1 else np.ones((1, 3)))
+            L = (B.const(mat3x2).mm(w) + b).logSoftMax(1).crossEntropy(B.const(eye3)).sum() + _sq_frob(w) + _sq_frob(b)
+            return L, (w, b)[which]
+        return f
+    c["nn Logistic 2 - wrt weight"] = (np.ones((2, 3)), logistic2(0))
+    c["nn Logistic 2 - wrt bias"] = (np.ones((1, 3)), logistic2(1))
+
+    def mlp1(which):
+        def f(B, m):
+            shapes = [(2, 32), (1, 32), (32, 3), (1, 3)]
+            ps = [B.param(m if which == i else np.ones(sh)) for i, sh in enumerate(shapes)]
+            h = ((B.const(mat3x2).mm(ps[0]) + ps[1]).logSoftMax(1).gelu()).mm(ps[2]) + ps[3]
+            L = h.crossEntropy(B.const(eye3)).sum()
+            for q in ps:
+                L = L + _sq_frob(q)
+            return L, ps[which]
+        return f
+    c["nn Mlp1 - wrt first weight"] = (np.ones((2, 32)), mlp1(0))
+    c["nn Mlp1 - wrt second weight"] = (np.ones((32, 3)), mlp1(2))
+    c["nn Mlp1 - wrt second bias"] = (np.ones((1, 3)), mlp1(3))
+
+
 def _more_cases(c):
+    _module_cases(c)
     """the remaining cases of autograd.test.scala that stay inside SURVEY section 8 (linear algebra, sparse tensors and `cross` are
     not mirrored).  Inputs and operator calls transcribed from the lines given in tests/golden/reference_kats.json."""
     P2 = lambda B: B.param(mat2x3 * 2)

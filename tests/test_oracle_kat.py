@@ -26,7 +26,7 @@ def test_autograd_kat_value_and_gradient(name):
 
 def test_exact_constants_at_full_precision():
     # the KATs the reference states with all digits
-    for name in ("softmax", "exp", "l2 logistic regression loss - nll_loss"):
+    for name in ("softmax", "exp", "l2 logistic regression loss - nll_loss", "nn Logistic 2 - wrt weight", "nn Mlp1 - wrt first weight"):
         value, _ = kats.run_case(B, name, backprop=False)
         assert abs(value - kats.EXPECTED[name]) <= 1e-9 * max(1.0, abs(kats.EXPECTED[name])), (name, value)
 
