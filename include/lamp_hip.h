@@ -494,6 +494,8 @@ int lamp_repeat_interleave_tensor(lamp_tensor** out, const lamp_tensor* a, const
 int lamp_masked_scatter(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* mask, const lamp_tensor* source);
 int lamp_gather(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index);
 int lamp_scatter_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src);
+int lamp_diag(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal);          /* ATen.diag: vector -> matrix, matrix -> k-th diagonal (ops.scala:333-350) */
+int lamp_cross(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, int64_t dim);   /* ATen.cross along a dimension of size 3 (ops.scala:581-601) */
 int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value);
 int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted);
 int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes);

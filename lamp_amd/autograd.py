@@ -116,6 +116,11 @@ class Variable:
     def indexFill(self, index, dim, fillValue): return apply_op("IndexFill", [self, index], d=[fillValue], i=[dim])
     def expandAs(self, other: STen): return apply_op("ExpandAs", [self], tensors=[other])
     def expand(self, shape): return apply_op("Expand", [self], i=list(shape))
+    def diag(self, diagonal=0): return apply_op("Diag", [self], i=[diagonal])
+    def cross(self, other, dim): return apply_op("Cross", [self, other], i=[dim])
+    def argmax(self, dim, keepDim=False): return apply_op("ArgMax", [self], i=[dim, 1 if keepDim else 0])
+    def oneHot(self, numClasses): return apply_op("OneHot", [self], i=[numClasses])
+    def eqWhere(self, b): return apply_op("EqWhere", [self], i=[int(b)])
     def tan(self): return apply_op("Tan", [self])
     def atan(self): return apply_op("ArcTan", [self])
     def powv(self, exponent): return apply_op("Pow", [self, exponent])

@@ -122,6 +122,11 @@ int lamp_op_apply(lamp_var** out, const char* name, lamp_var* const* vars, int n
   else if (n == "SmoothL1Loss") r = F::smooth_l1_loss(V(0), T(0), I(0), D(0));         // tensors = [target], i = [reduction], d = [beta]
   else if (n == "BinaryCrossEntropyWithLogitsLoss") r = F::binary_cross_entropy_with_logits(V(0), T(0), ntensors > 1 && tensors[1] ? T(1) : Ten(), I(0));
   else if (n == "MaxPool1D") r = F::max_pool1d(V(0), I(0), I(1), I(2), I(3));
+  else if (n == "Diag") r = F::diag(V(0), I(0));
+  else if (n == "Cross") r = F::cross(V(0), V(1), I(0));
+  else if (n == "ArgMax") r = F::argmax(V(0), I(0), I(1) != 0);
+  else if (n == "OneHot") r = F::one_hot(V(0), I(0));
+  else if (n == "EqWhere") r = F::eq_where(V(0), I(0));
   else LAMP_CHECK(false, "unknown Op '" << n << "'");
   *out = wrap(r);
   LAMP_API_END

@@ -90,6 +90,11 @@ Var weight_norm(const Var& v, const Var& g, int64_t dim);
 Var smooth_l1_loss(const Var& input, const Ten& target, int64_t reduction, double beta);
 Var binary_cross_entropy_with_logits(const Var& input, const Ten& target, const Ten& posWeights /* may be undefined */, int64_t reduction);
 Var max_pool1d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation);
+Var diag(const Var& a, int64_t diagonal);
+Var cross(const Var& a, const Var& b, int64_t dim);
+Var argmax(const Var& a, int64_t dim, bool keepDim);      // not differentiable: backprop through it raises, as in the reference
+Var one_hot(const Var& a, int64_t numClasses);            // not differentiable
+Var eq_where(const Var& a, int64_t b);
 
 }  // namespace F
 }  // namespace host

@@ -162,6 +162,51 @@ Var expand(const Var& a, const std::vector<int64_t>& shape) {
   return make_result(op, Ten(o));
 }
 
+// ---- Diag, Cross and the non-differentiable ArgMax / OneHot / EqWhere (ops.scala:120-132, 230-259, 333-350, 581-601) -----------------------
+Var diag(const Var& a, int64_t diagonal) {                            // backward: out += p.diag(diagonal)
+  auto op = new_op("Diag");
+  op->params.push_back({a, [diagonal](const Ten& p, Variable& out) {
+    lamp_tensor* d = nullptr; HCALL(lamp_diag(&d, p.h(), diagonal));
+    out.accumulate(Ten(d), true);
+  }});
+  lamp_tensor* v = nullptr; HCALL(lamp_diag(&v, a->value.h(), diagonal));
+  return make_result(op, Ten(v));
+}
+Var cross(const Var& a, const Var& b, int64_t dim) {
+  // as the reference writes it: a: out -= p * ones(a.shape).cross(b, dim) ; b: out += p * ones(b.shape).cross(a, dim)
+  auto op = new_op("Cross");
+  Ten av = a->value, bv = b->value;
+  auto ones_cross = [dim](const Ten& like, const Ten& other) {
+    lamp_tensor* c = nullptr; HCALL(lamp_cross(&c, ops::ones_like(like).h(), other.h(), dim));
+    return Ten(c);
+  };
+  op->params.push_back({a, [av, bv, ones_cross](const Ten& p, Variable& out) { out.subtract(ops::mul(p, ones_cross(av, bv))); }});
+  op->params.push_back({b, [av, bv, ones_cross](const Ten& p, Variable& out) { out.accumulate(ops::mul(p, ones_cross(bv, av)), true); }});
+  lamp_tensor* v = nullptr; HCALL(lamp_cross(&v, av.h(), bv.h(), dim));
+  return make_result(op, Ten(v));
+}
+namespace {
+Var not_differentiable(const char* name, const Var& a, const Ten& value) {
+  auto op = new_op(name);
+  std::string what = std::string(name) + " is not differentiable";
+  op->params.push_back({a, [what](const Ten&, Variable&) { throw Error(what); }});
+  return make_result(op, value);
+}
+}  // namespace
+Var argmax(const Var& a, int64_t dim, bool keepDim) {
+  lamp_tensor* v = nullptr; HCALL(lamp_argmax(&v, a->value.h(), dim, keepDim ? 1 : 0));
+  return not_differentiable("ArgMax", a, Ten(v));
+}
+Var one_hot(const Var& a, int64_t numClasses) {
+  lamp_tensor* v = nullptr; HCALL(lamp_one_hot(&v, a->value.h(), numClasses));
+  return not_differentiable("OneHot", a, Ten(v));
+}
+Var eq_where(const Var& a, int64_t b) {                               // no parameters: a constant of the graph
+  auto op = new_op("EqWhere");
+  lamp_tensor* v = nullptr; HCALL(lamp_eq_scalar(&v, a->value.h(), (double)b));
+  return make_result(op, Ten(v));
+}
+
 // ---- element-wise (ops.scala:841-916, 2287-2340) -------------------------------------------------------------------------------------
 Var tan(const Var& a) {                                               // Tan: tmp = value^2 ; tmp += ones(1) ; out.addcmulSelf(p, tmp, 1)
   auto op = new_op("Tan");

@@ -212,6 +212,25 @@ __global__ void gather_scatter_kernel(T* __restrict__ a /* gather: out ; scatter
   }
 }
 // index_fill along dim (IndexFill op, ops.scala:160-177)
+// diag(v, k): out[m, m] zero except out[i + max(-k, 0)][i + max(k, 0)] = v[i]   (ATen diag of a vector)
+template <class T>
+__global__ void diag_embed_kernel(const T* __restrict__ v, T* __restrict__ out, int64_t n, int64_t m, int64_t off_r, int64_t off_c) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[(i + off_r) * m + i + off_c] = v[i];
+}
+// cross product along a dimension of size 3 of two contiguous tensors of the same shape [outer, 3, inner]
+template <class T>
+__global__ void cross_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t outer, int64_t inner) {
+  using A = acc_t<T>;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= outer * inner) return;
+  const int64_t o = i / inner, r = i - o * inner, base = o * 3 * inner + r;
+  const A a0 = load_as<A>(a[base]), a1 = load_as<A>(a[base + inner]), a2 = load_as<A>(a[base + 2 * inner]);
+  const A b0 = load_as<A>(b[base]), b1 = load_as<A>(b[base + inner]), b2 = load_as<A>(b[base + 2 * inner]);
+  out[base] = store_as<T>(a1 * b2 - a2 * b1);
+  out[base + inner] = store_as<T>(a2 * b0 - a0 * b2);
+  out[base + 2 * inner] = store_as<T>(a0 * b1 - a1 * b0);
+}
 template <class T>
 __global__ void index_fill_kernel(T* __restrict__ out, const int64_t* __restrict__ index, int64_t nidx, int64_t outer, int64_t D, int64_t inner, T value) {
   const int64_t total = outer * nidx * inner;
@@ -711,6 +730,52 @@ int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const 
   if (total) {
     LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((index_fill_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, current_stream(a->device()), r->ptr<T>(),
                                                       ic->ptr<int64_t>(), ic->numel(), outer, D, inner, store_as<T>((acc_t<T>)value)));
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+  LAMP_API_END
+}
+int lamp_diag(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim == 1 || a->ndim == 2, "diag expects a vector or a matrix, got " << a->describe());
+  if (a->ndim == 1) {
+    const int64_t n = a->sizes[0], m = n + (diagonal < 0 ? -diagonal : diagonal);
+    Hold ac(contiguous(a));
+    int64_t sh[2] = {m, m};
+    Hold r(new_tensor(sh, 2, a->dtype, a->device()));
+    fill_zero(r.get());
+    if (n) {
+      LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((diag_embed_kernel<T>), dim3(grid_for(n, 256)), dim3(256), 0, current_stream(a->device()),
+                                                        ac->ptr<T>(), r->ptr<T>(), n, m, diagonal < 0 ? -diagonal : (int64_t)0, diagonal > 0 ? diagonal : (int64_t)0));
+      LAMP_LAUNCH_CHECK();
+    }
+    *out = r.take();
+  } else {
+    // the k-th diagonal of a matrix: a strided view (stride0 + stride1), copied out
+    const int64_t R = a->sizes[0], Cc = a->sizes[1];
+    const int64_t r0 = diagonal < 0 ? -diagonal : 0, c0 = diagonal > 0 ? diagonal : 0;
+    const int64_t n = std::max<int64_t>(0, std::min(R - r0, Cc - c0));
+    int64_t sz[1] = {n}, st[1] = {a->strides[0] + a->strides[1]};
+    Hold v(new_view(a, sz, st, 1, a->offset + r0 * a->strides[0] + c0 * a->strides[1]));
+    Hold r(new_tensor(sz, 1, a->dtype, a->device()));
+    copy_into(r.get(), v.get());
+    *out = r.take();
+  }
+  LAMP_API_END
+}
+int lamp_cross(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self"); check_device_tensor(b, "other"); check_same_device(a, b);
+  LAMP_CHECK(a->dtype == b->dtype && a->shape() == b->shape(), "cross: operands differ: " << a->describe() << " vs " << b->describe());
+  int64_t outer, D, inner;
+  split3(a, dim, outer, D, inner);
+  LAMP_CHECK(D == 3, "cross: dimension " << dim << " has size " << D << ", expected 3");
+  Hold ac(contiguous(a)), bc(contiguous(b));
+  Hold r(new_tensor(a->shape(), a->dtype, a->device()));
+  if (outer * inner) {
+    LAMP_DISPATCH_FLOAT(a->dtype, T, hipLaunchKernelGGL((cross_kernel<T>), dim3(grid_for(outer * inner, 256)), dim3(256), 0, current_stream(a->device()),
+                                                        ac->ptr<T>(), bc->ptr<T>(), r->ptr<T>(), outer, inner));
     LAMP_LAUNCH_CHECK();
   }
   *out = r.take();

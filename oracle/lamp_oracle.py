@@ -516,6 +516,33 @@ class Cos(Op):              # ops.scala:830-840
         self.value = Variable(aten.cos(a.value), self)
 
 
+class Diag(Op):             # ops.scala:333-350
+    def __init__(self, a, diagonal):
+        def da(p, out):
+            out += aten.diag(p, diagonal)
+        self.params = [(a, da)]
+        self.value = Variable(aten.diag(a.value, diagonal), self)
+
+
+class Cross(Op):            # ops.scala:581-601 (the backward closures as the reference writes them)
+    def __init__(self, a, b, dim):
+        def da(p, out):
+            out -= p * aten.cross(torch.ones(a.value.shape, dtype=p.dtype), b.value, dim)
+
+        def db(p, out):
+            out += p * aten.cross(torch.ones(b.value.shape, dtype=p.dtype), a.value, dim)
+        self.params = [(a, da), (b, db)]
+        self.value = Variable(aten.cross(a.value, b.value, dim), self)
+
+
+class _NotDifferentiable(Op):   # ArgMax / OneHot (ops.scala:230-259)
+    def __init__(self, a, value, name):
+        def da(p, out):
+            raise RuntimeError(name + " is not differentiable")
+        self.params = [(a, da)]
+        self.value = Variable(value, self)
+
+
 class Tan(Op):              # ops.scala:841-853
     def __init__(self, a):
         def da(p, out):
@@ -675,6 +702,10 @@ def _more_variable_methods():
     V.colSum = lambda self: self.sum([0], True)
     V.sin = lambda self: Sin(self).value
     V.cos = lambda self: Cos(self).value
+    V.diag = lambda self, diagonal=0: Diag(self, diagonal).value
+    V.cross = lambda self, other, dim: Cross(self, other, dim).value
+    V.argmax = lambda self, dim, keepDim=False: _NotDifferentiable(self, aten.argmax(self.value, dim, keepDim), "Argmax").value
+    V.oneHot = lambda self, n: _NotDifferentiable(self, aten.one_hot(self.value, n), "OneHot").value
     V.tan = lambda self: Tan(self).value
     V.atan = lambda self: ArcTan(self).value
     V.pow = lambda self, e: PowConst(self, e).value

@@ -198,11 +198,14 @@ def _module_cases(c):
 
 def _more_cases(c):
     _module_cases(c)
-    """the remaining cases of autograd.test.scala that stay inside SURVEY section 8 (linear algebra, sparse tensors and `cross` are
+    """the remaining cases of autograd.test.scala that stay inside SURVEY section 8 (linear algebra and sparse tensors are
     not mirrored).  Inputs and operator calls transcribed from the lines given in tests/golden/reference_kats.json."""
     P2 = lambda B: B.param(mat2x3 * 2)
 
     def un(f): return lambda B, m: (lambda x: (f(B, x), x))(B.param(m))
+    c["diag"] = (mat3x1, un(lambda B, x: x.view([-1]).diag(0).sum()))
+    c["cross left"] = (mat2x3, un(lambda B, x: x.cross(B.const(mat2x3_2), 1).sum()))
+    c["cross right"] = (mat2x3, un(lambda B, x: B.const(mat2x3_2).cross(x, 1).sum()))
     c["colSum"] = (mat2x3, un(lambda B, x: x.colSum().sum()))
     c["rowSum"] = (mat2x3, un(lambda B, x: x.rowSum().sum()))
     c["assign - right"] = (mat2x3, un(lambda B, x: P2(B).assign(x).sum()))
