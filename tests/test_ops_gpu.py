@@ -544,7 +544,8 @@ def test_convolution_forward_backward(gpu, dt, case):
 
 
 @pytest.mark.parametrize("case", [(16, 128, 128, 3), (13, 128, 100, 3), (9, 100, 100, 3), (24, 16, 128, 3), (11, 128, 100, 1), (8, 16, 128, 1),
-                                  (3, 100, 128, 3), (1100, 128, 128, 3)])
+                                  (3, 100, 128, 3), (1100, 128, 128, 3),
+                                  (16, 16, 16, 3), (13, 128, 16, 3), (9, 128, 64, 1), (21, 64, 48, 3)])   # 1 / 4 channel tiles per wave
 def test_igemm_eight_image_kernel(gpu, case, monkeypatch):
     """ig_conv8d_kernel (one workgroup per CU, eight images, wave = image x all output channels; the default for > 64 output channels
     once the batch gives every CU a workgroup): forced on small and ragged batches (N not a multiple of 8, N < 8), fprop with bias and
