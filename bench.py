@@ -36,7 +36,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "lm"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
