@@ -931,100 +931,6 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
 extern "C" int lamp_debug_ig8d_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ig8d_stamps), sizeof(ig8d_stamps)) == hipSuccess ? 0 : 1; }
 #endif
 
-// ---- wgrad --------------------------------------------------------------------------------------------
-// partial[(split * RS + rs)][128][128] (fp32) = sum over the split's images of dY[n] (128 x 64) . Xshift_rs[n]^T (64 x 128)
-template <int KS>
-__global__ __launch_bounds__(256) void ig_wgrad8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                        int N, int CO, int CI, int images_per_split) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RS = KS * KS;
-  constexpr int PAD = (KS - 1) / 2;
-  const int rs = blockIdx.x % RS, split = blockIdx.x / RS;
-  const int r = rs / KS, s = rs - r * KS;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
-  const int nbeg = split * images_per_split;
-  const int nend = min(nbeg + images_per_split, N);
-
-  auto load_x = [&](uint4 (&rx)[4], int n) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int c = tid + i * 256;
-      const int ci = c >> 3, h = c & 7;           // k chunk = image row h
-      const int hs = h + r - PAD;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ci < CI && hs >= 0 && hs < 8) {
-        v = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci) * 64 + hs * 8);
-        const int sh = s - PAD;                    // out[w] = in[w + sh]
-        if (sh < 0) v = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
-        else if (sh > 0) v = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
-      }
-      rx[i] = v;
-    }
-  };
-
-  f4v acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
-
-  uint4 ra[4], rb[4];
-  if (nbeg < nend) {
-    ig_stage_load_rows(ra, dy + (int64_t)nbeg * CO * 64, 64, 0, CO, 64, tid);
-    load_x(rb, nbeg);
-    ig_stage_store_rows(ra, smem, tid);
-    ig_stage_store_rows(rb, smem + IG_WTILE, tid);
-  }
-  __syncthreads();
-  for (int n = nbeg; n < nend; n++) {
-    const int cur = (n - nbeg) & 1;
-    if (n + 1 < nend) {
-      ig_stage_load_rows(ra, dy + (int64_t)(n + 1) * CO * 64, 64, 0, CO, 64, tid);
-      load_x(rb, n + 1);
-    }
-    const char* al = smem + cur * 2 * IG_WTILE;
-    const char* bl = al + IG_WTILE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      bf8v fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(al, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; j++) fb[j] = ig_frag_rows(bl, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    if (n + 1 < nend) {
-      ig_stage_store_rows(ra, smem + (cur ^ 1) * 2 * IG_WTILE, tid);
-      ig_stage_store_rows(rb, smem + (cur ^ 1) * 2 * IG_WTILE + IG_WTILE, tid);
-    }
-    __syncthreads();
-  }
-  float* out = partial + (int64_t)blockIdx.x * IG_M * IG_M;   // blockIdx.x = split * RS + rs
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = wc * 64 + j * 16 + (lane & 15);
-        out[co * IG_M + ci] = acc[i][j][rr];
-      }
-}
-// dw[co][ci][r][s] = sum_split partial[split][rs][co][ci]; threads run along ci (the contiguous index of the partials)
-__global__ void ig_wgrad_reduce_kernel(const float* __restrict__ partial, bf16_t* __restrict__ dw, int CO, int CI, int RS, int nsplit) {
-  const int total = RS * CO * CI;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int ci = e % CI, co = (e / CI) % CO, rs = e / (CI * CO);
-    float a = 0.f;
-    for (int sp = 0; sp < nsplit; sp++) a += partial[((int64_t)(sp * RS + rs) * IG_M + co) * IG_M + ci];
-    dw[((int64_t)co * CI + ci) * RS + rs] = bf16_t(a);
-  }
-}
-
 // ---- wgrad v2: all taps in one workgroup ----------------------------------------------------------------
 // Workgroup = (32-channel slice of Cin, image range); it owns dW[all taps][128 co][32 ci] in registers (9 x 4 MFMA
 // tiles per wave).  Per image: dY[128 co][64 px] is staged K-contiguous (swizzled 128-B rows) and X[32 ci][8x8] is
@@ -1564,27 +1470,6 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
     return true;
   }
-  // (v1, kept for reference: one tap per workgroup) enough workgroups to fill 256 CUs: RS taps x nsplit image ranges
-  int target_splits = (2 * num_cus() + RS - 1) / RS;
-  int ips = (int)std::max<int64_t>(1, (g.N + target_splits - 1) / target_splits);
-  if (ips < 8 && g.N >= 8) ips = 8;
-  const int nsplit = (int)((g.N + ips - 1) / ips);
-  int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * IG_M};
-  Hold partial(new_tensor(ps, 1, kF32, x->device()));
-  const size_t lds = 4 * IG_WTILE;
-  {
-    KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-    if (KS == 3) hipLaunchKernelGGL((ig_wgrad8_kernel<3>), dim3(nsplit * RS), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),
-                                    partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, ips);
-    else hipLaunchKernelGGL((ig_wgrad8_kernel<1>), dim3(nsplit * RS), dim3(256), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),
-                            partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, ips);
-    LAMP_LAUNCH_CHECK();
-  }
-  const int total = (int)(g.Cout * g.Cin * RS);
-  hipLaunchKernelGGL(ig_wgrad_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<bf16_t>(), (int)g.Cout,
-                     (int)g.Cin, RS, nsplit);
-  LAMP_LAUNCH_CHECK();
-  return true;
 }
 
 }  // namespace lamp
