@@ -7,6 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# a clean checkout has no shared library (it is git-ignored): build it once, as `__graft_entry__.build()` does
+if not os.path.exists(os.path.join(ROOT, "lamp_amd", "lib", "liblamp_hip.so")) and not os.environ.get("LAMP_TESTS_NO_BUILD"):
+    try:
+        import __graft_entry__
+        __graft_entry__.build()
+    except Exception as e:  # the ABI test reports the missing library with the reason
+        sys.stderr.write(f"conftest: building liblamp_hip.so failed: {e}\n")
+
 # load the HIP library before torch so that it binds the system ROCm runtime
 try:
     from lamp_amd._capi import lib as _lib
