@@ -350,7 +350,7 @@ def main():
 
     graph = None
     step_eager = step
-    use_graph = comm is None and not a.no_graph and ((a.workload == "resnet") or (a.graph and a.workload == "lm"))
+    use_graph = not a.no_graph and ((a.workload == "resnet") or (a.graph and a.workload == "lm"))
     if use_graph and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)):
         # rocprofv3's kernel tracing dies with SIGSEGV inside hipGraphLaunch on this image (5 of 8 runs on one box, never without the
         # profiler; the faulting frames are the profiler's graph hooks under lamp_graph_launch): a profiled run measures the eager step,
@@ -368,13 +368,24 @@ def main():
         step()
         lib.lamp_device_synchronize()
         lib.lamp_graph_begin_capture()
-        _, captured_grads = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
+        captured_n, captured_grads = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
         graph = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(graph))
-        def step():
-            lib.lamp_graph_launch(graph)
-            opt.step(captured_grads, 1.0)
-            return units_per_step
-        config["hip_graph"] = "forward + backprop replayed from a HIP graph, optimiser eager (--no-graph: eager step)"
+        if comm is None:
+            def step():
+                lib.lamp_graph_launch(graph)
+                opt.step(captured_grads, 1.0)
+                return units_per_step
+            config["hip_graph"] = "forward + backprop replayed from a HIP graph, optimiser eager (--no-graph: eager step)"
+        else:
+            # N ranks: the same replay, then averageGradients over RCCL (one flat fp32 bucket * n, all-reduce, / sum n) and the optimiser.
+            # The eager step (--no-graph) overlaps the exchange of the deep layers with the rest of backward instead; replaying the graph
+            # saves more (~90 us of launch gaps per step) than the overlap hides (one ~1.5 MB all-reduce).
+            def step():
+                lib.lamp_graph_launch(graph)
+                model.exchange_and_step(opt, captured_grads, captured_n, comm)
+                return units_per_step
+            config["hip_graph"] = ("forward + backprop replayed from a HIP graph, then gradient all-reduce (RCCL) + optimiser eager "
+                                   "(--no-graph: eager step with the exchange overlapped with backward)")
     if comm is not None and a.workload in ("resnet", "lm"):
         # what a data-parallel run does before its first batch: rank 0's module + optimiser state on every rank (the replicas are already
         # identical here - same seed - so this changes no value; it puts the broadcast path on the wire before the measurement)

@@ -143,6 +143,11 @@ int lamp_model_train_step_scheduled(lamp_model* m, lamp_optimizer* o, lamp_comm*
  * (distributed/package.scala:683-688).  lamp_model_train_step does it by itself before the first step over a communicator; call it
  * again before validation / checkpoints to make rank `root`'s non-parameter state the state of every rank. */
 int lamp_model_sync_state(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, int root);
+/* averageGradients + optimizer.step (distributed/package.scala:690-759) on gradients the caller has already computed - e.g. by replaying
+ * forward + backprop from a HIP graph: g_i *= n, one flat all-reduce with n, g_i /= sum n, step.  The replicas are made identical first
+ * if they have not been over this communicator. */
+int lamp_model_exchange_and_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, lamp_tensor* const* grads, int ngrads, int64_t num_examples,
+                                 double schedule_factor);
 /* Single-process data parallel, DataParallel.driveSynchronousLoop's `synchronousStep` (lamp-data DataParallel.scala:195-311): the main
  * model (with the optimiser) and `nreplicas` replicas on other GPUs; arrays of nreplicas + 1 entries, main first.  Copies the main
  * state to the replicas, computes every model's gradients on its own host thread, and - when `step` - averages the gradients weighted

@@ -376,6 +376,16 @@ int lamp_model_train_step_scheduled(lamp_model* m, lamp_optimizer* o, lamp_comm*
   *num_examples = m->dp.step(m->model, *o->o, borrow(samples), borrow(target), acc ? borrow(acc) : Ten(), schedule_factor);
   LAMP_API_END
 }
+int lamp_model_exchange_and_step(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, lamp_tensor* const* grads, int ngrads, int64_t num_examples,
+                                 double schedule_factor) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(comm, "NULL communicator");
+  m->dp.comm = comm;
+  std::vector<Ten> gs;
+  for (int i = 0; i < ngrads; i++) { LAMP_CHECK(grads[i], "NULL gradient"); gs.push_back(borrow(grads[i])); }
+  m->dp.exchange_and_step(m->model, *o->o, gs, num_examples, schedule_factor);
+  LAMP_API_END
+}
 int lamp_model_sync_state(lamp_model* m, lamp_optimizer* o, lamp_comm* comm, int root) {
   LAMP_API_BEGIN
   LAMP_CHECK(comm, "NULL communicator");

@@ -456,5 +456,25 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   return n;
 }
 
+// averageGradients + optimizer.step on gradients that are already computed (distributed/package.scala:690-759) - the second half of
+// `step` for callers that produce the gradients themselves, e.g. by replaying forward + backprop from a HIP graph: one flat f32 bucket
+// [n * g_i ... | n], one all-reduce on the CURRENT stream (nothing is left to overlap with), division by the summed n, step.
+void DataParallel::exchange_and_step(SupervisedModel& model, Optimizer& opt, const std::vector<Ten>& grads, int64_t n, double scheduleFactor) {
+  LAMP_CHECK(comm, "exchange_and_step needs a communicator");
+  if (synced_with != comm) sync_state(model, opt, 0);
+  std::vector<lamp_tensor*> gh;
+  int64_t cnt = 0;
+  for (auto& g : grads) { LAMP_CHECK(g.defined(), "exchange_and_step: undefined gradient"); gh.push_back(g.h()); cnt += g.numel(); }
+  const int device = grads.empty() ? 0 : grads[0].device();
+  if (!bucket_all.defined() || bucket_all.numel() != cnt + 1) bucket_all = ops::zeros({cnt + 1}, kF32, device);
+  if (!gh.empty()) HCALL(lamp_flatten_into_(bucket_all.h(), gh.data(), (int)gh.size(), (double)n));
+  ops::fill_(ops::slice(bucket_all, 0, cnt, cnt + 1, 1), (double)n);
+  lamp_tensor* bt[1] = {bucket_all.h()};
+  lamp_comm* cm[1] = {comm};
+  HCALL(lamp_comm_all_reduce(bt, cm, 1, 0));
+  if (!gh.empty()) HCALL(lamp_unflatten_from_(gh.data(), (int)gh.size(), bucket_all.h(), 1));
+  opt.step(grads, scheduleFactor);
+}
+
 }  // namespace host
 }  // namespace lamp

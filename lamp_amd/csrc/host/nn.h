@@ -177,6 +177,7 @@ struct SupervisedModel {
 struct DataParallel {
   lamp_comm* comm = nullptr;    // null => single process (no exchange)
   Ten bucket_deep, bucket_rest; // f32 [sum numel + 1] each, last element = numExamples
+  Ten bucket_all;               // the single bucket of exchange_and_step
   lamp_stream* comm_stream = nullptr;
   lamp_comm* synced_with = nullptr;   // communicator the replicas were last made identical over
   int64_t step(SupervisedModel& model, Optimizer& opt, const Ten& samples, const Ten& target, const Ten& acc, double scheduleFactor = 1.0);
@@ -184,6 +185,8 @@ struct DataParallel {
   // rank (distributed/package.scala:683-688 does this before every batch; here the replicas step identically, so once before the
   // first step - and whenever the caller wants the non-parameter state of rank 0 everywhere: validation, checkpoints)
   void sync_state(SupervisedModel& model, Optimizer& opt, int root = 0);
+  // the exchange + optimiser half of `step` on gradients computed elsewhere (a replayed HIP graph): example-weighted mean over the ranks
+  void exchange_and_step(SupervisedModel& model, Optimizer& opt, const std::vector<Ten>& grads, int64_t numExamples, double scheduleFactor = 1.0);
   ~DataParallel();
 };
 

@@ -199,6 +199,11 @@ class SupervisedModel:
                                                 float(scheduleFactor), C.byref(n))
         return n.value
 
+    def exchange_and_step(self, optimizer: Optimizer, grads: Sequence[STen], numExamples: int, comm, scheduleFactor: float = 1.0) -> None:
+        """averageGradients + optimizer.step on gradients computed elsewhere (a replayed HIP graph): distributed/package.scala:690-759."""
+        arr = (C.c_void_p * len(grads))(*[g.h for g in grads])
+        lib.lamp_model_exchange_and_step(self.h, optimizer.h, comm, arr, len(grads), int(numExamples), float(scheduleFactor))
+
     def sync_state(self, optimizer: Optimizer, comm, root: int = 0) -> None:
         """distributed `broadcast` (distributed/package.scala:683-688): rank `root`'s module + optimiser state on every rank."""
         lib.lamp_model_sync_state(self.h, optimizer.h, comm, int(root))

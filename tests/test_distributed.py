@@ -228,6 +228,54 @@ def test_overlapped_data_parallel_step_single_rank(gpu, dtype_name):
         assert np.array_equal(a, b), "single-rank data-parallel step must reproduce the plain step bit for bit"
 
 
+@pytest.mark.gpu
+def test_graph_replay_with_gradient_exchange_single_rank(gpu):
+    """bench.py's multi-rank step: forward + backprop replayed from a HIP graph, then lamp_model_exchange_and_step (one flat bucket
+    * n, all-reduce, / sum n, AdamW) on the replayed gradients.  With a world-size-1 communicator three steps must land on the
+    parameters of the plain eager step (n = 64: the scaling is exact)."""
+    from lamp_amd import sten as S, nn
+    from lamp_amd._capi import lib
+    dt = S.BF16
+    B = 64
+    x = S.STen.from_numpy((np.arange(B * 3 * 32 * 32) * 7919 % 1009 / 1009.0 - 0.5).reshape(B, 3, 32, 32).astype(np.float32), 0, dt)
+    target = S.STen.from_numpy((np.arange(B) * 7 % 100).astype(np.int64), 0)
+    uid = (C.c_uint8 * 128)(); lib.lamp_comm_get_unique_id(uid)
+    comm = C.c_void_p(); lib.lamp_comm_init_rank(C.byref(comm), 1, uid, 0)
+
+    def fresh():
+        lib.lamp_manual_seed(99)
+        mod = nn.resnet(100, 0.0, dt, 0)
+        model = nn.SupervisedModel(mod, nn.SupervisedModel.NLL, S.STen.ones([100], dt, 0))
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3, mixedPrecision=True)([p.value for p in mod.parameters])
+        return mod, model, opt, S.STen.zeros([1], dt, 0)
+
+    mod, model, opt, acc = fresh()
+    for _ in range(3):
+        model.train_step(opt, x, target, acc, None)
+    lib.lamp_device_synchronize()
+    plain = [s.value.castToDouble().to_numpy() for s in mod.state]
+
+    mod, model, opt, acc = fresh()
+    lib.lamp_device_synchronize()
+    st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(st)); lib.lamp_stream_set_current(st)
+    model.sync_state(opt, comm, 0)
+    n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)      # eager once: caches, attributes
+    model.exchange_and_step(opt, grads, n, comm)
+    lib.lamp_device_synchronize()
+    lib.lamp_graph_begin_capture()
+    n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
+    g = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(g))
+    for _ in range(2):
+        lib.lamp_graph_launch(g)
+        model.exchange_and_step(opt, grads, n, comm)
+    lib.lamp_device_synchronize()
+    dflt = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(dflt)); lib.lamp_stream_set_current(dflt)
+    got = [s.value.castToDouble().to_numpy() for s in mod.state]
+    lib.lamp_comm_destroy(comm)
+    for a, b in zip(plain, got):
+        assert np.array_equal(a, b), "graph replay + exchange_and_step must reproduce the plain step bit for bit"
+
+
 def test_row_shards_cover_every_row_once():
     """host logic of the row-sharded kNN graph: the per-rank blocks partition the rows, and the fixed-size contributions
     of the all-gather (short / empty last blocks re-query the tail rows) can always be cut back to exactly those blocks."""
