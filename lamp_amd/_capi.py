@@ -100,6 +100,10 @@ class _Lib:
             raise LampError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # kernel arguments in device memory: the step is ~100 short launches, and fetching each launch's arguments from host memory
+        # costs 1 % of the graph-replayed ResNet step and 10 % of the eager one (measured).  Must be in the environment before the HIP
+        # runtime initialises; a value the user has set wins.  (The library's own constructor does the same for non-Python hosts.)
+        os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
         self._dll = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
         self._dll.lamp_last_error.restype = C.c_char_p
         self.missing = []
