@@ -387,6 +387,13 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
                               const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
                               const int64_t* dilation, int nspatial, int transposed,
                               const int64_t* output_padding, int64_t groups, const uint8_t mask[3]);
+/* grad_input of the (non-transposed) convolution + addend, values of lamp_convolution_backward followed by lamp_add (each rounded to
+ * the tensor's dtype), in one pass where the kernel has the epilogue: autograd.scala:66-84 accumulates the partial derivatives of a
+ * Variable with several consumers (a residual block's input) by `+=`; this is that `+=` folded into the second contribution. */
+int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
+                                        const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
+                                        const int64_t* dilation, int nspatial, const int64_t* output_padding,
+                                        int64_t groups, const lamp_tensor* addend);
 int lamp_avg_pool2d(lamp_tensor** out, const lamp_tensor* x, int64_t kernel, int64_t stride, int64_t padding,
                     int ceil_mode, int count_include_pad);
 int lamp_avg_pool2d_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel,

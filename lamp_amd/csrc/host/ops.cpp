@@ -10,6 +10,8 @@
 // exactly), later closures add in place.  In-place native forms (addmm_out_transposed*, the fused
 // relu backward) take their beta = 0 / out-of-place variant for that first accumulation.
 #include "ops.h"
+#include <map>
+#include <tuple>
 
 #include <unordered_set>
 
@@ -63,8 +65,22 @@ void backprop(const Var& root) { backprop(root, nullptr); }
 // data-parallel step uses it to start the gradient exchange of the deep layers while the shallow ones are still in backward
 void backprop(const Var& root, const std::function<void(Variable*)>& after) {
   if (!root->needsGrad()) return;
-  root->grad = ops::ones_like(root->value);   // partialDerivative.get.fill_(1d)
-  root->grad_shared = false;
+  // partialDerivative.get.fill_(1d).  A one-element root (every loss) takes a constant kept per (thread, device, dtype, stream)
+  // instead of a fill launch per step; it is marked shared, so anything that wanted to modify it in place copies it first.
+  if (root->value.numel() == 1) {
+    struct Key { int device, dtype, ndim; lamp_stream* st; bool operator<(const Key& o) const { return std::tie(device, dtype, ndim, st) < std::tie(o.device, o.dtype, o.ndim, o.st); } };
+    static thread_local std::map<Key, Ten> ones;
+    lamp_stream* cur = nullptr;
+    HCALL(lamp_stream_get_current(root->value.device(), &cur));
+    const Key k{root->value.device(), root->value.dtype(), root->value.ndim(), cur};
+    auto it = ones.find(k);
+    if (it == ones.end()) it = ones.emplace(k, ops::ones_like(root->value)).first;
+    root->grad = it->second;
+    root->grad_shared = true;
+  } else {
+    root->grad = ops::ones_like(root->value);
+    root->grad_shared = false;
+  }
   for (Variable* v : topological_sort(root.get())) {
     if (v->op && v->has_grad()) {             // a node nothing flowed into contributes exact zeros
       for (auto& p : v->op->params)
@@ -553,8 +569,18 @@ Var convolution(const Var& input, const Var& weight, const Var& bias, const std:
   auto op = new_op("Convolution");
   const int ns = (int)stride.size();
   Ten iv = input->value, wv = weight->value;
+  static const bool fuse_accumulate = [] { const char* e = getenv("LAMP_CONV_DGRAD_ACCUMULATE"); return !(e && e[0] == '0'); }();
   auto back = [=](int which) {
     return [=](const Ten& p, Variable& out) {
+      if (which == 0 && !transposed && fuse_accumulate && out.has_grad() && out.grad.h()->is_device() && p.h()->is_device() && out.grad.dtype() == p.dtype()) {
+        // the input already holds another consumer's contribution (a residual block): `out += dgrad` inside the dgrad kernel
+        lamp_tensor* r = nullptr;
+        HCALL(lamp_convolution_backward_input_add(&r, p.h(), iv.h(), wv.h(), stride.data(), padding.data(), dilation.data(), ns,
+                                                  outputPadding.data(), groups, out.grad.h()));
+        out.grad = Ten(r);
+        out.grad_shared = false;
+        return;
+      }
       lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
       uint8_t mask[3] = {(uint8_t)(which == 0), (uint8_t)(which == 1), (uint8_t)(which == 2)};
       HCALL(lamp_convolution_backward(o3, p.h(), iv.h(), wv.h(), stride.data(), padding.data(), dilation.data(), ns, transposed,
@@ -661,7 +687,7 @@ static Var batch_norm_impl(const char* name, const Var& input, const Ten& x, con
     if (two_d) {
       std::vector<int64_t> tgt = o.shape();
       for (int i = 0; i < p.ndim() - 2; i++) tgt.push_back(1);
-      o.accumulate(ops::reshape(ops::unbroadcast(p, tgt), o.shape()), true);
+      o.accumulate(ops::reshape(ops::unbroadcast(p, tgt), o.shape()), p.shape() != tgt);   // equal shapes: a view of p, not ours to modify
     } else {
       Ten fp = ops::flatten(p, 1, p.ndim() - 1);
       o.accumulate(ops::unbroadcast(fp, o.shape()), fp.shape() != o.shape());

@@ -97,7 +97,7 @@ Var cast_to_precision(const Var& a, int dtype) {                      // CastToP
   if (a->value.dtype() == dtype) return a;
   auto op = new_op("CastToPrecision");
   const int from = a->value.dtype();
-  op->params.push_back({a, [from](const Ten& p, Variable& out) { out.accumulate(ops::cast(p, from), true); }});
+  op->params.push_back({a, [from](const Ten& p, Variable& out) { out.accumulate(ops::cast(p, from), p.dtype() != from); }});
   return make_result(op, ops::cast(a->value, dtype));
 }
 Var scatter_add(const Var& src, const Var& index, int64_t dim, int64_t maxIndex) { // ScatterAdd: out += p.gather(dim, index)

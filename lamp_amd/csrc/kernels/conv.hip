@@ -289,11 +289,14 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
 
 // implemented in conv_igemm.hip; return true when they handled the request
 bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
-bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+// addend (optional): dx = round(round(dgrad) + addend) when the kernel chosen has that epilogue; *addend_fused reports whether it was used
+bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
+                      bool* addend_fused = nullptr);
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 // implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
-bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
+                       bool* addend_fused = nullptr);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
@@ -373,6 +376,36 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
     db = Hold(reduce_dims(gc.get(), dims.data(), (int)dims.size(), false, 0));
   }
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  LAMP_API_END
+}
+
+int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* w,
+                                        const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial,
+                                        const int64_t* output_padding, int64_t groups, const lamp_tensor* addend) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(w, "weight"); check_device_tensor(grad_out, "grad_out"); check_device_tensor(addend, "addend");
+  LAMP_CHECK(x->dtype == w->dtype && grad_out->dtype == x->dtype && addend->dtype == x->dtype, "convolution_backward_input_add: dtype mismatch");
+  LAMP_CHECK(addend->ndim == x->ndim, "convolution_backward_input_add: addend " << addend->describe() << " does not have the input's shape " << x->describe());
+  for (int i = 0; i < x->ndim; i++)
+    LAMP_CHECK(addend->sizes[i] == x->sizes[i], "convolution_backward_input_add: addend " << addend->describe() << " does not have the input's shape " << x->describe());
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, output_padding, groups);
+  LAMP_CHECK(grad_out->ndim == x->ndim && grad_out->sizes[0] == g.N && grad_out->sizes[1] == g.Cout &&
+             grad_out->sizes[grad_out->ndim - 1] == g.Wo && (nspatial == 1 || grad_out->sizes[2] == g.Ho),
+             "convolution_backward_input_add: grad_out " << grad_out->describe() << " does not match the forward output shape");
+  Hold wc(contiguous(w)), gc(contiguous(grad_out)), ac(contiguous(addend));
+  hipStream_t st = current_stream(x->device());
+  Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
+  bool fused = false;
+  if (!igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) &&
+      !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
+  }
+  if (fused) { *out = dx.take(); }
+  else {
+    lamp_tensor* sum = nullptr;
+    if (lamp_add(&sum, ac.get(), dx.get(), 1.0) != 0) throw Error(lamp_last_error());
+    *out = sum;
+  }
   LAMP_API_END
 }
 

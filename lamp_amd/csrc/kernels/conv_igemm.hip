@@ -689,7 +689,8 @@ __device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | 
 
 template <int KS, int NCT>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg) {
+                                                        bf16_t* y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg,
+                                                        const bf16_t* addend) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -913,12 +914,33 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   IG_STAMP(4);
   if (n < N) {
     bf16_t* yp = y + (int64_t)n * CO * 64;
+    if (addend) {
+      // y = round(round(conv) + addend): the values of the convolution followed by an elementwise add (the gradient of a tensor with
+      // two consumers), without the second and third pass over the activation
+      const bf16_t* ap = addend + (int64_t)n * CO * 64;
+      uint4 av[NCT * 2];
 #pragma unroll
-    for (int it = 0; it < NCT * 2; it++) {
-      const int idx = it * 64 + lane;
-      const int co = idx >> 3, c = idx & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(El + co * 128 + ((c ^ (co & 7)) << 4));
-      if (co < CO) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
+      for (int it = 0; it < NCT * 2; it++) {
+        const int idx = it * 64 + lane;
+        const int co = idx >> 3, c = idx & 7;
+        av[it] = make_uint4(0, 0, 0, 0);
+        if (co < CO) av[it] = *reinterpret_cast<const uint4*>(ap + co * 64 + c * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < NCT * 2; it++) {
+        const int idx = it * 64 + lane;
+        const int co = idx >> 3, c = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(El + co * 128 + ((c ^ (co & 7)) << 4));
+        if (co < CO) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = add_bf16x8(v, av[it]);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NCT * 2; it++) {
+        const int idx = it * 64 + lane;
+        const int co = idx >> 3, c = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(El + co * 128 + ((c ^ (co & 7)) << 4));
+        if (co < CO) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
+      }
     }
   }
   IG_STAMP(5);
@@ -1299,7 +1321,10 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
   }
 }
 
-static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+// addend (dgrad, optional): out = round(round(conv) + addend) where the kernel chosen can do it in its epilogue; *addend_fused says whether it did
+static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
+                      const Tensor* addend = nullptr, bool* addend_fused = nullptr) {
+  if (addend_fused) *addend_fused = false;
   const int KS = g.kh, RS = KS * KS;
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
@@ -1340,8 +1365,10 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   do {                                                                                                                                      \
     allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
     hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp, per_wg);                                                                               \
+                       (int)g.N, CI, KP, CO, statp, per_wg, addp);                                                                         \
   } while (0)
+        const bf16_t* addp = addend ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
+        if (addend_fused) *addend_fused = addend != nullptr;
         if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
         else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
 #undef IG_LAUNCH_D
@@ -1401,9 +1428,10 @@ bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor
   run_conv8(x, w, bias, y, g, false, st);
   return true;
 }
-bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
+bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  if (addend_fused) *addend_fused = false;
   if (!ig_qualifies(g, dy->dtype)) return false;
-  run_conv8(dy, w, nullptr, dx, g, true, st);
+  run_conv8(dy, w, nullptr, dx, g, true, st, addend, addend_fused);
   return true;
 }
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {

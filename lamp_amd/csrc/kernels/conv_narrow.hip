@@ -217,9 +217,11 @@ __device__ unsigned long long ncv_stamps[1024 * 8];
 #define NCV_STAMP_ONCE(k) do { } while (0)
 #endif
 //   NS = shifts per MFMA (see NcvW): NS = 2 halves the P window phases an MFMA has to be issued for.
-template <int NK, int SW, int PH0, int NS>
+//   ADD: dst = round(round(conv) + add) - a separate instantiation (dgrad only: SW = 1) because the addend's registers cost the plain
+//   kernels a wave of occupancy
+template <int NK, int SW, int PH0, int NS, bool ADD>
 __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
-                                                       bf16_t* __restrict__ dst, NcvGeom q) {
+                                                       bf16_t* dst, NcvGeom q, const bf16_t* add) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
   NCV_STAMP_AT(0);
@@ -290,6 +292,21 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
           acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, fv), wfr[ks], acc[d], 0, 0, 0);
         }
       }
+      // add != nullptr: dst = round(round(conv) + add) (see ig_conv8d_kernel); the rows this lane stores.  Requested after the MFMAs:
+      // held across them they cost 12 - 20 registers and a wave of occupancy
+      constexpr int NROW = NS == 1 ? 4 : 2;
+      const int row0 = (lane >> 4) * 4 + (NS == 1 ? 0 : ((lane >> 3) & 1) * 2);
+      uint4 addv[NROW];
+      if (ADD && co < q.CO) {
+        const bf16_t* ap = add + (int64_t)n * q.CO * HoWo + co * HoWo;
+#pragma unroll
+        for (int k = 0; k < NROW; k++) {
+          const int i = row0 + k, tr = i / ncg, cg = i - tr * ncg;
+          const bf16_t* a = ap + (h0 + tr) * q.Wo + cg * P;
+          if (P == 8) addv[k] = *reinterpret_cast<const uint4*>(a);
+          else { const uint2 t = *reinterpret_cast<const uint2*>(a); addv[k] = make_uint4(t.x, t.y, 0, 0); }
+        }
+      }
       if (NS == 1) {
         if (co < q.CO) {
 #pragma unroll
@@ -302,6 +319,10 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
             for (int d = 0; d < P; d += 2) {
               const bf16_t lo(acc[d % ND][rr] + bv), hi(acc[(d + 1) % ND][rr] + bv);
               pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+            }
+            if (ADD) {
+#pragma unroll
+              for (int j = 0; j < P / 2; j++) pk[j] = add_bf16x2(pk[j], (&addv[rr % NROW].x)[j]);
             }
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
@@ -331,6 +352,10 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
             for (int d = 0; d < ND; d++) {
               const unsigned int even = sft ? got[h][d] : keep[h][d], odd = sft ? keep[h][d] : got[h][d];
               pk[d] = even | (odd << 16);
+            }
+            if (ADD) {
+#pragma unroll
+              for (int d = 0; d < ND; d++) pk[d] = add_bf16x2(pk[d], (&addv[h % NROW].x)[d]);
             }
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % ND], pk[3 % ND]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
@@ -752,7 +777,9 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
   }
 }
 
-static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
+                    const Tensor* addend = nullptr, bool* addend_fused = nullptr) {
+  if (addend_fused) *addend_fused = false;
   if (!ncv_common(g, in->dtype)) return false;
   NcvGeom q;
   q.N = (int)g.N; q.kh = g.kh; q.pf = 0; q.kh_inv = 65536 / g.kh + 1;
@@ -804,9 +831,10 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
     const void* kfn = nullptr;
-#define NCV_F2(NKv, SWv, PHv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1>
-#define NCV_F2_PH(NKv, SWv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0); else if (ph0 == 6) NCV_F2(NKv, SWv, 6); else NCV_F2(NKv, SWv, 7); } while (0)
-#define NCV_F2_SW(NKv) do { if (q.sw == 1) NCV_F2_PH(NKv, 1); else NCV_F2_PH(NKv, 2); } while (0)
+    const bool with_add = addend != nullptr && q.sw == 1;
+#define NCV_F2(NKv, SWv, PHv, ADDv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2, ADDv> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1, ADDv>
+#define NCV_F2_PH(NKv, SWv, ADDv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0, ADDv); else if (ph0 == 6) NCV_F2(NKv, SWv, 6, ADDv); else NCV_F2(NKv, SWv, 7, ADDv); } while (0)
+#define NCV_F2_SW(NKv) do { if (q.sw == 1) { if (with_add) NCV_F2_PH(NKv, 1, true); else NCV_F2_PH(NKv, 1, false); } else NCV_F2_PH(NKv, 2, false); } while (0)
     switch (NK2) {
       case 2: NCV_F2_SW(2); break;
       case 4: NCV_F2_SW(4); break;
@@ -822,7 +850,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
     const bf16_t* srcp = in->ptr<bf16_t>();
     bf16_t* dstp = out->ptr<bf16_t>();
-    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q};
+    const bf16_t* addp = with_add ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
+    if (addend_fused) *addend_fused = with_add;
+    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp};
     HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
     return true;
@@ -844,8 +874,8 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
   return ncv_run(x, w, bias, y, g, false, st);
 }
-bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
-  return ncv_run(dy, w, nullptr, dx, g, true, st);
+bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  return ncv_run(dy, w, nullptr, dx, g, true, st, addend, addend_fused);
 }
 
 template <int NT, int SW>

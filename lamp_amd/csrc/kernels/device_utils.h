@@ -36,6 +36,16 @@ struct alignas(2) bf16_t {
   }
 };
 
+// round(a + b) on packed bf16 pairs / groups of eight: the values of the elementwise add kernel (f32 sum, round to nearest even)
+__device__ __forceinline__ unsigned add_bf16x2(unsigned a, unsigned b) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+  return (unsigned)bf16_t(lo).bits | ((unsigned)bf16_t(hi).bits << 16);
+}
+__device__ __forceinline__ uint4 add_bf16x8(const uint4& a, const uint4& b) {
+  return make_uint4(add_bf16x2(a.x, b.x), add_bf16x2(a.y, b.y), add_bf16x2(a.z, b.z), add_bf16x2(a.w, b.w));
+}
+
 // f16 (IEEE half) storage type: lamp's HalfPrecision (STen.scala:726-731 scalar-type byte 5; AdamW's mixed-precision KAT runs on it,
 // adamw.test.scala:96-127).  Arithmetic happens in f32 (acc_t), the conversions are the hardware's round-to-nearest-even casts.
 struct alignas(2) f16_t {

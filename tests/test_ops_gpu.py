@@ -785,6 +785,69 @@ def test_igemm_pack_cache_sees_every_weight_write(gpu, cin, cout, hw, stride):
     check(to_torch(W).to(dt), "after a second optimiser step (images re-packed in place)")
 
 
+# (N, Cin, H, Cout, k, stride, pad, dtype, fused?)  fused = the dgrad kernel has the accumulate epilogue for this geometry
+DGRAD_ADD_CASES = [
+    (1024, 128, 8, 128, 3, 1, 1, torch.bfloat16, True),     # eight-image implicit GEMM, 8 channel tiles
+    (1024, 100, 8, 128, 3, 1, 1, torch.bfloat16, True),     # 7 tiles, 100 of 112 channels stored
+    (1024, 64, 8, 128, 1, 1, 0, torch.bfloat16, True),      # 1x1, 4 tiles
+    (1024, 16, 8, 128, 3, 1, 1, torch.bfloat16, True),      # 1 tile
+    (1027, 128, 8, 64, 3, 1, 1, torch.bfloat16, True),      # ragged last workgroup
+    (64, 128, 8, 128, 3, 1, 1, torch.bfloat16, False),      # small batch: the two-image kernel, then an add
+    (64, 6, 32, 6, 3, 1, 1, torch.bfloat16, True),          # narrow kernel, two output phases per MFMA
+    (64, 16, 16, 16, 3, 1, 1, torch.bfloat16, True),        # narrow kernel, one phase per MFMA
+    (64, 3, 32, 8, 5, 1, 2, torch.bfloat16, True),          # 5x5
+    (64, 16, 32, 32, 3, 2, 1, torch.bfloat16, None),        # stride 2: whichever kernel serves it
+    (8, 5, 12, 7, 3, 1, 1, torch.float32, False),           # f32: direct kernel, then an add
+    (4, 6, 10, 4, 3, 1, 1, torch.float64, False),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_ADD_CASES)
+def test_convolution_input_gradient_accumulates_in_the_kernel(gpu, case):
+    """lamp_convolution_backward_input_add = lamp_convolution_backward(mask 1,0,0) followed by lamp_add, BITWISE (each step rounded to
+    the dtype), with the add folded into the dgrad kernel's epilogue where that kernel has one (no elementwise launch then).
+    autograd.scala:66-84: a Variable with two consumers accumulates its partial derivatives; this is the second `+=`."""
+    N, Cin, H, Cout, k, stride, pad, dt, fused = case
+    x = closed_form((N, Cin, H, H), 3, 2.0, dt)
+    w = closed_form((Cout, Cin, k, k), 17, 0.5, dt)
+    ho = (H + 2 * pad - k) // stride + 1
+    gy = closed_form((N, Cout, ho, ho), 23, 1.0, dt)
+    addend = closed_form((N, Cin, H, H), 29, 3.0, dt)
+    X, W, GY, A = to_sten(x), to_sten(w), to_sten(gy), to_sten(addend)
+    geom = (i64_array([stride, stride]), i64_array([pad, pad]), i64_array([1, 1]), 2)
+    out3 = _out3()
+    lib.lamp_convolution_backward(out3, GY, X, W, *geom, 0, i64_array([0, 0]), 1, _mask3(1, 0, 0))
+    dx = S.STen(out3[0])
+    chain = C.c_void_p()
+    lib.lamp_add(C.byref(chain), A, dx, 1.0)
+    lib.lamp_kernel_timer_enable(1)
+    o = C.c_void_p()
+    lib.lamp_convolution_backward_input_add(C.byref(o), GY, X, W, *geom, i64_array([0, 0]), 1, A)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    got, want = to_torch(S.STen(o)), to_torch(S.STen(chain))
+    assert got.shape == want.shape and torch.equal(got, want), f"max diff {(got - want).abs().max().item()}"
+    assert torch.equal(to_torch(A).double(), addend.double()), "the addend is not modified"
+    if fused is not None:
+        assert (b"elementwise" not in buf.value) == fused, buf.value.decode()
+    gx = aten.convolution_backward(gy.float(), x.float(), w.float(), [0], [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    tol = {torch.float64: 1e-6, torch.float32: 1e-4, torch.bfloat16: 3e-2}[dt]
+    assert_close(got, (gx.double() + addend.double()), tol, "dgrad + addend")
+
+
+def test_convolution_input_gradient_accumulate_checks_its_arguments(gpu):
+    x = closed_form((4, 6, 8, 8), 3, 2.0, torch.bfloat16)
+    w = closed_form((5, 6, 3, 3), 17, 0.5, torch.bfloat16)
+    gy = closed_form((4, 5, 8, 8), 23, 1.0, torch.bfloat16)
+    o = C.c_void_p()
+    geom = (i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, i64_array([0, 0]), 1)
+    with pytest.raises(Exception, match="does not have the input's shape"):
+        lib.lamp_convolution_backward_input_add(C.byref(o), to_sten(gy), to_sten(x), to_sten(w), *geom, to_sten(gy))
+    with pytest.raises(Exception, match="dtype mismatch"):
+        lib.lamp_convolution_backward_input_add(C.byref(o), to_sten(gy), to_sten(x), to_sten(w), *geom, to_sten(x.float()))
+
+
 def test_weight_gradient_reductions_are_deferred_and_batched(gpu):
     """The reductions of the bf16 convolutions' weight-gradient partial sums are registered and run in ONE launch at
     lamp_flush_deferred (end of backprop) or when anything asks for the tensor (here: the copy to the host).  Results are those of
