@@ -13,6 +13,8 @@
 // Layout: x is [N, C, HW] contiguous (HW = 1 for the 2-D case). Pass 1 reduces each channel with
 // one or more workgroups (64-lane shuffle merge + LDS), pass 2 is a coalesced normalise.
 #include "device_utils.h"
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include "../core/strided.h"
 
@@ -517,6 +519,167 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
   }
 }
 
+// ---- batch-norm backward in ONE pass over (dy, x) ------------------------------------------------------------------------------
+// The two kernels above read dy and x (and the addend) twice: once for the channel sums, once for dx.  A bf16 activation of the
+// ResNet step is at most 33.5 MB, and the register files of the chip hold 128 MB: here workgroup (c, s) - 512 threads, slice s of
+// channel c's 16-byte packets - loads its packets ONCE, keeps the (masked) gradient and x in registers (NP packets of each per
+// thread), publishes its partial sums, waits for the S - 1 other workgroups of its channel, sums the S partials in a fixed order
+// (every workgroup of the channel gets the same bits; nothing is atomically accumulated) and writes dx (and the addend's gradient)
+// from the registers.  HBM traffic 5 -> 3 passes (7 -> 5 with an addend), one launch instead of two.
+// Waiting is safe because workgroups are handed out in launch order and a channel's S workgroups are consecutive (b = c * S + s):
+// the oldest incomplete channel always gets the next free slots.  Two SUCH kernels running at once on one device (different
+// streams) could in principle starve each other, so the host orders them by an event when the stream changes; a wait that is
+// never satisfied (~seconds) traps instead of hanging the device.
+// slots[c * S + s] = workgroup (c, s)'s (s1, s2), all-ones between launches; depart[c] counts the workgroups that have read the channel's
+// slots, zero between launches: the last one to leave resets both.
+template <int NP, bool RELU, bool ADD>                     // compile-time: run-time branches in the element loop let the compiler sink the sums
+__global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ mean,
+                                                           const bf16_t* __restrict__ invstd, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                           unsigned long long* slots, unsigned* depart, bf16_t* dweight, bf16_t* dbias, bf16_t* __restrict__ dx,
+                                                           int64_t N, int C, int HW, int S, double inv_m, int relu,
+                                                           const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift) {
+  __shared__ float sm[2][8];
+  __shared__ float stat[2];
+  const int c = blockIdx.x / S, s = blockIdx.x - c * S;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int vpp = HW >> 3;
+  const int64_t total = N * vpp;                            // packets of this channel
+  const float mu = (float)mean[c], is = (float)invstd[c];
+  const float wc = w ? (float)w[c] : 1.f;
+  const float scale = is * wc, bb = (RELU && b) ? (float)b[c] : 0.f;
+  uint4 gv[NP], xv[NP];
+  int base[NP];                                             // packet (16-byte) index into the tensors, -1: none (host: numel < 2^34)
+  const uint4* dy4 = reinterpret_cast<const uint4*>(dy);
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  const uint4* ad4 = reinterpret_cast<const uint4*>(addend);
+  // every load is issued unconditionally (a packet past the end re-reads the channel's first one and is zeroed): no branch and no
+  // 64-bit division between the loads, so all 2 NP of a thread are in flight together
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const unsigned i = (unsigned)(k * S + s) * 512u + (unsigned)tid;
+    const bool valid = i < (unsigned)total;
+    const unsigned ii = valid ? i : 0u;
+    const unsigned n = vshift >= 0 ? (ii >> vshift) : (ii / (unsigned)vpp);
+    const int idx = (int)((n * (unsigned)C + (unsigned)c) * (unsigned)vpp + (ii - n * (unsigned)vpp));
+    base[k] = valid ? idx : -1;
+    gv[k] = dy4[idx];
+    xv[k] = x4[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++)
+    if (base[k] < 0) gv[k] = make_uint4(0, 0, 0, 0);        // contributes nothing to the sums, never stored
+  float s1 = 0.f, s2 = 0.f;
+  constexpr int HALF = NP > 4 ? 4 : NP;                     // the addend is only needed for the mask: loaded in groups of <= 4 packets
+#pragma unroll
+  for (int h = 0; h < NP; h += HALF) {
+    uint4 av[HALF];
+    if (ADD) {
+#pragma unroll
+      for (int k = 0; k < HALF; k++) av[k] = ad4[base[h + k] >= 0 ? base[h + k] : c * vpp];
+    }
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+      unsigned* g32 = &gv[h + k].x;
+      const unsigned* x32 = &xv[h + k].x;
+      const unsigned* a32 = &av[k].x;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        unsigned gw = g32[q];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float xx = __uint_as_float(e ? (x32[q] & 0xffff0000u) : (x32[q] << 16));
+          float gg = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
+          if (RELU) {
+            bf16_t pre(bn_affine<float>(xx, mu, scale, bb));
+            if (ADD) pre = bf16_t((float)pre + __uint_as_float(e ? (a32[q] & 0xffff0000u) : (a32[q] << 16)));
+            if ((float)pre < 0.f) { gg = 0.f; gw &= e ? 0x0000ffffu : 0xffff0000u; }
+          }
+          s1 += gg; s2 = __builtin_fmaf(gg, xx - mu, s2);   // explicit: every instantiation rounds alike
+        }
+        g32[q] = gw;                                        // dy or 0: what dx and the addend's gradient are computed from
+      }
+      // the sums are one serial chain: without this the scheduler unpacks every packet ahead of it and keeps ~128 more values live
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // what crosses the wait is the PACKED data (128 registers at NP = 16); without this the compiler keeps the unpacked f32 values of
+  // the first phase for the second one (twice the registers, spilled)
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    asm volatile("" : "+v"(gv[k].x), "+v"(gv[k].y), "+v"(gv[k].z), "+v"(gv[k].w));
+    asm volatile("" : "+v"(xv[k].x), "+v"(xv[k].y), "+v"(xv[k].z), "+v"(xv[k].w));
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; }
+  __syncthreads();
+  if (wid == 0) {
+    // Exchange of the partial sums between the S workgroups of the channel.  No fences (a release / acquire pair at agent scope writes
+    // back and invalidates the XCD's whole L2: the step got 35 % slower) and no counter on the critical path: a workgroup publishes
+    // (s1, s2) as ONE 8-byte agent-scope atomic store into its slot, and everybody polls the S slots (agent-scope atomic loads bypass
+    // the per-XCD L2) until none holds the all-ones pattern the slots rest at between launches - two memory round trips in all.
+    float a = 0.f, bs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a += sm[0][k]; bs += sm[1][k]; }
+    if (S > 1) {
+      unsigned long long* slot = slots + (int64_t)c * S;
+      if (lane == 0) {
+        unsigned lo = __float_as_uint(a), hi = __float_as_uint(bs);
+        if (lo == 0xffffffffu) lo = 0x7fc00000u;            // a NaN either way; the all-ones pattern means "not written yet"
+        if (hi == 0xffffffffu) hi = 0x7fc00000u;
+        __hip_atomic_store(slot + s, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a = 0.f; bs = 0.f;
+      unsigned spins = 0;
+      for (int k = lane; k < S; k += 64) {
+        unsigned long long v;
+        while ((v = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 21)) __builtin_trap();       // seconds: a workgroup of the channel never arrived
+        }
+        a += __uint_as_float((unsigned)v); bs += __uint_as_float((unsigned)(v >> 32));
+      }
+      a = wave_sum(a); bs = wave_sum(bs);
+      // every slot of the channel has been read by this workgroup; the last one to say so puts the slots back to rest
+      if (lane == 0) {
+        const unsigned left = __hip_atomic_fetch_add(depart + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (unsigned)S - 1) {
+          for (int k = 0; k < S; k++) __hip_atomic_store(slot + k, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(depart + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (lane == 0) {
+      stat[0] = a; stat[1] = bs;
+      if (s == 0) {
+        if (dweight) dweight[c] = bf16_t(bs * is);
+        if (dbias) dbias[c] = bf16_t(a);
+      }
+    }
+  }
+  __syncthreads();
+  if (!dx && !dadd) return;
+  const float kk = stat[1] * is * is * (float)inv_m, gm = stat[0] * (float)inv_m;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    if (base[k] < 0) continue;
+    if (dadd) reinterpret_cast<uint4*>(dadd)[base[k]] = gv[k];
+    if (dx) {
+      uint4 r;
+      unsigned* r32 = &r.x;
+      const unsigned* g32 = &gv[k].x;
+      const unsigned* x32 = &xv[k].x;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float g0 = __uint_as_float(g32[q] << 16), g1 = __uint_as_float(g32[q] & 0xffff0000u);
+        const float x0 = __uint_as_float(x32[q] << 16), x1 = __uint_as_float(x32[q] & 0xffff0000u);
+        const bf16_t lo(__builtin_fmaf(-(x0 - mu), kk, g0 - gm) * is * wc), hi(__builtin_fmaf(-(x1 - mu), kk, g1 - gm) * is * wc);
+        r32[q] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+      }
+      reinterpret_cast<uint4*>(dx)[base[k]] = r;
+    }
+  }
+}
+
 // ---- layer norm: rows [M, D] ---------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ mean_out,
@@ -744,6 +907,96 @@ static int pick_split(int64_t outputs_blocks, int64_t N) {
   s = std::min<int64_t>(s, 256);
   return (int)std::max<int64_t>(s, 1);
 }
+// The one-pass backward (bn_bwd_fused_kernel).  Returns false when the geometry does not qualify (the caller runs the two kernels).
+struct BnFusedState { unsigned* sync = nullptr; hipStream_t last = nullptr; bool has_last = false; hipEvent_t ev = nullptr; };
+constexpr int BN_FUSED_MAXC = 4096;                         // depart[BN_FUSED_MAXC] (4-byte counters), then slots[BN_FUSED_SLOTS] (8 bytes each)
+constexpr int BN_FUSED_SLOTS = 4096;
+static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
+                                Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+  if (!on || g.C > BN_FUSED_MAXC || g.HW % 8 != 0 || xc->numel() >= (int64_t)1 << 34) return false;
+  const int64_t packets = g.N * (g.HW / 8);                 // per channel
+  if (packets <= 0 || packets >= (int64_t)1 << 30) return false;
+  if (addc && !relu) return false;
+  const int cus = num_cus();
+  static const int per_cu = [] { const char* e = getenv("LAMP_BN_FUSED_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();   // measured: 2 is slower
+  auto per_thread = [&](int64_t s) { return (packets + s * 512 - 1) / (s * 512); };
+  const void* kfn = nullptr;
+  int64_t S = 0;
+  for (int wgs = per_cu; wgs >= 1 && !kfn; wgs--) {        // workgroups per CU aimed at: more, smaller ones first
+    int64_t s = std::max<int64_t>(1, (int64_t)cus * wgs / g.C);
+    s = std::min<int64_t>(s, (packets + 511) / 512);
+    if (per_thread(s) > 16) s = (packets + 16 * 512 - 1) / (16 * 512);
+    const int ppt = (int)per_thread(s);
+    const int NP = ppt <= 1 ? 1 : ppt <= 2 ? 2 : ppt <= 4 ? 4 : ppt <= 8 ? 8 : 16;
+    // Which sizes take this path (bit = packets per thread).  Default: 8 and 16, i.e. activations of some 10 MB and more.  Below that the
+    // exchange between the workgroups (two memory round trips, ~3 us) costs what the second pass over an L2 / MALL-resident tensor
+    // costs: the ResNet step's six small layers were 4 us SLOWER in total with it, the six large ones 50 us faster.
+    static const int np_mask = [] { const char* e = getenv("LAMP_BN_FUSED_NP_MASK"); return e ? atoi(e) : 24; }();
+    if (!(np_mask & NP)) continue;
+#define BN_FUSED_K(NPv) (addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> : relu ? (const void*)bn_bwd_fused_kernel<NPv, true, false> \
+                              : (const void*)bn_bwd_fused_kernel<NPv, false, false>)
+    const void* k = NP == 1 ? BN_FUSED_K(1) : NP == 2 ? BN_FUSED_K(2) : NP == 4 ? BN_FUSED_K(4) : NP == 8 ? BN_FUSED_K(8) : BN_FUSED_K(16);
+#undef BN_FUSED_K
+    // every workgroup co-resident: nobody waits for a workgroup that has no slot yet
+    if (g.C * s <= std::min<int64_t>(BN_FUSED_SLOTS, (int64_t)cus * std::max(1, kernel_occupancy(k, 512, 0)))) { kfn = k; S = s; }
+  }
+  if (!kfn) return false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool capturing = cap == hipStreamCaptureStatusActive;
+  static std::mutex mu;
+  static std::map<int, BnFusedState> states;
+  unsigned* sync = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    BnFusedState& stt = states[xc->device()];
+    if (!stt.sync) {
+      // zeroed once, on a stream of its own and waited for: st may be capturing, and the counters must be zero in memory before the
+      // first launch really runs (whichever stream or graph that is)
+      HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + BN_FUSED_SLOTS * sizeof(unsigned long long)));
+      hipStream_t side = nullptr;
+      HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      HIP_CHECK(hipMemsetAsync(stt.sync, 0, BN_FUSED_MAXC * sizeof(unsigned), side));
+      HIP_CHECK(hipMemsetAsync(stt.sync + BN_FUSED_MAXC, 0xff, BN_FUSED_SLOTS * sizeof(unsigned long long), side));
+      HIP_CHECK(hipStreamSynchronize(side));
+      HIP_CHECK(hipStreamDestroy(side));
+      HIP_CHECK(hipEventCreateWithFlags(&stt.ev, hipEventDisableTiming));
+    }
+    if (!capturing) {
+      // one counter set per device and workgroups that wait for each other: two of these kernels must not overlap.  Same stream: ordered
+      // anyway.  Another stream: this launch waits for everything queued there so far.  (A graph replayed on one stream while another
+      // thread runs eagerly on a second one is not covered: LAMP_BN_FUSED_BWD=0 for such a program.)
+      if (stt.has_last && stt.last != st) {
+        HIP_CHECK(hipEventRecord(stt.ev, stt.last));
+        HIP_CHECK(hipStreamWaitEvent(st, stt.ev, 0));
+      }
+      stt.last = st; stt.has_last = true;
+    }
+    sync = stt.sync;
+  }
+  unsigned* departp = sync;
+  unsigned long long* slotp = reinterpret_cast<unsigned long long*>(sync + BN_FUSED_MAXC);
+  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);
+  KernelTimer kt("bn_bwd_fused", 0, passes * (double)xc->numel() * 2.0, st);
+  const bf16_t* dyp = gc->ptr<bf16_t>(); const bf16_t* xp = xc->ptr<bf16_t>();
+  const bf16_t* mp = mean_t->ptr<bf16_t>(); const bf16_t* ip = invstd_t->ptr<bf16_t>();
+  const bf16_t* wp = weight ? weight->ptr<bf16_t>() : (const bf16_t*)nullptr;
+  const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+  bf16_t* dwp = dw ? dw->ptr<bf16_t>() : (bf16_t*)nullptr; bf16_t* dbp = db ? db->ptr<bf16_t>() : (bf16_t*)nullptr;
+  bf16_t* dxp = dx ? dx->ptr<bf16_t>() : (bf16_t*)nullptr;
+  int64_t a_N = g.N; int a_C = (int)g.C, a_HW = (int)g.HW, a_S = (int)S, a_relu = relu;
+  double inv_m = 1.0 / (double)(g.N * g.HW);
+  const int vppi = (int)(g.HW / 8);
+  int a_vshift = -1;                                        // packets per image row a power of two: a shift instead of a division
+  for (int b = 0; b < 31; b++) if (vppi == (1 << b)) a_vshift = b;
+  const bf16_t* adp = addc ? addc->ptr<bf16_t>() : (const bf16_t*)nullptr;
+  bf16_t* dap = dadd ? dadd->ptr<bf16_t>() : (bf16_t*)nullptr;
+  void* args[] = {(void*)&dyp, (void*)&xp, (void*)&mp, (void*)&ip, (void*)&wp, (void*)&bp, (void*)&slotp, (void*)&departp, (void*)&dwp, (void*)&dbp, (void*)&dxp,
+                  (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift};
+  HIP_CHECK(hipLaunchKernel(kfn, dim3((unsigned)(g.C * S)), dim3(512), args, 0, st));
+  return true;
+}
 static void check_cvec(const Tensor* t, int64_t C, int dtype, const char* what) {
   if (!t) return;
   check_device_tensor(t, what);
@@ -903,6 +1156,12 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
     const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr) |
                                                           (uintptr_t)(addc.get() ? addc->data() : nullptr) | (uintptr_t)(dadd.get() ? dadd->data() : nullptr)) & 15) == 0;
     const bool col = g.HW < 64;
+    bool fused_done = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (training && vec && !col && total > 0 && (dx.get() || dadd.get()))
+        fused_done = bn_bwd_fused_launch(gc.get(), xc.get(), mean_t, invstd_t, weight, bias, dw.get(), db.get(), dx.get(), dadd.get(), addc.get(), g, relu, st);
+    }
+    if (!fused_done) {
     const int64_t blocks = col ? (g.C + 255) / 256 : g.C;
     const int nsplit = pick_split(blocks, g.N);
     int64_t ps[1] = {(int64_t)nsplit * g.C * 2};
@@ -940,6 +1199,7 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
                            invstd_t->ptr<T>(), wp, sums->ptr<A>(), dx->ptr<T>(), total, g.C, g.HW, 1.0 / (double)(g.N * g.HW), training, vec, relu, bp);
         LAMP_LAUNCH_CHECK();
       }
+    }
     }
   });
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();

@@ -464,6 +464,85 @@ def test_batch_norm_add_relu_fused_equals_unfused_chain(gpu, dt, shape):
         assert np.array_equal(u.to_numpy(), f.to_numpy()), what
 
 
+# (N, C, H, variant)  variant 0: batch norm, 1: + relu, 2: + addend + relu
+BN_ONE_PASS_CASES = [(2048, 128, 8, 2), (2048, 128, 8, 1), (2048, 100, 8, 0), (2048, 6, 32, 1), (2048, 16, 16, 2), (2049, 64, 8, 1),
+                     (2100, 5, 20, 2),                      # 50 packets per image row (a division, not a shift), ragged slices
+                     (1024, 64, 8, 0), (37, 5, 12, 2), (3, 130, 8, 1), (512, 300, 8, 0)]   # small: the two kernels
+
+
+@pytest.mark.parametrize("case", BN_ONE_PASS_CASES)
+def test_batch_norm_backward_in_one_pass(gpu, case):
+    """bf16 training-mode batch-norm backward reads dy and x ONCE (bn_bwd_fused_kernel: the workgroups of a channel keep their slice in
+    registers while they wait for each other's partial sums).  Checked against ATen in f32 on the bf16 inputs, at the ResNet step's
+    shapes and at ragged ones; repeated launches (the wait counters reset themselves) and launches that alternate between two
+    streams give bitwise the same tensors."""
+    N, Cc, H, variant = case
+    dt = torch.bfloat16
+    shape = (N, Cc, H, H)
+    x = closed_form(shape, 3, 4.0, dt) + 0.3
+    addend = closed_form(shape, 29, 3.0, dt)
+    gy = closed_form(shape, 11, 2.0, dt)
+    w, b = closed_form((Cc,), 1, 1.0, dt) + 1.0, closed_form((Cc,), 5, 1.0, dt)
+    rm, rv = closed_form((Cc,), 7, 0.5, dt), closed_form((Cc,), 9, 0.5, dt) + 1.0
+    X, AD, GY, Wt, Bt, RM, RV = (to_sten(t) for t in (x, addend, gy, w, b, rm, rv))
+    fwd = _out3()
+    lib.lamp_native_batch_norm(fwd, X, Wt, Bt, RM, RV, 1, 0.1, 1e-5)
+    _, sm, si = _wrap3(fwd)
+
+    def backward():
+        if variant == 2:
+            out4 = (C.c_void_p * 4)()
+            lib.lamp_native_batch_norm_add_relu_backward(out4, GY, X, AD, Wt, Bt, RM, RV, sm, si, 1, 1e-5, (C.c_uint8 * 4)(1, 1, 1, 1))
+            return [S.STen(out4[i]) for i in range(4)]
+        out = _out3()
+        if variant == 1:
+            lib.lamp_native_batch_norm_relu_backward(out, GY, X, Wt, Bt, RM, RV, sm, si, 1, 1e-5, _mask3(1, 1, 1))
+        else:
+            lib.lamp_native_batch_norm_backward(out, GY, X, Wt, RM, RV, sm, si, 1, 1e-5, _mask3(1, 1, 1))
+        return list(_wrap3(out))
+
+    lib.lamp_kernel_timer_enable(1)
+    first = backward()
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    if N >= 2048:                                           # the large activations (>= 8 packets per thread); small ones keep the two kernels
+        assert b"bn_bwd_fused" in buf.value and b"bn_bwd_reduce" not in buf.value, buf.value.decode()
+    first_np = [t.to_numpy() for t in first]
+    # reference: f32 arithmetic on the same bf16 values, the mask from the ROUNDED pre-activation as the kernels take it
+    xf, mean, invstd = x.float(), to_torch(sm).float(), to_torch(si).float()
+    g = gy.float()
+    if variant >= 1:
+        pre = ((xf - mean.view(1, -1, 1, 1)) * (invstd * w.float()).view(1, -1, 1, 1) + b.float().view(1, -1, 1, 1)).to(dt)
+        if variant == 2:
+            pre = (pre.float() + addend.float()).to(dt)
+        g = torch.where(pre.float() < 0, torch.zeros_like(g), g)
+    ref = aten.native_batch_norm_backward(g, xf, w.float(), None, None, mean, invstd, True, 1e-5, [True, True, True])
+    for got, want, what in zip(first, ref, ("dx", "dweight", "dbias")):
+        assert_close(to_torch(got), want.double(), 4e-2, what)
+    if variant == 2:
+        assert torch.equal(to_torch(first[3]).float(), g), "the addend's gradient is the masked dy, exactly"
+    for _ in range(5):
+        for a, t in zip(first_np, backward()):
+            assert np.array_equal(a, t.to_numpy()), "a repeated launch differs"
+    # two streams in turn (the host orders the waiting kernels of different streams by an event)
+    side = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(side))
+    dflt = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(dflt))
+    lib.lamp_device_synchronize()
+    try:
+        outs = []
+        for i in range(6):
+            lib.lamp_stream_set_current(side if i % 2 == 0 else dflt)
+            outs.append(backward())
+        lib.lamp_stream_synchronize(side)
+    finally:
+        lib.lamp_stream_set_current(dflt)
+    lib.lamp_device_synchronize()
+    for o in outs:
+        for a, t in zip(first_np, o):
+            assert np.array_equal(a, t.to_numpy()), "a launch on the other stream differs"
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("affine", [(True, True), (True, False), (False, False)])
 def test_layer_norm(gpu, dt, affine):
