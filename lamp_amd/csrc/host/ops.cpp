@@ -68,11 +68,17 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
   // partialDerivative.get.fill_(1d).  A one-element root (every loss) takes a constant kept per (thread, device, dtype, stream)
   // instead of a fill launch per step; it is marked shared, so anything that wanted to modify it in place copies it first.
   if (root->value.numel() == 1) {
-    struct Key { int device, dtype, ndim; lamp_stream* st; bool operator<(const Key& o) const { return std::tie(device, dtype, ndim, st) < std::tie(o.device, o.dtype, o.ndim, o.st); } };
+    struct Key { int device, dtype, ndim; void* st; bool operator<(const Key& o) const { return std::tie(device, dtype, ndim, st) < std::tie(o.device, o.dtype, o.ndim, o.st); } };
     static thread_local std::map<Key, Ten> ones;
-    lamp_stream* cur = nullptr;
-    HCALL(lamp_stream_get_current(root->value.device(), &cur));
-    const Key k{root->value.device(), root->value.dtype(), root->value.ndim(), cur};
+    void* native = nullptr;                                 // the stream the constant was filled on (a handle is a fresh object per call)
+    if (root->value.h()->is_device()) {
+      lamp_stream* cur = nullptr;
+      HCALL(lamp_stream_get_current(root->value.device(), &cur));
+      const int rc = lamp_stream_native(cur, &native);
+      lamp_stream_release(cur);
+      if (rc != 0) throw ::lamp::Error(lamp_last_error());
+    }
+    const Key k{root->value.device(), root->value.dtype(), root->value.ndim(), native};
     auto it = ones.find(k);
     if (it == ones.end()) it = ones.emplace(k, ops::ones_like(root->value)).first;
     root->grad = it->second;

@@ -22,10 +22,14 @@ struct WgradReduceArgs {
 __device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int block, float4 (*red)[32]) {
   const int M = a.COP;
   const int q = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int64_t per_split = (int64_t)a.RS * M * a.CIP / 4;   // float4 elements of one split
-  const int64_t col = (int64_t)block * 32 + q;
+  const int per_split = a.RS * M * a.CIP / 4;                // float4 elements of one split (host: < 2^31)
+  const int col = block * 32 + q;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < per_split) {
+  const int c4 = a.CIP / 4;                                  // a power of two (CIP = 16 or a multiple of 32 ... 128)
+  const int row = col / c4;
+  const int ci = (col - row * c4) * 4, rs = row / M, co = row - rs * M;
+  const bool real = col < per_split && co < a.CO && ci < a.CI;   // padding of the tile: not written by the kernels that skip it, never read here
+  if (real) {
     const float4* p4 = reinterpret_cast<const float4*>(a.partial) + col;
 #pragma unroll 4
     for (int sp = sg; sp < a.nsplit; sp += 8) {
@@ -35,17 +39,13 @@ __device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int
   }
   red[sg][q] = s;
   __syncthreads();
-  if (sg == 0 && col < per_split) {
+  if (sg == 0 && real) {
 #pragma unroll
     for (int g = 1; g < 8; g++) { const float4 v = red[g][q]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-    const int c4 = a.CIP / 4;
-    const int ci = (int)(col % c4) * 4, co = (int)((col / c4) % M), rs = (int)(col / ((int64_t)c4 * M));
-    if (co < a.CO) {
-      const float r[4] = {s.x, s.y, s.z, s.w};
+    const float r[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (ci + k < a.CI) a.dw[((int64_t)co * a.CI + ci + k) * a.RS + rs] = bf16_t(r[k]);
-    }
+    for (int k = 0; k < 4; k++)
+      if (ci + k < a.CI) a.dw[((int64_t)co * a.CI + ci + k) * a.RS + rs] = bf16_t(r[k]);
   }
 }
 
