@@ -17,7 +17,7 @@ import sys
 
 CLASSES = [  # kernel-name regex -> bench.py timer class
     (r"ig_conv8[a-d]?_kernel", "conv_igemm_fprop_dgrad"),
-    (r"ig_wgrad8v2_kernel", "conv_wgrad_igemm"),
+    (r"ig_wgrad8(v2|h)_kernel", "conv_wgrad_igemm"),
     (r"ig_wgrad_reduce_v2_kernel|wgrad_reduce_many_kernel", "conv_wgrad_reduce"),
     (r"ncv_fwd", "conv_narrow_fprop_dgrad"),
     (r"ncv_wgrad2?_kernel", "conv_wgrad_narrow"),
@@ -25,6 +25,7 @@ CLASSES = [  # kernel-name regex -> bench.py timer class
     (r"bn_apply2?_kernel", "bn_fwd_apply"),
     (r"bn_bwd_reduce_kernel", "bn_bwd_reduce"),
     (r"bn_bwd_apply2?_kernel", "bn_bwd_apply"),
+    (r"bn_bwd_fused_kernel", "bn_bwd_fused"),
     (r"ew_vec_kernel", "elementwise"),
     (r"gemm_bf16", "gemm_bf16"),
 ]
