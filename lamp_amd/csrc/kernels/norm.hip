@@ -954,6 +954,7 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
     if (!stt.sync) {
       // zeroed once, on a stream of its own and waited for: st may be capturing, and the counters must be zero in memory before the
       // first launch really runs (whichever stream or graph that is)
+      if (current_device() != xc->device()) return false;     // (callers run with the tensor's device current; the buffer must live there)
       HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + BN_FUSED_SLOTS * sizeof(unsigned long long)));
       hipStream_t side = nullptr;
       HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
