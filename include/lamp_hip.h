@@ -117,6 +117,7 @@ int lamp_kernel_timer_calibrate(double* out_us);
 int lamp_graph_begin_capture(void);
 int lamp_graph_end_capture(lamp_graph** out);
 int lamp_graph_launch(lamp_graph* g);
+int lamp_graph_is_capturing(int* out);   /* 1 between lamp_graph_begin_capture and _end_capture on this thread: work issued now is recorded, not run */
 int lamp_graph_release(lamp_graph* g);
 
 /* ------------------------------------------------------------------------------------------

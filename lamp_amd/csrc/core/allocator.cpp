@@ -89,6 +89,7 @@ void reap_pending(DevicePool& p, bool wait) {
 
 void allocator_begin_capture_pool() { tl_capturing = true; }
 void allocator_end_capture_pool() { tl_capturing = false; }
+bool allocator_capturing() { return tl_capturing; }
 
 void* device_alloc(int device, size_t bytes, void** cookie) {
   LAMP_CHECK(device >= 0 && device < 16, "bad device");

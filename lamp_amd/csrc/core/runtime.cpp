@@ -408,6 +408,11 @@ int lamp_graph_end_capture(lamp_graph** out) {
   *out = lg;
   LAMP_API_END
 }
+int lamp_graph_is_capturing(int* out) {
+  LAMP_API_BEGIN
+  *out = allocator_capturing() ? 1 : 0;
+  LAMP_API_END
+}
 int lamp_graph_launch(lamp_graph* g) {
   LAMP_API_BEGIN
   LAMP_CHECK(g && g->exec, "null graph");

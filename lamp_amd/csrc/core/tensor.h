@@ -174,6 +174,7 @@ void allocator_stats(int device, int64_t* reserved, int64_t* in_use, int64_t* n_
 void allocator_trim(int device);
 void allocator_begin_capture_pool();
 void allocator_end_capture_pool();
+bool allocator_capturing();                 // this thread is between lamp_graph_begin_capture and lamp_graph_end_capture
 
 // ---- runtime (core/runtime.cpp) ----
 int current_device();

@@ -80,9 +80,17 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     }
     const Key k{root->value.device(), root->value.dtype(), root->value.ndim(), native};
     auto it = ones.find(k);
-    if (it == ones.end()) it = ones.emplace(k, ops::ones_like(root->value)).first;
-    root->grad = it->second;
-    root->grad_shared = true;
+    int capturing = 0;
+    if (it == ones.end()) HCALL(lamp_graph_is_capturing(&capturing));
+    if (it == ones.end() && capturing) {
+      // a fill recorded into a graph has not run yet: a constant created here would be handed to later eager passes unfilled
+      root->grad = ops::ones_like(root->value);
+      root->grad_shared = false;
+    } else {
+      if (it == ones.end()) it = ones.emplace(k, ops::ones_like(root->value)).first;
+      root->grad = it->second;
+      root->grad_shared = true;
+    }
   } else {
     root->grad = ops::ones_like(root->value);
     root->grad_shared = false;

@@ -322,3 +322,37 @@ def test_hip_graph_replays_the_gradient_computation(gpu):
     finally:
         d = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(d)); lib.lamp_stream_set_current(d)
         lib.lamp_stream_release(st); lib.lamp_stream_release(d)
+
+
+@pytest.mark.gpu
+def test_backprop_recorded_into_a_graph_does_not_poison_later_eager_passes(gpu):
+    """The gradient of a one-element loss starts from a cached constant 1 (per thread, device, dtype, stream).  A capture must not
+    create that constant: its fill would only be RECORDED, and an eager backprop on the same stream before the first replay would
+    start from uninitialised memory.  Here the very first backprop on a fresh stream in f64 happens inside a capture, the graph is
+    never launched, and the eager pass that follows must still give the reference gradient."""
+    import ctypes as C
+    from lamp_amd import autograd as AG
+    from lamp_amd._capi import lib
+    x = O.closed_form(24, 3, 2.0, torch.float64).reshape(4, 6)
+    st = C.c_void_p(); lib.lamp_stream_get_from_pool(1, 0, C.byref(st)); lib.lamp_stream_set_current(st)   # a stream no other test computes f64 losses on
+    try:
+        X = to_sten(x)                                         # uploads synchronise: not inside a capture
+
+        def loss_and_grad():
+            v = AG.param(X)
+            (v * v).sum().backprop()
+            return v.partialDerivative
+        lib.lamp_device_synchronize()
+        lib.lamp_graph_begin_capture()
+        recorded = loss_and_grad()
+        g = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(g))
+        eager = loss_and_grad()                                 # the graph has not been launched
+        lib.lamp_device_synchronize()
+        assert_close(to_torch(eager), (2 * x).double(), 1e-12, "eager gradient after a capture")
+        lib.lamp_graph_launch(g)
+        lib.lamp_device_synchronize()
+        assert_close(to_torch(recorded), (2 * x).double(), 1e-12, "gradient of the replayed graph")
+        lib.lamp_graph_release(g)
+    finally:
+        d = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(d)); lib.lamp_stream_set_current(d)
+        lib.lamp_stream_release(st); lib.lamp_stream_release(d)
