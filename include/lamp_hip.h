@@ -468,6 +468,12 @@ int lamp_native_layer_norm_backward(lamp_tensor* out3[3] /* dx, dweight, dbias *
  * ------------------------------------------------------------------------------------------ */
 int lamp_log_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
 int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* output, int64_t dim);
+/* avg_pool2d(kernel = H = W) -> flatten -> log_softmax(dim 1) of [N, C, H, W] as one operator with the values of the three calls
+ * (each stage rounded to the dtype): the tail of Cnn.resnet (cnn.scala:129-136).  One kernel where the planes are whole 16-byte
+ * packets, the three calls otherwise.  _backward: grad and output are [N, C], x only gives the shape. */
+int lamp_global_avg_pool_log_softmax(lamp_tensor** out, const lamp_tensor* x);
+int lamp_global_avg_pool_log_softmax_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output,
+                                              const lamp_tensor* x);
 int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
 int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
                           const lamp_tensor* target /* i64 [N] */, const lamp_tensor* weight_or_null,

@@ -97,6 +97,16 @@ Var Sequential::forward(const Var& x) {
         i++;
         continue;
       }
+      // Fun(avgpool2d over the whole map) -> Fun(flatten the last three dims) -> Fun(logsoftmax over dim 1): one node, values of the chain
+      auto* pool = dynamic_cast<Fun*>(mods[i].get());
+      auto* lsm = i + 2 < mods.size() ? dynamic_cast<Fun*>(mods[i + 2].get()) : nullptr;
+      static const bool fuse_tail = [] { const char* e = getenv("LAMP_FUSE_POOL_LOGSOFTMAX"); return !(e && e[0] == '0'); }();
+      if (fuse_tail && pool && fn && lsm && pool->tag == "avgpool2d" && fn->tag == "flatten_last" && fn->a == 3 && lsm->tag == "logsoftmax" && lsm->a == 1 &&
+          v->value.ndim() == 4 && v->value.size(2) == (int64_t)pool->a && v->value.size(3) == (int64_t)pool->a && v->value.h()->is_device()) {
+        v = F::global_avg_pool_log_softmax(v);
+        i += 2;
+        continue;
+      }
     }
     v = mods[i]->forward(v);
   }
@@ -117,10 +127,10 @@ Mod make_fun(const std::string& name, double a, double b) {
   if (name == "tanh") return std::make_shared<Fun>([](const Var& x) { return F::tanh(x); });
   if (name == "hardswish") return std::make_shared<Fun>([](const Var& x) { return F::hardswish(x); });
   if (name == "swish1") return std::make_shared<Fun>([](const Var& x) { return F::mult(x, F::sigmoid(x)); });
-  if (name == "logsoftmax") return std::make_shared<Fun>([a](const Var& x) { return F::log_softmax(x, (int64_t)a); });
-  if (name == "avgpool2d") return std::make_shared<Fun>([a, b](const Var& x) { return F::avg_pool2d(x, (int64_t)a, (int64_t)b, 0); });
+  if (name == "logsoftmax") return std::make_shared<Fun>([a](const Var& x) { return F::log_softmax(x, (int64_t)a); }, "logsoftmax", a);
+  if (name == "avgpool2d") return std::make_shared<Fun>([a, b](const Var& x) { return F::avg_pool2d(x, (int64_t)a, (int64_t)b, 0); }, "avgpool2d", a, b);
   if (name == "maxpool2d") return std::make_shared<Fun>([a, b](const Var& x) { return F::max_pool2d(x, (int64_t)a, (int64_t)b, 0, 1); });
-  if (name == "flatten_last") return std::make_shared<Fun>([a](const Var& x) { return F::flatten(x, x->value.ndim() - (int64_t)a, -1); });
+  if (name == "flatten_last") return std::make_shared<Fun>([a](const Var& x) { return F::flatten(x, x->value.ndim() - (int64_t)a, -1); }, "flatten_last", a);
   LAMP_CHECK(false, "unknown Fun module '" << name << "'");
   return nullptr;
 }

@@ -85,8 +85,11 @@ struct Dropout : Module {       // nn/Dropout.scala:6-8 (skips the op when p <= 
 };
 struct Fun : Module {           // nn `Fun(scope => input => ...)`
   std::function<Var(const Var&)> f;
-  std::string tag;              // "relu" for the plain relu: lets Sequential fuse BatchNorm2D -> relu
-  explicit Fun(std::function<Var(const Var&)> f_, std::string tag_ = "") : f(std::move(f_)), tag(std::move(tag_)) {}
+  std::string tag;              // "relu" for the plain relu: lets Sequential fuse BatchNorm2D -> relu; "avgpool2d" / "flatten_last" /
+                                // "logsoftmax" (with their arguments in a, b): the tail of Cnn.resnet runs as one kernel
+  double a = 0, b = 0;
+  explicit Fun(std::function<Var(const Var&)> f_, std::string tag_ = "", double a_ = 0, double b_ = 0)
+      : f(std::move(f_)), tag(std::move(tag_)), a(a_), b(b_) {}
   void collect_state(std::vector<Var>&) override {}
   Var forward(const Var& x) override { return f(x); }
 };

@@ -623,6 +623,21 @@ Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding) {
   HCALL(lamp_avg_pool2d(&o, iv.h(), k, stride, padding, 0, 1));
   return make_result(op, Ten(o));
 }
+// AvgPool2D over the whole map -> Flatten -> LogSoftMax as one node (the closures of the three, composed)
+Var global_avg_pool_log_softmax(const Var& input) {
+  LAMP_CHECK(input->value.ndim() == 4, "Input dimensions must be 4");
+  auto op = new_op("GlobalAvgPoolLogSoftMax");
+  Ten iv = input->value;
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_global_avg_pool_log_softmax(&o, iv.h()));
+  Ten val(o);
+  op->params.push_back({input, [iv, val](const Ten& p, Variable& out) {
+    lamp_tensor* t = nullptr;
+    HCALL(lamp_global_avg_pool_log_softmax_backward(&t, p.h(), val.h(), iv.h()));
+    out.accumulate(Ten(t), true);
+  }});
+  return make_result(op, val);
+}
 Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation) {
   LAMP_CHECK(input->value.ndim() == 4, "Input dimensions must be 4");
   auto op = new_op("MaxPool2D");

@@ -51,6 +51,7 @@ Var convolution(const Var& input, const Var& weight, const Var& bias, const std:
                 const std::vector<int64_t>& outputPadding, int64_t groups);
 Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding);
 Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation);
+Var global_avg_pool_log_softmax(const Var& input);   // avg_pool2d(k = H = W) -> flatten -> log_softmax(1) in one launch, values of the chain
 Var batch_norm(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,
                double momentum, double eps);
 Var batch_norm_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, bool training,

@@ -18,18 +18,11 @@ template <> __device__ __forceinline__ float t_log1p(float x) { return log1pf(x)
 template <class A> __device__ __forceinline__ A t_log(A x) { return (A)log((double)x); }
 template <> __device__ __forceinline__ float t_log(float x) { return logf(x); }
 
-// x viewed as [outer, D, inner]; one wave per (outer, inner) pair. LOG: log-softmax else softmax.
+// One wave, one row of D elements with stride `inner`: the arithmetic of (log-)softmax and of its backward, shared by the row
+// kernels below and by the kernels that fuse a global average pool in front (gap_lsm_*): same order, same values.
 template <class T, bool LOG>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t outer, int64_t D,
-                                                          int64_t inner) {
+__device__ __forceinline__ void softmax_row(const T* xp, T* yp, int64_t D, int64_t inner, int64_t out_inner, int lane) {
   using A = acc_t<T>;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nrows = outer * inner;
-  if (wave >= nrows) return;
-  const int64_t o = wave / inner, i = wave - o * inner;
-  const T* xp = x + o * D * inner + i;
-  T* yp = y + o * D * inner + i;
   A m = -INFINITY;
   for (int64_t d = lane; d < D; d += 64) { A v = load_as<A>(xp[d * inner]); m = v > m ? v : m; }
   m = wave_max(m);
@@ -38,10 +31,79 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ 
   s = wave_sum(s);
   if (LOG) {
     const A ls = t_log<A>(s);
-    for (int64_t d = lane; d < D; d += 64) yp[d * inner] = store_as<T>((A)(load_as<A>(xp[d * inner]) - m - ls));
+    for (int64_t d = lane; d < D; d += 64) yp[d * out_inner] = store_as<T>((A)(load_as<A>(xp[d * inner]) - m - ls));
   } else {
     const A inv = A(1) / s;
-    for (int64_t d = lane; d < D; d += 64) yp[d * inner] = store_as<T>((A)(t_exp<A>(load_as<A>(xp[d * inner]) - m) * inv));
+    for (int64_t d = lane; d < D; d += 64) yp[d * out_inner] = store_as<T>((A)(t_exp<A>(load_as<A>(xp[d * inner]) - m) * inv));
+  }
+}
+// grad_in = grad - exp(output) * sum(grad)
+template <class T>
+__device__ __forceinline__ void log_softmax_bwd_row(const T* g, const T* out, T* gi, int64_t D, int64_t inner, int64_t gi_inner, int lane) {
+  using A = acc_t<T>;
+  A s = 0;
+  for (int64_t d = lane; d < D; d += 64) s += load_as<A>(g[d * inner]);
+  s = wave_sum(s);
+  for (int64_t d = lane; d < D; d += 64) gi[d * gi_inner] = store_as<T>((A)(load_as<A>(g[d * inner]) - t_exp<A>(load_as<A>(out[d * inner])) * s));
+}
+
+// x viewed as [outer, D, inner]; one wave per (outer, inner) pair. LOG: log-softmax else softmax.
+template <class T, bool LOG>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t outer, int64_t D,
+                                                          int64_t inner) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nrows = outer * inner;
+  if (wave >= nrows) return;
+  const int64_t o = wave / inner, i = wave - o * inner;
+  softmax_row<T, LOG>(x + o * D * inner + i, y + o * D * inner + i, D, inner, inner, lane);
+}
+
+// ---- global average pool + flatten + log-softmax in one kernel (the tail of Cnn.resnet, cnn.scala:129-136) ---------------------------
+// Workgroup = image.  The planes are pooled exactly as avg_pool_global_fwd_vec_kernel pools them (lpp lanes per plane, a sequential sum
+// of the packet's elements, a butterfly over the plane's lanes, one rounding to T), the rounded means go to LDS and the first wave runs
+// softmax_row over them: the values of the three-operator chain, two launches and one [N, C] round trip less.  The backward does the
+// same in reverse: log_softmax_bwd_row into LDS, divided by the plane size and rounded as avg_pool_global_bwd_vec_kernel does, then
+// broadcast over the planes in 16-byte packets.
+template <class T>
+__global__ __launch_bounds__(256) void gap_lsm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int C, int hw, int lpp) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* pl = reinterpret_cast<T*>(smem);
+  const int64_t n = blockIdx.x;
+  const int tid = threadIdx.x, ppp = 256 / lpp, sub = tid % lpp;
+  for (int c0 = 0; c0 < C; c0 += ppp) {
+    const int c = c0 + tid / lpp;
+    A s = 0;
+    if (c < C) {
+      const Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + ((n * C + c) * lpp + sub) * W);
+#pragma unroll
+      for (int k = 0; k < W; k++) s += load_as<A>(pk.v[k]);
+    }
+    for (int off = lpp >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (c < C && sub == 0) pl[c] = store_as<T>((A)(s / (A)hw));
+  }
+  __syncthreads();
+  if (tid < 64) softmax_row<T, true>(pl, y + n * C, C, 1, 1, tid);
+}
+template <class T>
+__global__ __launch_bounds__(256) void gap_lsm_bwd_kernel(const T* __restrict__ g, const T* __restrict__ out, T* __restrict__ dx, int C, int hw, int lpp) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* gl = reinterpret_cast<T*>(smem);
+  const int64_t n = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < 64) log_softmax_bwd_row<T>(g + n * C, out + n * C, gl, C, 1, 1, tid);
+  __syncthreads();
+  const int packets = C * lpp;
+  for (int p = tid; p < packets; p += 256) {
+    const T v = store_as<T>((A)(load_as<A>(gl[p / lpp]) / (A)hw));
+    Vec<T, W> pk;
+#pragma unroll
+    for (int k = 0; k < W; k++) pk.v[k] = v;
+    *reinterpret_cast<Vec<T, W>*>(dx + (n * packets + p) * W) = pk;
   }
 }
 
@@ -141,19 +203,12 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_vec_kernel(const T* __res
 template <class T>
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restrict__ g, const T* __restrict__ out, T* __restrict__ gi,
                                                               int64_t outer, int64_t D, int64_t inner) {
-  using A = acc_t<T>;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (wave >= outer * inner) return;
   const int64_t o = wave / inner, i = wave - o * inner;
   const int64_t base = o * D * inner + i;
-  A s = 0;
-  for (int64_t d = lane; d < D; d += 64) s += load_as<A>(g[base + d * inner]);
-  s = wave_sum(s);
-  for (int64_t d = lane; d < D; d += 64) {
-    const int64_t k = base + d * inner;
-    gi[k] = store_as<T>((A)(load_as<A>(g[k]) - t_exp<A>(load_as<A>(out[k])) * s));
-  }
+  log_softmax_bwd_row<T>(g + base, out + base, gi + base, D, inner, inner, lane);
 }
 
 // ---- NLL ---------------------------------------------------------------------------------------
@@ -312,6 +367,71 @@ extern "C" {
 
 int lamp_log_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim) { LAMP_API_BEGIN *out = softmax_impl<true>(x, dim); LAMP_API_END }
 int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim) { LAMP_API_BEGIN *out = softmax_impl<false>(x, dim); LAMP_API_END }
+
+// lanes per plane for the packet form (as pool.hip's global_pool_lanes), 0: the operators run as the three-call chain
+static int gap_lsm_lanes(const lamp_tensor* x) {
+  if (!x->is_device() || x->ndim != 4 || !x->is_contiguous() || x->numel() == 0) return 0;
+  if (x->dtype != kBF16 && x->dtype != kF16 && x->dtype != kF32 && x->dtype != kF64) return 0;
+  const int64_t C = x->sizes[1], hw = x->sizes[2] * x->sizes[3];
+  const int64_t D = C, W = 16 / x->itemsize();
+  if (D % W == 0 && D >= 64 * W / 2) return 0;            // the chain would take the packet row kernels there (another summation order)
+  const int64_t bytes = hw * x->itemsize();
+  if (bytes % 16 != 0 || C > 8192) return 0;
+  const int64_t lpp = bytes / 16;
+  if (lpp < 1 || lpp > 64 || (lpp & (lpp - 1)) != 0) return 0;
+  if (((uintptr_t)x->data() & 15) != 0) return 0;
+  return (int)lpp;
+}
+int lamp_global_avg_pool_log_softmax(lamp_tensor** out, const lamp_tensor* x) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(x != nullptr && x->ndim == 4, "global_avg_pool_log_softmax expects [N, C, H, W]");
+  LAMP_CHECK(x->sizes[2] == x->sizes[3], "global_avg_pool_log_softmax: square maps only (avg_pool2d takes one kernel size), got " << x->describe());
+  const int lpp = gap_lsm_lanes(x);
+  if (!lpp) {                                               // avg_pool2d(k = H) -> flatten -> log_softmax(dim 1)
+    lamp_tensor *p = nullptr, *f = nullptr;
+    if (lamp_avg_pool2d(&p, x, x->sizes[2], 1, 0, 0, 1) != 0) throw Error(lamp_last_error());
+    Hold ph(p);
+    int64_t fs[2] = {x->sizes[0], x->sizes[1]};
+    if (lamp_reshape(&f, p, fs, 2) != 0) throw Error(lamp_last_error());
+    Hold fh(f);
+    if (lamp_log_softmax(out, f, 1) != 0) throw Error(lamp_last_error());
+    return 0;
+  }
+  int64_t ys[2] = {x->sizes[0], x->sizes[1]};
+  Hold y(new_tensor(ys, 2, x->dtype, x->device()));
+  const int C = (int)x->sizes[1], hw = (int)(x->sizes[2] * x->sizes[3]);
+  LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((gap_lsm_fwd_kernel<T>), dim3((unsigned)x->sizes[0]), dim3(256), (size_t)C * sizeof(T), current_stream(x->device()),
+                                                      x->ptr<T>(), y->ptr<T>(), C, hw, lpp));
+  LAMP_LAUNCH_CHECK();
+  *out = y.take();
+  LAMP_API_END
+}
+int lamp_global_avg_pool_log_softmax_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output, const lamp_tensor* x) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(x != nullptr && x->ndim == 4 && grad && output, "global_avg_pool_log_softmax_backward: bad arguments");
+  LAMP_CHECK(grad->ndim == 2 && grad->sizes[0] == x->sizes[0] && grad->sizes[1] == x->sizes[1] && grad->shape() == output->shape() &&
+             grad->dtype == x->dtype && output->dtype == x->dtype,
+             "global_avg_pool_log_softmax_backward: grad " << grad->describe() << " / output " << output->describe() << " do not match input " << x->describe());
+  const int lpp = (grad->is_device() && output->is_device()) ? gap_lsm_lanes(x) : 0;
+  if (!lpp) {
+    lamp_tensor *gi = nullptr, *g4 = nullptr;
+    if (lamp_log_softmax_backward_data(&gi, grad, output, 1) != 0) throw Error(lamp_last_error());
+    Hold gih(gi);
+    int64_t s4[4] = {x->sizes[0], x->sizes[1], 1, 1};
+    if (lamp_reshape(&g4, gi, s4, 4) != 0) throw Error(lamp_last_error());
+    Hold g4h(g4);
+    if (lamp_avg_pool2d_backward(out, g4, x, x->sizes[2], 1, 0, 0, 1) != 0) throw Error(lamp_last_error());
+    return 0;
+  }
+  Hold gc(contiguous(grad)), oc(contiguous(output));
+  Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
+  const int C = (int)x->sizes[1], hw = (int)(x->sizes[2] * x->sizes[3]);
+  LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((gap_lsm_bwd_kernel<T>), dim3((unsigned)x->sizes[0]), dim3(256), (size_t)C * sizeof(T), current_stream(x->device()),
+                                                      static_cast<const Tensor*>(gc.get())->ptr<T>(), static_cast<const Tensor*>(oc.get())->ptr<T>(), dx->ptr<T>(), C, hw, lpp));
+  LAMP_LAUNCH_CHECK();
+  *out = dx.take();
+  LAMP_API_END
+}
 
 int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output, int64_t dim) {
   LAMP_API_BEGIN

@@ -864,6 +864,42 @@ def test_igemm_pack_cache_sees_every_weight_write(gpu, cin, cout, hw, stride):
     check(to_torch(W).to(dt), "after a second optimiser step (images re-packed in place)")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(64, 100, 8, 8), (2048, 100, 8, 8), (5, 10, 4, 4), (7, 33, 16, 16), (3, 256, 8, 8), (4, 12, 7, 7), (2, 6, 2, 2)])
+def test_global_avg_pool_log_softmax_is_bitwise_the_three_call_chain(gpu, dt, shape):
+    """lamp_global_avg_pool_log_softmax(+_backward) = avg_pool2d(k = H) -> flatten -> log_softmax(1) and its backward, BITWISE: one
+    kernel per direction where the planes are whole 16-byte packets (the tail of Cnn.resnet: cnn.scala:129-136), the three calls
+    otherwise (7x7 maps, 256-wide rows that the packet row kernels would serve, 2x2 f32 maps)."""
+    if shape[0] == 2048 and dt != torch.bfloat16:
+        pytest.skip("the large case only in the benchmark's dtype")
+    N, Cc, H, _ = shape
+    x = closed_form(shape, 3, 6.0, dt)
+    gy = closed_form((N, Cc), 11, 2.0, dt)
+    X, GY = to_sten(x), to_sten(gy)
+    p = C.c_void_p(); lib.lamp_avg_pool2d(C.byref(p), X, H, 1, 0, 0, 1)
+    P = S.STen(p)
+    f = C.c_void_p(); lib.lamp_reshape(C.byref(f), P, i64_array([N, Cc]), 2)
+    F_ = S.STen(f)
+    l = C.c_void_p(); lib.lamp_log_softmax(C.byref(l), F_, 1)
+    L = S.STen(l)
+    o = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax(C.byref(o), X)
+    Ofused = S.STen(o)
+    assert Ofused.shape == [N, Cc]
+    assert np.array_equal(Ofused.to_numpy(), L.to_numpy()), "forward differs from the chain"
+    ref = torch.log_softmax(x.double().mean(dim=(2, 3)), dim=1)
+    assert_close(to_torch(Ofused), ref, {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 3e-2}[dt], "forward vs f64")
+    gi = C.c_void_p(); lib.lamp_log_softmax_backward_data(C.byref(gi), GY, L, 1)
+    GI = S.STen(gi)
+    g4 = C.c_void_p(); lib.lamp_reshape(C.byref(g4), GI, i64_array([N, Cc, 1, 1]), 4)
+    G4 = S.STen(g4)
+    dxc = C.c_void_p(); lib.lamp_avg_pool2d_backward(C.byref(dxc), G4, X, H, 1, 0, 0, 1)
+    DXc = S.STen(dxc)
+    dxf = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax_backward(C.byref(dxf), GY, Ofused, X)
+    DXf = S.STen(dxf)
+    assert DXf.shape == list(shape)
+    assert np.array_equal(DXf.to_numpy(), DXc.to_numpy()), "backward differs from the chain"
+
+
 # (N, Cin, H, Cout, k, stride, pad, dtype, fused?)  fused = the dgrad kernel has the accumulate epilogue for this geometry
 DGRAD_ADD_CASES = [
     (1024, 128, 8, 128, 3, 1, 1, torch.bfloat16, True),     # eight-image implicit GEMM, 8 channel tiles
