@@ -478,6 +478,11 @@ int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
 int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
                           const lamp_tensor* target /* i64 [N] */, const lamp_tensor* weight_or_null,
                           int64_t reduction, int64_t ignore_index);
+/* the same, and acc += scale * loss in the same launch (acc: one element of x's dtype; reduction mean or sum): lamp's epoch-loss
+ * bookkeeping `acc += loss * numExamples` (IOLoops.scala:714), with the arithmetic of lamp_add_ on the rounded loss */
+int lamp_nll_loss_forward_accumulate_(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
+                                      const lamp_tensor* target, const lamp_tensor* weight_or_null, int64_t reduction,
+                                      int64_t ignore_index, lamp_tensor* acc, double scale);
 int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
                            const lamp_tensor* target, const lamp_tensor* weight_or_null, int64_t reduction,
                            int64_t ignore_index, const lamp_tensor* total_weight);

@@ -273,9 +273,22 @@ std::pair<Var, int64_t> SupervisedModel::loss(const Var& output, const Ten& targ
   if (loss_kind == 1) return {F::mse_loss(output, target, 1), output->value.size(0)};
   return {output, target.size(0)};
 }
+// NLL on the device with an accumulator of the loss's dtype: `acc += n * loss` rides in the loss kernel (one launch less per step)
+static bool loss_accumulates_in_kernel(const SupervisedModel& m, const Var& output, const Ten& acc) {
+  static const bool on = [] { const char* e = getenv("LAMP_FUSE_LOSS_ACCUMULATE"); return !(e && e[0] == '0'); }();
+  return on && m.loss_kind == 0 && m.reduction != 0 && acc.defined() && acc.h()->is_device() && output->value.h()->is_device() &&
+         acc.dtype() == output->value.dtype() && acc.numel() == 1 && acc.device() == output->value.device() && output->value.ndim() == 2;
+}
 int64_t SupervisedModel::addTotalLossAndReturnGradientsAndNumExamples(const Ten& samples, const Ten& target, const Ten& acc, bool zeroGrad,
                                                                       std::vector<Ten>* gradients) {
   Var output = run_module(*this, samples, target);            // BatchStream emits const(features) (BatchStream.scala:562)
+  if (loss_accumulates_in_kernel(*this, output, acc)) {
+    const int64_t n = output->value.size(0);
+    Var l = F::nll_loss_accumulate(output, target, classWeights, reduction, ignore, acc, (double)n);
+    std::vector<Ten> g = module->gradients(l, zeroGrad);
+    if (gradients) *gradients = g;
+    return n;
+  }
   auto ln = loss(output, target);
   std::vector<Ten> g = module->gradients(ln.first, zeroGrad);
   accumulate_loss(acc, ln.first->value, ln.second);

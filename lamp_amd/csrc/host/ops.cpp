@@ -468,11 +468,16 @@ Var dropout(const Var& a, double prob, bool train) {   // ops.scala:1079-1100
 
 // ---- losses (ops.scala:1176-1304) ---------------------------------------------------------------
 Var nll_loss(const Var& input, const Ten& target, const Ten& weights, int64_t reduction, int64_t ignore) {
+  return nll_loss_accumulate(input, target, weights, reduction, ignore, Ten(), 0.0);
+}
+// acc (optional): acc += scale * loss in the loss kernel's launch (the caller's epoch-loss bookkeeping, IOLoops.scala:714)
+Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights, int64_t reduction, int64_t ignore, const Ten& acc, double scale) {
   LAMP_CHECK(input->value.ndim() == 2, "Nll Loss assumes 2D input (samples x classes). Higher dimensions not implemented.");
   LAMP_CHECK(target.ndim() == 1, "Target should be a 1D tensor with [0,C-1] integers, C number of classes.");
   auto op = new_op("NllLoss");
   lamp_tensor *v = nullptr, *tw = nullptr;
-  HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
+  if (acc.defined()) HCALL(lamp_nll_loss_forward_accumulate_(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.h(), scale));
+  else HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
   Ten val(v), total_weight(tw), iv = input->value;
   op->params.push_back({input, [=](const Ten& p, Variable& out) {
     lamp_tensor* t = nullptr;

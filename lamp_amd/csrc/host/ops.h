@@ -40,6 +40,7 @@ Var softplus(const Var& a, double beta, double threshold);
 Var log_softmax(const Var& a, int64_t dim);
 Var dropout(const Var& a, double prob, bool train);
 Var nll_loss(const Var& input, const Ten& target, const Ten& weights, int64_t reduction = 1, int64_t ignore = -100);
+Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights, int64_t reduction, int64_t ignore, const Ten& acc, double scale);
 Var mse_loss(const Var& input, const Ten& target, int64_t reduction = 1);
 Var index_select(const Var& input, int64_t dim, const Var& index);
 Var mask_fill(const Var& input, const Ten& mask, double fill);   // MaskFill (ops.scala:148-159)

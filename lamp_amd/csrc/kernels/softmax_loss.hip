@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restric
 template <class T>
 __global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restrict__ x, const int64_t* __restrict__ target,
                                                               const T* __restrict__ w, T* __restrict__ out, T* __restrict__ total_weight,
-                                                              int64_t N, int64_t C, int64_t reduction, int64_t ignore, int* __restrict__ assert_word) {
+                                                              int64_t N, int64_t C, int64_t reduction, int64_t ignore, int* __restrict__ assert_word,
+                                                              T* acc, double acc_scale) {
   using A = acc_t<T>;
   __shared__ A sm[16];
   A loss = 0, tw = 0;
@@ -232,8 +233,10 @@ __global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restric
   tw = block_sum(tw, sm);
   if (threadIdx.x == 0) {
     *total_weight = store_as<T>(tw);
-    if (reduction == 1) *out = store_as<T>((A)(loss / tw));
-    else *out = store_as<T>(loss);
+    const T o = reduction == 1 ? store_as<T>((A)(loss / tw)) : store_as<T>(loss);
+    *out = o;
+    // the epoch-loss bookkeeping `acc += n * loss` (IOLoops.scala:714) in the same launch: the arithmetic of the add kernel on the ROUNDED loss
+    if (acc) *acc = store_as<T>((A)(load_as<A>(*acc) + (A)acc_scale * load_as<A>(o)));
   }
 }
 template <class T>
@@ -469,10 +472,27 @@ static void nll_check(const lamp_tensor* x, const lamp_tensor* target, const lam
   }
 }
 
+static int nll_forward_impl(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x, const lamp_tensor* target, const lamp_tensor* weight,
+                            int64_t reduction, int64_t ignore_index, lamp_tensor* acc, double acc_scale);
 int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x, const lamp_tensor* target,
                           const lamp_tensor* weight, int64_t reduction, int64_t ignore_index) {
+  return nll_forward_impl(out, total_weight, x, target, weight, reduction, ignore_index, nullptr, 0.0);
+}
+int lamp_nll_loss_forward_accumulate_(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x, const lamp_tensor* target,
+                                      const lamp_tensor* weight, int64_t reduction, int64_t ignore_index, lamp_tensor* acc, double scale) {
+  if (!acc) { set_last_error("nll_loss_forward_accumulate_: null accumulator"); return 1; }
+  return nll_forward_impl(out, total_weight, x, target, weight, reduction, ignore_index, acc, scale);
+}
+static int nll_forward_impl(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x, const lamp_tensor* target, const lamp_tensor* weight,
+                            int64_t reduction, int64_t ignore_index, lamp_tensor* acc, double acc_scale) {
   LAMP_API_BEGIN
   nll_check(x, target, weight);
+  if (acc) {
+    check_device_tensor(acc, "accumulator");
+    LAMP_CHECK(reduction != 0 && acc->numel() == 1 && acc->dtype == x->dtype && acc->device() == x->device(),
+               "nll_loss_forward_accumulate_: the accumulator must be a one-element tensor of the input's dtype on its device (and the reduction mean or sum), got "
+                   << acc->describe());
+  }
   LAMP_CHECK(reduction >= 0 && reduction <= 2, "bad reduction " << reduction);
   Hold xc(contiguous(x)), tc(contiguous(target));
   Hold wc(weight ? contiguous(weight) : nullptr);
@@ -495,7 +515,7 @@ int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const l
     Hold o(new_tensor(nullptr, 0, x->dtype, x->device()));
     LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_reduce_kernel<T>), dim3(1), dim3(1024), 0, st, xc->ptr<T>(),
                                                         tc->ptr<int64_t>(), wc.get() ? wc->ptr<T>() : (const T*)nullptr, o->ptr<T>(),
-                                                        tw->ptr<T>(), N, C, reduction, ignore_index, aw));
+                                                        tw->ptr<T>(), N, C, reduction, ignore_index, aw, acc ? acc->ptr<T>() : (T*)nullptr, acc_scale));
     LAMP_LAUNCH_CHECK();
     *out = o.take();
   }

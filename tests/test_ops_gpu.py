@@ -865,6 +865,33 @@ def test_igemm_pack_cache_sees_every_weight_write(gpu, cin, cout, hw, stride):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("reduction", [1, 2])
+def test_nll_loss_forward_accumulates_the_epoch_loss_in_its_launch(gpu, dt, reduction):
+    """lamp_nll_loss_forward_accumulate_ = lamp_nll_loss_forward followed by acc.add_(loss, alpha = n) (IOLoops.scala:714), bitwise:
+    loss, total weight and the accumulator; the accumulator's dtype and size are checked."""
+    N, Cc = 257, 10
+    x = torch.log_softmax(closed_form((N, Cc), 3, 4.0, dt).double(), 1).to(dt)
+    t = (torch.arange(N) * 7) % Cc
+    t[5] = -100
+    w = closed_form((Cc,), 9, 1.0, dt) + 1.0
+    X, Tt, Wt = to_sten(x), to_sten(t), to_sten(w)
+    acc0 = closed_form((1,), 21, 8.0, dt)
+    o, tw = C.c_void_p(), C.c_void_p()
+    lib.lamp_nll_loss_forward(C.byref(o), C.byref(tw), X, Tt, Wt, reduction, -100)
+    L, TW = S.STen(o), S.STen(tw)
+    A1 = to_sten(acc0)
+    lib.lamp_add_(A1, L.reshape(1), float(N))
+    A2 = to_sten(acc0)
+    o2, tw2 = C.c_void_p(), C.c_void_p()
+    lib.lamp_nll_loss_forward_accumulate_(C.byref(o2), C.byref(tw2), X, Tt, Wt, reduction, -100, A2, float(N))
+    L2, TW2 = S.STen(o2), S.STen(tw2)
+    assert np.array_equal(L2.to_numpy(), L.to_numpy()) and np.array_equal(TW2.to_numpy(), TW.to_numpy())
+    assert np.array_equal(A2.to_numpy(), A1.to_numpy()), (A2.to_numpy(), A1.to_numpy())
+    with pytest.raises(Exception, match="one-element tensor of the input's dtype"):
+        lib.lamp_nll_loss_forward_accumulate_(C.byref(o2), C.byref(tw2), X, Tt, Wt, reduction, -100, to_sten(closed_form((2,), 1, 1.0, dt)), 1.0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(64, 100, 8, 8), (2048, 100, 8, 8), (5, 10, 4, 4), (7, 33, 16, 16), (3, 256, 8, 8), (4, 12, 7, 7), (2, 6, 2, 2)])
 def test_global_avg_pool_log_softmax_is_bitwise_the_three_call_chain(gpu, dt, shape):
     """lamp_global_avg_pool_log_softmax(+_backward) = avg_pool2d(k = H) -> flatten -> log_softmax(1) and its backward, BITWISE: one
