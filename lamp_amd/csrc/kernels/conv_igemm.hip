@@ -736,7 +736,12 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       for (int k = 0; k < 8; k++) {
         const int c = ch * 32 + cg * 8 + k;
         rw[k] = make_uint4(0, 0, 0, 0);
-        if (c < CI && n < N) rw[k] = *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+        // fprop (statistics wanted): the input is not read again before the backward pass - streamed, the caches are for the output the
+        // batch norm reads next; dgrad: dY is what the weight-gradient kernel reads right after this one - cached
+        if (c < CI && n < N) {
+          const uint4* src = reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+          rw[k] = stats ? nt_load16(src) : *src;
+        }
       }
       char* xi = Xl + ch * XBUF + img * XIMG;
 #pragma unroll
@@ -1207,7 +1212,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int co = wq * 32 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
-        if (co < CO && ci < CI) out[co * CIP + ci] = acc[t][i][rr];   // padding rows / columns: never read by the reduction (100 of 128: 39 % of the tile)
+        // padding rows / columns: never read by the reduction (100 of 128: 39 % of the tile).  Streaming stores: 113 MB of partial sums per
+        // step that nobody reads before the end of backprop must not push the activations out of L2 / Infinity Cache
+        if (co < CO && ci < CI) __builtin_nontemporal_store(acc[t][i][rr], &out[co * CIP + ci]);
       }
   }
 }

@@ -46,6 +46,19 @@ __device__ __forceinline__ uint4 add_bf16x8(const uint4& a, const uint4& b) {
   return make_uint4(add_bf16x2(a.x, b.x), add_bf16x2(a.y, b.y), add_bf16x2(a.z, b.z), add_bf16x2(a.w, b.w));
 }
 
+// 16-byte load / store with the non-temporal hint: data that is read exactly once (or written for a reader far in the future) should not
+// displace what the next kernels will find in L2 / Infinity Cache
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store16(uint4* p, const uint4& v) {
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  const nt_u4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_u4*>(p));
+}
+
 // f16 (IEEE half) storage type: lamp's HalfPrecision (STen.scala:726-731 scalar-type byte 5; AdamW's mixed-precision KAT runs on it,
 // adamw.test.scala:96-127).  Arithmetic happens in f32 (acc_t), the conversions are the hardware's round-to-nearest-even casts.
 struct alignas(2) f16_t {

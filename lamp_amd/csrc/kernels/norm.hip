@@ -265,9 +265,10 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
     for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
       const int64_t n = i / vpp, v = i - n * vpp;
       const int64_t base = (n * C + c) * HW + v * W;
-      Vec<T, W> pk = *reinterpret_cast<const Vec<T, W>*>(x + base);
-      Vec<T, W> ad;
-      if (addend) ad = *reinterpret_cast<const Vec<T, W>*>(addend + base);
+      // x (and the addend) are not read again before the backward pass: streamed, so that y - which the next convolution reads - keeps the caches
+      Vec<T, W> pk, ad;
+      { const uint4 t = nt_load16(reinterpret_cast<const uint4*>(x + base)); pk = *reinterpret_cast<const Vec<T, W>*>(&t); }
+      if (addend) { const uint4 t = nt_load16(reinterpret_cast<const uint4*>(addend + base)); ad = *reinterpret_cast<const Vec<T, W>*>(&t); }
 #pragma unroll
       for (int k = 0; k < W; k++) {
         T o = store_as<T>(bn_affine<A>(load_as<A>(pk.v[k]), mu, scale, bb));
