@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int c = tid + i * 512, gr = c >> 3;
-      r[i] = gr < CO ? *reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3)) : make_uint4(0, 0, 0, 0);
+      r[i] = gr < CO ? nt_load16(reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3))) : make_uint4(0, 0, 0, 0);   // dY's last reader
     }
   };
   auto store_dy = [&](const uint4 (&r)[2], char* stage) {

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
     const unsigned n = vshift >= 0 ? (ii >> vshift) : (ii / (unsigned)vpp);
     const int idx = (int)((n * (unsigned)C + (unsigned)c) * (unsigned)vpp + (ii - n * (unsigned)vpp));
     base[k] = valid ? idx : -1;
-    gv[k] = dy4[idx];
+    gv[k] = nt_load16(dy4 + idx);                           // the gradient's last reader
     xv[k] = x4[idx];
   }
 #pragma unroll
