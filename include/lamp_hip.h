@@ -113,6 +113,18 @@ int lamp_kernel_timer_filter(const char* tag);
 /* median elapsed time of an (event, empty kernel, event) bracket on the current stream, microseconds */
 int lamp_kernel_timer_calibrate(double* out_us);
 
+/* "Kernels the library does not schedule are (delta = +1) / are no longer (-1) running on this device": while the count is positive,
+ * kernels whose workgroups wait for each other (the one-pass batch-norm backward) take their non-waiting two-kernel form.  The
+ * data-parallel step brackets its overlapped RCCL all-reduce with it (distributed/package.scala:690-719); a caller that runs its own
+ * side-stream work concurrently with backward does the same. */
+int lamp_device_shared_hint(int device, int delta);
+/* Batch-norm backward form: -1 the default rule (LAMP_BN_FUSED_BWD, sizes, sharing), 0 always the two kernels, 1 one pass where the
+ * geometry qualifies, 2 the same even while the device is marked shared (tests: proves the waiting kernel under CU pressure). */
+int lamp_bn_backward_mode(int mode);
+/* Test tool: `workgroups` single-wave workgroups that each spin for `microseconds` on `s` (NULL: the current stream) - with the
+ * register-file-filling kernels of the training step that is `workgroups` compute units taken away for that long. */
+int lamp_debug_occupy_cus(int workgroups, double microseconds, lamp_stream* s_or_null);
+
 /* HIP graph capture of the calling thread's current stream (launch-bound training steps) */
 int lamp_graph_begin_capture(void);
 int lamp_graph_end_capture(lamp_graph** out);

@@ -130,6 +130,10 @@ int lamp_comm_all_reduce(lamp_tensor* const* tensors, lamp_comm* const* comms, i
   LAMP_API_BEGIN
   const ncclRedOp_t rop = nccl_op(op);
   for (int i = 0; i < n; i++) check_comm_tensor(tensors[i], comms[i]);
+  // bench.py's untimed pass brackets the collective like any kernel class ("allreduce_us"); one bracket, on the first stream
+  double bytes = 0;
+  for (int i = 0; i < n; i++) bytes += (double)tensors[i]->numel() * (double)tensors[i]->itemsize();
+  KernelTimer kt("rccl_all_reduce", 0, bytes, n > 0 ? current_stream(comms[0]->device) : nullptr);
   GroupGuard group(n);
   for (int i = 0; i < n; i++) {
     NCCL_CHECK(ncclAllReduce(tensors[i]->data(), tensors[i]->data(), (size_t)tensors[i]->numel(), nccl_type(tensors[i]->dtype), rop,

@@ -6,6 +6,7 @@
 // calling thread's current stream.
 #include "tensor.h"
 
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <map>
@@ -122,10 +123,16 @@ const char* assert_text(int code) {
   switch (code) {
     case kAssertNllTarget: return "nll_loss: a target class index is outside [0, numClasses) and is not ignore_index";
     case kAssertIndexRange: return "index out of range";
+    case kAssertBnExchangeTimeout: return "batch-norm backward (one pass): a workgroup waited two minutes for the partial sums of its channel - "
+                                          "another kernel is holding the compute units; the gradients of that launch are invalid (LAMP_BN_FUSED_BWD=0 selects the two-kernel form)";
   }
   return "device-side assertion";
 }
 }  // namespace
+namespace { std::atomic<int> g_device_shared[16]; }
+void device_shared_add(int device, int delta) { if (device >= 0 && device < 16) g_device_shared[device].fetch_add(delta, std::memory_order_acq_rel); }
+int device_shared(int device) { return device >= 0 && device < 16 ? g_device_shared[device].load(std::memory_order_acquire) : 0; }
+
 int* device_assert_word(int device) {
   std::lock_guard<std::mutex> lk(g_assert_mu);
   if (!g_assert_words) {
@@ -263,6 +270,13 @@ int lamp_device_synchronize(void) {
   check_device_asserts(dev);
   LAMP_API_END
 }
+int lamp_device_shared_hint(int device, int delta) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(device >= 0 && device < 16, "device " << device << " out of range");
+  device_shared_add(device, delta);
+  LAMP_CHECK(device_shared(device) >= 0, "lamp_device_shared_hint: more releases than acquisitions on device " << device);
+  LAMP_API_END
+}
 int lamp_device_name(char* buf, int buflen) {
   LAMP_API_BEGIN
   hipDeviceProp_t p;
@@ -385,6 +399,9 @@ int lamp_graph_begin_capture(void) {
   hipStream_t s = current_stream();
   LAMP_CHECK(s != nullptr, "graph capture needs a non-default current stream "
                            "(lamp_stream_get_from_pool + lamp_stream_set_current first)");
+  // deferred kernels registered BEFORE the capture run now, eagerly: flushed by the first raw() inside the capture they would only be
+  // recorded and the eager pass would never produce their tensors
+  flush_deferred();
   allocator_begin_capture_pool();
   hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
   if (e != hipSuccess) {
@@ -397,6 +414,9 @@ int lamp_graph_end_capture(lamp_graph** out) {
   LAMP_API_BEGIN
   hipStream_t s = current_stream();
   hipGraph_t g = nullptr;
+  // deferred kernels registered INSIDE the capture belong to the graph: queue them on the capturing stream before it ends, otherwise
+  // they would run once, eagerly, after the capture and every replay would leave their tensors stale
+  try { flush_deferred(); } catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(s, &dead); if (dead) (void)hipGraphDestroy(dead); allocator_end_capture_pool(); throw; }
   hipError_t e = hipStreamEndCapture(s, &g);
   allocator_end_capture_pool();
   HIP_CHECK(e);

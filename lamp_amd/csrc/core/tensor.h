@@ -190,7 +190,11 @@ void allow_big_lds(const void* kernel);   // opt a kernel into 160 KiB of dynami
 void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P);
 lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P);   // +1 handle or nullptr
 // device-side assertions (runtime.cpp): a kernel stores a code into *device_assert_word(dev); the next host wait raises
-enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2 };
+enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2, kAssertBnExchangeTimeout = 3 };
+// "this device is also running kernels the library does not schedule" (an RCCL collective on the exchange stream while backward
+// continues, a caller's own side-stream work): kernels whose workgroups wait for each other take their non-waiting form meanwhile.
+void device_shared_add(int device, int delta);
+int device_shared(int device);
 int* device_assert_word(int device);
 void check_device_asserts(int device);
 uint64_t next_philox_offset(uint64_t n);  // advances the generator state by n draws

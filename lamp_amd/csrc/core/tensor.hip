@@ -4,6 +4,8 @@
 // lamp-sten/src/main/scala/lamp/STen.scala:845-1000, TensorHelpers.scala:44-345,
 // device.scala:62-114,221-225).
 #include "tensor.h"
+#include <cerrno>
+#include <cstring>
 #include "strided.h"
 #include "../kernels/device_utils.h"
 
@@ -396,8 +398,8 @@ int lamp_tensor_trace_list(int64_t* records, int64_t capacity, int64_t* count) {
   LAMP_API_END
 }
 
-// Tensor.from_file / tensors_from_file (STen.scala:115-194): the byte range [offset, offset + length) of `path` is mmap'ed (read-only,
-// private; mlock'ed when pin) and n one-dimensional host tensors are cut from it at (types[i], offsets[i], lengths[i] bytes).  Nothing is
+// Tensor.from_file / tensors_from_file (STen.scala:115-194): the byte range [offset, offset + length) of `path` is mmap'ed (private,
+// copy-on-write; mlock'ed when pin) and n one-dimensional host tensors are cut from it at (types[i], offsets[i], lengths[i] bytes).  Nothing is
 // copied: checkpoints and data sets reach the GPU with one lamp_to per tensor straight from the page cache.
 int lamp_tensors_from_file(lamp_tensor** outs, const char* path, int64_t offset, int64_t length, int pin, const int64_t* types,
                            const int64_t* offsets, const int64_t* lengths, int n) {
@@ -407,7 +409,8 @@ int lamp_tensors_from_file(lamp_tensor** outs, const char* path, int64_t offset,
   LAMP_CHECK(length >= 0, "negative length");
   for (int i = 0; i < n; i++) {
     LAMP_CHECK(offsets[i] % 8 == 0, "Some tensor offsets within the list is not aligned to 8");
-    LAMP_CHECK(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] + lengths[i] <= length, "Some tensor offset +length is out of bounds");
+    LAMP_CHECK(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] <= length && lengths[i] <= length - offsets[i],   // no int64 overflow
+               "Some tensor offset +length is out of bounds");
     LAMP_CHECK(lengths[i] % (int64_t)dtype_size((int)types[i]) == 0, "tensor " << i << ": byte length " << lengths[i] << " is not a multiple of the element size");
   }
   Storage* st = nullptr;
@@ -415,11 +418,17 @@ int lamp_tensors_from_file(lamp_tensor** outs, const char* path, int64_t offset,
     const int fd = open(path, O_RDONLY);
     LAMP_CHECK(fd >= 0, "cannot open " << path);
     struct stat sb;
-    if (fstat(fd, &sb) != 0 || (int64_t)sb.st_size < offset + length) { close(fd); LAMP_CHECK(false, path << " is shorter than offset + length = " << offset + length); }
-    void* base = mmap(nullptr, (size_t)length, PROT_READ, MAP_PRIVATE, fd, (off_t)offset);
+    if (fstat(fd, &sb) != 0 || offset > (int64_t)sb.st_size || length > (int64_t)sb.st_size - offset) { close(fd); LAMP_CHECK(false, path << " is shorter than offset + length = " << offset + length); }
+    // private and WRITABLE (copy on write, the file is never touched), as ATen's non-shared from_file maps it: in-place host
+    // arithmetic and copy_ into such a tensor work instead of faulting
+    void* base = mmap(nullptr, (size_t)length, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, (off_t)offset);
     close(fd);
     LAMP_CHECK(base != MAP_FAILED, "mmap of " << path << " failed");
-    if (pin) (void)mlock(base, (size_t)length);
+    if (pin && mlock(base, (size_t)length) != 0) {
+      const int err = errno;
+      munmap(base, (size_t)length);
+      LAMP_CHECK(false, "cannot pin " << length << " bytes of " << path << " (mlock: " << strerror(err) << "; RLIMIT_MEMLOCK?)");
+    }
     st = new Storage();
     st->ptr = base; st->bytes = (size_t)length; st->device = -1; st->owned = false; st->map_base = base; st->map_len = (size_t)length;
   }

@@ -374,6 +374,15 @@ struct StreamScope {
   void leave() { HCALL(lamp_stream_set_current(prev)); }
   ~StreamScope() { if (prev) { lamp_stream_set_current(prev); lamp_stream_release(prev); } }
 };
+// while a collective runs on the exchange stream beside backward the device is not this thread's alone: kernels whose workgroups wait
+// for each other (one-pass batch-norm backward) take their two-kernel form until the exchange has been joined (lamp_device_shared_hint)
+struct SharedDeviceScope {
+  int device, held = 0;
+  explicit SharedDeviceScope(int d) : device(d) {}
+  void acquire() { if (!held) { HCALL(lamp_device_shared_hint(device, +1)); held = 1; } }
+  void release() { if (held) { lamp_device_shared_hint(device, -1); held = 0; } }
+  ~SharedDeviceScope() { release(); }
+};
 }  // namespace
 
 void DataParallel::sync_state(SupervisedModel& model, Optimizer& opt, int root) {
@@ -422,6 +431,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   const int64_t n = ln.second;
 
   StreamScope scope(device);
+  SharedDeviceScope shared(device);
   lamp_stream* const cur = scope.prev;
   if (!comm_stream) HCALL(lamp_stream_get_from_pool(1, device, &comm_stream));
 
@@ -442,6 +452,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
     ops::fill_(ops::slice(bucket, 0, cnt, cnt + 1, 1), (double)n);
     lamp_tensor* bt[1] = {bucket.h()};
     lamp_comm* cm[1] = {comm};
+    shared.acquire();                                              // from here until the join below an RCCL kernel holds CUs of this device
     HCALL(lamp_comm_all_reduce(bt, cm, 1, 0));
     // averaged gradients back into the parameters' grad buffers, still on the exchange stream: for the deep bucket this overlaps
     // the rest of backward instead of queueing behind it
@@ -473,6 +484,7 @@ int64_t DataParallel::step(SupervisedModel& model, Optimizer& opt, const Ten& sa
   exchange(0, split, bucket_rest, g_rest, h_rest);
   accumulate_loss(acc, ln.first->value, n);
   HCALL(lamp_stream_wait_stream(cur, comm_stream));               // both averaged gradient sets are visible to the compute stream
+  shared.release();
   std::vector<Ten> grads(g_rest);
   grads.insert(grads.end(), g_deep.begin(), g_deep.end());
   opt.step(grads, scheduleFactor);

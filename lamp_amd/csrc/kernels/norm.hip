@@ -13,6 +13,7 @@
 // Layout: x is [N, C, HW] contiguous (HW = 1 for the 2-D case). Pass 1 reduces each channel with
 // one or more workgroups (64-lane shuffle merge + LDS), pass 2 is a coalesced normalise.
 #include "device_utils.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ invstd, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                            unsigned long long* slots, unsigned* depart, bf16_t* dweight, bf16_t* dbias, bf16_t* __restrict__ dx,
                                                            int64_t N, int C, int HW, int S, double inv_m, int relu,
-                                                           const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift) {
+                                                           const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift, int* assert_word) {
   __shared__ float sm[2][8];
   __shared__ float stat[2];
   const int c = blockIdx.x / S, s = blockIdx.x - c * S;
@@ -630,12 +631,22 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
         __hip_atomic_store(slot + s, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       a = 0.f; bs = 0.f;
+      // The wait ends when the channel's other workgroups have run, and they run as soon as compute units are free: workgroups are
+      // handed out in launch order, so a foreign kernel that holds CUs (an RCCL collective waiting for a slow peer) only delays this
+      // one.  No trap (a straggling rank must not abort the process): after two minutes of the 100 MHz clock the lane
+      // reports a device-side assertion - raised by the host's next wait - and goes on, so the slots still return to rest.
       unsigned spins = 0;
+      unsigned long long t0 = 0;
+      bool gave_up = false;
       for (int k = lane; k < S; k += 64) {
         unsigned long long v;
-        while ((v = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {
+        while ((v = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull && !gave_up) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 21)) __builtin_trap();       // seconds: a workgroup of the channel never arrived
+          if ((++spins & 0xfffu) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 12000000000ull) { gave_up = true; if (assert_word) *assert_word = kAssertBnExchangeTimeout; }
+          }
         }
         a += __uint_as_float((unsigned)v); bs += __uint_as_float((unsigned)(v >> 32));
       }
@@ -909,12 +920,18 @@ static int pick_split(int64_t outputs_blocks, int64_t N) {
   return (int)std::max<int64_t>(s, 1);
 }
 // The one-pass backward (bn_bwd_fused_kernel).  Returns false when the geometry does not qualify (the caller runs the two kernels).
+static std::atomic<int> g_bn_bwd_mode{-1};
 struct BnFusedState { unsigned* sync = nullptr; hipStream_t last = nullptr; bool has_last = false; hipEvent_t ev = nullptr; };
 constexpr int BN_FUSED_MAXC = 4096;                         // depart[BN_FUSED_MAXC] (4-byte counters), then slots[BN_FUSED_SLOTS] (8 bytes each)
 constexpr int BN_FUSED_SLOTS = 4096;
 static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
                                 Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st) {
-  static const bool on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+  static const bool env_on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+  const int mode = g_bn_bwd_mode.load(std::memory_order_relaxed);
+  const bool on = mode < 0 ? env_on : mode >= 1;
+  // a device that is also running kernels this library does not schedule (the overlapped RCCL all-reduce of the eager data-parallel
+  // step): the waiting workgroups would sit on their CUs until the foreign kernel lets the rest of their channel in - two kernels then
+  if (on && mode != 2 && device_shared(xc->device()) > 0) return false;
   if (!on || g.C > BN_FUSED_MAXC || g.HW % 8 != 0 || xc->numel() >= (int64_t)1 << 34) return false;
   const int64_t packets = g.N * (g.HW / 8);                 // per channel
   if (packets <= 0 || packets >= (int64_t)1 << 30) return false;
@@ -994,8 +1011,9 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   for (int b = 0; b < 31; b++) if (vppi == (1 << b)) a_vshift = b;
   const bf16_t* adp = addc ? addc->ptr<bf16_t>() : (const bf16_t*)nullptr;
   bf16_t* dap = dadd ? dadd->ptr<bf16_t>() : (bf16_t*)nullptr;
+  int* awp = device_assert_word(xc->device());
   void* args[] = {(void*)&dyp, (void*)&xp, (void*)&mp, (void*)&ip, (void*)&wp, (void*)&bp, (void*)&slotp, (void*)&departp, (void*)&dwp, (void*)&dbp, (void*)&dxp,
-                  (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift};
+                  (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift, (void*)&awp};
   HIP_CHECK(hipLaunchKernel(kfn, dim3((unsigned)(g.C * S)), dim3(512), args, 0, st));
   return true;
 }
@@ -1010,6 +1028,13 @@ static void check_cvec(const Tensor* t, int64_t C, int dtype, const char* what) 
 using namespace lamp;
 
 extern "C" {
+
+int lamp_bn_backward_mode(int mode) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(mode >= -1 && mode <= 2, "lamp_bn_backward_mode: mode must be -1, 0, 1 or 2");
+  g_bn_bwd_mode.store(mode, std::memory_order_relaxed);
+  LAMP_API_END
+}
 
 static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
                            lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu,

@@ -1,6 +1,7 @@
 // Deferred, batched reduction of the convolutions' weight-gradient partial sums (see wgrad_reduce.h).
 #include "wgrad_reduce.h"
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace lamp {
@@ -17,10 +18,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(WgradReduceMany 
 }
 
 namespace {
-struct Pending { WgradReduceArgs a; Tensor* partial; Tensor* dw; hipStream_t st; int device; };
+// Ownership: an entry belongs to the host thread that registered it.  flush_deferred() - the natural batching point - only
+// takes the CALLING thread's entries, so the replica threads of the single-process data-parallel step never flush (or clear the flags
+// of) each other's reductions; resolve_deferred(storage), reached from raw() of any thread, takes the entries of the thread that owns
+// that storage's entry.  g_mu is held from the moment entries leave the list until their kernels are queued and only then are the
+// `pending` flags cleared: a concurrent raw() of a pending tensor blocks on the mutex and returns with the reduction already queued
+// in front of whatever the caller launches next.
+struct Pending { WgradReduceArgs a; Tensor* partial; Tensor* dw; hipStream_t st; int device; std::thread::id owner; };
 std::mutex g_mu;
 std::vector<Pending> g_pending;
 
+// called with g_mu held.  Pointers are taken from the storages directly (raw() would recurse into resolve_deferred).
 void launch_batch(const std::vector<Pending>& v) {
   // one launch per (device, stream) group of at most WR_MAX reductions; order of registration kept
   std::vector<bool> done(v.size(), false);
@@ -31,8 +39,9 @@ void launch_batch(const std::vector<Pending>& v) {
     for (size_t j = i; j < v.size() && cnt < WR_MAX; j++) {
       if (done[j] || v[j].st != v[i].st || v[j].device != v[i].device) continue;
       m.e[cnt] = v[j].a;
-      m.e[cnt].partial = static_cast<const float*>(v[j].partial->raw());
-      m.e[cnt].dw = v[j].dw->ptr<bf16_t>();               // mutable pointer: bumps dw's version like any other writer
+      m.e[cnt].partial = reinterpret_cast<const float*>(static_cast<const char*>(v[j].partial->st->ptr)) + v[j].partial->offset;
+      m.e[cnt].dw = reinterpret_cast<bf16_t*>(static_cast<char*>(v[j].dw->st->ptr)) + v[j].dw->offset;
+      v[j].dw->st->version.fetch_add(1, std::memory_order_relaxed);   // a writer like any other: bumps dw's version
       maxb = std::max(maxb, v[j].a.blocks);
       done[j] = true;
       cnt++;
@@ -46,29 +55,53 @@ void launch_batch(const std::vector<Pending>& v) {
     // a reader on another stream of that device must see the result: order it behind the reduction
     hipStream_t cur = current_stream(v[i].device);
     if (cur != v[i].st) {
-      hipEvent_t ev;
-      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      HIP_CHECK(hipEventRecord(ev, v[i].st));
-      HIP_CHECK(hipStreamWaitEvent(cur, ev, 0));
-      HIP_CHECK(hipEventDestroy(ev));
+      if (allocator_capturing()) {
+        // the caller is recording a graph on `cur`: an event from outside the capture cannot be waited for inside it - wait on the host
+        HIP_CHECK(hipStreamSynchronize(v[i].st));
+      } else {
+        hipEvent_t ev;
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev, v[i].st));
+        HIP_CHECK(hipStreamWaitEvent(cur, ev, 0));
+        HIP_CHECK(hipEventDestroy(ev));
+      }
     }
   }
+}
+
+// takes the entries of `owner` out of the list, queues their kernels and clears their flags - all under g_mu
+void flush_owner_locked(std::thread::id owner) {
+  std::vector<Pending> v;
+  size_t keep = 0;
+  for (size_t i = 0; i < g_pending.size(); i++) {
+    if (g_pending[i].owner == owner) v.push_back(g_pending[i]);
+    else g_pending[keep++] = g_pending[i];
+  }
+  g_pending.resize(keep);
+  if (v.empty()) return;
+  struct Finish {
+    std::vector<Pending>& v;
+    ~Finish() {
+      for (auto& p : v) p.dw->st->pending.store(0, std::memory_order_release);   // after the launches are queued (or have failed)
+      for (auto& p : v) { release(p.partial); release(p.dw); }
+    }
+  } fin{v};
+  launch_batch(v);
 }
 }  // namespace
 
 void flush_deferred() {
-  std::vector<Pending> v;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_pending.empty()) return;
-    v.swap(g_pending);
-    for (auto& p : v) p.dw->st->pending.store(0, std::memory_order_release);   // before any pointer is taken below
-  }
-  struct Releaser { std::vector<Pending>& v; ~Releaser() { for (auto& p : v) { release(p.partial); release(p.dw); } } } rel{v};
-  launch_batch(v);
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_pending.empty()) return;
+  flush_owner_locked(std::this_thread::get_id());
 }
 
-void resolve_deferred(Storage*) { flush_deferred(); }
+void resolve_deferred(Storage* st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& p : g_pending)
+    if (p.dw->st == st) { flush_owner_locked(p.owner); return; }
+  // not in the list any more: another thread queued it while this one waited for the mutex
+}
 
 void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_tensor* dw, hipStream_t st) {
   static const bool defer = [] { const char* e = getenv("LAMP_DEFER_WGRAD_REDUCE"); return !(e && e[0] == '0'); }();
@@ -81,7 +114,7 @@ void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_t
     LAMP_LAUNCH_CHECK();
     return;
   }
-  Pending p{a, retain(partial), retain(dw), st, dw->device()};
+  Pending p{a, retain(partial), retain(dw), st, dw->device(), std::this_thread::get_id()};
   std::lock_guard<std::mutex> lk(g_mu);
   g_pending.push_back(p);
   dw->st->pending.store(1, std::memory_order_release);

@@ -43,8 +43,13 @@ def _recv_exact(sock: socket.socket, n: int) -> bytes:
     return bytes(buf)
 
 
+MAX_MSG_BYTES = 1 << 20          # control-plane messages are ids, digests and a few floats per rank
+
+
 def _recv_msg(sock: socket.socket):
     (n,) = struct.unpack("<I", _recv_exact(sock, 4))
+    if n > MAX_MSG_BYTES:
+        raise ConnectionError(f"control plane: a message of {n} bytes is not one of ours (limit {MAX_MSG_BYTES})")
     return json.loads(_recv_exact(sock, n).decode())
 
 
@@ -77,23 +82,35 @@ class ControlPlane:
             nonce = os.urandom(8).hex()
             if rdzv:
                 tmp = f"{rdzv}.{os.getpid()}.tmp"
-                with open(tmp, "w") as f:
-                    json.dump({"port": srv.getsockname()[1], "nonce": nonce}, f)
-                os.replace(tmp, rdzv)                                  # atomic: readers see nothing or the whole record
+                # owner-only: the nonce keeps strangers on a shared host out of the clique, so they must not be able to read it
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+                with os.fdopen(fd, "w") as f:
+                    json.dump({"port": srv.getsockname()[1], "nonce": nonce, "pid": os.getpid()}, f)
+                os.replace(tmp, rdzv)                                  # atomic: readers see nothing or the whole record (a stale one is replaced)
                 self._rdzv_written = rdzv
             try:
                 joined = 0
                 while joined < world - 1:
                     c, _ = srv.accept()
-                    c.settimeout(timeout)
-                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    hello = _recv_msg(c)
-                    r = int(hello["rank"])
-                    if hello.get("world") != world or not (0 < r < world) or self.peers[r] is not None or (rdzv and hello.get("nonce") != nonce):
-                        _send_msg(c, {"ok": False, "why": f"rank {r} of world {hello.get('world')} does not belong to this launch (world {world})"})
-                        c.close()
+                    # the handshake of ONE connection must not take rank 0 down or block the others: a stray or silent client (port
+                    # scanner, a rank of another launch reading a stale record) is dropped after a few seconds and the loop goes on
+                    try:
+                        c.settimeout(5.0)
+                        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        hello = _recv_msg(c)
+                        r = int(hello["rank"])
+                        if hello.get("world") != world or not (0 < r < world) or self.peers[r] is not None or (rdzv and hello.get("nonce") != nonce):
+                            _send_msg(c, {"ok": False, "why": f"rank {r} of world {hello.get('world')} does not belong to this launch (world {world})"})
+                            c.close()
+                            continue
+                        _send_msg(c, {"ok": True})
+                        c.settimeout(timeout)
+                    except (OSError, ValueError, KeyError, TypeError, AttributeError, ConnectionError, struct.error):
+                        try:
+                            c.close()
+                        except OSError:
+                            pass
                         continue
-                    _send_msg(c, {"ok": True})
                     self.peers[r] = c
                     joined += 1
             finally:
@@ -110,13 +127,13 @@ class ControlPlane:
                     else:
                         cport, nonce = port, None
                     s = socket.create_connection((addr, cport), timeout=5.0)
-                    s.settimeout(timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     _send_msg(s, {"rank": rank, "world": world, "nonce": nonce})
-                    ans = _recv_msg(s)
+                    ans = _recv_msg(s)            # still under the 5 s timeout: a stale record's port answers nothing, try again
                     if not ans.get("ok"):
                         s.close()
                         raise ConnectionError(ans.get("why", "refused"))
+                    s.settimeout(timeout)
                     self.up = s
                     break
                 except (OSError, ValueError, KeyError, ConnectionError) as e:   # not published yet / stale record / not listening yet

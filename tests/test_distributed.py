@@ -132,6 +132,45 @@ def test_control_plane_rejects_a_rank_of_another_launch(tmp_path):
     good.close(); box["cp"].close()
 
 
+def test_control_plane_survives_stray_connections(tmp_path):
+    """garbage, an absurd length prefix, a hello without a rank and a client that says nothing must not take rank 0 down,
+    make it allocate gigabytes or hold the clique up for the full timeout; the record is owner-only"""
+    import threading
+    import time
+    rdzv = str(tmp_path / "r.json")
+    box = {}
+
+    def serve():
+        try:
+            box["cp"] = D.ControlPlane(0, 2, "127.0.0.1", 0, rdzv, 60.0)
+        except Exception as e:                     # noqa: BLE001 - the test reports it
+            box["err"] = e
+    th = threading.Thread(target=serve)
+    th.start()
+    while not os.path.exists(rdzv):
+        time.sleep(0.01)
+    assert (os.stat(rdzv).st_mode & 0o077) == 0, "the nonce must not be readable by other users"
+    rec = json.load(open(rdzv))
+    strays = []
+    for payload in (b"GET / HTTP/1.1\r\n\r\n", b"\xff\xff\xff\xff" + b"x" * 16, None):
+        s = socket.create_connection(("127.0.0.1", rec["port"]))
+        if payload is not None:
+            s.sendall(payload)
+        strays.append(s)                           # the silent one stays open: rank 0 drops it after its 5 s handshake timeout
+    s = socket.create_connection(("127.0.0.1", rec["port"]))
+    D._send_msg(s, {"world": 2})                   # no rank
+    strays.append(s)
+    t0 = time.monotonic()
+    good = D.ControlPlane(1, 2, "127.0.0.1", 0, rdzv, 60.0)
+    th.join(60)
+    assert "err" not in box, box.get("err")
+    assert box["cp"].peers[1] is not None
+    assert time.monotonic() - t0 < 30.0
+    for s in strays:
+        s.close()
+    good.close(); box["cp"].close()
+
+
 def test_bench_dry_launch_two_ranks():
     """`python bench.py --gpus 2` started bare becomes the launcher: two rank processes with the torchrun environment rendezvous."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120)
@@ -461,3 +500,28 @@ def test_allocator_defers_reuse_of_blocks_another_stream_still_uses(gpu):
     d1 = C.c_int64(0); lib.lamp_allocator_deferred_frees(0, C.byref(d1))
     assert d1.value - d0.value >= 8
     lib.lamp_stream_release(side); lib.lamp_stream_release(cur)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_line_verifies_itself(gpu, tmp_path):
+    """the N-rank line must prove itself.  One GPU can drive the complete multi-rank code of bench.py with a
+    1-rank RCCL communicator (LAMP_BENCH_FORCE_COMM=1): both exchange modes are timed (`value` = the faster, the other under
+    `alt_mode`), the all-reduce of each is bracketed (`allreduce_us`), the averaged gradients of one ragged step are checked against
+    the example-weighted mean of the all-gathered per-rank gradients (`grad_avg_max_rel_err`) and the replicas' state digests are
+    compared (`replicas_identical`)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               LAMP_BENCH_FORCE_COMM="1", LAMP_RDZV_FILE=str(tmp_path / "r.json"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                          "--batch", "256", "--min-window-s", "0.05"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["replicas_identical"] is True
+    assert 0.0 <= line["grad_avg_max_rel_err"] <= 2.0 ** -7
+    assert line["grad_avg_examples_per_rank"] == [256]
+    assert set(line["allreduce_us"]) == {"graph_single_bucket", "eager_overlapped_two_buckets"}
+    assert line["allreduce_us"]["graph_single_bucket"]["launches_per_step"] == 1
+    assert line["allreduce_us"]["eager_overlapped_two_buckets"]["launches_per_step"] == 2
+    assert all(v["avg_us"] > 0 for v in line["allreduce_us"].values())
+    modes = {line["config"]["exchange_mode"].split(":")[0]} | {m["mode"].split(":")[0] for m in line["alt_mode"]}
+    assert modes == {"graph_single_bucket", "eager_overlapped_two_buckets"}
+    assert all(m["ms_per_step"] >= line["ms_per_step"] for m in line["alt_mode"]), "value is the faster mode"

@@ -102,7 +102,14 @@ def test_tensors_from_file_maps_without_copy(tmp_path):
     assert np.array_equal(a.to_numpy(), f32) and np.array_equal(b.to_numpy(), i64)
     a.release()                                               # the mapping lives as long as any member does
     assert np.array_equal(b.to_numpy(), i64)
-    for bad in ((100, 4096, [0], [8]), (4096, 4096, [4], [8]), (4096, 4096, [4090], [16])):
+    # the mapping is private and writable (copy on write, as ATen's non-shared from_file): in-place host arithmetic works and the
+    # file keeps its bytes (a read-only mapping turned `b += 1` into SIGSEGV)
+    lib.lamp_add_scalar_(b, 1.0, 1.0)
+    assert np.array_equal(b.to_numpy(), i64 + 1)
+    assert open(path, "rb").read() == bytes(blob)
+    for bad in ((100, 4096, [0], [8]), (4096, 4096, [4], [8]), (4096, 4096, [4090], [16]),
+                (4096, 4096, [8], [2 ** 63 - 8]),             # offset + length overflows int64: still "out of bounds", not a wrap-around
+                (4096, 2 ** 63 - 4096, [0], [8])):            # window past the end of the file
         with pytest.raises(LampError):
             o = (C.c_void_p * 1)()
             lib.lamp_tensors_from_file(o, path.encode(), bad[0], bad[1], 0, i64_array([S.F32]), i64_array(bad[2]), i64_array(bad[3]), 1)

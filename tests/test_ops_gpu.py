@@ -1065,3 +1065,179 @@ def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k,
     lib.lamp_mul_(Y, Y.onesLike())                                           # any write through the handle bumps the storage version
     _, _, _, rep3 = bn(Y)
     assert b"bn_fwd_stats" in rep3, "stale statistics were used after the tensor had been written"
+
+
+def _conv_wgrad_bf16(x, w, gy, k):
+    out3 = (C.c_void_p * 3)()
+    mask = (C.c_uint8 * 3)(0, 1, 0)
+    lib.lamp_convolution_backward(out3, gy, x, w, i64_array([1, 1]), i64_array([k // 2, k // 2]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1, mask)
+    return S.STen(out3[1])
+
+
+def test_deferred_reductions_and_graph_capture(gpu):
+    """(a) a bf16 convolution backward issued through the C ABI INSIDE a capture whose dW nobody touches before the capture
+    ends must still be part of the graph (lamp_graph_end_capture queues the registered reductions on the capturing stream): every
+    replay produces dW for the batch then in the input buffer; (b) reductions registered BEFORE lamp_graph_begin_capture run eagerly
+    at its start instead of being recorded by the first pointer access inside the capture."""
+    dt = torch.bfloat16
+    cin, cout, hw, k = 128, 128, 8, 3
+    xs = [closed_form((16, cin, hw, hw), 3 + 7 * i, 2.0, dt) for i in range(3)]
+    w = closed_form((cout, cin, k, k), 17, 1.0, dt)
+    gy = closed_form((16, cout, hw, hw), 23, 1.0, dt)
+    W, GY = to_sten(w), to_sten(gy)
+    eager = [to_torch(_conv_wgrad_bf16(to_sten(x), W, GY, k)) for x in xs]
+    st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(st))
+    dflt = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(dflt))
+    lib.lamp_device_synchronize()
+    lib.lamp_stream_set_current(st)
+    try:
+        x_buf = to_sten(xs[0])
+        _conv_wgrad_bf16(x_buf, W, GY, k).to_numpy()            # warm-up on this stream (attributes, caches)
+        before = _conv_wgrad_bf16(to_sten(xs[1]), W, GY, k)     # (b) registered, not yet reduced, when the capture begins
+        lib.lamp_graph_begin_capture()
+        dw = _conv_wgrad_bf16(x_buf, W, GY, k)                  # (a) never touched inside the capture
+        g = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(g))
+        lib.lamp_stream_synchronize(st)
+        assert torch.equal(to_torch(before), eager[1]), "a reduction registered before the capture must have run eagerly"
+        for i in (2, 0, 1):
+            x_buf.copyFrom(to_sten(xs[i]))
+            lib.lamp_graph_launch(g)
+            lib.lamp_stream_synchronize(st)
+            assert torch.equal(to_torch(dw), eager[i]), f"replay {i}: dW is not the eager result - the reduction is not in the graph"
+        lib.lamp_graph_release(g)
+    finally:
+        lib.lamp_stream_set_current(dflt)
+    lib.lamp_device_synchronize()
+
+
+def test_deferred_reductions_belong_to_the_thread_that_registered_them(gpu):
+    """the replica threads of the single-process data-parallel step finish backprop at about the same time; one
+    thread's flush must not take (and clear the flags of) another thread's reductions.  Four threads, each on its own stream, run
+    bf16 weight gradients + flush + an in-place scaling many times; every result must equal the single-threaded one bit for bit."""
+    import threading
+    dt = torch.bfloat16
+    cin, cout, hw, k = 128, 128, 8, 3
+    w = closed_form((cout, cin, k, k), 17, 1.0, dt)
+    gy = closed_form((16, cout, hw, hw), 23, 1.0, dt)
+    xs = [closed_form((16, cin, hw, hw), 3 + 11 * i, 2.0, dt) for i in range(4)]
+    W, GY = to_sten(w), to_sten(gy)
+    XS = [to_sten(x) for x in xs]
+    want = []
+    for X in XS:
+        d = _conv_wgrad_bf16(X, W, GY, k)
+        lib.lamp_flush_deferred()
+        lib.lamp_mul_scalar_(d, 0.5)
+        want.append(to_torch(d))
+    lib.lamp_device_synchronize()
+    errors = []
+    barrier = threading.Barrier(4)
+
+    def work(i):
+        try:
+            st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(st)); lib.lamp_stream_set_current(st)
+            for rep in range(40):
+                barrier.wait()
+                d = _conv_wgrad_bf16(XS[i], W, GY, k)
+                if rep % 2 == 0:
+                    lib.lamp_flush_deferred()               # the natural batching point ...
+                lib.lamp_mul_scalar_(d, 0.5)                # ... or the first pointer access resolves it
+                got = to_torch(d)
+                if not torch.equal(got, want[i]):
+                    errors.append(f"thread {i} repetition {rep}: weight gradient differs (max |d| {(got - want[i]).abs().max().item()})")
+                    break
+        except Exception as e:                             # noqa: BLE001
+            errors.append(f"thread {i}: {e}")
+            barrier.abort()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    lib.lamp_device_synchronize()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("held", [32, 64, 128, 224])
+def test_one_pass_batch_norm_backward_under_cu_pressure(gpu, held):
+    """the one-pass batch-norm backward (workgroups of a channel wait for each other's partial sums) on a device
+    it does NOT have to itself.  `held` single-wave workgroups spin for 3 ms on a high-priority second stream - with 512-thread,
+    register-file-filling batch-norm workgroups that is `held` CUs taken away - while the six large maps of the ResNet step run their
+    backward on the compute stream.  The kernel has to finish (workgroups are handed out in launch order, so the channels complete
+    one after the other as CUs free up) with bitwise the results it gives on an idle device, which in turn agree with the two-kernel
+    form; marked shared through lamp_device_shared_hint the host takes the two kernels by itself."""
+    dt = torch.bfloat16
+    maps = [(2048, 6, 32, 1), (2048, 16, 16, 2), (2048, 128, 8, 2), (2048, 128, 8, 1), (2048, 100, 8, 0), (2048, 16, 16, 1)]
+    hi = C.c_void_p(); lib.lamp_stream_get_from_pool(1, 0, C.byref(hi))
+    tensors = []
+    for (N, Cc, H, variant) in maps:
+        shape = (N, Cc, H, H)
+        x = closed_form(shape, 3, 4.0, dt) + 0.3
+        ad = closed_form(shape, 29, 3.0, dt)
+        gy = closed_form(shape, 11, 2.0, dt)
+        w, b = closed_form((Cc,), 1, 1.0, dt) + 1.0, closed_form((Cc,), 5, 1.0, dt)
+        rm, rv = closed_form((Cc,), 7, 0.5, dt), closed_form((Cc,), 9, 0.5, dt) + 1.0
+        X, AD, GY, Wt, Bt, RM, RV = (to_sten(t) for t in (x, ad, gy, w, b, rm, rv))
+        fwd = _out3()
+        lib.lamp_native_batch_norm(fwd, X, Wt, Bt, RM, RV, 1, 0.1, 1e-5)
+        _, sm, si = _wrap3(fwd)
+        tensors.append((variant, X, AD, GY, Wt, Bt, RM, RV, sm, si))
+
+    def backward_all():
+        outs = []
+        for (variant, X, AD, GY, Wt, Bt, RM, RV, sm, si) in tensors:
+            if variant == 2:
+                out4 = (C.c_void_p * 4)()
+                lib.lamp_native_batch_norm_add_relu_backward(out4, GY, X, AD, Wt, Bt, RM, RV, sm, si, 1, 1e-5, (C.c_uint8 * 4)(1, 1, 1, 1))
+                outs.extend(S.STen(out4[i]) for i in range(4))
+            else:
+                out = _out3()
+                if variant == 1:
+                    lib.lamp_native_batch_norm_relu_backward(out, GY, X, Wt, Bt, RM, RV, sm, si, 1, 1e-5, _mask3(1, 1, 1))
+                else:
+                    lib.lamp_native_batch_norm_backward(out, GY, X, Wt, RM, RV, sm, si, 1, 1e-5, _mask3(1, 1, 1))
+                outs.extend(_wrap3(out))
+        return outs
+
+    def classes(fn):
+        lib.lamp_kernel_timer_enable(1)
+        r = fn()
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        lib.lamp_kernel_timer_enable(0)
+        return r, buf.value
+
+    try:
+        lib.lamp_bn_backward_mode(0)
+        two, rep = classes(backward_all)
+        assert b"bn_bwd_fused" not in rep
+        two = [t.to_numpy() for t in two]
+        lib.lamp_bn_backward_mode(1)
+        alone, rep = classes(backward_all)
+        assert rep.count(b"bn_bwd_fused") == 1 and b"bn_bwd_reduce" not in rep, rep.decode()
+        alone = [t.to_numpy() for t in alone]
+        lib.lamp_device_synchronize()
+        for rnd in range(3):
+            lib.lamp_debug_occupy_cus(held, 3000.0, hi)            # 3 ms on the high-priority stream, then the backward passes beside it
+            pressed = backward_all()
+            lib.lamp_device_synchronize()                          # raises if a workgroup gave up waiting (device-side assertion)
+            for a, p in zip(alone, pressed):
+                assert np.array_equal(a, p.to_numpy()), f"round {rnd}: results under CU pressure differ from the idle device's"
+        # the two forms agree (different summation order of the channel sums: bf16 tolerance on dweight / dbias, dx follows them)
+        for a, t in zip(alone, two):
+            assert_close(torch.from_numpy(a), torch.from_numpy(t).double(), 4e-2, "one-pass vs two-kernel batch-norm backward")
+        # marked shared: the default rule takes the two kernels (what the eager data-parallel step does while its all-reduce is in flight)
+        lib.lamp_bn_backward_mode(-1)
+        lib.lamp_device_shared_hint(0, 1)
+        try:
+            shared, rep = classes(backward_all)
+            assert b"bn_bwd_fused" not in rep and b"bn_bwd_reduce" in rep, rep.decode()
+            for a, t in zip(two, shared):
+                assert np.array_equal(a, t.to_numpy())
+            lib.lamp_bn_backward_mode(2)                           # explicit override: one pass although shared
+            _, rep = classes(backward_all)
+            assert b"bn_bwd_fused" in rep
+        finally:
+            lib.lamp_device_shared_hint(0, -1)
+    finally:
+        lib.lamp_bn_backward_mode(-1)
+        lib.lamp_device_synchronize()
