@@ -50,6 +50,11 @@ inline bool is_float(int dt) { return dt == kF32 || dt == kF64 || dt == kBF16 ||
 struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+// a GPU-only operator met a host tensor (check_device_tensor): status LAMP_STATUS_HOST_TENSOR at the C ABI, where the generated
+// staging layer (core/host_staging.cpp) runs the operator on GPU copies when ALL tensor arguments are host tensors
+struct HostTensorError : Error {
+  using Error::Error;
+};
 
 #define LAMP_CHECK(cond, ...)                                                     \
   do {                                                                            \
@@ -73,9 +78,14 @@ void set_last_error(const std::string& msg);
 // every extern "C" body is wrapped in these: exceptions never cross the C ABI
 // (the JNI shim turns a non-zero status + lamp_last_error() into a JVM exception,
 // which is what lamp's Scope relies on - Scope.scala:394-421).
+#define LAMP_STATUS_HOST_TENSOR 2   /* lamp::HostTensorError: the generated staging layer (core/host_staging.cpp) retries on the GPU */
 #define LAMP_API_BEGIN try {
 #define LAMP_API_END                                                              \
   return 0;                                                                       \
+  }                                                                               \
+  catch (const ::lamp::HostTensorError& e) {                                      \
+    ::lamp::set_last_error(e.what());                                             \
+    return LAMP_STATUS_HOST_TENSOR;                                               \
   }                                                                               \
   catch (const std::exception& e) {                                               \
     ::lamp::set_last_error(e.what());                                             \
@@ -244,8 +254,14 @@ inline void check_same_device(const Tensor* a, const Tensor* b) {
 }
 inline void check_device_tensor(const Tensor* a, const char* what) {
   LAMP_CHECK(a != nullptr, what << " is null");
-  LAMP_CHECK(a->is_device(), what << " " << a->describe()
-             << " is a host tensor: this operator exists only as a GPU kernel, move the tensor to the GPU first");
+  if (!a->is_device()) {
+    // status LAMP_STATUS_HOST_TENSOR at the C ABI: when ALL tensor arguments are host tensors the staging layer runs the kernel on
+    // copies (core/host_staging.cpp); with mixed devices this message reaches the caller
+    std::ostringstream os;
+    os << what << " " << a->describe() << " is a host tensor while other arguments live on the GPU: this operator exists only as a GPU kernel - "
+       << "pass all tensors from one device (all-host arguments are staged through the GPU automatically)";
+    throw HostTensorError(os.str());
+  }
 }
 
 inline int grid_for(int64_t work_items, int block, int max_blocks_per_cu = 8) {

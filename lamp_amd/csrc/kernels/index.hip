@@ -502,7 +502,14 @@ static void check_index(const Tensor* index) {
 }
 
 template <int MODE> static Tensor* rng_new(const int64_t* sizes, int ndim, int dtype, int device, double p0, double p1) {
-  LAMP_CHECK(device >= 0, "random tensors are generated on the GPU; host generation is not supported");
+  if (device < 0) {
+    // lamp's CPU device (STen.rand / randint with CPU options, e.g. Umap.umap's default device): drawn by the same Philox kernel on
+    // the calling thread's current GPU and copied to host memory - one generator, one stream of numbers, whichever device is named
+    Hold d(rng_new<MODE>(sizes, ndim, dtype, current_device(), p0, p1));
+    Hold h(new_tensor(sizes, ndim, dtype, -1));
+    if (d->numel() > 0) copy_into(h.get(), d.get());
+    return h.take();
+  }
   Hold t(new_tensor(sizes, ndim, dtype, device));
   const int64_t n = t->numel();
   if (n) {

@@ -104,6 +104,10 @@ class ControlPlane:
                             c.close()
                             continue
                         _send_msg(c, {"ok": True})
+                        # the client confirms that it is still there: one that gave up waiting (rank 0 was busy with a silent stray)
+                        # has closed this connection and is retrying on a new one - counting the dead one would end the accept loop
+                        if not _recv_msg(c).get("ack"):
+                            raise ConnectionError("no acknowledgement")
                         c.settimeout(timeout)
                     except (OSError, ValueError, KeyError, TypeError, AttributeError, ConnectionError, struct.error):
                         try:
@@ -126,13 +130,14 @@ class ControlPlane:
                         cport, nonce = int(rec["port"]), rec["nonce"]
                     else:
                         cport, nonce = port, None
-                    s = socket.create_connection((addr, cport), timeout=5.0)
+                    s = socket.create_connection((addr, cport), timeout=15.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     _send_msg(s, {"rank": rank, "world": world, "nonce": nonce})
-                    ans = _recv_msg(s)            # still under the 5 s timeout: a stale record's port answers nothing, try again
+                    ans = _recv_msg(s)            # still under the 15 s timeout: a stale record's port answers nothing, try again
                     if not ans.get("ok"):
                         s.close()
                         raise ConnectionError(ans.get("why", "refused"))
+                    _send_msg(s, {"ack": True})
                     s.settimeout(timeout)
                     self.up = s
                     break

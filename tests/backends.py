@@ -38,6 +38,10 @@ class OracleBackend(Backend):
     def eq_scalar(self, t, v): return torch.ops.aten.eq.Scalar(t, v)
     def const_bool(self, t): return self.O.const(t)
     def param_transposed01(self, a): return self.O.param(self._t(a).transpose(0, 1))
+    def param_f32(self, a): return self.O.param(torch.tensor(np.asarray(a), dtype=torch.float32))
+    def sdpa(self, q, k, v, causal):
+        from oracle import lamp_transformer_oracle as TO
+        return TO.ScaledDotProductAttention(q, k, v, causal).value
 
 
 # give the oracle Variable the few method spellings the KATs use (lamp's names)
@@ -88,3 +92,5 @@ class HipBackend(Backend):
     def eq_scalar(self, t, v): return t.equ(v)
     def const_bool(self, t): return self.A.const(t)
     def param_transposed01(self, a): return self.A.param(self._t(a).transpose(0, 1))
+    def param_f32(self, a): return self.A.param(self.S.STen.from_numpy(np.asarray(a, dtype=np.float32), device=self.device, dtype=self.S.F32))
+    def sdpa(self, q, k, v, causal): return q.scaledDotProductAttention(k, v, None, causal)

@@ -332,6 +332,7 @@ def _more_cases(c):
             out = B.layer_norm(x, w, b, [3], 1e-5)
             return (out.mean([0, 1]) if mean else out), (x, w, b)[which]
         return f
+    c["layer norm 1d - wrt to input - no scale and no bias"] = (mat2x3, ln(0, False, False))
     c["layer norm 1d - wrt to weight"] = (ndx3, ln(1, True, True))
     c["layer norm 1d - wrt to weight - no bias"] = (ndx3, ln(1, True, False))
     c["layer norm 1d - wrt to bias"] = (ndx3, ln(2, True, True))
@@ -359,6 +360,36 @@ def _more_cases(c):
     c["tranposed conv2d - wrt input - padded"] = (nd1x2x3x3, tconv("x", 1))
     c["tranposed conv2d - wrt weight"] = (nd1x2x2x2, tconv("w", 0))
     c["tranposed conv2d - wrt bias"] = (ndx1, tconv("b", 0))
+
+
+# ---- the reference's fused-attention KATs (autograd.test.scala:219-285; CUDA only there: `testGradientAndValueCudaOnly`) -------------
+# q / k / v of shape (1, 8, 1, 8) in FLOAT32: one query and one key per head, so the softmax is 1 and the output is v - the value is
+# sum(v) (64, 64, 704 = 64 * 11) and the gradient w.r.t. q and k is exactly 0, w.r.t. v exactly 1.  All-ones K / V cannot discriminate
+# between layouts, but they are the only vectors the reference holds for the fused operator, so they are run as written.
+SDPA = GOLDEN["sdpa"]
+
+
+def run_sdpa_case(B: "Backend", name: str, m=None, backprop=True):
+    wrt = name[-1]
+    m = np.ones(64) if m is None else m
+    x = np.asarray(m, dtype=np.float32).reshape(1, 8, 1, 8)
+    ones = np.ones((1, 8, 1, 8), dtype=np.float32)
+    q = B.param_f32(x + np.float32(0.0) if wrt == "q" else ones)
+    k = B.param_f32(x + np.float32(0.0) if wrt == "k" else ones)
+    v = B.param_f32(x + np.float32(10.0) if wrt == "v" else ones)
+    L = B.sdpa(q, k, v, False).sum()
+    if backprop:
+        L.backprop()
+    return B.scalar(L), (B.grad({"q": q, "k": k, "v": v}[wrt]).reshape(-1) if backprop else None)
+
+
+def sdpa_finite_difference(B: "Backend", name: str):
+    eps = SDPA[name]["eps"]
+    g = np.zeros(64)
+    for i in range(64):
+        d = np.zeros(64); d[i] = eps
+        g[i] = (run_sdpa_case(B, name, np.ones(64) + d, False)[0] - run_sdpa_case(B, name, np.ones(64) - d, False)[0]) / (2 * eps)
+    return g
 
 
 CASES = _cases()

@@ -36,6 +36,23 @@ def test_reference_kat_on_gpu(gpu, name):
     np.testing.assert_allclose(grad, ograd, rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("device", [0, S.CPU])
+@pytest.mark.parametrize("name", sorted(kats.SDPA))
+def test_fused_attention_kat_on_gpu(gpu, name, device):
+    """autograd.test.scala:219-285 through lamp_scaled_dot_product_attention (+ _backward) in f32: value to 4 decimals, the exact
+    gradient, the reference's finite-difference rule where f32 resolves it, and agreement with the oracle (ATen's fused CPU operator).
+    Also with host tensors (the CPU device: staged through the GPU)."""
+    B = HipBackend(device=device)
+    value, grad = kats.run_sdpa_case(B, name)
+    assert round(value, 4) == round(kats.SDPA[name]["expected"], 4)
+    assert np.array_equal(grad, np.full(64, 1.0 if name.endswith("v") else 0.0))
+    fd = kats.sdpa_finite_difference(B, name)
+    digits = 1 if name.endswith("v") else 4
+    assert np.array_equal(np.round(grad, digits) + 0.0, np.round(fd, digits) + 0.0), (grad, fd)
+    ovalue, ograd = kats.run_sdpa_case(OracleBackend(), name)
+    assert value == ovalue and np.array_equal(grad, ograd)
+
+
 def test_adamw_kats_on_gpu(gpu):
     g = kats.GOLDEN["adamw"]
     for key in ("no_weight_decay", "weight_decay"):

@@ -125,6 +125,10 @@ def test_control_plane_rejects_a_rank_of_another_launch(tmp_path):
     s = socket.create_connection(("127.0.0.1", rec["port"]))
     D._send_msg(s, {"rank": 1, "world": 5, "nonce": rec["nonce"]})
     assert D._recv_msg(s)["ok"] is False
+    # a rank that gave up waiting and closed its connection after a valid hello is not counted as joined
+    gone = socket.create_connection(("127.0.0.1", rec["port"]))
+    D._send_msg(gone, {"rank": 1, "world": 2, "nonce": rec["nonce"]})
+    gone.close()
     s.close()
     good = D.ControlPlane(1, 2, "127.0.0.1", 0, rdzv, 30.0)
     th.join(30)

@@ -1,0 +1,165 @@
+"""The CPU device on operators that exist only as GPU kernels.
+
+lamp's defaults and its own tests use host tensors where this library has only kernels: `knnSearch` / `Umap.umap` default to
+`device = CPU` (knn/package.scala:145, umap.scala:357,423), the gradient suite runs its CPU variant first (`fun(m, _, false)`,
+autograd.test.scala:117-133), BASELINE config 1 is "the ATen CPU path".  Handed tensors that ALL live in host memory such an operator
+copies them to the current GPU, runs the same kernel and returns host tensors (generated layer: scripts/gen_host_staging.py ->
+csrc/core/host_staging.cpp + csrc/kernels/abi_dev_names.h).  No second implementation: the results are BITWISE those of the GPU device.
+
+not gpu: the generated files are current and the library exports both names of every staged entry point.
+gpu: all reference KATs, the optimiser KATs, kNN, UMAP and the MLP step on the CPU device; mixed devices still fail loudly."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from lamp_amd import _capi
+from lamp_amd._capi import lib, LampError, i64_array
+from lamp_amd import sten as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _generated():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gen_host_staging as G
+    return G
+
+
+def test_generated_staging_layer_is_current():
+    G = _generated()
+    names, cpp, fns = G.generate()
+    assert open(G.OUT_NAMES).read() == names, "run scripts/gen_host_staging.py (include/lamp_hip.h changed)"
+    assert open(G.OUT_CPP).read() == cpp, "run scripts/gen_host_staging.py (include/lamp_hip.h changed)"
+    assert len(fns) >= 190
+    for must in ("lamp_convolution", "lamp_convolution_backward", "lamp_native_batch_norm", "lamp_native_layer_norm", "lamp_log_softmax",
+                 "lamp_nll_loss_forward", "lamp_max_pool2d_with_indices", "lamp_embedding", "lamp_knn_squared_euclidean",
+                 "lamp_umap_loss_grad_skip_self", "lamp_adamw_step_", "lamp_scaled_dot_product_attention"):
+        assert must in fns, must
+
+
+def test_library_exports_both_names_of_every_staged_entry_point():
+    G = _generated()
+    _, _, fns = G.generate()
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    for f in fns:
+        assert f in exported and f + "__dev" in exported, f
+
+
+# ---- on the GPU box ----------------------------------------------------------------------------------------------------------------
+from tests import kats                                          # noqa: E402
+from tests.backends import HipBackend                           # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(kats.CASES))
+def test_reference_kat_on_the_cpu_device(gpu, name):
+    """the reference's `cuda = false` variant of every gradient KAT (autograd.test.scala:117-133): host tensors in, host tensors out,
+    the reference's acceptance rule, and bitwise the results of the GPU device (same kernels)."""
+    B = HipBackend(device=S.CPU)
+    value, grad = kats.run_case(B, name)
+    assert round(value, 4) == round(kats.EXPECTED[name], 4), (name, value, kats.EXPECTED[name])
+    fd = kats.finite_difference(B, name)
+    assert np.array_equal(np.round(grad.reshape(-1), 4) + 0.0, np.round(fd.reshape(-1), 4) + 0.0, equal_nan=True), (name, grad, fd)
+    gvalue, ggrad = kats.run_case(HipBackend(device=0), name)
+    assert value == gvalue or (np.isnan(value) and np.isnan(gvalue))
+    assert np.array_equal(grad, ggrad, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_outputs_of_staged_operators_live_on_the_host(gpu):
+    x = S.STen.from_numpy(np.arange(2 * 3 * 8 * 8, dtype=np.float32).reshape(2, 3, 8, 8) / 100.0, S.CPU)
+    w = S.STen.from_numpy(np.ones((4, 3, 3, 3), dtype=np.float32), S.CPU)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), x, w, None, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
+    y = S.STen(o)
+    assert y.device == S.CPU and y.shape == [2, 4, 8, 8]
+    o2 = C.c_void_p()
+    lib.lamp_convolution(C.byref(o2), S.STen.from_numpy(x.to_numpy(), 0), S.STen.from_numpy(w.to_numpy(), 0), None, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1)
+    assert np.array_equal(y.to_numpy(), S.STen(o2).to_numpy())
+    # in-place arguments are written back through the caller's host tensor (running statistics of a batch norm)
+    rm, rv = S.STen.from_numpy(np.zeros(3, dtype=np.float32), S.CPU), S.STen.from_numpy(np.ones(3, dtype=np.float32), S.CPU)
+    out3 = (C.c_void_p * 3)()
+    lib.lamp_native_batch_norm(out3, x, None, None, rm, rv, 1, 0.1, 1e-5)
+    assert all(S.STen(h).device == S.CPU for h in out3)
+    xn = x.to_numpy()
+    assert np.allclose(rm.to_numpy(), 0.1 * xn.mean((0, 2, 3)), rtol=1e-5)
+    # mixed devices: the kernel's own message, no staging
+    with pytest.raises(LampError, match="host tensor"):
+        lib.lamp_convolution(C.byref(o), x, S.STen.from_numpy(w.to_numpy(), 0), None, i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0,
+                             i64_array([0, 0]), 1)
+
+
+@pytest.mark.gpu
+def test_optimiser_kats_on_the_cpu_device(gpu):
+    """adamw.test.scala / sgd.test.scala run on the CPU in the reference: the fused multi-tensor kernels on host parameters"""
+    from lamp_amd import nn
+    g = kats.GOLDEN["adamw"]
+    for key in ("no_weight_decay", "weight_decay"):
+        p = S.STen.from_numpy(np.array([g["init"]]), S.CPU, S.F64)
+        grad = S.STen.from_numpy(np.array([g["gradients"]]), S.CPU, S.F64)
+        opt = nn.AdamW([p], weightDecay=g[key]["weightDecay"], learningRate=g["learningRate"], beta1=g["beta1"], beta2=g["beta2"])
+        for step in ("step1", "step2"):
+            opt.step([grad], 1.0)
+            assert p.device == S.CPU
+            np.testing.assert_allclose(p.to_numpy()[0], g[key][step], rtol=1e-14, atol=0)
+    s = kats.GOLDEN["sgd"]
+    p = S.STen.ones([1, 2], S.F64, S.CPU)
+    opt = nn.SGDW([p], 1.0, 0.1)
+    grad = S.STen.from_numpy(np.array([s["two_steps"]["grad"]]), S.CPU)
+    opt.step([grad], 1.0)
+    assert np.array_equal(np.round(p.to_numpy()[0], 4), np.round(s["two_steps"]["step1"], 4))
+    opt.step([grad], 1.0)
+    assert np.array_equal(np.round(p.to_numpy()[0], 4), np.round(s["two_steps"]["step2"], 4))
+    c = kats.GOLDEN["gradient_clipping"]
+    ts = [S.STen.ones(sh, S.F64, S.CPU) for sh in c["shapes"]]
+    nn.gradientClippingInPlace(ts, c["theta"])
+    assert np.array_equal(np.round(ts[0].to_numpy().reshape(-1), 4), np.round(np.full(6, c["expect"]), 4))
+
+
+@pytest.mark.gpu
+def test_knn_and_umap_with_the_reference_default_device(gpu):
+    """knnSearch(..., device = CPU) and Umap.umap(..., device = CPU) - the reference's default arguments (knn/package.scala:145,
+    umap.scala:357): same neighbours, same graph and (same Philox stream) the same layout as on the GPU device"""
+    from lamp_amd import knn as K, umap as U
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 50, (300, 16)).astype(np.float64)
+    for dist in (K.SquaredEuclideanDistance, K.JaccardDistance):
+        a = K.knnSearch(data, data[:40], 5, dist, device=S.CPU)
+        b = K.knnSearch(data, data[:40], 5, dist, device=0)
+        assert np.array_equal(a, b)
+    lay_c, b_c, loss_c = U.umap(data, device=S.CPU, k=6, iterations=20, randomSeed=7)
+    lay_g, b_g, loss_g = U.umap(data, device=0, k=6, iterations=20, randomSeed=7)
+    assert lay_c.device == S.CPU and b_c.device == S.CPU
+    assert np.array_equal(b_c.to_numpy(), b_g.to_numpy())
+    np.testing.assert_allclose(lay_c.to_numpy(), lay_g.to_numpy(), rtol=0, atol=1e-9)   # f64 atomics: summation order differs run to run
+    assert abs(loss_c - loss_g) <= 1e-9 * max(1.0, abs(loss_g))
+
+
+@pytest.mark.gpu
+def test_mlp_step_on_the_cpu_device_is_baseline_config_1(gpu):
+    """BASELINE config 1: 2-layer MLP forward + backward on a 1024 x 784 f32 batch, "lamp-core ATen CPU path": module, batch and
+    gradients on the CPU device, against the oracle (f32 forward <= 1e-5, gradients <= 1e-3)"""
+    import torch
+    from lamp_amd import nn
+    from oracle import lamp_oracle as O
+    from tests.util import to_torch, rel_err
+    dt = torch.float32
+    om = O.Sequential(O.mlp(784, 10, [256], dt), O.Fun(lambda v: v.logSoftMax(1)))
+    hm = nn.Sequential(nn.MLP(784, 10, [256], S.F32, S.CPU), nn.Fun("logsoftmax", 1))
+    hm.load([S.STen.from_numpy(v.value.numpy(), S.CPU) for v in om.state()])
+    x = O.closed_form(1024 * 784, 0, 1.0, dt).reshape(1024, 784)
+    t = torch.arange(1024) % 10
+    cw = torch.ones(10, dtype=dt)
+    oloss, ograds = O.training_step(om, O.nll_loss(10, cw), x, t, None)
+    model = nn.SupervisedModel(hm, nn.SupervisedModel.NLL, S.STen.from_numpy(cw.numpy(), S.CPU))
+    acc = S.STen.zeros([1], S.F32, S.CPU)
+    n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(S.STen.from_numpy(x.numpy(), S.CPU), S.STen.from_numpy(t.numpy(), S.CPU), acc)
+    assert n == 1024 and all(g.device == S.CPU for g in grads)
+    assert rel_err(to_torch(acc) / 1024, oloss.double().reshape(1)) <= 1e-5
+    for g, og in zip(grads, ograds):
+        assert rel_err(to_torch(g), og.double()) <= 1e-3

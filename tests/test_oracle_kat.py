@@ -24,6 +24,19 @@ def test_autograd_kat_value_and_gradient(name):
     assert np.array_equal(np.round(grad.reshape(-1), 4) + 0.0, np.round(fd.reshape(-1), 4) + 0.0, equal_nan=True), (name, grad, fd)
 
 
+@pytest.mark.parametrize("name", sorted(kats.SDPA))
+def test_fused_attention_kat_value_and_gradient(name):
+    """autograd.test.scala:219-285 (CUDA only in the reference): the fused operator on q / k / v of shape (1, 8, 1, 8), f32.
+    Value to 4 decimals; the autograd gradient is exact (0 for q and k, 1 for v) and equals the reference's central difference
+    wherever f32 can resolve it (the sum of 64 f32 values near 704 moves in steps of 6e-5: the v case compares to 1 decimal)."""
+    value, grad = kats.run_sdpa_case(B, name)
+    assert round(value, 4) == round(kats.SDPA[name]["expected"], 4)
+    assert np.array_equal(grad, np.full(64, 1.0 if name.endswith("v") else 0.0))
+    fd = kats.sdpa_finite_difference(B, name)
+    digits = 1 if name.endswith("v") else 4
+    assert np.array_equal(np.round(grad, digits) + 0.0, np.round(fd, digits) + 0.0), (grad, fd)
+
+
 def test_exact_constants_at_full_precision():
     # the KATs the reference states with all digits
     for name in ("softmax", "exp", "l2 logistic regression loss - nll_loss", "nn Logistic 2 - wrt weight", "nn Mlp1 - wrt first weight"):
