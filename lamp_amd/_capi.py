@@ -16,7 +16,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADERS = [os.path.join(ROOT, "include", "lamp_hip.h"), os.path.join(ROOT, "include", "lamp_host.h")]
-LIB_PATH = os.path.join(_HERE, "lib", "liblamp_hip.so")
+# LAMP_LIB_PATH: a diagnostic build of the same library (in-kernel stamps: `make EXTRA=-DGEMM_STAMP BUILD=build_stamp LIBDIR=../lib_stamp`)
+LIB_PATH = os.environ.get("LAMP_LIB_PATH") or os.path.join(_HERE, "lib", "liblamp_hip.so")
 
 
 class LampError(RuntimeError):

@@ -679,7 +679,9 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
 //    per 128-byte row: full cache lines instead of 8-byte pieces (ig_conv8b writes 1.5x its algorithmic bytes to HBM).
 #ifdef IG8D_STAMP
 __device__ unsigned long long ig8d_stamps[8 * 512];
-#define IG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) ig8d_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long ig8d_rt_stamps[8 * 512];      // the constant 100 MHz clock beside the shader clock: in-kernel frequency
+#define IG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) { ig8d_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+                                                                     ig8d_rt_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define IG_STAMP(k) do { } while (0)
 #endif
@@ -956,6 +958,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
 }
 #ifdef IG8D_STAMP
 extern "C" int lamp_debug_ig8d_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ig8d_stamps), sizeof(ig8d_stamps)) == hipSuccess ? 0 : 1; }
+extern "C" int lamp_debug_ig8d_rt_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(ig8d_rt_stamps), sizeof(ig8d_rt_stamps)) == hipSuccess ? 0 : 1; }
 #endif
 
 // ---- wgrad v2: all taps in one workgroup ----------------------------------------------------------------

@@ -450,9 +450,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmArgs g) {
 constexpr int QM = 256, QN = 256;
 constexpr int Q_IMG = QM * PK * 2, Q_SLOT = 2 * Q_IMG;     // 32 KiB per operand image, 64 KiB per stage
 
+// -DGEMM_STAMP (diagnostic builds only, `make EXTRA=-DGEMM_STAMP`; scripts/gemm_clock_probe.py): thread 0 of every workgroup stamps the
+// shader clock (s_memtime) AND the constant 100 MHz clock (s_memrealtime) at the kernel's start, around the main loop and at its end,
+// into a buffer nothing else reads: in-kernel clock = delta(s_memtime) / delta(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+#ifdef GEMM_STAMP
+__device__ unsigned long long gemm_stamps[512 * 8];
+#define GQ_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.z == 0) {                                  \
+    gemm_stamps[blockIdx.x * 8 + 2 * (k)] = __builtin_amdgcn_s_memtime();                                                \
+    gemm_stamps[blockIdx.x * 8 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int lamp_debug_gemm_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_stamps), sizeof(gemm_stamps)) == hipSuccess ? 0 : 1; }
+#else
+#define GQ_STAMP(k) do { } while (0)
+#endif
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GQ_STAMP(0);
   const int ntiles = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
   {
@@ -492,6 +506,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
   dma(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  GQ_STAMP(1);
+#ifdef GEMM_STAMP
+  __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0) alone: the stamp's scalar loads must not colour the loop's first LDS waits
+#endif
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
   bf8_t fa[8], fb[4];
@@ -531,6 +549,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
 #undef Q_READ
 #undef Q_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
+  GQ_STAMP(2);
 
   if (g.split_f32) {
     float* W = (float*)g.C + bz * g.c_bs;
@@ -577,6 +596,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
       *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
     }
   }
+  GQ_STAMP(3);
 }
 
 // split-K epilogue: C[m][n] = alpha * sum_s W[s][m][n] + beta * S[m][n], four columns per thread (N % 4 == 0), slices summed in order

@@ -261,6 +261,7 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
                      const double* beta2, double eps, double schedule_factor, int64_t step_count, int debias) {
   LAMP_API_BEGIN
   if (n == 0) return 0;
+  check_device_tensor(params[0], "parameter");                 // host parameters: the staging layer runs the step on GPU copies
   const int dev = params[0]->device();
   hipStream_t st = current_stream(dev);
   // group tensors by (state dtype, grad dtype) so that each launch is homogeneous

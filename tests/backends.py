@@ -93,4 +93,4 @@ class HipBackend(Backend):
     def const_bool(self, t): return self.A.const(t)
     def param_transposed01(self, a): return self.A.param(self._t(a).transpose(0, 1))
     def param_f32(self, a): return self.A.param(self.S.STen.from_numpy(np.asarray(a, dtype=np.float32), device=self.device, dtype=self.S.F32))
-    def sdpa(self, q, k, v, causal): return q.scaledDotProductAttention(k, v, None, causal)
+    def sdpa(self, q, k, v, causal): return q.scaledDotProductAttention(k, v, causal, None)

@@ -59,15 +59,17 @@ from tests.backends import HipBackend                           # noqa: E402
 @pytest.mark.parametrize("name", sorted(kats.CASES))
 def test_reference_kat_on_the_cpu_device(gpu, name):
     """the reference's `cuda = false` variant of every gradient KAT (autograd.test.scala:117-133): host tensors in, host tensors out,
-    the reference's acceptance rule, and bitwise the results of the GPU device (same kernels)."""
+    the reference's acceptance rule, and the results of the GPU device to f64 rounding."""
     B = HipBackend(device=S.CPU)
     value, grad = kats.run_case(B, name)
     assert round(value, 4) == round(kats.EXPECTED[name], 4), (name, value, kats.EXPECTED[name])
     fd = kats.finite_difference(B, name)
     assert np.array_equal(np.round(grad.reshape(-1), 4) + 0.0, np.round(fd.reshape(-1), 4) + 0.0, equal_nan=True), (name, grad, fd)
+    # against the GPU device: the kernels are the same ones; the element-wise ops and reductions around them run on the host for host
+    # tensors (lamp's CPU device computes where the tensor lives), so sums may differ in the last bits
     gvalue, ggrad = kats.run_case(HipBackend(device=0), name)
-    assert value == gvalue or (np.isnan(value) and np.isnan(gvalue))
-    assert np.array_equal(grad, ggrad, equal_nan=True)
+    assert abs(value - gvalue) <= 1e-12 * max(1.0, abs(gvalue)) or (np.isnan(value) and np.isnan(gvalue))
+    np.testing.assert_allclose(grad, ggrad, rtol=1e-10, atol=1e-12)
 
 
 @pytest.mark.gpu
