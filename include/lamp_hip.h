@@ -464,6 +464,19 @@ int lamp_native_batch_norm_add_relu_backward(lamp_tensor* out4[4] /* dx, dweight
                                              const lamp_tensor* bias_or_null, const lamp_tensor* running_mean_or_null,
                                              const lamp_tensor* running_var_or_null, const lamp_tensor* save_mean_or_null,
                                              const lamp_tensor* save_invstd_or_null, int training, double eps, const uint8_t mask[4]);
+/* relu(batch_norm(x) + batch_norm2(x2)): the tail of lamp's residual block when BOTH branches end in a batch norm (the right branch's
+ * Seq6 and the left branch's Conv2D -> BatchNorm2D, example-cifar100 cnn.scala:36-78, followed by Fun(relu)) as one kernel per direction.
+ * Training mode, maps of >= 64 elements.  Forward values are bitwise those of the chain batch_norm2 -> batch_norm_add_relu; out5 =
+ * y, save_mean, save_invstd, save_mean2, save_invstd2; out6 = dx, dweight, dbias, dx2, dweight2, dbias2 (mask selects). */
+int lamp_native_batch_norm2_add_relu(lamp_tensor* out5[5], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                                     lamp_tensor* running_mean, lamp_tensor* running_var, const lamp_tensor* x2, const lamp_tensor* weight2,
+                                     const lamp_tensor* bias2, lamp_tensor* running_mean2, lamp_tensor* running_var2, double momentum,
+                                     double momentum2, double eps, double eps2);
+int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                                              const lamp_tensor* bias, const lamp_tensor* save_mean, const lamp_tensor* save_invstd,
+                                              const lamp_tensor* x2, const lamp_tensor* weight2, const lamp_tensor* bias2,
+                                              const lamp_tensor* save_mean2, const lamp_tensor* save_invstd2, double eps, double eps2,
+                                              const uint8_t mask[6]);
 int lamp_native_layer_norm(lamp_tensor* out3[3] /* y, mean, rstd */, const lamp_tensor* x,
                            const int64_t* normalized_shape, int nnorm, const lamp_tensor* weight_or_null,
                            const lamp_tensor* bias_or_null, double eps);

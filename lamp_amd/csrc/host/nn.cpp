@@ -68,6 +68,21 @@ Var Residual::forward_relu(const Var& x) {
     // right branch up to (not including) its last batch norm, with the usual BatchNorm -> relu rewrite inside
     Sequential head(std::vector<Mod>(seq->mods.begin(), seq->mods.end() - 1));
     Var v = head.forward(x);
+    // both branches end in a batch norm (every block of Cnn.resnet: the left branch is Conv2D 1x1 -> BatchNorm2D): one op for
+    // relu(bn(right) + bn(left)) - the left batch norm's output is never written (LAMP_FUSE_BN_PAIR=0: the chain)
+    static const bool fuse_pair = [] { const char* e = getenv("LAMP_FUSE_BN_PAIR"); return !(e && e[0] == '0'); }();
+    auto* lseq = left ? dynamic_cast<Sequential*>(left.get()) : nullptr;
+    BatchNorm* lbn = (lseq && !lseq->mods.empty()) ? dynamic_cast<BatchNorm*>(lseq->mods.back().get()) : nullptr;
+    if (fuse_pair && lbn && bn->can_fuse_add_relu(v)) {
+      Sequential lhead(std::vector<Mod>(lseq->mods.begin(), lseq->mods.end() - 1));
+      Var lv = lhead.forward(x);
+      if (lbn->can_fuse_add_relu(lv) && lv->shape() == v->shape() && lv->value.dtype() == v->value.dtype())
+        return F::batch_norm2_add_relu_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps,
+                                          lv, lbn->weight, lbn->bias, lbn->runningMean->value, lbn->runningVar->value, lbn->momentum, lbn->eps);
+      Var l = lbn->forward(lv);
+      if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);
+      return F::relu(F::add(bn->forward(v), l));
+    }
     if (bn->can_fuse_add_relu(v)) {
       Var l = left ? left->forward(x) : x;
       if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);

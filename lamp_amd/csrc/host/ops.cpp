@@ -796,6 +796,55 @@ Var batch_norm_add_relu_2d(const Var& input, const Var& addend, const Var& weigh
   op->params.push_back({addend, back(3)});
   return make_result(op, out);
 }
+// relu(batch_norm_2d(x) + batch_norm_2d(x2)) as ONE op: the tail of lamp's residual block when the LEFT branch ends in a batch norm too
+// (Conv2D 1x1 -> BatchNorm2D, cnn.scala:62-78; every block of Cnn.resnet).  Forward values are bitwise those of the chain (left batch
+// norm, then batch_norm_add_relu_2d); neither the left branch's normalised output nor the relu-masked gradient is ever written
+// (lamp_native_batch_norm2_add_relu).  One backward call serves the six closures.
+Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum, double eps,
+                            const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2, const Ten& runningVar2, double momentum2,
+                            double eps2) {
+  auto op = new_op("BatchNorm2DPairAddRelu");
+  const Ten x = input->value, wv = weight->value, bv = bias->value, x2 = input2->value, wv2 = weight2->value, bv2 = bias2->value;
+  const std::vector<int64_t> expected = {x.size(1)};
+  LAMP_CHECK(weight->shape() == expected && bias->shape() == expected && weight2->shape() == expected && bias2->shape() == expected,
+             "batch norm weight / bias have the wrong shape");
+  LAMP_CHECK(runningMean.shape() == expected && runningVar.shape() == expected && runningMean2.shape() == expected && runningVar2.shape() == expected,
+             "running statistics have the wrong shape");
+  lamp_tensor* o5[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  HCALL(lamp_native_batch_norm2_add_relu(o5, x.h(), wv.h(), bv.h(), runningMean.h(), runningVar.h(), x2.h(), wv2.h(), bv2.h(), runningMean2.h(),
+                                         runningVar2.h(), momentum, momentum2, eps, eps2));
+  Ten out(o5[0]), saveMean(o5[1]), saveInvstd(o5[2]), saveMean2(o5[3]), saveInvstd2(o5[4]);
+  struct Cache { Ten g[6]; Ten p; };                       // dx, dweight, dbias, dx2, dweight2, dbias2 of one backward call, and the p they belong to
+  auto cache = std::make_shared<Cache>();
+  const bool want[6] = {input->needsGrad(), weight->needsGrad(), bias->needsGrad(), input2->needsGrad(), weight2->needsGrad(), bias2->needsGrad()};
+  auto back = [=](int which) {
+    return [=](const Ten& p, Variable& o) {
+      if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
+        uint8_t mask[6];
+        for (int i = 0; i < 6; i++) mask[i] = (uint8_t)want[i];
+        mask[which] = 1;
+        lamp_tensor* r6[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        HCALL(lamp_native_batch_norm2_add_relu_backward(r6, p.h(), x.h(), wv.h(), bv.h(), saveMean.h(), saveInvstd.h(), x2.h(), wv2.h(), bv2.h(),
+                                                        saveMean2.h(), saveInvstd2.h(), eps, eps2, mask));
+        for (int i = 0; i < 6; i++) cache->g[i] = r6[i] ? Ten(r6[i]) : Ten();
+        cache->p = p;
+      }
+      Ten g = cache->g[which];
+      cache->g[which] = Ten();
+      bool any = false;
+      for (int i = 0; i < 6; i++) any = any || cache->g[i].defined();
+      if (!any) cache->p = Ten();
+      o.accumulate(ops::reshape(g, o.shape()), true);
+    };
+  };
+  op->params.push_back({input, back(0)});
+  op->params.push_back({weight, back(1)});
+  op->params.push_back({bias, back(2)});
+  op->params.push_back({input2, back(3)});
+  op->params.push_back({weight2, back(4)});
+  op->params.push_back({bias2, back(5)});
+  return make_result(op, out);
+}
 Var layer_norm(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& normalizedShape, double eps) {
   auto op = new_op("LayerNormOp");
   lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};

@@ -62,6 +62,9 @@ Var batch_norm_relu_2d(const Var& input, const Var& weight, const Var& bias, con
                        double momentum, double eps);
 Var batch_norm_add_relu_2d(const Var& input, const Var& addend, const Var& weight, const Var& bias, const Ten& runningMean,
                            const Ten& runningVar, bool training, double momentum, double eps);
+Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum, double eps,
+                            const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2, const Ten& runningVar2, double momentum2,
+                            double eps2);   // relu(bn(input) + bn2(input2)), training mode, one op
 Var layer_norm(const Var& input, const Var& weight /*nullable*/, const Var& bias /*nullable*/, const std::vector<int64_t>& normalizedShape,
                double eps);
 Var embedding(const Var& input, const Var& weight);

@@ -193,28 +193,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
-// Channel-aligned normalise with the finalize folded in (training mode, maps of >= 64 elements): workgroup (c, slice).
-// Its first wavefront merges the channel's split partials exactly as bn_finalize_kernel does (same order, so every
-// workgroup of the channel gets bitwise the same mean / invstd), slice 0 also writes save_mean / save_invstd and updates the
-// running statistics; then the workgroup normalises its slice of the channel.  One launch less per batch norm, and no
-// cross-workgroup hand-off (the partials are complete at the kernel boundary).
+// Channel c's partial statistics -> (mean, invstd) as they are SAVED (rounded to T) in stat[0..1]; called by every thread of the
+// workgroup.  nsplit > 0: partial[s][c] (the statistics kernel), merged by the first wavefront; nsplit < 0: partial[c][s] with -nsplit
+// EQUAL-count triples (a convolution's per-image statistics), merged by the whole workgroup in a fixed order:
+// with shift = mean_0,  mean = shift + S1 / np,  m2 = sum m2_s + n0 (S2 - S1^2 / np)  where S1 = sum (mean_s - shift), S2 = sum (mean_s - shift)^2
+// (no division per partial).  Every workgroup of the channel gets bitwise the same values; slice 0 writes save_mean / save_invstd and
+// updates the running statistics.
 template <class T>
-__global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x, T* __restrict__ y, const acc_t<T>* __restrict__ partial, int nsplit,
-                                                        T* __restrict__ save_mean, T* __restrict__ save_invstd, T* running_mean, T* running_var,
-                                                        double momentum, double eps, const T* __restrict__ w, const T* __restrict__ b, int64_t N,
-                                                        int64_t C, int64_t HW, int nblk, int vec, int relu, const T* __restrict__ addend) {
+__device__ __forceinline__ void bn_merge_channel(const acc_t<T>* __restrict__ partial, int nsplit, int64_t c, int64_t C, int slice, T* __restrict__ save_mean,
+                                                 T* __restrict__ save_invstd, T* running_mean, T* running_var, double momentum, double eps,
+                                                 acc_t<T>* stat, acc_t<T> (*wpart)[3]) {
   using A = acc_t<T>;
-  constexpr int W = 16 / sizeof(T);
-  __shared__ A stat[2];
-  __shared__ A wpart[4][3];
-  const int64_t c = blockIdx.x;
-  const int slice = blockIdx.y;
-  // nsplit > 0: partial[s][c] (the statistics kernel); nsplit < 0: partial[c][s] with -nsplit entries (a convolution's per-image
-  // statistics, merged here by the whole workgroup in a fixed order)
   const int np = nsplit < 0 ? -nsplit : nsplit;
   if (nsplit < 0) {
-    // EQUAL-count triples (n0, mean_s, m2_s): with shift = mean_0,  mean = shift + S1 / np,  m2 = sum m2_s + n0 (S2 - S1^2 / np)
-    // where S1 = sum (mean_s - shift), S2 = sum (mean_s - shift)^2: no division per partial, fixed summation order
     const A* pc = partial + (int64_t)c * np * 3;
     const A shift = pc[1];
     A s1 = 0, s2 = 0, sm = 0;
@@ -235,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
       r.m2 = sm + n0 * (s2 - s1 * s1 / (A)np);
     } else {
       for (int s = lane; s < np; s += 64) {
-        const A* p = nsplit < 0 ? partial + ((int64_t)c * np + s) * 3 : partial + ((int64_t)s * C + c) * 3;
+        const A* p = partial + ((int64_t)s * C + c) * 3;
         r = wf_merge(r, Welford<A>{p[0], p[1], p[2]});
       }
       r = wf_wave(r);
@@ -258,9 +249,41 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
     }
   }
   __syncthreads();
+}
+// A second batch norm whose OUTPUT is the addend (lamp_native_batch_norm2_add_relu: the tail of lamp's residual block when the left
+// branch is convolution -> batch norm too, cnn.scala:62-78): x == nullptr means none.  Passed by value.
+template <class T> struct BnSecond {
+  const T* x; const acc_t<T>* partial; int nsplit; T* save_mean; T* save_invstd; T* running_mean; T* running_var; double momentum, eps; const T* w; const T* b;
+};
+
+// Channel-aligned normalise with the finalize folded in (training mode, maps of >= 64 elements): workgroup (c, slice).
+// bn_merge_channel gives every workgroup of the channel bitwise the same mean / invstd; then the workgroup normalises its slice of the
+// channel.  One launch less per batch norm, and no cross-workgroup hand-off (the partials are complete at the kernel boundary).
+// With `second`: y = relu(round(round(bn(x)) + round(bn2(x2)))) - the three-kernel chain bn2 -> (bn + add + relu) with every intermediate
+// rounded as the chain rounds it, without writing and re-reading bn2's output.
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x, T* __restrict__ y, const acc_t<T>* __restrict__ partial, int nsplit,
+                                                        T* __restrict__ save_mean, T* __restrict__ save_invstd, T* running_mean, T* running_var,
+                                                        double momentum, double eps, const T* __restrict__ w, const T* __restrict__ b, int64_t N,
+                                                        int64_t C, int64_t HW, int nblk, int vec, int relu, const T* __restrict__ addend,
+                                                        BnSecond<T> second) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  __shared__ A stat[2], stat2[2];
+  __shared__ A wpart[4][3];
+  const int64_t c = blockIdx.x;
+  const int slice = blockIdx.y;
+  bn_merge_channel<T>(partial, nsplit, c, C, slice, save_mean, save_invstd, running_mean, running_var, momentum, eps, stat, wpart);
+  if (second.x)
+    bn_merge_channel<T>(second.partial, second.nsplit, c, C, slice, second.save_mean, second.save_invstd, second.running_mean, second.running_var,
+                        second.momentum, second.eps, stat2, wpart);
   const A mu = stat[0];
   const A scale = stat[1] * (w ? load_as<A>(w[c]) : A(1));
   const A bb = b ? load_as<A>(b[c]) : A(0);
+  const A mu2 = second.x ? stat2[0] : A(0);
+  const A scale2 = second.x ? stat2[1] * (second.w ? load_as<A>(second.w[c]) : A(1)) : A(0);
+  const A bb2 = (second.x && second.b) ? load_as<A>(second.b[c]) : A(0);
+  const T* __restrict__ adsrc = second.x ? second.x : addend;
   if (vec) {
     const int64_t vpp = HW / W, total = N * vpp;
     for (int64_t i = (int64_t)slice * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
@@ -269,11 +292,15 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
       // x (and the addend) are not read again before the backward pass: streamed, so that y - which the next convolution reads - keeps the caches
       Vec<T, W> pk, ad;
       { const uint4 t = nt_load16(reinterpret_cast<const uint4*>(x + base)); pk = *reinterpret_cast<const Vec<T, W>*>(&t); }
-      if (addend) { const uint4 t = nt_load16(reinterpret_cast<const uint4*>(addend + base)); ad = *reinterpret_cast<const Vec<T, W>*>(&t); }
+      if (adsrc) { const uint4 t = nt_load16(reinterpret_cast<const uint4*>(adsrc + base)); ad = *reinterpret_cast<const Vec<T, W>*>(&t); }
 #pragma unroll
       for (int k = 0; k < W; k++) {
         T o = store_as<T>(bn_affine<A>(load_as<A>(pk.v[k]), mu, scale, bb));
-        if (addend) o = store_as<T>((A)(load_as<A>(o) + load_as<A>(ad.v[k])));     // the residual add, rounded as the add kernel rounds
+        if (adsrc) {
+          T a = ad.v[k];
+          if (second.x) a = store_as<T>(bn_affine<A>(load_as<A>(a), mu2, scale2, bb2));   // the left branch's batch norm, rounded as its own kernel rounds
+          o = store_as<T>((A)(load_as<A>(o) + load_as<A>(a)));                           // the residual add, rounded as the add kernel rounds
+        }
         if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
         pk.v[k] = o;
       }
@@ -285,7 +312,11 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
       const int64_t n = i / HW, v = i - n * HW;
       const int64_t base = (n * C + c) * HW + v;
       T o = store_as<T>(bn_affine<A>(load_as<A>(x[base]), mu, scale, bb));
-      if (addend) o = store_as<T>((A)(load_as<A>(o) + load_as<A>(addend[base])));
+      if (adsrc) {
+        T a = adsrc[base];
+        if (second.x) a = store_as<T>(bn_affine<A>(load_as<A>(a), mu2, scale2, bb2));
+        o = store_as<T>((A)(load_as<A>(o) + load_as<A>(a)));
+      }
       if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
       y[base] = o;
     }
@@ -534,14 +565,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
 // never satisfied (~seconds) traps instead of hanging the device.
 // slots[c * S + s] = workgroup (c, s)'s (s1, s2), all-ones between launches; depart[c] counts the workgroups that have read the channel's
 // slots, zero between launches: the last one to leave resets both.
-template <int NP, bool RELU, bool ADD>                     // compile-time: run-time branches in the element loop let the compiler sink the sums
+// DUAL (lamp_native_batch_norm2_add_relu_backward): the addend is itself a batch norm's output, round(bn2(x2)), which the forward never
+// wrote: `addend` points at x2, the mask is recomputed from (x, x2), a third sum (sum g (x2 - mean2)) travels through a second slot, and
+// instead of the masked gradient the kernel writes the SECOND batch norm's input gradient (x2 is read once more for that - by then it
+// comes from the Infinity Cache) and its dweight / dbias: one launch and 6 passes instead of two launches and 8.
+struct BnFusedDual { const bf16_t* mean2; const bf16_t* invstd2; const bf16_t* w2; const bf16_t* b2; bf16_t* dweight2; bf16_t* dbias2; unsigned long long* slots2; };
+template <int NP, bool RELU, bool ADD, bool DUAL = false>  // compile-time: run-time branches in the element loop let the compiler sink the sums
 __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ mean,
                                                            const bf16_t* __restrict__ invstd, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                            unsigned long long* slots, unsigned* depart, bf16_t* dweight, bf16_t* dbias, bf16_t* __restrict__ dx,
                                                            int64_t N, int C, int HW, int S, double inv_m, int relu,
-                                                           const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift, int* assert_word) {
-  __shared__ float sm[2][8];
-  __shared__ float stat[2];
+                                                           const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift, int* assert_word,
+                                                           BnFusedDual dual) {
+  __shared__ float sm[3][8];
+  __shared__ float stat[3];
   const int c = blockIdx.x / S, s = blockIdx.x - c * S;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int vpp = HW >> 3;
@@ -549,6 +586,9 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
   const float mu = (float)mean[c], is = (float)invstd[c];
   const float wc = w ? (float)w[c] : 1.f;
   const float scale = is * wc, bb = (RELU && b) ? (float)b[c] : 0.f;
+  const float mu2 = DUAL ? (float)dual.mean2[c] : 0.f, is2 = DUAL ? (float)dual.invstd2[c] : 0.f;
+  const float wc2 = (DUAL && dual.w2) ? (float)dual.w2[c] : 1.f;
+  const float scale2 = is2 * wc2, bb2 = (DUAL && dual.b2) ? (float)dual.b2[c] : 0.f;
   uint4 gv[NP], xv[NP];
   int base[NP];                                             // packet (16-byte) index into the tensors, -1: none (host: numel < 2^34)
   const uint4* dy4 = reinterpret_cast<const uint4*>(dy);
@@ -570,7 +610,7 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
 #pragma unroll
   for (int k = 0; k < NP; k++)
     if (base[k] < 0) gv[k] = make_uint4(0, 0, 0, 0);        // contributes nothing to the sums, never stored
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   constexpr int HALF = NP > 4 ? 4 : NP;                     // the addend is only needed for the mask: loaded in groups of <= 4 packets
 #pragma unroll
   for (int h = 0; h < NP; h += HALF) {
@@ -591,12 +631,18 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
         for (int e = 0; e < 2; e++) {
           const float xx = __uint_as_float(e ? (x32[q] & 0xffff0000u) : (x32[q] << 16));
           float gg = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
+          float x2v = 0.f;
           if (RELU) {
             bf16_t pre(bn_affine<float>(xx, mu, scale, bb));
-            if (ADD) pre = bf16_t((float)pre + __uint_as_float(e ? (a32[q] & 0xffff0000u) : (a32[q] << 16)));
+            if (ADD) {
+              float av_ = __uint_as_float(e ? (a32[q] & 0xffff0000u) : (a32[q] << 16));
+              if (DUAL) { x2v = av_; av_ = (float)bf16_t(bn_affine<float>(av_, mu2, scale2, bb2)); }   // the left branch's output as its kernel rounds it
+              pre = bf16_t((float)pre + av_);
+            }
             if ((float)pre < 0.f) { gg = 0.f; gw &= e ? 0x0000ffffu : 0xffff0000u; }
           }
           s1 += gg; s2 = __builtin_fmaf(gg, xx - mu, s2);   // explicit: every instantiation rounds alike
+          if (DUAL) s3 = __builtin_fmaf(gg, x2v - mu2, s3);
         }
         g32[q] = gw;                                        // dy or 0: what dx and the addend's gradient are computed from
       }
@@ -612,25 +658,29 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
     asm volatile("" : "+v"(xv[k].x), "+v"(xv[k].y), "+v"(xv[k].z), "+v"(xv[k].w));
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; }
+  if (DUAL) s3 = wave_sum(s3);
+  if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; if (DUAL) sm[2][wid] = s3; }
   __syncthreads();
   if (wid == 0) {
     // Exchange of the partial sums between the S workgroups of the channel.  No fences (a release / acquire pair at agent scope writes
     // back and invalidates the XCD's whole L2: the step got 35 % slower) and no counter on the critical path: a workgroup publishes
     // (s1, s2) as ONE 8-byte agent-scope atomic store into its slot, and everybody polls the S slots (agent-scope atomic loads bypass
     // the per-XCD L2) until none holds the all-ones pattern the slots rest at between launches - two memory round trips in all.
-    float a = 0.f, bs = 0.f;
+    float a = 0.f, bs = 0.f, cs = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { a += sm[0][k]; bs += sm[1][k]; }
+    for (int k = 0; k < 8; k++) { a += sm[0][k]; bs += sm[1][k]; if (DUAL) cs += sm[2][k]; }
     if (S > 1) {
       unsigned long long* slot = slots + (int64_t)c * S;
+      unsigned long long* slot2 = DUAL ? dual.slots2 + (int64_t)c * S : nullptr;
       if (lane == 0) {
         unsigned lo = __float_as_uint(a), hi = __float_as_uint(bs);
         if (lo == 0xffffffffu) lo = 0x7fc00000u;            // a NaN either way; the all-ones pattern means "not written yet"
         if (hi == 0xffffffffu) hi = 0x7fc00000u;
+        // DUAL: the third sum first (upper word 0: never the all-ones pattern); whoever then sees the first slot written ...
+        if (DUAL) __hip_atomic_store(slot2 + s, (unsigned long long)__float_as_uint(cs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(slot + s, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      a = 0.f; bs = 0.f;
+      a = 0.f; bs = 0.f; cs = 0.f;
       // The wait ends when the channel's other workgroups have run, and they run as soon as compute units are free: workgroups are
       // handed out in launch order, so a foreign kernel that holds CUs (an RCCL collective waiting for a slow peer) only delays this
       // one.  No trap (a straggling rank must not abort the process): after two minutes of the 100 MHz clock the lane
@@ -649,32 +699,78 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
           }
         }
         a += __uint_as_float((unsigned)v); bs += __uint_as_float((unsigned)(v >> 32));
+        if (DUAL) {
+          // ... polls the second one by itself (two independent relaxed stores are not ordered for the reader)
+          unsigned long long v2;
+          while ((v2 = __hip_atomic_load(slot2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull && !gave_up) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 0xfffu) == 0) {
+              const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+              if (t0 == 0) t0 = now;
+              else if (now - t0 > 12000000000ull) { gave_up = true; if (assert_word) *assert_word = kAssertBnExchangeTimeout; }
+            }
+          }
+          cs += __uint_as_float((unsigned)v2);
+        }
       }
       a = wave_sum(a); bs = wave_sum(bs);
+      if (DUAL) cs = wave_sum(cs);
       // every slot of the channel has been read by this workgroup; the last one to say so puts the slots back to rest
       if (lane == 0) {
         const unsigned left = __hip_atomic_fetch_add(depart + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left == (unsigned)S - 1) {
           for (int k = 0; k < S; k++) __hip_atomic_store(slot + k, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (DUAL) for (int k = 0; k < S; k++) __hip_atomic_store(slot2 + k, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(depart + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
     if (lane == 0) {
-      stat[0] = a; stat[1] = bs;
+      stat[0] = a; stat[1] = bs; if (DUAL) stat[2] = cs;
       if (s == 0) {
         if (dweight) dweight[c] = bf16_t(bs * is);
         if (dbias) dbias[c] = bf16_t(a);
+        if (DUAL) {
+          if (dual.dweight2) dual.dweight2[c] = bf16_t(cs * is2);
+          if (dual.dbias2) dual.dbias2[c] = bf16_t(a);
+        }
       }
     }
   }
   __syncthreads();
   if (!dx && !dadd) return;
   const float kk = stat[1] * is * is * (float)inv_m, gm = stat[0] * (float)inv_m;
+  const float kk2 = DUAL ? stat[2] * is2 * is2 * (float)inv_m : 0.f;
+  if (DUAL && dadd) {
+    // the second batch norm's input gradient: dx2 = (g - mean(g) - (x2 - mean2) k2) invstd2 w2 from the masked gradient in registers and
+    // x2 read once more (groups of <= 4 packets, as the mask's reads above)
+#pragma unroll
+    for (int h = 0; h < NP; h += HALF) {
+      uint4 av[HALF];
+#pragma unroll
+      for (int k = 0; k < HALF; k++) av[k] = ad4[base[h + k] >= 0 ? base[h + k] : c * vpp];
+#pragma unroll
+      for (int k = 0; k < HALF; k++) {
+        if (base[h + k] < 0) continue;
+        uint4 r;
+        unsigned* r32 = &r.x;
+        const unsigned* g32 = &gv[h + k].x;
+        const unsigned* x32 = &av[k].x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float g0 = __uint_as_float(g32[q] << 16), g1 = __uint_as_float(g32[q] & 0xffff0000u);
+          const float x0 = __uint_as_float(x32[q] << 16), x1 = __uint_as_float(x32[q] & 0xffff0000u);
+          const bf16_t lo(__builtin_fmaf(-(x0 - mu2), kk2, g0 - gm) * is2 * wc2), hi(__builtin_fmaf(-(x1 - mu2), kk2, g1 - gm) * is2 * wc2);
+          r32[q] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+        }
+        reinterpret_cast<uint4*>(dadd)[base[h + k]] = r;
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NP; k++) {
     if (base[k] < 0) continue;
-    if (dadd) reinterpret_cast<uint4*>(dadd)[base[k]] = gv[k];
+    if (!DUAL && dadd) reinterpret_cast<uint4*>(dadd)[base[k]] = gv[k];
     if (dx) {
       uint4 r;
       unsigned* r32 = &r.x;
@@ -924,8 +1020,11 @@ static std::atomic<int> g_bn_bwd_mode{-1};
 struct BnFusedState { unsigned* sync = nullptr; hipStream_t last = nullptr; bool has_last = false; hipEvent_t ev = nullptr; };
 constexpr int BN_FUSED_MAXC = 4096;                         // depart[BN_FUSED_MAXC] (4-byte counters), then slots[BN_FUSED_SLOTS] (8 bytes each)
 constexpr int BN_FUSED_SLOTS = 4096;
+// the second batch norm of the dual form (bn_bwd_fused_kernel<.., DUAL>): `addc` is then ITS input x2 and `dadd` receives ITS input gradient
+struct BnDualHost { const Tensor* mean2; const Tensor* invstd2; const Tensor* w2; const Tensor* b2; Tensor* dw2; Tensor* db2; };
 static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
-                                Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st) {
+                                Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st,
+                                const BnDualHost* dualh = nullptr) {
   static const bool env_on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
   const int mode = g_bn_bwd_mode.load(std::memory_order_relaxed);
   const bool on = mode < 0 ? env_on : mode >= 1;
@@ -950,10 +1049,11 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
     // Which sizes take this path (bit = packets per thread).  Default: 8 and 16, i.e. activations of some 10 MB and more.  Below that the
     // exchange between the workgroups (two memory round trips, ~3 us) costs what the second pass over an L2 / MALL-resident tensor
     // costs: the ResNet step's six small layers were 4 us SLOWER in total with it, the six large ones 50 us faster.
+    // The dual form replaces FOUR kernels (two reductions, two applies) and two passes more: taken at every size.
     static const int np_mask = [] { const char* e = getenv("LAMP_BN_FUSED_NP_MASK"); return e ? atoi(e) : 24; }();
-    if (!(np_mask & NP)) continue;
-#define BN_FUSED_K(NPv) (addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> : relu ? (const void*)bn_bwd_fused_kernel<NPv, true, false> \
-                              : (const void*)bn_bwd_fused_kernel<NPv, false, false>)
+    if (!dualh && !(np_mask & NP)) continue;
+#define BN_FUSED_K(NPv) (dualh ? (const void*)bn_bwd_fused_kernel<NPv, true, true, true> : addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> \
+                               : relu ? (const void*)bn_bwd_fused_kernel<NPv, true, false> : (const void*)bn_bwd_fused_kernel<NPv, false, false>)
     const void* k = NP == 1 ? BN_FUSED_K(1) : NP == 2 ? BN_FUSED_K(2) : NP == 4 ? BN_FUSED_K(4) : NP == 8 ? BN_FUSED_K(8) : BN_FUSED_K(16);
 #undef BN_FUSED_K
     // every workgroup co-resident: nobody waits for a workgroup that has no slot yet
@@ -973,11 +1073,11 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
       // zeroed once, on a stream of its own and waited for: st may be capturing, and the counters must be zero in memory before the
       // first launch really runs (whichever stream or graph that is)
       if (current_device() != xc->device()) return false;     // (callers run with the tensor's device current; the buffer must live there)
-      HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + BN_FUSED_SLOTS * sizeof(unsigned long long)));
+      HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + 2 * BN_FUSED_SLOTS * sizeof(unsigned long long)));   // + the dual form's second slots
       hipStream_t side = nullptr;
       HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       HIP_CHECK(hipMemsetAsync(stt.sync, 0, BN_FUSED_MAXC * sizeof(unsigned), side));
-      HIP_CHECK(hipMemsetAsync(stt.sync + BN_FUSED_MAXC, 0xff, BN_FUSED_SLOTS * sizeof(unsigned long long), side));
+      HIP_CHECK(hipMemsetAsync(stt.sync + BN_FUSED_MAXC, 0xff, 2 * BN_FUSED_SLOTS * sizeof(unsigned long long), side));
       HIP_CHECK(hipStreamSynchronize(side));
       HIP_CHECK(hipStreamDestroy(side));
       HIP_CHECK(hipEventCreateWithFlags(&stt.ev, hipEventDisableTiming));
@@ -996,7 +1096,7 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   }
   unsigned* departp = sync;
   unsigned long long* slotp = reinterpret_cast<unsigned long long*>(sync + BN_FUSED_MAXC);
-  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);
+  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);   // (the dual form's second read of x2 is served by the caches)
   KernelTimer kt("bn_bwd_fused", 0, passes * (double)xc->numel() * 2.0, st);
   const bf16_t* dyp = gc->ptr<bf16_t>(); const bf16_t* xp = xc->ptr<bf16_t>();
   const bf16_t* mp = mean_t->ptr<bf16_t>(); const bf16_t* ip = invstd_t->ptr<bf16_t>();
@@ -1012,8 +1112,16 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   const bf16_t* adp = addc ? addc->ptr<bf16_t>() : (const bf16_t*)nullptr;
   bf16_t* dap = dadd ? dadd->ptr<bf16_t>() : (bf16_t*)nullptr;
   int* awp = device_assert_word(xc->device());
+  BnFusedDual dual{};
+  if (dualh) {
+    dual.mean2 = dualh->mean2->ptr<bf16_t>(); dual.invstd2 = dualh->invstd2->ptr<bf16_t>();
+    dual.w2 = dualh->w2 ? dualh->w2->ptr<bf16_t>() : (const bf16_t*)nullptr; dual.b2 = dualh->b2 ? dualh->b2->ptr<bf16_t>() : (const bf16_t*)nullptr;
+    dual.dweight2 = dualh->dw2 ? dualh->dw2->ptr<bf16_t>() : (bf16_t*)nullptr; dual.dbias2 = dualh->db2 ? dualh->db2->ptr<bf16_t>() : (bf16_t*)nullptr;
+    dual.slots2 = slotp + BN_FUSED_SLOTS;
+  }
   void* args[] = {(void*)&dyp, (void*)&xp, (void*)&mp, (void*)&ip, (void*)&wp, (void*)&bp, (void*)&slotp, (void*)&departp, (void*)&dwp, (void*)&dbp, (void*)&dxp,
-                  (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift, (void*)&awp};
+                  (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift, (void*)&awp,
+                  (void*)&dual};
   HIP_CHECK(hipLaunchKernel(kfn, dim3((unsigned)(g.C * S)), dim3(512), args, 0, st));
   return true;
 }
@@ -1036,13 +1144,29 @@ int lamp_bn_backward_mode(int mode) {
   LAMP_API_END
 }
 
+// the batch norm whose output is the addend of lamp_native_batch_norm2_add_relu (statistics, running statistics and saved tensors of
+// its own; normalised inside the first one's kernel)
+struct BnSecondArgs {
+  const lamp_tensor* x; const lamp_tensor* weight; const lamp_tensor* bias; lamp_tensor* running_mean; lamp_tensor* running_var; double momentum, eps;
+  lamp_tensor* save_mean = nullptr; lamp_tensor* save_invstd = nullptr;        // results
+};
 static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
                            lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu,
-                           const lamp_tensor* addend = nullptr) {
+                           const lamp_tensor* addend = nullptr, BnSecondArgs* second = nullptr) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input");
   BnGeom g = bn_geom(x);
-  Hold addc;
+  Hold addc, x2c, mean2, invstd2;
+  if (second) {
+    check_device_tensor(second->x, "second input");
+    LAMP_CHECK(!addend && relu && training && g.HW >= 64, "the two-batch-norm residual tail exists in training mode for maps of at least 64 elements");
+    LAMP_CHECK(second->x->shape() == x->shape() && second->x->dtype == x->dtype, "second input " << second->x->describe() << " does not match input " << x->describe());
+    check_cvec(second->weight, g.C, x->dtype, "second weight"); check_cvec(second->bias, g.C, x->dtype, "second bias");
+    check_cvec(second->running_mean, g.C, x->dtype, "second running_mean"); check_cvec(second->running_var, g.C, x->dtype, "second running_var");
+    x2c = Hold(contiguous(second->x));
+    int64_t cs2[1] = {g.C};
+    mean2 = Hold(new_tensor(cs2, 1, x->dtype, x->device())); invstd2 = Hold(new_tensor(cs2, 1, x->dtype, x->device()));
+  }
   if (addend) {
     check_device_tensor(addend, "addend");
     LAMP_CHECK(relu && training && g.HW >= 64, "the fused batch-norm-add-relu exists in training mode for maps of at least 64 elements");
@@ -1059,7 +1183,7 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
-    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->raw() | (uintptr_t)y->raw()) & 15) == 0;
+    const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->raw() | (uintptr_t)y->raw() | (uintptr_t)(x2c.get() ? x2c->raw() : nullptr)) & 15) == 0;
     if (training) {
       LAMP_CHECK(g.N * g.HW > 0, "batch norm over an empty batch");
       const bool col = g.HW < 64;
@@ -1085,13 +1209,37 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
         else hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), partial->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
         LAMP_LAUNCH_CHECK();
       }
+      // the second batch norm's statistics: handed over by ITS convolution, or one statistics pass over its input
+      BnSecond<T> sec{};
+      Hold partial2;
+      if (second) {
+        LAMP_CHECK(!col && total > 0, "the two-batch-norm residual tail needs maps of at least 64 elements");
+        int npart2 = nsplit;
+        if (std::is_same<A, float>::value) partial2 = Hold(conv_stats_lookup(x2c.get(), g.C, &npart2));
+        const bool have2 = partial2.get() != nullptr;
+        if (!have2) {
+          npart2 = nsplit;
+          int64_t ps[1] = {(int64_t)nsplit * g.C * 3};
+          partial2 = Hold(new_tensor(ps, 1, acc_dtype<A>(), x->device()));
+          KernelTimer kt("bn_fwd_stats", 0, (double)total * sizeof(T), st);
+          hipLaunchKernelGGL((bn_stats_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(x2c.get())->ptr<T>(), partial2->ptr<A>(), g.N, g.C, g.HW, nsplit, vec);
+          LAMP_LAUNCH_CHECK();
+        }
+        sec.x = static_cast<const Tensor*>(x2c.get())->ptr<T>();
+        sec.partial = static_cast<const Tensor*>(partial2.get())->ptr<A>(); sec.nsplit = have2 ? -npart2 : npart2;
+        sec.save_mean = mean2->ptr<T>(); sec.save_invstd = invstd2->ptr<T>();
+        sec.running_mean = second->running_mean ? second->running_mean->ptr<T>() : (T*)nullptr;
+        sec.running_var = second->running_var ? second->running_var->ptr<T>() : (T*)nullptr;
+        sec.momentum = second->momentum; sec.eps = second->eps;
+        sec.w = second->weight ? second->weight->ptr<T>() : (const T*)nullptr; sec.b = second->bias ? second->bias->ptr<T>() : (const T*)nullptr;
+      }
       if (!col && total > 0) {
         // finalize folded into the channel-aligned normalise
-        KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
+        KernelTimer kt("bn_fwd_apply", 0, (second ? 3.0 : addc.get() ? 3.0 : 2.0) * (double)total * sizeof(T), st);
         hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), y->ptr<T>(),
                            static_cast<const Tensor*>(partial.get())->ptr<A>(), have_stats ? -npart : npart,
                            mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit,
-                           (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr);
+                           (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr, sec);
         LAMP_LAUNCH_CHECK();
       } else {
         hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
@@ -1122,6 +1270,7 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
     // ATen returns empty save tensors in eval mode; keep handles valid but zero-sized semantics are not needed by lamp
   }
   out3[0] = y.take(); out3[1] = mean.take(); out3[2] = invstd.take();
+  if (second) { second->save_mean = mean2.take(); second->save_invstd = invstd2.take(); }
   LAMP_API_END
 }
 int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
@@ -1259,6 +1408,84 @@ int lamp_native_batch_norm_add_relu_backward(lamp_tensor* out4[4], const lamp_te
   out4[3] = nullptr;
   return bn_backward_impl(out4, grad_out, x, weight, bias, running_mean, running_var, save_mean, save_invstd, training, eps, mask, 1, addend,
                           mask[3] ? &out4[3] : nullptr);
+}
+
+// relu(bn(x) + bn2(x2)) - the tail of lamp's residual block when both branches end in a batch norm (cnn.scala:62-78 under Fun(relu),
+// :36-46) - as ONE kernel per direction.  Values: those of the chain bn2 -> (bn + add + relu) with every intermediate rounded as the
+// chain rounds it (forward: bitwise); the forward never writes bn2's output, the backward never writes the masked gradient.
+int lamp_native_batch_norm2_add_relu(lamp_tensor* out5[5], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                                     lamp_tensor* running_mean, lamp_tensor* running_var, const lamp_tensor* x2, const lamp_tensor* weight2,
+                                     const lamp_tensor* bias2, lamp_tensor* running_mean2, lamp_tensor* running_var2, double momentum,
+                                     double momentum2, double eps, double eps2) {
+  for (int i = 0; i < 5; i++) out5[i] = nullptr;
+  if (!x2) { ::lamp::set_last_error("lamp_native_batch_norm2_add_relu: the second input is null"); return 1; }
+  BnSecondArgs sec{x2, weight2, bias2, running_mean2, running_var2, momentum2, eps2};
+  lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
+  const int rc = bn_forward_impl(o3, x, weight, bias, running_mean, running_var, 1, momentum, eps, 1, nullptr, &sec);
+  if (rc != 0) return rc;
+  out5[0] = o3[0]; out5[1] = o3[1]; out5[2] = o3[2]; out5[3] = sec.save_mean; out5[4] = sec.save_invstd;
+  return 0;
+}
+int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
+                                              const lamp_tensor* bias, const lamp_tensor* save_mean, const lamp_tensor* save_invstd,
+                                              const lamp_tensor* x2, const lamp_tensor* weight2, const lamp_tensor* bias2,
+                                              const lamp_tensor* save_mean2, const lamp_tensor* save_invstd2, double eps, double eps2,
+                                              const uint8_t mask[6]) {
+  LAMP_API_BEGIN
+  for (int i = 0; i < 6; i++) out6[i] = nullptr;
+  check_device_tensor(x, "input"); check_device_tensor(grad_out, "grad_out"); check_device_tensor(x2, "second input");
+  LAMP_CHECK(grad_out->shape() == x->shape() && grad_out->dtype == x->dtype, "grad_out " << grad_out->describe() << " does not match input " << x->describe());
+  LAMP_CHECK(x2->shape() == x->shape() && x2->dtype == x->dtype, "second input " << x2->describe() << " does not match input " << x->describe());
+  BnGeom g = bn_geom(x);
+  LAMP_CHECK(g.HW >= 64, "the two-batch-norm residual tail exists for maps of at least 64 elements, got " << x->describe());
+  check_cvec(weight, g.C, x->dtype, "weight"); check_cvec(bias, g.C, x->dtype, "bias");
+  check_cvec(weight2, g.C, x->dtype, "second weight"); check_cvec(bias2, g.C, x->dtype, "second bias");
+  LAMP_CHECK(save_mean && save_invstd && save_mean2 && save_invstd2, "the backward needs the saved statistics of both batch norms");
+  check_cvec(save_mean, g.C, x->dtype, "save_mean"); check_cvec(save_invstd, g.C, x->dtype, "save_invstd");
+  check_cvec(save_mean2, g.C, x->dtype, "second save_mean"); check_cvec(save_invstd2, g.C, x->dtype, "second save_invstd");
+  Hold xc(contiguous(x)), gc(contiguous(grad_out)), x2c(contiguous(x2));
+  hipStream_t st = current_stream(x->device());
+  const int64_t total = x->numel();
+  if (x->dtype == kBF16 && total > 0 && (mask[0] || mask[3])) {
+    int64_t cs[1] = {g.C};
+    Hold dx(mask[0] ? new_like(xc.get()) : nullptr), dx2(mask[3] ? new_like(xc.get()) : nullptr);
+    Hold dw(mask[1] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr), db(mask[2] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
+    Hold dw2(mask[4] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr), db2(mask[5] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
+    const bool aligned = g.HW % 8 == 0 && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)x2c->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr) |
+                                            (uintptr_t)(dx2.get() ? dx2->data() : nullptr)) & 15) == 0;
+    BnDualHost dh{save_mean2, save_invstd2, weight2, bias2, dw2.get(), db2.get()};
+    if (aligned && bn_bwd_fused_launch(gc.get(), xc.get(), save_mean, save_invstd, weight, bias, dw.get(), db.get(), dx.get(), dx2.get(), x2c.get(), g, 1, st, &dh)) {
+      out6[0] = dx.take(); out6[1] = dw.take(); out6[2] = db.take(); out6[3] = dx2.take(); out6[4] = dw2.take(); out6[5] = db2.take();
+      return 0;
+    }
+  }
+  // every other case (f32 / f64, small batches, a shared device): the chain itself - the second batch norm's output from its saved
+  // statistics, the one-addend backward, then the second batch norm's backward on the masked gradient
+  Hold l(new_like(x2c.get()));
+  if (total > 0) {
+    LAMP_DISPATCH_FLOAT(x->dtype, T, {
+      const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)x2c->raw() | (uintptr_t)l->raw()) & 15) == 0;
+      KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
+      hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, static_cast<const Tensor*>(x2c.get())->ptr<T>(), l->ptr<T>(),
+                         save_mean2->ptr<T>(), save_invstd2->ptr<T>(), weight2 ? weight2->ptr<T>() : (const T*)nullptr,
+                         bias2 ? bias2->ptr<T>() : (const T*)nullptr, total, g.C, g.HW, vec, 0);
+    });
+    LAMP_LAUNCH_CHECK();
+  }
+  const bool second_wanted = mask[3] || mask[4] || mask[5];
+  lamp_tensor* r4[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint8_t m4[4] = {mask[0], mask[1], mask[2], (uint8_t)second_wanted};
+  if (lamp_native_batch_norm_add_relu_backward(r4, gc.get(), xc.get(), l.get(), weight, bias, nullptr, nullptr, save_mean, save_invstd, 1, eps, m4) != 0)
+    throw Error(lamp_last_error());
+  Hold h0(r4[0]), h1(r4[1]), h2(r4[2]), h3(r4[3]);
+  lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
+  if (second_wanted) {
+    const uint8_t m3[3] = {mask[3], mask[4], mask[5]};
+    if (lamp_native_batch_norm_backward(r3, h3.get(), x2c.get(), weight2, nullptr, nullptr, save_mean2, save_invstd2, 1, eps2, m3) != 0)
+      throw Error(lamp_last_error());
+  }
+  out6[0] = h0.take(); out6[1] = h1.take(); out6[2] = h2.take(); out6[3] = r3[0]; out6[4] = r3[1]; out6[5] = r3[2];
+  LAMP_API_END
 }
 
 int lamp_native_layer_norm(lamp_tensor* out3[3], const lamp_tensor* x, const int64_t* normalized_shape, int nnorm,
