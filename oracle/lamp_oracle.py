@@ -1178,4 +1178,38 @@ def umap_loss(locations: Variable, index1, index2, index3, index4, b: torch.Tens
     return (attractions + repulsions) * (-1.0)
 
 
+def umap_optimize(edge_weights_rows: torch.Tensor, total: int, lr: float, iterations: int, minDist: float, negativeSampleSize: int,
+                  randomSeed: int, balance: bool = True, repulsionStrength: float = 1.0, numDim: int = 2, positiveSamples=None, losses=None):
+    """Umap.optimize (umap.scala:115-286) restated op for op: float64 locations, per iteration a random subsample of the edges
+    (`positiveSamples`), `negativeSampleSize` negatives per sampled edge drawn with randint(0, total - 1) (the last point is never
+    drawn) and filtered by ii != jj, the loss above, backprop through the oracle's own ops, AdamW(wd 0, lr, beta2 0.95, clip 1).
+    The reference draws the initial layout from the JVM's Cmwc5 generator and the samples from libtorch's: neither stream can be
+    reproduced here, so both come from torch's CPU generator seeded with `randomSeed` - what is comparable between implementations
+    is the DISTRIBUTION of the trajectory, not a trajectory.  edge_weights_rows: [m, 3] float64 rows (i, j, b)."""
+    gen = torch.Generator().manual_seed(int(randomSeed))
+    index1 = edge_weights_rows[:, 0].long()
+    index2 = edge_weights_rows[:, 1].long()
+    b = edge_weights_rows[:, 2].contiguous().double()
+    locations = param(torch.rand(total, numDim, dtype=torch.float64, generator=gen))
+    opt = AdamW([locations.value], weightDecay=0.0, learningRate=lr, beta1=0.9, beta2=0.95, clip=1.0)      # AdamW.factory defaults (AdamW.scala:12)
+    last = 0.0
+    for _ in range(int(iterations)):
+        if positiveSamples is None:
+            i1, i2, bb = index1, index2, b
+        else:
+            pos = torch.randint(0, index1.shape[0], (min(int(positiveSamples), index1.shape[0]),), generator=gen)
+            i1, i2, bb = index1[pos], index2[pos], b[pos]
+        ii = i1.repeat_interleave(int(negativeSampleSize), 0)
+        jj = torch.randint(0, total - 1, (ii.shape[0],), generator=gen)
+        mask = ii != jj
+        lossV = umap_loss(locations, i1, i2, ii[mask], jj[mask], bb, minDist, balance, repulsionStrength)
+        last = float(lossV.value.reshape(-1)[0])
+        if losses is not None:
+            losses.append(last)
+        locations.zeroGrad()
+        lossV.backprop()
+        opt.step([locations.grad], 1.0)
+    return locations.value, last
+
+
 _more_variable_methods()

@@ -517,27 +517,61 @@ def test_umap_pipeline_end_to_end(gpu):
     assert edge_len < 0.5 * rand_len, (edge_len, rand_len)      # graph neighbours end up close, random pairs do not
 
 
+def _mnist_fixture():
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "mnist_first1000.npz"))
+    return d["pixels"].astype(np.float64), d["labels"].astype(np.int64)
+
+
 def test_umap_mnist_meets_the_reference_acceptance(gpu):
     """The reference's own end-to-end UMAP test (umap.test.scala:57-79, "mnist"): the first 1000 MNIST records, numDim = 2,
-    positiveSamples = 5000, negativeSampleSize = 5, 1000 iterations -> `assert(loss < 0.7)` (here: < 0.78, see below).  The reference reads /mnist_train.csv.gz,
+    positiveSamples = 5000, negativeSampleSize = 5, 1000 iterations -> `assert(loss < 0.7)`.  The reference reads /mnist_train.csv.gz,
     which is not in its tree; the fixture holds the first 1000 records of the MNIST resource it does carry
-    (lamp-core/src/test/resources/mnist_test.csv.gz, scripts/make_mnist_fixture.py)."""
-    import os
+    (lamp-core/src/test/resources/mnist_test.csv.gz, scripts/make_mnist_fixture.py).
+
+    What that assertion looks at is the loss of the LAST iteration - one random subsample of 5000 edges and 25000 negatives - and
+    neither random stream of the reference (Cmwc5 for the initial layout, libtorch for the samples) can be reproduced.  So (VERDICT r2
+    item 5): the ORACLE runs the same recipe with its own generator over five seeds, the HIP path over the same five seeds, and
+      * the mean of the last 50 iterations meets the reference's 0.7 on every HIP seed (the bar, freed of the single-sample noise),
+      * the HIP distribution of that mean lies inside the oracle's (same mean within 0.02, i.e. ~1.5 of the oracle's own seed-to-seed
+        standard deviations),
+      * the last-iteration loss stays within the oracle's own last-iteration range widened by its noise (3 sigma of one run)."""
+    import torch
     from lamp_amd import umap as U
-    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "mnist_first1000.npz"))
-    data = d["pixels"].astype(np.float64)
-    layout, b, loss = U.umap(data, numDim=2, positiveSamples=5000, negativeSampleSize=5, iterations=1000)
-    loss = float(loss)
-    lay = layout.to_numpy() if hasattr(layout, "to_numpy") else np.asarray(layout)
+    data, labels = _mnist_fixture()
+    t = torch.from_numpy(data)
+    idx = O.knn_minibatched(t, t, 10, 1000)
+    d2 = O.squared_euclidean_distance(t, t)
+    idx = torch.stack([row[torch.argsort(d2[i][row], stable=True)] for i, row in enumerate(idx)])
+    dist = torch.stack([torch.linalg.vector_norm(t[i] - t[idx[i]], dim=1) for i in range(len(t))])
+    rows = torch.tensor(O.edge_weights(dist.tolist(), idx.tolist()), dtype=torch.float64)
+    seeds = (42, 1, 7, 11, 123)
+    o_mean, o_last, o_std = [], [], []
+    for seed in seeds:
+        losses = []
+        O.umap_optimize(rows, 1000, 0.1, 1000, 0.0, 5, seed, positiveSamples=5000, losses=losses)
+        o_mean.append(float(np.mean(losses[-50:]))); o_last.append(losses[-1]); o_std.append(float(np.std(losses[-50:])))
+    h_mean, h_last, lay = [], [], None
+    for seed in seeds:
+        losses = []
+        layout, b, loss = U.umap(data, numDim=2, positiveSamples=5000, negativeSampleSize=5, iterations=1000, randomSeed=seed,
+                                 log=lambda s_: losses.append(float(s_.split(",")[-1].strip(" )"))))
+        assert len(losses) == 1000 and abs(losses[-1] - float(loss)) < 1e-12
+        h_mean.append(float(np.mean(losses[-50:]))); h_last.append(losses[-1])
+        if seed == 42:
+            lay = layout.to_numpy()
+            assert np.array_equal(b.to_numpy()[:, :2], rows.numpy()[:, :2]) and np.abs(b.to_numpy()[:, 2] - rows.numpy()[:, 2]).max() < 1e-9, "same UMAP graph as the oracle"
+    print(f"UMAP MNIST, mean loss of the last 50 iterations: HIP {np.round(h_mean, 4).tolist()} oracle {np.round(o_mean, 4).tolist()}; "
+          f"last iteration: HIP {np.round(h_last, 4).tolist()} oracle {np.round(o_last, 4).tolist()}; oracle noise of one run {np.mean(o_std):.4f}")
+    assert max(h_mean) < 0.7, f"the reference's bar on the mean of the last 50 iterations: {h_mean}"
+    assert abs(np.mean(h_mean) - np.mean(o_mean)) < 0.02, (h_mean, o_mean)
+    assert min(o_mean) - 0.02 <= min(h_mean) and max(h_mean) <= max(o_mean) + 0.02, (h_mean, o_mean)
+    noise = 3.0 * max(o_std)
+    assert min(o_last) - noise <= min(h_last) and max(h_last) <= max(o_last) + noise, (h_last, o_last, noise)
     assert lay.shape == (1000, 2) and np.isfinite(lay).all()
-    # the reference asserts < 0.7 on ITS 1000 records (first lines of the train set); on these 1000 records of the test set this
-    # implementation ends at 0.690 with the default seed 42 and at 0.705 / 0.745 with seeds 1 / 7 (the loss of the last iteration is
-    # that of one random subsample of 5000 edges), so the bound here leaves room for that spread instead of sitting 0.01 above it
-    assert loss < 0.78, f"final loss {loss}"
     # the embedding means something: most of a point's 10 nearest neighbours in the layout carry its digit
-    labels = d["labels"].astype(np.int64)
-    d2 = ((lay[:, None, :] - lay[None, :, :]) ** 2).sum(-1)
-    np.fill_diagonal(d2, np.inf)
-    nn = np.argsort(d2, 1)[:, :10]
+    d2l = ((lay[:, None, :] - lay[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2l, np.inf)
+    nn = np.argsort(d2l, 1)[:, :10]
     purity = (labels[nn] == labels[:, None]).mean()
     assert purity > 0.6, f"neighbour purity {purity}"                  # measured 0.74
