@@ -35,9 +35,9 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "lm"])
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; umap-e2e: 1 - a step is a complete 1M-point run)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; umap-e2e: 1)")
+    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "umap-e2e", "lm"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -45,7 +45,12 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="resnet: issue the step eagerly instead of replaying forward + backprop from a HIP graph")
     ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous of the N ranks only (no GPU work): prints {\"dry_launch\": true, \"ranks\": N}")
     ap.add_argument("--min-window-s", type=float, default=0.5, help="repeat the K-step timed window until this much time is covered; the median window is reported")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 1 if a.workload == "umap-e2e" else 20
+    if a.warmup is None:
+        a.warmup = 1 if a.workload == "umap-e2e" else 10
+    return a
 
 
 def spawn_ranks(n):
@@ -254,9 +259,9 @@ def main():
 
     # CPU baseline first, in a child process, on rank 0 at N = 1 only (before this process touches the GPU)
     cpu_baseline = None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and a.workload in ("resnet", "gemm", "mlp"):   # secondary probes have no CPU leg
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and a.workload in ("resnet", "gemm", "mlp", "knn", "umap", "umap-e2e"):
         try:
-            wl = {"resnet": "resnet", "gemm": "gemm", "mlp": "mlp"}[a.workload]
+            wl = a.workload                   # kNN / UMAP: a bounded sample scaled to the unit of the line (oracle/cpu_baseline.py says how)
             out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--budget-s", "15"],
                                  capture_output=True, text=True, timeout=600)
             cpu_baseline = json.loads(out.stdout.strip().splitlines()[-1])
@@ -387,6 +392,41 @@ def main():
         units_per_step = 14.0 * Bz * H * Sq * Sq * D / 1e12      # 4 fwd + 10 bwd model flops per (query, key, feature)
         metric, unit = "attention fwd+bwd (model flops)", "TFLOP/s"
         config = {"workload": "ScaledDotProductAttention fwd + bwd, bf16, batch 8 x 16 heads x 4096 x 128, non-causal", "parallelism": "replicas"}
+    elif a.workload == "umap-e2e":
+        # BASELINE config 5 as ONE job: 1M x 128 f32 points resident in HBM -> kNN graph (k = 10, f32 search as `precision = SinglePrecision`) ->
+        # exact f64 neighbour distances -> edge weights -> 500 layout iterations (f64, 5 negatives per edge, AdamW); a step = the whole run
+        from lamp_amd import umap as U
+        n, d_, kk, iters = 1_000_000, 128, 10, 500
+        idx_ = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(d_) + np.arange(d_, dtype=np.uint64)[None, :]
+        pts = ((idx_ * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / 2.0 ** 32 + (np.arange(n) % 16)[:, None]   # closed form + 16 clusters
+        del idx_
+        X32 = S.STen.from_numpy(pts.astype(np.float32), local_rank, S.F32)
+        X64 = S.STen.from_numpy(pts, local_rank, S.F64)
+        del pts
+        phase = {}
+
+        def run(timed_phases=None):
+            def mark(name, t0):
+                if timed_phases is not None:
+                    lib.lamp_device_synchronize(); timed_phases[name] = time.perf_counter() - t0
+                return time.perf_counter()
+            t0 = time.perf_counter()
+            knn = U.knn_search(X32, X32, kk, 1000)
+            t0 = mark("knn_graph_s", t0)
+            dd = C.c_void_p(); lib.lamp_knn_row_distances(C.byref(dd), X64, knn)
+            dist = S.STen(dd)
+            t0 = mark("neighbour_distances_s", t0)
+            ew = U.edge_weights(dist, knn)
+            t0 = mark("edge_weights_s", t0)
+            layout, loss = U.optimize(ew, n, 0.1, iters, 0.0, 5, 42, True, 1.0, local_rank, 2)
+            mark("layout_500_iterations_s", t0)
+            return layout, loss, ew.shape[0]
+        step = lambda: run()
+        units_per_step = n
+        metric, unit = "UMAP end-to-end points/sec (1M x 128: kNN graph + edge weights + 500-iteration layout)", "points/s"
+        config = {"workload": "lamp.umap.Umap.umap on 1M x 128 synthetic points already resident in HBM: knnSearch (f32, k = 10) -> f64 neighbour distances -> "
+                              "edgeWeights -> optimize (500 iterations, 5 negatives per edge, f64, AdamW clip 1)", "parallelism": "replicas"}
+        a.dtype = "f32 kNN / f64 layout"
     elif a.workload == "umap":
         # BASELINE config 5, second half: one layout iteration of Umap.optimize at 1M points (9M edges, 5 negatives per edge, f64)
         from lamp_amd import umap as U
@@ -536,6 +576,18 @@ def main():
         lib.lamp_kernel_timer_filter(None)
         rows = kernel_report(lib)
 
+    if a.workload == "umap-e2e":
+        ph = {}
+        _, last_loss, n_edges = run(ph)            # untimed, instrumented pass: seconds per phase (device synchronised between phases)
+        result_extra["phases"] = ph
+        result_extra["edges"] = int(n_edges)
+        result_extra["final_loss"] = float(last_loss)
+        lay_rows = [r for r in class_rows if r["tag"] == "umap_pairs2"]
+        knn_rows = [r for r in class_rows if r["tag"].startswith("knn_fused")]
+        if lay_rows:
+            result_extra["roofline_layout"] = roofline_of(lay_rows)
+        if knn_rows:
+            result_extra["roofline_knn"] = roofline_of(knn_rows)
     if rank == 0:
         value = units_per_step * a.gpus * a.steps / elapsed
         roof = roofline_of(rows)
