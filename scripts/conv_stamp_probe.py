@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lamp_amd._capi import lib, i64_array; lib.load()
 from lamp_amd import sten as S
-N, Cin, Cout, k = 2048, 128, 128, 3
+N, Cin, Cout, k = 2048, int(os.environ.get("CIN", "128")), int(os.environ.get("COUT", "128")), 3
 rng = np.random.default_rng(0)
 x = S.STen.from_numpy(rng.standard_normal((N, Cin, 8, 8), dtype=np.float32), 0, S.BF16)
 w = S.STen.from_numpy(rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) * 0.05, 0, S.BF16)
