@@ -689,26 +689,15 @@ __device__ unsigned long long ig8d_rt_stamps[8 * 512];      // the constant 100 
 // (4 (w & 3) + chunk') mod 16 the 16 pixels of an MFMA tile (two rows x eight columns) read 16 different slots
 __device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | ((w >> 2) & 1); }
 
-// PIPE (round 3; 3x3 layers with two or more input-channel chunks and >= 5 channel tiles): the prologue fetches only chunk 0 of the eight
-// images; chunk kc + 1 is requested at the start of chunk kc and written to the other of TWO chunk buffers in the READ phase of chunk kc's
-// last tap - nine stages (~4.5 us) later, so nobody waits for HBM.  What made the round-2 attempt slower (54.7k instead of 41.7k cycles in
-// the main loop) was the in-order vmcnt: a wave that waits for its weight piece also waits for every image load it issued before it, and
-// all eight waves meet at every barrier.  Here the roles are split: waves 0-3 request ALL weight pieces (two per stage each), waves 4-7
-// request the images and never wait for anything but their own LDS reads until the chunk's last stage.
-template <int KS, int NCT, bool PIPE = false>
+template <int KS, int NCT>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg,
                                                         const bf16_t* addend) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(!PIPE || (KS == 3 && NCT >= 5), "the pipelined form exists for the wide 3x3 layers");
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int NI = 8, NT = 512;
-  // one weight stage: 128 rows x 32 k.  PIPE: the image chunks streaming in behind the weight pieces delay them (the CU's vector-memory
-  // path returns in order: an L2 hit queues behind the HBM misses of another wave - measured: main loop 39k -> 72k cycles with the
-  // three-slot ring), so the ring is eight slots deep and requested six stages (~3.5 us) ahead; the LDS comes from keeping two chunk
-  // buffers instead of all chunks
-  constexpr int WT = 128 * 32 * 2, NSLOT = PIPE ? 8 : 3, DAHEAD = PIPE ? 6 : 2;
+  constexpr int WT = 128 * 32 * 2, NSLOT = 3;   // one weight stage: 128 rows x 32 k
   constexpr int RB = 64;                    // bytes per pixel of one 32-channel chunk
   constexpr int XIMG = 64 * RB;             // one chunk of one image: 4 KiB
   constexpr int XBUF = NI * XIMG;           // one chunk of the workgroup's eight images
@@ -728,18 +717,8 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // stage (kc, rs): rows = output channels, k = input channels [32 kc, 32 kc + 32) of tap rs; one 1 KiB piece (16 rows) per wave
   const int d_row = wid * 16 + (lane >> 2);
   const int d_src = d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3);
-  // PIPE: the second piece of waves 0-3 (rows 64 ... 127 of the stage; wave 3's is skipped when NCT == 7)
-  const int d_row2 = d_row + 64;
-  const int d_src2 = d_row2 * KP + (((lane & 3) ^ ((4 - ((d_row2 >> 2) & 3)) & 3)) << 3);
-  const bool two_pieces = PIPE && wid + 4 < NCT;            // wave-uniform
   auto stage_dma = [&](int kc1, int rs1, int slot) {
-    if (PIPE) {
-      if (wid < 4) {
-        const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
-        __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
-        if (two_pieces) __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src2), (lds_char_t*)(Wl + slot * WT + (wid + 4) * 1024), 16, 0, 0);
-      }
-    } else if (wid < NCT) {                   // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
+    if (wid < NCT) {                          // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
       const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
       __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
     }
@@ -747,88 +726,38 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   IG_STAMP(0);
   stage_dma(0, 0, 0);
   if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
-  if (PIPE) {
-#pragma unroll
-    for (int d = 2; d < DAHEAD; d++) if (d < T) stage_dma(d / RS, d % RS, d);
-  }
   IG_STAMP(1);
   // NCHW -> [pixel][32 channels].  A thread takes 8 channels x one image row: eight coalesced 16-byte loads, an 8x8 transposition of the
-  // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).  Work item e of a chunk: (channel group cg,
-  // image row h, image img) = (e & 3, (e >> 2) & 7, (e >> 5) & 7); 256 items per chunk.
-  auto img_load = [&](int ch, int e, uint4 (&rw)[8]) {
-    const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7;
-    const int n = n0 + img;
+  // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).
+  {
+    for (int e = tid; e < NI * 8 * 4 * KC; e += NT) {
+      const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7, ch = e >> 8;
+      const int n = n0 + img;
+      uint4 rw[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int c = ch * 32 + cg * 8 + k;
-      rw[k] = make_uint4(0, 0, 0, 0);
-      // fprop (statistics wanted): the input is not read again before the backward pass - streamed, the caches are for the output the
-      // batch norm reads next; dgrad: dY is what the weight-gradient kernel reads right after this one - cached
-      if (c < CI && n < N) {
-        const uint4* src = reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
-        rw[k] = stats ? nt_load16(src) : *src;
+      for (int k = 0; k < 8; k++) {
+        const int c = ch * 32 + cg * 8 + k;
+        rw[k] = make_uint4(0, 0, 0, 0);
+        // fprop (statistics wanted): the input is not read again before the backward pass - streamed, the caches are for the output the
+        // batch norm reads next; dgrad: dY is what the weight-gradient kernel reads right after this one - cached
+        if (c < CI && n < N) {
+          const uint4* src = reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
+          rw[k] = stats ? nt_load16(src) : *src;
+        }
+      }
+      char* xi = Xl + ch * XBUF + img * XIMG;
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        unsigned int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned int lo = (&rw[2 * j].x)[p >> 1], hi = (&rw[2 * j + 1].x)[p >> 1];
+          d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ ig8d_swz(h, p)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
-  };
-  auto img_store = [&](int buf, int e, const uint4 (&rw)[8]) {          // buf: chunk index (all chunks resident) or chunk parity (PIPE)
-    const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7;
-    char* xi = Xl + buf * XBUF + img * XIMG;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      unsigned int d[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const unsigned int lo = (&rw[2 * j].x)[p >> 1], hi = (&rw[2 * j + 1].x)[p >> 1];
-        d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-      }
-      *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ ig8d_swz(h, p)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
-    }
-  };
-  if (PIPE) {
-    if (tid < 256) { uint4 rw[8]; img_load(0, tid, rw); img_store(0, tid, rw); }     // chunk 0 only: a quarter (or less) of the burst
-  } else {
-    for (int e = tid; e < NI * 8 * 4 * KC; e += NT) { uint4 rw[8]; img_load(e >> 8, e & 255, rw); img_store(e >> 8, e & 255, rw); }
   }
-  // PIPE, waves 4-7: the next chunk arrives in two halves of 4 channels x one image row per lane (16 registers in flight, not 32: with
-  // 128 accumulators the full item spilled): requested at taps 0 and 4, written at taps 4 and 8
-  uint4 nx[4];
-  const int pe = (wid - 4) * 64 + lane;         // this lane's work item
-  // (32-bit element offsets from one uniform base: the host guarantees numel < 2^31; 64-bit per-load address pairs cost the 128-accumulator
-  // instantiation its last free registers)
-  const unsigned pe_cg = pe & 3, pe_h = (pe >> 2) & 7, pe_img = (pe >> 5) & 7;
-  const bool pe_ok = n0 + (int)pe_img < N;
-  const unsigned pe_off = (((unsigned)(n0 + (int)pe_img) * (unsigned)CI + pe_cg * 8u) << 6) + pe_h * 8u;
-  // NO control flow around the loads: a load inside a branch made the compiler wait for it (vmcnt(0)) before leaving the branch - four
-  // serial HBM round trips per half, 72k instead of 39k cycles in the main loop.  Every lane always loads; a channel or image that does
-  // not exist re-reads this lane's first channel of chunk 0 (or element 0) and is zeroed when the half is written to LDS.
-  auto half_load = [&](int ch, int half, uint4 (&rw)[4]) {
-    const unsigned c0 = (unsigned)ch * 32u + pe_cg * 8u + (unsigned)half * 4u;
-    const unsigned off = pe_off + (((unsigned)ch * 32u + (unsigned)half * 4u) << 6);
-    const unsigned safe = pe_ok ? pe_off : 0u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool ok = pe_ok && c0 + k < (unsigned)CI;
-      rw[k] = *reinterpret_cast<const uint4*>(x + (ok ? off + (unsigned)k * 64u : safe));
-    }
-  };
-  auto half_store = [&](int ch, int buf, int e, int half, const uint4 (&rw)[4]) {
-    const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7;
-    char* xi = Xl + buf * XBUF + img * XIMG;
-    const unsigned c0 = (unsigned)ch * 32u + pe_cg * 8u + (unsigned)half * 4u;
-    unsigned keep[4];                          // all-ones where the channel (and the image) exists
-#pragma unroll
-    for (int k = 0; k < 4; k++) keep[k] = (pe_ok && c0 + k < (unsigned)CI) ? 0xffffffffu : 0u;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      unsigned int d[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const unsigned int lo = (&rw[2 * j].x)[p >> 1] & keep[2 * j], hi = (&rw[2 * j + 1].x)[p >> 1] & keep[2 * j + 1];
-        d[j] = (p & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-      }
-      *reinterpret_cast<uint2*>(xi + (h * 8 + p) * RB + ((cg ^ ig8d_swz(h, p)) << 4) + half * 8) = make_uint2(d[0], d[1]);
-    }
-  };
   f4v acc[NCT][4];
 #pragma unroll
   for (int i = 0; i < NCT; i++)
@@ -865,38 +794,20 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int t = 0, slot = 0;
   for (int kc = 0; kc < KC; kc++) {
-    const char* xk = Xl + (PIPE ? (kc & 1) : kc) * XBUF;
-    // PIPE: this chunk has just become current, the other buffer was last read a whole chunk ago - waves 4-7 request the next chunk now
-    if (PIPE && wid >= 4 && kc + 1 < KC) half_load(kc + 1, 0, nx);
+    const char* xk = Xl + kc * XBUF;
 #pragma unroll
     for (int rs = 0; rs < RS; rs++, t++) {
       const int r = rs / KS, s = rs - r * KS;
       const char* wl = Wl + slot * WT + a_off;
-      const int slot1 = PIPE ? ((slot + 1) & 7) : (slot == 2 ? 0 : slot + 1);
-      const int slot2 = PIPE ? ((slot + DAHEAD) & 7) : (slot1 == 2 ? 0 : slot1 + 1);     // the slot of stage t + DAHEAD
+      const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
       // ---- READ(t)
-      if (t + DAHEAD < T) stage_dma(kc + (rs + DAHEAD) / RS, (rs + DAHEAD) % RS, slot2);
+      if (t + 2 < T) stage_dma(kc + (rs + 2) / RS, (rs + 2) % RS, slot2);
 #pragma unroll
       for (int i = 0; i < NCT; i++) fa[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 1024));
       const char* xb = xk + va[r & 1][s];
 #pragma unroll
       for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s) + 16 * j) * RB));
-      if (PIPE) {
-        if (wid < 4) {                                 // the weight pieces: stage t + 1 landed, stages t + 2 ... t + 6 (one or two pieces each) may stay in flight
-          if (t + DAHEAD < T) { if (two_pieces) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); }
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if ((rs == 4 || rs == RS - 1) && kc + 1 < KC) {
-            // READ phase of the waves that run one phase behind: the partner waves of each SIMD are in their MFMA phase, and the first
-            // read of chunk kc + 1 comes after the barrier that closes the LAST tap's phase.  Each half was requested four stages ago.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            half_store(kc + 1, (kc + 1) & 1, pe, rs == 4 ? 0 : 1, nx);
-            if (rs == 4) half_load(kc + 1, 1, nx);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          }
-        }
-      } else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (KS == 3) {                                   // taps that fall outside the 8x8 image contribute zeros
         const bool colout = (s == 0 && col_lo) || (s == 2 && col_hi);
@@ -1460,21 +1371,15 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)((CI + 31) / 32) * 8 * 4096 + (KS == 3 ? 9 * 64 : 0), (size_t)8 * 16384 + 8 * 128 * 8);
         const int per_wg = (statp && g.N % 8 == 0) ? 1 : 0;
         if (per_wg) publish.P = blocksd;
-#define IG_LAUNCH_D(KS_, NCT_, ...)                                                                                                         \
+#define IG_LAUNCH_D(KS_, NCT_)                                                                                                              \
   do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_ __VA_ARGS__>);                                                                   \
-    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_ __VA_ARGS__>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
+    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
+    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
                        (int)g.N, CI, KP, CO, statp, per_wg, addp);                                                                         \
   } while (0)
         const bf16_t* addp = addend ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
         if (addend_fused) *addend_fused = addend != nullptr;
-        // wide 3x3 layers with several input-channel chunks: the image chunks arrive during the main loop (LAMP_IG_PIPE=0: all up front)
-        // (the 128-accumulator instantiation has no registers left for the chunk in flight - it spills - so it keeps the full prologue;
-        // LAMP_IG_PIPE=2 forces it for experiments)
-        static const int pipe_on = [] { const char* e = getenv("LAMP_IG_PIPE"); return e ? atoi(e) : 1; }();
-        const bool pipe = pipe_on && KS == 3 && CO > 64 && CI > 32 && (CO <= 112 || pipe_on == 2);
-        if (KS == 3 && pipe) { if (CO <= 112) IG_LAUNCH_D(3, 7, , true); else IG_LAUNCH_D(3, 8, , true); }
-        else if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
+        if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
         else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
 #undef IG_LAUNCH_D
         LAMP_LAUNCH_CHECK();
