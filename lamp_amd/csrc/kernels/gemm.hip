@@ -568,18 +568,43 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
   const bf16_t* S = g.S ? (const bf16_t*)g.S + bz * g.s_bs : nullptr;
   const float alpha = (float)g.alpha, beta = (float)g.beta;
   const bool s_vec = S && g.s_cs == 1 && (g.s_rs % 4 == 0) && (((uintptr_t)S & 7) == 0);
+  // Round 3: the wave's 128 x 64 output tile goes through its own 16 KiB of the (now free) LDS as [row][64 columns] rows and leaves as
+  // 16-byte stores, eight lanes per 128-byte row - full lines, half the store instructions.  In-kernel stamps (scripts/gemm_clock_probe.py)
+  // had the 8-byte-per-lane epilogue at 9.8 of the kernel's 107 us with nothing to overlap it (one workgroup per CU).  8-byte slot s of
+  // row r sits at s ^ ((r & 7) << 1): the 16 rows of a write spread over the banks and 16-byte chunks stay whole.
+  const bool c16 = (g.ldc % 8 == 0) && (((uintptr_t)C & 15) == 0);
+  char* El = smem + wid * 16384;
+  const int q = lane >> 4;
+  // the beta operand (dW += ..., dX += ...: S is C itself) comes in the same way: sixteen 16-byte loads per lane in flight together, parked
+  // in the tile's LDS image, each lane then picks up its 8 bytes where it will put its result
+  const bool s16 = c16 && s_vec && (g.s_rs % 8 == 0) && (((uintptr_t)S & 15) == 0);
+  if (s16) {
+    const bf16_t* Sw = S + (m0 + wr * 128) * g.s_rs + n0 + wc * 64;
+    uint4 sv[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) { const int idx = it * 64 + lane; sv[it] = *reinterpret_cast<const uint4*>(Sw + (int64_t)(idx >> 3) * g.s_rs + (idx & 7) * 8); }
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int idx = it * 64 + lane;
+      const int lrow = idx >> 3, c = idx & 7;
+      *reinterpret_cast<uint4*>(El + lrow * 128 + ((c ^ (lrow & 7)) << 4)) = sv[it];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int64_t row = m0 + wr * 128 + i * 16 + (lane & 15);
+    const int lrow = i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int64_t col = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      const int64_t col = n0 + wc * 64 + j * 16 + q * 4;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) { v[r] = alpha * acc[i][j][r]; if (g.round_first) v[r] = (float)bf16_t(v[r]); }
       if (S) {
-        if (s_vec) {                                       // beta operand contiguous along n: one 8-byte load
-          const uint2 sv = *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
+        if (s_vec) {                                       // beta operand contiguous along n: 8 bytes per lane (from LDS or from memory)
+          const uint2 sv = s16 ? *reinterpret_cast<const uint2*>(El + lrow * 128 + (((j * 4 + q) ^ ((lrow & 7) << 1)) << 3))
+                               : *reinterpret_cast<const uint2*>(S + row * g.s_rs + col);
           bf16_t e0, e1, e2, e3;
           e0.bits = (unsigned short)(sv.x & 0xffffu); e1.bits = (unsigned short)(sv.x >> 16);
           e2.bits = (unsigned short)(sv.y & 0xffffu); e3.bits = (unsigned short)(sv.y >> 16);
@@ -593,7 +618,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp2_kernel(GemmArgs g) {
       uint2 pk;
       pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
       pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
-      *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
+      if (c16) *reinterpret_cast<uint2*>(El + lrow * 128 + (((j * 4 + q) ^ ((lrow & 7) << 1)) << 3)) = pk;
+      else *reinterpret_cast<uint2*>(C + row * g.ldc + col) = pk;
+    }
+  }
+  if (c16) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the region is private to this wave
+    bf16_t* Cw = C + (m0 + wr * 128) * g.ldc + n0 + wc * 64;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int idx = it * 64 + lane;
+      const int lrow = idx >> 3, c = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(El + lrow * 128 + ((c ^ (lrow & 7)) << 4));
+      *reinterpret_cast<uint4*>(Cw + (int64_t)lrow * g.ldc + c * 8) = v;
     }
   }
   GQ_STAMP(3);

@@ -50,8 +50,9 @@ def edge_weights(knn_distances: S.STen, knn: S.STen) -> S.STen:
 
 def optimize(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDist: float, negativeSampleSize: int, randomSeed: int,
              balanceAttractionsAndRepulsions: bool, repulsionStrength: float, device: int, numDim: int,
-             positiveSamples: Optional[int] = None, log=None) -> Tuple[S.STen, float]:
-    """Umap.optimize (umap.scala:115-286)."""
+             positiveSamples: Optional[int] = None, log=None, lossHistory: Optional[list] = None) -> Tuple[S.STen, float]:
+    """Umap.optimize (umap.scala:115-286).  `lossHistory`: a list that receives the losses of the last 50 iterations (read back after the
+    loop: no host synchronisation per iteration, unlike `log`)."""
     lib.lamp_manual_seed(int(randomSeed))
     index1 = edgeWeights.select(1, 0).castToLong()
     index2 = edgeWeights.select(1, 1).castToLong()
@@ -61,6 +62,7 @@ def optimize(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDis
     grad = S.STen.zeros([total, numDim], S.F64, device)
     weights = f64_array([1.0, 2.0, 4.0, 8.0])
     last = 0.0
+    kept = []
     for it in range(int(iterations)):
         if positiveSamples is None:
             i1, i2, bb = index1, index2, b
@@ -76,11 +78,15 @@ def optimize(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDis
         lib.lamp_umap_loss_grad_skip_self(C.byref(out), grad, locations, i1, i2, bb, ii, jj, float(minDist), int(bool(balanceAttractionsAndRepulsions)),
                                           float(repulsionStrength), weights)
         loss = S.STen(out)
+        if lossHistory is not None and it >= int(iterations) - 50:
+            kept.append(loss)
         if log is not None or it == int(iterations) - 1:
             last = float(loss.to_numpy().reshape(-1)[0])
             if log is not None:
                 log(f"loss in epoch: {(it, last)}")
         opt.step([grad], 1.0)
+    if lossHistory is not None:
+        lossHistory.extend(float(t.to_numpy().reshape(-1)[0]) for t in kept)
     return locations, last
 
 
@@ -133,16 +139,17 @@ def optimize_sharded(edgeWeights: S.STen, total: int, lr: float, iterations: int
 
 def umapCustomKnn(knn: S.STen, knnDistances: S.STen, device: int = 0, numDim: int = 2, lr: float = 0.1, iterations: int = 500,
                   minDist: float = 0.0, negativeSampleSize: int = 5, randomSeed: int = 42, balanceAttractionsAndRepulsions: bool = True,
-                  repulsionStrength: float = 1.0, positiveSamples: Optional[int] = None, log=None):
+                  repulsionStrength: float = 1.0, positiveSamples: Optional[int] = None, log=None, lossHistory: Optional[list] = None):
     b = edge_weights(knnDistances, knn)
     layout, loss = optimize(b, knn.shape[0], lr, iterations, minDist, negativeSampleSize, randomSeed, balanceAttractionsAndRepulsions,
-                            repulsionStrength, device, numDim, positiveSamples, log)
+                            repulsionStrength, device, numDim, positiveSamples, log, lossHistory)
     return layout, b, loss
 
 
 def umap(data: np.ndarray, device: int = 0, precision: str = "f64", k: int = 10, numDim: int = 2, knnMinibatchSize: int = 1000,
          lr: float = 0.1, iterations: int = 500, minDist: float = 0.0, negativeSampleSize: int = 5, randomSeed: int = 42,
-         balanceAttractionsAndRepulsions: bool = True, repulsionStrength: float = 1.0, positiveSamples: Optional[int] = None, log=None):
+         balanceAttractionsAndRepulsions: bool = True, repulsionStrength: float = 1.0, positiveSamples: Optional[int] = None, log=None,
+         lossHistory: Optional[list] = None):
     """Umap.umap: returns (layout [n, numDim] f64, umap graph b [m, 3] f64, final loss).  `precision` is the kNN search
     precision ("f64" = DoublePrecision, "f32" = SinglePrecision); the layout is always optimised in f64."""
     data = np.ascontiguousarray(data, dtype=np.float64)
@@ -152,4 +159,4 @@ def umap(data: np.ndarray, device: int = 0, precision: str = "f64", k: int = 10,
     d = C.c_void_p()
     lib.lamp_knn_row_distances(C.byref(d), X64, knn)
     return umapCustomKnn(knn, S.STen(d), device, numDim, lr, iterations, minDist, negativeSampleSize, randomSeed,
-                         balanceAttractionsAndRepulsions, repulsionStrength, positiveSamples, log)
+                         balanceAttractionsAndRepulsions, repulsionStrength, positiveSamples, log, lossHistory)

@@ -532,7 +532,9 @@ def test_umap_mnist_meets_the_reference_acceptance(gpu):
     What that assertion looks at is the loss of the LAST iteration - one random subsample of 5000 edges and 25000 negatives - and
     neither random stream of the reference (Cmwc5 for the initial layout, libtorch for the samples) can be reproduced.  So (VERDICT r2
     item 5): the ORACLE runs the same recipe with its own generator over five seeds, the HIP path over the same five seeds, and
-      * the mean of the last 50 iterations meets the reference's 0.7 on every HIP seed (the bar, freed of the single-sample noise),
+      * the mean of the last 50 iterations meets the reference's 0.7 for the median HIP seed (the bar, freed of the single-sample noise;
+        on these records - the first 1000 of the TEST set, the train set is not in the reference's tree - the oracle itself ends above
+        0.7 for one seed in five: 0.66 ... 0.73, measured HIP 0.67 ... 0.72),
       * the HIP distribution of that mean lies inside the oracle's (same mean within 0.02, i.e. ~1.5 of the oracle's own seed-to-seed
         standard deviations),
       * the last-iteration loss stays within the oracle's own last-iteration range widened by its noise (3 sigma of one run)."""
@@ -547,23 +549,27 @@ def test_umap_mnist_meets_the_reference_acceptance(gpu):
     rows = torch.tensor(O.edge_weights(dist.tolist(), idx.tolist()), dtype=torch.float64)
     seeds = (42, 1, 7, 11, 123)
     o_mean, o_last, o_std = [], [], []
-    for seed in seeds:
-        losses = []
-        O.umap_optimize(rows, 1000, 0.1, 1000, 0.0, 5, seed, positiveSamples=5000, losses=losses)
-        o_mean.append(float(np.mean(losses[-50:]))); o_last.append(losses[-1]); o_std.append(float(np.std(losses[-50:])))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 8))       # 30k-element ops: ATen's OpenMP loops crawl on the 128+ threads of a GPU host
+    try:
+        for seed in seeds:
+            losses = []
+            O.umap_optimize(rows, 1000, 0.1, 1000, 0.0, 5, seed, positiveSamples=5000, losses=losses)
+            o_mean.append(float(np.mean(losses[-50:]))); o_last.append(losses[-1]); o_std.append(float(np.std(losses[-50:])))
+    finally:
+        torch.set_num_threads(threads)
     h_mean, h_last, lay = [], [], None
     for seed in seeds:
         losses = []
-        layout, b, loss = U.umap(data, numDim=2, positiveSamples=5000, negativeSampleSize=5, iterations=1000, randomSeed=seed,
-                                 log=lambda s_: losses.append(float(s_.split(",")[-1].strip(" )"))))
-        assert len(losses) == 1000 and abs(losses[-1] - float(loss)) < 1e-12
+        layout, b, loss = U.umap(data, numDim=2, positiveSamples=5000, negativeSampleSize=5, iterations=1000, randomSeed=seed, lossHistory=losses)
+        assert len(losses) == 50 and abs(losses[-1] - float(loss)) < 1e-12
         h_mean.append(float(np.mean(losses[-50:]))); h_last.append(losses[-1])
         if seed == 42:
             lay = layout.to_numpy()
             assert np.array_equal(b.to_numpy()[:, :2], rows.numpy()[:, :2]) and np.abs(b.to_numpy()[:, 2] - rows.numpy()[:, 2]).max() < 1e-9, "same UMAP graph as the oracle"
     print(f"UMAP MNIST, mean loss of the last 50 iterations: HIP {np.round(h_mean, 4).tolist()} oracle {np.round(o_mean, 4).tolist()}; "
           f"last iteration: HIP {np.round(h_last, 4).tolist()} oracle {np.round(o_last, 4).tolist()}; oracle noise of one run {np.mean(o_std):.4f}")
-    assert max(h_mean) < 0.7, f"the reference's bar on the mean of the last 50 iterations: {h_mean}"
+    assert float(np.median(h_mean)) < 0.7, f"the reference's bar on the mean of the last 50 iterations: {h_mean}"
     assert abs(np.mean(h_mean) - np.mean(o_mean)) < 0.02, (h_mean, o_mean)
     assert min(o_mean) - 0.02 <= min(h_mean) and max(h_mean) <= max(o_mean) + 0.02, (h_mean, o_mean)
     noise = 3.0 * max(o_std)
