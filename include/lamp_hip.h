@@ -211,6 +211,8 @@ int lamp_t(lamp_tensor** out, const lamp_tensor* t);
 int lamp_select(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t index);
 int lamp_slice(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t end, int64_t step);
 int lamp_narrow(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t start, int64_t length);
+/* ATen.as_strided: a view of t's storage with this geometry; storage_offset in elements from the start of the storage */
+int lamp_as_strided(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, const int64_t* strides, int ndim, int64_t storage_offset);
 int lamp_expand(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim);
 int lamp_expand_as(lamp_tensor** out, const lamp_tensor* t, const lamp_tensor* other);
 int lamp_squeeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim);   /* dim = INT64_MIN: all */

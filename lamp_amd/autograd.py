@@ -154,6 +154,11 @@ def apply_op(name: str, variables: Sequence[Optional[Variable]], tensors: Sequen
 
 
 # explicit constructors mirroring the case classes that take many arguments
+def PackedSelfAttention(x, wQuery, wKeys, wValues, numHeads, isCausal=True):
+    """self-attention's three projections + the fused attention as one node (csrc/host/ops.cpp packed_self_attention): (batch, sequence, heads x d)"""
+    return apply_op("PackedSelfAttention", [x, wQuery, wKeys, wValues], i=[int(numHeads), int(isCausal)])
+
+
 def Convolution(input, weight, bias, stride, padding, dilation, transposed, outputPadding, groups):
     ns = len(stride)
     return apply_op("Convolution", [input, weight, bias],

@@ -778,6 +778,22 @@ int lamp_narrow(lamp_tensor** out, const lamp_tensor* t, int64_t dim, int64_t st
   return lamp_slice(out, t, d, start, start + length, 1);
   LAMP_API_END
 }
+// ATen's as_strided: a view of t's STORAGE with the given geometry (storage_offset in elements from the start of the storage; every
+// element it can address must lie inside the storage)
+int lamp_as_strided(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, const int64_t* strides, int ndim, int64_t storage_offset) {
+  LAMP_API_BEGIN NOT_NULL(t);
+  LAMP_CHECK(ndim >= 0 && ndim <= kMaxDims && storage_offset >= 0, "as_strided: bad rank or offset");
+  int64_t last = storage_offset;
+  bool empty = false;
+  for (int i = 0; i < ndim; i++) {
+    LAMP_CHECK(sizes[i] >= 0 && strides[i] >= 0, "as_strided: negative size or stride");
+    if (sizes[i] == 0) empty = true;
+    else last += (sizes[i] - 1) * strides[i];
+  }
+  LAMP_CHECK(empty || (uint64_t)(last + 1) * t->itemsize() <= t->st->bytes, "as_strided: the view reaches element " << last << ", beyond the storage of " << t->describe());
+  *out = new_view(t, sizes, strides, ndim, storage_offset);
+  LAMP_API_END
+}
 int lamp_expand(lamp_tensor** out, const lamp_tensor* t, const int64_t* sizes, int ndim) {
   LAMP_API_BEGIN NOT_NULL(t);
   LAMP_CHECK(ndim >= t->ndim && ndim <= kMaxDims, "expand: target has fewer dims than the tensor");

@@ -85,6 +85,7 @@ int lamp_op_apply(lamp_var** out, const char* name, lamp_var* const* vars, int n
   else if (n == "EuclideanDistance") r = F::euclidean_distance(V(0), V(1), I(0));
   else if (n == "CappedShiftedNegativeExponential") r = F::capped_shifted_negative_exponential(V(0), D(0));
   else if (n == "ScaledDotProductAttention") r = F::scaled_dot_product_attention(V(0), V(1), V(2), I(0) != 0, ntensors > 0 && tensors[0] ? T(0) : Ten());   // i = [isCausal], tensors = [attentionBias?]
+  else if (n == "PackedSelfAttention") r = F::packed_self_attention(V(0), V(1), V(2), V(3), I(0), I(1) != 0);   // (x, wQ, wK, wV), i = [numHeads, isCausal]
   else if (n == "Convolution") {
     // i = [nspatial, stride.., padding.., dilation.., transposed, outputPadding.., groups]
     const int ns = (int)I(0);

@@ -552,6 +552,81 @@ Var capped_shifted_negative_exponential(const Var& a, double shift) {
 
 // ScaledDotProductAttention (ops.scala:2342-2390): joinedBackward - one backward call yields the three gradients.  Here the first
 // closure that runs makes the call and parks the other two results for its siblings (same p), as batch norm does above.
+// Self-attention's three projections and the fused attention as ONE node (round 3; MultiheadAttention with query, keys and values the
+// same Variable, Transformer.scala:889-962): q | k | v = x . [Wq | Wk | Wv] is one product (24576 x 768 x 2304 in the language model:
+// 3.4 rounds of the 256 x 256 kernel instead of 3 x 2), the attention kernels read the three column blocks in place, and the backward
+// gets dq | dk | dv as the column blocks of one buffer (lamp_scaled_dot_product_attention_backward on packed operands), so that
+// dX = [dq | dk | dv] . [Wq | Wk | Wv]^T and d[Wq | Wk | Wv] = x^T . [dq | dk | dv] are one product each.  Values: the projections are
+// bitwise those of three products; dX is rounded once instead of three times.  Returns (batch, sequence, heads x d).
+static Ten dense_copy_if_needed(const Ten& t) {
+  if (t.h()->is_contiguous()) return t;
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_contiguous(&o, t.h()));
+  return Ten(o);
+}
+Var packed_self_attention(const Var& x, const Var& wq, const Var& wk, const Var& wv, int64_t numHeads, bool isCausal) {
+  auto op = new_op("PackedSelfAttention");
+  const Ten xv = x->value;
+  const int64_t nB = xv.size(0), nS = xv.size(1), in = xv.size(2), HD = wq->value.size(1), D = HD / numHeads;
+  LAMP_CHECK(wk->value.shape() == wq->value.shape() && wv->value.shape() == wq->value.shape() && wq->value.size(0) == in && HD % numHeads == 0,
+             "packed_self_attention: the three projections must have one shape");
+  const Ten x2 = ops::reshape(xv, {nB * nS, in});
+  const Ten wcat = ops::cat({wq->value, wk->value, wv->value}, 1);                 // [in, 3 HD]
+  const Ten qkv = ops::mm(x2, wcat);                                                // [tokens, 3 HD]
+  auto block = [&](const Ten& base, int64_t which) {                                // (B, heads, S, d) view of column block `which`
+    const int64_t sz[4] = {nB, numHeads, nS, D}, st[4] = {nS * 3 * HD, D, 3 * HD, 1};
+    lamp_tensor* o = nullptr;
+    HCALL(lamp_as_strided(&o, base.h(), sz, st, 4, base.h()->offset + which * HD));
+    return Ten(o);
+  };
+  const Ten q4 = block(qkv, 0), k4 = block(qkv, 1), v4 = block(qkv, 2);
+  lamp_tensor *o = nullptr, *l = nullptr;
+  HCALL(lamp_scaled_dot_product_attention_bias(&o, &l, q4.h(), k4.h(), v4.h(), nullptr, isCausal, 0.0));
+  const Ten out(o), lse(l);
+  const Ten value = ops::flatten(ops::transpose(out, 1, 2), 2, 3);                  // (B, S, heads x d): a view when the kernel wrote (B, S, heads, d) storage
+  struct Cache { Ten dqkv, dwcat, p; };
+  auto cache = std::make_shared<Cache>();
+  auto ensure = [=](const Ten& p) {
+    if (cache->p.defined() && cache->p.h() == p.h()) return;
+    const Ten g4 = ops::transpose(ops::view(dense_copy_if_needed(p), {nB, nS, numHeads, D}), 1, 2);
+    lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
+    HCALL(lamp_scaled_dot_product_attention_bias_backward(r3, g4.h(), q4.h(), k4.h(), v4.h(), out.h(), lse.h(), nullptr, isCausal, 0.0));
+    const Ten dq(r3[0]), dk(r3[1]), dv(r3[2]);
+    const int64_t sz[2] = {nB * nS, 3 * HD}, st[2] = {3 * HD, 1};
+    if (dq.h()->st == dk.h()->st && dk.h()->st == dv.h()->st && dq.h()->strides[2] == 3 * HD && dk.h()->offset == dq.h()->offset + HD) {
+      lamp_tensor* packed = nullptr;                                                // the kernels wrote the three column blocks of one buffer
+      HCALL(lamp_as_strided(&packed, dq.h(), sz, st, 2, dq.h()->offset));
+      cache->dqkv = Ten(packed);
+    } else {                                                                        // composed attention (other dtypes / head widths): assemble
+      auto flat = [&](const Ten& t) { return ops::reshape(ops::transpose(t, 1, 2), {nB * nS, HD}); };
+      cache->dqkv = ops::cat({flat(dq), flat(dk), flat(dv)}, 1);
+    }
+    lamp_tensor* dw = nullptr;
+    const int64_t ws[2] = {in, 3 * HD};
+    HCALL(lamp_empty(&dw, ws, 2, xv.dtype(), xv.device()));
+    cache->dwcat = Ten(dw);
+    HCALL(lamp_addmm_out_transposed1(dw, dw, x2.h(), cache->dqkv.h(), 0.0, 1.0));     // d[Wq | Wk | Wv] = x^T . [dq | dk | dv]
+    cache->p = p;
+  };
+  op->params.push_back({x, [=](const Ten& p, Variable& o_) {                          // dX += [dq | dk | dv] . [Wq | Wk | Wv]^T
+    ensure(p);
+    gemm_accumulate(o_, [&](const Ten& g, double beta) {
+      const Ten g2 = ops::view(g, {nB * nS, in});
+      HCALL(lamp_addmm_out_transposed2(g2.h(), g2.h(), cache->dqkv.h(), wcat.h(), beta, 1.0));
+    });
+  }});
+  auto wback = [=](int which) {
+    return [=](const Ten& p, Variable& o_) {
+      ensure(p);
+      o_.accumulate(dense_copy_if_needed(ops::slice(cache->dwcat, 1, which * HD, (which + 1) * HD, 1)), true);
+      if (which == 2) { cache->dqkv = Ten(); cache->dwcat = Ten(); cache->p = Ten(); }
+    };
+  };
+  op->params.push_back({wq, wback(0)});
+  op->params.push_back({wk, wback(1)});
+  op->params.push_back({wv, wback(2)});
+  return make_result(op, value);
+}
 Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal, const Ten& attentionBias) {
   auto op = new_op("ScaledDotProductAttention");
   lamp_tensor *o = nullptr, *l = nullptr;

@@ -46,6 +46,7 @@ Var index_select(const Var& input, int64_t dim, const Var& index);
 Var mask_fill(const Var& input, const Ten& mask, double fill);   // MaskFill (ops.scala:148-159)
 Var euclidean_distance(const Var& a, const Var& b, int64_t dim);
 Var capped_shifted_negative_exponential(const Var& a, double shift);
+Var packed_self_attention(const Var& x, const Var& wq, const Var& wk, const Var& wv, int64_t numHeads, bool isCausal);   // projections + fused attention, one node
 Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& value, bool isCausal, const Ten& attentionBias = Ten());
 Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                 const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,

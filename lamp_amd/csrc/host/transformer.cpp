@@ -143,6 +143,13 @@ Var MultiheadAttention::multiheadAttention(const Var& query, const Var& keys, co
     auto s2 = t->shape();
     return F::reshape(t, {s2[0], s2[1], -1});
   };
+  // self-attention on bf16 with the fused kernels' head widths: one projection product, packed operands (LAMP_FUSE_QKV=0: three products)
+  static const bool fuse_qkv = [] { const char* e = getenv("LAMP_FUSE_QKV"); return !(e && e[0] == '0'); }();
+  if (fuse_qkv && !fused_call_as_written() && query.get() == keys.get() && keys.get() == values.get() && causalMask && !maxLength.defined() && !linearized &&
+      (dropout == 0.0 || !trainDropout) && query->value.dtype() == kBF16 && query->value.ndim() == 3 && query->value.h()->is_device() &&
+      wQuery->shape() == wKeys->shape() && wKeys->shape() == wValues->shape() && wQuery->value.size(1) % numHeads == 0 &&
+      (wQuery->value.size(1) / numHeads == 64 || wQuery->value.size(1) / numHeads == 128) && query->value.size(1) % 8 == 0)
+    return mm1(F::packed_self_attention(query, wQuery, wKeys, wValues, numHeads, true), wOutput, true);
   Var q1 = mm1(query, wQuery, true), k1 = mm1(keys, wKeys, true), v1 = mm1(values, wValues, true);
   const int64_t nQ = q1->value.size(1), nK = k1->value.size(1), nV = v1->value.size(1), nB = q1->value.size(0);
   const bool aligned = nQ % 8 == 0 && nK % 8 == 0 && nV % 8 == 0;

@@ -667,7 +667,23 @@ int lamp_scaled_dot_product_attention_bias_backward(lamp_tensor* out3[3], const 
     Hold lc(contiguous(logsumexp));
     int64_t n1[1] = {B * H * Sq};
     Hold dsum(new_tensor(n1, 1, kF32, q->device()));
-    Hold fdq(at_new_like_layout(q, B, H, Sq, D, kBF16)), fdk(at_new_like_layout(k, B, H, Sk, D, kBF16)), fdv(at_new_like_layout(v, B, H, Sk, Dv, kBF16));
+    Hold fdq, fdk, fdv;
+    // q, k, v are the three column blocks of ONE projection x . [Wq | Wk | Wv] (rows of 3 heads d elements; host: F::packed_self_attention):
+    // their gradients are written as the three column blocks of one buffer, so that dX and d[Wq | Wk | Wv] are ONE product each
+    const bool packed = q->st == k->st && k->st == v->st && Sq == Sk && D == Dv && q->strides[3] == 1 && q->strides[1] == D && q->strides[2] == 3 * H * D &&
+                        q->strides[0] == Sq * 3 * H * D && k->offset == q->offset + H * D && v->offset == k->offset + H * D;
+    bool same_strides = packed;
+    for (int i = 0; same_strides && i < 4; i++) same_strides = k->strides[i] == q->strides[i] && v->strides[i] == q->strides[i];
+    if (same_strides) {
+      int64_t bs[3] = {B, Sq, 3 * H * D};
+      Hold buf(new_tensor(bs, 3, kBF16, q->device()));
+      int64_t vs[4] = {B, H, Sq, D};
+      fdq = Hold(new_view(buf.get(), vs, q->strides, 4, buf->offset));
+      fdk = Hold(new_view(buf.get(), vs, q->strides, 4, buf->offset + H * D));
+      fdv = Hold(new_view(buf.get(), vs, q->strides, 4, buf->offset + 2 * H * D));
+    } else {
+      fdq = Hold(at_new_like_layout(q, B, H, Sq, D, kBF16)); fdk = Hold(at_new_like_layout(k, B, H, Sk, D, kBF16)); fdv = Hold(at_new_like_layout(v, B, H, Sk, Dv, kBF16));
+    }
     if (flash_attention_bwd(grad_out, q, k, v, out, lc.get(), fdq.get(), fdk.get(), fdv.get(), dsum.get(), is_causal, scale, current_stream(q->device()))) {
       out3[0] = fdq.take(); out3[1] = fdk.take(); out3[2] = fdv.take();
       return 0;

@@ -411,3 +411,54 @@ def test_language_model_bf16_flash_path_matches_f32_oracle(gpu):
     hg = hm.gradients(hloss); og = om.gradients(oloss)
     for i, (a, b) in enumerate(zip(hg, og)):
         assert_close(to_torch(a).double(), b.double(), 3e-2, f"gradient {i}", scale="max")     # a whole network in bf16: chained roundings
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Sq,heads,d", [(2, 384, 12, 64), (3, 128, 2, 128), (1, 64, 3, 64)])
+def test_packed_self_attention_equals_three_projections(gpu, B, Sq, heads, d):
+    """F::packed_self_attention (one product x . [Wq | Wk | Wv], the flash kernels on the three column blocks, dq | dk | dv written as the
+    column blocks of one buffer) against the three-projection composition it replaces: the forward is BITWISE the same (each output
+    element is the same dot product in the same order), dX is rounded once instead of three times and the weight gradients come from one
+    product - compared at bf16 resolution, and the packed gradient buffer is asserted through the kernel classes that ran."""
+    import ctypes as C
+    from lamp_amd._capi import lib
+    A, nn, S, TR = _hip()
+    dt = torch.bfloat16
+    inn, HD = 96, heads * d
+    x = closed_form((B, Sq, inn), 5, 2.0, dt)
+    ws = [closed_form((inn, HD), 11 + 7 * i, 2.0 / inn ** 0.5, dt) for i in range(3)]
+    c = closed_form((B, Sq, HD), 31, 1.0, dt)
+
+    def run(packed):
+        hx = A.param(to_sten(x))
+        hw = [A.param(to_sten(w)) for w in ws]
+        if packed:
+            out = A.PackedSelfAttention(hx, hw[0], hw[1], hw[2], heads, True)
+        else:
+            x2 = hx.view([B * Sq, inn])
+            q, k, v = (x2.mm(w).view([B, Sq, heads, d]).transpose(1, 2) for w in hw)       # (B, heads, S, d) strided views
+            out = q.scaledDotProductAttention(k, v, True).transpose(1, 2).reshape([B, Sq, HD])
+        (out * A.const(to_sten(c))).sum().backprop()
+        return to_torch(out.value), to_torch(hx.partialDerivative), [to_torch(w.partialDerivative) for w in hw]
+
+    lib.lamp_kernel_timer_filter(None); lib.lamp_kernel_timer_enable(1)
+    po, pdx, pdw = run(True)
+    lib.lamp_kernel_timer_enable(0)
+    buf = C.create_string_buffer(1 << 16); lib.lamp_kernel_timer_report(buf, len(buf))
+    ran = {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines()}
+    assert {"sdpa_flash_fwd", "sdpa_flash_bwd_dq", "sdpa_flash_bwd_dkv"} <= set(ran), ran
+    uo, udx, udw = run(False)
+    assert torch.equal(po, uo), "the packed projection must give bitwise the three projections' values"
+    assert_close(pdx, udx.double(), 2.0 ** -6, "dx", scale="max")
+    for i, (a, b) in enumerate(zip(pdw, udw)):
+        assert_close(a, b.double(), 2.0 ** -6, f"dW{i}", scale="max")
+    # and against f64 on the same bf16 inputs
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    q, k, v = ((xr.reshape(B * Sq, inn) @ w).reshape(B, Sq, heads, d).transpose(1, 2) for w in wr)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B, Sq, HD)
+    (ref * c.double()).sum().backward()
+    assert_close(po, ref.detach(), 2.0 ** -6, "forward vs f64", scale="max")
+    assert_close(pdx, xr.grad, 2.0 ** -5, "dx vs f64", scale="max")
+    for i, (a, b) in enumerate(zip(pdw, wr)):
+        assert_close(a, b.grad, 2.0 ** -5, f"dW{i} vs f64", scale="max")
