@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): full GPU test suite, bench line, rocprofv3 kernel stats, the two PMC passes and the secondary probes.
 # Everything judged is written under gpurun_out/refresh/ and copied into profiles/ by hand afterwards.
 set -u
-R=$PWD; O=$R/gpurun_out/refresh; mkdir -p $O; RND=${RND:-r02}
+R=$PWD; O=$R/gpurun_out/refresh; mkdir -p $O; RND=${RND:-r03}
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
 cd /tmp
@@ -19,11 +19,14 @@ python3 $R/scripts/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv"
 cp $O/pmc_traffic.json $R/profiles/${RND}_pmc_traffic.json   # the bench line below reads its roofline.traffic from this run's passes
 cd $R; python bench.py > $O/bench.log 2>$O/bench.err; cd /tmp
 for w in gemm knn attention umap lm; do
-  rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o k --output-format csv -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > /tmp/ks_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o k --output-format csv -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/ks_$w.log 2>&1
   cp $(find /tmp/ks_$w -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$w.csv
   grep -o '{"metric.*' /tmp/ks_$w.log | tail -1 > $O/bench_$w.log
 done
 cd $R
+# the un-profiled lines of the secondary workloads WITH their CPU baselines (kNN / UMAP: bounded samples, oracle/cpu_baseline.py)
+for w in knn umap umap-e2e mlp; do python bench.py --workload $w > $O/bench_full_$w.log 2>/dev/null; done
+LAMP_LIB_PATH=lamp_amd/lib_stamp/liblamp_hip.so python scripts/gemm_clock_probe.py > $O/gemm_clock.txt 2>/dev/null || true
 { python scripts/attn_probe.py 8 16 4096 128 0; python scripts/attn_probe.py 8 16 4096 128 1; python scripts/attn_probe.py 8 16 4096 64 0; } > $O/attention_probe.txt 2>&1
 python scripts/umap_full_probe.py 1000000 40 2>&1 | grep "umap n" > $O/umap_probe.txt
 python scripts/gemm_ab.py > $O/gemm_ab.txt 2>&1 || true
