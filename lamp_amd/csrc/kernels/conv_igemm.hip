@@ -1100,6 +1100,12 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // MFMA time); image ranges, partial sums and their reduction are exactly those of the v2 kernel.
 // (A 128 co x 64 ci tile per workgroup - dY read half as often - was 10 us faster on the class but doubles the partial sums for
 // a fixed number of workgroups: +15 us on the step through the reduction; removed.)
+// SHIFT_DY (round 3): the three filter ROWS are taken on the dY side.  A filter-row shift is a shift of the pixel index k by one image row =
+// one 16-byte chunk = one lane group of the fragment, and a product summed over k does not care which operand carries the shift:
+// sum_k dY[k] X[k + 8 (r - 1)] = sum_k dY[k - 8 (r - 1)] X[k].  So a k-step reads 3 row-shifted dY fragments per channel tile (rows that fall
+// outside the image are zeroed in registers) and 3 column-shifted X fragments, 6 + 3 = 9 fragment reads for its 18 MFMAs instead of 2 + 9 = 11:
+// the kernel is bound by its LDS fragment reads (176 KB per image and CU against 1152 matrix cycles).
+template <bool SHIFT_DY>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1161,6 +1167,35 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // would drain vmcnt and with it the prefetch.)
   auto compute = [&](const char* st) {
     const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
+    if (SHIFT_DY) {
+      const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int h = 4 * ks + (lane >> 4);                   // image row of this lane group's eight k
+        bf8v fa[KS][2];
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          const int hr = h - (r - PAD);                       // the dY row that meets X row h under filter row r
+          const bool inside = hr >= 0 && hr < 8;
+          const int hc = inside ? hr : h;
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const s8v v = *reinterpret_cast<const s8v*>(st + ig_kc_off(wq * 32 + i * 16 + (lane & 15), hc));
+            fa[r][i] = inside ? __builtin_bit_cast(bf8v, v) : zero8;
+          }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < KS; s_++) {
+          const s8v v = *reinterpret_cast<const s8v*>(xl + s_ * WG_XCOPY + (h + 1) * 16);   // X row h itself (rows sit one slot down: the zero row above the image)
+          const bf8v fb = __builtin_bit_cast(bf8v, v);
+#pragma unroll
+          for (int r = 0; r < KS; r++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r][i], fb, acc[r * KS + s_][i], 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
       bf8v fa[2];
@@ -1461,9 +1496,16 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     const size_t lds = 4 * (size_t)WG_STAGE;
     {
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      allow_big_lds((const void*)ig_wgrad8h_kernel);
-      hipLaunchKernelGGL(ig_wgrad8h_kernel, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                         (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+      static const bool shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return !(e && e[0] == '0'); }();
+      if (shift_dy) {
+        allow_big_lds((const void*)ig_wgrad8h_kernel<true>);
+        hipLaunchKernelGGL(ig_wgrad8h_kernel<true>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+      } else {
+        allow_big_lds((const void*)ig_wgrad8h_kernel<false>);
+        hipLaunchKernelGGL(ig_wgrad8h_kernel<false>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+      }
       LAMP_LAUNCH_CHECK();
     }
     const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
