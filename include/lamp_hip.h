@@ -479,6 +479,24 @@ int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_t
                                               const lamp_tensor* x2, const lamp_tensor* weight2, const lamp_tensor* bias2,
                                               const lamp_tensor* save_mean2, const lamp_tensor* save_invstd2, double eps, double eps2,
                                               const uint8_t mask[6]);
+/* The batch norm + relu BETWEEN two convolutions of a residual block (Conv2D -> BatchNorm2D -> relu -> Dropout(0) -> Conv2D, cnn.scala:38-60)
+ * applied by the second convolution while it stages its input, so that the normalised tensor is neither written nor re-read:
+ *   lamp_batch_norm_affine           the training-mode statistics of x (running statistics updated as lamp_native_batch_norm does) and the
+ *                                    f32 table [C, 4] = (mean, invstd * weight, bias, 0) per channel, both rounded as the saved tensors are;
+ *   lamp_convolution_bn_relu_input   convolution(relu(batch_norm(x)), w, bias): bitwise the result of the two separate operators;
+ *   ..._backward                     (gradient w.r.t. relu(batch_norm(x)), dweight, dbias); the caller continues with
+ *                                    lamp_native_batch_norm_relu_backward on out3[0] and x.
+ * f32 / f16 / bf16, no transposed convolution.  Geometries outside the kernels that fold the table materialise relu(bn(x)) once. */
+int lamp_batch_norm_affine(lamp_tensor* out3[3] /* affine, save_mean, save_invstd */, const lamp_tensor* x, const lamp_tensor* weight,
+                           const lamp_tensor* bias, lamp_tensor* running_mean, lamp_tensor* running_var, double momentum, double eps);
+int lamp_convolution_bn_relu_input_folds(int* out /* 1: both the forward and the weight-gradient kernel fold the table for this geometry */,
+                                         const lamp_tensor* x, const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
+                                         const int64_t* dilation, int nspatial, int64_t groups);
+int lamp_convolution_bn_relu_input(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* affine, const lamp_tensor* w, const lamp_tensor* bias_or_null,
+                                   const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial, int64_t groups);
+int lamp_convolution_bn_relu_input_backward(lamp_tensor* out3[3] /* dactivation, dweight, dbias */, const lamp_tensor* grad_out, const lamp_tensor* x,
+                                            const lamp_tensor* affine, const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
+                                            const int64_t* dilation, int nspatial, int64_t groups, const uint8_t mask[3]);
 int lamp_native_layer_norm(lamp_tensor* out3[3] /* y, mean, rstd */, const lamp_tensor* x,
                            const int64_t* normalized_shape, int nnorm, const lamp_tensor* weight_or_null,
                            const lamp_tensor* bias_or_null, double eps);

@@ -102,6 +102,20 @@ Var Sequential::forward(const Var& x) {
       auto* bn = dynamic_cast<BatchNorm*>(mods[i].get());
       auto* fn = dynamic_cast<Fun*>(mods[i + 1].get());
       if (bn && fn && fn->tag == "relu" && bn->can_fuse_relu(v)) {
+        // BatchNorm2D -> relu -> [Dropout(p <= 0)] -> Conv2D (the middle of every residual block, cnn.scala:38-60): the convolution applies
+        // the batch norm + relu while staging its input, bitwise the chain's values (LAMP_FUSE_BN_CONV=0: the chain)
+        static const bool fuse_conv = [] { const char* e = getenv("LAMP_FUSE_BN_CONV"); return !(e && e[0] == '0'); }();
+        size_t j = i + 2;
+        auto* drop = j < mods.size() ? dynamic_cast<Dropout*>(mods[j].get()) : nullptr;
+        if (drop && drop->prob <= 0) j++;
+        auto* conv = (!drop || drop->prob <= 0) && j < mods.size() ? dynamic_cast<Conv2D*>(mods[j].get()) : nullptr;
+        if (fuse_conv && conv && bn->training && F::conv_of_batch_norm_relu_2d_pays(v, conv->weights, conv->stride, conv->padding, conv->dilation, conv->groups)) {
+          v = F::conv_of_batch_norm_relu_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps, conv->weights,
+                                            conv->bias, {conv->stride, conv->stride}, {conv->padding, conv->padding}, {conv->dilation, conv->dilation},
+                                            conv->groups);
+          i = j;
+          continue;
+        }
         v = bn->forward_relu(v);
         i++;
         continue;

@@ -920,6 +920,71 @@ Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias
   op->params.push_back({bias2, back(5)});
   return make_result(op, out);
 }
+bool conv_of_batch_norm_relu_2d_pays(const Var& input, const Var& weight, int64_t stride, int64_t padding, int64_t dilation, int64_t groups) {
+  if (input->value.ndim() != 4 || weight->value.ndim() != 4) return false;
+  const int64_t s2[2] = {stride, stride}, p2[2] = {padding, padding}, d2[2] = {dilation, dilation};
+  int folds = 0;
+  HCALL(lamp_convolution_bn_relu_input_folds(&folds, input->value.h(), weight->value.h(), s2, p2, d2, 2, groups));
+  return folds != 0;
+}
+// Convolution(relu(BatchNorm2D(x))) as ONE node: the middle of lamp's residual block (Conv2D -> BatchNorm2D -> relu -> Dropout(0) -> Conv2D,
+// cnn.scala:38-60).  The batch norm becomes a per-channel table (lamp_batch_norm_affine) that the convolution applies while staging its
+// input; values are bitwise those of BatchNorm2D -> relu -> Convolution and the normalised tensor is never written.  Backward: the
+// convolution's gradients (the weight gradient rebuilds relu(bn(x)) the same way), then the fused batch-norm-relu backward on x.
+Var conv_of_batch_norm_relu_2d(const Var& input, const Var& bnWeight, const Var& bnBias, const Ten& runningMean, const Ten& runningVar, double momentum,
+                               double eps, const Var& weight, const Var& bias, const std::vector<int64_t>& stride, const std::vector<int64_t>& padding,
+                               const std::vector<int64_t>& dilation, int64_t groups) {
+  auto op = new_op("ConvolutionOfBatchNormRelu");
+  const Ten x = input->value, gv = bnWeight->value, bv = bnBias->value, wv = weight->value;
+  const std::vector<int64_t> expected = {x.size(1)};
+  LAMP_CHECK(x.ndim() == 4, "Input dimensions must be 4");
+  LAMP_CHECK(bnWeight->shape() == expected && bnBias->shape() == expected, "batch norm weight / bias have the wrong shape");
+  LAMP_CHECK(runningMean.shape() == expected && runningVar.shape() == expected, "running statistics have the wrong shape");
+  lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
+  HCALL(lamp_batch_norm_affine(o3, x.h(), gv.h(), bv.h(), runningMean.h(), runningVar.h(), momentum, eps));
+  Ten affine(o3[0]), saveMean(o3[1]), saveInvstd(o3[2]);
+  const int ns = (int)stride.size();
+  lamp_tensor* o = nullptr;
+  HCALL(lamp_convolution_bn_relu_input(&o, x.h(), affine.h(), wv.h(), bias->value.h(), stride.data(), padding.data(), dilation.data(), ns, groups));
+  struct Cache { Ten g[5]; Ten p; };                       // dx, d(bn weight), d(bn bias), d(conv weight), d(conv bias) of one backward pass
+  auto cache = std::make_shared<Cache>();
+  const bool want[5] = {input->needsGrad(), bnWeight->needsGrad(), bnBias->needsGrad(), weight->needsGrad(), bias->needsGrad()};
+  auto back = [=](int which) {
+    return [=](const Ten& p, Variable& out) {
+      if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
+        bool w[5];
+        for (int i = 0; i < 5; i++) w[i] = want[i];
+        w[which] = true;
+        const bool through_bn = w[0] || w[1] || w[2];
+        const uint8_t cmask[3] = {(uint8_t)through_bn, (uint8_t)w[3], (uint8_t)w[4]};
+        lamp_tensor* c3[3] = {nullptr, nullptr, nullptr};
+        HCALL(lamp_convolution_bn_relu_input_backward(c3, p.h(), x.h(), affine.h(), wv.h(), stride.data(), padding.data(), dilation.data(), ns, groups, cmask));
+        Ten dact = c3[0] ? Ten(c3[0]) : Ten();
+        cache->g[3] = c3[1] ? Ten(c3[1]) : Ten();
+        cache->g[4] = c3[2] ? Ten(c3[2]) : Ten();
+        if (through_bn) {
+          const uint8_t bmask[3] = {(uint8_t)w[0], (uint8_t)w[1], (uint8_t)w[2]};
+          lamp_tensor* b3[3] = {nullptr, nullptr, nullptr};
+          HCALL(lamp_native_batch_norm_relu_backward(b3, dact.h(), x.h(), gv.h(), bv.h(), runningMean.h(), runningVar.h(), saveMean.h(), saveInvstd.h(), 1, eps, bmask));
+          for (int i = 0; i < 3; i++) cache->g[i] = b3[i] ? Ten(b3[i]) : Ten();
+        }
+        cache->p = p;
+      }
+      Ten g = cache->g[which];
+      cache->g[which] = Ten();
+      bool any = false;
+      for (int i = 0; i < 5; i++) any = any || cache->g[i].defined();
+      if (!any) cache->p = Ten();
+      out.accumulate(ops::reshape(g, out.shape()), true);
+    };
+  };
+  op->params.push_back({input, back(0)});
+  op->params.push_back({bnWeight, back(1)});
+  op->params.push_back({bnBias, back(2)});
+  op->params.push_back({weight, back(3)});
+  op->params.push_back({bias, back(4)});
+  return make_result(op, Ten(o));
+}
 Var layer_norm(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& normalizedShape, double eps) {
   auto op = new_op("LayerNormOp");
   lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};

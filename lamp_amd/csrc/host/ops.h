@@ -63,6 +63,10 @@ Var batch_norm_relu_2d(const Var& input, const Var& weight, const Var& bias, con
                        double momentum, double eps);
 Var batch_norm_add_relu_2d(const Var& input, const Var& addend, const Var& weight, const Var& bias, const Ten& runningMean,
                            const Ten& runningVar, bool training, double momentum, double eps);
+bool conv_of_batch_norm_relu_2d_pays(const Var& input, const Var& weight, int64_t stride, int64_t padding, int64_t dilation, int64_t groups);
+Var conv_of_batch_norm_relu_2d(const Var& input, const Var& bnWeight, const Var& bnBias, const Ten& runningMean, const Ten& runningVar, double momentum,
+                               double eps, const Var& weight, const Var& bias, const std::vector<int64_t>& stride, const std::vector<int64_t>& padding,
+                               const std::vector<int64_t>& dilation, int64_t groups);
 Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum, double eps,
                             const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2, const Ten& runningVar2, double momentum2,
                             double eps2);   // relu(bn(input) + bn2(input2)), training mode, one op

@@ -292,7 +292,9 @@ bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor
 // addend (optional): dx = round(round(dgrad) + addend) when the kernel chosen has that epilogue; *addend_fused reports whether it was used
 bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
                       bool* addend_fused = nullptr);
-bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
+bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine = nullptr);
+bool igemm_conv_folds_affine(const ConvGeom& g, int dtype);
+bool igemm_conv_fwd_affine(const Tensor* x, const Tensor* affine, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 // implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
@@ -304,6 +306,31 @@ bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
 
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
 
+template <class T>
+__global__ __launch_bounds__(256) void bn_relu_materialise_kernel(const T* __restrict__ x, T* __restrict__ y, const float4* __restrict__ affine, int64_t total,
+                                                                  int64_t C, int64_t HW) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = affine[(i / HW) % C];
+    T o = store_as<T>(__builtin_fmaf(load_as<float>(x[i]) - a.x, a.y, a.z));           // norm.hip bn_affine<float>, rounded as bn_apply rounds
+    if (load_as<float>(o) < 0.f) o = store_as<T>(0.f);
+    y[i] = o;
+  }
+}
+Tensor* bn_relu_materialise(const Tensor* xc, const Tensor* affine, hipStream_t st) {
+  Hold y(new_like(xc));
+  const int64_t total = xc->numel(), C = xc->sizes[1];
+  int64_t HW = 1;
+  for (int i = 2; i < xc->ndim; i++) HW *= xc->sizes[i];
+  if (total > 0) {
+    const float4* aff = reinterpret_cast<const float4*>(affine->ptr<float>());
+    const dim3 grid(grid_for(total, 256));
+    if (xc->dtype == kBF16) hipLaunchKernelGGL((bn_relu_materialise_kernel<bf16_t>), grid, dim3(256), 0, st, xc->ptr<bf16_t>(), y->ptr<bf16_t>(), aff, total, C, HW);
+    else if (xc->dtype == kF16) hipLaunchKernelGGL((bn_relu_materialise_kernel<f16_t>), grid, dim3(256), 0, st, xc->ptr<f16_t>(), y->ptr<f16_t>(), aff, total, C, HW);
+    else hipLaunchKernelGGL((bn_relu_materialise_kernel<float>), grid, dim3(256), 0, st, xc->ptr<float>(), y->ptr<float>(), aff, total, C, HW);
+    LAMP_LAUNCH_CHECK();
+  }
+  return y.take();
+}
 }  // namespace lamp
 
 using namespace lamp;
@@ -376,6 +403,83 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
     db = Hold(reduce_dims(gc.get(), dims.data(), (int)dims.size(), false, 0));
   }
   out3[0] = dx.take(); out3[1] = dw.take(); out3[2] = db.take();
+  LAMP_API_END
+}
+
+// ---- conv(relu(bn(x))): the batch norm + relu between two convolutions folded into the consumer (round 3) -----------------------------
+// `affine` = f32 [C][4] rows (mean, invstd * weight, bias, -) from lamp_batch_norm_affine.  Where the implicit-GEMM kernels can apply it
+// while they stage their input (eight-image fprop kernel, eight-wave weight-gradient kernel: the wide 8x8 layers at large batch) the
+// normalised tensor is never written; every other geometry materialises it once with the same arithmetic and runs the plain operators.
+static void check_affine(const lamp_tensor* affine, const lamp_tensor* x) {
+  check_device_tensor(affine, "affine");
+  LAMP_CHECK(affine->dtype == kF32 && affine->ndim == 2 && affine->sizes[0] == x->sizes[1] && affine->sizes[1] == 4 && affine->is_contiguous(),
+             "affine must be the contiguous f32 [channels, 4] table of lamp_batch_norm_affine, got " << affine->describe());
+  LAMP_CHECK(x->dtype == kBF16 || x->dtype == kF16 || x->dtype == kF32, "conv(relu(bn(x))) with a folded batch norm is a reduced-precision path (f32 table): f64 runs the separate operators");
+}
+// *out = 1 when BOTH the forward and the weight-gradient kernel for this geometry apply the table while staging (the fold saves a pass
+// over the activation), 0 when either would materialise relu(bn(x)) first (the fold is then no faster than the separate operators)
+int lamp_convolution_bn_relu_input_folds(int* out, const lamp_tensor* x, const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
+                                         const int64_t* dilation, int nspatial, int64_t groups) {
+  LAMP_API_BEGIN
+  *out = 0;
+  if (!x->is_device() || !w->is_device() || x->dtype != w->dtype) return 0;
+  const int64_t zero2[2] = {0, 0};
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, zero2, groups);
+  *out = igemm_conv_folds_affine(g, x->dtype) ? 1 : 0;
+  LAMP_API_END
+}
+int lamp_convolution_bn_relu_input(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* affine, const lamp_tensor* w, const lamp_tensor* bias,
+                                   const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial, int64_t groups) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(w, "weight"); check_affine(affine, x);
+  LAMP_CHECK(x->dtype == w->dtype, "convolution: input " << x->describe() << " and weight " << w->describe() << " have different dtypes");
+  const int64_t zero2[2] = {0, 0};
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, zero2, groups);
+  if (bias) { check_device_tensor(bias, "bias"); LAMP_CHECK(bias->numel() == g.Cout && bias->dtype == x->dtype, "convolution: bias must have " << g.Cout << " elements"); }
+  Hold xc(contiguous(x)), wc(contiguous(w));
+  Hold bc(bias ? contiguous(bias) : nullptr);
+  hipStream_t st = current_stream(x->device());
+  std::vector<int64_t> oshape = {g.N, g.Cout};
+  if (nspatial == 2) oshape.push_back(g.Ho);
+  oshape.push_back(g.Wo);
+  Hold y(new_tensor(oshape, x->dtype, x->device()));
+  if (!igemm_conv_fwd_affine(xc.get(), affine, wc.get(), bc.get(), y.get(), g, st)) {
+    Hold act(bn_relu_materialise(xc.get(), affine, st));
+    lamp_tensor* o = nullptr;
+    if (lamp_convolution(&o, act.get(), wc.get(), bc.get(), stride, padding, dilation, nspatial, 0, zero2, groups) != 0) throw Error(lamp_last_error());
+    *out = o;
+    return 0;
+  }
+  *out = y.take();
+  LAMP_API_END
+}
+// out3 = (gradient w.r.t. relu(bn(x)), dweight, dbias); the caller runs the batch norm + relu backward on out3[0] and x
+int lamp_convolution_bn_relu_input_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* affine,
+                                            const lamp_tensor* w, const int64_t* stride, const int64_t* padding, const int64_t* dilation, int nspatial,
+                                            int64_t groups, const uint8_t mask[3]) {
+  LAMP_API_BEGIN
+  out3[0] = out3[1] = out3[2] = nullptr;
+  check_device_tensor(x, "input"); check_device_tensor(w, "weight"); check_device_tensor(grad_out, "grad_out"); check_affine(affine, x);
+  const int64_t zero2[2] = {0, 0};
+  ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, zero2, groups);
+  Hold xc(contiguous(x)), wc(contiguous(w)), gc(contiguous(grad_out));
+  hipStream_t st = current_stream(x->device());
+  Hold dw;
+  bool dw_done = false;
+  if (mask[1]) {
+    dw = Hold(new_like(wc.get()));
+    dw_done = igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st, affine);        // relu(bn(x)) rebuilt while staging
+  }
+  // everything else through the plain operator: the input gradient never needs the activation, the weight gradient gets a materialised one
+  const bool need_act = mask[1] && !dw_done;
+  Hold act(need_act ? bn_relu_materialise(xc.get(), affine, st) : nullptr);
+  const uint8_t m3[3] = {mask[0], (uint8_t)(mask[1] && !dw_done), mask[2]};
+  lamp_tensor* r3[3] = {nullptr, nullptr, nullptr};
+  if (m3[0] || m3[1] || m3[2]) {
+    if (lamp_convolution_backward(r3, gc.get(), need_act ? act.get() : xc.get(), wc.get(), stride, padding, dilation, nspatial, 0, zero2, groups, m3) != 0)
+      throw Error(lamp_last_error());
+  }
+  out3[0] = r3[0]; out3[1] = dw_done ? dw.take() : r3[1]; out3[2] = r3[2];
   LAMP_API_END
 }
 

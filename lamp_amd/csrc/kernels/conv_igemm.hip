@@ -657,6 +657,22 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
   }
 }
 
+// relu(bn(x)) applied to eight bf16 values of one channel while they are staged (round 3: the batch norm + relu BETWEEN two convolutions of a
+// residual block is folded into the consumer's staging, DESIGN "mid-block fold"): exactly bn_apply2_kernel's arithmetic - one fma on
+// (x - mean) with the ROUNDED mean / invstd the batch norm saves, rounded to bf16, then the comparison with 0 on the rounded value.
+__device__ __forceinline__ uint4 ig_bn_relu_x8(uint4 v, float mu, float scale, float bb) {
+  unsigned* w = &v.x;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float x0 = __uint_as_float(w[q] << 16), x1 = __uint_as_float(w[q] & 0xffff0000u);
+    bf16_t o0(__builtin_fmaf(x0 - mu, scale, bb)), o1(__builtin_fmaf(x1 - mu, scale, bb));
+    if ((float)o0 < 0.f) o0 = bf16_t(0.f);
+    if ((float)o1 < 0.f) o1 = bf16_t(0.f);
+    w[q] = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
+  }
+  return v;
+}
+
 // Variant for MORE than 64 output channels at large batch (the 128- and 100-channel layers of res3 / res4: 80 % of the network's FLOPs):
 // ONE workgroup per CU, eight images and eight waves, wave w = image w x ALL output channels (64 pixels x 128 channels, 128 f32
 // accumulators per lane).
@@ -692,7 +708,7 @@ __device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | 
 template <int KS, int NCT>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg,
-                                                        const bf16_t* addend) {
+                                                        const bf16_t* addend, const float4* __restrict__ affine) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -743,6 +759,14 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
         if (c < CI && n < N) {
           const uint4* src = reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + c) * 64 + h * 8);
           rw[k] = stats ? nt_load16(src) : *src;
+        }
+      }
+      if (affine) {
+        // the input is a convolution's raw output: relu(bn(.)) of it is what this convolution multiplies (per channel mean, invstd * weight, bias)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int c = ch * 32 + cg * 8 + k;
+          if (c < CI && n < N) { const float4 a = affine[c]; rw[k] = ig_bn_relu_x8(rw[k], a.x, a.y, a.z); }
         }
       }
       char* xi = Xl + ch * XBUF + img * XIMG;
@@ -1107,7 +1131,7 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // the kernel is bound by its LDS fragment reads (176 KB per image and CU against 1152 matrix cycles).
 template <bool SHIFT_DY>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile) {
+                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 3, RS = 9, PAD = 1;
   const int nsplit = gridDim.x / ntile;
@@ -1127,12 +1151,19 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 
   const bool xthread = tid < 256;
   const int xci = (tid & 255) >> 3, xh = tid & 7;             // (channel, image row) of the X tile: threads 0..255
+  // affine: x is a convolution's raw output and the forward multiplied relu(bn(x)) (ig_conv8d_kernel): the same values are rebuilt here
+  const float4 aff = (affine && xthread && ci0 + xci < CI) ? affine[ci0 + xci] : make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_x = [&](int n) -> uint4 {
-    if (xthread && ci0 + xci < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
+    if (xthread && ci0 + xci < CI) {
+      return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
+    }
     return make_uint4(0, 0, 0, 0);
   };
   auto store_x = [&](char* stage, uint4 v) {                  // copy s holds out[w] = in[w + s - 1]
     if (!xthread) return;
+    // the table is applied HERE, a pair after the load was requested (at the load it would wait for the data and undo the prefetch).
+    // Images beyond nend arrive as zeros and leave as relu(bn(0)): their dY is zero, so they add nothing
+    if (affine) v = ig_bn_relu_x8(v, aff.x, aff.y, aff.z);
     char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
     *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
     *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
@@ -1367,9 +1398,13 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
 }
 
 // addend (dgrad, optional): out = round(round(conv) + addend) where the kernel chosen can do it in its epilogue; *addend_fused says whether it did
+// affine (fprop, optional): f32 [Cin][4] = (mean, invstd * weight, bias, -) of the batch norm + relu that stands between the producer of
+// `in` and this convolution; applied while staging where the kernel chosen can do it - *affine_used says whether it did (else the caller
+// materialises relu(bn(in)) and calls again without it)
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
-                      const Tensor* addend = nullptr, bool* addend_fused = nullptr) {
+                      const Tensor* addend = nullptr, bool* addend_fused = nullptr, const Tensor* affine = nullptr, bool* affine_used = nullptr) {
   if (addend_fused) *addend_fused = false;
+  if (affine_used) *affine_used = false;
   const int KS = g.kh, RS = KS * KS;
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
@@ -1410,9 +1445,11 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   do {                                                                                                                                      \
     allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
     hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp, per_wg, addp);                                                                         \
+                       (int)g.N, CI, KP, CO, statp, per_wg, addp, affp);                                                                   \
   } while (0)
         const bf16_t* addp = addend ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
+        const float4* affp = affine ? reinterpret_cast<const float4*>(affine->ptr<float>()) : (const float4*)nullptr;
+        if (affine_used) *affine_used = affine != nullptr;
         if (addend_fused) *addend_fused = addend != nullptr;
         if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
         else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
@@ -1473,16 +1510,44 @@ bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor
   run_conv8(x, w, bias, y, g, false, st);
   return true;
 }
+// y = conv(relu(bn(x))) with the batch norm given as its per-channel table: true only if a kernel that applies it while staging ran
+// the eight-image kernel's conditions (run_conv8)
+static bool ig_fwd_folds_affine(const ConvGeom& g, int dtype) {
+  if (!ig_qualifies(g, dtype)) return false;
+  const char* variant = getenv("LAMP_IG_VARIANT");
+  if (variant && (variant[0] == 'a' || variant[0] == 'b')) return false;
+  static const bool small_d = [] { const char* e = getenv("LAMP_IG_SMALL_D"); return !(e && e[0] == '0'); }();
+  const bool force_d = variant && variant[0] == 'd';
+  return (g.Cout > 64 || small_d) && (force_d || g.N >= 4 * (int64_t)num_cus());
+}
+// the eight-wave weight-gradient kernel's conditions (igemm_conv_wgrad)
+static bool ig_wgrad_folds_affine(const ConvGeom& g, int dtype) {
+  static const bool wide_on = [] { const char* e = getenv("LAMP_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+  return ig_qualifies(g, dtype) && wide_on && g.kh == 3 && g.Cin > WG_CI && g.Cout > 64;
+}
+// both directions apply the batch-norm table while staging: only then does folding the batch norm into this convolution save a pass
+bool igemm_conv_folds_affine(const ConvGeom& g, int dtype) { return ig_fwd_folds_affine(g, dtype) && ig_wgrad_folds_affine(g, dtype); }
+bool igemm_conv_fwd_affine(const Tensor* x, const Tensor* affine, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
+  if (!ig_fwd_folds_affine(g, x->dtype)) return false;           // checked up front: nothing must be launched when the conditions do not hold
+  bool used = false;
+  run_conv8(x, w, bias, y, g, false, st, nullptr, nullptr, affine, &used);
+  LAMP_CHECK(used, "internal: the eight-image kernel did not run");
+  return true;
+}
 bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
   if (addend_fused) *addend_fused = false;
   if (!ig_qualifies(g, dy->dtype)) return false;
   run_conv8(dy, w, nullptr, dx, g, true, st, addend, addend_fused);
   return true;
 }
-bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+// affine (optional): x is the raw output of the producing convolution and the forward multiplied relu(bn(x)) - only the eight-wave kernel
+// rebuilds it while staging: false (nothing launched) when the geometry takes another kernel
+bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine) {
   if (!ig_qualifies(g, x->dtype)) return false;
   const int KS = g.kh, RS = KS * KS;
   static const bool wide_on = [] { const char* e = getenv("LAMP_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+  const float4* affp = affine ? reinterpret_cast<const float4*>(affine->ptr<float>()) : (const float4*)nullptr;
+  if (affine && !ig_wgrad_folds_affine(g, x->dtype)) return false;
   if (wide_on && KS == 3 && g.Cin > WG_CI && g.Cout > 64) {
     // eight-wave kernel: the v2 decomposition (32-channel slice of Cin, image range) with two waves per SIMD
     const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
@@ -1500,11 +1565,11 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
       if (shift_dy) {
         allow_big_lds((const void*)ig_wgrad8h_kernel<true>);
         hipLaunchKernelGGL(ig_wgrad8h_kernel<true>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp);
       } else {
         allow_big_lds((const void*)ig_wgrad8h_kernel<false>);
         hipLaunchKernelGGL(ig_wgrad8h_kernel<false>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp);
       }
       LAMP_LAUNCH_CHECK();
     }

@@ -250,6 +250,26 @@ __device__ __forceinline__ void bn_merge_channel(const acc_t<T>* __restrict__ pa
   }
   __syncthreads();
 }
+// The batch norm as a per-channel table instead of a normalised tensor (lamp_batch_norm_affine): affine[c] = (mean, invstd * weight, bias, 0),
+// the three operands of bn_affine<float>, for a convolution that applies batch norm + relu while it stages its input (conv_igemm.hip).
+template <class T>
+__global__ __launch_bounds__(256) void bn_affine_table_kernel(const acc_t<T>* __restrict__ partial, int nsplit, T* __restrict__ save_mean, T* __restrict__ save_invstd,
+                                                              T* running_mean, T* running_var, double momentum, double eps, const T* __restrict__ w,
+                                                              const T* __restrict__ b, int64_t C, float4* __restrict__ affine) {
+  using A = acc_t<T>;
+  __shared__ A stat[2];
+  __shared__ A wpart[4][3];
+  const int64_t c = blockIdx.x;
+  bn_merge_channel<T>(partial, nsplit, c, C, 0, save_mean, save_invstd, running_mean, running_var, momentum, eps, stat, wpart);
+  if (threadIdx.x == 0) affine[c] = make_float4((float)stat[0], (float)(stat[1] * (w ? load_as<A>(w[c]) : A(1))), b ? (float)load_as<A>(b[c]) : 0.f, 0.f);
+}
+template <class T>
+__global__ __launch_bounds__(256) void bn_affine_from_saved_kernel(const T* __restrict__ mean, const T* __restrict__ invstd, const T* __restrict__ w,
+                                                                   const T* __restrict__ b, int64_t C, float4* __restrict__ affine) {
+  using A = acc_t<T>;
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c < C) affine[c] = make_float4((float)load_as<A>(mean[c]), (float)(load_as<A>(invstd[c]) * (w ? load_as<A>(w[c]) : A(1))), b ? (float)load_as<A>(b[c]) : 0.f, 0.f);
+}
 // A second batch norm whose OUTPUT is the addend (lamp_native_batch_norm2_add_relu: the tail of lamp's residual block when the left
 // branch is convolution -> batch norm too, cnn.scala:62-78): x == nullptr means none.  Passed by value.
 template <class T> struct BnSecond {
@@ -1152,10 +1172,11 @@ struct BnSecondArgs {
 };
 static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
                            lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu,
-                           const lamp_tensor* addend = nullptr, BnSecondArgs* second = nullptr) {
+                           const lamp_tensor* addend = nullptr, BnSecondArgs* second = nullptr, bool table_only = false) {
   LAMP_API_BEGIN
   check_device_tensor(x, "input");
   BnGeom g = bn_geom(x);
+  LAMP_CHECK(!table_only || (training && !addend && !second && x->dtype != kF64), "the batch norm table exists in training mode, as an f32 table for f32 / f16 / bf16 inputs");
   Hold addc, x2c, mean2, invstd2;
   if (second) {
     check_device_tensor(second->x, "second input");
@@ -1176,14 +1197,15 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   check_cvec(weight, g.C, x->dtype, "weight"); check_cvec(bias, g.C, x->dtype, "bias");
   check_cvec(running_mean, g.C, x->dtype, "running_mean"); check_cvec(running_var, g.C, x->dtype, "running_var");
   Hold xc(contiguous(x));
-  Hold y(new_like(xc.get()));
-  int64_t cs[1] = {g.C};
+  int64_t cs[1] = {g.C}, ts[2] = {g.C, 4};
+  Hold y(table_only ? new_tensor(ts, 2, kF32, x->device()) : new_like(xc.get()));   // table_only: out3[0] is the [C, 4] table, x is never normalised here
   Hold mean(new_tensor(cs, 1, x->dtype, x->device())), invstd(new_tensor(cs, 1, x->dtype, x->device()));
   hipStream_t st = current_stream(x->device());
   const int64_t total = x->numel();
   LAMP_DISPATCH_FLOAT(x->dtype, T, {
     using A = acc_t<T>;
     const int vec = (g.HW % (16 / sizeof(T)) == 0) && (((uintptr_t)xc->raw() | (uintptr_t)y->raw() | (uintptr_t)(x2c.get() ? x2c->raw() : nullptr)) & 15) == 0;
+    float4* table = table_only ? reinterpret_cast<float4*>(y->raw()) : nullptr;
     if (training) {
       LAMP_CHECK(g.N * g.HW > 0, "batch norm over an empty batch");
       const bool col = g.HW < 64;
@@ -1233,7 +1255,11 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
         sec.momentum = second->momentum; sec.eps = second->eps;
         sec.w = second->weight ? second->weight->ptr<T>() : (const T*)nullptr; sec.b = second->bias ? second->bias->ptr<T>() : (const T*)nullptr;
       }
-      if (!col && total > 0) {
+      if (table_only && !col) {
+        hipLaunchKernelGGL((bn_affine_table_kernel<T>), dim3((unsigned)g.C), dim3(256), 0, st, static_cast<const Tensor*>(partial.get())->ptr<A>(),
+                           have_stats ? -npart : npart, mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.C, table);
+        LAMP_LAUNCH_CHECK();
+      } else if (!col && total > 0) {
         // finalize folded into the channel-aligned normalise
         KernelTimer kt("bn_fwd_apply", 0, (second ? 3.0 : addc.get() ? 3.0 : 2.0) * (double)total * sizeof(T), st);
         hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), y->ptr<T>(),
@@ -1245,7 +1271,10 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
         hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
                            mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps);
         LAMP_LAUNCH_CHECK();
-        if (total > 0) {
+        if (table_only) {
+          hipLaunchKernelGGL((bn_affine_from_saved_kernel<T>), dim3((unsigned)((g.C + 255) / 256)), dim3(256), 0, st, mean->ptr<T>(), invstd->ptr<T>(), wp, bp, g.C, table);
+          LAMP_LAUNCH_CHECK();
+        } else if (total > 0) {
           KernelTimer kt("bn_fwd_apply", 0, 2.0 * (double)total * sizeof(T), st);
           hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, xc->ptr<T>(), y->ptr<T>(), mean->ptr<T>(), invstd->ptr<T>(),
                              wp, bp, total, g.C, g.HW, vec, relu);
@@ -1280,6 +1309,13 @@ int lamp_native_batch_norm(lamp_tensor* out3[3], const lamp_tensor* x, const lam
 int lamp_native_batch_norm_relu(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
                                 lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps) {
   return bn_forward_impl(out3, x, weight, bias, running_mean, running_var, training, momentum, eps, 1);
+}
+
+// out3 = (affine f32 [C, 4], save_mean, save_invstd): the training-mode batch norm of x as the table a consumer convolution applies
+// (lamp_convolution_bn_relu_input); running statistics are updated exactly as lamp_native_batch_norm updates them
+int lamp_batch_norm_affine(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias, lamp_tensor* running_mean,
+                           lamp_tensor* running_var, double momentum, double eps) {
+  return bn_forward_impl(out3, x, weight, bias, running_mean, running_var, 1, momentum, eps, 1, nullptr, nullptr, true);
 }
 
 static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,

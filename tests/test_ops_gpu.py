@@ -1347,3 +1347,81 @@ def test_batch_norm_pair_add_relu_equals_the_chain(gpu, dt, shape):
     assert [bool(h) for h in o6c] == [False, True, False, True, False, True]
     for i in (1, 3, 5):
         assert np.array_equal(S.STen(o6c[i]).to_numpy(), fused[i].to_numpy()), names[i]
+
+
+# ---- the batch norm + relu between two convolutions, folded into the second convolution (round 3) ---------------------------------------
+# (N, Cin, H, W, Cout, k): the first two are the geometries whose kernels fold the table (eight-image fprop, eight-wave wgrad); the others
+# take the materialising path of the same entry points
+BN_CONV_SHAPES = [(1100, 128, 8, 8, 128, 3), (1030, 100, 8, 8, 100, 3), (1100, 40, 8, 8, 72, 3), (6, 5, 8, 8, 7, 3), (3, 16, 16, 16, 8, 1), (40, 128, 8, 8, 128, 3),
+                  (1100, 64, 8, 8, 64, 3), (5, 6, 4, 4, 3, 3)]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", BN_CONV_SHAPES)
+def test_convolution_of_batch_norm_relu_equals_the_chain(gpu, dt, shape):
+    """lamp_batch_norm_affine + lamp_convolution_bn_relu_input(+_backward) - the middle of lamp's residual block (cnn.scala:38-60) with the
+    batch norm applied while the convolution stages its input - against the chain it replaces: native_batch_norm_relu -> convolution and
+    convolution_backward -> native_batch_norm_relu_backward.  Statistics, running statistics and the convolution's output: BITWISE.  The
+    input gradient and the bias gradient: bitwise (same kernels); the weight gradient: bitwise too (the same kernel multiplies the same
+    rebuilt operand)."""
+    N, Ci, H, W, Co, k = shape
+    if N >= 1000 and dt != torch.bfloat16:
+        pytest.skip("the large shapes are the bf16 folding cases")
+    p = k // 2
+    x = closed_form((N, Ci, H, W), 3, 4.0, dt) + 0.3
+    g, b = closed_form((Ci,), 1, 1.0, dt) + 1.0, closed_form((Ci,), 5, 1.0, dt)
+    rm, rv = closed_form((Ci,), 7, 0.5, dt), closed_form((Ci,), 9, 0.5, dt) + 1.0
+    w = closed_form((Co, Ci, k, k), 17, 0.5, dt)
+    cb = closed_form((Co,), 29, 1.0, dt)
+    X, G, B, Wt, CB = (to_sten(t) for t in (x, g, b, w, cb))
+    RMc, RVc, RMf, RVf = (to_sten(t) for t in (rm, rv, rm, rv))
+    one, pad = i64_array([1, 1]), i64_array([p, p])
+    # the chain
+    o3 = _out3()
+    lib.lamp_native_batch_norm_relu(o3, X, G, B, RMc, RVc, 1, 0.1, 1e-5)
+    act, smc, sic = _wrap3(o3)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), act, Wt, CB, one, pad, one, 2, 0, i64_array([0, 0]), 1)
+    yc = S.STen(o)
+    # folded
+    folds = C.c_int(-1)
+    lib.lamp_convolution_bn_relu_input_folds(C.byref(folds), X, Wt, one, pad, one, 2, 1)
+    expect_fold = dt == torch.bfloat16 and N >= 1024 and Ci > 32 and Co > 64 and k == 3
+    assert folds.value == int(expect_fold)
+    a3 = _out3()
+    lib.lamp_batch_norm_affine(a3, X, G, B, RMf, RVf, 0.1, 1e-5)
+    aff, smf, sif = _wrap3(a3)
+    assert aff.shape == [Ci, 4] or tuple(aff.shape) == (Ci, 4)
+    lib.lamp_kernel_timer_enable(1)
+    o = C.c_void_p()
+    lib.lamp_convolution_bn_relu_input(C.byref(o), X, aff, Wt, CB, one, pad, one, 2, 1)
+    yf = S.STen(o)
+    for a, c_, what in ((yf, yc, "y"), (smf, smc, "save_mean"), (sif, sic, "save_invstd"), (RMf, RMc, "running_mean"), (RVf, RVc, "running_var")):
+        assert np.array_equal(a.to_numpy(), c_.to_numpy()), what
+    # the table is (mean, invstd * weight, bias) of the saved (rounded) statistics
+    t = to_torch(aff).float()
+    assert torch.equal(t[:, 0], to_torch(smf).float()) and torch.equal(t[:, 1], to_torch(sif).float() * g.float()) and torch.equal(t[:, 2], b.float())
+    # backward
+    gy = closed_form((N, Co, H, W), 11, 2.0, dt)
+    GY = to_sten(gy)
+    c3 = _out3()
+    lib.lamp_convolution_backward(c3, GY, act, Wt, one, pad, one, 2, 0, i64_array([0, 0]), 1, _mask3(1, 1, 1))
+    dactc, dwc, dcbc = _wrap3(c3)
+    f3 = _out3()
+    lib.lamp_convolution_bn_relu_input_backward(f3, GY, X, aff, Wt, one, pad, one, 2, 1, _mask3(1, 1, 1))
+    dactf, dwf, dcbf = _wrap3(f3)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    for a, c_, what in ((dactf, dactc, "d activation"), (dwf, dwc, "dweight"), (dcbf, dcbc, "dbias")):
+        assert np.array_equal(a.to_numpy(), c_.to_numpy()), what
+    # a subset of the gradients
+    f3b = _out3()
+    lib.lamp_convolution_bn_relu_input_backward(f3b, GY, X, aff, Wt, one, pad, one, 2, 1, _mask3(0, 1, 0))
+    assert [bool(h) for h in f3b] == [False, True, False]
+    assert np.array_equal(S.STen(f3b[1]).to_numpy(), dwf.to_numpy())
+    # and against ATen in f64 on the same rounded operands
+    view = (1, -1, 1, 1)
+    pre = torch.relu(torch.addcmul(b.float().view(view), x.float() - to_torch(smf).float().view(view), (to_torch(sif).float() * g.float()).view(view)).to(dt))
+    ref = aten.convolution(pre.double(), w.double(), cb.double(), [1, 1], [p, p], [1, 1], False, [0, 0], 1)
+    assert_close(to_torch(yf), ref, {torch.float32: 1e-4, torch.bfloat16: 2.0 ** -6}[dt], "conv(relu(bn(x))) vs ATen", scale="max")

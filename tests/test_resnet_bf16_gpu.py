@@ -143,3 +143,40 @@ def test_bf16_epoch_loss_accumulates_in_f64(gpu):
     for v in per:
         acc16 += torch.tensor([v], dtype=torch.bfloat16)
     assert abs(float(acc16[0]) / (B * nb) - expect) > 1e-3 * abs(expect)
+
+
+_STEP_DIGEST = r"""
+import hashlib, sys
+import torch
+from lamp_amd import nn, sten as S
+from oracle import lamp_oracle as O
+from tests.util import to_sten
+B = int(sys.argv[1])
+torch.manual_seed(1234)
+ob = O.resnet(100, torch.bfloat16)
+hm = nn.resnet(100, 0.0, S.BF16)
+hm.load([to_sten(v.value) for v in ob.state()])
+x = O.closed_form(B * 3 * 32 * 32, 5, 1.0, torch.bfloat16).reshape(B, 3, 32, 32)
+model = nn.SupervisedModel(hm, nn.SupervisedModel.NLL, S.STen.ones([100], S.BF16))
+acc = S.STen.zeros([1], S.F64)
+n, grads = model.addTotalLossAndReturnGradientsAndNumExamples(to_sten(x), to_sten((torch.arange(B) * 7) % 100), acc)
+h = hashlib.sha256(acc.to_numpy().tobytes())
+for g in grads: h.update(g.to_numpy().tobytes())
+for s in hm.state: h.update(s.value.to_numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_folding_the_mid_block_batch_norm_into_the_convolution_changes_no_bit(gpu):
+    """Sequential's rewrite BatchNorm2D -> relu -> Dropout(0) -> Conv2D => F::conv_of_batch_norm_relu_2d (nn.cpp) at a batch where the
+    wide blocks fold (B >= 1024): loss, all 37 gradients and every running statistic are BITWISE those of the separate operators
+    (LAMP_FUSE_BN_CONV=0) - the table holds the saved (rounded) statistics and the staging applies bn_affine + relu exactly as bn_apply does."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, LAMP_FUSE_BN_CONV=flag, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, "1024"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[flag] = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert digests["0"] == digests["1"]
