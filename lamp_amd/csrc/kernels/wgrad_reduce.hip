@@ -55,8 +55,12 @@ void launch_batch(const std::vector<Pending>& v) {
     // a reader on another stream of that device must see the result: order it behind the reduction
     hipStream_t cur = current_stream(v[i].device);
     if (cur != v[i].st) {
-      if (allocator_capturing()) {
-        // the caller is recording a graph on `cur`: an event from outside the capture cannot be waited for inside it - wait on the host
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (allocator_capturing()) HIP_CHECK(hipStreamIsCapturing(v[i].st, &cs));
+      if (allocator_capturing() && cs != hipStreamCaptureStatusActive) {
+        // the caller is recording a graph on `cur` and the reduction's stream is outside that capture: an event from outside the capture
+        // cannot be waited for inside it - wait on the host.  (A stream forked INTO the capture - the weight gradients' second stream,
+        // host/ops.cpp - is joined with an event like any other: both ends are nodes of the same graph.)
         HIP_CHECK(hipStreamSynchronize(v[i].st));
       } else {
         hipEvent_t ev;
