@@ -238,6 +238,8 @@ static void sdpa_add_bias(Tensor* scores, const Tensor* bias, int64_t B, int64_t
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
                int64_t k, hipStream_t st, int kind);   // knn_fused.hip
+bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim, int64_t k,
+               hipStream_t st);             // knn_split.hip: large f32 searches through the bf16 matrix pipe, same result
 
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;
@@ -346,7 +348,8 @@ static void knn_impl(lamp_tensor** indices, lamp_tensor** distances, const lamp_
     int64_t os[2] = {Q, k};
     Hold fi(new_tensor(os, 2, kI64, data->device())), fv(new_tensor(os, 2, data->dtype, data->device()));
     Hold dnc(contiguous(dn.get())), qnc(contiguous(qn.get()));
-    if (knn_fused(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st, kind)) {
+    if ((kind == 0 && knn_split(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st)) ||
+        knn_fused(qsrc, dsrc, qnc.get(), dnc.get(), fi.get(), fv.get(), Q, N, pdim, k, st, kind)) {
       *indices = fi.take();
       if (distances) *distances = fv.take();
       return;

@@ -1,0 +1,497 @@
+// k nearest neighbours of f32 points through the bf16 matrix pipe: a filter pass that cannot lose a neighbour + an exact re-rank.
+//
+// Reference: lamp-knn/src/main/scala/lamp/knn/package.scala:60-121 (knnSearch with SquaredEuclideanDistance, f32):
+//   d(q, x) = max(0, (|q|^2 + |x|^2) - 2 q.x), topk(k, largest = false) per query.
+// knn_fused.hip computes q.x on v_mfma_f32_16x16x4_f32: 157 TFLOP/s is all the f32 matrix pipe has, and a 1M x 1M x 128 search is
+// 256 TFLOP.  The bf16 pipe is 16 x wider, and an f32 value splits exactly into bf16 pieces:
+//   x = xh + xm + xr,  xh = bf16(x), xm = bf16(x - xh), |xr| <= 2^-16 |x|.
+// Pass 1 (knn_split_kernel) computes  q.x ~ qh.xh + qh.xm + qm.xh  (three bf16 products per k: 3/16 of the f32 pipe's time) with the
+//   top-k selection of knn_fused.hip fused in, and keeps the 16 best candidates per query by the approximate distance
+//   a = (|q|^2 + |x|^2) - 2 (that sum), the norms exact.  What is dropped (qm.xm, qh.xr, qr.xh: <= 3.1 * 2^-16 |q||x|) and the f32
+//   accumulation of 3 DIM products are bounded by 2^-12 |q||x|, so |a - d| <= eps_q = 2^-11 |q| max|x| + 2^-21 (|q|^2 + max|x|^2).
+// Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the f32 data (dot product accumulated in f64, rounded once, then
+//   the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
+//   a >= a_16, hence d >= a_16 - eps_q: when the k-th re-ranked distance is strictly below that, the k neighbours are exactly those an
+//   exact search returns - proven per query, not assumed.  Queries that fail the test (more than 16 - k points within eps of the k-th
+//   neighbour: near-duplicates, data far from the origin) are collected and run through knn_fused.hip.
+// So the result is that of an exact f32 search; only the time depends on the data (1M x 1M x 128 standard normal: no query fails).
+#include "device_utils.h"
+#include "../core/tensor.h"
+#include <type_traits>
+#include <vector>
+
+namespace lamp {
+
+typedef __bf16 ks_bf8 __attribute__((ext_vector_type(8)));
+typedef float ks_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char ks_lds_t;
+typedef const __attribute__((address_space(1))) char ks_glb_t;
+
+constexpr int KS_BQ = 256;        // queries per workgroup: 4 waves x 64
+constexpr int KS_BC = 64;         // points per tile
+constexpr int KS_M = 16;          // candidates kept per query
+constexpr int KS_RC = 24;           // capacity of a row's candidate buffer: flushed when a row holds more than KS_RC - 16 (a tile can add 16)
+
+template <int OFF, class V> __device__ __forceinline__ void ks_read128(V& d, unsigned a) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
+template <int I, int N, class F> __device__ __forceinline__ void ks_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ks_static_for<I + 1, N>(f); }
+}
+
+__device__ unsigned long long ks_dbg[8];      // diagnostic build (LAMP_KNN_SPLIT_DBG=3): visits, tiles tested, candidates, flushes, cycles in the selection
+
+struct KsWaveState {
+  float lv[64][KS_M];         // the row's 16 best so far, UNSORTED (the re-rank orders its candidates anyway): an insertion replaces the
+  int li[64][KS_M];           // largest entry and finds the new largest - no shifting through LDS
+  float thr[64];              // the largest value of the row's list
+  int mpos[64];               // and where it sits (the highest index among equal values)
+  float qn[64];               // the rows' squared norms (the selection reads norms and thresholds from here: indexing the register
+                              // copies by a runtime tile number would move those arrays to scratch)
+  float bv[64][KS_RC];        // per-row candidate buffers: a visit of the selection appends (LDS atomic counter per row), a flush lets
+  int bi[64][KS_RC];          // every row's lane insert its own entries - all rows at the same time
+  int bn[64];                 // entries in the row's buffer
+};
+
+// rows of [hi(DIM) | mid(DIM)] bf16 from rows of DIM f32
+template <int DIM>
+__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t rows) {
+  const int64_t total = rows * (DIM / 4);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / (DIM / 4);
+    const int c = (int)(e - r * (DIM / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * DIM + c);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], m[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bf16_t hi(f[i]);
+      const float rest = f[i] - (float)hi;          // exact: hi holds the leading 8 bits of f
+      h[i] = hi.bits;
+      m[i] = bf16_t(rest).bits;
+    }
+    bf16_t* o = out + r * (2 * DIM) + c;
+    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(o + DIM) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+  }
+}
+
+// The structure of knn_fused_kernel (one workgroup = its queries' fragments in registers, the data set streamed through two LDS
+// buffers by LDS-DMA, the filter of tile i - 1 in the basic block that multiplies tile i) with
+//   * wave = 64 queries (four 16-row tiles) x 64 points: 16 accumulator tiles, a B fragment read feeds 8 (hi) or 4 (mid) MFMAs;
+//   * a 512-byte LDS row per point = hi | mid, 16-byte chunk c of row r at c ^ (r & 15): chunk step j is one 32-deep k-slab of
+//     v_mfma_f32_16x16x32_bf16 (lane group g = k 8g .. 8g + 7), steps 0 .. NJ/2 - 1 the hi plane, the rest the mid plane;
+//   * KS_M = 16 candidates per row whatever k is (the re-rank needs the margin).
+template <int DIM, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restrict__ qs, const bf16_t* __restrict__ xs, const float* __restrict__ qn,
+                                                           const float* __restrict__ dn, int* __restrict__ out_idx, float* __restrict__ out_val, int Q,
+                                                           int N) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = 4 * DIM;               // bytes of one point in LDS (2 DIM bf16)
+  constexpr int NCHK = ROWB / 16;             // 16-byte chunks per point (>= 16)
+  constexpr int NJ = ROWB / 64;               // chunk steps: 4 lane groups x 16 bytes each
+  constexpr int NH = NJ / 2;                  // steps of one plane
+  constexpr int NCT = KS_BC / 16;
+  constexpr int TILE = KS_BC * ROWB;
+  static_assert(NCHK >= 16, "the swizzle needs at least 16 chunks per row");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int q0 = blockIdx.x * KS_BQ + wid * 64;
+  KsWaveState* ws = reinterpret_cast<KsWaveState*>(smem + 2 * TILE) + wid;
+
+  // ---- query fragments (A operand: lane = row c16 of the tile, k = 8 g .. 8 g + 7 of the slab) and norms
+  ks_bf8 qh[4][NH], qm[4][NH];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    int row = q0 + 16 * t + c16; row = row < Q ? row : Q - 1;
+    const bf16_t* qr = qs + (int64_t)row * (2 * DIM);
+#pragma unroll
+    for (int j = 0; j < NH; j++) {
+      qh[t][j] = *reinterpret_cast<const ks_bf8*>(qr + 32 * j + 8 * g);
+      qm[t][j] = *reinterpret_cast<const ks_bf8*>(qr + DIM + 32 * j + 8 * g);
+    }
+  }
+  // ---- selection state
+  for (int i = 0; i < KS_M; i++) { ws->lv[lane][i] = INFINITY; ws->li[lane][i] = 0x7fffffff - i; }
+  ws->thr[lane] = INFINITY;
+  ws->mpos[lane] = 0;
+  ws->bn[lane] = 0;
+  { int rr = q0 + lane; rr = rr < Q ? rr : Q - 1; ws->qn[lane] = qn[rr]; }
+
+  auto dma_tile = [&](int it, int buf) {
+    const int col0 = it * KS_BC;
+    constexpr int PIECES = TILE / 1024;
+#pragma unroll
+    for (int i = 0; i < PIECES / 4; i++) {
+      const int piece = wid * (PIECES / 4) + i;
+      const int pos = piece * 64 + lane;
+      const int row = pos / NCHK, cs = pos % NCHK;
+      const int c = cs ^ (row & 15);
+      int col = col0 + row; col = col < N ? col : N - 1;
+      __builtin_amdgcn_global_load_lds((ks_glb_t*)(xs + (int64_t)col * (2 * DIM) + c * 8), (ks_lds_t*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
+    }
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  unsigned bbase[NJ];                         // byte address of chunk step j of this lane's point in col tile 0, buffer 0
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { bbase[j] = lds0 + c16 * ROWB + ((((4 * j + g) ^ c16)) << 4); asm volatile("" : "+v"(bbase[j])); }
+
+  const int nit = (N + KS_BC - 1) / KS_BC;
+  float dnc[NCT], dnn[NCT], dno[NCT];         // column norms of the tile being multiplied / the next one / the one being filtered
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) { int col = 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; dno[ct] = 0.f; }
+  ks_f4 old[4][NCT];                          // dot products of the previous tile: filtered while this tile multiplies
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) old[t][ct] = ks_f4{0, 0, 0, 0};
+  int col0_old = N;                           // no valid column: the first pass filters nothing
+
+  // The selection proper.  What it costs is LDS round trips and idle lanes, not arithmetic (measured with in-kernel counters, 1M points:
+  // a wave sees ~3700 visits and ~17000 candidates; inserted one at a time by the lane that owns the row while 63 lanes wait, a
+  // candidate cost ~1500 cycles and the selection as much as all the MFMAs), so it is split:
+  //   visit (a wave whose filter fired; only the accumulator tiles that fired): exact test; a passing (value, index) goes to ITS ROW's
+  //     buffer - slot = LDS atomic increment of the row's counter.  Thresholds stay as they are (a few more candidates pass later);
+  //   flush (some row's buffer could overflow with the next tile, or the end): lane r = row r inserts the entries of its own buffer into
+  //     its list - 64 rows in parallel, the trip count is the fullest row's.  An insertion replaces the list's largest entry and finds the
+  //     new largest (the list is unsorted: the re-rank orders its candidates anyway); entries of one tile reach the buffer in any
+  //     order, so "better" is decided on (value, index).
+  // ONE copy of the visit's code for the sixteen accumulator tiles (a runtime loop; the switch moves a tile's values out of the
+  // register array): unrolled, it was 150 KB of instructions.
+  unsigned long long dbg_visits = 0, dbg_tiles = 0, dbg_cands = 0, dbg_flushes = 0, dbg_cycles = 0, dbg_flush_cycles = 0;
+  auto flush_candidates = [&]() {
+    unsigned long long t0f = 0;
+    if constexpr (DBG == 3) { dbg_flushes++; t0f = __builtin_amdgcn_s_memtime(); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {
+      float* lv = ws->lv[lane];
+      int* li = ws->li[lane];
+      float worst = ws->thr[lane];
+      int wpos = ws->mpos[lane];
+      int wi = li[wpos];
+      const int n = ws->bn[lane];
+      if constexpr (DBG == 3) dbg_cands += n;      // (lane 0's rows only: scaled by 64 in the report)
+      for (int e = 0; e < n; e++) {
+        const float cvv = ws->bv[lane][e];
+        const int cii = ws->bi[lane][e];
+        if (!(cvv < worst || (cvv == worst && cii < wi))) continue;
+        lv[wpos] = cvv; li[wpos] = cii;
+        float4 a4[4]; int4 i4[4];                           // the new worst entry: largest value, of equal values the highest index
+#pragma unroll
+        for (int c = 0; c < 4; c++) { a4[c] = *reinterpret_cast<const float4*>(lv + 4 * c); i4[c] = *reinterpret_cast<const int4*>(li + 4 * c); }
+        float mv = a4[0].x; int mi = i4[0].x, mp = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float vv[4] = {a4[c].x, a4[c].y, a4[c].z, a4[c].w};
+          const int ii[4] = {i4[c].x, i4[c].y, i4[c].z, i4[c].w};
+#pragma unroll
+          for (int w2 = 0; w2 < 4; w2++) {
+            const bool gt = vv[w2] > mv || (vv[w2] == mv && ii[w2] > mi);
+            mv = gt ? vv[w2] : mv; mi = gt ? ii[w2] : mi; mp = gt ? 4 * c + w2 : mp;
+          }
+        }
+        worst = mv; wi = mi; wpos = mp;
+      }
+      if (n) { ws->thr[lane] = worst; ws->mpos[lane] = wpos; ws->bn[lane] = 0; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (DBG == 3) dbg_flush_cycles += __builtin_amdgcn_s_memtime() - t0f;
+  };
+  auto select_tile = [&](const ks_f4 (&a)[4][NCT], const float* dnv, int c0, unsigned tmask) {
+    unsigned long long t0v = 0;
+    if constexpr (DBG == 3) { dbg_visits++; t0v = __builtin_amdgcn_s_memtime(); }
+    bool full = false;                            // some row of this lane's group is within one tile of its buffer's capacity
+    while (tmask) {
+      if constexpr (DBG == 3) dbg_tiles++;
+      const int idx = __builtin_ctz(tmask);
+      tmask &= tmask - 1;
+      const int t = idx >> 2, ct = idx & 3;
+      ks_f4 av; float dn1, q4[4], t4[4];
+      switch (idx) {
+#define KS_CASE(I) case I: av = a[(I) >> 2][(I) & 3]; dn1 = dnv[(I) & 3]; break;
+        KS_CASE(0) KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(7)
+        KS_CASE(8) KS_CASE(9) KS_CASE(10) KS_CASE(11) KS_CASE(12) KS_CASE(13) KS_CASE(14)
+        default: av = a[3][3]; dn1 = dnv[3]; break;
+#undef KS_CASE
+      }
+      {
+        const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g), tt4 = *reinterpret_cast<const float4*>(ws->thr + 16 * t + 4 * g);
+        q4[0] = qq.x; q4[1] = qq.y; q4[2] = qq.z; q4[3] = qq.w;
+        t4[0] = tt4.x; t4[1] = tt4.y; t4[2] = tt4.z; t4[3] = tt4.w;
+      }
+      const int col = c0 + 16 * ct + c16;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float d = (q4[r] + dn1) - 2.f * av[r];
+        const float v = d > 0.f ? d : 0.f;
+        // (<=: an equal value with a lower index than the list's worst entry must reach the flush, which decides on (value, index))
+        if (col < N && v <= t4[r]) {
+          const int row = 16 * t + 4 * g + r;
+          const int slot = atomicAdd(&ws->bn[row], 1);     // ds_add_rtn_u32: the sixteen lanes of a group that hit the same row get distinct slots
+          ws->bv[row][slot] = v; ws->bi[row][slot] = col;
+          full |= slot >= KS_RC - 17;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(full) != 0) { flush_candidates(); full = false; }
+    }
+    if constexpr (DBG == 3) dbg_cycles += __builtin_amdgcn_s_memtime() - t0v;
+  };
+  // The filter "does any distance of the previous tile beat its row's 16th best" as integer arithmetic between the MFMAs of this tile:
+  // for non-negative floats a < b <=> bits(a) < bits(b), and a (slightly) negative distance - which the clamp turns into 0 - has the
+  // sign bit set, so bits(d) - bits(thr) < 0 exactly when max(d, 0) < thr (thr > 0; thr == 0 only sends the wave to the exact test in
+  // select_tile for nothing).  One fma, one subtract, one min per value; the minimum per 16-row tile decides.  Columns beyond N
+  // repeat the last point: they can only cause a needless visit of select_tile, which tests the column.
+  auto filter_piece = [&](auto idxc, const ks_f4& a, float dnv, unsigned& mask) {
+    constexpr int idx = decltype(idxc)::value, t = idx >> 2;
+    // the row group's norms and thresholds come from LDS (two 16-byte reads, the same address for the sixteen lanes of a group): held
+    // in registers next to the 128 registers of query fragments they were spilled to scratch
+    const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g);
+    const int4 th = *reinterpret_cast<const int4*>(ws->thr + 16 * t + 4 * g);
+    int m = (int)__float_as_uint(__builtin_fmaf(-2.f, a[0], qq.x + dnv)) - th.x;
+    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[1], qq.y + dnv)) - th.y);
+    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[2], qq.z + dnv)) - th.z);
+    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[3], qq.w + dnv)) - th.w);
+    mask |= (__builtin_amdgcn_ballot_w64(m <= 0) != 0 ? 1u : 0u) << idx;       // one bit per accumulator tile, kept in a scalar register
+  };
+  dma_tile(0, 0);
+  for (int it = 0; it < nit; it++) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) dnc[ct] = dnn[ct];
+    if (it + 1 < nit) {
+      dma_tile(it + 1, buf ^ 1);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) { int col = (it + 1) * KS_BC + 16 * ct + c16; col = col < N ? col : N - 1; dnn[ct] = dn[col]; }
+    }
+    ks_f4 acc[4][NCT];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) acc[t][ct] = ks_f4{0, 0, 0, 0};
+    const unsigned boff = buf * TILE;
+    ks_bf8 bf[2][NCT];
+    auto b_issue = [&](auto jc, ks_bf8* dst) {
+      constexpr int j = decltype(jc)::value;
+      ks_static_for<0, NCT>([&](auto ctc) { constexpr int ct = decltype(ctc)::value; ks_read128<ct * 16 * ROWB>(dst[ct], bbase[j] + boff); });
+    };
+    auto b_fence = [&](ks_bf8* f, bool last) {
+      if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+    };
+    b_issue(std::integral_constant<int, 0>{}, bf[0]);
+    unsigned fmask = 0;                           // accumulator tiles of the previous tile in which some distance reaches its row's threshold
+    ks_static_for<0, NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + 1 < NJ) { b_issue(std::integral_constant<int, j + 1>{}, bf[(j + 1) & 1]); b_fence(bf[j & 1], false); }
+      else b_fence(bf[j & 1], true);
+      // sixteen independent accumulators between two uses of the same one: a dependent MFMA waits for its predecessor's result
+      if constexpr (j < NH) {               // the data's hi plane: against the queries' hi and mid planes
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[t][j], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qm[t][j], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
+      } else {                              // the data's mid plane: against the queries' hi plane
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[t][j - NH], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
+      }
+      // the filter of 16 / NJ accumulator tiles of the PREVIOUS tile: vector work that issues while the matrix pipe runs
+      constexpr int PER = 16 / NJ;
+      if constexpr (DBG != 2)
+        ks_static_for<0, PER>([&](auto uc) { constexpr int idx = j * PER + decltype(uc)::value; filter_piece(std::integral_constant<int, idx>{}, old[idx >> 2][idx & 3], dno[idx & 3], fmask); });
+    });
+    unsigned tmask = col0_old < N ? fmask : 0u;
+    if (DBG == 1 || DBG == 2) tmask = 0;
+    if (tmask) select_tile(old, dno, col0_old, tmask);
+    col0_old = it * KS_BC;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ct++) dno[ct] = dnc[ct];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ct++) old[t][ct] = acc[t][ct];
+  }
+  select_tile(old, dno, col0_old, 0xffffu);
+  flush_candidates();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if constexpr (DBG == 3) {
+    if (lane == 0) {
+      atomicAdd(&ks_dbg[0], dbg_visits); atomicAdd(&ks_dbg[1], dbg_tiles); atomicAdd(&ks_dbg[2], dbg_cands); atomicAdd(&ks_dbg[3], dbg_flushes);
+      atomicAdd(&ks_dbg[4], dbg_cycles); atomicAdd(&ks_dbg[5], dbg_flush_cycles); atomicAdd(&ks_dbg[6], 1ull);
+    }
+  }
+  if (q0 + lane < Q) {
+    for (int i = 0; i < KS_M; i++) out_idx[(int64_t)(q0 + lane) * KS_M + i] = ws->li[lane][i];
+    out_val[q0 + lane] = ws->thr[lane];         // a_16: no point outside the list has a smaller approximate distance
+  }
+}
+
+// One wave per query: the exact distances of its KS_M candidates (f32 data, the dot product summed in f64 and rounded once, then
+// the reference's (|q|^2 + |x|^2) - 2 q.x in f32 with the clamp), ranked by (distance, index).  The first k go to the result; the
+// query is appended to `failed` unless the k-th distance is strictly below every distance a non-candidate can have.
+template <int DIM>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ q, const float* __restrict__ x, const float* __restrict__ qn,
+                                                         const float* __restrict__ dn, const float* __restrict__ dn_max, const int* __restrict__ cand_idx,
+                                                         const float* __restrict__ cand_val, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                         int* __restrict__ failed, int* __restrict__ nfailed, int Q, int N, int k) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= Q) return;
+  const int c = lane >> 2, part = lane & 3;             // candidate, quarter of the features
+  const int ci = cand_idx[(int64_t)qi * KS_M + c];
+  const bool valid = ci >= 0 && ci < N;                   // fewer than KS_M points: the padding entries
+  const float* qr = q + (int64_t)qi * DIM + part * (DIM / 4);
+  const float* xr = x + (int64_t)(valid ? ci : 0) * DIM + part * (DIM / 4);
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < DIM / 4; i += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(qr + i), b = *reinterpret_cast<const float4*>(xr + i);
+    s += (double)a.x * (double)b.x; s += (double)a.y * (double)b.y; s += (double)a.z * (double)b.z; s += (double)a.w * (double)b.w;
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  const float qnv = qn[qi];
+  float d = (qnv + dn[valid ? ci : 0]) - 2.f * (float)s;
+  d = d > 0.f ? d : 0.f;
+  if (!valid) d = INFINITY;
+  // rank among the KS_M candidates by (d, index): every lane of a candidate computes the same rank
+  int rank = 0;
+#pragma unroll
+  for (int o = 0; o < KS_M; o++) {
+    const float od = __shfl(d, o * 4);
+    const int oi = __shfl(ci, o * 4);
+    rank += (od < d || (od == d && oi < ci)) ? 1 : 0;
+  }
+  if (part == 0 && rank < k) {
+    out_idx[(int64_t)qi * k + rank] = ci;
+    out_val[(int64_t)qi * k + rank] = d;
+  }
+  // the proof: a point outside the candidate list has an approximate distance >= a_last, and |approximate - exact| <= eps
+  const float a_last = cand_val[qi];
+  const float mx = dn_max[0];
+  const float eps = 0x1p-11f * sqrtf(qnv) * sqrtf(mx) + 0x1p-21f * (qnv + mx);
+  const bool all_points_are_candidates = N <= KS_M;
+  if (part == 0 && rank == k - 1 && !all_points_are_candidates && !(d < a_last - eps)) {
+    const int slot = atomicAdd(nfailed, 1);
+    failed[slot] = qi;
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst, int64_t n,
+                                                              int64_t width) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * width; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / width, c = e - r * width;
+    dst[e] = src[(int64_t)rows[r] * width + c];
+  }
+}
+__global__ __launch_bounds__(256) void knn_scatter_results_kernel(const int64_t* __restrict__ si, const float* __restrict__ sv, const int* __restrict__ rows,
+                                                                  int64_t* __restrict__ di, float* __restrict__ dv, int64_t n, int64_t k) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * k; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / k, c = e - r * k;
+    di[(int64_t)rows[r] * k + c] = si[e];
+    dv[(int64_t)rows[r] * k + c] = sv[e];
+  }
+}
+
+bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
+               int64_t k, hipStream_t st, int kind);   // knn_fused.hip
+Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
+
+namespace {
+int g_knn_split_mode = 1;      // 0 never, 1 where it pays (large searches), 2 whenever the shape is covered (tests)
+int64_t g_knn_split_failed = 0;
+}
+void knn_split_set_mode(int mode) { g_knn_split_mode = mode; }
+int64_t knn_split_last_failed() { return g_knn_split_failed; }
+
+template <int DIM>
+static void knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
+                          hipStream_t st) {
+  const int dev = x->device();
+  Hold xs(new_tensor({N, (int64_t)2 * DIM}, kBF16, dev)), qs(new_tensor({Q, (int64_t)2 * DIM}, kBF16, dev));
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM>), dim3(grid_for(N * (DIM / 4), 256)), dim3(256), 0, st, x->ptr<float>(), xs->ptr<bf16_t>(), N);
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM>), dim3(grid_for(Q * (DIM / 4), 256)), dim3(256), 0, st, q->ptr<float>(), qs->ptr<bf16_t>(), Q);
+  LAMP_LAUNCH_CHECK();
+  Hold ci(new_tensor({Q, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Q}, kF32, dev));        // candidates (unsorted) and a_16 per query
+  {
+    KernelTimer kt("knn_split_bf16", 2.0 * (double)Q * N * DIM, ((double)Q + N) * DIM * 4, st);   // the algorithmic work of the search, as knn_fused declares it
+    allow_big_lds((const void*)knn_split_kernel<DIM>);
+    const size_t lds = (size_t)2 * KS_BC * 4 * DIM + 4 * sizeof(KsWaveState);
+    const char* dbg = getenv("LAMP_KNN_SPLIT_DBG");
+    const int dm = dbg ? atoi(dbg) : 0;
+#define KS_LAUNCH(DB) do { allow_big_lds((const void*)knn_split_kernel<DIM, DB>); hipLaunchKernelGGL((knn_split_kernel<DIM, DB>), dim3((unsigned)((Q + KS_BQ - 1) / KS_BQ)), dim3(256), lds, st, qs->ptr<bf16_t>(), xs->ptr<bf16_t>(), qn->ptr<float>(), dn->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), (int)Q, (int)N); } while (0)
+    if (dm == 1) KS_LAUNCH(1); else if (dm == 2) KS_LAUNCH(2); else if (dm == 3) KS_LAUNCH(3); else KS_LAUNCH(0);
+    if (dm == 3) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      unsigned long long h[8] = {};
+      HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ks_dbg), sizeof(h)));
+      fprintf(stderr, "knn_split dbg: waves %llu  visits/wave %.0f  tiles tested/wave %.0f  candidates/wave %.0f  flushes/wave %.1f  selection cycles/wave %.3e (flush part %.3e)\n",
+              h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] * 64 / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+      unsigned long long z[8] = {};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ks_dbg), z, sizeof(z)));
+    }
+#undef KS_LAUNCH
+    LAMP_LAUNCH_CHECK();
+  }
+  Hold mx(reduce_dims(dn, nullptr, 0, false, 3));
+  Hold failed(new_tensor({Q + 1}, kI32, dev));                   // [0] = count, then the queries
+  HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
+  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, q->ptr<float>(), x->ptr<float>(), qn->ptr<float>(), dn->ptr<float>(),
+                     mx->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), idx->ptr<int64_t>(), val->ptr<float>(), failed->ptr<int>() + 1, failed->ptr<int>(), (int)Q,
+                     (int)N, (int)k);
+  LAMP_LAUNCH_CHECK();
+  int nfail = 0;
+  HIP_CHECK(hipMemcpyAsync(&nfail, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  g_knn_split_failed = nfail;
+  if (nfail == 0) return;
+  // the queries whose neighbourhood the filter could not prove: the exact kernel on exactly those
+  Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, kF32, dev)), fqn(new_tensor({(int64_t)nfail}, kF32, dev));
+  const int* rows = failed->ptr<int>() + 1;
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>(), rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
+  LAMP_LAUNCH_CHECK();
+  Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, kF32, dev));
+  LAMP_CHECK(knn_fused(fq.get(), x, fqn.get(), dn, fi.get(), fv.get(), nfail, N, DIM, k, st, 0), "internal: the exact kNN kernel refused the fallback queries");
+  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows, idx->ptr<int64_t>(),
+                     val->ptr<float>(), (int64_t)nfail, k);
+  LAMP_LAUNCH_CHECK();
+}
+
+// f32 squared-Euclidean search of 64 / 128 features, k <= 12 (16 candidates leave a margin of at least 4).  false: not covered / not worth it.
+bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim, int64_t k,
+               hipStream_t st) {
+  static const int env_mode = [] { const char* e = getenv("LAMP_KNN_SPLIT"); return e ? atoi(e) : -1; }();
+  const int mode = env_mode >= 0 ? env_mode : g_knn_split_mode;
+  if (mode == 0 || q->dtype != kF32 || !(dim == 64 || dim == 128) || k < 1 || k > 12 || N > 0x7fffff00 || Q > 0x7fffff00 || N < k || Q < 1) return false;
+  if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
+  // the two extra passes (planes, re-rank) and the host round trip for the verdict cost ~0.3 ms: below ~2^32 distance evaluations the exact kernel is as fast
+  if (mode == 1 && ((double)Q * (double)N < 4.0e9 || N < 16384)) return false;
+  if (dim == 128) knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st);
+  else knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st);
+  return true;
+}
+
+}  // namespace lamp
+
+extern "C" {
+/* 0: never use the split-bf16 filter, 1: where it pays (default), 2: whenever the shape is covered.  LAMP_KNN_SPLIT overrides. */
+int lamp_knn_split_mode(int mode) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(mode >= 0 && mode <= 2, "knn split mode must be 0, 1 or 2");
+  lamp::knn_split_set_mode(mode);
+  LAMP_API_END
+}
+/* queries of the last split search on this process that the filter could not prove and the exact kernel re-ran */
+int lamp_knn_split_last_failed(int64_t* out) {
+  LAMP_API_BEGIN
+  *out = lamp::knn_split_last_failed();
+  LAMP_API_END
+}
+}

@@ -581,3 +581,69 @@ def test_umap_mnist_meets_the_reference_acceptance(gpu):
     nn = np.argsort(d2l, 1)[:, :10]
     purity = (labels[nn] == labels[:, None]).mean()
     assert purity > 0.6, f"neighbour purity {purity}"                  # measured 0.74
+
+
+# ---- large f32 searches through the bf16 matrix pipe (kernels/knn_split.hip, round 3) ---------------------------------------------------
+def _knn(data, query, k):
+    i, d = C.c_void_p(), C.c_void_p()
+    lib.lamp_knn_squared_euclidean(C.byref(i), C.byref(d), to_sten(data), to_sten(query), k)
+    return S.STen(i).to_numpy(), S.STen(d).to_numpy()
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(20000, 1500, 128, 10), (5000, 700, 64, 12), (16, 40, 128, 3), (3001, 257, 128, 1), (70, 300, 64, 10)])
+def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
+    """knn_split.hip forced on small problems (mode 2): centred data, where the filter proves (nearly) every query, against the exact
+    fused kernel (mode 0) and the oracle.  Index sets equal on every row whose k-th / (k+1)-th neighbours are separated by more than the
+    f32 formula's own noise; distances within that noise; rows sorted by distance."""
+    g = torch.Generator().manual_seed(4242 + n)
+    data64 = torch.randn(n, d, generator=g, dtype=torch.float64)
+    rows = _well_separated_queries(data64, torch.arange(0, n, max(n // nq, 1))[:nq], min(k, n - 1), 1e-3) if n > k else torch.arange(min(nq, n))
+    data, query = data64.float(), data64[rows].float()
+    try:
+        lib.lamp_knn_split_mode(0)
+        ei, ed = _knn(data, query, k)
+        lib.lamp_knn_split_mode(2)
+        lib.lamp_kernel_timer_enable(1)
+        si, sd = _knn(data, query, k)
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        lib.lamp_kernel_timer_enable(0)
+        failed = C.c_int64(-1)
+        lib.lamp_knn_split_last_failed(C.byref(failed))
+    finally:
+        lib.lamp_knn_split_mode(1)
+    assert b"knn_split_bf16" in buf.value, "the split kernel did not run"
+    assert si.dtype == np.int64 and si.shape == (len(rows), k)
+    assert np.array_equal(np.sort(si, 1), np.sort(ei, 1)), "same neighbour sets as the exact kernel"
+    ref = O.knn_minibatched(data, query, k, 100)
+    assert np.array_equal(np.sort(si, 1), np.sort(ref.numpy(), 1)), "and as the reference algorithm"
+    assert (np.diff(sd, axis=1) >= 0).all()
+    exact = torch.gather(O.squared_euclidean_distance(data64[rows], data64), 1, torch.from_numpy(si))
+    assert (torch.from_numpy(sd).double() - exact).abs().max().item() <= 2e-4     # |q|^2 ~ d: a few ulp of 2 d
+    assert 0 <= failed.value <= max(2, len(rows) // 50), f"{failed.value} of {len(rows)} queries needed the exact kernel on centred data"
+
+
+def test_knn_split_filter_falls_back_where_it_cannot_prove(gpu):
+    """Data far from the origin (|x|^2 ~ 3e3, clusters 0.25 apart): the filter's error bound covers dozens of points around the k-th
+    neighbour, the proof fails and those queries go through the exact kernel - the results are then BITWISE the exact kernel's.  Ties
+    (duplicated points) resolve by the lower index on either path."""
+    g = torch.Generator().manual_seed(99)
+    n, d, k = 6000, 128, 10
+    data64 = torch.rand(n, d, generator=g, dtype=torch.float64) + (torch.arange(n) % 16).double().reshape(n, 1) * 0.25
+    data64[100:110] = data64[90:100]                                  # exact duplicates
+    data, query = data64.float(), data64[:900].float()
+    try:
+        lib.lamp_knn_split_mode(0)
+        ei, ed = _knn(data, query, k)
+        lib.lamp_knn_split_mode(2)
+        si, sd = _knn(data, query, k)
+        failed = C.c_int64(-1)
+        lib.lamp_knn_split_last_failed(C.byref(failed))
+    finally:
+        lib.lamp_knn_split_mode(1)
+    assert failed.value > 100, "this data is meant to defeat the filter"
+    # every query is either proven (distances recomputed from the f32 data: last-bit differences) or re-run by the exact kernel (bitwise)
+    bitwise = (si == ei).all(1) & (sd == ed).all(1)
+    assert bitwise.sum() >= failed.value
+    assert np.abs(sd.astype(np.float64) - ed).max() <= 5e-3          # the f32 formula's own noise at |q|^2 ~ 3e3
+    assert np.array_equal(si[90:100, 0], np.arange(90, 100)) and np.array_equal(si[100:110, 0], np.arange(90, 100)), "a duplicate's first neighbour is the lower index"
