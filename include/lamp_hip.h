@@ -641,6 +641,7 @@ int lamp_knn_jaccard(lamp_tensor** indices, lamp_tensor** distances_or_null, con
  * exact search (kernels/knn_split.hip).  mode 0: never, 1: where it pays (default), 2: whenever the shape is covered. */
 int lamp_knn_split_mode(int mode);
 int lamp_knn_split_last_failed(int64_t* out);   /* queries of the last split search that needed the exact kernel */
+int lamp_knn_split_last_planes(int* out);       /* bf16 planes per value it used: 2 or 3 (0: the split path did not run) */
 int lamp_knn_row_distances(lamp_tensor** out, const lamp_tensor* data, const lamp_tensor* indices);
 /* Umap.edgeWeights (umap.scala:50-113, JVM double loops in the reference): per point the smallest positive kNN
  * distance rho and the bisection for sigma (Umap.binarySearch, umap.scala:14-48), then for every neighbour j != i

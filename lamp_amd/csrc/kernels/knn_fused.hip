@@ -60,7 +60,7 @@ template <class T> struct KfWaveState {
 template <class T, int DIM, int KIND>   // KIND 0: squared Euclidean (qn, dn = squared norms), 1: Jaccard (qn, dn = row sums)
 __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__ q, const T* __restrict__ x, const T* __restrict__ qn,
                                                            const T* __restrict__ dn, int64_t* __restrict__ out_idx, T* __restrict__ out_val,
-                                                           int Q, int N, int k) {
+                                                           int Q, int N, int k, int chunk_len) {
   using TR = KfTraits<T>;
   using chunk_t = typename TR::chunk_t;
   using acc_t = typename TR::acc_t;
@@ -75,6 +75,15 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int q0 = blockIdx.x * KF_BQ + wid * 32;
+  // few queries against many points (chunk_len > 0): blockIdx.y takes a slice of the data set, every (query block, slice) its own
+  // result rows [slice][Q][k] with global indices; knn_merge_chunks_kernel picks the k best of a query's slices
+  int idx_base = 0;
+  if (chunk_len > 0) {
+    idx_base = blockIdx.y * chunk_len;
+    x += (int64_t)idx_base * DIM; dn += idx_base;
+    out_idx += (int64_t)blockIdx.y * Q * k; out_val += (int64_t)blockIdx.y * Q * k;
+    N = min(chunk_len, N - idx_base);
+  }
   KfWaveState<T>* ws = reinterpret_cast<KfWaveState<T>*>(smem + 2 * TILE) + wid;
 
   // ---- query fragments and norms
@@ -257,9 +266,31 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < 32 && q0 + lane < Q) {
     for (int i = 0; i < k; i++) {
-      out_idx[(int64_t)(q0 + lane) * k + i] = ws->li[lane][i];
+      out_idx[(int64_t)(q0 + lane) * k + i] = ws->li[lane][i] == 0x7fffffff ? (int64_t)0x7fffffff : (int64_t)ws->li[lane][i] + idx_base;
       out_val[(int64_t)(q0 + lane) * k + i] = ws->lv[lane][i];
     }
+  }
+}
+
+// the k best (value, then lower index) of a query's `chunks` sorted lists: one thread per query (few queries: that is why there are chunks)
+template <class T>
+__global__ __launch_bounds__(256) void knn_merge_chunks_kernel(const int64_t* __restrict__ ci, const T* __restrict__ cv, int64_t* __restrict__ out_idx,
+                                                               T* __restrict__ out_val, int Q, int k, int chunks) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= Q) return;
+  int head[64];                                 // next unread entry of every chunk's list (chunks <= 64)
+  for (int c = 0; c < chunks; c++) head[c] = 0;
+  for (int o = 0; o < k; o++) {
+    int best = -1; T bv = (T)INFINITY; int64_t bi = 0x7fffffff;
+    for (int c = 0; c < chunks; c++) {
+      if (head[c] >= k) continue;
+      const int64_t e = ((int64_t)c * Q + qi) * k + head[c];
+      const T v = cv[e]; const int64_t i = ci[e];
+      if (best < 0 || v < bv || (v == bv && i < bi)) { best = c; bv = v; bi = i; }
+    }
+    head[best]++;
+    out_idx[(int64_t)qi * k + o] = bi;
+    out_val[(int64_t)qi * k + o] = bv;
   }
 }
 
@@ -269,10 +300,25 @@ static void knn_fused_launch(const Tensor* q, const Tensor* x, const Tensor* qn,
                              hipStream_t st) {
   static bool attr = false;
   allow_big_lds((const void*)knn_fused_kernel<T, D, KIND>);
-  const dim3 grid((unsigned)((Q + KF_BQ - 1) / KF_BQ));
+  const int64_t wgs = (Q + KF_BQ - 1) / KF_BQ;
   const size_t lds = (size_t)2 * KfTraits<T>::BC * D * sizeof(T) + 4 * sizeof(KfWaveState<T>);
-  hipLaunchKernelGGL((knn_fused_kernel<T, D, KIND>), grid, dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(), idx->ptr<int64_t>(), val->ptr<T>(),
-                     (int)Q, (int)N, (int)k);
+  // A workgroup streams the whole data set: with fewer workgroups than CUs the search takes as long as a full round whatever Q is
+  // (442 queries against 1M points: 77 ms).  Then the data set is cut into slices over blockIdx.y and the per-slice lists are merged.
+  const int64_t cus = num_cus();
+  int64_t chunks = 1;
+  if (wgs * 2 <= cus && N >= 32768) chunks = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, cus / wgs), N / 8192));
+  if (chunks > 1 && k <= N / chunks) {
+    const int64_t chunk_len = (N + chunks - 1) / chunks;
+    chunks = (N + chunk_len - 1) / chunk_len;
+    Hold ti(new_tensor({chunks, Q, k}, kI64, x->device())), tv(new_tensor({chunks, Q, k}, q->dtype, x->device()));
+    hipLaunchKernelGGL((knn_fused_kernel<T, D, KIND>), dim3((unsigned)wgs, (unsigned)chunks), dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(),
+                       ti->ptr<int64_t>(), tv->ptr<T>(), (int)Q, (int)N, (int)k, (int)chunk_len);
+    hipLaunchKernelGGL((knn_merge_chunks_kernel<T>), dim3(grid_for(Q, 256)), dim3(256), 0, st, ti->ptr<int64_t>(), tv->ptr<T>(), idx->ptr<int64_t>(), val->ptr<T>(), (int)Q,
+                       (int)k, (int)chunks);
+    return;
+  }
+  hipLaunchKernelGGL((knn_fused_kernel<T, D, KIND>), dim3((unsigned)wgs), dim3(256), lds, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(), idx->ptr<int64_t>(),
+                     val->ptr<T>(), (int)Q, (int)N, (int)k, 0);
 }
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,

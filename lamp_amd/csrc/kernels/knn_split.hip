@@ -4,17 +4,24 @@
 //   d(q, x) = max(0, (|q|^2 + |x|^2) - 2 q.x), topk(k, largest = false) per query.
 // knn_fused.hip computes q.x on v_mfma_f32_16x16x4_f32: 157 TFLOP/s is all the f32 matrix pipe has, and a 1M x 1M x 128 search is
 // 256 TFLOP.  The bf16 pipe is 16 x wider, and an f32 value splits exactly into bf16 pieces:
-//   x = xh + xm + xr,  xh = bf16(x), xm = bf16(x - xh), |xr| <= 2^-16 |x|.
-// Pass 1 (knn_split_kernel) computes  q.x ~ qh.xh + qh.xm + qm.xh  (three bf16 products per k: 3/16 of the f32 pipe's time) with the
-//   top-k selection of knn_fused.hip fused in, and keeps the 16 best candidates per query by the approximate distance
-//   a = (|q|^2 + |x|^2) - 2 (that sum), the norms exact.  What is dropped (qm.xm, qh.xr, qr.xh: <= 3.1 * 2^-16 |q||x|) and the f32
-//   accumulation of 3 DIM products are bounded by 2^-12 |q||x|, so |a - d| <= eps_q = 2^-11 |q| max|x| + 2^-21 (|q|^2 + max|x|^2).
-// Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the f32 data (dot product accumulated in f64, rounded once, then
-//   the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
+//   x = x0 + x1 + x2 + r,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1):  |x - x0 - x1| <= 2^-18 |x|,  |r| <= 2^-27 |x|.
+// Pass 0 (knn_split_planes_kernel): distances do not change when every point moves by the same vector, but the error of a split product
+//   scales with |q| |x| - so the data set's mean is subtracted first, then each row is written as PL bf16 planes with its squared norm.
+// Pass 1 (knn_split_kernel) computes the dot products of the centred rows from the plane products whose weight is above the last plane's,
+//     PL = 2:  q0.x0 + q1.x0 + q0.x1                      (3 bf16 products per feature: 3/16 of the f32 pipe's time)
+//     PL = 3:  q0.x0 + q1.x0 + q2.x0 + q0.x1 + q1.x1 + q0.x2  (6)
+//   with the top-k selection fused in, and keeps the 16 best candidates per query by a = (|q|^2 + |x|^2) - 2 (that sum).
+//   Error of the sum: the dropped products (PL = 2: q1.x1, q0.r, r.x0 <= 3.1 * 2^-18 |q||x|; PL = 3: 3.1 * 2^-27) plus the f32
+//   accumulation of 4 PL (PL + 1) / 2 MFMA results (each a 32-term sum: <= 6 roundings each, 2^-24 relative to sum |q_i x_i|):
+//   bounded by c_PL |q||x| with c_2 = 2^-15, c_3 = 2^-18 (twice the analytic figure; the largest error seen on the test sets is 3 - 6 x
+//   below).  So |a - d| <= eps_q = 2 c_PL |q| max|x| + 2^-21 (|q|^2 + max|x|^2) (the second term: the rounding of the f32 formula itself).
+// Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the ORIGINAL f32 data (dot product accumulated in f64, rounded once,
+//   then the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
 //   a >= a_16, hence d >= a_16 - eps_q: when the k-th re-ranked distance is strictly below that, the k neighbours are exactly those an
-//   exact search returns - proven per query, not assumed.  Queries that fail the test (more than 16 - k points within eps of the k-th
-//   neighbour: near-duplicates, data far from the origin) are collected and run through knn_fused.hip.
-// So the result is that of an exact f32 search; only the time depends on the data (1M x 1M x 128 standard normal: no query fails).
+//   exact search returns.  Queries that fail the test (more than 16 - k points within eps of the k-th neighbour: near-duplicates, very
+//   dense neighbourhoods) are collected and run through knn_fused.hip.
+// Which PL: two planes where they can decide the data (a sample of the queries is searched first; PL = 2 stays if fewer than 5 % of them
+// fail), three planes otherwise.  The result is that of an exact f32 search; only the time depends on the data.
 #include "device_utils.h"
 #include "../core/tensor.h"
 #include <type_traits>
@@ -28,7 +35,6 @@ typedef __attribute__((address_space(3))) char ks_lds_t;
 typedef const __attribute__((address_space(1))) char ks_glb_t;
 
 constexpr int KS_BQ = 256;        // queries per workgroup: 4 waves x 64
-constexpr int KS_BC = 64;         // points per tile
 constexpr int KS_M = 16;          // candidates kept per query
 constexpr int KS_RC = 24;           // capacity of a row's candidate buffer: flushed when a row holds more than KS_RC - 16 (a tile can add 16)
 
@@ -51,45 +57,52 @@ struct KsWaveState {
   int bn[64];                 // entries in the row's buffer
 };
 
-// rows of [hi(DIM) | mid(DIM)] bf16 from rows of DIM f32
-template <int DIM>
-__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t rows) {
-  const int64_t total = rows * (DIM / 4);
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = e / (DIM / 4);
-    const int c = (int)(e - r * (DIM / 4)) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + r * DIM + c);
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    unsigned short h[4], m[4];
+// rows of PL bf16 planes [x0(DIM) | x1(DIM) | ..] of (row - mean), and the squared norm of (row - mean) in f32: one wave per row
+template <int DIM, int PL>
+__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, bf16_t* __restrict__ out,
+                                                               float* __restrict__ norm, int64_t rows) {
+  constexpr int PER = DIM / 64;                       // features per lane (1 or 2)
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const bf16_t hi(f[i]);
-      const float rest = f[i] - (float)hi;          // exact: hi holds the leading 8 bits of f
-      h[i] = hi.bits;
-      m[i] = bf16_t(rest).bits;
+  for (int e = 0; e < PER; e++) {
+    const int c = lane * PER + e;
+    float rest = x[r * DIM + c] - mean[c];
+    s = __builtin_fmaf(rest, rest, s);
+#pragma unroll
+    for (int pl = 0; pl < PL; pl++) {
+      const bf16_t piece(rest);
+      rest -= (float)piece;                           // exact: the piece holds the leading 8 bits of what was left
+      out[r * (PL * DIM) + pl * DIM + c] = piece;
     }
-    bf16_t* o = out + r * (2 * DIM) + c;
-    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    *reinterpret_cast<uint2*>(o + DIM) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) norm[r] = s;
 }
 
 // The structure of knn_fused_kernel (one workgroup = its queries' fragments in registers, the data set streamed through two LDS
 // buffers by LDS-DMA, the filter of tile i - 1 in the basic block that multiplies tile i) with
-//   * wave = 64 queries (four 16-row tiles) x 64 points: 16 accumulator tiles, a B fragment read feeds 8 (hi) or 4 (mid) MFMAs;
-//   * a 512-byte LDS row per point = hi | mid, 16-byte chunk c of row r at c ^ (r & 15): chunk step j is one 32-deep k-slab of
-//     v_mfma_f32_16x16x32_bf16 (lane group g = k 8g .. 8g + 7), steps 0 .. NJ/2 - 1 the hi plane, the rest the mid plane;
+//   * wave = 64 queries (four 16-row tiles) x BC points (64 with two planes, 32 with three: the LDS budget), a B fragment read feeds
+//     4 MFMAs per query plane it meets;
+//   * an LDS row per point = its PL planes, 16-byte chunk c of row r at c ^ (r & 15): chunk step j is one 32-deep k-slab of
+//     v_mfma_f32_16x16x32_bf16 (lane group g = k 8g .. 8g + 7), steps [p NH, (p + 1) NH) are plane p, multiplied by the query planes
+//     0 .. PL - 1 - p;
 //   * KS_M = 16 candidates per row whatever k is (the re-rank needs the margin).
-template <int DIM, int DBG = 0>
+template <int DIM, int PL, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restrict__ qs, const bf16_t* __restrict__ xs, const float* __restrict__ qn,
                                                            const float* __restrict__ dn, int* __restrict__ out_idx, float* __restrict__ out_val, int Q,
                                                            int N) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWB = 4 * DIM;               // bytes of one point in LDS (2 DIM bf16)
+  constexpr int KS_BC = PL == 2 ? 64 : 32;    // points per tile
+  constexpr int ROWB = 2 * PL * DIM;          // bytes of one point in LDS (PL DIM bf16)
   constexpr int NCHK = ROWB / 16;             // 16-byte chunks per point (>= 16)
   constexpr int NJ = ROWB / 64;               // chunk steps: 4 lane groups x 16 bytes each
-  constexpr int NH = NJ / 2;                  // steps of one plane
+  constexpr int NH = NJ / PL;                 // steps of one plane
   constexpr int NCT = KS_BC / 16;
+  constexpr int NACC = 4 * NCT;               // accumulator tiles of a wave
   constexpr int TILE = KS_BC * ROWB;
   static_assert(NCHK >= 16, "the swizzle needs at least 16 chunks per row");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,16 +112,15 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
   KsWaveState* ws = reinterpret_cast<KsWaveState*>(smem + 2 * TILE) + wid;
 
   // ---- query fragments (A operand: lane = row c16 of the tile, k = 8 g .. 8 g + 7 of the slab) and norms
-  ks_bf8 qh[4][NH], qm[4][NH];
+  ks_bf8 qf[PL][4][NH];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     int row = q0 + 16 * t + c16; row = row < Q ? row : Q - 1;
-    const bf16_t* qr = qs + (int64_t)row * (2 * DIM);
+    const bf16_t* qr = qs + (int64_t)row * (PL * DIM);
 #pragma unroll
-    for (int j = 0; j < NH; j++) {
-      qh[t][j] = *reinterpret_cast<const ks_bf8*>(qr + 32 * j + 8 * g);
-      qm[t][j] = *reinterpret_cast<const ks_bf8*>(qr + DIM + 32 * j + 8 * g);
-    }
+    for (int pl = 0; pl < PL; pl++)
+#pragma unroll
+      for (int j = 0; j < NH; j++) qf[pl][t][j] = *reinterpret_cast<const ks_bf8*>(qr + pl * DIM + 32 * j + 8 * g);
   }
   // ---- selection state
   for (int i = 0; i < KS_M; i++) { ws->lv[lane][i] = INFINITY; ws->li[lane][i] = 0x7fffffff - i; }
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       const int row = pos / NCHK, cs = pos % NCHK;
       const int c = cs ^ (row & 15);
       int col = col0 + row; col = col < N ? col : N - 1;
-      __builtin_amdgcn_global_load_lds((ks_glb_t*)(xs + (int64_t)col * (2 * DIM) + c * 8), (ks_lds_t*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((ks_glb_t*)(xs + (int64_t)col * (PL * DIM) + c * 8), (ks_lds_t*)(smem + buf * TILE + piece * 1024), 16, 0, 0);
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -204,13 +216,13 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       if constexpr (DBG == 3) dbg_tiles++;
       const int idx = __builtin_ctz(tmask);
       tmask &= tmask - 1;
-      const int t = idx >> 2, ct = idx & 3;
-      ks_f4 av; float dn1, q4[4], t4[4];
+      const int t = idx / NCT, ct = idx % NCT;
+      ks_f4 av = ks_f4{0, 0, 0, 0}; float dn1 = 0.f, q4[4], t4[4];
       switch (idx) {
-#define KS_CASE(I) case I: av = a[(I) >> 2][(I) & 3]; dn1 = dnv[(I) & 3]; break;
+#define KS_CASE(I) case I: if constexpr ((I) < NACC) { av = a[(I) / NCT][(I) % NCT]; dn1 = dnv[(I) % NCT]; } break;
         KS_CASE(0) KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(7)
-        KS_CASE(8) KS_CASE(9) KS_CASE(10) KS_CASE(11) KS_CASE(12) KS_CASE(13) KS_CASE(14)
-        default: av = a[3][3]; dn1 = dnv[3]; break;
+        KS_CASE(8) KS_CASE(9) KS_CASE(10) KS_CASE(11) KS_CASE(12) KS_CASE(13) KS_CASE(14) KS_CASE(15)
+        default: break;
 #undef KS_CASE
       }
       {
@@ -235,21 +247,20 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
     }
     if constexpr (DBG == 3) dbg_cycles += __builtin_amdgcn_s_memtime() - t0v;
   };
-  // The filter "does any distance of the previous tile beat its row's 16th best" as integer arithmetic between the MFMAs of this tile:
-  // for non-negative floats a < b <=> bits(a) < bits(b), and a (slightly) negative distance - which the clamp turns into 0 - has the
-  // sign bit set, so bits(d) - bits(thr) < 0 exactly when max(d, 0) < thr (thr > 0; thr == 0 only sends the wave to the exact test in
-  // select_tile for nothing).  One fma, one subtract, one min per value; the minimum per 16-row tile decides.  Columns beyond N
-  // repeat the last point: they can only cause a needless visit of select_tile, which tests the column.
+  // The filter "does any distance of the previous tile reach its row's 16th best" as integer arithmetic between the MFMAs of this tile:
+  // for non-negative floats a <= b <=> bits(a) <= bits(b).  One fma, one max, one subtract, one min per value; one bit per accumulator
+  // tile decides.  Columns beyond N repeat the last point: they can only cause a needless visit of select_tile, which tests the column.
   auto filter_piece = [&](auto idxc, const ks_f4& a, float dnv, unsigned& mask) {
-    constexpr int idx = decltype(idxc)::value, t = idx >> 2;
+    constexpr int idx = decltype(idxc)::value, t = idx / NCT;
     // the row group's norms and thresholds come from LDS (two 16-byte reads, the same address for the sixteen lanes of a group): held
     // in registers next to the 128 registers of query fragments they were spilled to scratch
     const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g);
     const int4 th = *reinterpret_cast<const int4*>(ws->thr + 16 * t + 4 * g);
-    int m = (int)__float_as_uint(__builtin_fmaf(-2.f, a[0], qq.x + dnv)) - th.x;
-    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[1], qq.y + dnv)) - th.y);
-    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[2], qq.z + dnv)) - th.z);
-    m = min(m, (int)__float_as_uint(__builtin_fmaf(-2.f, a[3], qq.w + dnv)) - th.w);
+    // (the clamp is part of the test: the bit pattern of a negative distance minus a threshold's would wrap around)
+    int m = (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[0], qq.x + dnv), 0.f)) - th.x;
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[1], qq.y + dnv), 0.f)) - th.y);
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[2], qq.z + dnv), 0.f)) - th.z);
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[3], qq.w + dnv), 0.f)) - th.w);
     mask |= (__builtin_amdgcn_ballot_w64(m <= 0) != 0 ? 1u : 0u) << idx;       // one bit per accumulator tile, kept in a scalar register
   };
   dma_tile(0, 0);
@@ -276,8 +287,13 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       ks_static_for<0, NCT>([&](auto ctc) { constexpr int ct = decltype(ctc)::value; ks_read128<ct * 16 * ROWB>(dst[ct], bbase[j] + boff); });
     };
     auto b_fence = [&](ks_bf8* f, bool last) {
-      if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
-      else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+      if constexpr (NCT == 4) {
+        if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+      } else {
+        if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]) : : "memory");
+      }
     };
     b_issue(std::integral_constant<int, 0>{}, bf[0]);
     unsigned fmask = 0;                           // accumulator tiles of the previous tile in which some distance reaches its row's threshold
@@ -285,26 +301,23 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       constexpr int j = decltype(jc)::value;
       if constexpr (j + 1 < NJ) { b_issue(std::integral_constant<int, j + 1>{}, bf[(j + 1) & 1]); b_fence(bf[j & 1], false); }
       else b_fence(bf[j & 1], true);
-      // sixteen independent accumulators between two uses of the same one: a dependent MFMA waits for its predecessor's result
-      if constexpr (j < NH) {               // the data's hi plane: against the queries' hi and mid planes
+      // data plane p = j / NH against the query planes 0 .. PL - 1 - p; NACC independent accumulators between two uses of the same one
+      // (a dependent MFMA waits for its predecessor's result)
+      constexpr int p = j / NH, jj = j % NH;
+      ks_static_for<0, PL - p>([&](auto qc) {
+        constexpr int qp = decltype(qc)::value;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++)
 #pragma unroll
-          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[t][j], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++)
-#pragma unroll
-          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qm[t][j], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
-      } else {                              // the data's mid plane: against the queries' hi plane
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++)
-#pragma unroll
-          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[t][j - NH], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
-      }
-      // the filter of 16 / NJ accumulator tiles of the PREVIOUS tile: vector work that issues while the matrix pipe runs
-      constexpr int PER = 16 / NJ;
+          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qp][t][jj], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
+      });
+      // the filter of the PREVIOUS tile's accumulator tiles, spread over the steps: vector work that issues while the matrix pipe runs
+      constexpr int PER = (NACC + NJ - 1) / NJ;
       if constexpr (DBG != 2)
-        ks_static_for<0, PER>([&](auto uc) { constexpr int idx = j * PER + decltype(uc)::value; filter_piece(std::integral_constant<int, idx>{}, old[idx >> 2][idx & 3], dno[idx & 3], fmask); });
+        ks_static_for<0, PER>([&](auto uc) {
+          constexpr int idx = j * PER + decltype(uc)::value;
+          if constexpr (idx < NACC) filter_piece(std::integral_constant<int, idx>{}, old[idx / NCT][idx % NCT], dno[idx % NCT], fmask);
+        });
     });
     unsigned tmask = col0_old < N ? fmask : 0u;
     if (DBG == 1 || DBG == 2) tmask = 0;
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
 #pragma unroll
       for (int ct = 0; ct < NCT; ct++) old[t][ct] = acc[t][ct];
   }
-  select_tile(old, dno, col0_old, 0xffffu);
+  select_tile(old, dno, col0_old, (1u << NACC) - 1u);
   flush_candidates();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if constexpr (DBG == 3) {
@@ -337,7 +350,8 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
 // query is appended to `failed` unless the k-th distance is strictly below every distance a non-candidate can have.
 template <int DIM>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ q, const float* __restrict__ x, const float* __restrict__ qn,
-                                                         const float* __restrict__ dn, const float* __restrict__ dn_max, const int* __restrict__ cand_idx,
+                                                         const float* __restrict__ dn, const float* __restrict__ qn_c, const float* __restrict__ dn_c_max,
+                                                         const float* __restrict__ dn_max, float c_dot, const int* __restrict__ cand_idx,
                                                          const float* __restrict__ cand_val, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
                                                          int* __restrict__ failed, int* __restrict__ nfailed, int Q, int N, int k) {
   const int lane = threadIdx.x & 63;
@@ -373,9 +387,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
     out_val[(int64_t)qi * k + rank] = d;
   }
   // the proof: a point outside the candidate list has an approximate distance >= a_last, and |approximate - exact| <= eps
+  // (the filter worked on the centred rows: its error scales with their norms; the formula's own rounding with the original ones)
   const float a_last = cand_val[qi];
-  const float mx = dn_max[0];
-  const float eps = 0x1p-11f * sqrtf(qnv) * sqrtf(mx) + 0x1p-21f * (qnv + mx);
+  const float eps = 2.f * c_dot * sqrtf(qn_c[qi]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qnv + dn_max[0]);
   const bool all_points_are_candidates = N <= KS_M;
   if (part == 0 && rank == k - 1 && !all_points_are_candidates && !(d < a_last - eps)) {
     const int slot = atomicAdd(nfailed, 1);
@@ -399,6 +413,19 @@ __global__ __launch_bounds__(256) void knn_scatter_results_kernel(const int64_t*
   }
 }
 
+__global__ void knn_strided_ids_kernel(int* __restrict__ ids, int64_t n, int64_t stride) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = (int)(i * stride);
+}
+// would two planes prove this query?  d16 - dk of an EXACT search against the two-plane error bound (both ends of the gap move by at most eps)
+__global__ void knn_predict_two_planes_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c,
+                                              const float* __restrict__ dn_c_max, const float* __restrict__ dn_max, int* __restrict__ nfail, int S, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const float eps = 2.f * 0x1p-15f * sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qn[i] + dn_max[0]);
+  if (!(val16[(int64_t)i * KS_M + KS_M - 1] - val16[(int64_t)i * KS_M + k - 1] > 2.f * eps)) atomicAdd(nfail, 1);
+}
+
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
                int64_t k, hipStream_t st, int kind);   // knn_fused.hip
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
@@ -406,62 +433,138 @@ Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdi
 namespace {
 int g_knn_split_mode = 1;      // 0 never, 1 where it pays (large searches), 2 whenever the shape is covered (tests)
 int64_t g_knn_split_failed = 0;
+int g_knn_split_planes = 0;    // planes of the last search (0: the split path did not run)
 }
 void knn_split_set_mode(int mode) { g_knn_split_mode = mode; }
 int64_t knn_split_last_failed() { return g_knn_split_failed; }
+int knn_split_last_planes() { return g_knn_split_planes; }
+
+namespace {
+// the rows of `src` as PL centred planes + centred norms
+template <int DIM, int PL>
+void make_planes(const Tensor* src, const Tensor* mean, Tensor* planes, Tensor* norm, int64_t rows, hipStream_t st) {
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>(), mean->ptr<float>(), planes->ptr<bf16_t>(),
+                     norm->ptr<float>(), rows);
+  LAMP_LAUNCH_CHECK();
+}
+struct SplitData {             // the data set for the filter: PL planes of the centred rows, their squared norms and the largest of those
+  Hold planes, norm, norm_max;
+};
+// filter + re-rank of queries [q_lo, q_hi) with PL planes; returns the number of queries without proof, their ids in failed[1 ..]
+template <int DIM, int PL>
+int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, const Tensor* dn_max, const Tensor* mean, SplitData& sd, Tensor* idx, Tensor* val,
+               Tensor* failed, int64_t q_lo, int64_t q_hi, int64_t N, int64_t k, hipStream_t st) {
+  const int dev = x->device();
+  const int64_t Qn = q_hi - q_lo;
+  if (!sd.planes.get()) {
+    sd.planes = Hold(new_tensor({N, (int64_t)PL * DIM}, kBF16, dev));
+    sd.norm = Hold(new_tensor({N}, kF32, dev));
+    make_planes<DIM, PL>(x, mean, sd.planes.get(), sd.norm.get(), N, st);
+    sd.norm_max = Hold(reduce_dims(sd.norm.get(), nullptr, 0, false, 3));
+  }
+  Hold qs(new_tensor({Qn, (int64_t)PL * DIM}, kBF16, dev)), qnc(new_tensor({Qn}, kF32, dev));
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((Qn + 3) / 4)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, mean->ptr<float>(), qs->ptr<bf16_t>(),
+                     qnc->ptr<float>(), Qn);
+  LAMP_LAUNCH_CHECK();
+  Hold ci(new_tensor({Qn, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Qn}, kF32, dev));        // candidates (unsorted) and a_16 per query
+  {
+    // declared: the algorithmic work of the search, as knn_fused declares it (the bf16 pipe executes PL (PL + 1) / 2 times the products)
+    KernelTimer kt(PL == 2 ? "knn_split_bf16x3" : "knn_split_bf16x6", 2.0 * (double)Qn * N * DIM, ((double)Qn + N) * DIM * 4, st);
+    constexpr int BC = PL == 2 ? 64 : 32;
+    const size_t lds = (size_t)2 * BC * 2 * PL * DIM + 4 * sizeof(KsWaveState);
+    const char* dbg = getenv("LAMP_KNN_SPLIT_DBG");
+    const int dm = dbg ? atoi(dbg) : 0;
+#define KS_LAUNCH(DB) do { allow_big_lds((const void*)knn_split_kernel<DIM, PL, DB>); hipLaunchKernelGGL((knn_split_kernel<DIM, PL, DB>), dim3((unsigned)((Qn + KS_BQ - 1) / KS_BQ)), dim3(256), lds, st, qs->ptr<bf16_t>(), sd.planes->ptr<bf16_t>(), qnc->ptr<float>(), sd.norm->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), (int)Qn, (int)N); } while (0)
+    if (dm == 3) KS_LAUNCH(3); else KS_LAUNCH(0);
+#undef KS_LAUNCH
+    LAMP_LAUNCH_CHECK();
+    if (dm == 3) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      unsigned long long h[8] = {};
+      HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ks_dbg), sizeof(h)));
+      fprintf(stderr, "knn_split dbg (%d planes): waves %llu  visits/wave %.0f  tiles tested/wave %.0f  candidates/wave %.0f  flushes/wave %.1f  selection cycles/wave %.3e (flush part %.3e)\n",
+              PL, h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] * 64 / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+      unsigned long long z[8] = {};
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ks_dbg), z, sizeof(z)));
+    }
+  }
+  HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
+  const float c_dot = PL == 2 ? 0x1p-15f : 0x1p-18f;
+  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Qn + 3) / 4)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, x->ptr<float>(), qn->ptr<float>() + q_lo,
+                     dn->ptr<float>(), qnc->ptr<float>(), sd.norm_max->ptr<float>(), dn_max->ptr<float>(), c_dot, ci->ptr<int>(), cv->ptr<float>(),
+                     idx->ptr<int64_t>() + q_lo * k, val->ptr<float>() + q_lo * k, failed->ptr<int>() + 1, failed->ptr<int>(), (int)Qn, (int)N, (int)k);
+  LAMP_LAUNCH_CHECK();
+  int nfail = 0;
+  HIP_CHECK(hipMemcpyAsync(&nfail, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return nfail;
+}
+// the queries [q_lo, q_lo + ..) listed in failed[1 .. nfail] (ids relative to q_lo) through the exact kernel
+template <int DIM>
+void exact_for_failed(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, const Tensor* failed, int nfail, int64_t q_lo,
+                      int64_t N, int64_t k, hipStream_t st) {
+  const int dev = x->device();
+  Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, kF32, dev)), fqn(new_tensor({(int64_t)nfail}, kF32, dev));
+  const int* rows = failed->ptr<int>() + 1;
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>() + q_lo, rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
+  LAMP_LAUNCH_CHECK();
+  Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, kF32, dev));
+  LAMP_CHECK(knn_fused(fq.get(), x, fqn.get(), dn, fi.get(), fv.get(), nfail, N, DIM, k, st, 0), "internal: the exact kNN kernel refused the fallback queries");
+  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows,
+                     idx->ptr<int64_t>() + q_lo * k, val->ptr<float>() + q_lo * k, (int64_t)nfail, k);
+  LAMP_LAUNCH_CHECK();
+}
+}  // namespace
 
 template <int DIM>
 static void knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
                           hipStream_t st) {
   const int dev = x->device();
-  Hold xs(new_tensor({N, (int64_t)2 * DIM}, kBF16, dev)), qs(new_tensor({Q, (int64_t)2 * DIM}, kBF16, dev));
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM>), dim3(grid_for(N * (DIM / 4), 256)), dim3(256), 0, st, x->ptr<float>(), xs->ptr<bf16_t>(), N);
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM>), dim3(grid_for(Q * (DIM / 4), 256)), dim3(256), 0, st, q->ptr<float>(), qs->ptr<bf16_t>(), Q);
-  LAMP_LAUNCH_CHECK();
-  Hold ci(new_tensor({Q, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Q}, kF32, dev));        // candidates (unsorted) and a_16 per query
-  {
-    KernelTimer kt("knn_split_bf16", 2.0 * (double)Q * N * DIM, ((double)Q + N) * DIM * 4, st);   // the algorithmic work of the search, as knn_fused declares it
-    allow_big_lds((const void*)knn_split_kernel<DIM>);
-    const size_t lds = (size_t)2 * KS_BC * 4 * DIM + 4 * sizeof(KsWaveState);
-    const char* dbg = getenv("LAMP_KNN_SPLIT_DBG");
-    const int dm = dbg ? atoi(dbg) : 0;
-#define KS_LAUNCH(DB) do { allow_big_lds((const void*)knn_split_kernel<DIM, DB>); hipLaunchKernelGGL((knn_split_kernel<DIM, DB>), dim3((unsigned)((Q + KS_BQ - 1) / KS_BQ)), dim3(256), lds, st, qs->ptr<bf16_t>(), xs->ptr<bf16_t>(), qn->ptr<float>(), dn->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), (int)Q, (int)N); } while (0)
-    if (dm == 1) KS_LAUNCH(1); else if (dm == 2) KS_LAUNCH(2); else if (dm == 3) KS_LAUNCH(3); else KS_LAUNCH(0);
-    if (dm == 3) {
-      HIP_CHECK(hipStreamSynchronize(st));
-      unsigned long long h[8] = {};
-      HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ks_dbg), sizeof(h)));
-      fprintf(stderr, "knn_split dbg: waves %llu  visits/wave %.0f  tiles tested/wave %.0f  candidates/wave %.0f  flushes/wave %.1f  selection cycles/wave %.3e (flush part %.3e)\n",
-              h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] * 64 / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
-      unsigned long long z[8] = {};
-      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(ks_dbg), z, sizeof(z)));
-    }
-#undef KS_LAUNCH
+  const int64_t zero = 0;
+  Hold mean(reduce_dims(x, &zero, 1, false, 1));                  // the data set's mean row: the filter works on (row - mean)
+  Hold dn_max(reduce_dims(dn, nullptr, 0, false, 3));
+  Hold failed(new_tensor({Q + 1}, kI32, dev));                    // [0] = count, then the queries
+  static const int env_planes = [] { const char* e = getenv("LAMP_KNN_SPLIT_PLANES"); return e ? atoi(e) : 0; }();
+  int planes = env_planes == 2 || env_planes == 3 ? env_planes : 0;
+  SplitData sd;
+  if (!planes) {
+    // Two planes or three?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices over
+    // the CUs: ~3 ms at 1M points) gives their d_k and d_16; two planes prove a query when that gap exceeds twice their error bound.
+    // Fewer than 5 % of the sample unproven: two planes (half the matrix work); otherwise three.
+    const int64_t S = std::min<int64_t>(Q, 1024), stride = Q / S;
+    Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, kF32, dev)), sqn(new_tensor({S}, kF32, dev));
+    hipLaunchKernelGGL(knn_strided_ids_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, ids->ptr<int>(), S, stride);
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), ids->ptr<int>(), sq->ptr<float>(), S, (int64_t)DIM);
+    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<float>(), ids->ptr<int>(), sqn->ptr<float>(), S, (int64_t)1);
     LAMP_LAUNCH_CHECK();
+    const int64_t ks = std::min<int64_t>(KS_M, N);
+    Hold si(new_tensor({S, ks}, kI64, dev)), sv(new_tensor({S, ks}, kF32, dev));
+    planes = 3;
+    if (ks == KS_M && knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, ks, st, 0)) {
+      // centred norms of the sample and of the data (the planes themselves are built once the count is known)
+      Hold scr(new_tensor({S, (int64_t)2 * DIM}, kBF16, dev)), sqc(new_tensor({S}, kF32, dev));
+      make_planes<DIM, 2>(sq.get(), mean.get(), scr.get(), sqc.get(), S, st);
+      sd.planes = Hold(new_tensor({N, (int64_t)2 * DIM}, kBF16, dev));
+      sd.norm = Hold(new_tensor({N}, kF32, dev));
+      make_planes<DIM, 2>(x, mean.get(), sd.planes.get(), sd.norm.get(), N, st);
+      sd.norm_max = Hold(reduce_dims(sd.norm.get(), nullptr, 0, false, 3));
+      HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
+      hipLaunchKernelGGL(knn_predict_two_planes_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(),
+                         sd.norm_max->ptr<float>(), dn_max->ptr<float>(), failed->ptr<int>(), (int)S, (int)k);
+      LAMP_LAUNCH_CHECK();
+      int unproven = 0;
+      HIP_CHECK(hipMemcpyAsync(&unproven, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if ((int64_t)unproven * 20 <= S) planes = 2;
+      else sd = SplitData();                                      // (the two-plane image of the data is of no use to three planes)
+    }
   }
-  Hold mx(reduce_dims(dn, nullptr, 0, false, 3));
-  Hold failed(new_tensor({Q + 1}, kI32, dev));                   // [0] = count, then the queries
-  HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
-  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, q->ptr<float>(), x->ptr<float>(), qn->ptr<float>(), dn->ptr<float>(),
-                     mx->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), idx->ptr<int64_t>(), val->ptr<float>(), failed->ptr<int>() + 1, failed->ptr<int>(), (int)Q,
-                     (int)N, (int)k);
-  LAMP_LAUNCH_CHECK();
-  int nfail = 0;
-  HIP_CHECK(hipMemcpyAsync(&nfail, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  g_knn_split_failed = nfail;
-  if (nfail == 0) return;
-  // the queries whose neighbourhood the filter could not prove: the exact kernel on exactly those
-  Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, kF32, dev)), fqn(new_tensor({(int64_t)nfail}, kF32, dev));
-  const int* rows = failed->ptr<int>() + 1;
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>(), rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
-  LAMP_LAUNCH_CHECK();
-  Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, kF32, dev));
-  LAMP_CHECK(knn_fused(fq.get(), x, fqn.get(), dn, fi.get(), fv.get(), nfail, N, DIM, k, st, 0), "internal: the exact kNN kernel refused the fallback queries");
-  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows, idx->ptr<int64_t>(),
-                     val->ptr<float>(), (int64_t)nfail, k);
-  LAMP_LAUNCH_CHECK();
+  const int nf = planes == 2 ? split_pass<DIM, 2>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st)
+                             : split_pass<DIM, 3>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st);
+  if (nf) exact_for_failed<DIM>(q, x, qn, dn, idx, val, failed.get(), nf, 0, N, k, st);
+  g_knn_split_failed = nf;
+  g_knn_split_planes = planes;
 }
 
 // f32 squared-Euclidean search of 64 / 128 features, k <= 12 (16 candidates leave a margin of at least 4).  false: not covered / not worth it.
@@ -469,9 +572,10 @@ bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
                hipStream_t st) {
   static const int env_mode = [] { const char* e = getenv("LAMP_KNN_SPLIT"); return e ? atoi(e) : -1; }();
   const int mode = env_mode >= 0 ? env_mode : g_knn_split_mode;
+  g_knn_split_planes = 0;
   if (mode == 0 || q->dtype != kF32 || !(dim == 64 || dim == 128) || k < 1 || k > 12 || N > 0x7fffff00 || Q > 0x7fffff00 || N < k || Q < 1) return false;
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
-  // the two extra passes (planes, re-rank) and the host round trip for the verdict cost ~0.3 ms: below ~2^32 distance evaluations the exact kernel is as fast
+  // the extra passes (mean, planes, sample, re-rank) and the host round trips for the verdicts cost ~0.5 ms: below ~4e9 distance evaluations the exact kernel is as fast
   if (mode == 1 && ((double)Q * (double)N < 4.0e9 || N < 16384)) return false;
   if (dim == 128) knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st);
   else knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st);
@@ -492,6 +596,12 @@ int lamp_knn_split_mode(int mode) {
 int lamp_knn_split_last_failed(int64_t* out) {
   LAMP_API_BEGIN
   *out = lamp::knn_split_last_failed();
+  LAMP_API_END
+}
+/* bf16 planes per value the last search used: 2 or 3; 0 = the split path did not run */
+int lamp_knn_split_last_planes(int* out) {
+  LAMP_API_BEGIN
+  *out = lamp::knn_split_last_planes();
   LAMP_API_END
 }
 }

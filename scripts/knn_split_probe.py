@@ -3,9 +3,10 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from lamp_amd._capi import lib; lib.load()
 from lamp_amd import sten as S
-n = int(sys.argv[1]); nq = int(sys.argv[2])
+n = int(sys.argv[1]); nq = int(sys.argv[2]); kind = sys.argv[3] if len(sys.argv) > 3 else "normal"
 g = torch.Generator().manual_seed(1)
-data = torch.randn(n, 128, generator=g)
+if kind == "normal": data = torch.randn(n, 128, generator=g)
+else: data = torch.rand(n, 128, generator=g) + (torch.arange(n) % 16).float().reshape(n, 1)      # bench.py's kNN points: 16 clusters, far from the origin
 D = S.STen.from_numpy(data.numpy(), 0, S.F32)
 Qt = D if nq == n else S.STen.from_numpy(data[:nq].numpy().copy(), 0, S.F32)
 def run(mode):
@@ -21,5 +22,6 @@ def run(mode):
 t0, i0, d0 = run(0)
 t2, i2, d2 = run(2)
 f = C.c_int64(); lib.lamp_knn_split_last_failed(C.byref(f))
+pl = C.c_int(); lib.lamp_knn_split_last_planes(C.byref(pl))
 same = (np.sort(i0, 1) == np.sort(i2, 1)).all(1)
-print(f"n {n} nq {nq}: exact {t0:.3f} s  split {t2:.3f} s  failed {f.value}  rows with the same set {same.mean():.6f}  max |dd| {np.abs(d0 - d2).max():.3e}")
+print(f"{kind} planes {pl.value}  n {n} nq {nq}: exact {t0:.3f} s  split {t2:.3f} s  failed {f.value}  rows with the same set {same.mean():.6f}  max |dd| {np.abs(d0 - d2).max():.3e}")

@@ -608,11 +608,13 @@ def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
         buf = C.create_string_buffer(1 << 16)
         lib.lamp_kernel_timer_report(buf, len(buf))
         lib.lamp_kernel_timer_enable(0)
-        failed = C.c_int64(-1)
+        failed, planes = C.c_int64(-1), C.c_int(-1)
         lib.lamp_knn_split_last_failed(C.byref(failed))
+        lib.lamp_knn_split_last_planes(C.byref(planes))
     finally:
         lib.lamp_knn_split_mode(1)
     assert b"knn_split_bf16" in buf.value, "the split kernel did not run"
+    assert planes.value == 2, "centred standard-normal data is decided by two planes"
     assert si.dtype == np.int64 and si.shape == (len(rows), k)
     assert np.array_equal(np.sort(si, 1), np.sort(ei, 1)), "same neighbour sets as the exact kernel"
     ref = O.knn_minibatched(data, query, k, 100)
@@ -623,27 +625,53 @@ def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
     assert 0 <= failed.value <= max(2, len(rows) // 50), f"{failed.value} of {len(rows)} queries needed the exact kernel on centred data"
 
 
-def test_knn_split_filter_falls_back_where_it_cannot_prove(gpu):
-    """Data far from the origin (|x|^2 ~ 3e3, clusters 0.25 apart): the filter's error bound covers dozens of points around the k-th
-    neighbour, the proof fails and those queries go through the exact kernel - the results are then BITWISE the exact kernel's.  Ties
-    (duplicated points) resolve by the lower index on either path."""
+def test_knn_split_filter_takes_three_planes_far_from_the_origin_and_falls_back_on_duplicates(gpu):
+    """bench.py's kNN points in small (uniform jitter + 16 clusters one unit apart in every coordinate: |x|^2 up to 3e4, where the f32
+    formula itself is only good to ~5e-3): the sample search says two planes cannot decide this data, the search runs with three planes on
+    the centred rows.  Rows with a well separated neighbourhood get the exact kernel's set; queries whose neighbours have exact
+    duplicates cannot be proven and go through the exact kernel (ties -> lower index on either path)."""
     g = torch.Generator().manual_seed(99)
-    n, d, k = 6000, 128, 10
-    data64 = torch.rand(n, d, generator=g, dtype=torch.float64) + (torch.arange(n) % 16).double().reshape(n, 1) * 0.25
-    data64[100:110] = data64[90:100]                                  # exact duplicates
-    data, query = data64.float(), data64[:900].float()
+    n, d, k = 20000, 128, 10
+    data64 = torch.rand(n, d, generator=g, dtype=torch.float64) + (torch.arange(n) % 16).double().reshape(n, 1)
+    data64[160:176] = data64[144:160]                                 # exact duplicates (same cluster: i % 16 is kept)
+    data64[300:320] = data64[300]                                     # twenty copies of one point: its 10th and 16th neighbours tie
+    data, query = data64.float(), data64[:1200].float()
     try:
         lib.lamp_knn_split_mode(0)
         ei, ed = _knn(data, query, k)
         lib.lamp_knn_split_mode(2)
         si, sd = _knn(data, query, k)
-        failed = C.c_int64(-1)
+        failed, planes = C.c_int64(-1), C.c_int(-1)
         lib.lamp_knn_split_last_failed(C.byref(failed))
+        lib.lamp_knn_split_last_planes(C.byref(planes))
     finally:
         lib.lamp_knn_split_mode(1)
-    assert failed.value > 100, "this data is meant to defeat the filter"
-    # every query is either proven (distances recomputed from the f32 data: last-bit differences) or re-run by the exact kernel (bitwise)
-    bitwise = (si == ei).all(1) & (sd == ed).all(1)
-    assert bitwise.sum() >= failed.value
-    assert np.abs(sd.astype(np.float64) - ed).max() <= 5e-3          # the f32 formula's own noise at |q|^2 ~ 3e3
-    assert np.array_equal(si[90:100, 0], np.arange(90, 100)) and np.array_equal(si[100:110, 0], np.arange(90, 100)), "a duplicate's first neighbour is the lower index"
+    assert planes.value == 3, "two planes must not be trusted with this data"
+    assert 20 <= failed.value <= 600, f"{failed.value} of 1200 queries needed the exact kernel"     # the twenty copies at least
+    sep = _well_separated_queries(data64, torch.arange(1200), k, 5e-2).numpy()
+    assert len(sep) > 300
+    assert np.array_equal(np.sort(si[sep], 1), np.sort(ei[sep], 1)), "same neighbour sets as the exact kernel where the data decides them"
+    assert np.abs(sd.astype(np.float64) - ed).max() <= 5e-2          # the f32 formula's own noise at |q|^2 ~ 3e4
+    assert np.array_equal(si[144:160, 0], np.arange(144, 160)) and np.array_equal(si[160:176, 0], np.arange(144, 160)), "a duplicate's first neighbour is the lower index"
+    assert np.array_equal(si[144:176, 1], np.r_[np.arange(160, 176), np.arange(160, 176)]), "then its copy"
+    assert np.array_equal(si[300:320], ei[300:320]) and np.array_equal(sd[300:320], ed[300:320]), "unprovable queries come from the exact kernel, bitwise"
+    assert np.array_equal(si[300:320], np.tile(np.arange(300, 310), (20, 1))), "ten of twenty equal points: the ten lowest indices"
+
+
+def test_knn_few_queries_slice_the_data_set(gpu):
+    """A handful of queries against many points: the exact kernel cuts the data set into slices over blockIdx.y (a workgroup per query block
+    would stream all of it alone) and merges the per-slice lists - same indices and values as the unsliced search of the same rows."""
+    g = torch.Generator().manual_seed(7)
+    n, d, k = 70000, 128, 16
+    data = torch.randn(n, d, generator=g)
+    data[500] = data[40]; data[69999] = data[40]                      # ties across slices
+    lib.lamp_knn_split_mode(0)
+    try:
+        qs = torch.cat([data[:300], data[69990:]])
+        few_i, few_d = _knn(data, qs, k)                              # 310 queries: 3 workgroups -> sliced
+        pad = torch.cat([qs, data[1000:1000 + 40000]])                # the same rows inside a search large enough not to be sliced
+        all_i, all_d = _knn(data, pad, k)
+    finally:
+        lib.lamp_knn_split_mode(1)
+    assert np.array_equal(few_i, all_i[:310]) and np.array_equal(few_d, all_d[:310])
+    assert few_i[40, 0] == 40 and few_i[40, 1] == 500 and few_i[40, 2] == 69999, "equal distances: ascending index, across slices too"
