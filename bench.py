@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--umap-points", default="mixed", choices=["mixed", "weyl"], help="umap-e2e: closed form of the points (see the workload's comment)")
     ap.add_argument("--no-graph", action="store_true", help="resnet: issue the step eagerly instead of replaying forward + backprop from a HIP graph")
     ap.add_argument("--dry-launch", action="store_true", help="launch + rendezvous of the N ranks only (no GPU work): prints {\"dry_launch\": true, \"ranks\": N}")
     ap.add_argument("--min-window-s", type=float, default=0.5, help="repeat the K-step timed window until this much time is covered; the median window is reported")
@@ -147,6 +148,13 @@ def roofline_of(rows):
     ai = flops / max(byts, 1.0)
     if flops > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
         peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_BF16_TFLOPS
+        if d["tag"].startswith("knn_split_bf16x"):
+            # the f32 search on the bf16 pipe (kernels/knn_split.hip): every f32 product is 3 (two planes) or 6 (three planes) bf16 products.
+            # The launcher declares the ALGORITHMIC work of the search; the roofline is priced on what the bf16 pipe executes.
+            terms = int(d["tag"][-1])
+            extra["bf16_products_per_f32_product"] = terms
+            flops = flops * terms
+            extra["executed_flops"] = flops
         ach = flops / avg_s / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **extra}
     ach = byts / avg_s / 1e9
@@ -373,7 +381,7 @@ def main():
             return S.STen(i)
         units_per_step = nq
         metric, unit = "kNN queries/sec (1M x 128 f32 points, k = 10)", "queries/s"
-        config = {"workload": "lamp.knn.knnSearch squared Euclidean, 131072 queries x 1M points x 128 features, k = 10 (top-k fused into the f32 MFMA GEMM)",
+        config = {"workload": "lamp.knn.knnSearch squared Euclidean, 131072 queries x 1M points x 128 features, k = 10 (split-bf16 filter with the top-k fused in, exact f32 re-rank with a per-query proof, exact f32 MFMA kernel for the unproven queries)",
                   "parallelism": "query rows sharded" if a.gpus > 1 else "single"}
         a.dtype = "f32"
     elif a.workload == "attention":
@@ -397,9 +405,21 @@ def main():
         # exact f64 neighbour distances -> edge weights -> 500 layout iterations (f64, 5 negatives per edge, AdamW); a step = the whole run
         from lamp_amd import umap as U
         n, d_, kk, iters = 1_000_000, 128, 10, 500
+        # closed-form pseudo-random points in [0, 1) + 16 clusters, "ties avoided by construction".  The survey's example,
+        # frac((i d + j) 2654435761 / 2^32), is a rank-1 lattice (point i + 1 is point i shifted by one constant modulo 1 in every
+        # coordinate): thousands of EXACTLY tied neighbour distances per query, i.e. no well defined neighbour sets.  The same index goes
+        # through murmur3's 32-bit finaliser instead (--umap-points weyl: the lattice, as measured in rounds 1 - 2).
         idx_ = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(d_) + np.arange(d_, dtype=np.uint64)[None, :]
-        pts = ((idx_ * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / 2.0 ** 32 + (np.arange(n) % 16)[:, None]   # closed form + 16 clusters
-        del idx_
+        if a.umap_points == "weyl":
+            h_ = (idx_ * np.uint64(2654435761)) % np.uint64(2 ** 32)
+        else:
+            m32 = np.uint64(0xffffffff)
+            h_ = idx_ & m32
+            h_ ^= h_ >> np.uint64(16); h_ = (h_ * np.uint64(0x85ebca6b)) & m32
+            h_ ^= h_ >> np.uint64(13); h_ = (h_ * np.uint64(0xc2b2ae35)) & m32
+            h_ ^= h_ >> np.uint64(16)
+        pts = h_.astype(np.float64) / 2.0 ** 32 + (np.arange(n) % 16)[:, None]
+        del idx_, h_
         X32 = S.STen.from_numpy(pts.astype(np.float32), local_rank, S.F32)
         X64 = S.STen.from_numpy(pts, local_rank, S.F64)
         del pts
@@ -424,7 +444,7 @@ def main():
         step = lambda: run()
         units_per_step = n
         metric, unit = "UMAP end-to-end points/sec (1M x 128: kNN graph + edge weights + 500-iteration layout)", "points/s"
-        config = {"workload": "lamp.umap.Umap.umap on 1M x 128 synthetic points already resident in HBM: knnSearch (f32, k = 10) -> f64 neighbour distances -> "
+        config = {"workload": "lamp.umap.Umap.umap on 1M x 128 synthetic points (closed form: murmur3-finalised index + 16 clusters) already resident in HBM: knnSearch (f32, k = 10) -> f64 neighbour distances -> "
                               "edgeWeights -> optimize (500 iterations, 5 negatives per edge, f64, AdamW clip 1)", "parallelism": "replicas"}
         a.dtype = "f32 kNN / f64 layout"
     elif a.workload == "umap":
@@ -583,7 +603,7 @@ def main():
         result_extra["edges"] = int(n_edges)
         result_extra["final_loss"] = float(last_loss)
         lay_rows = [r for r in class_rows if r["tag"] == "umap_pairs2"]
-        knn_rows = [r for r in class_rows if r["tag"].startswith("knn_fused")]
+        knn_rows = [r for r in class_rows if r["tag"].startswith("knn_fused") or r["tag"].startswith("knn_split")]
         if lay_rows:
             result_extra["roofline_layout"] = roofline_of(lay_rows)
         if knn_rows:

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __re
     for (int pl = 0; pl < PL; pl++) {
       const bf16_t piece(rest);
       rest -= (float)piece;                           // exact: the piece holds the leading 8 bits of what was left
-      out[r * (PL * DIM) + pl * DIM + c] = piece;
+      if (out) out[r * (PL * DIM) + pl * DIM + c] = piece;
     }
   }
 #pragma unroll
@@ -417,13 +417,15 @@ __global__ void knn_strided_ids_kernel(int* __restrict__ ids, int64_t n, int64_t
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) ids[i] = (int)(i * stride);
 }
-// would two planes prove this query?  d16 - dk of an EXACT search against the two-plane error bound (both ends of the gap move by at most eps)
-__global__ void knn_predict_two_planes_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c,
-                                              const float* __restrict__ dn_c_max, const float* __restrict__ dn_max, int* __restrict__ nfail, int S, int k) {
+// would two / three planes prove this query?  d16 - dk of an EXACT search against the error bounds (both ends of the gap move by at most eps)
+__global__ void knn_predict_planes_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c,
+                                          const float* __restrict__ dn_c_max, const float* __restrict__ dn_max, int* __restrict__ unproven /* [2] */, int S, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
-  const float eps = 2.f * 0x1p-15f * sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qn[i] + dn_max[0]);
-  if (!(val16[(int64_t)i * KS_M + KS_M - 1] - val16[(int64_t)i * KS_M + k - 1] > 2.f * eps)) atomicAdd(nfail, 1);
+  const float scale = sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]), noise = 0x1p-21f * (qn[i] + dn_max[0]);
+  const float gap = val16[(int64_t)i * KS_M + KS_M - 1] - val16[(int64_t)i * KS_M + k - 1];
+  if (!(gap > 2.f * (2.f * 0x1p-15f * scale + noise))) atomicAdd(unproven, 1);
+  if (!(gap > 2.f * (2.f * 0x1p-18f * scale + noise))) atomicAdd(unproven + 1, 1);
 }
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
@@ -443,8 +445,8 @@ namespace {
 // the rows of `src` as PL centred planes + centred norms
 template <int DIM, int PL>
 void make_planes(const Tensor* src, const Tensor* mean, Tensor* planes, Tensor* norm, int64_t rows, hipStream_t st) {
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>(), mean->ptr<float>(), planes->ptr<bf16_t>(),
-                     norm->ptr<float>(), rows);
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>(), mean->ptr<float>(),
+                     planes ? planes->ptr<bf16_t>() : (bf16_t*)nullptr, norm->ptr<float>(), rows);
   LAMP_LAUNCH_CHECK();
 }
 struct SplitData {             // the data set for the filter: PL planes of the centred rows, their squared norms and the largest of those
@@ -518,7 +520,7 @@ void exact_for_failed(const Tensor* q, const Tensor* x, const Tensor* qn, const 
 }  // namespace
 
 template <int DIM>
-static void knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
+static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
                           hipStream_t st) {
   const int dev = x->device();
   const int64_t zero = 0;
@@ -529,42 +531,41 @@ static void knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, co
   int planes = env_planes == 2 || env_planes == 3 ? env_planes : 0;
   SplitData sd;
   if (!planes) {
-    // Two planes or three?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices over
-    // the CUs: ~3 ms at 1M points) gives their d_k and d_16; two planes prove a query when that gap exceeds twice their error bound.
-    // Fewer than 5 % of the sample unproven: two planes (half the matrix work); otherwise three.
+    // Two planes, three, or none?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices
+    // over the CUs: ~3 ms at 1M points) gives their d_k and d_16; a plane count proves a query when that gap exceeds twice its error
+    // bound.  Two planes if they leave fewer than 5 % of the sample unproven (half the matrix work of three); three planes if those
+    // leave fewer than 15 %; otherwise the neighbourhoods of this data are ties within f32 (lattices, duplicates) and the filter would
+    // only add its time to the exact kernel's: not used.
     const int64_t S = std::min<int64_t>(Q, 1024), stride = Q / S;
     Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, kF32, dev)), sqn(new_tensor({S}, kF32, dev));
     hipLaunchKernelGGL(knn_strided_ids_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, ids->ptr<int>(), S, stride);
     hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), ids->ptr<int>(), sq->ptr<float>(), S, (int64_t)DIM);
     hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<float>(), ids->ptr<int>(), sqn->ptr<float>(), S, (int64_t)1);
     LAMP_LAUNCH_CHECK();
-    const int64_t ks = std::min<int64_t>(KS_M, N);
-    Hold si(new_tensor({S, ks}, kI64, dev)), sv(new_tensor({S, ks}, kF32, dev));
-    planes = 3;
-    if (ks == KS_M && knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, ks, st, 0)) {
-      // centred norms of the sample and of the data (the planes themselves are built once the count is known)
-      Hold scr(new_tensor({S, (int64_t)2 * DIM}, kBF16, dev)), sqc(new_tensor({S}, kF32, dev));
-      make_planes<DIM, 2>(sq.get(), mean.get(), scr.get(), sqc.get(), S, st);
-      sd.planes = Hold(new_tensor({N, (int64_t)2 * DIM}, kBF16, dev));
-      sd.norm = Hold(new_tensor({N}, kF32, dev));
-      make_planes<DIM, 2>(x, mean.get(), sd.planes.get(), sd.norm.get(), N, st);
-      sd.norm_max = Hold(reduce_dims(sd.norm.get(), nullptr, 0, false, 3));
-      HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
-      hipLaunchKernelGGL(knn_predict_two_planes_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(),
-                         sd.norm_max->ptr<float>(), dn_max->ptr<float>(), failed->ptr<int>(), (int)S, (int)k);
-      LAMP_LAUNCH_CHECK();
-      int unproven = 0;
-      HIP_CHECK(hipMemcpyAsync(&unproven, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      if ((int64_t)unproven * 20 <= S) planes = 2;
-      else sd = SplitData();                                      // (the two-plane image of the data is of no use to three planes)
-    }
+    if (N < KS_M) return false;
+    Hold si(new_tensor({S, (int64_t)KS_M}, kI64, dev)), sv(new_tensor({S, (int64_t)KS_M}, kF32, dev));
+    if (!knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, KS_M, st, 0)) return false;
+    Hold sqc(new_tensor({S}, kF32, dev)), dnc(new_tensor({N}, kF32, dev));           // centred norms of the sample and of the data
+    make_planes<DIM, 2>(sq.get(), mean.get(), nullptr, sqc.get(), S, st);
+    make_planes<DIM, 2>(x, mean.get(), nullptr, dnc.get(), N, st);
+    Hold dnc_max(reduce_dims(dnc.get(), nullptr, 0, false, 3));
+    HIP_CHECK(hipMemsetAsync(failed->raw(), 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(knn_predict_planes_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(), dnc_max->ptr<float>(),
+                       dn_max->ptr<float>(), failed->ptr<int>(), (int)S, (int)k);
+    LAMP_LAUNCH_CHECK();
+    int unproven[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(unproven, failed->raw(), sizeof(unproven), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    if ((int64_t)unproven[0] * 20 <= S) planes = 2;
+    else if ((int64_t)unproven[1] * 100 <= 15 * S) planes = 3;
+    else return false;
   }
   const int nf = planes == 2 ? split_pass<DIM, 2>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st)
                              : split_pass<DIM, 3>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st);
   if (nf) exact_for_failed<DIM>(q, x, qn, dn, idx, val, failed.get(), nf, 0, N, k, st);
   g_knn_split_failed = nf;
   g_knn_split_planes = planes;
+  return true;
 }
 
 // f32 squared-Euclidean search of 64 / 128 features, k <= 12 (16 candidates leave a margin of at least 4).  false: not covered / not worth it.
@@ -577,9 +578,7 @@ bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
   // the extra passes (mean, planes, sample, re-rank) and the host round trips for the verdicts cost ~0.5 ms: below ~4e9 distance evaluations the exact kernel is as fast
   if (mode == 1 && ((double)Q * (double)N < 4.0e9 || N < 16384)) return false;
-  if (dim == 128) knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st);
-  else knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st);
-  return true;
+  return dim == 128 ? knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st) : knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st);
 }
 
 }  // namespace lamp

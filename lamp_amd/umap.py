@@ -29,10 +29,11 @@ from ._capi import lib, f64_array, handle_array
 def knn_search(features: S.STen, query: S.STen, k: int, minibatchSize: int = 1000) -> S.STen:
     """lamp.knn.knnSearch with SquaredEuclideanDistance (knn/package.scala:60-121): i64 [q, k] neighbour indices.
     `minibatchSize` is the reference's query batch; the kernel chunks the distance block itself, so batches are merged into
-    calls of at most 131072 queries (same result)."""
+    calls of at most 1048576 queries (same result; every call pays for the data set's norms, its bf16 planes and the sample search of
+    kernels/knn_split.hip once)."""
     q = query.shape[0]
     step = max(int(minibatchSize), 1)
-    step = max(step, min(q, 131072) // step * step) if q > step else step
+    step = max(step, min(q, 1048576) // step * step) if q > step else step
     parts = []
     for lo in range(0, q, step):
         i = C.c_void_p()
