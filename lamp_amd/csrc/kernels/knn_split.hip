@@ -45,6 +45,9 @@ template <int I, int N, class F> __device__ __forceinline__ void ks_static_for(F
 
 __device__ unsigned long long ks_dbg[8];      // diagnostic build (LAMP_KNN_SPLIT_DBG=3): visits, tiles tested, candidates, flushes, cycles in the selection
 
+// points per LDS tile: as many as two tiles + the selection state leave room for (160 KB), in whole 1-KiB DMA pieces per wave
+constexpr int ks_tile_points(int dim, int planes) { return planes == 2 || dim == 64 ? 64 : 48; }
+
 struct KsWaveState {
   float lv[64][KS_M];         // the row's 16 best so far, UNSORTED (the re-rank orders its candidates anyway): an insertion replaces the
   int li[64][KS_M];           // largest entry and finds the new largest - no shifting through LDS
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
                                                            const float* __restrict__ dn, int* __restrict__ out_idx, float* __restrict__ out_val, int Q,
                                                            int N) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS_BC = PL == 2 ? 64 : 32;    // points per tile
+  constexpr int KS_BC = ks_tile_points(DIM, PL);   // points per tile
   constexpr int ROWB = 2 * PL * DIM;          // bytes of one point in LDS (PL DIM bf16)
   constexpr int NCHK = ROWB / 16;             // 16-byte chunks per point (>= 16)
   constexpr int NJ = ROWB / 64;               // chunk steps: 4 lane groups x 16 bytes each
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
   constexpr int NACC = 4 * NCT;               // accumulator tiles of a wave
   constexpr int TILE = KS_BC * ROWB;
   static_assert(NCHK >= 16, "the swizzle needs at least 16 chunks per row");
+  static_assert(TILE % 4096 == 0, "a tile is whole 1-KiB pieces per wave");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -290,6 +294,9 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       if constexpr (NCT == 4) {
         if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
+      } else if constexpr (NCT == 3) {
+        if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : : "memory");
       } else {
         if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]) : : "memory");
@@ -472,7 +479,7 @@ int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
   {
     // declared: the algorithmic work of the search, as knn_fused declares it (the bf16 pipe executes PL (PL + 1) / 2 times the products)
     KernelTimer kt(PL == 2 ? "knn_split_bf16x3" : "knn_split_bf16x6", 2.0 * (double)Qn * N * DIM, ((double)Qn + N) * DIM * 4, st);
-    constexpr int BC = PL == 2 ? 64 : 32;
+    constexpr int BC = ks_tile_points(DIM, PL);
     const size_t lds = (size_t)2 * BC * 2 * PL * DIM + 4 * sizeof(KsWaveState);
     const char* dbg = getenv("LAMP_KNN_SPLIT_DBG");
     const int dm = dbg ? atoi(dbg) : 0;
