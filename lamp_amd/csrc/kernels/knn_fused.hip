@@ -24,7 +24,7 @@ typedef double kf_d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char kf_lds_t;
 typedef const __attribute__((address_space(1))) char kf_glb_t;
 
-constexpr int KF_BQ = 128, KF_KMAX = 16, KF_CAND = 256;
+constexpr int KF_BQ = 128, KF_KMAX = 16, KF_RC = 24;   // KF_RC: a row's buffer is flushed when it holds more than KF_RC - 16 (a tile can add 16)
 
 template <class T> struct KfTraits;
 template <> struct KfTraits<float> {
@@ -52,9 +52,9 @@ template <class T> struct KfWaveState {
   T lv[32][KF_KMAX];          // sorted ascending by (value, index)
   int li[32][KF_KMAX];
   T thr[32];                  // lv[row][k - 1]
-  T cv[KF_CAND];              // candidates of the accumulator tile just filtered
-  int ci[KF_CAND];
-  int cr[KF_CAND];
+  T bv[32][KF_RC];            // per-row candidate buffers (round 3, from knn_split.hip): a visit of the selection appends - slot = LDS atomic
+  int bi[32][KF_RC];          // increment of the row's counter -, a flush lets every row's lane insert its own entries, all rows at once
+  int bn[32];
 };
 
 template <class T, int DIM, int KIND>   // KIND 0: squared Euclidean (qn, dn = squared norms), 1: Jaccard (qn, dn = row sums)
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
   if (lane < 32) {
     for (int i = 0; i < KF_KMAX; i++) { ws->lv[lane][i] = (T)INFINITY; ws->li[lane][i] = 0x7fffffff; }
     ws->thr[lane] = (T)INFINITY;
+    ws->bn[lane] = 0;
   }
   T thr[2][4];
 #pragma unroll
@@ -146,9 +147,35 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
       else { const T den = (qnr[t][r] + dnv) - a[r]; v[r] = T(1) - a[r] / den; }
     }
   };
-  // slow path (probability ~ k / points seen per candidate): append the passing candidates of every accumulator tile to the
-  // wave's buffer (ballot + prefix count) and let lane r insert the entries of row r into that row's sorted list
+  // slow path (probability ~ k / points seen per candidate).  Inserting every candidate at once - the lane that owns the row shifting
+  // its sorted list through LDS while the other lanes wait - cost ~1500 cycles per candidate (knn_split.hip's counters); so a visit only
+  // APPENDS the passing (value, index) to the row's buffer, and when some buffer could overflow with the next tile all 32 row lanes
+  // insert their own entries at the same time.  Thresholds are a little stale in between (a few more candidates pass); entries of one
+  // tile reach a buffer in any order, so the insertion compares (value, index) - ties go to the lower index as before.
+  auto flush_rows = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 32) {
+      T* lv = ws->lv[lane];
+      int* li = ws->li[lane];
+      const int n = ws->bn[lane];
+      for (int e = 0; e < n; e++) {
+        const T cvv = ws->bv[lane][e];
+        const int cii = ws->bi[lane][e];
+        if (!(cvv < lv[k - 1] || (cvv == lv[k - 1] && cii < li[k - 1]))) continue;
+        int p = k - 1;
+        while (p > 0 && (lv[p - 1] > cvv || (lv[p - 1] == cvv && li[p - 1] > cii))) { lv[p] = lv[p - 1]; li[p] = li[p - 1]; p--; }
+        lv[p] = cvv; li[p] = cii;
+      }
+      if (n) { ws->thr[lane] = lv[k - 1]; ws->bn[lane] = 0; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) thr[tt][r] = ws->thr[16 * tt + TR::row_of(g, r)];
+  };
   auto select_tile = [&](const acc_t (&a)[2][NCT], const T* dnv, int c0) {
+    bool full = false;
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -160,36 +187,16 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; r++) { pass[r] = col < N && v[r] < thr[t][r]; any |= pass[r]; }
         if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
-        int cnt = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(pass[r]);
           if (pass[r]) {
-            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            ws->cv[pos] = v[r]; ws->ci[pos] = col; ws->cr[pos] = 16 * t + TR::row_of(g, r);
+            const int row = 16 * t + TR::row_of(g, r);
+            const int slot = atomicAdd(&ws->bn[row], 1);       // the lanes of a group that hit the same row get distinct slots
+            ws->bv[row][slot] = v[r]; ws->bi[row][slot] = col;
+            full |= slot >= KF_RC - 17;
           }
-          cnt += __builtin_popcountll(m);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (lane < 32) {
-          T* lv = ws->lv[lane];
-          int* li = ws->li[lane];
-          for (int e = 0; e < cnt; e++) {
-            if (ws->cr[e] != lane) continue;
-            const T cvv = ws->cv[e];
-            const int cii = ws->ci[e];
-            if (!(cvv < lv[k - 1] || (cvv == lv[k - 1] && cii < li[k - 1]))) continue;
-            int p = k - 1;
-            while (p > 0 && (lv[p - 1] > cvv || (lv[p - 1] == cvv && li[p - 1] > cii))) { lv[p] = lv[p - 1]; li[p] = li[p - 1]; p--; }
-            lv[p] = cvv; li[p] = cii;
-          }
-          ws->thr[lane] = lv[k - 1];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) thr[tt][r] = ws->thr[16 * tt + TR::row_of(g, r)];
+        if (__builtin_amdgcn_ballot_w64(full) != 0) { flush_rows(); full = false; }
       }
   };
   // branch-free test "does any candidate of the tile beat its row's k-th best": plain VALU work the scheduler can place
@@ -262,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void knn_fused_kernel(const T* __restrict__
       for (int ct = 0; ct < NCT; ct++) old[t][ct] = acc[t][ct];
   }
   select_tile(old, dno, col0_old);
+  flush_rows();
   // ---- results: row lane of the wave
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < 32 && q0 + lane < Q) {
