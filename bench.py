@@ -148,11 +148,11 @@ def roofline_of(rows):
     ai = flops / max(byts, 1.0)
     if flops > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
         peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_BF16_TFLOPS
-        if d["tag"].startswith("knn_split_bf16x"):
-            # the f32 search on the bf16 pipe (kernels/knn_split.hip): every f32 product is 3 (two planes) or 6 (three planes) bf16 products.
-            # The launcher declares the ALGORITHMIC work of the search; the roofline is priced on what the bf16 pipe executes.
+        if d["tag"].startswith("knn_split_f16x"):
+            # the f32 search on the 16-bit matrix pipe (kernels/knn_split.hip): every f32 product is 3 f16 products (two planes per value).
+            # The launcher declares the ALGORITHMIC work of the search; the roofline is priced on what the f16 pipe executes (same peak as bf16).
             terms = int(d["tag"][-1])
-            extra["bf16_products_per_f32_product"] = terms
+            extra["f16_products_per_f32_product"] = terms
             flops = flops * terms
             extra["executed_flops"] = flops
         ach = flops / avg_s / 1e12
@@ -381,7 +381,7 @@ def main():
             return S.STen(i)
         units_per_step = nq
         metric, unit = "kNN queries/sec (1M x 128 f32 points, k = 10)", "queries/s"
-        config = {"workload": "lamp.knn.knnSearch squared Euclidean, 131072 queries x 1M points x 128 features, k = 10 (split-bf16 filter with the top-k fused in, exact f32 re-rank with a per-query proof, exact f32 MFMA kernel for the unproven queries)",
+        config = {"workload": "lamp.knn.knnSearch squared Euclidean, 131072 queries x 1M points x 128 features, k = 10 (split-f16 filter with the top-k fused in, exact f32 re-rank with a per-query proof, exact f32 MFMA kernel for the unproven queries)",
                   "parallelism": "query rows sharded" if a.gpus > 1 else "single"}
         a.dtype = "f32"
     elif a.workload == "attention":

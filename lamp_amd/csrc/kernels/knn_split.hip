@@ -1,27 +1,28 @@
-// k nearest neighbours of f32 points through the bf16 matrix pipe: a filter pass that cannot lose a neighbour + an exact re-rank.
+// k nearest neighbours of f32 points through the 16-bit matrix pipe: a filter pass that cannot lose a neighbour + an exact re-rank.
 //
 // Reference: lamp-knn/src/main/scala/lamp/knn/package.scala:60-121 (knnSearch with SquaredEuclideanDistance, f32):
 //   d(q, x) = max(0, (|q|^2 + |x|^2) - 2 q.x), topk(k, largest = false) per query.
 // knn_fused.hip computes q.x on v_mfma_f32_16x16x4_f32: 157 TFLOP/s is all the f32 matrix pipe has, and a 1M x 1M x 128 search is
-// 256 TFLOP.  The bf16 pipe is 16 x wider, and an f32 value splits exactly into bf16 pieces:
-//   x = x0 + x1 + x2 + r,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1):  |x - x0 - x1| <= 2^-18 |x|,  |r| <= 2^-27 |x|.
+// 256 TFLOP.  The f16 pipe is 16 x wider, and an f32 value splits exactly into f16 pieces (11 bits each):
+//   y = y0 + y1 + r,  y0 = f16(y), y1 = f16(y - y0):  |r| <= 2^-22 |y|   (bf16 pieces, 8 bits each, need three planes and six products
+//   for the same 22 - 24 bits: measured first, twice the matrix time).
 // Pass 0 (knn_split_planes_kernel): distances do not change when every point moves by the same vector, but the error of a split product
-//   scales with |q| |x| - so the data set's mean is subtracted first, then each row is written as PL bf16 planes with its squared norm.
-// Pass 1 (knn_split_kernel) computes the dot products of the centred rows from the plane products whose weight is above the last plane's,
-//     PL = 2:  q0.x0 + q1.x0 + q0.x1                      (3 bf16 products per feature: 3/16 of the f32 pipe's time)
-//     PL = 3:  q0.x0 + q1.x0 + q2.x0 + q0.x1 + q1.x1 + q0.x2  (6)
-//   with the top-k selection fused in, and keeps the 16 best candidates per query by a = (|q|^2 + |x|^2) - 2 (that sum).
-//   Error of the sum: the dropped products (PL = 2: q1.x1, q0.r, r.x0 <= 3.1 * 2^-18 |q||x|; PL = 3: 3.1 * 2^-27) plus the f32
-//   accumulation of 4 PL (PL + 1) / 2 MFMA results (each a 32-term sum: <= 6 roundings each, 2^-24 relative to sum |q_i x_i|):
-//   bounded by c_PL |q||x| with c_2 = 2^-15, c_3 = 2^-18 (twice the analytic figure; the largest error seen on the test sets is 3 - 6 x
-//   below).  So |a - d| <= eps_q = 2 c_PL |q| max|x| + 2^-21 (|q|^2 + max|x|^2) (the second term: the rounding of the f32 formula itself).
+//   scales with |q| |x| - so the data set's mean row is subtracted first; the centred rows are scaled by a power of two that puts their
+//   largest coordinate near 2^14 (f16's range; the pieces of small coordinates that fall into f16's denormals are 2^-39 of that, far
+//   below the bound) and written as two f16 planes, with the squared norm of the centred row.
+// Pass 1 (knn_split_kernel): q.x ~ (q0.x0 + q1.x0 + q0.x1) / scale^2 - three f16 products per feature, 3/16 of the f32 pipe's time -
+//   with the top-k selection fused in; the 16 best candidates per query by a = (|q|^2 + |x|^2) - 2 (that sum) are kept.
+//   Error of the sum: the dropped products (q1.x1, q0.r, r.x0: <= 3.1 * 2^-22 |q||x|) plus the f32 accumulation of 12 MFMA results (each a
+//   32-term sum; <= 6 roundings each, 2^-24 relative to sum |q_i x_i|): 2.1e-6 |q||x|, bounded by c = 2^-18 = 3.8e-6 (the largest error
+//   seen on the test sets is 4e-7).  So |a - d| <= eps_q = 2 c |q| max|x| + 2^-21 (|q|^2 + max|x|^2) (the second term: the f32 formula's own rounding).
 // Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the ORIGINAL f32 data (dot product accumulated in f64, rounded once,
 //   then the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
 //   a >= a_16, hence d >= a_16 - eps_q: when the k-th re-ranked distance is strictly below that, the k neighbours are exactly those an
-//   exact search returns.  Queries that fail the test (more than 16 - k points within eps of the k-th neighbour: near-duplicates, very
-//   dense neighbourhoods) are collected and run through knn_fused.hip.
-// Which PL: two planes where they can decide the data (a sample of the queries is searched first; PL = 2 stays if fewer than 5 % of them
-// fail), three planes otherwise.  The result is that of an exact f32 search; only the time depends on the data.
+//   exact search returns.  Queries that fail the test (ties at the k-th neighbour, more than 16 - k points within eps of it) are
+//   collected and run through knn_fused.hip.
+// Whether to run the filter at all: an exact search of ~1000 queries spread over the query set tells how many it would prove; below 85 %
+// (lattices, duplicated points: neighbourhoods that are ties within f32) the exact kernel does the whole search.
+// The result is that of an exact f32 search; only the time depends on the data.
 #include "device_utils.h"
 #include "../core/tensor.h"
 #include <type_traits>
@@ -29,7 +30,7 @@
 
 namespace lamp {
 
-typedef __bf16 ks_bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ks_h8 __attribute__((ext_vector_type(8)));
 typedef float ks_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char ks_lds_t;
 typedef const __attribute__((address_space(1))) char ks_glb_t;
@@ -60,9 +61,11 @@ struct KsWaveState {
   int bn[64];                 // entries in the row's buffer
 };
 
-// rows of PL bf16 planes [x0(DIM) | x1(DIM) | ..] of (row - mean), and the squared norm of (row - mean) in f32: one wave per row
+// rows of PL f16 planes [y0(DIM) | y1(DIM) | ..] of y = (row - mean) * scale (scale: a power of two that brings the largest coordinate near
+// 2^14, so every piece is a normal f16 number or a denormal far below the error bound), and the squared norm of (row - mean) in f32:
+// one wave per row.  out == nullptr: the norms only.
 template <int DIM, int PL>
-__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, float scale, _Float16* __restrict__ out,
                                                                float* __restrict__ norm, int64_t rows) {
   constexpr int PER = DIM / 64;                       // features per lane (1 or 2)
   const int lane = threadIdx.x & 63;
@@ -72,12 +75,13 @@ __global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __re
 #pragma unroll
   for (int e = 0; e < PER; e++) {
     const int c = lane * PER + e;
-    float rest = x[r * DIM + c] - mean[c];
-    s = __builtin_fmaf(rest, rest, s);
+    const float cen = x[r * DIM + c] - mean[c];
+    s = __builtin_fmaf(cen, cen, s);
+    float rest = cen * scale;
 #pragma unroll
     for (int pl = 0; pl < PL; pl++) {
-      const bf16_t piece(rest);
-      rest -= (float)piece;                           // exact: the piece holds the leading 8 bits of what was left
+      const _Float16 piece = (_Float16)rest;          // round to nearest even
+      rest -= (float)piece;                           // exact: the piece holds the leading 11 bits of what was left
       if (out) out[r * (PL * DIM) + pl * DIM + c] = piece;
     }
   }
@@ -88,16 +92,16 @@ __global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __re
 
 // The structure of knn_fused_kernel (one workgroup = its queries' fragments in registers, the data set streamed through two LDS
 // buffers by LDS-DMA, the filter of tile i - 1 in the basic block that multiplies tile i) with
-//   * wave = 64 queries (four 16-row tiles) x BC points (64 with two planes, 32 with three: the LDS budget), a B fragment read feeds
+//   * wave = 64 queries (four 16-row tiles) x BC points (64 with two planes; PL = 3 - 33 bits, kept for experiments - 48), a B fragment read feeds
 //     4 MFMAs per query plane it meets;
 //   * an LDS row per point = its PL planes, 16-byte chunk c of row r at c ^ (r & 15): chunk step j is one 32-deep k-slab of
-//     v_mfma_f32_16x16x32_bf16 (lane group g = k 8g .. 8g + 7), steps [p NH, (p + 1) NH) are plane p, multiplied by the query planes
+//     v_mfma_f32_16x16x32_f16 (lane group g = k 8g .. 8g + 7), steps [p NH, (p + 1) NH) are plane p, multiplied by the query planes
 //     0 .. PL - 1 - p;
 //   * KS_M = 16 candidates per row whatever k is (the re-rank needs the margin).
 template <int DIM, int PL, int DBG = 0>
-__global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restrict__ qs, const bf16_t* __restrict__ xs, const float* __restrict__ qn,
+__global__ __launch_bounds__(256, 1) void knn_split_kernel(const _Float16* __restrict__ qs, const _Float16* __restrict__ xs, const float* __restrict__ qn,
                                                            const float* __restrict__ dn, int* __restrict__ out_idx, float* __restrict__ out_val, int Q,
-                                                           int N) {
+                                                           int N, float m2 /* -2 / scale^2: the dot products of the scaled planes back to the rows' units */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS_BC = ks_tile_points(DIM, PL);   // points per tile
   constexpr int ROWB = 2 * PL * DIM;          // bytes of one point in LDS (PL DIM bf16)
@@ -116,15 +120,15 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
   KsWaveState* ws = reinterpret_cast<KsWaveState*>(smem + 2 * TILE) + wid;
 
   // ---- query fragments (A operand: lane = row c16 of the tile, k = 8 g .. 8 g + 7 of the slab) and norms
-  ks_bf8 qf[PL][4][NH];
+  ks_h8 qf[PL][4][NH];
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     int row = q0 + 16 * t + c16; row = row < Q ? row : Q - 1;
-    const bf16_t* qr = qs + (int64_t)row * (PL * DIM);
+    const _Float16* qr = qs + (int64_t)row * (PL * DIM);
 #pragma unroll
     for (int pl = 0; pl < PL; pl++)
 #pragma unroll
-      for (int j = 0; j < NH; j++) qf[pl][t][j] = *reinterpret_cast<const ks_bf8*>(qr + pl * DIM + 32 * j + 8 * g);
+      for (int j = 0; j < NH; j++) qf[pl][t][j] = *reinterpret_cast<const ks_h8*>(qr + pl * DIM + 32 * j + 8 * g);
   }
   // ---- selection state
   for (int i = 0; i < KS_M; i++) { ws->lv[lane][i] = INFINITY; ws->li[lane][i] = 0x7fffffff - i; }
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
       const int col = c0 + 16 * ct + c16;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float d = (q4[r] + dn1) - 2.f * av[r];
+        const float d = __builtin_fmaf(m2, av[r], q4[r] + dn1);
         const float v = d > 0.f ? d : 0.f;
         // (<=: an equal value with a lower index than the list's worst entry must reach the flush, which decides on (value, index))
         if (col < N && v <= t4[r]) {
@@ -261,10 +265,10 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
     const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g);
     const int4 th = *reinterpret_cast<const int4*>(ws->thr + 16 * t + 4 * g);
     // (the clamp is part of the test: the bit pattern of a negative distance minus a threshold's would wrap around)
-    int m = (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[0], qq.x + dnv), 0.f)) - th.x;
-    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[1], qq.y + dnv), 0.f)) - th.y);
-    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[2], qq.z + dnv), 0.f)) - th.z);
-    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(-2.f, a[3], qq.w + dnv), 0.f)) - th.w);
+    int m = (int)__float_as_uint(fmaxf(__builtin_fmaf(m2, a[0], qq.x + dnv), 0.f)) - th.x;
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(m2, a[1], qq.y + dnv), 0.f)) - th.y);
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(m2, a[2], qq.z + dnv), 0.f)) - th.z);
+    m = min(m, (int)__float_as_uint(fmaxf(__builtin_fmaf(m2, a[3], qq.w + dnv), 0.f)) - th.w);
     mask |= (__builtin_amdgcn_ballot_w64(m <= 0) != 0 ? 1u : 0u) << idx;       // one bit per accumulator tile, kept in a scalar register
   };
   dma_tile(0, 0);
@@ -285,12 +289,12 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
 #pragma unroll
       for (int ct = 0; ct < NCT; ct++) acc[t][ct] = ks_f4{0, 0, 0, 0};
     const unsigned boff = buf * TILE;
-    ks_bf8 bf[2][NCT];
-    auto b_issue = [&](auto jc, ks_bf8* dst) {
+    ks_h8 bf[2][NCT];
+    auto b_issue = [&](auto jc, ks_h8* dst) {
       constexpr int j = decltype(jc)::value;
       ks_static_for<0, NCT>([&](auto ctc) { constexpr int ct = decltype(ctc)::value; ks_read128<ct * 16 * ROWB>(dst[ct], bbase[j] + boff); });
     };
-    auto b_fence = [&](ks_bf8* f, bool last) {
+    auto b_fence = [&](ks_h8* f, bool last) {
       if constexpr (NCT == 4) {
         if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory");
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const bf16_t* __restr
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++)
 #pragma unroll
-          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qp][t][jj], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
+          for (int t = 0; t < 4; t++) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qp][t][jj], bf[j & 1][ct], acc[t][ct], 0, 0, 0);
       });
       // the filter of the PREVIOUS tile's accumulator tiles, spread over the steps: vector work that issues while the matrix pipe runs
       constexpr int PER = (NACC + NJ - 1) / NJ;
@@ -424,15 +428,14 @@ __global__ void knn_strided_ids_kernel(int* __restrict__ ids, int64_t n, int64_t
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) ids[i] = (int)(i * stride);
 }
-// would two / three planes prove this query?  d16 - dk of an EXACT search against the error bounds (both ends of the gap move by at most eps)
-__global__ void knn_predict_planes_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c,
-                                          const float* __restrict__ dn_c_max, const float* __restrict__ dn_max, int* __restrict__ unproven /* [2] */, int S, int k) {
+// would the filter prove this query?  d16 - dk of an EXACT search against the error bound (both ends of the gap move by at most eps)
+__global__ void knn_predict_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c, const float* __restrict__ dn_c_max,
+                                   const float* __restrict__ dn_max, float c_dot, int* __restrict__ unproven, int S, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
-  const float scale = sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]), noise = 0x1p-21f * (qn[i] + dn_max[0]);
+  const float eps = 2.f * c_dot * sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qn[i] + dn_max[0]);
   const float gap = val16[(int64_t)i * KS_M + KS_M - 1] - val16[(int64_t)i * KS_M + k - 1];
-  if (!(gap > 2.f * (2.f * 0x1p-15f * scale + noise))) atomicAdd(unproven, 1);
-  if (!(gap > 2.f * (2.f * 0x1p-18f * scale + noise))) atomicAdd(unproven + 1, 1);
+  if (!(gap > 2.f * eps)) atomicAdd(unproven, 1);
 }
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
@@ -449,41 +452,33 @@ int64_t knn_split_last_failed() { return g_knn_split_failed; }
 int knn_split_last_planes() { return g_knn_split_planes; }
 
 namespace {
-// the rows of `src` as PL centred planes + centred norms
+constexpr float KS_C_DOT = 0x1p-18f;   // |filter's dot product - exact| <= KS_C_DOT |q_c| |x_c| (header comment)
+
+// the rows of `src`, centred and scaled, as PL f16 planes (planes == nullptr: none) + the squared norms of the centred rows
 template <int DIM, int PL>
-void make_planes(const Tensor* src, const Tensor* mean, Tensor* planes, Tensor* norm, int64_t rows, hipStream_t st) {
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>(), mean->ptr<float>(),
-                     planes ? planes->ptr<bf16_t>() : (bf16_t*)nullptr, norm->ptr<float>(), rows);
+void make_planes(const Tensor* src, int64_t row0, const Tensor* mean, float scale, Tensor* planes, Tensor* norm, int64_t rows, hipStream_t st) {
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>() + row0 * DIM, mean->ptr<float>(), scale,
+                     planes ? reinterpret_cast<_Float16*>(planes->raw()) : (_Float16*)nullptr, norm->ptr<float>(), rows);
   LAMP_LAUNCH_CHECK();
 }
-struct SplitData {             // the data set for the filter: PL planes of the centred rows, their squared norms and the largest of those
-  Hold planes, norm, norm_max;
-};
-// filter + re-rank of queries [q_lo, q_hi) with PL planes; returns the number of queries without proof, their ids in failed[1 ..]
+// filter + re-rank of all queries with PL planes; returns the number of queries without proof, their ids in failed[1 ..]
 template <int DIM, int PL>
-int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, const Tensor* dn_max, const Tensor* mean, SplitData& sd, Tensor* idx, Tensor* val,
-               Tensor* failed, int64_t q_lo, int64_t q_hi, int64_t N, int64_t k, hipStream_t st) {
+int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, const Tensor* dn_max, const Tensor* mean, float scale, const Tensor* dnc,
+               const Tensor* dnc_max, const Tensor* qnc, Tensor* idx, Tensor* val, Tensor* failed, int64_t Q, int64_t N, int64_t k, hipStream_t st) {
   const int dev = x->device();
-  const int64_t Qn = q_hi - q_lo;
-  if (!sd.planes.get()) {
-    sd.planes = Hold(new_tensor({N, (int64_t)PL * DIM}, kBF16, dev));
-    sd.norm = Hold(new_tensor({N}, kF32, dev));
-    make_planes<DIM, PL>(x, mean, sd.planes.get(), sd.norm.get(), N, st);
-    sd.norm_max = Hold(reduce_dims(sd.norm.get(), nullptr, 0, false, 3));
-  }
-  Hold qs(new_tensor({Qn, (int64_t)PL * DIM}, kBF16, dev)), qnc(new_tensor({Qn}, kF32, dev));
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((Qn + 3) / 4)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, mean->ptr<float>(), qs->ptr<bf16_t>(),
-                     qnc->ptr<float>(), Qn);
-  LAMP_LAUNCH_CHECK();
-  Hold ci(new_tensor({Qn, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Qn}, kF32, dev));        // candidates (unsorted) and a_16 per query
+  Hold xs(new_tensor({N, (int64_t)PL * DIM}, kF16, dev)), qs(new_tensor({Q, (int64_t)PL * DIM}, kF16, dev)), scratch_n(new_tensor({std::max(N, Q)}, kF32, dev));
+  make_planes<DIM, PL>(x, 0, mean, scale, xs.get(), scratch_n.get(), N, st);
+  make_planes<DIM, PL>(q, 0, mean, scale, qs.get(), scratch_n.get(), Q, st);
+  Hold ci(new_tensor({Q, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Q}, kF32, dev));        // candidates (unsorted) and a_16 per query
   {
-    // declared: the algorithmic work of the search, as knn_fused declares it (the bf16 pipe executes PL (PL + 1) / 2 times the products)
-    KernelTimer kt(PL == 2 ? "knn_split_bf16x3" : "knn_split_bf16x6", 2.0 * (double)Qn * N * DIM, ((double)Qn + N) * DIM * 4, st);
+    // declared: the algorithmic work of the search, as knn_fused declares it (the f16 pipe executes PL (PL + 1) / 2 times the products)
+    KernelTimer kt(PL == 2 ? "knn_split_f16x3" : "knn_split_f16x6", 2.0 * (double)Q * N * DIM, ((double)Q + N) * DIM * 4, st);
     constexpr int BC = ks_tile_points(DIM, PL);
     const size_t lds = (size_t)2 * BC * 2 * PL * DIM + 4 * sizeof(KsWaveState);
+    const float m2 = -2.f / (scale * scale);
     const char* dbg = getenv("LAMP_KNN_SPLIT_DBG");
     const int dm = dbg ? atoi(dbg) : 0;
-#define KS_LAUNCH(DB) do { allow_big_lds((const void*)knn_split_kernel<DIM, PL, DB>); hipLaunchKernelGGL((knn_split_kernel<DIM, PL, DB>), dim3((unsigned)((Qn + KS_BQ - 1) / KS_BQ)), dim3(256), lds, st, qs->ptr<bf16_t>(), sd.planes->ptr<bf16_t>(), qnc->ptr<float>(), sd.norm->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), (int)Qn, (int)N); } while (0)
+#define KS_LAUNCH(DB) do { allow_big_lds((const void*)knn_split_kernel<DIM, PL, DB>); hipLaunchKernelGGL((knn_split_kernel<DIM, PL, DB>), dim3((unsigned)((Q + KS_BQ - 1) / KS_BQ)), dim3(256), lds, st, reinterpret_cast<const _Float16*>(qs->raw()), reinterpret_cast<const _Float16*>(xs->raw()), qnc->ptr<float>(), dnc->ptr<float>(), ci->ptr<int>(), cv->ptr<float>(), (int)Q, (int)N, m2); } while (0)
     if (dm == 3) KS_LAUNCH(3); else KS_LAUNCH(0);
 #undef KS_LAUNCH
     LAMP_LAUNCH_CHECK();
@@ -498,78 +493,80 @@ int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
     }
   }
   HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
-  const float c_dot = PL == 2 ? 0x1p-15f : 0x1p-18f;
-  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Qn + 3) / 4)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, x->ptr<float>(), qn->ptr<float>() + q_lo,
-                     dn->ptr<float>(), qnc->ptr<float>(), sd.norm_max->ptr<float>(), dn_max->ptr<float>(), c_dot, ci->ptr<int>(), cv->ptr<float>(),
-                     idx->ptr<int64_t>() + q_lo * k, val->ptr<float>() + q_lo * k, failed->ptr<int>() + 1, failed->ptr<int>(), (int)Qn, (int)N, (int)k);
+  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, q->ptr<float>(), x->ptr<float>(), qn->ptr<float>(), dn->ptr<float>(),
+                     qnc->ptr<float>(), dnc_max->ptr<float>(), dn_max->ptr<float>(), KS_C_DOT, ci->ptr<int>(), cv->ptr<float>(), idx->ptr<int64_t>(), val->ptr<float>(),
+                     failed->ptr<int>() + 1, failed->ptr<int>(), (int)Q, (int)N, (int)k);
   LAMP_LAUNCH_CHECK();
   int nfail = 0;
   HIP_CHECK(hipMemcpyAsync(&nfail, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   return nfail;
 }
-// the queries [q_lo, q_lo + ..) listed in failed[1 .. nfail] (ids relative to q_lo) through the exact kernel
+// the queries listed in failed[1 .. nfail] through the exact kernel
 template <int DIM>
-void exact_for_failed(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, const Tensor* failed, int nfail, int64_t q_lo,
-                      int64_t N, int64_t k, hipStream_t st) {
+void exact_for_failed(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, const Tensor* failed, int nfail, int64_t N,
+                      int64_t k, hipStream_t st) {
   const int dev = x->device();
   Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, kF32, dev)), fqn(new_tensor({(int64_t)nfail}, kF32, dev));
   const int* rows = failed->ptr<int>() + 1;
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>() + q_lo * DIM, rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>() + q_lo, rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>(), rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
   LAMP_LAUNCH_CHECK();
   Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, kF32, dev));
   LAMP_CHECK(knn_fused(fq.get(), x, fqn.get(), dn, fi.get(), fv.get(), nfail, N, DIM, k, st, 0), "internal: the exact kNN kernel refused the fallback queries");
-  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows,
-                     idx->ptr<int64_t>() + q_lo * k, val->ptr<float>() + q_lo * k, (int64_t)nfail, k);
+  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows, idx->ptr<int64_t>(),
+                     val->ptr<float>(), (int64_t)nfail, k);
   LAMP_LAUNCH_CHECK();
 }
 }  // namespace
 
 template <int DIM>
 static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
-                          hipStream_t st) {
+                          hipStream_t st, bool forced) {
   const int dev = x->device();
   const int64_t zero = 0;
+  if (N < KS_M) return false;
   Hold mean(reduce_dims(x, &zero, 1, false, 1));                  // the data set's mean row: the filter works on (row - mean)
   Hold dn_max(reduce_dims(dn, nullptr, 0, false, 3));
   Hold failed(new_tensor({Q + 1}, kI32, dev));                    // [0] = count, then the queries
+  // squared norms of the centred rows (their largest sets the error bound and the scale of the f16 planes)
+  Hold dnc(new_tensor({N}, kF32, dev)), qnc(new_tensor({Q}, kF32, dev));
+  make_planes<DIM, 2>(x, 0, mean.get(), 1.f, nullptr, dnc.get(), N, st);
+  make_planes<DIM, 2>(q, 0, mean.get(), 1.f, nullptr, qnc.get(), Q, st);
+  Hold dnc_max(reduce_dims(dnc.get(), nullptr, 0, false, 3)), qnc_max(reduce_dims(qnc.get(), nullptr, 0, false, 3));
+  // Is the filter worth running?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices
+  // over the CUs: ~3 ms at 1M points) gives their d_k and d_16; the filter proves a query when that gap exceeds twice its error bound.
+  // If it would leave more than 15 % of the sample unproven, the neighbourhoods of this data are ties within f32 (lattices, duplicates)
+  // and the filter would only add its time to the exact kernel's: not used.
+  const int64_t S = std::min<int64_t>(Q, 1024), stride = Q / S;
+  Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, kF32, dev)), sqn(new_tensor({S}, kF32, dev)), sqc(new_tensor({S}, kF32, dev));
+  hipLaunchKernelGGL(knn_strided_ids_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, ids->ptr<int>(), S, stride);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), ids->ptr<int>(), sq->ptr<float>(), S, (int64_t)DIM);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<float>(), ids->ptr<int>(), sqn->ptr<float>(), S, (int64_t)1);
+  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qnc->ptr<float>(), ids->ptr<int>(), sqc->ptr<float>(), S, (int64_t)1);
+  LAMP_LAUNCH_CHECK();
+  Hold si(new_tensor({S, (int64_t)KS_M}, kI64, dev)), sv(new_tensor({S, (int64_t)KS_M}, kF32, dev));
+  if (!knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, KS_M, st, 0)) return false;
+  HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(knn_predict_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(), dnc_max->ptr<float>(),
+                     dn_max->ptr<float>(), KS_C_DOT, failed->ptr<int>(), (int)S, (int)k);
+  LAMP_LAUNCH_CHECK();
+  int unproven = 0;
+  float mx[2] = {0.f, 0.f};
+  HIP_CHECK(hipMemcpyAsync(&unproven, failed->raw(), sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&mx[0], dnc_max->raw(), sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&mx[1], qnc_max->raw(), sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  if (!forced && (int64_t)unproven * 100 > 15 * S) return false;
+  // a power of two that puts the largest coordinate of any centred row at or below 2^14 (f16 holds 65504)
+  const float big = std::sqrt(std::max(mx[0], mx[1]));
+  LAMP_CHECK(std::isfinite(big), "knn: the data or the queries contain non-finite values");
+  const float scale = big > 0.f ? std::exp2(std::floor(14.f - std::log2(big))) : 1.f;
   static const int env_planes = [] { const char* e = getenv("LAMP_KNN_SPLIT_PLANES"); return e ? atoi(e) : 0; }();
-  int planes = env_planes == 2 || env_planes == 3 ? env_planes : 0;
-  SplitData sd;
-  if (!planes) {
-    // Two planes, three, or none?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices
-    // over the CUs: ~3 ms at 1M points) gives their d_k and d_16; a plane count proves a query when that gap exceeds twice its error
-    // bound.  Two planes if they leave fewer than 5 % of the sample unproven (half the matrix work of three); three planes if those
-    // leave fewer than 15 %; otherwise the neighbourhoods of this data are ties within f32 (lattices, duplicates) and the filter would
-    // only add its time to the exact kernel's: not used.
-    const int64_t S = std::min<int64_t>(Q, 1024), stride = Q / S;
-    Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, kF32, dev)), sqn(new_tensor({S}, kF32, dev));
-    hipLaunchKernelGGL(knn_strided_ids_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, ids->ptr<int>(), S, stride);
-    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), ids->ptr<int>(), sq->ptr<float>(), S, (int64_t)DIM);
-    hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<float>(), ids->ptr<int>(), sqn->ptr<float>(), S, (int64_t)1);
-    LAMP_LAUNCH_CHECK();
-    if (N < KS_M) return false;
-    Hold si(new_tensor({S, (int64_t)KS_M}, kI64, dev)), sv(new_tensor({S, (int64_t)KS_M}, kF32, dev));
-    if (!knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, KS_M, st, 0)) return false;
-    Hold sqc(new_tensor({S}, kF32, dev)), dnc(new_tensor({N}, kF32, dev));           // centred norms of the sample and of the data
-    make_planes<DIM, 2>(sq.get(), mean.get(), nullptr, sqc.get(), S, st);
-    make_planes<DIM, 2>(x, mean.get(), nullptr, dnc.get(), N, st);
-    Hold dnc_max(reduce_dims(dnc.get(), nullptr, 0, false, 3));
-    HIP_CHECK(hipMemsetAsync(failed->raw(), 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(knn_predict_planes_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(), dnc_max->ptr<float>(),
-                       dn_max->ptr<float>(), failed->ptr<int>(), (int)S, (int)k);
-    LAMP_LAUNCH_CHECK();
-    int unproven[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(unproven, failed->raw(), sizeof(unproven), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if ((int64_t)unproven[0] * 20 <= S) planes = 2;
-    else if ((int64_t)unproven[1] * 100 <= 15 * S) planes = 3;
-    else return false;
-  }
-  const int nf = planes == 2 ? split_pass<DIM, 2>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st)
-                             : split_pass<DIM, 3>(q, x, qn, dn, dn_max.get(), mean.get(), sd, idx, val, failed.get(), 0, Q, N, k, st);
-  if (nf) exact_for_failed<DIM>(q, x, qn, dn, idx, val, failed.get(), nf, 0, N, k, st);
+  const int planes = env_planes == 3 ? 3 : 2;
+  const int nf = planes == 2 ? split_pass<DIM, 2>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st)
+                             : split_pass<DIM, 3>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st);
+  if (nf) exact_for_failed<DIM>(q, x, qn, dn, idx, val, failed.get(), nf, N, k, st);
   g_knn_split_failed = nf;
   g_knn_split_planes = planes;
   return true;
@@ -585,7 +582,7 @@ bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
   // the extra passes (mean, planes, sample, re-rank) and the host round trips for the verdicts cost ~0.5 ms: below ~4e9 distance evaluations the exact kernel is as fast
   if (mode == 1 && ((double)Q * (double)N < 4.0e9 || N < 16384)) return false;
-  return dim == 128 ? knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st) : knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st);
+  return dim == 128 ? knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st, mode == 2) : knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st, mode == 2);
 }
 
 }  // namespace lamp

@@ -592,7 +592,7 @@ def _knn(data, query, k):
 
 @pytest.mark.parametrize("n,nq,d,k", [(20000, 1500, 128, 10), (5000, 700, 64, 12), (16, 40, 128, 3), (3001, 257, 128, 1), (70, 300, 64, 10)])
 def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
-    """knn_split.hip forced on small problems (mode 2): centred data, where the filter proves (nearly) every query, against the exact
+    """knn_split.hip forced on small problems (mode 2): standard-normal data, where the filter proves (nearly) every query, against the exact
     fused kernel (mode 0) and the oracle.  Index sets equal on every row whose k-th / (k+1)-th neighbours are separated by more than the
     f32 formula's own noise; distances within that noise; rows sorted by distance."""
     g = torch.Generator().manual_seed(4242 + n)
@@ -613,8 +613,8 @@ def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
         lib.lamp_knn_split_last_planes(C.byref(planes))
     finally:
         lib.lamp_knn_split_mode(1)
-    assert b"knn_split_bf16" in buf.value, "the split kernel did not run"
-    assert planes.value == 2, "centred standard-normal data is decided by two planes"
+    assert b"knn_split_f16" in buf.value, "the split kernel did not run"
+    assert planes.value == 2
     assert si.dtype == np.int64 and si.shape == (len(rows), k)
     assert np.array_equal(np.sort(si, 1), np.sort(ei, 1)), "same neighbour sets as the exact kernel"
     ref = O.knn_minibatched(data, query, k, 100)
@@ -625,11 +625,11 @@ def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
     assert 0 <= failed.value <= max(2, len(rows) // 50), f"{failed.value} of {len(rows)} queries needed the exact kernel on centred data"
 
 
-def test_knn_split_filter_takes_three_planes_far_from_the_origin_and_falls_back_on_duplicates(gpu):
+def test_knn_split_filter_far_from_the_origin_and_falls_back_on_duplicates(gpu):
     """bench.py's kNN points in small (uniform jitter + 16 clusters one unit apart in every coordinate: |x|^2 up to 3e4, where the f32
-    formula itself is only good to ~5e-3): the sample search says two planes cannot decide this data, the search runs with three planes on
-    the centred rows.  Rows with a well separated neighbourhood get the exact kernel's set; queries whose neighbours have exact
-    duplicates cannot be proven and go through the exact kernel (ties -> lower index on either path)."""
+    formula itself is only good to ~5e-3): the filter works on the centred rows, split into two f16 planes (22 bits).  Rows with a well
+    separated neighbourhood get the exact kernel's set; queries whose k-th neighbour has exact duplicates cannot be proven and go
+    through the exact kernel (ties -> lower index on either path)."""
     g = torch.Generator().manual_seed(99)
     n, d, k = 20000, 128, 10
     data64 = torch.rand(n, d, generator=g, dtype=torch.float64) + (torch.arange(n) % 16).double().reshape(n, 1)
@@ -646,7 +646,7 @@ def test_knn_split_filter_takes_three_planes_far_from_the_origin_and_falls_back_
         lib.lamp_knn_split_last_planes(C.byref(planes))
     finally:
         lib.lamp_knn_split_mode(1)
-    assert planes.value == 3, "two planes must not be trusted with this data"
+    assert planes.value == 2
     assert 20 <= failed.value <= 600, f"{failed.value} of 1200 queries needed the exact kernel"     # the twenty copies at least
     sep = _well_separated_queries(data64, torch.arange(1200), k, 5e-2).numpy()
     assert len(sep) > 300
