@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const _Float16* __res
       const int idx = __builtin_ctz(tmask);
       tmask &= tmask - 1;
       const int t = idx / NCT, ct = idx % NCT;
-      ks_f4 av = ks_f4{0, 0, 0, 0}; float dn1 = 0.f, q4[4], t4[4];
+      // the row group's norms and thresholds: requested first, so that the round trip runs under the switch below
+      const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g), tt4 = *reinterpret_cast<const float4*>(ws->thr + 16 * t + 4 * g);
+      ks_f4 av = ks_f4{0, 0, 0, 0}; float dn1 = 0.f;
       switch (idx) {
 #define KS_CASE(I) case I: if constexpr ((I) < NACC) { av = a[(I) / NCT][(I) % NCT]; dn1 = dnv[(I) % NCT]; } break;
         KS_CASE(0) KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(7)
@@ -233,11 +235,7 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const _Float16* __res
         default: break;
 #undef KS_CASE
       }
-      {
-        const float4 qq = *reinterpret_cast<const float4*>(ws->qn + 16 * t + 4 * g), tt4 = *reinterpret_cast<const float4*>(ws->thr + 16 * t + 4 * g);
-        q4[0] = qq.x; q4[1] = qq.y; q4[2] = qq.z; q4[3] = qq.w;
-        t4[0] = tt4.x; t4[1] = tt4.y; t4[2] = tt4.z; t4[3] = tt4.w;
-      }
+      const float q4[4] = {qq.x, qq.y, qq.z, qq.w}, t4[4] = {tt4.x, tt4.y, tt4.z, tt4.w};
       const int col = c0 + 16 * ct + c16;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
