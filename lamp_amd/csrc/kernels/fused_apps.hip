@@ -239,7 +239,7 @@ static void sdpa_add_bias(Tensor* scores, const Tensor* bias, int64_t B, int64_t
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
                int64_t k, hipStream_t st, int kind);   // knn_fused.hip
 bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim, int64_t k,
-               hipStream_t st);             // knn_split.hip: large f32 searches through the bf16 matrix pipe, same result
+               hipStream_t st);             // knn_split.hip: large f32 / f64 searches through the f16 matrix pipe, same result
 
 static Hold call1(int (*fn)(lamp_tensor**, const lamp_tensor*), const Tensor* a) {
   lamp_tensor* o = nullptr;

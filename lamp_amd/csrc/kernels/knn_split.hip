@@ -64,8 +64,8 @@ struct KsWaveState {
 // rows of PL f16 planes [y0(DIM) | y1(DIM) | ..] of y = (row - mean) * scale (scale: a power of two that brings the largest coordinate near
 // 2^14, so every piece is a normal f16 number or a denormal far below the error bound), and the squared norm of (row - mean) in f32:
 // one wave per row.  out == nullptr: the norms only.
-template <int DIM, int PL>
-__global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, float scale, _Float16* __restrict__ out,
+template <int DIM, int PL, class T>
+__global__ __launch_bounds__(256) void knn_split_planes_kernel(const T* __restrict__ x, const T* __restrict__ mean, float scale, _Float16* __restrict__ out,
                                                                float* __restrict__ norm, int64_t rows) {
   constexpr int PER = DIM / 64;                       // features per lane (1 or 2)
   const int lane = threadIdx.x & 63;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void knn_split_planes_kernel(const float* __re
 #pragma unroll
   for (int e = 0; e < PER; e++) {
     const int c = lane * PER + e;
-    const float cen = x[r * DIM + c] - mean[c];
+    const float cen = (float)(x[r * DIM + c] - mean[c]);      // (f64 rows: the difference in f64, then one rounding to f32 - 2^-24, far inside the bound)
     s = __builtin_fmaf(cen, cen, s);
     float rest = cen * scale;
 #pragma unroll
@@ -357,37 +357,34 @@ __global__ __launch_bounds__(256, 1) void knn_split_kernel(const _Float16* __res
 // One wave per query: the exact distances of its KS_M candidates (f32 data, the dot product summed in f64 and rounded once, then
 // the reference's (|q|^2 + |x|^2) - 2 q.x in f32 with the clamp), ranked by (distance, index).  The first k go to the result; the
 // query is appended to `failed` unless the k-th distance is strictly below every distance a non-candidate can have.
-template <int DIM>
-__global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict__ q, const float* __restrict__ x, const float* __restrict__ qn,
-                                                         const float* __restrict__ dn, const float* __restrict__ qn_c, const float* __restrict__ dn_c_max,
-                                                         const float* __restrict__ dn_max, float c_dot, const int* __restrict__ cand_idx,
-                                                         const float* __restrict__ cand_val, int64_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                         int* __restrict__ failed, int* __restrict__ nfailed, int Q, int N, int k) {
+template <int DIM, class T>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(const T* __restrict__ q, const T* __restrict__ x, const T* __restrict__ qn, const T* __restrict__ dn,
+                                                         const float* __restrict__ qn_c, const float* __restrict__ dn_c_max, const T* __restrict__ dn_max, float c_dot,
+                                                         const int* __restrict__ cand_idx, const float* __restrict__ cand_val, int64_t* __restrict__ out_idx,
+                                                         T* __restrict__ out_val, int* __restrict__ failed, int* __restrict__ nfailed, int Q, int N, int k) {
   const int lane = threadIdx.x & 63;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= Q) return;
   const int c = lane >> 2, part = lane & 3;             // candidate, quarter of the features
   const int ci = cand_idx[(int64_t)qi * KS_M + c];
   const bool valid = ci >= 0 && ci < N;                   // fewer than KS_M points: the padding entries
-  const float* qr = q + (int64_t)qi * DIM + part * (DIM / 4);
-  const float* xr = x + (int64_t)(valid ? ci : 0) * DIM + part * (DIM / 4);
+  const T* qr = q + (int64_t)qi * DIM + part * (DIM / 4);
+  const T* xr = x + (int64_t)(valid ? ci : 0) * DIM + part * (DIM / 4);
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < DIM / 4; i += 4) {
-    const float4 a = *reinterpret_cast<const float4*>(qr + i), b = *reinterpret_cast<const float4*>(xr + i);
-    s += (double)a.x * (double)b.x; s += (double)a.y * (double)b.y; s += (double)a.z * (double)b.z; s += (double)a.w * (double)b.w;
-  }
+  for (int i = 0; i < DIM / 4; i++) s += (double)qr[i] * (double)xr[i];
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);
-  const float qnv = qn[qi];
-  float d = (qnv + dn[valid ? ci : 0]) - 2.f * (float)s;
-  d = d > 0.f ? d : 0.f;
-  if (!valid) d = INFINITY;
+  // the reference's formula in the data's precision (f32: the dot product rounded once to f32 first)
+  const T qnv = qn[qi];
+  T d = (qnv + dn[valid ? ci : 0]) - T(2) * (T)s;
+  d = d > T(0) ? d : T(0);
+  if (!valid) d = (T)INFINITY;
   // rank among the KS_M candidates by (d, index): every lane of a candidate computes the same rank
   int rank = 0;
 #pragma unroll
   for (int o = 0; o < KS_M; o++) {
-    const float od = __shfl(d, o * 4);
+    const T od = __shfl(d, o * 4);
     const int oi = __shfl(ci, o * 4);
     rank += (od < d || (od == d && oi < ci)) ? 1 : 0;
   }
@@ -396,25 +393,28 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const float* __restrict
     out_val[(int64_t)qi * k + rank] = d;
   }
   // the proof: a point outside the candidate list has an approximate distance >= a_last, and |approximate - exact| <= eps
-  // (the filter worked on the centred rows: its error scales with their norms; the formula's own rounding with the original ones)
-  const float a_last = cand_val[qi];
-  const float eps = 2.f * c_dot * sqrtf(qn_c[qi]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qnv + dn_max[0]);
+  // (the filter worked on the centred rows: its error scales with their norms; the formula's own rounding - f32 only - with the original ones)
+  const double a_last = (double)cand_val[qi];
+  const double noise = std::is_same<T, float>::value ? 0x1p-21 * ((double)qnv + (double)dn_max[0]) : 0x1p-50 * ((double)qnv + (double)dn_max[0]);
+  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[qi]) * sqrt((double)dn_c_max[0]) + noise;
   const bool all_points_are_candidates = N <= KS_M;
-  if (part == 0 && rank == k - 1 && !all_points_are_candidates && !(d < a_last - eps)) {
+  if (part == 0 && rank == k - 1 && !all_points_are_candidates && !((double)d < a_last - eps)) {
     const int slot = atomicAdd(nfailed, 1);
     failed[slot] = qi;
   }
 }
 
-__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst, int64_t n,
+template <class T>
+__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ rows, T* __restrict__ dst, int64_t n,
                                                               int64_t width) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * width; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / width, c = e - r * width;
     dst[e] = src[(int64_t)rows[r] * width + c];
   }
 }
-__global__ __launch_bounds__(256) void knn_scatter_results_kernel(const int64_t* __restrict__ si, const float* __restrict__ sv, const int* __restrict__ rows,
-                                                                  int64_t* __restrict__ di, float* __restrict__ dv, int64_t n, int64_t k) {
+template <class T>
+__global__ __launch_bounds__(256) void knn_scatter_results_kernel(const int64_t* __restrict__ si, const T* __restrict__ sv, const int* __restrict__ rows,
+                                                                  int64_t* __restrict__ di, T* __restrict__ dv, int64_t n, int64_t k) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * k; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / k, c = e - r * k;
     di[(int64_t)rows[r] * k + c] = si[e];
@@ -427,13 +427,15 @@ __global__ void knn_strided_ids_kernel(int* __restrict__ ids, int64_t n, int64_t
   if (i < n) ids[i] = (int)(i * stride);
 }
 // would the filter prove this query?  d16 - dk of an EXACT search against the error bound (both ends of the gap move by at most eps)
-__global__ void knn_predict_kernel(const float* __restrict__ val16, const float* __restrict__ qn, const float* __restrict__ qn_c, const float* __restrict__ dn_c_max,
-                                   const float* __restrict__ dn_max, float c_dot, int* __restrict__ unproven, int S, int k) {
+template <class T>
+__global__ void knn_predict_kernel(const T* __restrict__ val16, const T* __restrict__ qn, const float* __restrict__ qn_c, const float* __restrict__ dn_c_max,
+                                   const T* __restrict__ dn_max, float c_dot, int* __restrict__ unproven, int S, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
-  const float eps = 2.f * c_dot * sqrtf(qn_c[i]) * sqrtf(dn_c_max[0]) + 0x1p-21f * (qn[i] + dn_max[0]);
-  const float gap = val16[(int64_t)i * KS_M + KS_M - 1] - val16[(int64_t)i * KS_M + k - 1];
-  if (!(gap > 2.f * eps)) atomicAdd(unproven, 1);
+  const double noise = (std::is_same<T, float>::value ? 0x1p-21 : 0x1p-50) * ((double)qn[i] + (double)dn_max[0]);
+  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[i]) * sqrt((double)dn_c_max[0]) + noise;
+  const double gap = (double)val16[(int64_t)i * KS_M + KS_M - 1] - (double)val16[(int64_t)i * KS_M + k - 1];
+  if (!(gap > 2.0 * eps)) atomicAdd(unproven, 1);
 }
 
 bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim,
@@ -453,24 +455,24 @@ namespace {
 constexpr float KS_C_DOT = 0x1p-18f;   // |filter's dot product - exact| <= KS_C_DOT |q_c| |x_c| (header comment)
 
 // the rows of `src`, centred and scaled, as PL f16 planes (planes == nullptr: none) + the squared norms of the centred rows
-template <int DIM, int PL>
+template <int DIM, int PL, class T>
 void make_planes(const Tensor* src, int64_t row0, const Tensor* mean, float scale, Tensor* planes, Tensor* norm, int64_t rows, hipStream_t st) {
-  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<float>() + row0 * DIM, mean->ptr<float>(), scale,
+  hipLaunchKernelGGL((knn_split_planes_kernel<DIM, PL, T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src->ptr<T>() + row0 * DIM, mean->ptr<T>(), scale,
                      planes ? reinterpret_cast<_Float16*>(planes->raw()) : (_Float16*)nullptr, norm->ptr<float>(), rows);
   LAMP_LAUNCH_CHECK();
 }
 // filter + re-rank of all queries with PL planes; returns the number of queries without proof, their ids in failed[1 ..]
-template <int DIM, int PL>
+template <int DIM, int PL, class T>
 int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, const Tensor* dn_max, const Tensor* mean, float scale, const Tensor* dnc,
                const Tensor* dnc_max, const Tensor* qnc, Tensor* idx, Tensor* val, Tensor* failed, int64_t Q, int64_t N, int64_t k, hipStream_t st) {
   const int dev = x->device();
   Hold xs(new_tensor({N, (int64_t)PL * DIM}, kF16, dev)), qs(new_tensor({Q, (int64_t)PL * DIM}, kF16, dev)), scratch_n(new_tensor({std::max(N, Q)}, kF32, dev));
-  make_planes<DIM, PL>(x, 0, mean, scale, xs.get(), scratch_n.get(), N, st);
-  make_planes<DIM, PL>(q, 0, mean, scale, qs.get(), scratch_n.get(), Q, st);
+  make_planes<DIM, PL, T>(x, 0, mean, scale, xs.get(), scratch_n.get(), N, st);
+  make_planes<DIM, PL, T>(q, 0, mean, scale, qs.get(), scratch_n.get(), Q, st);
   Hold ci(new_tensor({Q, (int64_t)KS_M}, kI32, dev)), cv(new_tensor({Q}, kF32, dev));        // candidates (unsorted) and a_16 per query
   {
     // declared: the algorithmic work of the search, as knn_fused declares it (the f16 pipe executes PL (PL + 1) / 2 times the products)
-    KernelTimer kt(PL == 2 ? "knn_split_f16x3" : "knn_split_f16x6", 2.0 * (double)Q * N * DIM, ((double)Q + N) * DIM * 4, st);
+    KernelTimer kt(PL == 2 ? "knn_split_f16x3" : "knn_split_f16x6", 2.0 * (double)Q * N * DIM, ((double)Q + N) * DIM * sizeof(T), st);
     constexpr int BC = ks_tile_points(DIM, PL);
     const size_t lds = (size_t)2 * BC * 2 * PL * DIM + 4 * sizeof(KsWaveState);
     const float m2 = -2.f / (scale * scale);
@@ -491,8 +493,8 @@ int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
     }
   }
   HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
-  hipLaunchKernelGGL((knn_rerank_kernel<DIM>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, q->ptr<float>(), x->ptr<float>(), qn->ptr<float>(), dn->ptr<float>(),
-                     qnc->ptr<float>(), dnc_max->ptr<float>(), dn_max->ptr<float>(), KS_C_DOT, ci->ptr<int>(), cv->ptr<float>(), idx->ptr<int64_t>(), val->ptr<float>(),
+  hipLaunchKernelGGL((knn_rerank_kernel<DIM, T>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, q->ptr<T>(), x->ptr<T>(), qn->ptr<T>(), dn->ptr<T>(),
+                     qnc->ptr<float>(), dnc_max->ptr<float>(), dn_max->ptr<T>(), KS_C_DOT, ci->ptr<int>(), cv->ptr<float>(), idx->ptr<int64_t>(), val->ptr<T>(),
                      failed->ptr<int>() + 1, failed->ptr<int>(), (int)Q, (int)N, (int)k);
   LAMP_LAUNCH_CHECK();
   int nfail = 0;
@@ -501,24 +503,24 @@ int split_pass(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
   return nfail;
 }
 // the queries listed in failed[1 .. nfail] through the exact kernel
-template <int DIM>
+template <int DIM, class T>
 void exact_for_failed(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, const Tensor* failed, int nfail, int64_t N,
                       int64_t k, hipStream_t st) {
   const int dev = x->device();
-  Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, kF32, dev)), fqn(new_tensor({(int64_t)nfail}, kF32, dev));
+  Hold fq(new_tensor({(int64_t)nfail, (int64_t)DIM}, q->dtype, dev)), fqn(new_tensor({(int64_t)nfail}, q->dtype, dev));
   const int* rows = failed->ptr<int>() + 1;
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), rows, fq->ptr<float>(), (int64_t)nfail, (int64_t)DIM);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<float>(), rows, fqn->ptr<float>(), (int64_t)nfail, (int64_t)1);
+  hipLaunchKernelGGL((knn_gather_rows_kernel<T>), dim3(grid_for((int64_t)nfail * DIM, 256)), dim3(256), 0, st, q->ptr<T>(), rows, fq->ptr<T>(), (int64_t)nfail, (int64_t)DIM);
+  hipLaunchKernelGGL((knn_gather_rows_kernel<T>), dim3(grid_for((int64_t)nfail, 256)), dim3(256), 0, st, qn->ptr<T>(), rows, fqn->ptr<T>(), (int64_t)nfail, (int64_t)1);
   LAMP_LAUNCH_CHECK();
-  Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, kF32, dev));
+  Hold fi(new_tensor({(int64_t)nfail, k}, kI64, dev)), fv(new_tensor({(int64_t)nfail, k}, q->dtype, dev));
   LAMP_CHECK(knn_fused(fq.get(), x, fqn.get(), dn, fi.get(), fv.get(), nfail, N, DIM, k, st, 0), "internal: the exact kNN kernel refused the fallback queries");
-  hipLaunchKernelGGL(knn_scatter_results_kernel, dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<float>(), rows, idx->ptr<int64_t>(),
-                     val->ptr<float>(), (int64_t)nfail, k);
+  hipLaunchKernelGGL((knn_scatter_results_kernel<T>), dim3(grid_for((int64_t)nfail * k, 256)), dim3(256), 0, st, fi->ptr<int64_t>(), fv->ptr<T>(), rows, idx->ptr<int64_t>(),
+                     val->ptr<T>(), (int64_t)nfail, k);
   LAMP_LAUNCH_CHECK();
 }
 }  // namespace
 
-template <int DIM>
+template <int DIM, class T>
 static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t k,
                           hipStream_t st, bool forced) {
   const int dev = x->device();
@@ -529,25 +531,25 @@ static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, co
   Hold failed(new_tensor({Q + 1}, kI32, dev));                    // [0] = count, then the queries
   // squared norms of the centred rows (their largest sets the error bound and the scale of the f16 planes)
   Hold dnc(new_tensor({N}, kF32, dev)), qnc(new_tensor({Q}, kF32, dev));
-  make_planes<DIM, 2>(x, 0, mean.get(), 1.f, nullptr, dnc.get(), N, st);
-  make_planes<DIM, 2>(q, 0, mean.get(), 1.f, nullptr, qnc.get(), Q, st);
+  make_planes<DIM, 2, T>(x, 0, mean.get(), 1.f, nullptr, dnc.get(), N, st);
+  make_planes<DIM, 2, T>(q, 0, mean.get(), 1.f, nullptr, qnc.get(), Q, st);
   Hold dnc_max(reduce_dims(dnc.get(), nullptr, 0, false, 3)), qnc_max(reduce_dims(qnc.get(), nullptr, 0, false, 3));
   // Is the filter worth running?  An exact search of ~1000 queries spread over the query set (16 neighbours each; the data set in slices
   // over the CUs: ~3 ms at 1M points) gives their d_k and d_16; the filter proves a query when that gap exceeds twice its error bound.
   // If it would leave more than 15 % of the sample unproven, the neighbourhoods of this data are ties within f32 (lattices, duplicates)
   // and the filter would only add its time to the exact kernel's: not used.
   const int64_t S = std::min<int64_t>(Q, 1024), stride = Q / S;
-  Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, kF32, dev)), sqn(new_tensor({S}, kF32, dev)), sqc(new_tensor({S}, kF32, dev));
+  Hold ids(new_tensor({S}, kI32, dev)), sq(new_tensor({S, (int64_t)DIM}, q->dtype, dev)), sqn(new_tensor({S}, q->dtype, dev)), sqc(new_tensor({S}, kF32, dev));
   hipLaunchKernelGGL(knn_strided_ids_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, ids->ptr<int>(), S, stride);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<float>(), ids->ptr<int>(), sq->ptr<float>(), S, (int64_t)DIM);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<float>(), ids->ptr<int>(), sqn->ptr<float>(), S, (int64_t)1);
-  hipLaunchKernelGGL(knn_gather_rows_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, qnc->ptr<float>(), ids->ptr<int>(), sqc->ptr<float>(), S, (int64_t)1);
+  hipLaunchKernelGGL((knn_gather_rows_kernel<T>), dim3(grid_for(S * DIM, 256)), dim3(256), 0, st, q->ptr<T>(), ids->ptr<int>(), sq->ptr<T>(), S, (int64_t)DIM);
+  hipLaunchKernelGGL((knn_gather_rows_kernel<T>), dim3(grid_for(S, 256)), dim3(256), 0, st, qn->ptr<T>(), ids->ptr<int>(), sqn->ptr<T>(), S, (int64_t)1);
+  hipLaunchKernelGGL((knn_gather_rows_kernel<float>), dim3(grid_for(S, 256)), dim3(256), 0, st, qnc->ptr<float>(), ids->ptr<int>(), sqc->ptr<float>(), S, (int64_t)1);
   LAMP_LAUNCH_CHECK();
-  Hold si(new_tensor({S, (int64_t)KS_M}, kI64, dev)), sv(new_tensor({S, (int64_t)KS_M}, kF32, dev));
+  Hold si(new_tensor({S, (int64_t)KS_M}, kI64, dev)), sv(new_tensor({S, (int64_t)KS_M}, q->dtype, dev));
   if (!knn_fused(sq.get(), x, sqn.get(), dn, si.get(), sv.get(), S, N, DIM, KS_M, st, 0)) return false;
   HIP_CHECK(hipMemsetAsync(failed->raw(), 0, sizeof(int), st));
-  hipLaunchKernelGGL(knn_predict_kernel, dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<float>(), sqn->ptr<float>(), sqc->ptr<float>(), dnc_max->ptr<float>(),
-                     dn_max->ptr<float>(), KS_C_DOT, failed->ptr<int>(), (int)S, (int)k);
+  hipLaunchKernelGGL((knn_predict_kernel<T>), dim3(grid_for(S, 256)), dim3(256), 0, st, sv->ptr<T>(), sqn->ptr<T>(), sqc->ptr<float>(), dnc_max->ptr<float>(),
+                     dn_max->ptr<T>(), KS_C_DOT, failed->ptr<int>(), (int)S, (int)k);
   LAMP_LAUNCH_CHECK();
   int unproven = 0;
   float mx[2] = {0.f, 0.f};
@@ -562,25 +564,29 @@ static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, co
   const float scale = big > 0.f ? std::exp2(std::floor(14.f - std::log2(big))) : 1.f;
   static const int env_planes = [] { const char* e = getenv("LAMP_KNN_SPLIT_PLANES"); return e ? atoi(e) : 0; }();
   const int planes = env_planes == 3 ? 3 : 2;
-  const int nf = planes == 2 ? split_pass<DIM, 2>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st)
-                             : split_pass<DIM, 3>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st);
-  if (nf) exact_for_failed<DIM>(q, x, qn, dn, idx, val, failed.get(), nf, N, k, st);
+  const int nf = planes == 2 ? split_pass<DIM, 2, T>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st)
+                             : split_pass<DIM, 3, T>(q, x, qn, dn, dn_max.get(), mean.get(), scale, dnc.get(), dnc_max.get(), qnc.get(), idx, val, failed.get(), Q, N, k, st);
+  if (nf) exact_for_failed<DIM, T>(q, x, qn, dn, idx, val, failed.get(), nf, N, k, st);
   g_knn_split_failed = nf;
   g_knn_split_planes = planes;
   return true;
 }
 
-// f32 squared-Euclidean search of 64 / 128 features, k <= 12 (16 candidates leave a margin of at least 4).  false: not covered / not worth it.
+// f32 / f64 squared-Euclidean search of 64 / 128 features, k <= 12 (16 candidates leave a margin of at least 4).  false: not covered / not worth it.
+// (f64 - lamp's default DoublePrecision: the same f16 filter on the rows rounded to f32 after centring; the re-rank and the proof in f64.)
 bool knn_split(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor* dn, Tensor* idx, Tensor* val, int64_t Q, int64_t N, int64_t dim, int64_t k,
                hipStream_t st) {
   static const int env_mode = [] { const char* e = getenv("LAMP_KNN_SPLIT"); return e ? atoi(e) : -1; }();
   const int mode = env_mode >= 0 ? env_mode : g_knn_split_mode;
   g_knn_split_planes = 0;
-  if (mode == 0 || q->dtype != kF32 || !(dim == 64 || dim == 128) || k < 1 || k > 12 || N > 0x7fffff00 || Q > 0x7fffff00 || N < k || Q < 1) return false;
+  const bool f32 = q->dtype == kF32, f64 = q->dtype == kF64;
+  if (mode == 0 || !(f32 || f64) || !(dim == 64 || dim == 128) || k < 1 || k > 12 || N > 0x7fffff00 || Q > 0x7fffff00 || N < k || Q < 1) return false;
   if ((((uintptr_t)q->data() | (uintptr_t)x->data()) & 15) != 0) return false;
-  // the extra passes (mean, planes, sample, re-rank) and the host round trips for the verdicts cost ~0.5 ms: below ~4e9 distance evaluations the exact kernel is as fast
+  // the extra passes (mean, norms, planes, sample, re-rank) and the host round trips for the verdicts cost ~0.5 ms: below ~4e9 distance evaluations the exact kernel is as fast
   if (mode == 1 && ((double)Q * (double)N < 4.0e9 || N < 16384)) return false;
-  return dim == 128 ? knn_split_run<128>(q, x, qn, dn, idx, val, Q, N, k, st, mode == 2) : knn_split_run<64>(q, x, qn, dn, idx, val, Q, N, k, st, mode == 2);
+  const bool forced = mode == 2;
+  if (f32) return dim == 128 ? knn_split_run<128, float>(q, x, qn, dn, idx, val, Q, N, k, st, forced) : knn_split_run<64, float>(q, x, qn, dn, idx, val, Q, N, k, st, forced);
+  return dim == 128 ? knn_split_run<128, double>(q, x, qn, dn, idx, val, Q, N, k, st, forced) : knn_split_run<64, double>(q, x, qn, dn, idx, val, Q, N, k, st, forced);
 }
 
 }  // namespace lamp

@@ -590,15 +590,16 @@ def _knn(data, query, k):
     return S.STen(i).to_numpy(), S.STen(d).to_numpy()
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n,nq,d,k", [(20000, 1500, 128, 10), (5000, 700, 64, 12), (16, 40, 128, 3), (3001, 257, 128, 1), (70, 300, 64, 10)])
-def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
+def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k, dt):
     """knn_split.hip forced on small problems (mode 2): standard-normal data, where the filter proves (nearly) every query, against the exact
     fused kernel (mode 0) and the oracle.  Index sets equal on every row whose k-th / (k+1)-th neighbours are separated by more than the
     f32 formula's own noise; distances within that noise; rows sorted by distance."""
     g = torch.Generator().manual_seed(4242 + n)
     data64 = torch.randn(n, d, generator=g, dtype=torch.float64)
     rows = _well_separated_queries(data64, torch.arange(0, n, max(n // nq, 1))[:nq], min(k, n - 1), 1e-3) if n > k else torch.arange(min(nq, n))
-    data, query = data64.float(), data64[rows].float()
+    data, query = data64.to(dt), data64[rows].to(dt)
     try:
         lib.lamp_knn_split_mode(0)
         ei, ed = _knn(data, query, k)
@@ -621,7 +622,7 @@ def test_knn_split_filter_returns_the_exact_search(gpu, n, nq, d, k):
     assert np.array_equal(np.sort(si, 1), np.sort(ref.numpy(), 1)), "and as the reference algorithm"
     assert (np.diff(sd, axis=1) >= 0).all()
     exact = torch.gather(O.squared_euclidean_distance(data64[rows], data64), 1, torch.from_numpy(si))
-    assert (torch.from_numpy(sd).double() - exact).abs().max().item() <= 2e-4     # |q|^2 ~ d: a few ulp of 2 d
+    assert (torch.from_numpy(sd).double() - exact).abs().max().item() <= (2e-4 if dt == torch.float32 else 1e-10)     # f32: |q|^2 ~ d, a few ulp of 2 d
     assert 0 <= failed.value <= max(2, len(rows) // 50), f"{failed.value} of {len(rows)} queries needed the exact kernel on centred data"
 
 
