@@ -31,10 +31,16 @@ struct MultiArgs {
 
 static_assert(sizeof(MultiArgs) <= 4096, "MultiArgs is passed by value: HIP kernel arguments are limited to 4 KB");
 
+// the tensor whose chunks contain workgroup chunk `blk`: binary search (the descriptor lives in the kernel-argument segment: every probe
+// is a dependent scalar load, and the linear walk over 40 tensors cost a 2-KB chunk more than its data did - 0.8 TB/s in the
+// gradient-norm kernels of the language model)
 __device__ __forceinline__ int mt_find(const MultiArgs& a, int blk) {
-  int t = 0;
-  while (t + 1 < a.n && blk >= a.blk_start[t + 1]) t++;
-  return t;
+  int lo = 0, hi = a.n - 1;                   // invariant: blk_start[lo] <= blk < blk_start[hi + 1]
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk >= a.blk_start[mid]) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
 // AdamW.scala:124-166.  T = parameter/optimizer-state dtype (f32 or f64; bf16 state allowed),
@@ -104,15 +110,35 @@ __global__ __launch_bounds__(256) void sgdw_kernel(MultiArgs a) {
 
 // sum of squares per workgroup -> partial[blockIdx.x] (deterministic two stage reduction)
 template <class T>
-__global__ __launch_bounds__(256) void mt_sumsq_kernel(MultiArgs a, acc_t<T>* __restrict__ partial) {
+__global__ __launch_bounds__(256) void mt_sumsq_kernel(MultiArgs a, acc_t<T>* __restrict__ partial, int per_wg) {
   using A = acc_t<T>;
   __shared__ A sm[4];
-  const int t = mt_find(a, blockIdx.x);
-  const int64_t begin = (int64_t)(blockIdx.x - a.blk_start[t]) * MT_CHUNK;
-  const int64_t end = min(begin + MT_CHUNK, a.numel[t]);
-  const T* g = (const T*)a.p[0][t];
+  // a workgroup takes `per_wg` consecutive chunks (a 2-KB chunk per workgroup is bound by the dispatch rate: 21 k workgroups in 46 us)
   A acc = 0;
-  for (int64_t i = begin + threadIdx.x; i < end; i += blockDim.x) { const A x = load_as<A>(g[i]); acc += x * x; }
+  const int nblk = a.blk_start[a.n];
+  int t = blockIdx.x * per_wg < nblk ? mt_find(a, blockIdx.x * per_wg) : 0;
+  for (int j = 0; j < per_wg; j++) {
+    const int blk = blockIdx.x * per_wg + j;
+    if (blk >= nblk) break;
+    while (blk >= a.blk_start[t + 1]) t++;
+    const int64_t begin = (int64_t)(blk - a.blk_start[t]) * MT_CHUNK;
+    const int64_t end = min(begin + MT_CHUNK, a.numel[t]);
+    const T* g = (const T*)a.p[0][t];
+    // 16-byte packets where the chunk starts on one
+    constexpr int W = 16 / sizeof(T);
+    int64_t i0 = begin;
+    if ((((uintptr_t)(g + begin)) & 15) == 0) {
+      const int64_t nv = (end - begin) / W;
+      const Vec<T, W>* gv = reinterpret_cast<const Vec<T, W>*>(g + begin);
+      for (int64_t v = threadIdx.x; v < nv; v += blockDim.x) {
+        const Vec<T, W> pk = gv[v];
+#pragma unroll
+        for (int k = 0; k < W; k++) { const A x = load_as<A>(pk.v[k]); acc += x * x; }
+      }
+      i0 = begin + nv * W;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < end; i += blockDim.x) { const A x = load_as<A>(g[i]); acc += x * x; }
+  }
   acc = block_sum(acc, sm);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
@@ -127,18 +153,37 @@ __global__ __launch_bounds__(256) void mt_accumulate_kernel(const A* __restrict_
 }
 // g *= min(1, theta / sqrt(total))     nn/package.scala:88-97
 template <class T>
-__global__ __launch_bounds__(256) void mt_clip_scale_kernel(MultiArgs a, const acc_t<T>* __restrict__ total) {
+__global__ __launch_bounds__(256) void mt_clip_scale_kernel(MultiArgs a, const acc_t<T>* __restrict__ total, int per_wg) {
   using A = acc_t<T>;
-  const int t = mt_find(a, blockIdx.x);
-  const int64_t begin = (int64_t)(blockIdx.x - a.blk_start[t]) * MT_CHUNK;
-  const int64_t end = min(begin + MT_CHUNK, a.numel[t]);
-  T* g = (T*)a.p[0][t];
   // same rounding points as the reference: norm = sqrt(sum) in the gradient dtype, scalar = theta/norm, min(scalar, 1)
   const A norm = (A)load_as<A>(store_as<T>((A)sqrt((double)total[0])));
   A sc = (A)a.s[0] / norm;
   sc = sc < A(1) ? sc : A(1);
   if (sc != sc) sc = A(1) < sc ? A(1) : sc;  // NaN norm: ATen minimum propagates NaN
-  for (int64_t i = begin + threadIdx.x; i < end; i += blockDim.x) g[i] = store_as<T>((A)(load_as<A>(g[i]) * sc));
+  const int nblk = a.blk_start[a.n];
+  int t = blockIdx.x * per_wg < nblk ? mt_find(a, blockIdx.x * per_wg) : 0;
+  for (int j = 0; j < per_wg; j++) {
+    const int blk = blockIdx.x * per_wg + j;
+    if (blk >= nblk) break;
+    while (blk >= a.blk_start[t + 1]) t++;
+    const int64_t begin = (int64_t)(blk - a.blk_start[t]) * MT_CHUNK;
+    const int64_t end = min(begin + MT_CHUNK, a.numel[t]);
+    T* g = (T*)a.p[0][t];
+    constexpr int W = 16 / sizeof(T);
+    int64_t i0 = begin;
+    if ((((uintptr_t)(g + begin)) & 15) == 0) {
+      const int64_t nv = (end - begin) / W;
+      Vec<T, W>* gv = reinterpret_cast<Vec<T, W>*>(g + begin);
+      for (int64_t v = threadIdx.x; v < nv; v += blockDim.x) {
+        Vec<T, W> pk = gv[v];
+#pragma unroll
+        for (int k = 0; k < W; k++) pk.v[k] = store_as<T>((A)(load_as<A>(pk.v[k]) * sc));
+        gv[v] = pk;
+      }
+      i0 = begin + nv * W;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < end; i += blockDim.x) g[i] = store_as<T>((A)(load_as<A>(g[i]) * sc));
+  }
 }
 
 // bucket[off_t + i] = scale * t[i] (as f32) ; p[0] = tensors, h[0][t] = element offset inside the bucket
@@ -242,15 +287,20 @@ int lamp_gradient_clipping_(lamp_tensor* const* grads, int n, double theta) {
     bool first = true;
     for_each_group(n, numels.data(), [&](MultiArgs& a, int t, int gi) { a.p[0][t] = grads[gi]->data(); },
                    [&](MultiArgs& a, int blk) {
-                     int64_t ps[1] = {blk};
+                     // up to 16 chunks per workgroup once there are more than 8 chunks per CU (small models keep one: the ResNet has 383 chunks)
+                     const int per_wg = std::min(16, std::max(1, blk / (8 * num_cus()))), wgs = (blk + per_wg - 1) / per_wg;
+                     int64_t ps[1] = {wgs};
                      Hold partial(new_tensor(ps, 1, adt, dev));
-                     hipLaunchKernelGGL((mt_sumsq_kernel<T>), dim3(blk), dim3(256), 0, st, a, partial->ptr<A>());
-                     hipLaunchKernelGGL((mt_accumulate_kernel<A>), dim3(1), dim3(256), 0, st, partial->ptr<A>(), blk, total->ptr<A>(), first ? 1 : 0);
+                     hipLaunchKernelGGL((mt_sumsq_kernel<T>), dim3(wgs), dim3(256), 0, st, a, partial->ptr<A>(), per_wg);
+                     hipLaunchKernelGGL((mt_accumulate_kernel<A>), dim3(1), dim3(256), 0, st, partial->ptr<A>(), wgs, total->ptr<A>(), first ? 1 : 0);
                      first = false;
                    });
     LAMP_LAUNCH_CHECK();
     for_each_group(n, numels.data(), [&](MultiArgs& a, int t, int gi) { a.p[0][t] = grads[gi]->data(); a.s[0] = theta; },
-                   [&](MultiArgs& a, int blk) { hipLaunchKernelGGL((mt_clip_scale_kernel<T>), dim3(blk), dim3(256), 0, st, a, total->ptr<A>()); });
+                   [&](MultiArgs& a, int blk) {
+                     const int per_wg = std::min(16, std::max(1, blk / (8 * num_cus()))), wgs = (blk + per_wg - 1) / per_wg;
+                     hipLaunchKernelGGL((mt_clip_scale_kernel<T>), dim3(wgs), dim3(256), 0, st, a, total->ptr<A>(), per_wg);
+                   });
     LAMP_LAUNCH_CHECK();
   });
   LAMP_API_END
