@@ -443,6 +443,7 @@ bool knn_fused(const Tensor* q, const Tensor* x, const Tensor* qn, const Tensor*
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
 
 namespace {
+// (process-wide switches and diagnostics, not synchronised: set the mode before searching from several threads)
 int g_knn_split_mode = 1;      // 0 never, 1 where it pays (large searches), 2 whenever the shape is covered (tests)
 int64_t g_knn_split_failed = 0;
 int g_knn_split_planes = 0;    // planes of the last search (0: the split path did not run)
@@ -560,7 +561,7 @@ static bool knn_split_run(const Tensor* q, const Tensor* x, const Tensor* qn, co
   if (!forced && (int64_t)unproven * 100 > 15 * S) return false;
   // a power of two that puts the largest coordinate of any centred row at or below 2^14 (f16 holds 65504)
   const float big = std::sqrt(std::max(mx[0], mx[1]));
-  LAMP_CHECK(std::isfinite(big), "knn: the data or the queries contain non-finite values");
+  if (!std::isfinite(big)) return false;                          // NaN / Inf in the data or the queries: the exact kernel's behaviour, not an error of this path
   const float scale = big > 0.f ? std::exp2(std::floor(14.f - std::log2(big))) : 1.f;
   static const int env_planes = [] { const char* e = getenv("LAMP_KNN_SPLIT_PLANES"); return e ? atoi(e) : 0; }();
   const int planes = env_planes == 3 ? 3 : 2;
