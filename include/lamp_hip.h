@@ -633,15 +633,17 @@ int lamp_knn_jaccard(lamp_tensor** indices, lamp_tensor** distances_or_null, con
  * term_weights reproduces how lamp's IndexSelect backward (`out += out.indexAdd(..)`, ops.scala:186-191)
  * accumulates the four gathers into one buffer: {1, 2, 4, 8} in the reference's traversal order;
  * pass {1, 1, 1, 1} for the mathematical gradient. */
-/* knnDistances of Umap.umap (umap.scala:382-402, a JVM loop in the reference): out[i, j] = exact f64 Euclidean distance
- * between data row i and data row indices[i, j], summed left to right over the columns.  out is [n, k] f64. */
-/* Large f32 squared-Euclidean searches (64 / 128 features, k <= 12) run a filter on the 16-bit matrix pipe (every value split exactly into
- * two f16 pieces, three products per feature) that keeps 16 candidates per query, re-rank them with exact f32 distances, and PROVE per
- * query that no other point can be among the k nearest; queries without proof go through the exact kernel.  The result is that of the
- * exact search (kernels/knn_split.hip).  mode 0: never, 1: where it pays (default), 2: whenever the shape is covered. */
+/* lamp_knn_squared_euclidean (knnSearch with SquaredEuclideanDistance, knn/package.scala:60-121) on large f32 / f64 searches (64 / 128
+ * features, k <= 12) runs a filter on the 16-bit matrix pipe (every value split exactly into two f16 pieces, three products per feature)
+ * that keeps 16 candidates per query, re-ranks them with exact distances in the data's precision, and PROVES per query that no other
+ * point can be among the k nearest; queries without proof go through the exact kernel.  The result is that of the exact search
+ * (kernels/knn_split.hip).  mode 0: never, 1: where it pays (default), 2: whenever the shape is covered.  Process-wide; no counterpart
+ * in the reference (its ATen call has one implementation). */
 int lamp_knn_split_mode(int mode);
 int lamp_knn_split_last_failed(int64_t* out);   /* queries of the last split search that needed the exact kernel */
 int lamp_knn_split_last_planes(int* out);       /* f16 planes per value it used (2; 0: the split path did not run) */
+/* knnDistances of Umap.umap (umap.scala:382-402, a JVM loop in the reference): out[i, j] = exact f64 Euclidean distance
+ * between data row i and data row indices[i, j], summed left to right over the columns.  out is [n, k] f64. */
 int lamp_knn_row_distances(lamp_tensor** out, const lamp_tensor* data, const lamp_tensor* indices);
 /* Umap.edgeWeights (umap.scala:50-113, JVM double loops in the reference): per point the smallest positive kNN
  * distance rho and the bisection for sigma (Umap.binarySearch, umap.scala:14-48), then for every neighbour j != i
