@@ -42,7 +42,7 @@ def knn(d: S.STen, query: S.STen, k: int, distanceMatrix: _Distance = SquaredEuc
 def knnMinibatched(d: S.STen, query: S.STen, k: int, distanceMatrix: _Distance = SquaredEuclideanDistance, minibatchSize: int = 1 << 30) -> S.STen:
     rows = query.shape[0]
     step = max(1, min(int(minibatchSize), rows))
-    # the kernel streams the data set once per launch (and the split-bf16 path prepares the data set once per call): merge the
+    # the kernel streams the data set once per launch (and the split-f16 path prepares the data set once per call): merge the
     # reference's small minibatches into launches of up to 1048576 rows
     step = max(step, min(rows, 1048576) // step * step)
     parts = [knn(d, query.slice(0, lo, min(lo + step, rows)), k, distanceMatrix) for lo in range(0, rows, step)]

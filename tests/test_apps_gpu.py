@@ -583,7 +583,7 @@ def test_umap_mnist_meets_the_reference_acceptance(gpu):
     assert purity > 0.6, f"neighbour purity {purity}"                  # measured 0.74
 
 
-# ---- large f32 searches through the bf16 matrix pipe (kernels/knn_split.hip, round 3) ---------------------------------------------------
+# ---- large f32 / f64 searches through the f16 matrix pipe (kernels/knn_split.hip, round 3) ---------------------------------------------------
 def _knn(data, query, k):
     i, d = C.c_void_p(), C.c_void_p()
     lib.lamp_knn_squared_euclidean(C.byref(i), C.byref(d), to_sten(data), to_sten(query), k)
