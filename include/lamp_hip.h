@@ -219,6 +219,8 @@ int lamp_squeeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim);   /* dim
 int lamp_unsqueeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim);
 int lamp_cat(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim);
 int lamp_cat_out(lamp_tensor* out, lamp_tensor* const* ts, int n, int64_t dim);
+/* outs[i] = x.chunk(n, dim)[i].contiguous() for equal chunks: what `ATen.chunk` / `slice` followed by `contiguous` give (STen.scala: slice, chunk), in one launch */
+int lamp_chunk_contiguous(lamp_tensor** outs, const lamp_tensor* x, int n, int64_t dim);
 int lamp_stack(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim);
 
 /* ------------------------------------------------------------------------------------------

@@ -842,7 +842,48 @@ int lamp_unsqueeze(lamp_tensor** out, const lamp_tensor* t, int64_t dim) {
   LAMP_API_END
 }
 
+// up to eight contiguous row blocks side by side in ONE launch (a copy per input costs a launch each: the packed projection weights of
+// the language model are three 768 x 768 blocks, 4.7 us per launch against 0.3 us of data).  dir 0: out[r][off_i + c] = part_i[r][c]
+// (cat along the last dimension), dir 1: part_i[r][c] = whole[r][off_i + c] (the inverse).  16-byte packets.
+struct ColBlocks { char* part[8]; int64_t width[8], off[8]; int n; int64_t rows, row_bytes; };   // widths / offsets in 16-byte packets
+__global__ __launch_bounds__(256) void col_blocks_kernel(ColBlocks a, char* whole, int dir) {
+  const int64_t per_row = a.row_bytes / 16, total = a.rows * per_row;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / per_row, c = e - r * per_row;
+    int i = 0;
+    while (i + 1 < a.n && c >= a.off[i + 1]) i++;
+    uint4* w = reinterpret_cast<uint4*>(whole) + e;
+    uint4* p = reinterpret_cast<uint4*>(a.part[i]) + r * a.width[i] + (c - a.off[i]);
+    if (dir == 0) *w = *p; else *p = *w;
+  }
+}
+// the 2-D view (rows, bytes per row) of a device tensor cut at dimension d, or false
+static bool col_block_of(const Tensor* t, int64_t d, int64_t* rows, int64_t* row_bytes) {
+  if (!t->is_device() || !t->is_contiguous() || t->numel() == 0) return false;
+  int64_t r = 1, w = (int64_t)t->itemsize();
+  for (int k = 0; k < t->ndim; k++) { if (k < d) r *= t->sizes[k]; else w *= t->sizes[k]; }
+  if (w % 16 != 0 || ((uintptr_t)t->raw() & 15) != 0) return false;
+  *rows = r; *row_bytes = w;
+  return true;
+}
+static bool cat_into_one_launch(Tensor* out, lamp_tensor* const* ts, int n, int64_t d) {
+  if (n < 2 || n > 8) return false;
+  ColBlocks a{};
+  int64_t rows = 0, wb = 0, orows = 0, owb = 0, pos = 0;
+  if (!col_block_of(out, d, &orows, &owb)) return false;
+  for (int i = 0; i < n; i++) {
+    if (ts[i]->dtype != out->dtype || ts[i]->device() != out->device() || !col_block_of(ts[i], d, &rows, &wb) || rows != orows) return false;
+    a.part[i] = const_cast<char*>(static_cast<const char*>(static_cast<const Tensor*>(ts[i])->raw()));
+    a.width[i] = wb / 16; a.off[i] = pos; pos += wb / 16;
+  }
+  if (pos * 16 != owb) return false;
+  a.n = n; a.rows = orows; a.row_bytes = owb;
+  hipLaunchKernelGGL(col_blocks_kernel, dim3(grid_for(orows * (owb / 16), 256)), dim3(256), 0, current_stream(out->device()), a, static_cast<char*>(out->raw()), 0);
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
 static void cat_into(Tensor* out, lamp_tensor* const* ts, int n, int64_t d) {
+  if (cat_into_one_launch(out, ts, n, d)) return;
   int64_t pos = 0;
   for (int i = 0; i < n; i++) {
     if (ts[i]->ndim == 1 && ts[i]->sizes[0] == 0 && out->ndim != 1) continue;  // legacy empty tensor
@@ -889,6 +930,39 @@ int lamp_cat_out(lamp_tensor* out, lamp_tensor* const* ts, int n, int64_t dim) {
   auto shape = cat_shape(ts, n, dim, &d);
   LAMP_CHECK(out->shape() == shape, "cat_out: output shape mismatch");
   cat_into(out, ts, n, d);
+  LAMP_API_END
+}
+// outs[i] = x.chunk(n, dim)[i].contiguous() (equal chunks) - one launch where the blocks are whole 16-byte packets
+int lamp_chunk_contiguous(lamp_tensor** outs, const lamp_tensor* x, int n, int64_t dim) {
+  LAMP_API_BEGIN NOT_NULL(x);
+  LAMP_CHECK(n >= 1, "chunk_contiguous: n must be positive");
+  const int64_t d = wrap_dim(dim, x->ndim);
+  LAMP_CHECK(x->sizes[d] % n == 0, "chunk_contiguous: dimension " << d << " of " << x->describe() << " does not divide into " << n << " equal chunks");
+  const int64_t len = x->sizes[d] / n;
+  std::vector<int64_t> shape = x->shape();
+  shape[d] = len;
+  std::vector<Hold> parts;
+  for (int i = 0; i < n; i++) parts.emplace_back(new_tensor(shape, x->dtype, x->device()));
+  bool done = false;
+  int64_t rows = 0, wb = 0, prow = 0, pwb = 0;
+  if (n >= 2 && n <= 8 && col_block_of(x, d, &rows, &wb) && col_block_of(parts[0].get(), d, &prow, &pwb) && prow == rows && pwb * n == wb) {
+    ColBlocks a{};
+    for (int i = 0; i < n; i++) { a.part[i] = static_cast<char*>(parts[i]->raw()); a.width[i] = pwb / 16; a.off[i] = i * (pwb / 16); }
+    a.n = n; a.rows = rows; a.row_bytes = wb;
+    hipLaunchKernelGGL(col_blocks_kernel, dim3(grid_for(rows * (wb / 16), 256)), dim3(256), 0, current_stream(x->device()), a,
+                       const_cast<char*>(static_cast<const char*>(x->raw())), 1);
+    LAMP_LAUNCH_CHECK();
+    done = true;
+  }
+  if (!done) {
+    for (int i = 0; i < n; i++) {
+      lamp_tensor* v = nullptr;
+      LAMP_CHECK(lamp_narrow(&v, x, d, i * len, len) == 0, lamp_last_error());
+      Hold hv(v);
+      copy_into(parts[i].get(), v);
+    }
+  }
+  for (int i = 0; i < n; i++) outs[i] = parts[i].take();
   LAMP_API_END
 }
 int lamp_stack(lamp_tensor** out, lamp_tensor* const* ts, int n, int64_t dim) {

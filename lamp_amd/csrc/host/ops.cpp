@@ -584,7 +584,7 @@ Var packed_self_attention(const Var& x, const Var& wq, const Var& wk, const Var&
   HCALL(lamp_scaled_dot_product_attention_bias(&o, &l, q4.h(), k4.h(), v4.h(), nullptr, isCausal, 0.0));
   const Ten out(o), lse(l);
   const Ten value = ops::flatten(ops::transpose(out, 1, 2), 2, 3);                  // (B, S, heads x d): a view when the kernel wrote (B, S, heads, d) storage
-  struct Cache { Ten dqkv, dwcat, p; };
+  struct Cache { Ten dqkv, dw[3], p; };
   auto cache = std::make_shared<Cache>();
   auto ensure = [=](const Ten& p) {
     if (cache->p.defined() && cache->p.h() == p.h()) return;
@@ -604,8 +604,11 @@ Var packed_self_attention(const Var& x, const Var& wq, const Var& wk, const Var&
     lamp_tensor* dw = nullptr;
     const int64_t ws[2] = {in, 3 * HD};
     HCALL(lamp_empty(&dw, ws, 2, xv.dtype(), xv.device()));
-    cache->dwcat = Ten(dw);
+    const Ten dwcat(dw);
     HCALL(lamp_addmm_out_transposed1(dw, dw, x2.h(), cache->dqkv.h(), 0.0, 1.0));     // d[Wq | Wk | Wv] = x^T . [dq | dk | dv]
+    lamp_tensor* parts[3] = {nullptr, nullptr, nullptr};
+    HCALL(lamp_chunk_contiguous(parts, dw, 3, 1));                                    // the three weights' gradients, dense, in one launch
+    for (int i = 0; i < 3; i++) cache->dw[i] = Ten(parts[i]);
     cache->p = p;
   };
   op->params.push_back({x, [=](const Ten& p, Variable& o_) {                          // dX += [dq | dk | dv] . [Wq | Wk | Wv]^T
@@ -618,8 +621,9 @@ Var packed_self_attention(const Var& x, const Var& wq, const Var& wk, const Var&
   auto wback = [=](int which) {
     return [=](const Ten& p, Variable& o_) {
       ensure(p);
-      o_.accumulate(dense_copy_if_needed(ops::slice(cache->dwcat, 1, which * HD, (which + 1) * HD, 1)), true);
-      if (which == 2) { cache->dqkv = Ten(); cache->dwcat = Ten(); cache->p = Ten(); }
+      o_.accumulate(cache->dw[which], true);
+      cache->dw[which] = Ten();
+      if (which == 2) { cache->dqkv = Ten(); cache->p = Ten(); }
     };
   };
   op->params.push_back({wq, wback(0)});

@@ -1425,3 +1425,24 @@ def test_convolution_of_batch_norm_relu_equals_the_chain(gpu, dt, shape):
     pre = torch.relu(torch.addcmul(b.float().view(view), x.float() - to_torch(smf).float().view(view), (to_torch(sif).float() * g.float()).view(view)).to(dt))
     ref = aten.convolution(pre.double(), w.double(), cb.double(), [1, 1], [p, p], [1, 1], False, [0, 0], 1)
     assert_close(to_torch(yf), ref, {torch.float32: 1e-4, torch.bfloat16: 2.0 ** -6}[dt], "conv(relu(bn(x))) vs ATen", scale="max")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float64])
+def test_cat_and_chunk_in_one_launch(gpu, dt):
+    """cat of contiguous blocks (16-byte multiples: one launch, `col_blocks_kernel`; anything else: a copy per input) and its inverse
+    lamp_chunk_contiguous, along every dimension, against torch."""
+    for shape, dim, n in (((768, 768), 1, 3), ((5, 8, 16), 2, 2), ((5, 8, 16), 1, 4), ((6, 24), 0, 3), ((7, 5), 1, 2), ((3, 8), 1, 8)):
+        parts = [closed_form(shape, 3 + 5 * i, 2.0, dt) for i in range(n)]
+        hs = [to_sten(p) for p in parts]
+        arr = (C.c_void_p * n)(*[h.h for h in hs])
+        o = C.c_void_p()
+        lib.lamp_cat(C.byref(o), arr, n, dim)
+        whole = S.STen(o)
+        ref = torch.cat(parts, dim)
+        assert torch.equal(to_torch(whole), ref.double()), (shape, dim, n)
+        outs = (C.c_void_p * n)()
+        lib.lamp_chunk_contiguous(outs, whole, n, dim)
+        for i in range(n):
+            assert torch.equal(to_torch(S.STen(outs[i])), parts[i].double()), (shape, dim, n, i)
+    with pytest.raises(Exception, match="equal chunks"):
+        lib.lamp_chunk_contiguous((C.c_void_p * 2)(), to_sten(closed_form((3, 5), 1, 1.0, dt)), 2, 1)
