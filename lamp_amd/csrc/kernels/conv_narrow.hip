@@ -231,6 +231,13 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
   const int co = NS == 2 ? (lane & 7) : (lane & 15);
   const int ncg = q.Wo / P, TR = 16 / ncg;
+  // The first image's packets are requested before anything else: a workgroup lives for two or three images, and in-kernel stamps
+  // (scripts/ncv_stamp_probe.py) showed 3800 - 6300 of its 11 - 20 k cycles between "weights in registers" and "first image in LDS" -
+  // the HBM round trip of that first load, started only after the weights had arrived and the LDS was zeroed.
+  const int64_t img_in = (int64_t)q.C * q.H * q.W;
+  NcvPre pre;
+  const NcvPlan plan = ncv_stage_plan(q, tid, nthreads);
+  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, plan, src + blockIdx.x * img_in, tid, nthreads);
   nv_bf8 wfr[NK];
   int koff[NK];
 #pragma unroll
@@ -252,10 +259,6 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   // A-side lane -> (row within the super-tile, column group)
   const int a_tr = (lane & 15) / ncg, a_cg = (lane & 15) - a_tr * ncg;
   const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
-  const int64_t img_in = (int64_t)q.C * q.H * q.W;
-  NcvPre pre;
-  const NcvPlan plan = ncv_stage_plan(q, tid, nthreads);
-  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, plan, src + blockIdx.x * img_in, tid, nthreads);
   for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
     __syncthreads();                                     // zero fill / the previous image's reads are done
     NCV_STAMP_ONCE(2);
