@@ -631,6 +631,7 @@ def main():
             sps = per_gpu / units_per_step                                    # steps per second and GPU
             line["step_roofline"] = {"algorithmic_tflops": decl_f * sps / 1e12, "frac_bf16_mfma_peak": decl_f * sps / 1e12 / PEAK_BF16_TFLOPS,
                                      "algorithmic_GBps": decl_b * sps / 1e9, "frac_hbm_peak": decl_b * sps / 1e9 / PEAK_HBM_GBS,
+                                     "frac_f32_mfma_peak": (decl_f * sps / 1e12 / PEAK_F32_TFLOPS) if a.dtype == "f32" else None,
                                      "declared_bytes_per_step": decl_b, "declared_flops_per_step": decl_f,
                                      "source": "sum of the launchers' declared algorithmic bytes / flops over every kernel class of one eager step",
                                      "survey_estimate": {"flops_per_sample": 153.3e6, "bytes_per_sample": 1.4e6,

@@ -295,6 +295,11 @@ bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvG
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine = nullptr);
 bool igemm_conv_folds_affine(const ConvGeom& g, int dtype);
 bool igemm_conv_fwd_affine(const Tensor* x, const Tensor* affine, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+// implemented in conv_igemm_f32.hip (the same layers in f32, on the f32 matrix instructions)
+bool igemm32_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool igemm32_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
+                        bool* addend_fused = nullptr);
+bool igemm32_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 // implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
@@ -354,8 +359,8 @@ int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
   Hold y(new_tensor(oshape, x->dtype, x->device()));
   hipStream_t st = current_stream(x->device());
   if (!transposed) {
-    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !narrow_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) &&
-        !small_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
+    if (!igemm_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !igemm32_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) &&
+        !narrow_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st) && !small_conv_fwd(xc.get(), wc.get(), bc.get(), y.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_fwd<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
     }
   } else {
@@ -384,12 +389,12 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
   Hold dw(mask[1] ? new_like(wc.get()) : nullptr);
   Hold db;
   if (!transposed) {
-    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) &&
-        !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+    if (dx.get() && !igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !igemm32_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) &&
+        !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
     }
-    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !narrow_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) &&
-        !small_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
+    if (dw.get() && !igemm_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !igemm32_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) &&
+        !narrow_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st) && !small_conv_wgrad(gc.get(), xc.get(), dw.get(), g, st)) {
       LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_wgrad<T>(gc.get(), xc.get(), dw.get(), g, st)));
     }
   } else {
@@ -500,8 +505,8 @@ int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* gr
   hipStream_t st = current_stream(x->device());
   Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
   bool fused = false;
-  if (!igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) &&
-      !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+  if (!igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !igemm32_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) &&
+      !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
     LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
   }
   if (fused) { *out = dx.take(); }

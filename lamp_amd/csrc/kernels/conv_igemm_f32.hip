@@ -1,0 +1,544 @@
+// Implicit-GEMM convolution in f32 on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 fused multiply-adds, the result is a
+// k-ordered fmaf chain) for the wide layers of the CIFAR ResNet - the precision the reference's example runs in
+// (example-cifar100/src/main/scala/lamp/example/cifar/cifar100.scala:127-129, model cnn.scala:89-137, operator ops.scala:1547-1651).
+//
+// Scope: f32, NCHW, H = W = 8, kernel 3x3 (pad 1) or 1x1 (pad 0), stride 1, dilation 1, groups 1, Cin and Cout <= 128 and multiples of 4.
+//
+// The f32 matrix pipe runs at 1/16 of the bf16 rate (256 FLOP per clock and CU), so these kernels are bound by MFMA issue and by nothing
+// else: a 128 -> 128 3x3 layer needs 74 k matrix cycles per image against 64 KiB of activations.  The design therefore spends nothing
+// on data movement cleverness and everything on keeping the pipe busy:
+//  * fprop and dgrad are ONE kernel (dgrad = fprop of dY with the weights transposed and the taps mirrored).  A workgroup owns four
+//    images; wave (image, half) multiplies the 64 pixels of its image with one half of the output-channel tiles (4 + 4, or 4 + 3 for
+//    100 channels) - the two waves of a SIMD fill each other's gaps.  D rows = pixels, D columns = output channels.
+//  * The images sit in LDS exactly as they sit in memory (NCHW rows of 64 f32 = 256 bytes), brought in by LDS-DMA with no register
+//    staging and no transposition: the pixel operand of an MFMA is ONE f32 per lane (A[pixel = lane & 15][k = lane >> 4]), i.e. a
+//    ds_read_b32, and a b32 read has no alignment: the tap shift is a byte offset, pixels outside the image are zeroed in registers.
+//    A 1 KiB DMA piece holds four channels; pieces are 1088 bytes apart so that the two lane groups of a half wave (k = channel 4q + j,
+//    q = 0 / 1 or 2 / 3: adjacent pieces) are 16 banks apart.
+//  * K runs over 16-channel chunks (outer) and taps (inner).  The weights of one (chunk, tap) - [128 output channels][16 input channels],
+//    8 KiB, 64-byte rows with the 16-byte chunks XOR-swizzled exactly as conv_igemm.hip's eight-image kernel - arrive by LDS-DMA in a
+//    two-slot ring, two stages ahead; a lane's ds_read_b128 of a weight row delivers the operands of FOUR k-steps: k-step j of lane group q is
+//    channel 4q + j, which is also what the pixel side reads.
+//  * The fragments of stage t + 1 are read while stage t multiplies (two register sets), one barrier per stage.
+//  * wgrad: dW[tap][co][ci] = sum over images and pixels of dY[co][p] X[ci][p + shift(tap)], K = pixels.  Workgroup = (16-channel tile
+//    of Cin, image range), wave = 16-channel tile of Cout x all nine taps (36 accumulator registers).  dY arrives by LDS-DMA ([co][64 px],
+//    16-byte chunks XOR-swizzled by the row), X through registers into rows of 65 dwords.  Per image a lane reads four dY fragments and
+//    the 34 X values its k-slots can meet under any tap (X[ci][16q - 9 .. 16q + 24]) ONCE; every MFMA then takes its operands straight
+//    from those registers.  Taps whose column falls outside the image for a whole k-step are skipped (132 instead of 144 MFMAs per image).
+//    The f32 partial sums per image range are reduced by the batched kernel of wgrad_reduce.hip.
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "device_utils.h"
+#include "conv_geom.h"
+#include "wgrad_reduce.h"
+
+namespace lamp {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char_t;
+typedef const __attribute__((address_space(1))) char glb_char_t;
+
+constexpr int F_ROWS = 128;             // rows of a packed weight image (output channels, zero padded)
+constexpr int F_WT = F_ROWS * 16 * 4;   // one weight stage: 128 rows x 16 k, f32
+constexpr int F_PSTR = 1088;            // LDS distance of two 4-channel image pieces
+constexpr int F_NI = 4;                 // images per workgroup
+
+// ---- weight packing ---------------------------------------------------------------------------------
+// fprop: wp[rs][co][ci] = W[co][ci][r][s]            (rows = Cout, k = Cin, row length KPf = round16(Cin))
+// dgrad: wp[rs][ci][co] = W[co][ci][kh-1-r][kw-1-s]  (rows = Cin,  k = Cout, row length KPd = round16(Cout))
+constexpr int F_PACK_MAX = 16;
+struct PackManyF32 { const float* w[F_PACK_MAX]; float* wp[F_PACK_MAX]; int Cout[F_PACK_MAX], Cin[F_PACK_MAX], KS[F_PACK_MAX], KPf[F_PACK_MAX], KPd[F_PACK_MAX]; };
+__global__ void ig32_pack_weights_many_kernel(PackManyF32 a) {
+  const int t = blockIdx.y;
+  const float* __restrict__ w = a.w[t];
+  float* __restrict__ wp = a.wp[t];
+  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], KPf = a.KPf[t], KPd = a.KPd[t];
+  const int RS = KS * KS;
+  const int nf = RS * F_ROWS * KPf, total = nf + RS * F_ROWS * KPd;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const int dgrad = e0 >= nf;
+    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
+    const int k = e % KP, row = (e / KP) % F_ROWS, rs = e / (KP * F_ROWS);
+    const int r = rs / KS, s = rs % KS;
+    float v = 0.f;
+    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
+    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
+    wp[e0] = v;
+  }
+}
+
+// ---- fprop / dgrad -----------------------------------------------------------------------------------
+// x [N][CI][64], wp [RS][128][KP], y [N][CO][64]; KP = round16(CI).  NCT = 16-channel tiles of the output; SPLITPX: the two waves of
+// an image split its PIXELS instead of the output channels (one tile of output channels: dgrad into a 16-channel layer).
+__device__ __forceinline__ int ig32_wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+template <int KS, int NCT, bool SPLITPX>
+__global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int N, int CI, int KP, int CO, const float* __restrict__ addend) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int CT0 = SPLITPX ? NCT : (NCT + 1) / 2;    // channel tiles of a half-0 wave (the loop bound of both halves)
+  constexpr int PT = SPLITPX ? 2 : 4;                   // pixel tiles (two image rows each) per wave
+  const int KC = KP >> 4;                               // 16-channel chunks of K
+  const int NP = KC * 4;                                // 4-channel pieces per image
+  const int XIMG = NP * F_PSTR;
+  char* Wl = smem;                                      // 2 x F_WT
+  char* Xl = smem + 2 * F_WT;                           // [4 images][NP pieces][1088]; taps outside the image read up to 36 bytes before /
+                                                        // after a row (ring, neighbouring piece or its padding) and are zeroed in registers
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = wid & 3, half = wid >> 2;
+  const int n0 = blockIdx.x * F_NI;
+  const int T = KC * RS;
+  const int m = lane & 15, q = lane >> 4;
+
+  // this wave's tiles
+  const int ct_first = SPLITPX ? 0 : half * CT0;
+  const int ct_count = SPLITPX ? NCT : (half == 0 ? CT0 : NCT - CT0);
+  const int jt0 = SPLITPX ? 2 * half : 0;
+
+  // weight stage (kc, rs): rows = output channels, k = input channels [16 kc, 16 kc + 16) of tap rs; one 1 KiB piece (16 rows) per wave
+  const int d_row = wid * 16 + (lane >> 2);
+  const int d_src = d_row * KP * 4 + (((lane & 3) ^ ig32_wswz(d_row)) << 4);
+  auto stage_dma = [&](int kc1, int rs1, int slot) {
+    if (wid < NCT) {
+      const char* base = reinterpret_cast<const char*>(wp) + ((int64_t)rs1 * F_ROWS * KP + kc1 * 16) * 4;
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * F_WT + wid * 1024), 16, 0, 0);
+    }
+  };
+  stage_dma(0, 0, 0);
+  // images: piece pid = (image, 4 channels) is 1 KiB of contiguous memory; pieces of channels that do not exist (CI < KP) are zeros
+  for (int pid = wid; pid < F_NI * NP; pid += 8) {
+    const int im = pid / NP, pc = pid - im * NP;
+    char* dst = Xl + im * XIMG + pc * F_PSTR;
+    if (pc * 4 < CI) {
+      const int n = min(n0 + im, N - 1);                 // images beyond the batch: a copy of the last one, never stored
+      const char* src = reinterpret_cast<const char*>(x + ((int64_t)n * CI + pc * 4) * 64) + lane * 16;
+      __builtin_amdgcn_global_load_lds((glb_char_t*)src, (lds_char_t*)dst, 16, 0, 0);
+    } else {
+      *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+
+  f4v acc[CT0][PT];
+#pragma unroll
+  for (int i = 0; i < CT0; i++)
+#pragma unroll
+    for (int j = 0; j < PT; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  // pixel operand: lane (m, q) of pixel tile jt, k-step j, tap (r, s) reads channel 16 kc + 4 q + j at pixel 16 jt + m + 8 (r - PAD) + (s - PAD)
+  const char* xq = Xl + img * XIMG + q * F_PSTR + (jt0 * 16 + m) * 4;
+  const bool col_lo = (m & 7) == 0, col_hi = (m & 7) == 7, row_lo = m < 8, row_hi = m >= 8;
+  // weight operand: row 16 (tile) + m, chunk q ^ swizzle(row)
+  const char* wq = Wl + (ct_first * 16 + m) * 64 + ((q ^ ig32_wswz(m)) << 4);
+
+  float fx[2][PT][4];
+  f4v fw[2][CT0];
+  auto load_frags = [&](int kc1, int rs, int set, int slot) {
+    const int r = rs / KS, s = rs - r * KS;
+    const char* xb = xq + kc1 * 4 * F_PSTR;
+#pragma unroll
+    for (int jt = 0; jt < PT; jt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        fx[set][jt][j] = *reinterpret_cast<const float*>(xb + j * 256 + (16 * jt + 8 * (r - PAD) + (s - PAD)) * 4);
+#pragma unroll
+    for (int i = 0; i < CT0; i++) fw[set][i] = *reinterpret_cast<const f4v*>(wq + slot * F_WT + i * 1024);
+  };
+  auto zero_edges = [&](int rs, int set) {
+    if (KS != 3) return;
+    const int r = rs / KS, s = rs - r * KS;
+    const bool colout = (s == 0 && col_lo) || (s == 2 && col_hi);
+#pragma unroll
+    for (int jt = 0; jt < PT; jt++) {
+      const bool out = colout || (r == 0 && jt0 + jt == 0 && row_lo) || (r == 2 && jt0 + jt == 3 && row_hi);
+      if (s != 1 || r != 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) fx[set][jt][j] = out ? 0.f : fx[set][jt][j];
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // images and weight stages 0, 1 are in LDS
+  load_frags(0, 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  zero_edges(0, 0);
+  __builtin_amdgcn_s_barrier();                        // every wave holds the fragments of stage 0: slot 0 may be refilled
+
+  // stage t = (kc, rs), register set and ring slot t & 1 (RS is odd: t = kc RS + rs has the parity of kc + rs):
+  //   DMA(t + 2) -> slot of W(t): every wave read W(t)'s fragments in stage t - 1 and retired the reads before that stage's barrier;
+  //   read the fragments of t + 1 (its weights were waited for before the last barrier) into the other register set;
+  //   multiply stage t; wait for DMA(t + 2) and the reads; barrier.
+  auto tap_loop = [&](int kc, auto par0c) {
+    constexpr int par0 = decltype(par0c)::value;
+#pragma unroll
+    for (int rs = 0; rs < RS; rs++) {
+      const int cur = (par0 + rs) & 1;
+      const int t = kc * RS + rs;
+      const int rs1 = (rs + 1) % RS, rs2 = (rs + 2) % RS;
+      const int kc1 = kc + (rs + 1) / RS, kc2 = kc + (rs + 2) / RS;
+      if (t + 2 < T) stage_dma(kc2, rs2, cur);
+      if (t + 1 < T) load_frags(kc1, rs1, cur ^ 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < CT0; i++)
+          if (SPLITPX || NCT % 2 == 0 || i < CT0 - 1 || half == 0) {
+#pragma unroll
+            for (int jt = 0; jt < PT; jt++)
+              acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[cur][jt][j], fw[cur][i][j], acc[i][jt], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < T) zero_edges(rs1, cur ^ 1);
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  {
+    int kc = 0;
+    for (; kc + 1 < KC; kc += 2) {
+      tap_loop(kc, std::integral_constant<int, 0>{});
+      tap_loop(kc + 1, std::integral_constant<int, 1>{});
+    }
+    if (kc < KC) tap_loop(kc, std::integral_constant<int, 0>{});
+  }
+
+  // epilogue: lane (m, q) holds output channel 16 tile + m and the four consecutive pixels 16 jt + 4 q .. + 3 of its image
+  const int n = n0 + img;
+  if (n < N) {
+    float* yp = y + (int64_t)n * CO * 64;
+    const float* ap = addend ? addend + (int64_t)n * CO * 64 : nullptr;
+#pragma unroll
+    for (int i = 0; i < CT0; i++) {
+      const int co = (ct_first + i) * 16 + m;
+      if (i < ct_count && co < CO) {
+        const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < PT; jt++) {
+          const int off = co * 64 + (jt0 + jt) * 16 + q * 4;
+          f4v v = acc[i][jt] + f4v{b, b, b, b};
+          if (ap) v += *reinterpret_cast<const f4v*>(ap + off);
+          *reinterpret_cast<f4v*>(yp + off) = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------------------
+constexpr int FW_DY = 128 * 256;                 // dY tile of one image: [128 co][64 px]
+constexpr int FW_XROW = 65 * 4;                  // X row: 64 px + one dword (lanes = channels: 16 consecutive banks)
+constexpr int FW_X = 16 * FW_XROW + 64;          // X tile (16 channels) + room for the reads beyond the last row
+constexpr int FW_STAGE = FW_DY + FW_X;           // 36,992 bytes
+
+template <int KS>
+__global__ __launch_bounds__(512) void ig32_wgrad8_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = KS * KS, PAD = (KS - 1) / 2;
+  constexpr int NXV = KS == 3 ? 34 : 16;                      // X values a lane can meet: offsets -9 .. 24 (3x3) or 0 .. 15 (1x1)
+  constexpr int XOFF = KS == 3 ? 9 : 0;
+  const int nsplit = gridDim.x / ntile;
+  int tile, split;
+  {                                                           // XCD-aware: the tiles of one image range share an L2 (dY is read ntile times)
+    const int b = blockIdx.x;
+    if ((nsplit & 7) == 0) { const int xcd = b & 7, slot = b >> 3; tile = slot % ntile; split = xcd + 8 * (slot / ntile); }
+    else { tile = b % ntile; split = b / ntile; }
+  }
+  const int ci0 = tile * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = this wave's tile of output channels
+  const int m = lane & 15, q = lane >> 4;
+  const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
+  const bool active = wid * 16 < CO;                          // tiles of padding are not multiplied
+
+  // dY by LDS-DMA: piece = four rows; LDS position (row, chunk') holds source chunk chunk' ^ (row & 15)
+  auto dma_dy = [&](int n, char* stage) {
+    const char* base = reinterpret_cast<const char*>(dy + (int64_t)n * CO * 64);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int piece = wid * 4 + i;
+      const int row = piece * 4 + (lane >> 4);
+      const int rowc = min(row, CO - 1);                      // rows of padding: copies of the last real row (their products are never stored)
+      const int chunk = (lane & 15) ^ (row & 15);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + rowc * 256 + chunk * 16), (lds_char_t*)(stage + piece * 1024), 16, 0, 0);
+    }
+  };
+  // X through registers (threads 0..255: channel tid >> 4, four pixels)
+  const bool xthread = tid < 256;
+  const int xc = (tid & 255) >> 4, xp = tid & 15;
+  auto load_x = [&](int n) -> uint4 {
+    if (xthread && ci0 + xc < CI) return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xc) * 64 + xp * 4);
+    return make_uint4(0, 0, 0, 0);
+  };
+  auto store_x = [&](char* stage, uint4 v) {
+    if (!xthread) return;
+    unsigned* d = reinterpret_cast<unsigned*>(stage + FW_DY + xc * FW_XROW + xp * 16);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  };
+
+  f4v acc[RS];
+#pragma unroll
+  for (int t = 0; t < RS; t++) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const char* st) {
+    // k-slot (m4, j) of lane group q is pixel 4 m4 + 16 q + j
+    f4v fa[4];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; m4++) fa[m4] = *reinterpret_cast<const f4v*>(st + (wid * 16 + m) * 256 + (((m4 + 4 * q) ^ m) << 4));
+    float xv[NXV];
+    const char* xs = st + FW_DY + m * FW_XROW + (16 * q - XOFF) * 4;
+#pragma unroll
+    for (int k = 0; k < NXV; k++) xv[k] = *reinterpret_cast<const float*>(xs + k * 4);
+    if (KS == 3) {
+      // offsets below 0 / above 15 are the previous / next two image rows: outside the image for the first / last lane group
+#pragma unroll
+      for (int k = 0; k < 9; k++) xv[k] = q == 0 ? 0.f : xv[k];
+#pragma unroll
+      for (int k = 25; k < 34; k++) xv[k] = q == 3 ? 0.f : xv[k];
+    }
+#pragma unroll
+    for (int m4 = 0; m4 < 4; m4++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < RS; t++) {
+          const int r = t / KS, s = t % KS;
+          // the column of this k-step's pixels is w0 = 4 (m4 & 1) + j for every lane: taps that leave the image row add nothing
+          const int w0 = 4 * (m4 & 1) + j + (s - PAD);
+          if (w0 < 0 || w0 > 7) continue;
+          const int off = 4 * m4 + j + 8 * (r - PAD) + (s - PAD) + XOFF;
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m4][j], xv[off], acc[t], 0, 0, 0);
+        }
+  };
+
+  uint4 xr = make_uint4(0, 0, 0, 0);
+  // zero the X regions once (the spare bytes behind the last row are read, then discarded: keep them finite anyway)
+  for (int o = tid * 4; o < FW_X; o += 512 * 4) { *reinterpret_cast<unsigned*>(smem + FW_DY + o) = 0u; *reinterpret_cast<unsigned*>(smem + FW_STAGE + FW_DY + o) = 0u; }
+  __syncthreads();
+  if (nbeg < nend) {
+    dma_dy(nbeg, smem);
+    xr = load_x(nbeg);
+    store_x(smem, xr);
+    if (nbeg + 1 < nend) { dma_dy(nbeg + 1, smem + FW_STAGE); xr = load_x(nbeg + 1); }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int n = nbeg; n < nend; n++, cur ^= 1) {
+    char* st = smem + cur * FW_STAGE;
+    char* nx = smem + (cur ^ 1) * FW_STAGE;
+    if (active) compute(st);
+    if (n + 1 < nend) store_x(nx, xr);                        // requested one image ago
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // stage cur is free, stage cur ^ 1 is complete
+    if (n + 2 < nend) { dma_dy(n + 2, st); xr = load_x(n + 2); }
+  }
+  // partial[(split * RS + t)][128][CIP]: lane (m, q) holds rows (output channels) 4 q .. 4 q + 3 of column (input channel) m
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < RS; t++) {
+      float* out = partial + (int64_t)(split * RS + t) * F_ROWS * CIP;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int co = wid * 16 + q * 4 + rr, ci = ci0 + m;
+        if (co < CO && ci < CI) out[co * CIP + ci] = acc[t][rr];
+      }
+    }
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------
+static bool ig32_qualifies(const ConvGeom& g, int dtype) {
+  static const bool on = [] { const char* e = getenv("LAMP_IGEMM_F32"); return !(e && e[0] == '0'); }();
+  if (!on || dtype != kF32) return false;
+  if (g.groups != 1 || g.transposed) return false;
+  if (g.H != 8 || g.W != 8 || g.Ho != 8 || g.Wo != 8) return false;
+  if (g.sh != 1 || g.sw != 1 || g.dh != 1 || g.dw != 1) return false;
+  if (!((g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1) || (g.kh == 1 && g.kw == 1 && g.ph == 0 && g.pw == 0))) return false;
+  if (g.Cin > 128 || g.Cout > 128 || g.Cin < 4 || g.Cout < 4 || (g.Cin & 3) || (g.Cout & 3)) return false;
+  if (g.Cin <= 16 && g.Cout <= 16) return false;             // the narrow layers stay on the image-per-workgroup kernels (conv_small.hip)
+  if (g.N < 1) return false;
+  return true;
+}
+static int pad16(int64_t c) { return (int)((c + 15) / 16) * 16; }
+
+// packed images [fprop | dgrad], cached per (weight storage, view, stream) while the storage's version is unchanged and re-packed in
+// place by the optimiser (see conv_igemm.hip: the same discipline, a separate cache because the element type differs)
+namespace {
+struct PackKey32 {
+  uint64_t uid; int64_t offset; int KS, Cout, Cin; hipStream_t st;
+  bool operator<(const PackKey32& o) const { return std::tie(uid, offset, KS, Cout, Cin, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.st); }
+};
+struct PackVal32 { uint64_t version; Tensor* packed; uint64_t tick; };
+std::mutex g_pack32_mu;
+std::map<PackKey32, PackVal32> g_pack32_cache;
+uint64_t g_pack32_tick = 0;
+}  // namespace
+
+static void launch_pack32(const float* w, float* wp, int Cout, int Cin, int KS, hipStream_t st) {
+  PackManyF32 a;
+  a.w[0] = w; a.wp[0] = wp; a.Cout[0] = Cout; a.Cin[0] = Cin; a.KS[0] = KS; a.KPf[0] = pad16(Cin); a.KPd[0] = pad16(Cout);
+  const int total = KS * KS * F_ROWS * (a.KPf[0] + a.KPd[0]);
+  hipLaunchKernelGGL(ig32_pack_weights_many_kernel, dim3((unsigned)std::min(512, (total + 255) / 256), 1u), dim3(256), 0, st, a);
+  LAMP_LAUNCH_CHECK();
+}
+
+static Tensor* packed_weights32(const Tensor* w, const ConvGeom& g, int KS, hipStream_t st, int64_t* dgrad_offset) {
+  const int RS = KS * KS;
+  const int KPf = pad16(g.Cin), KPd = pad16(g.Cout);
+  const int64_t nf = (int64_t)RS * F_ROWS * KPf, nd = (int64_t)RS * F_ROWS * KPd;
+  *dgrad_offset = nf;
+  static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
+  const bool cacheable = cache_on && w->st->owned;
+  const PackKey32 key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, st};
+  const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_pack32_mu);
+    auto it = g_pack32_cache.find(key);
+    if (it != g_pack32_cache.end() && it->second.version == ver) {
+      it->second.tick = ++g_pack32_tick;
+      return retain(it->second.packed);
+    }
+  }
+  int64_t ps[1] = {nf + nd};
+  Hold wp(new_tensor(ps, 1, kF32, w->device()));
+  launch_pack32(w->ptr<float>(), wp->ptr<float>(), (int)g.Cout, (int)g.Cin, KS, st);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_pack32_mu);
+    auto it = g_pack32_cache.find(key);
+    if (it != g_pack32_cache.end()) { release(it->second.packed); g_pack32_cache.erase(it); }
+    if (g_pack32_cache.size() >= 256) {
+      auto victim = g_pack32_cache.begin();
+      for (auto i = g_pack32_cache.begin(); i != g_pack32_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
+      release(victim->second.packed);
+      g_pack32_cache.erase(victim);
+    }
+    g_pack32_cache[key] = PackVal32{ver, retain(wp.get()), ++g_pack32_tick};
+  }
+  return wp.take();
+}
+
+// the optimisers' hook (optim.hip calls igemm_repack_cached, which forwards here): re-pack, in place and in one launch, every f32 weight
+// whose packed images are cached on this stream
+void igemm32_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
+  PackManyF32 a;
+  int cnt = 0, maxtotal = 0;
+  std::vector<std::pair<PackKey32, uint64_t>> done;
+  std::lock_guard<std::mutex> lk(g_pack32_mu);
+  if (g_pack32_cache.empty()) return;
+  for (int i = 0; i < n && cnt < F_PACK_MAX; i++) {
+    const Tensor* w = params[i];
+    if (!w || !w->is_device() || w->dtype != kF32 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
+    for (auto& kv : g_pack32_cache) {
+      if (kv.first.uid != w->st->uid || kv.first.offset != w->offset || kv.first.st != st) continue;
+      if (kv.first.Cout != (int)w->sizes[0] || kv.first.Cin != (int)w->sizes[1] || kv.first.KS != (int)w->sizes[2]) continue;
+      const int KS = kv.first.KS, RS = KS * KS, KPf = pad16(kv.first.Cin), KPd = pad16(kv.first.Cout);
+      const int total = RS * F_ROWS * (KPf + KPd);
+      if (kv.second.packed->numel() != total) continue;
+      a.w[cnt] = w->ptr<float>(); a.Cout[cnt] = kv.first.Cout; a.Cin[cnt] = kv.first.Cin; a.KS[cnt] = KS; a.KPf[cnt] = KPf; a.KPd[cnt] = KPd;
+      a.wp[cnt] = static_cast<float*>(kv.second.packed->raw());
+      done.push_back({kv.first, w->st->version.load(std::memory_order_relaxed)});
+      maxtotal = std::max(maxtotal, total);
+      cnt++;
+      break;
+    }
+  }
+  if (cnt == 0) return;
+  hipLaunchKernelGGL(ig32_pack_weights_many_kernel, dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
+  LAMP_LAUNCH_CHECK();
+  for (auto& d : done) {
+    auto it = g_pack32_cache.find(d.first);
+    if (it != g_pack32_cache.end()) { it->second.version = d.second; it->second.tick = ++g_pack32_tick; }
+  }
+}
+
+static void run_conv8_f32(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
+                          const Tensor* addend) {
+  const int KS = g.kh;
+  const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
+  const int KP = pad16(CI);
+  int64_t dgrad_off = 0;
+  Hold wpk(packed_weights32(w, g, KS, st, &dgrad_off));
+  const float* wpp = static_cast<const Tensor*>(wpk.get())->ptr<float>() + (dgrad ? dgrad_off : 0);
+  const int nct = (CO + 15) / 16;
+  const int blocks = (int)((g.N + F_NI - 1) / F_NI);
+  const size_t lds = (size_t)2 * F_WT + (size_t)F_NI * (KP / 4) * F_PSTR;
+  KernelTimer kt("conv_igemm_fprop_dgrad_f32", conv_flops(g), conv_bytes(g, 4), st);
+  const float* bp = bias ? bias->ptr<float>() : (const float*)nullptr;
+  const float* ap = addend ? addend->ptr<float>() : (const float*)nullptr;
+#define IG32_LAUNCH(KS_, NCT_, SP_)                                                                                                  \
+  do {                                                                                                                               \
+    allow_big_lds((const void*)ig32_conv8_kernel<KS_, NCT_, SP_>);                                                                   \
+    hipLaunchKernelGGL((ig32_conv8_kernel<KS_, NCT_, SP_>), dim3(blocks), dim3(512), lds, st, in->ptr<float>(), wpp, bp,             \
+                       out->ptr<float>(), (int)g.N, CI, KP, CO, ap);                                                                 \
+  } while (0)
+#define IG32_BY_NCT(KS_)                                                                                                             \
+  do {                                                                                                                               \
+    if (nct <= 1) IG32_LAUNCH(KS_, 1, true);                                                                                         \
+    else if (nct <= 2) IG32_LAUNCH(KS_, 2, false);                                                                                   \
+    else if (nct <= 4) IG32_LAUNCH(KS_, 4, false);                                                                                   \
+    else if (nct <= 6) IG32_LAUNCH(KS_, 6, false);                                                                                   \
+    else if (nct <= 7) IG32_LAUNCH(KS_, 7, false);                                                                                   \
+    else IG32_LAUNCH(KS_, 8, false);                                                                                                 \
+  } while (0)
+  if (KS == 3) IG32_BY_NCT(3); else IG32_BY_NCT(1);
+#undef IG32_BY_NCT
+#undef IG32_LAUNCH
+  LAMP_LAUNCH_CHECK();
+}
+
+bool igemm32_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
+  if (!ig32_qualifies(g, x->dtype)) return false;
+  run_conv8_f32(x, w, bias, y, g, false, st, nullptr);
+  return true;
+}
+bool igemm32_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  if (addend_fused) *addend_fused = false;
+  if (!ig32_qualifies(g, dy->dtype)) return false;
+  run_conv8_f32(dy, w, nullptr, dx, g, true, st, addend);
+  if (addend_fused) *addend_fused = addend != nullptr;
+  return true;
+}
+bool igemm32_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  if (!ig32_qualifies(g, x->dtype)) return false;
+  const int KS = g.kh, RS = KS * KS;
+  const int ntile = (int)((g.Cin + 15) / 16);
+  const int CIP = ntile * 16;
+  const int target = std::max(1, num_cus() / ntile);
+  int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
+  if (ips < 4 && g.N >= 4) ips = 4;
+  const int nsplit = (int)((g.N + ips - 1) / ips);
+  int64_t ps[1] = {(int64_t)nsplit * RS * F_ROWS * CIP};
+  Hold partial(new_tensor(ps, 1, kF32, x->device()));
+  const size_t lds = 2 * (size_t)FW_STAGE;
+  {
+    KernelTimer kt("conv_wgrad_igemm_f32", conv_flops(g), conv_bytes(g, 4), st);
+    if (KS == 3) {
+      allow_big_lds((const void*)ig32_wgrad8_kernel<3>);
+      hipLaunchKernelGGL(ig32_wgrad8_kernel<3>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<float>(), x->ptr<float>(), partial->ptr<float>(), (int)g.N,
+                         (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+    } else {
+      allow_big_lds((const void*)ig32_wgrad8_kernel<1>);
+      hipLaunchKernelGGL(ig32_wgrad8_kernel<1>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<float>(), x->ptr<float>(), partial->ptr<float>(), (int)g.N,
+                         (int)g.Cout, (int)g.Cin, CIP, ips, ntile);
+    }
+    LAMP_LAUNCH_CHECK();
+  }
+  const int64_t cols = (int64_t)RS * F_ROWS * CIP / 4;
+  WgradReduceArgs ra{};
+  ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = F_ROWS; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
+  ra.dw_f32 = 1;
+  wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+  return true;
+}
+
+}  // namespace lamp

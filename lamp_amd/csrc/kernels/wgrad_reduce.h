@@ -1,4 +1,4 @@
-// The second half of the bf16 convolutions' weight gradients: f32 partial sums per image range -> one rounded bf16 tensor, summed in
+// The second half of the matrix-core convolutions' weight gradients: f32 partial sums per image range -> one (rounded bf16 or f32) tensor, summed in
 // a fixed order (deterministic).  The two bodies below are used by (a) the per-layer kernels of conv_igemm.hip / conv_narrow.hip and
 // (b) the multi-tensor kernel of wgrad_reduce.hip, which runs ALL reductions a backward pass has registered in one launch:
 // the ResNet step had 13 of these ~5 us launches, each at the ~4.5 us launch floor.
@@ -10,7 +10,8 @@ namespace lamp {
 struct WgradReduceArgs {
   int kind;                 // 0: implicit GEMM v2 layout [split][tap][COP][CIP], 1: narrow layout [block][O]
   const float* partial;
-  bf16_t* dw;
+  void* dw;                 // bf16 (the bf16 convolutions) or f32 (conv_igemm_f32.hip: dw_f32 = 1)
+  int dw_f32;
   int CO, CI, CIP, COP, RS; // kind 0 (COP x CIP = the padded tile the kernel wrote per tap)
   int nsplit;               // kind 0: image ranges; kind 1: blocks
   int O;                    // kind 1: outputs
@@ -49,7 +50,10 @@ __device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int
     const float r[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (ci + k < a.CI) a.dw[((int64_t)co * a.CI + ci + k) * a.RS + rs] = bf16_t(r[k]);
+      if (ci + k < a.CI) {
+        const int64_t o = ((int64_t)co * a.CI + ci + k) * a.RS + rs;
+        if (a.dw_f32) static_cast<float*>(a.dw)[o] = r[k]; else static_cast<bf16_t*>(a.dw)[o] = bf16_t(r[k]);
+      }
   }
 }
 
@@ -61,7 +65,7 @@ __device__ __forceinline__ void wgrad_reduce_narrow(const WgradReduceArgs& a, in
   float s = 0.f;
   for (int b = lane; b < a.nsplit; b += 64) s += a.partial[(int64_t)b * a.O + o];
   s = wave_sum(s);
-  if (lane == 0) a.dw[o] = bf16_t(s);
+  if (lane == 0) { if (a.dw_f32) static_cast<float*>(a.dw)[o] = s; else static_cast<bf16_t*>(a.dw)[o] = bf16_t(s); }
 }
 
 // Registers the reduction (wgrad_reduce.hip): it runs with every other pending one at the next flush_deferred() - the end of

@@ -40,7 +40,7 @@ void launch_batch(const std::vector<Pending>& v) {
       if (done[j] || v[j].st != v[i].st || v[j].device != v[i].device) continue;
       m.e[cnt] = v[j].a;
       m.e[cnt].partial = reinterpret_cast<const float*>(static_cast<const char*>(v[j].partial->st->ptr)) + v[j].partial->offset;
-      m.e[cnt].dw = reinterpret_cast<bf16_t*>(static_cast<char*>(v[j].dw->st->ptr)) + v[j].dw->offset;
+      m.e[cnt].dw = static_cast<char*>(v[j].dw->st->ptr) + v[j].dw->offset * (v[j].a.dw_f32 ? 4 : 2);
       v[j].dw->st->version.fetch_add(1, std::memory_order_relaxed);   // a writer like any other: bumps dw's version
       maxb = std::max(maxb, v[j].a.blocks);
       done[j] = true;
@@ -113,7 +113,7 @@ void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_t
     WgradReduceMany m;
     m.e[0] = a;
     m.e[0].partial = partial->ptr<float>();
-    m.e[0].dw = dw->ptr<bf16_t>();
+    m.e[0].dw = dw->data();
     hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)a.blocks, 1), dim3(256), 0, st, m);
     LAMP_LAUNCH_CHECK();
     return;

@@ -7,6 +7,8 @@
 3. Composite parity vs the oracle on deterministic closed-form inputs: MLP step (BASELINE config 1),
    CIFAR ResNet step, several optimiser steps; f32 forward <= 1e-5, gradients <= 1e-3 (BASELINE.json).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,7 @@ import torch
 from lamp_amd import autograd as A
 from lamp_amd import nn
 from lamp_amd import sten as S
+from lamp_amd._capi import lib
 from oracle import lamp_oracle as O
 from tests import kats
 from tests.backends import HipBackend, OracleBackend
@@ -214,10 +217,22 @@ def test_resnet_training_steps_match_oracle(gpu, dt, B):
     for step in range(2):
         oloss, ograds = O.training_step(om, O.nll_loss(100, cw), x, target, None)
         acc = S.STen.zeros([1], ldt)
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_filter(None)
+        lib.lamp_kernel_timer_report(buf, len(buf))          # drops what earlier tests left in the log
+        lib.lamp_kernel_timer_enable(1)
         n, hgrads = model.addTotalLossAndReturnGradientsAndNumExamples(X, T, acc)
+        grads_t = [to_torch(hg) for hg in hgrads]
+        lib.lamp_kernel_timer_enable(0)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        if dt == torch.float32:
+            # the reference's own precision (cifar100.scala:127-129) must run on the f32 matrix-core convolutions, not on the direct kernels
+            ran = {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines() if l.strip()}
+            assert ran.get("conv_igemm_fprop_dgrad_f32", 0) >= 12 and ran.get("conv_wgrad_igemm_f32", 0) == 6, f"f32 matrix-core convolutions did not run: {ran}"
+            assert not any(k.startswith("conv_") and k.endswith("_direct") for k in ran), f"a wide layer fell to the direct kernels: {ran}"
         assert_close(to_torch(acc) / B, oloss.double().reshape(1), ftol, f"loss step {step}")
-        for i, (hg, og) in enumerate(zip(hgrads, ograds)):
-            assert_close(to_torch(hg), og.double(), btol, f"step {step} gradient {i} shape {list(og.shape)}")
+        for i, (hg, og) in enumerate(zip(grads_t, ograds)):
+            assert_close(hg, og.double(), btol, f"step {step} gradient {i} shape {list(og.shape)}")
         oopt.step(ograds, 1.0)
         hopt.step(hgrads, 1.0)
         for i, (hv, ov) in enumerate(zip(hm.state, om.state())):

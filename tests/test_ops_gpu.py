@@ -684,6 +684,59 @@ def test_igemm_eight_image_kernel(gpu, case, monkeypatch):
         monkeypatch.delenv("LAMP_IG_VARIANT")
 
 
+def _timer_classes():
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    return {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines() if l.strip()}
+
+
+@pytest.mark.parametrize("case", [(16, 128, 128, 3), (13, 128, 100, 3), (9, 100, 100, 3), (24, 16, 128, 3), (11, 128, 100, 1), (8, 16, 128, 1),
+                                  (3, 100, 128, 3), (1, 128, 128, 3), (5, 128, 16, 3), (6, 128, 16, 1), (7, 20, 36, 3), (10, 64, 48, 3),
+                                  (4, 4, 128, 3), (9, 92, 84, 1), (130, 128, 128, 3), (1030, 32, 100, 3)])
+def test_igemm_f32_kernels(gpu, case):
+    """conv_igemm_f32.hip - the f32 matrix-instruction convolutions of the 8x8 layers (v_mfma_f32_16x16x4_f32: exact f32 FMA chains):
+    fprop with bias, dgrad (plain and with the fused addend), wgrad and the bias gradient against ATen in f64 on the same f32 operands, at
+    north_star's tolerances (1e-5 forward, 1e-4 backward; ops.scala:1547-1651); batches that are not multiples of the four images per
+    workgroup, every count of 16-channel output tiles the kernels are instantiated for (1 = pixel split, 2, 4, 6, 7, 8), channel counts
+    that are multiples of 4 but not of 16, one image range and many in the weight gradient.  The kernel classes must have run."""
+    N, Cin, Cout, k = case
+    dt = torch.float32
+    x = closed_form((N, Cin, 8, 8), 3, 2.0, dt)
+    w = closed_form((Cout, Cin, k, k), 17, 1.0, dt)
+    b = closed_form((Cout,), 5, 1.0, dt)
+    p = (k - 1) // 2
+    args = ([1, 1], [p, p], [1, 1], False, [0, 0], 1)
+    gy = closed_form((N, Cout, 8, 8), 23, 1.0, dt)
+    add = closed_form((N, Cin, 8, 8), 29, 1.0, dt)
+    ref = aten.convolution(x.double(), w.double(), b.double(), *args)
+    refb = aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], *args, [True, True, True])
+    lib.lamp_kernel_timer_filter(None)
+    _timer_classes()                          # drop what earlier tests left in the log
+    lib.lamp_kernel_timer_enable(1)
+    o = C.c_void_p()
+    lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                         i64_array([0, 0]), 1)
+    out = _out3()
+    lib.lamp_convolution_backward(out, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                                  i64_array([0, 0]), 1, _mask3(1, 1, 1))
+    dx, dw, db = _wrap3(out)
+    oa = C.c_void_p()
+    lib.lamp_convolution_backward_input_add(C.byref(oa), to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2,
+                                            i64_array([0, 0]), 1, to_sten(add))
+    got_w = to_torch(dw)                      # resolves the deferred reduction of the partial sums
+    lib.lamp_kernel_timer_enable(0)
+    ran = _timer_classes()
+    got_add = to_torch(S.STen(oa))
+    assert ran.get("conv_igemm_fprop_dgrad_f32", 0) == 3 and ran.get("conv_wgrad_igemm_f32", 0) == 1, f"the f32 matrix-core kernels did not run: {ran}"
+    assert_close(to_torch(S.STen(o)), ref, 1e-5, "f32 igemm forward")
+    assert_close(to_torch(dx), refb[0], 1e-4, "f32 igemm dgrad")
+    assert_close(got_w, refb[1], 1e-4, "f32 igemm wgrad")
+    assert_close(to_torch(db), refb[2], 1e-4, "bias gradient")
+    assert_close(got_add, refb[0] + add.double(), 1e-4, "f32 igemm dgrad + addend")
+    # the fused addend is the unfused sum bit for bit: both are fl(fl(dgrad) + addend)
+    assert torch.equal(got_add.float(), to_torch(dx).float() + add)
+
+
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
 def test_conv1d_and_transposed(gpu, dt):
     x = closed_form((2, 3, 11), 3, 2.0, dt)
