@@ -6,22 +6,47 @@
 #include "tensor.h"
 #include "lamp_hip.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace lamp {
 namespace staging {
 
+// One distinct view of a host storage (the common case) is staged as before: a fresh, compact, aligned device tensor, written back through
+// the host view's strides if the operator may write it.  When the arguments of ONE call view the same host storage in two or more
+// different ways (an `_out` form whose destination aliases an input through another handle, a slice next to its
+// parent) the storage is staged as a BLOCK: the byte range its views span is copied to the GPU once and each argument becomes a view
+// of that block with the same sizes, strides and relative offset - they alias on the GPU exactly as on the host - and a block that
+// any argument may write is copied back once, whole.
 class Stager {
  public:
-  void see(const lamp_tensor* t) { if (t) seen_.push_back(t); }
+  void see(const lamp_tensor* t) {
+    if (!t) return;
+    seen_.push_back(t);
+    if (t->is_device() || !t->st || t->numel() == 0) return;
+    const int64_t isz = (int64_t)t->itemsize();
+    int64_t lo = t->offset, hi = t->offset;
+    for (int i = 0; i < t->ndim; i++) {
+      const int64_t span = (t->sizes[i] - 1) * t->strides[i];
+      if (span < 0) lo += span; else hi += span;
+    }
+    const int64_t b0 = (lo * isz) & ~(int64_t)15, b1 = (hi + 1) * isz;      // 16-byte aligned start: every dtype's offsets stay whole
+    for (Block& b : blocks_)
+      if (b.host == t->st) {
+        if (!same_view(b.first, t)) b.shared = true;
+        b.lo = std::min(b.lo, b0); b.hi = std::max(b.hi, b1);
+        return;
+      }
+    blocks_.push_back(Block{t->st, t, b0, b1, nullptr, false, false});
+  }
   // every tensor argument lives in host memory (and there is at least one): otherwise the kernel's own error stands
   bool all_host() const {
     if (seen_.empty()) return false;
     for (const lamp_tensor* t : seen_) if (t->is_device()) return false;
     return true;
   }
-  const lamp_tensor* in(const lamp_tensor* t) { return t ? pair_of(const_cast<lamp_tensor*>(t), false) : nullptr; }
-  lamp_tensor* inout(lamp_tensor* t) { return t ? pair_of(t, true) : nullptr; }
+  const lamp_tensor* in(const lamp_tensor* t) { return t ? view_of(const_cast<lamp_tensor*>(t), false) : nullptr; }
+  lamp_tensor* inout(lamp_tensor* t) { return t ? view_of(t, true) : nullptr; }
   void ran(int rc) { if (rc != 0) throw Error(lamp_last_error()); }
   // a device result -> a host tensor of the same shape and dtype (the device handle is released)
   lamp_tensor* out(lamp_tensor* dev) {
@@ -31,25 +56,67 @@ class Stager {
     if (d->numel() > 0) copy_into(h.get(), d.get());
     return h.take();
   }
-  // tensors the operator wrote in place: back into the caller's host tensors (through their strides)
+  // what the operator may have written: back into the caller's host memory
   void finish() {
-    for (Pair& p : pairs_)
-      if (p.writeback && p.host->numel() > 0) copy_into(p.host, p.dev);
+    for (View& v : views_)
+      if (v.writeback && v.host->numel() > 0) copy_into(v.host, v.dev);          // compact copies, through the host view's strides
+    for (Block& b : blocks_)
+      if (b.shared && b.writeback && b.dev) { Hold hv(bytes_of(b)); copy_into(hv.get(), b.dev); }
   }
-  ~Stager() { for (Pair& p : pairs_) release(p.dev); }
+  ~Stager() {
+    for (View& v : views_) release(v.dev);
+    for (Block& b : blocks_) if (b.dev) release(b.dev);
+  }
 
  private:
-  struct Pair { lamp_tensor* host; lamp_tensor* dev; bool writeback; };
-  lamp_tensor* pair_of(lamp_tensor* host, bool writeback) {
-    for (Pair& p : pairs_)
-      if (p.host == host) { p.writeback |= writeback; return p.dev; }     // the same handle passed twice: one copy
-    Hold d(new_tensor(host->sizes, host->ndim, host->dtype, current_device()));
-    if (host->numel() > 0) copy_into(d.get(), host);
-    pairs_.push_back(Pair{host, d.get(), writeback});
-    return d.take();
+  // [lo, hi): bytes of the host storage its views span; shared: viewed in more than one way by this call
+  struct Block { Storage* host; const lamp_tensor* first; int64_t lo, hi; lamp_tensor* dev; bool writeback, shared; };
+  struct View { lamp_tensor* host; lamp_tensor* dev; bool writeback; };
+  static bool same_view(const lamp_tensor* a, const lamp_tensor* b) {
+    if (a->offset != b->offset || a->ndim != b->ndim || a->dtype != b->dtype) return false;
+    for (int i = 0; i < a->ndim; i++) if (a->sizes[i] != b->sizes[i] || a->strides[i] != b->strides[i]) return false;
+    return true;
+  }
+  // the staged byte range of a host storage as a u8 host tensor (a view: no copy)
+  lamp_tensor* bytes_of(const Block& b) {
+    const int64_t n[1] = {b.hi - b.lo}, one[1] = {1};
+    lamp_tensor* t = new_view(b.first, n, one, 1, b.lo);
+    t->dtype = kU8;
+    return t;
+  }
+  lamp_tensor* view_of(lamp_tensor* host, bool writeback) {
+    Block* blk = nullptr;
+    if (host->st && host->numel() > 0)
+      for (Block& b : blocks_) if (b.host == host->st) blk = &b;
+    for (View& v : views_)
+      if (v.host == host || (blk && !blk->shared && v.host->st == host->st)) {     // the same handle, or another handle on the same view
+        if (!(blk && blk->shared)) v.writeback |= writeback;
+        else blk->writeback |= writeback;
+        return v.dev;
+      }
+    if (!blk || !blk->shared) {                                  // the only view of its storage (or empty): a compact device copy
+      Hold d(new_tensor(host->sizes, host->ndim, host->dtype, current_device()));
+      if (host->numel() > 0) copy_into(d.get(), host);
+      views_.push_back(View{host, d.get(), writeback});
+      return d.take();
+    }
+    blk->writeback |= writeback;
+    if (!blk->dev) {
+      const int64_t n[1] = {blk->hi - blk->lo};
+      Hold d(new_tensor(n, 1, kU8, current_device()));
+      Hold hv(bytes_of(*blk));
+      copy_into(d.get(), hv.get());
+      blk->dev = d.take();
+    }
+    const int64_t isz = (int64_t)host->itemsize();
+    lamp_tensor* d = new_view(blk->dev, host->sizes, host->strides, host->ndim, (host->offset * isz - blk->lo) / isz);
+    d->dtype = host->dtype;
+    views_.push_back(View{host, d, false});
+    return d;
   }
   std::vector<const lamp_tensor*> seen_;
-  std::vector<Pair> pairs_;
+  std::vector<Block> blocks_;
+  std::vector<View> views_;
 };
 
 }  // namespace staging

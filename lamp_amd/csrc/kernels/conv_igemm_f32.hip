@@ -13,13 +13,15 @@
 //  * The images sit in LDS exactly as they sit in memory (NCHW rows of 64 f32 = 256 bytes), brought in by LDS-DMA with no register
 //    staging and no transposition: the pixel operand of an MFMA is ONE f32 per lane (A[pixel = lane & 15][k = lane >> 4]), i.e. a
 //    ds_read_b32, and a b32 read has no alignment: the tap shift is a byte offset, pixels outside the image are zeroed in registers.
-//    A 1 KiB DMA piece holds four channels; pieces are 1088 bytes apart so that the two lane groups of a half wave (k = channel 4q + j,
-//    q = 0 / 1 or 2 / 3: adjacent pieces) are 16 banks apart.
-//  * K runs over 16-channel chunks (outer) and taps (inner).  The weights of one (chunk, tap) - [128 output channels][16 input channels],
-//    8 KiB, 64-byte rows with the 16-byte chunks XOR-swizzled exactly as conv_igemm.hip's eight-image kernel - arrive by LDS-DMA in a
-//    two-slot ring, two stages ahead; a lane's ds_read_b128 of a weight row delivers the operands of FOUR k-steps: k-step j of lane group q is
-//    channel 4q + j, which is also what the pixel side reads.
-//  * The fragments of stage t + 1 are read while stage t multiplies (two register sets), one barrier per stage.
+//    A 1 KiB DMA piece holds four channels (k-step j of a 16-channel chunk = piece j, lane group q = its row q); pieces are 1088 bytes
+//    apart: the spare 64 bytes take the reads past the last row.
+//  * K runs over 16-channel chunks (outer) and taps (inner).  The weights of one (chunk, tap) - [output channels][16 input channels],
+//    64-byte rows with the 16-byte chunks XOR-swizzled exactly as conv_igemm.hip's eight-image kernel - arrive by LDS-DMA in a two-slot
+//    ring per half of the workgroup, two stages ahead; a lane's ds_read_b128 of a weight row delivers the operands of FOUR k-steps (the
+//    pack kernel orders the 16 channels of a chunk so that k-step j of lane group q is channel 4 j + q, the pixel side's order).  A last
+//    chunk that is only partly filled (Cin = 100: 4 of 16) runs only the k-steps that hold channels.
+//  * The fragments of stage t + 1 are read while stage t multiplies (two register sets); the two waves of a SIMD run half a stage apart
+//    (two barriers per stage), so one's load issue / waits / edge selects sit under the other's MFMAs.
 //  * wgrad: dW[tap][co][ci] = sum over images and pixels of dY[co][p] X[ci][p + shift(tap)], K = pixels.  Workgroup = (16-channel tile
 //    of Cin, image range), wave = 16-channel tile of Cout x all nine taps (36 accumulator registers).  dY arrives by LDS-DMA ([co][64 px],
 //    16-byte chunks XOR-swizzled by the row), X through registers into rows of 65 dwords.  Per image a lane reads four dY fragments and
@@ -40,13 +42,12 @@ typedef __attribute__((address_space(3))) char lds_char_t;
 typedef const __attribute__((address_space(1))) char glb_char_t;
 
 constexpr int F_ROWS = 128;             // rows of a packed weight image (output channels, zero padded)
-constexpr int F_WT = F_ROWS * 16 * 4;   // one weight stage: 128 rows x 16 k, f32
 constexpr int F_PSTR = 1088;            // LDS distance of two 4-channel image pieces
 constexpr int F_NI = 4;                 // images per workgroup
 
 // ---- weight packing ---------------------------------------------------------------------------------
-// fprop: wp[rs][co][ci] = W[co][ci][r][s]            (rows = Cout, k = Cin, row length KPf = round16(Cin))
-// dgrad: wp[rs][ci][co] = W[co][ci][kh-1-r][kw-1-s]  (rows = Cin,  k = Cout, row length KPd = round16(Cout))
+// fprop: wp[rs][kc][co][16] <- W[co][ci][r][s]            (rows = Cout, k = Cin in chunks of 16, KPf = round16(Cin))
+// dgrad: wp[rs][kc][ci][16] <- W[co][ci][kh-1-r][kw-1-s]  (rows = Cin,  k = Cout, KPd = round16(Cout))
 constexpr int F_PACK_MAX = 16;
 struct PackManyF32 { const float* w[F_PACK_MAX]; float* wp[F_PACK_MAX]; int Cout[F_PACK_MAX], Cin[F_PACK_MAX], KS[F_PACK_MAX], KPf[F_PACK_MAX], KPd[F_PACK_MAX]; };
 __global__ void ig32_pack_weights_many_kernel(PackManyF32 a) {
@@ -59,7 +60,11 @@ __global__ void ig32_pack_weights_many_kernel(PackManyF32 a) {
   for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
     const int dgrad = e0 >= nf;
     const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
-    const int k = e % KP, row = (e / KP) % F_ROWS, rs = e / (KP * F_ROWS);
+    // [tap][16-channel chunk][128 rows][16]: the 16 x 16 tile one lane group of one wave multiplies is 1 KiB of contiguous memory
+    const int pos = e & 15, row = (e >> 4) % F_ROWS, kc = (e / (16 * F_ROWS)) % (KP >> 4), rs = e / (KP * F_ROWS);
+    // position 4 q + j of a chunk holds channel 4 j + q: a lane's 16-byte load (q) then delivers, as k-step j, a channel of [4 j, 4 j + 4) -
+    // the k-steps of a partly filled last chunk that hold no channel at all can be skipped
+    const int k = kc * 16 + 4 * (pos & 3) + (pos >> 2);
     const int r = rs / KS, s = rs % KS;
     float v = 0.f;
     if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
@@ -69,9 +74,21 @@ __global__ void ig32_pack_weights_many_kernel(PackManyF32 a) {
 }
 
 // ---- fprop / dgrad -----------------------------------------------------------------------------------
-// x [N][CI][64], wp [RS][128][KP], y [N][CO][64]; KP = round16(CI).  NCT = 16-channel tiles of the output; SPLITPX: the two waves of
+// x [N][CI][64], wp [RS][KP / 16][128][16], y [N][CO][64]; KP = round16(CI).  NCT = 16-channel tiles of the output; SPLITPX: the two waves of
 // an image split its PIXELS instead of the output channels (one tile of output channels: dgrad into a 16-channel layer).
-__device__ __forceinline__ int ig32_wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+// diagnostic build only (-DIG32_STAMP): shader-clock and 100 MHz stamps of wave 0 of every workgroup (scripts/conv_f32_stamp_probe.py)
+#ifdef IG32_STAMP
+__device__ unsigned long long ig32_stamps[8 * 1024];
+__device__ unsigned long long ig32_rt_stamps[8 * 1024];
+#define IG32_STAMP_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { ig32_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+                                                                           ig32_rt_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int lamp_debug_ig32_stamps(unsigned long long* out, unsigned long long* out_rt) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ig32_stamps), sizeof(ig32_stamps)) != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out_rt, HIP_SYMBOL(ig32_rt_stamps), sizeof(ig32_rt_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define IG32_STAMP_AT(k) do { } while (0)
+#endif
 
 template <int KS, int NCT, bool SPLITPX>
 __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -84,31 +101,22 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict
   const int KC = KP >> 4;                               // 16-channel chunks of K
   const int NP = KC * 4;                                // 4-channel pieces per image
   const int XIMG = NP * F_PSTR;
-  char* Wl = smem;                                      // 2 x F_WT
-  char* Xl = smem + 2 * F_WT;                           // [4 images][NP pieces][1088]; taps outside the image read up to 36 bytes before /
-                                                        // after a row (ring, neighbouring piece or its padding) and are zeroed in registers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = wid & 3, half = wid >> 2;
+  char* Xl = smem + 64;                                 // [4 images][NP pieces][1088]; taps outside the image read up to 36 bytes before /
+                                                        // after a row (spare bytes, neighbouring row, padding) and are zeroed in registers
   const int n0 = blockIdx.x * F_NI;
   const int T = KC * RS;
   const int m = lane & 15, q = lane >> 4;
+  const int nj_last = (CI - 16 * (KC - 1) + 3) >> 2;    // k-steps of the last chunk that hold channels
 
   // this wave's tiles
   const int ct_first = SPLITPX ? 0 : half * CT0;
   const int ct_count = SPLITPX ? NCT : (half == 0 ? CT0 : NCT - CT0);
   const int jt0 = SPLITPX ? 2 * half : 0;
 
-  // weight stage (kc, rs): rows = output channels, k = input channels [16 kc, 16 kc + 16) of tap rs; one 1 KiB piece (16 rows) per wave
-  const int d_row = wid * 16 + (lane >> 2);
-  const int d_src = d_row * KP * 4 + (((lane & 3) ^ ig32_wswz(d_row)) << 4);
-  auto stage_dma = [&](int kc1, int rs1, int slot) {
-    if (wid < NCT) {
-      const char* base = reinterpret_cast<const char*>(wp) + ((int64_t)rs1 * F_ROWS * KP + kc1 * 16) * 4;
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * F_WT + wid * 1024), 16, 0, 0);
-    }
-  };
-  stage_dma(0, 0, 0);
+  IG32_STAMP_AT(0);
   // images: piece pid = (image, 4 channels) is 1 KiB of contiguous memory; pieces of channels that do not exist (CI < KP) are zeros
   for (int pid = wid; pid < F_NI * NP; pid += 8) {
     const int im = pid / NP, pc = pid - im * NP;
@@ -121,7 +129,6 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict
       *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
     }
   }
-  if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
 
   f4v acc[CT0][PT];
 #pragma unroll
@@ -129,24 +136,28 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < PT; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-  // pixel operand: lane (m, q) of pixel tile jt, k-step j, tap (r, s) reads channel 16 kc + 4 q + j at pixel 16 jt + m + 8 (r - PAD) + (s - PAD)
-  const char* xq = Xl + img * XIMG + q * F_PSTR + (jt0 * 16 + m) * 4;
+  // pixel operand: lane (m, q) of pixel tile jt, k-step j, tap (r, s) reads channel 16 kc + 4 j + q (row q of piece 4 kc + j) at pixel
+  // 16 jt + m + 8 (r - PAD) + (s - PAD)
+  const char* xq = Xl + img * XIMG + q * 256 + (jt0 * 16 + m) * 4;
   const bool col_lo = (m & 7) == 0, col_hi = (m & 7) == 7, row_lo = m < 8, row_hi = m >= 8;
-  // weight operand: row 16 (tile) + m, chunk q ^ swizzle(row)
-  const char* wq = Wl + (ct_first * 16 + m) * 64 + ((q ^ ig32_wswz(m)) << 4);
+  // weight operand, straight from memory (L2: every workgroup reads the same 0.6 MB): the 16 bytes of row 16 (tile) + m, lane group q, of
+  // stage (tap, chunk) - k-step j of them is channel 4 j + q (ig32_pack_weights_many_kernel).  No LDS ring, no barrier in the main loop:
+  // the waves of a workgroup share nothing but the read-only images
+  const char* wq = reinterpret_cast<const char*>(wp) + ((ct_first * 16 + m) * 16 + q * 4) * 4;
 
   float fx[2][PT][4];
   f4v fw[2][CT0];
-  auto load_frags = [&](int kc1, int rs, int set, int slot) {
+  auto load_frags = [&](int kc1, int rs, int set) {
     const int r = rs / KS, s = rs - r * KS;
+    const char* wb = wq + (int64_t)(rs * KC + kc1) * (F_ROWS * 16 * 4);
+#pragma unroll
+    for (int i = 0; i < CT0; i++) fw[set][i] = *reinterpret_cast<const f4v*>(wb + i * 1024);
     const char* xb = xq + kc1 * 4 * F_PSTR;
 #pragma unroll
     for (int jt = 0; jt < PT; jt++)
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        fx[set][jt][j] = *reinterpret_cast<const float*>(xb + j * 256 + (16 * jt + 8 * (r - PAD) + (s - PAD)) * 4);
-#pragma unroll
-    for (int i = 0; i < CT0; i++) fw[set][i] = *reinterpret_cast<const f4v*>(wq + slot * F_WT + i * 1024);
+        fx[set][jt][j] = *reinterpret_cast<const float*>(xb + j * F_PSTR + (16 * jt + 8 * (r - PAD) + (s - PAD)) * 4);
   };
   auto zero_edges = [&](int rs, int set) {
     if (KS != 3) return;
@@ -163,43 +174,37 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict
   };
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                        // images and weight stages 0, 1 are in LDS
-  load_frags(0, 0, 0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  zero_edges(0, 0);
-  __builtin_amdgcn_s_barrier();                        // every wave holds the fragments of stage 0: slot 0 may be refilled
+  __builtin_amdgcn_s_barrier();                        // the images are in LDS: the only barrier of the kernel
+  load_frags(0, 0, 0);
+  IG32_STAMP_AT(1);
 
-  // stage t = (kc, rs), register set and ring slot t & 1 (RS is odd: t = kc RS + rs has the parity of kc + rs):
-  //   DMA(t + 2) -> slot of W(t): every wave read W(t)'s fragments in stage t - 1 and retired the reads before that stage's barrier;
-  //   read the fragments of t + 1 (its weights were waited for before the last barrier) into the other register set;
-  //   multiply stage t; wait for DMA(t + 2) and the reads; barrier.
+  // Stage t = (kc, rs) on register set t & 1 (RS is odd: t = kc RS + rs has the parity of kc + rs): request the fragments of stage t + 1
+  // into the other set (weights from L2, pixels from LDS), select the out-of-image lanes of this stage's pixels to zero, multiply.  Every
+  // wave runs on its own: while one waits for its loads or selects, the other wave of its SIMD feeds the matrix pipe.
+  // (Measured, 128 -> 128 3x3, B = 2048: with the weights in a two-slot LDS-DMA ring shared by the workgroup - one or two barriers per stage,
+  //  the halves in step or half a stage apart - the main loop took 4700 - 4800 cycles per stage against 4096 of matrix work.)
   auto tap_loop = [&](int kc, auto par0c) {
     constexpr int par0 = decltype(par0c)::value;
+    const int nj = kc == KC - 1 ? nj_last : 4;
 #pragma unroll
     for (int rs = 0; rs < RS; rs++) {
       const int cur = (par0 + rs) & 1;
       const int t = kc * RS + rs;
-      const int rs1 = (rs + 1) % RS, rs2 = (rs + 2) % RS;
-      const int kc1 = kc + (rs + 1) / RS, kc2 = kc + (rs + 2) / RS;
-      if (t + 2 < T) stage_dma(kc2, rs2, cur);
-      if (t + 1 < T) load_frags(kc1, rs1, cur ^ 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      const int rs1 = (rs + 1) % RS;
+      const int kc1 = kc + (rs + 1) / RS;
+      if (t + 1 < T) load_frags(kc1, rs1, cur ^ 1);
+      zero_edges(rs, cur);
 #pragma unroll
       for (int j = 0; j < 4; j++)
+        if (j < nj) {
 #pragma unroll
-        for (int i = 0; i < CT0; i++)
-          if (SPLITPX || NCT % 2 == 0 || i < CT0 - 1 || half == 0) {
+          for (int i = 0; i < CT0; i++)
+            if (SPLITPX || NCT % 2 == 0 || i < CT0 - 1 || half == 0) {
 #pragma unroll
-            for (int jt = 0; jt < PT; jt++)
-              acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[cur][jt][j], fw[cur][i][j], acc[i][jt], 0, 0, 0);
-          }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < T) zero_edges(rs1, cur ^ 1);
-      __builtin_amdgcn_s_barrier();
+              for (int jt = 0; jt < PT; jt++)
+                acc[i][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[cur][jt][j], fw[cur][i][j], acc[i][jt], 0, 0, 0);
+            }
+        }
     }
   };
   {
@@ -210,27 +215,44 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const float* __restrict
     }
     if (kc < KC) tap_loop(kc, std::integral_constant<int, 0>{});
   }
+  IG32_STAMP_AT(2);
 
-  // epilogue: lane (m, q) holds output channel 16 tile + m and the four consecutive pixels 16 jt + 4 q .. + 3 of its image
+  // epilogue: lane (m, q) holds output channel 16 tile + m and the four consecutive pixels 16 jt + 4 q .. + 3 of its image.  Every tile's
+  // bias value is requested up front: one memory round trip instead of one per tile
   const int n = n0 + img;
   if (n < N) {
     float* yp = y + (int64_t)n * CO * 64;
     const float* ap = addend ? addend + (int64_t)n * CO * 64 : nullptr;
+    float bv[CT0];
+#pragma unroll
+    for (int i = 0; i < CT0; i++) {
+      const int co = (ct_first + i) * 16 + m;
+      bv[i] = (bias && co < CO) ? bias[co] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < CT0; i++) {
       const int co = (ct_first + i) * 16 + m;
       if (i < ct_count && co < CO) {
-        const float b = bias ? bias[co] : 0.f;
+        f4v av[PT];
+        if (ap) {
+#pragma unroll
+          for (int jt = 0; jt < PT; jt++) av[jt] = *reinterpret_cast<const f4v*>(ap + co * 64 + (jt0 + jt) * 16 + q * 4);
+        }
 #pragma unroll
         for (int jt = 0; jt < PT; jt++) {
           const int off = co * 64 + (jt0 + jt) * 16 + q * 4;
-          f4v v = acc[i][jt] + f4v{b, b, b, b};
-          if (ap) v += *reinterpret_cast<const f4v*>(ap + off);
+          f4v v = acc[i][jt] + f4v{bv[i], bv[i], bv[i], bv[i]};
+          if (ap) v += av[jt];
           *reinterpret_cast<f4v*>(yp + off) = v;
         }
       }
     }
   }
+  IG32_STAMP_AT(3);
+#ifdef IG32_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IG32_STAMP_AT(4);
+#endif
 }
 
 // ---- wgrad ---------------------------------------------------------------------------------------------
@@ -471,7 +493,7 @@ static void run_conv8_f32(const Tensor* in, const Tensor* w, const Tensor* bias,
   const float* wpp = static_cast<const Tensor*>(wpk.get())->ptr<float>() + (dgrad ? dgrad_off : 0);
   const int nct = (CO + 15) / 16;
   const int blocks = (int)((g.N + F_NI - 1) / F_NI);
-  const size_t lds = (size_t)2 * F_WT + (size_t)F_NI * (KP / 4) * F_PSTR;
+  const size_t lds = 64 + (size_t)F_NI * (KP / 4) * F_PSTR;
   KernelTimer kt("conv_igemm_fprop_dgrad_f32", conv_flops(g), conv_bytes(g, 4), st);
   const float* bp = bias ? bias->ptr<float>() : (const float*)nullptr;
   const float* ap = addend ? addend->ptr<float>() : (const float*)nullptr;

@@ -77,7 +77,14 @@ def plan(name, plist):
         ha = re.match(r"^(const )?(lamp_\w+)\* ?const\*$", t)
         h1 = re.match(r"^(const )?(lamp_\w+)\*$", t)
         oa = re.match(r"^(lamp_\w+)\*\[(\d+)\]$", t)
-        if hm and hm.group(2) in HANDLES:
+        if hm and hm.group(2) in HANDLES and re.match(r"^(outs\w*|parts|pieces)$", n):
+            # a caller-sized array of result handles (lamp_chunk_contiguous(outs, x, n, dim)): its length is the function's count parameter.
+            # classified as ONE out parameter this wrote n handles through the address of a single stack slot
+            cnt = [q[1] for q in ps if q[0] == "int" and re.match(r"^(n|count|ntensors|nparts|chunks)$", q[1])]
+            if len(cnt) != 1:
+                return None
+            outs.append(P("handle_outs", n, count_name=cnt[0]))
+        elif hm and hm.group(2) in HANDLES:
             outs.append(P("handle", n))
         elif oa:
             outs.append(P("handle_array", n, n=int(oa.group(2))))
@@ -120,10 +127,12 @@ def result_types(outs):
         o = outs[0]
         if o.kind == "handle":
             return "long", "jlong"
-        if o.kind == "handle_array":
+        if o.kind in ("handle_array", "handle_outs"):
             return "long[]", "jlongArray"
         return {"scalar:int": ("int", "jint"), "scalar:int64_t": ("long", "jlong"), "scalar:uint64_t": ("long", "jlong"),
                 "scalar:double": ("double", "jdouble")}[o.kind]
+    if any(o.kind == "handle_outs" for o in outs):
+        return None, None                      # a variable-length result next to other results: needs a hand-written native
     if all(o.kind in ("handle", "handle_array") for o in outs):
         return "long[]", "jlongArray"
     if all(o.kind.startswith("scalar:int") or o.kind.startswith("scalar:uint") for o in outs):
@@ -191,6 +200,11 @@ def emit_function(name, plist):
         elif o.kind == "handle_array":
             pre.append(f"  void* {o.cname}_o[{o.n}] = {{0}};")
             args_by_name[o.cname] = f"(void*){o.cname}_o"
+        elif o.kind == "handle_outs":
+            pre.append(f"  if ({o.count_name} < 0 || {o.count_name} > LAMP_JNI_MAX_OUTS) {{ lamp_throw_msg(env, \"{name}: result count out of range\"); return NULL; }}")
+            pre.append(f"  void* {o.cname}_o[LAMP_JNI_MAX_OUTS];")
+            pre.append(f"  for (int i_ = 0; i_ < (int){o.count_name}; i_++) {o.cname}_o[i_] = NULL;")
+            args_by_name[o.cname] = f"(void*){o.cname}_o"
         else:
             ct = o.kind.split(":")[1]
             pre.append(f"  {ct} {o.cname}_o = 0;")
@@ -211,6 +225,12 @@ def emit_function(name, plist):
         c.append(f"  return (jlong)(intptr_t){outs[0].cname}_o;")
     elif len(outs) == 1 and outs[0].kind.startswith("scalar"):
         c.append(f"  return ({cret}){outs[0].cname}_o;")
+    elif len(outs) == 1 and outs[0].kind == "handle_outs":
+        o = outs[0]
+        c.append(f"  jlongArray a_ = (*env)->NewLongArray(env, (jsize){o.count_name});")
+        c.append(f"  if (a_) {{ jlong r_[LAMP_JNI_MAX_OUTS]; for (int i_ = 0; i_ < (int){o.count_name}; i_++) r_[i_] = (jlong)(intptr_t){o.cname}_o[i_]; "
+                 f"(*env)->SetLongArrayRegion(env, a_, 0, (jsize){o.count_name}, r_); }}")
+        c.append("  return a_;")
     else:
         vals = []
         for o in outs:
@@ -247,9 +267,15 @@ C_PROLOGUE = '''/* GENERATED by scripts/gen_jni.py from include/lamp_hip.h - do 
 
 #define H(x) ((void*)(intptr_t)(x))
 
+#define LAMP_JNI_MAX_OUTS 4096   /* bound of a caller-sized array of result handles (lamp_chunk_contiguous, lamp_tensors_from_file) */
+
 static void lamp_throw(JNIEnv* env) {
   jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
   if (ex) (*env)->ThrowNew(env, ex, lamp_last_error());
+}
+static void lamp_throw_msg(JNIEnv* env, const char* msg) {
+  jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
+  if (ex) (*env)->ThrowNew(env, ex, msg);
 }
 
 /* ---- hand-written natives: host buffers, strings, raw pointers ------------------------------------------------------------------ */

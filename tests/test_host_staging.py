@@ -165,3 +165,66 @@ def test_mlp_step_on_the_cpu_device_is_baseline_config_1(gpu):
     assert rel_err(to_torch(acc) / 1024, oloss.double().reshape(1)) <= 1e-5
     for g, og in zip(grads, ograds):
         assert rel_err(to_torch(g), og.double()) <= 1e-3
+
+
+def _handles(ts):
+    return (C.c_void_p * len(ts))(*[t.h for t in ts])
+
+
+@pytest.mark.gpu
+def test_aliasing_host_views_alias_on_the_gpu_too(gpu):
+    """arguments that view ONE host storage in different ways (weight | bias cut from one buffer, running mean | running
+    variance cut from another and written in place, the input passed through two handles) are staged as one device block with the same
+    views - the call equals, bit for bit, the same call on device tensors with the same aliasing structure."""
+    rng = np.random.default_rng(5)
+    Cn = 6
+    x_np = rng.standard_normal((4, Cn, 5, 5)).astype(np.float32)
+    wb_np = rng.standard_normal(2 * Cn).astype(np.float32)
+    rs_np = np.concatenate([np.zeros(Cn), np.ones(Cn)]).astype(np.float32)
+
+    def run(dev):
+        x = S.STen.from_numpy(x_np, dev)
+        wb = S.STen.from_numpy(wb_np, dev)
+        rs = S.STen.from_numpy(rs_np, dev)
+        w, b = wb.narrow(0, 0, Cn), wb.narrow(0, Cn, Cn)
+        rm, rv = rs.narrow(0, 0, Cn), rs.narrow(0, Cn, Cn)
+        out = (C.c_void_p * 3)()
+        lib.lamp_native_batch_norm(out, x.h, w.h, b.h, rm.h, rv.h, 1, 0.1, 1e-5)
+        y, mean, invstd = (S.STen(C.c_void_p(h)) for h in out)
+        assert y.device == dev and rs.device == dev
+        return y.to_numpy(), mean.to_numpy(), invstd.to_numpy(), rs.to_numpy()
+
+    host, gpu_ = run(S.CPU), run(0)
+    for a, b in zip(host, gpu_):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(host[3], rs_np), "the running statistics were written back into the shared host buffer"
+    # the same view through two different handles: one device copy, one write-back
+    g = S.STen.from_numpy(np.full((3, 2), 2.0), S.CPU, S.F64)
+    g2 = g.view(3, 2)
+    lib.lamp_gradient_clipping_(_handles([g, g2]), 2, 1.0)
+    gd = S.STen.from_numpy(np.full((3, 2), 2.0), 0, S.F64)
+    gd2 = gd.view(3, 2)
+    lib.lamp_gradient_clipping_(_handles([gd, gd2]), 2, 1.0)
+    assert np.array_equal(g.to_numpy(), gd.to_numpy()) and np.array_equal(g2.to_numpy(), gd.to_numpy())
+
+
+@pytest.mark.gpu
+def test_all_host_adamw_with_a_null_master_array(gpu):
+    """the generated wrapper dereferenced every tensor ARRAY argument - a NULL `master_or_null` (no mixed precision) on host
+    parameters was a segfault instead of the plain f64 step; read-only arrays (the gradients) are staged without a copy back."""
+    p0 = np.array([[1.0, -2.0, 3.0]])
+    g0 = np.array([[0.5, 0.25, -1.0]])
+    one = (C.c_double * 1)
+
+    def run(dev):
+        p, g = S.STen.from_numpy(p0, dev, S.F64), S.STen.from_numpy(g0, dev, S.F64)
+        m, v = S.STen.zeros([1, 3], S.F64, dev), S.STen.zeros([1, 3], S.F64, dev)
+        for step in (1, 2):
+            lib.lamp_adamw_step_(_handles([p]), _handles([g]), _handles([m]), _handles([v]), None, 1, one(1e-3), one(0.01), one(0.9), one(0.95), 1e-8,
+                                 1.0, step, 1)
+        return p.to_numpy(), m.to_numpy(), v.to_numpy(), g.to_numpy()
+
+    host, dev = run(S.CPU), run(0)
+    for a, b in zip(host, dev):
+        assert np.array_equal(a, b)
+    assert np.array_equal(host[3], g0)

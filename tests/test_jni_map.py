@@ -37,6 +37,25 @@ def test_generated_adapter_is_current_and_complete():
     assert {"copyFromDoubleArray", "copyToFloatArray", "copyFromLongArray", "lamp_tensor_sizes", "lamp_tensors_from_file"} <= natives
 
 
+def test_caller_sized_handle_arrays_come_back_as_arrays():
+    """`lamp_tensor** outs` + a count is an ARRAY of results (lamp_chunk_contiguous(outs, x, n, dim) writes n handles):
+    the native must return long[] and hand the C function room for n handles, never the address of one stack slot."""
+    import re
+    java, c, _ = gen_jni.generate()
+    found = 0
+    for name, _, plist in gen_jni.parse_header():
+        ps = [gen_jni.split_param(p) for p in plist]
+        if not any(t.replace("const ", "") == "lamp_tensor**" and re.match(r"^(outs\w*|parts|pieces)$", n) for t, n in ps):
+            continue
+        found += 1
+        decl = [l for l in java.splitlines() if re.search(r"\b%s\(" % name, l)]
+        assert decl and "long[] " + name in decl[0], f"{name}: caller-sized result array must map to long[]: {decl}"
+        body = c[c.index("Java_aten_LampNative_" + name.replace("_", "_1") + "("):]
+        body = body[:body.index("\n}\n")]
+        assert "&outs" not in body and re.search(r"outs\w*(_o)?\[(LAMP_JNI_MAX_OUTS|4096)\]", body), f"{name}: no array for the result handles:\n{body}"
+    assert found >= 2      # lamp_chunk_contiguous, lamp_tensors_from_file
+
+
 def test_generated_adapter_compiles():
     out = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DLAMP_JNI_SYNTAX_CHECK", "-I", os.path.join(ROOT, "include"),
                           "-I", os.path.join(ROOT, "jni"), gen_jni.OUT_C], capture_output=True, text=True)
