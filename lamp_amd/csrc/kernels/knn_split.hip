@@ -14,7 +14,10 @@
 //   with the top-k selection fused in; the 16 best candidates per query by a = (|q|^2 + |x|^2) - 2 (that sum) are kept.
 //   Error of the sum: the dropped products (q1.x1, q0.r, r.x0: <= 3.1 * 2^-22 |q||x|) plus the f32 accumulation of 12 MFMA results (each a
 //   32-term sum; <= 6 roundings each, 2^-24 relative to sum |q_i x_i|): 2.1e-6 |q||x|, bounded by c = 2^-18 = 3.8e-6 (the largest error
-//   seen on the test sets is 4e-7).  So |a - d| <= eps_q = 2 c |q| max|x| + 2^-21 (|q|^2 + max|x|^2) (the second term: the f32 formula's own rounding).
+//   seen on the test sets is 4e-7).  So |a - d| <= eps_q = 2 c |q_c| max|x_c| + 2^-21 (|q|^2 + max|x|^2) + 2^-20 (|q_c|^2 + max|x_c|^2): the second term is
+//   the f32 formula's own rounding (f64 searches: 2^-50), the third the f32 accumulation of the centred norms and the rounding of the centred
+//   rows to f32 before the split (_c = after the mean row was subtracted) - a far outlier opposite the mean makes max|x_c|^2 large and the
+//   slack in c alone does not cover that (tests: an f64 set with such an outlier and near-tied k-th / (k+1)-th neighbours).
 // Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the ORIGINAL f32 data (dot product accumulated in f64, rounded once,
 //   then the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
 //   a >= a_16, hence d >= a_16 - eps_q: when the k-th re-ranked distance is strictly below that, the k neighbours are exactly those an
@@ -396,7 +399,11 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const T* __restrict__ q
   // (the filter worked on the centred rows: its error scales with their norms; the formula's own rounding - f32 only - with the original ones)
   const double a_last = (double)cand_val[qi];
   const double noise = std::is_same<T, float>::value ? 0x1p-21 * ((double)qnv + (double)dn_max[0]) : 0x1p-50 * ((double)qnv + (double)dn_max[0]);
-  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[qi]) * sqrt((double)dn_c_max[0]) + noise;
+  // + the f32 arithmetic of the quantities the FILTER compared: the centred norms qn_c / dn_c are accumulated in f32 and the
+  // centred rows are rounded to f32 before they are split - at most 2^-21 + 2^-22 of (|q_c|^2 + |x_c|^2), bounded by 2^-20 of it; on the f64
+  // path nothing else covers these (its `noise` is 2^-50)
+  const double filter_noise = 0x1p-20 * ((double)qn_c[qi] + (double)dn_c_max[0]);
+  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[qi]) * sqrt((double)dn_c_max[0]) + noise + filter_noise;
   const bool all_points_are_candidates = N <= KS_M;
   if (part == 0 && rank == k - 1 && !all_points_are_candidates && !((double)d < a_last - eps)) {
     const int slot = atomicAdd(nfailed, 1);
@@ -433,7 +440,8 @@ __global__ void knn_predict_kernel(const T* __restrict__ val16, const T* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
   const double noise = (std::is_same<T, float>::value ? 0x1p-21 : 0x1p-50) * ((double)qn[i] + (double)dn_max[0]);
-  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[i]) * sqrt((double)dn_c_max[0]) + noise;
+  const double filter_noise = 0x1p-20 * ((double)qn_c[i] + (double)dn_c_max[0]);     // as in knn_rerank_kernel
+  const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[i]) * sqrt((double)dn_c_max[0]) + noise + filter_noise;
   const double gap = (double)val16[(int64_t)i * KS_M + KS_M - 1] - (double)val16[(int64_t)i * KS_M + k - 1];
   if (!(gap > 2.0 * eps)) atomicAdd(unproven, 1);
 }

@@ -659,6 +659,43 @@ def test_knn_split_filter_far_from_the_origin_and_falls_back_on_duplicates(gpu):
     assert np.array_equal(si[300:320], np.tile(np.arange(300, 310), (20, 1))), "ten of twenty equal points: the ten lowest indices"
 
 
+def test_knn_split_proof_holds_with_a_far_outlier_and_near_ties(gpu):
+    """the per-query proof must also cover the f32 arithmetic of what the filter compares (centred norms accumulated in f32, centred
+    rows rounded to f32).  f64 data - where nothing else covers it - in a tight cluster away from the origin, ONE far outlier opposite the mean
+    (max |x_c|^2 is then ~1e6 times a neighbour's) and queries whose 1st .. 30th neighbours sit on a shell with radii 1e-7 apart (squared
+    distances 2e-10 apart: above the f64 formula's own noise at |q|^2 = 1600, far below anything an f16 filter resolves): the filter cannot order them, so those queries must fail the proof and come from the exact kernel - the neighbour sets are the exact search's
+    on EVERY row."""
+    g = torch.Generator().manual_seed(31)
+    n, d, k, nshell = 6000, 64, 10, 40
+    data = 5.0 + 1e-2 * torch.randn(n, d, generator=g, dtype=torch.float64)
+    data[n - 1] = -1000.0                                                     # the outlier
+    base = 200
+    for s_ in range(nshell):                                                  # query s_: thirty points on a thin shell around it
+        c = data[s_].clone()
+        dirs = torch.randn(30, d, generator=g, dtype=torch.float64)
+        dirs /= dirs.norm(dim=1, keepdim=True)
+        radii = 1e-3 * (1.0 + 1e-4 * torch.arange(30, dtype=torch.float64))
+        data[base + 30 * s_: base + 30 * (s_ + 1)] = c + dirs * radii.reshape(30, 1)
+    query = data[:400].clone()
+    try:
+        lib.lamp_knn_split_mode(0)
+        ei, ed = _knn(data, query, k)
+        lib.lamp_knn_split_mode(2)
+        si, sd = _knn(data, query, k)
+        failed = C.c_int64(-1)
+        lib.lamp_knn_split_last_failed(C.byref(failed))
+    finally:
+        lib.lamp_knn_split_mode(1)
+    exact = O.squared_euclidean_distance(query, data)
+    ref = torch.topk(exact, k, 1, largest=False, sorted=True)[1].numpy()
+    v = torch.topk(exact, k + 1, 1, largest=False, sorted=True)[0]
+    sep = ((v[:, k] - v[:, k - 1]) > 1e-11).numpy()                          # rows the f64 formula decides (its noise at |q|^2 = 1600 is ~4e-13)
+    assert sep[:nshell].all() and sep.sum() > 300
+    assert np.array_equal(np.sort(ei[sep], 1), np.sort(ref[sep], 1)), "the exact kernel resolves squared distances 2e-10 apart in f64"
+    assert np.array_equal(np.sort(si, 1), np.sort(ei, 1)), "filter + proof + fallback = the exact search on every row"
+    assert failed.value >= nshell, f"only {failed.value} queries failed the proof: the shell queries cannot be proven by an f16 filter"
+
+
 def test_knn_few_queries_slice_the_data_set(gpu):
     """A handful of queries against many points: the exact kernel cuts the data set into slices over blockIdx.y (a workgroup per query block
     would stream all of it alone) and merges the per-slice lists - same indices and values as the unsliced search of the same rows."""
