@@ -409,23 +409,25 @@ def main():
         # frac((i d + j) 2654435761 / 2^32), is a rank-1 lattice (point i + 1 is point i shifted by one constant modulo 1 in every
         # coordinate): thousands of EXACTLY tied neighbour distances per query, i.e. no well defined neighbour sets.  The same index goes
         # through murmur3's 32-bit finaliser instead (--umap-points weyl: the lattice, as measured in rounds 1 - 2).
-        idx_ = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(d_) + np.arange(d_, dtype=np.uint64)[None, :]
-        if a.umap_points == "weyl":
-            h_ = (idx_ * np.uint64(2654435761)) % np.uint64(2 ** 32)
-        else:
-            m32 = np.uint64(0xffffffff)
-            h_ = idx_ & m32
-            h_ ^= h_ >> np.uint64(16); h_ = (h_ * np.uint64(0x85ebca6b)) & m32
-            h_ ^= h_ >> np.uint64(13); h_ = (h_ * np.uint64(0xc2b2ae35)) & m32
-            h_ ^= h_ >> np.uint64(16)
-        pts = h_.astype(np.float64) / 2.0 ** 32 + (np.arange(n) % 16)[:, None]
-        del idx_, h_
-        X32 = S.STen.from_numpy(pts.astype(np.float32), local_rank, S.F32)
-        X64 = S.STen.from_numpy(pts, local_rank, S.F64)
-        del pts
+        def make_points(kind):
+            idx_ = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(d_) + np.arange(d_, dtype=np.uint64)[None, :]
+            if kind == "weyl":
+                h_ = (idx_ * np.uint64(2654435761)) % np.uint64(2 ** 32)
+            else:
+                m32 = np.uint64(0xffffffff)
+                h_ = idx_ & m32
+                h_ ^= h_ >> np.uint64(16); h_ = (h_ * np.uint64(0x85ebca6b)) & m32
+                h_ ^= h_ >> np.uint64(13); h_ = (h_ * np.uint64(0xc2b2ae35)) & m32
+                h_ ^= h_ >> np.uint64(16)
+            pts = h_.astype(np.float64) / 2.0 ** 32 + (np.arange(n) % 16)[:, None]
+            del idx_, h_
+            return S.STen.from_numpy(pts.astype(np.float32), local_rank, S.F32), S.STen.from_numpy(pts, local_rank, S.F64)
+        umap_pts = make_points(a.umap_points)
         phase = {}
 
-        def run(timed_phases=None):
+        def run(timed_phases=None, X32=None, X64=None):
+            X32 = X32 if X32 is not None else umap_pts[0]
+            X64 = X64 if X64 is not None else umap_pts[1]
             def mark(name, t0):
                 if timed_phases is not None:
                     lib.lamp_device_synchronize(); timed_phases[name] = time.perf_counter() - t0
@@ -602,6 +604,20 @@ def main():
         result_extra["phases"] = ph
         result_extra["edges"] = int(n_edges)
         result_extra["final_loss"] = float(last_loss)
+        if a.umap_points == "mixed" and a.gpus == 1:
+            # the headline points differ from SURVEY 8d's example (a lattice of exactly tied distances, where the f16 kNN filter
+            # cannot prove anything and the exact kernel runs): the same job on the survey's points, one warm-up and one timed run, so that the
+            # line stays comparable with rounds 1 - 2
+            sx32, sx64 = make_points("weyl")
+            run(None, sx32, sx64)
+            lib.lamp_device_synchronize()
+            t_s = time.perf_counter()
+            run(None, sx32, sx64)
+            lib.lamp_device_synchronize()
+            t_s = time.perf_counter() - t_s
+            result_extra["survey_points"] = {"points": "SURVEY 8d's closed form frac((i d + j) 2654435761 / 2^32) + 16 clusters (a rank-1 lattice: tied distances)",
+                                             "seconds": t_s, "value": n / t_s, "unit": "points/s"}
+            del sx32, sx64
         lay_rows = [r for r in class_rows if r["tag"] == "umap_pairs2"]
         knn_rows = [r for r in class_rows if r["tag"].startswith("knn_fused") or r["tag"].startswith("knn_split")]
         if lay_rows:

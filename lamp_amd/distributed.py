@@ -81,9 +81,9 @@ class ControlPlane:
             srv.settimeout(timeout)
             nonce = os.urandom(8).hex()
             if rdzv:
-                tmp = f"{rdzv}.{os.getpid()}.tmp"
-                # owner-only: the nonce keeps strangers on a shared host out of the clique, so they must not be able to read it
-                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+                # owner-only (mkstemp: 0600, O_EXCL, an unpredictable name - nobody can plant a symlink where this process is about to
+                # write): the nonce keeps strangers on a shared host out of the clique, so they must not be able to read it
+                fd, tmp = tempfile.mkstemp(prefix=os.path.basename(rdzv) + ".", suffix=".tmp", dir=os.path.dirname(rdzv) or ".")
                 with os.fdopen(fd, "w") as f:
                     json.dump({"port": srv.getsockname()[1], "nonce": nonce, "pid": os.getpid()}, f)
                 os.replace(tmp, rdzv)                                  # atomic: readers see nothing or the whole record (a stale one is replaced)
@@ -108,6 +108,9 @@ class ControlPlane:
                         # has closed this connection and is retrying on a new one - counting the dead one would end the accept loop
                         if not _recv_msg(c).get("ack"):
                             raise ConnectionError("no acknowledgement")
+                        # ... and is told that it now counts: a client whose acknowledgement came too late for the 5 s above sees this
+                        # connection closed instead and joins again on a new one (it used to keep the dead socket)
+                        _send_msg(c, {"joined": True})
                         c.settimeout(timeout)
                     except (OSError, ValueError, KeyError, TypeError, AttributeError, ConnectionError, struct.error):
                         try:
@@ -138,6 +141,9 @@ class ControlPlane:
                         s.close()
                         raise ConnectionError(ans.get("why", "refused"))
                     _send_msg(s, {"ack": True})
+                    if not _recv_msg(s).get("joined"):    # rank 0 dropped this connection (acknowledgement too late): closed socket -> retry
+                        s.close()
+                        raise ConnectionError("rank 0 did not confirm the join")
                     s.settimeout(timeout)
                     self.up = s
                     break
