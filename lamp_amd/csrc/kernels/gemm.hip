@@ -57,6 +57,8 @@ struct GemmArgs {
   int split_f32;
   // bf16: round alpha * acc to bf16 before the beta operand is added - bitwise the chain `mm` then `add` that lamp's Linear issues
   int round_first;
+  // split-K of the f32 / f64 kernel: blockIdx.z = K chunk of g.K (the last one shorter: k_split_total - z g.K), raw sums to C[z][M][N]
+  int64_t k_split_total;
 };
 
 // ================================================================================================
@@ -657,6 +659,21 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   }
 }
 
+// split-K epilogue of the f32 / f64 kernel: C[m][n] = alpha * sum_z W[z][m][n] + beta * S[m][n], slices summed in order (deterministic)
+template <class T>
+__global__ __launch_bounds__(256) void gemm_fp_splitk_reduce_kernel(const T* __restrict__ W, int split, int64_t M, int64_t N, T* __restrict__ C, int64_t ldc,
+                                                                    const T* __restrict__ S, int64_t s_rs, int64_t s_cs, T alpha, T beta) {
+  const int64_t total = M * N;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    T a = W[e];
+    for (int z = 1; z < split; z++) a += W[(int64_t)z * total + e];
+    const int64_t row = e / N, col = e - row * N;
+    T v = alpha * a;
+    if (S) v += beta * S[row * s_rs + col * s_cs];
+    C[row * ldc + col] = v;
+  }
+}
+
 // ================================================================================================
 // f32 / f64 kernel: 64 x 64 x 16 tile, 256 threads = 4 waves (2 x 2), 32 x 32 per wave,
 // v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64. LDS tiles are k-major [16][64+pad] so a
@@ -697,6 +714,7 @@ __global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
   const int bz = blockIdx.z;
   const T* A = (const T*)g.A + bz * g.a_bs;
   const T* B = (const T*)g.B + bz * g.b_bs;
+  const int64_t K = g.k_split_total > 0 ? min(g.K, g.k_split_total - (int64_t)bz * g.K) : g.K;
 
   acc4 acc[2][2];
 #pragma unroll
@@ -716,8 +734,8 @@ __global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
       if (a_kc) { ar = e >> 4; ak = e & 15; } else { ak = e >> 6; ar = e & 63; }
       if (b_kc) { bn = e >> 4; bk = e & 15; } else { bk = e >> 6; bn = e & 63; }
       const int64_t gm = m0 + ar, gka = k0 + ak, gn = n0 + bn, gkb = k0 + bk;
-      ra[i] = (gm < g.M && gka < g.K) ? A[gm * g.a_rs + gka * g.a_cs] : T(0);
-      rb[i] = (gn < g.N && gkb < g.K) ? B[gkb * g.b_rs + gn * g.b_cs] : T(0);
+      ra[i] = (gm < g.M && gka < K) ? A[gm * g.a_rs + gka * g.a_cs] : T(0);
+      rb[i] = (gn < g.N && gkb < K) ? B[gkb * g.b_rs + gn * g.b_cs] : T(0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(256) void gemm_fp_kernel(GemmArgs g) {
     }
   };
 
-  const int nk = (int)((g.K + FK - 1) / FK);
+  const int nk = (int)((K + FK - 1) / FK);
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -1189,6 +1207,41 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     const int64_t lda32 = a_kc32 ? g.a_rs : g.a_cs, ldb32 = b_kc32 ? g.b_cs : g.b_rs;
     const bool big32 = a->dtype == kF32 && (lda32 % 4 == 0) && (ldb32 % 4 == 0) && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0 &&
                        (g.a_bs % 4 == 0) && (g.b_bs % 4 == 0) && ((g.M + GM - 1) / GM) * ((g.N + GN - 1) / GN) * g.batch >= 128;
+    // Few output tiles over a long K (config 1's MLP: 1024 x 784 . 784 x 256 is 64 tiles on 256 CUs, each walking 49 k-steps one global
+    // round trip at a time: 35 us for 0.4 GFLOP): K is split over blockIdx.z until every CU has a workgroup (chunks of at least 64), the
+    // f32 / f64 slices are summed in order by a second launch.  LAMP_GEMM_SPLITK=0: off.
+    static const bool allow_fp_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
+    const int64_t fp_tiles = (int64_t)g.tiles_m * g.tiles_n;
+    if (allow_fp_split && g.batch == 1 && !g.knn_q && fp_tiles < 128 && g.K >= 128) {
+      static const int64_t fp_split_wgs = [] { const char* e = getenv("LAMP_GEMM_FP_SPLIT_WGS"); return e ? std::max(1, atoi(e)) : 512; }();
+      int64_t split = std::min<int64_t>(std::min<int64_t>((fp_split_wgs + fp_tiles - 1) / fp_tiles, g.K / 64), 32);
+      if (split > 1) {
+        const int64_t kc = ((g.K + split - 1) / split + FK - 1) / FK * FK;
+        split = (g.K + kc - 1) / kc;
+      }
+      if (split > 1) {
+        const int64_t kc = ((g.K + split - 1) / split + FK - 1) / FK * FK;
+        Hold ws(new_tensor({split, g.M, g.N}, a->dtype, out->device()));
+        GemmArgs h = g;
+        h.k_split_total = g.K; h.K = kc;
+        h.a_bs = kc * g.a_cs; h.b_bs = kc * g.b_rs;
+        h.C = ws->data(); h.ldc = g.N; h.c_bs = g.M * g.N; h.S = nullptr; h.alpha = 1.0; h.beta = 0.0;
+        dim3 sgrid(g.tiles_m * g.tiles_n, 1, (unsigned)split);
+        if (a->dtype == kF32) {
+          hipLaunchKernelGGL((gemm_fp_kernel<float>), sgrid, dim3(256), 0, stm, h);
+          LAMP_LAUNCH_CHECK();
+          hipLaunchKernelGGL((gemm_fp_splitk_reduce_kernel<float>), dim3(grid_for(g.M * g.N, 256)), dim3(256), 0, stm, (const float*)ws->data(), (int)split, g.M, g.N,
+                             (float*)g.C, g.ldc, (const float*)g.S, g.s_rs, g.s_cs, (float)g.alpha, (float)g.beta);
+        } else {
+          hipLaunchKernelGGL((gemm_fp_kernel<double>), sgrid, dim3(256), 0, stm, h);
+          LAMP_LAUNCH_CHECK();
+          hipLaunchKernelGGL((gemm_fp_splitk_reduce_kernel<double>), dim3(grid_for(g.M * g.N, 256)), dim3(256), 0, stm, (const double*)ws->data(), (int)split, g.M,
+                             g.N, (double*)g.C, g.ldc, (const double*)g.S, g.s_rs, g.s_cs, g.alpha, g.beta);
+        }
+        LAMP_LAUNCH_CHECK();
+        return;
+      }
+    }
     if (big32) {
       g.tiles_m = (int)((g.M + GM - 1) / GM);
       g.tiles_n = (int)((g.N + GN - 1) / GN);

@@ -259,6 +259,29 @@ def test_gemm_split_k(gpu, M, N, K):
     assert_close(to_torch(O), o0.double() + ref, 1.6e-2, "out += x^T . p")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 784), (784, 256, 1024), (256, 10, 1024), (100, 60, 1000), (64, 64, 130), (1, 300, 4097)])
+def test_gemm_f32_split_k(gpu, dt, M, N, K):
+    """the f32 / f64 kernel with few output tiles over a long K (config 1's MLP shapes: 64 / 52 / 4 tiles on 256 CUs)
+    splits K over blockIdx.z - chunks that are multiples of the 16-deep k-step, a shorter last chunk, K not a multiple of anything -
+    and sums the slices in order: north_star's 1e-5 (f32) against f64, the beta operand and transposed layouts included, and the
+    same bits on every run."""
+    a, b = closed_form((M, K), 1, 2.0, dt), closed_form((K, N), 77, 2.0, dt)
+    ref = a.double() @ b.double()
+    tol = 1e-5 if dt == torch.float32 else 1e-12
+    A, B = to_sten(a), to_sten(b)
+    got = A.mm(B).to_numpy()
+    assert_close(torch.from_numpy(got), ref, tol, "mm")
+    assert np.array_equal(got, A.mm(B).to_numpy()), "fixed summation order: bitwise reproducible"
+    assert_close(to_torch(to_sten(a.t().contiguous()).t.mm(to_sten(b.t().contiguous()).t)), ref, tol, "mm of transposed views")
+    o0, p = closed_form((K, N), 5, 1.0, dt), closed_form((M, N), 9, 1.0, dt)
+    O = to_sten(o0)
+    S.STen.addmm_out_transposed1(O, O, A, to_sten(p), 1.0, 1.0)          # K of THIS product is M
+    assert_close(to_torch(O), o0.double() + a.double().t() @ p.double(), tol * 2, "out += a^T . p")
+    bias = closed_form((1, N), 4, 1.0, dt)
+    assert_close(to_torch(to_sten(bias).addmm(A, B, 0.5, 2.0)), 0.5 * bias.double() + 2.0 * ref, tol * 2, "addmm broadcast self")
+
+
 @pytest.mark.parametrize("M,N,K", [(96, 40, 72), (512, 1024, 768), (4096, 4096, 512), (256, 256, 4096)])
 def test_linear_bias_is_bitwise_the_mm_add_chain(gpu, M, N, K):
     """lamp's Linear and the transformer MLP issue x.mm(w) + bias; lamp_linear_bias adds the row vector in the GEMM epilogue after
