@@ -564,6 +564,27 @@ int lamp_diag(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal);       
 int lamp_cross(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* b, int64_t dim);   /* ATen.cross along a dimension of size 3 (ops.scala:581-601) */
 int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value);
 int lamp_topk(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t k, int64_t dim, int largest, int sorted);
+/* Sorting family (kernels/sort.hip; STen.scala:1592 argsort, :1761 sort, :1553 median, :1037-1055 unique, :1034 bincount).  The sort is
+ * stable in both directions (equal values keep their order; NaN sorts above every number, as ATen's), which is also a legal result of
+ * ATen's unstable sort.  lamp_unique / lamp_bincount have data dependent output sizes: one host synchronisation each. */
+int lamp_sort(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t dim, int descending);
+int lamp_argsort(lamp_tensor** out, const lamp_tensor* a, int stable, int64_t dim, int descending);
+int lamp_median_dim(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t dim, int keepdim);   /* median_1: the lower median */
+int lamp_unique(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a);   /* _unique / _unique2, sorted */
+int lamp_bincount(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* weights_or_null, int64_t minlength);
+/* Overwriting scatters (STen.scala:1412-1423 scatter, :1715-1726 indexPut / put / indexCopy).  Duplicate targets without accumulation: one
+ * of the writers wins (unspecified in ATen too); out-of-range indices raise at the next host wait (device assertion, like ATen's). */
+int lamp_scatter(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src);          /* scatter_0 */
+int lamp_scatter_value(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, double value);              /* scatter_1 */
+int lamp_index_put(lamp_tensor** out, const lamp_tensor* self, lamp_tensor* const* indices, int n, const lamp_tensor* values, int accumulate);
+int lamp_put(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* index, const lamp_tensor* values, int accumulate);
+int lamp_index_copy(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
+/* Triangles and diagonals (STen.scala:1883-1886, :1322) */
+int lamp_tril(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal);
+int lamp_triu(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal);
+int lamp_tril_out(lamp_tensor* out, const lamp_tensor* a, int64_t diagonal);           /* out may be a itself (STen.tril_) */
+int lamp_diagonal(lamp_tensor** out, const lamp_tensor* a, int64_t offset, int64_t dim1, int64_t dim2);   /* a view */
+int lamp_trace(lamp_tensor** out, const lamp_tensor* a);
 int lamp_one_hot(lamp_tensor** out, const lamp_tensor* a, int64_t num_classes);
 int lamp_embedding(lamp_tensor** out, const lamp_tensor* weight, const lamp_tensor* indices);
 /* ATen embedding_backward(grad, indices, num_weights, padding_idx, false, false): rows equal to padding_idx get no gradient;
@@ -575,6 +596,10 @@ int lamp_rand(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int 
 int lamp_randn(lamp_tensor** out, const int64_t* sizes, int ndim, int dtype, int device);
 int lamp_normal(lamp_tensor** out, double mean, double std, const int64_t* sizes, int ndim, int dtype, int device);
 int lamp_randint(lamp_tensor** out, int64_t low, int64_t high, const int64_t* sizes, int ndim, int dtype, int device);
+/* STen.randperm (:274, int64) and STen.multinomial (:259-264; the language model's sampler, languagemodel/package.scala:100): the library's
+ * Philox stream; with replacement an inverse-CDF draw per sample, without replacement the num_samples first of the exponential clocks E / p. */
+int lamp_randperm(lamp_tensor** out, int64_t n, int dtype, int device);
+int lamp_multinomial(lamp_tensor** out, const lamp_tensor* probs, int64_t num_samples, int replacement);
 int lamp_dropout_(lamp_tensor* self, double p, int training);
 
 /* ------------------------------------------------------------------------------------------

@@ -211,6 +211,53 @@ __global__ void gather_scatter_kernel(T* __restrict__ a /* gather: out ; scatter
     else a[ao] = b[bo + t * g.bstr[g.dim]];
   }
 }
+// scatter WITHOUT accumulation (ATen.scatter, STen.scala:1412-1423): self[.., index[e], ..] = src[e] or a scalar.  Duplicate targets: one of
+// the writers wins (ATen leaves it unspecified too)
+template <class T, bool VALUE>
+__global__ void scatter_set_kernel(T* __restrict__ a, const int64_t* __restrict__ index, const T* __restrict__ b, T value, int64_t n, GsGeom g,
+                                   int* __restrict__ assert_word) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e, io = 0, ao = 0, bo = 0;
+    for (int d = g.ndim - 1; d >= 0; d--) {
+      const int64_t c = r % g.isz[d]; r /= g.isz[d];
+      io += c * g.istr[d];
+      if (d != g.dim) ao += c * g.astr[d];
+      bo += c * g.bstr[d];
+    }
+    const int64_t t = index[io];
+    if (t < 0 || t >= g.dlim) { *(volatile int*)assert_word = kAssertIndexRange; continue; }
+    a[ao + t * g.astr[g.dim]] = VALUE ? value : b[bo];
+  }
+}
+// index_put / put (STen.scala:1715-1722): K index tensors (each with NI elements) address the first K dimensions of `a`; every index
+// position carries `inner` trailing elements.  Negative indices count from the end.
+struct IpGeom { int K; const int64_t* idx[kMaxDims]; int64_t size[kMaxDims]; int64_t stride[kMaxDims]; };
+template <class T, bool ACC>
+__global__ void index_put_kernel(T* __restrict__ a, const T* __restrict__ v, IpGeom g, int64_t NI, int64_t inner, int* __restrict__ assert_word) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < NI * inner; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = e / inner, r = e - p * inner;
+    int64_t off = r;
+    bool ok = true;
+    for (int k = 0; k < g.K; k++) {
+      int64_t t = g.idx[k][p];
+      if (t < 0) t += g.size[k];
+      if (t < 0 || t >= g.size[k]) { ok = false; break; }
+      off += t * g.stride[k];
+    }
+    if (!ok) { *(volatile int*)assert_word = kAssertIndexRange; continue; }
+    if (ACC) atomic_add_t<T>(a + off, v[e]); else a[off] = v[e];
+  }
+}
+// tril / triu of the last two dimensions (STen.scala:1883-1884)
+template <class T>
+__global__ void tri_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t total, int64_t R, int64_t Cn, int64_t diagonal, int lower) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = e % Cn, r = (e / Cn) % R;
+    const bool keep = lower ? (c - r <= diagonal) : (c - r >= diagonal);
+    T z; memset(&z, 0, sizeof(T));
+    out[e] = keep ? x[e] : z;
+  }
+}
 // index_fill along dim (IndexFill op, ops.scala:160-177)
 // diag(v, k): out[m, m] zero except out[i + max(-k, 0)][i + max(k, 0)] = v[i]   (ATen diag of a vector)
 template <class T>
@@ -723,6 +770,175 @@ int lamp_scatter_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, co
     LAMP_LAUNCH_CHECK();
   }
   *out = r.take();
+  LAMP_API_END
+}
+static void scatter_set(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src, double value) {
+  check_device_tensor(self, "self"); check_device_tensor(index, "index");
+  if (src) { check_device_tensor(src, "src"); LAMP_CHECK(self->dtype == src->dtype, "scatter: dtype mismatch"); }
+  Hold r(new_tensor(self->shape(), self->dtype, self->device()));
+  copy_into(r.get(), self);
+  const GsGeom g = gs_geom(r.get(), index, src ? src : index, dim, true);
+  const int64_t n = index->numel();
+  if (n) {
+    hipStream_t st = current_stream(self->device());
+    if (src) {
+      LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((scatter_set_kernel<T, false>), dim3(grid_for(n, 256)), dim3(256), 0, st, r->ptr<T>(), index->ptr<int64_t>(),
+                                                           src->ptr<T>(), T{}, n, g, device_assert_word(self->device())));
+    } else {
+      LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((scatter_set_kernel<T, true>), dim3(grid_for(n, 256)), dim3(256), 0, st, r->ptr<T>(), index->ptr<int64_t>(),
+                                                           (const T*)nullptr, store_as<T>((acc_t<T>)value), n, g, device_assert_word(self->device())));
+    }
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+}
+int lamp_scatter(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* src) {
+  LAMP_API_BEGIN scatter_set(out, self, dim, index, src, 0.0); LAMP_API_END
+}
+int lamp_scatter_value(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, double value) {
+  LAMP_API_BEGIN scatter_set(out, self, dim, index, nullptr, value); LAMP_API_END
+}
+// out = self with out[indices[0][p], .., indices[K-1][p], ...] (+)= values[p, ...]: the index tensors are broadcast to one shape I, values to
+// I x (the remaining dimensions of self)
+static void index_put_impl(lamp_tensor** out, const lamp_tensor* self, lamp_tensor* const* indices, int n, const lamp_tensor* values, int accumulate) {
+  check_device_tensor(self, "self"); check_device_tensor(values, "values");
+  LAMP_CHECK(n >= 1 && n <= self->ndim, "index_put: " << n << " index tensors for " << self->describe());
+  LAMP_CHECK(values->dtype == self->dtype, "index_put: values " << values->describe() << " differ in dtype from self " << self->describe());
+  std::vector<int64_t> ishape;
+  for (int k = 0; k < n; k++) {
+    LAMP_CHECK(indices[k] != nullptr, "index_put: undefined index tensors (None) are not supported");
+    check_device_tensor(indices[k], "index");
+    LAMP_CHECK(indices[k]->dtype == kI64, "index_put: indices must be int64, got " << indices[k]->describe());
+    ishape = k == 0 ? indices[k]->shape() : broadcast_shapes(ishape, indices[k]->shape());
+  }
+  Hold r(new_tensor(self->shape(), self->dtype, self->device()));
+  copy_into(r.get(), self);
+  IpGeom g;
+  g.K = n;
+  std::vector<Hold> idx;
+  int64_t NI = 1;
+  for (int64_t v : ishape) NI *= v;
+  for (int k = 0; k < n; k++) {
+    Hold e(new_tensor(ishape, kI64, self->device()));
+    copy_into(e.get(), indices[k]);                       // broadcast
+    g.idx[k] = e->ptr<int64_t>(); g.size[k] = r->sizes[k]; g.stride[k] = r->strides[k];
+    idx.push_back(std::move(e));
+  }
+  std::vector<int64_t> vshape = ishape;
+  int64_t inner = 1;
+  for (int d = n; d < self->ndim; d++) { vshape.push_back(self->sizes[d]); inner *= self->sizes[d]; }
+  Hold ve(new_tensor(vshape, self->dtype, self->device()));
+  copy_into(ve.get(), values);                            // broadcast
+  if (NI * inner) {
+    hipStream_t st = current_stream(self->device());
+    if (accumulate) {
+      LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((index_put_kernel<T, true>), dim3(grid_for(NI * inner, 256)), dim3(256), 0, st, r->ptr<T>(), ve->ptr<T>(), g, NI,
+                                                           inner, device_assert_word(self->device())));
+    } else {
+      LAMP_DISPATCH_ALL(self->dtype, T, hipLaunchKernelGGL((index_put_kernel<T, false>), dim3(grid_for(NI * inner, 256)), dim3(256), 0, st, r->ptr<T>(), ve->ptr<T>(), g, NI,
+                                                           inner, device_assert_word(self->device())));
+    }
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
+}
+int lamp_index_put(lamp_tensor** out, const lamp_tensor* self, lamp_tensor* const* indices, int n, const lamp_tensor* values, int accumulate) {
+  LAMP_API_BEGIN index_put_impl(out, self, indices, n, values, accumulate); LAMP_API_END
+}
+// ATen.put: self viewed as one long vector
+int lamp_put(lamp_tensor** out, const lamp_tensor* self, const lamp_tensor* index, const lamp_tensor* values, int accumulate) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self"); check_device_tensor(index, "index"); check_device_tensor(values, "values");
+  LAMP_CHECK(index->numel() == values->numel(), "put: index " << index->describe() << " and values " << values->describe() << " differ in length");
+  Hold sc(contiguous(self));
+  int64_t flat[1] = {sc->numel()}, one[1] = {1}, nn[1] = {index->numel()};
+  Hold sf(new_view(sc.get(), flat, one, 1, sc->offset));
+  Hold ic(contiguous(index)), vc(contiguous(values));
+  Hold i1(new_view(ic.get(), nn, one, 1, ic->offset)), v1(new_view(vc.get(), nn, one, 1, vc->offset));
+  lamp_tensor* ids[1] = {i1.get()};
+  lamp_tensor* o = nullptr;
+  index_put_impl(&o, sf.get(), ids, 1, v1.get(), accumulate);
+  Hold oh(o);
+  int64_t cst[kMaxDims], run = 1;
+  for (int i = self->ndim - 1; i >= 0; i--) { cst[i] = run; run *= self->sizes[i]; }
+  *out = new_view(oh.get(), self->sizes, cst, self->ndim, oh->offset);
+  LAMP_API_END
+}
+// ATen.index_copy: out = self with out.select(dim, index[i]) = source.select(dim, i)
+int lamp_index_copy(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source) {
+  LAMP_API_BEGIN
+  check_device_tensor(self, "self"); check_index(index); check_device_tensor(source, "source");
+  LAMP_CHECK(self->ndim >= 1 && source->ndim == self->ndim && source->dtype == self->dtype, "index_copy: source " << source->describe() << " does not match self " << self->describe());
+  const int64_t d = wrap_dim(dim, self->ndim);
+  LAMP_CHECK(source->sizes[d] == index->numel(), "index_copy: source has " << source->sizes[d] << " slices along dim, index " << index->numel());
+  // move dim first on both, then it is an index_put with one index tensor
+  lamp_tensor *st = nullptr, *srt = nullptr;
+  LAMP_CHECK(lamp_transpose(&st, self, 0, d) == 0, lamp_last_error());
+  Hold sth(st);
+  LAMP_CHECK(lamp_transpose(&srt, source, 0, d) == 0, lamp_last_error());
+  Hold srth(srt);
+  Hold sc(contiguous(sth.get()));
+  Hold i1(contiguous(index));
+  lamp_tensor* ids[1] = {i1.get()};
+  lamp_tensor* o = nullptr;
+  index_put_impl(&o, sc.get(), ids, 1, srth.get(), 0);
+  Hold oh(o);
+  lamp_tensor* back = nullptr;
+  LAMP_CHECK(lamp_transpose(&back, oh.get(), 0, d) == 0, lamp_last_error());
+  Hold bh(back);
+  *out = contiguous(bh.get());
+  LAMP_API_END
+}
+static void tri_impl(lamp_tensor* dst_or_null, lamp_tensor** out, const lamp_tensor* a, int64_t diagonal, int lower) {
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim >= 2, "tril / triu expects at least a matrix, got " << a->describe());
+  Hold ac(contiguous(a));
+  Hold r(new_tensor(a->shape(), a->dtype, a->device()));
+  const int64_t total = ac->numel();
+  if (total) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((tri_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, current_stream(a->device()), ac->ptr<T>(), r->ptr<T>(), total,
+                                                      a->sizes[a->ndim - 2], a->sizes[a->ndim - 1], diagonal, lower));
+    LAMP_LAUNCH_CHECK();
+  }
+  if (dst_or_null) copy_into(dst_or_null, r.get()); else *out = r.take();
+}
+int lamp_tril(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal) { LAMP_API_BEGIN tri_impl(nullptr, out, a, diagonal, 1); LAMP_API_END }
+int lamp_triu(lamp_tensor** out, const lamp_tensor* a, int64_t diagonal) { LAMP_API_BEGIN tri_impl(nullptr, out, a, diagonal, 0); LAMP_API_END }
+int lamp_tril_out(lamp_tensor* out, const lamp_tensor* a, int64_t diagonal) {
+  LAMP_API_BEGIN
+  check_device_tensor(out, "out");
+  LAMP_CHECK(out->shape() == a->shape() && out->dtype == a->dtype, "tril_out: out " << out->describe() << " does not match self " << a->describe());
+  tri_impl(out, nullptr, a, diagonal, 1);                 // through a temporary: out may be self (STen.tril_)
+  LAMP_API_END
+}
+// ATen.diagonal: a VIEW of the diagonal of dimensions (dim1, dim2), appended as the last dimension (STen.scala:1885-1886)
+int lamp_diagonal(lamp_tensor** out, const lamp_tensor* a, int64_t offset, int64_t dim1, int64_t dim2) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(a != nullptr, "self is null");
+  LAMP_CHECK(a->ndim >= 2, "diagonal expects at least a matrix, got " << a->describe());
+  const int64_t d1 = wrap_dim(dim1, a->ndim), d2 = wrap_dim(dim2, a->ndim);
+  LAMP_CHECK(d1 != d2, "diagonal: the two dimensions must differ");
+  const int64_t r0 = offset < 0 ? -offset : 0, c0 = offset > 0 ? offset : 0;
+  const int64_t n = std::max<int64_t>(0, std::min(a->sizes[d1] - r0, a->sizes[d2] - c0));
+  int64_t sz[kMaxDims], st[kMaxDims];
+  int nd = 0;
+  for (int i = 0; i < a->ndim; i++) if (i != d1 && i != d2) { sz[nd] = a->sizes[i]; st[nd] = a->strides[i]; nd++; }
+  sz[nd] = n; st[nd] = a->strides[d1] + a->strides[d2]; nd++;
+  *out = new_view(a, sz, st, nd, a->offset + (n > 0 ? r0 * a->strides[d1] + c0 * a->strides[d2] : 0));
+  LAMP_API_END
+}
+// ATen.trace: the sum of the main diagonal of a matrix (STen.scala:1322)
+int lamp_trace(lamp_tensor** out, const lamp_tensor* a) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim == 2, "trace expects a matrix, got " << a->describe());
+  lamp_tensor* dg = nullptr;
+  LAMP_CHECK(lamp_diagonal(&dg, a, 0, 0, 1) == 0, lamp_last_error());
+  Hold dh(dg);
+  Hold dc(contiguous(dh.get()));
+  lamp_tensor* s_ = nullptr;
+  LAMP_CHECK(lamp_sum_all(&s_, dc.get()) == 0, lamp_last_error());
+  *out = s_;
   LAMP_API_END
 }
 int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value) {

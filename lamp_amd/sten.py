@@ -389,6 +389,43 @@ class STen:
         return STen(v), STen(i)
     def dropout_(self, p, training): lib.lamp_dropout_(self.h, float(p), int(training))
 
+    # ---- sorting / overwriting scatters / triangles (STen.scala:1037-1068, 1412-1423, 1551-1557, 1592, 1715-1726, 1761, 1883-1886) ----
+    def sort(self, dim, descending):
+        v, i = _out(), _out()
+        lib.lamp_sort(C.byref(v), C.byref(i), self.h, dim, int(descending))
+        return STen(v), STen(i)
+    def argsort(self, stable, dim, descending): return self._u("lamp_argsort", int(stable), dim, int(descending))
+    def median(self, dim, keepDim):
+        v, i = _out(), _out()
+        lib.lamp_median_dim(C.byref(v), C.byref(i), self.h, dim, int(keepDim))
+        return STen(v), STen(i)
+    def unique(self, sorted_=True, returnInverse=True, returnCounts=True):
+        v, i, c = _out(), _out(), _out()
+        lib.lamp_unique(C.byref(v), C.byref(i), C.byref(c), self.h)
+        return STen(v), STen(i), STen(c)
+    def bincount(self, weights=None, minLength=0): return self._u("lamp_bincount", weights.h if weights is not None else None, int(minLength))
+    def scatter(self, dim, index, source):
+        if isinstance(source, STen):
+            return self._u("lamp_scatter", dim, index.h, source.h)
+        return self._u("lamp_scatter_value", dim, index.h, float(source))
+    def indexPut(self, indices, values, accumulate):
+        return self._u("lamp_index_put", handle_array([t.h for t in indices]), len(indices), values.h, int(accumulate))
+    def put(self, index, values, accumulate): return self._u("lamp_put", index.h, values.h, int(accumulate))
+    def indexCopy(self, dim, index, source): return self._u("lamp_index_copy", dim, index.h, source.h)
+    def tril(self, diagonal=0): return self._u("lamp_tril", int(diagonal))
+    def triu(self, diagonal=0): return self._u("lamp_triu", int(diagonal))
+    def tril_(self, diagonal=0): lib.lamp_tril_out(self.h, self.h, int(diagonal))
+    def diagonalView(self, offset, dim1, dim2): return self._u("lamp_diagonal", int(offset), int(dim1), int(dim2))
+    def trace(self): return self._u("lamp_trace")
+
+    @staticmethod
+    def randperm(n, dtype=I64, device=0):
+        o = _out(); lib.lamp_randperm(C.byref(o), int(n), dtype, device); return STen(o)
+
+    @staticmethod
+    def multinomial(probs, numSamples, replacement):
+        o = _out(); lib.lamp_multinomial(C.byref(o), probs.h, int(numSamples), int(replacement)); return STen(o)
+
 
 def synchronize():
     lib.lamp_device_synchronize()

@@ -36,6 +36,16 @@ CLASSES = ("ATen", "Tensor", "CudaStream", "NcclComm", "TensorTrace")
 # arguments (aten passes options the backend has one value for), or is the non-`out` form.  (aten parameter list, result type, Java body).
 # N = LampNative, h = Tensor.handleOf, own = Tensor.owning; Scala Option arguments arrive as Object (Tensor.handleOfOption).
 EXPLICIT = {
+    "ATen._unique": ("Tensor self, boolean sorted, boolean returnInverse", "Tensor[]",
+                     "long[] r = N.lamp_unique(h(self));\n    N.lamp_tensor_release(r[2]);\n    return new Tensor[] {own(r[0]), own(r[1])};"),
+    "ATen._unique2": ("Tensor self, boolean sorted, boolean returnInverse, boolean returnCounts", "Tensor[]",
+                      "return Tensor.owningAll(N.lamp_unique(h(self)));"),
+    "ATen.index_copy_out": ("Tensor out, Tensor self, long dim, Tensor index, Tensor source", "void",
+                            "long r = N.lamp_index_copy(h(self), dim, h(index), h(source));\n    N.lamp_copy_(h(out), r, 0);\n    N.lamp_tensor_release(r);"),
+    "ATen.median_0": ("Tensor self", "Tensor",
+                      "long f = N.lamp_view(h(self), new long[] {-1});\n    long[] r = N.lamp_median_dim(f, 0, 0);\n    N.lamp_tensor_release_all(new long[] {f, r[1]});\n    return own(r[0]);"),
+    "ATen.scatter_1": ("Tensor self, long dim, Tensor index, double value", "Tensor",
+                       "return own(N.lamp_scatter_value(h(self), dim, h(index), value));"),
     "ATen._log_softmax_backward_data": ("Tensor gradOutput, Tensor output, long dim, byte inputDtype", "Tensor",
                                         "return own(N.lamp_log_softmax_backward_data(h(gradOutput), h(output), dim));"),
     "ATen._scaled_dot_product_cudnn_attention": ("Tensor query, Tensor key, Tensor value, Object attnBias, boolean computeLogSumExp, double dropoutP, boolean isCausal, boolean returnDebugMask", "Object[]",

@@ -1522,3 +1522,165 @@ def test_cat_and_chunk_in_one_launch(gpu, dt):
             assert torch.equal(to_torch(S.STen(outs[i])), parts[i].double()), (shape, dim, n, i)
     with pytest.raises(Exception, match="equal chunks"):
         lib.lamp_chunk_contiguous((C.c_void_p * 2)(), to_sten(closed_form((3, 5), 1, 1.0, dt)), 2, 1)
+
+
+# ---- the sorting / overwriting-scatter / triangle names of the STen surface --------------------------------------------
+def _out1():
+    return C.c_void_p()
+
+
+@pytest.mark.parametrize("shape,dim", [((7,), 0), ((5, 33), 1), ((5, 33), 0), ((3, 4, 50), -1), ((2, 3000), 1), ((70001,), 0), ((4, 1), 1), ((6, 2048), 1)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64, torch.int64, torch.bfloat16])
+def test_sort_argsort_are_the_stable_sort(gpu, shape, dim, dt):
+    """STen.sort / argsort (STen.scala:1761, 1592): values and int64 indices bit-exact against ATen's STABLE sort in both directions - ties
+    (the closed form repeats every 1009 elements; the integer case has few distinct values), NaN above everything, rows shorter and
+    longer than one LDS chunk, lengths that are no power of two."""
+    x = closed_form(shape, 3, 50.0, torch.float64)
+    if dt == torch.int64:
+        x = (x.round() % 7).to(torch.int64)
+    else:
+        x = x.to(dt)
+        if x.numel() > 5:
+            x.view(-1)[3] = float("nan"); x.view(-1)[x.numel() // 2] = float("nan")
+    X = to_sten(x)
+    for desc in (0, 1):
+        ref_v, ref_i = torch.sort(x, dim=dim, descending=bool(desc), stable=True)
+        v, i = _out1(), _out1()
+        lib.lamp_sort(C.byref(v), C.byref(i), X, dim, desc)
+        V, I = S.STen(v), S.STen(i)
+        assert np.array_equal(I.to_numpy(), ref_i.numpy()), f"sort indices (descending={desc})"
+        got = to_torch(V).to(torch.float64)
+        assert torch.equal(torch.nan_to_num(got, nan=1e300), torch.nan_to_num(ref_v.to(torch.float64), nan=1e300)), "sort values"
+        a = _out1()
+        lib.lamp_argsort(C.byref(a), X, 1, dim, desc)
+        assert np.array_equal(S.STen(a).to_numpy(), ref_i.numpy()), "argsort"
+    mv, mi = _out1(), _out1()
+    lib.lamp_median_dim(C.byref(mv), C.byref(mi), X, dim, 0)
+    if dt != torch.bfloat16 and not (dt != torch.int64 and x.numel() > 5):          # ATen's median propagates NaN: compare on NaN-free inputs only
+        rv, ri = torch.median(x, dim=dim)
+        assert torch.equal(to_torch(S.STen(mv)).to(torch.float64), rv.to(torch.float64)), "median values"
+        # the position of the median may be any index holding that value: the value at it must be the median
+        assert torch.equal(torch.gather(x, dim if x.ndim else 0, torch.from_numpy(S.STen(mi).to_numpy()).unsqueeze(dim)).squeeze(dim).to(torch.float64), rv.to(torch.float64))
+
+
+def test_unique_and_bincount(gpu):
+    """STen.unique (sorted, with inverse and counts: STen.scala:1037-1055) and bincount (:1034) against ATen"""
+    for n, mod in [(1, 3), (10, 3), (5000, 37), (70000, 1009)]:
+        x = ((torch.arange(n) * 7919) % mod).to(torch.int64).reshape(-1)
+        for t in (x, x.to(torch.float32) * 0.5, x.reshape(-1, 1) if n > 1 else x):
+            v, inv, cnt = _out1(), _out1(), _out1()
+            lib.lamp_unique(C.byref(v), C.byref(inv), C.byref(cnt), to_sten(t))
+            rv, rinv, rcnt = torch.unique(t, sorted=True, return_inverse=True, return_counts=True)
+            assert np.array_equal(S.STen(v).to_numpy(), rv.numpy()) and np.array_equal(S.STen(inv).to_numpy(), rinv.numpy()) and np.array_equal(S.STen(cnt).to_numpy(), rcnt.numpy())
+        o = _out1()
+        lib.lamp_bincount(C.byref(o), to_sten(x), None, mod + 5)
+        assert np.array_equal(S.STen(o).to_numpy(), torch.bincount(x, minlength=mod + 5).numpy())
+        w = closed_form((n,), 5, 2.0, torch.float64)
+        o = _out1()
+        lib.lamp_bincount(C.byref(o), to_sten(x), to_sten(w), 0)
+        np.testing.assert_allclose(S.STen(o).to_numpy(), torch.bincount(x, weights=w).numpy(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64, torch.int64, torch.bfloat16])
+def test_overwriting_scatters(gpu, dt):
+    """scatter (tensor and scalar source), index_put (with and without accumulation, broadcast indices and values, negative indices), put and
+    index_copy (STen.scala:1412-1423, 1715-1726) against ATen; index sets without duplicates where the result would be unspecified."""
+    x = closed_form((6, 9, 4), 3, 20.0, torch.float64).round().to(dt)
+    src = closed_form((6, 5, 4), 9, 20.0, torch.float64).round().to(dt)
+    idx = torch.stack([torch.randperm(9, generator=torch.Generator().manual_seed(s))[:5] for s in range(24)]).reshape(6, 4, 5).permute(0, 2, 1).contiguous()
+    X, SRC, IDX = to_sten(x), to_sten(src), to_sten(idx)
+    o = _out1(); lib.lamp_scatter(C.byref(o), X, 1, IDX, SRC)
+    assert torch.equal(to_torch(S.STen(o)).double(), x.scatter(1, idx, src).double())
+    o = _out1(); lib.lamp_scatter_value(C.byref(o), X, 1, IDX, 3.0)
+    assert torch.equal(to_torch(S.STen(o)).double(), x.scatter(1, idx, 3.0).double())
+    # index_put: two index tensors (the second broadcast from one row), values broadcast over the trailing dimension
+    i0 = torch.tensor([[0], [4], [-1]]); i1 = torch.tensor([[1, 3, 8]])
+    vals = closed_form((3, 3, 1), 4, 10.0, torch.float64).round().to(dt)
+    I0, I1 = to_sten(i0), to_sten(i1)
+    hs = (C.c_void_p * 2)(I0.h, I1.h)
+    for acc in (0, 1):
+        o = _out1(); lib.lamp_index_put(C.byref(o), X, hs, 2, to_sten(vals), acc)
+        assert torch.equal(to_torch(S.STen(o)).double(), x.index_put((i0, i1), vals, accumulate=bool(acc)).double()), f"index_put accumulate={acc}"
+    # accumulation with duplicates is defined: sums
+    d0 = torch.tensor([2, 2, 2, 4])
+    dv = closed_form((4, 9, 4), 6, 4.0, torch.float64).round().to(dt)
+    D0 = to_sten(d0)
+    hs1 = (C.c_void_p * 1)(D0.h)
+    o = _out1(); lib.lamp_index_put(C.byref(o), X, hs1, 1, to_sten(dv), 1)
+    assert torch.equal(to_torch(S.STen(o)).double(), x.index_put((d0,), dv, accumulate=True).double())
+    pi = torch.tensor([[0, 17], [215, 100]]); pv = closed_form((2, 2), 8, 9.0, torch.float64).round().to(dt)
+    for acc in (0, 1):
+        o = _out1(); lib.lamp_put(C.byref(o), X, to_sten(pi), to_sten(pv), acc)
+        assert torch.equal(to_torch(S.STen(o)).double(), x.put(pi, pv, accumulate=bool(acc)).double())
+    ci = torch.tensor([7, 0, 3]); cs = closed_form((6, 3, 4), 2, 9.0, torch.float64).round().to(dt)
+    o = _out1(); lib.lamp_index_copy(C.byref(o), X, 1, to_sten(ci), to_sten(cs))
+    assert torch.equal(to_torch(S.STen(o)).double(), x.index_copy(1, ci, cs).double())
+    with pytest.raises(Exception):                       # out of range: the device assertion surfaces at the next host wait
+        far = to_sten(torch.full((6, 1, 4), 9))
+        bad = _out1(); lib.lamp_scatter_value(C.byref(bad), X, 1, far, 1.0)
+        S.STen(bad).to_numpy()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64, torch.int64, torch.bfloat16])
+def test_triangles_and_diagonals(gpu, dt):
+    """tril / tril_ / triu, diagonal (a view) and trace (STen.scala:1883-1886, 1322)"""
+    x = closed_form((3, 5, 7), 3, 20.0, torch.float64).round().to(dt)
+    X = to_sten(x)
+    for k in (-2, 0, 1, 9):
+        o = _out1(); lib.lamp_tril(C.byref(o), X, k)
+        assert torch.equal(to_torch(S.STen(o)).double(), x.tril(k).double())
+        o = _out1(); lib.lamp_triu(C.byref(o), X, k)
+        assert torch.equal(to_torch(S.STen(o)).double(), x.triu(k).double())
+    Y = to_sten(x.clone())
+    lib.lamp_tril_out(Y, Y, -1)                        # STen.tril_: out is self
+    assert torch.equal(to_torch(Y).double(), x.tril(-1).double())
+    for off, d1, d2 in [(0, 0, 1), (1, 1, 2), (-2, 2, 0), (0, -1, -2)]:
+        o = _out1(); lib.lamp_diagonal(C.byref(o), X, off, d1, d2)
+        D = S.STen(o)
+        assert torch.equal(to_torch(D).double(), x.diagonal(off, d1, d2).double())
+    m = x[0]
+    o = _out1(); lib.lamp_trace(C.byref(o), to_sten(m))
+    assert float(to_torch(S.STen(o)).double()) == float(m.double().trace())
+    # diagonal is a view: writing through it changes the matrix
+    M = to_sten(torch.zeros(4, 4, dtype=torch.float64))
+    o = _out1(); lib.lamp_diagonal(C.byref(o), M, 0, 0, 1)
+    S.STen(o).fill_(2.0)
+    assert np.array_equal(M.to_numpy(), 2.0 * np.eye(4))
+
+
+def test_randperm_and_multinomial(gpu):
+    """STen.randperm (a permutation; positions are uniform) and STen.multinomial (with replacement: frequencies follow the weights; without:
+    distinct indices, zero-weight categories never drawn, the first draw follows the weights) - the sampler of the language model
+    (languagemodel/package.scala:100)."""
+    for n in (1, 2, 1000, 70000):
+        o = _out1(); lib.lamp_randperm(C.byref(o), n, S.I64, 0)
+        p = S.STen(o).to_numpy()
+        assert p.dtype == np.int64 and np.array_equal(np.sort(p), np.arange(n))
+    # uniformity: the position of element 0 over many small permutations
+    pos = []
+    for _ in range(300):
+        o = _out1(); lib.lamp_randperm(C.byref(o), 8, S.I64, 0)
+        pos.append(int(np.where(S.STen(o).to_numpy() == 0)[0][0]))
+    counts = np.bincount(pos, minlength=8)
+    assert counts.min() >= 15 and counts.max() <= 70, counts          # expectation 37.5, sd 5.7
+    o = _out1(); lib.lamp_randperm(C.byref(o), 5, S.I64, -1)
+    assert S.STen(o).device == S.CPU
+    w = torch.tensor([[0.1, 0.0, 0.3, 0.6], [5.0, 5.0, 0.0, 0.0]], dtype=torch.float32)
+    o = _out1(); lib.lamp_multinomial(C.byref(o), to_sten(w), 20000, 1)
+    s = S.STen(o).to_numpy()
+    assert s.shape == (2, 20000) and s.dtype == np.int64
+    f0 = np.bincount(s[0], minlength=4) / 20000.0
+    f1 = np.bincount(s[1], minlength=4) / 20000.0
+    assert np.abs(f0 - np.array([0.1, 0.0, 0.3, 0.6])).max() < 0.015 and f0[1] == 0.0, f0
+    assert np.abs(f1 - np.array([0.5, 0.5, 0.0, 0.0])).max() < 0.015 and f1[2] == 0.0 and f1[3] == 0.0, f1
+    firsts = []
+    wv = torch.tensor([0.1, 0.2, 0.3, 0.4, 0.0], dtype=torch.float64)
+    for _ in range(400):
+        o = _out1(); lib.lamp_multinomial(C.byref(o), to_sten(wv), 4, 0)
+        d = S.STen(o).to_numpy()
+        assert d.shape == (4,) and sorted(d.tolist()) == [0, 1, 2, 3], "without replacement: the four categories with weight, each once"
+        firsts.append(int(d[0]))
+    ff = np.bincount(firsts, minlength=5) / 400.0
+    assert np.abs(ff[:4] - np.array([0.1, 0.2, 0.3, 0.4])).max() < 0.08, ff
+    with pytest.raises(Exception):
+        bad = _out1(); lib.lamp_multinomial(C.byref(bad), to_sten(wv), 9, 0)
