@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; umap-e2e: 1 - a step is a complete 1M-point run)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; umap-e2e: 1)")
-    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "umap-e2e", "lm"])
+    ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "umap-e2e", "lm", "epoch"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -48,9 +48,9 @@ def parse():
     ap.add_argument("--min-window-s", type=float, default=0.5, help="repeat the K-step timed window until this much time is covered; the median window is reported")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 1 if a.workload == "umap-e2e" else 20
+        a.steps = 1 if a.workload == "umap-e2e" else (2 if a.workload == "epoch" else 20)
     if a.warmup is None:
-        a.warmup = 1 if a.workload == "umap-e2e" else 10
+        a.warmup = 1 if a.workload in ("umap-e2e", "epoch") else 10
     return a
 
 
@@ -322,6 +322,63 @@ def main():
         config = {"workload": "example-cifar100 Cnn.resnet(100) training step (fwd+backprop+AdamW), synthetic CIFAR batch",
                   "per_gpu_batch": B, "global_batch": B * a.gpus, "parallelism": f"dp{a.gpus}" if a.gpus > 1 else "single",
                   "optimizer": "AdamW lr 1e-3 wd 0 beta2 0.95" + (" mixedPrecision" if a.dtype == "bf16" else "")}
+    elif a.workload == "epoch":
+        # the reference's own number is "instances/sec" of an EPOCH (IOLoops.scala:728-743) through
+        # BatchStream.minibatchesFromFull (BatchStream.scala:528-592: shuffle -> gather -> pinned staging -> copy on another stream, one batch
+        # ahead: IOLoops.scala:833-874).  A step here = one epoch of lamp_amd.loops.oneEpoch over 50 000 CIFAR-shaped records (u8 pixels cast
+        # to float, as Cifar.loadImageFile does) with the eager training step; every variant of where the data set lives is timed and reported,
+        # the headline value is the host-resident arrangement with the cast folded into the gather, at B = --batch.
+        from lamp_amd import loops
+        from lamp_amd.data import BatchStream
+        NREC = 50000
+        lib.lamp_manual_seed(1234)
+        model_mod = nn.resnet(100, 0.0, dtype, local_rank)
+        cw = S.STen.ones([100], dtype, local_rank)
+        model = nn.SupervisedModel(model_mod, nn.SupervisedModel.NLL, cw)
+        opt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3, mixedPrecision=(a.dtype == "bf16"))([p.value for p in model_mod.parameters])
+        pix = ((np.arange(NREC * 3 * 32 * 32, dtype=np.int64) * 2654435761 + rank * 97) >> 9) % 256
+        pix = pix.astype(np.uint8).reshape(NREC, 3, 32, 32)
+        labels = S.STen.from_numpy(((np.arange(NREC) * 7 + rank) % 100).astype(np.int64), S.CPU)
+        host_u8 = S.STen.from_numpy(pix, S.CPU)
+        host_f32 = S.STen.from_numpy(pix.astype(np.float32), S.CPU)
+        dev_x = S.STen.from_numpy(pix.astype(np.float32), local_rank, dtype)
+        order = np.random.default_rng(7).permutation(NREC)
+
+        def stream_of(kind, B):
+            if kind == "device_resident":
+                return BatchStream.minibatchesFromFull(B, False, dev_x, labels, order=order, device=local_rank)
+            src = host_f32 if kind == "host_f32_pinned" else host_u8
+            return BatchStream.minibatchesFromFull(B, False, src, labels, order=order, device=local_rank, hostResident=True, outDtype=dtype)
+
+        def epoch_rate(kind, B, epochs):
+            st = stream_of(kind, B)
+            loops.oneEpoch(0, model, opt, st)                      # warm-up epoch (allocator, packed weights, pinning)
+            barrier()
+            t0 = time.perf_counter()
+            for e in range(epochs):
+                loops.oneEpoch(e + 1, model, opt, st)
+            barrier()
+            rate = NREC * epochs / (time.perf_counter() - t0)
+            del st
+            import gc; gc.collect()
+            return rate
+
+        epoch_variants = {}
+        for kind in os.environ.get("LAMP_EPOCH_VARIANTS", "device_resident,host_f32_pinned,host_u8_pinned").split(","):
+            for B in sorted({a.batch, 256}, reverse=True):
+                epoch_variants[f"{kind}_B{B}"] = epoch_rate(kind, B, a.steps)
+        # headline: the records stay on the host as the u8 pixels of the CIFAR file and the cast Cifar.loadImageFile applies (castToFloat) runs
+        # inside the gather: 3 KB instead of 12 KB per record over PCIe.  (Measured: shader reads of host memory do not overlap the training
+        # step - the float variant, 25 MB per batch, costs its full 0.4 ms per batch - while a DMA-engine copy of the same bytes is free;
+        # scripts/epoch_interference_probe.py.)
+        headline = stream_of("host_u8_pinned", a.batch)
+        step = lambda: loops.oneEpoch(0, model, opt, headline)
+        units_per_step = NREC
+        metric, unit = "epoch instances/sec (IOLoops.oneEpoch over minibatchesFromFull)", "samples/s"
+        config = {"workload": "example-cifar100 Cnn.resnet(100): one epoch of 50 000 CIFAR-shaped records through BatchStream.minibatchesFromFull "
+                              "(host-resident u8 records in pinned memory, minibatch gathered over PCIe and cast on the GPU one batch ahead on a side stream), eager training step",
+                  "per_gpu_batch": a.batch, "records": NREC, "parallelism": "single"}
+        result_extra["epoch_variants_instances_per_s"] = epoch_variants
     elif a.workload == "lm":
         # example-autoregressivelm (model.scala:9-37, train.scala:40-66): byte-level GPT, 12 blocks x 768 x 12 heads, context 384,
         # bf16 parameters + mixed-precision AdamW (weight decay on the attention / MLP matrices only, clip 1), DP over the ranks

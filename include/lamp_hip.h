@@ -550,6 +550,10 @@ int lamp_binary_cross_entropy_with_logits(lamp_tensor** out, const lamp_tensor* 
  * knn/package.scala:55).  Index tensors are i64 and results are bit-exact.
  * ------------------------------------------------------------------------------------------ */
 int lamp_index_select(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index);
+/* rows of a PINNED HOST tensor gathered by a device index list straight into a device batch (the GPU reads them over PCIe), converted to
+ * out_dtype on the way (-1: the stored type; f32 -> bf16, u8 -> f32 / bf16, f64 -> f32): the minibatch of a host-resident data set
+ * (BatchStream.scala:539-556: host gather + pinned staging buffer + copy).  Runs on the current stream of index's device. */
+int lamp_index_select_pinned(lamp_tensor** out, const lamp_tensor* pinned, const lamp_tensor* index, int out_dtype);
 int lamp_index_add(lamp_tensor** out, const lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
 int lamp_index_add_(lamp_tensor* self, int64_t dim, const lamp_tensor* index, const lamp_tensor* source);
 int lamp_masked_select(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* mask);   /* syncs (output size) */

@@ -180,6 +180,12 @@ int lamp_cifar_load_image_file(lamp_tensor** labels, lamp_tensor** images, const
 typedef struct lamp_batch_stream lamp_batch_stream;
 int lamp_batch_stream_from_full(lamp_batch_stream** out, const lamp_tensor* features, const lamp_tensor* target, const int64_t* order, int64_t n,
                                 int64_t minibatch_size, int drop_last, int device);
+/* The same stream over a data set that STAYS IN HOST MEMORY, as in the reference (BatchStream.scala:539-556: host gather, pinned staging buffer,
+ * copy on another stream; `pinned` of cifar100.scala): the features are pinned (copied once if they are not), and the GPU gathers a
+ * minibatch's rows over PCIe on a side stream one batch ahead of the consumer (IOLoops.scala:833-874), converting to out_dtype (-1: as
+ * stored) on the way.  Batches, order and values are those of lamp_batch_stream_from_full. */
+int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor* features, const lamp_tensor* target, const int64_t* order, int64_t n,
+                                     int64_t minibatch_size, int drop_last, int device, int out_dtype);
 int lamp_batch_stream_every_nth(lamp_batch_stream* s, int64_t n, int64_t offset);
 int lamp_batch_stream_num_batches(const lamp_batch_stream* s, int64_t* out);
 int lamp_batch_stream_next(lamp_batch_stream* s, lamp_tensor** x, lamp_tensor** target);

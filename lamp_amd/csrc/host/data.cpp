@@ -14,6 +14,8 @@
 //     kernel on the device: no per-step PCIe traffic, no host gather.
 //   * the CIFAR file is uploaded as raw bytes; label / pixel split and the cast run on the GPU.
 //   * files are read with plain reads into (optionally pinned) host memory, not mmap.
+//   * a data set that must stay in host memory (lamp_batch_stream_from_full_host) is kept pinned; the GPU gathers a minibatch's rows over
+//     PCIe itself (lamp_index_select_pinned), one batch ahead on a side stream - no host gather, no staging buffer.
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -255,8 +257,16 @@ std::vector<Ten> read_tensors(const std::string& path, int device, bool pin) {
 
 // ---- the minibatch stream ------------------------------------------------------------------------------------------
 struct BatchStreamImpl {
-  Ten features, target, order;   // all on `device`; order: i64 [n]
+  Ten features, target, order;   // target and order (i64 [n]) on `device`; features on `device`, or - host_resident - in pinned host memory
   int64_t n = 0, minibatch = 1, num_batches = 0, cursor = 0, every = 1, offset = 0;
+  // host-resident variant (lamp_batch_stream_from_full_host): the GPU gathers a minibatch's rows over PCIe on a side stream, one batch ahead
+  // (the reference's prefetch: IOLoops.scala:833-874 loads batch i + 1 while batch i trains)
+  bool host_resident = false;
+  int device = 0, out_dtype = -1;
+  lamp_stream* side = nullptr;
+  Ten ahead_x, ahead_t;          // the prefetched batch (valid when ahead_for >= 0)
+  int64_t ahead_for = -1;
+  ~BatchStreamImpl() { if (side) lamp_stream_release(side); }
 };
 
 }  // namespace host
@@ -374,6 +384,56 @@ int lamp_batch_stream_from_full(lamp_batch_stream** out, const lamp_tensor* feat
   LAMP_API_END
 }
 
+int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor* features, const lamp_tensor* target, const int64_t* order, int64_t n,
+                                     int64_t minibatch_size, int drop_last, int device, int out_dtype) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(features && target && (order || n == 0), "minibatchesFromFull: NULL argument");
+  LAMP_CHECK(minibatch_size >= 1, "minibatchSize must be positive");
+  LAMP_CHECK(device >= 0, "minibatchesFromFull needs a GPU device");
+  int64_t fs[LAMP_MAX_DIMS], ts[LAMP_MAX_DIMS];
+  HCALL(lamp_tensor_sizes(features, fs));
+  HCALL(lamp_tensor_sizes(target, ts));
+  LAMP_CHECK(n <= fs[0] && fs[0] == ts[0], "minibatchesFromFull: features and target disagree on the number of rows, or the order is longer");
+  for (int64_t i = 0; i < n; i++) LAMP_CHECK(order[i] >= 0 && order[i] < fs[0], "minibatchesFromFull: order[" << i << "] = " << order[i] << " is out of range");
+  int fdev = 0;
+  HCALL(lamp_tensor_device(features, &fdev));
+  LAMP_CHECK(fdev < 0, "lamp_batch_stream_from_full_host: the features must live in host memory");
+  auto stream = std::make_unique<lamp_batch_stream>();
+  BatchStreamImpl& s = stream->s;
+  int pinned = 0;
+  HCALL(lamp_tensor_is_pinned(features, &pinned));
+  if (pinned) { lamp_tensor* r = nullptr; HCALL(lamp_tensor_retain(features, &r)); s.features = Ten(r); }
+  else { lamp_tensor* p = nullptr; HCALL(lamp_pin_memory(&p, features)); s.features = Ten(p); }      // the reference's `pinned = true` (cifar100.scala --pinned)
+  { int dt = 0; HCALL(lamp_tensor_scalar_type(target, &dt)); lamp_tensor* o = nullptr; HCALL(lamp_to(&o, target, dt, device, 0, 0)); s.target = Ten(o); }
+  const std::vector<int64_t> osz = {n};
+  s.order = empty_tensor(osz, kI64, device);
+  if (n) HCALL(lamp_copy_from_host(s.order.h(), order, (size_t)n * 8));
+  s.n = n; s.minibatch = minibatch_size; s.device = device; s.out_dtype = out_dtype; s.host_resident = true;
+  s.num_batches = (n + minibatch_size - 1) / minibatch_size;
+  if (drop_last && s.num_batches > 0) s.num_batches--;
+  HCALL(lamp_stream_get_from_pool(0, device, &s.side));
+  *out = stream.release();
+  LAMP_API_END
+}
+
+// queues the gather of batch `b` on the side stream (which first waits for everything the compute stream has queued: the order tensor and,
+// through the allocator's stream bookkeeping, the blocks it is about to reuse)
+static void prefetch_batch(BatchStreamImpl& s, int64_t b) {
+  const int64_t lo = b * s.minibatch, hi = std::min(lo + s.minibatch, s.n);
+  Ten idx = ops::slice(s.order, 0, lo, hi, 1);
+  lamp_stream* cur = nullptr;
+  HCALL(lamp_stream_get_current(s.device, &cur));
+  HCALL(lamp_stream_wait_stream(s.side, cur));
+  HCALL(lamp_stream_set_current(s.side));
+  lamp_tensor *x = nullptr, *t = nullptr;
+  const int rc1 = lamp_index_select_pinned(&x, s.features.h(), idx.h(), s.out_dtype);
+  const int rc2 = rc1 == 0 ? lamp_index_select(&t, s.target.h(), 0, idx.h()) : 1;
+  (void)lamp_stream_set_current(cur);
+  (void)lamp_stream_release(cur);
+  if (rc1 != 0 || rc2 != 0) { if (x) lamp_tensor_release(x); throw Error(lamp_last_error()); }
+  s.ahead_x = Ten(x); s.ahead_t = Ten(t); s.ahead_for = b;
+}
+
 int lamp_batch_stream_every_nth(lamp_batch_stream* st, int64_t n, int64_t offset) {
   LAMP_API_BEGIN
   LAMP_CHECK(n >= 1 && offset >= 0 && offset < n, "everyNth(n, offset) needs 0 <= offset < n");
@@ -395,6 +455,26 @@ int lamp_batch_stream_next(lamp_batch_stream* st, lamp_tensor** x, lamp_tensor**
   *x = nullptr; *target = nullptr;
   while (s.cursor < s.num_batches && s.cursor % s.every != s.offset) s.cursor++;
   if (s.cursor >= s.num_batches) return 0;               // EndStream
+  if (s.host_resident) {
+    const int64_t b = s.cursor++;
+    if (s.ahead_for != b) prefetch_batch(s, b);              // first batch of an epoch (or after a reset)
+    Ten xb = s.ahead_x, tb = s.ahead_t;
+    s.ahead_x = Ten(); s.ahead_t = Ten(); s.ahead_for = -1;
+    // the consumer (the caller's current stream) waits for the gather, and the blocks - allocated under the side stream - must not be
+    // recycled there while the consumer still reads them
+    lamp_stream* cur = nullptr;
+    HCALL(lamp_stream_get_current(s.device, &cur));
+    HCALL(lamp_stream_wait_stream(cur, s.side));
+    HCALL(lamp_tensor_record_stream(xb.h(), cur));
+    HCALL(lamp_tensor_record_stream(tb.h(), cur));
+    HCALL(lamp_stream_release(cur));
+    int64_t nb = s.cursor;                                   // the next batch this stream will hand out
+    while (nb < s.num_batches && nb % s.every != s.offset) nb++;
+    if (nb < s.num_batches) prefetch_batch(s, nb);
+    HCALL(lamp_tensor_retain(xb.h(), x));
+    HCALL(lamp_tensor_retain(tb.h(), target));
+    return 0;
+  }
   const int64_t lo = s.cursor * s.minibatch, hi = std::min(lo + s.minibatch, s.n);
   s.cursor++;
   Ten idx = ops::slice(s.order, 0, lo, hi, 1);
@@ -404,7 +484,12 @@ int lamp_batch_stream_next(lamp_batch_stream* st, lamp_tensor** x, lamp_tensor**
   LAMP_API_END
 }
 
-int lamp_batch_stream_reset(lamp_batch_stream* st) { LAMP_API_BEGIN st->s.cursor = 0; LAMP_API_END }
+int lamp_batch_stream_reset(lamp_batch_stream* st) {
+  LAMP_API_BEGIN
+  st->s.cursor = 0;
+  st->s.ahead_x = Ten(); st->s.ahead_t = Ten(); st->s.ahead_for = -1;
+  LAMP_API_END
+}
 int lamp_batch_stream_release(lamp_batch_stream* st) { LAMP_API_BEGIN delete st; LAMP_API_END }
 
 }  // extern "C"

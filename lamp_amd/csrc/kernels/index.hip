@@ -258,6 +258,39 @@ __global__ void tri_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t
     out[e] = keep ? x[e] : z;
   }
 }
+// rows of a PINNED HOST matrix gathered by a device index list, straight over PCIe into a device batch (one pass: no host gather, no staging
+// buffer), converted on the fly when the stored type differs (u8 pixels -> the model's type).  A wave copies one row, 16 bytes per lane.
+template <class S, class D>
+__global__ __launch_bounds__(256) void gather_pinned_rows_kernel(const S* __restrict__ src, const int64_t* __restrict__ index, D* __restrict__ dst, int64_t rows,
+                                                                 int64_t width, int64_t src_rows, int* __restrict__ assert_word) {
+  const int lane = threadIdx.x & 63;
+  constexpr int V = 16 / sizeof(S);                     // elements per 16-byte request over the bus
+  for (int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t t = index[r];
+    if (t < 0 || t >= src_rows) { if (lane == 0) *(volatile int*)assert_word = kAssertIndexRange; continue; }
+    const S* s = src + t * width;
+    D* d = dst + r * width;
+    if (width % V == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)d & (sizeof(D) * V - 1) & 15) == 0) {
+      // 16 bytes per lane and request, four requests in flight per lane: the reads cross PCIe (microseconds each)
+      const int64_t nv = width / V;
+      for (int64_t c0 = lane; c0 < nv; c0 += 256) {
+        Vec<S, V> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (c0 + 64 * u < nv) v[u] = *reinterpret_cast<const Vec<S, V>*>(s + (c0 + 64 * u) * V);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (c0 + 64 * u < nv) {
+            Vec<D, V> o;
+#pragma unroll
+            for (int k = 0; k < V; k++) o.v[k] = store_as<D>((acc_t<D>)load_as<acc_t<S>>(v[u].v[k]));
+            *reinterpret_cast<Vec<D, V>*>(d + (c0 + 64 * u) * V) = o;
+          }
+      }
+    } else {
+      for (int64_t c = lane; c < width; c += 64) d[c] = store_as<D>((acc_t<D>)load_as<acc_t<S>>(s[c]));
+    }
+  }
+}
 // index_fill along dim (IndexFill op, ops.scala:160-177)
 // diag(v, k): out[m, m] zero except out[i + max(-k, 0)][i + max(k, 0)] = v[i]   (ATen diag of a vector)
 template <class T>
@@ -939,6 +972,41 @@ int lamp_trace(lamp_tensor** out, const lamp_tensor* a) {
   lamp_tensor* s_ = nullptr;
   LAMP_CHECK(lamp_sum_all(&s_, dc.get()) == 0, lamp_last_error());
   *out = s_;
+  LAMP_API_END
+}
+// out[i, ...] = (out_dtype) pinned[index[i], ...]: `pinned` lives in page-locked host memory, `index` (int64 vector) and the result on `index`'s
+// device; runs on that device's current stream.  The minibatch gather of a host-resident data set (BatchStream.scala:539-556 gathers on the
+// host, stages in a pinned buffer and copies: here the GPU reads the rows it wants over PCIe).
+int lamp_index_select_pinned(lamp_tensor** out, const lamp_tensor* pinned, const lamp_tensor* index, int out_dtype) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(pinned != nullptr && !pinned->is_device() && pinned->st && pinned->st->pinned, "index_select_pinned: the source must be a pinned host tensor (lamp_pin_memory)");
+  check_index(index);
+  LAMP_CHECK(pinned->ndim >= 1 && pinned->is_contiguous(), "index_select_pinned: the source must be contiguous");
+  const int odt = out_dtype < 0 ? pinned->dtype : out_dtype;
+  std::vector<int64_t> oshape = pinned->shape();
+  oshape[0] = index->numel();
+  Hold r(new_tensor(oshape, odt, index->device()));
+  Hold ic(contiguous(index));
+  const int64_t rows = index->numel(), width = pinned->sizes[0] ? pinned->numel() / pinned->sizes[0] : 0;
+  if (rows * width) {
+    hipStream_t st = current_stream(index->device());
+    // The reads cross PCIe: ~50 GB/s whatever the grid, as long as ~100 KB of requests are in flight - a few dozen workgroups do that.
+    // A grid that covers the chip (tried first: two workgroups on every CU for the 0.5 ms a 25 MB batch takes) starved the training step it is
+    // meant to run beside: the step's first kernel waited 300 us for a slot and then ran 10 x slower (rocprofv3 timeline, scripts/epoch_overlap_probe.py)
+    static const int64_t gp_wgs = [] { const char* e = getenv("LAMP_PINNED_GATHER_WGS"); return (int64_t)(e ? std::max(1, atoi(e)) : 48); }();
+    const dim3 grid((unsigned)std::min<int64_t>((rows + 3) / 4, gp_wgs));
+    int* aw = device_assert_word(index->device());
+#define GP_LAUNCH(S_, D_) hipLaunchKernelGGL((gather_pinned_rows_kernel<S_, D_>), grid, dim3(256), 0, st, pinned->ptr<S_>(), ic->ptr<int64_t>(), r->ptr<D_>(), rows, width, pinned->sizes[0], aw)
+    if (pinned->dtype == odt) { LAMP_DISPATCH_ALL(odt, T, GP_LAUNCH(T, T)); }
+    else if (pinned->dtype == kF32 && odt == kBF16) GP_LAUNCH(float, bf16_t);
+    else if (pinned->dtype == kU8 && odt == kBF16) GP_LAUNCH(uint8_t, bf16_t);
+    else if (pinned->dtype == kU8 && odt == kF32) GP_LAUNCH(uint8_t, float);
+    else if (pinned->dtype == kF64 && odt == kF32) GP_LAUNCH(double, float);
+    else LAMP_CHECK(false, "index_select_pinned: no conversion from " << dtype_name(pinned->dtype) << " to " << dtype_name(odt));
+#undef GP_LAUNCH
+    LAMP_LAUNCH_CHECK();
+  }
+  *out = r.take();
   LAMP_API_END
 }
 int lamp_index_fill(lamp_tensor** out, const lamp_tensor* a, int64_t dim, const lamp_tensor* index, double value) {

@@ -93,15 +93,20 @@ class BatchStream:
 
     @staticmethod
     def minibatchesFromFull(minibatchSize: int, dropLast: bool, features: STen, target: STen, rng=None, device: int = 0,
-                            order: Optional[Sequence[int]] = None) -> "BatchStream":
-        """`rng`: an object with shuffle(list) -> list (JavaRandom, or anything else); `order` overrides it."""
+                            order: Optional[Sequence[int]] = None, hostResident: bool = False, outDtype: int = -1) -> "BatchStream":
+        """`rng`: an object with shuffle(list) -> list (JavaRandom, or anything else); `order` overrides it.  hostResident: the features
+        stay in (pinned) host memory as in the reference and every minibatch is gathered over PCIe one batch ahead, converted to outDtype."""
         n = features.shape[0]
         if order is None:
             order = rng.shuffle(list(range(n))) if rng is not None else list(range(n))
         arr = np.ascontiguousarray(order, dtype=np.int64)
         o = C.c_void_p()
-        lib.lamp_batch_stream_from_full(C.byref(o), features, target, arr.ctypes.data_as(C.POINTER(C.c_int64)), len(arr), int(minibatchSize),
-                                        int(bool(dropLast)), device)
+        if hostResident:
+            lib.lamp_batch_stream_from_full_host(C.byref(o), features, target, arr.ctypes.data_as(C.POINTER(C.c_int64)), len(arr), int(minibatchSize),
+                                                 int(bool(dropLast)), device, int(outDtype))
+        else:
+            lib.lamp_batch_stream_from_full(C.byref(o), features, target, arr.ctypes.data_as(C.POINTER(C.c_int64)), len(arr), int(minibatchSize),
+                                            int(bool(dropLast)), device)
         return BatchStream(o)
 
     def everyNth(self, n: int, offset: int) -> "BatchStream":

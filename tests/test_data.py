@@ -204,6 +204,51 @@ def test_minibatches_from_full(gpu, host_resident):
 
 
 @pytest.mark.gpu
+def test_minibatches_from_a_data_set_that_stays_in_host_memory(gpu):
+    """BatchStream.minibatchesFromFull as the reference arranges it (BatchStream.scala:539-556: the records stay on the host, pinned; the
+    minibatch travels on another stream one batch ahead, IOLoops.scala:833-874): the GPU gathers the rows over PCIe.  Same batches, bit for
+    bit, as the device-resident stream - plain, with the cast folded into the gather (u8 records -> f32 / bf16, f32 -> bf16), under
+    everyNth, across epochs and after a reset in the middle of an epoch; out-of-range rows raise."""
+    n, mb = 1003, 64
+    rng = np.random.default_rng(3)
+    x32 = rng.standard_normal((n, 3, 5, 7)).astype(np.float32)
+    x8 = rng.integers(0, 256, (n, 3, 5, 7)).astype(np.uint8)
+    y = np.arange(n, dtype=np.int64) * 7
+    order = D.JavaRandom(5).shuffle(list(range(n)))
+    fy = S.STen.from_numpy(y, S.CPU)
+    for host, out_dt, ref in ((x32, -1, x32), (x8, S.F32, x8.astype(np.float32)), (x32, S.BF16, None), (x8, S.BF16, None)):
+        fx = S.STen.from_numpy(host, S.CPU)
+        st = D.BatchStream.minibatchesFromFull(mb, False, fx, fy, order=order, hostResident=True, outDtype=out_dt)
+        if ref is None:                                        # the device-resident stream of the same records cast on the GPU
+            dref = D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(host.astype(np.float32), 0, S.BF16), fy, order=order)
+        assert st.numBatches == (n + mb - 1) // mb
+        for epoch in range(2):
+            got = list(st)
+            assert len(got) == st.numBatches
+            want = list(dref) if ref is None else None
+            for i, (bx, by) in enumerate(got):
+                g = order[i * mb:(i + 1) * mb]
+                assert bx.device == 0 and by.device == 0 and np.array_equal(by.to_numpy(), y[g])
+                assert np.array_equal(bx.to_numpy(), want[i][0].to_numpy() if ref is None else ref[g])
+            st.reset()
+            if ref is None:
+                dref.reset()
+        # a reset in the middle of an epoch discards the batch that was gathered ahead
+        it = iter(st); next(it); next(it)
+        st.reset()
+        bx, by = st.nextBatch()
+        assert np.array_equal(by.to_numpy(), y[order[:mb]])
+    shards = []
+    for r in range(3):
+        st = D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(x32, S.CPU), fy, order=order, hostResident=True).everyNth(3, r)
+        for bx, by in st:
+            shards.append(by.to_numpy())
+    assert sorted(np.concatenate(shards).tolist()) == sorted(y.tolist())
+    with pytest.raises(LampError, match="host memory"):
+        D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(x32, 0), fy, order=order, hostResident=True)
+
+
+@pytest.mark.gpu
 def test_training_from_stream_and_resume(gpu, tmp_path):
     """End to end: CIFAR-style records -> device-resident stream -> a few training steps -> checkpoint -> a fresh model loaded
     from it continues bit-identically to the original."""
