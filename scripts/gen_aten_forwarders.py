@@ -48,7 +48,7 @@ EXPLICIT = {
                        "return own(N.lamp_scatter_value(h(self), dim, h(index), value));"),
     "ATen._log_softmax_backward_data": ("Tensor gradOutput, Tensor output, long dim, byte inputDtype", "Tensor",
                                         "return own(N.lamp_log_softmax_backward_data(h(gradOutput), h(output), dim));"),
-    "ATen._scaled_dot_product_cudnn_attention": ("Tensor query, Tensor key, Tensor value, Object attnBias, boolean computeLogSumExp, double dropoutP, boolean isCausal, boolean returnDebugMask", "Object[]",
+    "ATen._scaled_dot_product_cudnn_attention": ("Tensor query, Tensor key, Tensor value, scala.Option<Tensor> attnBias, boolean computeLogSumExp, double dropoutP, boolean isCausal, boolean returnDebugMask", "Object[]",
         "long b = Tensor.handleOfOption(attnBias);\n    long[] r = b == 0 ? N.lamp_scaled_dot_product_attention(h(query), h(key), h(value), isCausal ? 1 : 0, 0.0)\n"
         "                      : N.lamp_scaled_dot_product_attention_bias(h(query), h(key), h(value), b, isCausal ? 1 : 0, 0.0);\n"
         "    // (output, logsumexp, cum_seq_q, cum_seq_k, max_q, max_k, philox_seed, philox_offset, debug_attn_mask): no dropout, so the bookkeeping tensors are empty\n"
@@ -78,14 +78,14 @@ EXPLICIT = {
                         "return own(N.lamp_avg_pool2d(h(self), kernelSize[0], stride[0], padding[0], ceilMode ? 1 : 0, countIncludePad ? 1 : 0));"),
     "ATen.avg_pool2d_backward": ("Tensor gradOutput, Tensor self, long[] kernelSize, long[] stride, long[] padding, boolean ceilMode, boolean countIncludePad, long divisorOverride", "Tensor",
                                  "return own(N.lamp_avg_pool2d_backward(h(gradOutput), h(self), kernelSize[0], stride[0], padding[0], ceilMode ? 1 : 0, countIncludePad ? 1 : 0));"),
-    "ATen.binary_cross_entropy_with_logits": ("Tensor self, Tensor target, Object weight, Object posWeight, long reduction", "Tensor",
+    "ATen.binary_cross_entropy_with_logits": ("Tensor self, Tensor target, scala.Option<Tensor> weight, scala.Option<Tensor> posWeight, long reduction", "Tensor",
                                               "if (Tensor.handleOfOption(weight) != 0) throw new UnsupportedOperationException(\"binary_cross_entropy_with_logits: per-element weights are not used by lamp\");\n"
                                               "    return own(N.lamp_binary_cross_entropy_with_logits(h(self), h(target), Tensor.handleOfOption(posWeight), reduction));"),
     "ATen.conv1d_0": ("Tensor input, Tensor weight, Object bias, long[] stride, long[] padding, long[] dilation, long groups", "Tensor",
                       "return own(N.lamp_convolution(h(input), h(weight), Tensor.handleOfOption(bias), stride, padding, dilation, 0, new long[] {0}, groups));"),
     "ATen.conv_transpose1d": ("Tensor input, Tensor weight, Object bias, long[] stride, long[] padding, long[] outputPadding, long groups, long[] dilation", "Tensor",
                               "return own(N.lamp_convolution(h(input), h(weight), Tensor.handleOfOption(bias), stride, padding, dilation, 1, outputPadding, groups));"),
-    "ATen.convolution_backward": ("Tensor gradOutput, Tensor input, Tensor weight, Object biasSizes, long[] stride, long[] padding, long[] dilation, boolean transposed, long[] outputPadding, long groups, boolean[] outputMask", "Tensor[]",
+    "ATen.convolution_backward": ("Tensor gradOutput, Tensor input, Tensor weight, scala.Option<long[]> biasSizes, long[] stride, long[] padding, long[] dilation, boolean transposed, long[] outputPadding, long groups, boolean[] outputMask", "Tensor[]",
                                   "return Tensor.owningAll(N.lamp_convolution_backward(h(gradOutput), h(input), h(weight), stride, padding, dilation, transposed ? 1 : 0, outputPadding, groups, outputMask));"),
     "ATen.embedding": ("Tensor weight, Tensor indices, long paddingIdx, boolean scaleGradByFreq, boolean sparse", "Tensor",
                        "return own(N.lamp_embedding(h(weight), h(indices)));"),
@@ -208,22 +208,114 @@ def split_args(s):
     return out
 
 
-def arg_kind(a):
-    a = re.sub(r"\s+", " ", a)
+DECL_RE = re.compile(r"\b([a-z][A-Za-z0-9_]*)\s*:\s*(Boolean|Int|Long|Short|Byte|Double|Float|String|Option\[[A-Za-z\[\]]+\]|(?:Seq|List|Array|Vector)\[[A-Za-z\[\]]+\]|STen|Tensor|Variable)")
+
+
+def strip_comments(src):
+    """comments blanked out (newlines kept, so line numbers stay): commented-out calls are not call sites"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '"':
+            if src.startswith('"""', i):
+                j = src.find('"""', i + 3)
+                j = n if j < 0 else j + 3
+            else:
+                j = i + 1
+                while j < n and src[j] != '"' and src[j] != "\n":
+                    j += 2 if src[j] == "\\" else 1
+                j = min(j + 1, n)
+            out.append(src[i:j]); i = j
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            j = n if j < 0 else j
+            out.append(" " * (j - i)); i = j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            j = n if j < 0 else j + 2
+            out.append("".join(ch if ch == "\n" else " " for ch in src[i:j])); i = j
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
+def declared_types(src):
+    """identifier -> declared Scala type, for the identifiers a file declares with ONE type (parameters, vals, fields): what a call site's
+    argument is can then be read off lexically"""
+    seen = {}
+    for m in DECL_RE.finditer(src):
+        seen.setdefault(m.group(1), set()).add(m.group(2))
+    return {k: next(iter(v)) for k, v in seen.items() if len(v) == 1}
+
+
+def type_kind(t):
+    if t == "Boolean":
+        return "bool"
+    if t in ("Int", "Long", "Short", "Byte"):
+        return "long"
+    if t in ("Double", "Float"):
+        return "double"
+    if t == "String":
+        return "string"
+    if t.startswith("Option["):
+        inner = t[7:-1]
+        return "option:" + {"STen": "tensor", "Tensor": "tensor", "Variable": "tensor"}.get(inner, type_kind(inner) if inner in ("Boolean", "Int", "Long", "Double", "Float", "String") else "expr")
+    if re.match(r"(Seq|List|Array|Vector)\[(Int|Long)\]", t):
+        return "longs"
+    if re.match(r"(Seq|List|Array|Vector)\[(STen|Tensor|Variable)\]", t):
+        return "tensors"
+    return "expr"
+
+
+def arg_kind(a, types=None):
+    """what a call site passes at one position, as far as the text says: literal kinds, Option(...) / Some(...) / None, arrays, `.value` tensors,
+    boolean expressions, and identifiers whose declared type the file states"""
+    types = types or {}
+    a = re.sub(r"\s+", " ", a).strip()
     if a in ("true", "false"):
         return "bool"
     if re.fullmatch(r"-?\d+[lL]?", a):
         return "long"
     if re.fullmatch(r"-?\d*\.\d+(e-?\d+)?[dD]?|-?\d+[dD]|-?\d+e-?\d+", a):
         return "double"
-    if re.search(r"(tensorOptions|options|tOpt|opt)\w*\.value$|\.options(\.value)?$|TensorOptions\.", a):
+    if a == "None":
+        return "option:none"
+    m = re.fullmatch(r"(?:Option|Some)\((.*)\)", a)
+    if m:
+        return "option:" + arg_kind(m.group(1), types).split(":")[-1]
+    if re.search(r"\.map\(\s*_\.value\s*\)$", a) and not re.search(r"\.toArray", a):
+        base = re.sub(r"\.map\(\s*_\.value\s*\)$", "", a)
+        t = types.get(base.split(".")[-1], "")
+        return "tensors" if re.match(r"(Seq|List|Array|Vector)\[", t) else "option:tensor"
+    if re.search(r"(?i)(options|opt)[A-Za-z0-9]*\b[^,]*\.value$|\.options(\([^)]*\))?(\.value)?$|TensorOptions\.", a):
         return "options"
-    if re.search(r"map\(_\.value\)\.toArray|\.toArray\.map\(_\.value\)|Array\(.*value", a):
+    if re.search(r"map\(_(\._\d)?\.value\)\.toArray|\.toArray\.map\(_\.value\)|Array\(.*value", a):
         return "tensors"
-    if re.search(r"\.toArray|Array\(|Array\.", a):
+    if re.fullmatch(r"Array\((\s*(true|false)\s*,?)+\)", a):
+        return "bools"
+    if re.search(r"Array\(|Array\.|map\(_\.toLong\)", a):
         return "longs"
-    if a.endswith(".value") or a == "value" or a.endswith(".value)"):
+    if re.search(r"\.toArray", a):
+        base = re.sub(r"\.toArray.*$", "", a)
+        t = types.get(base.split(".")[-1], "") if re.fullmatch(r"[A-Za-z_][A-Za-z0-9_.]*", base) else ""
+        k = type_kind(t) if t else "expr"
+        return k if k in ("longs", "tensors") else "array"
+    if a.endswith(".value") or a.endswith(".value)"):
         return "tensor"
+    if a == "value":
+        return type_kind(types["value"]) if "value" in types else "tensor"
+    if a.startswith('"'):
+        return "string"
+    if re.search(r"\.toLong$|\.toInt$", a):
+        return "long"
+    if re.search(r"\.toDouble$|\.toFloat$", a):
+        return "double"
+    if re.search(r"==|!=|<=|>=|&&|\|\||^!|\.isDefined$|\.isEmpty$|\.nonEmpty$", a):
+        return "bool"
+    if re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*(\.[A-Za-z_][A-Za-z0-9_]*)*", a):
+        t = types.get(a.split(".")[-1])
+        if t:
+            return type_kind(t)
     return "expr"
 
 
@@ -232,8 +324,10 @@ def collect():
     sites = {c: {} for c in CLASSES}
     for d in G.REF_DIRS:
         for f in sorted(glob.glob(os.path.join(ref, d, "**", "*.scala"), recursive=True)):
-            src = open(f).read()
+            src = strip_comments(open(f).read())
             rel = os.path.relpath(f, ref)
+            file_types = declared_types(src)
+            defs = [(d.start(), d.end()) for d in re.finditer(r"\bdef\s+[^\s(\[=:]+", src)]
             for m in re.finditer(r"\b(ATen|Tensor|CudaStream|NcclComm|TensorTrace)\s*\.\s*([A-Za-z_][A-Za-z_0-9]*)\s*\(", src):
                 cls, name = m.group(1), m.group(2)
                 i, depth = m.end(), 1
@@ -248,10 +342,25 @@ def collect():
                         depth -= 1
                     i += 1
                 args = split_args(src[m.end():i - 1])
+                # identifiers are typed by the parameter list of the enclosing def first (STen.scala declares `other` as STen, Double and Long in
+                # neighbouring overloads), then by what the file declares unambiguously
+                types = dict(file_types)
+                enclosing = [d for d in defs if d[0] < m.start()]
+                if enclosing:
+                    head = src[enclosing[-1][1]:m.start()]
+                    cut = re.search(r"\)\s*(:\s*[A-Za-z\[\], ().]+)?\s*=\s", head)
+                    sig_text = head[:cut.start() + 1] if cut else head[:400]
+                    for dm in DECL_RE.finditer(sig_text):
+                        types[dm.group(1)] = dm.group(2)
                 line = src.count("\n", 0, m.start()) + 1
                 e = sites[cls].setdefault(name, {"calls": []})
-                e["calls"].append({"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a) for a in args]})
-    out = {"_source": {"dirs": G.REF_DIRS, "note": "call sites of the aten package in lamp's hot-path modules: argument counts and literal kinds only "
+                # `val (a, b, c) = ATen.x(...)`: the call's result is destructured as a tuple of that many members
+                before = src[max(0, m.start() - 200):m.start()]
+                tm = re.search(r"val\s*\(([^()=]*)\)\s*=\s*(?:[A-Za-z_.]*\(\s*)?$", before)
+                tup = len(split_args(tm.group(1))) if tm else 0
+                tup = tup if tup >= 2 else 0                       # `val (x) = ...` is no tuple
+                e["calls"].append({"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a, types) for a in args], "tuple": tup})
+    out = {"_source": {"dirs": G.REF_DIRS, "note": "call sites of the aten package in lamp's hot-path modules: argument counts, argument kinds (literals, Option / Some / None, arrays, tensors, booleans, identifiers by their declared type) and the arity of a destructured result - no source text "
                                                    "(scripts/gen_aten_forwarders.py collect, build container)"}}
     for c in CLASSES:
         out[c] = {n: sites[c][n] for n in sorted(sites[c])}
@@ -330,22 +439,96 @@ def wrap_result(jret, outs):
     return jret, "return {call};"
 
 
+def kinds_at(e, n_params):
+    """per parameter position: the kinds the call sites (of that arity) pass there"""
+    ks = [set() for _ in range(n_params)]
+    for c in e["calls"]:
+        if c["arity"] == n_params:
+            for i, k in enumerate(c["kinds"]):
+                ks[i].add(k)
+    return ks
+
+
+def tuple_arity(e):
+    t = {c.get("tuple", 0) for c in e["calls"]} - {0}
+    return max(t) if t else 0
+
+
+def compatible(jt, kind):
+    if kind == "expr":
+        return True
+    if kind.startswith("option:"):
+        return jt.startswith("scala.Option<")
+    if kind == "array":
+        return jt.endswith("[]")
+    # (a Long argument where the forwarder takes a double: Scala widens it)
+    return jt in {"tensor": ("Tensor",), "bool": ("boolean",), "long": ("long", "int", "short", "byte", "double"), "double": ("double", "float"),
+                  "longs": ("long[]",), "tensors": ("Tensor[]",), "bools": ("boolean[]",), "options": ("TensorOptions",),
+                  "string": ("String",)}.get(kind, (jt,))
+
+
+def refine_params(ps, kinds):
+    """the native's input list re-typed by what the call sites pass: scala.Option where they pass Option / Some / None, boolean where they pass
+    Booleans (the C ABI takes flags as ints)"""
+    out = []
+    for (jt, name, exprs), ks in zip(ps, kinds):
+        if any(k.startswith("option:") for k in ks):
+            if jt == "Tensor":
+                jt, exprs = "scala.Option<Tensor>", [f"Tensor.handleOfOption({name})"]
+            elif jt == "long[]":
+                jt, exprs = "scala.Option<long[]>", [f"Tensor.longsOfOption({name})"]
+        elif "bool" in ks and jt == "long" and exprs == [f"(int) {name}"]:
+            jt, exprs = "boolean", [f"{name} ? 1 : 0"]
+        out.append((jt, name, exprs))
+    return out
+
+
+def tuple_type(k, parts):
+    return f"scala.Tuple{k}<{', '.join(parts)}>"
+
+
 def forwarders():
     sites = json.load(open(CALLSITES))
     nm = json.load(open(G.NAME_MAP))
     syms = G.exported_symbols()
     sig = native_signatures()
-    per_class, report = {c: [] for c in CLASSES}, {"forwarded": 0, "arity_mismatch": [], "unmapped": [], "no_native": []}
+    per_class, report = {c: [] for c in CLASSES}, {"forwarded": 0, "arity_mismatch": [], "kind_mismatch": [], "unmapped": [], "no_native": []}
+
+    def check_kinds(key, e, jtypes, rtype):
+        for c in e["calls"]:
+            if c["arity"] != len(jtypes):
+                continue
+            for i, (jt, k) in enumerate(zip(jtypes, c["kinds"])):
+                if not compatible(jt, k):
+                    report["kind_mismatch"].append({"name": key, "at": c["at"], "position": i, "call_site_passes": k, "forwarder_takes": jt})
+            t = c.get("tuple", 0)
+            if t and not rtype.startswith(f"scala.Tuple{t}<"):
+                report["kind_mismatch"].append({"name": key, "at": c["at"], "position": "result", "call_site_passes": f"val ({t} names) =", "forwarder_takes": rtype})
+
     for cls in CLASSES:
         for name, e in sites.get(cls, {}).items():
             sym, _ = symbol_of(cls, name, nm, syms)
             key = f"{cls}.{name}"
             if key in EXPLICIT:
-                params, rtype, body = EXPLICIT[key]
-                n_params = 0 if not params.strip() else len(params.split(","))
+                params, rtype, body = EXPLICIT[key][:3]
+                plist = [] if not params.strip() else [p.strip() for p in params.split(",")]
+                n_params = len(plist)
                 arities = sorted({c["arity"] for c in e["calls"]})
                 where = e["calls"][0]["at"]
-                per_class[cls].append((name, f"  /** {cls}.{name} ({where}) */\n  public static {rtype} {name}({params}) {{\n    {body}\n  }}", n_params, arities))
+                tk = tuple_arity(e)
+                if tk and rtype in ("Tensor[]", "Object[]"):
+                    # the call sites destructure the result: the body (which builds an array) moves into a private method, the public one wraps
+                    parts = list(EXPLICIT[key][3]) if len(EXPLICIT[key]) > 3 else ["Tensor"] * tk
+                    tt = tuple_type(tk, parts)
+                    args_ = ", ".join(p.split()[-1] for p in plist)
+                    items = ", ".join(f"({parts[i]}) r_[{i}]" for i in range(tk))
+                    text = (f"  /** {cls}.{name} ({where}) */\n  public static {tt} {name}({params}) {{\n    {rtype} r_ = {name}__parts({args_});\n"
+                            f"    return new {tt}({items});\n  }}\n  private static {rtype} {name}__parts({params}) {{\n    {body}\n  }}")
+                    rtype = tt
+                else:
+                    text = f"  /** {cls}.{name} ({where}) */\n  public static {rtype} {name}({params}) {{\n    {body}\n  }}"
+                per_class[cls].append((name, text, n_params, arities))
+                check_kinds(key, e, [" ".join(p.split()[:-1]) for p in plist], rtype)
                 report["forwarded"] += 1
                 report.setdefault("explicit", []).append(key)
                 if arities != [n_params]:
@@ -361,12 +544,18 @@ def forwarders():
                 continue
             ins, outs, jret = sig[sym]
             ps = aten_params(ins)
+            ps = refine_params(ps, kinds_at(e, len(ps)))
             arities = sorted({c["arity"] for c in e["calls"]})
             rtype, body = wrap_result(jret, outs)
+            tk = tuple_arity(e)
+            if tk and rtype == "Tensor[]" and len([o for o in outs]) >= 1:
+                tt = tuple_type(tk, ["Tensor"] * tk)
+                rtype, body = tt, "long[] r_ = {call}; return new " + tt + "(" + ", ".join(f"Tensor.owning(r_[{i}])" for i in range(tk)) + ");"
             call = f"LampNative.{sym}({', '.join(x for _, _, xs in ps for x in xs)})"
             decl = ", ".join(f"{t} {n}" for t, n, _ in ps)
             where = e["calls"][0]["at"]
             per_class[cls].append((name, f"  /** {cls}.{name} - {sym} ({where}) */\n  public static {rtype} {name}({decl}) {{ {body.format(call=call)} }}", len(ps), arities))
+            check_kinds(f"{cls}.{name}", e, [t for t, _, _ in ps], rtype)
             report["forwarded"] += 1
             if arities != [len(ps)]:
                 report["arity_mismatch"].append({"name": f"{cls}.{name}", "symbol": sym, "forwarder_arity": len(ps), "call_site_arities": arities,
@@ -389,6 +578,15 @@ SUPPORT = {
       if ((Boolean) o.getClass().getMethod("isEmpty").invoke(o)) return 0L;
       return handleOf((Tensor) o.getClass().getMethod("get").invoke(o));
     } catch (ReflectiveOperationException e) { throw new IllegalArgumentException("expected scala.Option[aten.Tensor], got " + o.getClass(), e); }
+  }
+  /** a Scala Option[Array[Long]] (or a long[], or null) */
+  static long[] longsOfOption(Object o) {
+    if (o == null) return null;
+    if (o instanceof long[]) return (long[]) o;
+    try {
+      if ((Boolean) o.getClass().getMethod("isEmpty").invoke(o)) return null;
+      return (long[]) o.getClass().getMethod("get").invoke(o);
+    } catch (ReflectiveOperationException e) { throw new IllegalArgumentException("expected scala.Option[Array[Long]], got " + o.getClass(), e); }
   }
   static long[] handlesOf(Tensor[] ts) { long[] r = new long[ts.length]; for (int i = 0; i < ts.length; i++) r[i] = handleOf(ts[i]); return r; }
   public void release() { if (handle != 0) { LampNative.lamp_tensor_release(handle); handle = 0; } }
@@ -472,6 +670,6 @@ if __name__ == "__main__":
     else:
         r = check()
         print(json.dumps({k: (len(v) if isinstance(v, list) else v) for k, v in r.items()}))
-        for m in r["arity_mismatch"]:
+        for m in r["arity_mismatch"] + r["kind_mismatch"]:
             print("  ", m)
-        sys.exit(1 if r["arity_mismatch"] else 0)
+        sys.exit(1 if (r["arity_mismatch"] or r["kind_mismatch"]) else 0)

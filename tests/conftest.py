@@ -43,3 +43,22 @@ def gpu():
     if not _has_gpu():
         pytest.fail("no MI355X visible: the product path has no CPU fallback (run -m 'not gpu' on CPU boxes)")
     return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    """LAMP_SOAK=N (scripts/soak.sh): every collected test N times, the whole list shuffled (seed LAMP_SOAK_SEED) - the hunt for the order- or
+    timing-dependent failure of VERDICT r3 (weak 1): spin-wait grids, deferred reductions, cross-stream allocator reuse, graph capture."""
+    n = int(os.environ.get("LAMP_SOAK", "0") or 0)
+    if n <= 1:
+        return
+    import copy
+    import random
+    base = list(items)
+    out = []
+    for k in range(n):
+        for it in base:
+            c = copy.copy(it)
+            c._nodeid = f"{it.nodeid}#soak{k}"
+            out.append(c)
+    random.Random(int(os.environ.get("LAMP_SOAK_SEED", "1"))).shuffle(out)
+    items[:] = out
