@@ -8,6 +8,7 @@
 //   dgrad : dx[n, :, h, w]   = sum_{co,r,s}   dy[n, co, (h + p - r)/sh, (w + p - s)/sw] * w[co, :, r, s]
 #include "device_utils.h"
 #include "conv_geom.h"
+#include "wgrad_reduce.h"
 
 namespace lamp {
 
@@ -254,6 +255,15 @@ template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, T
     else if (CB == 16 && KW == 1) CS_WG(16, 1); else if (CB == 16 && KW == 3) CS_WG(16, 3); else CS_WG(16, 5);
 #undef CS_WG
     LAMP_LAUNCH_CHECK();
+  }
+  // the per-block sums join the backward pass's batched reduction (wgrad_reduce.hip: one launch for every layer's partial sums; the same
+  // lanes-over-blocks + butterfly order as cs_wgrad_reduce_kernel, so the same bits) - seven ~5 us launches of the f32 ResNet step
+  if (std::is_same<T, float>::value || std::is_same<T, bf16_t>::value) {
+    WgradReduceArgs ra{};
+    ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
+    ra.dw_f32 = std::is_same<T, float>::value ? 1 : 0;
+    wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+    return true;
   }
   hipLaunchKernelGGL((cs_wgrad_reduce_kernel<T>), dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<T>(), O, nblocks);
   LAMP_LAUNCH_CHECK();
