@@ -1,0 +1,55 @@
+"""Per-kernel means of a rocprofv3 --pmc + --kernel-trace run (one counter group): counters per dispatch, dispatch duration from the kernel
+trace, and - where the group has them - MFMA busy and wait shares.
+  python scripts/pmc_sq_summary.py <rocprof dir>            -> one block per kernel (those that took >= 1 % of the GPU time)
+  python scripts/pmc_sq_summary.py --table <gpurun_out/sq>   -> a table over the *_group1.txt / *_group2.txt files of scripts/sq_counters.sh
+SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the chip's 1024 SIMDs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+quad-cycles per wave (MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE sums the 8 XCDs."""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+def short(k):
+    k = re.sub(r"^void ", "", k)
+    k = re.sub(r"\(.*$", "", k)
+    return k.replace("lamp::", "")[:58]
+
+def summarize(root):
+    cnt = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = cnt[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    dur = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            d = dur[short(r["Kernel_Name"])]
+            d[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; d[1] += 1
+    total = sum(v[0] for v in dur.values()) or 1.0
+    for k in sorted(dur, key=lambda k: -dur[k][0]):
+        if dur[k][0] < 0.01 * total or k not in cnt:
+            continue
+        n, us = dur[k][1], dur[k][0] / dur[k][1]
+        c = {name: s / m for name, (s, m) in cnt[k].items()}
+        print(f"{k}\n  dispatches {n}  avg_us {us:.2f}  share_of_gpu_time {dur[k][0] / total:.3f}")
+        for name in sorted(c):
+            print(f"  {name:30s} {c[name]:16.0f}")
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0:
+            w = c["SQ_WAVE_CYCLES"]
+            print("  shares of wave cycles: " + ", ".join(f"{n2[3:].lower()} {c[n2] / w:.3f}" for n2 in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if n2 in c))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+            print(f"  mfma_busy_cycles / sq_busy_cycles {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}")
+        if "GRBM_GUI_ACTIVE" in c:
+            print(f"  clock_MHz_from_GRBM_GUI_ACTIVE {c['GRBM_GUI_ACTIVE'] / 8.0 / us:.0f}")
+
+if sys.argv[1] == "--table":
+    d = sys.argv[2]
+    for f in sorted(glob.glob(os.path.join(d, "*_group1.txt"))):
+        print("==", os.path.basename(f)[:-11])
+        blocks = open(f).read().split("\n")
+        name = None
+        for line in blocks:
+            if line and not line.startswith(" "):
+                name = line
+            elif "avg_us" in line or "shares of wave" in line or "mfma_busy" in line or "SQ_VALU_MFMA_BUSY_CYCLES" in line or "SQ_INSTS_MFMA" in line:
+                print(f"{name[:50]:50s} {line.strip()}")
+else:
+    summarize(sys.argv[1])
