@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
+PEAK_F64_TFLOPS = 78.6         # v_mfma_f64_16x16x4_f64: half the f32 rate
 
 
 def parse():
@@ -40,7 +41,7 @@ def parse():
     ap.add_argument("--workload", default="resnet", choices=["resnet", "gemm", "mlp", "knn", "attention", "umap", "umap-e2e", "lm", "epoch"])
     ap.add_argument("--batch", type=int, default=2048, help="per-GPU batch (resnet)")
     ap.add_argument("--graph", action="store_true", help="lm on one GPU: capture forward + backprop into a HIP graph, replay it per step (optimiser eager); the default for resnet")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--umap-points", default="mixed", choices=["mixed", "weyl"], help="umap-e2e: closed form of the points (see the workload's comment)")
     ap.add_argument("--no-graph", action="store_true", help="resnet: issue the step eagerly instead of replaying forward + backprop from a HIP graph")
@@ -147,7 +148,7 @@ def roofline_of(rows):
     traffic = traffic[0] if traffic is not None else None
     ai = flops / max(byts, 1.0)
     if flops > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
-        peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_BF16_TFLOPS
+        peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_F64_TFLOPS if d["tag"].endswith("f64") else PEAK_BF16_TFLOPS
         if d["tag"].startswith("knn_split_f16x"):
             # the f32 search on the 16-bit matrix pipe (kernels/knn_split.hip): every f32 product is 3 f16 products (two planes per value).
             # The launcher declares the ALGORITHMIC work of the search; the roofline is priced on what the f16 pipe executes (same peak as bf16).
@@ -304,7 +305,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    dtype = S.BF16 if a.dtype == "bf16" else S.F32
+    dtype = {"bf16": S.BF16, "f32": S.F32, "f64": S.F64}[a.dtype]
     result_extra = {}
     if a.workload == "resnet":
         B = a.batch
@@ -541,7 +542,7 @@ def main():
     step_eager = step
     modes = None                                  # multi-rank: [(name, step function)] - every exchange mode is timed, the faster one is `value`
     use_graph = not a.no_graph and ((a.workload == "resnet") or (a.graph and a.workload == "lm"))
-    if use_graph and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)):
+    if use_graph and not os.environ.get("LAMP_BENCH_GRAPH_UNDER_PROFILER") and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)):
         # rocprofv3's kernel tracing dies with SIGSEGV inside hipGraphLaunch on this image (5 of 8 runs on one box, never without the
         # profiler; the faulting frames are the profiler's graph hooks under lamp_graph_launch): a profiled run measures the eager step,
         # whose kernels are the replayed ones, and says so
@@ -705,6 +706,7 @@ def main():
             line["step_roofline"] = {"algorithmic_tflops": decl_f * sps / 1e12, "frac_bf16_mfma_peak": decl_f * sps / 1e12 / PEAK_BF16_TFLOPS,
                                      "algorithmic_GBps": decl_b * sps / 1e9, "frac_hbm_peak": decl_b * sps / 1e9 / PEAK_HBM_GBS,
                                      "frac_f32_mfma_peak": (decl_f * sps / 1e12 / PEAK_F32_TFLOPS) if a.dtype == "f32" else None,
+                                     "frac_f64_mfma_peak": (decl_f * sps / 1e12 / PEAK_F64_TFLOPS) if a.dtype == "f64" else None,
                                      "declared_bytes_per_step": decl_b, "declared_flops_per_step": decl_f,
                                      "source": "sum of the launchers' declared algorithmic bytes / flops over every kernel class of one eager step",
                                      "survey_estimate": {"flops_per_sample": 153.3e6, "bytes_per_sample": 1.4e6,

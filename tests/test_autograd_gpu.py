@@ -225,11 +225,12 @@ def test_resnet_training_steps_match_oracle(gpu, dt, B):
         grads_t = [to_torch(hg) for hg in hgrads]
         lib.lamp_kernel_timer_enable(0)
         lib.lamp_kernel_timer_report(buf, len(buf))
-        if dt == torch.float32:
-            # the reference's own precision (cifar100.scala:127-129) must run on the f32 matrix-core convolutions, not on the direct kernels
-            ran = {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines() if l.strip()}
-            assert ran.get("conv_igemm_fprop_dgrad_f32", 0) >= 12 and ran.get("conv_wgrad_igemm_f32", 0) == 6, f"f32 matrix-core convolutions did not run: {ran}"
-            assert not any(k.startswith("conv_") and k.endswith("_direct") for k in ran), f"a wide layer fell to the direct kernels: {ran}"
+        # the reference's own precisions (cifar100.scala:127-129: double unless --single) must run on the f32 / f64 matrix-core convolutions,
+        # not on the direct kernels
+        sfx = "f32" if dt == torch.float32 else "f64"
+        ran = {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines() if l.strip()}
+        assert ran.get("conv_igemm_fprop_dgrad_" + sfx, 0) >= 12 and ran.get("conv_wgrad_igemm_" + sfx, 0) == 6, f"{sfx} matrix-core convolutions did not run: {ran}"
+        assert not any(k.startswith("conv_") and k.endswith("_direct") for k in ran), f"a wide layer fell to the direct kernels: {ran}"
         assert_close(to_torch(acc) / B, oloss.double().reshape(1), ftol, f"loss step {step}")
         for i, (hg, og) in enumerate(zip(grads_t, ograds)):
             assert_close(hg, og.double(), btol, f"step {step} gradient {i} shape {list(og.shape)}")

@@ -716,14 +716,17 @@ def _timer_classes():
 @pytest.mark.parametrize("case", [(16, 128, 128, 3), (13, 128, 100, 3), (9, 100, 100, 3), (24, 16, 128, 3), (11, 128, 100, 1), (8, 16, 128, 1),
                                   (3, 100, 128, 3), (1, 128, 128, 3), (5, 128, 16, 3), (6, 128, 16, 1), (7, 20, 36, 3), (10, 64, 48, 3),
                                   (4, 4, 128, 3), (9, 92, 84, 1), (130, 128, 128, 3), (1030, 32, 100, 3)])
-def test_igemm_f32_kernels(gpu, case):
-    """conv_igemm_f32.hip - the f32 matrix-instruction convolutions of the 8x8 layers (v_mfma_f32_16x16x4_f32: exact f32 FMA chains):
-    fprop with bias, dgrad (plain and with the fused addend), wgrad and the bias gradient against ATen in f64 on the same f32 operands, at
-    north_star's tolerances (1e-5 forward, 1e-4 backward; ops.scala:1547-1651); batches that are not multiples of the four images per
-    workgroup, every count of 16-channel output tiles the kernels are instantiated for (1 = pixel split, 2, 4, 6, 7, 8), channel counts
-    that are multiples of 4 but not of 16, one image range and many in the weight gradient.  The kernel classes must have run."""
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_igemm_f32_kernels(gpu, case, dt):
+    """conv_igemm_f32.hip - the f32 and f64 matrix-instruction convolutions of the 8x8 layers (v_mfma_f32_16x16x4_f32 /
+    v_mfma_f64_16x16x4_f64: exact IEEE FMA chains): fprop with bias, dgrad (plain and with the fused addend), wgrad and the bias gradient
+    against ATen in f64 on the same operands, at north_star's tolerances (f32: 1e-5 forward, 1e-4 backward; f64: 1e-12 / 1e-10;
+    ops.scala:1547-1651); batches that are not multiples of the four (f64: two) images per workgroup, every count of 16-channel output
+    tiles the kernels are instantiated for (1 = pixel split, 2, 4, 6, 7, 8), channel counts that are multiples of 4 but not of 16, one
+    image range and many in the weight gradient.  The kernel classes must have run."""
     N, Cin, Cout, k = case
-    dt = torch.float32
+    sfx = "f32" if dt == torch.float32 else "f64"
+    ftol, btol = (1e-5, 1e-4) if dt == torch.float32 else (1e-12, 1e-10)
     x = closed_form((N, Cin, 8, 8), 3, 2.0, dt)
     w = closed_form((Cout, Cin, k, k), 17, 1.0, dt)
     b = closed_form((Cout,), 5, 1.0, dt)
@@ -750,14 +753,14 @@ def test_igemm_f32_kernels(gpu, case):
     lib.lamp_kernel_timer_enable(0)
     ran = _timer_classes()
     got_add = to_torch(S.STen(oa))
-    assert ran.get("conv_igemm_fprop_dgrad_f32", 0) == 3 and ran.get("conv_wgrad_igemm_f32", 0) == 1, f"the f32 matrix-core kernels did not run: {ran}"
-    assert_close(to_torch(S.STen(o)), ref, 1e-5, "f32 igemm forward")
-    assert_close(to_torch(dx), refb[0], 1e-4, "f32 igemm dgrad")
-    assert_close(got_w, refb[1], 1e-4, "f32 igemm wgrad")
-    assert_close(to_torch(db), refb[2], 1e-4, "bias gradient")
-    assert_close(got_add, refb[0] + add.double(), 1e-4, "f32 igemm dgrad + addend")
+    assert ran.get("conv_igemm_fprop_dgrad_" + sfx, 0) == 3 and ran.get("conv_wgrad_igemm_" + sfx, 0) == 1, f"the {sfx} matrix-core kernels did not run: {ran}"
+    assert_close(to_torch(S.STen(o)), ref, ftol, sfx + " igemm forward")
+    assert_close(to_torch(dx), refb[0], btol, sfx + " igemm dgrad")
+    assert_close(got_w, refb[1], btol, sfx + " igemm wgrad")
+    assert_close(to_torch(db), refb[2], btol, "bias gradient")
+    assert_close(got_add, refb[0] + add.double(), btol, sfx + " igemm dgrad + addend")
     # the fused addend is the unfused sum bit for bit: both are fl(fl(dgrad) + addend)
-    assert torch.equal(got_add.float(), to_torch(dx).float() + add)
+    assert torch.equal(got_add.to(dt), to_torch(dx).to(dt) + add)
 
 
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
