@@ -110,6 +110,223 @@ __global__ __launch_bounds__(256) void cs_dgrad_kernel(const T* __restrict__ dy,
   }
 }
 
+// ---- round 4: the same layers in f32 and f64 (the precisions the reference's example trains in), specialised ----------------------------
+// The generic kernels above spend more instructions on addressing than on arithmetic (runtime tap loops, an integer division per tap in the
+// strided dgrad, a division per staged element) and issue one v_fmac per channel.  For square power-of-two maps, kernel 1 / 3 / 5 with
+// "same" padding and stride 1 / 2 - every narrow layer of Cnn.resnet - the forms below unroll the taps, stage with 16-byte loads and shifts,
+// keep f32 accumulators in register PAIRS (v_pk_fma_f32: two channels per instruction, the weight pair an SGPR operand, the pixel broadcast by
+// op_sel - the VALU's full f32 rate, which is also the rate of the f32 matrix pipe) and f64 accumulators for f64 tensors (v_fma_f64 runs at
+// the rate of the unpacked f32 FMA).  The strided dgrad maps a thread to an ST x ST block of input pixels: which taps reach which pixel of
+// the block is then a compile-time fact (9 of 36 tap-pixel pairs for 3x3 stride 2), not a per-lane test.
+typedef float cs_float2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double cs_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <class T> struct CsAccOf { using type = float; };
+template <> struct CsAccOf<double> { using type = double; };
+
+template <class A, int CB> struct CsAcc {
+  A v[CB];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int c = 0; c < CB; c++) v[c] = A(0);
+  }
+  __device__ __forceinline__ void fma(A x, const A* __restrict__ w) {
+#pragma unroll
+    for (int c = 0; c < CB; c++) v[c] = cs_fma(x, w[c], v[c]);
+  }
+  __device__ __forceinline__ A get(int c) const { return v[c]; }
+};
+template <int CB> struct CsAcc<float, CB> {
+  cs_float2 v[CB / 2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int c = 0; c < CB / 2; c++) v[c] = cs_float2{0.f, 0.f};
+  }
+  __device__ __forceinline__ void fma(float x, const float* __restrict__ w) {
+    const cs_float2 x2 = {x, x};
+#pragma unroll
+    for (int c = 0; c < CB / 2; c++) v[c] = __builtin_elementwise_fma(x2, *reinterpret_cast<const cs_float2*>(w + 2 * c), v[c]);
+  }
+  __device__ __forceinline__ float get(int c) const { return (c & 1) ? v[c >> 1].y : v[c >> 1].x; }
+};
+
+// image (or gradient) of one sample -> LDS [C][S + 2 HALO][S + 2 HALO] with a zero halo; S = 1 << shift, 16 bytes per load
+template <class T, class A>
+__device__ __forceinline__ void cs2_stage(const T* __restrict__ src, A* __restrict__ dst, int C, int shift, int HALO, int tid, int nthreads) {
+  const int S = 1 << shift, Sp = S + 2 * HALO;
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  if (HALO > 0) {
+    for (int i = tid; i < C * Sp * Sp; i += nthreads) dst[i] = A(0);
+    __syncthreads();
+  }
+  const int total = (C << (2 * shift)) / V;
+  for (int i = tid; i < total; i += nthreads) {
+    const vec_t v = *reinterpret_cast<const vec_t*>(src + (int64_t)i * V);
+    const int e = i * V;
+    const int w_ = e & (S - 1), h_ = (e >> shift) & (S - 1), c_ = e >> (2 * shift);
+    A* d = dst + (c_ * Sp + h_ + HALO) * Sp + w_ + HALO;
+#pragma unroll
+    for (int k = 0; k < V; k++) d[k] = (A)v[k];
+  }
+  __syncthreads();
+}
+
+// fprop: one workgroup per image, one thread per output pixel (pixels beyond the workgroup's size in further rounds)
+template <class T, int CB, int KS, int ST>
+__global__ __launch_bounds__(256) void cs2_fwd_kernel(const T* __restrict__ x, const typename CsAccOf<T>::type* __restrict__ wf, const T* __restrict__ bias,
+                                                      T* __restrict__ y, int Cin, int Cout, int shift) {
+  using A = typename CsAccOf<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  constexpr int PAD = KS / 2;
+  const int S = 1 << shift, Sp = S + 2 * PAD;
+  const int oshift = ST == 2 ? shift - 1 : shift, So = 1 << oshift;
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  cs2_stage<T, A>(x + (n * Cin << (2 * shift)), xs, Cin, shift, PAD, tid, blockDim.x);
+  T* yp = y + (n * Cout << (2 * oshift));
+  for (int p = tid; p < So * So; p += blockDim.x) {
+    const int ho = p >> oshift, wo = p & (So - 1);
+    CsAcc<A, CB> acc;
+    acc.zero();
+    const A* xb = xs + (ho * ST) * Sp + wo * ST;
+    const A* wk = wf;
+    for (int ci = 0; ci < Cin; ci++) {
+#pragma unroll
+      for (int r = 0; r < KS; r++)
+#pragma unroll
+        for (int s = 0; s < KS; s++) acc.fma(xb[(ci * Sp + r) * Sp + s], wk + (r * KS + s) * CB);
+      wk += KS * KS * CB;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+      if (c < Cout) yp[(c << (2 * oshift)) + p] = (T)(acc.get(c) + (bias ? (A)bias[c] : A(0)));
+  }
+}
+
+// dgrad: one workgroup per image, one thread per ST x ST block of dx; dy staged with a halo of PAD zeros
+template <class T, int CB, int KS, int ST>
+__global__ __launch_bounds__(256) void cs2_dgrad_kernel(const T* __restrict__ dy, const typename CsAccOf<T>::type* __restrict__ wf, T* __restrict__ dx,
+                                                        int Cin, int Cout, int shift) {
+  using A = typename CsAccOf<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  A* ds = reinterpret_cast<A*>(smem_raw);
+  constexpr int PAD = KS / 2;
+  const int oshift = ST == 2 ? shift - 1 : shift, So = 1 << oshift, Sq = So + 2 * PAD;    // dy is So x So; a block of dx = one pixel of dy
+  const int S = 1 << shift;
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  cs2_stage<T, A>(dy + (n * Cout << (2 * oshift)), ds, Cout, oshift, PAD, tid, blockDim.x);
+  T* xp = dx + (n * Cin << (2 * shift));
+  for (int b = tid; b < So * So; b += blockDim.x) {
+    const int hb = b >> oshift, wb = b & (So - 1);
+    CsAcc<A, CB> acc[ST][ST];
+#pragma unroll
+    for (int i = 0; i < ST; i++)
+#pragma unroll
+      for (int j = 0; j < ST; j++) acc[i][j].zero();
+    const A* db = ds + (hb + PAD) * Sq + wb + PAD;
+    const A* wk = wf;
+    for (int co = 0; co < Cout; co++) {
+#pragma unroll
+      for (int r = 0; r < KS; r++)
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+          for (int i = 0; i < ST; i++)
+#pragma unroll
+            for (int j = 0; j < ST; j++) {
+              // dx[h, w] takes dy[(h + PAD - r) / ST, (w + PAD - s) / ST] where both divisions are exact
+              const int hn = i + PAD - r, wn = j + PAD - s;
+              if (hn % ST != 0 || wn % ST != 0) continue;
+              acc[i][j].fma(db[(co * Sq + hn / ST) * Sq + wn / ST], wk + (r * KS + s) * CB);
+            }
+      wk += KS * KS * CB;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+      if (c < Cin) {
+#pragma unroll
+        for (int i = 0; i < ST; i++) {
+          T* o = xp + (c << (2 * shift)) + (hb * ST + i) * S + wb * ST;
+          if (ST == 2) {
+            typedef T pair_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<pair_t*>(o) = pair_t{(T)acc[i][0].get(c), (T)acc[i][ST - 1].get(c)};
+          } else {
+            o[0] = (T)acc[i][0].get(c);
+          }
+        }
+      }
+  }
+}
+
+template <class T, class A>
+__global__ void cs2_pack_kernel(const T* __restrict__ w, A* __restrict__ wf, int Cout, int Cin, int KS, int CB, int dgrad) {
+  const int total = (dgrad ? Cout : Cin) * KS * KS * CB;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int c = e % CB, krs = e / CB;
+    const int s = krs % KS, r = (krs / KS) % KS, k = krs / (KS * KS);
+    A v = A(0);
+    if (!dgrad) { if (c < Cout) v = (A)w[((c * Cin + k) * KS + r) * KS + s]; }
+    else { if (c < Cin) v = (A)w[((k * Cin + c) * KS + r) * KS + s]; }
+    wf[e] = v;
+  }
+}
+
+static int cs2_shift_of(int64_t v) { int sh = 0; while ((1LL << sh) < v) sh++; return (1LL << sh) == v ? sh : -1; }
+static bool cs2_qualifies(const ConvGeom& g) {
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_SMALL2"); return !(e && e[0] == '0'); }();
+  if (!on || g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
+  if (g.Cin > 16 || g.Cout > 16 || g.N < 1) return false;
+  if (g.kh != g.kw || !(g.kh == 1 || g.kh == 3 || g.kh == 5) || g.ph != g.kh / 2 || g.pw != g.kh / 2) return false;
+  if (g.sh != g.sw || !(g.sh == 1 || g.sh == 2)) return false;
+  if (g.H != g.W || cs2_shift_of(g.H) < 2) return false;                 // square power-of-two maps, at least 4 x 4 (16-byte rows)
+  if (g.Ho != g.H / g.sh || g.Wo != g.W / g.sw || g.Ho < 1) return false;
+  return true;
+}
+
+template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+  using A = typename CsAccOf<T>::type;
+  if (!cs2_qualifies(g)) return false;
+  const int KS = g.kh, ST = g.sh, PAD = KS / 2;
+  const int shift = cs2_shift_of(g.H);
+  const int cb_ch = (int)(dgrad ? g.Cin : g.Cout);
+  const int CB = cb_ch == 6 ? 6 : (cb_ch <= 8 ? 8 : 16);
+  const int64_t side = (dgrad ? g.Ho : g.H) + 2 * PAD;
+  const size_t lds = (size_t)((dgrad ? g.Cout : g.Cin) * side * side) * sizeof(A);
+  if (lds > 150 * 1024) return false;
+  const int64_t nk = (dgrad ? g.Cout : g.Cin) * KS * KS * CB;
+  int64_t ps[1] = {nk};
+  Hold wf(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, in->device()));
+  hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3(grid_for(nk, 256)), dim3(256), 0, st, w->ptr<T>(), wf->ptr<A>(), (int)g.Cout, (int)g.Cin, KS, CB, dgrad ? 1 : 0);
+  LAMP_LAUNCH_CHECK();
+  const int64_t px = g.Ho * g.Wo;                        // fprop: output pixels; dgrad: ST x ST blocks of dx
+  const int block = px >= 256 ? 256 : (px >= 128 ? 128 : 64);
+  KernelTimer kt(dgrad ? "conv_dgrad_small" : "conv_fwd_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
+  const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+#define CS2_GO(CBv, KSv, STv)                                                                                                                       \
+  do {                                                                                                                                              \
+    if (!dgrad) {                                                                                                                                   \
+      if (lds > 64 * 1024) allow_big_lds((const void*)cs2_fwd_kernel<T, CBv, KSv, STv>);                                                            \
+      hipLaunchKernelGGL((cs2_fwd_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<A>(), bp, out->ptr<T>(), \
+                         (int)g.Cin, (int)g.Cout, shift);                                                                                           \
+    } else {                                                                                                                                        \
+      if (lds > 64 * 1024) allow_big_lds((const void*)cs2_dgrad_kernel<T, CBv, KSv, STv>);                                                          \
+      hipLaunchKernelGGL((cs2_dgrad_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<A>(), out->ptr<T>(), \
+                         (int)g.Cin, (int)g.Cout, shift);                                                                                           \
+    }                                                                                                                                               \
+  } while (0)
+#define CS2_BY_ST(CBv, KSv) do { if (ST == 1) CS2_GO(CBv, KSv, 1); else CS2_GO(CBv, KSv, 2); } while (0)
+#define CS2_BY_KS(CBv) do { if (KS == 1) CS2_BY_ST(CBv, 1); else if (KS == 3) CS2_BY_ST(CBv, 3); else CS2_BY_ST(CBv, 5); } while (0)
+  if (CB == 6) CS2_BY_KS(6); else if (CB == 8) CS2_BY_KS(8); else CS2_BY_KS(16);
+#undef CS2_BY_KS
+#undef CS2_BY_ST
+#undef CS2_GO
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+
 static bool cs_qualifies(const ConvGeom& g, bool dgrad) {
   if (g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
   if (g.Cin > 16 || g.Cout > 16) return false;
@@ -149,28 +366,28 @@ template <class T> static bool cs_run(const Tensor* in, const Tensor* w, const T
 // (ci, r) pair and a slice of the output rows and keeps a CB x KW register block of partial filter taps
 // (all output channels x all horizontal taps): per output pixel CB + KW LDS reads feed CB*KW FMAs.
 // Slices are combined with LDS atomics, workgroups through a partial buffer + deterministic reduce.
-template <class T, int CB, int KW>
-__global__ __launch_bounds__(256) void cs_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ partial, ConvGeom g,
+template <class T, int CB, int KW, class A = float>
+__global__ __launch_bounds__(256) void cs_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, A* __restrict__ partial, ConvGeom g,
                                                        int PS, int images_per_block) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int Hp = (int)g.H + 2 * g.ph, Wp = (int)g.W + 2 * g.pw + KW;   // + KW: slack so the last taps never read past the row
   const int Cin = (int)g.Cin, Cout = (int)g.Cout, H = (int)g.H, W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
-  float* xs = reinterpret_cast<float*>(smem_raw);             // [Cin][Hp][Wp]
-  float* ds = xs + Cin * Hp * Wp;                              // [CB][Ho][Wo] (rows >= Cout zero)
-  float* accs = ds + CB * Ho * Wo;                             // [PS][Cout][Cin][kh][KW] per-slice partials
+  A* xs = reinterpret_cast<A*>(smem_raw);                     // [Cin][Hp][Wp]
+  A* ds = xs + Cin * Hp * Wp;                                  // [CB][Ho][Wo] (rows >= Cout zero)
+  A* accs = ds + CB * Ho * Wo;                                 // [PS][Cout][Cin][kh][KW] per-slice partials
   const int O = Cout * Cin * g.kh * KW;
   const int tid = threadIdx.x;
-  for (int i = tid; i < Cin * Hp * Wp; i += blockDim.x) xs[i] = 0.f;
-  for (int i = tid; i < CB * Ho * Wo; i += blockDim.x) ds[i] = 0.f;
+  for (int i = tid; i < Cin * Hp * Wp; i += blockDim.x) xs[i] = A(0);
+  for (int i = tid; i < CB * Ho * Wo; i += blockDim.x) ds[i] = A(0);
   const int ntask = Cin * g.kh;
   const int task = tid % ntask, slice = tid / ntask;
   const bool active = slice < PS;
   const int ci = task / g.kh, r = task - ci * g.kh;
-  float acc[CB][KW];
+  A acc[CB][KW];
 #pragma unroll
   for (int c = 0; c < CB; c++)
 #pragma unroll
-    for (int s = 0; s < KW; s++) acc[c][s] = 0.f;
+    for (int s = 0; s < KW; s++) acc[c][s] = A(0);
   const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min(n0 + images_per_block, g.N);
   for (int64_t n = n0; n < n1; n++) {
     __syncthreads();
@@ -178,23 +395,23 @@ __global__ __launch_bounds__(256) void cs_wgrad_kernel(const T* __restrict__ dy,
     const T* dp = dy + n * Cout * Ho * Wo;
     for (int i = tid; i < Cin * H * W; i += blockDim.x) {
       const int w_ = i % W, h_ = (i / W) % H, c_ = i / (W * H);
-      xs[(c_ * Hp + h_ + g.ph) * Wp + w_ + g.pw] = load_as<float>(xp[i]);
+      xs[(c_ * Hp + h_ + g.ph) * Wp + w_ + g.pw] = load_as<A>(xp[i]);
     }
-    for (int i = tid; i < Cout * Ho * Wo; i += blockDim.x) ds[i] = load_as<float>(dp[i]);
+    for (int i = tid; i < Cout * Ho * Wo; i += blockDim.x) ds[i] = load_as<A>(dp[i]);
     __syncthreads();
     if (active) {
       for (int ho = slice; ho < Ho; ho += PS) {
-        const float* xr = xs + (ci * Hp + ho * g.sh + r) * Wp;
-        const float* dr = ds + ho * Wo;
+        const A* xr = xs + (ci * Hp + ho * g.sh + r) * Wp;
+        const A* dr = ds + ho * Wo;
         for (int wo = 0; wo < Wo; wo++) {
-          float xv[KW];
+          A xv[KW];
 #pragma unroll
           for (int s = 0; s < KW; s++) xv[s] = xr[wo * g.sw + s];
 #pragma unroll
           for (int c = 0; c < CB; c++) {
-            const float gv = dr[c * Ho * Wo + wo];
+            const A gv = dr[c * Ho * Wo + wo];
 #pragma unroll
-            for (int s = 0; s < KW; s++) acc[c][s] = fmaf(gv, xv[s], acc[c][s]);
+            for (int s = 0; s < KW; s++) acc[c][s] = cs_fma(gv, xv[s], acc[c][s]);
           }
         }
       }
@@ -211,47 +428,49 @@ __global__ __launch_bounds__(256) void cs_wgrad_kernel(const T* __restrict__ dy,
   __syncthreads();
   // fixed-order sum over the row slices: bitwise reproducible
   for (int i = tid; i < O; i += blockDim.x) {
-    float a = 0.f;
+    A a = A(0);
     for (int sl = 0; sl < PS; sl++) a += accs[sl * O + i];
     partial[(int64_t)blockIdx.x * O + i] = a;
   }
 }
-template <class T>
-__global__ __launch_bounds__(256) void cs_wgrad_reduce_kernel(const float* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
+template <class T, class A = float>
+__global__ __launch_bounds__(256) void cs_wgrad_reduce_kernel(const A* __restrict__ partial, T* __restrict__ dw, int O, int nblocks) {
   const int lane = threadIdx.x & 63;
   const int o = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6);
   if (o >= O) return;
-  float a = 0.f;
+  A a = A(0);
   for (int b = lane; b < nblocks; b += 64) a += partial[(int64_t)b * O + o];
   a = wave_sum(a);
   if (lane == 0) dw[o] = store_as<T>(a);
 }
 
 template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  using A = typename CsAccOf<T>::type;
   if (g.groups != 1 || g.transposed || g.dh != 1 || g.dw != 1) return false;
   if (g.Cin > 16 || g.Cout > 16 || g.kh != g.kw || !(g.kw == 1 || g.kw == 3 || g.kw == 5)) return false;
   const int ntask = (int)g.Cin * g.kh;
   if (ntask > 256 || g.N < 1) return false;
-  const int CB = g.Cout <= 8 ? 8 : 16, KW = g.kw;
+  const int CB = g.Cout == 6 ? 6 : (g.Cout <= 8 ? 8 : 16), KW = g.kw;
   const int Hp = (int)g.H + 2 * g.ph, Wp = (int)g.W + 2 * g.pw + KW;
   const int O = (int)(g.Cout * g.Cin * g.kh * KW);
   const int PS = std::min<int>(256 / ntask, (int)g.Ho);
-  const size_t lds = (size_t)(g.Cin * Hp * Wp + CB * g.Ho * g.Wo + (int64_t)PS * O) * 4;
+  const size_t lds = (size_t)(g.Cin * Hp * Wp + CB * g.Ho * g.Wo + (int64_t)PS * O) * sizeof(A);
   if (lds > 150 * 1024) return false;
   const int nb = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * 2);
   const int ipb = (int)((g.N + nb - 1) / nb);
   const int nblocks = (int)((g.N + ipb - 1) / ipb);
   int64_t ps[1] = {(int64_t)nblocks * O};
-  Hold partial(new_tensor(ps, 1, kF32, dy->device()));
+  Hold partial(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, dy->device()));
   {
     KernelTimer kt("conv_wgrad_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
 #define CS_WG(CBv, KWv)                                                                                                              \
   do {                                                                                                                               \
     static bool attr = false;                                                                                                        \
-    allow_big_lds((const void*)cs_wgrad_kernel<T, CBv, KWv>); \
-    hipLaunchKernelGGL((cs_wgrad_kernel<T, CBv, KWv>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<float>(), g, PS, ipb); \
+    allow_big_lds((const void*)cs_wgrad_kernel<T, CBv, KWv, A>); \
+    hipLaunchKernelGGL((cs_wgrad_kernel<T, CBv, KWv, A>), dim3(nblocks), dim3(256), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<A>(), g, PS, ipb); \
   } while (0)
-    if (CB == 8 && KW == 1) CS_WG(8, 1); else if (CB == 8 && KW == 3) CS_WG(8, 3); else if (CB == 8 && KW == 5) CS_WG(8, 5);
+    if (CB == 6 && KW == 1) CS_WG(6, 1); else if (CB == 6 && KW == 3) CS_WG(6, 3); else if (CB == 6 && KW == 5) CS_WG(6, 5);
+    else if (CB == 8 && KW == 1) CS_WG(8, 1); else if (CB == 8 && KW == 3) CS_WG(8, 3); else if (CB == 8 && KW == 5) CS_WG(8, 5);
     else if (CB == 16 && KW == 1) CS_WG(16, 1); else if (CB == 16 && KW == 3) CS_WG(16, 3); else CS_WG(16, 5);
 #undef CS_WG
     LAMP_LAUNCH_CHECK();
@@ -265,25 +484,28 @@ template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, T
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
     return true;
   }
-  hipLaunchKernelGGL((cs_wgrad_reduce_kernel<T>), dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<float>(), dw->ptr<T>(), O, nblocks);
+  hipLaunchKernelGGL((cs_wgrad_reduce_kernel<T, A>), dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), dw->ptr<T>(), O, nblocks);
   LAMP_LAUNCH_CHECK();
   return true;
 }
 bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
   if (x->dtype == kBF16) return cs_wgrad_run<bf16_t>(dy, x, dw, g, st);
   if (x->dtype == kF32) return cs_wgrad_run<float>(dy, x, dw, g, st);
+  if (x->dtype == kF64) return cs_wgrad_run<double>(dy, x, dw, g, st);
   return false;
 }
 
-// f32 accumulation is only parity-safe for bf16/f32 inputs; f64 stays on the generic direct kernels
+// f32 accumulation is only parity-safe for bf16/f32 inputs; f64 runs the specialised forms with f64 accumulators or the generic direct kernels
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
   if (x->dtype == kBF16) return cs_run<bf16_t>(x, w, bias, y, g, false, st);
-  if (x->dtype == kF32) return cs_run<float>(x, w, bias, y, g, false, st);
+  if (x->dtype == kF32) return cs2_run<float>(x, w, bias, y, g, false, st) || cs_run<float>(x, w, bias, y, g, false, st);
+  if (x->dtype == kF64) return cs2_run<double>(x, w, bias, y, g, false, st);
   return false;
 }
 bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
   if (dy->dtype == kBF16) return cs_run<bf16_t>(dy, w, nullptr, dx, g, true, st);
-  if (dy->dtype == kF32) return cs_run<float>(dy, w, nullptr, dx, g, true, st);
+  if (dy->dtype == kF32) return cs2_run<float>(dy, w, nullptr, dx, g, true, st) || cs_run<float>(dy, w, nullptr, dx, g, true, st);
+  if (dy->dtype == kF64) return cs2_run<double>(dy, w, nullptr, dx, g, true, st);
   return false;
 }
 

@@ -17,5 +17,5 @@ for i in $(seq 1 $M); do
   out=$(timeout 900 python -m pytest tests -q -m gpu -k "$SEL_FRESH" -p no:cacheprovider --no-header -rf 2>&1 | grep -E "passed|failed|error|^FAILED|^ERROR" | tail -4)
   if echo "$out" | grep -qE "failed|error"; then fail=$((fail + 1)); echo "fresh process $i: $out" >> $O/soak.txt; else pass=$((pass + 1)); fi
 done
-echo "fresh processes: $pass clean, $fail with failures (last summary: $out)" >> $O/soak.txt
+echo "fresh processes: $pass clean, $fail with failures (last summary: ${out:-none})" >> $O/soak.txt
 cat $O/soak.txt
