@@ -6,6 +6,10 @@
 // read through the scalar cache (wave-uniform indices -> s_load, used as SGPR operands of v_fmac).
 //   fprop : y[n, :, ho, wo]  = b + sum_{ci,r,s} x[n, ci, ho*sh - p + r, wo*sw - p + s] * w[:, ci, r, s]
 //   dgrad : dx[n, :, h, w]   = sum_{co,r,s}   dy[n, co, (h + p - r)/sh, (w + p - s)/sw] * w[co, :, r, s]
+#include <map>
+#include <vector>
+#include <mutex>
+#include <tuple>
 #include "device_utils.h"
 #include "conv_geom.h"
 #include "wgrad_reduce.h"
@@ -261,17 +265,108 @@ __global__ __launch_bounds__(256) void cs2_dgrad_kernel(const T* __restrict__ dy
   }
 }
 
+// both weight images of a layer - [fprop: (ci, r, s) x CBf output channels | dgrad: (co, r, s) x CBd input channels] - for up to 16 layers
+// in one launch (blockIdx.y = layer)
+constexpr int CS2_PACK_MAX = 16;
+struct Cs2PackMany { const void* w[CS2_PACK_MAX]; void* wf[CS2_PACK_MAX]; int Cout[CS2_PACK_MAX], Cin[CS2_PACK_MAX], KS[CS2_PACK_MAX], CBf[CS2_PACK_MAX], CBd[CS2_PACK_MAX]; };
 template <class T, class A>
-__global__ void cs2_pack_kernel(const T* __restrict__ w, A* __restrict__ wf, int Cout, int Cin, int KS, int CB, int dgrad) {
-  const int total = (dgrad ? Cout : Cin) * KS * KS * CB;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+__global__ void cs2_pack_kernel(Cs2PackMany a) {
+  const int t = blockIdx.y;
+  const T* __restrict__ w = static_cast<const T*>(a.w[t]);
+  A* __restrict__ wf = static_cast<A*>(a.wf[t]);
+  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], CBf = a.CBf[t], CBd = a.CBd[t];
+  const int nf = Cin * KS * KS * CBf, total = nf + Cout * KS * KS * CBd;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const bool dgrad = e0 >= nf;
+    const int e = dgrad ? e0 - nf : e0, CB = dgrad ? CBd : CBf;
     const int c = e % CB, krs = e / CB;
     const int s = krs % KS, r = (krs / KS) % KS, k = krs / (KS * KS);
     A v = A(0);
     if (!dgrad) { if (c < Cout) v = (A)w[((c * Cin + k) * KS + r) * KS + s]; }
     else { if (c < Cin) v = (A)w[((k * Cin + c) * KS + r) * KS + s]; }
-    wf[e] = v;
+    wf[e0] = v;
   }
+}
+static int cs2_cb_of(int64_t ch) { return ch == 6 ? 6 : (ch <= 8 ? 8 : 16); }
+
+// the packed images are kept per (weight view, stream) while the weight's storage is unchanged: the backward pass of a step finds what its
+// forward pass packed (13 -> 6 pack launches per ResNet step)
+namespace {
+struct Cs2PackKey {
+  uint64_t uid; int64_t offset; int KS, Cout, Cin, dtype; hipStream_t st;
+  bool operator<(const Cs2PackKey& o) const { return std::tie(uid, offset, KS, Cout, Cin, dtype, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.dtype, o.st); }
+};
+struct Cs2PackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+std::mutex g_cs2_mu;
+std::map<Cs2PackKey, Cs2PackVal> g_cs2_cache;
+uint64_t g_cs2_tick = 0;
+}  // namespace
+template <class T, class A> static Tensor* cs2_packed(const Tensor* w, const ConvGeom& g, hipStream_t st, int64_t* dgrad_offset) {
+  const int KS = g.kh, CBf = cs2_cb_of(g.Cout), CBd = cs2_cb_of(g.Cin);
+  const int64_t nf = g.Cin * KS * KS * CBf, nd = g.Cout * KS * KS * CBd;
+  *dgrad_offset = nf;
+  const bool cacheable = w->st->owned;
+  const Cs2PackKey key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, w->dtype, st};
+  const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_cs2_mu);
+    auto it = g_cs2_cache.find(key);
+    if (it != g_cs2_cache.end() && it->second.version == ver) { it->second.tick = ++g_cs2_tick; return retain(it->second.packed); }
+  }
+  int64_t ps[1] = {nf + nd};
+  Hold wf(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, w->device()));
+  Cs2PackMany pm;
+  pm.w[0] = w->raw(); pm.wf[0] = wf->raw(); pm.Cout[0] = (int)g.Cout; pm.Cin[0] = (int)g.Cin; pm.KS[0] = KS; pm.CBf[0] = CBf; pm.CBd[0] = CBd;
+  hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3((unsigned)std::min<int64_t>(64, (nf + nd + 255) / 256), 1u), dim3(256), 0, st, pm);
+  LAMP_LAUNCH_CHECK();
+  if (cacheable) {
+    std::lock_guard<std::mutex> lk(g_cs2_mu);
+    auto it = g_cs2_cache.find(key);
+    if (it != g_cs2_cache.end()) { release(it->second.packed); g_cs2_cache.erase(it); }
+    if (g_cs2_cache.size() >= 64) {
+      auto victim = g_cs2_cache.begin();
+      for (auto i = g_cs2_cache.begin(); i != g_cs2_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
+      release(victim->second.packed);
+      g_cs2_cache.erase(victim);
+    }
+    g_cs2_cache[key] = Cs2PackVal{ver, retain(wf.get()), ++g_cs2_tick};
+  }
+  return wf.take();
+}
+
+// the optimisers' hook (optim.hip): every cached pair of images whose weight was just updated is re-packed in place, one launch per element
+// type - a replayed graph (whose capture found the images in the cache and recorded no pack launch) keeps reading current weights
+template <class T, class A> static void cs2_repack_t(lamp_tensor* const* params, int n, hipStream_t st, int dtype) {
+  Cs2PackMany pm;
+  int cnt = 0;
+  std::vector<std::pair<Cs2PackKey, uint64_t>> done;
+  for (int i = 0; i < n && cnt < CS2_PACK_MAX; i++) {
+    const Tensor* w = params[i];
+    if (!w || !w->is_device() || w->dtype != dtype || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
+    for (auto& kv : g_cs2_cache) {
+      const Cs2PackKey& k = kv.first;
+      if (k.uid != w->st->uid || k.offset != w->offset || k.st != st || k.dtype != dtype) continue;
+      if (k.Cout != (int)w->sizes[0] || k.Cin != (int)w->sizes[1] || k.KS != (int)w->sizes[2]) continue;
+      pm.w[cnt] = w->raw(); pm.wf[cnt] = kv.second.packed->raw(); pm.Cout[cnt] = k.Cout; pm.Cin[cnt] = k.Cin; pm.KS[cnt] = k.KS;
+      pm.CBf[cnt] = cs2_cb_of(k.Cout); pm.CBd[cnt] = cs2_cb_of(k.Cin);
+      done.push_back({k, w->st->version.load(std::memory_order_relaxed)});
+      cnt++;
+      break;
+    }
+  }
+  if (cnt == 0) return;
+  hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3(16u, (unsigned)cnt), dim3(256), 0, st, pm);
+  LAMP_LAUNCH_CHECK();
+  for (auto& d : done) {
+    auto it = g_cs2_cache.find(d.first);
+    if (it != g_cs2_cache.end()) { it->second.version = d.second; it->second.tick = ++g_cs2_tick; }
+  }
+}
+void small_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_cs2_mu);
+  if (g_cs2_cache.empty()) return;
+  cs2_repack_t<float, float>(params, n, st, kF32);
+  cs2_repack_t<double, double>(params, n, st, kF64);
 }
 
 static int cs2_shift_of(int64_t v) { int sh = 0; while ((1LL << sh) < v) sh++; return (1LL << sh) == v ? sh : -1; }
@@ -291,16 +386,13 @@ template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const 
   if (!cs2_qualifies(g)) return false;
   const int KS = g.kh, ST = g.sh, PAD = KS / 2;
   const int shift = cs2_shift_of(g.H);
-  const int cb_ch = (int)(dgrad ? g.Cin : g.Cout);
-  const int CB = cb_ch == 6 ? 6 : (cb_ch <= 8 ? 8 : 16);
+  const int CB = cs2_cb_of(dgrad ? g.Cin : g.Cout);
   const int64_t side = (dgrad ? g.Ho : g.H) + 2 * PAD;
   const size_t lds = (size_t)((dgrad ? g.Cout : g.Cin) * side * side) * sizeof(A);
   if (lds > 150 * 1024) return false;
-  const int64_t nk = (dgrad ? g.Cout : g.Cin) * KS * KS * CB;
-  int64_t ps[1] = {nk};
-  Hold wf(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, in->device()));
-  hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3(grid_for(nk, 256)), dim3(256), 0, st, w->ptr<T>(), wf->ptr<A>(), (int)g.Cout, (int)g.Cin, KS, CB, dgrad ? 1 : 0);
-  LAMP_LAUNCH_CHECK();
+  int64_t dgrad_off = 0;
+  Hold wf(cs2_packed<T, A>(w, g, st, &dgrad_off));
+  const A* wfp = static_cast<const Tensor*>(wf.get())->ptr<A>() + (dgrad ? dgrad_off : 0);
   const int64_t px = g.Ho * g.Wo;                        // fprop: output pixels; dgrad: ST x ST blocks of dx
   const int block = px >= 256 ? 256 : (px >= 128 ? 128 : 64);
   KernelTimer kt(dgrad ? "conv_dgrad_small" : "conv_fwd_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
@@ -309,11 +401,11 @@ template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const 
   do {                                                                                                                                              \
     if (!dgrad) {                                                                                                                                   \
       if (lds > 64 * 1024) allow_big_lds((const void*)cs2_fwd_kernel<T, CBv, KSv, STv>);                                                            \
-      hipLaunchKernelGGL((cs2_fwd_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<A>(), bp, out->ptr<T>(), \
+      hipLaunchKernelGGL((cs2_fwd_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wfp, bp, out->ptr<T>(), \
                          (int)g.Cin, (int)g.Cout, shift);                                                                                           \
     } else {                                                                                                                                        \
       if (lds > 64 * 1024) allow_big_lds((const void*)cs2_dgrad_kernel<T, CBv, KSv, STv>);                                                          \
-      hipLaunchKernelGGL((cs2_dgrad_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wf->ptr<A>(), out->ptr<T>(), \
+      hipLaunchKernelGGL((cs2_dgrad_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wfp, out->ptr<T>(), \
                          (int)g.Cin, (int)g.Cout, shift);                                                                                           \
     }                                                                                                                                               \
   } while (0)
@@ -488,10 +580,151 @@ template <class T> static bool cs_wgrad_run(const Tensor* dy, const Tensor* x, T
   LAMP_LAUNCH_CHECK();
   return true;
 }
+// ---- round 4: weight gradient of the same layers, accumulators in registers ------------------------------------------------------------------
+// cs_wgrad_kernel above reads CB + KW values from LDS for CB x KW multiply-adds: LDS-bound.  Here a thread owns output PIXELS (lane = pixel,
+// 64 per round) and a wave owns a share of the filter taps: the units (input channel, filter row, half of the output channels when there
+// are 16) are dealt round-robin to the eight waves, at most MAXU per wave; for each of its units a thread keeps COH x KS accumulators in
+// registers (f32: as pairs of output channels, v_pk_fma_f32) and per pixel reads COH gradients + KS image values for COH x KS
+// multiply-adds.  The accumulators live across all the images of the workgroup and are summed over the wave's lanes once at the end.
+template <class T, int CO, int KS, int ST, int MAXU>
+__global__ __launch_bounds__(512) void cs2_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, typename CsAccOf<T>::type* __restrict__ partial,
+                                                        int64_t N, int Cin, int shift, int images_per_block) {
+  using A = typename CsAccOf<T>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int PAD = KS / 2;
+  constexpr int COH = CO <= 8 ? CO : CO / 2, NH = CO / COH;
+  const int S = 1 << shift, Sp = S + 2 * PAD;
+  const int oshift = ST == 2 ? shift - 1 : shift, So = 1 << oshift;
+  A* xs = reinterpret_cast<A*>(smem_raw);                      // [Cin][Sp][Sp], zero halo
+  A* ds = xs + Cin * Sp * Sp;                                  // [CO][So][So]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nunits = Cin * KS * NH;
+  int xoff[MAXU], doff[MAXU];                                   // wave-uniform LDS offsets of this wave's units
+#pragma unroll
+  for (int k = 0; k < MAXU; k++) {
+    const int u = min(wid + 8 * k, nunits - 1);
+    const int h = u % NH, cr = u / NH, r = cr % KS, ci = cr / KS;
+    xoff[k] = (ci * Sp + r) * Sp;
+    doff[k] = (h * COH) << (2 * oshift);
+  }
+  A acc[MAXU][KS][COH];
+#pragma unroll
+  for (int k = 0; k < MAXU; k++)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; s_++)
+#pragma unroll
+      for (int c = 0; c < COH; c++) acc[k][s_][c] = A(0);
+
+  const int64_t n0 = (int64_t)blockIdx.x * images_per_block, n1 = min(n0 + images_per_block, N);
+  for (int64_t n = n0; n < n1; n++) {
+    __syncthreads();                                           // the previous image has been consumed
+    cs2_stage<T, A>(x + (n * Cin << (2 * shift)), xs, Cin, shift, PAD, tid, 512);
+    cs2_stage<T, A>(dy + (n * CO << (2 * oshift)), ds, CO, oshift, 0, tid, 512);
+    for (int p = lane; p < So * So; p += 64) {
+      const int ho = p >> oshift, wo = p & (So - 1);
+      const A* xb = xs + (ho * ST) * Sp + wo * ST;
+#pragma unroll
+      for (int k = 0; k < MAXU; k++) {
+        if (wid + 8 * k < nunits) {
+          A gv[COH];
+#pragma unroll
+          for (int c = 0; c < COH; c++) gv[c] = ds[doff[k] + (c << (2 * oshift)) + p];
+#pragma unroll
+          for (int s_ = 0; s_ < KS; s_++) {
+            const A xv = xb[xoff[k] + s_];
+            if constexpr (std::is_same<A, float>::value) {
+              const cs_float2 x2 = {xv, xv};
+#pragma unroll
+              for (int c = 0; c < COH; c += 2) {
+                cs_float2 a = {acc[k][s_][c], acc[k][s_][c + 1]};
+                a = __builtin_elementwise_fma(cs_float2{gv[c], gv[c + 1]}, x2, a);
+                acc[k][s_][c] = a.x; acc[k][s_][c + 1] = a.y;
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < COH; c++) acc[k][s_][c] = cs_fma(gv[c], xv, acc[k][s_][c]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // sum over the wave's lanes (fixed butterfly order), one writer per accumulator: partial[block][((co Cin + ci) KS + r) KS + s]
+  const int O = CO * Cin * KS * KS;
+#pragma unroll
+  for (int k = 0; k < MAXU; k++) {
+    const int u = wid + 8 * k;
+    if (u < nunits) {
+      const int h = u % NH, cr = u / NH, r = cr % KS, ci = cr / KS;
+#pragma unroll
+      for (int s_ = 0; s_ < KS; s_++)
+#pragma unroll
+        for (int c = 0; c < COH; c++) {
+          const A v = wave_sum(acc[k][s_][c]);
+          if (lane == 0) partial[(int64_t)blockIdx.x * O + (((h * COH + c) * Cin + ci) * KS + r) * KS + s_] = v;
+        }
+    }
+  }
+}
+
+template <class T> static bool cs2_wgrad_run(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+  using A = typename CsAccOf<T>::type;
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_SMALL2_WGRAD"); return !(e && e[0] == '0'); }();
+  if (!on || !cs2_qualifies(g)) return false;
+  if (!(g.Cout == 6 || g.Cout == 16) || g.Ho < 8) return false;
+  const int KS = g.kh, ST = g.sh, PAD = KS / 2;
+  const int NH = g.Cout <= 8 ? 1 : 2;
+  const int nunits = (int)g.Cin * KS * NH;
+  const int maxu = (nunits + 7) / 8;
+  if (maxu > (g.Cout == 6 ? 3 : 5)) return false;             // register budget: MAXU x COH x KS accumulators per lane
+  const int shift = cs2_shift_of(g.H);
+  const int64_t side = g.H + 2 * PAD;
+  const size_t lds = (size_t)(g.Cin * side * side + g.Cout * g.Ho * g.Wo) * sizeof(A);
+  if (lds > 150 * 1024) return false;
+  const int O = (int)(g.Cout * g.Cin * KS * KS);
+  const int nb = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * 2);
+  const int ipb = (int)((g.N + nb - 1) / nb);
+  const int nblocks = (int)((g.N + ipb - 1) / ipb);
+  int64_t ps[1] = {(int64_t)nblocks * O};
+  Hold partial(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, dy->device()));
+  {
+    KernelTimer kt("conv_wgrad_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
+#define CS2_WG(COv, KSv, STv, MUv)                                                                                                                  \
+  do {                                                                                                                                              \
+    if (lds > 64 * 1024) allow_big_lds((const void*)cs2_wgrad_kernel<T, COv, KSv, STv, MUv>);                                                       \
+    hipLaunchKernelGGL((cs2_wgrad_kernel<T, COv, KSv, STv, MUv>), dim3(nblocks), dim3(512), lds, st, dy->ptr<T>(), x->ptr<T>(), partial->ptr<A>(),  \
+                       g.N, (int)g.Cin, shift, ipb);                                                                                                \
+  } while (0)
+#define CS2_WG_ST(COv, KSv, MUv) do { if (ST == 1) CS2_WG(COv, KSv, 1, MUv); else CS2_WG(COv, KSv, 2, MUv); } while (0)
+#define CS2_WG_MU(COv, KSv)                                                                                                                         \
+  do {                                                                                                                                              \
+    if (maxu <= 1) CS2_WG_ST(COv, KSv, 1); else if (maxu == 2) CS2_WG_ST(COv, KSv, 2); else if (maxu == 3) CS2_WG_ST(COv, KSv, 3);                  \
+    else if (COv == 16 && maxu == 4) CS2_WG_ST(COv, KSv, 4); else CS2_WG_ST(COv, KSv, 5);                                                           \
+  } while (0)
+    if (g.Cout == 6) { if (KS == 1) CS2_WG_MU(6, 1); else if (KS == 3) CS2_WG_MU(6, 3); else CS2_WG_MU(6, 5); }
+    else { if (KS == 1) CS2_WG_MU(16, 1); else if (KS == 3) CS2_WG_MU(16, 3); else CS2_WG_MU(16, 5); }
+#undef CS2_WG_MU
+#undef CS2_WG_ST
+#undef CS2_WG
+    LAMP_LAUNCH_CHECK();
+  }
+  if (std::is_same<T, float>::value) {
+    WgradReduceArgs ra{};
+    ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
+    ra.dw_f32 = 1;
+    wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+    return true;
+  }
+  hipLaunchKernelGGL((cs_wgrad_reduce_kernel<T, A>), dim3((unsigned)(((int64_t)O * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), dw->ptr<T>(), O, nblocks);
+  LAMP_LAUNCH_CHECK();
+  return true;
+}
+
 bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
   if (x->dtype == kBF16) return cs_wgrad_run<bf16_t>(dy, x, dw, g, st);
-  if (x->dtype == kF32) return cs_wgrad_run<float>(dy, x, dw, g, st);
-  if (x->dtype == kF64) return cs_wgrad_run<double>(dy, x, dw, g, st);
+  if (x->dtype == kF32) return cs2_wgrad_run<float>(dy, x, dw, g, st) || cs_wgrad_run<float>(dy, x, dw, g, st);
+  if (x->dtype == kF64) return cs2_wgrad_run<double>(dy, x, dw, g, st) || cs_wgrad_run<double>(dy, x, dw, g, st);
   return false;
 }
 

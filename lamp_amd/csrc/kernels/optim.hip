@@ -16,6 +16,7 @@ namespace lamp {
 void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   // conv_igemm.hip
 void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);  // conv_narrow.hip
 void igemm32_repack_cached(lamp_tensor* const* params, int n, hipStream_t st); // conv_igemm_f32.hip
+void small_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   // conv_small.hip
 
 constexpr int MT_MAX = 40;       // tensors per launch (the descriptor is a by-value kernel argument: 3.4 KB of the 4 KB limit; the ResNet has 37)
 constexpr int MT_CHUNK = 1024;   // elements per workgroup (4096: the ResNet's 392 k parameters made ~130 workgroups for 256 CUs - 15 us per AdamW launch)
@@ -368,6 +369,7 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
   igemm_repack_cached(params, n, st);     // the convolution weights' packed images follow the update in one launch (conv_igemm.hip)
   narrow_repack_cached(params, n, st);
   igemm32_repack_cached(params, n, st);
+  small_repack_cached(params, n, st);
   LAMP_API_END
 }
 
@@ -396,6 +398,7 @@ int lamp_sgdw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_
   igemm_repack_cached(params, n, st);
   narrow_repack_cached(params, n, st);
   igemm32_repack_cached(params, n, st);
+  small_repack_cached(params, n, st);
   LAMP_API_END
 }
 

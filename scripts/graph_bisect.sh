@@ -1,6 +1,7 @@
 #!/bin/bash
 # every case of scripts/graph_bisect.py bare and under `rocprofv3 --kernel-trace`; exit codes -> gpurun_out/graphbisect/summary.txt
 set -u
+ulimit -c 0
 R=$PWD; O=$R/gpurun_out/graphbisect; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 : > $O/summary.txt
 for c in ${CASES:-ew3 ew200 zeros sum conv_small_bf16 conv_bf16 conv_f32 conv_bwd_bf16 conv_bwd_f32 bn_bf16 bn_f32 mlp resnet_f32 resnet_bf16 resnet_bf16_b2048 resnet_bf16_b2048_opt}; do

@@ -2,6 +2,7 @@
 # the graph-replayed training step under `rocprofv3 --kernel-trace` (bench.py normally turns the graph off there: forced on
 # with LAMP_BENCH_GRAPH_UNDER_PROFILER=1), R runs per variant; exit codes and signals -> gpurun_out/graphrepro/summary.txt
 set -u
+ulimit -c 0
 R=$PWD; O=$R/gpurun_out/graphrepro; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 RUNS=${1:-8}
 variant() {   # name, then NAME=VALUE settings (exported to the program through the environment of this shell: the program itself follows `--`)

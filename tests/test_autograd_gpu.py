@@ -358,6 +358,51 @@ def test_hip_graph_replays_the_gradient_computation(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ldt,tol", [(S.F32, 1e-6), (S.F64, 1e-12), (S.BF16, 2.0 ** -7)], ids=["f32", "f64", "bf16"])
+def test_replayed_resnet_step_tracks_the_weights(gpu, ldt, tol):
+    """Cnn.resnet forward + backprop captured once and replayed while AdamW updates the weights eagerly between replays: the convolutions'
+    packed weight images (implicit-GEMM, narrow, small - found in their caches during the capture, so the graph holds no pack launch) must
+    follow every update (the optimisers' re-pack hook).  Three replayed steps == three eager steps."""
+    import ctypes as C
+    from lamp_amd._capi import lib
+    B = 8
+    lib.lamp_manual_seed(77)
+    em = nn.resnet(100, 0.0, ldt)
+    gm = nn.resnet(100, 0.0, ldt)
+    gm.load([v.value for v in em.state])
+    cw = S.STen.ones([100], ldt)
+    tdt = {S.F32: torch.float32, S.F64: torch.float64, S.BF16: torch.bfloat16}[ldt]
+    x = to_sten(O.closed_form(B * 3 * 32 * 32, 5, 1.0, torch.float32).reshape(B, 3, 32, 32).to(tdt))
+    t = to_sten((torch.arange(B) * 7) % 100)
+    emodel, gmodel = nn.SupervisedModel(em, nn.SupervisedModel.NLL, cw), nn.SupervisedModel(gm, nn.SupervisedModel.NLL, cw)
+    eopt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-2, mixedPrecision=(ldt == S.BF16))([p.value for p in em.parameters])
+    gopt = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-2, mixedPrecision=(ldt == S.BF16))([p.value for p in gm.parameters])
+    st = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(st)); lib.lamp_stream_set_current(st)
+    try:
+        # step 1 eagerly on both (fills the caches), steps 2 - 4: eager vs replayed
+        for model, opt in ((emodel, eopt), (gmodel, gopt)):
+            n, g1 = model.addTotalLossAndReturnGradientsAndNumExamples(x, t, None)
+            opt.step(g1, 1.0)
+        for _ in range(3):
+            n, ge = emodel.addTotalLossAndReturnGradientsAndNumExamples(x, t, None)
+            eopt.step(ge, 1.0)
+        lib.lamp_device_synchronize()
+        lib.lamp_graph_begin_capture()
+        n, grads = gmodel.addTotalLossAndReturnGradientsAndNumExamples(x, t, None)
+        g = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(g))
+        for _ in range(3):
+            lib.lamp_graph_launch(g)
+            gopt.step(grads, 1.0)
+        lib.lamp_device_synchronize()
+        for i, (a, b) in enumerate(zip(gm.state, em.state)):
+            assert_close(to_torch(a.value), to_torch(b.value).double(), tol, f"state {i} after three replayed steps")
+        lib.lamp_graph_release(g)
+    finally:
+        d = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(d)); lib.lamp_stream_set_current(d)
+        lib.lamp_stream_release(st); lib.lamp_stream_release(d)
+
+
+@pytest.mark.gpu
 def test_backprop_recorded_into_a_graph_does_not_poison_later_eager_passes(gpu):
     """The gradient of a one-element loss starts from a cached constant 1 (per thread, device, dtype, stream).  A capture must not
     create that constant: its fill would only be RECORDED, and an eager backprop on the same stream before the first replay would
