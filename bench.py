@@ -656,6 +656,12 @@ def main():
         lib.lamp_kernel_timer_filter(None)
         rows = kernel_report(lib)
 
+    if a.workload == "knn":
+        # which search ran: the filter's own sample decides per data set whether the f16 pass pays (kernels/knn_split.hip)
+        pl = C.c_int(0); lib.lamp_knn_split_last_planes(C.byref(pl))
+        nf = C.c_int64(0); lib.lamp_knn_split_last_failed(C.byref(nf))
+        result_extra["knn_path"] = (f"split-f16 filter ({pl.value} planes) + exact re-rank; {nf.value} of {units_per_step} queries went to the exact kernel"
+                                    if pl.value else "exact f32 kernel for every query (the filter's sample predicted too few provable queries)")
     if a.workload == "umap-e2e":
         ph = {}
         _, last_loss, n_edges = run(ph)            # untimed, instrumented pass: seconds per phase (device synchronised between phases)

@@ -12,12 +12,15 @@
 //   below the bound) and written as two f16 planes, with the squared norm of the centred row.
 // Pass 1 (knn_split_kernel): q.x ~ (q0.x0 + q1.x0 + q0.x1) / scale^2 - three f16 products per feature, 3/16 of the f32 pipe's time -
 //   with the top-k selection fused in; the 16 best candidates per query by a = (|q|^2 + |x|^2) - 2 (that sum) are kept.
-//   Error of the sum: the dropped products (q1.x1, q0.r, r.x0: <= 3.1 * 2^-22 |q||x|) plus the f32 accumulation of 12 MFMA results (each a
-//   32-term sum; <= 6 roundings each, 2^-24 relative to sum |q_i x_i|): 2.1e-6 |q||x|, bounded by c = 2^-18 = 3.8e-6 (the largest error
-//   seen on the test sets is 4e-7).  So |a - d| <= eps_q = 2 c |q_c| max|x_c| + 2^-21 (|q|^2 + max|x|^2) + 2^-20 (|q_c|^2 + max|x_c|^2): the second term is
-//   the f32 formula's own rounding (f64 searches: 2^-50), the third the f32 accumulation of the centred norms and the rounding of the centred
-//   rows to f32 before the split (_c = after the mean row was subtracted) - a far outlier opposite the mean makes max|x_c|^2 large and the
-//   slack in c alone does not cover that (tests: an f64 set with such an outlier and near-tied k-th / (k+1)-th neighbours).
+//   Error of the sum: the dropped products (q1.x1, q0.r, r.x0: <= 3.1 * 2^-22 |q||x| = 7.4e-7) plus the f32 accumulation of 12 MFMA results (each a
+//   32-term sum with <= 6 internal roundings, then 12 roundings of the running sum: 18 * 2^-24 = 1.07e-6 relative to sum |q_i x_i|): 1.8e-6 |q||x|,
+//   bounded by c = 1.1875 * 2^-19 = 2.27e-6 (the largest error seen on the test sets is 4e-7).  So |a - d| <= eps_q =
+//   2 c |q_c| max|x_c| + 2^-21 (|q|^2 + max|x|^2) + 1.5 * 2^-21 (|q_c|^2 + max|x_c|^2): the second term is the f32 formula's own rounding
+//   (f64 searches: 2^-50); the third is everything the centred norms carry (_c = after the mean row was subtracted): the rounding of the
+//   centred rows to f32 before the split (2 * 2^-24 of a squared norm), their f32 accumulation (one fma per lane + a six-level butterfly:
+//   8 roundings), the sum of the two norms and the final subtraction (1 each) - 12 * 2^-24.  Round 3 relied on slack in c (then 2^-18) for
+//   the third term; a far outlier opposite the mean makes max|x_c|^2 large and that slack did not cover it (test: an f64 set with
+//   such an outlier and near-tied k-th / (k+1)-th neighbours).  With every term explicit, c is its derived value plus 25 %.
 // Pass 2 (knn_rerank_kernel) recomputes d for the 16 candidates from the ORIGINAL f32 data (dot product accumulated in f64, rounded once,
 //   then the reference's formula in f32), sorts them by (d, index) and returns the first k.  Every point that is NOT a candidate has
 //   a >= a_16, hence d >= a_16 - eps_q: when the k-th re-ranked distance is strictly below that, the k neighbours are exactly those an
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const T* __restrict__ q
   // + the f32 arithmetic of the quantities the FILTER compared: the centred norms qn_c / dn_c are accumulated in f32 and the
   // centred rows are rounded to f32 before they are split - at most 2^-21 + 2^-22 of (|q_c|^2 + |x_c|^2), bounded by 2^-20 of it; on the f64
   // path nothing else covers these (its `noise` is 2^-50)
-  const double filter_noise = 0x1p-20 * ((double)qn_c[qi] + (double)dn_c_max[0]);
+  const double filter_noise = 0x1.8p-21 * ((double)qn_c[qi] + (double)dn_c_max[0]);
   const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[qi]) * sqrt((double)dn_c_max[0]) + noise + filter_noise;
   const bool all_points_are_candidates = N <= KS_M;
   if (part == 0 && rank == k - 1 && !all_points_are_candidates && !((double)d < a_last - eps)) {
@@ -440,7 +443,7 @@ __global__ void knn_predict_kernel(const T* __restrict__ val16, const T* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
   const double noise = (std::is_same<T, float>::value ? 0x1p-21 : 0x1p-50) * ((double)qn[i] + (double)dn_max[0]);
-  const double filter_noise = 0x1p-20 * ((double)qn_c[i] + (double)dn_c_max[0]);     // as in knn_rerank_kernel
+  const double filter_noise = 0x1.8p-21 * ((double)qn_c[i] + (double)dn_c_max[0]);     // as in knn_rerank_kernel
   const double eps = 2.0 * (double)c_dot * sqrt((double)qn_c[i]) * sqrt((double)dn_c_max[0]) + noise + filter_noise;
   const double gap = (double)val16[(int64_t)i * KS_M + KS_M - 1] - (double)val16[(int64_t)i * KS_M + k - 1];
   if (!(gap > 2.0 * eps)) atomicAdd(unproven, 1);
@@ -461,7 +464,7 @@ int64_t knn_split_last_failed() { return g_knn_split_failed; }
 int knn_split_last_planes() { return g_knn_split_planes; }
 
 namespace {
-constexpr float KS_C_DOT = 0x1p-18f;   // |filter's dot product - exact| <= KS_C_DOT |q_c| |x_c| (header comment)
+constexpr float KS_C_DOT = 0x1.3p-19f;   // 2.27e-6: |filter's dot product - exact| <= KS_C_DOT |q_c| |x_c| (header comment)
 
 // the rows of `src`, centred and scaled, as PL f16 planes (planes == nullptr: none) + the squared norms of the centred rows
 template <int DIM, int PL, class T>

@@ -713,3 +713,34 @@ def test_knn_few_queries_slice_the_data_set(gpu):
         lib.lamp_knn_split_mode(1)
     assert np.array_equal(few_i, all_i[:310]) and np.array_equal(few_d, all_d[:310])
     assert few_i[40, 0] == 40 and few_i[40, 1] == 500 and few_i[40, 2] == 69999, "equal distances: ascending index, across slices too"
+@pytest.mark.gpu
+def test_knn_default_mode_takes_the_filter_on_the_bench_points(gpu):
+    """The default mode decides by a sample whether the f16 filter pays.  On bench.py's kNN points (uniform [0, 1)^128 + 16 clusters along the
+    diagonal, |x - mean|^2 up to ~7200) it must: a too generous error bound makes the sample decline and the search falls back to the exact
+    kernel at a third of the speed (round 4: the bound's third term at 2^-20 with c = 2^-18 did exactly that, unnoticed by the parity
+    tests).  Same neighbours as the exact search."""
+    n, nq, d, k = 131072, 32768, 128, 10                      # 4.3e9 distance evaluations: above the default mode's threshold
+    rng = np.random.default_rng(0)
+    pts = rng.random((n, d), dtype=np.float32) + (np.arange(n) % 16)[:, None].astype(np.float32)
+    X = S.STen.from_numpy(pts, 0, S.F32)
+    Q = X.slice(0, 1000, 1000 + nq)
+    planes, failed = C.c_int(-1), C.c_int64(-1)
+    try:
+        lib.lamp_knn_split_mode(0)
+        e, ed = C.c_void_p(), C.c_void_p(); lib.lamp_knn_squared_euclidean(C.byref(e), C.byref(ed), X, Q, k)
+        exact, exact_d = S.STen(e).to_numpy(), S.STen(ed).to_numpy()
+        lib.lamp_knn_split_mode(1)
+        f, fd = C.c_void_p(), C.c_void_p(); lib.lamp_knn_squared_euclidean(C.byref(f), C.byref(fd), X, Q, k)
+        got, got_d = S.STen(f).to_numpy(), S.STen(fd).to_numpy()
+        lib.lamp_knn_split_last_planes(C.byref(planes)); lib.lamp_knn_split_last_failed(C.byref(failed))
+    finally:
+        lib.lamp_knn_split_mode(1)
+    assert planes.value == 2, "the default mode declined the filter on the bench's points"
+    assert failed.value < nq // 10, f"{failed.value} of {nq} queries unproven"
+    # |x|^2 reaches 3e4 here: one f32 ulp of the formula's intermediate is 2e-3, and the exact kernel (f32 fma chain) and the re-rank (f64 dot
+    # product, rounded once) round differently - rows whose k-th and (k+1)-th neighbours are closer than that may swap them
+    same = (np.sort(got, 1) == np.sort(exact, 1)).all(1)
+    assert same.mean() > 0.97, f"only {same.mean():.4f} of the rows have the exact search's neighbour set"
+    assert np.abs(got_d - exact_d).max() < 0.03
+
+
