@@ -147,8 +147,10 @@ def roofline_of(rows):
     extra["algorithmic_flops"] = flops
     traffic = traffic[0] if traffic is not None else None
     ai = flops / max(byts, 1.0)
-    if flops > 0 and ai > 150.0:      # compute bound on MI355X (2.5 PF / 8 TB/s ~ 312 FLOP/B; conv/gemm tiles sit well above)
-        peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_F64_TFLOPS if d["tag"].endswith("f64") else PEAK_BF16_TFLOPS
+    peak = PEAK_F32_TFLOPS if d["tag"].endswith("f32") else PEAK_F64_TFLOPS if d["tag"].endswith("f64") else PEAK_BF16_TFLOPS
+    # compute bound on MI355X: arithmetic intensity above (about half of) the ridge of the pipe the class runs on - bf16 2.5 PF / 8 TB/s ~ 312
+    # FLOP/B (threshold 150, conv / gemm tiles sit well above), f32 157 TF -> 20 (9.4), f64 78.6 TF -> 10 (4.7)
+    if flops > 0 and ai > 150.0 * peak / PEAK_BF16_TFLOPS:
         if d["tag"].startswith("knn_split_f16x"):
             # the f32 search on the 16-bit matrix pipe (kernels/knn_split.hip): every f32 product is 3 f16 products (two planes per value).
             # The launcher declares the ALGORITHMIC work of the search; the roofline is priced on what the f16 pipe executes (same peak as bf16).
@@ -340,8 +342,11 @@ def main():
         pix = ((np.arange(NREC * 3 * 32 * 32, dtype=np.int64) * 2654435761 + rank * 97) >> 9) % 256
         pix = pix.astype(np.uint8).reshape(NREC, 3, 32, 32)
         labels = S.STen.from_numpy(((np.arange(NREC) * 7 + rank) % 100).astype(np.int64), S.CPU)
-        host_u8 = S.STen.from_numpy(pix, S.CPU)
-        host_f32 = S.STen.from_numpy(pix.astype(np.float32), S.CPU)
+        # pinned ONCE, as a training run does (cifar100.scala --pinned): every stream over them shares these buffers.  (Measured,
+        # scripts/pinned_placement_probe.py: a pinned buffer that is freed and allocated again between variants lands on differently
+        # fragmented pages now and then and gathers at 19 - 39 GB/s instead of 44 - 53.)
+        host_u8 = S.STen.from_numpy(pix, S.CPU).pin()
+        host_f32 = S.STen.from_numpy(pix.astype(np.float32), S.CPU).pin()
         dev_x = S.STen.from_numpy(pix.astype(np.float32), local_rank, dtype)
         order = np.random.default_rng(7).permutation(NREC)
 

@@ -218,6 +218,9 @@ class STen:
         return self._u("lamp_to", self.dtype if dtype is None else dtype, self.device if device is None else device,
                        int(non_blocking), int(copy))
     def cpu(self): return self.to(device=CPU)
+    def pin(self):
+        """STen.pin (STen.scala `pin`): a copy of a host tensor in page-locked memory (what the host-resident minibatch stream gathers from)"""
+        return self._u("lamp_pin_memory")
     def copyFrom(self, src: "STen", nonBlocking=True):
         lib.lamp_copy_(self.h, src.h, int(nonBlocking))
     def zero_(self): lib.lamp_zero_(self.h)

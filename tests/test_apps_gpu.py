@@ -727,7 +727,7 @@ def test_knn_default_mode_takes_the_filter_on_the_bench_points(gpu):
     planes, failed = C.c_int(-1), C.c_int64(-1)
     try:
         lib.lamp_knn_split_mode(0)
-        e, ed = C.c_void_p(), C.c_void_p(); lib.lamp_knn_squared_euclidean(C.byref(e), C.byref(ed), X, Q, k)
+        e, ed = C.c_void_p(), C.c_void_p(); lib.lamp_knn_squared_euclidean(C.byref(e), C.byref(ed), X, Q, k + 1)
         exact, exact_d = S.STen(e).to_numpy(), S.STen(ed).to_numpy()
         lib.lamp_knn_split_mode(1)
         f, fd = C.c_void_p(), C.c_void_p(); lib.lamp_knn_squared_euclidean(C.byref(f), C.byref(fd), X, Q, k)
@@ -737,10 +737,12 @@ def test_knn_default_mode_takes_the_filter_on_the_bench_points(gpu):
         lib.lamp_knn_split_mode(1)
     assert planes.value == 2, "the default mode declined the filter on the bench's points"
     assert failed.value < nq // 10, f"{failed.value} of {nq} queries unproven"
-    # |x|^2 reaches 3e4 here: one f32 ulp of the formula's intermediate is 2e-3, and the exact kernel (f32 fma chain) and the re-rank (f64 dot
-    # product, rounded once) round differently - rows whose k-th and (k+1)-th neighbours are closer than that may swap them
-    same = (np.sort(got, 1) == np.sort(exact, 1)).all(1)
-    assert same.mean() > 0.97, f"only {same.mean():.4f} of the rows have the exact search's neighbour set"
-    assert np.abs(got_d - exact_d).max() < 0.03
+    # |x|^2 reaches 3e4 here: one f32 ulp of the formula's intermediates is 2 - 4e-3 and the exact kernel's dot product is a chain of 128 f32
+    # fmas at that magnitude (noise ~ 1e-2 in d, bounded by the 2^-21 (|q|^2 + |x|^2) = 0.03 of the proof); the re-rank rounds an f64 dot
+    # product once.  Rows whose k-th and (k+1)-th neighbours are closer than that may legitimately swap them
+    clear = (exact_d[:, k] - exact_d[:, k - 1]) > 0.1
+    assert clear.mean() > 0.15, f"only {clear.mean():.3f} of the rows are clearly separated"
+    assert np.array_equal(np.sort(got[clear], 1), np.sort(exact[clear, :k], 1)), "neighbour sets differ where the f32 formula can tell them apart"
+    assert np.abs(got_d - exact_d[:, :k]).max() < 0.06
 
 
