@@ -363,6 +363,11 @@ def main():
             t0 = time.perf_counter()
             for e in range(epochs):
                 loops.oneEpoch(e + 1, model, opt, st)
+                if os.environ.get("LAMP_EPOCH_TRACE"):
+                    barrier()
+                    r_, u_, m_, d_ = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+                    lib.lamp_allocator_stats(local_rank, C.byref(r_), C.byref(u_), C.byref(m_)); lib.lamp_allocator_deferred_frees(local_rank, C.byref(d_))
+                    sys.stderr.write(f"epoch trace {kind} B={B} epoch {e}: {time.perf_counter() - t0:.3f} s since start; reserved {r_.value >> 20} MB in use {u_.value >> 20} MB mallocs {m_.value} deferred frees {d_.value}\n")
             barrier()
             rate = NREC * epochs / (time.perf_counter() - t0)
             del st
@@ -382,7 +387,7 @@ def main():
         units_per_step = NREC
         metric, unit = "epoch instances/sec (IOLoops.oneEpoch over minibatchesFromFull)", "samples/s"
         config = {"workload": "example-cifar100 Cnn.resnet(100): one epoch of 50 000 CIFAR-shaped records through BatchStream.minibatchesFromFull "
-                              "(host-resident u8 records in pinned memory, minibatch gathered over PCIe and cast on the GPU one batch ahead on a side stream), eager training step",
+                              "(host-resident u8 records in pinned memory, minibatch gathered over PCIe and cast by a GPU kernel queued one batch ahead), eager training step",
                   "per_gpu_batch": a.batch, "records": NREC, "parallelism": "single"}
         result_extra["epoch_variants_instances_per_s"] = epoch_variants
     elif a.workload == "lm":

@@ -182,7 +182,7 @@ int lamp_batch_stream_from_full(lamp_batch_stream** out, const lamp_tensor* feat
                                 int64_t minibatch_size, int drop_last, int device);
 /* The same stream over a data set that STAYS IN HOST MEMORY, as in the reference (BatchStream.scala:539-556: host gather, pinned staging buffer,
  * copy on another stream; `pinned` of cifar100.scala): the features are pinned (copied once if they are not), and the GPU gathers a
- * minibatch's rows over PCIe on a side stream one batch ahead of the consumer (IOLoops.scala:833-874), converting to out_dtype (-1: as
+ * minibatch's rows over PCIe, queued one batch ahead of the consumer (IOLoops.scala:833-874), converting to out_dtype (-1: as
  * stored) on the way.  Batches, order and values are those of lamp_batch_stream_from_full. */
 int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor* features, const lamp_tensor* target, const int64_t* order, int64_t n,
                                      int64_t minibatch_size, int drop_last, int device, int out_dtype);

@@ -15,7 +15,7 @@
 //   * the CIFAR file is uploaded as raw bytes; label / pixel split and the cast run on the GPU.
 //   * files are read with plain reads into (optionally pinned) host memory, not mmap.
 //   * a data set that must stay in host memory (lamp_batch_stream_from_full_host) is kept pinned; the GPU gathers a minibatch's rows over
-//     PCIe itself (lamp_index_select_pinned), one batch ahead on a side stream - no host gather, no staging buffer.
+//     PCIe itself (lamp_index_select_pinned), queued one batch ahead - no host gather, no staging buffer.
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -259,7 +259,7 @@ std::vector<Ten> read_tensors(const std::string& path, int device, bool pin) {
 struct BatchStreamImpl {
   Ten features, target, order;   // target and order (i64 [n]) on `device`; features on `device`, or - host_resident - in pinned host memory
   int64_t n = 0, minibatch = 1, num_batches = 0, cursor = 0, every = 1, offset = 0;
-  // host-resident variant (lamp_batch_stream_from_full_host): the GPU gathers a minibatch's rows over PCIe on a side stream, one batch ahead
+  // host-resident variant (lamp_batch_stream_from_full_host): the GPU gathers a minibatch's rows over PCIe, queued one batch ahead (on a side stream with LAMP_HOST_STREAM_SIDE=1)
   // (the reference's prefetch: IOLoops.scala:833-874 loads batch i + 1 while batch i trains)
   bool host_resident = false;
   int device = 0, out_dtype = -1;
@@ -411,7 +411,12 @@ int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor*
   s.n = n; s.minibatch = minibatch_size; s.device = device; s.out_dtype = out_dtype; s.host_resident = true;
   s.num_batches = (n + minibatch_size - 1) / minibatch_size;
   if (drop_last && s.num_batches > 0) s.num_batches--;
-  HCALL(lamp_stream_get_from_pool(0, device, &s.side));
+  // LAMP_HOST_STREAM_SIDE=1: the gather on a side stream, ordered by events (round 4's first form).  Measured (bench.py --workload epoch):
+  // a kernel that reads host memory does not run beside the training step anyway, so the side stream bought nothing at B = 2048 (1.64 M
+  // samples/s either way), cost 12 % at B = 256 (three cross-stream waits per batch) and, for some streams of a process, put the whole
+  // epoch into a 3 x slower mode (EXPERIMENTS (17)): the default queues the gather on the consumer's stream.
+  static const bool use_side = [] { const char* e = getenv("LAMP_HOST_STREAM_SIDE"); return e && e[0] == '1'; }();
+  if (use_side) HCALL(lamp_stream_get_from_pool(0, device, &s.side));
   *out = stream.release();
   LAMP_API_END
 }
@@ -421,11 +426,18 @@ int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor*
 static void prefetch_batch(BatchStreamImpl& s, int64_t b) {
   const int64_t lo = b * s.minibatch, hi = std::min(lo + s.minibatch, s.n);
   Ten idx = ops::slice(s.order, 0, lo, hi, 1);
+  lamp_tensor *x = nullptr, *t = nullptr;
+  if (!s.side) {                                             // default: the gather is queued on the consumer's stream
+    const int rc1 = lamp_index_select_pinned(&x, s.features.h(), idx.h(), s.out_dtype);
+    const int rc2 = rc1 == 0 ? lamp_index_select(&t, s.target.h(), 0, idx.h()) : 1;
+    if (rc1 != 0 || rc2 != 0) { if (x) lamp_tensor_release(x); throw Error(lamp_last_error()); }
+    s.ahead_x = Ten(x); s.ahead_t = Ten(t); s.ahead_for = b;
+    return;
+  }
   lamp_stream* cur = nullptr;
   HCALL(lamp_stream_get_current(s.device, &cur));
   HCALL(lamp_stream_wait_stream(s.side, cur));
   HCALL(lamp_stream_set_current(s.side));
-  lamp_tensor *x = nullptr, *t = nullptr;
   const int rc1 = lamp_index_select_pinned(&x, s.features.h(), idx.h(), s.out_dtype);
   const int rc2 = rc1 == 0 ? lamp_index_select(&t, s.target.h(), 0, idx.h()) : 1;
   (void)lamp_stream_set_current(cur);
@@ -462,12 +474,14 @@ int lamp_batch_stream_next(lamp_batch_stream* st, lamp_tensor** x, lamp_tensor**
     s.ahead_x = Ten(); s.ahead_t = Ten(); s.ahead_for = -1;
     // the consumer (the caller's current stream) waits for the gather, and the blocks - allocated under the side stream - must not be
     // recycled there while the consumer still reads them
-    lamp_stream* cur = nullptr;
-    HCALL(lamp_stream_get_current(s.device, &cur));
-    HCALL(lamp_stream_wait_stream(cur, s.side));
-    HCALL(lamp_tensor_record_stream(xb.h(), cur));
-    HCALL(lamp_tensor_record_stream(tb.h(), cur));
-    HCALL(lamp_stream_release(cur));
+    if (s.side) {
+      lamp_stream* cur = nullptr;
+      HCALL(lamp_stream_get_current(s.device, &cur));
+      HCALL(lamp_stream_wait_stream(cur, s.side));
+      HCALL(lamp_tensor_record_stream(xb.h(), cur));
+      HCALL(lamp_tensor_record_stream(tb.h(), cur));
+      HCALL(lamp_stream_release(cur));
+    }
     int64_t nb = s.cursor;                                   // the next batch this stream will hand out
     while (nb < s.num_batches && nb % s.every != s.offset) nb++;
     if (nb < s.num_batches) prefetch_batch(s, nb);
