@@ -40,16 +40,36 @@ def summarize(root):
         if "GRBM_GUI_ACTIVE" in c:
             print(f"  clock_MHz_from_GRBM_GUI_ACTIVE {c['GRBM_GUI_ACTIVE'] / 8.0 / us:.0f}")
 
+def parse_blocks(path):
+    out, name = {}, None
+    for line in open(path).read().split("\n"):
+        if line and not line.startswith(" "):
+            name = line; out[name] = {}
+        elif name and line.strip():
+            parts = line.split()
+            try: out[name][parts[0]] = float(parts[-1])
+            except ValueError: pass
+    return out
+
 if sys.argv[1] == "--table":
     d = sys.argv[2]
     for f in sorted(glob.glob(os.path.join(d, "*_group1.txt"))):
         print("==", os.path.basename(f)[:-11])
-        blocks = open(f).read().split("\n")
+        g2 = parse_blocks(f.replace("_group1.txt", "_group2.txt")) if os.path.exists(f.replace("_group1.txt", "_group2.txt")) else {}
+        g1 = parse_blocks(f)
         name = None
-        for line in blocks:
+        for line in open(f).read().split("\n"):
             if line and not line.startswith(" "):
                 name = line
-            elif "avg_us" in line or "shares of wave" in line or "mfma_busy" in line or "SQ_VALU_MFMA_BUSY_CYCLES" in line or "SQ_INSTS_MFMA" in line:
+                # the matrix pipes' busy share of the kernel's elapsed cycles: MFMA-busy cycles summed over 1024 SIMDs (group 1) against
+                # GRBM_GUI_ACTIVE summed over 8 XCDs (group 2, another run of the same command)
+                if name in g2 and "GRBM_GUI_ACTIVE" in g2[name] and "SQ_VALU_MFMA_BUSY_CYCLES" in g1.get(name, {}):
+                    busy = g1[name]["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (g2[name]["GRBM_GUI_ACTIVE"] / 8.0)
+                    extra = ""
+                    if "SQ_ACTIVE_INST_LDS" in g2[name]:
+                        extra = f", lds-instruction cycles per SIMD / elapsed {g2[name]['SQ_ACTIVE_INST_LDS'] * 4.0 / 1024.0 / (g2[name]['GRBM_GUI_ACTIVE'] / 8.0):.3f}"
+                    print(f"{name[:50]:50s} mfma_pipe_busy / elapsed cycles {busy:.3f} at {g2[name].get('clock_MHz_from_GRBM_GUI_ACTIVE', 0):.0f} MHz{extra}")
+            elif "avg_us" in line or "shares of wave" in line or "SQ_VALU_MFMA_BUSY_CYCLES" in line or "SQ_INSTS_MFMA" in line:
                 print(f"{name[:50]:50s} {line.strip()}")
 else:
     summarize(sys.argv[1])
