@@ -551,7 +551,7 @@ def main():
     graph = None
     step_eager = step
     modes = None                                  # multi-rank: [(name, step function)] - every exchange mode is timed, the faster one is `value`
-    use_graph = not a.no_graph and ((a.workload == "resnet") or (a.graph and a.workload == "lm"))
+    use_graph = not a.no_graph and ((a.workload in ("resnet", "mlp")) or (a.graph and a.workload == "lm"))
     if use_graph and not os.environ.get("LAMP_BENCH_GRAPH_UNDER_PROFILER") and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)):
         # rocprofv3's kernel tracing dies with SIGSEGV inside hipGraphLaunch on this image (5 of 8 runs on one box, never without the
         # profiler; the faulting frames are the profiler's graph hooks under lamp_graph_launch): a profiled run measures the eager step,
@@ -571,7 +571,12 @@ def main():
         lib.lamp_graph_begin_capture()
         captured_n, captured_grads = model.addTotalLossAndReturnGradientsAndNumExamples(x, target, acc)
         graph = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(graph))
-        if comm is None:
+        if a.workload == "mlp":                   # config 1 is forward + backward only
+            def step():
+                lib.lamp_graph_launch(graph)
+                return units_per_step
+            config["hip_graph"] = "forward + backprop replayed from a HIP graph (--no-graph: eager step)"
+        elif comm is None:
             def step():
                 lib.lamp_graph_launch(graph)
                 opt.step(captured_grads, 1.0)

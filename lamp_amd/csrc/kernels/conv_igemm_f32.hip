@@ -106,9 +106,29 @@ extern "C" int lamp_debug_ig32_stamps(unsigned long long* out, unsigned long lon
 #define IG32_STAMP_AT(k) do { } while (0)
 #endif
 
+// Welford triple (count, mean, M2) of the 16 output values a lane holds for one output channel of its image, merged over the four lane
+// groups that share the channel: the statistics of the image's 64 pixels of that channel, from the values the batch norm will read
+// (as conv_igemm.hip's epilogue publishes them: norm.hip merges the per-image triples and skips its statistics pass)
+__device__ __forceinline__ void ig32_stats_wave(const float (&v)[16], float& n, float& mean, float& m2) {
+  const float sh = v[0];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { const float d = v[k] - sh; s1 += d; s2 += d * d; }
+  n = 16.f; mean = sh + s1 * (1.f / 16.f); m2 = s2 - s1 * s1 * (1.f / 16.f);
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float n2 = __shfl_xor(n, off, 64), mean2 = __shfl_xor(mean, off, 64), m22 = __shfl_xor(m2, off, 64);
+    const float nt = n + n2, d = mean2 - mean, f = n2 / nt;
+    mean = mean + d * f;
+    m2 = m2 + m22 + d * d * n * f;
+    n = nt;
+  }
+}
+
 template <class T, int KS, int NCT, bool SPLITPX>
 __global__ __launch_bounds__(512) void ig32_conv8_kernel(const T* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
-                                                         T* __restrict__ y, int N, int CI, int KP, int CO, const T* __restrict__ addend) {
+                                                         T* __restrict__ y, int N, int CI, int KP, int CO, const T* __restrict__ addend,
+                                                         float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using TR = IgT<T>;
   using acc_v = typename TR::acc;
@@ -262,12 +282,19 @@ __global__ __launch_bounds__(512) void ig32_conv8_kernel(const T* __restrict__ x
 #pragma unroll
             for (int jt = 0; jt < PT; jt++) av[jt] = *reinterpret_cast<const f4v*>(ap + co * 64 + (jt0 + jt) * 16 + q * 4);
           }
+          float vals[16];
 #pragma unroll
           for (int jt = 0; jt < PT; jt++) {
             const int off = co * 64 + (jt0 + jt) * 16 + q * 4;
             f4v v = acc[i][jt] + f4v{bv[i], bv[i], bv[i], bv[i]};
             if (ap) v += av[jt];
             *reinterpret_cast<f4v*>(yp + off) = v;
+            if (!SPLITPX) { vals[4 * jt + 0] = v[0]; vals[4 * jt + 1] = v[1]; vals[4 * jt + 2] = v[2]; vals[4 * jt + 3] = v[3]; }
+          }
+          if (!SPLITPX && stats) {                // one partial per image and channel, [channel][image][3]
+            float wn, wm, w2;
+            ig32_stats_wave(vals, wn, wm, w2);
+            if (q == 0) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = wn; sp[1] = wm; sp[2] = w2; }
           }
         } else {
 #pragma unroll
@@ -559,6 +586,16 @@ static void run_conv8_t(const Tensor* in, const Tensor* w, const Tensor* bias, T
   constexpr int NI = IgT<T>::NI;
   const int blocks = (int)((g.N + NI - 1) / NI);
   const size_t lds = 16 * sizeof(T) + (size_t)NI * (KP / 4) * ig_pstr<T>();
+  // fprop in f32: per-image batch-norm statistics of the output from the epilogue, handed to the batch norm that follows (LAMP_CONV_BN_STATS=0: off)
+  static const bool bn_stats = [] { const char* e = getenv("LAMP_CONV_BN_STATS"); return !(e && e[0] == '0'); }();
+  Hold statt;
+  float* statp = nullptr;
+  if (std::is_same<T, float>::value && bn_stats && !dgrad && g.N >= 2 && nct > 1) {
+    int64_t ps[1] = {(int64_t)g.N * CO * 3};
+    statt = Hold(new_tensor(ps, 1, kF32, in->device()));
+    statp = statt->ptr<float>();
+  }
+  struct Publish { Hold& t; const Tensor* y; int P; ~Publish() { if (t.get()) conv_stats_publish(y, t.get(), P); } } publish{statt, out, (int)g.N};
   KernelTimer kt(std::is_same<T, float>::value ? "conv_igemm_fprop_dgrad_f32" : "conv_igemm_fprop_dgrad_f64", conv_flops(g), conv_bytes(g, sizeof(T)), st);
   const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
   const T* ap = addend ? addend->ptr<T>() : (const T*)nullptr;
@@ -566,7 +603,7 @@ static void run_conv8_t(const Tensor* in, const Tensor* w, const Tensor* bias, T
   do {                                                                                                                               \
     allow_big_lds((const void*)ig32_conv8_kernel<T, KS_, NCT_, SP_>);                                                                \
     hipLaunchKernelGGL((ig32_conv8_kernel<T, KS_, NCT_, SP_>), dim3(blocks), dim3(512), lds, st, in->ptr<T>(), wpp, bp,              \
-                       out->ptr<T>(), (int)g.N, CI, KP, CO, ap);                                                                     \
+                       out->ptr<T>(), (int)g.N, CI, KP, CO, ap, statp);                                                              \
   } while (0)
 #define IG32_BY_NCT(KS_)                                                                                                             \
   do {                                                                                                                               \

@@ -761,6 +761,27 @@ def test_igemm_f32_kernels(gpu, case, dt):
     assert_close(got_add, refb[0] + add.double(), btol, sfx + " igemm dgrad + addend")
     # the fused addend is the unfused sum bit for bit: both are fl(fl(dgrad) + addend)
     assert torch.equal(got_add.to(dt), to_torch(dx).to(dt) + add)
+    if dt == torch.float32 and N >= 2 and Cout > 16:
+        # the statistics hand-off: a training-mode batch norm directly on the f32 convolution's output merges the epilogue's per-image
+        # Welford triples instead of running its statistics pass - and gets ATen's statistics
+        o2 = C.c_void_p()
+        lib.lamp_convolution(C.byref(o2), to_sten(x), to_sten(w), to_sten(b), i64_array([1, 1]), i64_array([p, p]), i64_array([1, 1]), 2, 0,
+                             i64_array([0, 0]), 1)
+        Y = S.STen(o2)
+        gam, bet = closed_form((Cout,), 7, 1.0, dt) + 1.0, closed_form((Cout,), 9, 1.0, dt)
+        _timer_classes()
+        lib.lamp_kernel_timer_enable(1)
+        out3 = _out3()
+        lib.lamp_native_batch_norm(out3, Y, to_sten(gam), to_sten(bet), to_sten(torch.zeros(Cout, dtype=dt)), to_sten(torch.ones(Cout, dtype=dt)), 1, 0.1, 1e-5)
+        yn, mean, invstd = _wrap3(out3)
+        got_yn = to_torch(yn)
+        lib.lamp_kernel_timer_enable(0)
+        ran = _timer_classes()
+        assert "bn_fwd_stats" not in ran, f"the batch norm ran its own statistics pass: {ran}"
+        rn = aten.native_batch_norm(to_torch(Y).double(), gam.double(), bet.double(), torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64), True, 0.1, 1e-5)
+        assert_close(to_torch(mean), rn[1], 1e-5, "save_mean from the f32 epilogue's partials")
+        assert_close(to_torch(invstd), rn[2], 1e-5, "save_invstd from the f32 epilogue's partials")
+        assert_close(got_yn, rn[0], 1e-5, "batch norm on the hand-off statistics")
 
 
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
