@@ -106,6 +106,7 @@ struct Storage {
   void* pool = nullptr;     // allocator block cookie
   void* map_base = nullptr; // host storage that is a window of an mmap'ed file (Tensor.from_file): base and length of the mapping,
   size_t map_len = 0;       // shared by every tensor cut from it (they share this Storage); munmap'ed with the last handle
+  size_t pinned_capacity = 0;   // pinned host storage: the size of the page-locked block behind it (blocks are recycled, tensor.hip)
   std::atomic<int> refs{1};
   // Bumped whenever a MUTABLE pointer into the storage is handed out (data() / ptr<T>() on a non-const handle): every kernel
   // that writes a tensor has to go through one of those, so "version unchanged" proves "contents unchanged" - the packed-weight

@@ -3,6 +3,9 @@
 // Replaces the `aten.Tensor` instance surface lamp-sten drives (reference:
 // lamp-sten/src/main/scala/lamp/STen.scala:845-1000, TensorHelpers.scala:44-345,
 // device.scala:62-114,221-225).
+#include <map>
+#include <mutex>
+#include <algorithm>
 #include "tensor.h"
 #include <cerrno>
 #include <cstring>
@@ -45,6 +48,49 @@ static inline void untrack(const Tensor* t) {
   }
 }
 
+// Page-locked host blocks are recycled instead of returned to the driver: a hipHostFree / hipHostMalloc cycle costs ~0.2 ms per MB and,
+// measured, hands back pages that the GPU then reads at anything between 19 and 53 GB/s (EXPERIMENTS (17)).  A freed block waits in a small
+// cache (LAMP_PINNED_CACHE_MB, default 2048; 0: off); it is handed out again for a request it fits with at most 25 % of slack, after a device
+// synchronise - asynchronous copies that still read the old contents (lamp_to / copy_ with non_blocking from a pinned source) finish first,
+// which is what hipHostFree's implicit synchronisation guaranteed before.
+namespace {
+struct PinnedCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> blocks;      // capacity -> pointer
+  size_t cached = 0;
+  size_t limit = [] { const char* e = getenv("LAMP_PINNED_CACHE_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 2048) << 20; }();
+};
+PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return *c; }      // never destroyed: storages may outlive static destructors
+}  // namespace
+static void* pinned_alloc(size_t bytes, size_t* capacity) {
+  PinnedCache& c = pinned_cache();
+  const size_t want = bytes ? bytes : 1;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.blocks.lower_bound(want);
+    if (it != c.blocks.end() && it->first <= want + want / 4) {
+      void* p = it->second;
+      *capacity = it->first;
+      c.cached -= it->first;
+      c.blocks.erase(it);
+      (void)hipDeviceSynchronize();
+      return p;
+    }
+  }
+  void* p = nullptr;
+  HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+  *capacity = want;
+  return p;
+}
+static void pinned_free(void* p, size_t capacity) {
+  PinnedCache& c = pinned_cache();
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (capacity >= (1u << 16) && c.cached + capacity <= c.limit) { c.blocks.emplace(capacity, p); c.cached += capacity; return; }
+  }
+  (void)hipHostFree(p);
+}
+
 static Storage* new_storage(size_t bytes, int device, bool pinned = false) {
   Storage* s = new Storage();
   s->bytes = bytes;
@@ -53,7 +99,7 @@ static Storage* new_storage(size_t bytes, int device, bool pinned = false) {
   if (device >= 0) {
     s->ptr = device_alloc(device, bytes, &s->pool);
   } else if (pinned) {
-    HIP_CHECK(hipHostMalloc(&s->ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    s->ptr = pinned_alloc(bytes, &s->pinned_capacity);
   } else {
     s->ptr = malloc(bytes ? bytes : 1);
     LAMP_CHECK(s->ptr, "host malloc of " << bytes << " bytes failed");
@@ -67,7 +113,7 @@ static void storage_unref(Storage* s) {
       (void)munmap(s->map_base, s->map_len);
     } else if (s->owned) {
       if (s->device >= 0) device_free(s->device, s->ptr, s->pool);
-      else if (s->pinned) (void)hipHostFree(s->ptr);
+      else if (s->pinned) pinned_free(s->ptr, s->pinned_capacity);
       else free(s->ptr);
     }
     delete s;

@@ -198,14 +198,17 @@ def test_aliasing_host_views_alias_on_the_gpu_too(gpu):
     for a, b in zip(host, gpu_):
         assert np.array_equal(a, b)
     assert not np.array_equal(host[3], rs_np), "the running statistics were written back into the shared host buffer"
-    # the same view through two different handles: one device copy, one write-back
-    g = S.STen.from_numpy(np.full((3, 2), 2.0), S.CPU, S.F64)
-    g2 = g.view(3, 2)
-    lib.lamp_gradient_clipping_(_handles([g, g2]), 2, 1.0)
-    gd = S.STen.from_numpy(np.full((3, 2), 2.0), 0, S.F64)
-    gd2 = gd.view(3, 2)
-    lib.lamp_gradient_clipping_(_handles([gd, gd2]), 2, 1.0)
-    assert np.array_equal(g.to_numpy(), gd.to_numpy()) and np.array_equal(g2.to_numpy(), gd.to_numpy())
+    # the same view through two different handles: one device copy serves both arguments.  (Until the end of round 4 this part clipped the
+    # gradients [g, g2] in place - two handles on the SAME memory written by one multi-tensor launch: which block scales an element first is
+    # a race on the GPU too, and the comparison failed once in ~20 runs.  Read-only aliases have one answer.)
+    g_np = rng.standard_normal((3, 2))
+    def mse(dev):
+        g = S.STen.from_numpy(g_np, dev, S.F64)
+        g2 = g.view(3, 2)
+        o = C.c_void_p()
+        lib.lamp_mse_loss(C.byref(o), g.h, g2.h, 1)
+        return S.STen(o).to_numpy()
+    assert np.array_equal(mse(S.CPU), mse(0)) and float(mse(S.CPU)) == 0.0
 
 
 @pytest.mark.gpu
