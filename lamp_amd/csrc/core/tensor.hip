@@ -65,7 +65,7 @@ PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return 
 static void* pinned_alloc(size_t bytes, size_t* capacity) {
   PinnedCache& c = pinned_cache();
   const size_t want = bytes ? bytes : 1;
-  {
+  if (!allocator_capturing()) {                               // (a device synchronise would break a stream capture: allocate fresh there)
     std::lock_guard<std::mutex> lk(c.mu);
     auto it = c.blocks.lower_bound(want);
     if (it != c.blocks.end() && it->first <= want + want / 4) {
