@@ -7,6 +7,7 @@
 #include "lamp_hip.h"
 
 #include <algorithm>
+#include <tuple>
 #include <vector>
 
 namespace lamp {
@@ -118,6 +119,69 @@ class Stager {
   std::vector<Block> blocks_;
   std::vector<View> views_;
 };
+
+// ---- one template for every staged entry point ------------------------------------------------------------------------------------
+// scripts/gen_host_staging.py writes ONE line per C-ABI function: `return staging::call(<name>__dev, role{arg}...)`, the role saying what
+// the header's parameter convention means (round 4; until then the generator spelled these ~18 lines out per function: 3.9 k lines).
+struct Out { lamp_tensor** p; };                                  // lamp_tensor** name: one output handle (NULL: not wanted)
+template <int K> struct OutK { lamp_tensor** p; };               // lamp_tensor* name[K]: K output handles
+struct In { const lamp_tensor* t; };                              // const lamp_tensor* name: read (NULL allowed)
+struct InOut { lamp_tensor* t; };                                 // lamp_tensor* name: written in place
+struct Arr { lamp_tensor* const* a; int n; bool read_only; };     // lamp_tensor* const* name + n (a NULL array is passed through)
+
+// first attempt: the caller's own arguments
+template <class T> inline T raw(T v) { return v; }
+inline lamp_tensor** raw(Out o) { return o.p; }
+template <int K> inline lamp_tensor** raw(OutK<K> o) { return o.p; }
+inline const lamp_tensor* raw(In i) { return i.t; }
+inline lamp_tensor* raw(InOut i) { return i.t; }
+inline lamp_tensor* const* raw(Arr a) { return a.a; }
+
+template <class T> inline void see(Stager&, const T&) {}
+inline void see(Stager& s, In i) { s.see(i.t); }
+inline void see(Stager& s, InOut i) { s.see(i.t); }
+inline void see(Stager& s, Arr a) { if (a.a) for (int i = 0; i < a.n; i++) s.see(a.a[i]); }
+
+// second attempt: what each argument becomes on the GPU, and what happens to it afterwards
+template <class T> struct Held { T v; Held(Stager&, T x) : v(x) {} T arg() { return v; } void done(Stager&) {} };
+template <> struct Held<Out> {
+  lamp_tensor** p; lamp_tensor* d = nullptr;
+  Held(Stager&, Out o) : p(o.p) {}
+  lamp_tensor** arg() { return p ? &d : nullptr; }
+  void done(Stager& s) { if (p) *p = s.out(d); }
+};
+template <int K> struct Held<OutK<K>> {
+  lamp_tensor** p; lamp_tensor* d[K] = {};
+  Held(Stager&, OutK<K> o) : p(o.p) {}
+  lamp_tensor** arg() { return d; }
+  void done(Stager& s) { for (int i = 0; i < K; i++) p[i] = s.out(d[i]); }
+};
+template <> struct Held<In> { const lamp_tensor* d; Held(Stager& s, In i) : d(s.in(i.t)) {} const lamp_tensor* arg() { return d; } void done(Stager&) {} };
+template <> struct Held<InOut> { lamp_tensor* d; Held(Stager& s, InOut i) : d(s.inout(i.t)) {} lamp_tensor* arg() { return d; } void done(Stager&) {} };
+template <> struct Held<Arr> {
+  std::vector<lamp_tensor*> d; bool null;
+  Held(Stager& s, Arr a) : d(a.a && a.n > 0 ? a.n : 0), null(!a.a) {
+    if (a.a) for (int i = 0; i < a.n; i++) d[i] = a.read_only ? const_cast<lamp_tensor*>(s.in(a.a[i])) : s.inout(a.a[i]);
+  }
+  lamp_tensor* const* arg() { return null ? nullptr : d.data(); }
+  void done(Stager&) {}
+};
+
+// rc = fn(args); host tensors everywhere?  stage -> fn on the copies -> outputs and in-place results back to the host
+template <class Fn, class... A>
+int call(Fn fn, A... a) {
+  const int rc = fn(raw(a)...);
+  if (rc != LAMP_STATUS_HOST_TENSOR) return rc;
+  LAMP_API_BEGIN
+  Stager s;
+  (see(s, a), ...);
+  if (!s.all_host()) return rc;          // mixed devices (or nothing to stage): the kernel's own message stands
+  std::tuple<Held<A>...> h{Held<A>(s, a)...};                     // (braced: built left to right, the order of the parameters)
+  s.ran(std::apply([&](auto&... x) { return fn(x.arg()...); }, h));
+  std::apply([&](auto&... x) { (x.done(s), ...); }, h);
+  s.finish();
+  LAMP_API_END
+}
 
 }  // namespace staging
 }  // namespace lamp
