@@ -156,10 +156,6 @@ EXPLICIT = {
     "Tensor.tensors_from_file": ("String path, long offset, long length, boolean pin, byte[] scalarTypes, long[] tensorOffsets, long[] tensorLengths", "Tensor[]",
                                  "long[] types = new long[scalarTypes.length];\n    for (int i = 0; i < types.length; i++) types[i] = scalarTypes[i];\n"
                                  "    return owningAll(N.lamp_tensors_from_file(path, offset, length, pin, types, tensorOffsets, tensorLengths));"),
-    "NcclComm.comm_init_rank": ("int nranks, byte[] uniqueId, int rank", "long", "return N.lamp_comm_init_rank(nranks, uniqueId, rank);"),
-    "NcclComm.broadcast": ("Tensor[] tensors, long[] comms", "void", "N.lamp_comm_broadcast(Tensor.handlesOf(tensors), comms, 0);"),
-    "TensorTrace.disable": ("", "void", "N.lamp_tensor_trace_enable(0);"),
-    "TensorTrace.enable": ("", "void", "N.lamp_tensor_trace_enable(1);"),
     # --- same arity as the native, different meaning of an argument (found by comparing literal kinds at the call sites) ---
     "ATen._cast_Char": ("Tensor self, boolean nonBlocking", "Tensor", "return own(N.lamp_cast(h(self), 1));"),
     "ATen._cast_Short": ("Tensor self, boolean nonBlocking", "Tensor", "return own(N.lamp_cast(h(self), 2));"),
@@ -211,6 +207,9 @@ def split_args(s):
 DECL_RE = re.compile(r"\b([a-z][A-Za-z0-9_]*)\s*:\s*(Boolean|Int|Long|Short|Byte|Double|Float|String|Option\[[A-Za-z\[\]]+\]|(?:Seq|List|Array|Vector)\[[A-Za-z\[\]]+\]|STen|Tensor|Variable)")
 
 
+DECL_RUNTIME_RE = re.compile(r"\b([a-z][A-Za-z0-9_]*)\s*:\s*(?:aten\.)?(STenOptions|TensorOptions|CudaStream|NcclComm)\b")
+
+
 def strip_comments(src):
     """comments blanked out (newlines kept, so line numbers stay): commented-out calls are not call sites"""
     out, i, n = [], 0, len(src)
@@ -248,6 +247,158 @@ def declared_types(src):
     return {k: next(iter(v)) for k, v in seen.items() if len(v) == 1}
 
 
+class Scopes:
+    """Lexical scoping of a (comment-stripped) Scala source, as far as braces and parameter lists state it: which declaration `name: Type` a
+    use of `name` at a given position refers to.  A declaration is visible at a position when the innermost `{ }` block around the declaration
+    also contains the position; a declaration inside the parameter list of a `class` / `def` header belongs to the block (or, for a def
+    without braces, the expression) that follows the header.  The NEAREST visible declaration wins - ops.scala declares `weight` as
+    `Variable`, `Option[Variable]` and `STen` in neighbouring case classes, so file-wide types say nothing there."""
+
+    def __init__(self, src):
+        self.src = src
+        n = len(src)
+        self.block_of = [0] * (n + 1)            # position -> id of the innermost block (0 = file)
+        self.blocks = [(0, n, 0)]                # id -> (start, end, parent)
+        self.paren_open = [-1] * (n + 1)         # position -> start of the outermost open '(' / '[' inside the innermost block, or -1
+        stack, parens, i = [0], [[]], 0
+        while i < n:
+            c = src[i]
+            if c == '"':                         # string literals: no structure inside
+                if src.startswith('"""', i):
+                    j = src.find('"""', i + 3); j = n if j < 0 else j + 3
+                else:
+                    j = i + 1
+                    while j < n and src[j] != '"' and src[j] != "\n":
+                        j += 2 if src[j] == "\\" else 1
+                    j = min(j + 1, n)
+                for k in range(i, j):
+                    self.block_of[k] = stack[-1]; self.paren_open[k] = parens[-1][0] if parens[-1] else -1
+                i = j
+                continue
+            if c == "{":
+                self.blocks.append((i, n, stack[-1])); stack.append(len(self.blocks) - 1); parens.append([])
+            self.block_of[i] = stack[-1]
+            self.paren_open[i] = parens[-1][0] if parens[-1] else -1
+            if c in "([":
+                parens[-1].append(i)
+            elif c in ")]" and parens[-1]:
+                parens[-1].pop()
+            elif c == "}" and len(stack) > 1:
+                b = stack.pop(); parens.pop()
+                self.blocks[b] = (self.blocks[b][0], i, self.blocks[b][2])
+            i += 1
+        self.block_of[n] = 0
+        self.decls = {}
+        for m in DECL_RE.finditer(src):
+            self.decls.setdefault(m.group(1), []).append((m.start(), m.group(2)))
+        for m in DECL_RUNTIME_RE.finditer(src):
+            self.decls.setdefault(m.group(1), []).append((m.start(), m.group(2)))
+        # locals bound to a native's result have no written type: `val x = ATen.f(...)` is a Tensor, `val (a, b) = ATen.g(...)` are Tensors,
+        # `val s = CudaStream.get...(...)` a CudaStream, `val c = NcclComm.comm_init_rank(...)` a NcclComm
+        for m in re.finditer(r"\bval\s+([a-z][A-Za-z0-9_]*)\s*=\s*(?:aten\.)?(?:ATen|Tensor)\s*\.\s*[A-Za-z_0-9]+\s*\(", src):
+            self.decls.setdefault(m.group(1), []).append((m.start(1), "Tensor"))
+        for m in re.finditer(r"\bval\s*\(([^()=]*)\)\s*=\s*(?:aten\.)?ATen\s*\.", src):
+            for nm in split_args(m.group(1)):
+                if re.fullmatch(r"[a-z][A-Za-z0-9_]*", nm):
+                    self.decls.setdefault(nm, []).append((m.start(1), "Tensor"))
+        for m in re.finditer(r"\bval\s+([a-z][A-Za-z0-9_]*)\s*=\s*(?:aten\.)?CudaStream\s*\.\s*get", src):
+            self.decls.setdefault(m.group(1), []).append((m.start(1), "CudaStream"))
+        for m in re.finditer(r"\bval\s+([a-z][A-Za-z0-9_]*)\s*=\s*(?:aten\.)?NcclComm\s*\.\s*comm_init", src):
+            self.decls.setdefault(m.group(1), []).append((m.start(1), "NcclComm"))
+        for k in self.decls:
+            self.decls[k].sort()
+
+    def contains(self, block, pos):
+        s, e, _ = self.blocks[block]
+        return block == 0 or s < pos <= e
+
+    def header_scope(self, p):
+        """(start, end) of what a parameter declared at p (inside a header's parameter list) is visible in"""
+        src, n = self.src, len(self.src)
+        i, depth = self.paren_open[p], 0
+        while i < n:                              # the end of this parameter list, and of the ones that follow it directly
+            depth += src[i] in "(["; depth -= src[i] in ")]"
+            i += 1
+            if depth == 0:
+                j = i
+                while j < n and src[j] in " \n\t":
+                    j += 1
+                if j < n and src[j] == "(":
+                    i = j; continue
+                break
+        # up to the body: `extends X(...)`, `: Type`, `=`; a `{` opens the body block, otherwise the expression runs to the next def / class / blank line
+        m = re.compile(r"\{|=(?![=>])|\bdef\s|\bclass\s|\bobject\s|\n\s*\n").search(src, i)
+        if m and m.group(0) == "=":                # a def's body: a block, or an expression that ends with the line its brackets close on
+            j = m.end()
+            while j < n and src[j] in " \n\t":
+                j += 1
+            if j < n and src[j] == "{":
+                m = re.compile(r"\{").search(src, j)
+            else:
+                depth, k = 0, j
+                while k < n:
+                    depth += src[k] in "([{"; depth -= src[k] in ")]}"
+                    if depth < 0:
+                        break
+                    if src[k] == "\n" and depth == 0 and not re.match(r"\s*\.", src[k + 1:k + 40]):
+                        break
+                    k += 1
+                return i, k
+        if m and m.group(0) == "{":
+            b = self.block_of[m.start()]
+            return self.blocks[b][0], self.blocks[b][1]
+        return i, (m.start() if m else n)
+
+    def type_of(self, name, pos):
+        best = None
+        for p, t in self.decls.get(name, ()):
+            if p >= pos:
+                break
+            if self.paren_open[p] >= 0 and re.search(r"\b(class|def)\s+[^\s(\[=:{]+\s*(\[[^\]]*\])?\s*$", self.src[max(0, self.paren_open[p] - 120):self.paren_open[p]]):
+                s, e = self.header_scope(p)
+                ok = s < pos <= e
+            else:
+                ok = self.contains(self.block_of[p], pos)
+            if ok:
+                best = t
+        return best
+
+
+class SiteTypes:
+    """the `types` argument of arg_kind for one call site: scoped declarations first, then what the file declares with one type only"""
+
+    def __init__(self, scopes, pos, file_types):
+        self.scopes, self.pos, self.file_types = scopes, pos, file_types
+
+    def get(self, name, default=None):
+        t = self.scopes.type_of(name, self.pos)
+        return t if t is not None else self.file_types.get(name, default)
+
+    def __contains__(self, name):
+        return self.get(name) is not None
+
+    def __getitem__(self, name):
+        return self.get(name)
+
+
+def block_value_tuple(src, scopes, call_start):
+    """`val (a, b, c) = { ...; val r = ATen.x(...); ...; r }` (STen.scala:559-581): the native's result is bound to a name that is the VALUE of a
+    block, and the block is destructured - the arity of that pattern, or 0"""
+    m = re.search(r"\bval\s+([A-Za-z_][A-Za-z0-9_]*)\s*(?::[^=]+)?=\s*$", src[max(0, call_start - 120):call_start])
+    if not m:
+        return 0
+    b = scopes.block_of[call_start]
+    if b == 0:
+        return 0
+    s, e, _ = scopes.blocks[b]
+    last = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", src[s + 1:e])
+    if not last or last.group(1) != m.group(1):
+        return 0
+    tm = re.search(r"val\s*\(([^()=]*)\)\s*=\s*$", src[max(0, s - 200):s])
+    k = len(split_args(tm.group(1))) if tm else 0
+    return k if k >= 2 else 0
+
+
 def type_kind(t):
     if t == "Boolean":
         return "bool"
@@ -257,9 +408,13 @@ def type_kind(t):
         return "double"
     if t == "String":
         return "string"
+    if t in ("STen", "Tensor", "Variable"):
+        return "tensor"
     if t.startswith("Option["):
         inner = t[7:-1]
         return "option:" + {"STen": "tensor", "Tensor": "tensor", "Variable": "tensor"}.get(inner, type_kind(inner) if inner in ("Boolean", "Int", "Long", "Double", "Float", "String") else "expr")
+    if re.match(r"Array\[Int\]", t):
+        return "ints"
     if re.match(r"(Seq|List|Array|Vector)\[(Int|Long)\]", t):
         return "longs"
     if re.match(r"(Seq|List|Array|Vector)\[(STen|Tensor|Variable)\]", t):
@@ -283,6 +438,18 @@ def arg_kind(a, types=None):
     m = re.fullmatch(r"(?:Option|Some)\((.*)\)", a)
     if m:
         return "option:" + arg_kind(m.group(1), types).split(":")[-1]
+    om = re.match(r"([A-Za-z_][A-Za-z0-9_]*)\.map\(", a)
+    if om:                                                   # the balanced end of `.map( ... )`, then nothing or `.getOrElse( ... )`
+        i, depth = om.end(), 1
+        while i < len(a) and depth:
+            depth += a[i] in "([{"; depth -= a[i] in ")]}"; i += 1
+        rest = a[i:]
+        om = (om.group(1), a[om.end():i - 1], rest) if depth == 0 and (rest == "" or re.fullmatch(r"\.getOrElse\(.*\)", rest)) else None
+    if om and str(types.get(om[0], "")).startswith("Option["):
+        inner = type_kind(types.get(om[0]))                  # option:tensor for Option[STen | Tensor | Variable]
+        if inner == "option:tensor" and not re.search(r"_(\.value)+\s*$|=>.*\.value\s*$", om[1]):
+            inner = "option:expr"                            # mapped to something that is not the wrapped aten.Tensor
+        return inner.split(":")[-1] if om[2] else inner
     if re.search(r"\.map\(\s*_\.value\s*\)$", a) and not re.search(r"\.toArray", a):
         base = re.sub(r"\.map\(\s*_\.value\s*\)$", "", a)
         t = types.get(base.split(".")[-1], "")
@@ -293,6 +460,11 @@ def arg_kind(a, types=None):
         return "tensors"
     if re.fullmatch(r"Array\((\s*(true|false)\s*,?)+\)", a):
         return "bools"
+    am = re.fullmatch(r"Array\((.*)\)", a)
+    if am:
+        ek = {arg_kind(x, types) for x in split_args(am.group(1))}
+        if "tensor" in ek and ek <= {"tensor", "expr"}:
+            return "tensors"
     if re.search(r"Array\(|Array\.|map\(_\.toLong\)", a):
         return "longs"
     if re.search(r"\.toArray", a):
@@ -327,7 +499,7 @@ def collect():
             src = strip_comments(open(f).read())
             rel = os.path.relpath(f, ref)
             file_types = declared_types(src)
-            defs = [(d.start(), d.end()) for d in re.finditer(r"\bdef\s+[^\s(\[=:]+", src)]
+            scopes = Scopes(src)
             for m in re.finditer(r"\b(ATen|Tensor|CudaStream|NcclComm|TensorTrace)\s*\.\s*([A-Za-z_][A-Za-z_0-9]*)\s*\(", src):
                 cls, name = m.group(1), m.group(2)
                 i, depth = m.end(), 1
@@ -344,14 +516,7 @@ def collect():
                 args = split_args(src[m.end():i - 1])
                 # identifiers are typed by the parameter list of the enclosing def first (STen.scala declares `other` as STen, Double and Long in
                 # neighbouring overloads), then by what the file declares unambiguously
-                types = dict(file_types)
-                enclosing = [d for d in defs if d[0] < m.start()]
-                if enclosing:
-                    head = src[enclosing[-1][1]:m.start()]
-                    cut = re.search(r"\)\s*(:\s*[A-Za-z\[\], ().]+)?\s*=\s", head)
-                    sig_text = head[:cut.start() + 1] if cut else head[:400]
-                    for dm in DECL_RE.finditer(sig_text):
-                        types[dm.group(1)] = dm.group(2)
+                types = SiteTypes(scopes, m.start(), file_types)
                 line = src.count("\n", 0, m.start()) + 1
                 e = sites[cls].setdefault(name, {"calls": []})
                 # `val (a, b, c) = ATen.x(...)`: the call's result is destructured as a tuple of that many members
@@ -359,6 +524,7 @@ def collect():
                 tm = re.search(r"val\s*\(([^()=]*)\)\s*=\s*(?:[A-Za-z_.]*\(\s*)?$", before)
                 tup = len(split_args(tm.group(1))) if tm else 0
                 tup = tup if tup >= 2 else 0                       # `val (x) = ...` is no tuple
+                tup = tup or block_value_tuple(src, scopes, m.start())
                 e["calls"].append({"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a, types) for a in args], "tuple": tup})
     out = {"_source": {"dirs": G.REF_DIRS, "note": "call sites of the aten package in lamp's hot-path modules: argument counts, argument kinds (literals, Option / Some / None, arrays, tensors, booleans, identifiers by their declared type) and the arity of a destructured result - no source text "
                                                    "(scripts/gen_aten_forwarders.py collect, build container)"}}
@@ -366,6 +532,83 @@ def collect():
         out[c] = {n: sites[c][n] for n in sorted(sites[c])}
     json.dump(out, open(CALLSITES, "w"), indent=1)
     print({c: len(out[c]) for c in CLASSES}, sum(len(v["calls"]) for c in CLASSES for v in out[c].values()), "call sites")
+
+
+INSTANCE_SITES = os.path.join(ROOT, "tests", "golden", "aten_instance_sites.json")
+VALUE_STEP = {"Variable": "STen", "STen": "Tensor", "STenOptions": "TensorOptions"}       # what `.value` of each wrapper is
+NOT_ATEN_MEMBERS = {"owned", "toLongArray", "toDoubleArray", "toFloatArray", "toMat", "toVec", "shape", "location", "getShape", "getCpu", "getScalarType",
+                    "getStackTrace", "getBirth", "getValue"}                          # lamp's own extension methods / TensorTraceData's getters
+
+
+def collect_instances():
+    """what lamp calls on INSTANCES of aten.{Tensor, TensorOptions, CudaStream, NcclComm}: receiver chains `x`, `x.value`, `x.value.value` whose
+    root the scoped declarations type as Variable / STen / Tensor / STenOptions / TensorOptions / CudaStream / NcclComm -> method, arity, kinds"""
+    ref = "/root/reference"
+    res = {}
+    for d in G.REF_DIRS:
+        for f in sorted(glob.glob(os.path.join(ref, d, "**", "*.scala"), recursive=True)):
+            src = strip_comments(open(f).read())
+            rel = os.path.relpath(f, ref)
+            sc = Scopes(src)
+            for m in re.finditer(r"(?<![A-Za-z0-9_.])([a-z][A-Za-z0-9_]*)((?:\s*\.\s*value)*)\s*\.\s*([A-Za-z_][A-Za-z0-9_]*)\b([ \t]*\()?", src):
+                root, chain, meth, paren = m.group(1), m.group(2), m.group(3), m.group(4)
+                if meth == "value" or meth in NOT_ATEN_MEMBERS:
+                    continue
+                t = sc.type_of(root, m.start())
+                if t is None or t.startswith("Option["):
+                    continue
+                for _ in range(len(re.findall("value", chain))):
+                    t = VALUE_STEP.get(t)
+                    if t is None:
+                        break
+                if t not in ("Tensor", "TensorOptions", "CudaStream", "NcclComm"):
+                    continue
+                args = []
+                if paren:
+                    i, depth = m.end(), 1
+                    while i < len(src) and depth:
+                        depth += src[i] in "([{"; depth -= src[i] in ")]}"; i += 1
+                    args = split_args(src[m.end():i - 1])
+                line = src.count("\n", 0, m.start()) + 1
+                site = {"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a, SiteTypes(sc, m.start(), {})) for a in args]}
+                res.setdefault(t, {}).setdefault(meth, {"calls": []})["calls"].append(site)
+    out = {"_source": {"dirs": G.REF_DIRS, "note": "instance-method call sites of the aten runtime classes in lamp's hot-path modules (receiver typed lexically through "
+                                                   "`.value` chains): method, argument count, argument kinds - no source text (scripts/gen_aten_forwarders.py collect)"}}
+    for c in sorted(res):
+        out[c] = {n: res[c][n] for n in sorted(res[c])}
+    json.dump(out, open(INSTANCE_SITES, "w"), indent=1)
+    print({c: len(out[c]) for c in out if not c.startswith("_")}, "instance methods")
+
+
+def instance_members():
+    """(class, method) -> (result type, [parameter types]) of the PUBLIC NON-STATIC members the hand-written blocks define"""
+    out = {}
+    srcs = dict(SUPPORT)
+    srcs["TensorOptions"] = TENSOR_OPTIONS
+    for cls, text in srcs.items():
+        for m in re.finditer(r"^  public (?!static)(\S+(?:<[^;{]*>)?(?:\[\])?) (\w+)\(([^)]*)\)", text, re.M):
+            plist = [] if not m.group(3).strip() else [q.strip() for q in m.group(3).split(",")]
+            out.setdefault((cls, m.group(2)), []).append((m.group(1), [" ".join(q.split()[:-1]) for q in plist]))
+    return out
+
+
+def check_instances():
+    """every collected instance call site meets a member with that name, that many parameters and compatible kinds"""
+    sites = json.load(open(INSTANCE_SITES))
+    members = instance_members()
+    problems = []
+    for cls, table in sites.items():
+        if cls.startswith("_"):
+            continue
+        for meth, e in table.items():
+            cands = members.get((cls, meth))
+            if not cands:
+                problems.append(f"{cls}.{meth}: no member ({e['calls'][0]['at']})")
+                continue
+            for c in e["calls"]:
+                if not any(len(pt) == c["arity"] and all(compatible(jt, k) for jt, k in zip(pt, c["kinds"])) for _, pt in cands):
+                    problems.append(f"{cls}.{meth} at {c['at']}: passes {c['kinds']}, members take {[pt for _, pt in cands]}")
+    return problems
 
 
 def native_signatures():
@@ -463,7 +706,7 @@ def compatible(jt, kind):
         return jt.endswith("[]")
     # (a Long argument where the forwarder takes a double: Scala widens it)
     return jt in {"tensor": ("Tensor",), "bool": ("boolean",), "long": ("long", "int", "short", "byte", "double"), "double": ("double", "float"),
-                  "longs": ("long[]",), "tensors": ("Tensor[]",), "bools": ("boolean[]",), "options": ("TensorOptions",),
+                  "longs": ("long[]",), "ints": ("int[]",), "tensors": ("Tensor[]",), "bools": ("boolean[]",), "options": ("TensorOptions",),
                   "string": ("String",)}.get(kind, (jt,))
 
 
@@ -509,6 +752,18 @@ def forwarders():
         for name, e in sites.get(cls, {}).items():
             sym, _ = symbol_of(cls, name, nm, syms)
             key = f"{cls}.{name}"
+            if name in HANDWRITTEN.get(cls, ()):
+                hm = re.search(r"public static (\S+(?:<[^;{]*>)?(?:\[\])?) %s\(([^)]*)\)" % re.escape(name), SUPPORT[cls])
+                assert hm, f"{key}: listed as hand-written but not in the support block"
+                plist = [] if not hm.group(2).strip() else [q.strip() for q in hm.group(2).split(",")]
+                arities = sorted({c["arity"] for c in e["calls"]})
+                check_kinds(key, e, [" ".join(q.split()[:-1]) for q in plist], hm.group(1))
+                report["forwarded"] += 1
+                report.setdefault("handwritten", []).append(key)
+                if arities != [len(plist)]:
+                    report["arity_mismatch"].append({"name": key, "symbol": "hand-written", "forwarder_arity": len(plist), "call_site_arities": arities,
+                                                     "at": [c["at"] for c in e["calls"] if c["arity"] != len(plist)][:3]})
+                continue
             if key in EXPLICIT:
                 params, rtype, body = EXPLICIT[key][:3]
                 plist = [] if not params.strip() else [p.strip() for p in params.split(",")]
@@ -564,10 +819,19 @@ def forwarders():
 
 
 SUPPORT = {
-    "Tensor": '''  /** the C-ABI handle (lamp_tensor*); 0 after release() */
+    # Hand-written members of the aten classes: what lamp calls on INSTANCES (collected lexically into tests/golden/aten_instance_sites.json by
+    # `collect`; tests/golden/aten_descriptors.json is the hand-audited table tests/test_jni_map.py holds these sources to).
+    "Tensor": """  /** the C-ABI handle (lamp_tensor*); 0 after release() and for Tensor.undefined() */
   private long handle;
   private Tensor(long h) { handle = h; }
-  static Tensor owning(long h) { return h == 0 ? null : new Tensor(h); }
+  private static final java.util.concurrent.ConcurrentHashMap<Long, StackTraceElement[]> births = new java.util.concurrent.ConcurrentHashMap<>();
+  static volatile boolean tracing = false;
+  static StackTraceElement[] birthOf(long h) { StackTraceElement[] t = births.get(h); return t == null ? new StackTraceElement[0] : t; }
+  static Tensor owning(long h) {
+    if (h == 0) return null;
+    if (tracing) births.put(h, new Throwable().getStackTrace());
+    return new Tensor(h);
+  }
   static Tensor[] owningAll(long[] hs) { Tensor[] r = new Tensor[hs.length]; for (int i = 0; i < hs.length; i++) r[i] = owning(hs[i]); return r; }
   static long handleOf(Tensor t) { return t == null ? 0L : t.handle; }
   /** a Scala Option[Tensor] (or a Tensor, or null): lamp passes optional tensors as scala.Option */
@@ -589,22 +853,249 @@ SUPPORT = {
     } catch (ReflectiveOperationException e) { throw new IllegalArgumentException("expected scala.Option[Array[Long]], got " + o.getClass(), e); }
   }
   static long[] handlesOf(Tensor[] ts) { long[] r = new long[ts.length]; for (int i = 0; i < ts.length; i++) r[i] = handleOf(ts[i]); return r; }
-  public void release() { if (handle != 0) { LampNative.lamp_tensor_release(handle); handle = 0; } }
-  public static void releaseAll(Tensor[] ts) { LampNative.lamp_tensor_release_all(handlesOf(ts)); for (Tensor t : ts) if (t != null) t.handle = 0; }
+  /** STen.scala:559-580: the placeholder lamp passes for an absent optional tensor; release() on it is a no-op */
+  public static Tensor undefined() { return new Tensor(0L); }
+  public static boolean hasCuda() { return LampNative.lamp_has_gpu() != 0; }                       // STen.scala:1895 `if (aten.Tensor.hasCuda())`
+  public static int getNumGPUs() { return LampNative.lamp_get_num_gpus(); }                        // device.scala:217
+  public static void allowtf32(boolean flag) { LampNative.lamp_allow_tf32(flag ? 1 : 0); }
+  public static void setPinnedMemoryAllocator() {}                                                  // pinned staging is lamp_pin_memory: nothing to install
+  public void release() { if (handle != 0) { births.remove(handle); LampNative.lamp_tensor_release(handle); handle = 0; } }
+  public static void releaseAll(Tensor[] ts) {
+    for (Tensor t : ts) if (t != null) births.remove(t.handle);
+    LampNative.lamp_tensor_release_all(handlesOf(ts));
+    for (Tensor t : ts) if (t != null) t.handle = 0;
+  }
+  // ---- metadata (STen.scala:845-870) ----
   public long[] sizes() { return LampNative.lamp_tensor_sizes(handle); }
   public long[] strides() { return LampNative.lamp_tensor_strides(handle); }
   public long numel() { return LampNative.lamp_tensor_numel(handle); }
   public long dim() { return LampNative.lamp_tensor_ndim(handle); }
+  public long elementSize() { return LampNative.lamp_tensor_element_size(handle); }
   public byte scalarTypeByte() { return (byte) LampNative.lamp_tensor_scalar_type(handle); }
+  public boolean isCuda() { return LampNative.lamp_tensor_device(handle) >= 0; }
+  public boolean is_pinned() { return LampNative.lamp_tensor_is_pinned(handle) != 0; }
+  /** a NEW TensorOptions the caller releases (STen.scala:864, device.scala:221-225) */
   public TensorOptions options() { return new TensorOptions((byte) LampNative.lamp_tensor_scalar_type(handle), LampNative.lamp_tensor_device(handle)); }
+  // ---- copies and placement (STen.scala:918-944, 1895-1898; device.scala:223) ----
+  public Tensor to(TensorOptions options, boolean nonBlocking, boolean copy) {
+    return owning(LampNative.lamp_to(handle, options.scalarTypeByte(), options.deviceIndex(), nonBlocking ? 1 : 0, copy ? 1 : 0));
+  }
+  public Tensor cpu() { return owning(LampNative.lamp_to(handle, LampNative.lamp_tensor_scalar_type(handle), -1, 0, 0)); }
+  public Tensor pin_memory() { return owning(LampNative.lamp_pin_memory(handle)); }
+  public void copyFrom(Tensor source, boolean nonBlocking) { LampNative.lamp_copy_(handle, handleOf(source), nonBlocking ? 1 : 0); }
+  public Tensor expand_as(Tensor other) { return owning(LampNative.lamp_expand_as(handle, handleOf(other))); }
+  /** Tensor.repeat (STen.scala:1758): the tensor tiled `repeats[d]` times along each dimension */
+  public Tensor repeat(long[] repeats) {
+    long[] sz = sizes();
+    int lead = repeats.length - sz.length;
+    if (lead < 0) throw new IllegalArgumentException("repeat: fewer repeats than dimensions");
+    long[] v = new long[2 * repeats.length], e = new long[2 * repeats.length], o = new long[repeats.length];
+    for (int d = 0; d < repeats.length; d++) {
+      long s = d < lead ? 1 : sz[d - lead];
+      v[2 * d] = 1; v[2 * d + 1] = s; e[2 * d] = repeats[d]; e[2 * d + 1] = s; o[d] = repeats[d] * s;
+    }
+    long a = LampNative.lamp_reshape(handle, v), b = LampNative.lamp_expand(a, e), c = LampNative.lamp_reshape(b, o);
+    long r = LampNative.lamp_clone(c);
+    LampNative.lamp_tensor_release_all(new long[] {a, b, c});
+    return owning(r);
+  }
+  // ---- in-place scalar arithmetic (STen.scala:1123-1127, 1193-1197) ----
+  public void add_(double other, double alpha) { LampNative.lamp_add_scalar_(handle, other, alpha); }
+  public void add_l_(long other, long alpha) { LampNative.lamp_add_scalar_(handle, (double) other, (double) alpha); }
+  public void mul_(double other) { LampNative.lamp_mul_scalar_(handle, other); }
+  public void mul_l_(long other) { LampNative.lamp_mul_scalar_(handle, (double) other); }
+  // ---- host arrays (TensorHelpers.scala:57-253): CPU tensors, `false` on failure as lamp asserts on the result ----
   public boolean copyFromDoubleArray(double[] a) { return LampNative.copyFromDoubleArray(handle, a); }
   public boolean copyFromFloatArray(float[] a) { return LampNative.copyFromFloatArray(handle, a); }
   public boolean copyFromLongArray(long[] a) { return LampNative.copyFromLongArray(handle, a); }
+  public boolean copyFromIntArray(int[] a) { return LampNative.copyFromIntArray(handle, a); }
+  public boolean copyFromShortArray(short[] a) { return LampNative.copyFromShortArray(handle, a); }
+  public boolean copyFromByteArray(byte[] a) { return LampNative.copyFromByteArray(handle, a); }
   public boolean copyToDoubleArray(double[] a) { return LampNative.copyToDoubleArray(handle, a); }
   public boolean copyToFloatArray(float[] a) { return LampNative.copyToFloatArray(handle, a); }
   public boolean copyToLongArray(long[] a) { return LampNative.copyToLongArray(handle, a); }
-''',
+  public boolean copyToIntArray(int[] a) { return LampNative.copyToIntArray(handle, a); }
+  public boolean copyToShortArray(short[] a) { return LampNative.copyToShortArray(handle, a); }
+  public boolean copyToByteArray(byte[] a) { return LampNative.copyToByteArray(handle, a); }
+  /** the n elements from `offset` on of the flattened tensor (TensorHelpers.scala:190) */
+  private long window(long offset, long n) {
+    long f = LampNative.lamp_view(handle, new long[] {-1});
+    try { return LampNative.lamp_narrow(f, 0, offset, n); } finally { LampNative.lamp_tensor_release(f); }
+  }
+  public boolean copyFromDoubleArrayAtOffset(double[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromDoubleArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  public boolean copyFromFloatArrayAtOffset(float[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromFloatArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  public boolean copyFromLongArrayAtOffset(long[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromLongArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  public boolean copyFromIntArrayAtOffset(int[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromIntArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  public boolean copyFromShortArrayAtOffset(short[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromShortArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  public boolean copyFromByteArrayAtOffset(byte[] a, long offset) {
+    try { long w = window(offset, a.length); try { return LampNative.copyFromByteArray(w, a); } finally { LampNative.lamp_tensor_release(w); } } catch (RuntimeException e) { return false; }
+  }
+  // ---- sparse tensors: outside SURVEY section 8 (jni/name_map.json states the gap); named so that lamp-sten links ----
+  public Tensor coalesce() { throw new UnsupportedOperationException("sparse tensors are not provided by liblamp_hip"); }
+  public Tensor indices() { throw new UnsupportedOperationException("sparse tensors are not provided by liblamp_hip"); }
+  public Tensor values() { throw new UnsupportedOperationException("sparse tensors are not provided by liblamp_hip"); }
+  public Tensor to_dense() { throw new UnsupportedOperationException("sparse tensors are not provided by liblamp_hip"); }
+""",
+    "CudaStream": """  /** the C-ABI handle (lamp_stream*) */
+  private final long handle;
+  private CudaStream(long h) { handle = h; }
+  static long handleOf(CudaStream s) { return s == null ? 0L : s.handle; }
+  /** device.scala:181-208: `default.synchronize()`, `orig.synchronize()` */
+  public void synchronize() { LampNative.lamp_stream_synchronize(handle); }
+  /** the current stream and device are per OS thread (device.scala:119-129) */
+  public static CudaStream getCurrentCUDAStream(byte device) { return new CudaStream(LampNative.lamp_stream_get_current(device)); }
+  public static CudaStream getDefaultCUDAStream(byte device) { return new CudaStream(LampNative.lamp_stream_get_default(device)); }
+  public static CudaStream getStreamFromPool(boolean highPriority, byte device) { return new CudaStream(LampNative.lamp_stream_get_from_pool(highPriority ? 1 : 0, device)); }
+  public static void setCurrentCUDAStream(CudaStream s) { LampNative.lamp_stream_set_current(handleOf(s)); }
+  public static int cudaGetDevice() { return LampNative.lamp_get_device(); }                       // STen.scala:636
+  public static void cudaSetDevice(int device) { LampNative.lamp_set_device(device); }             // STen.scala:637, 639
+""",
+    "NcclComm": """  /** the C-ABI handle (lamp_comm*: an RCCL communicator) */
+  private long handle;
+  private NcclComm(long h) { handle = h; }
+  static long[] handlesOf(NcclComm[] cs) { long[] r = new long[cs.length]; for (int i = 0; i < cs.length; i++) r[i] = cs[i] == null ? 0L : cs[i].handle; return r; }
+  /** STen.scala:1906: `Base64.getEncoder.encodeToString(aten.NcclComm.get_unique_id)` */
+  public static byte[] get_unique_id() { return LampNative.lamp_comm_get_unique_id(); }
+  /** STen.scala:638: blocks until all ranks have joined */
+  public static NcclComm comm_init_rank(int nRanks, byte[] uniqueId, int myRank) { return new NcclComm(LampNative.lamp_comm_init_rank(nRanks, uniqueId, myRank)); }
+  /** STen.scala:648-651: one entry per GPU this thread drives (a group call); the root is rank 0 */
+  public static void broadcast(Tensor[] tensors, NcclComm[] comms) { LampNative.lamp_comm_broadcast(Tensor.handlesOf(tensors), handlesOf(comms), 0); }
+  /** STen.scala:664-670: op 0 = sum; the output lives on the root rank */
+  public static void reduce(Tensor[] inputs, Tensor output, int rootRank, int op, NcclComm[] comms) {
+    LampNative.lamp_comm_reduce(Tensor.handlesOf(inputs), Tensor.handleOf(output), rootRank, op, handlesOf(comms));
+  }
+  /** not in aten-scala: the one-call gradient exchange SURVEY section 8b asks the new backend to add */
+  public static void all_reduce(Tensor[] tensors, NcclComm[] comms, int op) { LampNative.lamp_comm_all_reduce(Tensor.handlesOf(tensors), handlesOf(comms), op); }
+  public void comm_destroy() { if (handle != 0) { LampNative.lamp_comm_destroy(handle); handle = 0; } }
+""",
+    "TensorTrace": """  private TensorTrace() {}
+  /** TensorLogger.scala:200, 233 */
+  public static void enable() { Tensor.tracing = true; LampNative.lamp_tensor_trace_enable(1); }
+  public static void disable() { Tensor.tracing = false; LampNative.lamp_tensor_trace_enable(0); }
+  /** TensorLogger.scala:23: `aten.TensorTrace.list.map(v => v.getValue)` - (handle, data) pairs of the live traced tensors.
+   *  lamp_tensor_trace_list records are 14 longs: handle, birth (ns), scalar type, device, ndim, 8 sizes, bytes. */
+  @SuppressWarnings("unchecked")
+  public static java.util.Map.Entry<Long, TensorTraceData>[] list() {
+    long[] rec = LampNative.lamp_tensor_trace_list();
+    int n = rec.length / 14;
+    java.util.Map.Entry<Long, TensorTraceData>[] out = (java.util.Map.Entry<Long, TensorTraceData>[]) new java.util.Map.Entry[n];
+    for (int i = 0; i < n; i++) {
+      int b = 14 * i, nd = (int) rec[b + 4];
+      long[] shape = new long[nd];
+      for (int d = 0; d < nd; d++) shape[d] = rec[b + 5 + d];
+      out[i] = new java.util.AbstractMap.SimpleImmutableEntry<>(rec[b], new TensorTraceData(shape, rec[b + 3] < 0, (byte) rec[b + 2], rec[b + 1], Tensor.birthOf(rec[b])));
+    }
+    return out;
+  }
+""",
 }
+
+# classes without forwarders: written whole
+EXTRA_CLASSES = {
+    "TensorTraceData": """// GENERATED by scripts/gen_aten_forwarders.py - do not edit.
+// aten.TensorTraceData as lamp.TensorLogger reads it (TensorLogger.scala:13-62): shape, device class, scalar type byte, birth time, creating stack.
+package aten;
+
+public final class TensorTraceData {
+  private final long[] shape;
+  private final boolean cpu;
+  private final byte scalarType;
+  private final long birth;
+  private final StackTraceElement[] stackTrace;
+  TensorTraceData(long[] shape, boolean cpu, byte scalarType, long birth, StackTraceElement[] stackTrace) {
+    this.shape = shape; this.cpu = cpu; this.scalarType = scalarType; this.birth = birth; this.stackTrace = stackTrace;
+  }
+  public long[] getShape() { return shape; }
+  public boolean getCpu() { return cpu; }
+  public byte getScalarType() { return scalarType; }
+  public long getBirth() { return birth; }
+  public StackTraceElement[] getStackTrace() { return stackTrace; }
+}
+""",
+    "TensorOptionsTrace": """// GENERATED by scripts/gen_aten_forwarders.py - do not edit.
+// aten.TensorOptionsTrace (TensorLogger.scala:31, 201, 234): TensorOptions are plain JVM values here - no native object, nothing to leak or list.
+package aten;
+
+public final class TensorOptionsTrace {
+  private TensorOptionsTrace() {}
+  public static void enable() {}
+  public static void disable() {}
+  @SuppressWarnings("unchecked")
+  public static java.util.Map.Entry<Long, TensorTraceData>[] list() { return (java.util.Map.Entry<Long, TensorTraceData>[]) new java.util.Map.Entry[0]; }
+}
+""",
+}
+
+# statics that the hand-written blocks above define: no generated forwarder beside them
+HANDWRITTEN = {"Tensor": {"hasCuda", "getNumGPUs", "releaseAll", "undefined", "allowtf32", "setPinnedMemoryAllocator"},
+               "CudaStream": {"getCurrentCUDAStream", "getDefaultCUDAStream", "getStreamFromPool", "setCurrentCUDAStream", "cudaGetDevice", "cudaSetDevice"},
+               "NcclComm": {"get_unique_id", "comm_init_rank", "broadcast", "reduce"},
+               "TensorTrace": {"enable", "disable", "list"}}
+
+
+TENSOR_OPTIONS = '''// GENERATED by scripts/gen_aten_forwarders.py - do not edit.
+// aten.TensorOptions as lamp uses it (STenOptions, lamp-sten/src/main/scala/lamp/STen.scala:678-780; statics STen.scala:18-35): a (scalar type,
+// device) pair; the C ABI takes the two as ints (scalar type byte as in ATen: 0 u8, 1 i8, 2 i16, 3 i32, 4 i64, 5 f16, 6 f32, 7 f64, 11 bool,
+// 15 bf16; device -1 = CPU, >= 0 = GPU ordinal).  Every method returns a NEW value; release() exists because lamp's Scope calls it.
+package aten;
+
+public final class TensorOptions {
+  private final byte scalarType;
+  private final int device;
+  TensorOptions(byte scalarType, int device) { this.scalarType = scalarType; this.device = device; }
+  public static TensorOptions dtypeDouble() { return new TensorOptions((byte) 7, -1); }
+  public static TensorOptions dtypeFloat() { return new TensorOptions((byte) 6, -1); }
+  public static TensorOptions dtypeLong() { return new TensorOptions((byte) 4, -1); }
+  public static TensorOptions dtypeHalf() { return new TensorOptions((byte) 5, -1); }
+  public static TensorOptions dtypeBF16() { return new TensorOptions((byte) 15, -1); }
+  public static TensorOptions d() { return dtypeDouble(); }
+  public static TensorOptions f() { return dtypeFloat(); }
+  public static TensorOptions l() { return dtypeLong(); }
+  public static TensorOptions i() { return new TensorOptions((byte) 3, -1); }
+  public static TensorOptions sh() { return new TensorOptions((byte) 2, -1); }
+  public static TensorOptions b() { return new TensorOptions((byte) 1, -1); }               // "compatible with Scala's Byte": signed 8 bit
+  public static TensorOptions fromScalarType(byte scalarType) { return new TensorOptions(scalarType, -1); }
+  public TensorOptions cpu() { return new TensorOptions(scalarType, -1); }
+  public TensorOptions cuda() { return new TensorOptions(scalarType, 0); }
+  public TensorOptions cuda_index(short index) { return new TensorOptions(scalarType, index); }
+  /** device(deviceType, index): 0 cpu, 1 cuda (= the GPU here), 13 mps (STen.scala:757-759; no such device behind this library) */
+  public TensorOptions device(byte deviceType, int index) {
+    if (deviceType == 0) return new TensorOptions(scalarType, -1);
+    if (deviceType == 1) return new TensorOptions(scalarType, index);
+    throw new UnsupportedOperationException("TensorOptions.device: device type " + deviceType + " is not provided by liblamp_hip");
+  }
+  public TensorOptions toDouble() { return new TensorOptions((byte) 7, device); }
+  public TensorOptions toFloat() { return new TensorOptions((byte) 6, device); }
+  public TensorOptions toHalf() { return new TensorOptions((byte) 5, device); }
+  public TensorOptions toBF16() { return new TensorOptions((byte) 15, device); }
+  public TensorOptions toLong() { return new TensorOptions((byte) 4, device); }
+  public TensorOptions toInt() { return new TensorOptions((byte) 3, device); }
+  public TensorOptions toShort() { return new TensorOptions((byte) 2, device); }
+  public TensorOptions toByte() { return new TensorOptions((byte) 1, device); }
+  public boolean isDouble() { return scalarType == 7; }
+  public boolean isFloat() { return scalarType == 6; }
+  public boolean isLong() { return scalarType == 4; }
+  public boolean isInt() { return scalarType == 3; }
+  public boolean isShort() { return scalarType == 2; }
+  public boolean isByte() { return scalarType == 1; }
+  public boolean isCPU() { return device < 0; }
+  public boolean isCuda() { return device >= 0; }
+  public boolean isSparse() { return false; }
+  public int deviceIndex() { return device; }
+  public byte scalarTypeByte() { return scalarType; }
+  public void release() {}
+}
+'''
 
 
 HELPERS = """  private static final class N extends LampNative {}     // (static natives: `N.lamp_x(...)` reads shorter)
@@ -622,36 +1113,9 @@ def emit():
                f"// aten.{cls}: the static methods lamp calls on this class, forwarded to the natives of aten.LampNative (jni/aten_jni.c over liblamp_hip.so).\n"
                f"package aten;\n\npublic final class {cls} {{\n" + SUPPORT.get(cls, f"  private {cls}() {{}}\n") + HELPERS + "\n" + body + "\n}\n")
         open(os.path.join(OUT_DIR, f"{cls}.java"), "w").write(src)
-    open(os.path.join(OUT_DIR, "TensorOptions.java"), "w").write('''// GENERATED by scripts/gen_aten_forwarders.py - do not edit.
-// aten.TensorOptions as lamp uses it (STenOptions, lamp-sten/src/main/scala/lamp/STen.scala): a (scalar type, device) pair; the C ABI takes the
-// two as ints (scalar type byte as in ATen: 0 u8, 2 i16, 3 i32, 4 i64, 5 f16, 6 f32, 7 f64, 11 bool, 15 bf16; device -1 = CPU, >= 0 = GPU ordinal).
-package aten;
-
-public final class TensorOptions {
-  private final byte scalarType;
-  private final int device;
-  TensorOptions(byte scalarType, int device) { this.scalarType = scalarType; this.device = device; }
-  public static TensorOptions dtypeDouble() { return new TensorOptions((byte) 7, -1); }
-  public static TensorOptions dtypeFloat() { return new TensorOptions((byte) 6, -1); }
-  public static TensorOptions dtypeLong() { return new TensorOptions((byte) 4, -1); }
-  public static TensorOptions dtypeHalf() { return new TensorOptions((byte) 5, -1); }
-  public static TensorOptions dtypeBFloat16() { return new TensorOptions((byte) 15, -1); }
-  public static TensorOptions d() { return dtypeDouble(); }
-  public static TensorOptions f() { return dtypeFloat(); }
-  public static TensorOptions l() { return dtypeLong(); }
-  public TensorOptions cpu() { return new TensorOptions(scalarType, -1); }
-  public TensorOptions cuda() { return new TensorOptions(scalarType, 0); }
-  public TensorOptions cuda_index(short i) { return new TensorOptions(scalarType, i); }
-  public TensorOptions toDouble() { return new TensorOptions((byte) 7, device); }
-  public TensorOptions toFloat() { return new TensorOptions((byte) 6, device); }
-  public TensorOptions toLong() { return new TensorOptions((byte) 4, device); }
-  public boolean isCPU() { return device < 0; }
-  public boolean isCuda() { return device >= 0; }
-  public int deviceIndex() { return device; }
-  public byte scalarTypeByte() { return scalarType; }
-  public void release() {}
-}
-''')
+    open(os.path.join(OUT_DIR, "TensorOptions.java"), "w").write(TENSOR_OPTIONS)
+    for cls, text in EXTRA_CLASSES.items():
+        open(os.path.join(OUT_DIR, f"{cls}.java"), "w").write(text)
     json.dump(report, open(os.path.join(OUT_DIR, "forwarders_report.json"), "w"), indent=1)
     print({k: (len(v) if isinstance(v, list) else v) for k, v in report.items()})
 
@@ -665,6 +1129,7 @@ if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "emit"
     if cmd == "collect":
         collect()
+        collect_instances()
     elif cmd == "emit":
         emit()
     else:
@@ -672,4 +1137,7 @@ if __name__ == "__main__":
         print(json.dumps({k: (len(v) if isinstance(v, list) else v) for k, v in r.items()}))
         for m in r["arity_mismatch"] + r["kind_mismatch"]:
             print("  ", m)
-        sys.exit(1 if (r["arity_mismatch"] or r["kind_mismatch"]) else 0)
+        inst = check_instances()
+        for m in inst:
+            print("  ", m)
+        sys.exit(1 if (r["arity_mismatch"] or r["kind_mismatch"] or inst) else 0)
