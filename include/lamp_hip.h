@@ -411,6 +411,14 @@ int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* gr
                                         const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
                                         const int64_t* dilation, int nspatial, const int64_t* output_padding,
                                         int64_t groups, const lamp_tensor* addend);
+/* TWO (non-transposed) convolutions of ONE input: out2 = {convolution(x, w_a, bias_a, geometry a), convolution(x, w_b, bias_b, geometry b)} - the
+ * two branches of lamp's residual block both start with a Conv2D on the block's input (example-cifar100 cnn.scala:16-20, 38-78: 3x3 and the
+ * 1x1 shortcut).  Values (and the batch-norm statistics hand-off of each output) are those of two lamp_convolution calls; where a kernel
+ * holds the staged input for both products (bf16 3x3 + 1x1 on 8x8 maps with equal output channels) they are one launch. */
+int lamp_convolution_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp_tensor* w_a, const lamp_tensor* bias_a_or_null,
+                          const int64_t* stride_a, const int64_t* padding_a, const int64_t* dilation_a, const lamp_tensor* w_b,
+                          const lamp_tensor* bias_b_or_null, const int64_t* stride_b, const int64_t* padding_b,
+                          const int64_t* dilation_b, int nspatial, int64_t groups);
 int lamp_avg_pool2d(lamp_tensor** out, const lamp_tensor* x, int64_t kernel, int64_t stride, int64_t padding,
                     int ceil_mode, int count_include_pad);
 int lamp_avg_pool2d_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x, int64_t kernel,

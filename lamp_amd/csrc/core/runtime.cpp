@@ -47,6 +47,24 @@ static int g_num_cus = -1;
 static std::atomic<uint64_t> g_seed{0x5eed1234abcdULL};
 static std::atomic<uint64_t> g_philox_offset{0};
 
+// every device some thread of this process has selected (bit d): what "all work that may still touch a recycled pinned block" ranges over
+static std::atomic<uint32_t> g_devices_used{0};
+uint32_t devices_used_mask() { return g_devices_used.load(std::memory_order_acquire); }
+// Waits for all queued work on every device this process has used, from any thread (the calling thread's current device is restored).
+// hipHostFree waits like this implicitly; a recycled pinned block needs the same guarantee: a loader thread that never selected a device
+// sits on device 0 while training runs on device N, and one process may drive several GPUs (DataParallel.scala:195-311).
+void synchronize_all_used_devices() {
+  const uint32_t mask = devices_used_mask();
+  if (!mask) return;
+  int prev = -1;
+  HIP_CHECK(hipGetDevice(&prev));
+  for (int d = 0; d < 16; d++) {
+    if (!(mask & (1u << d))) continue;
+    HIP_CHECK(hipSetDevice(d));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  HIP_CHECK(hipSetDevice(prev));
+}
 int current_device() {
   if (!tl_device_set) {
     // adopt the process default (LOCAL_RANK based selection happens via lamp_set_device)
@@ -55,6 +73,7 @@ int current_device() {
     hipError_t e = hipSetDevice(0);
     if (e != hipSuccess) throw Error(std::string("hipSetDevice(0) failed: ") + hipGetErrorString(e) +
                                      " - no usable MI355X device; this library has no CPU fallback");
+    g_devices_used.fetch_or(1u, std::memory_order_acq_rel);
   }
   return tl_device;
 }
@@ -62,6 +81,7 @@ void set_device(int d) {
   HIP_CHECK(hipSetDevice(d));
   tl_device = d;
   tl_device_set = true;
+  if (d >= 0 && d < 16) g_devices_used.fetch_or(1u << d, std::memory_order_acq_rel);
 }
 hipStream_t current_stream(int device) {
   LAMP_CHECK(device >= 0 && device < 16, "bad device " << device);
@@ -123,6 +143,7 @@ const char* assert_text(int code) {
   switch (code) {
     case kAssertNllTarget: return "nll_loss: a target class index is outside [0, numClasses) and is not ignore_index";
     case kAssertIndexRange: return "index out of range";
+    case kAssertMultinomial: return "multinomial: invalid distribution (a weight is negative, infinite or NaN, or a row sums to zero)";
     case kAssertBnExchangeTimeout: return "batch-norm backward (one pass): a workgroup waited two minutes for the partial sums of its channel - "
                                           "another kernel is holding the compute units; the gradients of that launch are invalid (LAMP_BN_FUSED_BWD=0 selects the two-kernel form)";
   }

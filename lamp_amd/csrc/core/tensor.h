@@ -190,6 +190,8 @@ bool allocator_capturing();                 // this thread is between lamp_graph
 // ---- runtime (core/runtime.cpp) ----
 int current_device();
 void set_device(int d);
+uint32_t devices_used_mask();           // bit d: some thread of this process has selected device d
+void synchronize_all_used_devices();    // hipDeviceSynchronize on each of them (checked); the caller's current device is restored
 hipStream_t current_stream();           // thread-local current stream of current device
 hipStream_t current_stream(int device);
 int num_cus();
@@ -201,7 +203,7 @@ void allow_big_lds(const void* kernel);   // opt a kernel into 160 KiB of dynami
 void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P);
 lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P);   // +1 handle or nullptr
 // device-side assertions (runtime.cpp): a kernel stores a code into *device_assert_word(dev); the next host wait raises
-enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2, kAssertBnExchangeTimeout = 3 };
+enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2, kAssertBnExchangeTimeout = 3, kAssertMultinomial = 4 };
 // "this device is also running kernels the library does not schedule" (an RCCL collective on the exchange stream while backward
 // continues, a caller's own side-stream work): kernels whose workgroups wait for each other take their non-waiting form meanwhile.
 void device_shared_add(int device, int delta);

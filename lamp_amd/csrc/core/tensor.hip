@@ -50,9 +50,11 @@ static inline void untrack(const Tensor* t) {
 
 // Page-locked host blocks are recycled instead of returned to the driver: a hipHostFree / hipHostMalloc cycle costs ~0.2 ms per MB and,
 // measured, hands back pages that the GPU then reads at anything between 19 and 53 GB/s (EXPERIMENTS (17)).  A freed block waits in a small
-// cache (LAMP_PINNED_CACHE_MB, default 2048; 0: off); it is handed out again for a request it fits with at most 25 % of slack, after a device
-// synchronise - asynchronous copies that still read the old contents (lamp_to / copy_ with non_blocking from a pinned source) finish first,
-// which is what hipHostFree's implicit synchronisation guaranteed before.
+// cache (LAMP_PINNED_CACHE_MB, default 2048; 0: off); it is handed out again for a request it fits with at most 25 % of slack, after a
+// synchronise of EVERY device this process has used (from any thread: a loader thread that never selected a device sits on device 0 while the
+// step runs on device N) - asynchronous copies that still read or write the old contents (lamp_to / copy_ with non_blocking)
+// finish first, which is what hipHostFree's implicit synchronisation guaranteed.  The wait happens outside the cache's lock and its result
+// is checked; a failed hipHostMalloc empties the cache and tries once more.
 namespace {
 struct PinnedCache {
   std::mutex mu;
@@ -62,23 +64,45 @@ struct PinnedCache {
 };
 PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return *c; }      // never destroyed: storages may outlive static destructors
 }  // namespace
+static void pinned_cache_flush() {
+  PinnedCache& c = pinned_cache();
+  std::multimap<size_t, void*> victims;
+  { std::lock_guard<std::mutex> lk(c.mu); victims.swap(c.blocks); c.cached = 0; }
+  for (auto& kv : victims) (void)hipHostFree(kv.second);      // (hipHostFree waits for the device itself)
+}
 static void* pinned_alloc(size_t bytes, size_t* capacity) {
   PinnedCache& c = pinned_cache();
   const size_t want = bytes ? bytes : 1;
   if (!allocator_capturing()) {                               // (a device synchronise would break a stream capture: allocate fresh there)
-    std::lock_guard<std::mutex> lk(c.mu);
-    auto it = c.blocks.lower_bound(want);
-    if (it != c.blocks.end() && it->first <= want + want / 4) {
-      void* p = it->second;
-      *capacity = it->first;
-      c.cached -= it->first;
-      c.blocks.erase(it);
-      (void)hipDeviceSynchronize();
+    void* p = nullptr;
+    size_t cap = 0;
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      auto it = c.blocks.lower_bound(want);
+      if (it != c.blocks.end() && it->first <= want + want / 4) {
+        p = it->second; cap = it->first;
+        c.cached -= cap;
+        c.blocks.erase(it);
+      }
+    }
+    if (p) {
+      try {
+        synchronize_all_used_devices();                       // outside the lock; throws when a device reports an error
+      } catch (...) {
+        (void)hipHostFree(p);                                 // the block's old readers may not be done: never hand it out
+        throw;
+      }
+      *capacity = cap;
       return p;
     }
   }
   void* p = nullptr;
-  HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+  hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+  if (e != hipSuccess) {                                      // the cache may be what holds the memory: give it back and try once more
+    (void)hipGetLastError();
+    pinned_cache_flush();
+    HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+  }
   *capacity = want;
   return p;
 }

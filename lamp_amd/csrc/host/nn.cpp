@@ -67,15 +67,33 @@ Var Residual::forward_relu(const Var& x) {
   if (bn) {
     // right branch up to (not including) its last batch norm, with the usual BatchNorm -> relu rewrite inside
     Sequential head(std::vector<Mod>(seq->mods.begin(), seq->mods.end() - 1));
-    Var v = head.forward(x);
+    auto* lseq = left ? dynamic_cast<Sequential*>(left.get()) : nullptr;
+    BatchNorm* lbn = (lseq && !lseq->mods.empty()) ? dynamic_cast<BatchNorm*>(lseq->mods.back().get()) : nullptr;
+    // Both branches START with a Conv2D on x (every block of Cnn.resnet: cnn.scala:38-45 and 64-72): the two convolutions are one call, which
+    // is one launch where a kernel keeps the staged input for both products (LAMP_CONV_SIBLING=0: two calls).  Same nodes, same values.
+    static const bool pair_on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
+    auto* c3 = head.mods.empty() ? nullptr : dynamic_cast<Conv2D*>(head.mods[0].get());
+    auto* c1 = (lbn && lseq->mods.size() == 2) ? dynamic_cast<Conv2D*>(lseq->mods[0].get()) : nullptr;
+    Var v, lconv;                                  // lconv: the left branch's convolution output when it came with the right one
+    if (pair_on && c3 && c1 && c3->groups == c1->groups && x->value.h()->is_device()) {
+      auto pr = F::convolution_pair(x, c3->weights, c3->bias, {c3->stride, c3->stride}, {c3->padding, c3->padding}, {c3->dilation, c3->dilation},
+                                    c1->weights, c1->bias, {c1->stride, c1->stride}, {c1->padding, c1->padding}, {c1->dilation, c1->dilation}, c3->groups);
+      Sequential rest(std::vector<Mod>(head.mods.begin() + 1, head.mods.end()));
+      v = rest.forward(pr.first);
+      lconv = pr.second;
+    } else {
+      v = head.forward(x);
+    }
+    auto left_branch = [&]() -> Var { return lconv ? lbn->forward(lconv) : (left ? left->forward(x) : x); };
     // both branches end in a batch norm (every block of Cnn.resnet: the left branch is Conv2D 1x1 -> BatchNorm2D): one op for
     // relu(bn(right) + bn(left)) - the left batch norm's output is never written (LAMP_FUSE_BN_PAIR=0: the chain)
     static const bool fuse_pair = [] { const char* e = getenv("LAMP_FUSE_BN_PAIR"); return !(e && e[0] == '0'); }();
-    auto* lseq = left ? dynamic_cast<Sequential*>(left.get()) : nullptr;
-    BatchNorm* lbn = (lseq && !lseq->mods.empty()) ? dynamic_cast<BatchNorm*>(lseq->mods.back().get()) : nullptr;
     if (fuse_pair && lbn && bn->can_fuse_add_relu(v)) {
-      Sequential lhead(std::vector<Mod>(lseq->mods.begin(), lseq->mods.end() - 1));
-      Var lv = lhead.forward(x);
+      Var lv = lconv;
+      if (!lv) {
+        Sequential lhead(std::vector<Mod>(lseq->mods.begin(), lseq->mods.end() - 1));
+        lv = lhead.forward(x);
+      }
       if (lbn->can_fuse_add_relu(lv) && lv->shape() == v->shape() && lv->value.dtype() == v->value.dtype())
         return F::batch_norm2_add_relu_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps,
                                           lv, lbn->weight, lbn->bias, lbn->runningMean->value, lbn->runningVar->value, lbn->momentum, lbn->eps);
@@ -84,11 +102,11 @@ Var Residual::forward_relu(const Var& x) {
       return F::relu(F::add(bn->forward(v), l));
     }
     if (bn->can_fuse_add_relu(v)) {
-      Var l = left ? left->forward(x) : x;
+      Var l = left_branch();
       if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);
       return F::relu(F::add(bn->forward(v), l));
     }
-    Var l = left ? left->forward(x) : x;
+    Var l = left_branch();
     return F::relu(F::add(bn->forward(v), l));
   }
   return F::relu(forward(x));

@@ -661,9 +661,10 @@ Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& va
 }
 
 // ---- convolution / pooling (ops.scala:1547-1825) ------------------------------------------------
-Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
-                const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
-                const std::vector<int64_t>& outputPadding, int64_t groups) {
+// the Convolution node (ops.scala:1547-1651); `computed`, when given, is the forward value a fused launch has already produced
+static Var convolution_node(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
+                            const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
+                            const std::vector<int64_t>& outputPadding, int64_t groups, const Ten* computed) {
   auto op = new_op("Convolution");
   const int ns = (int)stride.size();
   Ten iv = input->value, wv = weight->value;
@@ -689,10 +690,33 @@ Var convolution(const Var& input, const Var& weight, const Var& bias, const std:
   op->params.push_back({input, back(0)});
   op->params.push_back({weight, back(1)});
   op->params.push_back({bias, back(2)});
+  if (computed) return make_result(op, *computed);
   lamp_tensor* o = nullptr;
   HCALL(lamp_convolution(&o, iv.h(), wv.h(), bias->value.h(), stride.data(), padding.data(), dilation.data(), ns, transposed,
                          outputPadding.data(), groups));
   return make_result(op, Ten(o));
+}
+Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
+                const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
+                const std::vector<int64_t>& outputPadding, int64_t groups) {
+  return convolution_node(input, weight, bias, stride, padding, dilation, transposed, outputPadding, groups, nullptr);
+}
+// Two Convolution nodes on ONE input (the two branches of Residual, cnn.scala:16-20) whose forward values come from one call: the graph, the
+// closures and every value are those of two `convolution` calls
+std::pair<Var, Var> convolution_pair(const Var& input, const Var& weight_a, const Var& bias_a, const std::vector<int64_t>& stride_a,
+                                     const std::vector<int64_t>& padding_a, const std::vector<int64_t>& dilation_a, const Var& weight_b,
+                                     const Var& bias_b, const std::vector<int64_t>& stride_b, const std::vector<int64_t>& padding_b,
+                                     const std::vector<int64_t>& dilation_b, int64_t groups) {
+  const int ns = (int)stride_a.size();
+  LAMP_CHECK(ns == (int)stride_b.size(), "convolution_pair: the two convolutions have different numbers of spatial dimensions");
+  lamp_tensor* o2[2] = {nullptr, nullptr};
+  HCALL(lamp_convolution_pair(o2, input->value.h(), weight_a->value.h(), bias_a->value.h(), stride_a.data(), padding_a.data(), dilation_a.data(),
+                              weight_b->value.h(), bias_b->value.h(), stride_b.data(), padding_b.data(), dilation_b.data(), ns, groups));
+  const Ten ya(o2[0]), yb(o2[1]);
+  const std::vector<int64_t> zero(ns, 0);
+  Var a = convolution_node(input, weight_a, bias_a, stride_a, padding_a, dilation_a, false, zero, groups, &ya);
+  Var b = convolution_node(input, weight_b, bias_b, stride_b, padding_b, dilation_b, false, zero, groups, &yb);
+  return {a, b};
 }
 Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding) {
   LAMP_CHECK(input->value.ndim() == 4, "Input dimensions must be 4");

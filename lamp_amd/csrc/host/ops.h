@@ -51,6 +51,10 @@ Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& va
 Var convolution(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                 const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
                 const std::vector<int64_t>& outputPadding, int64_t groups);
+std::pair<Var, Var> convolution_pair(const Var& input, const Var& weight_a, const Var& bias_a, const std::vector<int64_t>& stride_a,
+                                     const std::vector<int64_t>& padding_a, const std::vector<int64_t>& dilation_a, const Var& weight_b,
+                                     const Var& bias_b, const std::vector<int64_t>& stride_b, const std::vector<int64_t>& padding_b,
+                                     const std::vector<int64_t>& dilation_b, int64_t groups);
 Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding);
 Var max_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding, int64_t dilation);
 Var global_avg_pool_log_softmax(const Var& input);   // avg_pool2d(k = H = W) -> flatten -> log_softmax(1) in one launch, values of the chain

@@ -289,6 +289,8 @@ template <class T> static void launch_wgrad(const Tensor* dy, const Tensor* x, T
 
 // implemented in conv_igemm.hip; return true when they handled the request
 bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool igemm_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, const Tensor* w1, const Tensor* bias1,
+                         Tensor* y1, const ConvGeom& g1, hipStream_t st);
 // addend (optional): dx = round(round(dgrad) + addend) when the kernel chosen has that epilogue; *addend_fused reports whether it was used
 bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
                       bool* addend_fused = nullptr);
@@ -367,6 +369,40 @@ int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
     LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(xc.get(), wc.get(), bc.get(), y.get(), g, st)));
   }
   *out = y.take();
+  LAMP_API_END
+}
+
+int lamp_convolution_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp_tensor* w_a, const lamp_tensor* bias_a, const int64_t* stride_a,
+                          const int64_t* padding_a, const int64_t* dilation_a, const lamp_tensor* w_b, const lamp_tensor* bias_b,
+                          const int64_t* stride_b, const int64_t* padding_b, const int64_t* dilation_b, int nspatial, int64_t groups) {
+  LAMP_API_BEGIN
+  out2[0] = out2[1] = nullptr;
+  check_device_tensor(x, "input"); check_device_tensor(w_a, "weight a"); check_device_tensor(w_b, "weight b");
+  const int64_t zero2[2] = {0, 0};
+  bool fused = false;
+  if (nspatial == 2 && x->dtype == w_a->dtype && x->dtype == w_b->dtype && x->dtype == kBF16 && (!bias_a || bias_a->is_device()) && (!bias_b || bias_b->is_device())) {
+    ConvGeom ga = make_geom(x, w_a, stride_a, padding_a, dilation_a, nspatial, 0, zero2, groups);
+    ConvGeom gb = make_geom(x, w_b, stride_b, padding_b, dilation_b, nspatial, 0, zero2, groups);
+    const bool biases_ok = (!bias_a || (bias_a->numel() == ga.Cout && bias_a->dtype == x->dtype)) && (!bias_b || (bias_b->numel() == gb.Cout && bias_b->dtype == x->dtype));
+    if (biases_ok && ga.Ho == gb.Ho && ga.Wo == gb.Wo) {
+      Hold xc(contiguous(x)), wa(contiguous(w_a)), wb(contiguous(w_b));
+      Hold ba(bias_a ? contiguous(bias_a) : nullptr), bb(bias_b ? contiguous(bias_b) : nullptr);
+      Hold ya(new_tensor({ga.N, ga.Cout, ga.Ho, ga.Wo}, x->dtype, x->device())), yb(new_tensor({gb.N, gb.Cout, gb.Ho, gb.Wo}, x->dtype, x->device()));
+      hipStream_t st = current_stream(x->device());
+      if (igemm_conv_fwd_pair(xc.get(), wa.get(), ba.get(), ya.get(), ga, wb.get(), bb.get(), yb.get(), gb, st)) {
+        out2[0] = ya.take(); out2[1] = yb.take();
+        fused = true;
+      }
+    }
+  }
+  if (!fused) {                                       // the two calls (each validates its own arguments)
+    lamp_tensor* a = nullptr;
+    if (lamp_convolution(&a, x, w_a, bias_a, stride_a, padding_a, dilation_a, nspatial, 0, zero2, groups) != 0) throw Error(lamp_last_error());
+    Hold ha(a);
+    lamp_tensor* b = nullptr;
+    if (lamp_convolution(&b, x, w_b, bias_b, stride_b, padding_b, dilation_b, nspatial, 0, zero2, groups) != 0) throw Error(lamp_last_error());
+    out2[0] = ha.take(); out2[1] = b;
+  }
   LAMP_API_END
 }
 

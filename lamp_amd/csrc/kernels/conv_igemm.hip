@@ -705,10 +705,52 @@ __device__ unsigned long long ig8d_rt_stamps[8 * 512];      // the constant 100 
 // (4 (w & 3) + chunk') mod 16 the 16 pixels of an MFMA tile (two rows x eight columns) read 16 different slots
 __device__ __forceinline__ int ig8d_swz(int h, int w) { return ((h & 1) << 1) | ((w >> 2) & 1); }
 
-template <int KS, int NCT>
+// mean and M2 of the 64 bf16-ROUNDED values of one (image, channel) held as pk[4] by the four lanes q = lane >> 4 of the channel: packed f32
+// math on sums shifted by the lane's first value, then two equal-count merges over the lanes (xor 16, 32) without divisions.
+// 8 waves x 8 tiles of this is pure vector-issue time (measured: 10.7k of the kernel's 69k cycles with the per-value Welford form).
+__device__ __forceinline__ void ig8d_tile_stats(const uint2 (&pk)[4], float& mean, float& m2) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  const float sh = __uint_as_float(pk[0].x << 16);
+  const f2v sh2 = {sh, sh};
+  f2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const f2v va = {__uint_as_float(pk[j].x << 16), __uint_as_float(pk[j].x & 0xffff0000u)};
+    const f2v vb = {__uint_as_float(pk[j].y << 16), __uint_as_float(pk[j].y & 0xffff0000u)};
+    const f2v da = va - sh2, db = vb - sh2;
+    s1 += da; s2 = __builtin_elementwise_fma(da, da, s2);
+    s1 += db; s2 = __builtin_elementwise_fma(db, db, s2);
+  }
+  const float t1 = s1[0] + s1[1], t2 = s2[0] + s2[1];
+  mean = sh + t1 * (1.f / 16.f); m2 = t2 - t1 * t1 * (1.f / 16.f);
+  // merge over the four lanes that hold the channel (xor 16, 32): equal counts n, so mean' = mean + d / 2, M2' = M2a + M2b + d^2 n / 2
+  // (v_permlane16/32_swap leave {own, partner} in {a, b} in an order that depends on the lane: the merge is written on (a, b);
+  // lanes may differ in the last bit, only lane q == 0 publishes)
+  {
+    float ma = mean, mb = mean, qa = m2, qb = m2;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+    const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 8.f;
+  }
+  {
+    float ma = mean, mb = mean, qa = m2, qb = m2;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+    const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 16.f;
+  }
+}
+
+// The SIBLING of a 3x3 convolution (SIB instantiations): a 1x1 convolution of the SAME input with as many output channels - the shortcut of
+// lamp's residual block, whose two branches both start with a Conv2D on the block's input (cnn.scala:16-20, 38-78).  Its product is a second,
+// 1/9-length main loop over the images that are already in LDS (centre tap only), run BEFORE the 3x3 product because the 3x3 epilogue
+// overwrites the images; it saves the 1x1 launch with its own image burst (33.5 MB for res4), prologue and ramp.
+struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; };
+
+template <int KS, int NCT, bool SIB>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg,
-                                                        const bf16_t* addend, const float4* __restrict__ affine) {
+                                                        const bf16_t* addend, const float4* __restrict__ affine, const IgSibling sib) {
+  static_assert(!SIB || KS == 3, "the sibling product is the centre tap of a 3x3 staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -732,16 +774,24 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   typedef const __attribute__((address_space(1))) char glb_char_t;
   // stage (kc, rs): rows = output channels, k = input channels [32 kc, 32 kc + 32) of tap rs; one 1 KiB piece (16 rows) per wave
   const int d_row = wid * 16 + (lane >> 2);
-  const int d_src = d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3);
-  auto stage_dma = [&](int kc1, int rs1, int slot) {
+  // the lane's BYTE offset inside a stage, unsigned: uniform base + zero-extended 32-bit offset is the saddr + voffset form of the load (one
+  // VGPR); as a signed element index the compiler kept one 64-bit address pair per tap in registers (18 VGPRs beside 128 accumulators)
+  const unsigned d_src = (unsigned)(d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3)) * 2u;
+  auto stage_dma_of = [&](const bf16_t* wimg, int kc1, int rs1, int slot) {
     if (wid < NCT) {                          // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
-      const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + kc1 * 32;
+      const char* base = reinterpret_cast<const char*>(wimg + (int64_t)rs1 * IG_M * KP + kc1 * 32);
       __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
     }
   };
+  auto stage_dma = [&](int kc1, int rs1, int slot) { stage_dma_of(wp, kc1, rs1, slot); };
   IG_STAMP(0);
-  stage_dma(0, 0, 0);
-  if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+  if (SIB) {                                  // the sibling's stages (one tap: stage = 32-channel chunk) come first
+    stage_dma_of(sib.wp, 0, 0, 0);
+    if (KC > 1) stage_dma_of(sib.wp, 1, 0, 1);
+  } else {
+    stage_dma(0, 0, 0);
+    if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+  }
   IG_STAMP(1);
   // NCHW -> [pixel][32 channels].  A thread takes 8 channels x one image row: eight coalesced 16-byte loads, an 8x8 transposition of the
   // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).
@@ -815,6 +865,119 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // closing READ(t), which both groups pass before anyone starts READ(t+1).
   bf8v fa[NCT], fb[4];
   const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
+  if constexpr (SIB) {
+    // ---- sibling product: KC stages of the centre tap, same ring and phases
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int sslot = 0;
+    for (int kc = 0; kc < KC; kc++) {
+      const char* wl = Wl + sslot * WT + a_off;
+      const int slot1 = sslot == 2 ? 0 : sslot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if (kc + 2 < KC) stage_dma_of(sib.wp, kc + 2, 0, slot2);
+#pragma unroll
+      for (int i = 0; i < NCT; i++) fa[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 1024));
+      const char* xb = Xl + kc * XBUF + va[PAD & 1][PAD];
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((PAD * 8 + PAD) + 16 * j) * RB));
+      if (kc + 2 < KC) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NCT; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      sslot = slot1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // every wave has read its last weight stage: the ring is free
+    // The 3x3 product's first stage is requested now (slot 0) and lands during this epilogue, which goes through 2 KiB of slots 1 - 2 per
+    // wave, one channel tile at a time (the images must stay): [16 channels][64 pixels] rows written as the MFMA leaves them, read back as
+    // 16-byte chunks, stored as whole 128-byte rows - the same bytes and statistics as the kernel's own epilogue produces.
+    stage_dma(0, 0, 0);
+    {
+      const int n = n0 + wid;
+      char* Sc = Wl + WT + wid * 2048;
+      const int q = lane >> 4;
+      const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+      unsigned bpair[(NCT + 1) / 2];                  // bias of tiles 2k, 2k + 1 in one register (this epilogue runs beside 128 live accumulators)
+#pragma unroll
+      for (int k = 0; k < (NCT + 1) / 2; k++) {
+        const int c0 = 2 * k * 16 + (lane & 15), c1 = c0 + 16;
+        const unsigned b0 = (sib.bias && c0 < CO) ? sib.bias[c0].bits : 0u, b1 = (sib.bias && 2 * k + 1 < NCT && c1 < CO) ? sib.bias[c1].bits : 0u;
+        bpair[k] = b0 | (b1 << 16);
+      }
+      // statistics of tile i wait in lane group q = i & 3 of register i >> 2 (NCT separate registers beside 128 accumulators spilled);
+      // every group gets group 0's bits - the value the kernel's own epilogue publishes (the merges differ in the last bit between lanes)
+      float smean[(NCT + 3) / 4], sm2[(NCT + 3) / 4];
+#pragma unroll
+      for (int k = 0; k < (NCT + 3) / 4; k++) { smean[k] = 0.f; sm2[k] = 0.f; }
+      bf16_t* yp = sib.y + (int64_t)n * CO * 64;
+#pragma unroll
+      for (int i = 0; i < NCT; i++) {
+        const int cl = lane & 15;
+        const float b = __uint_as_float((i & 1) ? (bpair[i >> 1] & 0xffff0000u) : (bpair[i >> 1] << 16));
+        uint2 pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const f2v lo = {acc[i][j][0] + b, acc[i][j][1] + b}, hi = {acc[i][j][2] + b, acc[i][j][3] + b};
+          pk[j].x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2v));
+          pk[j].y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2v));
+          const int sl = (2 * j + qrow) * 2 + (qw >> 2);
+          *reinterpret_cast<uint2*>(Sc + cl * 128 + ((sl ^ ((cl & 7) << 1)) << 3)) = pk[j];
+          acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};         // the 3x3 product starts from zero
+        }
+        if (sib.stats) {
+          float mean, m2;
+          ig8d_tile_stats(pk, mean, m2);
+          mean = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 15) << 2, __builtin_bit_cast(int, mean)));
+          m2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 15) << 2, __builtin_bit_cast(int, m2)));
+          if (q == (i & 3)) { smean[i >> 2] = mean; sm2[i >> 2] = m2; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+          const int idx = it * 64 + lane;
+          const int cr = idx >> 3, c = idx & 7, co = i * 16 + cr;
+          const uint4 v = *reinterpret_cast<const uint4*>(Sc + cr * 128 + ((c ^ (cr & 7)) << 4));
+          if (co < CO && n < N) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
+        }
+      }
+      if (sib.stats) {
+        if (stats_per_wg) {
+          // the eight images' (mean, M2) of every channel meet in the scratch area (1 KiB of float2 per wave), one triple per workgroup leaves
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < (NCT + 3) / 4; k++)
+            if (4 * k + q < NCT) reinterpret_cast<float2*>(Sc)[(4 * k + q) * 16 + (lane & 15)] = make_float2(smean[k], sm2[k]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (tid < NCT * 16 && tid < CO) {
+            const float2* sl = reinterpret_cast<const float2*>(Wl + WT) + tid;
+            const float shift = sl[0].x;
+            float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) { const float2 v = sl[w * 256]; const float d = v.x - shift; s1 += d; s2 += d * d; sm += v.y; }
+            float* sp = sib.stats + ((int64_t)tid * gridDim.x + blockIdx.x) * 3;
+            sp[0] = 512.f; sp[1] = shift + s1 * 0.125f; sp[2] = sm + 64.f * (s2 - s1 * s1 * 0.125f);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < (NCT + 3) / 4; k++) {
+            const int co = (4 * k + q) * 16 + (lane & 15);
+            if (4 * k + q < NCT && co < CO && n < N) { float* sp = sib.stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = smean[k]; sp[2] = sm2[k]; }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // nobody reads the scratch area any more: slots 1 - 2 belong to the ring again
+    if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0 and 1 (and this wave's sibling stores, which share the counter)
+    __builtin_amdgcn_s_barrier();
+  }
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int t = 0, slot = 0;
   for (int kc = 0; kc < KC; kc++) {
@@ -863,9 +1026,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   char* El = smem + wid * 16384;
   const int q = lane >> 4;
   const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
-  // 8 waves x 8 tiles of epilogue arithmetic is pure vector-issue time (measured: 10.7k of the kernel's 69k cycles with the per-value
-  // Welford form): the statistics use packed f32 math on shifted sums, merge the four lanes of a channel without divisions (equal
-  // counts: the same values as ig_stats_merge gives), and are skipped altogether when nobody asked for them (dgrad)
+  // the statistics (ig8d_tile_stats) are skipped altogether when nobody asked for them (dgrad)
   typedef float f2v __attribute__((ext_vector_type(2)));
   // every tile's bias value requested up front: one memory round trip instead of one per tile (a load inside the tile loop also made
   // every tile wait for the previous tile's statistics stores: vmcnt counts loads and stores in one queue)
@@ -891,35 +1052,8 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       *reinterpret_cast<uint2*>(El + co * 128 + ((sl ^ ((co & 7) << 1)) << 3)) = pk[j];
     }
     if (stats) {                              // one partial per image: the batch norm that follows merges them (norm.hip)
-      // the 16 bf16-ROUNDED values of this lane as f32 pairs (low half << 16, high half masked), shifted by the first one
-      const float sh = __uint_as_float(pk[0].x << 16);
-      const f2v sh2 = {sh, sh};
-      f2v s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const f2v va = {__uint_as_float(pk[j].x << 16), __uint_as_float(pk[j].x & 0xffff0000u)};
-        const f2v vb = {__uint_as_float(pk[j].y << 16), __uint_as_float(pk[j].y & 0xffff0000u)};
-        const f2v da = va - sh2, db = vb - sh2;
-        s1 += da; s2 = __builtin_elementwise_fma(da, da, s2);
-        s1 += db; s2 = __builtin_elementwise_fma(db, db, s2);
-      }
-      const float t1 = s1[0] + s1[1], t2 = s2[0] + s2[1];
-      float mean = sh + t1 * (1.f / 16.f), m2 = t2 - t1 * t1 * (1.f / 16.f);
-      // merge over the four lanes that hold the channel (xor 16, 32): equal counts n, so mean' = mean + d / 2, M2' = M2a + M2b + d^2 n / 2
-      // (v_permlane16/32_swap leave {own, partner} in {a, b} in an order that depends on the lane: the merge is written on (a, b);
-      // lanes may differ in the last bit, only lane q == 0 publishes)
-      {
-        float ma = mean, mb = mean, qa = m2, qb = m2;
-        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
-        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-        const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 8.f;
-      }
-      {
-        float ma = mean, mb = mean, qa = m2, qb = m2;
-        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
-        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-        const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 16.f;
-      }
+      float mean, m2;
+      ig8d_tile_stats(pk, mean, m2);
       if (stats_per_wg) {                       // one triple per WORKGROUP (host: N % 8 == 0): the eight images' triples meet in LDS below
         if (q == 0) { float2* sl = reinterpret_cast<float2*>(smem + 8 * 16384) + wid * 128 + co; *sl = make_float2(mean, m2); }
       } else if (q == 0 && co < CO && n < N) { float* sp = stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = mean; sp[2] = m2; }
@@ -1313,7 +1447,7 @@ struct PackKey {
   uint64_t uid; int64_t offset; int KS, Cout, Cin; hipStream_t st;
   bool operator<(const PackKey& o) const { return std::tie(uid, offset, KS, Cout, Cin, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.st); }
 };
-struct PackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+struct PackVal { uint64_t version; Tensor* packed; uint64_t tick; bool pinned = false; };   // pinned: a captured HIP graph reads this image's address
 std::mutex g_pack_mu;
 std::map<PackKey, PackVal> g_pack_cache;
 uint64_t g_pack_tick = 0;
@@ -1335,6 +1469,7 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
     auto it = g_pack_cache.find(key);
     if (it != g_pack_cache.end() && it->second.version == ver) {
       it->second.tick = ++g_pack_tick;
+      if (allocator_capturing()) it->second.pinned = true;   // the graph being captured records this address: never evict the entry
       return retain(it->second.packed);
     }
   }
@@ -1347,13 +1482,13 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
     std::lock_guard<std::mutex> lk(g_pack_mu);
     auto it = g_pack_cache.find(key);
     if (it != g_pack_cache.end()) { release(it->second.packed); g_pack_cache.erase(it); }
-    if (g_pack_cache.size() >= 256) {           // evict the least recently used entry
-      auto victim = g_pack_cache.begin();
-      for (auto i = g_pack_cache.begin(); i != g_pack_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
-      release(victim->second.packed);
-      g_pack_cache.erase(victim);
+    if (g_pack_cache.size() >= 256) {           // evict the least recently used entry that no captured graph reads
+      auto victim = g_pack_cache.end();
+      for (auto i = g_pack_cache.begin(); i != g_pack_cache.end(); ++i)
+        if (!i->second.pinned && (victim == g_pack_cache.end() || i->second.tick < victim->second.tick)) victim = i;
+      if (victim != g_pack_cache.end()) { release(victim->second.packed); g_pack_cache.erase(victim); }
     }
-    g_pack_cache[key] = PackVal{ver, retain(wp.get()), ++g_pack_tick};
+    g_pack_cache[key] = PackVal{ver, retain(wp.get()), ++g_pack_tick, allocator_capturing()};
   }
   return wp.take();
 }
@@ -1369,7 +1504,14 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
   int cnt = 0, maxtotal = 0;
   std::vector<std::pair<PackKey, uint64_t>> done;       // (entry, storage version its image now corresponds to)
   std::lock_guard<std::mutex> lk(g_pack_mu);
-  for (int i = 0; i < n && cnt < IG_PACK_MAX; i++) {
+  auto flush = [&] {                                    // one launch per IG_PACK_MAX images (the loop used to STOP there, and a
+    if (cnt == 0) return;                               // replayed graph that had captured a cache hit kept reading the stale image)
+    hipLaunchKernelGGL(ig_pack_weights_many_kernel, dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
+    LAMP_LAUNCH_CHECK();
+    cnt = 0; maxtotal = 0;
+  };
+  for (int i = 0; i < n; i++) {
+    if (cnt == IG_PACK_MAX) flush();
     const Tensor* w = params[i];
     if (!w || !w->is_device() || w->dtype != kBF16 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
     for (auto& kv : g_pack_cache) {
@@ -1388,9 +1530,7 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
       break;
     }
   }
-  if (cnt == 0) return;
-  hipLaunchKernelGGL(ig_pack_weights_many_kernel, dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
-  LAMP_LAUNCH_CHECK();
+  flush();
   for (auto& d : done) {
     auto it = g_pack_cache.find(d.first);
     if (it != g_pack_cache.end()) { it->second.version = d.second; it->second.tick = ++g_pack_tick; }
@@ -1401,10 +1541,15 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
 // affine (fprop, optional): f32 [Cin][4] = (mean, invstd * weight, bias, -) of the batch norm + relu that stands between the producer of
 // `in` and this convolution; applied while staging where the kernel chosen can do it - *affine_used says whether it did (else the caller
 // materialises relu(bn(in)) and calls again without it)
+// sibling (fprop of a 3x3, optional): a 1x1 convolution of the same input with the same number of output channels, computed by the same launch
+// where the eight-image kernel runs - *sibling_fused says whether it did (else the caller runs it as its own convolution)
+struct SiblingConv { const Tensor* w; const Tensor* bias; Tensor* out; const ConvGeom* g; };
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
-                      const Tensor* addend = nullptr, bool* addend_fused = nullptr, const Tensor* affine = nullptr, bool* affine_used = nullptr) {
+                      const Tensor* addend = nullptr, bool* addend_fused = nullptr, const Tensor* affine = nullptr, bool* affine_used = nullptr,
+                      const SiblingConv* sibling = nullptr, bool* sibling_fused = nullptr) {
   if (addend_fused) *addend_fused = false;
   if (affine_used) *affine_used = false;
+  if (sibling_fused) *sibling_fused = false;
   const int KS = g.kh, RS = KS * KS;
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
@@ -1441,18 +1586,40 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         const size_t ldsd = std::max<size_t>((size_t)3 * (128 * 32 * 2) + (size_t)((CI + 31) / 32) * 8 * 4096 + (KS == 3 ? 9 * 64 : 0), (size_t)8 * 16384 + 8 * 128 * 8);
         const int per_wg = (statp && g.N % 8 == 0) ? 1 : 0;
         if (per_wg) publish.P = blocksd;
-#define IG_LAUNCH_D(KS_, NCT_)                                                                                                              \
+#define IG_LAUNCH_D(KS_, NCT_, SIB_)                                                                                                        \
   do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_>);                                                                               \
-    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp, per_wg, addp, affp);                                                                   \
+    allow_big_lds((const void*)ig_conv8d_kernel<KS_, NCT_, SIB_>);                                                                         \
+    hipLaunchKernelGGL((ig_conv8d_kernel<KS_, NCT_, SIB_>), dim3(blocksd), dim3(512), ldsd, st, in->ptr<bf16_t>(), wpp, bpb,               \
+                       out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, per_wg, addp, affp, sibk);                                         \
   } while (0)
         const bf16_t* addp = addend ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
         const float4* affp = affine ? reinterpret_cast<const float4*>(affine->ptr<float>()) : (const float4*)nullptr;
         if (affine_used) *affine_used = affine != nullptr;
         if (addend_fused) *addend_fused = addend != nullptr;
-        if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1); else if (CO <= 64) IG_LAUNCH_D(3, 4); else if (CO <= 112) IG_LAUNCH_D(3, 7); else IG_LAUNCH_D(3, 8); }
-        else { if (CO <= 16) IG_LAUNCH_D(1, 1); else if (CO <= 64) IG_LAUNCH_D(1, 4); else if (CO <= 112) IG_LAUNCH_D(1, 7); else IG_LAUNCH_D(1, 8); }
+        // the sibling 1x1 of a residual block's first 3x3 (same input, same output channels): second product of this launch
+        static const bool sib_on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
+        IgSibling sibk{nullptr, nullptr, nullptr, nullptr};
+        Hold sib_wpk, sib_statt;
+        const bool sib = sib_on && sibling && !dgrad && KS == 3 && !addend && sibling->g->kh == 1 && sibling->g->Cout == g.Cout &&
+                         sibling->g->Cin == g.Cin && sibling->g->N == g.N;
+        struct PublishSib { Hold& t; const Tensor* y; int P; ~PublishSib() { if (t.get()) conv_stats_publish(y, t.get(), P); } }
+            publish_sib{sib_statt, sib ? sibling->out : nullptr, per_wg ? blocksd : (int)g.N};
+        if (sib) {
+          int64_t off1 = 0;
+          sib_wpk = Hold(packed_weights(sibling->w, *sibling->g, 1, st, &off1));
+          sibk.wp = static_cast<const Tensor*>(sib_wpk.get())->ptr<bf16_t>();
+          sibk.bias = sibling->bias ? sibling->bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+          sibk.y = sibling->out->ptr<bf16_t>();
+          if (statp) {
+            int64_t ps[1] = {(int64_t)g.N * CO * 3};
+            sib_statt = Hold(new_tensor(ps, 1, kF32, in->device()));
+            sibk.stats = sib_statt->ptr<float>();
+          }
+          if (sibling_fused) *sibling_fused = true;
+        }
+        if (sib) { if (CO <= 16) IG_LAUNCH_D(3, 1, true); else if (CO <= 64) IG_LAUNCH_D(3, 4, true); else if (CO <= 112) IG_LAUNCH_D(3, 7, true); else IG_LAUNCH_D(3, 8, true); }
+        else if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1, false); else if (CO <= 64) IG_LAUNCH_D(3, 4, false); else if (CO <= 112) IG_LAUNCH_D(3, 7, false); else IG_LAUNCH_D(3, 8, false); }
+        else { if (CO <= 16) IG_LAUNCH_D(1, 1, false); else if (CO <= 64) IG_LAUNCH_D(1, 4, false); else if (CO <= 112) IG_LAUNCH_D(1, 7, false); else IG_LAUNCH_D(1, 8, false); }
 #undef IG_LAUNCH_D
         LAMP_LAUNCH_CHECK();
         return;
@@ -1508,6 +1675,23 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
 bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
   if (!ig_qualifies(g, x->dtype)) return false;
   run_conv8(x, w, bias, y, g, false, st);
+  return true;
+}
+static bool ig_fwd_folds_affine(const ConvGeom& g, int dtype);
+// y = conv3x3(x, w, bias) and y1 = conv1x1(x, w1, bias1) - two convolutions of ONE input with the same number of output channels (the two
+// branches of lamp's residual block, cnn.scala:16-20) - in one launch of the eight-image kernel: false (nothing launched) when that kernel
+// does not take the geometry; the values of both outputs and of the statistics hand-offs are those of the two separate launches
+bool igemm_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, const Tensor* w1, const Tensor* bias1,
+                         Tensor* y1, const ConvGeom& g1, hipStream_t st) {
+  if (!ig_qualifies(g, x->dtype) || !ig_qualifies(g1, x->dtype) || g.kh != 3 || g1.kh != 1) return false;
+  if (g.Cout != g1.Cout || g.Cin != g1.Cin || g.N != g1.N) return false;
+  if (!ig_fwd_folds_affine(g, x->dtype)) return false;                 // (= the eight-image kernel's conditions)
+  static const bool sib_on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
+  if (!sib_on) return false;
+  const SiblingConv sc{w1, bias1, y1, &g1};
+  bool fused = false;
+  run_conv8(x, w, bias, y, g, false, st, nullptr, nullptr, nullptr, nullptr, &sc, &fused);
+  LAMP_CHECK(fused, "internal: the eight-image kernel did not take the sibling convolution");
   return true;
 }
 // y = conv(relu(bn(x))) with the batch norm given as its per-channel table: true only if a kernel that applies it while staging ran

@@ -497,7 +497,7 @@ struct PackKey32 {
   uint64_t uid; int64_t offset; int KS, Cout, Cin, dtype; hipStream_t st;
   bool operator<(const PackKey32& o) const { return std::tie(uid, offset, KS, Cout, Cin, dtype, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.dtype, o.st); }
 };
-struct PackVal32 { uint64_t version; Tensor* packed; uint64_t tick; };
+struct PackVal32 { uint64_t version; Tensor* packed; uint64_t tick;  bool pinned = false; };
 std::mutex g_pack32_mu;
 std::map<PackKey32, PackVal32> g_pack32_cache;
 uint64_t g_pack32_tick = 0;
@@ -525,6 +525,7 @@ static Tensor* packed_weights32(const Tensor* w, const ConvGeom& g, int KS, hipS
     auto it = g_pack32_cache.find(key);
     if (it != g_pack32_cache.end() && it->second.version == ver) {
       it->second.tick = ++g_pack32_tick;
+      if (allocator_capturing()) it->second.pinned = true;
       return retain(it->second.packed);
     }
   }
@@ -536,13 +537,13 @@ static Tensor* packed_weights32(const Tensor* w, const ConvGeom& g, int KS, hipS
     std::lock_guard<std::mutex> lk(g_pack32_mu);
     auto it = g_pack32_cache.find(key);
     if (it != g_pack32_cache.end()) { release(it->second.packed); g_pack32_cache.erase(it); }
-    if (g_pack32_cache.size() >= 256) {
-      auto victim = g_pack32_cache.begin();
-      for (auto i = g_pack32_cache.begin(); i != g_pack32_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
-      release(victim->second.packed);
-      g_pack32_cache.erase(victim);
+    if (g_pack32_cache.size() >= 256) {         // least recently used entry that no captured graph reads
+      auto victim = g_pack32_cache.end();
+      for (auto i = g_pack32_cache.begin(); i != g_pack32_cache.end(); ++i)
+        if (!i->second.pinned && (victim == g_pack32_cache.end() || i->second.tick < victim->second.tick)) victim = i;
+      if (victim != g_pack32_cache.end()) { release(victim->second.packed); g_pack32_cache.erase(victim); }
     }
-    g_pack32_cache[key] = PackVal32{ver, retain(wp.get()), ++g_pack32_tick};
+    g_pack32_cache[key] = PackVal32{ver, retain(wp.get()), ++g_pack32_tick, allocator_capturing()};
   }
   return wp.take();
 }
@@ -553,7 +554,14 @@ template <class T> static void repack_cached_t(lamp_tensor* const* params, int n
   PackManyT<T> a;
   int cnt = 0, maxtotal = 0;
   std::vector<std::pair<PackKey32, uint64_t>> done;
-  for (int i = 0; i < n && cnt < F_PACK_MAX; i++) {
+  auto flush = [&] {                                    // one launch per F_PACK_MAX images; the loop goes on (it used to stop)
+    if (cnt == 0) return;
+    hipLaunchKernelGGL((ig32_pack_weights_many_kernel<T>), dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
+    LAMP_LAUNCH_CHECK();
+    cnt = 0; maxtotal = 0;
+  };
+  for (int i = 0; i < n; i++) {
+    if (cnt == F_PACK_MAX) flush();
     const Tensor* w = params[i];
     if (!w || !w->is_device() || w->dtype != dtype || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
     for (auto& kv : g_pack32_cache) {
@@ -570,9 +578,7 @@ template <class T> static void repack_cached_t(lamp_tensor* const* params, int n
       break;
     }
   }
-  if (cnt == 0) return;
-  hipLaunchKernelGGL((ig32_pack_weights_many_kernel<T>), dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)cnt), dim3(256), 0, st, a);
-  LAMP_LAUNCH_CHECK();
+  flush();
   for (auto& d : done) {
     auto it = g_pack32_cache.find(d.first);
     if (it != g_pack32_cache.end()) { it->second.version = d.second; it->second.tick = ++g_pack32_tick; }

@@ -698,7 +698,7 @@ struct NcvPackKey {
     return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, ns, sw, st) < std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.ns, o.sw, o.st);
   }
 };
-struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick;  bool pinned = false; };
 std::mutex g_ncv_mu;
 std::map<NcvPackKey, NcvPackVal> g_ncv_cache;
 uint64_t g_ncv_tick = 0;
@@ -721,6 +721,7 @@ static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t s
     auto it = g_ncv_cache.find(key);
     if (it != g_ncv_cache.end() && it->second.version == ver) {
       it->second.tick = ++g_ncv_tick;
+      if (allocator_capturing()) it->second.pinned = true;       // a graph being captured records this address: never evict the entry
       return retain(it->second.packed);
     }
   }
@@ -733,13 +734,13 @@ static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t s
     std::lock_guard<std::mutex> lk(g_ncv_mu);
     auto it = g_ncv_cache.find(key);
     if (it != g_ncv_cache.end()) { release(it->second.packed); g_ncv_cache.erase(it); }
-    if (g_ncv_cache.size() >= 256) {           // evict the least recently used entry
-      auto victim = g_ncv_cache.begin();
-      for (auto i = g_ncv_cache.begin(); i != g_ncv_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
-      release(victim->second.packed);
-      g_ncv_cache.erase(victim);
+    if (g_ncv_cache.size() >= 256) {           // evict the least recently used entry that no captured graph reads
+      auto victim = g_ncv_cache.end();
+      for (auto i = g_ncv_cache.begin(); i != g_ncv_cache.end(); ++i)
+        if (!i->second.pinned && (victim == g_ncv_cache.end() || i->second.tick < victim->second.tick)) victim = i;
+      if (victim != g_ncv_cache.end()) { release(victim->second.packed); g_ncv_cache.erase(victim); }
     }
-    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick};
+    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick, allocator_capturing()};
   }
   return wp.take();
 }

@@ -296,7 +296,7 @@ struct Cs2PackKey {
   uint64_t uid; int64_t offset; int KS, Cout, Cin, dtype; hipStream_t st;
   bool operator<(const Cs2PackKey& o) const { return std::tie(uid, offset, KS, Cout, Cin, dtype, st) < std::tie(o.uid, o.offset, o.KS, o.Cout, o.Cin, o.dtype, o.st); }
 };
-struct Cs2PackVal { uint64_t version; Tensor* packed; uint64_t tick; };
+struct Cs2PackVal { uint64_t version; Tensor* packed; uint64_t tick;  bool pinned = false; };
 std::mutex g_cs2_mu;
 std::map<Cs2PackKey, Cs2PackVal> g_cs2_cache;
 uint64_t g_cs2_tick = 0;
@@ -311,7 +311,11 @@ template <class T, class A> static Tensor* cs2_packed(const Tensor* w, const Con
   if (cacheable) {
     std::lock_guard<std::mutex> lk(g_cs2_mu);
     auto it = g_cs2_cache.find(key);
-    if (it != g_cs2_cache.end() && it->second.version == ver) { it->second.tick = ++g_cs2_tick; return retain(it->second.packed); }
+    if (it != g_cs2_cache.end() && it->second.version == ver) {
+      it->second.tick = ++g_cs2_tick;
+      if (allocator_capturing()) it->second.pinned = true;
+      return retain(it->second.packed);
+    }
   }
   int64_t ps[1] = {nf + nd};
   Hold wf(new_tensor(ps, 1, std::is_same<A, float>::value ? kF32 : kF64, w->device()));
@@ -323,13 +327,13 @@ template <class T, class A> static Tensor* cs2_packed(const Tensor* w, const Con
     std::lock_guard<std::mutex> lk(g_cs2_mu);
     auto it = g_cs2_cache.find(key);
     if (it != g_cs2_cache.end()) { release(it->second.packed); g_cs2_cache.erase(it); }
-    if (g_cs2_cache.size() >= 64) {
-      auto victim = g_cs2_cache.begin();
-      for (auto i = g_cs2_cache.begin(); i != g_cs2_cache.end(); ++i) if (i->second.tick < victim->second.tick) victim = i;
-      release(victim->second.packed);
-      g_cs2_cache.erase(victim);
+    if (g_cs2_cache.size() >= 64) {             // least recently used entry that no captured graph reads
+      auto victim = g_cs2_cache.end();
+      for (auto i = g_cs2_cache.begin(); i != g_cs2_cache.end(); ++i)
+        if (!i->second.pinned && (victim == g_cs2_cache.end() || i->second.tick < victim->second.tick)) victim = i;
+      if (victim != g_cs2_cache.end()) { release(victim->second.packed); g_cs2_cache.erase(victim); }
     }
-    g_cs2_cache[key] = Cs2PackVal{ver, retain(wf.get()), ++g_cs2_tick};
+    g_cs2_cache[key] = Cs2PackVal{ver, retain(wf.get()), ++g_cs2_tick, allocator_capturing()};
   }
   return wf.take();
 }
@@ -340,7 +344,14 @@ template <class T, class A> static void cs2_repack_t(lamp_tensor* const* params,
   Cs2PackMany pm;
   int cnt = 0;
   std::vector<std::pair<Cs2PackKey, uint64_t>> done;
-  for (int i = 0; i < n && cnt < CS2_PACK_MAX; i++) {
+  auto flush = [&] {                                    // one launch per CS2_PACK_MAX images; the loop goes on (it used to stop)
+    if (cnt == 0) return;
+    hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3(16u, (unsigned)cnt), dim3(256), 0, st, pm);
+    LAMP_LAUNCH_CHECK();
+    cnt = 0;
+  };
+  for (int i = 0; i < n; i++) {
+    if (cnt == CS2_PACK_MAX) flush();
     const Tensor* w = params[i];
     if (!w || !w->is_device() || w->dtype != dtype || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
     for (auto& kv : g_cs2_cache) {
@@ -354,9 +365,7 @@ template <class T, class A> static void cs2_repack_t(lamp_tensor* const* params,
       break;
     }
   }
-  if (cnt == 0) return;
-  hipLaunchKernelGGL((cs2_pack_kernel<T, A>), dim3(16u, (unsigned)cnt), dim3(256), 0, st, pm);
-  LAMP_LAUNCH_CHECK();
+  flush();
   for (auto& d : done) {
     auto it = g_cs2_cache.find(d.first);
     if (it != g_cs2_cache.end()) { it->second.version = d.second; it->second.tick = ++g_cs2_tick; }

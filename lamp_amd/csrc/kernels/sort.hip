@@ -18,6 +18,7 @@ constexpr int SORT_CH = 2048;       // pairs a workgroup sorts in LDS
 template <class T> __device__ __forceinline__ uint64_t sort_key_of(T v);
 template <> __device__ __forceinline__ uint64_t sort_key_of<double>(double v) {
   if (v != v) return ~0ull;
+  if (v == 0.0) v = 0.0;                      // -0.0 == +0.0 for ATen's comparisons: one key (a stable sort keeps their order, unique counts them once)
   const uint64_t b = (uint64_t)__double_as_longlong(v);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
@@ -232,9 +233,39 @@ __global__ void multinomial_sample_kernel(const double* __restrict__ cdf, int64_
 
 // ---- unique / bincount ----------------------------------------------------------------------------------------------------------------
 // flags[i] = 1 where sorted element i starts a new run; serial scan by blocks (the counts are small next to the sort)
-__global__ void unique_flag_kernel(const uint64_t* __restrict__ keys, int64_t* __restrict__ flag, int64_t n) {
+// nan_key (floating tensors): the key all NaNs share; NaN != NaN, so each NaN is a value of its own, as in ATen
+__global__ void unique_flag_kernel(const uint64_t* __restrict__ keys, int64_t* __restrict__ flag, int64_t n, int nan_key) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1] || (nan_key && keys[i] == ~0ull)) ? 1 : 0;
+}
+// ATen.median propagates NaN: a slice that holds one returns NaN and the position of its FIRST NaN.  x viewed as [outer][L][inner].
+template <class T>
+__global__ void median_nan_kernel(const T* __restrict__ x, T* __restrict__ vals, int64_t* __restrict__ idx, int64_t outer, int64_t L, int64_t inner) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= outer * inner) return;
+  const int64_t o = e / inner, i = e - o * inner;
+  for (int64_t l = 0; l < L; l++) {
+    const T v = x[(o * L + l) * inner + i];
+    const float f = load_as<float>(v);
+    if (f != f) { vals[e] = v; idx[e] = l; return; }
+  }
+}
+// one workgroup per row: every weight finite and >= 0, the row's sum > 0 (ATen raises "invalid multinomial distribution")
+template <class T>
+__global__ __launch_bounds__(256) void multinomial_check_kernel(const T* __restrict__ p, int64_t L, int* __restrict__ assert_word) {
+  __shared__ double part[256];
+  const T* pr = p + (int64_t)blockIdx.x * L;
+  double s = 0.0;
+  bool bad = false;
+  for (int64_t i = threadIdx.x; i < L; i += 256) {
+    const double v = (double)load_as<acc_t<T>>(pr[i]);
+    if (!(v >= 0.0) || v > 1.7e308) bad = true;
+    s += v;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < 256; k++) t += part[k]; if (!(t > 0.0)) bad = true; }
+  if (bad) *(volatile int*)assert_word = kAssertMultinomial;
 }
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const int64_t* __restrict__ v, int64_t* __restrict__ sums, int64_t n) {
   __shared__ int64_t red[256];
@@ -336,6 +367,18 @@ int lamp_median_dim(lamp_tensor** values, lamp_tensor** indices, const lamp_tens
     LAMP_CHECK(lamp_select(&is, ih.get(), d, (L - 1) / 2) == 0, lamp_last_error());
     Hold t2(is);
     Hold vc(contiguous(t1.get())), ic(contiguous(t2.get()));
+    if (a->dtype == kF32 || a->dtype == kF64 || a->dtype == kBF16 || a->dtype == kF16) {
+      Hold ac(contiguous(a));
+      int64_t outer = 1, inner = 1;
+      for (int i = 0; i < d; i++) outer *= a->sizes[i];
+      for (int i = (int)d + 1; i < nd; i++) inner *= a->sizes[i];
+      if (outer * inner > 0) {
+        hipStream_t st = current_stream(a->device());
+        LAMP_DISPATCH_FLOAT(a->dtype, T, hipLaunchKernelGGL((median_nan_kernel<T>), dim3(grid_for(outer * inner, 256)), dim3(256), 0, st, ac->ptr<T>(), vc->ptr<T>(),
+                                                             ic->ptr<int64_t>(), outer, L, inner));
+        LAMP_LAUNCH_CHECK();
+      }
+    }
     if (keepdim) {
       lamp_tensor *vu = nullptr, *iu = nullptr;
       LAMP_CHECK(lamp_unsqueeze(&vu, vc.get(), d) == 0, lamp_last_error());
@@ -379,6 +422,8 @@ int lamp_multinomial(lamp_tensor** out, const lamp_tensor* probs, int64_t num_sa
   hipStream_t st = current_stream(probs->device());
   std::vector<int64_t> oshape = pc->ndim == 2 ? std::vector<int64_t>{rows, num_samples} : std::vector<int64_t>{num_samples};
   Hold r(new_tensor(oshape, kI64, probs->device()));
+  LAMP_DISPATCH_FLOAT(pc->dtype, T, hipLaunchKernelGGL((multinomial_check_kernel<T>), dim3((unsigned)rows), dim3(256), 0, st, pc->ptr<T>(), L, device_assert_word(probs->device())));
+  LAMP_LAUNCH_CHECK();
   if (replacement) {
     int64_t cs[1] = {rows * L};
     Hold cdf(new_tensor(cs, 1, kF64, probs->device()));
@@ -419,7 +464,8 @@ int lamp_unique(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor
   int64_t fs[1] = {std::max<int64_t>(n, 1)}, bs[1] = {nb + 1};
   Hold flag(new_tensor(fs, 1, kI64, a->device())), incl(new_tensor(fs, 1, kI64, a->device())), sums(new_tensor(bs, 1, kI64, a->device()));
   if (n) {
-    hipLaunchKernelGGL(unique_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint64_t*)s.keys->ptr<int64_t>(), flag->ptr<int64_t>(), n);
+    const int nan_key = (a->dtype == kF32 || a->dtype == kF64 || a->dtype == kBF16 || a->dtype == kF16) ? 1 : 0;
+    hipLaunchKernelGGL(unique_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint64_t*)s.keys->ptr<int64_t>(), flag->ptr<int64_t>(), n, nan_key);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flag->ptr<int64_t>(), sums->ptr<int64_t>(), n);
     hipLaunchKernelGGL(scan_serial_kernel, dim3(1), dim3(1), 0, st, sums->ptr<int64_t>(), nb);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flag->ptr<int64_t>(), sums->ptr<int64_t>(), incl->ptr<int64_t>(), n);

@@ -368,3 +368,30 @@ def test_to_batched(gpu):
     out2 = S.toBatched([_host(a + 1) for a in arrs], bufs)          # the buffers are reused; earlier results are clones
     for a, t, t2 in zip(arrs, out, out2):
         assert np.array_equal(t.to_numpy(), a) and np.array_equal(t2.to_numpy(), a + 1)
+
+
+@pytest.mark.gpu
+def test_recycled_pinned_blocks_wait_for_copies_that_still_read_them(gpu):
+    """core/tensor.hip: a freed page-locked block is handed out again only after EVERY device this process has used is idle (what hipHostFree's
+    implicit wait guaranteed) - also when the next owner is a thread that never selected a device (the reference's loader fiber).  A 64 MB
+    pinned source is copied to the device without blocking and released at once; another thread pins a tensor of the same size (it receives
+    the recycled block: same address) and overwrites it; the device copy must hold the OLD contents, every time."""
+    import threading
+    n = 16 << 20
+    for trial in range(6):
+        src = S.STen.from_numpy(np.full(n, float(trial + 1), dtype=np.float32), S.CPU).pin()
+        addr = src.data_ptr()
+        dev = S.STen.zeros([n], S.F32, 0)
+        lib.lamp_copy_(dev, src, 1)                      # non_blocking: the DMA may still be reading `src` when it is released
+        src.release()
+        seen = {}
+
+        def loader():
+            t = S.STen.from_numpy(np.full(n, -1.0, dtype=np.float32), S.CPU).pin()   # recycles the block and writes it
+            seen["addr"] = t.data_ptr()
+            t.release()
+        th = threading.Thread(target=loader); th.start(); th.join()
+        got = dev.to_numpy()
+        assert np.all(got == np.float32(trial + 1)), f"trial {trial}: the copy read a recycled block ({got[:4]})"
+        assert seen["addr"] == addr, "the freed pinned block was not recycled (the test would prove nothing)"
+        dev.release()

@@ -1175,6 +1175,64 @@ def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k,
     assert b"bn_fwd_stats" in rep3, "stale statistics were used after the tensor had been written"
 
 
+@pytest.mark.parametrize("cin,cout,N", [(128, 100, 1024), (16, 128, 1024), (128, 128, 1032), (100, 100, 1024), (64, 64, 1024), (16, 16, 1027),
+                                        (128, 100, 64), (6, 6, 64)])
+def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, N):
+    """lamp_convolution_pair(x, 3x3, 1x1) - the two branches of lamp's residual block start with a Conv2D on the same input (cnn.scala:16-20,
+    38-78) - returns BITWISE what two lamp_convolution calls return, hands each output's batch-norm statistics to its consumer as the single
+    convolutions do, and is ONE launch of the eight-image kernel where that kernel takes the geometry (N >= 4 x CUs, bf16, 8x8 maps); every
+    other geometry runs the two calls inside the entry point."""
+    dt = torch.bfloat16
+    x = closed_form((N, cin, 8, 8), 3, 2.0, dt)
+    wa, ba = closed_form((cout, cin, 3, 3), 17, 0.2, dt), closed_form((cout,), 5, 1.0, dt)
+    wb, bb = closed_form((cout, cin, 1, 1), 23, 0.4, dt), closed_form((cout,), 13, 1.0, dt)
+    X, WA, BA, WB, BB = to_sten(x), to_sten(wa), to_sten(ba), to_sten(wb), to_sten(bb)
+    one, p1, p0, z = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0]), i64_array([0, 0])
+
+    def single(W, B, pad):
+        o = C.c_void_p()
+        lib.lamp_convolution(C.byref(o), X, W, B, one, pad, one, 2, 0, z, 1)
+        return S.STen(o)
+    ya, yb = single(WA, BA, p1), single(WB, BB, p0)
+    o2 = (C.c_void_p * 2)()
+    lib.lamp_kernel_timer_enable(1)
+    lib.lamp_convolution_pair(o2, X, WA, BA, one, p1, one, WB, BB, one, p0, one, 2, 1)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    pa, pb = S.STen(o2[0]), S.STen(o2[1])
+    assert torch.equal(to_torch(pa), to_torch(ya)), "3x3 output of the pair differs from the single convolution"
+    assert torch.equal(to_torch(pb), to_torch(yb)), "1x1 output of the pair differs from the single convolution"
+    launches = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if ln.strip()}       # "tag count total_ms flops bytes"
+    fused = N >= 1024 and cin >= 8
+    assert sum(n for t, n in launches.items() if t.startswith("conv_")) == (1 if fused else 2), (fused, launches)
+    # against the oracle (ATen f32 on the same bf16 values)
+    ra = aten.convolution(x.float(), wa.float(), ba.float(), [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    rb = aten.convolution(x.float(), wb.float(), bb.float(), [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+    assert_close(to_torch(pa), ra.double(), FWD_TOL[dt] * 4, "3x3 against the oracle")
+    assert_close(to_torch(pb), rb.double(), FWD_TOL[dt] * 4, "1x1 against the oracle")
+    # the statistics hand-off of BOTH outputs: the batch norm that reads them launches no statistics pass and returns the bits it returns
+    # for the single convolutions' outputs
+    g, b = closed_form((cout,), 1, 1.0, dt) + 1.0, closed_form((cout,), 9, 1.0, dt)
+
+    def bn(t):
+        out = _out3()
+        RM, RV = to_sten(torch.zeros(cout, dtype=dt)), to_sten(torch.ones(cout, dtype=dt))
+        lib.lamp_kernel_timer_enable(1)
+        lib.lamp_native_batch_norm_relu(out, t, to_sten(g), to_sten(b), RM, RV, 1, 0.1, 1e-5)
+        rb_ = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(rb_, len(rb_))
+        lib.lamp_kernel_timer_enable(0)
+        return [to_torch(h) for h in _wrap3(out)] + [to_torch(RM), to_torch(RV)], rb_.value
+    for got, want, name in ((pa, ya, "3x3"), (pb, yb, "1x1")):
+        (r1, rep1), (r2, rep2) = bn(got), bn(want)
+        assert (b"bn_fwd_stats" in rep1) == (b"bn_fwd_stats" in rep2), f"{name}: the pair's output carries a different hand-off"
+        if cin >= 8:
+            assert b"bn_fwd_stats" not in rep1, f"{name}: no statistics were handed over"
+        for u, v in zip(r1, r2):
+            assert torch.equal(u, v), f"{name}: batch norm of the pair's output differs from batch norm of the single convolution's"
+
+
 def _conv_wgrad_bf16(x, w, gy, k):
     out3 = (C.c_void_p * 3)()
     mask = (C.c_uint8 * 3)(0, 1, 0)
@@ -1670,6 +1728,44 @@ def test_triangles_and_diagonals(gpu, dt):
     o = _out1(); lib.lamp_diagonal(C.byref(o), M, 0, 0, 1)
     S.STen(o).fill_(2.0)
     assert np.array_equal(M.to_numpy(), 2.0 * np.eye(4))
+
+
+def test_sorting_family_special_values(gpu):
+    """-0.0 and +0.0 are ONE value for ATen's comparisons (a stable sort keeps their order, unique counts them once), every NaN is a
+    value of its own for unique, median propagates NaN with the position of the slice's first NaN, and multinomial rejects negative / NaN /
+    all-zero rows (raised at the next host wait, as the other device-side checks)."""
+    nan = float("nan")
+    z = torch.tensor([0.0, -0.0, -0.0, 0.0, -1.0, 0.0], dtype=torch.float32)
+    sv, si = _out1(), _out1()
+    lib.lamp_sort(C.byref(sv), C.byref(si), to_sten(z), 0, 0)
+    rv, ri = torch.sort(z, stable=True)
+    assert np.array_equal(S.STen(si).to_numpy(), ri.numpy()) and np.array_equal(np.signbit(S.STen(sv).to_numpy()), np.signbit(rv.numpy()))
+    for dt in (torch.float32, torch.float64):
+        x = torch.tensor([0.0, -0.0, nan, 2.0, nan, 1.0, 2.0], dtype=dt)
+        v, inv, cnt = _out1(), _out1(), _out1()
+        lib.lamp_unique(C.byref(v), C.byref(inv), C.byref(cnt), to_sten(x))
+        rv, rinv, rcnt = torch.ops.aten._unique2(x, True, True, True)
+        gv = S.STen(v).to_numpy()
+        assert np.array_equal(gv, rv.numpy(), equal_nan=True) and np.array_equal(S.STen(cnt).to_numpy(), rcnt.numpy()), (gv, rv)
+        # each NaN element maps to one of the NaN slots, each slot used once (which NaN lands where is unspecified)
+        gi = S.STen(inv).to_numpy()
+        assert np.array_equal(gi[[0, 1, 3, 5, 6]], rinv.numpy()[[0, 1, 3, 5, 6]]) and sorted(gi[[2, 4]].tolist()) == sorted(rinv.numpy()[[2, 4]].tolist())
+        m = torch.tensor([[1.0, nan, 0.5, nan], [3.0, 1.0, 2.0, 0.0], [nan, nan, nan, nan]], dtype=dt)
+        for dim in (0, 1):
+            mv, mi = _out1(), _out1()
+            lib.lamp_median_dim(C.byref(mv), C.byref(mi), to_sten(m), dim, 0)
+            rmv, rmi = torch.ops.aten.median.dim(m, dim, False)
+            assert np.array_equal(S.STen(mv).to_numpy(), rmv.numpy(), equal_nan=True), (dim, S.STen(mv).to_numpy(), rmv)
+            nanrows = torch.isnan(rmv).numpy()
+            assert np.array_equal(S.STen(mi).to_numpy()[nanrows], rmi.numpy()[nanrows]), "position of the first NaN"
+    for bad in ([0.2, -0.1, 0.9], [0.0, 0.0, 0.0], [0.5, nan, 0.5], [0.5, float("inf"), 0.5]):
+        for repl in (0, 1):
+            with pytest.raises(Exception, match="multinomial"):
+                o = _out1()
+                lib.lamp_multinomial(C.byref(o), to_sten(torch.tensor([[0.3, 0.3, 0.4], bad], dtype=torch.float32)), 2, repl)
+                S.STen(o).to_numpy()                     # the host wait that reports the device-side check
+    o = _out1(); lib.lamp_multinomial(C.byref(o), to_sten(torch.tensor([0.0, 1.0, 0.0])), 3, 1)
+    assert S.STen(o).to_numpy().tolist() == [1, 1, 1]
 
 
 def test_randperm_and_multinomial(gpu):
