@@ -552,7 +552,8 @@ def main():
     step_eager = step
     modes = None                                  # multi-rank: [(name, step function)] - every exchange mode is timed, the faster one is `value`
     use_graph = not a.no_graph and ((a.workload in ("resnet", "mlp")) or (a.graph and a.workload == "lm"))
-    if use_graph and not os.environ.get("LAMP_BENCH_GRAPH_UNDER_PROFILER") and ("rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)):
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    if use_graph and not os.environ.get("LAMP_BENCH_GRAPH_UNDER_PROFILER") and under_profiler:
         # rocprofv3's kernel tracing dies with SIGSEGV inside hipGraphLaunch on this image (5 of 8 runs on one box, never without the
         # profiler; the faulting frames are the profiler's graph hooks under lamp_graph_launch): a profiled run measures the eager step,
         # whose kernels are the replayed ones, and says so
@@ -703,6 +704,53 @@ def main():
             result_extra["roofline_layout"] = roofline_of(lay_rows)
         if knn_rows:
             result_extra["roofline_knn"] = roofline_of(knn_rows)
+    # ---- the same K-step protocol, after the headline measurement and its roofline passes (never inside its timed region),
+    # for the step in the reference example's own precisions (cifar100.scala:127-129) and at the small batch SURVEY 8d config 3 also asks for:
+    # fresh model, one eager step, forward + backprop captured into a HIP graph, warm-up, K-step windows between device synchronisations, median.
+    also = None
+    if a.workload == "resnet" and a.gpus == 1 and rank == 0 and os.environ.get("LAMP_BENCH_ALSO", "1") != "0" and not under_profiler:
+        def variant_ms(dt_name, Bv):
+            dtv = {"bf16": S.BF16, "f32": S.F32, "f64": S.F64}[dt_name]
+            lib.lamp_manual_seed(1234)
+            mm = nn.resnet(100, 0.0, dtv, local_rank)
+            xv = S.STen.from_numpy(closed_form_np(Bv * 3 * 32 * 32, 5).reshape(Bv, 3, 32, 32).astype(np.float32), local_rank, dtv)
+            tv = S.STen.from_numpy(((np.arange(Bv) * 7) % 100).astype(np.int64), local_rank)
+            mv = nn.SupervisedModel(mm, nn.SupervisedModel.NLL, S.STen.ones([100], dtv, local_rank))
+            ov = nn.AdamW_factory(weightDecay=0.0, learningRate=1e-3, mixedPrecision=(dt_name == "bf16"))([p_.value for p_ in mm.parameters])
+            av = S.STen.zeros([1], dtv, local_rank)
+            mv.train_step(ov, xv, tv, av, None)
+            lib.lamp_device_synchronize()
+            if use_graph:
+                lib.lamp_graph_begin_capture()
+                _, gv = mv.addTotalLossAndReturnGradientsAndNumExamples(xv, tv, av)
+                gh = C.c_void_p(); lib.lamp_graph_end_capture(C.byref(gh))
+                def fn():
+                    lib.lamp_graph_launch(gh)
+                    ov.step(gv, 1.0)
+            else:
+                fn = lambda: mv.train_step(ov, xv, tv, av, None)
+            for _ in range(a.warmup):
+                fn()
+            ws, total = [], 0.0
+            while total < 0.3 and len(ws) < 50:
+                lib.lamp_device_synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    fn()
+                lib.lamp_device_synchronize()
+                ws.append(time.perf_counter() - t0); total += ws[-1]
+            ws.sort()
+            return ws[len(ws) // 2] / a.steps * 1e3
+        also = {"protocol": f"{a.warmup} warm-up + windows of {a.steps} steps between device synchronisations, median window; same step as the headline "
+                            "(fwd + backprop + AdamW, HIP graph as the headline), run after it"}
+        for key, dtn, Bv in (("f32_ms_per_step", "f32", a.batch), ("f64_ms_per_step", "f64", a.batch), ("b256_ms_per_step", a.dtype, 256),
+                             ("b32_ms_per_step", a.dtype, 32)):
+            if (dtn, Bv) == (a.dtype, a.batch):
+                continue
+            try:
+                also[key] = variant_ms(dtn, Bv)
+            except Exception as e:                       # informative keys: never lose the headline line because of them
+                also[key] = f"failed: {e}"
     if rank == 0:
         value = units_per_step * a.gpus * a.steps / elapsed
         roof = roofline_of(rows)
@@ -713,6 +761,8 @@ def main():
                 "timed_windows": {"count": len(windows), "steps_each": a.steps, "reported": "median",
                                   "min_ms_per_step": min(windows) / a.steps * 1e3, "max_ms_per_step": max(windows) / a.steps * 1e3}}
         line.update(result_extra)
+        if also is not None:
+            line["also"] = also
         if alt_mode is not None:
             line["alt_mode"] = alt_mode
         if verify is not None:

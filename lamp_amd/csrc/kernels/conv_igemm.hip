@@ -777,10 +777,23 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // the lane's BYTE offset inside a stage, unsigned: uniform base + zero-extended 32-bit offset is the saddr + voffset form of the load (one
   // VGPR); as a signed element index the compiler kept one 64-bit address pair per tap in registers (18 VGPRs beside 128 accumulators)
   const unsigned d_src = (unsigned)(d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3)) * 2u;
+  // SIB: waves 0 - 3 request BOTH 1 KiB pieces (wid, wid + 4) of every stage and waves 4 - 7 none - the sibling's output is stored by waves
+  // 4 - 7 only, whose vmcnt then never gates a weight stage: the 33 MB the chip writes at that moment drain under the 3x3 main loop instead of
+  // in front of it (first version, every wave storing its own image: the fused launch saved 4 us of the 17 the second launch cost)
+  const unsigned d_src4 = d_src + 64u * (unsigned)KP * 2u;      // the same lane of piece wid + 4: 64 rows further
+  constexpr int NPIECE = SIB ? 2 : 1;                           // this wave's pieces per stage (when it requests any)
+  const bool dma_wave = SIB ? wid < 4 : wid < NCT;
   auto stage_dma_of = [&](const bf16_t* wimg, int kc1, int rs1, int slot) {
-    if (wid < NCT) {                          // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
-      const char* base = reinterpret_cast<const char*>(wimg + (int64_t)rs1 * IG_M * KP + kc1 * 32);
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+    const char* base = reinterpret_cast<const char*>(wimg + (int64_t)rs1 * IG_M * KP + kc1 * 32);
+    if constexpr (SIB) {
+      if (wid < 4) {
+        __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+        // (rows of channel tiles nobody multiplies, NCT < 8, are loaded all the same: the vmcnt arithmetic stays uniform)
+        __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src4), (lds_char_t*)(Wl + slot * WT + (wid + 4) * 1024), 16, 0, 0);
+      }
+    } else {
+      if (wid < NCT)                          // rows of channel tiles nobody multiplies (NCT < 8) stay unloaded
+        __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
     }
   };
   auto stage_dma = [&](int kc1, int rs1, int slot) { stage_dma_of(wp, kc1, rs1, slot); };
@@ -793,6 +806,15 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
   }
   IG_STAMP(1);
+  unsigned bpair[SIB ? (NCT + 1) / 2 : 1];            // the sibling's bias, tiles 2k and 2k + 1 in one register (its epilogue runs beside 128 live
+  if constexpr (SIB) {                                // accumulators); requested with the images so that no wait for it stands behind the ring
+#pragma unroll
+    for (int k = 0; k < (NCT + 1) / 2; k++) {
+      const int c0 = 2 * k * 16 + (lane & 15), c1 = c0 + 16;
+      const unsigned b0 = (sib.bias && c0 < CO) ? sib.bias[c0].bits : 0u, b1 = (sib.bias && 2 * k + 1 < NCT && c1 < CO) ? sib.bias[c1].bits : 0u;
+      bpair[k] = b0 | (b1 << 16);
+    }
+  }
   // NCHW -> [pixel][32 channels].  A thread takes 8 channels x one image row: eight coalesced 16-byte loads, an 8x8 transposition of the
   // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).
   {
@@ -858,6 +880,10 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // images and weight stages 0, 1 are in LDS
+  if constexpr (SIB) {                               // (the compiler's own wait for the bias belongs here, where everything has landed)
+#pragma unroll
+    for (int k = 0; k < (NCT + 1) / 2; k++) asm volatile("" : "+v"(bpair[k]));
+  }
   IG_STAMP(2);
 
   // Two-phase ping-pong, ring discipline as in ig_conv8_kernel: DMA(t+2) is issued in READ(t) into the slot last read in READ(t-1)
@@ -878,7 +904,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       const char* xb = Xl + kc * XBUF + va[PAD & 1][PAD];
 #pragma unroll
       for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((PAD * 8 + PAD) + 16 * j) * RB));
-      if (kc + 2 < KC) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      if (kc + 2 < KC) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // (two pieces per stage and requesting wave)
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
@@ -892,8 +918,9 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();        // every wave has read its last weight stage: the ring is free
     // The 3x3 product's first stage is requested now (slot 0) and lands during this epilogue, which goes through 2 KiB of slots 1 - 2 per
-    // wave, one channel tile at a time (the images must stay): [16 channels][64 pixels] rows written as the MFMA leaves them, read back as
-    // 16-byte chunks, stored as whole 128-byte rows - the same bytes and statistics as the kernel's own epilogue produces.
+    // wave, one channel tile at a time (the images must stay): every wave writes its [16 channels][64 pixels] tile as the MFMA leaves it,
+    // waves 4 - 7 read two images' tiles back as 16-byte chunks and store whole 128-byte rows - the same bytes and statistics as the
+    // kernel's own epilogue produces.
     stage_dma(0, 0, 0);
     {
       const int n = n0 + wid;
@@ -902,19 +929,15 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
       typedef float f2v __attribute__((ext_vector_type(2)));
       typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
-      unsigned bpair[(NCT + 1) / 2];                  // bias of tiles 2k, 2k + 1 in one register (this epilogue runs beside 128 live accumulators)
-#pragma unroll
-      for (int k = 0; k < (NCT + 1) / 2; k++) {
-        const int c0 = 2 * k * 16 + (lane & 15), c1 = c0 + 16;
-        const unsigned b0 = (sib.bias && c0 < CO) ? sib.bias[c0].bits : 0u, b1 = (sib.bias && 2 * k + 1 < NCT && c1 < CO) ? sib.bias[c1].bits : 0u;
-        bpair[k] = b0 | (b1 << 16);
-      }
       // statistics of tile i wait in lane group q = i & 3 of register i >> 2 (NCT separate registers beside 128 accumulators spilled);
       // every group gets group 0's bits - the value the kernel's own epilogue publishes (the merges differ in the last bit between lanes)
       float smean[(NCT + 3) / 4], sm2[(NCT + 3) / 4];
 #pragma unroll
       for (int k = 0; k < (NCT + 3) / 4; k++) { smean[k] = 0.f; sm2[k] = 0.f; }
-      bf16_t* yp = sib.y + (int64_t)n * CO * 64;
+      // waves 4 - 7 store the images of waves 2 (wid - 4) and 2 (wid - 4) + 1
+      const int src0 = (wid & 3) * 2;
+      const char* Sr = Wl + WT + src0 * 2048;
+      bf16_t* yp0 = sib.y + (int64_t)(n0 + src0) * CO * 64;
 #pragma unroll
       for (int i = 0; i < NCT; i++) {
         const int cl = lane & 15;
@@ -937,37 +960,59 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
           if (q == (i & 3)) { smean[i >> 2] = mean; sm2[i >> 2] = m2; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's tile i is in the scratch area
+        if (wid >= 4) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
-          const int idx = it * 64 + lane;
-          const int cr = idx >> 3, c = idx & 7, co = i * 16 + cr;
-          const uint4 v = *reinterpret_cast<const uint4*>(Sc + cr * 128 + ((c ^ (cr & 7)) << 4));
-          if (co < CO && n < N) *reinterpret_cast<uint4*>(yp + co * 64 + c * 8) = v;
+          for (int u = 0; u < 2; u++) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+              const int idx = it * 64 + lane;
+              const int cr = idx >> 3, c = idx & 7, co = i * 16 + cr;
+              const uint4 v = *reinterpret_cast<const uint4*>(Sr + u * 2048 + cr * 128 + ((c ^ (cr & 7)) << 4));
+              if (co < CO && n0 + src0 + u < N) *reinterpret_cast<uint4*>(yp0 + (int64_t)u * CO * 64 + co * 64 + c * 8) = v;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();                  // ... and has been read: the next tile may overwrite it
       }
       if (sib.stats) {
         if (stats_per_wg) {
           // the eight images' (mean, M2) of every channel meet in the scratch area (1 KiB of float2 per wave), one triple per workgroup leaves
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          // (stored by threads of waves 4 - 7, as everything of the sibling)
 #pragma unroll
           for (int k = 0; k < (NCT + 3) / 4; k++)
             if (4 * k + q < NCT) reinterpret_cast<float2*>(Sc)[(4 * k + q) * 16 + (lane & 15)] = make_float2(smean[k], sm2[k]);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (tid < NCT * 16 && tid < CO) {
-            const float2* sl = reinterpret_cast<const float2*>(Wl + WT) + tid;
+          const int ch = tid - 256;
+          if (ch >= 0 && ch < NCT * 16 && ch < CO) {
+            const float2* sl = reinterpret_cast<const float2*>(Wl + WT) + ch;
             const float shift = sl[0].x;
             float s1 = 0.f, s2 = 0.f, sm = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; w++) { const float2 v = sl[w * 256]; const float d = v.x - shift; s1 += d; s2 += d * d; sm += v.y; }
-            float* sp = sib.stats + ((int64_t)tid * gridDim.x + blockIdx.x) * 3;
+            float* sp = sib.stats + ((int64_t)ch * gridDim.x + blockIdx.x) * 3;
             sp[0] = 512.f; sp[1] = shift + s1 * 0.125f; sp[2] = sm + 64.f * (s2 - s1 * s1 * 0.125f);
           }
         } else {
+          // one triple per image: through the scratch area as well, so that waves 4 - 7 store them
 #pragma unroll
-          for (int k = 0; k < (NCT + 3) / 4; k++) {
-            const int co = (4 * k + q) * 16 + (lane & 15);
-            if (4 * k + q < NCT && co < CO && n < N) { float* sp = sib.stats + ((int64_t)co * N + n) * 3; sp[0] = 64.f; sp[1] = smean[k]; sp[2] = sm2[k]; }
+          for (int k = 0; k < (NCT + 3) / 4; k++)
+            if (4 * k + q < NCT) reinterpret_cast<float2*>(Sc)[(4 * k + q) * 16 + (lane & 15)] = make_float2(smean[k], sm2[k]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (wid >= 4) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const int img = n0 + src0 + u;
+#pragma unroll
+              for (int h = 0; h < 2; h++) {
+                const int ch = h * 64 + lane;
+                const float2 v = reinterpret_cast<const float2*>(Sr + u * 2048)[ch];
+                if (ch < NCT * 16 && ch < CO && img < N) { float* sp = sib.stats + ((int64_t)ch * N + img) * 3; sp[0] = 64.f; sp[1] = v.x; sp[2] = v.y; }
+              }
+            }
           }
         }
       }
@@ -975,7 +1020,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // nobody reads the scratch area any more: slots 1 - 2 belong to the ring again
     if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0 and 1 (and this wave's sibling stores, which share the counter)
+    if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 and 1; waves 4 - 7 have only their stores in flight and do not wait
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();
@@ -994,8 +1039,14 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       const char* xb = xk + va[r & 1][s];
 #pragma unroll
       for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s) + 16 * j) * RB));
-      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if constexpr (SIB) {
+        if (!dma_wave) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (its outstanding vector-memory operations are the sibling's stores)
+        else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       if (KS == 3) {                                   // taps that fall outside the 8x8 image contribute zeros
         const bool colout = (s == 0 && col_lo) || (s == 2 && col_hi);
 #pragma unroll

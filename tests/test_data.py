@@ -380,7 +380,7 @@ def test_recycled_pinned_blocks_wait_for_copies_that_still_read_them(gpu):
     n = 16 << 20
     for trial in range(6):
         src = S.STen.from_numpy(np.full(n, float(trial + 1), dtype=np.float32), S.CPU).pin()
-        addr = src.data_ptr()
+        addr = src.data_ptr
         dev = S.STen.zeros([n], S.F32, 0)
         lib.lamp_copy_(dev, src, 1)                      # non_blocking: the DMA may still be reading `src` when it is released
         src.release()
@@ -388,7 +388,7 @@ def test_recycled_pinned_blocks_wait_for_copies_that_still_read_them(gpu):
 
         def loader():
             t = S.STen.from_numpy(np.full(n, -1.0, dtype=np.float32), S.CPU).pin()   # recycles the block and writes it
-            seen["addr"] = t.data_ptr()
+            seen["addr"] = t.data_ptr
             t.release()
         th = threading.Thread(target=loader); th.start(); th.join()
         got = dev.to_numpy()
