@@ -778,8 +778,9 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // VGPR); as a signed element index the compiler kept one 64-bit address pair per tap in registers (18 VGPRs beside 128 accumulators)
   const unsigned d_src = (unsigned)(d_row * KP + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3)) * 2u;
   // SIB: waves 0 - 3 request BOTH 1 KiB pieces (wid, wid + 4) of every stage and waves 4 - 7 none - the sibling's output is stored by waves
-  // 4 - 7 only, whose vmcnt then never gates a weight stage: the 33 MB the chip writes at that moment drain under the 3x3 main loop instead of
-  // in front of it (first version, every wave storing its own image: the fused launch saved 4 us of the 17 the second launch cost)
+  // 4 - 7 only, whose vmcnt then never gates a weight stage, so the sibling's stores may drain under the 3x3 main loop.  Measured: no faster
+  // than every wave storing its own image behind a vmcnt(0) (1.0903 vs 1.0913 ms per step, EXPERIMENTS (21)) - the pair is bound by the bytes
+  // it writes, wherever the wait stands; kept because it is the form that was tested
   const unsigned d_src4 = d_src + 64u * (unsigned)KP * 2u;      // the same lane of piece wid + 4: 64 rows further
   constexpr int NPIECE = SIB ? 2 : 1;                           // this wave's pieces per stage (when it requests any)
   const bool dma_wave = SIB ? wid < 4 : wid < NCT;
@@ -1316,7 +1317,8 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // the kernel is bound by its LDS fragment reads (176 KB per image and CU against 1152 matrix cycles).
 template <bool SHIFT_DY>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine) {
+                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
+                                                         int stream_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 3, RS = 9, PAD = 1;
   const int nsplit = gridDim.x / ntile;
@@ -1800,11 +1802,11 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
       if (shift_dy) {
         allow_big_lds((const void*)ig_wgrad8h_kernel<true>);
         hipLaunchKernelGGL(ig_wgrad8h_kernel<true>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp);
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);
       } else {
         allow_big_lds((const void*)ig_wgrad8h_kernel<false>);
         hipLaunchKernelGGL(ig_wgrad8h_kernel<false>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp);
+                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);
       }
       LAMP_LAUNCH_CHECK();
     }

@@ -16,6 +16,7 @@ struct WgradReduceArgs {
   int nsplit;               // kind 0: image ranges; kind 1: blocks
   int O;                    // kind 1: outputs
   int blocks;               // workgroups (256 threads) this reduction needs
+  int cached;               // 1: the reduction runs right behind the kernel that wrote the partial sums (they are read from the caches: plain loads)
 };
 
 // kind 0.  Thread (q, sg) sums float4 column q of this block over the splits sg, sg+8, ... (independent 16-byte loads in flight), the 8
@@ -37,8 +38,9 @@ __device__ __forceinline__ void wgrad_reduce_igemm(const WgradReduceArgs& a, int
       // read exactly once: streamed past the caches (with the eight-wave kernel's streaming stores: -14 us per step; the same hints on the
       // small partial sums of the v2 / narrow kernels cost +12 us - those still sit in the Infinity Cache when the reduction runs)
       typedef float nt_f4 __attribute__((ext_vector_type(4)));
-      const nt_f4 nv = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(&p4[(int64_t)sp * per_split]));
-      const float4 v = make_float4(nv[0], nv[1], nv[2], nv[3]);
+      float4 v;
+      if (a.cached) v = p4[(int64_t)sp * per_split];
+      else { const nt_f4 nv = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(&p4[(int64_t)sp * per_split])); v = make_float4(nv[0], nv[1], nv[2], nv[3]); }
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
@@ -72,5 +74,6 @@ __device__ __forceinline__ void wgrad_reduce_narrow(const WgradReduceArgs& a, in
 // backprop - or the moment anything asks for a pointer into dw's storage (Tensor::raw()), whichever comes first.
 // LAMP_DEFER_WGRAD_REDUCE=0: launch it now.
 void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_tensor* dw, hipStream_t st);
+bool wgrad_reduce_deferred();      // false: LAMP_DEFER_WGRAD_REDUCE=0 (the producers then leave their partial sums in the caches)
 
 }  // namespace lamp

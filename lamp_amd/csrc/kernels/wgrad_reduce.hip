@@ -107,11 +107,16 @@ void resolve_deferred(Storage* st) {
   // not in the list any more: another thread queued it while this one waited for the mutex
 }
 
-void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_tensor* dw, hipStream_t st) {
+bool wgrad_reduce_deferred() {
   static const bool defer = [] { const char* e = getenv("LAMP_DEFER_WGRAD_REDUCE"); return !(e && e[0] == '0'); }();
+  return defer;
+}
+void wgrad_reduce_enqueue(const WgradReduceArgs& a, lamp_tensor* partial, lamp_tensor* dw, hipStream_t st) {
+  const bool defer = wgrad_reduce_deferred();
   if (!defer || !dw->st->owned) {
     WgradReduceMany m;
     m.e[0] = a;
+    m.e[0].cached = defer ? 0 : 1;
     m.e[0].partial = partial->ptr<float>();
     m.e[0].dw = dw->data();
     hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)a.blocks, 1), dim3(256), 0, st, m);

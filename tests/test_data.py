@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from lamp_amd import data as D, sten as S
-from lamp_amd._capi import LampError
+from lamp_amd._capi import LampError, lib
 
 
 def _host(a, dtype=None):
@@ -382,7 +382,7 @@ def test_recycled_pinned_blocks_wait_for_copies_that_still_read_them(gpu):
         src = S.STen.from_numpy(np.full(n, float(trial + 1), dtype=np.float32), S.CPU).pin()
         addr = src.data_ptr
         dev = S.STen.zeros([n], S.F32, 0)
-        lib.lamp_copy_(dev, src, 1)                      # non_blocking: the DMA may still be reading `src` when it is released
+        dev.copyFrom(src, True)                          # non_blocking: the DMA may still be reading `src` when it is released
         src.release()
         seen = {}
 
