@@ -583,6 +583,14 @@ int lamp_sort(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a,
 int lamp_argsort(lamp_tensor** out, const lamp_tensor* a, int stable, int64_t dim, int descending);
 int lamp_median_dim(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t dim, int keepdim);   /* median_1: the lower median */
 int lamp_unique(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a);   /* _unique / _unique2, sorted */
+/* unique_dim (STen.scala:1059): the distinct slices along `dim`, sorted lexicographically over their flattened elements (ATen's order), the
+ * run of every input slice and the multiplicities; unique_consecutive (STen.scala:1068): runs of equal NEIGHBOURING slices, in place order */
+int lamp_unique_dim(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a, int64_t dim);
+int lamp_unique_consecutive(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a, int64_t dim);
+/* mode (STen.scala:1561): per slice along dim the smallest most frequent value and the position of its last occurrence */
+int lamp_mode(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t dim, int keepdim);
+/* cartesian_prod (STen.scala:674): rows = all combinations of the 1-D tensors' elements, first tensor slowest */
+int lamp_cartesian_prod(lamp_tensor** out, lamp_tensor* const* tensors, int n);
 int lamp_bincount(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* weights_or_null, int64_t minlength);
 /* Overwriting scatters (STen.scala:1412-1423 scatter, :1715-1726 indexPut / put / indexCopy).  Duplicate targets without accumulation: one
  * of the writers wins (unspecified in ATen too); out-of-range indices raise at the next host wait (device assertion, like ATen's). */

@@ -1691,7 +1691,6 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         return;
       }
       const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
-      static bool a3 = false, a1 = false;
       if (KS == 3) {
         allow_big_lds((const void*)ig_conv8b_kernel<3>);
         hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);

@@ -527,4 +527,235 @@ int lamp_bincount(lamp_tensor** out, const lamp_tensor* a, const lamp_tensor* we
   LAMP_API_END
 }
 
+
+// ---- mode / unique along a dimension / unique_consecutive / cartesian_prod (round 5) ----------------------------------------
+// STen.mode (STen.scala:1561), STen.unique(dim, ...) (:1059), STen.uniqueConsecutive (:1068), STen.cartesianProduct (:674).  Off every hot path:
+// compositions of the sort above with thread-per-slice scans; data-dependent output lengths cost one host synchronisation, as lamp_unique.
+}  // extern "C"
+
+namespace lamp {
+// the dimension d moved to the front, the others in their order (ATen's moveaxis(d, 0)), contiguous: [L][M]
+static Tensor* slices_first(const Tensor* a, int64_t d) {
+  Hold cur(retain(a));
+  for (int64_t k = d; k > 0; k--) {
+    lamp_tensor* t = nullptr;
+    LAMP_CHECK(lamp_transpose(&t, cur.get(), k, k - 1) == 0, lamp_last_error());
+    cur = Hold(t);
+  }
+  return contiguous(cur.get());
+}
+// values sorted along the last dimension with their original positions: per row the SMALLEST most frequent value and the position of its LAST
+// occurrence (ATen.mode): the first longest run of the ascending stable sort, whose last member has the largest original index
+template <class T>
+__global__ void mode_rows_kernel(const T* __restrict__ v, const int64_t* __restrict__ ix, T* __restrict__ ov, int64_t* __restrict__ oi, int64_t rows, int64_t L) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const T* vr = v + r * L;
+  const int64_t* ir = ix + r * L;
+  int64_t best_end = 0, best_len = 0, start = 0;
+  for (int64_t i = 1; i <= L; i++) {
+    if (i == L || !(load_as<acc_t<T>>(vr[i]) == load_as<acc_t<T>>(vr[i - 1]))) {
+      if (i - start > best_len) { best_len = i - start; best_end = i - 1; }
+      start = i;
+    }
+  }
+  ov[r] = vr[best_end];
+  oi[r] = ir[best_end];
+}
+// flag[r] = 1 where slice order[r] differs from slice order[r - 1] (order == nullptr: the slices as they stand); x is [L][M]
+template <class T>
+__global__ void slice_flag_kernel(const T* __restrict__ x, const int* __restrict__ order, int64_t* __restrict__ flag, int64_t L, int64_t M) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= L) return;
+  if (r == 0) { flag[0] = 1; return; }
+  const T* a = x + (order ? (int64_t)order[r] : r) * M;
+  const T* b = x + (order ? (int64_t)order[r - 1] : r - 1) * M;
+  int64_t f = 0;
+  for (int64_t j = 0; j < M; j++)
+    if (!(load_as<acc_t<T>>(a[j]) == load_as<acc_t<T>>(b[j]))) { f = 1; break; }
+  flag[r] = f;
+}
+// one pass of the least-significant-column-first lexicographic sort: key of the slice that currently stands at rank r, position = r
+template <class T>
+__global__ void slice_keys_kernel(const T* __restrict__ x, const int* __restrict__ order, uint64_t* __restrict__ keys, int* __restrict__ idx, int64_t L, int64_t P,
+                                  int64_t M, int64_t col) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  keys[r] = r < L ? sort_key_of<T>(x[(int64_t)order[r] * M + col]) : ~0ull;
+  idx[r] = (int)r;
+}
+__global__ void compose_order_kernel(const int* __restrict__ order, const int* __restrict__ idx, int* __restrict__ out, int64_t L) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < L) out[r] = order[idx[r]];
+}
+__global__ void iota_i32_kernel(int* __restrict__ o, int64_t n) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < n) o[r] = (int)r;
+}
+// runs of equal slices in rank order -> the slice that starts each run, every slice's run, the run lengths
+__global__ void runs_write_kernel(const int* __restrict__ order, const int64_t* __restrict__ flag, const int64_t* __restrict__ incl, int64_t* __restrict__ starts,
+                                  int64_t* __restrict__ inverse, int64_t* __restrict__ counts, int64_t L) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= L) return;
+  const int64_t run = incl[r] - 1, pos = order ? (int64_t)order[r] : r;
+  if (inverse) inverse[pos] = run;
+  if (flag[r]) {
+    starts[run] = pos;
+    if (counts) {
+      int64_t lo = r + 1, hi = L;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (incl[mid] > incl[r]) hi = mid; else lo = mid + 1; }
+      counts[run] = lo - r;
+    }
+  }
+}
+// shared tail of unique_dim / unique_consecutive: flags in rank order -> (values = the run-starting slices along d, inverse, counts)
+static void unique_slices(const Tensor* a, int64_t d, const Tensor* xs /* [L][M] */, const int* order, Tensor** values, Tensor** inverse, Tensor** counts, hipStream_t st) {
+  const int64_t L = a->sizes[d], M = L ? xs->numel() / L : 0;
+  int64_t nu = 0;
+  const int64_t nb = (L + 4095) / 4096;
+  int64_t fs[1] = {std::max<int64_t>(L, 1)}, bs[1] = {nb + 1};
+  Hold flag(new_tensor(fs, 1, kI64, a->device())), incl(new_tensor(fs, 1, kI64, a->device())), sums(new_tensor(bs, 1, kI64, a->device()));
+  if (L) {
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((slice_flag_kernel<T>), dim3(grid_for(L, 256)), dim3(256), 0, st, xs->ptr<T>(), order, flag->ptr<int64_t>(), L, M));
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flag->ptr<int64_t>(), sums->ptr<int64_t>(), L);
+    hipLaunchKernelGGL(scan_serial_kernel, dim3(1), dim3(1), 0, st, sums->ptr<int64_t>(), nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flag->ptr<int64_t>(), sums->ptr<int64_t>(), incl->ptr<int64_t>(), L);
+    LAMP_LAUNCH_CHECK();
+    HIP_CHECK(hipMemcpyAsync(&nu, sums->ptr<int64_t>() + nb, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+  }
+  int64_t us[1] = {nu}, ls[1] = {L};
+  Hold starts(new_tensor(us, 1, kI64, a->device()));
+  Hold inv(inverse ? new_tensor(ls, 1, kI64, a->device()) : nullptr), cnt(counts ? new_tensor(us, 1, kI64, a->device()) : nullptr);
+  if (L) {
+    hipLaunchKernelGGL(runs_write_kernel, dim3(grid_for(L, 256)), dim3(256), 0, st, order, flag->ptr<int64_t>(), incl->ptr<int64_t>(), starts->ptr<int64_t>(),
+                       inv.get() ? inv->ptr<int64_t>() : (int64_t*)nullptr, cnt.get() ? cnt->ptr<int64_t>() : (int64_t*)nullptr, L);
+    LAMP_LAUNCH_CHECK();
+  }
+  lamp_tensor* v = nullptr;
+  LAMP_CHECK(lamp_index_select(&v, a, d, starts.get()) == 0, lamp_last_error());
+  *values = v;
+  if (inverse) *inverse = inv.take();
+  if (counts) *counts = cnt.take();
+}
+}  // namespace lamp
+
+extern "C" {
+
+int lamp_mode(lamp_tensor** values, lamp_tensor** indices, const lamp_tensor* a, int64_t dim, int keepdim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  const int nd = a->ndim;
+  const int64_t d = nd ? wrap_dim(dim, nd) : 0;
+  const int64_t L = nd ? a->sizes[d] : 1;
+  LAMP_CHECK(L > 0, "mode of an empty dimension");
+  lamp_tensor *v = nullptr, *ix = nullptr;
+  sort_dim(a, dim, false, -1, &v, &ix);
+  Hold vh(v), ih(ix);
+  Hold vt, it;
+  if (nd) {
+    lamp_tensor *t1 = nullptr, *t2 = nullptr;
+    LAMP_CHECK(lamp_transpose(&t1, vh.get(), d, nd - 1) == 0, lamp_last_error());
+    Hold h1(t1);
+    LAMP_CHECK(lamp_transpose(&t2, ih.get(), d, nd - 1) == 0, lamp_last_error());
+    Hold h2(t2);
+    vt = Hold(contiguous(h1.get())); it = Hold(contiguous(h2.get()));
+  } else { vt = Hold(contiguous(vh.get())); it = Hold(contiguous(ih.get())); }
+  const int64_t rows = vt->numel() / L;
+  // the transposed shape without its last dimension: dimension d holds what was the last one
+  std::vector<int64_t> oshape;
+  for (int i = 0; i + 1 < nd; i++) oshape.push_back(vt->sizes[i]);
+  Hold ov(new_tensor(oshape, a->dtype, a->device())), oi(new_tensor(oshape, kI64, a->device()));
+  if (rows) {
+    hipStream_t st = current_stream(a->device());
+    LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((mode_rows_kernel<T>), dim3(grid_for(rows, 256)), dim3(256), 0, st, vt->ptr<T>(), it->ptr<int64_t>(), ov->ptr<T>(),
+                                                      oi->ptr<int64_t>(), rows, L));
+    LAMP_LAUNCH_CHECK();
+  }
+  // back to the input's dimension order: with keepdim the reduced dimension returns (size 1) to position d
+  auto finish = [&](Hold& h, lamp_tensor** out) {
+    if (!nd) { *out = h.take(); return; }
+    lamp_tensor* u = nullptr;
+    LAMP_CHECK(lamp_unsqueeze(&u, h.get(), nd - 1) == 0, lamp_last_error());            // [..., last-at-d ..., 1]
+    Hold hu(u);
+    lamp_tensor* t = nullptr;
+    LAMP_CHECK(lamp_transpose(&t, hu.get(), d, nd - 1) == 0, lamp_last_error());        // the 1 at d, the former last dimension back at the end
+    Hold ht(t);
+    if (keepdim) { *out = contiguous(ht.get()); return; }
+    lamp_tensor* q = nullptr;
+    LAMP_CHECK(lamp_squeeze(&q, ht.get(), d) == 0, lamp_last_error());
+    Hold hq(q);
+    *out = contiguous(hq.get());
+  };
+  finish(ov, values); finish(oi, indices);
+  LAMP_API_END
+}
+
+int lamp_unique_consecutive(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim >= 1, "unique_consecutive along a dimension needs at least one dimension");
+  const int64_t d = wrap_dim(dim, a->ndim);
+  hipStream_t st = current_stream(a->device());
+  Hold xs(slices_first(a, d));
+  unique_slices(a, d, xs.get(), nullptr, values, inverse_or_null, counts_or_null, st);
+  LAMP_API_END
+}
+
+int lamp_unique_dim(lamp_tensor** values, lamp_tensor** inverse_or_null, lamp_tensor** counts_or_null, const lamp_tensor* a, int64_t dim) {
+  LAMP_API_BEGIN
+  check_device_tensor(a, "self");
+  LAMP_CHECK(a->ndim >= 1, "unique along a dimension needs at least one dimension");
+  const int64_t d = wrap_dim(dim, a->ndim);
+  hipStream_t st = current_stream(a->device());
+  Hold xs(slices_first(a, d));
+  const int64_t L = a->sizes[d], M = L ? xs->numel() / L : 0;
+  LAMP_CHECK(L < ((int64_t)1 << 31), "unique: dimension of " << L << " slices is too long");
+  const int64_t P = pow2_at_least(std::max<int64_t>(L, 1));
+  int64_t ps[1] = {P}, ls[1] = {std::max<int64_t>(L, 1)};
+  Hold keys(new_tensor(ps, 1, kI64, a->device())), idx(new_tensor(ps, 1, kI32, a->device()));
+  Hold order(new_tensor(ls, 1, kI32, a->device())), next(new_tensor(ls, 1, kI32, a->device()));
+  if (L) {
+    hipLaunchKernelGGL(iota_i32_kernel, dim3(grid_for(L, 256)), dim3(256), 0, st, order->ptr<int32_t>(), L);
+    // slices sorted lexicographically over their flattened elements: stable sorts by column M - 1, M - 2, ..., 0
+    for (int64_t col = M - 1; col >= 0; col--) {
+      LAMP_DISPATCH_ALL(a->dtype, T, hipLaunchKernelGGL((slice_keys_kernel<T>), dim3(grid_for(P, 256)), dim3(256), 0, st, xs->ptr<T>(), order->ptr<int32_t>(),
+                                                        (uint64_t*)keys->ptr<int64_t>(), idx->ptr<int32_t>(), L, P, M, col));
+      LAMP_LAUNCH_CHECK();
+      sort_pairs((uint64_t*)keys->ptr<int64_t>(), idx->ptr<int32_t>(), 1, P, st);
+      hipLaunchKernelGGL(compose_order_kernel, dim3(grid_for(L, 256)), dim3(256), 0, st, order->ptr<int32_t>(), idx->ptr<int32_t>(), next->ptr<int32_t>(), L);
+      LAMP_LAUNCH_CHECK();
+      std::swap(order, next);
+    }
+  }
+  unique_slices(a, d, xs.get(), order->ptr<int32_t>(), values, inverse_or_null, counts_or_null, st);
+  LAMP_API_END
+}
+
+int lamp_cartesian_prod(lamp_tensor** out, lamp_tensor* const* tensors, int n) {
+  LAMP_API_BEGIN
+  LAMP_CHECK(n >= 1, "cartesian_prod of no tensors");
+  for (int i = 0; i < n; i++) LAMP_CHECK(tensors[i] && tensors[i]->ndim == 1, "cartesian_prod expects 1-D tensors");
+  if (n == 1) { *out = retain(tensors[0]); return 0; }
+  std::vector<int64_t> full(n);
+  for (int i = 0; i < n; i++) full[i] = tensors[i]->sizes[0];
+  std::vector<Hold> cols;
+  std::vector<lamp_tensor*> raw;
+  for (int i = 0; i < n; i++) {
+    std::vector<int64_t> one(n, 1);
+    one[i] = full[i];
+    lamp_tensor *v = nullptr, *e = nullptr, *f = nullptr;
+    LAMP_CHECK(lamp_reshape(&v, tensors[i], one.data(), n) == 0, lamp_last_error());
+    Hold hv(v);
+    LAMP_CHECK(lamp_expand(&e, hv.get(), full.data(), n) == 0, lamp_last_error());
+    Hold he(e);
+    const int64_t flat[1] = {-1};
+    LAMP_CHECK(lamp_reshape(&f, he.get(), flat, 1) == 0, lamp_last_error());
+    cols.emplace_back(f);
+    raw.push_back(cols.back().get());
+  }
+  return lamp_stack(out, raw.data(), n, 1);
+  LAMP_API_END
+}
+
 }  // extern "C"

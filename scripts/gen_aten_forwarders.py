@@ -40,6 +40,10 @@ EXPLICIT = {
                      "long[] r = N.lamp_unique(h(self));\n    N.lamp_tensor_release(r[2]);\n    return new Tensor[] {own(r[0]), own(r[1])};"),
     "ATen._unique2": ("Tensor self, boolean sorted, boolean returnInverse, boolean returnCounts", "Tensor[]",
                       "return Tensor.owningAll(N.lamp_unique(h(self)));"),
+    "ATen.unique_dim": ("Tensor self, long dim, boolean sorted, boolean returnInverse, boolean returnCounts", "Tensor[]",
+                        "return Tensor.owningAll(N.lamp_unique_dim(h(self), dim));"),
+    "ATen.unique_consecutive": ("Tensor self, boolean returnInverse, boolean returnCounts, long dim", "Tensor[]",
+                                "return Tensor.owningAll(N.lamp_unique_consecutive(h(self), dim));"),
     "ATen.index_copy_out": ("Tensor out, Tensor self, long dim, Tensor index, Tensor source", "void",
                             "long r = N.lamp_index_copy(h(self), dim, h(index), h(source));\n    N.lamp_copy_(h(out), r, 0);\n    N.lamp_tensor_release(r);"),
     "ATen.median_0": ("Tensor self", "Tensor",

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from lamp_amd import sten as S
-from lamp_amd._capi import lib, i64_array
+from lamp_amd._capi import lib, i64_array, handle_array
 from tests.util import DTYPES, FWD_TOL, assert_close, closed_form, to_sten, to_torch
 
 pytestmark = pytest.mark.gpu
@@ -1766,6 +1766,37 @@ def test_sorting_family_special_values(gpu):
                 S.STen(o).to_numpy()                     # the host wait that reports the device-side check
     o = _out1(); lib.lamp_multinomial(C.byref(o), to_sten(torch.tensor([0.0, 1.0, 0.0])), 3, 1)
     assert S.STen(o).to_numpy().tolist() == [1, 1, 1]
+
+
+def test_mode_unique_along_a_dimension_and_cartesian_product(gpu):
+    """STen.mode (STen.scala:1561), STen.unique(dim, ...) (:1059), STen.uniqueConsecutive (:1068), STen.cartesianProduct (:674) against ATen:
+    values and integer outputs bit-exact (mode: the smallest most frequent value and the position of its LAST occurrence; unique_dim: slices
+    sorted lexicographically over their flattened elements - the third dimension of a 3-D tensor included, where the flattening order matters)."""
+    g = torch.Generator().manual_seed(7)
+    for shape, dim in [((5,), 0), ((6, 9), 1), ((6, 9), 0), ((4, 5, 6), 1), ((4, 5, 6), 2), ((300, 7), 0), ((3, 2000), 1)]:
+        for dt in (torch.int64, torch.float32):
+            x = torch.randint(0, 4, shape, generator=g).to(dt)
+            for keep in (0, 1):
+                mv, mi = _out1(), _out1()
+                lib.lamp_mode(C.byref(mv), C.byref(mi), to_sten(x), dim, keep)
+                rv, ri = torch.mode(x, dim, bool(keep))
+                assert np.array_equal(S.STen(mv).to_numpy(), rv.numpy()) and np.array_equal(S.STen(mi).to_numpy(), ri.numpy()), (shape, dim, dt, keep)
+            for name, ref in (("lamp_unique_dim", lambda t: torch.unique(t, sorted=True, return_inverse=True, return_counts=True, dim=dim)),
+                              ("lamp_unique_consecutive", lambda t: torch.unique_consecutive(t, return_inverse=True, return_counts=True, dim=dim))):
+                v, inv, cnt = _out1(), _out1(), _out1()
+                getattr(lib, name)(C.byref(v), C.byref(inv), C.byref(cnt), to_sten(x), dim)
+                rv, rinv, rcnt = ref(x)
+                assert np.array_equal(S.STen(v).to_numpy(), rv.numpy()), (name, shape, dim, dt)
+                assert np.array_equal(S.STen(inv).to_numpy(), rinv.numpy()) and np.array_equal(S.STen(cnt).to_numpy(), rcnt.numpy()), (name, shape, dim, dt)
+                v2 = _out1()
+                getattr(lib, name)(C.byref(v2), None, None, to_sten(x), dim)
+                assert np.array_equal(S.STen(v2).to_numpy(), rv.numpy())
+    ts = [torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4.0, 5.0]), torch.tensor([7.0, 8.0, 9.0, 10.0])]
+    for k in (1, 2, 3):
+        o = _out1()
+        hs = [to_sten(t) for t in ts[:k]]
+        lib.lamp_cartesian_prod(C.byref(o), handle_array([h.h for h in hs]), k)
+        assert np.array_equal(S.STen(o).to_numpy(), torch.cartesian_prod(*ts[:k]).numpy())
 
 
 def test_randperm_and_multinomial(gpu):
