@@ -808,6 +808,172 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
   }
 }
 
+// ---- the one-pass backward in f32 and f64 (round 5): the precisions the reference's CIFAR example runs in ---------------
+// (example-cifar100 cifar100.scala:127-129; op ops.scala:2037-2140).  The same protocol as bn_bwd_fused_kernel on 16-byte packets of 4 floats /
+// 2 doubles: workgroup (c, s) keeps its NP packets of (masked) dy and of x in registers, publishes its two partial sums, polls the S slots
+// of its channel, sums them in a fixed order and writes dx (and the addend's gradient) from the registers: 5 -> 3 passes (7 -> 5 with an
+// addend), one launch instead of two.  Sums in the accumulation type of the two-kernel form (f32 / f64).  An f32 activation of the step is
+// 67 MB - more than 256 co-resident workgroups hold (33.5 MB per operand) - so the host launches the channels in CHUNKS that are each fully
+// co-resident (64 channels x 4 slices for 128 x 2048 x 8 x 8 in f32): c0 is the chunk's first channel, slots are indexed inside the chunk.
+// f64 sums need 16 bytes: the second sum travels through a second slot array (each slot is written by one 8-byte atomic store; the reader
+// polls both, as the dual bf16 form does).
+template <class A> __device__ __forceinline__ unsigned long long bn_slot_bits(A v);
+template <> __device__ __forceinline__ unsigned long long bn_slot_bits<double>(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return b == ~0ull ? 0x7ff8000000000000ull : b;            // a NaN either way; the all-ones pattern means "not written yet"
+}
+template <class T, int NP, bool RELU, bool ADD>
+__global__ __launch_bounds__(512) void bn_bwd_fused_fp_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ mean, const T* __restrict__ invstd,
+                                                              const T* __restrict__ w, const T* __restrict__ b, unsigned long long* slots, unsigned long long* slots2,
+                                                              unsigned* depart, T* dweight, T* dbias, T* __restrict__ dx, int64_t N, int C, int HW, int S, double inv_m,
+                                                              const T* __restrict__ addend, T* __restrict__ dadd, int vshift, int* assert_word, int c0) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / (int)sizeof(T);
+  constexpr bool F64 = sizeof(A) == 8;
+  __shared__ A sm[2][8];
+  __shared__ A stat[2];
+  const int cl = blockIdx.x / S, s = blockIdx.x - cl * S, c = c0 + cl;      // cl: channel inside this launch's chunk
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int vpp = HW / W;
+  const int64_t total = N * vpp;                            // packets of this channel
+  const A mu = load_as<A>(mean[c]), is = load_as<A>(invstd[c]);
+  const A wc = w ? load_as<A>(w[c]) : A(1);
+  const A scale = is * wc, bb = (RELU && b) ? load_as<A>(b[c]) : A(0);
+  uint4 gv[NP], xv[NP];
+  int base[NP];                                             // packet (16-byte) index into the tensors, -1: none (host: packets < 2^31)
+  const uint4* dy4 = reinterpret_cast<const uint4*>(dy);
+  const uint4* x4 = reinterpret_cast<const uint4*>(x);
+  const uint4* ad4 = reinterpret_cast<const uint4*>(addend);
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const unsigned i = (unsigned)(k * S + s) * 512u + (unsigned)tid;
+    const bool valid = i < (unsigned)total;
+    const unsigned ii = valid ? i : 0u;
+    const unsigned n = vshift >= 0 ? (ii >> vshift) : (ii / (unsigned)vpp);
+    const int idx = (int)((n * (unsigned)C + (unsigned)c) * (unsigned)vpp + (ii - n * (unsigned)vpp));
+    base[k] = valid ? idx : -1;
+    gv[k] = nt_load16(dy4 + idx);                           // the gradient's last reader
+    xv[k] = x4[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++)
+    if (base[k] < 0) gv[k] = make_uint4(0, 0, 0, 0);        // contributes nothing to the sums, never stored
+  A s1 = 0, s2 = 0;
+  constexpr int GRP = NP > 4 ? 4 : NP;                      // the addend is only needed for the mask: loaded in groups of <= 4 packets
+#pragma unroll
+  for (int h = 0; h < NP; h += GRP) {
+    uint4 av[GRP];
+    if (ADD) {
+#pragma unroll
+      for (int k = 0; k < GRP; k++) av[k] = ad4[base[h + k] >= 0 ? base[h + k] : c * vpp];
+    }
+#pragma unroll
+    for (int k = 0; k < GRP; k++) {
+      T* gp = reinterpret_cast<T*>(&gv[h + k]);
+      const T* xp = reinterpret_cast<const T*>(&xv[h + k]);
+      const T* ap = reinterpret_cast<const T*>(&av[k]);
+#pragma unroll
+      for (int q = 0; q < W; q++) {
+        const A xx = load_as<A>(xp[q]);
+        A gg = load_as<A>(gp[q]);
+        if (RELU) {
+          T pre = store_as<T>(bn_affine<A>(xx, mu, scale, bb));
+          if (ADD) pre = store_as<T>((A)(load_as<A>(pre) + load_as<A>(ap[q])));
+          if (load_as<A>(pre) < A(0)) { gg = A(0); gp[q] = store_as<T>(A(0)); }
+        }
+        s1 += gg;
+        if (F64) s2 = (A)__builtin_fma((double)gg, (double)(xx - mu), (double)s2); else s2 = (A)__builtin_fmaf((float)gg, (float)(xx - mu), (float)s2);
+      }
+      __builtin_amdgcn_sched_barrier(0);                    // the sums are one serial chain (as in the bf16 kernel)
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    asm volatile("" : "+v"(gv[k].x), "+v"(gv[k].y), "+v"(gv[k].z), "+v"(gv[k].w));
+    asm volatile("" : "+v"(xv[k].x), "+v"(xv[k].y), "+v"(xv[k].z), "+v"(xv[k].w));
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { sm[0][wid] = s1; sm[1][wid] = s2; }
+  __syncthreads();
+  if (wid == 0) {
+    A a = 0, bs = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a += sm[0][k]; bs += sm[1][k]; }
+    if (S > 1) {
+      unsigned long long* slot = slots + (int64_t)cl * S;
+      unsigned long long* slot2 = slots2 + (int64_t)cl * S;
+      if (lane == 0) {
+        if (F64) {
+          __hip_atomic_store(slot2 + s, bn_slot_bits<double>((double)bs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + s, bn_slot_bits<double>((double)a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          unsigned lo = __float_as_uint((float)a), hi = __float_as_uint((float)bs);
+          if (lo == 0xffffffffu) lo = 0x7fc00000u;
+          if (hi == 0xffffffffu) hi = 0x7fc00000u;
+          __hip_atomic_store(slot + s, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      a = 0; bs = 0;
+      unsigned spins = 0;
+      unsigned long long t0 = 0;
+      bool gave_up = false;
+      auto poll = [&](unsigned long long* p) {
+        unsigned long long v;
+        while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull && !gave_up) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((++spins & 0xfffu) == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 12000000000ull) { gave_up = true; if (assert_word) *assert_word = kAssertBnExchangeTimeout; }
+          }
+        }
+        return v;
+      };
+      for (int k = lane; k < S; k += 64) {
+        const unsigned long long v = poll(slot + k);
+        if (F64) {
+          const unsigned long long v2 = poll(slot2 + k);    // (two independent relaxed stores are not ordered for the reader)
+          a += (A)__longlong_as_double((long long)v); bs += (A)__longlong_as_double((long long)v2);
+        } else { a += (A)__uint_as_float((unsigned)v); bs += (A)__uint_as_float((unsigned)(v >> 32)); }
+      }
+      a = wave_sum(a); bs = wave_sum(bs);
+      if (lane == 0) {
+        const unsigned left = __hip_atomic_fetch_add(depart + cl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (unsigned)S - 1) {
+          for (int k = 0; k < S; k++) __hip_atomic_store(slot + k, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (F64) for (int k = 0; k < S; k++) __hip_atomic_store(slot2 + k, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(depart + cl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (lane == 0) {
+      stat[0] = a; stat[1] = bs;
+      if (s == 0) {
+        if (dweight) dweight[c] = store_as<T>((A)(bs * is));
+        if (dbias) dbias[c] = store_as<T>(a);
+      }
+    }
+  }
+  __syncthreads();
+  if (!dx && !dadd) return;
+  // dx = (g - mean(g) - (x - mean) k) invstd w, k = sum(g (x - mean)) invstd^2 / m: the expression of bn_bwd_apply2_kernel
+  const A kk = stat[1] * is * is * (A)inv_m, gm = stat[0] * (A)inv_m;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    if (base[k] < 0) continue;
+    if (dadd) reinterpret_cast<uint4*>(dadd)[base[k]] = gv[k];
+    if (dx) {
+      uint4 r;
+      T* rp = reinterpret_cast<T*>(&r);
+      const T* gp = reinterpret_cast<const T*>(&gv[k]);
+      const T* xp = reinterpret_cast<const T*>(&xv[k]);
+#pragma unroll
+      for (int q = 0; q < W; q++) rp[q] = store_as<T>((A)((load_as<A>(gp[q]) - gm - (load_as<A>(xp[q]) - mu) * kk) * is * wc));
+      reinterpret_cast<uint4*>(dx)[base[k]] = r;
+    }
+  }
+}
+
 // ---- layer norm: rows [M, D] ---------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ mean_out,
@@ -1042,6 +1208,96 @@ constexpr int BN_FUSED_MAXC = 4096;                         // depart[BN_FUSED_M
 constexpr int BN_FUSED_SLOTS = 4096;
 // the second batch norm of the dual form (bn_bwd_fused_kernel<.., DUAL>): `addc` is then ITS input x2 and `dadd` receives ITS input gradient
 struct BnDualHost { const Tensor* mean2; const Tensor* invstd2; const Tensor* w2; const Tensor* b2; Tensor* dw2; Tensor* db2; };
+// the per-device counters / slots of the waiting kernels, created on first use; orders this launch behind the previous waiting kernel of
+// another stream (two of them must not overlap).  nullptr: the buffer cannot be created from this thread (the tensor's device is not current).
+static unsigned* bn_fused_sync_state(int device, hipStream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool capturing = cap == hipStreamCaptureStatusActive;
+  static std::mutex mu;
+  static std::map<int, BnFusedState> states;
+  std::lock_guard<std::mutex> lk(mu);
+  BnFusedState& stt = states[device];
+  if (!stt.sync) {
+    if (current_device() != device) return nullptr;
+    HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + 2 * BN_FUSED_SLOTS * sizeof(unsigned long long)));
+    hipStream_t side = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_CHECK(hipMemsetAsync(stt.sync, 0, BN_FUSED_MAXC * sizeof(unsigned), side));
+    HIP_CHECK(hipMemsetAsync(stt.sync + BN_FUSED_MAXC, 0xff, 2 * BN_FUSED_SLOTS * sizeof(unsigned long long), side));
+    HIP_CHECK(hipStreamSynchronize(side));
+    HIP_CHECK(hipStreamDestroy(side));
+    HIP_CHECK(hipEventCreateWithFlags(&stt.ev, hipEventDisableTiming));
+  }
+  if (!capturing) {
+    if (stt.has_last && stt.last != st) {
+      HIP_CHECK(hipEventRecord(stt.ev, stt.last));
+      HIP_CHECK(hipStreamWaitEvent(st, stt.ev, 0));
+    }
+    stt.last = st; stt.has_last = true;
+  }
+  return stt.sync;
+}
+// f32 / f64 (bn_bwd_fused_fp_kernel): the channels are launched in chunks whose workgroups are all co-resident
+template <class T>
+static bool bn_bwd_fused_fp_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
+                                   Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st) {
+  static const bool env_on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+  static const bool fp_on = [] { const char* e = getenv("LAMP_BN_FUSED_FP"); return !(e && e[0] == '0'); }();
+  const int mode = g_bn_bwd_mode.load(std::memory_order_relaxed);
+  const bool on = mode < 0 ? (env_on && fp_on) : mode >= 1;
+  if (on && mode != 2 && device_shared(xc->device()) > 0) return false;
+  constexpr int W = 16 / (int)sizeof(T);
+  if (!on || g.HW % W != 0) return false;
+  const int64_t packets = g.N * (g.HW / W);                 // per channel
+  if (packets <= 0 || packets >= (int64_t)1 << 30 || xc->numel() / W >= (int64_t)1 << 31) return false;
+  if (addc && !relu) return false;
+  const int cus = num_cus();
+  auto per_thread = [&](int64_t s) { return (packets + s * 512 - 1) / (s * 512); };
+  int64_t s = std::max<int64_t>(1, (int64_t)cus / g.C);
+  s = std::min<int64_t>(s, (packets + 511) / 512);
+  if (per_thread(s) > 16) s = (packets + 16 * 512 - 1) / (16 * 512);
+  const int ppt = (int)per_thread(s);
+  const int NP = ppt <= 1 ? 1 : ppt <= 2 ? 2 : ppt <= 4 ? 4 : ppt <= 8 ? 8 : 16;
+  static const int np_mask = [] { const char* e = getenv("LAMP_BN_FUSED_NP_MASK"); return e ? atoi(e) : 24; }();   // as the bf16 form: the large activations
+  if (!(np_mask & NP)) return false;
+#define BN_FP_K(NPv) (addc ? (const void*)bn_bwd_fused_fp_kernel<T, NPv, true, true> : relu ? (const void*)bn_bwd_fused_fp_kernel<T, NPv, true, false> \
+                           : (const void*)bn_bwd_fused_fp_kernel<T, NPv, false, false>)
+  const void* kfn = NP == 1 ? BN_FP_K(1) : NP == 2 ? BN_FP_K(2) : NP == 4 ? BN_FP_K(4) : NP == 8 ? BN_FP_K(8) : BN_FP_K(16);
+#undef BN_FP_K
+  const int64_t resident = std::min<int64_t>(BN_FUSED_SLOTS, (int64_t)cus * std::max(1, kernel_occupancy(kfn, 512, 0)));
+  if (s > resident) return false;                           // one channel's slices alone do not fit the chip
+  const int64_t chunk = std::min<int64_t>(std::min<int64_t>(g.C, resident / s), BN_FUSED_MAXC);
+  unsigned* sync = bn_fused_sync_state(xc->device(), st);
+  if (!sync) return false;
+  unsigned* departp = sync;
+  unsigned long long* slotp = reinterpret_cast<unsigned long long*>(sync + BN_FUSED_MAXC);
+  unsigned long long* slot2p = slotp + BN_FUSED_SLOTS;
+  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);
+  KernelTimer kt("bn_bwd_fused", 0, passes * (double)xc->numel() * sizeof(T), st);
+  const T* dyp = gc->ptr<T>(); const T* xp = xc->ptr<T>();
+  const T* mp = mean_t->ptr<T>(); const T* ip = invstd_t->ptr<T>();
+  const T* wp = weight ? weight->ptr<T>() : (const T*)nullptr;
+  const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+  T* dwp = dw ? dw->ptr<T>() : (T*)nullptr; T* dbp = db ? db->ptr<T>() : (T*)nullptr;
+  T* dxp = dx ? dx->ptr<T>() : (T*)nullptr;
+  int64_t a_N = g.N; int a_C = (int)g.C, a_HW = (int)g.HW, a_S = (int)s;
+  double inv_m = 1.0 / (double)(g.N * g.HW);
+  const int vppi = (int)(g.HW / W);
+  int a_vshift = -1;
+  for (int b = 0; b < 31; b++) if (vppi == (1 << b)) a_vshift = b;
+  const T* adp = addc ? addc->ptr<T>() : (const T*)nullptr;
+  T* dap = dadd ? dadd->ptr<T>() : (T*)nullptr;
+  int* awp = device_assert_word(xc->device());
+  for (int64_t c0 = 0; c0 < g.C; c0 += chunk) {
+    int a_c0 = (int)c0;
+    const int64_t nc = std::min<int64_t>(chunk, g.C - c0);
+    void* args[] = {(void*)&dyp, (void*)&xp, (void*)&mp, (void*)&ip, (void*)&wp, (void*)&bp, (void*)&slotp, (void*)&slot2p, (void*)&departp, (void*)&dwp, (void*)&dbp,
+                    (void*)&dxp, (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&adp, (void*)&dap, (void*)&a_vshift, (void*)&awp, (void*)&a_c0};
+    HIP_CHECK(hipLaunchKernel(kfn, dim3((unsigned)(nc * s)), dim3(512), args, 0, st));
+  }
+  return true;
+}
 static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
                                 Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st,
                                 const BnDualHost* dualh = nullptr) {
@@ -1080,40 +1336,12 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
     if (g.C * s <= std::min<int64_t>(BN_FUSED_SLOTS, (int64_t)cus * std::max(1, kernel_occupancy(k, 512, 0)))) { kfn = k; S = s; }
   }
   if (!kfn) return false;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-  const bool capturing = cap == hipStreamCaptureStatusActive;
-  static std::mutex mu;
-  static std::map<int, BnFusedState> states;
-  unsigned* sync = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    BnFusedState& stt = states[xc->device()];
-    if (!stt.sync) {
-      // zeroed once, on a stream of its own and waited for: st may be capturing, and the counters must be zero in memory before the
-      // first launch really runs (whichever stream or graph that is)
-      if (current_device() != xc->device()) return false;     // (callers run with the tensor's device current; the buffer must live there)
-      HIP_CHECK(hipMalloc((void**)&stt.sync, BN_FUSED_MAXC * sizeof(unsigned) + 2 * BN_FUSED_SLOTS * sizeof(unsigned long long)));   // + the dual form's second slots
-      hipStream_t side = nullptr;
-      HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      HIP_CHECK(hipMemsetAsync(stt.sync, 0, BN_FUSED_MAXC * sizeof(unsigned), side));
-      HIP_CHECK(hipMemsetAsync(stt.sync + BN_FUSED_MAXC, 0xff, 2 * BN_FUSED_SLOTS * sizeof(unsigned long long), side));
-      HIP_CHECK(hipStreamSynchronize(side));
-      HIP_CHECK(hipStreamDestroy(side));
-      HIP_CHECK(hipEventCreateWithFlags(&stt.ev, hipEventDisableTiming));
-    }
-    if (!capturing) {
-      // one counter set per device and workgroups that wait for each other: two of these kernels must not overlap.  Same stream: ordered
-      // anyway.  Another stream: this launch waits for everything queued there so far.  (A graph replayed on one stream while another
-      // thread runs eagerly on a second one is not covered: LAMP_BN_FUSED_BWD=0 for such a program.)
-      if (stt.has_last && stt.last != st) {
-        HIP_CHECK(hipEventRecord(stt.ev, stt.last));
-        HIP_CHECK(hipStreamWaitEvent(st, stt.ev, 0));
-      }
-      stt.last = st; stt.has_last = true;
-    }
-    sync = stt.sync;
-  }
+  // one counter set per device and workgroups that wait for each other: two of these kernels must not overlap.  Same stream: ordered anyway.
+  // Another stream: this launch waits for everything queued there so far.  (A graph replayed on one stream while another thread runs eagerly
+  // on a second one is not covered: LAMP_BN_FUSED_BWD=0 for such a program.)  The buffer is zeroed once, on a stream of its own and waited
+  // for: st may be capturing, and the counters must be zero in memory before the first launch really runs.
+  unsigned* sync = bn_fused_sync_state(xc->device(), st);
+  if (!sync) return false;                                  // (callers run with the tensor's device current; the buffer must live there)
   unsigned* departp = sync;
   unsigned long long* slotp = reinterpret_cast<unsigned long long*>(sync + BN_FUSED_MAXC);
   const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);   // (the dual form's second read of x2 is served by the caches)
@@ -1372,6 +1600,9 @@ static int bn_backward_impl(lamp_tensor* out3[3], const lamp_tensor* grad_out, c
     if constexpr (std::is_same<T, bf16_t>::value) {
       if (training && vec && !col && total > 0 && (dx.get() || dadd.get()))
         fused_done = bn_bwd_fused_launch(gc.get(), xc.get(), mean_t, invstd_t, weight, bias, dw.get(), db.get(), dx.get(), dadd.get(), addc.get(), g, relu, st);
+    } else if constexpr (std::is_same<T, float>::value || std::is_same<T, double>::value) {
+      if (training && vec && !col && total > 0 && (dx.get() || dadd.get()))
+        fused_done = bn_bwd_fused_fp_launch<T>(gc.get(), xc.get(), mean_t, invstd_t, weight, bias, dw.get(), db.get(), dx.get(), dadd.get(), addc.get(), g, relu, st);
     }
     if (!fused_done) {
     const int64_t blocks = col ? (g.C + 255) / 256 : g.C;

@@ -51,24 +51,50 @@ def parse_blocks(path):
             except ValueError: pass
     return out
 
+NSQ = 32            # SQ_BUSY_CYCLES is summed over the chip's 8 XCDs x 4 shader engines (a 112 us GEMM at the 1.9 - 2.0 GHz its in-kernel clock shows: 30.2 kernel lengths)
+NSIMD = 1024
+FMAX_MHZ = 2400.0   # the part's maximum engine clock: an implied clock above it means the counter window was wider than the kernel
+
 if sys.argv[1] == "--table":
+    # the elapsed-cycle denominator comes from the SAME pass as the numerators - SQ_BUSY_CYCLES / 32 - instead of
+    # GRBM_GUI_ACTIVE / 8 of another run (whose window is wider than a 5 - 40 us kernel: implied clocks of 3 - 5 GHz in round 4's table);
+    # the clock it implies against the kernel-trace duration is printed and rows above the part's 2.4 GHz are refused; a lower bound of the
+    # matrix-pipe share that needs no cycle counter at all (kernel-trace duration x 2.4 GHz) stands beside it.
     d = sys.argv[2]
     for f in sorted(glob.glob(os.path.join(d, "*_group1.txt"))):
         print("==", os.path.basename(f)[:-11])
         g2 = parse_blocks(f.replace("_group1.txt", "_group2.txt")) if os.path.exists(f.replace("_group1.txt", "_group2.txt")) else {}
         g1 = parse_blocks(f)
+        text = open(f).read().split("\n")
+        us_of = {}
         name = None
-        for line in open(f).read().split("\n"):
+        for line in text:
             if line and not line.startswith(" "):
                 name = line
-                # the matrix pipes' busy share of the kernel's elapsed cycles: MFMA-busy cycles summed over 1024 SIMDs (group 1) against
-                # GRBM_GUI_ACTIVE summed over 8 XCDs (group 2, another run of the same command)
-                if name in g2 and "GRBM_GUI_ACTIVE" in g2[name] and "SQ_VALU_MFMA_BUSY_CYCLES" in g1.get(name, {}):
-                    busy = g1[name]["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (g2[name]["GRBM_GUI_ACTIVE"] / 8.0)
-                    extra = ""
-                    if "SQ_ACTIVE_INST_LDS" in g2[name]:
-                        extra = f", lds-instruction cycles per SIMD / elapsed {g2[name]['SQ_ACTIVE_INST_LDS'] * 4.0 / 1024.0 / (g2[name]['GRBM_GUI_ACTIVE'] / 8.0):.3f}"
-                    print(f"{name[:50]:50s} mfma_pipe_busy / elapsed cycles {busy:.3f} at {g2[name].get('clock_MHz_from_GRBM_GUI_ACTIVE', 0):.0f} MHz{extra}")
+            elif name and "avg_us" in line:
+                us_of[name] = float(line.split("avg_us")[1].split()[0])
+        name = None
+        for line in text:
+            if line and not line.startswith(" "):
+                name = line
+                c, us = g1.get(name, {}), us_of.get(name)
+                if us and c.get("SQ_BUSY_CYCLES", 0) > 0:
+                    elapsed = c["SQ_BUSY_CYCLES"] / NSQ
+                    clock = elapsed / us                               # MHz
+                    mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / NSIMD
+                    lower = mf / (us * FMAX_MHZ)
+                    if clock > FMAX_MHZ * 1.02:
+                        print(f"{name[:50]:50s} REFUSED: SQ_BUSY_CYCLES / {NSQ} implies {clock:.0f} MHz over a {us:.2f} us kernel (> {FMAX_MHZ:.0f}): no cycle-based share; "
+                              f"mfma_pipe_busy >= {lower:.3f} of the duration at {FMAX_MHZ:.0f} MHz")
+                    else:
+                        extra = ""
+                        if name in g2 and "SQ_ACTIVE_INST_LDS" in g2[name]:
+                            extra = f", lds-instruction cycles per SIMD / elapsed {g2[name]['SQ_ACTIVE_INST_LDS'] * 4.0 / NSIMD / elapsed:.3f}"
+                        print(f"{name[:50]:50s} mfma_pipe_busy / sq_busy cycles {mf / elapsed:.3f} (implied clock {clock:.0f} MHz; >= {lower:.3f} of the duration at {FMAX_MHZ:.0f} MHz){extra}")
+                    if name in g2 and "GRBM_GUI_ACTIVE" in g2[name] and name in us_of:
+                        gclk = g2[name]["GRBM_GUI_ACTIVE"] / 8.0 / us
+                        flag = "  <- wider than the kernel: not used" if gclk > FMAX_MHZ * 1.02 else ""
+                        print(f"{name[:50]:50s} cross-check: GRBM_GUI_ACTIVE / 8 of the second pass implies {gclk:.0f} MHz{flag}")
             elif "avg_us" in line or "shares of wave" in line or "SQ_VALU_MFMA_BUSY_CYCLES" in line or "SQ_INSTS_MFMA" in line:
                 print(f"{name[:50]:50s} {line.strip()}")
 else:

@@ -495,14 +495,15 @@ BN_ONE_PASS_CASES = [(2048, 128, 8, 2), (2048, 128, 8, 1), (2048, 100, 8, 0), (2
                      (1024, 64, 8, 0), (37, 5, 12, 2), (3, 130, 8, 1), (512, 300, 8, 0)]   # small: the two kernels
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float64])
 @pytest.mark.parametrize("case", BN_ONE_PASS_CASES)
-def test_batch_norm_backward_in_one_pass(gpu, case):
-    """bf16 training-mode batch-norm backward reads dy and x ONCE (bn_bwd_fused_kernel: the workgroups of a channel keep their slice in
-    registers while they wait for each other's partial sums).  Checked against ATen in f32 on the bf16 inputs, at the ResNet step's
-    shapes and at ragged ones; repeated launches (the wait counters reset themselves) and launches that alternate between two
-    streams give bitwise the same tensors."""
+def test_batch_norm_backward_in_one_pass(gpu, case, dt):
+    """Training-mode batch-norm backward reads dy and x ONCE (bn_bwd_fused_kernel, and since round 5 bn_bwd_fused_fp_kernel for f32 / f64 - the
+    precisions the reference's example runs in - whose channels are launched in co-resident chunks): the workgroups of a channel keep their
+    slice in registers while they wait for each other's partial sums.  Checked against ATen (f32 arithmetic on the bf16 inputs; f64 for the
+    wide types), at the ResNet step's shapes and at ragged ones; repeated launches (the wait counters reset themselves) and launches that
+    alternate between two streams give bitwise the same tensors."""
     N, Cc, H, variant = case
-    dt = torch.bfloat16
     shape = (N, Cc, H, H)
     x = closed_form(shape, 3, 4.0, dt) + 0.3
     addend = closed_form(shape, 29, 3.0, dt)
@@ -534,19 +535,33 @@ def test_batch_norm_backward_in_one_pass(gpu, case):
     if N >= 2048:                                           # the large activations (>= 8 packets per thread); small ones keep the two kernels
         assert b"bn_bwd_fused" in buf.value and b"bn_bwd_reduce" not in buf.value, buf.value.decode()
     first_np = [t.to_numpy() for t in first]
-    # reference: f32 arithmetic on the same bf16 values, the mask from the ROUNDED pre-activation as the kernels take it
-    xf, mean, invstd = x.float(), to_torch(sm).float(), to_torch(si).float()
-    g = gy.float()
+    # reference: the accumulation type's arithmetic on the same values, the mask from the ROUNDED pre-activation as the kernels take it
+    at = torch.float64 if dt == torch.float64 else torch.float32
+    xf, mean, invstd = x.to(at), to_torch(sm).to(at), to_torch(si).to(at)
+    g = gy.to(at)
     if variant >= 1:
-        pre = ((xf - mean.view(1, -1, 1, 1)) * (invstd * w.float()).view(1, -1, 1, 1) + b.float().view(1, -1, 1, 1)).to(dt)
+        pre = torch.addcmul(b.to(at).view(1, -1, 1, 1), xf - mean.view(1, -1, 1, 1), (invstd * w.to(at)).view(1, -1, 1, 1)).to(dt)
         if variant == 2:
-            pre = (pre.float() + addend.float()).to(dt)
-        g = torch.where(pre.float() < 0, torch.zeros_like(g), g)
-    ref = aten.native_batch_norm_backward(g, xf, w.float(), None, None, mean, invstd, True, 1e-5, [True, True, True])
-    for got, want, what in zip(first, ref, ("dx", "dweight", "dbias")):
-        assert_close(to_torch(got), want.double(), 4e-2, what)
-    if variant == 2:
+            pre = (pre.to(at) + addend.to(at)).to(dt)
+        g = torch.where(pre.to(at) < 0, torch.zeros_like(g), g)
+    ref = aten.native_batch_norm_backward(g.double(), xf.double(), w.double(), None, None, mean.double(), invstd.double(), True, 1e-5, [True, True, True])
+    tol = {torch.bfloat16: 4e-2, torch.float32: 2e-4, torch.float64: 1e-9}[dt]
+    if dt == torch.bfloat16 or variant == 0:                # (wide types: an element whose pre-activation is within rounding of 0 may take the other branch)
+        for got, want, what in zip(first, ref, ("dx", "dweight", "dbias")):
+            assert_close(to_torch(got), want.double(), tol, what)
+    if variant == 2 and dt == torch.bfloat16:
         assert torch.equal(to_torch(first[3]).float(), g), "the addend's gradient is the masked dy, exactly"
+    if dt != torch.bfloat16:
+        # the two-kernel form on the same inputs: same masks (same expression), sums in another order
+        lib.lamp_bn_backward_mode(0)
+        try:
+            two = backward()
+        finally:
+            lib.lamp_bn_backward_mode(-1)
+        for got, want, what in zip(first, two, ("dx", "dweight", "dbias", "daddend")):
+            assert_close(to_torch(got), to_torch(want), tol, "one pass vs two kernels: " + what)
+        if variant == 2:
+            assert torch.equal(to_torch(first[3]), to_torch(two[3])), "the addend's gradient (the masked dy) is exact in both forms"
     for _ in range(5):
         for a, t in zip(first_np, backward()):
             assert np.array_equal(a, t.to_numpy()), "a repeated launch differs"
@@ -1323,15 +1338,17 @@ def test_deferred_reductions_belong_to_the_thread_that_registered_them(gpu):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32, torch.float64])
 @pytest.mark.parametrize("held", [32, 64, 128, 224])
-def test_one_pass_batch_norm_backward_under_cu_pressure(gpu, held):
+def test_one_pass_batch_norm_backward_under_cu_pressure(gpu, held, dt):
     """the one-pass batch-norm backward (workgroups of a channel wait for each other's partial sums) on a device
     it does NOT have to itself.  `held` single-wave workgroups spin for 3 ms on a high-priority second stream - with 512-thread,
     register-file-filling batch-norm workgroups that is `held` CUs taken away - while the six large maps of the ResNet step run their
     backward on the compute stream.  The kernel has to finish (workgroups are handed out in launch order, so the channels complete
     one after the other as CUs free up) with bitwise the results it gives on an idle device, which in turn agree with the two-kernel
-    form; marked shared through lamp_device_shared_hint the host takes the two kernels by itself."""
-    dt = torch.bfloat16
+    form; marked shared through lamp_device_shared_hint the host takes the two kernels by itself.  f32 / f64 (round 5): the chunked launches
+    of bn_bwd_fused_fp_kernel size their chunks for an idle chip - under pressure a chunk is NOT fully co-resident and completes channel
+    by channel all the same."""
     maps = [(2048, 6, 32, 1), (2048, 16, 16, 2), (2048, 128, 8, 2), (2048, 128, 8, 1), (2048, 100, 8, 0), (2048, 16, 16, 1)]
     hi = C.c_void_p(); lib.lamp_stream_get_from_pool(1, 0, C.byref(hi))
     tensors = []
@@ -1390,7 +1407,8 @@ def test_one_pass_batch_norm_backward_under_cu_pressure(gpu, held):
                 assert np.array_equal(a, p.to_numpy()), f"round {rnd}: results under CU pressure differ from the idle device's"
         # the two forms agree (different summation order of the channel sums: bf16 tolerance on dweight / dbias, dx follows them)
         for a, t in zip(alone, two):
-            assert_close(torch.from_numpy(a), torch.from_numpy(t).double(), 4e-2, "one-pass vs two-kernel batch-norm backward")
+            assert_close(torch.from_numpy(a), torch.from_numpy(t).double(), {torch.bfloat16: 4e-2, torch.float32: 2e-4, torch.float64: 1e-9}[dt],
+                         "one-pass vs two-kernel batch-norm backward")
         # marked shared: the default rule takes the two kernels (what the eager data-parallel step does while its all-reduce is in flight)
         lib.lamp_bn_backward_mode(-1)
         lib.lamp_device_shared_hint(0, 1)
