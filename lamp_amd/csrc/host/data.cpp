@@ -266,7 +266,8 @@ struct BatchStreamImpl {
   lamp_stream* side = nullptr;
   Ten ahead_x, ahead_t;          // the prefetched batch (valid when ahead_for >= 0)
   int64_t ahead_for = -1;
-  ~BatchStreamImpl() { if (side) lamp_stream_release(side); }
+  lamp_stream* ahead_stream = nullptr;   // default mode: the stream the prefetched batch was queued on (the consumer's current stream THEN)
+  ~BatchStreamImpl() { if (side) lamp_stream_release(side); if (ahead_stream) lamp_stream_release(ahead_stream); }
 };
 
 }  // namespace host
@@ -398,6 +399,15 @@ int lamp_batch_stream_from_full_host(lamp_batch_stream** out, const lamp_tensor*
   int fdev = 0;
   HCALL(lamp_tensor_device(features, &fdev));
   LAMP_CHECK(fdev < 0, "lamp_batch_stream_from_full_host: the features must live in host memory");
+  {
+    // the conversions the gather kernel has (kernels/index.hip, lamp_index_select_pinned): checked here, not at the first batch
+    int fdt = 0;
+    HCALL(lamp_tensor_scalar_type(features, &fdt));
+    const int odt = out_dtype < 0 ? fdt : out_dtype;
+    const bool ok = odt == fdt || (fdt == kF32 && odt == kBF16) || (fdt == kU8 && (odt == kBF16 || odt == kF32)) || (fdt == kF64 && odt == kF32);
+    LAMP_CHECK(ok, "lamp_batch_stream_from_full_host: no gather converts records of scalar type " << fdt << " to " << odt
+                   << " (same type, f32 -> bf16, u8 -> bf16 / f32, f64 -> f32)");
+  }
   auto stream = std::make_unique<lamp_batch_stream>();
   BatchStreamImpl& s = stream->s;
   int pinned = 0;
@@ -428,6 +438,10 @@ static void prefetch_batch(BatchStreamImpl& s, int64_t b) {
   Ten idx = ops::slice(s.order, 0, lo, hi, 1);
   lamp_tensor *x = nullptr, *t = nullptr;
   if (!s.side) {                                             // default: the gather is queued on the consumer's stream
+    // ... of THIS call: a consumer that has another current stream when the batch is handed out (the reference's loader runs on its own
+    // stream, device.scala:199-213) is ordered behind this one then
+    if (s.ahead_stream) { (void)lamp_stream_release(s.ahead_stream); s.ahead_stream = nullptr; }
+    HCALL(lamp_stream_get_current(s.device, &s.ahead_stream));
     const int rc1 = lamp_index_select_pinned(&x, s.features.h(), idx.h(), s.out_dtype);
     const int rc2 = rc1 == 0 ? lamp_index_select(&t, s.target.h(), 0, idx.h()) : 1;
     if (rc1 != 0 || rc2 != 0) { if (x) lamp_tensor_release(x); throw Error(lamp_last_error()); }
@@ -480,6 +494,18 @@ int lamp_batch_stream_next(lamp_batch_stream* st, lamp_tensor** x, lamp_tensor**
       HCALL(lamp_stream_wait_stream(cur, s.side));
       HCALL(lamp_tensor_record_stream(xb.h(), cur));
       HCALL(lamp_tensor_record_stream(tb.h(), cur));
+      HCALL(lamp_stream_release(cur));
+    } else if (s.ahead_stream) {
+      // queued on whatever stream was current one call ago: the same one now (the usual case) needs nothing
+      lamp_stream* cur = nullptr;
+      HCALL(lamp_stream_get_current(s.device, &cur));
+      void *a = nullptr, *c = nullptr;
+      (void)lamp_stream_native(s.ahead_stream, &a); (void)lamp_stream_native(cur, &c);
+      if (a != c) {
+        HCALL(lamp_stream_wait_stream(cur, s.ahead_stream));
+        HCALL(lamp_tensor_record_stream(xb.h(), cur));
+        HCALL(lamp_tensor_record_stream(tb.h(), cur));
+      }
       HCALL(lamp_stream_release(cur));
     }
     int64_t nb = s.cursor;                                   // the next batch this stream will hand out

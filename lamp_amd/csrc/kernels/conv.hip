@@ -308,7 +308,8 @@ bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const Conv
                        bool* addend_fused = nullptr);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
-bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st);
+bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
+                      bool* addend_fused = nullptr);
 bool small_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 
 Tensor* reduce_dims(const Tensor* a, const int64_t* dims, int ndims, bool keepdim, int op);
@@ -542,7 +543,7 @@ int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* gr
   Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
   bool fused = false;
   if (!igemm_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !igemm32_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) &&
-      !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st)) {
+      !narrow_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused) && !small_conv_dgrad(gc.get(), wc.get(), dx.get(), g, st, ac.get(), &fused)) {
     LAMP_DISPATCH_FLOAT(x->dtype, T, (launch_dgrad<T>(gc.get(), wc.get(), nullptr, dx.get(), g, st)));
   }
   if (fused) { *out = dx.take(); }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void cs2_fwd_kernel(const T* __restrict__ x, c
 // dgrad: one workgroup per image, one thread per ST x ST block of dx; dy staged with a halo of PAD zeros
 template <class T, int CB, int KS, int ST>
 __global__ __launch_bounds__(256) void cs2_dgrad_kernel(const T* __restrict__ dy, const typename CsAccOf<T>::type* __restrict__ wf, T* __restrict__ dx,
-                                                        int Cin, int Cout, int shift) {
+                                                        int Cin, int Cout, int shift, const T* __restrict__ addend) {
   using A = typename CsAccOf<T>::type;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   A* ds = reinterpret_cast<A*>(smem_raw);
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void cs2_dgrad_kernel(const T* __restrict__ dy
   const int64_t n = blockIdx.x;
   cs2_stage<T, A>(dy + (n * Cout << (2 * oshift)), ds, Cout, oshift, PAD, tid, blockDim.x);
   T* xp = dx + (n * Cin << (2 * shift));
+  // addend (round 5): dx = round(round(dgrad) + addend) - the second contribution to a residual block's input gradient (autograd.scala:66-84)
+  // added here instead of by an elementwise pass over the map (the f32 step had two such passes, 32 us, behind its strided narrow dgrads)
+  const T* ap = addend ? addend + (n * Cin << (2 * shift)) : nullptr;
   for (int b = tid; b < So * So; b += blockDim.x) {
     const int hb = b >> oshift, wb = b & (So - 1);
     CsAcc<A, CB> acc[ST][ST];
@@ -253,12 +256,17 @@ __global__ __launch_bounds__(256) void cs2_dgrad_kernel(const T* __restrict__ dy
       if (c < Cin) {
 #pragma unroll
         for (int i = 0; i < ST; i++) {
-          T* o = xp + (c << (2 * shift)) + (hb * ST + i) * S + wb * ST;
+          const int64_t off = (c << (2 * shift)) + (hb * ST + i) * S + wb * ST;
+          T* o = xp + off;
           if (ST == 2) {
             typedef T pair_t __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<pair_t*>(o) = pair_t{(T)acc[i][0].get(c), (T)acc[i][ST - 1].get(c)};
+            pair_t v = pair_t{(T)acc[i][0].get(c), (T)acc[i][ST - 1].get(c)};
+            if (ap) { const pair_t a = *reinterpret_cast<const pair_t*>(ap + off); v = pair_t{(T)(v[0] + a[0]), (T)(v[1] + a[1])}; }
+            *reinterpret_cast<pair_t*>(o) = v;
           } else {
-            o[0] = (T)acc[i][0].get(c);
+            T v = (T)acc[i][0].get(c);
+            if (ap) v = (T)(v + ap[off]);
+            o[0] = v;
           }
         }
       }
@@ -390,7 +398,8 @@ static bool cs2_qualifies(const ConvGeom& g) {
   return true;
 }
 
-template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st) {
+template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
+                                       const Tensor* addend = nullptr) {
   using A = typename CsAccOf<T>::type;
   if (!cs2_qualifies(g)) return false;
   const int KS = g.kh, ST = g.sh, PAD = KS / 2;
@@ -406,6 +415,7 @@ template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const 
   const int block = px >= 256 ? 256 : (px >= 128 ? 128 : 64);
   KernelTimer kt(dgrad ? "conv_dgrad_small" : "conv_fwd_small", conv_flops(g), conv_bytes(g, sizeof(T)), st);
   const T* bp = bias ? bias->ptr<T>() : (const T*)nullptr;
+  const T* addp = (dgrad && addend) ? addend->ptr<T>() : (const T*)nullptr;
 #define CS2_GO(CBv, KSv, STv)                                                                                                                       \
   do {                                                                                                                                              \
     if (!dgrad) {                                                                                                                                   \
@@ -415,7 +425,7 @@ template <class T> static bool cs2_run(const Tensor* in, const Tensor* w, const 
     } else {                                                                                                                                        \
       if (lds > 64 * 1024) allow_big_lds((const void*)cs2_dgrad_kernel<T, CBv, KSv, STv>);                                                          \
       hipLaunchKernelGGL((cs2_dgrad_kernel<T, CBv, KSv, STv>), dim3((unsigned)g.N), dim3(block), lds, st, in->ptr<T>(), wfp, out->ptr<T>(), \
-                         (int)g.Cin, (int)g.Cout, shift);                                                                                           \
+                         (int)g.Cin, (int)g.Cout, shift, addp);                                                                                     \
     }                                                                                                                                               \
   } while (0)
 #define CS2_BY_ST(CBv, KSv) do { if (ST == 1) CS2_GO(CBv, KSv, 1); else CS2_GO(CBv, KSv, 2); } while (0)
@@ -744,10 +754,18 @@ bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor
   if (x->dtype == kF64) return cs2_run<double>(x, w, bias, y, g, false, st);
   return false;
 }
-bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st) {
+// addend (optional): added in the store of the f32 / f64 kernel where that kernel takes the geometry - *addend_fused says whether it did
+bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  if (addend_fused) *addend_fused = false;
   if (dy->dtype == kBF16) return cs_run<bf16_t>(dy, w, nullptr, dx, g, true, st);
-  if (dy->dtype == kF32) return cs2_run<float>(dy, w, nullptr, dx, g, true, st) || cs_run<float>(dy, w, nullptr, dx, g, true, st);
-  if (dy->dtype == kF64) return cs2_run<double>(dy, w, nullptr, dx, g, true, st);
+  if (dy->dtype == kF32) {
+    if (cs2_run<float>(dy, w, nullptr, dx, g, true, st, addend)) { if (addend_fused) *addend_fused = addend != nullptr; return true; }
+    return cs_run<float>(dy, w, nullptr, dx, g, true, st);
+  }
+  if (dy->dtype == kF64) {
+    if (cs2_run<double>(dy, w, nullptr, dx, g, true, st, addend)) { if (addend_fused) *addend_fused = addend != nullptr; return true; }
+    return false;
+  }
   return false;
 }
 

@@ -1210,6 +1210,10 @@ static void gemm_dispatch(Tensor* out, const Tensor* self, const Tensor* a, cons
     // Few output tiles over a long K (config 1's MLP: 1024 x 784 . 784 x 256 is 64 tiles on 256 CUs, each walking 49 k-steps one global
     // round trip at a time: 35 us for 0.4 GFLOP): K is split over blockIdx.z until every CU has a workgroup (chunks of at least 64), the
     // f32 / f64 slices are summed in order by a second launch.  LAMP_GEMM_SPLITK=0: off.
+    // What this changes: a row's dot product is no longer ONE fma chain over K but `split` chains added in slice order, and
+    // `split` depends on the tile count, i.e. on M and N - the same input row can give different last bits at another batch size (within
+    // the 1e-5 the f32 path is held to; deterministic for a given shape).  The slices carry no epilogue: only (alpha, beta, S) of GemmArgs
+    // are applied, by the reduction - any other epilogue field keeps the un-split path (the condition below lists them).
     static const bool allow_fp_split = !(getenv("LAMP_GEMM_SPLITK") && atoi(getenv("LAMP_GEMM_SPLITK")) == 0);
     const int64_t fp_tiles = (int64_t)g.tiles_m * g.tiles_n;
     if (allow_fp_split && g.batch == 1 && !g.knn_q && fp_tiles < 128 && g.K >= 128) {

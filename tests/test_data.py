@@ -4,6 +4,7 @@ CPU tests follow lamp-data/src/test/scala/lamp/data/ReadWrite.test.scala ("io em
 pin the descriptor text to the format the reference documents (Writer.scala:14-38, schemas.scala:30-56).  GPU tests follow
 "checkpoint modules" and batchstream.test.scala.  The JVM is not available here: byte-level agreement with a file written by
 the reference itself is unpinned; the descriptor grammar and blob layout are taken from the reference's specification."""
+import ctypes as C
 import json
 import os
 
@@ -246,6 +247,25 @@ def test_minibatches_from_a_data_set_that_stays_in_host_memory(gpu):
     assert sorted(np.concatenate(shards).tolist()) == sorted(y.tolist())
     with pytest.raises(LampError, match="host memory"):
         D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(x32, 0), fy, order=order, hostResident=True)
+    # a conversion the gather does not have is refused when the stream is built, not at the first batch
+    with pytest.raises(LampError, match="no gather converts"):
+        D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(y.reshape(n, 1), S.CPU), fy, order=order, hostResident=True, outDtype=S.BF16)
+    # a consumer whose current stream changes between two calls still reads a complete batch (the batch handed out was queued one call
+    # ago, on the stream that was current then): alternate the consumer between two streams, batch contents as above
+    side = C.c_void_p(); lib.lamp_stream_get_from_pool(0, 0, C.byref(side))
+    dflt = C.c_void_p(); lib.lamp_stream_get_default(0, C.byref(dflt))
+    st = D.BatchStream.minibatchesFromFull(mb, False, S.STen.from_numpy(x32, S.CPU), fy, order=order, hostResident=True)
+    try:
+        for i in range(st.numBatches):
+            lib.lamp_stream_set_current(side if i % 2 == 0 else dflt)
+            bx, by = st.nextBatch()
+            two = bx._u("lamp_mul_scalar", 2.0)             # consumed on the current stream at once
+            g = order[i * mb:(i + 1) * mb]
+            assert np.array_equal(bx.to_numpy(), x32[g]) and np.array_equal(by.to_numpy(), y[g])
+            assert np.array_equal(two.to_numpy(), x32[g] * 2)
+    finally:
+        lib.lamp_stream_set_current(dflt)
+        lib.lamp_device_synchronize()
 
 
 @pytest.mark.gpu
