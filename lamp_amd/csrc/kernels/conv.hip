@@ -304,6 +304,8 @@ bool igemm32_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const Con
 bool igemm32_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 // implemented in conv_small.hip (narrow layers: image-per-workgroup LDS kernels)
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
+bool narrow_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, const Tensor* w1, const Tensor* bias1,
+                          Tensor* y1, const ConvGeom& g1, hipStream_t st);
 bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
                        bool* addend_fused = nullptr);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
@@ -390,7 +392,8 @@ int lamp_convolution_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp
       Hold ba(bias_a ? contiguous(bias_a) : nullptr), bb(bias_b ? contiguous(bias_b) : nullptr);
       Hold ya(new_tensor({ga.N, ga.Cout, ga.Ho, ga.Wo}, x->dtype, x->device())), yb(new_tensor({gb.N, gb.Cout, gb.Ho, gb.Wo}, x->dtype, x->device()));
       hipStream_t st = current_stream(x->device());
-      if (igemm_conv_fwd_pair(xc.get(), wa.get(), ba.get(), ya.get(), ga, wb.get(), bb.get(), yb.get(), gb, st)) {
+      if (igemm_conv_fwd_pair(xc.get(), wa.get(), ba.get(), ya.get(), ga, wb.get(), bb.get(), yb.get(), gb, st) ||
+          narrow_conv_fwd_pair(xc.get(), wa.get(), ba.get(), ya.get(), ga, wb.get(), bb.get(), yb.get(), gb, st)) {
         out2[0] = ya.take(); out2[1] = yb.take();
         fused = true;
       }

@@ -1623,7 +1623,11 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         statp = statt->ptr<float>();
       }
       struct Publish { Hold& t; const Tensor* y; int P; ~Publish() { if (t.get()) conv_stats_publish(y, t.get(), P); } } publish{statt, out, (int)g.N};
-      KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g), conv_bytes(g, 2), st);
+      // (a sibling, when given, always runs in this launch - igemm_conv_fwd_pair checks the eight-image kernel's conditions first: its work
+      // is declared with the launch; its input is the one already counted)
+      const double sib_fl = sibling ? conv_flops(*sibling->g) : 0.0;
+      const double sib_by = sibling ? conv_bytes(*sibling->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;
+      KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g) + sib_fl, conv_bytes(g, 2) + sib_by, st);
       const bf16_t* bpb = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
       // more than 64 output channels and enough images to give every CU a workgroup of eight: one workgroup per CU, wave = image x all
       // channels (LAMP_IG_VARIANT=d forces it for any batch, =b keeps the two-image kernel)

@@ -63,6 +63,11 @@ struct NcvW {
   const bf16_t* w;
   int Cout, Cin, kh, kw, dgrad;
   int ns, sw;            // shifts per MFMA (1 or 2) and the window stride between them
+  // round 5, fprop only: a SIBLING 1x1 filter [Cout2][Cin] of the same input (the shortcut of lamp's residual block, cnn.scala:16-20) as
+  // output columns Cout .. Cout + Cout2 - 1 whose only non-zero tap is the centre one - the two convolutions are then ONE product over the
+  // staged image (the 6-channel layers use 6 of the MFMA's 16 columns: the second convolution rides in the padding)
+  const bf16_t* w2;
+  int Cout2;
 };
 __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
   const int n = lane & 15, pair = ks * 4 + (lane >> 4);
@@ -74,7 +79,10 @@ __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int la
     unsigned short e = 0;
     const int t = j - shift;                  // filter column
     if (t >= 0 && t < wq.kw) {
-      if (!wq.dgrad) { if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + t].bits; }
+      if (!wq.dgrad) {
+        if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + t].bits;
+        else if (wq.w2 && co < wq.Cout + wq.Cout2 && c < wq.Cin && r == wq.kh / 2 && t == wq.kw / 2) e = wq.w2[(co - wq.Cout) * wq.Cin + c].bits;
+      }
       else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - t)].bits; }
     }
     v[j] = (short)e;
@@ -221,7 +229,8 @@ __device__ unsigned long long ncv_stamps[1024 * 8];
 //   kernels a wave of occupancy
 template <int NK, int SW, int PH0, int NS, bool ADD>
 __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
-                                                       bf16_t* dst, NcvGeom q, const bf16_t* add) {
+                                                       bf16_t* dst, NcvGeom q, const bf16_t* add, bf16_t* dst2, const bf16_t* __restrict__ bias2, int co_a) {
+  // co_a: output columns [0, co_a) belong to dst, [co_a, q.CO) to dst2 (the sibling 1x1 of NcvW; co_a = q.CO and dst2 = nullptr otherwise)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
   NCV_STAMP_AT(0);
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
     const int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
     koff[ks] = (c * q.Hs + r) * q.Ws * 2;
   }
-  const float bv = (bias && co < q.CO) ? (float)bias[co] : 0.f;
+  const float bv = co < co_a ? (bias ? (float)bias[co] : 0.f) : ((bias2 && co < q.CO) ? (float)bias2[co - co_a] : 0.f);
 #ifdef NCV_STAMP
   __builtin_amdgcn_s_waitcnt(0);
   NCV_STAMP_AT(1);
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
     __syncthreads();
     NCV_STAMP_ONCE(3);
     if (q.pf && n + (int)gridDim.x < q.N) ncv_stage_load(pre, plan, src + (n + (int)gridDim.x) * img_in, tid, nthreads);   // in flight during the MFMAs
-    bf16_t* yp = dst + (int64_t)n * q.CO * HoWo;
+    // this lane's output plane: channel co of dst, or channel co - co_a of the sibling's tensor
+    bf16_t* yc = co < co_a ? dst + ((int64_t)n * co_a + co) * HoWo : dst2 + ((int64_t)n * (q.CO - co_a) + (co - co_a)) * HoWo;
     for (int st = wid; st < nsuper; st += nwaves) {
       const int h0 = st * TR;
       const char* base = smem + a_off + h0 * q.sh * q.Ws * 2;
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
           for (int rr = 0; rr < 4; rr++) {
             const int i = (lane >> 4) * 4 + rr;
             const int tr = i / ncg, cg = i - tr * ncg;
-            bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
+            bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
             unsigned int pk[P / 2];
 #pragma unroll
             for (int d = 0; d < P; d += 2) {
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
           for (int h = 0; h < 2; h++) {
             const int i = (lane >> 4) * 4 + sft * 2 + h;
             const int tr = i / ncg, cg = i - tr * ncg;
-            bf16_t* o = yp + co * HoWo + (h0 + tr) * q.Wo + cg * P;
+            bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
             unsigned int pk[ND];
 #pragma unroll
             for (int d = 0; d < ND; d++) {
@@ -694,11 +704,14 @@ static void ncv_launch(const bf16_t* src, const nv_bf8* wpk, const bf16_t* bias,
 namespace {
 struct NcvPackKey {
   uint64_t uid; int64_t offset; int Cout, Cin, kh, kw, dgrad, ns, sw; hipStream_t st;
+  uint64_t uid2; int64_t offset2; int Cout2;     // the sibling 1x1 filter packed into the same image (0 / 0 / 0: none)
   bool operator<(const NcvPackKey& o) const {
-    return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, ns, sw, st) < std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.ns, o.sw, o.st);
+    return std::tie(uid, offset, Cout, Cin, kh, kw, dgrad, ns, sw, st, uid2, offset2, Cout2) <
+           std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.ns, o.sw, o.st, o.uid2, o.offset2, o.Cout2);
   }
 };
-struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick;  bool pinned = false; };
+// version2 / w2: the sibling's storage version and data pointer (the re-pack hook sees one parameter at a time and needs the other's address)
+struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; bool pinned = false; uint64_t version2 = 0; const bf16_t* w1 = nullptr; const bf16_t* w2 = nullptr; };
 std::mutex g_ncv_mu;
 std::map<NcvPackKey, NcvPackVal> g_ncv_cache;
 uint64_t g_ncv_tick = 0;
@@ -711,15 +724,17 @@ static void ncv_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) {
 }
 
 // returns a +1 handle on the fragment image of `w` for this direction
-static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st) {
+static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st, const Tensor* w2 = nullptr) {
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
-  const bool cacheable = cache_on && w->st->owned;
-  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns, wq.sw, st};
+  const bool cacheable = cache_on && w->st->owned && (!w2 || w2->st->owned);
+  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns, wq.sw, st,
+                       w2 ? w2->st->uid : 0, w2 ? w2->offset : 0, w2 ? wq.Cout2 : 0};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
+  const uint64_t ver2 = w2 ? w2->st->version.load(std::memory_order_relaxed) : 0;
   if (cacheable) {
     std::lock_guard<std::mutex> lk(g_ncv_mu);
     auto it = g_ncv_cache.find(key);
-    if (it != g_ncv_cache.end() && it->second.version == ver) {
+    if (it != g_ncv_cache.end() && it->second.version == ver && it->second.version2 == ver2) {
       it->second.tick = ++g_ncv_tick;
       if (allocator_capturing()) it->second.pinned = true;       // a graph being captured records this address: never evict the entry
       return retain(it->second.packed);
@@ -740,7 +755,7 @@ static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t s
         if (!i->second.pinned && (victim == g_ncv_cache.end() || i->second.tick < victim->second.tick)) victim = i;
       if (victim != g_ncv_cache.end()) { release(victim->second.packed); g_ncv_cache.erase(victim); }
     }
-    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick, allocator_capturing()};
+    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick, allocator_capturing(), ver2, wq.w, wq.w2};
   }
   return wp.take();
 }
@@ -754,7 +769,8 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
   if (g_ncv_cache.empty()) return;
   NcvPackMany a;
   int cnt = 0;
-  std::vector<std::pair<NcvPackKey, uint64_t>> done;
+  struct Done { NcvPackKey k; uint64_t version; bool second; };
+  std::vector<Done> done;
   auto flush = [&] {
     if (cnt == 0) return;
     ncv_pack_launch(a, cnt, st);
@@ -766,30 +782,43 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
     if (w->sizes[0] > 16 || w->sizes[1] > 16) continue;
     for (auto& kv : g_ncv_cache) {
       const NcvPackKey& k = kv.first;
-      if (k.uid != w->st->uid || k.offset != w->offset || k.st != st) continue;
-      if (k.Cout != (int)w->sizes[0] || k.Cin != (int)w->sizes[1] || k.kh != (int)w->sizes[2] || k.kw != (int)w->sizes[3]) continue;
-      a.w[cnt] = NcvW{w->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw};
+      if (k.st != st) continue;
+      const bool first = k.uid == w->st->uid && k.offset == w->offset && k.Cout == (int)w->sizes[0] && k.Cin == (int)w->sizes[1] &&
+                         k.kh == (int)w->sizes[2] && k.kw == (int)w->sizes[3];
+      // the sibling 1x1 of a pair image: the image is packed again from BOTH filters (the other one's address was kept at the first pack;
+      // the optimiser passes both parameters, so the image is current after the second of the two visits)
+      const bool second = !first && k.Cout2 > 0 && k.uid2 == w->st->uid && k.offset2 == w->offset && k.Cout2 == (int)w->sizes[0] &&
+                          k.Cin == (int)w->sizes[1] && w->sizes[2] == 1 && w->sizes[3] == 1;
+      if (!first && !second) continue;
+      const bf16_t* w1p = first ? w->ptr<bf16_t>() : kv.second.w1;
+      const bf16_t* w2p = second ? w->ptr<bf16_t>() : kv.second.w2;
+      a.w[cnt] = NcvW{w1p, k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw, k.Cout2 > 0 ? w2p : nullptr, k.Cout2};
       a.dst[cnt] = static_cast<nv_bf8*>(kv.second.packed->raw());
-      done.push_back({k, w->st->version.load(std::memory_order_relaxed)});
+      done.push_back({k, w->st->version.load(std::memory_order_relaxed), second});
       if (++cnt == NCV_PACK_MAX) flush();
     }
   }
   flush();
   for (auto& d : done) {
-    auto it = g_ncv_cache.find(d.first);
-    if (it != g_ncv_cache.end()) { it->second.version = d.second; it->second.tick = ++g_ncv_tick; }
+    auto it = g_ncv_cache.find(d.k);
+    if (it != g_ncv_cache.end()) { (d.second ? it->second.version2 : it->second.version) = d.version; it->second.tick = ++g_ncv_tick; }
   }
 }
 
+// sibling (fprop, optional): a 1x1 convolution of the same input, same stride and output map, whose Cout2 channels fit beside w's in the
+// MFMA's 16 columns: both outputs from one launch of the aligned kernel (false, nothing launched, when that kernel does not take the pair)
+struct NcvSibling { const Tensor* w; const Tensor* bias; Tensor* out; };
 static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
-                    const Tensor* addend = nullptr, bool* addend_fused = nullptr) {
+                    const Tensor* addend = nullptr, bool* addend_fused = nullptr, const NcvSibling* sib = nullptr) {
   if (addend_fused) *addend_fused = false;
   if (!ncv_common(g, in->dtype)) return false;
+  const int cout2 = sib ? (int)sib->w->sizes[0] : 0;
+  if (sib && (dgrad || g.Cout + cout2 > 16)) return false;
   NcvGeom q;
   q.N = (int)g.N; q.kh = g.kh; q.pf = 0; q.kh_inv = 65536 / g.kh + 1;
   if (!dgrad) {
     if (g.W % 8 != 0) return false;
-    q.C = (int)g.Cin; q.CO = (int)g.Cout; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
+    q.C = (int)g.Cin; q.CO = (int)g.Cout + cout2; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
     q.top = g.ph; q.left = NCV_LEFT;
     q.Ho = (int)g.Ho; q.Wo = (int)g.Wo; q.sh = g.sh; q.sw = g.sw; q.wx = NCV_LEFT - g.pw;
     q.Hs = std::max((int)g.H + 2 * g.ph, (q.Ho - 1) * g.sh + g.kh);
@@ -812,6 +841,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   if (aligned && !(ncg == 2 || ncg == 4 || ncg == 8 || ncg == 16)) aligned = false;
   if (aligned && q.Ho % (16 / ncg) != 0) aligned = false;
   if (aligned) q.Ws = round_up(std::max(q.Ws, q.Wo * q.sw + (q.wx - ph0) + 16), 8);
+  if (sib && !aligned) return false;
   const int pairs = q.C * q.kh;
   const int nk_real = (pairs + 3) / 4;
   static const int nk_opts[] = {1, 2, 4, 5, 8, 12};
@@ -823,8 +853,8 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   // two output phases per MFMA where the columns allow it (see NcvW)
   static const bool two_shift_on = [] { const char* e = getenv("LAMP_NCV_TWO_SHIFT"); return !(e && e[0] == '0'); }();
   const int NS = (two_shift_on && aligned && q.CO <= 8 && g.kw + q.sw <= 8) ? 2 : 1;
-  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw};
-  Hold wpk_h(ncv_packed_weights(w, wq, st));
+  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw, sib ? sib->w->ptr<bf16_t>() : (const bf16_t*)nullptr, cout2};
+  Hold wpk_h(ncv_packed_weights(w, wq, st, sib ? sib->w : nullptr));
   const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
   static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2
   const int lds_per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
@@ -851,12 +881,18 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     // persistent grid: as many workgroups as are really co-resident (registers and LDS), each walks a strided range of images
     const int per_cu = std::min(lds_per_cu, kernel_occupancy(kfn, threads, lds));
     const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * per_cu);
-    KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
+    // (the sibling's work is declared with the launch; its input is the one already counted)
+    const double sib_fl = sib ? 2.0 * (double)g.N * cout2 * (double)g.Ho * g.Wo * (double)g.Cin : 0.0;
+    const double sib_by = sib ? ((double)g.N * cout2 * g.Ho * g.Wo + (double)cout2 * g.Cin) * 2.0 : 0.0;
+    KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g) + sib_fl, conv_bytes(g, 2) + sib_by, st);
     const bf16_t* srcp = in->ptr<bf16_t>();
     bf16_t* dstp = out->ptr<bf16_t>();
     const bf16_t* addp = with_add ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
     if (addend_fused) *addend_fused = with_add;
-    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp};
+    bf16_t* dst2p = sib ? sib->out->ptr<bf16_t>() : (bf16_t*)nullptr;
+    const bf16_t* bias2p = (sib && sib->bias) ? sib->bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+    int co_a = sib ? (int)g.Cout : q.CO;
+    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp, (void*)&dst2p, (void*)&bias2p, (void*)&co_a};
     HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
     return true;
@@ -877,6 +913,19 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
 
 bool narrow_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {
   return ncv_run(x, w, bias, y, g, false, st);
+}
+// y = conv3x3(x, w) and y1 = conv1x1(x, w1), same stride and output map (the two branches of lamp's residual block on its input,
+// cnn.scala:16-20), Cout + Cout1 <= 16: one launch, the values of the two separate ones (the second filter is the centre tap of extra
+// output columns); false = nothing launched
+bool narrow_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, const Tensor* w1, const Tensor* bias1,
+                          Tensor* y1, const ConvGeom& g1, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
+  if (!on || x->dtype != kBF16) return false;
+  if (g.kh != 3 || g.kw != 3 || g.ph != 1 || g.pw != 1 || g1.kh != 1 || g1.kw != 1 || g1.ph != 0 || g1.pw != 0) return false;
+  if (g.sh != g1.sh || g.sw != g1.sw || g.Ho != g1.Ho || g.Wo != g1.Wo || g.Cin != g1.Cin || g.N != g1.N || g.groups != 1 || g1.groups != 1) return false;
+  if (g.dh != 1 || g.dw != 1 || g1.dh != 1 || g1.dw != 1) return false;
+  const NcvSibling sb{w1, bias1, y1};
+  return ncv_run(x, w, bias, y, g, false, st, nullptr, nullptr, &sb);
 }
 bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
   return ncv_run(dy, w, nullptr, dx, g, true, st, addend, addend_fused);

@@ -1194,28 +1194,30 @@ def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k,
     assert b"bn_fwd_stats" in rep3, "stale statistics were used after the tensor had been written"
 
 
-@pytest.mark.parametrize("cin,cout,N", [(128, 100, 1024), (16, 128, 1024), (128, 128, 1032), (100, 100, 1024), (64, 64, 1024), (16, 16, 1027),
-                                        (128, 100, 64), (6, 6, 64)])
-def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, N):
+@pytest.mark.parametrize("cin,cout,N,H,stride", [(128, 100, 1024, 8, 1), (16, 128, 1024, 8, 1), (128, 128, 1032, 8, 1), (100, 100, 1024, 8, 1),
+                                                 (64, 64, 1024, 8, 1), (16, 16, 1027, 8, 1), (128, 100, 64, 8, 1), (6, 6, 64, 8, 1),
+                                                 (6, 6, 67, 32, 2), (3, 8, 16, 32, 2), (6, 5, 9, 32, 1), (6, 16, 33, 16, 2)])
+def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, N, H, stride):
     """lamp_convolution_pair(x, 3x3, 1x1) - the two branches of lamp's residual block start with a Conv2D on the same input (cnn.scala:16-20,
     38-78) - returns BITWISE what two lamp_convolution calls return, hands each output's batch-norm statistics to its consumer as the single
-    convolutions do, and is ONE launch of the eight-image kernel where that kernel takes the geometry (N >= 4 x CUs, bf16, 8x8 maps); every
+    convolutions do, and is ONE launch of the eight-image kernel where that kernel takes the geometry (N >= 4 x CUs, bf16, 8x8 maps) or of the
+    narrow kernel where both filters' output channels fit the MFMA's 16 columns (res1 of Cnn.resnet: 6 + 6 channels, 32 x 32, stride 2); every
     other geometry runs the two calls inside the entry point."""
     dt = torch.bfloat16
-    x = closed_form((N, cin, 8, 8), 3, 2.0, dt)
+    x = closed_form((N, cin, H, H), 3, 2.0, dt)
     wa, ba = closed_form((cout, cin, 3, 3), 17, 0.2, dt), closed_form((cout,), 5, 1.0, dt)
     wb, bb = closed_form((cout, cin, 1, 1), 23, 0.4, dt), closed_form((cout,), 13, 1.0, dt)
     X, WA, BA, WB, BB = to_sten(x), to_sten(wa), to_sten(ba), to_sten(wb), to_sten(bb)
-    one, p1, p0, z = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0]), i64_array([0, 0])
+    one, p1, p0, z, sd = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0]), i64_array([0, 0]), i64_array([stride, stride])
 
     def single(W, B, pad):
         o = C.c_void_p()
-        lib.lamp_convolution(C.byref(o), X, W, B, one, pad, one, 2, 0, z, 1)
+        lib.lamp_convolution(C.byref(o), X, W, B, sd, pad, one, 2, 0, z, 1)
         return S.STen(o)
     ya, yb = single(WA, BA, p1), single(WB, BB, p0)
     o2 = (C.c_void_p * 2)()
     lib.lamp_kernel_timer_enable(1)
-    lib.lamp_convolution_pair(o2, X, WA, BA, one, p1, one, WB, BB, one, p0, one, 2, 1)
+    lib.lamp_convolution_pair(o2, X, WA, BA, sd, p1, one, WB, BB, sd, p0, one, 2, 1)
     buf = C.create_string_buffer(1 << 16)
     lib.lamp_kernel_timer_report(buf, len(buf))
     lib.lamp_kernel_timer_enable(0)
@@ -1223,11 +1225,11 @@ def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, 
     assert torch.equal(to_torch(pa), to_torch(ya)), "3x3 output of the pair differs from the single convolution"
     assert torch.equal(to_torch(pb), to_torch(yb)), "1x1 output of the pair differs from the single convolution"
     launches = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if ln.strip()}       # "tag count total_ms flops bytes"
-    fused = N >= 1024 and cin >= 8
+    fused = (H == 8 and N >= 1024 and cin >= 8) or (H == 32 and 2 * cout <= 16)       # the eight-image kernel / the narrow kernel's spare columns
     assert sum(n for t, n in launches.items() if t.startswith("conv_")) == (1 if fused else 2), (fused, launches)
     # against the oracle (ATen f32 on the same bf16 values)
-    ra = aten.convolution(x.float(), wa.float(), ba.float(), [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
-    rb = aten.convolution(x.float(), wb.float(), bb.float(), [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+    ra = aten.convolution(x.float(), wa.float(), ba.float(), [stride, stride], [1, 1], [1, 1], False, [0, 0], 1)
+    rb = aten.convolution(x.float(), wb.float(), bb.float(), [stride, stride], [0, 0], [1, 1], False, [0, 0], 1)
     assert_close(to_torch(pa), ra.double(), FWD_TOL[dt] * 4, "3x3 against the oracle")
     assert_close(to_torch(pb), rb.double(), FWD_TOL[dt] * 4, "1x1 against the oracle")
     # the statistics hand-off of BOTH outputs: the batch norm that reads them launches no statistics pass and returns the bits it returns
@@ -1246,7 +1248,7 @@ def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, 
     for got, want, name in ((pa, ya, "3x3"), (pb, yb, "1x1")):
         (r1, rep1), (r2, rep2) = bn(got), bn(want)
         assert (b"bn_fwd_stats" in rep1) == (b"bn_fwd_stats" in rep2), f"{name}: the pair's output carries a different hand-off"
-        if cin >= 8:
+        if cin >= 8 and H == 8:
             assert b"bn_fwd_stats" not in rep1, f"{name}: no statistics were handed over"
         for u, v in zip(r1, r2):
             assert torch.equal(u, v), f"{name}: batch norm of the pair's output differs from batch norm of the single convolution's"
