@@ -334,13 +334,18 @@ __device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, fl
 // workgroup, the images WITHOUT halo (taps outside the image read a shared zero pixel), two weight slots: 32 + 0.25 + 32 KiB of
 // LDS.  The two workgroups of a CU are independent, so the prologue / epilogue of one overlaps the main loop of the other and
 // their READ / MFMA phases interleave without an explicit stagger.
-template <int KS>
-__global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
+// NWV = 4: waves = 2 images x 2 halves of 64 output channels (two such workgroups per CU at large batches).  NWV = 8 (round 5, batches of at
+// most 2 x CUs images, where a CU holds ONE workgroup and the kernel is the latency chain of one wave: 18 stages x 32 dependent MFMAs behind
+// 16 fragment reads each - 17 us per 128-channel 3x3 launch at B = 32 ... 256 whatever the batch): 2 images x 4 quarters of 32 channels,
+// half the MFMAs and 12 instead of 16 fragment reads per wave and stage.
+template <int KS, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
-  constexpr int NW = 2, NT = 256, LPT = 4;
+  constexpr int NW = 2, NT = NWV * 64, LPT = 16 / NWV;      // 16 one-KiB pieces per weight stage, LPT per wave
+  constexpr int NTI = 16 / NWV;                              // output-channel tiles of 16 per wave: 4 (64 channels) or 2 (32)
   const int RB = KP * 2;
   const int XIMG = 64 * RB;                 // 8x8 pixels, no halo
   char* Xl = smem;                          // [2][64][KP] + one zero pixel
@@ -398,9 +403,9 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
     }
   }
 
-  f4v acc[4][4];
+  f4v acc[NTI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NTI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
@@ -419,13 +424,13 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
                           : ZOFF + (((lane >> 4) & cmask) << 4);
     }
   }
-  const int a_row = (wr * 64 + (lane & 15)) * 128;
+  const int a_row = (wr * (NTI * 16) + (lane & 15)) * 128;
   const int a_ch0 = ((lane >> 4) ^ (lane & 7)) << 4, a_ch1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  bf8v fa0[4], fb0[4], fa1[4], fb1[4];
+  bf8v fa0[NTI], fb0[4], fa1[NTI], fb1[4];
   int t = 0;
 #pragma unroll
   for (int rs = 0; rs < RS; rs++) {
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
       if (t + 1 < T) stage_dma(t + 1, (t + 1) & 1);
       const int u = ((cc * (KW >> 3)) & cmask) << 4;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NTI; i++) {
         fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
         fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
       }
@@ -446,11 +451,11 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NTI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NTI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
@@ -465,8 +470,8 @@ __global__ __launch_bounds__(256) void ig_conv8b_kernel(const bf16_t* __restrict
     const int q = lane >> 4;
     const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int co = wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < NTI; i++) {
+      const int co = wr * (NTI * 16) + i * 16 + (lane & 15);
       const float b = (bias && co < CO) ? (float)bias[co] : 0.f;
       float vals[16];
 #pragma unroll
@@ -1695,13 +1700,18 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         return;
       }
       const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
-      if (KS == 3) {
-        allow_big_lds((const void*)ig_conv8b_kernel<3>);
-        hipLaunchKernelGGL((ig_conv8b_kernel<3>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
-      } else {
-        allow_big_lds((const void*)ig_conv8b_kernel<1>);
-        hipLaunchKernelGGL((ig_conv8b_kernel<1>), dim3(blocksb), dim3(256), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
-      }
+      // at most one workgroup per CU (small batches): eight waves per image pair (LAMP_IG_W8=0: always four)
+      static const bool w8_on = [] { const char* e = getenv("LAMP_IG_W8"); return !(e && e[0] == '0'); }();
+      const bool w8 = w8_on && blocksb <= num_cus();
+#define IG_LAUNCH_B(KS_, NWV_)                                                                                                                  \
+  do {                                                                                                                                          \
+    allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_>);                                                                                   \
+    hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_>), dim3(blocksb), dim3(NWV_ * 64), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
+                       (int)g.N, CI, KP, CO, statp);                                                                                            \
+  } while (0)
+      if (KS == 3) { if (w8) IG_LAUNCH_B(3, 8); else IG_LAUNCH_B(3, 4); }
+      else { if (w8) IG_LAUNCH_B(1, 8); else IG_LAUNCH_B(1, 4); }
+#undef IG_LAUNCH_B
       LAMP_LAUNCH_CHECK();
       return;
     }
@@ -1782,6 +1792,13 @@ bool igemm_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvG
 }
 // affine (optional): x is the raw output of the producing convolution and the forward multiplied relu(bn(x)) - only the eight-wave kernel
 // rebuilds it while staging: false (nothing launched) when the geometry takes another kernel
+// images per workgroup at least: fewer images per workgroup = more, shorter workgroups and more partial sums.  8 at large batches; 2 at
+// N <= 512, where the launch is a latency chain and the partial sums are small (B = 256: 0.5606 -> 0.5538 ms per step, round 5).
+// LAMP_WGRAD_MIN_IPS overrides both.
+static int wgrad_min_ips(int64_t N) {
+  static const int v = [] { const char* e = getenv("LAMP_WGRAD_MIN_IPS"); return e ? std::max(2, atoi(e)) : 0; }();
+  return v ? v : (N <= 512 ? 2 : 8);
+}
 bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine) {
   if (!ig_qualifies(g, x->dtype)) return false;
   const int KS = g.kh, RS = KS * KS;
@@ -1794,7 +1811,7 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     const int CIP = ntile * WG_CI;
     int target = std::max(1, num_cus() / ntile);
     int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
-    if (ips < 8 && g.N >= 8) ips = 8;
+    if (ips < wgrad_min_ips(g.N) && g.N >= wgrad_min_ips(g.N)) ips = wgrad_min_ips(g.N);
     const int nsplit = (int)((g.N + ips - 1) / ips);
     int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
@@ -1832,7 +1849,7 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     static const int narrow_per_cu = [] { const char* e = getenv("LAMP_WGRAD_NARROW_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();   // measured: 2 and 3 are 1 % slower on the step
     int target = std::max(1, (num_cus() * (narrow ? narrow_per_cu : wgs_per_cu)) / ntile);
     int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
-    if (ips < 8 && g.N >= 8) ips = 8;
+    if (ips < wgrad_min_ips(g.N) && g.N >= wgrad_min_ips(g.N)) ips = wgrad_min_ips(g.N);
     const int nsplit = (int)((g.N + ips - 1) / ips);
     int64_t ps[1] = {(int64_t)nsplit * RS * COP * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
