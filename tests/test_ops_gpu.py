@@ -987,6 +987,46 @@ def test_igemm_pack_cache_sees_every_weight_write(gpu, cin, cout, hw, stride):
     check(to_torch(W).to(dt), "after a second optimiser step (images re-packed in place)")
 
 
+@pytest.mark.parametrize("cin,cout,N,H,stride", [(6, 6, 16, 32, 2), (128, 100, 1024, 8, 1)])
+def test_pair_launch_sees_every_write_to_either_filter(gpu, cin, cout, N, H, stride):
+    """lamp_convolution_pair keeps ONE packed image per pair in the narrow kernel (both filters in it) and two cached images in the
+    eight-image kernel: whichever way EITHER filter changes - in place, through the optimiser stepping only the 3x3, only the 1x1, or both
+    (the optimiser re-packs the cached images itself, in place: a replayed HIP graph keeps their address) - the next pair launch equals the
+    two separate convolutions on the current weights, bit for bit."""
+    from lamp_amd import nn as NN
+    dt = torch.bfloat16
+    x = closed_form((N, cin, H, H), 3, 2.0, dt)
+    WA, BA = to_sten(closed_form((cout, cin, 3, 3), 17, 0.2, dt)), to_sten(closed_form((cout,), 5, 1.0, dt))
+    WB, BB = to_sten(closed_form((cout, cin, 1, 1), 23, 0.4, dt)), to_sten(closed_form((cout,), 13, 1.0, dt))
+    X = to_sten(x)
+    one, p1, p0, z, sd = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0]), i64_array([0, 0]), i64_array([stride, stride])
+
+    def check(what):
+        o2 = (C.c_void_p * 2)()
+        lib.lamp_convolution_pair(o2, X, WA, BA, sd, p1, one, WB, BB, sd, p0, one, 2, 1)
+        pa, pb = S.STen(o2[0]), S.STen(o2[1])
+        oa, ob = C.c_void_p(), C.c_void_p()
+        lib.lamp_convolution(C.byref(oa), X, WA, BA, sd, p1, one, 2, 0, z, 1)
+        lib.lamp_convolution(C.byref(ob), X, WB, BB, sd, p0, one, 2, 0, z, 1)
+        assert torch.equal(to_torch(pa), to_torch(S.STen(oa))), what + ": 3x3"
+        assert torch.equal(to_torch(pb), to_torch(S.STen(ob))), what + ": 1x1"
+        # ... and the single convolutions themselves follow the weights (against the oracle on the CURRENT values)
+        ra = aten.convolution(x.float(), to_torch(WA).float(), to_torch(BA).float(), [stride, stride], [1, 1], [1, 1], False, [0, 0], 1)
+        assert_close(to_torch(pa), ra.double(), FWD_TOL[dt] * 4, what + ": 3x3 against the oracle")
+        rb = aten.convolution(x.float(), to_torch(WB).float(), to_torch(BB).float(), [stride, stride], [0, 0], [1, 1], False, [0, 0], 1)
+        assert_close(to_torch(pb), rb.double(), FWD_TOL[dt] * 4, what + ": 1x1 against the oracle")
+
+    check("first call"); check("cached call")
+    lib.lamp_mul_scalar_(WB, 0.5); check("after the 1x1 was scaled in place")
+    lib.lamp_mul_scalar_(WA, -1.5); check("after the 3x3 was scaled in place")
+    ga, gb = S.STen.ones([cout, cin, 3, 3], S.BF16, 0), S.STen.ones([cout, cin, 1, 1], S.BF16, 0)
+    NN.SGDW([WA], 0.25, 0.0).step([ga], 1.0); check("after the optimiser stepped the 3x3 alone")
+    NN.SGDW([WB], 0.25, 0.0).step([gb], 1.0); check("after the optimiser stepped the 1x1 alone")
+    both = NN.SGDW([WA, WB], 0.125, 0.0)
+    both.step([ga, gb], 1.0); check("after the optimiser stepped both")
+    both.step([ga, gb], 1.0); check("after a second step of both (images re-packed in place)")
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("reduction", [1, 2])
 def test_nll_loss_forward_accumulates_the_epoch_loss_in_its_launch(gpu, dt, reduction):
