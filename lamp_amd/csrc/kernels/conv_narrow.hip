@@ -227,10 +227,32 @@ __device__ unsigned long long ncv_stamps[1024 * 8];
 //   NS = shifts per MFMA (see NcvW): NS = 2 halves the P window phases an MFMA has to be issued for.
 //   ADD: dst = round(round(conv) + add) - a separate instantiation (dgrad only: SW = 1) because the addend's registers cost the plain
 //   kernels a wave of occupancy
-template <int NK, int SW, int PH0, int NS, bool ADD>
-__global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
-                                                       bf16_t* dst, NcvGeom q, const bf16_t* add, bf16_t* dst2, const bf16_t* __restrict__ bias2, int co_a) {
+struct NcvWf { float n, mean, m2; };
+__device__ __forceinline__ NcvWf ncv_wf_merge(const NcvWf& a, const NcvWf& b) {   // Chan's merge; either side may be empty
+  NcvWf r;
+  r.n = a.n + b.n;
+  if (r.n == 0.f) { r.mean = 0.f; r.m2 = 0.f; return r; }
+  const float d = b.mean - a.mean, f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+//   STATS (fprop): the batch-norm statistics of the output leave with it, as Welford triples (count, mean, M2) over the ROUNDED values as
+//   they are stored: stats[channel][part][3], part = image (stats_per_wg == 0) or workgroup (every workgroup walks the same number of images) -
+//   the layout bn_merge_channel takes from the implicit-GEMM kernels (equal counts), so the batch norm behind a narrow convolution launches
+//   no statistics pass (5 launches of the ResNet step).  The sums are taken by the matrix cores, which idle here: a lane's packed output
+//   row IS a B fragment (8 bf16 of column j = lane & 15), so  ones . Y  accumulates sum y per column and  Y^T . Y  accumulates sum y^2 on its
+//   diagonal - exact products, f32 accumulation, no VALU work per value (as shifted VALU sums the statistics cost the B = 2048 step what the
+//   five statistics launches had cost).  Unshifted sums over at most a few thousand values: M2 loses ~1e-6 (mean / std)^2 relative.
+//   The epilogue must not cost the kernel a wave of occupancy: hence the second launch bound.  What it still costs (scripts/ncv_stats_probe.py,
+//   stem / 6 -> 6 / 6 -> 16 layer at N = 2048: 11.3 / 5.5 / 4.8 us without, 14.2 / 7.4 / 6.3 us with): 1.3 - 2.2 us for the end of the workgroup
+//   (barrier, the waves' sums through LDS, one more store round trip behind the last output store) and, on the stem, 1.5 us of matrix-core time.
+template <int NK, int SW, int PH0, int NS, bool ADD, bool STATS>
+__global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
+                                                       bf16_t* dst, NcvGeom q, const bf16_t* add, bf16_t* dst2, const bf16_t* __restrict__ bias2, int co_a,
+                                                       float* __restrict__ stats, float* __restrict__ stats2, int stats_per_wg) {
   // co_a: output columns [0, co_a) belong to dst, [co_a, q.CO) to dst2 (the sibling 1x1 of NcvW; co_a = q.CO and dst2 = nullptr otherwise)
+  __shared__ float sst[STATS ? 2 : 1][4][16][3];           // [image parity][wave][MFMA column]: the waves' triples of one image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(smem);
   NCV_STAMP_AT(0);
@@ -268,9 +290,41 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
   // A-side lane -> (row within the super-tile, column group)
   const int a_tr = (lane & 15) / ncg, a_cg = (lane & 15) - a_tr * ncg;
   const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
-  for (int n = blockIdx.x; n < q.N; n += gridDim.x) {
+  // the waves' sums of one part (left in sst[par] before the barrier the caller has just passed) -> stats[channel][part] = (count, mean, M2),
+  // added in wave order; NS = 2: channel co sits in columns co and co + 8
+  auto stats_flush = [&](int part, int nparts, int par) {
+    if (wid == 0 && lane < (NS == 2 ? 8 : 16) && lane < q.CO) {
+      float cnt = 0.f, sy = 0.f, sq = 0.f;
+      for (int h = 0; h < NS; h++)
+        for (int k = 0; k < nwaves; k++) { cnt += sst[par][k][lane + 8 * h][0]; sy += sst[par][k][lane + 8 * h][1]; sq += sst[par][k][lane + 8 * h][2]; }
+      const float mean = sy / cnt;                         // (cnt > 0: every image has at least one super-tile)
+      float* o = lane < co_a ? stats + ((int64_t)lane * nparts + part) * 3 : stats2 + ((int64_t)(lane - co_a) * nparts + part) * 3;
+      o[0] = cnt; o[1] = mean; o[2] = fmaxf(sq - sy * mean, 0.f);
+    }
+  };
+  // sum y (every row of st1 alike) and sum y^2 (diagonal of st2: row j of column j = lane & 15 is register j & 3 of lane group j >> 2) of this
+  // wave's `tiles` super-tiles -> sst[par][wave][column] = (count, sum y, sum y^2)
+  nv_f4 st1 = nv_f4{0.f, 0.f, 0.f, 0.f}, st2 = nv_f4{0.f, 0.f, 0.f, 0.f};
+  int tiles = 0;
+  auto stats_leave = [&](int par) {
+    const int j = lane & 15, r = j & 3;
+    const float sq = r == 0 ? st2[0] : r == 1 ? st2[1] : r == 2 ? st2[2] : st2[3];
+    if ((lane >> 4) == (j >> 2)) { sst[par][wid][j][0] = (float)(tiles * (16 * P / NS)); sst[par][wid][j][1] = st1[0]; sst[par][wid][j][2] = sq; }
+    st1 = nv_f4{0.f, 0.f, 0.f, 0.f}; st2 = nv_f4{0.f, 0.f, 0.f, 0.f}; tiles = 0;
+  };
+  const unsigned ones2 = 0x3f803f80u;                      // two bf16 ones
+  typedef unsigned int nv_u4 __attribute__((ext_vector_type(4)));
+  const nv_bf8 ones = __builtin_bit_cast(nv_bf8, nv_u4{ones2, ones2, ones2, ones2});
+  auto stats_take = [&](unsigned a, unsigned b, unsigned c, unsigned d) {
+    const nv_bf8 y = __builtin_bit_cast(nv_bf8, nv_u4{a, b, c, d});
+    st1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, y, st1, 0, 0, 0);
+    st2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y, y, st2, 0, 0, 0);
+  };
+  int it = 0;
+  for (int n = blockIdx.x; n < q.N; n += gridDim.x, it++) {
     __syncthreads();                                     // zero fill / the previous image's reads are done
     NCV_STAMP_ONCE(2);
+    if (STATS && !stats_per_wg && it > 0) stats_flush(n - (int)gridDim.x, q.N, (it - 1) & 1);
     if (q.pf) ncv_stage_store(xs, pre, plan, q.dil);
     else ncv_stage(xs, src + n * img_in, q, tid, nthreads);
     __syncthreads();
@@ -320,23 +374,30 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
           else { const uint2 t = *reinterpret_cast<const uint2*>(a); addv[k] = make_uint4(t.x, t.y, 0, 0); }
         }
       }
+      if (STATS) tiles++;
       if (NS == 1) {
-        if (co < q.CO) {
+        unsigned int prev[P / 2];                          // P = 4: two rows make one fragment
 #pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            const int i = (lane >> 4) * 4 + rr;
-            const int tr = i / ncg, cg = i - tr * ncg;
-            bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
-            unsigned int pk[P / 2];
+        for (int rr = 0; rr < 4; rr++) {
+          const int i = (lane >> 4) * 4 + rr;
+          const int tr = i / ncg, cg = i - tr * ncg;
+          bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
+          unsigned int pk[P / 2];
 #pragma unroll
-            for (int d = 0; d < P; d += 2) {
-              const bf16_t lo(acc[d % ND][rr] + bv), hi(acc[(d + 1) % ND][rr] + bv);
-              pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
-            }
-            if (ADD) {
+          for (int d = 0; d < P; d += 2) {
+            const bf16_t lo(acc[d % ND][rr] + bv), hi(acc[(d + 1) % ND][rr] + bv);
+            pk[d >> 1] = (unsigned)lo.bits | ((unsigned)hi.bits << 16);
+          }
+          if (ADD) {
 #pragma unroll
-              for (int j = 0; j < P / 2; j++) pk[j] = add_bf16x2(pk[j], (&addv[rr % NROW].x)[j]);
-            }
+            for (int j = 0; j < P / 2; j++) pk[j] = add_bf16x2(pk[j], (&addv[rr % NROW].x)[j]);
+          }
+          if (STATS) {                                     // (every lane: the columns beyond CO carry zeros)
+            if (P == 8) stats_take(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
+            else if (rr & 1) stats_take(prev[0], prev[1], pk[0], pk[1]);
+            else { prev[0] = pk[0]; prev[1] = pk[1]; }
+          }
+          if (co < q.CO) {
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
           }
@@ -354,29 +415,42 @@ __global__ __launch_bounds__(256) void ncv_fwd2_kernel(const bf16_t* __restrict_
             keep[h][d] = mine.bits;
             got[h][d] = (unsigned)__shfl_xor((int)theirs.bits, 8, 64);
           }
-        if (co < q.CO) {
+        unsigned int prev[ND];
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int i = (lane >> 4) * 4 + sft * 2 + h;
-            const int tr = i / ncg, cg = i - tr * ncg;
-            bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
-            unsigned int pk[ND];
+        for (int h = 0; h < 2; h++) {
+          const int i = (lane >> 4) * 4 + sft * 2 + h;
+          const int tr = i / ncg, cg = i - tr * ncg;
+          bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
+          unsigned int pk[ND];
 #pragma unroll
-            for (int d = 0; d < ND; d++) {
-              const unsigned int even = sft ? got[h][d] : keep[h][d], odd = sft ? keep[h][d] : got[h][d];
-              pk[d] = even | (odd << 16);
-            }
-            if (ADD) {
+          for (int d = 0; d < ND; d++) {
+            const unsigned int even = sft ? got[h][d] : keep[h][d], odd = sft ? keep[h][d] : got[h][d];
+            pk[d] = even | (odd << 16);
+          }
+          if (ADD) {
 #pragma unroll
-              for (int d = 0; d < ND; d++) pk[d] = add_bf16x2(pk[d], (&addv[h % NROW].x)[d]);
-            }
+            for (int d = 0; d < ND; d++) pk[d] = add_bf16x2(pk[d], (&addv[h % NROW].x)[d]);
+          }
+          if (STATS) {
+            if (P == 8) stats_take(pk[0], pk[1], pk[2 % ND], pk[3 % ND]);
+            else if (h) stats_take(prev[0], prev[1], pk[0], pk[1]);
+            else { prev[0] = pk[0]; prev[1] = pk[1]; }
+          }
+          if (co < q.CO) {
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % ND], pk[3 % ND]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
           }
         }
       }
     }
+    if (STATS && !stats_per_wg) stats_leave(it & 1);
     NCV_STAMP_ONCE(4);
+  }
+  if (STATS && it > 0) {
+    if (stats_per_wg) stats_leave(0);
+    __syncthreads();
+    if (stats_per_wg) stats_flush((int)blockIdx.x, (int)gridDim.x, 0);
+    else stats_flush((int)blockIdx.x + (it - 1) * (int)gridDim.x, q.N, (it - 1) & 1);
   }
 #ifdef NCV_STAMP
   NCV_STAMP_AT(5);
@@ -866,9 +940,18 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
     const void* kfn = nullptr;
     const bool with_add = addend != nullptr && q.sw == 1;
-#define NCV_F2(NKv, SWv, PHv, ADDv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2, ADDv> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1, ADDv>
-#define NCV_F2_PH(NKv, SWv, ADDv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0, ADDv); else if (ph0 == 6) NCV_F2(NKv, SWv, 6, ADDv); else NCV_F2(NKv, SWv, 7, ADDv); } while (0)
-#define NCV_F2_SW(NKv) do { if (q.sw == 1) { if (with_add) NCV_F2_PH(NKv, 1, true); else NCV_F2_PH(NKv, 1, false); } else NCV_F2_PH(NKv, 2, false); } while (0)
+    // fprop: per-image batch-norm statistics of the output(s) from the epilogue (LAMP_CONV_BN_STATS=0 turns the hand-off off)
+    static const bool bn_stats = [] {
+      const char* e = getenv("LAMP_CONV_BN_STATS");
+      const char* n = getenv("LAMP_NCV_BN_STATS");          // the narrow kernels' alone (A/B)
+      return !(e && e[0] == '0') && !(n && n[0] == '0');
+    }();
+    const bool with_stats = bn_stats && !dgrad && !addend && g.N >= 2 && (int64_t)q.Ho * q.Wo >= 64;
+#define NCV_F2(NKv, SWv, PHv, ADDv, STv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2, ADDv, STv> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1, ADDv, STv>
+#define NCV_F2_PH(NKv, SWv, ADDv, STv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0, ADDv, STv); else if (ph0 == 6) NCV_F2(NKv, SWv, 6, ADDv, STv); else NCV_F2(NKv, SWv, 7, ADDv, STv); } while (0)
+#define NCV_F2_SW(NKv) do { if (with_stats) { if (q.sw == 1) NCV_F2_PH(NKv, 1, false, true); else NCV_F2_PH(NKv, 2, false, true); }                \
+                            else if (q.sw == 1) { if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); }                \
+                            else NCV_F2_PH(NKv, 2, false, false); } while (0)
     switch (NK2) {
       case 2: NCV_F2_SW(2); break;
       case 4: NCV_F2_SW(4); break;
@@ -892,9 +975,28 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     bf16_t* dst2p = sib ? sib->out->ptr<bf16_t>() : (bf16_t*)nullptr;
     const bf16_t* bias2p = (sib && sib->bias) ? sib->bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
     int co_a = sib ? (int)g.Cout : q.CO;
-    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp, (void*)&dst2p, (void*)&bias2p, (void*)&co_a};
+    Hold statt, statt2;
+    float* statp = nullptr;
+    float* stat2p = nullptr;
+    // one triple per workgroup where every workgroup walks the same number of images (equal counts), else one per image
+    int stats_per_wg = g.N % blocks == 0 ? 1 : 0;
+    const int parts = stats_per_wg ? blocks : (int)g.N;
+    if (with_stats) {
+      int64_t ps[1] = {(int64_t)parts * g.Cout * 3};
+      statt = Hold(new_tensor(ps, 1, kF32, in->device()));
+      statp = statt->ptr<float>();
+      if (sib) {
+        int64_t ps2[1] = {(int64_t)parts * cout2 * 3};
+        statt2 = Hold(new_tensor(ps2, 1, kF32, in->device()));
+        stat2p = statt2->ptr<float>();
+      }
+    }
+    void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp, (void*)&dst2p, (void*)&bias2p, (void*)&co_a,
+                    (void*)&statp, (void*)&stat2p, (void*)&stats_per_wg};
     HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
+    if (statt.get()) conv_stats_publish(out, statt.get(), parts);
+    if (statt2.get()) conv_stats_publish(sib->out, statt2.get(), parts);
     return true;
   }
   const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * lds_per_cu);
