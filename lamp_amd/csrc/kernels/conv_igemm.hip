@@ -340,7 +340,8 @@ __device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, fl
 // half the MFMAs and 12 instead of 16 fragment reads per wave and stage.
 template <int KS, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats,
+                                                        const bf16_t* addend) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -481,6 +482,10 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
           uint2 pk;
           pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
           pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+          if (addend) {                             // dgrad: y = round(round(conv) + addend), as ig_conv8d_kernel (the statistics are fprop's)
+            const uint2 av = *reinterpret_cast<const uint2*>(addend + (int64_t)n * CO * 64 + co * 64 + (2 * j + qrow) * 8 + qw);
+            pk.x = add_bf16x2(pk.x, av.x); pk.y = add_bf16x2(pk.y, av.y);
+          }
           *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
         }
         vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
@@ -502,7 +507,8 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
 //  * 16 + 0.1 + 32 KiB of LDS: three workgroups fit a CU.
 template <int KS>
 __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
-                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats) {
+                                                        bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats,
+                                                        const bf16_t* addend) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -648,6 +654,10 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
           uint2 pk;
           pk.x = (unsigned)o0.bits | ((unsigned)o1.bits << 16);
           pk.y = (unsigned)o2.bits | ((unsigned)o3.bits << 16);
+          if (addend) {                             // dgrad: y = round(round(conv) + addend), as ig_conv8d_kernel (the statistics are fprop's)
+            const uint2 av = *reinterpret_cast<const uint2*>(addend + (int64_t)n * CO * 64 + co * 64 + (2 * j + qrow) * 8 + qw);
+            pk.x = add_bf16x2(pk.x, av.x); pk.y = add_bf16x2(pk.y, av.y);
+          }
           *reinterpret_cast<uint2*>(yp + co * 64 + (2 * j + qrow) * 8 + qw) = pk;
         }
         vals[4 * j + 0] = __uint_as_float((unsigned)o0.bits << 16); vals[4 * j + 1] = __uint_as_float((unsigned)o1.bits << 16);
@@ -1686,15 +1696,18 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         LAMP_LAUNCH_CHECK();
         return;
       }
+      // the two-image kernels add the second contribution of a residual block's input gradient in their stores too (B <= 512: two add launches less)
+      const bf16_t* addbc = (addend && dgrad) ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
+      if (addend_fused) *addend_fused = addbc != nullptr;
       if (CO <= 64 && !(variant && variant[0] == 'b')) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
         const size_t ldsc = (size_t)2 * 64 * KP * 2 + KP * 2 + 4 * (64 * 64 * 2);
         static bool c3 = false, c1 = false;
         if (KS == 3) {
           allow_big_lds((const void*)ig_conv8c_kernel<3>);
-          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
+          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc);
         } else {
           allow_big_lds((const void*)ig_conv8c_kernel<1>);
-          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp);
+          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc);
         }
         LAMP_LAUNCH_CHECK();
         return;
@@ -1707,7 +1720,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   do {                                                                                                                                          \
     allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_>);                                                                                   \
     hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_>), dim3(blocksb), dim3(NWV_ * 64), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp);                                                                                            \
+                       (int)g.N, CI, KP, CO, statp, addbc);                                                                                          \
   } while (0)
       if (KS == 3) { if (w8) IG_LAUNCH_B(3, 8); else IG_LAUNCH_B(3, 4); }
       else { if (w8) IG_LAUNCH_B(1, 8); else IG_LAUNCH_B(1, 4); }

@@ -1097,7 +1097,11 @@ DGRAD_ADD_CASES = [
     (1024, 64, 8, 128, 1, 1, 0, torch.bfloat16, True),      # 1x1, 4 tiles
     (1024, 16, 8, 128, 3, 1, 1, torch.bfloat16, True),      # 1 tile
     (1027, 128, 8, 64, 3, 1, 1, torch.bfloat16, True),      # ragged last workgroup
-    (64, 128, 8, 128, 3, 1, 1, torch.bfloat16, False),      # small batch: the two-image kernel, then an add
+    (64, 128, 8, 128, 3, 1, 1, torch.bfloat16, True),       # small batch: the two-image kernel (eight waves), adds in its stores since round 5
+    (600, 128, 8, 100, 3, 1, 1, torch.bfloat16, True),      # two-image kernel, four waves, 100 of 128 channels stored
+    (65, 100, 8, 128, 1, 1, 0, torch.bfloat16, True),       # 1x1, ragged last workgroup
+    (64, 64, 8, 128, 3, 1, 1, torch.bfloat16, True),        # at most 64 gradient channels out: the 64-row kernel
+    (31, 16, 8, 64, 1, 1, 0, torch.bfloat16, True),
     (64, 6, 32, 6, 3, 1, 1, torch.bfloat16, True),          # narrow kernel, two output phases per MFMA
     (64, 16, 16, 16, 3, 1, 1, torch.bfloat16, True),        # narrow kernel, one phase per MFMA
     (64, 3, 32, 8, 5, 1, 2, torch.bfloat16, True),          # 5x5
