@@ -411,6 +411,15 @@ int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* gr
                                         const lamp_tensor* w, const int64_t* stride, const int64_t* padding,
                                         const int64_t* dilation, int nspatial, const int64_t* output_padding,
                                         int64_t groups, const lamp_tensor* addend);
+/* grad_input of TWO (non-transposed) convolutions of ONE input x, summed (+ addend when given): what autograd.scala:66-84 accumulates into
+ * the input of lamp's residual block (cnn.scala:16-20: a 3x3 branch and the 1x1 shortcut) from its two consumers.  Where one kernel takes
+ * both gradients (bf16, the narrow layers: 3x3 pad 1 + 1x1 pad 0 of equal stride) the two products are summed in f32 and rounded ONCE;
+ * everywhere else the value is lamp_convolution_backward (b) followed by lamp_convolution_backward_input_add (a), each rounded to the dtype. */
+int lamp_convolution_backward_input_pair(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor* grad_out_a, const lamp_tensor* w_a,
+                                         const int64_t* stride_a, const int64_t* padding_a, const int64_t* dilation_a,
+                                         const lamp_tensor* grad_out_b, const lamp_tensor* w_b, const int64_t* stride_b,
+                                         const int64_t* padding_b, const int64_t* dilation_b, int nspatial, int64_t groups,
+                                         const lamp_tensor* addend_or_null);
 /* TWO (non-transposed) convolutions of ONE input: out2 = {convolution(x, w_a, bias_a, geometry a), convolution(x, w_b, bias_b, geometry b)} - the
  * two branches of lamp's residual block both start with a Conv2D on the block's input (example-cifar100 cnn.scala:16-20, 38-78: 3x3 and the
  * 1x1 shortcut).  Values (and the batch-norm statistics hand-off of each output) are those of two lamp_convolution calls; where a kernel

@@ -96,6 +96,7 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     root->grad_shared = false;
   }
   for (Variable* v : topological_sort(root.get())) {
+    if (v->pending) { auto f = std::move(v->pending); v->pending = nullptr; f(); }   // (all consumers are done: nothing will complete the pair)
     if (v->op && v->has_grad()) {             // a node nothing flowed into contributes exact zeros
       for (auto& p : v->op->params)
         if (p.first->needsGrad()) p.second(v->grad, *p.first);
@@ -662,15 +663,27 @@ Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& va
 
 // ---- convolution / pooling (ops.scala:1547-1825) ------------------------------------------------
 // the Convolution node (ops.scala:1547-1651); `computed`, when given, is the forward value a fused launch has already produced
+// The two Convolution nodes of convolution_pair share this: the first of the two input-gradient closures to run leaves its incoming
+// derivative here (and a fallback on the input variable), the second one computes both contributions with lamp_convolution_backward_input_pair.
+struct ConvPairGrad {
+  struct Side { Ten w; std::vector<int64_t> stride, padding, dilation; Ten p; };
+  Side side[2];
+  int64_t groups = 1;
+  int waiting = -1;                            // which side's derivative is held
+};
 static Var convolution_node(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                             const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
-                            const std::vector<int64_t>& outputPadding, int64_t groups, const Ten* computed) {
+                            const std::vector<int64_t>& outputPadding, int64_t groups, const Ten* computed,
+                            const std::shared_ptr<ConvPairGrad>& pair = nullptr, int pair_side = 0) {
   auto op = new_op("Convolution");
   const int ns = (int)stride.size();
   Ten iv = input->value, wv = weight->value;
   static const bool fuse_accumulate = [] { const char* e = getenv("LAMP_CONV_DGRAD_ACCUMULATE"); return !(e && e[0] == '0'); }();
+  static const bool fuse_pair = [] { const char* e = getenv("LAMP_CONV_DGRAD_PAIR"); return !(e && e[0] == '0'); }();
   auto back = [=](int which) {
-    return [=](const Ten& p, Variable& out) {
+    // (a plain function object: the pair's deferred form calls it again)
+    std::function<void(const Ten&, Variable&)> single;
+    single = [=](const Ten& p, Variable& out) {
       if (which == 0 && !transposed && fuse_accumulate && out.has_grad() && out.grad.h()->is_device() && p.h()->is_device() && out.grad.dtype() == p.dtype()) {
         // the input already holds another consumer's contribution (a residual block): `out += dgrad` inside the dgrad kernel
         lamp_tensor* r = nullptr;
@@ -686,6 +699,40 @@ static Var convolution_node(const Var& input, const Var& weight, const Var& bias
                                       outputPadding.data(), groups, mask));
       out.accumulate(Ten(o3[which]), true);
     };
+    if (which != 0 || !pair || !fuse_pair || transposed) return Backward(single);
+    return Backward([=](const Ten& p, Variable& out) {
+      if (!(p.h()->is_device() && fuse_accumulate)) { single(p, out); return; }
+      ConvPairGrad& st = *pair;
+      if (st.waiting < 0) {
+        // first of the two: hold the derivative; should the sibling's never arrive, the input's own turn in backprop computes this one alone
+        st.waiting = pair_side;
+        st.side[pair_side].p = p;
+        Variable* outp = &out;
+        out.pending = [=] {
+          ConvPairGrad& s2 = *pair;
+          if (s2.waiting != pair_side) return;
+          const Ten held = s2.side[pair_side].p;
+          s2.side[pair_side].p = Ten(); s2.waiting = -1;
+          single(held, *outp);
+        };
+        return;
+      }
+      if (st.waiting == pair_side) { single(p, out); return; }                       // (a second pass over the same node: not a pair)
+      const int other = st.waiting;
+      const Ten po = st.side[other].p;
+      st.side[other].p = Ten(); st.waiting = -1;
+      out.pending = nullptr;
+      const Ten& pa = pair_side == 0 ? p : po;
+      const Ten& pb = pair_side == 0 ? po : p;
+      const bool have = out.has_grad() && out.grad.h()->is_device() && out.grad.dtype() == p.dtype();
+      if (out.has_grad() && !have) { single(po, out); single(p, out); return; }
+      lamp_tensor* r = nullptr;
+      HCALL(lamp_convolution_backward_input_pair(&r, iv.h(), pa.h(), st.side[0].w.h(), st.side[0].stride.data(), st.side[0].padding.data(),
+                                                 st.side[0].dilation.data(), pb.h(), st.side[1].w.h(), st.side[1].stride.data(),
+                                                 st.side[1].padding.data(), st.side[1].dilation.data(), ns, st.groups, have ? out.grad.h() : nullptr));
+      out.grad = Ten(r);
+      out.grad_shared = false;
+    });
   };
   op->params.push_back({input, back(0)});
   op->params.push_back({weight, back(1)});
@@ -714,8 +761,12 @@ std::pair<Var, Var> convolution_pair(const Var& input, const Var& weight_a, cons
                               weight_b->value.h(), bias_b->value.h(), stride_b.data(), padding_b.data(), dilation_b.data(), ns, groups));
   const Ten ya(o2[0]), yb(o2[1]);
   const std::vector<int64_t> zero(ns, 0);
-  Var a = convolution_node(input, weight_a, bias_a, stride_a, padding_a, dilation_a, false, zero, groups, &ya);
-  Var b = convolution_node(input, weight_b, bias_b, stride_b, padding_b, dilation_b, false, zero, groups, &yb);
+  auto pg = std::make_shared<ConvPairGrad>();
+  pg->side[0] = {weight_a->value, stride_a, padding_a, dilation_a, Ten()};
+  pg->side[1] = {weight_b->value, stride_b, padding_b, dilation_b, Ten()};
+  pg->groups = groups;
+  Var a = convolution_node(input, weight_a, bias_a, stride_a, padding_a, dilation_a, false, zero, groups, &ya, pg, 0);
+  Var b = convolution_node(input, weight_b, bias_b, stride_b, padding_b, dilation_b, false, zero, groups, &yb, pg, 1);
   return {a, b};
 }
 Var avg_pool2d(const Var& input, int64_t k, int64_t stride, int64_t padding) {

@@ -45,6 +45,10 @@ struct NcvGeom {
   int kh;
   int kh_inv;            // 65536 / kh + 1: pair / kh == (pair * kh_inv) >> 16 for pair < 4096 (no integer division in the prologue)
   int pf;                // the image fits the register prefetch (W % 8 == 0 and at most NCV_PF 16-byte packets per thread)
+  // ncv_fwd2_kernel, dgrad of a PAIR (round 5): channels [0, C1) of the staged image come from the first tensor and take part with all kh
+  // filter rows, channels [C1, C) come from a second tensor (the gradient of a sibling 1x1 convolution of the same input) and take part with
+  // the centre row only: K pairs (c, r) = C1 * kh + (C - C1).  C1 = C: one source.
+  int C1;
 };
 
 constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligned rows for the vector copy
@@ -55,7 +59,7 @@ constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligne
 // (storage, view, stream, direction) like the implicit-GEMM images and re-packed in one launch by the optimiser step), so a
 // workgroup's prologue is NK 16-byte loads per lane.  Gathering them per lane from the filter tensor (8 two-byte loads and two
 // integer divisions per k-step) took 5.5 - 6.5 k of the ~22 k cycles a workgroup lives (scripts/ncv_stamp_probe.py).
-constexpr int NCV_NKMAX = 12;
+constexpr int NCV_NKMAX = 16;
 // ns = 2 ("two-shift" images, for at most 8 output channels and kw + sw <= 8): MFMA column n = 8*s + co carries the filter of
 // channel co moved s*sw taps to the right inside the 8-wide window, i.e. ONE MFMA produces the output pixels of two neighbouring
 // window phases - half the MFMAs (and half the funnel shifts) per output pixel; the 6-channel layers used 6 of 16 columns before.
@@ -66,13 +70,17 @@ struct NcvW {
   // round 5, fprop only: a SIBLING 1x1 filter [Cout2][Cin] of the same input (the shortcut of lamp's residual block, cnn.scala:16-20) as
   // output columns Cout .. Cout + Cout2 - 1 whose only non-zero tap is the centre one - the two convolutions are then ONE product over the
   // staged image (the 6-channel layers use 6 of the MFMA's 16 columns: the second convolution rides in the padding)
+  // dgrad: w2 = the sibling's filter too, but as EXTRA K pairs (its output gradient is a second source of the staged image, NcvGeom::C1)
   const bf16_t* w2;
   int Cout2;
 };
 __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
   const int n = lane & 15, pair = ks * 4 + (lane >> 4);
   const int co = wq.ns == 2 ? (n & 7) : n, shift = wq.ns == 2 ? (n >> 3) * wq.sw : 0;
-  const int c = pair / wq.kh, r = pair - c * wq.kh;
+  int c = pair / wq.kh, r = pair - c * wq.kh;
+  // dgrad of a pair: behind the Cout * kh pairs of the first filter come Cout2 pairs (c2, centre row) of the sibling 1x1 filter [Cout2][Cin]
+  const bool second_k = wq.dgrad && wq.w2 && pair >= wq.Cout * wq.kh;
+  if (second_k) { c = pair - wq.Cout * wq.kh; r = wq.kh / 2; }
   nv_s8 v;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -83,6 +91,7 @@ __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int la
         if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + t].bits;
         else if (wq.w2 && co < wq.Cout + wq.Cout2 && c < wq.Cin && r == wq.kh / 2 && t == wq.kw / 2) e = wq.w2[(co - wq.Cout) * wq.Cin + c].bits;
       }
+      else if (second_k) { if (co < wq.Cin && c < wq.Cout2 && t == wq.kw / 2) e = wq.w2[c * wq.Cin + co].bits; }   // (the centre tap is its own mirror image)
       else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - t)].bits; }
     }
     v[j] = (short)e;
@@ -107,22 +116,23 @@ __global__ __launch_bounds__(256) void ncv_pack_kernel(NcvPackMany a) {
 // the same packets of every image, so their LDS destinations are computed once (ncv_stage_plan): -1 = no packet.
 constexpr int NCV_PF = 4;
 struct NcvPre { uint4 v[NCV_PF]; };
-struct NcvPlan { int dst[NCV_PF]; };
+struct NcvPlan { int dst[NCV_PF]; int src[NCV_PF]; };      // src: element offset in the image's source tensor, + (1 << 30) for the second one
 __device__ __forceinline__ NcvPlan ncv_stage_plan(const NcvGeom& q, int tid, int nthreads) {
   NcvPlan pl;
-  const int rc = q.W >> 3, total = q.C * q.H * rc;
+  const int rc = q.W >> 3, total = q.C * q.H * rc, first = q.C1 * q.H * rc;
 #pragma unroll
   for (int k = 0; k < NCV_PF; k++) {
     const int i = tid + k * nthreads;
     const int b = i % rc, a = (i / rc) % q.H, c = i / (rc * q.H);
     pl.dst[k] = (q.pf && i < total) ? (c * q.Hs + q.top + a * q.dil) * q.Ws + q.left + b * 8 * q.dil : -1;
+    pl.src[k] = i < first ? i * 8 : ((i - first) * 8) | (1 << 30);
   }
   return pl;
 }
-__device__ __forceinline__ void ncv_stage_load(NcvPre& r, const NcvPlan& pl, const bf16_t* __restrict__ sp, int tid, int nthreads) {
+__device__ __forceinline__ void ncv_stage_load(NcvPre& r, const NcvPlan& pl, const bf16_t* __restrict__ sp, const bf16_t* __restrict__ sp2) {
 #pragma unroll
   for (int k = 0; k < NCV_PF; k++)
-    if (pl.dst[k] >= 0) r.v[k] = *reinterpret_cast<const uint4*>(sp + (tid + k * nthreads) * 8);
+    if (pl.dst[k] >= 0) r.v[k] = *reinterpret_cast<const uint4*>(((pl.src[k] >> 30) ? sp2 : sp) + (pl.src[k] & ((1 << 30) - 1)));
 }
 __device__ __forceinline__ void ncv_stage_store(unsigned short* xs, const NcvPre& r, const NcvPlan& pl, int dil) {
 #pragma unroll
@@ -250,7 +260,9 @@ __device__ __forceinline__ NcvWf ncv_wf_merge(const NcvWf& a, const NcvWf& b) { 
 template <int NK, int SW, int PH0, int NS, bool ADD, bool STATS>
 __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
                                                        bf16_t* dst, NcvGeom q, const bf16_t* add, bf16_t* dst2, const bf16_t* __restrict__ bias2, int co_a,
-                                                       float* __restrict__ stats, float* __restrict__ stats2, int stats_per_wg) {
+                                                       float* __restrict__ stats, float* __restrict__ stats2, int stats_per_wg,
+                                                       const bf16_t* __restrict__ src2) {
+  // src2 (dgrad of a pair): the second source of the staged image, channels [q.C1, q.C)
   // co_a: output columns [0, co_a) belong to dst, [co_a, q.CO) to dst2 (the sibling 1x1 of NcvW; co_a = q.CO and dst2 = nullptr otherwise)
   __shared__ float sst[STATS ? 2 : 1][4][16][3];           // [image parity][wave][MFMA column]: the waves' triples of one image
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -265,18 +277,20 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
   // The first image's packets are requested before anything else: a workgroup lives for two or three images, and in-kernel stamps
   // (scripts/ncv_stamp_probe.py) showed 3800 - 6300 of its 11 - 20 k cycles between "weights in registers" and "first image in LDS" -
   // the HBM round trip of that first load, started only after the weights had arrived and the LDS was zeroed.
-  const int64_t img_in = (int64_t)q.C * q.H * q.W;
+  const int64_t img_in = (int64_t)q.C1 * q.H * q.W, img_in2 = (int64_t)(q.C - q.C1) * q.H * q.W;
   NcvPre pre;
   const NcvPlan plan = ncv_stage_plan(q, tid, nthreads);
-  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, plan, src + blockIdx.x * img_in, tid, nthreads);
+  if (q.pf && (int)blockIdx.x < q.N) ncv_stage_load(pre, plan, src + blockIdx.x * img_in, src2 + blockIdx.x * img_in2);
   nv_bf8 wfr[NK];
   int koff[NK];
 #pragma unroll
   for (int ks = 0; ks < NK; ks++) {
     wfr[ks] = wpk[ks * 64 + lane];
     int pair = ks * 4 + (lane >> 4);
-    if (pair >= q.C * q.kh) pair = 0;
-    const int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
+    const int pairs1 = q.C1 * q.kh;
+    if (pair >= pairs1 + (q.C - q.C1)) pair = 0;
+    int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
+    if (pair >= pairs1) { c = q.C1 + (pair - pairs1); r = q.kh >> 1; }   // second source: centre row only
     koff[ks] = (c * q.Hs + r) * q.Ws * 2;
   }
   const float bv = co < co_a ? (bias ? (float)bias[co] : 0.f) : ((bias2 && co < q.CO) ? (float)bias2[co - co_a] : 0.f);
@@ -329,7 +343,8 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
     else ncv_stage(xs, src + n * img_in, q, tid, nthreads);
     __syncthreads();
     NCV_STAMP_ONCE(3);
-    if (q.pf && n + (int)gridDim.x < q.N) ncv_stage_load(pre, plan, src + (n + (int)gridDim.x) * img_in, tid, nthreads);   // in flight during the MFMAs
+    if (q.pf && n + (int)gridDim.x < q.N)                 // in flight during the MFMAs
+      ncv_stage_load(pre, plan, src + (n + (int)gridDim.x) * img_in, src2 + (n + (int)gridDim.x) * img_in2);
     // this lane's output plane: channel co of dst, or channel co - co_a of the sibling's tensor
     bf16_t* yc = co < co_a ? dst + ((int64_t)n * co_a + co) * HoWo : dst2 + ((int64_t)n * (q.CO - co_a) + (co - co_a)) * HoWo;
     for (int st = wid; st < nsuper; st += nwaves) {
@@ -882,17 +897,22 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
 // sibling (fprop, optional): a 1x1 convolution of the same input, same stride and output map, whose Cout2 channels fit beside w's in the
 // MFMA's 16 columns: both outputs from one launch of the aligned kernel (false, nothing launched, when that kernel does not take the pair)
 struct NcvSibling { const Tensor* w; const Tensor* bias; Tensor* out; };
+// second (dgrad, optional): the output gradient and the filter of a sibling 1x1 convolution of the same input (same stride and output map): both
+// input gradients, summed in f32, from one launch of the aligned kernel (false, nothing launched, when that kernel does not take the pair)
+struct NcvSecondGrad { const Tensor* dy; const Tensor* w; };
 static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
-                    const Tensor* addend = nullptr, bool* addend_fused = nullptr, const NcvSibling* sib = nullptr) {
+                    const Tensor* addend = nullptr, bool* addend_fused = nullptr, const NcvSibling* sib = nullptr,
+                    const NcvSecondGrad* second = nullptr) {
   if (addend_fused) *addend_fused = false;
   if (!ncv_common(g, in->dtype)) return false;
-  const int cout2 = sib ? (int)sib->w->sizes[0] : 0;
+  const int cout2 = sib ? (int)sib->w->sizes[0] : second ? (int)second->w->sizes[0] : 0;
   if (sib && (dgrad || g.Cout + cout2 > 16)) return false;
+  if (second && (!dgrad || sib || cout2 > 16)) return false;
   NcvGeom q;
   q.N = (int)g.N; q.kh = g.kh; q.pf = 0; q.kh_inv = 65536 / g.kh + 1;
   if (!dgrad) {
     if (g.W % 8 != 0) return false;
-    q.C = (int)g.Cin; q.CO = (int)g.Cout + cout2; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
+    q.C = (int)g.Cin; q.C1 = q.C; q.CO = (int)g.Cout + cout2; q.H = (int)g.H; q.W = (int)g.W; q.dil = 1;
     q.top = g.ph; q.left = NCV_LEFT;
     q.Ho = (int)g.Ho; q.Wo = (int)g.Wo; q.sh = g.sh; q.sw = g.sw; q.wx = NCV_LEFT - g.pw;
     q.Hs = std::max((int)g.H + 2 * g.ph, (q.Ho - 1) * g.sh + g.kh);
@@ -900,7 +920,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   } else {
     // dx = stride-1 correlation of the dilated dy image with the mirrored filter, padding k-1-p
     const int pt = g.kh - 1 - g.ph, pl = g.kw - 1 - g.pw;
-    q.C = (int)g.Cout; q.CO = (int)g.Cin; q.H = (int)g.Ho; q.W = (int)g.Wo; q.dil = g.sh;
+    q.C1 = (int)g.Cout; q.C = q.C1 + (second ? cout2 : 0); q.CO = (int)g.Cin; q.H = (int)g.Ho; q.W = (int)g.Wo; q.dil = g.sh;
     if (q.dil == 1 && q.W % 8 != 0) return false;
     q.top = pt; q.left = NCV_LEFT;
     q.Ho = (int)g.H; q.Wo = (int)g.W; q.sh = 1; q.sw = 1; q.wx = NCV_LEFT - pl;
@@ -915,10 +935,10 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   if (aligned && !(ncg == 2 || ncg == 4 || ncg == 8 || ncg == 16)) aligned = false;
   if (aligned && q.Ho % (16 / ncg) != 0) aligned = false;
   if (aligned) q.Ws = round_up(std::max(q.Ws, q.Wo * q.sw + (q.wx - ph0) + 16), 8);
-  if (sib && !aligned) return false;
-  const int pairs = q.C * q.kh;
+  if ((sib || second) && !aligned) return false;
+  const int pairs = q.C1 * q.kh + (q.C - q.C1);
   const int nk_real = (pairs + 3) / 4;
-  static const int nk_opts[] = {1, 2, 4, 5, 8, 12};
+  static const int nk_opts[] = {1, 2, 4, 5, 6, 8, 12, 16};
   int NK = 0;
   for (int o : nk_opts) if (o >= nk_real) { NK = o; break; }
   if (!NK) return false;
@@ -927,8 +947,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   // two output phases per MFMA where the columns allow it (see NcvW)
   static const bool two_shift_on = [] { const char* e = getenv("LAMP_NCV_TWO_SHIFT"); return !(e && e[0] == '0'); }();
   const int NS = (two_shift_on && aligned && q.CO <= 8 && g.kw + q.sw <= 8) ? 2 : 1;
-  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw, sib ? sib->w->ptr<bf16_t>() : (const bf16_t*)nullptr, cout2};
-  Hold wpk_h(ncv_packed_weights(w, wq, st, sib ? sib->w : nullptr));
+  const Tensor* wsecond = sib ? sib->w : second ? second->w : nullptr;
+  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw, wsecond ? wsecond->ptr<bf16_t>() : (const bf16_t*)nullptr, cout2};
+  Hold wpk_h(ncv_packed_weights(w, wq, st, wsecond));
   const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
   static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2
   const int lds_per_cu = (int)std::max<size_t>(1, std::min<size_t>(max_per_cu, (size_t)(150 * 1024) / std::max<size_t>(lds, 1)));
@@ -937,7 +958,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     const int nsuper = q.Ho / (16 / ncg);
     const int threads = 64 * std::min(4, nsuper);
     q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
-    const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : 12));
+    if (second && !q.pf) return false;                     // (two sources are staged through the register prefetch only)
+    if (NK > 12 && !second) return false;
+    const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : (NK <= 6 && second ? 6 : (NK <= 8 && second ? 8 : (NK <= 12 ? 12 : 16)))));
     const void* kfn = nullptr;
     const bool with_add = addend != nullptr && q.sw == 1;
     // fprop: per-image batch-norm statistics of the output(s) from the epilogue (LAMP_CONV_BN_STATS=0 turns the hand-off off)
@@ -952,12 +975,18 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
 #define NCV_F2_SW(NKv) do { if (with_stats) { if (q.sw == 1) NCV_F2_PH(NKv, 1, false, true); else NCV_F2_PH(NKv, 2, false, true); }                \
                             else if (q.sw == 1) { if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); }                \
                             else NCV_F2_PH(NKv, 2, false, false); } while (0)
+    // (6, 8 and 16 k-steps: the pairs' input gradients only - stride-1 correlations without statistics)
+#define NCV_F2_PAIR(NKv) do { if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); } while (0)
     switch (NK2) {
       case 2: NCV_F2_SW(2); break;
       case 4: NCV_F2_SW(4); break;
       case 5: NCV_F2_SW(5); break;
+      case 6: NCV_F2_PAIR(6); break;
+      case 8: NCV_F2_PAIR(8); break;
+      case 16: NCV_F2_PAIR(16); break;
       default: NCV_F2_SW(12); break;
     }
+#undef NCV_F2_PAIR
 #undef NCV_F2_SW
 #undef NCV_F2_PH
 #undef NCV_F2
@@ -967,8 +996,11 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     // (the sibling's work is declared with the launch; its input is the one already counted)
     const double sib_fl = sib ? 2.0 * (double)g.N * cout2 * (double)g.Ho * g.Wo * (double)g.Cin : 0.0;
     const double sib_by = sib ? ((double)g.N * cout2 * g.Ho * g.Wo + (double)cout2 * g.Cin) * 2.0 : 0.0;
-    KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g) + sib_fl, conv_bytes(g, 2) + sib_by, st);
+    const double sec_fl = second ? 2.0 * (double)g.N * cout2 * (double)g.Ho * g.Wo * (double)g.Cin : 0.0;
+    const double sec_by = second ? ((double)g.N * cout2 * g.Ho * g.Wo + (double)cout2 * g.Cin) * 2.0 : 0.0;
+    KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g) + sib_fl + sec_fl, conv_bytes(g, 2) + sib_by + sec_by, st);
     const bf16_t* srcp = in->ptr<bf16_t>();
+    const bf16_t* src2p = second ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
     bf16_t* dstp = out->ptr<bf16_t>();
     const bf16_t* addp = with_add ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
     if (addend_fused) *addend_fused = with_add;
@@ -992,13 +1024,14 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
       }
     }
     void* args[] = {(void*)&srcp, (void*)&wpk, (void*)&bp, (void*)&dstp, (void*)&q, (void*)&addp, (void*)&dst2p, (void*)&bias2p, (void*)&co_a,
-                    (void*)&statp, (void*)&stat2p, (void*)&stats_per_wg};
+                    (void*)&statp, (void*)&stat2p, (void*)&stats_per_wg, (void*)&src2p};
     HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
     if (statt.get()) conv_stats_publish(out, statt.get(), parts);
     if (statt2.get()) conv_stats_publish(sib->out, statt2.get(), parts);
     return true;
   }
+  if (NK > 12) return false;
   const int blocks = (int)std::min<int64_t>(g.N, (int64_t)num_cus() * lds_per_cu);
   KernelTimer kt(dgrad ? "conv_dgrad_narrow" : "conv_fwd_narrow", conv_flops(g), conv_bytes(g, 2), st);
   switch (NK) {
@@ -1006,7 +1039,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     case 2: ncv_launch<2>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
     case 4: ncv_launch<4>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
     case 5: ncv_launch<5>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
-    case 8: ncv_launch<8>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
+    case 6: case 8: ncv_launch<8>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
     default: ncv_launch<12>(in->ptr<bf16_t>(), wpk, bp, out->ptr<bf16_t>(), q, blocks, lds, st); break;
   }
   LAMP_LAUNCH_CHECK();
@@ -1031,6 +1064,21 @@ bool narrow_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, 
 }
 bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend, bool* addend_fused) {
   return ncv_run(dy, w, nullptr, dx, g, true, st, addend, addend_fused);
+}
+// dx = round(dgrad3x3(dy, w) + dgrad1x1(dy1, w1) [then round(. + addend)]: the input gradient of the two branches of lamp's residual block
+// (cnn.scala:16-20; autograd.scala:66-84 accumulates the two partial derivatives) from ONE launch - the second gradient tensor is staged
+// as extra channels of the image, the second filter is their centre tap - summed in f32 before the one rounding (the two-launch chain
+// rounds each contribution first); false = nothing launched
+bool narrow_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g, const Tensor* dy1, const Tensor* w1, const ConvGeom& g1, Tensor* dx,
+                            hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  if (addend_fused) *addend_fused = false;
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_DGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  if (!on || dy->dtype != kBF16 || dy1->dtype != kBF16) return false;
+  if (g.kh != 3 || g.kw != 3 || g.ph != 1 || g.pw != 1 || g1.kh != 1 || g1.kw != 1 || g1.ph != 0 || g1.pw != 0) return false;
+  if (g.sh != g1.sh || g.sw != g1.sw || g.Ho != g1.Ho || g.Wo != g1.Wo || g.H != g1.H || g.W != g1.W || g.Cin != g1.Cin || g.N != g1.N) return false;
+  if (g.groups != 1 || g1.groups != 1 || g.dh != 1 || g.dw != 1 || g1.dh != 1 || g1.dw != 1 || g1.Cout > 16) return false;
+  const NcvSecondGrad sg{dy1, w1};
+  return ncv_run(dy, w, nullptr, dx, g, true, st, addend, addend_fused, nullptr, &sg);
 }
 
 template <int NT, int SW>

@@ -1149,6 +1149,90 @@ def test_convolution_input_gradient_accumulates_in_the_kernel(gpu, case):
     assert_close(got, (gx.double() + addend.double()), tol, "dgrad + addend")
 
 
+# (N, Cin, H, Cout_a, Cout_b, stride, dtype, addend?, one launch?)
+DGRAD_PAIR_CASES = [
+    (64, 6, 32, 6, 6, 2, torch.bfloat16, False, True),      # res1 of Cnn.resnet: 6 + 6 gradient channels on 16x16 -> 6 x 32x32
+    (67, 6, 32, 6, 6, 2, torch.bfloat16, True, True),       # ragged batch, a third consumer's contribution already there
+    (64, 6, 16, 16, 16, 2, torch.bfloat16, False, True),    # res2: 16 + 16 channels, sixteen k-steps
+    (2050, 6, 16, 16, 16, 2, torch.bfloat16, True, True),   # more images than workgroups
+    (33, 6, 16, 6, 6, 1, torch.bfloat16, False, True),      # stride 1
+    (16, 8, 32, 5, 3, 1, torch.bfloat16, False, True),
+    (1024, 128, 8, 128, 128, 1, torch.bfloat16, False, False),   # implicit-GEMM layers: the chain of two launches, bitwise
+    (64, 128, 8, 100, 100, 1, torch.bfloat16, True, False),
+    (8, 5, 12, 7, 4, 1, torch.float32, False, False),
+    (4, 6, 10, 4, 4, 2, torch.float64, True, False),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_PAIR_CASES)
+def test_input_gradient_of_a_block_s_two_first_convolutions(gpu, case):
+    """lamp_convolution_backward_input_pair: the input gradient of the 3x3 and the 1x1 convolution lamp's residual block applies to its
+    input (cnn.scala:16-20), summed - what autograd.scala:66-84 accumulates from the two consumers.  The narrow bf16 layers take both
+    output gradients in one launch (the second tensor as extra channels of the staged image, its filter as their centre tap), summed in f32
+    and rounded once: within one bf16 rounding of the chain convolution_backward -> convolution_backward_input_add, and at least as close
+    to the f32 oracle.  Every other geometry runs that chain inside the entry point, bitwise."""
+    N, Cin, H, Ca, Cb, stride, dt, with_add, one_launch = case
+    x = closed_form((N, Cin, H, H), 3, 2.0, dt)
+    wa, wb = closed_form((Ca, Cin, 3, 3), 17, 0.5, dt), closed_form((Cb, Cin, 1, 1), 19, 0.7, dt)
+    ho = (H + 2 - 3) // stride + 1
+    assert ho == (H - 1) // stride + 1
+    ga, gb = closed_form((N, Ca, ho, ho), 23, 1.0, dt), closed_form((N, Cb, ho, ho), 31, 1.0, dt)
+    addend = closed_form((N, Cin, H, H), 29, 3.0, dt)
+    X, WA, WB, GA, GB, A = to_sten(x), to_sten(wa), to_sten(wb), to_sten(ga), to_sten(gb), to_sten(addend)
+    sd, p1, p0, one, z = i64_array([stride, stride]), i64_array([1, 1]), i64_array([0, 0]), i64_array([1, 1]), i64_array([0, 0])
+    # the chain, in the order backprop reaches the block: the shortcut's gradient (+ addend), then the 3x3's added to it
+    if with_add:
+        first = C.c_void_p()
+        lib.lamp_convolution_backward_input_add(C.byref(first), GB, X, WB, sd, p0, one, 2, z, 1, A)
+        first = S.STen(first)
+    else:
+        out3 = _out3()
+        lib.lamp_convolution_backward(out3, GB, X, WB, sd, p0, one, 2, 0, z, 1, _mask3(1, 0, 0))
+        first = S.STen(out3[0])
+    chain = C.c_void_p()
+    lib.lamp_convolution_backward_input_add(C.byref(chain), GA, X, WA, sd, p1, one, 2, z, 1, first)
+    chain = to_torch(S.STen(chain))
+    lib.lamp_kernel_timer_enable(1)
+    o = C.c_void_p()
+    lib.lamp_convolution_backward_input_pair(C.byref(o), X, GA, WA, sd, p1, one, GB, WB, sd, p0, one, 2, 1, A if with_add else None)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    got = to_torch(S.STen(o))
+    rep = buf.value.decode()
+    f = torch.float64 if dt == torch.float64 else torch.float32
+    ref = (aten.convolution_backward(ga.to(f), x.to(f), wa.to(f), [0], [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0] +
+           aten.convolution_backward(gb.to(f), x.to(f), wb.to(f), [0], [stride, stride], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]).double()
+    if with_add:
+        ref = ref + addend.double()
+    tol = {torch.float64: 1e-6, torch.float32: 1e-4, torch.bfloat16: 3e-2}[dt]
+    assert_close(got, ref, tol, "pair against the oracle")
+    if one_launch:
+        lines = [l for l in rep.splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith("conv_dgrad_narrow") and int(lines[0].split()[1]) == 1, rep
+        assert_close(got, chain.double(), 2.0 ** -6, "pair against the chain")   # (each of the chain's two roundings is relative to its own term)
+        err_pair, err_chain = (got.double() - ref).abs().mean().item(), (chain.double() - ref).abs().mean().item()
+        assert err_pair <= err_chain * 1.02, f"one rounding should not be further from the oracle than two: {err_pair} vs {err_chain}"
+    else:
+        assert torch.equal(got, chain), f"max diff {(got - chain).abs().max().item()}"
+    assert torch.equal(to_torch(A).double(), addend.double()), "the addend is not modified"
+
+
+def test_input_gradient_pair_checks_its_arguments(gpu):
+    dt = torch.bfloat16
+    x = closed_form((4, 6, 8, 8), 3, 2.0, dt)
+    wa, wb = closed_form((5, 6, 3, 3), 17, 0.5, dt), closed_form((5, 6, 1, 1), 19, 0.5, dt)
+    gy = closed_form((4, 5, 8, 8), 23, 1.0, dt)
+    one, p1, p0 = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0])
+    o = C.c_void_p()
+    with pytest.raises(Exception, match="does not match its forward output shape"):
+        lib.lamp_convolution_backward_input_pair(C.byref(o), to_sten(x), to_sten(gy), to_sten(wa), one, p1, one, to_sten(x), to_sten(wb), one, p0, one, 2, 1, None)
+    with pytest.raises(Exception, match="dtype mismatch"):
+        lib.lamp_convolution_backward_input_pair(C.byref(o), to_sten(x), to_sten(gy), to_sten(wa), one, p1, one, to_sten(gy.float()), to_sten(wb), one, p0, one, 2, 1, None)
+    with pytest.raises(Exception, match="does not have the input's shape"):
+        lib.lamp_convolution_backward_input_pair(C.byref(o), to_sten(x), to_sten(gy), to_sten(wa), one, p1, one, to_sten(gy), to_sten(wb), one, p0, one, 2, 1, to_sten(gy))
+
+
 def test_convolution_input_gradient_accumulate_checks_its_arguments(gpu):
     x = closed_form((4, 6, 8, 8), 3, 2.0, torch.bfloat16)
     w = closed_form((5, 6, 3, 3), 17, 0.5, torch.bfloat16)
