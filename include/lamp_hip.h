@@ -420,6 +420,13 @@ int lamp_convolution_backward_input_pair(lamp_tensor** out, const lamp_tensor* x
                                          const lamp_tensor* grad_out_b, const lamp_tensor* w_b, const int64_t* stride_b,
                                          const int64_t* padding_b, const int64_t* dilation_b, int nspatial, int64_t groups,
                                          const lamp_tensor* addend_or_null);
+/* grad_weight of the same two convolutions: out2 = {dW_a, dW_b}, the values of two lamp_convolution_backward calls with mask (0, 1, 0); one
+ * launch that stages x once where a kernel takes both output gradients (bf16 narrow layers, 3x3 pad 1 + 1x1 pad 0, at most 16 output
+ * channels together).  w_a / w_b give the filters' shapes and dtype. */
+int lamp_convolution_backward_weight_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp_tensor* grad_out_a, const lamp_tensor* w_a,
+                                          const int64_t* stride_a, const int64_t* padding_a, const int64_t* dilation_a,
+                                          const lamp_tensor* grad_out_b, const lamp_tensor* w_b, const int64_t* stride_b,
+                                          const int64_t* padding_b, const int64_t* dilation_b, int nspatial, int64_t groups);
 /* TWO (non-transposed) convolutions of ONE input: out2 = {convolution(x, w_a, bias_a, geometry a), convolution(x, w_b, bias_b, geometry b)} - the
  * two branches of lamp's residual block both start with a Conv2D on the block's input (example-cifar100 cnn.scala:16-20, 38-78: 3x3 and the
  * 1x1 shortcut).  Values (and the batch-norm statistics hand-off of each output) are those of two lamp_convolution calls; where a kernel

@@ -153,7 +153,7 @@ struct Variable {
   bool grad_shared = false;
   // a contribution one of this variable's consumers has put off until another consumer's arrives (the two first convolutions of a residual
   // block: their input gradients come from one launch); backprop runs it when it reaches this variable and it is still there
-  std::function<void()> pending;
+  std::vector<std::function<void()>> pending;
   bool needsGrad() const { return wants_grad; }
   std::vector<int64_t> shape() const { return value.shape(); }
   void zeroGrad() { grad = Ten(); grad_shared = false; }            // lazily zero

@@ -63,8 +63,12 @@ std::vector<Variable*> topological_sort(Variable* root) {
 void backprop(const Var& root) { backprop(root, nullptr); }
 // `after` runs once per visited node, after the node's backward closures (also for nodes nothing flowed into): the
 // data-parallel step uses it to start the gradient exchange of the deep layers while the shallow ones are still in backward
+// true while a backprop with an `after` hook runs on this thread: a parameter's gradient must be final when the hook sees the parameter
+// (the data-parallel step starts its exchange there), so nothing may put a weight gradient off
+static thread_local bool tls_backprop_hooked = false;
 void backprop(const Var& root, const std::function<void(Variable*)>& after) {
   if (!root->needsGrad()) return;
+  struct Hooked { bool prev; Hooked(bool h) : prev(tls_backprop_hooked) { tls_backprop_hooked = h; } ~Hooked() { tls_backprop_hooked = prev; } } hooked((bool)after);
   // partialDerivative.get.fill_(1d).  A one-element root (every loss) takes a constant kept per (thread, device, dtype, stream)
   // instead of a fill launch per step; it is marked shared, so anything that wanted to modify it in place copies it first.
   if (root->value.numel() == 1) {
@@ -96,7 +100,11 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     root->grad_shared = false;
   }
   for (Variable* v : topological_sort(root.get())) {
-    if (v->pending) { auto f = std::move(v->pending); v->pending = nullptr; f(); }   // (all consumers are done: nothing will complete the pair)
+    if (!v->pending.empty()) {                // (all consumers are done: nothing will complete a pair now)
+      auto fs = std::move(v->pending);
+      v->pending.clear();
+      for (auto& f : fs) f();
+    }
     if (v->op && v->has_grad()) {             // a node nothing flowed into contributes exact zeros
       for (auto& p : v->op->params)
         if (p.first->needsGrad()) p.second(v->grad, *p.first);
@@ -666,10 +674,11 @@ Var scaled_dot_product_attention(const Var& query, const Var& key, const Var& va
 // The two Convolution nodes of convolution_pair share this: the first of the two input-gradient closures to run leaves its incoming
 // derivative here (and a fallback on the input variable), the second one computes both contributions with lamp_convolution_backward_input_pair.
 struct ConvPairGrad {
-  struct Side { Ten w; std::vector<int64_t> stride, padding, dilation; Ten p; };
+  struct Side { Ten w; std::vector<int64_t> stride, padding, dilation; Ten p; Ten pw; Variable* wout = nullptr; };
   Side side[2];
   int64_t groups = 1;
-  int waiting = -1;                            // which side's derivative is held
+  int waiting = -1;                            // which side's derivative is held for the input gradient
+  int wwaiting = -1;                           // ... and for the weight gradients (pw, wout: the derivative and the parameter it belongs to)
 };
 static Var convolution_node(const Var& input, const Var& weight, const Var& bias, const std::vector<int64_t>& stride,
                             const std::vector<int64_t>& padding, const std::vector<int64_t>& dilation, bool transposed,
@@ -699,6 +708,44 @@ static Var convolution_node(const Var& input, const Var& weight, const Var& bias
                                       outputPadding.data(), groups, mask));
       out.accumulate(Ten(o3[which]), true);
     };
+    static const bool fuse_wpair = [] { const char* e = getenv("LAMP_CONV_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+    if (which == 1 && pair && fuse_wpair && !transposed) {
+      // the two weight gradients from one call (x is staged once).  The fallback sits on the INPUT variable, which backprop reaches after
+      // both convolutions (a parameter is reached right after its own node, before the sibling has run)
+      Variable* inp = input.get();
+      return Backward([=](const Ten& p, Variable& out) {
+        if (!p.h()->is_device() || tls_backprop_hooked) { single(p, out); return; }
+        ConvPairGrad& st = *pair;
+        if (st.wwaiting < 0) {
+          st.wwaiting = pair_side;
+          st.side[pair_side].pw = p;
+          st.side[pair_side].wout = &out;
+          inp->pending.push_back([=] {
+            ConvPairGrad& s2 = *pair;
+            if (s2.wwaiting != pair_side) return;
+            const Ten held = s2.side[pair_side].pw;
+            Variable* wo = s2.side[pair_side].wout;
+            s2.side[pair_side].pw = Ten(); s2.side[pair_side].wout = nullptr; s2.wwaiting = -1;
+            single(held, *wo);
+          });
+          return;
+        }
+        if (st.wwaiting == pair_side) { single(p, out); return; }
+        const int other = st.wwaiting;
+        const Ten po = st.side[other].pw;
+        Variable* wo = st.side[other].wout;
+        st.side[other].pw = Ten(); st.side[other].wout = nullptr; st.wwaiting = -1;
+        const Ten& pa = pair_side == 0 ? p : po;
+        const Ten& pb = pair_side == 0 ? po : p;
+        lamp_tensor* o2[2] = {nullptr, nullptr};
+        HCALL(lamp_convolution_backward_weight_pair(o2, iv.h(), pa.h(), st.side[0].w.h(), st.side[0].stride.data(), st.side[0].padding.data(),
+                                                    st.side[0].dilation.data(), pb.h(), st.side[1].w.h(), st.side[1].stride.data(),
+                                                    st.side[1].padding.data(), st.side[1].dilation.data(), ns, st.groups));
+        const Ten da(o2[0]), db(o2[1]);
+        (pair_side == 0 ? out : *wo).accumulate(da, true);
+        (pair_side == 0 ? *wo : out).accumulate(db, true);
+      });
+    }
     if (which != 0 || !pair || !fuse_pair || transposed) return Backward(single);
     return Backward([=](const Ten& p, Variable& out) {
       if (!(p.h()->is_device() && fuse_accumulate)) { single(p, out); return; }
@@ -708,20 +755,19 @@ static Var convolution_node(const Var& input, const Var& weight, const Var& bias
         st.waiting = pair_side;
         st.side[pair_side].p = p;
         Variable* outp = &out;
-        out.pending = [=] {
+        out.pending.push_back([=] {
           ConvPairGrad& s2 = *pair;
           if (s2.waiting != pair_side) return;
           const Ten held = s2.side[pair_side].p;
           s2.side[pair_side].p = Ten(); s2.waiting = -1;
           single(held, *outp);
-        };
+        });
         return;
       }
       if (st.waiting == pair_side) { single(p, out); return; }                       // (a second pass over the same node: not a pair)
       const int other = st.waiting;
       const Ten po = st.side[other].p;
-      st.side[other].p = Ten(); st.waiting = -1;
-      out.pending = nullptr;
+      st.side[other].p = Ten(); st.waiting = -1;             // (its fallback on `out` finds nothing waiting)
       const Ten& pa = pair_side == 0 ? p : po;
       const Ten& pb = pair_side == 0 ? po : p;
       const bool have = out.has_grad() && out.grad.h()->is_device() && out.grad.dtype() == p.dtype();

@@ -311,6 +311,7 @@ bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const Conv
 bool narrow_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g, const Tensor* dy1, const Tensor* w1, const ConvGeom& g1, Tensor* dx,
                             hipStream_t st, const Tensor* addend, bool* addend_fused);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
+bool narrow_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
                       bool* addend_fused = nullptr);
@@ -610,6 +611,43 @@ int lamp_convolution_backward_input_pair(lamp_tensor** out, const lamp_tensor* x
   }
   Hold ph(part);
   if (lamp_convolution_backward_input_add(out, grad_out_a, x, w_a, stride_a, padding_a, dilation_a, nspatial, zero2, groups, ph.get()) != 0) throw Error(lamp_last_error());
+  LAMP_API_END
+}
+
+int lamp_convolution_backward_weight_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp_tensor* grad_out_a, const lamp_tensor* w_a,
+                                          const int64_t* stride_a, const int64_t* padding_a, const int64_t* dilation_a,
+                                          const lamp_tensor* grad_out_b, const lamp_tensor* w_b, const int64_t* stride_b,
+                                          const int64_t* padding_b, const int64_t* dilation_b, int nspatial, int64_t groups) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(w_a, "first weight"); check_device_tensor(grad_out_a, "first grad_out");
+  check_device_tensor(w_b, "second weight"); check_device_tensor(grad_out_b, "second grad_out");
+  LAMP_CHECK(x->dtype == w_a->dtype && x->dtype == w_b->dtype && grad_out_a->dtype == x->dtype && grad_out_b->dtype == x->dtype,
+             "convolution_backward_weight_pair: dtype mismatch");
+  LAMP_CHECK(nspatial >= 1 && nspatial <= 2, "convolution_backward_weight_pair: 1 or 2 spatial dimensions");
+  const int64_t zero2[2] = {0, 0};
+  ConvGeom ga = make_geom(x, w_a, stride_a, padding_a, dilation_a, nspatial, 0, zero2, groups);
+  ConvGeom gb = make_geom(x, w_b, stride_b, padding_b, dilation_b, nspatial, 0, zero2, groups);
+  auto check_grad = [&](const lamp_tensor* gy, const ConvGeom& g, const char* which) {
+    LAMP_CHECK(gy->ndim == x->ndim && gy->sizes[0] == g.N && gy->sizes[1] == g.Cout && gy->sizes[gy->ndim - 1] == g.Wo && (nspatial == 1 || gy->sizes[2] == g.Ho),
+               "convolution_backward_weight_pair: the " << which << " grad_out " << gy->describe() << " does not match its forward output shape");
+  };
+  check_grad(grad_out_a, ga, "first"); check_grad(grad_out_b, gb, "second");
+  if (x->dtype == kBF16 && nspatial == 2) {
+    Hold xc(contiguous(x)), wa(contiguous(w_a)), wb(contiguous(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b));
+    hipStream_t st = current_stream(x->device());
+    Hold dwa(new_like(wa.get())), dwb(new_like(wb.get()));
+    if (narrow_conv_wgrad_pair(gya.get(), gyb.get(), xc.get(), dwa.get(), dwb.get(), ga, gb, st)) {
+      out2[0] = dwa.take(); out2[1] = dwb.take();
+      return 0;
+    }
+  }
+  const uint8_t m3[3] = {0, 1, 0};
+  lamp_tensor* ra[3] = {nullptr, nullptr, nullptr};
+  if (lamp_convolution_backward(ra, grad_out_a, x, w_a, stride_a, padding_a, dilation_a, nspatial, 0, zero2, groups, m3) != 0) throw Error(lamp_last_error());
+  Hold ha(ra[1]);
+  lamp_tensor* rb[3] = {nullptr, nullptr, nullptr};
+  if (lamp_convolution_backward(rb, grad_out_b, x, w_b, stride_b, padding_b, dilation_b, nspatial, 0, zero2, groups, m3) != 0) throw Error(lamp_last_error());
+  out2[0] = ha.take(); out2[1] = rb[1];
   LAMP_API_END
 }
 

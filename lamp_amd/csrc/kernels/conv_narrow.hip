@@ -484,6 +484,10 @@ struct NcvWGeom {
   int Hs, Ws;            // SW == 1: LDS x image [Cin][Hs][Ws]; SW == 2: [Cin][Hs][2 parities][Ws]
   int ncol;              // Cin * kh * kw
   int IG;                // images staged per round
+  // ncv_wgrad2_kernel, weight gradients of a PAIR (round 5): rows [Cout, Cout + Cout2) of the staged gradient image come from a second tensor,
+  // the output gradient of a sibling 1x1 convolution of the same x (same stride and output map); of their products only the centre tap is
+  // its weight gradient [Cout2][Cin] (the other taps are computed and dropped: the MFMA's 16 rows were 6 of 16 used).  0: none.
+  int Cout2;
 };
 constexpr int NCV_OFF2 = 4;   // stride 2: column w lives at plane (w & 1), position (w >> 1) + NCV_OFF2
 
@@ -588,7 +592,7 @@ constexpr int NCV_OFFA = 8;   // column origin of the staged rows (both strides)
 constexpr int NCV_WPF = 6;    // 16-byte packets per thread the image-group prefetch holds
 template <int KW, int PW, int SW, int NPT>
 __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial, NcvWGeom q,
-                                                         int images_per_block) {
+                                                         int images_per_block, const bf16_t* __restrict__ dy2, float* __restrict__ partial2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int HoWo = q.Ho * q.Wo;
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
   const int chunks_per_img = HoWo >> 5;
   // Staging in two halves (as in ncv_fwd2_kernel): the x and dy packets of the NEXT image group are loaded into registers while this
   // group is multiplied, and written to LDS after the barrier.  A group is [image][x packets | dy packets] of 16 bytes.
-  const int xpk = (q.Cin * q.H * q.W) >> 3, dpk = (q.Cout * HoWo) >> 3, per = xpk + dpk;
+  const int xpk = (q.Cin * q.H * q.W) >> 3, dpk = (q.Cout * HoWo) >> 3, dpk2 = (q.Cout2 * HoWo) >> 3, per = xpk + dpk + dpk2;
   const int rc = q.W >> 3;
   // a thread handles the same packets of every group: source offsets (elements, from the group's first image) and LDS destinations
   // (elements from xs) are computed once; meta = image index within the group, or -1 (no packet)
@@ -637,18 +641,22 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
       const int b = j % rc, a = (j / rc) % q.H, c = j / (rc * q.H);
       p_src[k] = im * q.Cin * q.H * q.W + j * 8;
       p_dst[k] = im * ximg + (SW == 1 ? (c * q.Hs + q.ph + a) * q.Ws + NCV_OFFA + b * 8 : ((c * q.Hs + q.ph + a) * 2) * q.Ws + NCV_OFFA + b * 4);
-    } else {
+    } else if (j < xpk + dpk) {
       p_src[k] = -(im * q.Cout * HoWo + (j - xpk) * 8) - 1;          // negative: a dy packet
       p_dst[k] = q.IG * ximg + im * 16 * HoWo + (j - xpk) * 8;
+    } else {
+      p_src[k] = -(im * q.Cout2 * HoWo + (j - xpk - dpk) * 8) - 1 - (1 << 30);   // below -2^30: a packet of the second gradient tensor
+      p_dst[k] = q.IG * ximg + im * 16 * HoWo + q.Cout * HoWo + (j - xpk - dpk) * 8;
     }
   }
   auto pre_load = [&](int64_t nb, int ig) {
     const bf16_t* xg = x + nb * q.Cin * q.H * q.W;
     const bf16_t* dg = dy + nb * q.Cout * HoWo;
+    const bf16_t* dg2 = dy2 + nb * q.Cout2 * HoWo;
 #pragma unroll
     for (int k = 0; k < NCV_WPF; k++)
       if (p_im[k] >= 0 && p_im[k] < ig) {
-        const bf16_t* sp = p_src[k] >= 0 ? xg + p_src[k] : dg + (-p_src[k] - 1);
+        const bf16_t* sp = p_src[k] >= 0 ? xg + p_src[k] : p_src[k] >= -(1 << 30) ? dg + (-p_src[k] - 1) : dg2 + (-p_src[k] - 1 - (1 << 30));
         pre[k] = *reinterpret_cast<const uint4*>(sp);
       }
   };
@@ -689,6 +697,8 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
       const bf16_t* dp = dy + (nb + im) * q.Cout * HoWo;
       unsigned short* di = ds + im * 16 * HoWo;
       for (int i = tid; i < dpk; i += 256) *reinterpret_cast<uint4*>(di + i * 8) = *reinterpret_cast<const uint4*>(dp + i * 8);
+      const bf16_t* dp2 = dy2 + (nb + im) * q.Cout2 * HoWo;
+      for (int i = tid; i < dpk2; i += 256) *reinterpret_cast<uint4*>(di + q.Cout * HoWo + i * 8) = *reinterpret_cast<const uint4*>(dp2 + i * 8);
     }
     __syncthreads();
     if (pf && nb + q.IG < n1) pre_load(nb + q.IG, (int)min<int64_t>(q.IG, n1 - nb - q.IG));      // in flight during the MFMAs
@@ -766,6 +776,17 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
 #pragma unroll
     for (int w = 0; w < 4; w++) a += red[(w * 16 + co) * NCOLT + col];
     partial[(int64_t)blockIdx.x * O + i] = a;
+  }
+  // the sibling 1x1's weight gradient [Cout2][Cin]: the centre tap of rows Cout ...
+  const int O2 = q.Cout2 * q.Cin;
+  for (int i = tid; i < O2; i += 256) {
+    const int co2 = i / q.Cin, ci = i - co2 * q.Cin;
+    const int pair = ci * q.kh + (q.kh >> 1), s = KW >> 1;
+    const int col = ((pair >> 4) * KW + s) * 16 + (pair & 15);
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) a += red[(w * 16 + q.Cout + co2) * NCOLT + col];
+    partial2[(int64_t)blockIdx.x * O2 + i] = a;
   }
 }
 
@@ -1088,12 +1109,17 @@ static void ncv_wg_launch(const bf16_t* dy, const bf16_t* x, float* partial, con
   hipLaunchKernelGGL((ncv_wgrad_kernel<NT, SW>), dim3(blocks), dim3(256), lds, st, dy, x, partial, q, ipb);
 }
 
-bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) {
+// second (optional): the output gradient of a sibling 1x1 convolution of the same x and ITS weight gradient: both from the one launch of the
+// aligned kernel (false, nothing launched, when that kernel does not take the pair)
+struct NcvSecondWgrad { const Tensor* dy; Tensor* dw; };
+static bool ncv_wgrad_run(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const NcvSecondWgrad* second) {
   if (!ncv_common(g, x->dtype)) return false;
   if (g.W % 8 != 0 || g.Wo % 8 != 0 || (g.Ho * g.Wo) % 32 != 0) return false;
+  const int cout2 = second ? (int)second->dy->sizes[1] : 0;
+  if (second && (g.Cout + cout2 > 16 || g.kh != 3 || g.kw != 3 || g.ph != 1 || g.pw != 1)) return false;
   NcvWGeom q;
   q.N = (int)g.N; q.Cin = (int)g.Cin; q.Cout = (int)g.Cout; q.H = (int)g.H; q.W = (int)g.W; q.Ho = (int)g.Ho; q.Wo = (int)g.Wo;
-  q.kh = g.kh; q.kw = g.kw; q.ph = g.ph; q.pw = g.pw;
+  q.kh = g.kh; q.kw = g.kw; q.ph = g.ph; q.pw = g.pw; q.Cout2 = cout2;
   q.ncol = (int)g.Cin * g.kh * g.kw;
   const int SW = g.sh;
   q.Hs = std::max((int)g.H + 2 * g.ph, ((int)g.Ho - 1) * g.sh + g.kh);
@@ -1134,23 +1160,38 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
       const int nblocks = (int)((g.N + ipb - 1) / ipb);
       int64_t ps[1] = {(int64_t)nblocks * O};
       Hold partial(new_tensor(ps, 1, kF32, dy->device()));
+      const int O2 = cout2 * q.Cin;
+      Hold partial2;
+      if (second) { int64_t ps2[1] = {(int64_t)nblocks * O2}; partial2 = Hold(new_tensor(ps2, 1, kF32, dy->device())); }
       {
-        KernelTimer kt("conv_wgrad_narrow", conv_flops(g), conv_bytes(g, 2), st);
+        // (the sibling's work is declared with the launch; x is the one already counted)
+        const double sec_fl = second ? 2.0 * (double)g.N * cout2 * (double)g.Ho * g.Wo * (double)g.Cin : 0.0;
+        const double sec_by = second ? ((double)g.N * cout2 * g.Ho * g.Wo + (double)cout2 * g.Cin) * 2.0 : 0.0;
+        KernelTimer kt("conv_wgrad_narrow", conv_flops(g) + sec_fl, conv_bytes(g, 2) + sec_by, st);
         const bf16_t* dp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
+        const bf16_t* dp2 = second ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
+        float* pp2 = second ? partial2->ptr<float>() : (float*)nullptr;
         int ipb_arg = ipb;
-        void* args[] = {(void*)&dp, (void*)&xp, (void*)&pp, (void*)&q, (void*)&ipb_arg};
+        void* args[] = {(void*)&dp, (void*)&xp, (void*)&pp, (void*)&q, (void*)&ipb_arg, (void*)&dp2, (void*)&pp2};
         HIP_CHECK(hipLaunchKernel(kfn, dim3(nblocks), dim3(256), args, lds2, st));
         LAMP_LAUNCH_CHECK();
       }
       WgradReduceArgs ra{};
       ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
       wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+      if (second) {
+        WgradReduceArgs rb{};
+        rb.kind = 1; rb.O = O2; rb.nsplit = nblocks; rb.blocks = (int)(((int64_t)O2 * 64 + 255) / 256);
+        wgrad_reduce_enqueue(rb, partial2.get(), second->dw, st);
+      }
       return true;
     }
+    if (second) return false;
     // does not fit: restore the geometry of the generic kernel
     if (SW == 1) q.Ws = round_up(std::max(NCV_LEFT + (int)g.W, (int)g.Wo - 1 + g.kw - 1 - g.pw + NCV_LEFT + 1), 8);
     else { const int half_max = (g.kw - 1 - g.pw) >> 1; q.Ws = round_up(std::max((int)g.W / 2, (int)g.Wo + half_max) + NCV_OFF2 + 1, 8); }
   }
+  if (second) return false;
   const int nt_real = (q.ncol + 15) / 16;
   static const int nt_opts[] = {1, 2, 4, 5, 9};
   int NT = 0;
@@ -1190,6 +1231,20 @@ bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const Conv
   ra.kind = 1; ra.O = O; ra.nsplit = nblocks; ra.blocks = (int)(((int64_t)O * 64 + 255) / 256);
   wgrad_reduce_enqueue(ra, partial.get(), dw, st);
   return true;
+}
+
+bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st) { return ncv_wgrad_run(dy, x, dw, g, st, nullptr); }
+// dw = wgrad3x3(dy, x) and dw1 = wgrad1x1(dy1, x) - the weight gradients of the two convolutions lamp's residual block applies to its input
+// (cnn.scala:16-20) - from one launch that stages x once: the values of the two separate launches (the second gradient tensor rides in the
+// spare rows of the MFMA tile, its weight gradient is the centre tap of those rows); false = nothing launched
+bool narrow_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  if (!on || x->dtype != kBF16 || dy->dtype != kBF16 || dy1->dtype != kBF16) return false;
+  if (g1.kh != 1 || g1.kw != 1 || g1.ph != 0 || g1.pw != 0) return false;
+  if (g.sh != g1.sh || g.sw != g1.sw || g.Ho != g1.Ho || g.Wo != g1.Wo || g.H != g1.H || g.W != g1.W || g.Cin != g1.Cin || g.N != g1.N) return false;
+  if (g.groups != 1 || g1.groups != 1 || g.dh != 1 || g.dw != 1 || g1.dh != 1 || g1.dw != 1) return false;
+  const NcvSecondWgrad sw{dy1, dw1};
+  return ncv_wgrad_run(dy, x, dw, g, st, &sw);
 }
 
 }  // namespace lamp

@@ -1218,6 +1218,64 @@ def test_input_gradient_of_a_block_s_two_first_convolutions(gpu, case):
     assert torch.equal(to_torch(A).double(), addend.double()), "the addend is not modified"
 
 
+# (N, Cin, H, Cout_a, Cout_b, stride, dtype, one launch?)
+WGRAD_PAIR_CASES = [
+    (64, 6, 32, 6, 6, 2, torch.bfloat16, True),         # res1 of Cnn.resnet
+    (67, 6, 32, 6, 6, 2, torch.bfloat16, True),         # ragged batch
+    (2050, 6, 16, 6, 6, 1, torch.bfloat16, True),       # stride 1, more image groups than workgroups
+    (16, 8, 32, 5, 3, 1, torch.bfloat16, True),
+    (33, 3, 32, 8, 8, 2, torch.bfloat16, True),         # all 16 rows of the tile
+    (64, 6, 16, 16, 16, 2, torch.bfloat16, False),      # res2: 32 rows do not fit one tile - two launches
+    (64, 128, 8, 128, 128, 1, torch.bfloat16, False),   # implicit-GEMM layers
+    (8, 5, 12, 7, 4, 1, torch.float32, False),
+    (4, 6, 10, 4, 4, 2, torch.float64, False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PAIR_CASES)
+def test_weight_gradients_of_a_block_s_two_first_convolutions(gpu, case):
+    """lamp_convolution_backward_weight_pair: dW of the 3x3 and of the 1x1 convolution lamp's residual block applies to its input
+    (cnn.scala:16-20).  On the narrow bf16 layers with at most 16 output channels together the two output gradients share the rows of the
+    matrix-core tile and x is staged once: the 3x3's gradient BITWISE that of its own launch (same products in the same order), the 1x1's
+    - the centre tap of the extra rows - equal up to the order the image groups are summed in (f32 sums rounded to bf16).  Everything else
+    runs the two lamp_convolution_backward calls inside the entry point, bitwise."""
+    N, Cin, H, Ca, Cb, stride, dt, one_launch = case
+    x = closed_form((N, Cin, H, H), 3, 2.0, dt)
+    wa, wb = closed_form((Ca, Cin, 3, 3), 17, 0.5, dt), closed_form((Cb, Cin, 1, 1), 19, 0.7, dt)
+    ho = (H - 1) // stride + 1
+    ga, gb = closed_form((N, Ca, ho, ho), 23, 1.0, dt), closed_form((N, Cb, ho, ho), 31, 1.0, dt)
+    X, WA, WB, GA, GB = to_sten(x), to_sten(wa), to_sten(wb), to_sten(ga), to_sten(gb)
+    sd, p1, p0, one, z = i64_array([stride, stride]), i64_array([1, 1]), i64_array([0, 0]), i64_array([1, 1]), i64_array([0, 0])
+
+    def single(G, W, pad):
+        out3 = _out3()
+        lib.lamp_convolution_backward(out3, G, X, W, sd, pad, one, 2, 0, z, 1, _mask3(0, 1, 0))
+        return to_torch(S.STen(out3[1]))
+    da, db = single(GA, WA, p1), single(GB, WB, p0)
+    lib.lamp_kernel_timer_enable(1)
+    o2 = (C.c_void_p * 2)()
+    lib.lamp_convolution_backward_weight_pair(o2, X, GA, WA, sd, p1, one, GB, WB, sd, p0, one, 2, 1)
+    pa, pb = to_torch(S.STen(o2[0])), to_torch(S.STen(o2[1]))       # (reading them runs the deferred reductions)
+    buf = C.create_string_buffer(1 << 16)
+    lib.lamp_kernel_timer_report(buf, len(buf))
+    lib.lamp_kernel_timer_enable(0)
+    rep = buf.value.decode()
+    assert pa.shape == wa.shape and pb.shape == wb.shape
+    assert torch.equal(pa, da), f"3x3: max diff {(pa - da).abs().max().item()}"
+    if one_launch:
+        lines = [l for l in rep.splitlines() if l.startswith("conv_wgrad")]
+        assert len(lines) == 1 and lines[0].startswith("conv_wgrad_narrow") and int(lines[0].split()[1]) == 1, rep
+        assert_close(pb, db.double(), 2.0 ** -7, "1x1 against its own launch")
+    else:
+        assert torch.equal(pb, db), f"1x1: max diff {(pb - db).abs().max().item()}"
+    f = torch.float64 if dt == torch.float64 else torch.float32
+    ra = aten.convolution_backward(ga.to(f), x.to(f), wa.to(f), [0], [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    rb = aten.convolution_backward(gb.to(f), x.to(f), wb.to(f), [0], [stride, stride], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    tol = {torch.float64: 1e-6, torch.float32: 2e-4, torch.bfloat16: 2e-2}[dt]
+    assert_close(pa, ra.double(), tol, "3x3 against the oracle")
+    assert_close(pb, rb.double(), tol, "1x1 against the oracle")
+
+
 def test_input_gradient_pair_checks_its_arguments(gpu):
     dt = torch.bfloat16
     x = closed_form((4, 6, 8, 8), 3, 2.0, dt)
