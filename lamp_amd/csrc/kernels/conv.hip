@@ -310,6 +310,8 @@ bool narrow_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const Conv
                        bool* addend_fused = nullptr);
 bool narrow_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g, const Tensor* dy1, const Tensor* w1, const ConvGeom& g1, Tensor* dx,
                             hipStream_t st, const Tensor* addend, bool* addend_fused);
+bool igemm_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g, const Tensor* dy1, const Tensor* w1, const ConvGeom& g1, Tensor* dx,
+                           hipStream_t st, const Tensor* addend, bool* addend_fused);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 bool narrow_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
@@ -590,7 +592,8 @@ int lamp_convolution_backward_input_pair(lamp_tensor** out, const lamp_tensor* x
     hipStream_t st = current_stream(x->device());
     Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
     bool fused = false;
-    if (narrow_conv_dgrad_pair(gya.get(), wa.get(), ga, gyb.get(), wb.get(), gb, dx.get(), st, ac.get(), &fused)) {
+    if (narrow_conv_dgrad_pair(gya.get(), wa.get(), ga, gyb.get(), wb.get(), gb, dx.get(), st, ac.get(), &fused) ||
+        igemm_conv_dgrad_pair(gya.get(), wa.get(), ga, gyb.get(), wb.get(), gb, dx.get(), st, ac.get(), &fused)) {
       if (ac.get() && !fused) {
         lamp_tensor* sum = nullptr;
         if (lamp_add(&sum, ac.get(), dx.get(), 1.0) != 0) throw Error(lamp_last_error());

@@ -759,13 +759,18 @@ __device__ __forceinline__ void ig8d_tile_stats(const uint2 (&pk)[4], float& mea
 // lamp's residual block, whose two branches both start with a Conv2D on the block's input (cnn.scala:16-20, 38-78).  Its product is a second,
 // 1/9-length main loop over the images that are already in LDS (centre tap only), run BEFORE the 3x3 product because the 3x3 epilogue
 // overwrites the images; it saves the 1x1 launch with its own image burst (33.5 MB for res4), prologue and ramp.
-struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; };
+// SIBM = 2 (round 5, dgrad): a SECOND SOURCE instead - the output gradient x2 of that 1x1 sibling, whose input gradient is the other contribution
+// to the block's input gradient (autograd.scala:66-84 accumulates the two).  Its product (centre tap, the sibling's transposed filter) runs first
+// on its own images, then the 3x3's images replace them in LDS and the 3x3 product continues in the SAME accumulators: one rounding, one
+// epilogue, and neither the 1x1's 33.5 MB result nor its re-read as the addend.
+struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; const bf16_t* x2; };
 
-template <int KS, int NCT, bool SIB>
+template <int KS, int NCT, int SIBM>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* y, int N, int CI, int KP, int CO, float* __restrict__ stats, int stats_per_wg,
                                                         const bf16_t* addend, const float4* __restrict__ affine, const IgSibling sib) {
-  static_assert(!SIB || KS == 3, "the sibling product is the centre tap of a 3x3 staging");
+  constexpr bool SIB = SIBM == 1, DG2 = SIBM == 2;
+  static_assert(SIBM == 0 || KS == 3, "the sibling product is the centre tap of a 3x3 staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   };
   auto stage_dma = [&](int kc1, int rs1, int slot) { stage_dma_of(wp, kc1, rs1, slot); };
   IG_STAMP(0);
-  if (SIB) {                                  // the sibling's stages (one tap: stage = 32-channel chunk) come first
+  if (SIB || DG2) {                           // the sibling's stages (one tap: stage = 32-channel chunk) come first
     stage_dma_of(sib.wp, 0, 0, 0);
     if (KC > 1) stage_dma_of(sib.wp, 1, 0, 1);
   } else {
@@ -833,7 +838,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   }
   // NCHW -> [pixel][32 channels].  A thread takes 8 channels x one image row: eight coalesced 16-byte loads, an 8x8 transposition of the
   // 16-bit elements in registers, eight 16-byte LDS writes (8 channels of one pixel each).
-  {
+  auto load_images = [&](const bf16_t* __restrict__ x) {
     for (int e = tid; e < NI * 8 * 4 * KC; e += NT) {
       const int cg = e & 3, h = (e >> 2) & 7, img = (e >> 5) & 7, ch = e >> 8;
       const int n = n0 + img;
@@ -869,7 +874,8 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
         *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ ig8d_swz(h, p)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
-  }
+  };
+  load_images(DG2 ? sib.x2 : x);
   f4v acc[NCT][4];
 #pragma unroll
   for (int i = 0; i < NCT; i++)
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // closing READ(t), which both groups pass before anyone starts READ(t+1).
   bf8v fa[NCT], fb[4];
   const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
-  if constexpr (SIB) {
+  if constexpr (SIB || DG2) {
     // ---- sibling product: KC stages of the centre tap, same ring and phases
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int sslot = 0;
@@ -920,8 +926,10 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       const char* xb = Xl + kc * XBUF + va[PAD & 1][PAD];
 #pragma unroll
       for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((PAD * 8 + PAD) + 16 * j) * RB));
-      if (kc + 2 < KC) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // (two pieces per stage and requesting wave)
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (kc + 2 < KC) {
+        if constexpr (SIB) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");  // (two pieces per stage and requesting wave)
+        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -938,7 +946,14 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     // waves 4 - 7 read two images' tiles back as 16-byte chunks and store whole 128-byte rows - the same bytes and statistics as the
     // kernel's own epilogue produces.
     stage_dma(0, 0, 0);
-    {
+    if constexpr (DG2) {
+      // ... or, second source: nobody reads the sibling's images any more; the 3x3's own images take their place, the accumulators stay
+      if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+      load_images(x);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // images and weight stages 0, 1 are in LDS
+    }
+    if constexpr (SIB) {
       const int n = n0 + wid;
       char* Sc = Wl + WT + wid * 2048;
       const int q = lane >> 4;
@@ -1033,11 +1048,13 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // nobody reads the scratch area any more: slots 1 - 2 belong to the ring again
-    if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
-    if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 and 1; waves 4 - 7 have only their stores in flight and do not wait
-    __builtin_amdgcn_s_barrier();
+    if constexpr (SIB) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // nobody reads the scratch area any more: slots 1 - 2 belong to the ring again
+      if (T > 1) stage_dma(1 / RS, 1 % RS, 1);
+      if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0 and 1; waves 4 - 7 have only their stores in flight and do not wait
+      __builtin_amdgcn_s_barrier();
+    }
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int t = 0, slot = 0;
@@ -1612,12 +1629,18 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
 // sibling (fprop of a 3x3, optional): a 1x1 convolution of the same input with the same number of output channels, computed by the same launch
 // where the eight-image kernel runs - *sibling_fused says whether it did (else the caller runs it as its own convolution)
 struct SiblingConv { const Tensor* w; const Tensor* bias; Tensor* out; const ConvGeom* g; };
+// second (dgrad of a 3x3, optional): the output gradient and the filter of a sibling 1x1 convolution of the same input; its input gradient is
+// accumulated by the same launch (ig_conv8d_kernel<3, ., 2>) - *second_fused says whether it was (igemm_conv_dgrad_pair checks the
+// conditions first, so that nothing is launched otherwise)
+struct SecondGradConv { const Tensor* dy; const Tensor* w; const ConvGeom* g; };
 static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Tensor* out, const ConvGeom& g, bool dgrad, hipStream_t st,
                       const Tensor* addend = nullptr, bool* addend_fused = nullptr, const Tensor* affine = nullptr, bool* affine_used = nullptr,
-                      const SiblingConv* sibling = nullptr, bool* sibling_fused = nullptr) {
+                      const SiblingConv* sibling = nullptr, bool* sibling_fused = nullptr, const SecondGradConv* second = nullptr,
+                      bool* second_fused = nullptr) {
   if (addend_fused) *addend_fused = false;
   if (affine_used) *affine_used = false;
   if (sibling_fused) *sibling_fused = false;
+  if (second_fused) *second_fused = false;
   const int KS = g.kh, RS = KS * KS;
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
@@ -1640,8 +1663,9 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       struct Publish { Hold& t; const Tensor* y; int P; ~Publish() { if (t.get()) conv_stats_publish(y, t.get(), P); } } publish{statt, out, (int)g.N};
       // (a sibling, when given, always runs in this launch - igemm_conv_fwd_pair checks the eight-image kernel's conditions first: its work
       // is declared with the launch; its input is the one already counted)
-      const double sib_fl = sibling ? conv_flops(*sibling->g) : 0.0;
-      const double sib_by = sibling ? conv_bytes(*sibling->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;
+      const double sib_fl = sibling ? conv_flops(*sibling->g) : second ? conv_flops(*second->g) : 0.0;
+      const double sib_by = sibling ? conv_bytes(*sibling->g, 2) - (double)g.N * g.Cin * 64 * 2
+                                    : second ? conv_bytes(*second->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;   // (one output for both)
       KernelTimer kt("conv_igemm_fprop_dgrad", conv_flops(g) + sib_fl, conv_bytes(g, 2) + sib_by, st);
       const bf16_t* bpb = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
       // more than 64 output channels and enough images to give every CU a workgroup of eight: one workgroup per CU, wave = image x all
@@ -1670,7 +1694,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         if (addend_fused) *addend_fused = addend != nullptr;
         // the sibling 1x1 of a residual block's first 3x3 (same input, same output channels): second product of this launch
         static const bool sib_on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
-        IgSibling sibk{nullptr, nullptr, nullptr, nullptr};
+        IgSibling sibk{nullptr, nullptr, nullptr, nullptr, nullptr};
         Hold sib_wpk, sib_statt;
         const bool sib = sib_on && sibling && !dgrad && KS == 3 && !addend && sibling->g->kh == 1 && sibling->g->Cout == g.Cout &&
                          sibling->g->Cin == g.Cin && sibling->g->N == g.N;
@@ -1689,7 +1713,17 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
           }
           if (sibling_fused) *sibling_fused = true;
         }
-        if (sib) { if (CO <= 16) IG_LAUNCH_D(3, 1, true); else if (CO <= 64) IG_LAUNCH_D(3, 4, true); else if (CO <= 112) IG_LAUNCH_D(3, 7, true); else IG_LAUNCH_D(3, 8, true); }
+        // dgrad: the input gradient of the sibling 1x1 accumulated by this launch (its output gradient is a second source of images)
+        const bool dg2 = second && dgrad && KS == 3 && second->g->kh == 1 && second->g->Cout == g.Cout && second->g->Cin == g.Cin && second->g->N == g.N;
+        if (dg2) {
+          int64_t off1 = 0;
+          sib_wpk = Hold(packed_weights(second->w, *second->g, 1, st, &off1));
+          sibk.wp = static_cast<const Tensor*>(sib_wpk.get())->ptr<bf16_t>() + off1;
+          sibk.x2 = second->dy->ptr<bf16_t>();
+          if (second_fused) *second_fused = true;
+        }
+        if (dg2) { if (CO <= 16) IG_LAUNCH_D(3, 1, 2); else if (CO <= 64) IG_LAUNCH_D(3, 4, 2); else if (CO <= 112) IG_LAUNCH_D(3, 7, 2); else IG_LAUNCH_D(3, 8, 2); }
+        else if (sib) { if (CO <= 16) IG_LAUNCH_D(3, 1, true); else if (CO <= 64) IG_LAUNCH_D(3, 4, true); else if (CO <= 112) IG_LAUNCH_D(3, 7, true); else IG_LAUNCH_D(3, 8, true); }
         else if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1, false); else if (CO <= 64) IG_LAUNCH_D(3, 4, false); else if (CO <= 112) IG_LAUNCH_D(3, 7, false); else IG_LAUNCH_D(3, 8, false); }
         else { if (CO <= 16) IG_LAUNCH_D(1, 1, false); else if (CO <= 64) IG_LAUNCH_D(1, 4, false); else if (CO <= 112) IG_LAUNCH_D(1, 7, false); else IG_LAUNCH_D(1, 8, false); }
 #undef IG_LAUNCH_D
@@ -1749,6 +1783,27 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   else { if (NW == 4) IG_LAUNCH(1, 4); else IG_LAUNCH(1, 2); }
 #undef IG_LAUNCH
   LAMP_LAUNCH_CHECK();
+}
+
+// dx = dgrad3x3(dy, w) + dgrad1x1(dy1, w1) [+ addend] in one launch of the eight-image kernel (the two products share the accumulators: one
+// rounding); false (nothing launched) when that kernel does not take the geometry
+bool igemm_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g, const Tensor* dy1, const Tensor* w1, const ConvGeom& g1, Tensor* dx,
+                           hipStream_t st, const Tensor* addend, bool* addend_fused) {
+  if (addend_fused) *addend_fused = false;
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_DGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  if (!on || !ig_qualifies(g, dy->dtype) || !ig_qualifies(g1, dy1->dtype) || g.kh != 3 || g1.kh != 1) return false;
+  if (g.Cout != g1.Cout || g.Cin != g1.Cin || g.N != g1.N) return false;
+  // the eight-image kernel's conditions for a dgrad (run_conv8): its output channels are the convolution's input channels
+  const char* variant = getenv("LAMP_IG_VARIANT");
+  if (variant && (variant[0] == 'a' || variant[0] == 'b')) return false;
+  static const bool small_d = [] { const char* e = getenv("LAMP_IG_SMALL_D"); return !(e && e[0] == '0'); }();
+  const bool force_d = variant && variant[0] == 'd';
+  if (!((g.Cin > 64 || small_d) && (force_d || g.N >= 4 * (int64_t)num_cus()))) return false;
+  const SecondGradConv sg{dy1, w1, &g1};
+  bool fused = false;
+  run_conv8(dy, w, nullptr, dx, g, true, st, addend, addend_fused, nullptr, nullptr, nullptr, nullptr, &sg, &fused);
+  LAMP_CHECK(fused, "internal: the eight-image kernel did not take the second gradient");
+  return true;
 }
 
 bool igemm_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st) {

@@ -1157,8 +1157,11 @@ DGRAD_PAIR_CASES = [
     (2050, 6, 16, 16, 16, 2, torch.bfloat16, True, True),   # more images than workgroups
     (33, 6, 16, 6, 6, 1, torch.bfloat16, False, True),      # stride 1
     (16, 8, 32, 5, 3, 1, torch.bfloat16, False, True),
-    (1024, 128, 8, 128, 128, 1, torch.bfloat16, False, False),   # implicit-GEMM layers: the chain of two launches, bitwise
-    (64, 128, 8, 100, 100, 1, torch.bfloat16, True, False),
+    (1024, 128, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),   # res4: the eight-image kernel takes the second gradient as a second set of images
+    (1027, 100, 8, 128, 128, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),    # ragged last workgroup, 7 channel tiles, a third contribution
+    (1024, 16, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),    # res3: 16 input channels (one tile)
+    (1024, 64, 8, 64, 64, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),       # two 32-channel chunks, 4 tiles
+    (64, 128, 8, 100, 100, 1, torch.bfloat16, True, False),      # small batch: the chain of two launches, bitwise
     (8, 5, 12, 7, 4, 1, torch.float32, False, False),
     (4, 6, 10, 4, 4, 2, torch.float64, True, False),
 ]
@@ -1170,7 +1173,8 @@ def test_input_gradient_of_a_block_s_two_first_convolutions(gpu, case):
     input (cnn.scala:16-20), summed - what autograd.scala:66-84 accumulates from the two consumers.  The narrow bf16 layers take both
     output gradients in one launch (the second tensor as extra channels of the staged image, its filter as their centre tap), summed in f32
     and rounded once: within one bf16 rounding of the chain convolution_backward -> convolution_backward_input_add, and at least as close
-    to the f32 oracle.  Every other geometry runs that chain inside the entry point, bitwise."""
+    to the f32 oracle.  The eight-image implicit-GEMM kernel (8x8 maps, N >= 4 x CUs) does the same with two sets of images in turn and one
+    set of accumulators.  Every other geometry runs that chain inside the entry point, bitwise."""
     N, Cin, H, Ca, Cb, stride, dt, with_add, one_launch = case
     x = closed_form((N, Cin, H, H), 3, 2.0, dt)
     wa, wb = closed_form((Ca, Cin, 3, 3), 17, 0.5, dt), closed_form((Cb, Cin, 1, 1), 19, 0.7, dt)
@@ -1208,8 +1212,9 @@ def test_input_gradient_of_a_block_s_two_first_convolutions(gpu, case):
     tol = {torch.float64: 1e-6, torch.float32: 1e-4, torch.bfloat16: 3e-2}[dt]
     assert_close(got, ref, tol, "pair against the oracle")
     if one_launch:
+        cls = "conv_dgrad_narrow" if one_launch is True else one_launch
         lines = [l for l in rep.splitlines() if l.strip()]
-        assert len(lines) == 1 and lines[0].startswith("conv_dgrad_narrow") and int(lines[0].split()[1]) == 1, rep
+        assert len(lines) == 1 and lines[0].startswith(cls) and int(lines[0].split()[1]) == 1, rep
         assert_close(got, chain.double(), 2.0 ** -6, "pair against the chain")   # (each of the chain's two roundings is relative to its own term)
         err_pair, err_chain = (got.double() - ref).abs().mean().item(), (chain.double() - ref).abs().mean().item()
         assert err_pair <= err_chain * 1.02, f"one rounding should not be further from the oracle than two: {err_pair} vs {err_chain}"
