@@ -330,6 +330,16 @@ __device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, fl
   for (int off = 16; off <= 32; off <<= 1) ig_stats_merge(n, mean, m2, __shfl_xor(n, off, 64), __shfl_xor(mean, off, 64), __shfl_xor(m2, off, 64));
 }
 
+// The SIBLING of a 3x3 convolution (SIB instantiations): a 1x1 convolution of the SAME input with as many output channels - the shortcut of
+// lamp's residual block, whose two branches both start with a Conv2D on the block's input (cnn.scala:16-20, 38-78).  Its product is a second,
+// 1/9-length main loop over the images that are already in LDS (centre tap only), run BEFORE the 3x3 product because the 3x3 epilogue
+// overwrites the images; it saves the 1x1 launch with its own image burst (33.5 MB for res4), prologue and ramp.
+// SIBM = 2 (round 5, dgrad): a SECOND SOURCE instead - the output gradient x2 of that 1x1 sibling, whose input gradient is the other contribution
+// to the block's input gradient (autograd.scala:66-84 accumulates the two).  Its product (centre tap, the sibling's transposed filter) runs first
+// on its own images, then the 3x3's images replace them in LDS and the 3x3 product continues in the SAME accumulators: one rounding, one
+// epilogue, and neither the 1x1's 33.5 MB result nor its re-read as the addend.
+struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; const bf16_t* x2; };
+
 // DEFAULT variant, TWO co-resident workgroups per CU (LAMP_IG_VARIANT=a selects the 4-image kernel above): two images and four waves per
 // workgroup, the images WITHOUT halo (taps outside the image read a shared zero pixel), two weight slots: 32 + 0.25 + 32 KiB of
 // LDS.  The two workgroups of a CU are independent, so the prologue / epilogue of one overlaps the main loop of the other and
@@ -338,10 +348,14 @@ __device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, fl
 // most 2 x CUs images, where a CU holds ONE workgroup and the kernel is the latency chain of one wave: 18 stages x 32 dependent MFMAs behind
 // 16 fragment reads each - 17 us per 128-channel 3x3 launch at B = 32 ... 256 whatever the batch): 2 images x 4 quarters of 32 channels,
 // half the MFMAs and 12 instead of 16 fragment reads per wave and stage.
-template <int KS, int NWV = 4>
+// SIBM (round 5, the small-batch forms of ig_conv8d_kernel's): 1 = a sibling 1x1 convolution of the same input (fprop) runs first on the staged
+// images (centre tap, KP / 64 stages of its own weights) and leaves through the same epilogue into its own tensor; 2 = (dgrad) the sibling's output
+// gradient x2 is staged first, multiplied with the sibling's transposed filter, then the 3x3's images replace it and the accumulators go on.
+template <int KS, int NWV = 4, int SIBM = 0>
 __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats,
-                                                        const bf16_t* addend) {
+                                                        const bf16_t* addend, const IgSibling sib) {
+  static_assert(SIBM == 0 || KS == 3, "the sibling product is the centre tap of a 3x3 staging");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -364,20 +378,24 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   const int T = RS * CC;
   typedef __attribute__((address_space(3))) char lds_char_t;
   typedef const __attribute__((address_space(1))) char glb_char_t;
-  auto stage_dma = [&](int t, int slot) {
+  // stage g of the launch: the sibling's KP / 64 centre-tap stages first (SIBM), then the T stages of this convolution; slot = g & 1
+  const int CS = SIBM ? CC : 0;
+  auto stage_dma = [&](int g) {
+    const bf16_t* wimg = (SIBM && g < CS) ? sib.wp : wp;
+    const int t = (SIBM && g < CS) ? g : g - CS;
     const int rs1 = t / CC, cc1 = t - rs1 * CC;
-    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
+    const bf16_t* base = wimg + (int64_t)rs1 * IG_M * KP + cc1 * KW;
 #pragma unroll
     for (int i = 0; i < LPT; i++) {
       const int piece = wid * LPT + i;
       const int p = piece * 64 + lane;
       const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * IG_WTILE + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + (g & 1) * IG_WTILE + piece * 1024), 16, 0, 0);
     }
   };
-  stage_dma(0, 0);
+  stage_dma(0);
   if (tid * 16 < RB) *reinterpret_cast<uint4*>(Xl + ZOFF + tid * 16) = make_uint4(0, 0, 0, 0);
-  {
+  auto load_images = [&](const bf16_t* __restrict__ x) {
     const int ncgp = KP >> 3;
     for (int e = tid; e < NW * 8 * ncgp; e += NT) {
       const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
@@ -402,7 +420,8 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
         *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ x_swz(h + 1, p + 1, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
-  }
+  };
+  load_images(SIBM == 2 ? sib.x2 : x);
 
   f4v acc[NTI][4];
 #pragma unroll
@@ -432,41 +451,10 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   __builtin_amdgcn_s_barrier();
 
   bf8v fa0[NTI], fb0[4], fa1[NTI], fb1[4];
-  int t = 0;
-#pragma unroll
-  for (int rs = 0; rs < RS; rs++) {
-    for (int cc = 0; cc < CC; cc++, t++) {
-      const char* wl = Wl + (t & 1) * IG_WTILE + a_row;
-      if (t + 1 < T) stage_dma(t + 1, (t + 1) & 1);
-      const int u = ((cc * (KW >> 3)) & cmask) << 4;
-#pragma unroll
-      for (int i = 0; i < NTI; i++) {
-        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
-        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u)));
-        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u ^ (4 << 4))));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < NTI; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NTI; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  }
-
-  const int n = n0 + wc;
-  if (n < N) {
+  // epilogue: + bias, round, [+ addend], store, statistics of the rounded values
+  auto epilogue = [&](bf16_t* __restrict__ y, const bf16_t* __restrict__ bias, float* __restrict__ stats, const bf16_t* addend) {
+    const int n = n0 + wc;
+    if (n >= N) return;
     bf16_t* yp = y + (int64_t)n * CO * 64;
     const int q = lane >> 4;
     const int qrow = (q == 1 || q == 2) ? 1 : 0, qw = (q >= 2) ? 4 : 0;
@@ -497,7 +485,83 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
         if (q == 0 && co < CO) { float* sp = stats + ((int64_t)co * N + n) * 3; /* [channel][image][3] */ sp[0] = wn; sp[1] = wm; sp[2] = w2; }
       }
     }
+  };
+  if constexpr (SIBM != 0) {
+    // ---- the sibling's product: KP / 64 stages of the centre tap
+    for (int cc = 0; cc < CC; cc++) {
+      const char* wl = Wl + (cc & 1) * IG_WTILE + a_row;
+      stage_dma(cc + 1);                               // (the stage behind the sibling's last one is this convolution's first)
+      const int u = ((cc * (KW >> 3)) & cmask) << 4;
+#pragma unroll
+      for (int i = 0; i < NTI; i++) {
+        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
+        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[RS / 2][j] ^ u)));
+        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[RS / 2][j] ^ u ^ (4 << 4))));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NTI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NTI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (SIBM == 1) {
+      epilogue(sib.y, sib.bias, sib.stats, nullptr);
+#pragma unroll
+      for (int i = 0; i < NTI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    } else {
+      load_images(x);                                  // (every wave is past its last read of the sibling's images)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
+  int t = 0;
+#pragma unroll
+  for (int rs = 0; rs < RS; rs++) {
+    for (int cc = 0; cc < CC; cc++, t++) {
+      const char* wl = Wl + ((CS + t) & 1) * IG_WTILE + a_row;
+      if (t + 1 < T) stage_dma(CS + t + 1);
+      const int u = ((cc * (KW >> 3)) & cmask) << 4;
+#pragma unroll
+      for (int i = 0; i < NTI; i++) {
+        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
+        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u)));
+        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[rs][j] ^ u ^ (4 << 4))));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NTI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NTI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  epilogue(y, bias, stats, addend);
 }
 
 // Variant for at most 64 output channels (every igemm layer of the CIFAR ResNet): as ig_conv8b_kernel, but
@@ -505,10 +569,12 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
 //  * FOUR weight slots, stages requested three ahead behind a counted vmcnt (variant b has one stage in flight and pays an L2 round
 //    trip per stage);
 //  * 16 + 0.1 + 32 KiB of LDS: three workgroups fit a CU.
-template <int KS>
+// SIBM = 2 (dgrad): a sibling's output gradient as a first set of images, as in ig_conv8b_kernel.
+template <int KS, int SIBM = 0>
 __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats,
-                                                        const bf16_t* addend) {
+                                                        const bf16_t* addend, const IgSibling sib) {
+  static_assert(SIBM == 0 || (SIBM == 2 && KS == 3), "second-source input gradients of a 3x3 only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -531,22 +597,26 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
   const int T = RS * CC;
   typedef __attribute__((address_space(3))) char lds_char_t;
   typedef const __attribute__((address_space(1))) char glb_char_t;
-  auto stage_dma = [&](int t, int slot) {
+  // stage g of the launch: the sibling's KP / 64 centre-tap stages first (SIBM), then the T stages of this convolution; slot = g & 3
+  const int CS = SIBM ? CC : 0, TT = CS + T;
+  auto stage_dma = [&](int g) {
+    const bf16_t* wimg = (SIBM && g < CS) ? sib.wp : wp;
+    const int t = (SIBM && g < CS) ? g : g - CS;
     const int rs1 = t / CC, cc1 = t - rs1 * CC;
-    const bf16_t* base = wp + (int64_t)rs1 * IG_M * KP + cc1 * KW;
+    const bf16_t* base = wimg + (int64_t)rs1 * IG_M * KP + cc1 * KW;
 #pragma unroll
     for (int i = 0; i < LPT; i++) {
       const int piece = wid * LPT + i;
       const int p = piece * 64 + lane;
       const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + slot * WT + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + (g & 3) * WT + piece * 1024), 16, 0, 0);
     }
   };
-  stage_dma(0, 0);
-  if (1 < T) stage_dma(1, 1);
-  if (2 < T) stage_dma(2, 2);
+  stage_dma(0);
+  if (1 < TT) stage_dma(1);
+  if (2 < TT) stage_dma(2);
   if (tid * 16 < RB) *reinterpret_cast<uint4*>(Xl + ZOFF + tid * 16) = make_uint4(0, 0, 0, 0);
-  {
+  auto load_images = [&](const bf16_t* __restrict__ x) {
     const int ncgp = KP >> 3;
     for (int e = tid; e < NW * 8 * ncgp; e += NT) {
       const int cg = e % ncgp, h = (e / ncgp) & 7, img = e / (ncgp * 8);
@@ -571,7 +641,8 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
         *reinterpret_cast<uint4*>(xi + (h * 8 + p) * RB + ((cg ^ x_swz(h + 1, p + 1, cmask)) << 4)) = make_uint4(d[0], d[1], d[2], d[3]);
       }
     }
-  }
+  };
+  load_images(SIBM == 2 ? sib.x2 : x);
 
   f4v acc[2][4];
 #pragma unroll
@@ -601,12 +672,49 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
   __builtin_amdgcn_s_barrier();
 
   bf8v fa0[2], fb0[4], fa1[2], fb1[4];
+  if constexpr (SIBM == 2) {
+    // ---- the sibling's product (centre tap), then this convolution's images take the place of the sibling's
+    for (int g = 0; g < CS; g++) {
+      const char* wl = Wl + (g & 3) * WT + a_row;
+      if (g + 3 < TT) stage_dma(g + 3);
+      const int u = ((g * (KW >> 3)) & cmask) << 4;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        fa0[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch0));
+        fa1[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 16 * 128 + a_ch1));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        fb0[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[RS / 2][j] ^ u)));
+        fb1[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(Xl + (pre[RS / 2][j] ^ u ^ (4 << 4))));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (g + 3 < TT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (g + 2 < TT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    load_images(x);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   int t = 0;
 #pragma unroll
   for (int rs = 0; rs < RS; rs++) {
     for (int cc = 0; cc < CC; cc++, t++) {
-      const char* wl = Wl + (t & 3) * WT + a_row;
-      if (t + 3 < T) stage_dma(t + 3, (t + 3) & 3);
+      const int g = CS + t;
+      const char* wl = Wl + (g & 3) * WT + a_row;
+      if (g + 3 < TT) stage_dma(g + 3);
       const int u = ((cc * (KW >> 3)) & cmask) << 4;
 #pragma unroll
       for (int i = 0; i < 2; i++) {
@@ -629,9 +737,9 @@ __global__ __launch_bounds__(256) void ig_conv8c_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      // stage t + 1 must have landed; stages t + 2 and t + 3 (LPT loads each) may stay in flight
-      if (t + 3 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      // stage g + 1 must have landed; stages g + 2 and g + 3 (LPT loads each) may stay in flight
+      if (g + 3 < TT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (g + 2 < TT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -754,16 +862,6 @@ __device__ __forceinline__ void ig8d_tile_stats(const uint2 (&pk)[4], float& mea
     const float d = mb - ma; mean = ma + d * 0.5f; m2 = qa + qb + d * d * 16.f;
   }
 }
-
-// The SIBLING of a 3x3 convolution (SIB instantiations): a 1x1 convolution of the SAME input with as many output channels - the shortcut of
-// lamp's residual block, whose two branches both start with a Conv2D on the block's input (cnn.scala:16-20, 38-78).  Its product is a second,
-// 1/9-length main loop over the images that are already in LDS (centre tap only), run BEFORE the 3x3 product because the 3x3 epilogue
-// overwrites the images; it saves the 1x1 launch with its own image burst (33.5 MB for res4), prologue and ramp.
-// SIBM = 2 (round 5, dgrad): a SECOND SOURCE instead - the output gradient x2 of that 1x1 sibling, whose input gradient is the other contribution
-// to the block's input gradient (autograd.scala:66-84 accumulates the two).  Its product (centre tap, the sibling's transposed filter) runs first
-// on its own images, then the 3x3's images replace them in LDS and the 3x3 product continues in the SAME accumulators: one rounding, one
-// epilogue, and neither the 1x1's 33.5 MB result nor its re-read as the addend.
-struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; const bf16_t* x2; };
 
 template <int KS, int NCT, int SIBM>
 __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
@@ -1733,15 +1831,47 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       // the two-image kernels add the second contribution of a residual block's input gradient in their stores too (B <= 512: two add launches less)
       const bf16_t* addbc = (addend && dgrad) ? addend->ptr<bf16_t>() : (const bf16_t*)nullptr;
       if (addend_fused) *addend_fused = addbc != nullptr;
-      if (CO <= 64 && !(variant && variant[0] == 'b')) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
+      // ... and take the sibling 1x1 of a block's first 3x3 (fprop, the 128-row kernel) or its output gradient as a second source (dgrad) too
+      IgSibling sibb{nullptr, nullptr, nullptr, nullptr, nullptr};
+      Hold sibb_wpk, sibb_statt;
+      const bool same_shape2 = second && second->g->kh == 1 && second->g->Cout == g.Cout && second->g->Cin == g.Cin && second->g->N == g.N;
+      const bool dg2b = second && dgrad && KS == 3 && same_shape2;
+      const bool kernel_c = CO <= 64 && !(variant && variant[0] == 'b');
+      static const bool sib_on_b = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
+      const bool sibf = sib_on_b && sibling && !dgrad && KS == 3 && !addend && !kernel_c && sibling->g->kh == 1 && sibling->g->Cout == g.Cout &&
+                        sibling->g->Cin == g.Cin && sibling->g->N == g.N;
+      struct PublishSibB { Hold& t; const Tensor* y; int P; ~PublishSibB() { if (t.get()) conv_stats_publish(y, t.get(), P); } }
+          publish_sibb{sibb_statt, sibf ? sibling->out : nullptr, (int)g.N};
+      if (dg2b) {
+        int64_t off1 = 0;
+        sibb_wpk = Hold(packed_weights(second->w, *second->g, 1, st, &off1));
+        sibb.wp = static_cast<const Tensor*>(sibb_wpk.get())->ptr<bf16_t>() + off1;
+        sibb.x2 = second->dy->ptr<bf16_t>();
+        if (second_fused) *second_fused = true;
+      } else if (sibf) {
+        int64_t off1 = 0;
+        sibb_wpk = Hold(packed_weights(sibling->w, *sibling->g, 1, st, &off1));
+        sibb.wp = static_cast<const Tensor*>(sibb_wpk.get())->ptr<bf16_t>();
+        sibb.bias = sibling->bias ? sibling->bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
+        sibb.y = sibling->out->ptr<bf16_t>();
+        if (statp) {
+          int64_t ps[1] = {(int64_t)g.N * CO * 3};
+          sibb_statt = Hold(new_tensor(ps, 1, kF32, in->device()));
+          sibb.stats = sibb_statt->ptr<float>();
+        }
+        if (sibling_fused) *sibling_fused = true;
+      }
+      if (kernel_c) {   // 64-row weight stages, four-slot ring (LAMP_IG_VARIANT=b: the 128-row kernel)
         const size_t ldsc = (size_t)2 * 64 * KP * 2 + KP * 2 + 4 * (64 * 64 * 2);
-        static bool c3 = false, c1 = false;
-        if (KS == 3) {
+        if (dg2b) {
+          allow_big_lds((const void*)ig_conv8c_kernel<3, 2>);
+          hipLaunchKernelGGL((ig_conv8c_kernel<3, 2>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);
+        } else if (KS == 3) {
           allow_big_lds((const void*)ig_conv8c_kernel<3>);
-          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc);
+          hipLaunchKernelGGL((ig_conv8c_kernel<3>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);
         } else {
           allow_big_lds((const void*)ig_conv8c_kernel<1>);
-          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc);
+          hipLaunchKernelGGL((ig_conv8c_kernel<1>), dim3(blocksb), dim3(256), ldsc, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);
         }
         LAMP_LAUNCH_CHECK();
         return;
@@ -1750,14 +1880,16 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       // at most one workgroup per CU (small batches): eight waves per image pair (LAMP_IG_W8=0: always four)
       static const bool w8_on = [] { const char* e = getenv("LAMP_IG_W8"); return !(e && e[0] == '0'); }();
       const bool w8 = w8_on && blocksb <= num_cus();
-#define IG_LAUNCH_B(KS_, NWV_)                                                                                                                  \
+#define IG_LAUNCH_B(KS_, NWV_, SIBM_)                                                                                                           \
   do {                                                                                                                                          \
-    allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_>);                                                                                   \
-    hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_>), dim3(blocksb), dim3(NWV_ * 64), ldsb, st, in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), \
-                       (int)g.N, CI, KP, CO, statp, addbc);                                                                                          \
+    allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_, SIBM_>);                                                                            \
+    hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_, SIBM_>), dim3(blocksb), dim3(NWV_ * 64), ldsb, st, in->ptr<bf16_t>(), wpp, bpb,             \
+                       out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);                                                            \
   } while (0)
-      if (KS == 3) { if (w8) IG_LAUNCH_B(3, 8); else IG_LAUNCH_B(3, 4); }
-      else { if (w8) IG_LAUNCH_B(1, 8); else IG_LAUNCH_B(1, 4); }
+      if (dg2b) { if (w8) IG_LAUNCH_B(3, 8, 2); else IG_LAUNCH_B(3, 4, 2); }
+      else if (sibf) { if (w8) IG_LAUNCH_B(3, 8, 1); else IG_LAUNCH_B(3, 4, 1); }
+      else if (KS == 3) { if (w8) IG_LAUNCH_B(3, 8, 0); else IG_LAUNCH_B(3, 4, 0); }
+      else { if (w8) IG_LAUNCH_B(1, 8, 0); else IG_LAUNCH_B(1, 4, 0); }
 #undef IG_LAUNCH_B
       LAMP_LAUNCH_CHECK();
       return;
@@ -1793,12 +1925,9 @@ bool igemm_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g,
   static const bool on = [] { const char* e = getenv("LAMP_CONV_DGRAD_PAIR"); return !(e && e[0] == '0'); }();
   if (!on || !ig_qualifies(g, dy->dtype) || !ig_qualifies(g1, dy1->dtype) || g.kh != 3 || g1.kh != 1) return false;
   if (g.Cout != g1.Cout || g.Cin != g1.Cin || g.N != g1.N) return false;
-  // the eight-image kernel's conditions for a dgrad (run_conv8): its output channels are the convolution's input channels
+  // every kernel of run_conv8's default variant takes a second source (eight images per workgroup at large batches, two below)
   const char* variant = getenv("LAMP_IG_VARIANT");
-  if (variant && (variant[0] == 'a' || variant[0] == 'b')) return false;
-  static const bool small_d = [] { const char* e = getenv("LAMP_IG_SMALL_D"); return !(e && e[0] == '0'); }();
-  const bool force_d = variant && variant[0] == 'd';
-  if (!((g.Cin > 64 || small_d) && (force_d || g.N >= 4 * (int64_t)num_cus()))) return false;
+  if (variant && variant[0] == 'a') return false;
   const SecondGradConv sg{dy1, w1, &g1};
   bool fused = false;
   run_conv8(dy, w, nullptr, dx, g, true, st, addend, addend_fused, nullptr, nullptr, nullptr, nullptr, &sg, &fused);
@@ -1819,7 +1948,10 @@ bool igemm_conv_fwd_pair(const Tensor* x, const Tensor* w, const Tensor* bias, T
                          Tensor* y1, const ConvGeom& g1, hipStream_t st) {
   if (!ig_qualifies(g, x->dtype) || !ig_qualifies(g1, x->dtype) || g.kh != 3 || g1.kh != 1) return false;
   if (g.Cout != g1.Cout || g.Cin != g1.Cin || g.N != g1.N) return false;
-  if (!ig_fwd_folds_affine(g, x->dtype)) return false;                 // (= the eight-image kernel's conditions)
+  // the eight-image kernel (its conditions), or - small batches - the two-image kernel with 128-row weight stages (more than 64 output channels)
+  const char* variant = getenv("LAMP_IG_VARIANT");
+  if (variant && variant[0] == 'a') return false;
+  if (!ig_fwd_folds_affine(g, x->dtype) && !(g.Cout > 64 || (variant && variant[0] == 'b'))) return false;
   static const bool sib_on = [] { const char* e = getenv("LAMP_CONV_SIBLING"); return !(e && e[0] == '0'); }();
   if (!sib_on) return false;
   const SiblingConv sc{w1, bias1, y1, &g1};

@@ -1161,7 +1161,10 @@ DGRAD_PAIR_CASES = [
     (1027, 100, 8, 128, 128, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),    # ragged last workgroup, 7 channel tiles, a third contribution
     (1024, 16, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),    # res3: 16 input channels (one tile)
     (1024, 64, 8, 64, 64, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),       # two 32-channel chunks, 4 tiles
-    (64, 128, 8, 100, 100, 1, torch.bfloat16, True, False),      # small batch: the chain of two launches, bitwise
+    (64, 128, 8, 100, 100, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),     # small batch: the two-image kernel (eight waves) takes the second source too
+    (600, 128, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),   # ... with four waves
+    (33, 16, 8, 128, 128, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),      # ... the 64-row kernel (16 gradient channels out), ragged
+    (64, 64, 8, 64, 64, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),
     (8, 5, 12, 7, 4, 1, torch.float32, False, False),
     (4, 6, 10, 4, 4, 2, torch.float64, True, False),
 ]
@@ -1445,6 +1448,7 @@ def test_batch_norm_takes_its_statistics_from_the_narrow_convolution(gpu, cin, c
 
 @pytest.mark.parametrize("cin,cout,N,H,stride", [(128, 100, 1024, 8, 1), (16, 128, 1024, 8, 1), (128, 128, 1032, 8, 1), (100, 100, 1024, 8, 1),
                                                  (64, 64, 1024, 8, 1), (16, 16, 1027, 8, 1), (128, 100, 64, 8, 1), (6, 6, 64, 8, 1),
+                                                 (16, 128, 33, 8, 1), (128, 128, 600, 8, 1), (64, 64, 64, 8, 1),
                                                  (6, 6, 67, 32, 2), (3, 8, 16, 32, 2), (6, 5, 9, 32, 1), (6, 16, 33, 16, 2)])
 def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, N, H, stride):
     """lamp_convolution_pair(x, 3x3, 1x1) - the two branches of lamp's residual block start with a Conv2D on the same input (cnn.scala:16-20,
@@ -1474,7 +1478,8 @@ def test_convolution_pair_is_the_two_convolutions_in_one_launch(gpu, cin, cout, 
     assert torch.equal(to_torch(pa), to_torch(ya)), "3x3 output of the pair differs from the single convolution"
     assert torch.equal(to_torch(pb), to_torch(yb)), "1x1 output of the pair differs from the single convolution"
     launches = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if ln.strip()}       # "tag count total_ms flops bytes"
-    fused = (H == 8 and N >= 1024 and cin >= 8) or (H == 32 and 2 * cout <= 16)       # the eight-image kernel / the narrow kernel's spare columns
+    # the eight-image kernel / (round 5) the two-image kernel with 128-row weight stages at small batches / the narrow kernel's spare columns
+    fused = (H == 8 and cin >= 8 and (N >= 1024 or cout > 64)) or (H == 32 and 2 * cout <= 16)
     assert sum(n for t, n in launches.items() if t.startswith("conv_")) == (1 if fused else 2), (fused, launches)
     # against the oracle (ATen f32 on the same bf16 values)
     ra = aten.convolution(x.float(), wa.float(), ba.float(), [stride, stride], [1, 1], [1, 1], False, [0, 0], 1)

@@ -214,7 +214,7 @@ def test_paired_input_gradients_and_epilogue_statistics_stay_within_bf16_roundin
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
     for flag in ("0", "1"):
-        env = dict(os.environ, LAMP_CONV_DGRAD_PAIR=flag, LAMP_NCV_BN_STATS=flag, PYTHONPATH=root)
+        env = dict(os.environ, LAMP_CONV_DGRAD_PAIR=flag, LAMP_NCV_BN_STATS=flag, LAMP_CONV_WGRAD_PAIR=flag, PYTHONPATH=root)
         f = str(tmp_path / f"step{flag}.npz")
         out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, str(batch), f], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -228,5 +228,6 @@ def test_paired_input_gradients_and_epilogue_statistics_stay_within_bf16_roundin
         u, v = a[k].astype(np.float64).ravel(), b[k].astype(np.float64).ravel()
         rel = np.linalg.norm(u - v) / max(np.linalg.norm(u), 1e-30)
         worst = max(worst, rel)
-        assert rel <= 3e-2, f"{k}: relative L2 difference {rel:.3e}"
+        # (a convolution bias in front of a batch norm has no gradient but rounding noise - norm ~5e-3 against 2e-2 .. 5e-1 elsewhere: absolute bound)
+        assert rel <= 3e-2 or np.linalg.norm(u - v) <= 5e-4, f"{k}: relative L2 difference {rel:.3e}, absolute {np.linalg.norm(u - v):.3e}"
     assert worst > 0.0 or batch < 0, "the two runs are bitwise equal: the fusions did not run"
