@@ -1327,9 +1327,10 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
     // costs: the ResNet step's six small layers were 4 us SLOWER in total with it, the six large ones 50 us faster.
     // The dual form replaces FOUR kernels (two reductions, two applies) and two passes more: taken at every size.
     static const int np_mask = [] { const char* e = getenv("LAMP_BN_FUSED_NP_MASK"); return e ? atoi(e) : 24; }();
-    // Activations under 4 MiB (the B <= 256 steps): both kernels of the two-pass form sit at the launch floor there, and one launch with an
-    // exchange beats two (A/B: B = 256 0.5433 -> 0.5359 ms per step, B = 32 0.4671 -> 0.4545); at 4 - 6 MB (B = 2048's small maps) it is even.
-    static const int64_t small_bytes = [] { const char* e = getenv("LAMP_BN_FUSED_SMALL_BYTES"); return e ? (int64_t)atoll(e) : (int64_t)4 << 20; }();
+    // Activations of at most 4 MiB (the B <= 256 steps): both kernels of the two-pass form sit at the launch floor there, and one launch with an
+    // exchange beats two (A/B: B = 256 0.5433 -> 0.5359 ms per step, B = 32 0.4671 -> 0.4545; the 4 MiB layer itself 0.5137 -> 0.5115); above
+    // (B = 2048's small maps, 4 - 8 MB) it is even.
+    static const int64_t small_bytes = [] { const char* e = getenv("LAMP_BN_FUSED_SMALL_BYTES"); return e ? (int64_t)atoll(e) : ((int64_t)4 << 20) + 1; }();
     if (!dualh && !(np_mask & NP) && !(xc->numel() * 2 < small_bytes)) continue;
 #define BN_FUSED_K(NPv) (dualh ? (const void*)bn_bwd_fused_kernel<NPv, true, true, true> : addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> \
                                : relu ? (const void*)bn_bwd_fused_kernel<NPv, true, false> : (const void*)bn_bwd_fused_kernel<NPv, false, false>)
