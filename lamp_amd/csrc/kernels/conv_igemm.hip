@@ -351,7 +351,9 @@ struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats
 // SIBM (round 5, the small-batch forms of ig_conv8d_kernel's): 1 = a sibling 1x1 convolution of the same input (fprop) runs first on the staged
 // images (centre tap, KP / 64 stages of its own weights) and leaves through the same epilogue into its own tensor; 2 = (dgrad) the sibling's output
 // gradient x2 is staged first, multiplied with the sibling's transposed filter, then the 3x3's images replace it and the accumulators go on.
-template <int KS, int NWV = 4, int SIBM = 0>
+// NW = 1 (round 5, batches of at most one image per CU): ONE image per workgroup, eight waves x 16 output channels - at B <= 256 the two-image
+// form fills half the CUs or fewer, and a stage of it is bound by its 96 fragment reads (768 LDS cycles against 512 matrix cycles).
+template <int KS, int NWV = 4, int SIBM = 0, int NW = 2>
 __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const bf16_t* __restrict__ bias,
                                                         bf16_t* __restrict__ y, int N, int CI, int KP, int CO, float* __restrict__ stats,
                                                         const bf16_t* addend, const IgSibling sib) {
@@ -359,8 +361,9 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
-  constexpr int NW = 2, NT = NWV * 64, LPT = 16 / NWV;      // 16 one-KiB pieces per weight stage, LPT per wave
-  constexpr int NTI = 16 / NWV;                              // output-channel tiles of 16 per wave: 4 (64 channels) or 2 (32)
+  constexpr int NT = NWV * 64, LPT = 16 / NWV;              // 16 one-KiB pieces per weight stage, LPT per wave
+  constexpr int NTI = 8 * NW / NWV;                          // output-channel tiles of 16 per wave: 4 (64 channels), 2 (32) or 1
+  static_assert(NW == 2 || (NW == 1 && NWV == 8), "one image per workgroup: eight waves");
   const int RB = KP * 2;
   const int XIMG = 64 * RB;                 // 8x8 pixels, no halo
   char* Xl = smem;                          // [2][64][KP] + one zero pixel
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   char* Wl = smem + NW * XIMG + RB;         // 2 x IG_WTILE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = NW == 2 ? wid >> 1 : wid, wc = NW == 2 ? wid & 1 : 0;
   const int n0 = blockIdx.x * NW;
   const int cmask = (KP >> 3) - 1;
 
@@ -1876,20 +1879,23 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
         LAMP_LAUNCH_CHECK();
         return;
       }
-      const size_t ldsb = (size_t)2 * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
-      // at most one workgroup per CU (small batches): eight waves per image pair (LAMP_IG_W8=0: always four)
+      // at most one workgroup per CU (small batches): eight waves per image pair (LAMP_IG_W8=0: always four); at most one IMAGE per CU: one
+      // image per workgroup (LAMP_IG_ONE_IMAGE=0: pairs)
       static const bool w8_on = [] { const char* e = getenv("LAMP_IG_W8"); return !(e && e[0] == '0'); }();
+      static const bool one_on = [] { const char* e = getenv("LAMP_IG_ONE_IMAGE"); return !(e && e[0] == '0'); }();
       const bool w8 = w8_on && blocksb <= num_cus();
-#define IG_LAUNCH_B(KS_, NWV_, SIBM_)                                                                                                           \
+      const bool one = one_on && w8 && g.N <= num_cus();
+      const size_t ldsb = (size_t)(one ? 1 : 2) * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
+#define IG_LAUNCH_B(KS_, NWV_, SIBM_, NW_)                                                                                                      \
   do {                                                                                                                                          \
-    allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_, SIBM_>);                                                                            \
-    hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_, SIBM_>), dim3(blocksb), dim3(NWV_ * 64), ldsb, st, in->ptr<bf16_t>(), wpp, bpb,             \
-                       out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);                                                            \
+    allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_, SIBM_, NW_>);                                                                       \
+    hipLaunchKernelGGL((ig_conv8b_kernel<KS_, NWV_, SIBM_, NW_>), dim3(NW_ == 1 ? (int)g.N : blocksb), dim3(NWV_ * 64), ldsb, st,               \
+                       in->ptr<bf16_t>(), wpp, bpb, out->ptr<bf16_t>(), (int)g.N, CI, KP, CO, statp, addbc, sibb);                               \
   } while (0)
-      if (dg2b) { if (w8) IG_LAUNCH_B(3, 8, 2); else IG_LAUNCH_B(3, 4, 2); }
-      else if (sibf) { if (w8) IG_LAUNCH_B(3, 8, 1); else IG_LAUNCH_B(3, 4, 1); }
-      else if (KS == 3) { if (w8) IG_LAUNCH_B(3, 8, 0); else IG_LAUNCH_B(3, 4, 0); }
-      else { if (w8) IG_LAUNCH_B(1, 8, 0); else IG_LAUNCH_B(1, 4, 0); }
+      if (dg2b) { if (one) IG_LAUNCH_B(3, 8, 2, 1); else if (w8) IG_LAUNCH_B(3, 8, 2, 2); else IG_LAUNCH_B(3, 4, 2, 2); }
+      else if (sibf) { if (one) IG_LAUNCH_B(3, 8, 1, 1); else if (w8) IG_LAUNCH_B(3, 8, 1, 2); else IG_LAUNCH_B(3, 4, 1, 2); }
+      else if (KS == 3) { if (one) IG_LAUNCH_B(3, 8, 0, 1); else if (w8) IG_LAUNCH_B(3, 8, 0, 2); else IG_LAUNCH_B(3, 4, 0, 2); }
+      else { if (one) IG_LAUNCH_B(1, 8, 0, 1); else if (w8) IG_LAUNCH_B(1, 8, 0, 2); else IG_LAUNCH_B(1, 4, 0, 2); }
 #undef IG_LAUNCH_B
       LAMP_LAUNCH_CHECK();
       return;
