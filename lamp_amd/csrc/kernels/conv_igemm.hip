@@ -1351,10 +1351,9 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
   auto store_x = [&](char* stage, uint4 v, int ct) {
     char* xb = stage + IG_WTILE + (ct * WG_CI + xci) * WG_XCH + (xh + 1) * 16;
     if (KS == 1) { *reinterpret_cast<uint4*>(xb) = v; return; }
-    // copy s holds out[w] = in[w + s - 1]
-    *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
+    // (round 5: only the unshifted copy is stored; the fragments of the filter columns s = 0 / 2, out[w] = in[w -/+ 1], are cut from it in
+    // registers after the read - 4 + 3 instead of 4 + 9 fragment reads per k-step, one LDS write per packet instead of three)
     *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
-    *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
   };
 
   f4v acc[CIT][RS][4];
@@ -1399,15 +1398,33 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
       for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(st, wr * 64 + i * 16, ks, lane);
       const int h = 4 * ks + (lane >> 4);
 #pragma unroll
-      for (int ct = 0; ct < CIT; ct++)
+      for (int ct = 0; ct < CIT; ct++) {
+        if constexpr (KS == 3) {
+          typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int t = 0; t < RS; t++) {
-          const int r = t / KS, s = t % KS;
-          s8v v = *reinterpret_cast<const s8v*>(xl + ct * WG_CI * WG_XCH + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
-          const bf8v fb = __builtin_bit_cast(bf8v, v);
+          for (int r = 0; r < KS; r++) {
+            const u4v_ xc = *reinterpret_cast<const u4v_*>(xl + ct * WG_CI * WG_XCH + WG_XCOPY + (h + r + (1 - PAD)) * 16);
 #pragma unroll
-          for (int i = 0; i < 4; i++) acc[ct][t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][t][i], 0, 0, 0);
+            for (int s_ = 0; s_ < KS; s_++) {
+              const u4v_ sh = s_ == 0 ? u4v_{xc[0] << 16, (xc[1] << 16) | (xc[0] >> 16), (xc[2] << 16) | (xc[1] >> 16), (xc[3] << 16) | (xc[2] >> 16)}
+                            : s_ == 1 ? xc
+                                      : u4v_{(xc[0] >> 16) | (xc[1] << 16), (xc[1] >> 16) | (xc[2] << 16), (xc[2] >> 16) | (xc[3] << 16), xc[3] >> 16};
+              const bf8v fb = __builtin_bit_cast(bf8v, sh);
+#pragma unroll
+              for (int i = 0; i < 4; i++) acc[ct][r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][r * KS + s_][i], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < RS; t++) {
+            const int r = t / KS, s = t % KS;
+            s8v v = *reinterpret_cast<const s8v*>(xl + ct * WG_CI * WG_XCH + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
+            const bf8v fb = __builtin_bit_cast(bf8v, v);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[ct][t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][t][i], 0, 0, 0);
+          }
         }
+      }
     }
     if (n + 1 < nend) {
       char* nx = smem + (cur ^ 1) * STAGE;
@@ -1448,7 +1465,10 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // sum_k dY[k] X[k + 8 (r - 1)] = sum_k dY[k - 8 (r - 1)] X[k].  So a k-step reads 3 row-shifted dY fragments per channel tile (rows that fall
 // outside the image are zeroed in registers) and 3 column-shifted X fragments, 6 + 3 = 9 fragment reads for its 18 MFMAs instead of 2 + 9 = 11:
 // the kernel is bound by its LDS fragment reads (176 KB per image and CU against 1152 matrix cycles).
-template <bool SHIFT_DY>
+// SHIFT_DY = 2 (round 5): ... and the two column-shifted X fragments are cut from the centre one in registers (the shifts store_x used to write as
+// two more LDS copies: out[w] = in[w -/+ 1] with a zero at the border, four shift / or pairs each): 6 + 1 = 7 fragment reads for the 18 MFMAs of a
+// k-step instead of 9 - the LDS array falls from the matrix pipe's 1152 cycles per image to 896 - and one LDS write per X packet instead of three.
+template <int SHIFT_DY>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
                                                          int stream_out) {
@@ -1485,8 +1505,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
     // Images beyond nend arrive as zeros and leave as relu(bn(0)): their dY is zero, so they add nothing
     if (affine) v = ig_bn_relu_x8(v, aff.x, aff.y, aff.z);
     char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
-    *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
     *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
+    if (SHIFT_DY == 2) return;                               // the shifted fragments are cut from this one after the read
+    *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
     *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
   };
   // dY tile [128 co][64 px]: 1024 16-byte packets, two per thread
@@ -1535,9 +1556,19 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
             fa[r][i] = inside ? __builtin_bit_cast(bf8v, v) : zero8;
           }
         }
+        typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
+        const u4v_ xc = SHIFT_DY == 2 ? *reinterpret_cast<const u4v_*>(xl + WG_XCOPY + (h + 1) * 16) : u4v_{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int s_ = 0; s_ < KS; s_++) {
-          const s8v v = *reinterpret_cast<const s8v*>(xl + s_ * WG_XCOPY + (h + 1) * 16);   // X row h itself (rows sit one slot down: the zero row above the image)
+          s8v v;
+          if (SHIFT_DY == 2) {
+            const u4v_ sh = s_ == 0 ? u4v_{xc[0] << 16, (xc[1] << 16) | (xc[0] >> 16), (xc[2] << 16) | (xc[1] >> 16), (xc[3] << 16) | (xc[2] >> 16)}
+                          : s_ == 1 ? xc
+                                    : u4v_{(xc[0] >> 16) | (xc[1] << 16), (xc[1] >> 16) | (xc[2] << 16), (xc[2] >> 16) | (xc[3] << 16), xc[3] >> 16};
+            v = __builtin_bit_cast(s8v, sh);
+          } else {
+            v = *reinterpret_cast<const s8v*>(xl + s_ * WG_XCOPY + (h + 1) * 16);   // X row h itself (rows sit one slot down: the zero row above the image)
+          }
           const bf8v fb = __builtin_bit_cast(bf8v, v);
 #pragma unroll
           for (int r = 0; r < KS; r++)
@@ -2024,16 +2055,15 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     const size_t lds = 4 * (size_t)WG_STAGE;
     {
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      static const bool shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return !(e && e[0] == '0'); }();
-      if (shift_dy) {
-        allow_big_lds((const void*)ig_wgrad8h_kernel<true>);
-        hipLaunchKernelGGL(ig_wgrad8h_kernel<true>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);
-      } else {
-        allow_big_lds((const void*)ig_wgrad8h_kernel<false>);
-        hipLaunchKernelGGL(ig_wgrad8h_kernel<false>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(), partial->ptr<float>(), (int)g.N,
-                           (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);
-      }
+      static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();   // 0: off, 1: dY rows, 2: + X columns in registers
+#define IG_LAUNCH_WG8H(M_)                                                                                                                  \
+  do {                                                                                                                                      \
+    allow_big_lds((const void*)ig_wgrad8h_kernel<M_>);                                                                                     \
+    hipLaunchKernelGGL(ig_wgrad8h_kernel<M_>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),                \
+                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);   \
+  } while (0)
+      if (shift_dy >= 2) IG_LAUNCH_WG8H(2); else if (shift_dy == 1) IG_LAUNCH_WG8H(1); else IG_LAUNCH_WG8H(0);
+#undef IG_LAUNCH_WG8H
       LAMP_LAUNCH_CHECK();
     }
     const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
