@@ -314,6 +314,7 @@ bool igemm_conv_dgrad_pair(const Tensor* dy, const Tensor* w, const ConvGeom& g,
                            hipStream_t st, const Tensor* addend, bool* addend_fused);
 bool narrow_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st);
 bool narrow_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st);
+bool igemm_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st);
 bool small_conv_fwd(const Tensor* x, const Tensor* w, const Tensor* bias, Tensor* y, const ConvGeom& g, hipStream_t st);
 bool small_conv_dgrad(const Tensor* dy, const Tensor* w, Tensor* dx, const ConvGeom& g, hipStream_t st, const Tensor* addend = nullptr,
                       bool* addend_fused = nullptr);
@@ -639,7 +640,8 @@ int lamp_convolution_backward_weight_pair(lamp_tensor* out2[2], const lamp_tenso
     Hold xc(contiguous(x)), wa(contiguous(w_a)), wb(contiguous(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b));
     hipStream_t st = current_stream(x->device());
     Hold dwa(new_like(wa.get())), dwb(new_like(wb.get()));
-    if (narrow_conv_wgrad_pair(gya.get(), gyb.get(), xc.get(), dwa.get(), dwb.get(), ga, gb, st)) {
+    if (narrow_conv_wgrad_pair(gya.get(), gyb.get(), xc.get(), dwa.get(), dwb.get(), ga, gb, st) ||
+        igemm_conv_wgrad_pair(gya.get(), gyb.get(), xc.get(), dwa.get(), dwb.get(), ga, gb, st)) {
       out2[0] = dwa.take(); out2[1] = dwb.take();
       return 0;
     }

@@ -1468,10 +1468,18 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // SHIFT_DY = 2 (round 5): ... and the two column-shifted X fragments are cut from the centre one in registers (the shifts store_x used to write as
 // two more LDS copies: out[w] = in[w -/+ 1] with a zero at the border, four shift / or pairs each): 6 + 1 = 7 fragment reads for the 18 MFMAs of a
 // k-step instead of 9 - the LDS array falls from the matrix pipe's 1152 cycles per image to 896 - and one LDS write per X packet instead of three.
-template <int SHIFT_DY>
+// PAIR (round 5, with SHIFT_DY = 2): the output gradient dy2 [N][CO2][64] of a sibling 1x1 convolution of the same x is staged beside dY (the LDS the
+// two shifted X copies no longer need holds it: 2 x 16 KiB + 5.5 KiB per image), and its weight gradient [CO2][CI] - the centre-tap product
+// dy2 . x - accumulates in 8 more registers per lane: 2 more fragment reads and 2 more MFMAs per k-step (18 -> 20) instead of a launch of its own
+// that reads x again.  partial2[split][128][CIP].
+template <int SHIFT_DY, bool PAIR = false>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
-                                                         int stream_out) {
+                                                         int stream_out, const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2) {
+  static_assert(!PAIR || SHIFT_DY == 2, "the pair uses the LDS of the shifted X copies");
+  // stage layout: [dY tile | X copies ...] or, PAIR, [dY tile | dY2 tile | X]; XC = offset of the unshifted X copy
+  constexpr int XC = PAIR ? 2 * IG_WTILE : IG_WTILE + WG_XCOPY;
+  constexpr int STG = PAIR ? 2 * IG_WTILE + WG_XCOPY + 512 : WG_STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 3, RS = 9, PAD = 1;
   const int nsplit = gridDim.x / ntile;
@@ -1486,7 +1494,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wid >> 1, wc = wid & 1;                      // 32-channel block of co, 16-channel half of ci
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
-  for (int o = tid * 16; o < 4 * WG_STAGE; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
+  for (int o = tid * 16; o < 4 * STG; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
   __syncthreads();
 
   const bool xthread = tid < 256;
@@ -1504,9 +1512,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
     // the table is applied HERE, a pair after the load was requested (at the load it would wait for the data and undo the prefetch).
     // Images beyond nend arrive as zeros and leave as relu(bn(0)): their dY is zero, so they add nothing
     if (affine) v = ig_bn_relu_x8(v, aff.x, aff.y, aff.z);
+    if (SHIFT_DY == 2) { *reinterpret_cast<uint4*>(stage + XC + xci * WG_XCH + (xh + 1) * 16) = v; return; }   // the shifted fragments are cut from this one after the read
     char* xb = stage + IG_WTILE + xci * WG_XCH + (xh + 1) * 16;
     *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
-    if (SHIFT_DY == 2) return;                               // the shifted fragments are cut from this one after the read
     *reinterpret_cast<uint4*>(xb) = make_uint4(v.x << 16, (v.y << 16) | (v.x >> 16), (v.z << 16) | (v.y >> 16), (v.w << 16) | (v.z >> 16));
     *reinterpret_cast<uint4*>(xb + 2 * WG_XCOPY) = make_uint4((v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), v.w >> 16);
   };
@@ -1523,12 +1531,21 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; i++) { const int c = tid + i * 512; *reinterpret_cast<uint4*>(stage + ig_kc_off(c >> 3, c & 7)) = r[i]; }
   };
+  auto load_dy2 = [&](uint4 (&r)[2], int n) {
+    const bf16_t* base = dy2 + (int64_t)n * CO2 * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + i * 512, gr = c >> 3;
+      r[i] = gr < CO2 ? nt_load16(reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3))) : make_uint4(0, 0, 0, 0);
+    }
+  };
 
   f4v acc[RS][2];
 #pragma unroll
   for (int t = 0; t < RS; t++)
 #pragma unroll
     for (int i = 0; i < 2; i++) acc[t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+  f4v acc2[2] = {f4v{0.f, 0.f, 0.f, 0.f}, f4v{0.f, 0.f, 0.f, 0.f}};      // PAIR: the sibling's [32 co][16 ci] block of this wave
 
   // Image PAIRS: an LDS stage holds two images, and per pair the loop is
   //     LDS-store the NEXT pair (its registers were requested one pair ago)  ->  request the pair after that  ->  multiply THIS pair  ->  barrier
@@ -1538,7 +1555,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // at the same time, so the matrix pipe idled 58 % of the loop.  (The barrier is a raw s_barrier behind lgkmcnt(0): __syncthreads()
   // would drain vmcnt and with it the prefetch.)
   auto compute = [&](const char* st) {
-    const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
+    const char* xl = st + (SHIFT_DY == 2 ? XC - WG_XCOPY : IG_WTILE) + (wc * 16 + (lane & 15)) * WG_XCH;   // (xl + WG_XCOPY = the unshifted copy)
     if (SHIFT_DY) {
       const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
 #pragma unroll
@@ -1558,6 +1575,14 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
         }
         typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
         const u4v_ xc = SHIFT_DY == 2 ? *reinterpret_cast<const u4v_*>(xl + WG_XCOPY + (h + 1) * 16) : u4v_{0u, 0u, 0u, 0u};
+        if constexpr (PAIR) {
+          const bf8v fbc = __builtin_bit_cast(bf8v, xc);
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const s8v v2 = *reinterpret_cast<const s8v*>(st + IG_WTILE + ig_kc_off(wq * 32 + i * 16 + (lane & 15), h));
+            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, v2), fbc, acc2[i], 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int s_ = 0; s_ < KS; s_++) {
           s8v v;
@@ -1596,16 +1621,23 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   };
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
   // images at or beyond nend load as zeros (an odd image count: the missing partner contributes nothing)
+  uint4 rb[PAIR ? 2 : 1][2];                                 // PAIR: the sibling's dY packets of the pair in flight
   auto load_pair = [&](uint4 (&ra_)[2][2], uint4 (&rx_)[2], int n) {
 #pragma unroll
     for (int im = 0; im < 2; im++) {
-      if (n + im < nend) { load_dy(ra_[im], n + im); rx_[im] = load_x(n + im); }
-      else { ra_[im][0] = ra_[im][1] = make_uint4(0, 0, 0, 0); rx_[im] = make_uint4(0, 0, 0, 0); }
+      if (n + im < nend) { load_dy(ra_[im], n + im); rx_[im] = load_x(n + im); if constexpr (PAIR) load_dy2(rb[im], n + im); }
+      else {
+        ra_[im][0] = ra_[im][1] = make_uint4(0, 0, 0, 0); rx_[im] = make_uint4(0, 0, 0, 0);
+        if constexpr (PAIR) rb[im][0] = rb[im][1] = make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto store_pair = [&](const uint4 (&ra_)[2][2], const uint4 (&rx_)[2], char* stage) {
 #pragma unroll
-    for (int im = 0; im < 2; im++) { store_dy(ra_[im], stage + im * WG_STAGE); store_x(stage + im * WG_STAGE, rx_[im]); }
+    for (int im = 0; im < 2; im++) {
+      store_dy(ra_[im], stage + im * STG); store_x(stage + im * STG, rx_[im]);
+      if constexpr (PAIR) store_dy(rb[im], stage + im * STG + IG_WTILE);
+    }
   };
   uint4 ra[2][2], rx[2];
   if (nbeg < nend) {
@@ -1616,12 +1648,23 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   __syncthreads();
   int cur = 0;
   for (int n = nbeg; n < nend; n += 2, cur ^= 1) {
-    char* st = smem + cur * (2 * WG_STAGE);
-    if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * WG_STAGE));      // nobody reads that stage since the last barrier
+    char* st = smem + cur * (2 * STG);
+    if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG));      // nobody reads that stage since the last barrier
     if (n + 4 < nend) load_pair(ra, rx, n + 4);
     compute(st);
-    compute(st + WG_STAGE);
+    compute(st + STG);
     lds_barrier();
+  }
+  if constexpr (PAIR) {
+    // the sibling's block: partial2[split][128][CIP]
+    float* out2 = partial2 + (int64_t)split * IG_M * CIP;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int co = wq * 32 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+        if (co < CO2 && ci < CI) __builtin_nontemporal_store(acc2[i][rr], &out2[co * CIP + ci]);
+      }
   }
   // partial[(split * RS + t)][128][CIP]
 #pragma unroll
@@ -2036,7 +2079,11 @@ static int wgrad_min_ips(int64_t N) {
   static const int v = [] { const char* e = getenv("LAMP_WGRAD_MIN_IPS"); return e ? std::max(2, atoi(e)) : 0; }();
   return v ? v : (N <= 512 ? 2 : 8);
 }
-bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine) {
+// second (optional, the eight-wave kernel only): the output gradient of a sibling 1x1 convolution of the same x and the tensor that receives ITS
+// weight gradient - both from the one launch (igemm_conv_wgrad_pair checks the conditions first)
+struct SecondWgradConv { const Tensor* dy; Tensor* dw; const ConvGeom* g; };
+static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine,
+                                  const SecondWgradConv* second) {
   if (!ig_qualifies(g, x->dtype)) return false;
   const int KS = g.kh, RS = KS * KS;
   static const bool wide_on = [] { const char* e = getenv("LAMP_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
@@ -2052,17 +2099,28 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     const int nsplit = (int)((g.N + ips - 1) / ips);
     int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
-    const size_t lds = 4 * (size_t)WG_STAGE;
+    static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();   // 0: off, 1: dY rows, 2: + X columns in registers
+    const bool pair = second != nullptr;
+    LAMP_CHECK(!pair || shift_dy >= 2, "internal: the weight-gradient pair needs the register-shifted X fragments");
+    Hold partial2;
+    if (pair) { int64_t ps2[1] = {(int64_t)nsplit * IG_M * CIP}; partial2 = Hold(new_tensor(ps2, 1, kF32, x->device())); }
+    const size_t lds = pair ? 4 * (size_t)(2 * IG_WTILE + WG_XCOPY + 512) : 4 * (size_t)WG_STAGE;
     {
-      KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();   // 0: off, 1: dY rows, 2: + X columns in registers
-#define IG_LAUNCH_WG8H(M_)                                                                                                                  \
+      const double sec_fl = pair ? conv_flops(*second->g) : 0.0;
+      const double sec_by = pair ? conv_bytes(*second->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;          // (x is the one already counted)
+      KernelTimer kt("conv_wgrad_igemm", conv_flops(g) + sec_fl, conv_bytes(g, 2) + sec_by, st);
+      const bf16_t* dy2p = pair ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
+      float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
+      const int co2 = pair ? (int)second->g->Cout : 0;
+#define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
   do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_wgrad8h_kernel<M_>);                                                                                     \
-    hipLaunchKernelGGL(ig_wgrad8h_kernel<M_>, dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),                \
-                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0);   \
+    allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_>);                                                                                 \
+    hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),          \
+                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0,    \
+                       dy2p, p2p, co2);                                                                                                     \
   } while (0)
-      if (shift_dy >= 2) IG_LAUNCH_WG8H(2); else if (shift_dy == 1) IG_LAUNCH_WG8H(1); else IG_LAUNCH_WG8H(0);
+      if (pair) IG_LAUNCH_WG8H(2, true);
+      else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
 #undef IG_LAUNCH_WG8H
       LAMP_LAUNCH_CHECK();
     }
@@ -2070,8 +2128,15 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     WgradReduceArgs ra{};
     ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = IG_M; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+    if (pair) {
+      const int64_t cols2 = (int64_t)IG_M * CIP / 4;
+      WgradReduceArgs rb{};
+      rb.kind = 0; rb.CO = (int)second->g->Cout; rb.CI = (int)g.Cin; rb.CIP = CIP; rb.COP = IG_M; rb.RS = 1; rb.nsplit = nsplit; rb.blocks = (int)((cols2 + 31) / 32);
+      wgrad_reduce_enqueue(rb, partial2.get(), second->dw, st);
+    }
     return true;
   }
+  if (second) return false;
   {
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     // 1x1 with more than one slice of Cin: one workgroup owns all of them (CIT = 4), dY is read once
@@ -2108,6 +2173,22 @@ bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvG
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
     return true;
   }
+}
+bool igemm_conv_wgrad(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine) {
+  return igemm_conv_wgrad_impl(dy, x, dw, g, st, affine, nullptr);
+}
+// dw = wgrad3x3(dy, x) and dw1 = wgrad1x1(dy1, x) from one launch of the eight-wave kernel (x staged once; the sibling's output gradient sits in
+// the LDS the shifted X copies no longer need): the values of the two separate launches up to the order the image ranges are summed in for dw1;
+// false = nothing launched
+bool igemm_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x, Tensor* dw, Tensor* dw1, const ConvGeom& g, const ConvGeom& g1, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("LAMP_CONV_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  static const bool wide_on = [] { const char* e = getenv("LAMP_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+  static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();
+  if (!on || !wide_on || shift_dy < 2) return false;
+  if (!ig_qualifies(g, x->dtype) || !ig_qualifies(g1, x->dtype) || g.kh != 3 || g1.kh != 1) return false;
+  if (g.Cin != g1.Cin || g.N != g1.N || !(g.Cin > WG_CI && g.Cout > 64)) return false;      // (the eight-wave kernel's conditions)
+  const SecondWgradConv sw{dy1, dw1, &g1};
+  return igemm_conv_wgrad_impl(dy, x, dw, g, st, nullptr, &sw);
 }
 
 }  // namespace lamp

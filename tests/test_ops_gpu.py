@@ -1234,7 +1234,10 @@ WGRAD_PAIR_CASES = [
     (16, 8, 32, 5, 3, 1, torch.bfloat16, True),
     (33, 3, 32, 8, 8, 2, torch.bfloat16, True),         # all 16 rows of the tile
     (64, 6, 16, 16, 16, 2, torch.bfloat16, False),      # res2: 32 rows do not fit one tile - two launches
-    (64, 128, 8, 128, 128, 1, torch.bfloat16, False),   # implicit-GEMM layers
+    (64, 128, 8, 128, 128, 1, torch.bfloat16, "conv_wgrad_igemm"),     # implicit-GEMM layers with more than 32 input channels: the eight-wave kernel stages the second gradient too
+    (1027, 128, 8, 100, 100, 1, torch.bfloat16, "conv_wgrad_igemm"),   # res4 of Cnn.resnet, ragged
+    (2048, 64, 8, 128, 100, 1, torch.bfloat16, "conv_wgrad_igemm"),    # different output-channel counts
+    (64, 16, 8, 128, 128, 1, torch.bfloat16, False),    # res3: 16 input channels run on the four-wave kernel - two launches
     (8, 5, 12, 7, 4, 1, torch.float32, False),
     (4, 6, 10, 4, 4, 2, torch.float64, False),
 ]
@@ -1245,8 +1248,9 @@ def test_weight_gradients_of_a_block_s_two_first_convolutions(gpu, case):
     """lamp_convolution_backward_weight_pair: dW of the 3x3 and of the 1x1 convolution lamp's residual block applies to its input
     (cnn.scala:16-20).  On the narrow bf16 layers with at most 16 output channels together the two output gradients share the rows of the
     matrix-core tile and x is staged once: the 3x3's gradient BITWISE that of its own launch (same products in the same order), the 1x1's
-    - the centre tap of the extra rows - equal up to the order the image groups are summed in (f32 sums rounded to bf16).  Everything else
-    runs the two lamp_convolution_backward calls inside the entry point, bitwise."""
+    - the centre tap of the extra rows - equal up to the order the image groups are summed in (f32 sums rounded to bf16).  The eight-wave
+    implicit-GEMM kernel (8x8 maps, more than 32 input and 64 output channels) stages the second gradient beside the first and keeps its
+    centre-tap product in eight more registers.  Everything else runs the two lamp_convolution_backward calls inside the entry point, bitwise."""
     N, Cin, H, Ca, Cb, stride, dt, one_launch = case
     x = closed_form((N, Cin, H, H), 3, 2.0, dt)
     wa, wb = closed_form((Ca, Cin, 3, 3), 17, 0.5, dt), closed_form((Cb, Cin, 1, 1), 19, 0.7, dt)
@@ -1271,8 +1275,9 @@ def test_weight_gradients_of_a_block_s_two_first_convolutions(gpu, case):
     assert pa.shape == wa.shape and pb.shape == wb.shape
     assert torch.equal(pa, da), f"3x3: max diff {(pa - da).abs().max().item()}"
     if one_launch:
-        lines = [l for l in rep.splitlines() if l.startswith("conv_wgrad")]
-        assert len(lines) == 1 and lines[0].startswith("conv_wgrad_narrow") and int(lines[0].split()[1]) == 1, rep
+        cls = "conv_wgrad_narrow" if one_launch is True else one_launch
+        lines = [l for l in rep.splitlines() if l.startswith("conv_wgrad") and not l.startswith("conv_wgrad_reduce")]
+        assert len(lines) == 1 and lines[0].startswith(cls) and int(lines[0].split()[1]) == 1, rep
         assert_close(pb, db.double(), 2.0 ** -7, "1x1 against its own launch")
     else:
         assert torch.equal(pb, db), f"1x1: max diff {(pb - db).abs().max().item()}"

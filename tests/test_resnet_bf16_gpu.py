@@ -191,14 +191,15 @@ def test_running_a_block_s_two_first_convolutions_as_one_launch_changes_no_bit(g
     """Residual's rewrite (nn.cpp): both branches of every block of Cnn.resnet start with a Conv2D on the block's input (cnn.scala:38-45,
     64-72); F::convolution_pair runs the 3x3 and the 1x1 of res3 / res4 in one launch of the eight-image kernel (B >= 1024).  Loss, all 37
     gradients and every running statistic of a training step are BITWISE those of the two separate convolutions (LAMP_CONV_SIBLING=0).
-    (Two things that come with the pair are switched off for this comparison because they do change low bits, and are checked with a
-    tolerance below: the narrow pair's batch-norm statistics are summed in another lane order than a single filter's, and the pair's input
-    gradients are summed in f32 and rounded once instead of twice.)"""
+    (Three things that come with the pair are switched off for this comparison because they do change low bits, and are checked with a
+    tolerance below: the narrow pair's batch-norm statistics are summed in another lane order than a single filter's, the pair's input
+    gradients are summed in f32 and rounded once instead of twice, and the shortcut's weight gradient sums its image ranges in the 3x3's
+    partition.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for flag in ("0", "1"):
-        env = dict(os.environ, LAMP_CONV_SIBLING=flag, LAMP_CONV_DGRAD_PAIR="0", LAMP_NCV_BN_STATS="0", PYTHONPATH=root)
+        env = dict(os.environ, LAMP_CONV_SIBLING=flag, LAMP_CONV_DGRAD_PAIR="0", LAMP_CONV_WGRAD_PAIR="0", LAMP_NCV_BN_STATS="0", PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, "1024"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[flag] = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
