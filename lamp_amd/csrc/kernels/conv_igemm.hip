@@ -1317,9 +1317,13 @@ constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies 
 // NARROW: some 16-channel tiles hold only padding and are not written (see tile_active)
 // CIT = 32-channel slices of Cin one workgroup owns.  3x3: 1 (144 accumulator registers for the nine taps of one slice).  1x1: up to 4 -
 // the whole Cin - so that dY is read ONCE instead of once per slice (128 -> 100: 139 -> 60 MB per launch, 33 -> ~15 us).
-template <int KS, bool NARROW, int CIT>
+// PAIR (round 5, 3x3 with one Cin slice per workgroup): the output gradient dy2 [N][CO2][64] of a sibling 1x1 convolution of the same x is staged
+// behind the X copies and its weight gradient (the centre-tap product) accumulates in four more tiles: partial2[split][COP2][CIP].
+template <int KS, bool NARROW, int CIT, bool PAIR = false>
 __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                          int N, int CO, int CI, int CIP, int images_per_split, int COP, int ntile) {
+                                                          int N, int CO, int CI, int CIP, int images_per_split, int COP, int ntile,
+                                                          const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2, int COP2) {
+  static_assert(!PAIR || (KS == 3 && CIT == 1), "the pair rides on the 3x3 kernel with one slice of Cin");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -1334,7 +1338,8 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     else { tile = b % ntile; split = b / ntile; }
   }
   const int ci0 = tile * WG_CI * CIT;
-  constexpr int STAGE = IG_WTILE + (CIT > 1 ? CIT * WG_XCOPY : 3 * WG_XCOPY) + 512;   // dY tile + X copies; host: 2 * this
+  constexpr int STAGE1 = IG_WTILE + (CIT > 1 ? CIT * WG_XCOPY : 3 * WG_XCOPY) + 512;  // dY tile + X copies
+  constexpr int STAGE = STAGE1 + (PAIR ? IG_WTILE : 0);                               // (+ the sibling's dY tile); host: 2 * this
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
@@ -1372,12 +1377,19 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 #pragma unroll
   for (int i = 0; i < 4; i++) tile_active[i] = col_active && (wr * 64 + i * 16 < COP);
 
-  uint4 ra[4], rx[CIT];
+  uint4 ra[4], rx[CIT], rb[PAIR ? 4 : 1];
+  f4v acc2[PAIR ? 4 : 1];
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc2[i] = f4v{0.f, 0.f, 0.f, 0.f};
+  }
   if (nbeg < nend) {
     ig_stage_load_rows(ra, dy + (int64_t)nbeg * CO * 64, 64, 0, CO, 64, tid);
+    if constexpr (PAIR) ig_stage_load_rows(rb, dy2 + (int64_t)nbeg * CO2 * 64, 64, 0, CO2, 64, tid);
 #pragma unroll
     for (int ct = 0; ct < CIT; ct++) rx[ct] = load_x(nbeg, ct);
     ig_stage_store_rows(ra, smem, tid);
+    if constexpr (PAIR) ig_stage_store_rows(rb, smem + STAGE1, tid);
 #pragma unroll
     for (int ct = 0; ct < CIT; ct++) store_x(smem, rx[ct], ct);
   }
@@ -1386,6 +1398,7 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     const int cur = (n - nbeg) & 1;
     if (n + 1 < nend) {
       ig_stage_load_rows(ra, dy + (int64_t)(n + 1) * CO * 64, 64, 0, CO, 64, tid);
+      if constexpr (PAIR) ig_stage_load_rows(rb, dy2 + (int64_t)(n + 1) * CO2 * 64, 64, 0, CO2, 64, tid);
 #pragma unroll
       for (int ct = 0; ct < CIT; ct++) rx[ct] = load_x(n + 1, ct);
     }
@@ -1412,6 +1425,13 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
               const bf8v fb = __builtin_bit_cast(bf8v, sh);
 #pragma unroll
               for (int i = 0; i < 4; i++) acc[ct][r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][r * KS + s_][i], 0, 0, 0);
+              if constexpr (PAIR) {
+                if (r == PAD && s_ == PAD) {                // the centre tap: the sibling's product on the same X fragment
+#pragma unroll
+                  for (int i = 0; i < 4; i++)
+                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ig_frag_rows(st + STAGE1, wr * 64 + i * 16, ks, lane), fb, acc2[i], 0, 0, 0);
+                }
+              }
             }
           }
         } else {
@@ -1429,10 +1449,23 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     if (n + 1 < nend) {
       char* nx = smem + (cur ^ 1) * STAGE;
       ig_stage_store_rows(ra, nx, tid);
+      if constexpr (PAIR) ig_stage_store_rows(rb, nx + STAGE1, tid);
 #pragma unroll
       for (int ct = 0; ct < CIT; ct++) store_x(nx, rx[ct], ct);
     }
     __syncthreads();
+  }
+  if constexpr (PAIR) {
+    float* out2 = partial2 + (int64_t)split * COP2 * CIP;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (col_active && wr * 64 + i * 16 < COP2) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+          if (co < CO2 && ci < CI) out2[co * CIP + ci] = acc2[i][rr];
+        }
+      }
   }
   // partial[(split * RS + t)][COP][CIP]
 #pragma unroll
@@ -2136,7 +2169,6 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
     }
     return true;
   }
-  if (second) return false;
   {
     // v2: workgroup = (32-channel slice of Cin, image range), all taps in registers
     // 1x1 with more than one slice of Cin: one workgroup owns all of them (CIT = 4), dY is read once
@@ -2154,16 +2186,28 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
     const int nsplit = (int)((g.N + ips - 1) / ips);
     int64_t ps[1] = {(int64_t)nsplit * RS * COP * CIP};
     Hold partial(new_tensor(ps, 1, kF32, x->device()));
-    const size_t lds = all_ci ? 2 * (size_t)(IG_WTILE + 4 * WG_XCOPY + 512) : 2 * (size_t)WG_STAGE;
+    const bool pair = second != nullptr;
+    if (pair && (KS != 3 || all_ci)) return false;              // (igemm_conv_wgrad_pair only asks for a 3x3)
+    const int COP2 = pair ? (int)((second->g->Cout + 15) / 16) * 16 : 0;
+    Hold partial2;
+    if (pair) { int64_t ps2[1] = {(int64_t)nsplit * COP2 * CIP}; partial2 = Hold(new_tensor(ps2, 1, kF32, x->device())); }
+    const size_t lds = all_ci ? 2 * (size_t)(IG_WTILE + 4 * WG_XCOPY + 512) : 2 * (size_t)(WG_STAGE + (pair ? IG_WTILE : 0));
     {
-      KernelTimer kt("conv_wgrad_igemm", conv_flops(g), conv_bytes(g, 2), st);
-      const void* kfn = KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1> : (const void*)ig_wgrad8v2_kernel<3, false, 1>)
+      const double sec_fl = pair ? conv_flops(*second->g) : 0.0;
+      const double sec_by = pair ? conv_bytes(*second->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;
+      KernelTimer kt("conv_wgrad_igemm", conv_flops(g) + sec_fl, conv_bytes(g, 2) + sec_by, st);
+      const void* kfn = pair    ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1, true> : (const void*)ig_wgrad8v2_kernel<3, false, 1, true>)
+                      : KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1> : (const void*)ig_wgrad8v2_kernel<3, false, 1>)
                       : all_ci  ? (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 4> : (const void*)ig_wgrad8v2_kernel<1, false, 4>)
                                 : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 1> : (const void*)ig_wgrad8v2_kernel<1, false, 1>);
       allow_big_lds(kfn);
       const bf16_t* dyp = dy->ptr<bf16_t>(); const bf16_t* xp = x->ptr<bf16_t>(); float* pp = partial->ptr<float>();
+      const bf16_t* dy2p = pair ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
+      float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
       int a_N = (int)g.N, a_CO = (int)g.Cout, a_CI = (int)g.Cin, a_CIP = CIP, a_ips = ips, a_COP = COP, a_ntile = ntile;
-      void* args[] = {(void*)&dyp, (void*)&xp, (void*)&pp, (void*)&a_N, (void*)&a_CO, (void*)&a_CI, (void*)&a_CIP, (void*)&a_ips, (void*)&a_COP, (void*)&a_ntile};
+      int a_CO2 = pair ? (int)second->g->Cout : 0, a_COP2 = COP2;
+      void* args[] = {(void*)&dyp, (void*)&xp, (void*)&pp, (void*)&a_N, (void*)&a_CO, (void*)&a_CI, (void*)&a_CIP, (void*)&a_ips, (void*)&a_COP, (void*)&a_ntile,
+                      (void*)&dy2p, (void*)&p2p, (void*)&a_CO2, (void*)&a_COP2};
       HIP_CHECK(hipLaunchKernel(kfn, dim3(ntile * nsplit), dim3(256), args, lds, st));
       LAMP_LAUNCH_CHECK();
     }
@@ -2171,6 +2215,12 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
     WgradReduceArgs ra{};
     ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = COP; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
     wgrad_reduce_enqueue(ra, partial.get(), dw, st);
+    if (pair) {
+      const int64_t cols2 = (int64_t)COP2 * CIP / 4;
+      WgradReduceArgs rb{};
+      rb.kind = 0; rb.CO = (int)second->g->Cout; rb.CI = (int)g.Cin; rb.CIP = CIP; rb.COP = COP2; rb.RS = 1; rb.nsplit = nsplit; rb.blocks = (int)((cols2 + 31) / 32);
+      wgrad_reduce_enqueue(rb, partial2.get(), second->dw, st);
+    }
     return true;
   }
 }
@@ -2186,7 +2236,8 @@ bool igemm_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x,
   static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();
   if (!on || !wide_on || shift_dy < 2) return false;
   if (!ig_qualifies(g, x->dtype) || !ig_qualifies(g1, x->dtype) || g.kh != 3 || g1.kh != 1) return false;
-  if (g.Cin != g1.Cin || g.N != g1.N || !(g.Cin > WG_CI && g.Cout > 64)) return false;      // (the eight-wave kernel's conditions)
+  if (g.Cin != g1.Cin || g.N != g1.N) return false;
+  // (more than 32 input and 64 output channels: the eight-wave kernel; else the four-wave kernel, one Cin slice per workgroup)
   const SecondWgradConv sw{dy1, dw1, &g1};
   return igemm_conv_wgrad_impl(dy, x, dw, g, st, nullptr, &sw);
 }

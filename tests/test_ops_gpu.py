@@ -1237,7 +1237,9 @@ WGRAD_PAIR_CASES = [
     (64, 128, 8, 128, 128, 1, torch.bfloat16, "conv_wgrad_igemm"),     # implicit-GEMM layers with more than 32 input channels: the eight-wave kernel stages the second gradient too
     (1027, 128, 8, 100, 100, 1, torch.bfloat16, "conv_wgrad_igemm"),   # res4 of Cnn.resnet, ragged
     (2048, 64, 8, 128, 100, 1, torch.bfloat16, "conv_wgrad_igemm"),    # different output-channel counts
-    (64, 16, 8, 128, 128, 1, torch.bfloat16, False),    # res3: 16 input channels run on the four-wave kernel - two launches
+    (64, 16, 8, 128, 128, 1, torch.bfloat16, "conv_wgrad_igemm"),      # res3: 16 input channels, the four-wave kernel
+    (1024, 16, 8, 128, 100, 1, torch.bfloat16, "conv_wgrad_igemm"),
+    (100, 64, 8, 64, 48, 1, torch.bfloat16, "conv_wgrad_igemm"),       # two slices of Cin, at most 64 output channels
     (8, 5, 12, 7, 4, 1, torch.float32, False),
     (4, 6, 10, 4, 4, 2, torch.float64, False),
 ]
