@@ -1,5 +1,5 @@
 set -u
-O=gpurun_out/r05aj; mkdir -p $O
+O=gpurun_out/r05ak; mkdir -p $O
 timeout 900 python -m pytest tests/test_ops_gpu.py -q -m gpu -x -k "weight_gradients_of or wgrad or conv" 2>&1 | tail -8 > $O/pytest_a.txt
 timeout 900 python -m pytest tests/test_resnet_bf16_gpu.py tests/test_autograd_gpu.py -q -m gpu -x 2>&1 | tail -5 > $O/pytest_b.txt
 export LAMP_BENCH_ALSO=0
