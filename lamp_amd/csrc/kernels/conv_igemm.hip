@@ -364,11 +364,14 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   constexpr int NT = NWV * 64, LPT = 16 / NWV;              // 16 one-KiB pieces per weight stage, LPT per wave
   constexpr int NTI = 8 * NW / NWV;                          // output-channel tiles of 16 per wave: 4 (64 channels), 2 (32) or 1
   static_assert(NW == 2 || (NW == 1 && NWV == 8), "one image per workgroup: eight waves");
+  // weight slots: two (the next stage requested while this one is multiplied), or - one image per workgroup, where a stage is too short to
+  // cover an L2 round trip - four, requested three stages ahead behind a counted vmcnt (as ig_conv8c_kernel)
+  constexpr int NSLOT = NW == 1 ? 4 : 2;
   const int RB = KP * 2;
   const int XIMG = 64 * RB;                 // 8x8 pixels, no halo
   char* Xl = smem;                          // [2][64][KP] + one zero pixel
   const int ZOFF = NW * XIMG;
-  char* Wl = smem + NW * XIMG + RB;         // 2 x IG_WTILE
+  char* Wl = smem + NW * XIMG + RB;         // NSLOT x IG_WTILE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = NW == 2 ? wid >> 1 : wid, wc = NW == 2 ? wid & 1 : 0;
@@ -381,8 +384,8 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   const int T = RS * CC;
   typedef __attribute__((address_space(3))) char lds_char_t;
   typedef const __attribute__((address_space(1))) char glb_char_t;
-  // stage g of the launch: the sibling's KP / 64 centre-tap stages first (SIBM), then the T stages of this convolution; slot = g & 1
-  const int CS = SIBM ? CC : 0;
+  // stage g of the launch: the sibling's KP / 64 centre-tap stages first (SIBM), then the T stages of this convolution; slot = g % NSLOT
+  const int CS = SIBM ? CC : 0, TT = CS + T;
   auto stage_dma = [&](int g) {
     const bf16_t* wimg = (SIBM && g < CS) ? sib.wp : wp;
     const int t = (SIBM && g < CS) ? g : g - CS;
@@ -393,10 +396,19 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
       const int piece = wid * LPT + i;
       const int p = piece * 64 + lane;
       const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + (g & 1) * IG_WTILE + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(base + row * KP + chunk * 8), (lds_char_t*)(Wl + (g & (NSLOT - 1)) * IG_WTILE + piece * 1024), 16, 0, 0);
     }
   };
   stage_dma(0);
+#pragma unroll
+  for (int d = 1; d < NSLOT - 1; d++)
+    if (d < TT) stage_dma(d);
+  // the wait that ends stage g: stage g + 1 has landed, the (at most NSLOT - 2) stages requested behind it may stay in flight
+  auto stage_wait = [&](int g) {
+    if (NSLOT == 4 && g + 3 < TT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (NSLOT == 4 && g + 2 < TT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   if (tid * 16 < RB) *reinterpret_cast<uint4*>(Xl + ZOFF + tid * 16) = make_uint4(0, 0, 0, 0);
   auto load_images = [&](const bf16_t* __restrict__ x) {
     const int ncgp = KP >> 3;
@@ -492,8 +504,8 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
   if constexpr (SIBM != 0) {
     // ---- the sibling's product: KP / 64 stages of the centre tap
     for (int cc = 0; cc < CC; cc++) {
-      const char* wl = Wl + (cc & 1) * IG_WTILE + a_row;
-      stage_dma(cc + 1);                               // (the stage behind the sibling's last one is this convolution's first)
+      const char* wl = Wl + (cc & (NSLOT - 1)) * IG_WTILE + a_row;
+      if (cc + NSLOT - 1 < TT) stage_dma(cc + NSLOT - 1);   // (the stages behind the sibling's last one are this convolution's first)
       const int u = ((cc * (KW >> 3)) & cmask) << 4;
 #pragma unroll
       for (int i = 0; i < NTI; i++) {
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_wait(cc);
       __builtin_amdgcn_s_barrier();
     }
     if constexpr (SIBM == 1) {
@@ -535,8 +547,8 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
 #pragma unroll
   for (int rs = 0; rs < RS; rs++) {
     for (int cc = 0; cc < CC; cc++, t++) {
-      const char* wl = Wl + ((CS + t) & 1) * IG_WTILE + a_row;
-      if (t + 1 < T) stage_dma(CS + t + 1);
+      const char* wl = Wl + ((CS + t) & (NSLOT - 1)) * IG_WTILE + a_row;
+      if (CS + t + NSLOT - 1 < TT) stage_dma(CS + t + NSLOT - 1);
       const int u = ((cc * (KW >> 3)) & cmask) << 4;
 #pragma unroll
       for (int i = 0; i < NTI; i++) {
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(NWV * 64) void ig_conv8b_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_wait(CS + t);
       __builtin_amdgcn_s_barrier();
     }
   }
@@ -1992,7 +2004,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
       static const bool one_on = [] { const char* e = getenv("LAMP_IG_ONE_IMAGE"); return !(e && e[0] == '0'); }();
       const bool w8 = w8_on && blocksb <= num_cus();
       const bool one = one_on && w8 && g.N <= num_cus();
-      const size_t ldsb = (size_t)(one ? 1 : 2) * 64 * KP * 2 + KP * 2 + 2 * IG_WTILE;
+      const size_t ldsb = (size_t)(one ? 1 : 2) * 64 * KP * 2 + KP * 2 + (one ? 4 : 2) * IG_WTILE;
 #define IG_LAUNCH_B(KS_, NWV_, SIBM_, NW_)                                                                                                      \
   do {                                                                                                                                          \
     allow_big_lds((const void*)ig_conv8b_kernel<KS_, NWV_, SIBM_, NW_>);                                                                       \
