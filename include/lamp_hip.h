@@ -545,6 +545,11 @@ int lamp_log_softmax_backward_data(lamp_tensor** out, const lamp_tensor* grad_ou
 int lamp_global_avg_pool_log_softmax(lamp_tensor** out, const lamp_tensor* x);
 int lamp_global_avg_pool_log_softmax_backward(lamp_tensor** out, const lamp_tensor* grad, const lamp_tensor* output,
                                               const lamp_tensor* x);
+/* ... and the NllLoss behind it (SupervisedModel: loss(LogSoftMax(pool(x)), target)): nll_loss_backward followed by the call above, the loss's
+ * gradient row built inside the launch (values of the two calls, each stage rounded to the dtype). */
+int lamp_global_avg_pool_log_softmax_nll_backward(lamp_tensor** out, const lamp_tensor* grad_loss, const lamp_tensor* target /* i64 [N] */,
+                                                  const lamp_tensor* weight_or_null, int64_t reduction, int64_t ignore_index,
+                                                  const lamp_tensor* total_weight, const lamp_tensor* output, const lamp_tensor* x);
 int lamp_softmax(lamp_tensor** out, const lamp_tensor* x, int64_t dim);
 int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
                           const lamp_tensor* target /* i64 [N] */, const lamp_tensor* weight_or_null,

@@ -10,6 +10,7 @@
 // exactly), later closures add in place.  In-place native forms (addmm_out_transposed*, the fused
 // relu backward) take their beta = 0 / out-of-place variant for that first accumulation.
 #include "ops.h"
+#include <cstring>
 #include <map>
 #include <tuple>
 
@@ -488,7 +489,19 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
   if (acc.defined()) HCALL(lamp_nll_loss_forward_accumulate_(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.h(), scale));
   else HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
   Ten val(v), total_weight(tw), iv = input->value;
+  static const bool fuse_tail = [] { const char* e = getenv("LAMP_FUSE_LOSS_BACKWARD"); return !(e && e[0] == '0'); }();
   op->params.push_back({input, [=](const Ten& p, Variable& out) {
+    // Cnn.resnet's tail: the log-probabilities come from the pooled LogSoftMax node.  Its input gradient is linear in this contribution, so
+    // the contribution goes straight to THAT node's input in one launch (the [N, C] gradient row is never written); anything else that
+    // flows into `out` takes the node's own closure as before
+    if (fuse_tail && out.op && out.op->params.size() == 1 && std::strcmp(out.op->name, "GlobalAvgPoolLogSoftMax") == 0 && p.h()->is_device() &&
+        out.op->params[0].first->needsGrad()) {
+      Variable& xin = *out.op->params[0].first;
+      lamp_tensor* t = nullptr;
+      HCALL(lamp_global_avg_pool_log_softmax_nll_backward(&t, p.h(), target.h(), weights.h(), reduction, ignore, total_weight.h(), iv.h(), xin.value.h()));
+      xin.accumulate(Ten(t), true);
+      return;
+    }
     lamp_tensor* t = nullptr;
     HCALL(lamp_nll_loss_backward(&t, p.h(), iv.h(), target.h(), weights.h(), reduction, ignore, total_weight.h()));
     out.accumulate(Ten(t), true);

@@ -107,6 +107,43 @@ __global__ __launch_bounds__(256) void gap_lsm_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ... with the gradient row itself built in LDS from the loss: g[n][c] = nll_loss_backward(grad_loss, target, weight)[n][c] as nll_bwd_kernel
+// rounds it (lamp_global_avg_pool_log_softmax_nll_backward: the NllLoss and the pooled LogSoftMax of Cnn.resnet's tail in one backward launch)
+template <class T>
+__global__ __launch_bounds__(256) void gap_lsm_nll_bwd_kernel(const T* __restrict__ grad, const int64_t* __restrict__ target, const T* __restrict__ w,
+                                                              const T* __restrict__ total_weight, int64_t reduction, int64_t ignore,
+                                                              const T* __restrict__ out, T* __restrict__ dx, int C, int hw, int lpp) {
+  using A = acc_t<T>;
+  constexpr int W = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* gl = reinterpret_cast<T*>(smem);                       // [C]: the pooled gradient
+  T* grow = gl + ((C + 7) & ~7);                            // [C]: the loss's gradient row
+  const int64_t n = blockIdx.x;
+  const int tid = threadIdx.x;
+  {
+    const int64_t t = target[n];
+    A v = 0;
+    if (t != ignore && t >= 0 && t < C) {
+      A g = load_as<A>(reduction == 0 ? grad[n] : grad[0]);
+      if (reduction == 1) g = g / load_as<A>(*total_weight);
+      v = -(w ? load_as<A>(w[t]) : A(1)) * g;
+    }
+    const T vt = store_as<T>(v), zero = store_as<T>(A(0));
+    for (int c = tid; c < C; c += 256) grow[c] = c == t ? vt : zero;
+  }
+  __syncthreads();
+  if (tid < 64) log_softmax_bwd_row<T>(grow, out + n * C, gl, C, 1, 1, tid);
+  __syncthreads();
+  const int packets = C * lpp;
+  for (int p = tid; p < packets; p += 256) {
+    const T v = store_as<T>((A)(load_as<A>(gl[p / lpp]) / (A)hw));
+    Vec<T, W> pk;
+#pragma unroll
+    for (int k = 0; k < W; k++) pk.v[k] = v;
+    *reinterpret_cast<Vec<T, W>*>(dx + (n * packets + p) * W) = pk;
+  }
+}
+
 // contiguous rows (inner == 1), D a multiple of the packet width: 16-byte loads; rows of up to 64 * MAXP packets stay in registers
 // (one read of x), longer ones (LM vocabularies) are streamed three times with vector loads (MAXP == 0)
 template <class T, bool LOG, int MAXP>
@@ -543,6 +580,43 @@ int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const
     LAMP_LAUNCH_CHECK();
   }
   *out = gi.take();
+  LAMP_API_END
+}
+
+int lamp_global_avg_pool_log_softmax_nll_backward(lamp_tensor** out, const lamp_tensor* grad_loss, const lamp_tensor* target, const lamp_tensor* weight,
+                                                  int64_t reduction, int64_t ignore_index, const lamp_tensor* total_weight, const lamp_tensor* output,
+                                                  const lamp_tensor* x) {
+  LAMP_API_BEGIN
+  check_device_tensor(x, "input"); check_device_tensor(output, "output");
+  nll_check(output, target, weight);
+  check_device_tensor(grad_loss, "grad_output"); check_device_tensor(total_weight, "total_weight");
+  LAMP_CHECK(x->ndim == 4 && output->ndim == 2 && output->sizes[0] == x->sizes[0] && output->sizes[1] == x->sizes[1] && output->dtype == x->dtype,
+             "global_avg_pool_log_softmax_nll_backward: output " << output->describe() << " does not match input " << x->describe());
+  LAMP_CHECK(grad_loss->dtype == x->dtype && total_weight->dtype == x->dtype, "global_avg_pool_log_softmax_nll_backward: dtype mismatch");
+  const int64_t N = x->sizes[0];
+  if (reduction == 0) LAMP_CHECK(grad_loss->numel() == N, "nll_loss_backward: grad_output must have N elements for reduction none");
+  else LAMP_CHECK(grad_loss->numel() == 1, "nll_loss_backward: grad_output must be a scalar");
+  const int lpp = (grad_loss->is_device() && output->is_device() && target->is_device()) ? gap_lsm_lanes(x) : 0;
+  if (!lpp || N == 0) {
+    // the two calls
+    lamp_tensor* gy = nullptr;
+    if (lamp_nll_loss_backward(&gy, grad_loss, output, target, weight, reduction, ignore_index, total_weight) != 0) throw Error(lamp_last_error());
+    Hold gyh(gy);
+    if (lamp_global_avg_pool_log_softmax_backward(out, gy, output, x) != 0) throw Error(lamp_last_error());
+    return 0;
+  }
+  Hold gc(contiguous(grad_loss)), tc(contiguous(target)), oc(contiguous(output));
+  Hold wc(weight ? contiguous(weight) : nullptr);
+  Hold dx(new_tensor(x->shape(), x->dtype, x->device()));
+  const int C = (int)x->sizes[1], hw = (int)(x->sizes[2] * x->sizes[3]);
+  LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((gap_lsm_nll_bwd_kernel<T>), dim3((unsigned)N), dim3(256), (size_t)(((C + 7) & ~7) + C) * sizeof(T),
+                                                      current_stream(x->device()), static_cast<const Tensor*>(gc.get())->ptr<T>(),
+                                                      static_cast<const Tensor*>(tc.get())->ptr<int64_t>(),
+                                                      wc.get() ? static_cast<const Tensor*>(wc.get())->ptr<T>() : (const T*)nullptr,
+                                                      total_weight->ptr<T>(), reduction, ignore_index, static_cast<const Tensor*>(oc.get())->ptr<T>(),
+                                                      dx->ptr<T>(), C, hw, lpp));
+  LAMP_LAUNCH_CHECK();
+  *out = dx.take();
   LAMP_API_END
 }
 

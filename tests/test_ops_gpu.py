@@ -1088,6 +1088,23 @@ def test_global_avg_pool_log_softmax_is_bitwise_the_three_call_chain(gpu, dt, sh
     DXf = S.STen(dxf)
     assert DXf.shape == list(shape)
     assert np.array_equal(DXf.to_numpy(), DXc.to_numpy()), "backward differs from the chain"
+    # ... and with the NllLoss behind it (SupervisedModel.scala: the loss of the pooled log-probabilities): nll_loss_backward -> the call above
+    # as ONE call, bitwise, for every reduction, with and without class weights, with an ignored class
+    target = (torch.arange(N) * 7) % Cc
+    wts = closed_form((Cc,), 13, 1.0, dt).abs() + 0.5
+    T_ = to_sten(target)
+    for reduction in (0, 1, 2):
+        for W_ in (None, to_sten(wts)):
+            for ignore in (-100, 7):
+                lv, tw = C.c_void_p(), C.c_void_p()
+                lib.lamp_nll_loss_forward(C.byref(lv), C.byref(tw), Ofused, T_, W_, reduction, ignore)
+                LV, TW = S.STen(lv), S.STen(tw)
+                gl_ = closed_form(tuple(LV.shape) if LV.shape else (1,), 17, 1.0, dt).reshape(LV.shape) + 1.0
+                GL = to_sten(gl_)
+                gyn = C.c_void_p(); lib.lamp_nll_loss_backward(C.byref(gyn), GL, Ofused, T_, W_, reduction, ignore, TW)
+                two = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax_backward(C.byref(two), S.STen(gyn), Ofused, X)
+                one = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax_nll_backward(C.byref(one), GL, T_, W_, reduction, ignore, TW, Ofused, X)
+                assert np.array_equal(S.STen(one).to_numpy(), S.STen(two).to_numpy()), f"loss backward differs from the two calls (reduction {reduction}, ignore {ignore})"
 
 
 # (N, Cin, H, Cout, k, stride, pad, dtype, fused?)  fused = the dgrad kernel has the accumulate epilogue for this geometry
