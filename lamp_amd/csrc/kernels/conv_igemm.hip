@@ -931,8 +931,21 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     }
   };
   auto stage_dma = [&](int kc1, int rs1, int slot) { stage_dma_of(wp, kc1, rs1, slot); };
+  // WIDE stages (round 5, one channel tile per wave: NCT = 1, not with a fprop sibling): a stage of the narrow form is 16 rows x 32 k - four
+  // MFMAs between two barriers, and a 128-channel input costs 36 (+ 4) of them: the 16-channel input gradient of res3 took 26 us for 67 MB of
+  // gradients.  Here a stage is a whole TAP, 16 rows x all KC chunks (wave kc requests chunk kc's 1 KiB piece): RS (+ 1) stages.
+  constexpr bool WIDE = NCT == 1 && !SIB;
+  const unsigned d_srcw = (unsigned)((lane >> 2) * KP + wid * 32 + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2u;
+  auto stage_dma_w = [&](const bf16_t* wimg, int rs1, int slot) {
+    if (wid < KC)
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(reinterpret_cast<const char*>(wimg + (int64_t)rs1 * IG_M * KP) + d_srcw),
+                                       (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+  };
   IG_STAMP(0);
-  if (SIB || DG2) {                           // the sibling's stages (one tap: stage = 32-channel chunk) come first
+  if constexpr (WIDE) {
+    if (DG2) { stage_dma_w(sib.wp, 0, 0); stage_dma_w(wp, 0, 1); }
+    else { stage_dma_w(wp, 0, 0); if (RS > 1) stage_dma_w(wp, 1, 1); }
+  } else if (SIB || DG2) {                    // the sibling's stages (one tap: stage = 32-channel chunk) come first
     stage_dma_of(sib.wp, 0, 0, 0);
     if (KC > 1) stage_dma_of(sib.wp, 1, 0, 1);
   } else {
@@ -1026,6 +1039,76 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   // closing READ(t), which both groups pass before anyone starts READ(t+1).
   bf8v fa[NCT], fb[4];
   const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
+  if constexpr (WIDE) {
+    // one stage = one tap over every chunk: READ (all chunks' fragments) | barrier | MFMA | barrier, waves 4 - 7 one phase behind as below.
+    // Stage sequence: [the second source's centre tap (DG2)], then the RS taps; slot = stage index mod 3, requested two stages ahead.
+    bf8v fw[4], fx[4][4];
+    auto read_stage = [&](int slot, int r, int s) {
+      const char* wl = Wl + slot * WT + a_off;
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++)
+        if (kc < KC) {
+          fw[kc] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + kc * 1024));
+          const char* xb = Xl + kc * XBUF + va[r & 1][s];
+#pragma unroll
+          for (int j = 0; j < 4; j++) fx[kc][j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s) + 16 * j) * RB));
+        }
+    };
+    auto zero_outside = [&](int r, int s) {
+      if (KS != 3) return;
+      const bool colout = (s == 0 && col_lo) || (s == 2 && col_hi);
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++)
+        if (kc < KC) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const bool out = colout || (r == 0 && j == 0 && row_lo) || (r == 2 && j == 3 && row_hi);
+            if (s != 1 || (r == 0 && j == 0) || (r == 2 && j == 3)) fx[kc][j] = out ? zero8 : fx[kc][j];
+          }
+        }
+    };
+    auto multiply = [&] {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++)
+        if (kc < KC) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kc][j], fw[kc], acc[0][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    int slot = 0;
+    if constexpr (DG2) {
+      if (grp == 1) __builtin_amdgcn_s_barrier();
+      if (RS > 1) stage_dma_w(wp, 1, 2);                     // (stage 0 of this convolution sits in slot 1 already)
+      read_stage(0, PAD, PAD);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      multiply();
+      __builtin_amdgcn_s_barrier();
+      if (grp == 0) __builtin_amdgcn_s_barrier();            // nobody reads the second source's images any more
+      load_images(x);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      slot = 1;
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rs = 0; rs < RS; rs++) {
+      const int r = rs / KS, s = rs - r * KS;
+      const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if (rs + 2 < RS) stage_dma_w(wp, rs + 2, slot2);
+      read_stage(slot, r, s);
+      if (rs + 2 < RS) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      zero_outside(r, s);
+      __builtin_amdgcn_s_barrier();
+      multiply();
+      __builtin_amdgcn_s_barrier();
+      slot = slot1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();              // every READ phase of every wave is over: LDS is free
+  } else {
   if constexpr (SIB || DG2) {
     // ---- sibling product: KC stages of the centre tap, same ring and phases
     if (grp == 1) __builtin_amdgcn_s_barrier();
@@ -1214,6 +1297,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();          // every READ phase of every wave is over: LDS is free
+  }
   IG_STAMP(3);
 
   // epilogue: + bias, round to bf16, batch-norm statistics from the rounded values (as ig_conv8b), then [channel][64 pixels] rows
