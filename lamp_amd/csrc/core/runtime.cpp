@@ -6,6 +6,7 @@
 // calling thread's current stream.
 #include "tensor.h"
 
+#include <unordered_map>
 #include <atomic>
 #include <mutex>
 #include <set>
@@ -475,7 +476,17 @@ int lamp_graph_release(lamp_graph* g) {
 // ---- convolution -> batch-norm statistics hand-off ------------------------------------------------------------------------
 namespace lamp {
 namespace {
-struct ConvStatsEntry { uint64_t uid = 0, version = 0; int64_t offset = 0, N = 0, C = 0, HW = 0; lamp_tensor* partial = nullptr; int P = 0; };
+struct ConvStatsEntry {
+  uint64_t uid = 0, version = 0; int64_t offset = 0, N = 0, C = 0, HW = 0; lamp_tensor* partial = nullptr; int P = 0;
+  uint64_t producer = 0;                    // who computed them (the filter's storage uid; 0: not tracked)
+  bool consumed = false;                    // a batch norm has taken them
+  uint64_t hits_then = 0;                   // g_conv_stats_hits when they were published
+};
+uint64_t g_conv_stats_hits = 0;             // hand-offs taken so far
+// producers whose last statistics nobody took (a convolution that is not followed by a batch norm: the stem of Cnn.resnet): they stop
+// computing them, and probe again every 64th call
+struct ConvStatsUse { bool unused = false; unsigned calls = 0; };
+std::unordered_map<uint64_t, ConvStatsUse> g_conv_stats_use;
 inline int64_t spatial_of(const lamp_tensor* t) { int64_t hw = 1; for (int i = 2; i < t->ndim; i++) hw *= t->sizes[i]; return hw; }
 constexpr int kConvStatsRing = 32;
 ConvStatsEntry g_conv_stats[kConvStatsRing];
@@ -483,15 +494,29 @@ int g_conv_stats_next = 0;
 std::mutex g_conv_stats_mu;
 }  // namespace
 
-void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P) {
+void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P, uint64_t producer) {
   std::lock_guard<std::mutex> lock(g_conv_stats_mu);
   ConvStatsEntry& e = g_conv_stats[g_conv_stats_next];
   g_conv_stats_next = (g_conv_stats_next + 1) % kConvStatsRing;
   if (e.partial) lamp_tensor_release(e.partial);
   e.uid = y->st->uid; e.version = y->st->version.load(std::memory_order_relaxed); e.offset = y->offset;
   e.N = y->sizes[0]; e.C = y->sizes[1]; e.HW = spatial_of(y);
-  e.partial = nullptr; e.P = P;
+  e.partial = nullptr; e.P = P; e.producer = producer; e.consumed = false; e.hits_then = g_conv_stats_hits;
   lamp_tensor_retain(partial, &e.partial);
+}
+bool conv_stats_wanted(uint64_t producer) {
+  std::lock_guard<std::mutex> lock(g_conv_stats_mu);
+  // its previous output's fate: taken, or passed over - later hand-offs were taken while this one was not (two calls in a row with no
+  // batch norm in between say nothing)
+  for (auto& o : g_conv_stats)
+    if (o.partial && o.producer == producer) {
+      if (o.consumed) g_conv_stats_use[producer].unused = false;
+      else if (g_conv_stats_hits > o.hits_then) g_conv_stats_use[producer].unused = true;
+      o.producer = 0;
+    }
+  auto it = g_conv_stats_use.find(producer);
+  if (it == g_conv_stats_use.end() || !it->second.unused) return true;
+  return (++it->second.calls & 63u) == 0;
 }
 
 lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P) {
@@ -504,6 +529,8 @@ lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P) {
       lamp_tensor* r = nullptr;
       lamp_tensor_retain(e.partial, &r);
       *P = e.P;
+      e.consumed = true;
+      g_conv_stats_hits++;
       return r;
     }
   }

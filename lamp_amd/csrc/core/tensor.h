@@ -200,7 +200,8 @@ void allow_big_lds(const void* kernel);   // opt a kernel into 160 KiB of dynami
 // Batch-norm statistics computed by a convolution's epilogue: Welford triples [P][C][3] (f32) over P disjoint slices of the output,
 // keyed by the output's storage (uid, offset) and valid while its version is unchanged.  The batch norm that consumes the tensor
 // picks them up instead of re-reading it (norm.hip).  A small ring: the consumer runs right after the producer.
-void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P);
+void conv_stats_publish(const lamp_tensor* y, lamp_tensor* partial, int P, uint64_t producer = 0);
+bool conv_stats_wanted(uint64_t producer);   // false: this producer's last statistics were never taken (it probes again every 64th call)
 lamp_tensor* conv_stats_lookup(const lamp_tensor* x, int64_t C, int* P);   // +1 handle or nullptr
 // device-side assertions (runtime.cpp): a kernel stores a code into *device_assert_word(dev); the next host wait raises
 enum DeviceAssert : int { kAssertNllTarget = 1, kAssertIndexRange = 2, kAssertBnExchangeTimeout = 3, kAssertMultinomial = 4 };

@@ -990,7 +990,8 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
       const char* n = getenv("LAMP_NCV_BN_STATS");          // the narrow kernels' alone (A/B)
       return !(e && e[0] == '0') && !(n && n[0] == '0');
     }();
-    const bool with_stats = bn_stats && !dgrad && !addend && g.N >= 2 && (int64_t)q.Ho * q.Wo >= 64;
+    // (a filter whose output's statistics nobody took last time - the stem of Cnn.resnet feeds res1's convolutions directly - stops paying for them)
+    const bool with_stats = bn_stats && !dgrad && !addend && g.N >= 2 && (int64_t)q.Ho * q.Wo >= 64 && (sib || conv_stats_wanted(w->st->uid));
 #define NCV_F2(NKv, SWv, PHv, ADDv, STv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 2, ADDv, STv> : (const void*)ncv_fwd2_kernel<NKv, SWv, PHv, 1, ADDv, STv>
 #define NCV_F2_PH(NKv, SWv, ADDv, STv) do { if (ph0 == 0) NCV_F2(NKv, SWv, 0, ADDv, STv); else if (ph0 == 6) NCV_F2(NKv, SWv, 6, ADDv, STv); else NCV_F2(NKv, SWv, 7, ADDv, STv); } while (0)
 #define NCV_F2_SW(NKv) do { if (with_stats) { if (q.sw == 1) NCV_F2_PH(NKv, 1, false, true); else NCV_F2_PH(NKv, 2, false, true); }                \
@@ -1048,7 +1049,7 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
                     (void*)&statp, (void*)&stat2p, (void*)&stats_per_wg, (void*)&src2p};
     HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(threads), args, lds, st));
     LAMP_LAUNCH_CHECK();
-    if (statt.get()) conv_stats_publish(out, statt.get(), parts);
+    if (statt.get()) conv_stats_publish(out, statt.get(), parts, sib ? 0 : w->st->uid);
     if (statt2.get()) conv_stats_publish(sib->out, statt2.get(), parts);
     return true;
   }
