@@ -514,6 +514,7 @@ bool conv_stats_wanted(uint64_t producer) {
       else if (g_conv_stats_hits > o.hits_then) g_conv_stats_use[producer].unused = true;
       o.producer = 0;
     }
+  if (g_conv_stats_use.size() > 4096) g_conv_stats_use.clear();          // (filters come and go: forget rather than grow)
   auto it = g_conv_stats_use.find(producer);
   if (it == g_conv_stats_use.end() || !it->second.unused) return true;
   return (++it->second.calls & 63u) == 0;
