@@ -31,6 +31,7 @@
 #include "device_utils.h"
 #include "conv_geom.h"
 #include "wgrad_reduce.h"
+#include "conv_narrow_pack.h"
 
 namespace lamp {
 
@@ -99,6 +100,31 @@ __global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __r
 constexpr int IG_PACK_MAX = 16;
 struct PackMany { const bf16_t* w[IG_PACK_MAX]; bf16_t* wp[IG_PACK_MAX]; int Cout[IG_PACK_MAX], Cin[IG_PACK_MAX], KS[IG_PACK_MAX], KPf[IG_PACK_MAX], KPd[IG_PACK_MAX]; };
 __global__ void ig_pack_weights_many_kernel(PackMany a) {
+  const int t = blockIdx.y;
+  const bf16_t* __restrict__ w = a.w[t];
+  bf16_t* __restrict__ wp = a.wp[t];
+  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], KPf = a.KPf[t], KPd = a.KPd[t];
+  const int RS = KS * KS;
+  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+    const int dgrad = e0 >= nf;
+    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
+    const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
+    const int r = rs / KS, s = rs % KS;
+    bf16_t v; v.bits = 0;
+    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
+    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
+    wp[e0] = v;
+  }
+}
+
+// ... and the narrow convolutions' fragment images (conv_narrow_pack.h) in the same launch: blockIdx.y >= nig belongs to them
+__global__ void ig_ncv_pack_many_kernel(PackMany a, NcvPackMany b, int nig, int nncv) {
+  if ((int)blockIdx.y >= nig) {                              // ONE extra row of the grid: block x = (narrow image x / 4, quarter x % 4) - host: 4 nncv <= gridDim.x
+    const int e = (int)blockIdx.x >> 2;
+    if (e < nncv) ncv_pack_body(b, e, (int)((blockIdx.x & 3) * blockDim.x + threadIdx.x));
+    return;
+  }
   const int t = blockIdx.y;
   const bf16_t* __restrict__ w = a.w[t];
   bf16_t* __restrict__ wp = a.wp[t];
@@ -1886,9 +1912,16 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
 // implicit-GEMM convolution used before, on this stream) is packed again now, all of them in one launch, and the cache entries are
 // moved to the new storage version - the next step's convolutions find them fresh.  Values are exactly those a lazy pack at first use
 // would produce (same kernel body, same weights).  LAMP_PACK_AFTER_STEP=0 restores the lazy packs.
+void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st, NcvPackMany* fill, int* fill_cnt);   // conv_narrow.hip
+void narrow_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st);
+// (round 5: ... and the narrow convolutions' fragment images ride in the last of these launches - the step had two pack launches of 4 - 6 us)
 void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("LAMP_PACK_AFTER_STEP"); return !(e && e[0] == '0'); }();
   if (!on) return;
+  NcvPackMany nb;
+  int ncnt = 0;
+  narrow_repack_cached(params, n, st, &nb, &ncnt);
+  struct NarrowLeft { const NcvPackMany& b; int& c; hipStream_t s; ~NarrowLeft() { if (c > 0) narrow_pack_launch(b, c, s); } } narrow_left{nb, ncnt, st};
   PackMany a;
   int cnt = 0, maxtotal = 0;
   std::vector<std::pair<PackKey, uint64_t>> done;       // (entry, storage version its image now corresponds to)
@@ -1918,6 +1951,12 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
       cnt++;
       break;
     }
+  }
+  static_assert(NCV_NKMAX * 64 <= 4 * 256, "a narrow image is four blocks of the pack kernel");
+  if (cnt > 0 && ncnt > 0 && 4 * ncnt <= std::min(512, (maxtotal + 255) / 256)) {      // the last batch takes the narrow images along
+    hipLaunchKernelGGL(ig_ncv_pack_many_kernel, dim3((unsigned)std::min(512, (maxtotal + 255) / 256), (unsigned)(cnt + 1)), dim3(256), 0, st, a, nb, cnt, ncnt);
+    LAMP_LAUNCH_CHECK();
+    cnt = 0; ncnt = 0;
   }
   flush();
   for (auto& d : done) {

@@ -27,12 +27,11 @@
 #include <mutex>
 #include <tuple>
 #include <vector>
+#include "conv_narrow_pack.h"
 
 namespace lamp {
 
-typedef short nv_s8 __attribute__((ext_vector_type(8)));
 typedef nv_s8 __attribute__((aligned(2))) nv_s8_u;      // 16-byte LDS read at 2-byte alignment
-typedef __bf16 nv_bf8 __attribute__((ext_vector_type(8)));
 typedef float nv_f4 __attribute__((ext_vector_type(4)));
 
 struct NcvGeom {
@@ -53,62 +52,8 @@ struct NcvGeom {
 
 constexpr int NCV_LEFT = 8;   // staged images start at column 8: 16-byte aligned rows for the vector copy
 
-// Weight fragments.  Fragment of k-step ks for lane = co + 16*g: pair (c, r) = 4*ks + g, element j = filter column (zero for
-// j >= kw);   fprop: W[co][c][r][j]      dgrad (c = conv Cout, "co" = conv Cin): W[c][co][kh-1-r][kw-1-j].
-// They are packed ONCE per weight version into a [NCV_NKMAX][64 lanes][8] image (12 KiB; ncv_pack_kernel, cached per
-// (storage, view, stream, direction) like the implicit-GEMM images and re-packed in one launch by the optimiser step), so a
-// workgroup's prologue is NK 16-byte loads per lane.  Gathering them per lane from the filter tensor (8 two-byte loads and two
-// integer divisions per k-step) took 5.5 - 6.5 k of the ~22 k cycles a workgroup lives (scripts/ncv_stamp_probe.py).
-constexpr int NCV_NKMAX = 16;
-// ns = 2 ("two-shift" images, for at most 8 output channels and kw + sw <= 8): MFMA column n = 8*s + co carries the filter of
-// channel co moved s*sw taps to the right inside the 8-wide window, i.e. ONE MFMA produces the output pixels of two neighbouring
-// window phases - half the MFMAs (and half the funnel shifts) per output pixel; the 6-channel layers used 6 of 16 columns before.
-struct NcvW {
-  const bf16_t* w;
-  int Cout, Cin, kh, kw, dgrad;
-  int ns, sw;            // shifts per MFMA (1 or 2) and the window stride between them
-  // round 5, fprop only: a SIBLING 1x1 filter [Cout2][Cin] of the same input (the shortcut of lamp's residual block, cnn.scala:16-20) as
-  // output columns Cout .. Cout + Cout2 - 1 whose only non-zero tap is the centre one - the two convolutions are then ONE product over the
-  // staged image (the 6-channel layers use 6 of the MFMA's 16 columns: the second convolution rides in the padding)
-  // dgrad: w2 = the sibling's filter too, but as EXTRA K pairs (its output gradient is a second source of the staged image, NcvGeom::C1)
-  const bf16_t* w2;
-  int Cout2;
-};
-__device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
-  const int n = lane & 15, pair = ks * 4 + (lane >> 4);
-  const int co = wq.ns == 2 ? (n & 7) : n, shift = wq.ns == 2 ? (n >> 3) * wq.sw : 0;
-  int c = pair / wq.kh, r = pair - c * wq.kh;
-  // dgrad of a pair: behind the Cout * kh pairs of the first filter come Cout2 pairs (c2, centre row) of the sibling 1x1 filter [Cout2][Cin]
-  const bool second_k = wq.dgrad && wq.w2 && pair >= wq.Cout * wq.kh;
-  if (second_k) { c = pair - wq.Cout * wq.kh; r = wq.kh / 2; }
-  nv_s8 v;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    unsigned short e = 0;
-    const int t = j - shift;                  // filter column
-    if (t >= 0 && t < wq.kw) {
-      if (!wq.dgrad) {
-        if (co < wq.Cout && c < wq.Cin) e = wq.w[((co * wq.Cin + c) * wq.kh + r) * wq.kw + t].bits;
-        else if (wq.w2 && co < wq.Cout + wq.Cout2 && c < wq.Cin && r == wq.kh / 2 && t == wq.kw / 2) e = wq.w2[(co - wq.Cout) * wq.Cin + c].bits;
-      }
-      else if (second_k) { if (co < wq.Cin && c < wq.Cout2 && t == wq.kw / 2) e = wq.w2[c * wq.Cin + co].bits; }   // (the centre tap is its own mirror image)
-      else { if (co < wq.Cin && c < wq.Cout) e = wq.w[((c * wq.Cin + co) * wq.kh + (wq.kh - 1 - r)) * wq.kw + (wq.kw - 1 - t)].bits; }
-    }
-    v[j] = (short)e;
-  }
-  return __builtin_bit_cast(nv_bf8, v);
-}
-constexpr int NCV_PACK_MAX = 16;
-struct NcvPackMany {
-  NcvW w[NCV_PACK_MAX];
-  nv_bf8* dst[NCV_PACK_MAX];
-};
-// grid (3, entries) x 256 threads: thread = (k-step, lane) of one fragment image
-__global__ __launch_bounds__(256) void ncv_pack_kernel(NcvPackMany a) {
-  const int t = blockIdx.x * 256 + threadIdx.x, e = blockIdx.y;
-  if (t >= NCV_NKMAX * 64) return;
-  a.dst[e][t] = ncv_weight_frag(a.w[e], t >> 6, t & 63);
-}
+// (the weight-fragment layout, ncv_weight_frag and NcvPackMany live in conv_narrow_pack.h: conv_igemm.hip packs these images in its own launch)
+__global__ __launch_bounds__(256) void ncv_pack_kernel(NcvPackMany a) { ncv_pack_body(a, blockIdx.y, blockIdx.x * 256 + threadIdx.x); }
 
 // Image staging in two halves, so that the NEXT image's global loads are in flight while the current one is multiplied: the image
 // [C][H][W] is read as consecutive 16-byte packets (W % 8 == 0), packet tid + k * nthreads into register k of the thread, and
@@ -872,7 +817,10 @@ static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t s
 
 // Called by the optimisers right after they have written the parameters (next to igemm_repack_cached): every cached fragment image of
 // these parameters on this stream is packed again IN PLACE (a captured HIP graph keeps the address), all of them in one launch.
-void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
+// `fill` (optional): instead of launching, hand the LAST batch of at most NCV_PACK_MAX images to the caller (*fill, *fill_cnt) - the optimiser's hook
+// in conv_igemm.hip packs them in the launch that packs the implicit-GEMM images; earlier full batches are still launched here
+void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st, NcvPackMany* fill, int* fill_cnt) {
+  if (fill_cnt) *fill_cnt = 0;
   static const bool on = [] { const char* e = getenv("LAMP_PACK_AFTER_STEP"); return !(e && e[0] == '0'); }();
   if (!on) return;
   std::lock_guard<std::mutex> lk(g_ncv_mu);
@@ -900,20 +848,23 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
       const bool second = !first && k.Cout2 > 0 && k.uid2 == w->st->uid && k.offset2 == w->offset && k.Cout2 == (int)w->sizes[0] &&
                           k.Cin == (int)w->sizes[1] && w->sizes[2] == 1 && w->sizes[3] == 1;
       if (!first && !second) continue;
+      if (cnt == NCV_PACK_MAX) flush();
       const bf16_t* w1p = first ? w->ptr<bf16_t>() : kv.second.w1;
       const bf16_t* w2p = second ? w->ptr<bf16_t>() : kv.second.w2;
       a.w[cnt] = NcvW{w1p, k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw, k.Cout2 > 0 ? w2p : nullptr, k.Cout2};
       a.dst[cnt] = static_cast<nv_bf8*>(kv.second.packed->raw());
       done.push_back({k, w->st->version.load(std::memory_order_relaxed), second});
-      if (++cnt == NCV_PACK_MAX) flush();
+      cnt++;
     }
   }
-  flush();
+  if (fill && cnt > 0) { *fill = a; *fill_cnt = cnt; }
+  else flush();
   for (auto& d : done) {
     auto it = g_ncv_cache.find(d.k);
     if (it != g_ncv_cache.end()) { (d.second ? it->second.version2 : it->second.version) = d.version; it->second.tick = ++g_ncv_tick; }
   }
 }
+void narrow_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) { ncv_pack_launch(a, cnt, st); }
 
 // sibling (fprop, optional): a 1x1 convolution of the same input, same stride and output map, whose Cout2 channels fit beside w's in the
 // MFMA's 16 columns: both outputs from one launch of the aligned kernel (false, nothing launched, when that kernel does not take the pair)

@@ -14,7 +14,6 @@
 namespace lamp {
 
 void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   // conv_igemm.hip
-void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);  // conv_narrow.hip
 void igemm32_repack_cached(lamp_tensor* const* params, int n, hipStream_t st); // conv_igemm_f32.hip
 void small_repack_cached(lamp_tensor* const* params, int n, hipStream_t st);   // conv_small.hip
 
@@ -366,8 +365,7 @@ int lamp_adamw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp
       LAMP_LAUNCH_CHECK();
     }
   }
-  igemm_repack_cached(params, n, st);     // the convolution weights' packed images follow the update in one launch (conv_igemm.hip)
-  narrow_repack_cached(params, n, st);
+  igemm_repack_cached(params, n, st);     // the convolution weights' packed images follow the update in one launch (conv_igemm.hip; the narrow ones ride along)
   igemm32_repack_cached(params, n, st);
   small_repack_cached(params, n, st);
   LAMP_API_END
@@ -396,7 +394,6 @@ int lamp_sgdw_step_(lamp_tensor* const* params, lamp_tensor* const* grads, lamp_
       [&](MultiArgs& a, int blk) { hipLaunchKernelGGL((sgdw_kernel<T>), dim3(blk), dim3(256), 0, st, a); }));
   LAMP_LAUNCH_CHECK();
   igemm_repack_cached(params, n, st);
-  narrow_repack_cached(params, n, st);
   igemm32_repack_cached(params, n, st);
   small_repack_cached(params, n, st);
   LAMP_API_END
