@@ -1802,11 +1802,15 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   }
   __syncthreads();
   int cur = 0;
+  // (round 5) the second wave of every SIMD (waves 4 - 7) multiplies the pair's first image BEFORE it stores / requests the next pairs: while one
+  // wave of a SIMD is busy with LDS stores and load issue the other one has MFMAs to issue (LAMP_WGRAD_STAGGER=0 via `stream_out` bit 1: off)
+  const bool late = (wid >> 2) != 0 && !(stream_out & 2) && images_per_split >= 8;     // (with one or two pairs per workgroup the order only delays: B = 256 +2 us)
   for (int n = nbeg; n < nend; n += 2, cur ^= 1) {
     char* st = smem + cur * (2 * STG);
+    if (late) compute(st);
     if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG));      // nobody reads that stage since the last barrier
     if (n + 4 < nend) load_pair(ra, rx, n + 4);
-    compute(st);
+    if (!late) compute(st);
     compute(st + STG);
     lds_barrier();
   }
@@ -2280,12 +2284,13 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
       const bf16_t* dy2p = pair ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
       float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
       const int co2 = pair ? (int)second->g->Cout : 0;
+      static const bool wg_stagger = [] { const char* e = getenv("LAMP_WGRAD_STAGGER"); return !(e && e[0] == '0'); }();
 #define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
   do {                                                                                                                                      \
     allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_>);                                                                                 \
     hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),          \
-                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp, wgrad_reduce_deferred() ? 1 : 0,    \
-                       dy2p, p2p, co2);                                                                                                     \
+                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp,                                     \
+                       (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2), dy2p, p2p, co2);                                                                                                                                            \
   } while (0)
       if (pair) IG_LAUNCH_WG8H(2, true);
       else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
