@@ -1649,8 +1649,12 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wid >> 1, wc = wid & 1;                      // 32-channel block of co, 16-channel half of ci
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
-  for (int o = tid * 16; o < 4 * STG; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
-  __syncthreads();
+  // (the shifted X copies kept zero rows / columns that are never written again; with SHIFT_DY = 2 every byte that is read - the dY tiles, rows
+  // 1 .. 8 of the unshifted X copy - is written for every image, so nothing has to be cleared)
+  if (SHIFT_DY != 2) {
+    for (int o = tid * 16; o < 4 * STG; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
+    __syncthreads();
+  }
 
   const bool xthread = tid < 256;
   const int xci = (tid & 255) >> 3, xh = tid & 7;             // (channel, image row) of the X tile: threads 0..255
