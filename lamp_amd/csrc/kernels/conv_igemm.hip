@@ -1441,7 +1441,10 @@ constexpr int WG_STAGE = IG_WTILE + 3 * WG_XCOPY + 512;   // dY tile + 3 copies 
 // the whole Cin - so that dY is read ONCE instead of once per slice (128 -> 100: 139 -> 60 MB per launch, 33 -> ~15 us).
 // PAIR (round 5, 3x3 with one Cin slice per workgroup): the output gradient dy2 [N][CO2][64] of a sibling 1x1 convolution of the same x is staged
 // behind the X copies and its weight gradient (the centre-tap product) accumulates in four more tiles: partial2[split][COP2][CIP].
-template <int KS, bool NARROW, int CIT, bool PAIR = false>
+// CI16 (round 5): a partial-sum tile of 16 input-channel columns (Cin <= 16).  The default wave layout - two halves of the output channels x two
+// halves of the 32 columns - leaves the waves of the second column half multiplying padding; here the four waves own 32 output channels each:
+// half the MFMAs per wave, all of them real.
+template <int KS, bool NARROW, int CIT, bool PAIR = false, bool CI16 = false>
 __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                           int N, int CO, int CI, int CIP, int images_per_split, int COP, int ntile,
                                                           const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2, int COP2) {
@@ -1463,7 +1466,9 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
   constexpr int STAGE1 = IG_WTILE + (CIT > 1 ? CIT * WG_XCOPY : 3 * WG_XCOPY) + 512;  // dY tile + X copies
   constexpr int STAGE = STAGE1 + (PAIR ? IG_WTILE : 0);                               // (+ the sibling's dY tile); host: 2 * this
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
+  constexpr int NI = CI16 ? 2 : 4;                           // output-channel tiles of 16 per wave
+  const int wr = CI16 ? wid : wid >> 1, wc = CI16 ? 0 : wid & 1;
+  const int co_w = wr * (NI * 16);                            // this wave's first output channel
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
   // zero both stages once: the padding rows of the shifted copies are never written again
   for (int o = tid * 16; o < 2 * STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
@@ -1483,27 +1488,27 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     *reinterpret_cast<uint4*>(xb + WG_XCOPY) = v;
   };
 
-  f4v acc[CIT][RS][4];
+  f4v acc[CIT][RS][NI];
 #pragma unroll
   for (int ct = 0; ct < CIT; ct++)
 #pragma unroll
     for (int t = 0; t < RS; t++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) acc[ct][t][i] = f4v{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NI; i++) acc[ct][t][i] = f4v{0.f, 0.f, 0.f, 0.f};
   // Narrow layers (at most 64 output or 16 input channels): output-channel tiles at or beyond COP = round16(CO) and the second
   // 16-column half when CIP = 16 hold only padding - they are not written, and the partial sums are [COP][CIP] per tap instead of
   // [128][32] (16 -> 16: 2.4 MB of partials per launch instead of 37.7 MB).  They ARE still multiplied: uniform branches inside the
   // MFMA chain made the kernel 25 - 50 % slower (measured), and skipping the tiles did not make the narrow layers faster either
   const bool col_active = ci0 + wc * 16 < CIP;
-  bool tile_active[4];
+  bool tile_active[NI];
 #pragma unroll
-  for (int i = 0; i < 4; i++) tile_active[i] = col_active && (wr * 64 + i * 16 < COP);
+  for (int i = 0; i < NI; i++) tile_active[i] = col_active && (co_w + i * 16 < COP);
 
   uint4 ra[4], rx[CIT], rb[PAIR ? 4 : 1];
-  f4v acc2[PAIR ? 4 : 1];
+  f4v acc2[PAIR ? NI : 1];
   if constexpr (PAIR) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc2[i] = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; i++) acc2[i] = f4v{0.f, 0.f, 0.f, 0.f};
   }
   if (nbeg < nend) {
     ig_stage_load_rows(ra, dy + (int64_t)nbeg * CO * 64, 64, 0, CO, 64, tid);
@@ -1528,9 +1533,9 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
     const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      bf8v fa[4];
+      bf8v fa[NI];
 #pragma unroll
-      for (int i = 0; i < 4; i++) fa[i] = ig_frag_rows(st, wr * 64 + i * 16, ks, lane);
+      for (int i = 0; i < NI; i++) fa[i] = ig_frag_rows(st, co_w + i * 16, ks, lane);
       const int h = 4 * ks + (lane >> 4);
 #pragma unroll
       for (int ct = 0; ct < CIT; ct++) {
@@ -1546,12 +1551,12 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
                                       : u4v_{(xc[0] >> 16) | (xc[1] << 16), (xc[1] >> 16) | (xc[2] << 16), (xc[2] >> 16) | (xc[3] << 16), xc[3] >> 16};
               const bf8v fb = __builtin_bit_cast(bf8v, sh);
 #pragma unroll
-              for (int i = 0; i < 4; i++) acc[ct][r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][r * KS + s_][i], 0, 0, 0);
+              for (int i = 0; i < NI; i++) acc[ct][r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][r * KS + s_][i], 0, 0, 0);
               if constexpr (PAIR) {
                 if (r == PAD && s_ == PAD) {                // the centre tap: the sibling's product on the same X fragment
 #pragma unroll
-                  for (int i = 0; i < 4; i++)
-                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ig_frag_rows(st + STAGE1, wr * 64 + i * 16, ks, lane), fb, acc2[i], 0, 0, 0);
+                  for (int i = 0; i < NI; i++)
+                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ig_frag_rows(st + STAGE1, co_w + i * 16, ks, lane), fb, acc2[i], 0, 0, 0);
                 }
               }
             }
@@ -1563,7 +1568,7 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
             s8v v = *reinterpret_cast<const s8v*>(xl + ct * WG_CI * WG_XCH + s * WG_XCOPY + (h + r + (1 - PAD)) * 16);
             const bf8v fb = __builtin_bit_cast(bf8v, v);
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[ct][t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][t][i], 0, 0, 0);
+            for (int i = 0; i < NI; i++) acc[ct][t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[ct][t][i], 0, 0, 0);
           }
         }
       }
@@ -1580,11 +1585,11 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
   if constexpr (PAIR) {
     float* out2 = partial2 + (int64_t)split * COP2 * CIP;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (col_active && wr * 64 + i * 16 < COP2) {
+    for (int i = 0; i < NI; i++)
+      if (col_active && co_w + i * 16 < COP2) {
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
+          const int co = co_w + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + wc * 16 + (lane & 15);
           if (co < CO2 && ci < CI) out2[co * CIP + ci] = acc2[i][rr];
         }
       }
@@ -1596,11 +1601,11 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 #pragma unroll
     for (int ct = 0; ct < CIT; ct++)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NI; i++)
         if (!NARROW || tile_active[i]) {
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
-            const int co = wr * 64 + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + ct * WG_CI + wc * 16 + (lane & 15);
+            const int co = co_w + i * 16 + (lane >> 4) * 4 + rr, ci = ci0 + ct * WG_CI + wc * 16 + (lane & 15);
             if (co < CO && ci < CI) out[co * CIP + ci] = acc[ct][t][i][rr];   // the reduction skips the padding too
           }
         }
@@ -2340,7 +2345,10 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
       const double sec_fl = pair ? conv_flops(*second->g) : 0.0;
       const double sec_by = pair ? conv_bytes(*second->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;
       KernelTimer kt("conv_wgrad_igemm", conv_flops(g) + sec_fl, conv_bytes(g, 2) + sec_by, st);
-      const void* kfn = pair    ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1, true> : (const void*)ig_wgrad8v2_kernel<3, false, 1, true>)
+      static const bool ci16_on = [] { const char* e = getenv("LAMP_WGRAD_CI16"); return !(e && e[0] == '0'); }();
+      const bool ci16 = ci16_on && KS == 3 && CIP == 16;           // (then `narrow` holds: Cin <= 16)
+      const void* kfn = ci16    ? (pair ? (const void*)ig_wgrad8v2_kernel<3, true, 1, true, true> : (const void*)ig_wgrad8v2_kernel<3, true, 1, false, true>)
+                      : pair    ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1, true> : (const void*)ig_wgrad8v2_kernel<3, false, 1, true>)
                       : KS == 3 ? (narrow ? (const void*)ig_wgrad8v2_kernel<3, true, 1> : (const void*)ig_wgrad8v2_kernel<3, false, 1>)
                       : all_ci  ? (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 4> : (const void*)ig_wgrad8v2_kernel<1, false, 4>)
                                 : (narrow ? (const void*)ig_wgrad8v2_kernel<1, true, 1> : (const void*)ig_wgrad8v2_kernel<1, false, 1>);
