@@ -967,9 +967,19 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       __builtin_amdgcn_global_load_lds((glb_char_t*)(reinterpret_cast<const char*>(wimg + (int64_t)rs1 * IG_M * KP) + d_srcw),
                                        (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
   };
+  // ... and with ONE chunk (at most 32 input channels: the 16 -> 16 layers) a stage is FOUR taps (wave w requests tap 4 g + w): three stages
+  // instead of nine for a 3x3
+  const bool taps4 = WIDE && !DG2 && KC == 1 && RS > 1;
+  auto stage_dma_t = [&](int g, int slot) {
+    const int tap = 4 * g + wid;
+    if (wid < 4 && tap < RS)
+      __builtin_amdgcn_global_load_lds((glb_char_t*)(reinterpret_cast<const char*>(wp + (int64_t)tap * IG_M * KP) + (d_srcw - (unsigned)(wid * 32) * 2u)),
+                                       (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+  };
   IG_STAMP(0);
   if constexpr (WIDE) {
-    if (DG2) { stage_dma_w(sib.wp, 0, 0); stage_dma_w(wp, 0, 1); }
+    if (taps4) { stage_dma_t(0, 0); stage_dma_t(1, 1); }
+    else if (DG2) { stage_dma_w(sib.wp, 0, 0); stage_dma_w(wp, 0, 1); }
     else { stage_dma_w(wp, 0, 0); if (RS > 1) stage_dma_w(wp, 1, 1); }
   } else if (SIB || DG2) {                    // the sibling's stages (one tap: stage = 32-channel chunk) come first
     stage_dma_of(sib.wp, 0, 0, 0);
@@ -1104,6 +1114,57 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       __builtin_amdgcn_s_setprio(0);
     };
     int slot = 0;
+    if (taps4) {
+      // ---- one chunk: stages of four taps
+      constexpr int NG = (RS + 3) / 4;
+      if (grp == 1) __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (g + 2 < NG) stage_dma_t(g + 2, slot2);
+        const char* wl = Wl + slot * WT + a_off;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const int tap = 4 * g + p;
+          if (tap < RS) {
+            const int r = tap / KS, s_ = tap - r * KS;
+            fw[p] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + p * 1024));
+            const char* xb = Xl + va[r & 1][s_];
+#pragma unroll
+            for (int j = 0; j < 4; j++) fx[p][j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + ((r * 8 + s_) + 16 * j) * RB));
+          }
+        }
+        if (g + 2 < NG) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (KS == 3) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const int tap = 4 * g + p;
+            if (tap < RS) {
+              const int r = tap / KS, s_ = tap - r * KS;
+              const bool colout = (s_ == 0 && col_lo) || (s_ == 2 && col_hi);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const bool out = colout || (r == 0 && j == 0 && row_lo) || (r == 2 && j == 3 && row_hi);
+                if (s_ != 1 || (r == 0 && j == 0) || (r == 2 && j == 3)) fx[p][j] = out ? zero8 : fx[p][j];
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+          if (4 * g + p < RS) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[p][j], fw[p], acc[0][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        slot = slot1;
+      }
+      if (grp == 0) __builtin_amdgcn_s_barrier();            // every READ phase of every wave is over: LDS is free
+    } else {
     if constexpr (DG2) {
       if (grp == 1) __builtin_amdgcn_s_barrier();
       if (RS > 1) stage_dma_w(wp, 1, 2);                     // (stage 0 of this convolution sits in slot 1 already)
@@ -1134,6 +1195,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       slot = slot1;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();              // every READ phase of every wave is over: LDS is free
+    }
   } else {
   if constexpr (SIB || DG2) {
     // ---- sibling product: KC stages of the centre tap, same ring and phases
