@@ -1715,6 +1715,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wid >> 1, wc = wid & 1;                      // 32-channel block of co, 16-channel half of ci
+  // SHIFT_DY = 2: the wave's tile is 16 co x 32 ci instead (wave = co block, both ci halves): 3 dY fragments and 2 X fragments serve the
+  // 18 MFMAs of a k-step - 5 LDS reads instead of 6 + 1 (the LDS pipe: 640 + 288 cycles per image instead of 896 + 288, next to 1152 MFMA cycles)
+  constexpr bool W16 = SHIFT_DY == 2;
   const int nbeg = split * images_per_split, nend = min(nbeg + images_per_split, N);
   // (the shifted X copies kept zero rows / columns that are never written again; with SHIFT_DY = 2 every byte that is read - the dY tiles, rows
   // 1 .. 8 of the unshifted X copy - is written for every image, so nothing has to be cleared)
@@ -1781,6 +1784,46 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // at the same time, so the matrix pipe idled 58 % of the loop.  (The barrier is a raw s_barrier behind lgkmcnt(0): __syncthreads()
   // would drain vmcnt and with it the prefetch.)
   auto compute = [&](const char* st) {
+    if constexpr (W16) {
+      typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
+      const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
+      const char* xrow = st + XC + (lane & 15) * WG_XCH;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const int h = 4 * ks + (lane >> 4);                   // image row of this lane group's eight k
+        bf8v fa[KS];
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          const int hr = h - (r - PAD);                       // the dY row that meets X row h under filter row r
+          const bool inside = hr >= 0 && hr < 8;
+          const s8v v = *reinterpret_cast<const s8v*>(st + ig_kc_off(wid * 16 + (lane & 15), inside ? hr : h));
+          fa[r] = inside ? __builtin_bit_cast(bf8v, v) : zero8;
+        }
+        u4v_ xc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) xc[i] = *reinterpret_cast<const u4v_*>(xrow + i * 16 * WG_XCH + (h + 1) * 16);
+        if constexpr (PAIR) {
+          const s8v v2 = *reinterpret_cast<const s8v*>(st + IG_WTILE + ig_kc_off(wid * 16 + (lane & 15), h));
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, xc[i]), __builtin_bit_cast(bf8v, v2), acc2[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < KS; s_++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const u4v_ c = xc[i];
+            const u4v_ sh = s_ == 0 ? u4v_{c[0] << 16, (c[1] << 16) | (c[0] >> 16), (c[2] << 16) | (c[1] >> 16), (c[3] << 16) | (c[2] >> 16)}
+                          : s_ == 1 ? c
+                                    : u4v_{(c[0] >> 16) | (c[1] << 16), (c[1] >> 16) | (c[2] << 16), (c[2] >> 16) | (c[3] << 16), c[3] >> 16};
+            const bf8v fb = __builtin_bit_cast(bf8v, sh);
+#pragma unroll
+            // X is the A operand: the lane then holds FOUR CONSECUTIVE ci of one co - the partial sums leave as 16-byte stores (18 per lane, not 72)
+            for (int r = 0; r < KS; r++) acc[r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[r], acc[r * KS + s_][i], 0, 0, 0);
+          }
+      }
+      return;
+    }
     const char* xl = st + (SHIFT_DY == 2 ? XC - WG_XCOPY : IG_WTILE) + (wc * 16 + (lane & 15)) * WG_XCH;   // (xl + WG_XCOPY = the unshifted copy)
     if (SHIFT_DY) {
       const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
@@ -1884,6 +1927,28 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
     if (!late) compute(st);
     compute(st + STG);
     lds_barrier();
+  }
+  if constexpr (W16) {
+    // acc[t][i] = [16 ci of half i (rows: 4 consecutive per lane)][16 co (lane & 15)]; columns ci >= CI of a row are padding the reduction never reads
+    const int co = wid * 16 + (lane & 15);
+    if constexpr (PAIR) {
+      float* out2 = partial2 + (int64_t)split * IG_M * CIP;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int ci = ci0 + i * 16 + (lane >> 4) * 4;
+        if (co < CO2 && ci < CI) __builtin_nontemporal_store(acc2[i], reinterpret_cast<f4v*>(&out2[co * CIP + ci]));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RS; t++) {
+      float* out = partial + (int64_t)(split * RS + t) * IG_M * CIP;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int ci = ci0 + i * 16 + (lane >> 4) * 4;
+        if (co < CO && ci < CI) __builtin_nontemporal_store(acc[t][i], reinterpret_cast<f4v*>(&out[co * CIP + ci]));
+      }
+    }
+    return;
   }
   if constexpr (PAIR) {
     // the sibling's block: partial2[split][128][CIP]
