@@ -1694,6 +1694,12 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // two shifted X copies no longer need holds it: 2 x 16 KiB + 5.5 KiB per image), and its weight gradient [CO2][CI] - the centre-tap product
 // dy2 . x - accumulates in 8 more registers per lane: 2 more fragment reads and 2 more MFMAs per k-step (18 -> 20) instead of a launch of its own
 // that reads x again.  partial2[split][128][CIP].
+#ifdef LAMP_WG8H_STAMPS
+__device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
+#endif
+#ifndef LAMP_WG8H_PIPE
+#define LAMP_WG8H_PIPE 1
+#endif
 template <int SHIFT_DY, bool PAIR = false>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
@@ -1702,6 +1708,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // stage layout: [dY tile | X copies ...] or, PAIR, [dY tile | dY2 tile | X]; XC = offset of the unshifted X copy
   constexpr int XC = PAIR ? 2 * IG_WTILE : IG_WTILE + WG_XCOPY;
   constexpr int STG = PAIR ? 2 * IG_WTILE + WG_XCOPY + 512 : WG_STAGE;
+  constexpr int ZSLOT = STG - 512;                          // 16 zero bytes per image stage (in the padding; SHIFT_DY = 2 reads them for dY rows outside the image)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 3, RS = 9, PAD = 1;
   const int nsplit = gridDim.x / ntile;
@@ -1724,6 +1731,8 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   if (SHIFT_DY != 2) {
     for (int o = tid * 16; o < 4 * STG; o += 512 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);   // 2 stages x 2 images
     __syncthreads();
+  } else if (tid < 4) {
+    *reinterpret_cast<uint4*>(smem + tid * STG + ZSLOT) = make_uint4(0, 0, 0, 0);   // (the barrier behind the first pair's stores publishes it)
   }
 
   const bool xthread = tid < 256;
@@ -1735,6 +1744,17 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
       return *reinterpret_cast<const uint4*>(x + ((int64_t)n * CI + ci0 + xci) * 64 + xh * 8);
     }
     return make_uint4(0, 0, 0, 0);
+  };
+  // W16: the X tiles of a PAIR of images are 512 packets - one per thread (image tid >> 8), requested without a branch: channels beyond CI read
+  // channel CI - 1 (accumulator rows that are never stored), an image beyond nend reads image nend - 1 (its dY is stored as zeros)
+  const int xim = tid >> 8, xcc = min(ci0 + xci, CI - 1);
+  const float4 aff2 = affine ? affine[xcc] : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_x2 = [&](int n) -> uint4 {
+    return *reinterpret_cast<const uint4*>(x + ((int64_t)min(n + xim, nend - 1) * CI + xcc) * 64 + xh * 8);
+  };
+  auto store_x2 = [&](char* stage, uint4 v) {
+    if (affine) v = ig_bn_relu_x8(v, aff2.x, aff2.y, aff2.z);
+    *reinterpret_cast<uint4*>(stage + xim * STG + XC + xci * WG_XCH + (xh + 1) * 16) = v;
   };
   auto store_x = [&](char* stage, uint4 v) {                  // copy s holds out[w] = in[w + s - 1]
     if (!xthread) return;
@@ -1753,7 +1773,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int c = tid + i * 512, gr = c >> 3;
-      r[i] = gr < CO ? nt_load16(reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3))) : make_uint4(0, 0, 0, 0);   // dY's last reader
+      // (W16: rows beyond CO load row CO - 1 again - they only reach accumulator columns that are never stored - so the request needs no branch)
+      if constexpr (W16) r[i] = nt_load16(reinterpret_cast<const uint4*>(base + min(gr, CO - 1) * 64 + ((c & 7) << 3)));
+      else r[i] = gr < CO ? nt_load16(reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3))) : make_uint4(0, 0, 0, 0);   // dY's last reader
     }
   };
   auto store_dy = [&](const uint4 (&r)[2], char* stage) {
@@ -1765,7 +1787,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int c = tid + i * 512, gr = c >> 3;
-      r[i] = gr < CO2 ? nt_load16(reinterpret_cast<const uint4*>(base + gr * 64 + ((c & 7) << 3))) : make_uint4(0, 0, 0, 0);
+      r[i] = nt_load16(reinterpret_cast<const uint4*>(base + min(gr, CO2 - 1) * 64 + ((c & 7) << 3)));   // (PAIR implies W16: as above)
     }
   };
 
@@ -1892,6 +1914,16 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // images at or beyond nend load as zeros (an odd image count: the missing partner contributes nothing)
   uint4 rb[PAIR ? 2 : 1][2];                                 // PAIR: the sibling's dY packets of the pair in flight
   auto load_pair = [&](uint4 (&ra_)[2][2], uint4 (&rx_)[2], int n) {
+    if constexpr (W16) {
+#pragma unroll
+      for (int im = 0; im < 2; im++) {
+        const int nn = min(n + im, nend - 1);
+        load_dy(ra_[im], nn);
+        if constexpr (PAIR) load_dy2(rb[im], nn);
+      }
+      rx_[0] = load_x2(n);
+      return;
+    }
 #pragma unroll
     for (int im = 0; im < 2; im++) {
       if (n + im < nend) { load_dy(ra_[im], n + im); rx_[im] = load_x(n + im); if constexpr (PAIR) load_dy2(rb[im], n + im); }
@@ -1901,7 +1933,20 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
       }
     }
   };
-  auto store_pair = [&](const uint4 (&ra_)[2][2], const uint4 (&rx_)[2], char* stage) {
+  auto store_pair = [&](const uint4 (&ra_)[2][2], const uint4 (&rx_)[2], char* stage, int n) {
+    if constexpr (W16) {
+#pragma unroll
+      for (int im = 0; im < 2; im++) {
+        const bool live = n + im < nend;                    // (uniform) the missing partner of an odd image count: zeros
+        // (component selects: a ?: between two uint4 objects selects ADDRESSES and sends the register arrays to scratch memory)
+        auto keep = [live](const uint4& v) { return make_uint4(live ? v.x : 0u, live ? v.y : 0u, live ? v.z : 0u, live ? v.w : 0u); };
+        const uint4 t[2] = {keep(ra_[im][0]), keep(ra_[im][1])};
+        store_dy(t, stage + im * STG);
+        if constexpr (PAIR) { const uint4 t2[2] = {keep(rb[im][0]), keep(rb[im][1])}; store_dy(t2, stage + im * STG + IG_WTILE); }
+      }
+      store_x2(stage, rx_[0]);
+      return;
+    }
 #pragma unroll
     for (int im = 0; im < 2; im++) {
       store_dy(ra_[im], stage + im * STG); store_x(stage + im * STG, rx_[im]);
@@ -1911,7 +1956,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   uint4 ra[2][2], rx[2];
   if (nbeg < nend) {
     load_pair(ra, rx, nbeg);
-    store_pair(ra, rx, smem);
+    store_pair(ra, rx, smem, nbeg);
     if (nbeg + 2 < nend) load_pair(ra, rx, nbeg + 2);
   }
   __syncthreads();
@@ -1919,15 +1964,102 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // (round 5) the second wave of every SIMD (waves 4 - 7) multiplies the pair's first image BEFORE it stores / requests the next pairs: while one
   // wave of a SIMD is busy with LDS stores and load issue the other one has MFMAs to issue (LAMP_WGRAD_STAGGER=0 via `stream_out` bit 1: off)
   const bool late = (wid >> 2) != 0 && !(stream_out & 2) && images_per_split >= 8;     // (with one or two pairs per workgroup the order only delays: B = 256 +2 us)
+  const bool prio = (stream_out & 4) != 0;
+#ifdef LAMP_WG8H_STAMPS
+  unsigned int stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+  const unsigned int stamp_begin = (unsigned int)__builtin_amdgcn_s_memtime();
+#define WG8H_STAMP(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime(); \
+    if (k) stamp_sum[k] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define WG8H_STAMP(k) do { } while (0)
+#endif
+  // W16: the pair's four k-steps as a pipeline - the fragments of k-step j + 1 are requested before the MFMAs of k-step j are issued (two sets of
+  // 20 / 24 registers), so one LDS latency per pair is exposed instead of four.  In-kernel clocks of the unpipelined loop: a wave alone on its SIMD's
+  // matrix pipe needed 1110 ticks for the 36 MFMAs of an image (~440 ticks of issue) - two exposed fragment reads per image.
+  struct Frag { bf8v fa[KS]; unsigned int xc[2][4]; bf8v d2; };
+  auto rd = [&](Frag& f, const char* st, int ks) {
+    const int h = 4 * ks + (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const int hr = h - (r - PAD);
+      const bool inside = hr >= 0 && hr < 8;
+      // a dY row outside the image: the lane reads the stage's zero slot instead (an address chosen once, outside the loop - a select per
+      // register here would take the vector issue slots the MFMAs leave: 2 per MFMA for both waves of the SIMD together)
+      f.fa[r] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(st + (inside ? ig_kc_off(wid * 16 + (lane & 15), hr) : ZSLOT)));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint4 v = *reinterpret_cast<const uint4*>(st + XC + (i * 16 + (lane & 15)) * WG_XCH + (h + 1) * 16);
+      f.xc[i][0] = v.x; f.xc[i][1] = v.y; f.xc[i][2] = v.z; f.xc[i][3] = v.w;
+    }
+    if constexpr (PAIR) f.d2 = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(st + IG_WTILE + ig_kc_off(wid * 16 + (lane & 15), h)));
+  };
+  auto mul = [&](const Frag& f) {
+    typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const u4v_ c = u4v_{f.xc[i][0], f.xc[i][1], f.xc[i][2], f.xc[i][3]};
+      if constexpr (PAIR) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, c), f.d2, acc2[i], 0, 0, 0);
+#pragma unroll
+      for (int s_ = 0; s_ < KS; s_++) {
+        const u4v_ sh = s_ == 0 ? u4v_{c[0] << 16, (c[1] << 16) | (c[0] >> 16), (c[2] << 16) | (c[1] >> 16), (c[3] << 16) | (c[2] >> 16)}
+                      : s_ == 1 ? c
+                                : u4v_{(c[0] >> 16) | (c[1] << 16), (c[1] >> 16) | (c[2] << 16), (c[2] >> 16) | (c[3] << 16), c[3] >> 16};
+        const bf8v fb = __builtin_bit_cast(bf8v, sh);
+#pragma unroll
+        for (int r = 0; r < KS; r++) acc[r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, f.fa[r], acc[r * KS + s_][i], 0, 0, 0);
+      }
+    }
+  };
+#define WG8H_SB() __builtin_amdgcn_sched_barrier(0)
   for (int n = nbeg; n < nend; n += 2, cur ^= 1) {
     char* st = smem + cur * (2 * STG);
-    if (late) compute(st);
-    if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG));      // nobody reads that stage since the last barrier
+    WG8H_STAMP(0);
+    if constexpr (W16 && LAMP_WG8H_PIPE) {
+      Frag f0, f1;
+      if (late) {
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        rd(f0, st, 0); rd(f1, st, 1); WG8H_SB(); mul(f0); WG8H_SB(); rd(f0, st + STG, 0); WG8H_SB(); mul(f1); WG8H_SB();
+        if (prio) __builtin_amdgcn_s_setprio(0);
+      }
+      WG8H_STAMP(1);
+      if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG), n + 2);      // nobody reads that stage since the last barrier
+      WG8H_STAMP(2);
+      if (n + 4 < nend) load_pair(ra, rx, n + 4);
+      WG8H_STAMP(3);
+      if (prio) __builtin_amdgcn_s_setprio(2);
+      if (!late) { rd(f0, st, 0); rd(f1, st, 1); WG8H_SB(); mul(f0); WG8H_SB(); rd(f0, st + STG, 0); WG8H_SB(); mul(f1); WG8H_SB(); }
+      WG8H_STAMP(4);
+      rd(f1, st + STG, 1); WG8H_SB(); mul(f0); WG8H_SB(); mul(f1);
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      WG8H_STAMP(5);
+      lds_barrier();
+      WG8H_STAMP(6);
+      continue;
+    }
+    if (late) { if (prio) __builtin_amdgcn_s_setprio(2); compute(st); if (prio) __builtin_amdgcn_s_setprio(0); }
+    WG8H_STAMP(1);
+    if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG), n + 2);      // nobody reads that stage since the last barrier
+    WG8H_STAMP(2);
     if (n + 4 < nend) load_pair(ra, rx, n + 4);
+    WG8H_STAMP(3);
+    if (prio) __builtin_amdgcn_s_setprio(2);
     if (!late) compute(st);
+    WG8H_STAMP(4);
     compute(st + STG);
+    if (prio) __builtin_amdgcn_s_setprio(0);
+    WG8H_STAMP(5);
     lds_barrier();
+    WG8H_STAMP(6);
   }
+#ifdef LAMP_WG8H_STAMPS
+  if (lane == 0) {
+    unsigned int* o = g_wg8h_stamps + (blockIdx.x * 8 + wid) * 8;
+    for (int k = 1; k < 7; k++) o[k] = stamp_sum[k];
+    o[0] = stamp_last - stamp_begin;                       // the loop
+    o[7] = (unsigned int)__builtin_amdgcn_s_memtime() - stamp_begin;
+  }
+#endif
   if constexpr (W16) {
     // acc[t][i] = [16 ci of half i (rows: 4 consecutive per lane)][16 co (lane & 15)]; columns ci >= CI of a row are padding the reduction never reads
     const int co = wid * 16 + (lane & 15);
@@ -2421,12 +2553,13 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
       float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
       const int co2 = pair ? (int)second->g->Cout : 0;
       static const bool wg_stagger = [] { const char* e = getenv("LAMP_WGRAD_STAGGER"); return !(e && e[0] == '0'); }();
+      static const bool wg_prio = [] { const char* e = getenv("LAMP_WGRAD_PRIO"); return !(e && e[0] == '0'); }();
 #define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
   do {                                                                                                                                      \
     allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_>);                                                                                 \
     hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),          \
                        partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp,                                     \
-                       (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2), dy2p, p2p, co2);                                                                                                                                            \
+                       (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2) | (wg_prio ? 4 : 0), dy2p, p2p, co2);                                                                                                                                            \
   } while (0)
       if (pair) IG_LAUNCH_WG8H(2, true);
       else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
@@ -2522,3 +2655,10 @@ bool igemm_conv_wgrad_pair(const Tensor* dy, const Tensor* dy1, const Tensor* x,
 }
 
 }  // namespace lamp
+
+#ifdef LAMP_WG8H_STAMPS
+extern "C" int lamp_debug_wg8h_stamps(unsigned int* out, int n) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lamp::g_wg8h_stamps), (size_t)n * 4);
+}
+#endif
