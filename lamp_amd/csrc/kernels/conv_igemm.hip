@@ -1697,9 +1697,6 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 #ifdef LAMP_WG8H_STAMPS
 __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #endif
-#ifndef LAMP_WG8H_PIPE
-#define LAMP_WG8H_PIPE 1
-#endif
 template <int SHIFT_DY, bool PAIR = false>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
@@ -1805,48 +1802,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   // 1060 multiplying (the matrix pipe's share), 546 storing, 482 at the barrier, 430 issuing loads - every wave in the same phase
   // at the same time, so the matrix pipe idled 58 % of the loop.  (The barrier is a raw s_barrier behind lgkmcnt(0): __syncthreads()
   // would drain vmcnt and with it the prefetch.)
+  // (SHIFT_DY = 0 / 1 only - the A/B forms kept behind LAMP_WGRAD_SHIFT_DY; SHIFT_DY = 2 multiplies through rd() / mul() below)
   auto compute = [&](const char* st) {
-    if constexpr (W16) {
-      typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
-      const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
-      const char* xrow = st + XC + (lane & 15) * WG_XCH;
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const int h = 4 * ks + (lane >> 4);                   // image row of this lane group's eight k
-        bf8v fa[KS];
-#pragma unroll
-        for (int r = 0; r < KS; r++) {
-          const int hr = h - (r - PAD);                       // the dY row that meets X row h under filter row r
-          const bool inside = hr >= 0 && hr < 8;
-          const s8v v = *reinterpret_cast<const s8v*>(st + ig_kc_off(wid * 16 + (lane & 15), inside ? hr : h));
-          fa[r] = inside ? __builtin_bit_cast(bf8v, v) : zero8;
-        }
-        u4v_ xc[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) xc[i] = *reinterpret_cast<const u4v_*>(xrow + i * 16 * WG_XCH + (h + 1) * 16);
-        if constexpr (PAIR) {
-          const s8v v2 = *reinterpret_cast<const s8v*>(st + IG_WTILE + ig_kc_off(wid * 16 + (lane & 15), h));
-#pragma unroll
-          for (int i = 0; i < 2; i++)
-            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, xc[i]), __builtin_bit_cast(bf8v, v2), acc2[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < KS; s_++)
-#pragma unroll
-          for (int i = 0; i < 2; i++) {
-            const u4v_ c = xc[i];
-            const u4v_ sh = s_ == 0 ? u4v_{c[0] << 16, (c[1] << 16) | (c[0] >> 16), (c[2] << 16) | (c[1] >> 16), (c[3] << 16) | (c[2] >> 16)}
-                          : s_ == 1 ? c
-                                    : u4v_{(c[0] >> 16) | (c[1] << 16), (c[1] >> 16) | (c[2] << 16), (c[2] >> 16) | (c[3] << 16), c[3] >> 16};
-            const bf8v fb = __builtin_bit_cast(bf8v, sh);
-#pragma unroll
-            // X is the A operand: the lane then holds FOUR CONSECUTIVE ci of one co - the partial sums leave as 16-byte stores (18 per lane, not 72)
-            for (int r = 0; r < KS; r++) acc[r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[r], acc[r * KS + s_][i], 0, 0, 0);
-          }
-      }
-      return;
-    }
-    const char* xl = st + (SHIFT_DY == 2 ? XC - WG_XCOPY : IG_WTILE) + (wc * 16 + (lane & 15)) * WG_XCH;   // (xl + WG_XCOPY = the unshifted copy)
+    const char* xl = st + IG_WTILE + (wc * 16 + (lane & 15)) * WG_XCH;   // (xl + WG_XCOPY = the unshifted copy)
     if (SHIFT_DY) {
       const bf8v zero8 = __builtin_bit_cast(bf8v, s8v{0, 0, 0, 0, 0, 0, 0, 0});
 #pragma unroll
@@ -1864,27 +1822,9 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
             fa[r][i] = inside ? __builtin_bit_cast(bf8v, v) : zero8;
           }
         }
-        typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
-        const u4v_ xc = SHIFT_DY == 2 ? *reinterpret_cast<const u4v_*>(xl + WG_XCOPY + (h + 1) * 16) : u4v_{0u, 0u, 0u, 0u};
-        if constexpr (PAIR) {
-          const bf8v fbc = __builtin_bit_cast(bf8v, xc);
-#pragma unroll
-          for (int i = 0; i < 2; i++) {
-            const s8v v2 = *reinterpret_cast<const s8v*>(st + IG_WTILE + ig_kc_off(wq * 32 + i * 16 + (lane & 15), h));
-            acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, v2), fbc, acc2[i], 0, 0, 0);
-          }
-        }
 #pragma unroll
         for (int s_ = 0; s_ < KS; s_++) {
-          s8v v;
-          if (SHIFT_DY == 2) {
-            const u4v_ sh = s_ == 0 ? u4v_{xc[0] << 16, (xc[1] << 16) | (xc[0] >> 16), (xc[2] << 16) | (xc[1] >> 16), (xc[3] << 16) | (xc[2] >> 16)}
-                          : s_ == 1 ? xc
-                                    : u4v_{(xc[0] >> 16) | (xc[1] << 16), (xc[1] >> 16) | (xc[2] << 16), (xc[2] >> 16) | (xc[3] << 16), xc[3] >> 16};
-            v = __builtin_bit_cast(s8v, sh);
-          } else {
-            v = *reinterpret_cast<const s8v*>(xl + s_ * WG_XCOPY + (h + 1) * 16);   // X row h itself (rows sit one slot down: the zero row above the image)
-          }
+          const s8v v = *reinterpret_cast<const s8v*>(xl + s_ * WG_XCOPY + (h + 1) * 16);   // X row h itself (rows sit one slot down: the zero row above the image)
           const bf8v fb = __builtin_bit_cast(bf8v, v);
 #pragma unroll
           for (int r = 0; r < KS; r++)
@@ -1996,26 +1936,36 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   };
   auto mul = [&](const Frag& f) {
     typedef unsigned int u4v_ __attribute__((ext_vector_type(4)));
+    // the centre column's six MFMAs need no shifted fragment: they are issued first, and the shifts / permutes of the other two columns are
+    // spread between MFMAs (two vector instructions fit in the issue slots an MFMA leaves; a clump of eight in front of them drains the pipe)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const bf8v fc = __builtin_bit_cast(bf8v, u4v_{f.xc[i][0], f.xc[i][1], f.xc[i][2], f.xc[i][3]});
+      if constexpr (PAIR) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc, f.d2, acc2[i], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < KS; r++) acc[r * KS + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc, f.fa[r], acc[r * KS + 1][i], 0, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const u4v_ c = u4v_{f.xc[i][0], f.xc[i][1], f.xc[i][2], f.xc[i][3]};
-      if constexpr (PAIR) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, c), f.d2, acc2[i], 0, 0, 0);
 #pragma unroll
-      for (int s_ = 0; s_ < KS; s_++) {
+      for (int s_ = 0; s_ < KS; s_ += 2) {
         const u4v_ sh = s_ == 0 ? u4v_{c[0] << 16, (c[1] << 16) | (c[0] >> 16), (c[2] << 16) | (c[1] >> 16), (c[3] << 16) | (c[2] >> 16)}
-                      : s_ == 1 ? c
                                 : u4v_{(c[0] >> 16) | (c[1] << 16), (c[1] >> 16) | (c[2] << 16), (c[2] >> 16) | (c[3] << 16), c[3] >> 16};
         const bf8v fb = __builtin_bit_cast(bf8v, sh);
 #pragma unroll
         for (int r = 0; r < KS; r++) acc[r * KS + s_][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, f.fa[r], acc[r * KS + s_][i], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 9; k++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 11 : 9, 0);
   };
 #define WG8H_SB() __builtin_amdgcn_sched_barrier(0)
   for (int n = nbeg; n < nend; n += 2, cur ^= 1) {
     char* st = smem + cur * (2 * STG);
     WG8H_STAMP(0);
-    if constexpr (W16 && LAMP_WG8H_PIPE) {
+    if constexpr (W16) {
       Frag f0, f1;
       if (late) {
         if (prio) __builtin_amdgcn_s_setprio(2);

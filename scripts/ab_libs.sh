@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B/C... of several builds of the library on ONE box: bash scripts/ab_libs.sh ROUNDS LIB1 LIB2 [LIB3 ...] -> alternating headline steps (ms)
+set -u
+P=$1; shift
+for i in $(seq 1 $P); do for x in "$@"; do
+  ms=$(LAMP_LIB_PATH=$x python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; l=[x for x in sys.stdin if x.startswith('{')]; print(json.loads(l[-1])['ms_per_step'])")
+  echo "$x ms_per_step $ms"
+done; done
