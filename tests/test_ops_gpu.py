@@ -631,6 +631,8 @@ CONV_CASES = [
     (5, 100, 8, 8, 128, 3, 1, 1, 1, 1),    # odd batch on the implicit-GEMM path
     (7, 16, 8, 8, 128, 1, 1, 0, 1, 1),     # res3.l (1x1)
     (70, 128, 8, 8, 128, 3, 1, 1, 1, 1),   # several image splits in wgrad
+    (9, 50, 8, 8, 70, 3, 1, 1, 1, 1),      # eight-wave wgrad: Cin not a multiple of 4 (16-byte partial-sum stores reach padding columns), Cout not of 16 (clamped dY rows), odd batch (the pair's missing image)
+    (131, 34, 8, 8, 66, 3, 1, 1, 1, 1),    # ... two channels in the second slice of Cin, two in the fifth 16-row block of Cout, ragged image ranges
     (3, 4, 9, 7, 6, 3, 2, 1, 2, 2),        # odd sizes, dilation, groups
     (1, 2, 3, 3, 1, 3, 1, 0, 1, 1),        # reference KAT geometry (autograd.test.scala:2043)
 ]
