@@ -1694,6 +1694,12 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // two shifted X copies no longer need holds it: 2 x 16 KiB + 5.5 KiB per image), and its weight gradient [CO2][CI] - the centre-tap product
 // dy2 . x - accumulates in 8 more registers per lane: 2 more fragment reads and 2 more MFMAs per k-step (18 -> 20) instead of a launch of its own
 // that reads x again.  partial2[split][128][CIP].
+// SHIFT_DY = 2, later in round 5 (EXPERIMENTS 51 - 57; the cycle counts above assumed 8 LDS cycles per ds_read_b128 - it is 4, and the LDS array
+// is ~40 % busy here): a wave's tile is 16 co x 32 ci (3 dY + 2 X fragment reads per k-step; PAIR: + 1), X is the MFMA's A operand (a lane
+// holds four consecutive ci of one co: 16-byte partial-sum stores), the fragments of k-step j + 1 are requested before the MFMAs of k-step j
+// (rd / mul below), no image request sits in a branch (clamped rows / channels / images, the missing image of an odd range zeroed when it is
+// stored), dY rows outside the image are read from a zero slot of the stage, the centre column's MFMAs come first with the shifts of the other
+// two columns spread between MFMAs, and the multiplying wave runs at s_setprio 2.  -DLAMP_WG8H_STAMPS: s_memtime per phase (scripts/wg8h_stamps.py).
 #ifdef LAMP_WG8H_STAMPS
 __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #endif
