@@ -1703,6 +1703,9 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 #ifdef LAMP_WG8H_STAMPS
 __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #endif
+#ifndef LAMP_WG8H_DMA
+#define LAMP_WG8H_DMA 1          // SHIFT_DY = 2: the dY tiles arrive by LDS-DMA (0: through registers and ds_write, the A/B form)
+#endif
 template <int SHIFT_DY, bool PAIR = false>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
@@ -1859,6 +1862,40 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
   auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
   // images at or beyond nend load as zeros (an odd image count: the missing partner contributes nothing)
   uint4 rb[PAIR ? 2 : 1][2];                                 // PAIR: the sibling's dY packets of the pair in flight
+  // LDS-DMA of a [128 co][64 px] dY tile (global_load_lds_dwordx4: no staging registers, no ds_write): the destination is lane-linear, so the
+  // tile's XOR swizzle sits on the SOURCE address - position p of the image holds chunk (p & 7) ^ (row & 7) of row p >> 3, as ig_kc_off() reads it.
+  // Rows beyond `rows` fetch the last real row (accumulator columns that are never stored).
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  auto dma_tile = [&](const bf16_t* src, int rows, char* tile) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int piece = wid * 2 + i, pos = piece * 64 + lane, row = pos >> 3, chunk = (pos & 7) ^ (row & 7);
+      // As inline asm: through the builtin hipcc knows of a pending LDS write and puts vmcnt(0) in front of the next ds_read of ANY stage (it
+      // cannot tell the stages apart) - the DMA would be waited for where it is issued.  Its arrival is counted by hand in front of the
+      // pair's barrier; hipcc's own count for the x request stays right (that request is the only load it sees, and the youngest).
+      const bf16_t* gsrc = src + min(row, rows - 1) * 64 + chunk * 8;
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_char_t*)(tile + piece * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  auto zero_tile = [&](char* tile) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) *reinterpret_cast<uint4*>(tile + (tid + i * 512) * 16) = make_uint4(0, 0, 0, 0);
+  };
+  auto dma_pair = [&](char* stage, int n) {                  // the missing partner of an odd image count: a tile of zeros (uniform branch)
+#pragma unroll
+    for (int im = 0; im < 2; im++) {
+      if (n + im < nend) {
+        dma_tile(dy + (int64_t)(n + im) * CO * 64, CO, stage + im * STG);
+        if constexpr (PAIR) dma_tile(dy2 + (int64_t)(n + im) * CO2 * 64, CO2, stage + im * STG + IG_WTILE);
+      } else {
+        zero_tile(stage + im * STG);
+        if constexpr (PAIR) zero_tile(stage + im * STG + IG_WTILE);
+      }
+    }
+  };
   auto load_pair = [&](uint4 (&ra_)[2][2], uint4 (&rx_)[2], int n) {
     if constexpr (W16) {
 #pragma unroll
@@ -1900,7 +1937,14 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
     }
   };
   uint4 ra[2][2], rx[2];
-  if (nbeg < nend) {
+  if constexpr (W16 && LAMP_WG8H_DMA) {
+    if (nbeg < nend) {
+      dma_pair(smem, nbeg);
+      store_x2(smem, load_x2(nbeg));
+      if (nbeg + 2 < nend) rx[0] = load_x2(nbeg + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA's arrival is counted by vmcnt (the x request behind it is waited for too, once)
+  } else if (nbeg < nend) {
     load_pair(ra, rx, nbeg);
     store_pair(ra, rx, smem, nbeg);
     if (nbeg + 2 < nend) load_pair(ra, rx, nbeg + 2);
@@ -1979,9 +2023,20 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
         if (prio) __builtin_amdgcn_s_setprio(0);
       }
       WG8H_STAMP(1);
-      if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG), n + 2);      // nobody reads that stage since the last barrier
-      WG8H_STAMP(2);
-      if (n + 4 < nend) load_pair(ra, rx, n + 4);
+      if constexpr (LAMP_WG8H_DMA) {
+        // x of pair n + 2 from its registers (requested one pair ago), the request of x for pair n + 4, then pair n + 2's dY tiles by DMA - in
+        // this order: hipcc puts a vmcnt(0) of its own in front of the x request (it counts nothing in flight there), which behind the DMAs
+        // would wait for them.  Everything requested here is waited for once, in front of the pair's barrier, a pair of images later.
+        char* nx = smem + (cur ^ 1) * (2 * STG);                // nobody reads that stage since the last barrier
+        if (n + 2 < nend) store_x2(nx, rx[0]);
+        WG8H_STAMP(2);
+        if (n + 4 < nend) rx[0] = load_x2(n + 4);
+        if (n + 2 < nend) dma_pair(nx, n + 2);
+      } else {
+        if (n + 2 < nend) store_pair(ra, rx, smem + (cur ^ 1) * (2 * STG), n + 2);      // nobody reads that stage since the last barrier
+        WG8H_STAMP(2);
+        if (n + 4 < nend) load_pair(ra, rx, n + 4);
+      }
       WG8H_STAMP(3);
       if (prio) __builtin_amdgcn_s_setprio(2);
       if (!late) { rd(f0, st, 0); rd(f1, st, 1); WG8H_SB(); mul(f0); WG8H_SB(); rd(f0, st + STG, 0); WG8H_SB(); mul(f1); WG8H_SB(); }
@@ -1989,6 +2044,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
       rd(f1, st + STG, 1); WG8H_SB(); mul(f0); WG8H_SB(); mul(f1);
       if (prio) __builtin_amdgcn_s_setprio(0);
       WG8H_STAMP(5);
+      if constexpr (LAMP_WG8H_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       WG8H_STAMP(6);
       continue;
