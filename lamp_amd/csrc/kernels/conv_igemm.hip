@@ -1699,7 +1699,9 @@ __global__ __launch_bounds__(256) void ig_wgrad8v2_kernel(const bf16_t* __restri
 // holds four consecutive ci of one co: 16-byte partial-sum stores), the fragments of k-step j + 1 are requested before the MFMAs of k-step j
 // (rd / mul below), no image request sits in a branch (clamped rows / channels / images, the missing image of an odd range zeroed when it is
 // stored), dY rows outside the image are read from a zero slot of the stage, the centre column's MFMAs come first with the shifts of the other
-// two columns spread between MFMAs, and the multiplying wave runs at s_setprio 2.  -DLAMP_WG8H_STAMPS: s_memtime per phase (scripts/wg8h_stamps.py).
+// two columns spread between MFMAs, and the multiplying wave runs at s_setprio 2; the dY tiles arrive by LDS-DMA (dma_tile below: swizzle on the
+// source address, inline asm, one vmcnt wait in front of the pair's barrier), x through registers (one packet per thread and pair; the batch-norm
+// fold transforms it on the way).  -DLAMP_WG8H_STAMPS: s_memtime per phase (scripts/wg8h_stamps.py); -DLAMP_WG8H_DMA=0: dY through registers.
 #ifdef LAMP_WG8H_STAMPS
 __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #endif
