@@ -385,23 +385,143 @@ class SiteTypes:
         return self.get(name)
 
 
-def block_value_tuple(src, scopes, call_start):
+def block_value_tuple(src, scopes, call_start, with_names=False):
     """`val (a, b, c) = { ...; val r = ATen.x(...); ...; r }` (STen.scala:559-581): the native's result is bound to a name that is the VALUE of a
     block, and the block is destructured - the arity of that pattern, or 0"""
+    none = (0, []) if with_names else 0
     m = re.search(r"\bval\s+([A-Za-z_][A-Za-z0-9_]*)\s*(?::[^=]+)?=\s*$", src[max(0, call_start - 120):call_start])
     if not m:
-        return 0
+        return none
     b = scopes.block_of[call_start]
     if b == 0:
-        return 0
+        return none
     s, e, _ = scopes.blocks[b]
     last = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", src[s + 1:e])
     if not last or last.group(1) != m.group(1):
-        return 0
+        return none
     tm = re.search(r"val\s*\(([^()=]*)\)\s*=\s*$", src[max(0, s - 200):s])
     k = len(split_args(tm.group(1))) if tm else 0
-    return k if k >= 2 else 0
+    if k < 2:
+        return none
+    return (k, split_args(tm.group(1))) if with_names else k
 
+
+
+# ---- tuple ELEMENT types (VERDICT r5 item 1): a destructured native result is typed per element by what the Scala does with each name ----
+def _balanced_end(src, i):
+    """position just after the bracket that closes the one opened at src[i - 1]"""
+    depth, n = 1, len(src)
+    while i < n and depth:
+        c = src[i]
+        if c == '"':
+            i += 1
+            while i < n and src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+        elif c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+        i += 1
+    return i
+
+
+def _calls_in(text):
+    """(callee, [argument texts], start) for every `name(`, `a.b.name(` or `name[T](` call in text (nested calls included)"""
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_.]*)\s*(?:\[[^\]\[]*\])?\s*\(", text):
+        e = _balanced_end(text, m.end())
+        yield m.group(1), split_args(text[m.end():e - 1]), m.start()
+
+
+def _tensor_use(text, name):
+    """the name is handled as an aten.Tensor: wrapped (`owned(x)`, `x.owned`), released, registered with a scope, or passed on to another native"""
+    n = re.escape(name)
+    if re.search(r"\bowned\(\s*%s\s*\)" % n, text) or re.search(r"\b%s\s*\.\s*(owned|release|value|sizes|numel|options|scalarTypeByte|to[A-Z])\b" % n, text):
+        return True
+    if re.search(r"\bregister\(\s*%s\s*\)" % n, text):
+        return True
+    for callee, args, _ in _calls_in(text):
+        if re.match(r"(?:aten\.)?(ATen|Tensor)\.", callee) and any(re.fullmatch(r"(?:Option|Some)\(\s*%s\s*\)|%s" % (n, n), a) for a in args):
+            return True
+        if callee.endswith("releaseAll") and re.search(r"\b%s\b" % n, " ".join(args)):
+            return True
+    return False
+
+
+def _bare_tuple_position(text, name):
+    """index of `name` as an UNWRAPPED member of a tuple expression `( ..., name, ... )` (a parenthesis that is no call's argument list), or None"""
+    for m in re.finditer(r"(?<![A-Za-z0-9_\]\)])\s*\(", text):
+        if re.search(r"\bval\s*$", text[:m.start() + 1].rstrip("(").rstrip()):
+            continue                                        # the destructuring pattern itself
+        e = _balanced_end(text, m.end())
+        parts = split_args(text[m.end():e - 1])
+        if len(parts) >= 2 and name in parts:
+            return parts.index(name), len(parts)
+    return None
+
+
+def _def_params(sources, fname):
+    """parameter (name, type) lists of every `def fname` in the given sources"""
+    out = []
+    for src in sources.values():
+        for m in re.finditer(r"\bdef\s+%s\b\s*(?:\[[^\]]*\])?\s*\(" % re.escape(fname), src):
+            e = _balanced_end(src, m.end())
+            ps = []
+            for a in split_args(src[m.end():e - 1]):
+                pm = re.match(r"\s*([A-Za-z_][A-Za-z0-9_]*)\s*:\s*(.+?)\s*(?:=.*)?$", a, re.S)
+                if pm:
+                    ps.append((pm.group(1), " ".join(pm.group(2).split())))
+            out.append(ps)
+    return out
+
+
+def _kind_by_consumers(sources, defname, index, arity, depth=0):
+    """a def returns the element unwrapped at `index` of an `arity`-tuple: follow the callers that destructure that result and read the element's
+    type off the DECLARED type of the parameter it is handed to next (STen.scala:536-537 -> ops.scala:2352, 2375-2376 -> STen.scala:555-556)"""
+    found = set()
+    for src in sources.values():
+        for m in re.finditer(r"\bval\s*\(([^()=]*)\)\s*=\s*(?:[A-Za-z_][A-Za-z0-9_]*\s*\.\s*)*%s\b\s*(?:\[[^\]]*\])?\s*\(" % re.escape(defname), src):
+            names = split_args(m.group(1))
+            if len(names) != arity or not re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*", names[index]) or names[index] == "_":
+                continue
+            nm = names[index]
+            rest = src[m.end():]
+            for callee, args, _ in _calls_in(rest):
+                for j, a in enumerate(args):
+                    named = re.fullmatch(r"([A-Za-z_][A-Za-z0-9_]*)\s*=\s*%s" % re.escape(nm), a)
+                    if a != nm and not named:
+                        continue
+                    for ps in _def_params(sources, callee.split(".")[-1]):
+                        if named:
+                            ts = [t for n_, t in ps if n_ == named.group(1)]
+                        else:
+                            ts = [ps[j][1]] if j < len(ps) else []
+                        for t in ts:
+                            k = type_kind(t)
+                            if k != "expr":
+                                found.add(k)
+    return found
+
+
+def tuple_element_kinds(src, scopes, call_start, call_end, names, sources):
+    """per destructured name: "tensor", a scalar kind ("long" / "double" / "bool") the element is declared as downstream, "unused", or "unknown"."""
+    b = scopes.block_of[call_start]
+    scope_end = scopes.blocks[b][1] if b else len(src)
+    text = src[call_end:scope_end]
+    dm = None
+    for dm in re.finditer(r"\bdef\s+([A-Za-z_][A-Za-z0-9_]*)", src[:call_start]):
+        pass
+    kinds = []
+    for nm in names:
+        if nm == "_" or not re.search(r"\b%s\b" % re.escape(nm), text):
+            kinds.append("unused"); continue
+        if _tensor_use(text, nm):
+            kinds.append("tensor"); continue
+        pos = _bare_tuple_position(text, nm)
+        got = set()
+        if pos is not None and dm is not None:
+            got = _kind_by_consumers(sources, dm.group(1), pos[0], pos[1])
+        kinds.append(sorted(got)[0] if len(got) == 1 else "unknown")
+    return kinds
 
 def type_kind(t):
     if t == "Boolean":
@@ -498,9 +618,13 @@ def arg_kind(a, types=None):
 def collect():
     ref = "/root/reference"
     sites = {c: {} for c in CLASSES}
+    sources = {}
     for d in G.REF_DIRS:
         for f in sorted(glob.glob(os.path.join(ref, d, "**", "*.scala"), recursive=True)):
-            src = strip_comments(open(f).read())
+            sources[f] = strip_comments(open(f).read())
+    for d in G.REF_DIRS:
+        for f in sorted(glob.glob(os.path.join(ref, d, "**", "*.scala"), recursive=True)):
+            src = sources[f]
             rel = os.path.relpath(f, ref)
             file_types = declared_types(src)
             scopes = Scopes(src)
@@ -528,8 +652,18 @@ def collect():
                 tm = re.search(r"val\s*\(([^()=]*)\)\s*=\s*(?:[A-Za-z_.]*\(\s*)?$", before)
                 tup = len(split_args(tm.group(1))) if tm else 0
                 tup = tup if tup >= 2 else 0                       # `val (x) = ...` is no tuple
-                tup = tup or block_value_tuple(src, scopes, m.start())
-                e["calls"].append({"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a, types) for a in args], "tuple": tup})
+                names = split_args(tm.group(1)) if tup else []
+                if not tup:
+                    tup, names = block_value_tuple(src, scopes, m.start(), with_names=True)
+                site = {"at": f"{rel}:{line}", "arity": len(args), "kinds": [arg_kind(a, types) for a in args], "tuple": tup}
+                if tup:
+                    # what each destructured member IS, by its downstream use (a tensor is wrapped / released / registered / passed to a native;
+                    # a member returned unwrapped is typed by the declared parameter its consumer hands it to)
+                    end = i
+                    if not tm:                                 # block-valued: the names are used after the block
+                        end = scopes.blocks[scopes.block_of[m.start()]][1] + 1
+                    site["elements"] = tuple_element_kinds(src, scopes, m.start() if tm else end, end, names, sources)
+                e["calls"].append(site)
     out = {"_source": {"dirs": G.REF_DIRS, "note": "call sites of the aten package in lamp's hot-path modules: argument counts, argument kinds (literals, Option / Some / None, arrays, tensors, booleans, identifiers by their declared type) and the arity of a destructured result - no source text "
                                                    "(scripts/gen_aten_forwarders.py collect, build container)"}}
     for c in CLASSES:
@@ -701,6 +835,20 @@ def tuple_arity(e):
     return max(t) if t else 0
 
 
+ELEMENT_JAVA = {"tensor": "Tensor", "long": "Long", "double": "Double", "bool": "Boolean", "unused": "Tensor"}    # boxed: members of a scala.TupleN
+
+
+def tuple_parts(e, k):
+    """Java type of each member of the k-tuple the call sites destructure, from the collector's element kinds (`elements`); a member no site
+    can type ("unknown") or that two sites type differently is an error - the table is not allowed to guess"""
+    parts = []
+    for i in range(k):
+        ks = {c["elements"][i] for c in e["calls"] if c.get("tuple", 0) == k and "elements" in c} - {"unused"}
+        assert len(ks) <= 1 and "unknown" not in ks, f"tuple member {i}: call sites say {sorted(ks)}"
+        parts.append(ELEMENT_JAVA[next(iter(ks))] if ks else "Tensor")
+    return parts
+
+
 def compatible(jt, kind):
     if kind == "expr":
         return True
@@ -751,6 +899,12 @@ def forwarders():
             t = c.get("tuple", 0)
             if t and not rtype.startswith(f"scala.Tuple{t}<"):
                 report["kind_mismatch"].append({"name": key, "at": c["at"], "position": "result", "call_site_passes": f"val ({t} names) =", "forwarder_takes": rtype})
+            elif t:
+                # member TYPES too: `val (.., max_q, ..) = ATen.f(...)` with max_q handed on to a `Long` parameter needs a Long there
+                members = [x.strip() for x in rtype[rtype.index("<") + 1:rtype.rindex(">")].split(",")]
+                for i, (jt, k) in enumerate(zip(members, c.get("elements", []))):
+                    if k not in ("unused",) and ELEMENT_JAVA.get(k) != jt:
+                        report["kind_mismatch"].append({"name": key, "at": c["at"], "position": f"result._{i + 1}", "call_site_passes": k, "forwarder_takes": jt})
 
     for cls in CLASSES:
         for name, e in sites.get(cls, {}).items():
@@ -777,7 +931,7 @@ def forwarders():
                 tk = tuple_arity(e)
                 if tk and rtype in ("Tensor[]", "Object[]"):
                     # the call sites destructure the result: the body (which builds an array) moves into a private method, the public one wraps
-                    parts = list(EXPLICIT[key][3]) if len(EXPLICIT[key]) > 3 else ["Tensor"] * tk
+                    parts = tuple_parts(e, tk)
                     tt = tuple_type(tk, parts)
                     args_ = ", ".join(p.split()[-1] for p in plist)
                     items = ", ".join(f"({parts[i]}) r_[{i}]" for i in range(tk))
@@ -808,6 +962,7 @@ def forwarders():
             rtype, body = wrap_result(jret, outs)
             tk = tuple_arity(e)
             if tk and rtype == "Tensor[]" and len([o for o in outs]) >= 1:
+                assert tuple_parts(e, tk) == ["Tensor"] * tk, f"{cls}.{name}: the call sites use non-tensor members of a native that returns handles only"
                 tt = tuple_type(tk, ["Tensor"] * tk)
                 rtype, body = tt, "long[] r_ = {call}; return new " + tt + "(" + ", ".join(f"Tensor.owning(r_[{i}])" for i in range(tk)) + ");"
             call = f"LampNative.{sym}({', '.join(x for _, _, xs in ps for x in xs)})"

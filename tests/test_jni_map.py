@@ -245,6 +245,92 @@ object O {
     assert sd["at"].endswith("STen.scala:563") and sd["tuple"] == 3 and sd["kinds"][8] == "tensor"
 
 
+def test_collector_types_the_members_of_a_destructured_result():
+    """`val (.., max_q, max_k, ..) = ATen._scaled_dot_product_cudnn_attention(...)` returns max_q / max_k UNWRAPPED
+    (STen.scala:509-540) and their consumer hands them to parameters declared `Long` (ops.scala:2352-2380 -> STen.scala:555-556): members 5
+    and 6 of that Tuple9 are Longs.  The round-5 collector typed arguments and tuple ARITY only, so a Tuple9 of nine Tensors (which casts two
+    Longs to Tensor) passed every check.  Rules on synthetic Scala of the same shape (no reference text), then the committed fixture."""
+    F = _fwd()
+    a = F.strip_comments("""
+object STen {
+  def fused[S: Sc](q: STen, causal: Boolean) = {
+    val (out, lse, mq, dbg, cnt) = ATen._fused(q.value, causal)
+    dbg.release
+    (owned(out), owned(lse), mq, cnt)
+  }
+  def fusedBackward[S: Sc](g: STen, out: STen, lse: STen, max_q: Long, scale: Double) =
+    ATen._fused_backward(g.value, out.value, lse.value, max_q, scale).owned
+  def stats[S: Sc](x: STen) = {
+    val (m, v) = ATen.var_mean_9(x.value)
+    scope.register(v)
+    ATen.sqrt(m).owned
+  }
+}
+""")
+    b = F.strip_comments("""
+case class Fused(scope: Scope, q: Variable) extends Op {
+  val (o, l, maxq, factor) = STen.fused(q.value, true)(scope)
+  val g = STen.fusedBackward(p, o, l, maxq, scale = factor)
+}
+""")
+    sources = {"a.scala": a, "b.scala": b}
+    sc = F.Scopes(a)
+    import re
+    m = re.search(r"ATen\._fused\(", a)
+    end = F._balanced_end(a, m.end())
+    kinds = F.tuple_element_kinds(a, sc, m.start(), end, ["out", "lse", "mq", "dbg", "cnt"], sources)
+    assert kinds == ["tensor", "tensor", "long", "tensor", "double"]        # mq -> positional `max_q: Long`, cnt -> named `scale: Double`
+    m = re.search(r"ATen\.var_mean_9\(", a)
+    assert F.tuple_element_kinds(a, sc, m.start(), F._balanced_end(a, m.end()), ["m", "v"], sources) == ["tensor", "tensor"]
+    assert F.tuple_element_kinds(a, sc, m.start(), F._balanced_end(a, m.end()), ["m", "_"], sources) == ["tensor", "unused"]
+    # a member nothing types stays "unknown" and the emitter refuses to guess
+    lone = F.strip_comments("object P { def f(x: STen) = { val (a, b) = ATen.g(x.value)\n (owned(a), b) } }")
+    m = re.search(r"ATen\.g\(", lone)
+    assert F.tuple_element_kinds(lone, F.Scopes(lone), m.start(), F._balanced_end(lone, m.end()), ["a", "b"], {"p": lone}) == ["tensor", "unknown"]
+    with pytest.raises(AssertionError):
+        F.tuple_parts({"calls": [{"tuple": 2, "elements": ["tensor", "unknown"]}]}, 2)
+    # the committed fixture: every destructuring site carries member kinds, none unknown; the fused attention's are (T, T, T, T, Long, Long, T, T, T)
+    sites = json.load(open(F.CALLSITES))
+    tup = [c for cls in F.CLASSES for v in sites[cls].values() for c in v["calls"] if c.get("tuple")]
+    assert len(tup) >= 30 and all(len(c["elements"]) == c["tuple"] and "unknown" not in c["elements"] for c in tup)
+    sd = sites["ATen"]["_scaled_dot_product_cudnn_attention"]
+    assert sd["calls"][0]["elements"] == ["tensor"] * 4 + ["long", "long"] + ["tensor"] * 3
+    assert F.tuple_parts(sd, 9) == ["Tensor"] * 4 + ["Long", "Long"] + ["Tensor"] * 3
+    assert [c["at"] for c in tup if set(c["elements"]) - {"tensor"}] == [sd["calls"][0]["at"]]          # the only native lamp takes scalars out of
+    # ... and the checker now SEES a wrong member type: round 5's descriptor for this native is reported
+    _, report = F.forwarders()
+    assert report["kind_mismatch"] == []
+    r5 = "scala.Tuple9<" + ", ".join(["Tensor"] * 9) + ">"
+    saved = F.tuple_parts
+    try:
+        F.tuple_parts = lambda e, k: ["Tensor"] * k                        # what round 5 emitted
+        _, bad = F.forwarders()
+    finally:
+        F.tuple_parts = saved
+    hits = [x for x in bad["kind_mismatch"] if x["name"] == "ATen._scaled_dot_product_cudnn_attention"]
+    assert [x["position"] for x in hits] == ["result._5", "result._6"] and all(x["call_site_passes"] == "long" and x["forwarder_takes"] == "Tensor" for x in hits)
+    aten = open(os.path.join(ROOT, "jni", "aten", "ATen.java")).read()
+    assert r5 not in aten and "(Long) r_[4], (Long) r_[5]" in aten and "(Tensor) r_[4]" not in aten
+
+
+def test_tuple_descriptors_agree_with_the_members_the_call_sites_use():
+    """the hand-audited table and the collector are two readings of the same Scala: every tuple-returning entry of aten_descriptors.json must
+    have, member for member, the Java type the collector derives from the reference's use of that member (the table certified
+    Tensor where lamp takes a Long)"""
+    F = _fwd()
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "aten_descriptors.json")))
+    sites = json.load(open(F.CALLSITES))
+    seen = 0
+    for key, want in table.items():
+        if key.startswith("_") or not want["returns"].startswith("scala.Tuple"):
+            continue
+        cls, name = key.split(".", 1)
+        members = [x.strip() for x in want["returns"][want["returns"].index("<") + 1:-1].split(",")]
+        assert F.tuple_parts(sites[cls][name], len(members)) == members, key
+        seen += 1
+    assert seen >= 10
+
+
 def test_aten_classes_have_the_hand_audited_jvm_signatures():
     """tests/golden/aten_descriptors.json: the signature each member must have for unmodified lamp to compile, read BY HAND from the reference
     call sites for SURVEY section 8b's minimum export set and the runtime classes (streams, communicators, options, trace).  "Cls.name" =
