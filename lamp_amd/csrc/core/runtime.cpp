@@ -59,12 +59,13 @@ void synchronize_all_used_devices() {
   if (!mask) return;
   int prev = -1;
   HIP_CHECK(hipGetDevice(&prev));
+  // the error path too leaves the thread on the device tl_device names (a throw used to leave HIP on device d)
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
   for (int d = 0; d < 16; d++) {
     if (!(mask & (1u << d))) continue;
     HIP_CHECK(hipSetDevice(d));
     HIP_CHECK(hipDeviceSynchronize());
   }
-  HIP_CHECK(hipSetDevice(prev));
 }
 int current_device() {
   if (!tl_device_set) {

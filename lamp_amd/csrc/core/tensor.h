@@ -118,6 +118,9 @@ struct Storage {
   // weight-gradient partial sums run batched in one launch).  Every pointer into the storage goes through lamp_tensor::raw(), which
   // resolves the deferral first - so nobody can observe the tensor before it is complete.
   std::atomic<uint32_t> pending{0};
+  // a strided filter's contiguous copy made inside a convolution entry point (kernels/conv.hip): it dies with the call, so no packed-weight
+  // cache keeps an image of it (an entry under its never-reused uid could only be evicted, and a pair image would outlive one of its sources)
+  bool scratch = false;
 };
 void resolve_deferred(Storage* st);   // runs every pending deferred kernel now (on the streams they were registered on)
 void flush_deferred();                // the same, called at the natural batching points (end of backprop, lamp_flush_deferred)

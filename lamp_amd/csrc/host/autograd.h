@@ -137,6 +137,9 @@ struct Op {
   virtual ~Op() = default;
   std::vector<std::pair<Var, Backward>> params;
   const char* name = "op";
+  // state a node's closures keep BETWEEN each other during one backprop (the convolution pair's held derivatives): backprop calls this
+  // for every node before it starts, so a pass that was abandoned half-way (an exception between two siblings) leaves nothing behind
+  std::function<void()> reset;
 };
 
 // Gradient buffers.  lamp allocates a zeros_like buffer for every op output up front (autograd.scala:89-96) and

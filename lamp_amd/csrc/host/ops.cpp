@@ -100,7 +100,12 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     root->grad = ops::ones_like(root->value);
     root->grad_shared = false;
   }
-  for (Variable* v : topological_sort(root.get())) {
+  const std::vector<Variable*> order = topological_sort(root.get());
+  for (Variable* v : order) {                 // what an earlier, abandoned pass over this graph may have left parked
+    v->pending.clear();
+    if (v->op && v->op->reset) v->op->reset();
+  }
+  for (Variable* v : order) {
     if (!v->pending.empty()) {                // (all consumers are done: nothing will complete a pair now)
       auto fs = std::move(v->pending);
       v->pending.clear();
@@ -494,7 +499,8 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
     // Cnn.resnet's tail: the log-probabilities come from the pooled LogSoftMax node.  Its input gradient is linear in this contribution, so
     // the contribution goes straight to THAT node's input in one launch (the [N, C] gradient row is never written); anything else that
     // flows into `out` takes the node's own closure as before
-    if (fuse_tail && out.op && out.op->params.size() == 1 && std::strcmp(out.op->name, "GlobalAvgPoolLogSoftMax") == 0 && p.h()->is_device() &&
+    // (under a backprop with an `after` hook every visited variable must carry its derivative, as in autograd.scala: no short cut then)
+    if (fuse_tail && !tls_backprop_hooked && out.op && out.op->params.size() == 1 && std::strcmp(out.op->name, "GlobalAvgPoolLogSoftMax") == 0 && p.h()->is_device() &&
         out.op->params[0].first->needsGrad()) {
       Variable& xin = *out.op->params[0].first;
       lamp_tensor* t = nullptr;
@@ -727,7 +733,9 @@ static Var convolution_node(const Var& input, const Var& weight, const Var& bias
       // both convolutions (a parameter is reached right after its own node, before the sibling has run)
       Variable* inp = input.get();
       return Backward([=](const Ten& p, Variable& out) {
-        if (!p.h()->is_device() || tls_backprop_hooked) { single(p, out); return; }
+        // only a LEAF filter's gradient may arrive late: a filter computed by other nodes (weight norm) is visited right after this node
+        // and its own closures must find the complete derivative
+        if (!p.h()->is_device() || tls_backprop_hooked || out.op) { single(p, out); return; }
         ConvPairGrad& st = *pair;
         if (st.wwaiting < 0) {
           st.wwaiting = pair_side;
@@ -796,6 +804,10 @@ static Var convolution_node(const Var& input, const Var& weight, const Var& bias
   op->params.push_back({input, back(0)});
   op->params.push_back({weight, back(1)});
   op->params.push_back({bias, back(2)});
+  if (pair) op->reset = [pair] {
+    pair->waiting = pair->wwaiting = -1;
+    for (auto& sd : pair->side) { sd.p = Ten(); sd.pw = Ten(); sd.wout = nullptr; }
+  };
   if (computed) return make_result(op, *computed);
   lamp_tensor* o = nullptr;
   HCALL(lamp_convolution(&o, iv.h(), wv.h(), bias->value.h(), stride.data(), padding.data(), dilation.data(), ns, transposed,

@@ -347,6 +347,13 @@ Tensor* bn_relu_materialise(const Tensor* xc, const Tensor* affine, hipStream_t 
   }
   return y.take();
 }
+// a filter as the kernels want it: itself (+1) when contiguous, otherwise a copy that lives for this call only and is marked so that the
+// packed-weight caches do not keep images of it
+static Tensor* contiguous_filter(const Tensor* w) {
+  Tensor* c = contiguous(w);
+  if (c->st != w->st) c->st->scratch = true;
+  return c;
+}
 }  // namespace lamp
 
 using namespace lamp;
@@ -362,7 +369,7 @@ int lamp_convolution(lamp_tensor** out, const lamp_tensor* x, const lamp_tensor*
   ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, transposed, output_padding, groups);
   const int64_t out_c = transposed ? g.Cin : g.Cout;
   if (bias) { check_device_tensor(bias, "bias"); LAMP_CHECK(bias->numel() == out_c && bias->dtype == x->dtype, "convolution: bias must have " << out_c << " elements"); }
-  Hold xc(contiguous(x)), wc(contiguous(w));
+  Hold xc(contiguous(x)), wc(contiguous_filter(w));
   Hold bc(bias ? contiguous(bias) : nullptr);
   std::vector<int64_t> oshape = {g.N, out_c};
   if (nspatial == 2) oshape.push_back(transposed ? g.H : g.Ho);
@@ -394,7 +401,7 @@ int lamp_convolution_pair(lamp_tensor* out2[2], const lamp_tensor* x, const lamp
     ConvGeom gb = make_geom(x, w_b, stride_b, padding_b, dilation_b, nspatial, 0, zero2, groups);
     const bool biases_ok = (!bias_a || (bias_a->numel() == ga.Cout && bias_a->dtype == x->dtype)) && (!bias_b || (bias_b->numel() == gb.Cout && bias_b->dtype == x->dtype));
     if (biases_ok && ga.Ho == gb.Ho && ga.Wo == gb.Wo) {
-      Hold xc(contiguous(x)), wa(contiguous(w_a)), wb(contiguous(w_b));
+      Hold xc(contiguous(x)), wa(contiguous_filter(w_a)), wb(contiguous_filter(w_b));
       Hold ba(bias_a ? contiguous(bias_a) : nullptr), bb(bias_b ? contiguous(bias_b) : nullptr);
       Hold ya(new_tensor({ga.N, ga.Cout, ga.Ho, ga.Wo}, x->dtype, x->device())), yb(new_tensor({gb.N, gb.Cout, gb.Ho, gb.Wo}, x->dtype, x->device()));
       hipStream_t st = current_stream(x->device());
@@ -429,7 +436,7 @@ int lamp_convolution_backward(lamp_tensor* out3[3], const lamp_tensor* grad_out,
                grad_out->sizes[grad_out->ndim - 1] == ow && (nspatial == 1 || grad_out->sizes[2] == oh),
                "convolution_backward: grad_out " << grad_out->describe() << " does not match the forward output shape");
   }
-  Hold xc(contiguous(x)), wc(contiguous(w)), gc(contiguous(grad_out));
+  Hold xc(contiguous(x)), wc(contiguous_filter(w)), gc(contiguous(grad_out));
   hipStream_t st = current_stream(x->device());
   Hold dx(mask[0] ? new_like(xc.get()) : nullptr);
   Hold dw(mask[1] ? new_like(wc.get()) : nullptr);
@@ -487,7 +494,7 @@ int lamp_convolution_bn_relu_input(lamp_tensor** out, const lamp_tensor* x, cons
   const int64_t zero2[2] = {0, 0};
   ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, zero2, groups);
   if (bias) { check_device_tensor(bias, "bias"); LAMP_CHECK(bias->numel() == g.Cout && bias->dtype == x->dtype, "convolution: bias must have " << g.Cout << " elements"); }
-  Hold xc(contiguous(x)), wc(contiguous(w));
+  Hold xc(contiguous(x)), wc(contiguous_filter(w));
   Hold bc(bias ? contiguous(bias) : nullptr);
   hipStream_t st = current_stream(x->device());
   std::vector<int64_t> oshape = {g.N, g.Cout};
@@ -513,7 +520,7 @@ int lamp_convolution_bn_relu_input_backward(lamp_tensor* out3[3], const lamp_ten
   check_device_tensor(x, "input"); check_device_tensor(w, "weight"); check_device_tensor(grad_out, "grad_out"); check_affine(affine, x);
   const int64_t zero2[2] = {0, 0};
   ConvGeom g = make_geom(x, w, stride, padding, dilation, nspatial, 0, zero2, groups);
-  Hold xc(contiguous(x)), wc(contiguous(w)), gc(contiguous(grad_out));
+  Hold xc(contiguous(x)), wc(contiguous_filter(w)), gc(contiguous(grad_out));
   hipStream_t st = current_stream(x->device());
   Hold dw;
   bool dw_done = false;
@@ -547,7 +554,7 @@ int lamp_convolution_backward_input_add(lamp_tensor** out, const lamp_tensor* gr
   LAMP_CHECK(grad_out->ndim == x->ndim && grad_out->sizes[0] == g.N && grad_out->sizes[1] == g.Cout &&
              grad_out->sizes[grad_out->ndim - 1] == g.Wo && (nspatial == 1 || grad_out->sizes[2] == g.Ho),
              "convolution_backward_input_add: grad_out " << grad_out->describe() << " does not match the forward output shape");
-  Hold wc(contiguous(w)), gc(contiguous(grad_out)), ac(contiguous(addend));
+  Hold wc(contiguous_filter(w)), gc(contiguous(grad_out)), ac(contiguous(addend));
   hipStream_t st = current_stream(x->device());
   Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
   bool fused = false;
@@ -589,7 +596,7 @@ int lamp_convolution_backward_input_pair(lamp_tensor** out, const lamp_tensor* x
   };
   check_grad(grad_out_a, ga, "first"); check_grad(grad_out_b, gb, "second");
   if (x->dtype == kBF16 && nspatial == 2) {
-    Hold wa(contiguous(w_a)), wb(contiguous(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b)), ac(addend ? contiguous(addend) : nullptr);
+    Hold wa(contiguous_filter(w_a)), wb(contiguous_filter(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b)), ac(addend ? contiguous(addend) : nullptr);
     hipStream_t st = current_stream(x->device());
     Hold dx(new_tensor(std::vector<int64_t>(x->sizes, x->sizes + x->ndim), x->dtype, x->device()));
     bool fused = false;
@@ -637,7 +644,7 @@ int lamp_convolution_backward_weight_pair(lamp_tensor* out2[2], const lamp_tenso
   };
   check_grad(grad_out_a, ga, "first"); check_grad(grad_out_b, gb, "second");
   if (x->dtype == kBF16 && nspatial == 2) {
-    Hold xc(contiguous(x)), wa(contiguous(w_a)), wb(contiguous(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b));
+    Hold xc(contiguous(x)), wa(contiguous_filter(w_a)), wb(contiguous_filter(w_b)), gya(contiguous(grad_out_a)), gyb(contiguous(grad_out_b));
     hipStream_t st = current_stream(x->device());
     Hold dwa(new_like(wa.get())), dwb(new_like(wb.get()));
     if (narrow_conv_wgrad_pair(gya.get(), gyb.get(), xc.get(), dwa.get(), dwb.get(), ga, gb, st) ||

@@ -1708,7 +1708,7 @@ __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #ifndef LAMP_WG8H_DMA
 #define LAMP_WG8H_DMA 1          // SHIFT_DY = 2: the dY tiles arrive by LDS-DMA (0: through registers and ds_write, the A/B form)
 #endif
-template <int SHIFT_DY, bool PAIR = false>
+template <int SHIFT_DY, bool PAIR = false, bool DMA = (LAMP_WG8H_DMA != 0)>
 __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
                                                          int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
                                                          int stream_out, const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2) {
@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
     }
   };
   uint4 ra[2][2], rx[2];
-  if constexpr (W16 && LAMP_WG8H_DMA) {
+  if constexpr (W16 && DMA) {
     if (nbeg < nend) {
       dma_pair(smem, nbeg);
       store_x2(smem, load_x2(nbeg));
@@ -2025,7 +2025,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
         if (prio) __builtin_amdgcn_s_setprio(0);
       }
       WG8H_STAMP(1);
-      if constexpr (LAMP_WG8H_DMA) {
+      if constexpr (DMA) {
         // x of pair n + 2 from its registers (requested one pair ago), the request of x for pair n + 4, then pair n + 2's dY tiles by DMA - in
         // this order: hipcc puts a vmcnt(0) of its own in front of the x request (it counts nothing in flight there), which behind the DMAs
         // would wait for them.  Everything requested here is waited for once, in front of the pair's barrier, a pair of images later.
@@ -2046,7 +2046,7 @@ __global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restric
       rd(f1, st + STG, 1); WG8H_SB(); mul(f0); WG8H_SB(); mul(f1);
       if (prio) __builtin_amdgcn_s_setprio(0);
       WG8H_STAMP(5);
-      if constexpr (LAMP_WG8H_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       WG8H_STAMP(6);
       continue;
@@ -2162,7 +2162,7 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
   const int64_t nf = (int64_t)RS * IG_M * KPf, nd = (int64_t)RS * IG_M * KPd;
   *dgrad_offset = nf;
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
-  const bool cacheable = cache_on && w->st->owned;
+  const bool cacheable = cache_on && w->st->owned && !w->st->scratch;
   const PackKey key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, st};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
   if (cacheable) {
@@ -2568,16 +2568,24 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
       const int co2 = pair ? (int)second->g->Cout : 0;
       static const bool wg_stagger = [] { const char* e = getenv("LAMP_WGRAD_STAGGER"); return !(e && e[0] == '0'); }();
       static const bool wg_prio = [] { const char* e = getenv("LAMP_WGRAD_PRIO"); return !(e && e[0] == '0'); }();
+      // LAMP_WG8H_DMA=0 (run time): the dY tiles through registers and ds_write instead of LDS-DMA - the same arithmetic in the same order, kept
+      // as the fallback and the bitwise A/B of the hand-counted vmcnt waits (tests/test_ops_gpu.py)
+      static const bool wg_dma = [] { const char* e = getenv("LAMP_WG8H_DMA"); return e ? e[0] != '0' : (LAMP_WG8H_DMA != 0); }();
 #define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
   do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_>);                                                                                 \
-    hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),          \
+    if (M_ == 2 && !wg_dma) { IG_LAUNCH_WG8H_(M_, P_, false); } else { IG_LAUNCH_WG8H_(M_, P_, true); }                                       \
+  } while (0)
+#define IG_LAUNCH_WG8H_(M_, P_, D_)                                                                                                         \
+  do {                                                                                                                                      \
+    allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_, D_>);                                                                             \
+    hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_, D_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),      \
                        partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp,                                     \
                        (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2) | (wg_prio ? 4 : 0), dy2p, p2p, co2);                                                                                                                                            \
   } while (0)
       if (pair) IG_LAUNCH_WG8H(2, true);
       else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
 #undef IG_LAUNCH_WG8H
+#undef IG_LAUNCH_WG8H_
       LAMP_LAUNCH_CHECK();
     }
     const int64_t cols = (int64_t)RS * IG_M * CIP / 4;

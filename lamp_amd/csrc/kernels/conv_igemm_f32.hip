@@ -517,7 +517,7 @@ static Tensor* packed_weights32(const Tensor* w, const ConvGeom& g, int KS, hipS
   const int64_t nf = (int64_t)RS * F_ROWS * KPf, nd = (int64_t)RS * F_ROWS * KPd;
   *dgrad_offset = nf;
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
-  const bool cacheable = cache_on && w->st->owned;
+  const bool cacheable = cache_on && w->st->owned && !w->st->scratch;
   const PackKey32 key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, w->dtype, st};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
   if (cacheable) {

@@ -765,8 +765,8 @@ struct NcvPackKey {
            std::tie(o.uid, o.offset, o.Cout, o.Cin, o.kh, o.kw, o.dgrad, o.ns, o.sw, o.st, o.uid2, o.offset2, o.Cout2);
   }
 };
-// version2 / w2: the sibling's storage version and data pointer (the re-pack hook sees one parameter at a time and needs the other's address)
-struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; bool pinned = false; uint64_t version2 = 0; const bf16_t* w1 = nullptr; const bf16_t* w2 = nullptr; };
+// version2: the sibling's storage version.  No data pointers are kept: the re-pack hook resolves both filters among the parameters it is handed
+struct NcvPackVal { uint64_t version; Tensor* packed; uint64_t tick; bool pinned = false; uint64_t version2 = 0; };
 std::mutex g_ncv_mu;
 std::map<NcvPackKey, NcvPackVal> g_ncv_cache;
 uint64_t g_ncv_tick = 0;
@@ -781,7 +781,7 @@ static void ncv_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) {
 // returns a +1 handle on the fragment image of `w` for this direction
 static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st, const Tensor* w2 = nullptr) {
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
-  const bool cacheable = cache_on && w->st->owned && (!w2 || w2->st->owned);
+  const bool cacheable = cache_on && w->st->owned && !w->st->scratch && (!w2 || (w2->st->owned && !w2->st->scratch));
   const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns, wq.sw, st,
                        w2 ? w2->st->uid : 0, w2 ? w2->offset : 0, w2 ? wq.Cout2 : 0};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
@@ -810,7 +810,7 @@ static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t s
         if (!i->second.pinned && (victim == g_ncv_cache.end() || i->second.tick < victim->second.tick)) victim = i;
       if (victim != g_ncv_cache.end()) { release(victim->second.packed); g_ncv_cache.erase(victim); }
     }
-    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick, allocator_capturing(), ver2, wq.w, wq.w2};
+    g_ncv_cache[key] = NcvPackVal{ver, retain(wp.get()), ++g_ncv_tick, allocator_capturing(), ver2};
   }
   return wp.take();
 }
@@ -825,44 +825,55 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st, Ncv
   if (!on) return;
   std::lock_guard<std::mutex> lk(g_ncv_mu);
   if (g_ncv_cache.empty()) return;
+  // the narrow filters among the parameters just written: an image is packed again ONLY from tensors the caller holds right now (ADVICE r5:
+  // the entry used to keep raw data pointers of both filters of a pair and read the absent one's after its storage could be gone)
+  std::vector<const Tensor*> cand;
+  for (int i = 0; i < n; i++) {
+    const Tensor* w = params[i];
+    if (!w || !w->is_device() || w->dtype != kBF16 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
+    if (w->sizes[0] > 16 || w->sizes[1] > 16) continue;
+    cand.push_back(w);
+  }
+  if (cand.empty()) return;
+  auto find = [&](uint64_t uid, int64_t offset, int co, int ci, int kh, int kw) -> const Tensor* {
+    for (const Tensor* w : cand)
+      if (w->st->uid == uid && w->offset == offset && (int)w->sizes[0] == co && (int)w->sizes[1] == ci && (int)w->sizes[2] == kh && (int)w->sizes[3] == kw)
+        return w;
+    return nullptr;
+  };
   NcvPackMany a;
   int cnt = 0;
-  struct Done { NcvPackKey k; uint64_t version; bool second; };
-  std::vector<Done> done;
   auto flush = [&] {
     if (cnt == 0) return;
     ncv_pack_launch(a, cnt, st);
     cnt = 0;
   };
-  for (int i = 0; i < n; i++) {
-    const Tensor* w = params[i];
-    if (!w || !w->is_device() || w->dtype != kBF16 || w->ndim != 4 || !w->st->owned || !w->is_contiguous()) continue;
-    if (w->sizes[0] > 16 || w->sizes[1] > 16) continue;
-    for (auto& kv : g_ncv_cache) {
-      const NcvPackKey& k = kv.first;
-      if (k.st != st) continue;
-      const bool first = k.uid == w->st->uid && k.offset == w->offset && k.Cout == (int)w->sizes[0] && k.Cin == (int)w->sizes[1] &&
-                         k.kh == (int)w->sizes[2] && k.kw == (int)w->sizes[3];
-      // the sibling 1x1 of a pair image: the image is packed again from BOTH filters (the other one's address was kept at the first pack;
-      // the optimiser passes both parameters, so the image is current after the second of the two visits)
-      const bool second = !first && k.Cout2 > 0 && k.uid2 == w->st->uid && k.offset2 == w->offset && k.Cout2 == (int)w->sizes[0] &&
-                          k.Cin == (int)w->sizes[1] && w->sizes[2] == 1 && w->sizes[3] == 1;
-      if (!first && !second) continue;
-      if (cnt == NCV_PACK_MAX) flush();
-      const bf16_t* w1p = first ? w->ptr<bf16_t>() : kv.second.w1;
-      const bf16_t* w2p = second ? w->ptr<bf16_t>() : kv.second.w2;
-      a.w[cnt] = NcvW{w1p, k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw, k.Cout2 > 0 ? w2p : nullptr, k.Cout2};
-      a.dst[cnt] = static_cast<nv_bf8*>(kv.second.packed->raw());
-      done.push_back({k, w->st->version.load(std::memory_order_relaxed), second});
-      cnt++;
+  for (auto it = g_ncv_cache.begin(); it != g_ncv_cache.end();) {
+    const NcvPackKey& k = it->first;
+    NcvPackVal& v = it->second;
+    if (k.st != st) { ++it; continue; }
+    const Tensor* w1 = find(k.uid, k.offset, k.Cout, k.Cin, k.kh, k.kw);
+    const Tensor* w2 = k.Cout2 > 0 ? find(k.uid2, k.offset2, k.Cout2, k.Cin, 1, 1) : nullptr;
+    if (!w1 && !w2) { ++it; continue; }                          // none of this call's parameters
+    if (!w1 || (k.Cout2 > 0 && !w2)) {
+      // a pair image with only ONE of its filters among the parameters (the other was a temporary, or its layer was rebuilt): it cannot be
+      // brought up to date here.  Drop it - the next convolution packs a fresh image from the tensors it is given - unless a captured graph
+      // reads this address; that entry stays, stale by its versions, exactly as when a parameter is written outside the optimiser.
+      if (!v.pinned) { release(v.packed); it = g_ncv_cache.erase(it); }
+      else ++it;
+      continue;
     }
+    if (cnt == NCV_PACK_MAX) flush();
+    a.w[cnt] = NcvW{w1->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw, w2 ? w2->ptr<bf16_t>() : nullptr, k.Cout2};
+    a.dst[cnt] = static_cast<nv_bf8*>(v.packed->raw());
+    v.version = w1->st->version.load(std::memory_order_relaxed);
+    v.version2 = w2 ? w2->st->version.load(std::memory_order_relaxed) : 0;
+    v.tick = ++g_ncv_tick;
+    cnt++;
+    ++it;
   }
   if (fill && cnt > 0) { *fill = a; *fill_cnt = cnt; }
   else flush();
-  for (auto& d : done) {
-    auto it = g_ncv_cache.find(d.k);
-    if (it != g_ncv_cache.end()) { (d.second ? it->second.version2 : it->second.version) = d.version; it->second.tick = ++g_ncv_tick; }
-  }
 }
 void narrow_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) { ncv_pack_launch(a, cnt, st); }
 

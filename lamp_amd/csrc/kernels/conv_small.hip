@@ -313,7 +313,7 @@ template <class T, class A> static Tensor* cs2_packed(const Tensor* w, const Con
   const int KS = g.kh, CBf = cs2_cb_of(g.Cout), CBd = cs2_cb_of(g.Cin);
   const int64_t nf = g.Cin * KS * KS * CBf, nd = g.Cout * KS * KS * CBd;
   *dgrad_offset = nf;
-  const bool cacheable = w->st->owned;
+  const bool cacheable = w->st->owned && !w->st->scratch;
   const Cs2PackKey key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, w->dtype, st};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
   if (cacheable) {

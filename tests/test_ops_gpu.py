@@ -6,6 +6,7 @@ deterministic closed forms.  Tolerances: bit-exact for index/bool results, <= 1e
 f32 forward (BASELINE.json), 1e-12 for f64, bf16 at bf16 resolution (stated per test).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1029,6 +1030,57 @@ def test_pair_launch_sees_every_write_to_either_filter(gpu, cin, cout, N, H, str
     both.step([ga, gb], 1.0); check("after a second step of both (images re-packed in place)")
 
 
+def test_pair_image_is_never_packed_again_from_a_filter_that_is_gone(gpu):
+    """the narrow kernels' pair image used to remember RAW data pointers of both filters and the optimiser's re-pack hook
+    read the absent one's - after a strided sibling (whose contiguous copy dies with the call) or a rebuilt shortcut that pointer dangled.  Now
+    an image is re-packed only from tensors the optimiser is handed, a pair entry with one filter missing is dropped, and copies made inside
+    the entry point are not cached at all.  The pair must keep equalling the two convolutions on the CURRENT weights through all of it."""
+    from lamp_amd import nn as NN
+    dt = torch.bfloat16
+    cin = cout = 6
+    N, H, stride = 16, 32, 2
+    x = closed_form((N, cin, H, H), 3, 2.0, dt)
+    X = to_sten(x)
+    WA, BA = to_sten(closed_form((cout, cin, 3, 3), 17, 0.2, dt)), to_sten(closed_form((cout,), 5, 1.0, dt))
+    wide = to_sten(closed_form((cout, 2 * cin, 1, 1), 23, 0.4, dt))
+    BB = to_sten(closed_form((cout,), 13, 1.0, dt))
+    one, p1, p0, z, sd = i64_array([1, 1]), i64_array([1, 1]), i64_array([0, 0]), i64_array([0, 0]), i64_array([stride, stride])
+
+    def check(WB, what):
+        o2 = (C.c_void_p * 2)()
+        lib.lamp_convolution_pair(o2, X, WA, BA, sd, p1, one, WB, BB, sd, p0, one, 2, 1)
+        pa, pb = S.STen(o2[0]), S.STen(o2[1])
+        ra = aten.convolution(x.float(), to_torch(WA).float(), to_torch(BA).float(), [stride, stride], [1, 1], [1, 1], False, [0, 0], 1)
+        rb = aten.convolution(x.float(), to_torch(WB).float(), to_torch(BB).float(), [stride, stride], [0, 0], [1, 1], False, [0, 0], 1)
+        assert_close(to_torch(pa), ra.double(), FWD_TOL[dt] * 4, what + ": 3x3")
+        assert_close(to_torch(pb), rb.double(), FWD_TOL[dt] * 4, what + ": 1x1")
+
+    ga = S.STen.ones([cout, cin, 3, 3], S.BF16, 0)
+    opt = NN.SGDW([WA], 0.125, 0.0)
+    # (1) a strided sibling: every call makes (and frees) a contiguous copy of it
+    WBs = wide.slice(1, 0, 2 * cin, 2)
+    assert not WBs.is_contiguous()
+    for i in range(4):
+        check(WBs, f"strided sibling, round {i}")
+        junk = [S.STen.full([cout * cin], 1e4, S.BF16, 0) for _ in range(8)]          # what the freed copy's pool block is handed out as next
+        opt.step([ga], 1.0)                                                         # the hook visits the 3x3 alone
+        del junk
+    # (2) the shortcut is rebuilt while the 3x3 is kept
+    for i in range(4):
+        WB = to_sten(closed_form((cout, cin, 1, 1), 29 + i, 0.4, dt))
+        check(WB, f"rebuilt shortcut {i}: first call"); check(WB, f"rebuilt shortcut {i}: cached call")
+        del WB
+        junk = [S.STen.full([cout * cin], -1e4, S.BF16, 0) for _ in range(8)]
+        opt.step([ga], 1.0)
+        del junk
+    WB = to_sten(closed_form((cout, cin, 1, 1), 41, 0.4, dt))
+    check(WB, "after the rebuilds")
+    gb = S.STen.ones([cout, cin, 1, 1], S.BF16, 0)
+    NN.SGDW([WA, WB], 0.125, 0.0).step([ga, gb], 1.0)
+    check(WB, "both stepped")
+    lib.lamp_device_synchronize()
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("reduction", [1, 2])
 def test_nll_loss_forward_accumulates_the_epoch_loss_in_its_launch(gpu, dt, reduction):
@@ -1308,6 +1360,27 @@ def test_weight_gradients_of_a_block_s_two_first_convolutions(gpu, case):
     tol = {torch.float64: 1e-6, torch.float32: 2e-4, torch.bfloat16: 2e-2}[dt]
     assert_close(pa, ra.double(), tol, "3x3 against the oracle")
     assert_close(pb, rb.double(), tol, "1x1 against the oracle")
+
+
+@pytest.mark.parametrize("min_ips", ["2", "3"])
+def test_eight_wave_weight_gradient_dma_and_register_forms_agree_bit_for_bit(gpu, min_ips):
+    """`ig_wgrad8h_kernel` brings its dY tiles in by LDS-DMA through inline asm with hand-counted `s_waitcnt vmcnt` (correct only while
+    hipcc keeps its own waits where they are).  The register form of the same kernel (`LAMP_WG8H_DMA=0`, a run-time switch and the fallback) does
+    the same arithmetic in the same order, so over odd batches, image ranges of one to three images, Cout < 128 and Cin off the 32-channel grid
+    - alone and with the shortcut's gradient riding along - the two must agree BIT FOR BIT.  One child process per form (the switch is read once)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = {}
+    for dma in ("0", "1"):
+        env = dict(os.environ, LAMP_WG8H_DMA=dma, LAMP_WGRAD_MIN_IPS=min_ips)
+        r = subprocess.run([sys.executable, os.path.join(here, "wg8h_digest.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[dma] = r.stdout.strip().splitlines()
+    assert len(outs["0"]) == len(outs["1"]) >= 10
+    assert outs["0"][-1] == outs["1"][-1] and "conv_wgrad_igemm" in outs["1"][-1], outs["1"][-1]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert a == b, f"register form {a} != DMA form {b}"
 
 
 def test_input_gradient_pair_checks_its_arguments(gpu):
