@@ -130,6 +130,24 @@ def pmc_traffic(tag):
     return cls["traffic_bytes"], os.path.relpath(files[-1], ROOT)
 
 
+def rocprof_class(tag):
+    """average launch duration of a kernel class by the rocprofv3 kernel trace of this same command, from the newest committed
+    profiles/r*_class_rocprof.json (scripts/class_rocprof.py builds it from the kernel-stats csv; the profile is of the EAGER step -
+    rocprofv3 and hipGraphLaunch cannot be combined on this image - while the timed region replays the graph)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_class_rocprof.json")))
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[-1]))
+        cls = j["classes"].get(tag)
+    except Exception:
+        return None
+    if not cls:
+        return None
+    return cls["avg_us"], os.path.relpath(files[-1], ROOT), j.get("note", "")
+
+
 def roofline_of(rows):
     """roofline object for the kernel class that took the most time.  avg_us is the plain HIP-event bracket around every launch of
     the class (recorded on the launch's own stream in an UNTIMED pass after the timed region); nothing is subtracted: an (event,
@@ -159,6 +177,14 @@ def roofline_of(rows):
             flops = flops * terms
             extra["executed_flops"] = flops
         ach = flops / avg_s / 1e12
+        rp = rocprof_class(d["tag"])
+        if rp is not None and not d["tag"].startswith("knn_split_f16x"):
+            # labelled, never replacing the event-bracketed figure above: the committed kernel trace of this command
+            extra["avg_us_rocprof"] = rp[0]
+            extra["frac_rocprof"] = flops / (rp[0] * 1e-6) / 1e12 / peak
+            extra["rocprof_source"] = rp[1] + " (committed rocprofv3 kernel trace of the eager step on another box; not measured in this run)"
+        if d["tag"].startswith("knn_split_f16x"):
+            extra["frac_algorithmic"] = d["flops"] / avg_s / 1e12 / peak      # SURVEY 8(d)'s definition: f32 products of the search, not the f16 products executed
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, **extra}
     ach = byts / avg_s / 1e9
     if d["tag"] == "umap_pairs2":

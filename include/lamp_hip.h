@@ -559,6 +559,16 @@ int lamp_nll_loss_forward(lamp_tensor** out, lamp_tensor** total_weight, const l
 int lamp_nll_loss_forward_accumulate_(lamp_tensor** out, lamp_tensor** total_weight, const lamp_tensor* x,
                                       const lamp_tensor* target, const lamp_tensor* weight_or_null, int64_t reduction,
                                       int64_t ignore_index, lamp_tensor* acc, double scale);
+/* nll_loss_forward (mean or sum; acc_or_null as above) on the log-probabilities x [N, C] that lamp_global_avg_pool_log_softmax made of maps
+ * of plane_elems = H * W elements, and from the SAME launch the input gradient of that pooled LogSoftMax for an incoming loss gradient of one -
+ * what backprop seeds the loss with (Variable.backprop, autograd.scala:264-282): plane_grad [N, C], where every element of plane (n, c) of
+ * lamp_global_avg_pool_log_softmax_nll_backward(ones, ...) equals plane_grad[n][c], bit for bit.  plane_grad is stored class-major (strides
+ * [1, N]: its consumer walks one channel at a time).  The caller hands the gradient on as the view expand(plane_grad.unsqueeze(2).unsqueeze(3),
+ * [N, C, H, W]) (strides [1, N, 0, 0]); the one-pass batch-norm backward reads such a view without materialising it.
+ * *plane_grad is NULL (and the call is the plain forward) for shapes the fused form does not take. */
+int lamp_nll_loss_forward_pooled_gradient_(lamp_tensor** out, lamp_tensor** total_weight, lamp_tensor** plane_grad, const lamp_tensor* x,
+                                           const lamp_tensor* target /* i64 [N] */, const lamp_tensor* weight_or_null, int64_t reduction,
+                                           int64_t ignore_index, lamp_tensor* acc_or_null, double scale, int64_t plane_elems);
 int lamp_nll_loss_backward(lamp_tensor** out, const lamp_tensor* grad_out, const lamp_tensor* x,
                            const lamp_tensor* target, const lamp_tensor* weight_or_null, int64_t reduction,
                            int64_t ignore_index, const lamp_tensor* total_weight);

@@ -67,6 +67,9 @@ void backprop(const Var& root) { backprop(root, nullptr); }
 // true while a backprop with an `after` hook runs on this thread: a parameter's gradient must be final when the hook sees the parameter
 // (the data-parallel step starts its exchange there), so nothing may put a weight gradient off
 static thread_local bool tls_backprop_hooked = false;
+// the handle of the ones the running backprop seeded its one-element root with (nullptr otherwise): a closure that sees exactly this tensor
+// as its incoming derivative knows the derivative IS one without reading it (the loss tail's gradient is computed ahead for that case)
+static thread_local const lamp_tensor* tls_seed_ones = nullptr;
 void backprop(const Var& root, const std::function<void(Variable*)>& after) {
   if (!root->needsGrad()) return;
   struct Hooked { bool prev; Hooked(bool h) : prev(tls_backprop_hooked) { tls_backprop_hooked = h; } ~Hooked() { tls_backprop_hooked = prev; } } hooked((bool)after);
@@ -100,6 +103,8 @@ void backprop(const Var& root, const std::function<void(Variable*)>& after) {
     root->grad = ops::ones_like(root->value);
     root->grad_shared = false;
   }
+  struct Seed { const lamp_tensor* prev; Seed(const lamp_tensor* h) : prev(tls_seed_ones) { tls_seed_ones = h; } ~Seed() { tls_seed_ones = prev; } }
+      seed(root->value.numel() == 1 ? root->grad.h() : nullptr);
   const std::vector<Variable*> order = topological_sort(root.get());
   for (Variable* v : order) {                 // what an earlier, abandoned pass over this graph may have left parked
     v->pending.clear();
@@ -490,12 +495,35 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
   LAMP_CHECK(input->value.ndim() == 2, "Nll Loss assumes 2D input (samples x classes). Higher dimensions not implemented.");
   LAMP_CHECK(target.ndim() == 1, "Target should be a 1D tensor with [0,C-1] integers, C number of classes.");
   auto op = new_op("NllLoss");
-  lamp_tensor *v = nullptr, *tw = nullptr;
-  if (acc.defined()) HCALL(lamp_nll_loss_forward_accumulate_(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.h(), scale));
-  else HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
-  Ten val(v), total_weight(tw), iv = input->value;
+  lamp_tensor *v = nullptr, *tw = nullptr, *pgh = nullptr;
   static const bool fuse_tail = [] { const char* e = getenv("LAMP_FUSE_LOSS_BACKWARD"); return !(e && e[0] == '0'); }();
+  // Cnn.resnet's tail with the loss as the root (SupervisedModel.scala:190-211): the loss launch also produces, for a derivative of one, the
+  // pooled LogSoftMax's input gradient as one value per plane (LAMP_FUSE_LOSS_TAIL=0: the separate backward launch)
+  static const bool fuse_ahead = [] { const char* e = getenv("LAMP_FUSE_LOSS_TAIL"); return !(e && e[0] == '0'); }();
+  const bool from_tail = input->op && input->op->params.size() == 1 && std::strcmp(input->op->name, "GlobalAvgPoolLogSoftMax") == 0 &&
+                         input->value.h()->is_device() && input->op->params[0].first->needsGrad() && input->op->params[0].first->value.ndim() == 4;
+  if (fuse_tail && fuse_ahead && from_tail && reduction != 0) {
+    const Ten& xin = input->op->params[0].first->value;
+    HCALL(lamp_nll_loss_forward_pooled_gradient_(&v, &tw, &pgh, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.defined() ? acc.h() : nullptr, scale,
+                                                 xin.size(2) * xin.size(3)));
+  } else if (acc.defined()) HCALL(lamp_nll_loss_forward_accumulate_(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.h(), scale));
+  else HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
+  Ten val(v), total_weight(tw), iv = input->value, plane_grad = pgh ? Ten(pgh) : Ten();
   op->params.push_back({input, [=](const Ten& p, Variable& out) {
+    if (plane_grad.defined() && p.h() == tls_seed_ones && !tls_backprop_hooked && out.op && out.op->params.size() == 1 &&
+        std::strcmp(out.op->name, "GlobalAvgPoolLogSoftMax") == 0) {
+      // the derivative is the seed itself: the gradient computed ahead is the one the launch below would write, as an expanded view
+      Variable& xin = *out.op->params[0].first;
+      const std::vector<int64_t> xs = xin.value.shape();
+      lamp_tensor *u2 = nullptr, *u3 = nullptr, *e = nullptr;
+      HCALL(lamp_unsqueeze(&u2, plane_grad.h(), 2));
+      const Ten t2(u2);
+      HCALL(lamp_unsqueeze(&u3, t2.h(), 3));
+      const Ten pv(u3);
+      HCALL(lamp_expand(&e, pv.h(), xs.data(), 4));
+      xin.accumulate(Ten(e), false);                        // (shared: nothing may add into a stride-0 view in place)
+      return;
+    }
     // Cnn.resnet's tail: the log-probabilities come from the pooled LogSoftMax node.  Its input gradient is linear in this contribution, so
     // the contribution goes straight to THAT node's input in one launch (the [N, C] gradient row is never written); anything else that
     // flows into `out` takes the node's own closure as before

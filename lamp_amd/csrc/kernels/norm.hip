@@ -590,13 +590,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
 // instead of the masked gradient the kernel writes the SECOND batch norm's input gradient (x2 is read once more for that - by then it
 // comes from the Infinity Cache) and its dweight / dbias: one launch and 6 passes instead of two launches and 8.
 struct BnFusedDual { const bf16_t* mean2; const bf16_t* invstd2; const bf16_t* w2; const bf16_t* b2; bf16_t* dweight2; bf16_t* dbias2; unsigned long long* slots2; };
-template <int NP, bool RELU, bool ADD, bool DUAL = false>  // compile-time: run-time branches in the element loop let the compiler sink the sums
+template <int NP, bool RELU, bool ADD, bool DUAL = false, bool PLANES = false>  // compile-time: run-time branches in the element loop let the compiler sink the sums
 __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ mean,
                                                            const bf16_t* __restrict__ invstd, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                            unsigned long long* slots, unsigned* depart, bf16_t* dweight, bf16_t* dbias, bf16_t* __restrict__ dx,
                                                            int64_t N, int C, int HW, int S, double inv_m, int relu,
                                                            const bf16_t* __restrict__ addend, bf16_t* __restrict__ dadd, int vshift, int* assert_word,
-                                                           BnFusedDual dual) {
+                                                           BnFusedDual dual, int dy_sc) {
+  // PLANES: dy holds one value per PLANE, class-major - (n, c) at dy[c * dy_sc + n] - for 8 x 8 maps: the gradient arrives as a view expanded
+  // over the map (the pooled LogSoftMax's input gradient, lamp_nll_loss_forward_pooled_gradient_); a packet is that value eight times, and the
+  // [N, C, H, W] tensor does not exist.  A wave's 64 packets are the eight planes n8 .. n8 + 7 of channel c, whose values are 16 consecutive
+  // bytes at a wave-uniform address: ONE scalar load per round (inline asm: the sixteen of a thread are all in flight together and waited for
+  // once, behind the vector loads of x - as an ordinary load hipcc sank each into the lane-select branches with a wait of its own)
   __shared__ float sm[3][8];
   __shared__ float stat[3];
   const int c = blockIdx.x / S, s = blockIdx.x - c * S;
@@ -610,6 +615,8 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
   const float wc2 = (DUAL && dual.w2) ? (float)dual.w2[c] : 1.f;
   const float scale2 = is2 * wc2, bb2 = (DUAL && dual.b2) ? (float)dual.b2[c] : 0.f;
   uint4 gv[NP], xv[NP];
+  typedef unsigned int bn_u4s __attribute__((ext_vector_type(4)));
+  bn_u4s pq[PLANES ? NP : 1];                               // PLANES: the eight plane values of each round, in scalar registers
   int base[NP];                                             // packet (16-byte) index into the tensors, -1: none (host: numel < 2^34)
   const uint4* dy4 = reinterpret_cast<const uint4*>(dy);
   const uint4* x4 = reinterpret_cast<const uint4*>(x);
@@ -624,8 +631,25 @@ __global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const bf16_t* __restr
     const unsigned n = vshift >= 0 ? (ii >> vshift) : (ii / (unsigned)vpp);
     const int idx = (int)((n * (unsigned)C + (unsigned)c) * (unsigned)vpp + (ii - n * (unsigned)vpp));
     base[k] = valid ? idx : -1;
-    gv[k] = nt_load16(dy4 + idx);                           // the gradient's last reader
+    if constexpr (PLANES) {
+      const unsigned ibase = (unsigned)(k * S + s) * 512u + (unsigned)(tid & ~63);
+      const unsigned n8 = __builtin_amdgcn_readfirstlane(ibase < (unsigned)total ? (ibase >> 3) : 0u);
+      const unsigned short* a = reinterpret_cast<const unsigned short*>(dy) + (size_t)c * (unsigned)dy_sc + n8;
+      asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(pq[k]) : "s"(a));
+    } else gv[k] = nt_load16(dy4 + idx);                    // the gradient's last reader
     xv[k] = x4[idx];
+  }
+  if constexpr (PLANES) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      asm volatile("" : "+s"(pq[k]));                       // (produced by the wait above)
+      const int d = lane >> 4;
+      const unsigned w32 = d == 0 ? pq[k][0] : d == 1 ? pq[k][1] : d == 2 ? pq[k][2] : pq[k][3];
+      const unsigned u = ((lane >> 3) & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+      const unsigned uu = u | (u << 16);
+      gv[k] = make_uint4(uu, uu, uu, uu);
+    }
   }
 #pragma unroll
   for (int k = 0; k < NP; k++)
@@ -1298,9 +1322,11 @@ static bool bn_bwd_fused_fp_launch(const Tensor* gc, const Tensor* xc, const Ten
   }
   return true;
 }
+// gplanes (instead of gc): the gradient as one value per plane (see plane_broadcast_base)
+struct BnPlaneGrad { const bf16_t* p = nullptr; int sn = 0, sc = 0; };
 static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor* mean_t, const Tensor* invstd_t, const Tensor* weight, const Tensor* bias,
                                 Tensor* dw, Tensor* db, Tensor* dx, Tensor* dadd, const Tensor* addc, const BnGeom& g, int relu, hipStream_t st,
-                                const BnDualHost* dualh = nullptr) {
+                                const BnDualHost* dualh = nullptr, BnPlaneGrad gplanes = BnPlaneGrad()) {
   static const bool env_on = [] { const char* e = getenv("LAMP_BN_FUSED_BWD"); return !(e && e[0] == '0'); }();
   const int mode = g_bn_bwd_mode.load(std::memory_order_relaxed);
   const bool on = mode < 0 ? env_on : mode >= 1;
@@ -1314,6 +1340,10 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   const int cus = num_cus();
   static const int per_cu = [] { const char* e = getenv("LAMP_BN_FUSED_PER_CU"); return e ? std::max(1, atoi(e)) : 1; }();   // measured: 2 is slower
   auto per_thread = [&](int64_t s) { return (packets + s * 512 - 1) / (s * 512); };
+  // the scalar-load form of a plane gradient: 8 x 8 maps, class-major values in whole 16-byte groups (a wave's 64 packets are eight whole planes), the
+  // dual form (the only consumer of the loss tail's gradient in Cnn.resnet); anything else gets the materialised tensor from the caller
+  const bool planes = gplanes.p != nullptr;
+  if (planes && !(dualh && g.HW == 64 && gplanes.sn == 1 && g.N % 8 == 0 && gplanes.sc % 8 == 0 && ((uintptr_t)gplanes.p & 15) == 0)) return false;
   const void* kfn = nullptr;
   int64_t S = 0;
   for (int wgs = per_cu; wgs >= 1 && !kfn; wgs--) {        // workgroups per CU aimed at: more, smaller ones first
@@ -1332,7 +1362,8 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
     // (B = 2048's small maps, 4 - 8 MB) it is even.
     static const int64_t small_bytes = [] { const char* e = getenv("LAMP_BN_FUSED_SMALL_BYTES"); return e ? (int64_t)atoll(e) : ((int64_t)4 << 20) + 1; }();
     if (!dualh && !(np_mask & NP) && !(xc->numel() * 2 < small_bytes)) continue;
-#define BN_FUSED_K(NPv) (dualh ? (const void*)bn_bwd_fused_kernel<NPv, true, true, true> : addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> \
+#define BN_FUSED_K(NPv) (dualh ? (planes ? (const void*)bn_bwd_fused_kernel<NPv, true, true, true, true> : (const void*)bn_bwd_fused_kernel<NPv, true, true, true>) \
+                               : addc ? (const void*)bn_bwd_fused_kernel<NPv, true, true> \
                                : relu ? (const void*)bn_bwd_fused_kernel<NPv, true, false> : (const void*)bn_bwd_fused_kernel<NPv, false, false>)
     const void* k = NP == 1 ? BN_FUSED_K(1) : NP == 2 ? BN_FUSED_K(2) : NP == 4 ? BN_FUSED_K(4) : NP == 8 ? BN_FUSED_K(8) : BN_FUSED_K(16);
 #undef BN_FUSED_K
@@ -1348,15 +1379,15 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   if (!sync) return false;                                  // (callers run with the tensor's device current; the buffer must live there)
   unsigned* departp = sync;
   unsigned long long* slotp = reinterpret_cast<unsigned long long*>(sync + BN_FUSED_MAXC);
-  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0);   // (the dual form's second read of x2 is served by the caches)
+  const double passes = (dx ? 3.0 : 2.0) + (addc ? 1.0 : 0.0) + (dadd ? 1.0 : 0.0) - (gplanes.p ? 1.0 : 0.0);   // (the dual form's second read of x2 is served by the caches)
   KernelTimer kt("bn_bwd_fused", 0, passes * (double)xc->numel() * 2.0, st);
-  const bf16_t* dyp = gc->ptr<bf16_t>(); const bf16_t* xp = xc->ptr<bf16_t>();
+  const bf16_t* dyp = gplanes.p ? gplanes.p : gc->ptr<bf16_t>(); const bf16_t* xp = xc->ptr<bf16_t>();
   const bf16_t* mp = mean_t->ptr<bf16_t>(); const bf16_t* ip = invstd_t->ptr<bf16_t>();
   const bf16_t* wp = weight ? weight->ptr<bf16_t>() : (const bf16_t*)nullptr;
   const bf16_t* bp = bias ? bias->ptr<bf16_t>() : (const bf16_t*)nullptr;
   bf16_t* dwp = dw ? dw->ptr<bf16_t>() : (bf16_t*)nullptr; bf16_t* dbp = db ? db->ptr<bf16_t>() : (bf16_t*)nullptr;
   bf16_t* dxp = dx ? dx->ptr<bf16_t>() : (bf16_t*)nullptr;
-  int64_t a_N = g.N; int a_C = (int)g.C, a_HW = (int)g.HW, a_S = (int)S, a_relu = relu;
+  int64_t a_N = g.N; int a_C = (int)g.C, a_HW = (int)g.HW, a_S = (int)S, a_relu = relu, a_sc = gplanes.sc;
   double inv_m = 1.0 / (double)(g.N * g.HW);
   const int vppi = (int)(g.HW / 8);
   int a_vshift = -1;                                        // packets per image row a power of two: a shift instead of a division
@@ -1373,9 +1404,20 @@ static bool bn_bwd_fused_launch(const Tensor* gc, const Tensor* xc, const Tensor
   }
   void* args[] = {(void*)&dyp, (void*)&xp, (void*)&mp, (void*)&ip, (void*)&wp, (void*)&bp, (void*)&slotp, (void*)&departp, (void*)&dwp, (void*)&dbp, (void*)&dxp,
                   (void*)&a_N, (void*)&a_C, (void*)&a_HW, (void*)&a_S, (void*)&inv_m, (void*)&a_relu, (void*)&adp, (void*)&dap, (void*)&a_vshift, (void*)&awp,
-                  (void*)&dual};
+                  (void*)&dual, (void*)&a_sc};
   HIP_CHECK(hipLaunchKernel(kfn, dim3((unsigned)(g.C * S)), dim3(512), args, 0, st));
   return true;
+}
+// A gradient that is constant over every plane, handed over as a view expanded over the map (strides [sn, sc, 0, 0]) of one value per (n, c):
+// where those values start and how they are laid out, or {nullptr}.  (Produced by the loss tail, lamp_nll_loss_forward_pooled_gradient_.)
+static BnPlaneGrad plane_broadcast_base(const Tensor* g) {
+  BnPlaneGrad r;
+  if (!g || g->dtype != kBF16 || g->ndim != 4 || !g->is_device()) return r;
+  if (g->sizes[2] * g->sizes[3] <= 1 || g->strides[2] != 0 || g->strides[3] != 0) return r;
+  const int64_t sn = g->sizes[0] > 1 ? g->strides[0] : 0, sc = g->sizes[1] > 1 ? g->strides[1] : 0;
+  if (sn < 0 || sc < 0 || sn >= ((int64_t)1 << 24) || sc >= ((int64_t)1 << 24) || (g->sizes[0] - 1) * sn + (g->sizes[1] - 1) * sc >= ((int64_t)1 << 31)) return r;
+  r.p = g->ptr<bf16_t>(); r.sn = (int)sn; r.sc = (int)sc;
+  return r;
 }
 static void check_cvec(const Tensor* t, int64_t C, int dtype, const char* what) {
   if (!t) return;
@@ -1714,7 +1756,9 @@ int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_t
   LAMP_CHECK(save_mean && save_invstd && save_mean2 && save_invstd2, "the backward needs the saved statistics of both batch norms");
   check_cvec(save_mean, g.C, x->dtype, "save_mean"); check_cvec(save_invstd, g.C, x->dtype, "save_invstd");
   check_cvec(save_mean2, g.C, x->dtype, "second save_mean"); check_cvec(save_invstd2, g.C, x->dtype, "second save_invstd");
-  Hold xc(contiguous(x)), gc(contiguous(grad_out)), x2c(contiguous(x2));
+  // (a plane-broadcast gradient - the loss tail's - is read as its [N, C] values by the one-pass kernel; materialised only if that kernel does not run)
+  const BnPlaneGrad gplanes = plane_broadcast_base(grad_out);
+  Hold xc(contiguous(x)), gc(gplanes.p ? nullptr : contiguous(grad_out)), x2c(contiguous(x2));
   hipStream_t st = current_stream(x->device());
   const int64_t total = x->numel();
   if (x->dtype == kBF16 && total > 0 && (mask[0] || mask[3])) {
@@ -1722,14 +1766,21 @@ int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_t
     Hold dx(mask[0] ? new_like(xc.get()) : nullptr), dx2(mask[3] ? new_like(xc.get()) : nullptr);
     Hold dw(mask[1] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr), db(mask[2] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
     Hold dw2(mask[4] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr), db2(mask[5] ? new_tensor(cs, 1, x->dtype, x->device()) : nullptr);
-    const bool aligned = g.HW % 8 == 0 && (((uintptr_t)xc->data() | (uintptr_t)gc->data() | (uintptr_t)x2c->data() | (uintptr_t)(dx.get() ? dx->data() : nullptr) |
-                                            (uintptr_t)(dx2.get() ? dx2->data() : nullptr)) & 15) == 0;
+    const bool aligned = g.HW % 8 == 0 && (((uintptr_t)xc->data() | (uintptr_t)(gc.get() ? gc->data() : nullptr) | (uintptr_t)x2c->data() |
+                                            (uintptr_t)(dx.get() ? dx->data() : nullptr) | (uintptr_t)(dx2.get() ? dx2->data() : nullptr)) & 15) == 0;
     BnDualHost dh{save_mean2, save_invstd2, weight2, bias2, dw2.get(), db2.get()};
-    if (aligned && bn_bwd_fused_launch(gc.get(), xc.get(), save_mean, save_invstd, weight, bias, dw.get(), db.get(), dx.get(), dx2.get(), x2c.get(), g, 1, st, &dh)) {
+    bool done = aligned && bn_bwd_fused_launch(gc.get(), xc.get(), save_mean, save_invstd, weight, bias, dw.get(), db.get(), dx.get(), dx2.get(), x2c.get(), g, 1, st, &dh, gplanes);
+    if (!done && !gc.get()) {                               // the plane form did not take it: the same kernel on the materialised gradient
+      gc = Hold(contiguous(grad_out));
+      done = (((uintptr_t)gc->data()) & 15) == 0 && g.HW % 8 == 0 &&
+             bn_bwd_fused_launch(gc.get(), xc.get(), save_mean, save_invstd, weight, bias, dw.get(), db.get(), dx.get(), dx2.get(), x2c.get(), g, 1, st, &dh);
+    }
+    if (done) {
       out6[0] = dx.take(); out6[1] = dw.take(); out6[2] = db.take(); out6[3] = dx2.take(); out6[4] = dw2.take(); out6[5] = db2.take();
       return 0;
     }
   }
+  if (!gc.get()) gc = Hold(contiguous(grad_out));
   // every other case (f32 / f64, small batches, a shared device): the chain itself - the second batch norm's output from its saved
   // statistics, the one-addend backward, then the second batch norm's backward on the masked gradient
   Hold l(new_like(x2c.get()));

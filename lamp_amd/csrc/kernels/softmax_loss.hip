@@ -276,6 +276,83 @@ __global__ __launch_bounds__(1024) void nll_fwd_reduce_kernel(const T* __restric
     if (acc) *acc = store_as<T>((A)(load_as<A>(*acc) + (A)acc_scale * load_as<A>(o)));
   }
 }
+// nll_fwd_reduce_kernel and, from the same launch, the INPUT GRADIENT OF THE POOLED LogSoftMax IN FRONT OF IT for an incoming loss gradient of one
+// (lamp_nll_loss_forward_pooled_gradient_; Cnn.resnet's tail, cnn.scala:129-136 + SupervisedModel.scala:190-211: the loss is the root of backprop,
+// whose derivative autograd.scala:264-282 fills with ones).  Workgroup 0 is nll_fwd_reduce_kernel, statement for statement.  Every other
+// workgroup takes 16 rows, a wave each: it sums the total weight itself (the same 1024 partial sums in the same order: the same bits as
+// workgroup 0's - it needs nothing from another workgroup), builds the loss's gradient row in LDS as gap_lsm_nll_bwd_kernel does, runs
+// log_softmax_bwd_row over it and divides by the plane size with that kernel's roundings.  What leaves is ONE value per (sample, class): every
+// element of plane (n, c) of the [N, C, H, W] gradient gap_lsm_nll_bwd_kernel would write equals that value - the consumer reads it through an
+// expanded view and the [N, C, H, W] tensor is neither written nor read.  The values are stored CLASS-MAJOR (plane_grad_t[c][n]: the batch norm
+// that consumes them walks one channel at a time), sixteen consecutive samples per store segment.
+template <class T>
+__global__ __launch_bounds__(1024) void nll_fwd_tail_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, const T* __restrict__ w,
+                                                            T* __restrict__ out, T* __restrict__ total_weight, int64_t N, int64_t C, int64_t reduction,
+                                                            int64_t ignore, int* __restrict__ assert_word, T* acc, double acc_scale,
+                                                            T* __restrict__ plane_grad_t, int hw) {
+  using A = acc_t<T>;
+  __shared__ A sm[16];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool first = blockIdx.x == 0;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int CP = ((int)C + 7) & ~7;
+  T* gl = reinterpret_cast<T*>(smem) + (size_t)wid * (CP + (int)C);      // [C]: the pooled gradient (this wave's row)
+  T* grow = gl + CP;                                                     // [C]: the loss's gradient row; before that, the row's log-probabilities
+  const int64_t n0 = ((int64_t)blockIdx.x - 1) * 16, n = n0 + wid;
+  const bool live = !first && n < N;
+  // this wave's row and target are requested before the scan over all targets (whose round trips they share)
+  int64_t trow = 0;
+  if (live) {
+    trow = target[n];
+    for (int c = lane; c < (int)C; c += 64) grow[c] = x[n * C + c];
+  }
+  A loss = 0, tw = 0;
+  for (int64_t i = threadIdx.x; i < N; i += blockDim.x) {
+    const int64_t t = target[i];
+    if (t == ignore) continue;
+    if (t < 0 || t >= C) { if (first) *(volatile int*)assert_word = kAssertNllTarget; continue; }
+    const A wt = w ? load_as<A>(w[t]) : A(1);
+    if (first) loss -= wt * load_as<A>(x[i * C + t]);
+    tw += wt;
+  }
+  if (first) loss = block_sum(loss, sm);                    // (block-uniform)
+  tw = block_sum(tw, sm);
+  const T twT = store_as<T>(tw);
+  if (first) {
+    if (threadIdx.x == 0) {
+      *total_weight = twT;
+      const T o = reduction == 1 ? store_as<T>((A)(loss / tw)) : store_as<T>(loss);
+      *out = o;
+      if (acc) *acc = store_as<T>((A)(load_as<A>(*acc) + (A)acc_scale * load_as<A>(o)));
+    }
+    return;
+  }
+  if (live) {
+    // grad_in = g - exp(output) * sum(g) with g = the one-hot row of nll_bwd_kernel: log_softmax_bwd_row's arithmetic (its sum over the row is
+    // the row's only non-zero plus zeros: exact in any order), then the division by the plane size as gap_lsm_nll_bwd_kernel rounds it
+    A v = 0;
+    if (trow != ignore && trow >= 0 && trow < C) {
+      A g = load_as<A>(store_as<T>(A(1)));                  // the root's derivative
+      if (reduction == 1) g = g / load_as<A>(twT);
+      v = -(w ? load_as<A>(w[trow]) : A(1)) * g;
+    }
+    const T vt = store_as<T>(v), zero = store_as<T>(A(0));
+    A s = 0;
+    for (int c = lane; c < (int)C; c += 64) s += load_as<A>(c == trow ? vt : zero);
+    s = wave_sum(s);
+    for (int c = lane; c < (int)C; c += 64) {
+      const T gi = store_as<T>((A)(load_as<A>(c == trow ? vt : zero) - t_exp<A>(load_as<A>(grow[c])) * s));
+      gl[c] = store_as<T>((A)(load_as<A>(gi) / (A)hw));
+    }
+  }
+  __syncthreads();
+  // class-major store: [c][n0 .. n0 + 16)
+  const int rows = (int)((N - n0) < 16 ? (N - n0) : 16);
+  for (int idx = threadIdx.x; idx < 16 * (int)C; idx += 1024) {
+    const int c = idx >> 4, r = idx & 15;
+    if (r < rows) plane_grad_t[(int64_t)c * N + n0 + r] = (reinterpret_cast<const T*>(smem) + (size_t)r * (CP + (int)C))[c];
+  }
+}
 template <class T>
 __global__ void nll_fwd_none_kernel(const T* __restrict__ x, const int64_t* __restrict__ target, const T* __restrict__ w,
                                     T* __restrict__ out, int64_t N, int64_t C, int64_t ignore, int* __restrict__ assert_word) {
@@ -557,6 +634,45 @@ static int nll_forward_impl(lamp_tensor** out, lamp_tensor** total_weight, const
     *out = o.take();
   }
   *total_weight = tw.take();
+  LAMP_API_END
+}
+
+int lamp_nll_loss_forward_pooled_gradient_(lamp_tensor** out, lamp_tensor** total_weight, lamp_tensor** plane_grad, const lamp_tensor* x,
+                                           const lamp_tensor* target, const lamp_tensor* weight, int64_t reduction, int64_t ignore_index,
+                                           lamp_tensor* acc_or_null, double scale, int64_t plane_elems) {
+  LAMP_API_BEGIN
+  *plane_grad = nullptr;
+  nll_check(x, target, weight);
+  LAMP_CHECK(reduction == 1 || reduction == 2, "nll_loss_forward_pooled_gradient_: reduction mean (1) or sum (2), got " << reduction);
+  LAMP_CHECK(plane_elems >= 1 && plane_elems <= (1 << 24), "nll_loss_forward_pooled_gradient_: bad plane size " << plane_elems);
+  const int64_t N = x->sizes[0], C = x->sizes[1];
+  const size_t lds = 16 * (size_t)((((int)C + 7) & ~7) + (int)C) * x->itemsize();
+  if (N == 0 || C > 4096 || lds > 48 * 1024) {              // no fused form for this shape: the plain forward, no gradient (the caller runs the backward)
+    return nll_forward_impl(out, total_weight, x, target, weight, reduction, ignore_index, acc_or_null, scale);
+  }
+  if (acc_or_null) {
+    check_device_tensor(acc_or_null, "accumulator");
+    LAMP_CHECK(acc_or_null->numel() == 1 && acc_or_null->dtype == x->dtype && acc_or_null->device() == x->device(),
+               "nll_loss_forward_pooled_gradient_: the accumulator must be a one-element tensor of the input's dtype on its device, got " << acc_or_null->describe());
+  }
+  Hold xc(contiguous(x)), tc(contiguous(target));
+  Hold wc(weight ? contiguous(weight) : nullptr);
+  hipStream_t st = current_stream(x->device());
+  Hold tw(new_tensor(nullptr, 0, x->dtype, x->device())), o(new_tensor(nullptr, 0, x->dtype, x->device()));
+  int64_t ts[2] = {C, N};
+  Hold pgt(new_tensor(ts, 2, x->dtype, x->device()));       // class-major values; handed out as their [N, C] transpose (strides [1, N])
+  int* aw = device_assert_word(x->device());
+  const unsigned blocks = 1u + (unsigned)((N + 15) / 16);
+  LAMP_DISPATCH_FLOAT(x->dtype, T, hipLaunchKernelGGL((nll_fwd_tail_kernel<T>), dim3(blocks), dim3(1024), lds, st, static_cast<const Tensor*>(xc.get())->ptr<T>(),
+                                                      static_cast<const Tensor*>(tc.get())->ptr<int64_t>(),
+                                                      wc.get() ? static_cast<const Tensor*>(wc.get())->ptr<T>() : (const T*)nullptr, o->ptr<T>(), tw->ptr<T>(), N, C,
+                                                      reduction, ignore_index, aw, acc_or_null ? acc_or_null->ptr<T>() : (T*)nullptr, scale, pgt->ptr<T>(), (int)plane_elems));
+  LAMP_LAUNCH_CHECK();
+  *out = o.take();
+  *total_weight = tw.take();
+  lamp_tensor* tr = nullptr;
+  if (lamp_transpose(&tr, pgt.get(), 0, 1) != 0) throw Error(lamp_last_error());
+  *plane_grad = tr;
   LAMP_API_END
 }
 

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="resnet")
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=256)   # the same B or B / 8 of the GPU run's 2048
     ap.add_argument("--budget-s", type=float, default=15.0)
     ap.add_argument("--threads", type=int, default=32)
     a = ap.parse_args()
@@ -36,7 +36,8 @@ def main():
         opt = O.AdamW([p.value for p in m.parameters()], 0.0, 1e-3, 0.9, 0.95)
         step = lambda: O.training_step(m, O.nll_loss(100, cw), x, target, opt)
         unit, per_step = "samples/s", B
-        sample = f"Cnn.resnet(100) fwd+bwd+AdamW, fp32, batch {B} (GPU run uses batch 2048 per GPU), ATen CPU kernels via torch.ops.aten"
+        sample = (f"Cnn.resnet(100) fwd+bwd+AdamW, fp32, batch {B} (= B / {2048 // B} of the GPU run's 2048 per GPU, SURVEY 8d), ATen CPU kernels via torch.ops.aten, "
+                  f"{T} intra-op threads on a host of {os.cpu_count()} logical cores")
     elif a.workload == "mlp":
         m = O.Sequential(O.mlp(784, 10, [256], dt), O.Fun(lambda v: v.logSoftMax(1)))
         B = 1024
@@ -115,7 +116,7 @@ def main():
         total_s = state["knn_1m_s"] + 500 * it_1m_s
         value = 1_000_000 / total_s
         sample += f" -> {total_s:.0f} s end to end"
-    print(json.dumps({"value": value, "unit": unit, "cores": T, "kind": "port", "sample": sample + f"; {k} steps in {dtm:.1f} s on {cpu}"}))
+    print(json.dumps({"value": value, "unit": unit, "cores": T, "host_cores": os.cpu_count(), "kind": "port", "sample": sample + f"; {k} steps in {dtm:.1f} s on {cpu}"}))
 
 
 if __name__ == "__main__":

@@ -1109,6 +1109,97 @@ def test_nll_loss_forward_accumulates_the_epoch_loss_in_its_launch(gpu, dt, redu
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(64, 100, 8, 8), (2048, 100, 8, 8), (37, 10, 4, 4), (1, 7, 8, 8), (19, 130, 8, 8)])
+def test_loss_launch_also_yields_the_pooled_log_softmax_input_gradient(gpu, dt, shape):
+    """lamp_nll_loss_forward_pooled_gradient_ (round 6): the NllLoss forward of Cnn.resnet's tail and - from the same launch, for the derivative
+    of one that backprop seeds a loss with (autograd.scala:264-282) - the input gradient of the pooled LogSoftMax in front of it, as ONE value per
+    (sample, class) plane.  Loss, total weight and epoch accumulator BITWISE those of lamp_nll_loss_forward(_accumulate_); the plane values
+    BITWISE every element of their plane in lamp_global_avg_pool_log_softmax_nll_backward(ones, ...) - with and without class weights, with an
+    ignored class, mean and sum; and against the f64 mathematics."""
+    if shape[0] == 2048 and dt != torch.bfloat16:
+        pytest.skip("the large case only in the benchmark's dtype")
+    N, Cc, H, _ = shape
+    x = closed_form(shape, 3, 6.0, dt)
+    X = to_sten(x)
+    o = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax(C.byref(o), X)
+    Y = S.STen(o)
+    target = (torch.arange(N) * 7) % Cc
+    if N > 5:
+        target[5] = 3
+    T_ = to_sten(target)
+    wts = closed_form((Cc,), 13, 1.0, dt).abs() + 0.5
+    ones = S.STen.ones([], S.F64 if dt == torch.float64 else S.F32 if dt == torch.float32 else S.BF16, 0)
+    for reduction in (1, 2):
+        for W_ in (None, to_sten(wts)):
+            for ignore in (-100, 3):
+                lv, tw = C.c_void_p(), C.c_void_p()
+                acc0 = closed_form((1,), 21, 8.0, dt)
+                A1 = to_sten(acc0)
+                lib.lamp_nll_loss_forward_accumulate_(C.byref(lv), C.byref(tw), Y, T_, W_, reduction, ignore, A1, float(N))
+                LV, TW = S.STen(lv), S.STen(tw)
+                one = C.c_void_p(); lib.lamp_global_avg_pool_log_softmax_nll_backward(C.byref(one), ones, T_, W_, reduction, ignore, TW, Y, X)
+                DX = S.STen(one).to_numpy()
+                A2 = to_sten(acc0)
+                l2, t2, pg = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                lib.lamp_nll_loss_forward_pooled_gradient_(C.byref(l2), C.byref(t2), C.byref(pg), Y, T_, W_, reduction, ignore, A2, float(N), H * H)
+                what = f"reduction {reduction}, weights {W_ is not None}, ignore {ignore}"
+                assert pg.value, "no fused form for " + str(shape)
+                assert np.array_equal(S.STen(l2).to_numpy(), LV.to_numpy()) and np.array_equal(S.STen(t2).to_numpy(), TW.to_numpy()), what
+                assert np.array_equal(A2.to_numpy(), A1.to_numpy()), what
+                PG = S.STen(pg)
+                assert PG.shape == [N, Cc]
+                view = PG.unsqueeze(2).unsqueeze(3).expand([N, Cc, H, H])
+                assert view.strides[2:] == [0, 0] and (N == 1 or view.strides[:2] == [1, N])        # class-major values
+                assert np.array_equal(view.to_numpy(), DX), what + ": plane values differ from the backward launch"
+                # without an accumulator
+                l3, t3, pg3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                lib.lamp_nll_loss_forward_pooled_gradient_(C.byref(l3), C.byref(t3), C.byref(pg3), Y, T_, W_, reduction, ignore, None, 0.0, H * H)
+                assert np.array_equal(S.STen(l3).to_numpy(), LV.to_numpy()) and np.array_equal(S.STen(pg3).to_numpy(), PG.to_numpy()), what
+    # the mathematics (mean, weighted): d loss / d x[n, c, h, w] = w[t_n] (softmax(pool(x))[n, c] - [c == t_n]) / (sum w[t]) / (H W)
+    xd = x.double().requires_grad_(True)
+    lp = torch.log_softmax(xd.mean(dim=(2, 3)), dim=1)
+    torch.nn.functional.nll_loss(lp, target, weight=wts.double(), reduction="mean").backward()
+    l4, t4, pg4 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    lib.lamp_nll_loss_forward_pooled_gradient_(C.byref(l4), C.byref(t4), C.byref(pg4), Y, T_, to_sten(wts), 1, -100, None, 0.0, H * H)
+    assert_close(to_torch(S.STen(pg4)), xd.grad[:, :, 0, 0], {torch.float64: 1e-10, torch.float32: 1e-3, torch.bfloat16: 6e-2}[dt], "plane gradient vs f64")
+    with pytest.raises(Exception, match="reduction mean"):
+        lib.lamp_nll_loss_forward_pooled_gradient_(C.byref(l4), C.byref(t4), C.byref(pg4), Y, T_, None, 0, -100, None, 0.0, H * H)
+
+
+@pytest.mark.parametrize("shape", [(2048, 100, 8, 8), (256, 128, 8, 8), (70, 16, 16, 16)])
+def test_batch_norm_pair_backward_reads_a_plane_broadcast_gradient_in_place(gpu, shape):
+    """The one-pass backward of relu(bn(x) + bn2(x2)) handed the loss tail's gradient as the stride-0 view expand([N, C, 1, 1] -> [N, C, H, W])
+    (lamp_nll_loss_forward_pooled_gradient_): all six results BITWISE those for the materialised tensor - the kernel reads the [N, C] values and
+    the 26 MB gradient of the benchmark's last block is neither written nor read."""
+    dt = torch.bfloat16
+    N, Cc, H, _ = shape
+    x, x2 = closed_form(shape, 3, 4.0, dt), closed_form(shape, 29, 3.0, dt)
+    w, b, w2, b2 = (closed_form((Cc,), k, 1.0, dt) + (1.0 if k in (5, 11) else 0.0) for k in (5, 7, 11, 13))
+    pg = closed_form((N, Cc), 17, 0.01, dt)
+    X, X2, W_, B_, W2, B2, PG = (to_sten(t) for t in (x, x2, w, b, w2, b2, pg))
+    z = lambda: to_sten(torch.zeros(Cc, dtype=dt))
+    out5 = (C.c_void_p * 5)()
+    lib.lamp_native_batch_norm2_add_relu(out5, X, W_, B_, z(), z(), X2, W2, B2, z(), z(), 0.1, 0.1, 1e-5, 1e-5)
+    _, sm, si, sm2, si2 = (S.STen(h) for h in out5)
+    view = PG.view(N, Cc, 1, 1).expand([N, Cc, H, H])
+    dense = view.contiguous()
+    assert view.strides == [Cc, 1, 0, 0] and dense.strides != view.strides
+    # ... and class-major values (what the loss launch hands out): strides [1, N, 0, 0]
+    PGT = to_sten(pg.t().contiguous()).transpose(0, 1)
+    view_t = PGT.unsqueeze(2).unsqueeze(3).expand([N, Cc, H, H])
+    assert view_t.strides == [1, N, 0, 0] and np.array_equal(view_t.to_numpy(), dense.to_numpy())
+    mask = (C.c_uint8 * 6)(1, 1, 1, 1, 1, 1)
+    res = {}
+    for name, G in (("view", view), ("class-major view", view_t), ("dense", dense)):
+        out6 = (C.c_void_p * 6)()
+        lib.lamp_native_batch_norm2_add_relu_backward(out6, G, X, W_, B_, sm, si, X2, W2, B2, sm2, si2, 1e-5, 1e-5, mask)
+        res[name] = [S.STen(h).to_numpy() for h in out6]
+    for name in ("view", "class-major view"):
+        for i, (a, b_) in enumerate(zip(res[name], res["dense"])):
+            assert np.array_equal(a, b_), f"result {i} differs between the {name} and the materialised gradient"
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(64, 100, 8, 8), (2048, 100, 8, 8), (5, 10, 4, 4), (7, 33, 16, 16), (3, 256, 8, 8), (4, 12, 7, 7), (2, 6, 2, 2)])
 def test_global_avg_pool_log_softmax_is_bitwise_the_three_call_chain(gpu, dt, shape):
     """lamp_global_avg_pool_log_softmax(+_backward) = avg_pool2d(k = H) -> flatten -> log_softmax(1) and its backward, BITWISE: one

@@ -187,6 +187,22 @@ def test_folding_the_mid_block_batch_norm_into_the_convolution_changes_no_bit(gp
     assert digests["0"] == digests["1"]
 
 
+@pytest.mark.parametrize("batch", ["64", "1024"])
+def test_computing_the_tail_gradient_in_the_loss_launch_changes_no_bit(gpu, batch):
+    """Round 6: the NllLoss forward launch also produces the pooled LogSoftMax's input gradient for the seed derivative of one, one value per
+    plane, and the last block's batch-norm backward reads it through an expanded view (LAMP_FUSE_LOSS_TAIL=0: the separate backward launch that
+    writes the [N, C, H, W] gradient).  Loss, all 37 gradients and every running statistic of a training step are BITWISE the same."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, LAMP_FUSE_LOSS_TAIL=flag, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, batch], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[flag] = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert digests["0"] == digests["1"]
+
+
 def test_running_a_block_s_two_first_convolutions_as_one_launch_changes_no_bit(gpu):
     """Residual's rewrite (nn.cpp): both branches of every block of Cnn.resnet start with a Conv2D on the block's input (cnn.scala:38-45,
     64-72); F::convolution_pair runs the 3x3 and the 1x1 of res3 / res4 in one launch of the eight-image kernel (B >= 1024).  Loss, all 37
