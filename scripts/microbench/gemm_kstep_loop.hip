@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -49,12 +50,31 @@ __device__ __forceinline__ u4v frag_ks(const char* img, int row0, int s, int lan
 // SRC (modes with DMA): 0 = every workgroup fills its stages from the same 256 KiB (L2 hits only: what the DMA itself costs the loop - issue, LDS
 // write port), 1 = the operands of a 4096^3 product with the kernel's own addressing and tile order (A and B shared between workgroups as there)
 template <int MODE, int BT, int SRC>
-__global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src, float* out, unsigned long long* cyc, int stages, int ld, int group_m) {
+__global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src, float* out, unsigned long long* cyc, int stages, int ld, int group_m, int rot_mode, int rnd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  for (int o = tid * 16; o < 2 * SLOT; o += 512 * 16) *reinterpret_cast<u4v*>(smem + o) = u4v{0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u};
+  // operand values: RANDOM bf16 uniform in [-1, 1) (rnd = 1: the matrix pipe's power, and with it the clock, depends on the data - the benchmark's
+  // operands are random) or the constants 1, 0.5, 0.25 (rnd = 0)
+  for (int o = tid * 16; o < 2 * SLOT; o += 512 * 16) {
+    u4v v = u4v{0x3f803f80u, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u};
+    if (rnd) {
+      unsigned x = (unsigned)(o + 1) * 2654435761u + blockIdx.x * 40503u;
+      unsigned w[4];
+      for (int j = 0; j < 4; j++) {
+        unsigned h[2];
+        for (int e = 0; e < 2; e++) {
+          x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+          const float f = (float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;      // [-1, 1)
+          h[e] = __float_as_uint(f) >> 16;
+        }
+        w[j] = h[0] | (h[1] << 16);
+      }
+      v = u4v{w[0], w[1], w[2], w[3]};
+    }
+    *reinterpret_cast<u4v*>(smem + o) = v;
+  }
   __syncthreads();
   f4v acc[8][4];
 #pragma unroll
@@ -89,10 +109,16 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src,
         const int row = p >> 3, chunk = (p & 7) ^ (row & 7);
         __builtin_amdgcn_global_load_lds((glb_t*)(Ag + ((size_t)(tm * 256 + row) * ld + k0 + chunk * 8) * 2), (lds_t*)(sb + piece * 1024), 16, 0, 0);
       }
+      // rot: the ORDER in which a workgroup requests the 32 pieces of B's stage (any order fills the same image): workgroups that walk the same
+      // rows in the same order hammer the same few memory channels at the same time
+      const int rot = rot_mode == 1 ? tn * 4 : rot_mode == 2 ? tn * 4 + tm : rot_mode == 3 ? tm * 8 : rot_mode == 4 ? tn * 2 + tm * 8 : 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int piece = wid * 4 + i, p = piece * 64 + lane;
-        if (BT) {                                           // B: image [64 k][32 chunks], 32-byte pairs XOR ks_swz(k)
+        const int piece = (wid * 4 + i + rot) & 31, p = piece * 64 + lane;
+        if (BT == 2) {                                      // B K-strided, image cut into four [64 k][64 columns] sub-images: a piece = 8 k rows x 128 bytes
+          const int sub = piece >> 3, k = ((piece & 7) << 3) + (lane >> 3), c = lane & 7;
+          __builtin_amdgcn_global_load_lds((glb_t*)(Bg + ((size_t)(k0 + k) * ld + tn * 256 + sub * 64 + c * 8) * 2), (lds_t*)(sb + IMG + piece * 1024), 16, 0, 0);
+        } else if (BT) {                                    // B: image [64 k][32 chunks], 32-byte pairs XOR ks_swz(k)
           const int k = p >> 5, c = p & 31;
           const int col8 = ((((c >> 1) ^ ks_swz(k))) << 1) | (c & 1);
           __builtin_amdgcn_global_load_lds((glb_t*)(Bg + ((size_t)(k0 + k) * ld + tn * 256 + col8 * 8) * 2), (lds_t*)(sb + IMG + piece * 1024), 16, 0, 0);
@@ -121,7 +147,38 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src,
   FENCE8("s_waitcnt lgkmcnt(0)", fa[0]); FENCE4("", fb[0]);
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  if (MODE == 0) {
+  if (MODE == 6) {
+    // the same flops per k-step from v_mfma_f32_32x32x16_bf16 (a 128 x 64 wave tile = 4 x 2 tiles of 32 x 32; 16 MFMAs of 32768 flop per 32-deep
+    // k-step): does the wider instruction, which reads a quarter of the operand registers per flop, sustain more on random data?
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v c[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) c[i][j][e] = 0.f;
+    for (int t = 0; t < stages; t++) {
+      asm volatile("" : "+v"(fa[0][0]), "+v"(fb[0][0]));
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, fb[0][j * 2 + kk]), __builtin_bit_cast(bf8v, fa[0][i * 2 + kk]), c[i][j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][j][e & 3] += c[i][j][e];
+  } else if (MODE == 0) {
     for (int t = 0; t < stages; t++) {
       asm volatile("" : "+v"(fa[0][0]), "+v"(fb[0][0]));
       __builtin_amdgcn_sched_barrier(0); mfma(0); __builtin_amdgcn_sched_barrier(0); mfma(0); __builtin_amdgcn_sched_barrier(0);
@@ -188,15 +245,17 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src,
   if (lane == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
 }
 
+int g_rnd = 0;
 template <int MODE, int BT, int SRC = 0>
-static void run(const char* src, float* out, unsigned long long* cyc, const char* what, int ld = 4096, int group_m = 4) {
+static void run(const char* src, float* out, unsigned long long* cyc, const char* what, int ld = 4096, int group_m = 4, int rot_mode = 0) {
+  extern int g_rnd; const int rnd = g_rnd;
   const int stages = 2048;
   (void)hipFuncSetAttribute((const void*)loop_kernel<MODE, BT, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float ms = 0.f;
   for (int rep = 0; rep < 3; rep++) {
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((loop_kernel<MODE, BT, SRC>), dim3(256), dim3(512), 2 * SLOT, 0, src, out, cyc, stages, ld, group_m);
+    hipLaunchKernelGGL((loop_kernel<MODE, BT, SRC>), dim3(256), dim3(512), 2 * SLOT, 0, src, out, cyc, stages, ld, group_m, rot_mode, rnd);
     (void)hipEventRecord(e1, 0); (void)hipDeviceSynchronize(); (void)hipEventElapsedTime(&ms, e0, e1);
   }
   hipError_t err = hipGetLastError();
@@ -206,7 +265,7 @@ static void run(const char* src, float* out, unsigned long long* cyc, const char
   for (int b = 0; b < 256; b++) for (int w = 0; w < 8; w++) c += (double)h[b * 8 + w];
   c /= 256.0 * 8 * stages * 2;
   const double flops = 256.0 * 8 * stages * 64.0 * 16384.0;
-  printf("mode %d BT %d SRC %d ld %d group_m %d (%s): %.0f ticks per k-step and wave (32 MFMAs) = %.1f per MFMA and SIMD; launch %.3f ms = %.0f TFLOP/s = %.3f of 2.5 PF; %.2f ticks/ns%s\n", MODE, BT, SRC, ld, group_m, what, c,
+  printf("%s mode %d BT %d SRC %d ld %d group_m %d rot %d (%s): %.0f ticks per k-step and wave (32 MFMAs) = %.1f per MFMA and SIMD; launch %.3f ms = %.0f TFLOP/s = %.3f of 2.5 PF; %.2f ticks/ns%s\n", rnd ? "RANDOM" : "const", MODE, BT, SRC, ld, group_m, rot_mode, what, c,
          c / 32.0 / 2.0, ms, flops / (ms * 1e-3) * 1e-12, flops / (ms * 1e-3) * 1e-12 / 2500.0, c * stages * 2 / (ms * 1e6), err == hipSuccess ? "" : "  [HIP ERROR]");
 }
 
@@ -216,25 +275,23 @@ int main() {
   const size_t bytes = (size_t)2 * 4096 * 4352 * 2;
   (void)hipMalloc(&src, bytes);
   (void)hipMemset(src, 0x3f, bytes);
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < 4; pass++) {
+    g_rnd = pass & 1;
+    if (g_rnd) {                                            // the global operands too
+      std::vector<unsigned short> h(bytes / 2);
+      unsigned x = 12345u;
+      for (size_t i = 0; i < h.size(); i++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; float f = (float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+      (void)hipMemcpy(src, h.data(), bytes, hipMemcpyHostToDevice);
+    } else (void)hipMemset(src, 0x3f, bytes);
     run<0, 0>(src, out, cyc, "MFMAs only");
+    run<6, 0>(src, out, cyc, "MFMAs only, v_mfma_f32_32x32x16_bf16");
     run<1, 0>(src, out, cyc, "kernel schedule, B by ds_read_b128");
     run<1, 1>(src, out, cyc, "kernel schedule, B by ds_read_b64_tr_b16");
     run<2, 0, 0>(src, out, cyc, "kernel schedule + DMA of L2-resident bytes, b128");
     run<2, 1, 0>(src, out, cyc, "kernel schedule + DMA of L2-resident bytes, tr");
-    run<2, 0, 1>(src, out, cyc, "kernel schedule + DMA of the 4096^3 operands, b128 (= the kernel's dX form without its epilogue)");
-    run<2, 1, 1>(src, out, cyc, "kernel schedule + DMA of the 4096^3 operands, tr (= the forward)");
-    for (int gm : {1, 2, 8, 16}) run<2, 1, 1>(src, out, cyc, "the forward, another tile order", 4096, gm);
-    for (int gm : {1, 2, 8, 16}) run<2, 0, 1>(src, out, cyc, "the dX form, another tile order", 4096, gm);
-    run<2, 1, 1>(src, out, cyc, "the forward, leading dimensions 4096 + 64", 4160, 4);
-    run<2, 1, 1>(src, out, cyc, "the forward, leading dimensions 4096 + 256", 4352, 4);
-    run<2, 0, 1>(src, out, cyc, "the dX form, leading dimensions 4096 + 64", 4160, 4);
+    run<2, 0, 1>(src, out, cyc, "kernel schedule + DMA of the 4096^3 operands, b128 (the kernel's dX form without prologue / epilogue)");
+    run<2, 1, 1>(src, out, cyc, "kernel schedule + DMA of the 4096^3 operands, tr (the forward)");
     run<3, 0>(src, out, cyc, "wave-pipelined reads, one barrier per k-step, b128");
-    run<3, 1>(src, out, cyc, "wave-pipelined reads, tr");
-    run<4, 0, 0>(src, out, cyc, "wave-pipelined + DMA of L2-resident bytes, b128");
-    run<4, 0, 1>(src, out, cyc, "wave-pipelined + DMA of the 4096^3 operands, b128");
-    run<4, 1, 1>(src, out, cyc, "wave-pipelined + DMA of the 4096^3 operands, tr");
-    run<5, 0, 1>(src, out, cyc, "wave-pipelined + DMA of the 4096^3 operands, reads spread, b128");
   }
   return 0;
 }
