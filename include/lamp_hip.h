@@ -739,6 +739,14 @@ int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, c
                                   const lamp_tensor* index1, const lamp_tensor* index2, const lamp_tensor* b,
                                   const lamp_tensor* index3, const lamp_tensor* index4, double min_dist,
                                   int balance, double repulsion_strength, const double* term_weights);
+/* Umap.optimize's negatives drawn by the library (round 6).  lamp_umap_negatives: ii = index1.repeatInterleave(n), jj = randint(0, high, [E1 * n])
+ * (umap.scala:211-213) from one counter block of the generator.  lamp_umap_loss_grad_sampled = lamp_umap_loss_grad_skip_self on exactly those
+ * negatives when it takes the generator at the same point (lamp_manual_seed + the same calls since) - drawn INSIDE the kernels for 2-D layouts: the
+ * per-iteration index tensors (0.72 GB at 1M points), repeatInterleave, randint and the pair count's pass over them do not exist. */
+int lamp_umap_negatives(lamp_tensor** ii, lamp_tensor** jj, const lamp_tensor* index1, int64_t negatives_per_edge, int64_t high);
+int lamp_umap_loss_grad_sampled(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1,
+                                const lamp_tensor* index2, const lamp_tensor* b, int64_t negatives_per_edge, int64_t high, double min_dist,
+                                int balance, double repulsion_strength, const double* term_weights);
 
 /* The layout with its EDGE LIST sharded over ranks (lamp-umap is single-device): every rank evaluates its slice of the
  * attractive edges and its own negatives under GLOBAL normalisers - bsum (sum of b over all ranks, one element of b's dtype) and

@@ -10,6 +10,7 @@
 //         softmax(Q K^T * scale + mask) V of Transformer.scala:784-804 (the fused op has no CPU
 //         known-answer test in the reference: parity is pinned to the composed form).
 #include "device_utils.h"
+#include "philox.h"
 #include "../core/strided.h"
 
 namespace lamp {
@@ -110,11 +111,25 @@ __global__ __launch_bounds__(256) void umap_pairs_kernel(const T* __restrict__ l
 // summed across the wave before the atomic: the edge list is sorted by that index (runs of ~k attractive and ~k * negatives
 // repulsive pairs per point), so a segmented scan leaves one atomic per run.  ~1.1 requests per pair instead of 4.
 // The distance and the loss terms are computed exactly as above (d^2 = dx^2 + dy^2 in that order on both lanes).
-template <class T>
+// SAMPLED (round 6): the negative pairs are not read from (i3, i4) but DRAWN here - pair q = e * neg + j of edge e is (i1[e], the j-th negative of e),
+// a counter-based draw (umap_negative) that umap_count_kept_kernel reproduces for the normaliser: what Umap.optimize builds per iteration with
+// repeatInterleave + randint + ne + two maskedSelects (umap.scala:211-227) - 0.72 GB of indices written and read back at 1M points - is gone.
+// The stream is not torch's (nor was randint's); the distribution is randint(0, hi)'s, value for value the one lamp_umap_negatives materialises.
+struct UmapSampled { int neg; double hi; uint64_t seed, offset; };
+// the j-th negative of edge e: uniform in [0, hi) as rng_kernel<long, 2> draws randint(0, hi) - floor(u * hi), u a 53-bit uniform; Philox counter =
+// (offset + j / 2, subsequence e), the two doubles of a block serve j and j + 1
+__device__ __forceinline__ int64_t umap_negative(const UmapSampled& sp, int64_t e, int j) {
+  Philox ph(sp.seed, (uint64_t)e, sp.offset + (uint64_t)(j >> 1));
+  const uint4 r = ph.next();
+  const double u = (j & 1) ? u01(r.z, r.w) : u01(r.x, r.y);
+  return (int64_t)floor(0.0 + u * (sp.hi - 0.0));
+}
+template <class T, bool SAMPLED = false>
 __global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ loc, const int64_t* __restrict__ i1, const int64_t* __restrict__ i2,
                                                           const T* __restrict__ b, int64_t E1, const int64_t* __restrict__ i3, const int64_t* __restrict__ i4,
                                                           int64_t E2, const T* __restrict__ bsum, double min_dist, int balance, double strength,
-                                                          double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc, const int64_t* __restrict__ e2_kept, int skip_self) {
+                                                          double w1, double w2, double w3, double w4, T* __restrict__ grad, double* __restrict__ loss_acc, const int64_t* __restrict__ e2_kept, int skip_self,
+                                                          UmapSampled sp) {
   __shared__ double sm[4];
   double local = 0.0;
   const double attr_scale = balance ? 1.0 / (double)bsum[0] : 1.0;
@@ -127,7 +142,15 @@ __global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ 
   for (int64_t it = 0; it < rounds; it++, e += stride) {
     const int64_t ee = e < E ? e : E - 1;
     const bool attr = ee < E1;
-    const int64_t a = attr ? i1[ee] : i3[ee - E1], c = attr ? i2[ee] : i4[ee - E1];
+    int64_t a, c;
+    if constexpr (SAMPLED) {
+      if (attr) { a = i1[ee]; c = i2[ee]; }
+      else {
+        const unsigned q = (unsigned)(ee - E1), eq = q / (unsigned)sp.neg;       // (host: E2 < 2^31)
+        a = i1[eq];
+        c = umap_negative(sp, (int64_t)eq, (int)(q - eq * (unsigned)sp.neg));
+      }
+    } else { a = attr ? i1[ee] : i3[ee - E1]; c = attr ? i2[ee] : i4[ee - E1]; }
     const bool valid = e < E && !(skip_self && !attr && a == c);    // the reference drops negative pairs that hit themselves
     const double diff = (double)loc[a * 2 + dim] - (double)loc[c * 2 + dim];
     const double sq = diff * diff, sq_o = __shfl_xor(sq, 1, 64);
@@ -175,6 +198,27 @@ __global__ __launch_bounds__(256) void umap_pairs2_kernel(const T* __restrict__ 
   if (threadIdx.x == 0) atomicAdd(loss_acc, local);
 }
 template <class T> __global__ void cast_scalar_kernel(const double* in, T* out) { *out = (T)(*in); }
+// the number of drawn negatives that do not hit their own point (the normaliser of the repulsion): the draws of umap_pairs2_kernel<., true>
+__global__ __launch_bounds__(256) void umap_count_kept_kernel(const int64_t* __restrict__ i1, int64_t E1, UmapSampled sp, int64_t* __restrict__ out) {
+  __shared__ double sm[4];
+  double local = 0.0;   // exact below 2^53
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E1; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = i1[e];
+    for (int j = 0; j < sp.neg; j++) local += umap_negative(sp, e, j) != a ? 1.0 : 0.0;
+  }
+  local = block_sum(local, sm);
+  if (threadIdx.x == 0 && local != 0.0) atomicAdd((unsigned long long*)out, (unsigned long long)local);
+}
+// ... and the same draws written out: ii = i1 repeated neg times, jj = the negatives (lamp_umap_negatives: tests, sharded edge lists, layouts
+// of more than two dimensions)
+__global__ __launch_bounds__(256) void umap_negatives_kernel(const int64_t* __restrict__ i1, int64_t E1, UmapSampled sp, int64_t* __restrict__ ii, int64_t* __restrict__ jj) {
+  const int64_t n = E1 * sp.neg;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = q / sp.neg;
+    ii[q] = i1[e];
+    jj[q] = umap_negative(sp, e, (int)(q - e * sp.neg));
+  }
+}
 __global__ __launch_bounds__(256) void count_ne_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t n, int64_t* __restrict__ out) {
   __shared__ double sm[4];
   double local = 0.0;   // exact below 2^53
@@ -484,16 +528,21 @@ int lamp_umap_edge_weights(lamp_tensor** out, const lamp_tensor* knn_distances, 
 static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
                                 const lamp_tensor* b, const lamp_tensor* index3, const lamp_tensor* index4, double min_dist, int balance,
                                 double repulsion_strength, const double* term_weights, int skip_self,
-                                const lamp_tensor* bsum_global = nullptr, const lamp_tensor* kept_global = nullptr) {
+                                const lamp_tensor* bsum_global = nullptr, const lamp_tensor* kept_global = nullptr, const UmapSampled* sampled = nullptr) {
+  // sampled: the negatives are drawn inside the kernels (index3 / index4 are null; 2-D layouts)
   check_device_tensor(locations, "locations"); check_device_tensor(grad_accum, "grad_accum");
-  check_device_tensor(index1, "index1"); check_device_tensor(index2, "index2"); check_device_tensor(index3, "index3"); check_device_tensor(index4, "index4");
+  check_device_tensor(index1, "index1"); check_device_tensor(index2, "index2");
+  if (!sampled) { check_device_tensor(index3, "index3"); check_device_tensor(index4, "index4"); }
   check_device_tensor(b, "b");
   LAMP_CHECK(locations->ndim == 2 && locations->is_contiguous() && grad_accum->is_contiguous() && grad_accum->shape() == locations->shape() &&
              grad_accum->dtype == locations->dtype, "umap: locations/grad must be contiguous [n, dim] tensors of one dtype");
   LAMP_CHECK(locations->dtype == kF64 || locations->dtype == kF32, "umap layout runs in f64 (reference) or f32");
-  for (const lamp_tensor* ix : {index1, index2, index3, index4}) LAMP_CHECK(ix->dtype == kI64 && ix->ndim == 1 && ix->is_contiguous(), "umap: indices must be contiguous int64 vectors");
-  const int64_t E1 = index1->numel(), E2 = index3->numel();
-  LAMP_CHECK(index2->numel() == E1 && b->numel() == E1 && index4->numel() == E2 && b->dtype == locations->dtype && b->is_contiguous(), "umap: edge list size mismatch");
+  for (const lamp_tensor* ix : {index1, index2, index3, index4})
+    if (ix) LAMP_CHECK(ix->dtype == kI64 && ix->ndim == 1 && ix->is_contiguous(), "umap: indices must be contiguous int64 vectors");
+  const int64_t E1 = index1->numel(), E2 = sampled ? E1 * sampled->neg : index3->numel();
+  LAMP_CHECK(index2->numel() == E1 && b->numel() == E1 && (sampled || index4->numel() == E2) && b->dtype == locations->dtype && b->is_contiguous(), "umap: edge list size mismatch");
+  LAMP_CHECK(!sampled || (locations->sizes[1] == 2 && E2 < ((int64_t)1 << 31)), "internal: the sampled form is the 2-D kernel's");
+  const UmapSampled spv = sampled ? *sampled : UmapSampled{1, 1.0, 0, 0};
   hipStream_t st = current_stream(locations->device());
   // sharded edge lists (one slice per rank): the normalisers are the GLOBAL sum of b and count of kept negatives, handed in
   Hold bsum;
@@ -512,37 +561,43 @@ static void umap_loss_grad_impl(lamp_tensor** loss, lamp_tensor* grad_accum, con
   } else if (skip_self) {
     kept = Hold(new_tensor(one, 1, kI64, locations->device()));
     fill_zero(kept.get());
-    if (E2 > 0) { hipLaunchKernelGGL(count_ne_kernel, dim3(grid_for(E2, 256)), dim3(256), 0, st, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, kept->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
+    if (E2 > 0 && sampled) { hipLaunchKernelGGL(umap_count_kept_kernel, dim3(grid_for(E1, 256)), dim3(256), 0, st, index1->ptr<int64_t>(), E1, spv, kept->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
+    else if (E2 > 0) { hipLaunchKernelGGL(count_ne_kernel, dim3(grid_for(E2, 256)), dim3(256), 0, st, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, kept->ptr<int64_t>()); LAMP_LAUNCH_CHECK(); }
   }
   const int64_t* keptp = kept.get() ? static_cast<const Tensor*>(kept.get())->ptr<int64_t>() : nullptr;
   const double w[4] = {term_weights ? term_weights[0] : 1.0, term_weights ? term_weights[1] : 1.0, term_weights ? term_weights[2] : 1.0,
                        term_weights ? term_weights[3] : 1.0};
   static const bool pairs2 = [] { const char* e = getenv("LAMP_UMAP_PAIRS2"); return !(e && e[0] == '0'); }();
-  if (pairs2 && locations->sizes[1] == 2 && E1 + E2 > 0) {
+  const int64_t* i3p = index3 ? index3->ptr<int64_t>() : nullptr;
+  const int64_t* i4p = index4 ? index4->ptr<int64_t>() : nullptr;
+  if ((pairs2 || sampled) && locations->sizes[1] == 2 && E1 + E2 > 0) {
     // algorithmic traffic per pair: two int64 indices, two 2-D points gathered, b for the attractive pairs, and the read-modify-write of
     // two gradient points.  The `flops` slot carries the number of memory-side atomic requests if nothing were merged (two per pair,
     // x and y of a point share a 64-byte line): bench.py divides by the duration for the atomic-request rate.
     const double esz = (double)dtype_size(locations->dtype);
-    KernelTimer kt("umap_pairs2", 2.0 * (double)(E1 + E2), (double)(E1 + E2) * (16.0 + 4.0 * esz + 8.0 * esz) + (double)E1 * esz, st);
+    // (sampled: the negatives cost one int64 per EDGE - the first point - instead of two per pair)
+    const double idx_bytes = sampled ? (double)E1 * 16.0 + (double)E1 * 8.0 : (double)(E1 + E2) * 16.0;
+    KernelTimer kt("umap_pairs2", 2.0 * (double)(E1 + E2), idx_bytes + (double)(E1 + E2) * (4.0 * esz + 8.0 * esz) + (double)E1 * esz, st);
+#define UMAP_P2(T_, S_)                                                                                                                                         \
+  hipLaunchKernelGGL((umap_pairs2_kernel<T_, S_>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<T_>(), index1->ptr<int64_t>(),           \
+                     index2->ptr<int64_t>(), b->ptr<T_>(), E1, i3p, i4p, E2, bsum->ptr<T_>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3],      \
+                     grad_accum->ptr<T_>(), acc->ptr<double>(), keptp, skip_self, spv)
     if (locations->dtype == kF64) {
-      hipLaunchKernelGGL((umap_pairs2_kernel<double>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<double>(), index1->ptr<int64_t>(),
-                         index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<double>(), min_dist, balance,
-                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>(), keptp, skip_self);
+      if (sampled) UMAP_P2(double, true); else UMAP_P2(double, false);
       hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
     } else {
-      hipLaunchKernelGGL((umap_pairs2_kernel<float>), dim3(grid_for(2 * (E1 + E2), 256)), dim3(256), 0, st, locations->ptr<float>(), index1->ptr<int64_t>(),
-                         index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2, bsum->ptr<float>(), min_dist, balance,
-                         repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>(), keptp, skip_self);
+      if (sampled) UMAP_P2(float, true); else UMAP_P2(float, false);
       hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
     }
+#undef UMAP_P2
   } else if (locations->dtype == kF64) {
     hipLaunchKernelGGL((umap_pairs_kernel<double>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<double>(), locations->sizes[1],
-                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<double>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
+                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<double>(), E1, i3p, i4p, E2,
                        bsum->ptr<double>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<double>(), acc->ptr<double>(), keptp, skip_self);
     hipLaunchKernelGGL((cast_scalar_kernel<double>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<double>());
   } else {
     hipLaunchKernelGGL((umap_pairs_kernel<float>), dim3(grid_for(E1 + E2, 256)), dim3(256), 0, st, locations->ptr<float>(), locations->sizes[1],
-                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<float>(), E1, index3->ptr<int64_t>(), index4->ptr<int64_t>(), E2,
+                       index1->ptr<int64_t>(), index2->ptr<int64_t>(), b->ptr<float>(), E1, i3p, i4p, E2,
                        bsum->ptr<float>(), min_dist, balance, repulsion_strength, w[0], w[1], w[2], w[3], grad_accum->ptr<float>(), acc->ptr<double>(), keptp, skip_self);
     hipLaunchKernelGGL((cast_scalar_kernel<float>), dim3(1), dim3(1), 0, st, acc->ptr<double>(), out->ptr<float>());
   }
@@ -579,6 +634,51 @@ int lamp_umap_loss_grad_sharded(lamp_tensor** loss, lamp_tensor* grad_accum, con
   LAMP_CHECK(bsum_global && kept_global, "umap sharded: the global normalisers are required");
   umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, index3, index4, min_dist, balance, repulsion_strength, term_weights, 1, bsum_global,
                       kept_global);
+  LAMP_API_END
+}
+// the negatives of Umap.optimize as the library draws them: ii = index1.repeatInterleave(n), jj = randint(0, high, [E1 * n]) (umap.scala:211-213),
+// from ONE counter block of the generator (lamp_manual_seed + the calls since): lamp_umap_loss_grad_sampled draws exactly these when it takes the
+// generator at the same point
+static UmapSampled umap_sampled_draw(int64_t negatives_per_edge, int64_t high) {
+  LAMP_CHECK(negatives_per_edge >= 1 && negatives_per_edge <= 1024, "umap: negatives per edge must be in [1, 1024], got " << negatives_per_edge);
+  LAMP_CHECK(high >= 1, "umap: randint(0, high) needs high >= 1, got " << high);
+  UmapSampled sp;
+  sp.neg = (int)negatives_per_edge; sp.hi = (double)high; sp.seed = philox_seed();
+  sp.offset = next_philox_offset((uint64_t)(negatives_per_edge + 1) / 2 + 1);
+  return sp;
+}
+int lamp_umap_negatives(lamp_tensor** ii, lamp_tensor** jj, const lamp_tensor* index1, int64_t negatives_per_edge, int64_t high) {
+  LAMP_API_BEGIN
+  check_device_tensor(index1, "index1");
+  LAMP_CHECK(index1->dtype == kI64 && index1->ndim == 1 && index1->is_contiguous(), "umap: indices must be contiguous int64 vectors");
+  const UmapSampled sp = umap_sampled_draw(negatives_per_edge, high);
+  const int64_t E1 = index1->numel();
+  int64_t n[1] = {E1 * negatives_per_edge};
+  Hold a(new_tensor(n, 1, kI64, index1->device())), c(new_tensor(n, 1, kI64, index1->device()));
+  if (n[0] > 0) {
+    hipLaunchKernelGGL(umap_negatives_kernel, dim3(grid_for(n[0], 256)), dim3(256), 0, current_stream(index1->device()), index1->ptr<int64_t>(), E1, sp,
+                       a->ptr<int64_t>(), c->ptr<int64_t>());
+    LAMP_LAUNCH_CHECK();
+  }
+  *ii = a.take(); *jj = c.take();
+  LAMP_API_END
+}
+int lamp_umap_loss_grad_sampled(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1, const lamp_tensor* index2,
+                                const lamp_tensor* b, int64_t negatives_per_edge, int64_t high, double min_dist, int balance, double repulsion_strength,
+                                const double* term_weights) {
+  LAMP_API_BEGIN
+  check_device_tensor(locations, "locations"); check_device_tensor(index1, "index1");
+  const int64_t E1 = index1->numel();
+  if (locations->ndim == 2 && locations->sizes[1] == 2 && E1 * negatives_per_edge < ((int64_t)1 << 31)) {
+    const UmapSampled sp = umap_sampled_draw(negatives_per_edge, high);
+    umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, nullptr, nullptr, min_dist, balance, repulsion_strength, term_weights, 1, nullptr, nullptr, &sp);
+  } else {
+    // other layouts: the same draws, written out, through the generic kernel
+    lamp_tensor *ii = nullptr, *jj = nullptr;
+    if (lamp_umap_negatives(&ii, &jj, index1, negatives_per_edge, high) != 0) throw Error(lamp_last_error());
+    Hold hi_(ii), hj_(jj);
+    umap_loss_grad_impl(loss, grad_accum, locations, index1, index2, b, ii, jj, min_dist, balance, repulsion_strength, term_weights, 1);
+  }
   LAMP_API_END
 }
 int lamp_umap_loss_grad_skip_self(lamp_tensor** loss, lamp_tensor* grad_accum, const lamp_tensor* locations, const lamp_tensor* index1,

@@ -70,14 +70,13 @@ def optimize(edgeWeights: S.STen, total: int, lr: float, iterations: int, minDis
         else:
             pos = S.STen.randint(0, index1.shape[0], [min(int(positiveSamples), index1.shape[0])], S.I64, device)
             i1, i2, bb = index1.indexSelect(0, pos), index2.indexSelect(0, pos), b.indexSelect(0, pos)
-        ii = i1.repeatInterleave(int(negativeSampleSize), 0)
-        jj = S.STen.randint(0, total - 1, [ii.shape[0]], S.I64, device)
         grad.zero_()
         out = C.c_void_p()
-        # the reference's mask = ii.ne(jj) + two maskedSelects are folded into the kernel (pairs that hit themselves are skipped and
-        # the repulsion is normalised by the number of pairs kept): same sums, no 45M-element compactions
-        lib.lamp_umap_loss_grad_skip_self(C.byref(out), grad, locations, i1, i2, bb, ii, jj, float(minDist), int(bool(balanceAttractionsAndRepulsions)),
-                                          float(repulsionStrength), weights)
+        # ii = i1.repeatInterleave(negativeSampleSize), jj = randint(0, total - 1, ...) (umap.scala:211-213), the reference's mask = ii.ne(jj) and its
+        # two maskedSelects: all inside the layout kernel - the negatives are drawn there (counter-based, randint's distribution), pairs that hit
+        # themselves are skipped and the repulsion is normalised by the number of pairs kept.  Same sums; no 45M-element index tensors
+        lib.lamp_umap_loss_grad_sampled(C.byref(out), grad, locations, i1, i2, bb, int(negativeSampleSize), int(total) - 1, float(minDist),
+                                        int(bool(balanceAttractionsAndRepulsions)), float(repulsionStrength), weights)
         loss = S.STen(out)
         if lossHistory is not None and it >= int(iterations) - 50:
             kept.append(loss)
@@ -117,8 +116,11 @@ def optimize_sharded(edgeWeights: S.STen, total: int, lr: float, iterations: int
     weights = f64_array([1.0, 2.0, 4.0, 8.0])
     last = 0.0
     for it in range(int(iterations)):
-        ii = index1.repeatInterleave(int(negativeSampleSize), 0)
-        jj = S.STen.randint(0, total - 1, [ii.shape[0]], S.I64, device)
+        # the same draws as optimize's kernel makes (one counter block of the generator per iteration), written out: the count of kept pairs has to
+        # be made global between them and the loss
+        ii_h, jj_h = C.c_void_p(), C.c_void_p()
+        lib.lamp_umap_negatives(C.byref(ii_h), C.byref(jj_h), index1, int(negativeSampleSize), int(total) - 1)
+        ii, jj = S.STen(ii_h), S.STen(jj_h)
         kept = C.c_void_p()
         lib.lamp_count_ne(C.byref(kept), ii, jj)
         kept = S.STen(kept)

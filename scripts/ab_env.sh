@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B of one environment switch on ONE box: bash scripts/ab_env.sh VAR A B [pairs] [bench args...] -> alternating headline steps (ms) per setting
+# A/B of environment settings on ONE box with one library: bash scripts/ab_env.sh ROUNDS "VAR=a" "VAR=b" ... -> alternating headline steps (ms); AB_ARGS: extra bench arguments
 set -u
-V=$1; A=$2; B=$3; P=${4:-3}; shift 4 || shift $#
-for i in $(seq 1 $P); do for x in "$A" "$B"; do
-  ms=$(env $V=$x python bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "import json,sys; l=[x for x in sys.stdin if x.startswith('{')]; print(json.loads(l[-1])['ms_per_step'])")
-  echo "$V=$x ms_per_step $ms"
+P=$1; shift
+for i in $(seq 1 $P); do for x in "$@"; do
+  ms=$(env LAMP_BENCH_ALSO=0 $x python bench.py --no-cpu-baseline ${AB_ARGS:-} 2>/dev/null | python3 -c "import json,sys; l=[x for x in sys.stdin if x.startswith('{')]; print(json.loads(l[-1])['ms_per_step'])")
+  echo "$x ${AB_ARGS:-} ms_per_step $ms"
 done; done

@@ -16,7 +16,12 @@ for r in seg:
     if last_end is None or s >= last_end: busy += e - s
     elif e > last_end: busy += e - last_end
     last_end = e if last_end is None else max(last_end, e)
-    if '--timeline' in sys.argv: print(f"{(s - int(seg[0]['Start_Timestamp'])) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  {nm}")
+    if '--timeline' in sys.argv:
+        geo = ""
+        if '--geometry' in sys.argv:      # grid (workgroups), workgroup size, LDS bytes, registers: what a same-grid copy kernel has to reproduce
+            gx, wx = int(r.get('Grid_Size_X', 0) or 0), int(r.get('Workgroup_Size_X', 1) or 1)
+            geo = f"  wgs {gx // max(wx, 1):6d} x {wx:4d}  lds {r.get('LDS_Block_Size', '?'):>6}  vgpr {r.get('VGPR_Count', '?'):>4}"
+        print(f"{(s - int(seg[0]['Start_Timestamp'])) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  {nm}{geo}")
 span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3
 tot = sum(v[1] for v in agg.values())
 print(f"launches {sum(v[0] for v in agg.values())}  kernel us {tot:.1f}  busy us {busy / 1e3:.1f}  span us {span:.1f}  idle {100 * (1 - busy / 1e3 / span):.1f} %")

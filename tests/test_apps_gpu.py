@@ -335,6 +335,52 @@ def test_umap_skip_self_equals_masked_pairs(gpu):
         assert np.abs(res[0][1] - res[1][1]).max() <= 1e-12 * np.abs(res[0][1]).max()
 
 
+@pytest.mark.parametrize("min_dist", [0.0, 0.1])
+def test_umap_negatives_drawn_inside_the_kernel(gpu, min_dist):
+    """Round 6: lamp_umap_loss_grad_sampled draws Umap.optimize's negatives (ii = index1.repeatInterleave(n), jj = randint(0, total - 1),
+    umap.scala:211-213) inside the layout kernel from a counter-based generator; lamp_umap_negatives writes the SAME draws out when it takes the
+    generator at the same point.  So: loss and gradient of the sampled call == lamp_umap_loss_grad_skip_self on the materialised negatives (the
+    self-hits dropped and the repulsion normalised by the pairs kept, both), for 2-D (drawn in the kernel) and 3-D (written out inside the entry
+    point) layouts; the draws are in [0, high), cover it uniformly, and differ between edges, between the negatives of an edge and between calls."""
+    rng = np.random.default_rng(9)
+    n, e1, neg = 257, 4000, 5
+    a1 = np.sort(rng.integers(0, n, e1)); a2 = (a1 + 1 + rng.integers(0, n - 1, e1)) % n
+    I1, I2 = S.STen.from_numpy(a1, 0), S.STen.from_numpy(a2, 0)
+    b = S.STen.from_numpy(rng.random(e1), 0, S.F64)
+    w = f64_array([1.0, 2.0, 4.0, 8.0])
+    for dim in (2, 3):
+        loc = S.STen.from_numpy(rng.random((n, dim)), 0, S.F64)
+        lib.lamp_manual_seed(77)
+        ii, jj = C.c_void_p(), C.c_void_p()
+        lib.lamp_umap_negatives(C.byref(ii), C.byref(jj), I1, neg, n - 1)
+        II, JJ = S.STen(ii), S.STen(jj)
+        ii_np, jj_np = II.to_numpy(), JJ.to_numpy()
+        assert np.array_equal(ii_np, np.repeat(a1, neg))
+        assert jj_np.min() >= 0 and jj_np.max() == n - 2                      # randint's high is exclusive (the reference never draws the last point)
+        counts = np.bincount(jj_np, minlength=n - 1)
+        assert counts.min() > 0 and abs(counts.mean() - e1 * neg / (n - 1)) < 1e-9 and counts.std() < 3.0 * np.sqrt(e1 * neg / (n - 1))
+        assert (ii_np == jj_np).sum() > 0                                    # some negatives do hit their own point: the case the kernel must drop
+        per_edge = jj_np.reshape(e1, neg)
+        assert (per_edge[:, 0] != per_edge[:, 1]).mean() > 0.98 and (per_edge[0] != per_edge[1]).any()
+        g_ref = S.STen.zeros([n, dim], S.F64)
+        lo = C.c_void_p()
+        lib.lamp_umap_loss_grad_skip_self(C.byref(lo), g_ref, loc, I1, I2, b, II, JJ, min_dist, 1, 1.5, w)
+        l_ref = float(S.STen(lo).to_numpy())
+        lib.lamp_manual_seed(77)
+        g = S.STen.zeros([n, dim], S.F64)
+        lo2 = C.c_void_p()
+        lib.lamp_umap_loss_grad_sampled(C.byref(lo2), g, loc, I1, I2, b, neg, n - 1, min_dist, 1, 1.5, w)
+        l = float(S.STen(lo2).to_numpy())
+        assert abs(l - l_ref) <= 1e-12 * abs(l_ref), (dim, l, l_ref)
+        assert np.abs(g.to_numpy() - g_ref.to_numpy()).max() <= 1e-11 * np.abs(g_ref.to_numpy()).max()
+        # the next call takes the generator further: other negatives
+        ii2, jj2 = C.c_void_p(), C.c_void_p()
+        lib.lamp_umap_negatives(C.byref(ii2), C.byref(jj2), I1, neg, n - 1)
+        assert (S.STen(jj2).to_numpy() != jj_np).mean() > 0.9
+    with pytest.raises(Exception, match="negatives per edge"):
+        lib.lamp_umap_negatives(C.byref(ii), C.byref(jj), I1, 0, n - 1)
+
+
 def test_umap_sharded_layout_building_blocks(gpu):
     """Edge list split over ranks: the sum over the shards of lamp_umap_loss_grad_sharded (global normalisers handed in) equals the
     unsharded loss / gradient; with one rank optimize_sharded reproduces optimize."""
