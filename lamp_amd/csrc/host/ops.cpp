@@ -502,7 +502,8 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
   static const bool fuse_ahead = [] { const char* e = getenv("LAMP_FUSE_LOSS_TAIL"); return !(e && e[0] == '0'); }();
   const bool from_tail = input->op && input->op->params.size() == 1 && std::strcmp(input->op->name, "GlobalAvgPoolLogSoftMax") == 0 &&
                          input->value.h()->is_device() && input->op->params[0].first->needsGrad() && input->op->params[0].first->value.ndim() == 4;
-  if (fuse_tail && fuse_ahead && from_tail && reduction != 0) {
+  // (bf16: the dtype whose batch-norm backward reads the plane values in place; in f32 / f64 the expanded view would be written out again)
+  if (fuse_tail && fuse_ahead && from_tail && reduction != 0 && input->value.dtype() == kBF16) {
     const Ten& xin = input->op->params[0].first->value;
     HCALL(lamp_nll_loss_forward_pooled_gradient_(&v, &tw, &pgh, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.defined() ? acc.h() : nullptr, scale,
                                                  xin.size(2) * xin.size(3)));

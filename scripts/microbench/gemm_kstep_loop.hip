@@ -178,6 +178,26 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* __restrict__ src,
       for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[i][j][e & 3] += c[i][j][e];
+  } else if (MODE == 7) {
+    // the legacy K = 16 instruction (v_mfma_f32_16x16x16_bf16): half the flops of the K = 32 one - in half its time?  (a 16-wide tail chunk for the
+    // 100-channel layers of the ResNet only pays if so).  64 MFMAs per k-step here, the same flops as the other modes
+    typedef short s4v __attribute__((ext_vector_type(4)));
+    for (int t = 0; t < stages; t++) {
+      asm volatile("" : "+v"(fa[0][0]), "+v"(fb[0][0]));
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const s4v bb = __builtin_bit_cast(s4v, u2v{fb[0][j][2 * h], fb[0][j][2 * h + 1]}), aa = __builtin_bit_cast(s4v, u2v{fa[0][i][2 * h], fa[0][i][2 * h + 1]});
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bb, aa, acc[i][j], 0, 0, 0);
+            }
+      }
+    }
   } else if (MODE == 0) {
     for (int t = 0; t < stages; t++) {
       asm volatile("" : "+v"(fa[0][0]), "+v"(fb[0][0]));
@@ -285,6 +305,7 @@ int main() {
     } else (void)hipMemset(src, 0x3f, bytes);
     run<0, 0>(src, out, cyc, "MFMAs only");
     run<6, 0>(src, out, cyc, "MFMAs only, v_mfma_f32_32x32x16_bf16");
+    run<7, 0>(src, out, cyc, "MFMAs only, v_mfma_f32_16x16x16_bf16 (64 per k-step)");
     run<1, 0>(src, out, cyc, "kernel schedule, B by ds_read_b128");
     run<1, 1>(src, out, cyc, "kernel schedule, B by ds_read_b64_tr_b16");
     run<2, 0, 0>(src, out, cyc, "kernel schedule + DMA of L2-resident bytes, b128");
