@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void ncv_fwd_kernel(const bf16_t* __restrict__
 // pixels per accumulator register, stored as one 16- or 8-byte write.
 //   PH0 = (window origin wx) & 7.
 // -DNCV_STAMP (diagnostic builds only; scripts/ncv_stamp_probe.py): s_memtime stamps of thread 0 of the first 1024 workgroups
+#if defined(NCV_SKIP) && (NCV_SKIP & 2)
+#define NCV_STORE_COND && pk[0] == 0x12345678u
+#else
+#define NCV_STORE_COND
+#endif
 #ifdef NCV_STAMP
 __device__ unsigned long long ncv_stamps[1024 * 8];
 #define NCV_STAMP_AT(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) ncv_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -284,10 +289,18 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
     __syncthreads();                                     // zero fill / the previous image's reads are done
     NCV_STAMP_ONCE(2);
     if (STATS && !stats_per_wg && it > 0) stats_flush(n - (int)gridDim.x, q.N, (it - 1) & 1);
+#if defined(NCV_SKIP) && (NCV_SKIP & 4)
+    if (n < 0)
+#endif
+    {
     if (q.pf) ncv_stage_store(xs, pre, plan, q.dil);
     else ncv_stage(xs, src + n * img_in, q, tid, nthreads);
+    }
     __syncthreads();
     NCV_STAMP_ONCE(3);
+#if defined(NCV_SKIP) && (NCV_SKIP & 4)
+    if (n < 0)
+#endif
     if (q.pf && n + (int)gridDim.x < q.N)                 // in flight during the MFMAs
       ncv_stage_load(pre, plan, src + (n + (int)gridDim.x) * img_in, src2 + (n + (int)gridDim.x) * img_in2);
     // this lane's output plane: channel co of dst, or channel co - co_a of the sibling's tensor
@@ -298,6 +311,10 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
       nv_f4 acc[ND];
 #pragma unroll
       for (int d = 0; d < ND; d++) acc[d] = nv_f4{0.f, 0.f, 0.f, 0.f};
+#ifdef NCV_SKIP                      // diagnostic builds only (scripts/build_variant.sh): 1 = no k-loop, 2 = no output stores, 4 = no image staging
+      if (NCV_SKIP & 1) { acc[0][0] = (float)lane; }
+      else
+#endif
 #pragma unroll
       for (int ks = 0; ks < NK; ks++) {
         unsigned int sg[NSEG * 4 + 1];
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
             else if (rr & 1) stats_take(prev[0], prev[1], pk[0], pk[1]);
             else { prev[0] = pk[0]; prev[1] = pk[1]; }
           }
-          if (co < q.CO) {
+          if (co < q.CO NCV_STORE_COND) {
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % (P / 2)], pk[3 % (P / 2)]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
           }
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
             else if (h) stats_take(prev[0], prev[1], pk[0], pk[1]);
             else { prev[0] = pk[0]; prev[1] = pk[1]; }
           }
-          if (co < q.CO) {
+          if (co < q.CO NCV_STORE_COND) {
             if (P == 8) *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2 % ND], pk[3 % ND]);
             else *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
           }
