@@ -24,6 +24,7 @@
 #include "conv_geom.h"
 #include "wgrad_reduce.h"
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -187,6 +188,9 @@ __device__ unsigned long long ncv_stamps[1024 * 8];
 //   NS = shifts per MFMA (see NcvW): NS = 2 halves the P window phases an MFMA has to be issued for.
 //   ADD: dst = round(round(conv) + add) - a separate instantiation (dgrad only: SW = 1) because the addend's registers cost the plain
 //   kernels a wave of occupancy
+template <int I0, int I1, class F> __device__ __forceinline__ void ncv_static_for(F&& f) {
+  if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); ncv_static_for<I0 + 1, I1>(f); }
+}
 struct NcvWf { float n, mean, m2; };
 __device__ __forceinline__ NcvWf ncv_wf_merge(const NcvWf& a, const NcvWf& b) {   // Chan's merge; either side may be empty
   NcvWf r;
@@ -207,7 +211,12 @@ __device__ __forceinline__ NcvWf ncv_wf_merge(const NcvWf& a, const NcvWf& b) { 
 //   The epilogue must not cost the kernel a wave of occupancy: hence the second launch bound.  What it still costs (scripts/ncv_stats_probe.py,
 //   stem / 6 -> 6 / 6 -> 16 layer at N = 2048: 11.3 / 5.5 / 4.8 us without, 14.2 / 7.4 / 6.3 us with): 1.3 - 2.2 us for the end of the workgroup
 //   (barrier, the waves' sums through LDS, one more store round trip behind the last output store) and, on the stem, 1.5 us of matrix-core time.
-template <int NK, int SW, int PH0, int NS, bool ADD, bool STATS>
+//   PAR (round 6; input gradients of stride-2 convolutions, kh = 3, NK even): the staged image is zero-dilated, so an output row meets non-zero
+//   image rows under ONE parity of the filter row r only.  The K pairs are packed by that parity (NcvW::nke = NK / 2) and a super-tile takes TR
+//   rows of one parity (rows blk * 2 TR + 2 tr + par): it runs the NK / 2 k-steps of its class instead of all NK - the other half multiplied
+//   structural zeros (EXPERIMENTS 66: the two such launches of the step spent 12 and 9 us in their k-loops).  Same products, same order per
+//   output element as far as non-zero terms go; the skipped terms were exact zeros.
+template <int NK, int SW, int PH0, int NS, bool ADD, bool STATS, bool PAR = false>
 __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kernel(const bf16_t* __restrict__ src, const nv_bf8* __restrict__ wpk, const bf16_t* __restrict__ bias,
                                                        bf16_t* dst, NcvGeom q, const bf16_t* add, bf16_t* dst2, const bf16_t* __restrict__ bias2, int co_a,
                                                        float* __restrict__ stats, float* __restrict__ stats2, int stats_per_wg,
@@ -241,6 +250,16 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
     if (pair >= pairs1 + (q.C - q.C1)) pair = 0;
     int c = (pair * q.kh_inv) >> 16, r = pair - c * q.kh;
     if (pair >= pairs1) { c = q.C1 + (pair - pairs1); r = q.kh >> 1; }   // second source: centre row only
+    if constexpr (PAR) {                                  // the packed image's parity order (NcvW::nke = NK / 2, kh == 3)
+      const int pr = ks * 4 + (lane >> 4);
+      if (ks < NK / 2) { c = pr >> 1; r = 2 * (pr & 1); if (c >= q.C1) { c = 0; r = 0; } }
+      else {
+        const int p2 = pr - (NK / 2) * 4;
+        if (p2 < q.C1) { c = p2; r = 1; }
+        else if (p2 < q.C) { c = p2; r = 1; }            // second source: channels [C1, C) of the staged image, centre row
+        else { c = 0; r = 0; }                            // (padded pairs: zero weights, any valid address)
+      }
+    }
     koff[ks] = (c * q.Hs + r) * q.Ws * 2;
   }
   const float bv = co < co_a ? (bias ? (float)bias[co] : 0.f) : ((bias2 && co < q.CO) ? (float)bias2[co - co_a] : 0.f);
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
   for (int o = tid * 8; o < img_elems; o += nthreads * 8) *reinterpret_cast<uint4*>(xs + o) = make_uint4(0, 0, 0, 0);
   // A-side lane -> (row within the super-tile, column group)
   const int a_tr = (lane & 15) / ncg, a_cg = (lane & 15) - a_tr * ncg;
-  const int a_off = (a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;
+  const int a_off = ((PAR ? 2 : 1) * a_tr * q.sh * q.Ws + a_cg * 8 + (q.wx - PH0)) * 2;      // PAR: a tile's rows are two apart
   // the waves' sums of one part (left in sst[par] before the barrier the caller has just passed) -> stats[channel][part] = (count, mean, M2),
   // added in wave order; NS = 2: channel co sits in columns co and co + 8
   auto stats_flush = [&](int part, int nparts, int par) {
@@ -306,7 +325,9 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
     // this lane's output plane: channel co of dst, or channel co - co_a of the sibling's tensor
     bf16_t* yc = co < co_a ? dst + ((int64_t)n * co_a + co) * HoWo : dst2 + ((int64_t)n * (q.CO - co_a) + (co - co_a)) * HoWo;
     for (int st = wid; st < nsuper; st += nwaves) {
-      const int h0 = st * TR;
+      // rows of the super-tile: h0 + RS * tr (PAR: super-tiles 2 b and 2 b + 1 share the 2 TR rows of block b, one parity each)
+      constexpr int RS = PAR ? 2 : 1;
+      const int h0 = PAR ? (st >> 1) * (2 * TR) + (st & 1) : st * TR;
       const char* base = smem + a_off + h0 * q.sh * q.Ws * 2;
       nv_f4 acc[ND];
 #pragma unroll
@@ -315,8 +336,9 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
       if (NCV_SKIP & 1) { acc[0][0] = (float)lane; }
       else
 #endif
-#pragma unroll
-      for (int ks = 0; ks < NK; ks++) {
+      {
+      auto kstep = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
         unsigned int sg[NSEG * 4 + 1];
 #pragma unroll
         for (int e = 0; e < NSEG; e++) {
@@ -335,6 +357,12 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
           const u4v fv = {f[0], f[1], f[2], f[3]};
           acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nv_bf8, fv), wfr[ks], acc[d], 0, 0, 0);
         }
+      };
+      if constexpr (PAR) {
+        // rows h0 + 2 tr of the dilated image hold values iff (row + r - top) is even: the class of k-steps whose r has the parity of (h0 + top)
+        if (((h0 + q.top) & 1) == 0) ncv_static_for<0, NK / 2>(kstep);          // r in {0, 2}
+        else ncv_static_for<NK / 2, NK>(kstep);                                  // r = 1 (and the second source's centre row)
+      } else ncv_static_for<0, NK>(kstep);
       }
       // add != nullptr: dst = round(round(conv) + add) (see ig_conv8d_kernel); the rows this lane stores.  Requested after the MFMAs:
       // held across them they cost 12 - 20 registers and a wave of occupancy
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
 #pragma unroll
         for (int k = 0; k < NROW; k++) {
           const int i = row0 + k, tr = i / ncg, cg = i - tr * ncg;
-          const bf16_t* a = ap + (h0 + tr) * q.Wo + cg * P;
+          const bf16_t* a = ap + (h0 + RS * tr) * q.Wo + cg * P;
           if (P == 8) addv[k] = *reinterpret_cast<const uint4*>(a);
           else { const uint2 t = *reinterpret_cast<const uint2*>(a); addv[k] = make_uint4(t.x, t.y, 0, 0); }
         }
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
         for (int rr = 0; rr < 4; rr++) {
           const int i = (lane >> 4) * 4 + rr;
           const int tr = i / ncg, cg = i - tr * ncg;
-          bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
+          bf16_t* o = yc + (h0 + RS * tr) * q.Wo + cg * P;
           unsigned int pk[P / 2];
 #pragma unroll
           for (int d = 0; d < P; d += 2) {
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256, (STATS && NK <= 5) ? 3 : 1) void ncv_fwd2_kern
         for (int h = 0; h < 2; h++) {
           const int i = (lane >> 4) * 4 + sft * 2 + h;
           const int tr = i / ncg, cg = i - tr * ncg;
-          bf16_t* o = yc + (h0 + tr) * q.Wo + cg * P;
+          bf16_t* o = yc + (h0 + RS * tr) * q.Wo + cg * P;
           unsigned int pk[ND];
 #pragma unroll
           for (int d = 0; d < ND; d++) {
@@ -799,7 +827,7 @@ static void ncv_pack_launch(const NcvPackMany& a, int cnt, hipStream_t st) {
 static Tensor* ncv_packed_weights(const Tensor* w, const NcvW& wq, hipStream_t st, const Tensor* w2 = nullptr) {
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
   const bool cacheable = cache_on && w->st->owned && !w->st->scratch && (!w2 || (w2->st->owned && !w2->st->scratch));
-  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns, wq.sw, st,
+  const NcvPackKey key{w->st->uid, w->offset, wq.Cout, wq.Cin, wq.kh, wq.kw, wq.dgrad, wq.ns + 16 * wq.nke, wq.sw, st,
                        w2 ? w2->st->uid : 0, w2 ? w2->offset : 0, w2 ? wq.Cout2 : 0};
   const uint64_t ver = w->st->version.load(std::memory_order_relaxed);
   const uint64_t ver2 = w2 ? w2->st->version.load(std::memory_order_relaxed) : 0;
@@ -881,7 +909,7 @@ void narrow_repack_cached(lamp_tensor* const* params, int n, hipStream_t st, Ncv
       continue;
     }
     if (cnt == NCV_PACK_MAX) flush();
-    a.w[cnt] = NcvW{w1->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns, k.sw, w2 ? w2->ptr<bf16_t>() : nullptr, k.Cout2};
+    a.w[cnt] = NcvW{w1->ptr<bf16_t>(), k.Cout, k.Cin, k.kh, k.kw, k.dgrad, k.ns & 15, k.sw, w2 ? w2->ptr<bf16_t>() : nullptr, k.Cout2, k.ns >> 4};   // (key: ns + 16 nke)
     a.dst[cnt] = static_cast<nv_bf8*>(v.packed->raw());
     v.version = w1->st->version.load(std::memory_order_relaxed);
     v.version2 = w2 ? w2->st->version.load(std::memory_order_relaxed) : 0;
@@ -942,13 +970,35 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
   int NK = 0;
   for (int o : nk_opts) if (o >= nk_real) { NK = o; break; }
   if (!NK) return false;
+  // round 6: the input gradient of a stride-2 pair runs its super-tiles by row parity over K pairs packed by the parity of the filter row
+  // (ncv_fwd2_kernel<.., PAR>; LAMP_NCV_DGRAD_PARITY=0: the plain form): half the k-steps per super-tile
+  int nke = 0;
+  static const bool par_on = [] { const char* e = getenv("LAMP_NCV_DGRAD_PARITY"); return !(e && e[0] == '0'); }();
+  if (par_on && aligned && dgrad && second && q.dil == 2 && g.kh == 3 && NK > 5) {
+    const int nk2 = NK <= 6 ? 6 : NK <= 8 ? 8 : 16;
+    const int need_e = (q.C1 * 2 + 3) / 4, need_o = (q.C + 3) / 4;      // pairs (c, r even) / (c, 1) and the second source's centre rows
+    if (need_e <= nk2 / 2 && need_o <= nk2 / 2 && q.Ho % (2 * (16 / ncg)) == 0) nke = nk2 / 2;
+  }
+  // The row pitch of the LDS image decides the bank conflicts of the fragment reads: the 16 lanes of a quarter-wave read 16 bytes each at
+  // (row a_tr, column group a_cg) = a_tr * RS * sh * pitch + a_cg * 16 (RS = 2 with the parity tiles), TR x ncg = 16 of them; they are 16
+  // DIFFERENT 16-byte bank slots iff (RS * sh * Ws / 8) mod 16 is an odd multiple of ncg.  (Round 6: the res2 pair's image had a 64-byte pitch -
+  // rows a_tr and a_tr + 4 on the same banks, and with the parity tiles' two-apart rows a_tr and a_tr + 2: the halved k-loop read twice as slowly
+  // and the launch gained nothing.)  The pitch is widened by at most 15 x 16 bytes to the next such value.
+  static const bool pitch_on = [] { const char* e = getenv("LAMP_NCV_PITCH"); return !(e && e[0] == '0'); }();
+  if (pitch_on && aligned) {
+    const int rs = (nke > 0 ? 2 : 1) * q.sh;
+    for (int k = 0; k < 16; k++) {
+      const int step = (rs * ((q.Ws >> 3) + k)) & 15;
+      if (step % ncg == 0 && ((step / ncg) & 1) == 1 && (size_t)q.C * q.Hs * (q.Ws + 8 * k) * 2 <= 64 * 1024) { q.Ws += 8 * k; break; }
+    }
+  }
   const size_t lds = (size_t)q.C * q.Hs * q.Ws * 2;
   if (lds > 64 * 1024) return false;
   // two output phases per MFMA where the columns allow it (see NcvW)
   static const bool two_shift_on = [] { const char* e = getenv("LAMP_NCV_TWO_SHIFT"); return !(e && e[0] == '0'); }();
   const int NS = (two_shift_on && aligned && q.CO <= 8 && g.kw + q.sw <= 8) ? 2 : 1;
   const Tensor* wsecond = sib ? sib->w : second ? second->w : nullptr;
-  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw, wsecond ? wsecond->ptr<bf16_t>() : (const bf16_t*)nullptr, cout2};
+  const NcvW wq{w->ptr<bf16_t>(), (int)g.Cout, (int)g.Cin, g.kh, g.kw, dgrad ? 1 : 0, NS, q.sw, wsecond ? wsecond->ptr<bf16_t>() : (const bf16_t*)nullptr, cout2, nke};
   Hold wpk_h(ncv_packed_weights(w, wq, st, wsecond));
   const nv_bf8* wpk = reinterpret_cast<const nv_bf8*>(static_cast<const Tensor*>(wpk_h.get())->ptr<bf16_t>());
   static const int max_per_cu = [] { const char* e = getenv("LAMP_NCV_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();   // A/B on one device: 4 beats 8 and 2
@@ -977,7 +1027,10 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
                             else if (q.sw == 1) { if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); }                \
                             else NCV_F2_PH(NKv, 2, false, false); } while (0)
     // (6, 8 and 16 k-steps: the pairs' input gradients only - stride-1 correlations without statistics)
-#define NCV_F2_PAIR(NKv) do { if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); } while (0)
+#define NCV_F2P(NKv, PHv, ADDv) kfn = NS == 2 ? (const void*)ncv_fwd2_kernel<NKv, 1, PHv, 2, ADDv, false, true> : (const void*)ncv_fwd2_kernel<NKv, 1, PHv, 1, ADDv, false, true>
+#define NCV_F2P_PH(NKv, ADDv) do { if (ph0 == 0) NCV_F2P(NKv, 0, ADDv); else if (ph0 == 6) NCV_F2P(NKv, 6, ADDv); else NCV_F2P(NKv, 7, ADDv); } while (0)
+#define NCV_F2_PAIR(NKv) do { if (nke > 0) { if (with_add) NCV_F2P_PH(NKv, true); else NCV_F2P_PH(NKv, false); }                                   \
+                              else if (with_add) NCV_F2_PH(NKv, 1, true, false); else NCV_F2_PH(NKv, 1, false, false); } while (0)
     switch (NK2) {
       case 2: NCV_F2_SW(2); break;
       case 4: NCV_F2_SW(4); break;
@@ -988,6 +1041,8 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
       default: NCV_F2_SW(12); break;
     }
 #undef NCV_F2_PAIR
+#undef NCV_F2P_PH
+#undef NCV_F2P
 #undef NCV_F2_SW
 #undef NCV_F2_PH
 #undef NCV_F2

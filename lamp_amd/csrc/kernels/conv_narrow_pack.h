@@ -29,14 +29,29 @@ struct NcvW {
   // dgrad: w2 = the sibling's filter too, but as EXTRA K pairs (its output gradient is a second source of the staged image, NcvGeom::C1)
   const bf16_t* w2;
   int Cout2;
+  // round 6, input gradients of stride-2 convolutions (kh = 3; ncv_fwd2_kernel<.., PAR>): nke > 0 = the K pairs are ordered by the PARITY of their
+  // filter row - k-steps [0, nke) hold the pairs (c, r) with r even (pair p: c = p / 2, r = 2 (p % 2)), k-steps [nke, 2 nke) those with r = 1
+  // (pair p': c = p') followed by the second source's centre-row pairs.  An output row of the zero-dilated image meets non-zero rows under
+  // one parity of r only, so a super-tile of rows of one parity runs half the k-steps.
+  int nke;
 };
 __device__ __forceinline__ nv_bf8 ncv_weight_frag(const NcvW& wq, int ks, int lane) {
   const int n = lane & 15, pair = ks * 4 + (lane >> 4);
   const int co = wq.ns == 2 ? (n & 7) : n, shift = wq.ns == 2 ? (n >> 3) * wq.sw : 0;
   int c = pair / wq.kh, r = pair - c * wq.kh;
   // dgrad of a pair: behind the Cout * kh pairs of the first filter come Cout2 pairs (c2, centre row) of the sibling 1x1 filter [Cout2][Cin]
-  const bool second_k = wq.dgrad && wq.w2 && pair >= wq.Cout * wq.kh;
+  bool second_k = wq.dgrad && wq.w2 && pair >= wq.Cout * wq.kh;
   if (second_k) { c = pair - wq.Cout * wq.kh; r = wq.kh / 2; }
+  if (wq.nke > 0) {                           // parity order (dgrad, kh == 3): see NcvW::nke
+    second_k = false;
+    if (ks < wq.nke) { c = pair >> 1; r = 2 * (pair & 1); if (c >= wq.Cout) c = 1 << 20; }                 // (beyond the filter: zero weights)
+    else {
+      const int p2 = pair - wq.nke * 4;
+      if (p2 < wq.Cout) { c = p2; r = 1; }
+      else if (wq.w2 && p2 < wq.Cout + wq.Cout2) { second_k = true; c = p2 - wq.Cout; r = 1; }
+      else c = 1 << 20;
+    }
+  }
   nv_s8 v;
 #pragma unroll
   for (int j = 0; j < 8; j++) {

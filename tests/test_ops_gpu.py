@@ -1474,6 +1474,29 @@ def test_eight_wave_weight_gradient_dma_and_register_forms_agree_bit_for_bit(gpu
         assert a == b, f"register form {a} != DMA form {b}"
 
 
+def test_stride_two_input_gradient_pairs_by_row_parity(gpu, tmp_path):
+    """Round 6 (`ncv_fwd2_kernel<.., PAR>`): the input gradient of a stride-2 pair is a stride-1 correlation over the zero-DILATED output gradient,
+    so an output row meets non-zero rows under one parity of the filter row only; the kernel packs its K pairs by that parity and a super-tile takes
+    rows of one parity - half the k-steps.  The skipped products were exact zeros: against the plain form (LAMP_NCV_DGRAD_PARITY=0) the results may
+    differ only by the order of the f32 sums - at most one bf16 rounding, on few elements."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    got = {}
+    for flag in ("0", "1"):
+        f = str(tmp_path / f"par{flag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "dgrad_parity_dump.py"), f], env=dict(os.environ, LAMP_NCV_DGRAD_PARITY=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[flag] = np.load(f)
+    for k in got["0"].files:
+        a, b = got["0"][k].astype(np.float64), got["1"][k].astype(np.float64)
+        assert a.shape == b.shape and np.isfinite(b).all()
+        d = np.abs(a - b)
+        scale = np.abs(a) + np.abs(a).mean()
+        assert (d <= 2.0 ** -7 * scale).all(), f"{k}: max relative difference {(d / scale).max():.3e}"
+        assert (d > 0).mean() < 0.25, f"{k}: {100 * (d > 0).mean():.1f} % of the elements differ"
+
+
 def test_input_gradient_pair_checks_its_arguments(gpu):
     dt = torch.bfloat16
     x = closed_form((4, 6, 8, 8), 3, 2.0, dt)
