@@ -679,6 +679,9 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
   for (int64_t nb = n0; nb < n1; nb += q.IG) {
     const int ig = (int)min<int64_t>(q.IG, n1 - nb);
     __syncthreads();
+#if defined(NCV_WSKIP) && (NCV_WSKIP & 4)   // diagnostic builds only: 1 = no k-loop, 4 = no staging (requests and LDS writes)
+    if (nb < 0)
+#endif
     if (pf) pre_store(ig);
     else for (int im = 0; im < ig; im++) {
       const bf16_t* xp = x + (nb + im) * q.Cin * q.H * q.W;
@@ -691,8 +694,14 @@ __global__ __launch_bounds__(256) void ncv_wgrad2_kernel(const bf16_t* __restric
       for (int i = tid; i < dpk2; i += 256) *reinterpret_cast<uint4*>(di + q.Cout * HoWo + i * 8) = *reinterpret_cast<const uint4*>(dp2 + i * 8);
     }
     __syncthreads();
+#if defined(NCV_WSKIP) && (NCV_WSKIP & 4)
+    if (nb < 0)
+#endif
     if (pf && nb + q.IG < n1) pre_load(nb + q.IG, (int)min<int64_t>(q.IG, n1 - nb - q.IG));      // in flight during the MFMAs
     const int nchunks = ig * chunks_per_img;
+#if defined(NCV_WSKIP) && (NCV_WSKIP & 1)
+    if (nb < 0)
+#endif
     for (int ch = wid; ch < nchunks; ch += 4) {
       const int pg = ch * 32 + (lane >> 4) * 8;
       const int im = pg / HoWo, pp = pg - im * HoWo;
