@@ -79,20 +79,43 @@ __device__ __forceinline__ int x_swz(int hp, int wp, int nchunk_mask) { return (
 // ---- weight packing ---------------------------------------------------------------------------------
 // fprop: wp[rs][co][ci] = W[co][ci][r][s]            (rows = Cout, k = Cin)
 // dgrad: wp[rs][ci][co] = W[co][ci][kh-1-r][kw-1-s]  (rows = Cin,  k = Cout)
-// one launch writes BOTH layouts: [fprop image (KPf) | dgrad image (KPd)]
-__global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KS, int KPf, int KPd) {
+// one launch writes BOTH layouts: [fprop image (KPf) | dgrad image (KPd) | fprop K-tail | dgrad K-tail]
+// K-TAILS (round 6, 3x3 filters whose K side has 1 .. 8 channels beyond its last whole 32-channel chunk: the ResNet's 100-channel layers).  In
+// the images above the last chunk of such a filter is nine stages of 32 k with at most 8 real ones.  A tail image holds the same channels as
+// THREE stages of FOUR taps: tail[g][row][8 q + c] = the filter's value for tap 4 g + q, channel 32 (K / 32) + c (zero for tap >= 9 or a channel
+// beyond the filter) - ig_conv8d_kernel reads the lane group q of such a stage from the pixel tap 4 g + q needs.  30 stages instead of 36.
+constexpr int IG_TAIL_STAGES = 3;
+constexpr int IG_TAIL_ELEMS = IG_TAIL_STAGES * IG_M * 32;
+__host__ __device__ inline bool ig_tail_ok(int K, int KS) { return KS == 3 && K > 32 && (K & 31) >= 1 && (K & 31) <= 8; }
+__device__ __forceinline__ void ig_pack_body(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KS, int KPf, int KPd, int first, int stride) {
   const int RS = KS * KS;
-  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
-  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
-    const int dgrad = e0 >= nf;
-    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
-    const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
-    const int r = rs / KS, s = rs % KS;
+  const int lf = KPf == 128 ? 7 : 6, ld = KPd == 128 ? 7 : 6;            // (pad_k: 64 or 128)
+  const int nf = RS * IG_M * KPf, nfd = nf + RS * IG_M * KPd;
+  const int ntf = ig_tail_ok(Cin, KS) ? IG_TAIL_ELEMS : 0, total = nfd + ntf + (ig_tail_ok(Cout, KS) ? IG_TAIL_ELEMS : 0);
+  for (int e0 = first; e0 < total; e0 += stride) {
     bf16_t v; v.bits = 0;
-    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
-    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
+    if (e0 < nfd) {
+      const int dgrad = e0 >= nf;
+      const int e = dgrad ? e0 - nf : e0, l2 = dgrad ? ld : lf;
+      const int k = e & ((1 << l2) - 1), row = (e >> l2) & (IG_M - 1), rs = e >> (l2 + 7);
+      const int r = KS == 3 ? (rs * 11) >> 5 : 0, s = rs - r * KS;          // (rs / 3 for rs < 9)
+      if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
+      else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
+    } else {
+      const int dgrad = e0 >= nfd + ntf;
+      const int e = e0 - nfd - (dgrad ? ntf : 0);
+      const int c = e & 7, tap = 4 * (e >> 12) + ((e >> 3) & 3), row = (e >> 5) & (IG_M - 1);
+      const int r = (tap * 11) >> 5, s = tap - r * 3;
+      if (tap < 9) {
+        if (!dgrad) { const int k = (Cin & ~31) + c; if (row < Cout && k < Cin) v = w[((row * Cin + k) * 3 + r) * 3 + s]; }
+        else { const int k = (Cout & ~31) + c; if (row < Cin && k < Cout) v = w[((k * Cin + row) * 3 + (2 - r)) * 3 + (2 - s)]; }
+      }
+    }
     wp[e0] = v;
   }
+}
+__global__ void ig_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int Cout, int Cin, int KS, int KPf, int KPd) {
+  ig_pack_body(w, wp, Cout, Cin, KS, KPf, KPd, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // the same for up to IG_PACK_MAX weight tensors in ONE launch (blockIdx.y = tensor): the optimiser re-packs every weight it has just
@@ -101,21 +124,7 @@ constexpr int IG_PACK_MAX = 16;
 struct PackMany { const bf16_t* w[IG_PACK_MAX]; bf16_t* wp[IG_PACK_MAX]; int Cout[IG_PACK_MAX], Cin[IG_PACK_MAX], KS[IG_PACK_MAX], KPf[IG_PACK_MAX], KPd[IG_PACK_MAX]; };
 __global__ void ig_pack_weights_many_kernel(PackMany a) {
   const int t = blockIdx.y;
-  const bf16_t* __restrict__ w = a.w[t];
-  bf16_t* __restrict__ wp = a.wp[t];
-  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], KPf = a.KPf[t], KPd = a.KPd[t];
-  const int RS = KS * KS;
-  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
-  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
-    const int dgrad = e0 >= nf;
-    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
-    const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
-    const int r = rs / KS, s = rs % KS;
-    bf16_t v; v.bits = 0;
-    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
-    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
-    wp[e0] = v;
-  }
+  ig_pack_body(a.w[t], a.wp[t], a.Cout[t], a.Cin[t], a.KS[t], a.KPf[t], a.KPd[t], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ... and the narrow convolutions' fragment images (conv_narrow_pack.h) in the same launch: blockIdx.y >= nig belongs to them
@@ -126,21 +135,7 @@ __global__ void ig_ncv_pack_many_kernel(PackMany a, NcvPackMany b, int nig, int 
     return;
   }
   const int t = blockIdx.y;
-  const bf16_t* __restrict__ w = a.w[t];
-  bf16_t* __restrict__ wp = a.wp[t];
-  const int Cout = a.Cout[t], Cin = a.Cin[t], KS = a.KS[t], KPf = a.KPf[t], KPd = a.KPd[t];
-  const int RS = KS * KS;
-  const int nf = RS * IG_M * KPf, total = nf + RS * IG_M * KPd;
-  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
-    const int dgrad = e0 >= nf;
-    const int e = dgrad ? e0 - nf : e0, KP = dgrad ? KPd : KPf;
-    const int k = e % KP, row = (e / KP) % IG_M, rs = e / (KP * IG_M);
-    const int r = rs / KS, s = rs % KS;
-    bf16_t v; v.bits = 0;
-    if (!dgrad) { if (row < Cout && k < Cin) v = w[((row * Cin + k) * KS + r) * KS + s]; }
-    else { if (row < Cin && k < Cout) v = w[((k * Cin + row) * KS + (KS - 1 - r)) * KS + (KS - 1 - s)]; }
-    wp[e0] = v;
-  }
+  ig_pack_body(a.w[t], a.wp[t], a.Cout[t], a.Cin[t], a.KS[t], a.KPf[t], a.KPd[t], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- fprop / dgrad -----------------------------------------------------------------------------------
@@ -364,7 +359,8 @@ __device__ __forceinline__ void ig_stats_wave(const float (&v)[16], float& n, fl
 // to the block's input gradient (autograd.scala:66-84 accumulates the two).  Its product (centre tap, the sibling's transposed filter) runs first
 // on its own images, then the 3x3's images replace them in LDS and the 3x3 product continues in the SAME accumulators: one rounding, one
 // epilogue, and neither the 1x1's 33.5 MB result nor its re-read as the addend.
-struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; const bf16_t* x2; };
+// wtail (round 6, ig_conv8d_kernel only; not a sibling's): the K-tail image of the launch's OWN filter (ig_pack_body), or null
+struct IgSibling { const bf16_t* wp; const bf16_t* bias; bf16_t* y; float* stats; const bf16_t* x2; const bf16_t* wtail; };
 
 // DEFAULT variant, TWO co-resident workgroups per CU (LAMP_IG_VARIANT=a selects the 4-image kernel above): two images and four waves per
 // workgroup, the images WITHOUT halo (taps outside the image read a shared zero pixel), two weight slots: 32 + 0.25 + 32 KiB of
@@ -927,7 +923,10 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   const int grp = wid >> 2;                 // second wave of its SIMD: runs one phase behind
   const int n0 = blockIdx.x * NI;
   const int KC = (CI + 31) >> 5;            // 32-channel chunks that hold real channels
-  const int T = RS * KC;
+  // K-tail (host: KS == 3, 1 .. 8 channels in the last chunk, not the whole-tap form): the last chunk's nine stages are three of four taps each
+  const bool tailm = KS == 3 && !SIB && sib.wtail != nullptr;     // (not beside a forward sibling: its epilogue state and the tail's six registers spilled)
+  const int KCF = tailm ? KC - 1 : KC;      // chunks multiplied tap by tap
+  const int T = RS * KCF + (tailm ? IG_TAIL_STAGES : 0);
 
   typedef __attribute__((address_space(3))) char lds_char_t;
   typedef const __attribute__((address_space(1))) char glb_char_t;
@@ -956,7 +955,15 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
         __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_src), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
     }
   };
-  auto stage_dma = [&](int kc1, int rs1, int slot) { stage_dma_of(wp, kc1, rs1, slot); };
+  // (stage t1 >= RS KCF: stage t1 - RS KCF of the K-tail image [3][128 rows][32 k] - the same pieces and swizzle at a row pitch of 32)
+  const unsigned d_srct = (unsigned)(d_row * 32 + (((lane & 3) ^ ((4 - ((d_row >> 2) & 3)) & 3)) << 3)) * 2u;
+  auto stage_dma = [&](int kc1, int rs1, int slot) {
+    if (kc1 < KCF) { stage_dma_of(wp, kc1, rs1, slot); return; }
+    if constexpr (!SIB) {
+      const char* base = reinterpret_cast<const char*>(sib.wtail + ((kc1 - KCF) * RS + rs1) * (IG_M * 32));
+      if (wid < NCT) __builtin_amdgcn_global_load_lds((glb_char_t*)(base + d_srct), (lds_char_t*)(Wl + slot * WT + wid * 1024), 16, 0, 0);
+    }
+  };
   // WIDE stages (round 5, one channel tile per wave: NCT = 1, not with a fprop sibling): a stage of the narrow form is 16 rows x 32 k - four
   // MFMAs between two barriers, and a 128-channel input costs 36 (+ 4) of them: the 16-channel input gradient of res3 took 26 us for 67 MB of
   // gradients.  Here a stage is a whole TAP, 16 rows x all KC chunks (wave kc requests chunk kc's 1 KiB piece): RS (+ 1) stages.
@@ -1342,7 +1349,7 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int t = 0, slot = 0;
-  for (int kc = 0; kc < KC; kc++) {
+  for (int kc = 0; kc < KCF; kc++) {
     const char* xk = Xl + kc * XBUF;
 #pragma unroll
     for (int rs = 0; rs < RS; rs++, t++) {
@@ -1382,6 +1389,50 @@ __global__ __launch_bounds__(512) void ig_conv8d_kernel(const bf16_t* __restrict
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
       slot = slot1;
+    }
+  }
+  if constexpr (KS == 3 && !SIB) {
+    if (tailm) {
+      // ---- K-tail: three stages of four taps over the first 8 channels of chunk KCF.  Lane group q = lane >> 4 is tap 4 g + q: its pixel
+      // fragment is the 16-byte piece 0 of the pixel that tap needs (one address per lane and stage, the tile j an immediate), zeroed where
+      // the tap leaves the image or does not exist (taps 9 - 11).  Addresses and masks are made HERE, from an opaque copy of the lane
+      // number: six registers that must not live beside the accumulators through the loop above.
+      int lane2 = lane;
+      asm volatile("" : "+v"(lane2));
+      int rsel2, wpx2;
+      px_of_col(lane2 & 15, rsel2, wpx2);
+      const char* xk = Xl + KCF * XBUF + wid * XIMG;
+#pragma unroll
+      for (int g = 0; g < IG_TAIL_STAGES; g++, t++) {
+        const int tap = 4 * g + (lane2 >> 4), tapc = tap < RS ? tap : RS - 1;
+        const int r = (tapc * 11) >> 5, s_ = tapc - 3 * r;
+        const int hp = rsel2 + r - PAD, wq = wpx2 + s_ - PAD;
+        const char* xb = xk + (hp * 8 + wq) * RB + (ig8d_swz(hp, wq) << 4);
+        const bool outc = tap >= RS || wq < 0 || wq > 7;
+        const bool out0 = outc || hp < 0, out3 = outc || hp + 6 > 7;
+        const char* wl = Wl + slot * WT + a_off;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (t + 2 < T) stage_dma(KCF, g + 2, slot2);
+#pragma unroll
+        for (int i = 0; i < NCT; i++) fa[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(wl + i * 1024));
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(bf8v, *reinterpret_cast<const s8v*>(xb + 16 * j * RB));
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        fb[0] = out0 ? zero8 : fb[0];
+        fb[1] = outc ? zero8 : fb[1];
+        fb[2] = outc ? zero8 : fb[2];
+        fb[3] = out3 ? zero8 : fb[3];
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NCT; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        slot = slot1;
+      }
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();          // every READ phase of every wave is over: LDS is free
@@ -2156,11 +2207,14 @@ uint64_t g_pack_tick = 0;
 
 static int pad_k(int64_t c);
 // returns a +1 handle on the buffer [fprop image | dgrad image]; *dgrad_offset = element offset of the second image
-static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStream_t st, int64_t* dgrad_offset) {
+// (tail_offset, optional: element offsets of the fprop / dgrad K-tail images, -1 where the filter has none - ig_tail_ok)
+static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStream_t st, int64_t* dgrad_offset, int64_t* tail_offset = nullptr) {
   const int RS = KS * KS;
   const int KPf = pad_k(g.Cin), KPd = pad_k(g.Cout);
   const int64_t nf = (int64_t)RS * IG_M * KPf, nd = (int64_t)RS * IG_M * KPd;
+  const int64_t ntf = ig_tail_ok((int)g.Cin, KS) ? IG_TAIL_ELEMS : 0, ntd = ig_tail_ok((int)g.Cout, KS) ? IG_TAIL_ELEMS : 0;
   *dgrad_offset = nf;
+  if (tail_offset) { tail_offset[0] = ntf ? nf + nd : -1; tail_offset[1] = ntd ? nf + nd + ntf : -1; }
   static const bool cache_on = [] { const char* e = getenv("LAMP_PACK_CACHE"); return !(e && e[0] == '0'); }();
   const bool cacheable = cache_on && w->st->owned && !w->st->scratch;
   const PackKey key{w->st->uid, w->offset, KS, (int)g.Cout, (int)g.Cin, st};
@@ -2174,7 +2228,7 @@ static Tensor* packed_weights(const Tensor* w, const ConvGeom& g, int KS, hipStr
       return retain(it->second.packed);
     }
   }
-  int64_t ps[1] = {nf + nd};
+  int64_t ps[1] = {nf + nd + ntf + ntd};
   Hold wp(new_tensor(ps, 1, kBF16, w->device()));
   hipLaunchKernelGGL(ig_pack_weights_kernel, dim3(grid_for(ps[0], 256)), dim3(256), 0, st, w->ptr<bf16_t>(), wp->ptr<bf16_t>(), (int)g.Cout,
                      (int)g.Cin, KS, KPf, KPd);
@@ -2226,7 +2280,7 @@ void igemm_repack_cached(lamp_tensor* const* params, int n, hipStream_t st) {
       if (kv.first.uid != w->st->uid || kv.first.offset != w->offset || kv.first.st != st) continue;
       if (kv.first.Cout != (int)w->sizes[0] || kv.first.Cin != (int)w->sizes[1] || kv.first.KS != (int)w->sizes[2]) continue;
       const int KS = kv.first.KS, RS = KS * KS, KPf = pad_k(kv.first.Cin), KPd = pad_k(kv.first.Cout);
-      const int total = RS * IG_M * (KPf + KPd);
+      const int total = RS * IG_M * (KPf + KPd) + (ig_tail_ok(kv.first.Cin, KS) ? IG_TAIL_ELEMS : 0) + (ig_tail_ok(kv.first.Cout, KS) ? IG_TAIL_ELEMS : 0);
       if (kv.second.packed->numel() != total) continue;
       a.w[cnt] = w->ptr<bf16_t>(); a.Cout[cnt] = kv.first.Cout; a.Cin[cnt] = kv.first.Cin; a.KS[cnt] = KS; a.KPf[cnt] = KPf; a.KPd[cnt] = KPd;
       // IN PLACE: the entry belongs to this stream, so every convolution that read the old image is ordered before this launch - and a
@@ -2274,8 +2328,12 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
   const int CI = (int)(dgrad ? g.Cout : g.Cin), CO = (int)(dgrad ? g.Cin : g.Cout);
   const int KP = pad_k(CI);
   int64_t dgrad_off = 0;
-  Hold wpk(packed_weights(w, g, KS, st, &dgrad_off));
+  int64_t tail_off[2] = {-1, -1};
+  Hold wpk(packed_weights(w, g, KS, st, &dgrad_off, tail_off));
   const bf16_t* wpp = static_cast<const Tensor*>(wpk.get())->ptr<bf16_t>() + (dgrad ? dgrad_off : 0);
+  // the K-tail image of this direction (1 .. 8 channels beyond the last whole chunk of a 3x3's K side): LAMP_IG_KTAIL=0 multiplies the padded chunk
+  const bool ktail_on = [] { const char* e = getenv("LAMP_IG_KTAIL"); return !(e && e[0] == '0'); }();      // (read per call: the A/B test flips it)
+  const bf16_t* wtailp = (ktail_on && tail_off[dgrad ? 1 : 0] >= 0) ? static_cast<const Tensor*>(wpk.get())->ptr<bf16_t>() + tail_off[dgrad ? 1 : 0] : (const bf16_t*)nullptr;
   {
     const char* variant = getenv("LAMP_IG_VARIANT");
     if (!(variant && variant[0] == 'a')) {   // default: two co-resident workgroups per CU (A/B on one device: 7 % faster per launch)
@@ -2351,6 +2409,7 @@ static void run_conv8(const Tensor* in, const Tensor* w, const Tensor* bias, Ten
           sibk.x2 = second->dy->ptr<bf16_t>();
           if (second_fused) *second_fused = true;
         }
+        if (KS == 3 && CO > 16 && !sib) sibk.wtail = wtailp;        // (not in the whole-tap stages of the one-tile form, not beside a forward sibling)
         if (dg2) { if (CO <= 16) IG_LAUNCH_D(3, 1, 2); else if (CO <= 64) IG_LAUNCH_D(3, 4, 2); else if (CO <= 112) IG_LAUNCH_D(3, 7, 2); else IG_LAUNCH_D(3, 8, 2); }
         else if (sib) { if (CO <= 16) IG_LAUNCH_D(3, 1, true); else if (CO <= 64) IG_LAUNCH_D(3, 4, true); else if (CO <= 112) IG_LAUNCH_D(3, 7, true); else IG_LAUNCH_D(3, 8, true); }
         else if (KS == 3) { if (CO <= 16) IG_LAUNCH_D(3, 1, false); else if (CO <= 64) IG_LAUNCH_D(3, 4, false); else if (CO <= 112) IG_LAUNCH_D(3, 7, false); else IG_LAUNCH_D(3, 8, false); }

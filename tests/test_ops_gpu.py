@@ -671,7 +671,8 @@ def test_convolution_forward_backward(gpu, dt, case):
 
 @pytest.mark.parametrize("case", [(16, 128, 128, 3), (13, 128, 100, 3), (9, 100, 100, 3), (24, 16, 128, 3), (11, 128, 100, 1), (8, 16, 128, 1),
                                   (3, 100, 128, 3), (1100, 128, 128, 3),
-                                  (16, 16, 16, 3), (13, 128, 16, 3), (9, 128, 64, 1), (21, 64, 48, 3)])   # 1 / 4 channel tiles per wave
+                                  (16, 16, 16, 3), (13, 128, 16, 3), (9, 128, 64, 1), (21, 64, 48, 3),    # 1 / 4 channel tiles per wave
+                                  (10, 40, 72, 3), (5, 33, 97, 3), (7, 36, 36, 3), (1032, 100, 100, 3)])  # K-tails of 8, 1 and 4 channels (fprop: Cin, dgrad: Cout)
 def test_igemm_eight_image_kernel(gpu, case, monkeypatch):
     """ig_conv8d_kernel (one workgroup per CU, eight images, wave = image x all output channels; the default for > 64 output channels
     once the batch gives every CU a workgroup): forced on small and ragged batches (N not a multiple of 8, N < 8), fprop with bias and
@@ -723,6 +724,44 @@ def test_igemm_eight_image_kernel(gpu, case, monkeypatch):
         assert_close(to_torch(invstd), rn[2].double(), 2.0 ** -8, "save_invstd from the epilogue's partials")
         assert_close(to_torch(yn), rn[0].double(), 2.0 ** -7, "batch norm on the hand-off statistics")
         monkeypatch.delenv("LAMP_IG_VARIANT")
+
+
+@pytest.mark.parametrize("case", [(9, 100, 100), (1029, 100, 100), (12, 40, 72), (5, 33, 97), (6, 104, 41), (8, 68, 128)])
+def test_igemm_k_tail_stages_multiply_what_the_padded_chunk_did(gpu, case, monkeypatch):
+    """ig_conv8d_kernel's K-tail (round 6): a 3x3 whose K side ends 1 .. 8 channels past a whole 32-channel chunk multiplies those channels as three
+    stages of four taps (tail image of ig_pack_body) instead of nine stages of 32 k that are mostly padding.  The products are the same f32
+    values summed in another order: forward and input gradient with the tail stages (default) and without (LAMP_IG_KTAIL=0) agree within one
+    bf16 rounding, both with the f64 convolution of the same operands, and the batch-norm partials the forward publishes describe its own output."""
+    N, Cin, Cout = case
+    dt = torch.bfloat16
+    x = closed_form((N, Cin, 8, 8), 3, 2.0, dt)
+    w = closed_form((Cout, Cin, 3, 3), 17, 1.0, dt)
+    b = closed_form((Cout,), 5, 1.0, dt)
+    gy = closed_form((N, Cout, 8, 8), 23, 1.0, dt)
+    args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    monkeypatch.setenv("LAMP_IG_VARIANT", "d")
+
+    def run(ktail):
+        monkeypatch.setenv("LAMP_IG_KTAIL", ktail)
+        o = C.c_void_p()
+        lib.lamp_convolution(C.byref(o), to_sten(x), to_sten(w), to_sten(b), i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0,
+                             i64_array([0, 0]), 1)
+        out = _out3()
+        lib.lamp_convolution_backward(out, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0,
+                                      i64_array([0, 0]), 1, _mask3(1, 0, 0))
+        return to_torch(S.STen(o)), to_torch(_wrap3(out)[0])
+
+    y1, dx1 = run("1")
+    y0, dx0 = run("0")
+    ref = aten.convolution(x.double(), w.double(), b.double(), *args)
+    refb = aten.convolution_backward(gy.double(), x.double(), w.double(), [Cout], *args, [True, False, False])
+    assert_close(y1, ref, 2.0 ** -7, "forward with tail stages")
+    assert_close(dx1, refb[0], 2.0 ** -7, "input gradient with tail stages")
+    assert_close(y1, y0.double(), 2.0 ** -7, "forward: tail stages vs padded chunk")
+    assert_close(dx1, dx0.double(), 2.0 ** -7, "input gradient: tail stages vs padded chunk")
+    # at least as close to the exact result as the padded form, up to the noise of one rounding
+    e1, e0 = (y1.double() - ref).norm(), (y0.double() - ref).norm()
+    assert e1 <= 1.05 * e0 + 1e-12, (e1, e0)
 
 
 def _timer_classes():
@@ -1321,6 +1360,7 @@ DGRAD_PAIR_CASES = [
     (16, 8, 32, 5, 3, 1, torch.bfloat16, False, True),
     (1024, 128, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),   # res4: the eight-image kernel takes the second gradient as a second set of images
     (1027, 100, 8, 128, 128, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),    # ragged last workgroup, 7 channel tiles, a third contribution
+    (1032, 128, 8, 100, 100, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),    # res4's own geometry: 100 gradient channels, the 3x3's last four as K-tail stages
     (1024, 16, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),    # res3: 16 input channels (one tile)
     (1024, 64, 8, 64, 64, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),       # two 32-channel chunks, 4 tiles
     (64, 128, 8, 100, 100, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),     # small batch: the two-image kernel (eight waves) takes the second source too
