@@ -1019,7 +1019,9 @@ static bool ncv_run(const Tensor* in, const Tensor* w, const Tensor* bias, Tenso
     q.pf = (q.W % 8 == 0 && (int64_t)q.C * q.H * q.W <= (int64_t)NCV_PF * threads * 8) ? 1 : 0;
     if (second && !q.pf) return false;                     // (two sources are staged through the register prefetch only)
     if (NK > 12 && !second) return false;
-    const int NK2 = NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : (NK <= 6 && second ? 6 : (NK <= 8 && second ? 8 : (NK <= 12 ? 12 : 16)))));
+    // (parity tiles: the kernel's k-steps are the packed image's two halves - 2 nke, whatever the plain form would have taken: 12 k-steps of
+    // pairs are 16 there)
+    const int NK2 = nke > 0 ? 2 * nke : NK <= 2 ? 2 : (NK <= 4 ? 4 : (NK <= 5 ? 5 : (NK <= 6 && second ? 6 : (NK <= 8 && second ? 8 : (NK <= 12 ? 12 : 16)))));
     const void* kfn = nullptr;
     const bool with_add = addend != nullptr && q.sw == 1;
     // fprop: per-image batch-norm statistics of the output(s) from the epilogue (LAMP_CONV_BN_STATS=0 turns the hand-off off)

@@ -1357,6 +1357,9 @@ DGRAD_PAIR_CASES = [
     (64, 6, 16, 16, 16, 2, torch.bfloat16, False, True),    # res2: 16 + 16 channels, sixteen k-steps
     (2050, 6, 16, 16, 16, 2, torch.bfloat16, True, True),   # more images than workgroups
     (33, 6, 16, 6, 6, 1, torch.bfloat16, False, True),      # stride 1
+    (40, 6, 16, 12, 12, 2, torch.bfloat16, False, True),    # 48 K pairs: twelve k-steps in the plain form, 8 + 8 by row parity
+    (40, 5, 16, 9, 7, 2, torch.bfloat16, True, True),       # ... 34 pairs, uneven halves
+    (40, 6, 16, 8, 8, 2, torch.bfloat16, False, True),      # 32 pairs: both halves full (4 + 4)
     (16, 8, 32, 5, 3, 1, torch.bfloat16, False, True),
     (1024, 128, 8, 128, 128, 1, torch.bfloat16, False, "conv_igemm_fprop_dgrad"),   # res4: the eight-image kernel takes the second gradient as a second set of images
     (1027, 100, 8, 128, 128, 1, torch.bfloat16, True, "conv_igemm_fprop_dgrad"),    # ragged last workgroup, 7 channel tiles, a third contribution
