@@ -500,6 +500,14 @@ int lamp_native_batch_norm2_add_relu(lamp_tensor* out5[5], const lamp_tensor* x,
                                      lamp_tensor* running_mean, lamp_tensor* running_var, const lamp_tensor* x2, const lamp_tensor* weight2,
                                      const lamp_tensor* bias2, lamp_tensor* running_mean2, lamp_tensor* running_var2, double momentum,
                                      double momentum2, double eps, double eps2);
+/* ... followed by AvgPool2D over the whole map -> Flatten -> LogSoftMax: the LAST block of Cnn.resnet and the network's tail (cnn.scala:129-136) in
+ * one call.  The block's output has one reader, the pool, and is never written: out5[0] = the log-probabilities [N, C] (bitwise those of
+ * lamp_global_avg_pool_log_softmax(lamp_native_batch_norm2_add_relu(...)[0])), the other four as above.  Its backward is
+ * lamp_native_batch_norm2_add_relu_backward on the pooled LogSoftMax's input gradient (one value per plane, as an expanded view). */
+int lamp_native_batch_norm2_add_relu_pool_log_softmax(lamp_tensor* out5[5], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                                                      lamp_tensor* running_mean, lamp_tensor* running_var, const lamp_tensor* x2,
+                                                      const lamp_tensor* weight2, const lamp_tensor* bias2, lamp_tensor* running_mean2,
+                                                      lamp_tensor* running_var2, double momentum, double momentum2, double eps, double eps2);
 int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,
                                               const lamp_tensor* bias, const lamp_tensor* save_mean, const lamp_tensor* save_invstd,
                                               const lamp_tensor* x2, const lamp_tensor* weight2, const lamp_tensor* bias2,

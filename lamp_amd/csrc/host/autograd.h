@@ -140,6 +140,10 @@ struct Op {
   // state a node's closures keep BETWEEN each other during one backprop (the convolution pair's held derivatives): backprop calls this
   // for every node before it starts, so a pass that was abandoned half-way (an exception between two siblings) leaves nothing behind
   std::function<void()> reset;
+  // a node whose value is LogSoftMax(pool(y)) of a tensor y it never wrote (batch_norm2_add_relu_pool_log_softmax_2d): takes y's gradient as one
+  // value per plane ([N, C], any strides) and accumulates the gradients of its inputs at once.  The loss's closure calls it INSTEAD of
+  // accumulating into the node's output when it holds that gradient already (nll_loss_accumulate); the node's own closures then never run.
+  std::function<void(const Ten& plane_grad)> pooled_input_grad;
 };
 
 // Gradient buffers.  lamp allocates a zeros_like buffer for every op output up front (autograd.scala:89-96) and

@@ -61,7 +61,13 @@ bool BatchNorm::can_fuse_add_relu(const Var& x) const { return training && can_f
 Var BatchNorm::forward_add_relu(const Var& x, const Var& addend) {
   return F::batch_norm_add_relu_2d(x, addend, weight, bias, runningMean->value, runningVar->value, training, momentum, eps);
 }
-Var Residual::forward_relu(const Var& x) {
+Var Residual::forward_relu(const Var& x, int64_t pool_tail) {
+  // (the tail behind the block's output y, where the one-node form does not apply)
+  auto tail = [&](const Var& y) -> Var {
+    if (!pool_tail) return y;
+    if (y->value.ndim() == 4 && y->value.size(2) == pool_tail && y->value.size(3) == pool_tail && y->value.h()->is_device()) return F::global_avg_pool_log_softmax(y);
+    return F::log_softmax(F::flatten(F::avg_pool2d(y, pool_tail, 1, 0), y->value.ndim() - 3, -1), 1);
+  };
   auto* seq = dynamic_cast<Sequential*>(right.get());
   BatchNorm* bn = (seq && !seq->mods.empty()) ? dynamic_cast<BatchNorm*>(seq->mods.back().get()) : nullptr;
   if (bn) {
@@ -94,28 +100,70 @@ Var Residual::forward_relu(const Var& x) {
         Sequential lhead(std::vector<Mod>(lseq->mods.begin(), lseq->mods.end() - 1));
         lv = lhead.forward(x);
       }
-      if (lbn->can_fuse_add_relu(lv) && lv->shape() == v->shape() && lv->value.dtype() == v->value.dtype())
-        return F::batch_norm2_add_relu_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps,
-                                          lv, lbn->weight, lbn->bias, lbn->runningMean->value, lbn->runningVar->value, lbn->momentum, lbn->eps);
+      if (lbn->can_fuse_add_relu(lv) && lv->shape() == v->shape() && lv->value.dtype() == v->value.dtype()) {
+        // ... and with the network's tail behind it, the block's output is never written (LAMP_FUSE_BLOCK_TAIL=0: the two nodes)
+        if (pool_tail && v->value.ndim() == 4 && v->value.size(2) == pool_tail && v->value.size(3) == pool_tail)
+          return F::batch_norm2_add_relu_pool_log_softmax_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps,
+                                                             lv, lbn->weight, lbn->bias, lbn->runningMean->value, lbn->runningVar->value, lbn->momentum, lbn->eps);
+        return tail(F::batch_norm2_add_relu_2d(v, bn->weight, bn->bias, bn->runningMean->value, bn->runningVar->value, bn->momentum, bn->eps,
+                                               lv, lbn->weight, lbn->bias, lbn->runningMean->value, lbn->runningVar->value, lbn->momentum, lbn->eps));
+      }
       Var l = lbn->forward(lv);
-      if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);
-      return F::relu(F::add(bn->forward(v), l));
+      if (l->shape() == v->shape()) return tail(bn->forward_add_relu(v, l));
+      return tail(F::relu(F::add(bn->forward(v), l)));
     }
     if (bn->can_fuse_add_relu(v)) {
       Var l = left_branch();
-      if (l->shape() == v->shape()) return bn->forward_add_relu(v, l);
-      return F::relu(F::add(bn->forward(v), l));
+      if (l->shape() == v->shape()) return tail(bn->forward_add_relu(v, l));
+      return tail(F::relu(F::add(bn->forward(v), l)));
     }
     Var l = left_branch();
-    return F::relu(F::add(bn->forward(v), l));
+    return tail(F::relu(F::add(bn->forward(v), l)));
   }
-  return F::relu(forward(x));
+  return tail(F::relu(forward(x)));
+}
+// [..., Residual, relu, Dropout(p <= 0)*] or [..., Sequential that can]: everything in front of the last block as usual, the block with the tail
+Var Sequential::forward_pool_tail(const Var& x, int64_t pool, bool probe) {
+  size_t n = mods.size();
+  while (n > 0) {
+    auto* d = dynamic_cast<Dropout*>(mods[n - 1].get());
+    if (d && d->prob <= 0) n--; else break;
+  }
+  if (n == 0) return nullptr;
+  if (auto* inner = dynamic_cast<Sequential*>(mods[n - 1].get())) {
+    if (!inner->forward_pool_tail(x, pool, true)) return nullptr;
+    if (probe) return x;
+    const Var v = n > 1 ? Sequential(std::vector<Mod>(mods.begin(), mods.begin() + (n - 1))).forward(x) : x;
+    return inner->forward_pool_tail(v, pool, false);
+  }
+  auto* fn = dynamic_cast<Fun*>(mods[n - 1].get());
+  auto* res = n >= 2 ? dynamic_cast<Residual*>(mods[n - 2].get()) : nullptr;
+  if (!(fn && fn->tag == "relu" && res)) return nullptr;
+  if (probe) return x;
+  const Var v = n > 2 ? Sequential(std::vector<Mod>(mods.begin(), mods.begin() + (n - 2))).forward(x) : x;
+  return res->forward_relu(v, pool);
 }
 // The reference's Sequential is a plain fold (nn/Sequential.scala).  The one rewrite done here: BatchNorm2D directly followed by
 // Fun(relu) runs as the fused op (same values, three elementwise passes fewer).
 Var Sequential::forward(const Var& x) {
   Var v = x;
   for (size_t i = 0; i < mods.size(); i++) {
+    if (i + 3 < mods.size() && v->value.h()->is_device()) {
+      // module -> Fun(avgpool2d, stride 1) -> Fun(flatten the last three dims) -> Fun(logsoftmax over dim 1) where the module ends in a residual
+      // block under a relu (Cnn.resnet: the Sequential of the four blocks, cnn.scala:118-136): the last block and the tail as one node - the
+      // block's output, which only the pool reads, is never written (LAMP_FUSE_BLOCK_TAIL=0: off)
+      static const bool fuse_tail0 = [] { const char* e = getenv("LAMP_FUSE_POOL_LOGSOFTMAX"); return !(e && e[0] == '0'); }();
+      static const bool fuse_block_tail = [] { const char* e = getenv("LAMP_FUSE_BLOCK_TAIL"); return !(e && e[0] == '0'); }();
+      auto* pool = dynamic_cast<Fun*>(mods[i + 1].get());
+      auto* flat = dynamic_cast<Fun*>(mods[i + 2].get());
+      auto* lsm = dynamic_cast<Fun*>(mods[i + 3].get());
+      if (fuse_tail0 && fuse_block_tail && pool && flat && lsm && pool->tag == "avgpool2d" && pool->b == 1 && pool->a >= 1 && flat->tag == "flatten_last" &&
+          flat->a == 3 && lsm->tag == "logsoftmax" && lsm->a == 1 && mods[i]->forward_pool_tail(v, (int64_t)pool->a, true)) {
+        v = mods[i]->forward_pool_tail(v, (int64_t)pool->a, false);
+        i += 3;
+        continue;
+      }
+    }
     if (i + 1 < mods.size()) {
       auto* bn = dynamic_cast<BatchNorm*>(mods[i].get());
       auto* fn = dynamic_cast<Fun*>(mods[i + 1].get());

@@ -21,6 +21,10 @@ struct Module {
   // GenericModule[A, B] with a tuple / case-class input (Transformer.scala, lm.scala): the Variables and the plain tensors of A in
   // the reference's order; an Option that is None is an undefined Ten.  Single-input modules ignore the extras.
   virtual Var forward_multi(const std::vector<Var>& xs, const std::vector<Ten>& aux) { (void)aux; return forward(xs.at(0)); }
+  // LogSoftMax(Flatten(AvgPool2D(forward(x), pool))) where this module can produce it WITHOUT writing forward(x) - the tail of Cnn.resnet behind
+  // its last block (cnn.scala:129-136; Sequential::forward asks the module in front of that tail).  `probe`: only say whether it can (structure
+  // alone: a non-null dummy), compute nothing.  nullptr: cannot - the caller runs forward and the tail as usual.
+  virtual Var forward_pool_tail(const Var& x, int64_t pool, bool probe) { (void)x; (void)pool; (void)probe; return nullptr; }
   virtual void set_training(bool) {}   // TrainingMode.asEval / asTraining
   std::vector<Var> state() { std::vector<Var> s; collect_state(s); return s; }
   std::vector<Var> parameters() {
@@ -98,6 +102,7 @@ struct Sequential : Module {
   explicit Sequential(std::vector<Mod> m) : mods(std::move(m)) {}
   void collect_state(std::vector<Var>& o) override { for (auto& m : mods) m->collect_state(o); }
   Var forward(const Var& x) override;
+  Var forward_pool_tail(const Var& x, int64_t pool, bool probe) override;
   void set_training(bool t) override { for (auto& m : mods) m->set_training(t); }
 };
 struct Residual : Module {      // cnn.scala:11-21
@@ -111,7 +116,8 @@ struct Residual : Module {      // cnn.scala:11-21
   }
   // relu(forward(x)); when the right branch is a Sequential ending in a fusable BatchNorm2D the add and the relu run inside
   // its normalise kernel (identical values)
-  Var forward_relu(const Var& x);
+  // pool_tail > 0: LogSoftMax(Flatten(AvgPool2D(relu(forward(x)), pool_tail))) - one node with the two batch norms where that form applies
+  Var forward_relu(const Var& x, int64_t pool_tail = 0);
   void set_training(bool t) override { right->set_training(t); if (left) left->set_training(t); }
 };
 

@@ -502,8 +502,11 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
   static const bool fuse_ahead = [] { const char* e = getenv("LAMP_FUSE_LOSS_TAIL"); return !(e && e[0] == '0'); }();
   const bool from_tail = input->op && input->op->params.size() == 1 && std::strcmp(input->op->name, "GlobalAvgPoolLogSoftMax") == 0 &&
                          input->value.h()->is_device() && input->op->params[0].first->needsGrad() && input->op->params[0].first->value.ndim() == 4;
+  // ... or from the node that holds the last block too (batch_norm2_add_relu_pool_log_softmax_2d): its first input has the pooled tensor's shape
+  const bool from_block_tail = input->op && (bool)input->op->pooled_input_grad && input->op->params.size() == 6 && input->value.h()->is_device() &&
+                               input->op->params[0].first->value.ndim() == 4;
   // (bf16: the dtype whose batch-norm backward reads the plane values in place; in f32 / f64 the expanded view would be written out again)
-  if (fuse_tail && fuse_ahead && from_tail && reduction != 0 && input->value.dtype() == kBF16) {
+  if (fuse_tail && fuse_ahead && (from_tail || from_block_tail) && reduction != 0 && input->value.dtype() == kBF16) {
     const Ten& xin = input->op->params[0].first->value;
     HCALL(lamp_nll_loss_forward_pooled_gradient_(&v, &tw, &pgh, input->value.h(), target.h(), weights.h(), reduction, ignore, acc.defined() ? acc.h() : nullptr, scale,
                                                  xin.size(2) * xin.size(3)));
@@ -511,6 +514,10 @@ Var nll_loss_accumulate(const Var& input, const Ten& target, const Ten& weights,
   else HCALL(lamp_nll_loss_forward(&v, &tw, input->value.h(), target.h(), weights.h(), reduction, ignore));
   Ten val(v), total_weight(tw), iv = input->value, plane_grad = pgh ? Ten(pgh) : Ten();
   op->params.push_back({input, [=](const Ten& p, Variable& out) {
+    if (plane_grad.defined() && p.h() == tls_seed_ones && !tls_backprop_hooked && out.op && out.op->pooled_input_grad) {
+      out.op->pooled_input_grad(plane_grad);                // the node of the last block + tail: its inputs' gradients at once
+      return;
+    }
     if (plane_grad.defined() && p.h() == tls_seed_ones && !tls_backprop_hooked && out.op && out.op->params.size() == 1 &&
         std::strcmp(out.op->name, "GlobalAvgPoolLogSoftMax") == 0) {
       // the derivative is the seed itself: the gradient computed ahead is the one the launch below would write, as an expanded view
@@ -1097,6 +1104,91 @@ Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias
   op->params.push_back({input2, back(3)});
   op->params.push_back({weight2, back(4)});
   op->params.push_back({bias2, back(5)});
+  return make_result(op, out);
+}
+// ... and, as the LAST block of Cnn.resnet, with the network's tail behind it: LogSoftMax(Flatten(AvgPool2D(relu(bn(x) + bn2(x2))))) as ONE node
+// (cnn.scala:129-136; lamp_native_batch_norm2_add_relu_pool_log_softmax).  The block's output y has one reader, the pool: it is never written.
+// Backward: y's gradient is one value per plane - the pooled LogSoftMax's input gradient, (p - exp(out) sum p) / HW with the roundings of
+// lamp_global_avg_pool_log_softmax_backward - handed to lamp_native_batch_norm2_add_relu_backward as a view expanded over the map.
+static Ten expand_planes(const Ten& plane_grad, const std::vector<int64_t>& xs) {
+  lamp_tensor *u2 = nullptr, *u3 = nullptr, *e = nullptr;
+  HCALL(lamp_unsqueeze(&u2, plane_grad.h(), 2));
+  const Ten t2(u2);
+  HCALL(lamp_unsqueeze(&u3, t2.h(), 3));
+  const Ten pv(u3);
+  HCALL(lamp_expand(&e, pv.h(), xs.data(), 4));
+  return Ten(e);
+}
+Var batch_norm2_add_relu_pool_log_softmax_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum,
+                                             double eps, const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2,
+                                             const Ten& runningVar2, double momentum2, double eps2) {
+  auto op = new_op("BatchNorm2DPairAddReluPoolLogSoftMax");
+  const Ten x = input->value, wv = weight->value, bv = bias->value, x2 = input2->value, wv2 = weight2->value, bv2 = bias2->value;
+  const std::vector<int64_t> expected = {x.size(1)};
+  LAMP_CHECK(x.ndim() == 4, "Input dimensions must be 4");
+  LAMP_CHECK(weight->shape() == expected && bias->shape() == expected && weight2->shape() == expected && bias2->shape() == expected,
+             "batch norm weight / bias have the wrong shape");
+  LAMP_CHECK(runningMean.shape() == expected && runningVar.shape() == expected && runningMean2.shape() == expected && runningVar2.shape() == expected,
+             "running statistics have the wrong shape");
+  lamp_tensor* o5[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  HCALL(lamp_native_batch_norm2_add_relu_pool_log_softmax(o5, x.h(), wv.h(), bv.h(), runningMean.h(), runningVar.h(), x2.h(), wv2.h(), bv2.h(), runningMean2.h(),
+                                                          runningVar2.h(), momentum, momentum2, eps, eps2));
+  Ten out(o5[0]), saveMean(o5[1]), saveInvstd(o5[2]), saveMean2(o5[3]), saveInvstd2(o5[4]);
+  const std::vector<int64_t> xs = x.shape();
+  const double hw = (double)(xs[2] * xs[3]);
+  const bool want[6] = {input->needsGrad(), weight->needsGrad(), bias->needsGrad(), input2->needsGrad(), weight2->needsGrad(), bias2->needsGrad()};
+  // the six gradients for y's gradient given as plane values [N, C]
+  auto six = [=](const Ten& plane_grad, const bool (&need)[6], Ten (&g)[6]) {
+    const Ten gy = expand_planes(plane_grad, xs);
+    uint8_t mask[6];
+    for (int i = 0; i < 6; i++) mask[i] = (uint8_t)need[i];
+    lamp_tensor* r6[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    HCALL(lamp_native_batch_norm2_add_relu_backward(r6, gy.h(), x.h(), wv.h(), bv.h(), saveMean.h(), saveInvstd.h(), x2.h(), wv2.h(), bv2.h(), saveMean2.h(),
+                                                    saveInvstd2.h(), eps, eps2, mask));
+    for (int i = 0; i < 6; i++) g[i] = r6[i] ? Ten(r6[i]) : Ten();
+  };
+  // p -> plane values: _log_softmax_backward_data, then / HW (each rounded to the dtype, as the pooled LogSoftMax's own backward rounds them)
+  auto planes_of = [=](const Ten& p) {
+    lamp_tensor *gi = nullptr, *pg = nullptr;
+    HCALL(lamp_log_softmax_backward_data(&gi, p.h(), out.h(), 1));
+    const Ten gih(gi);
+    HCALL(lamp_div_scalar(&pg, gih.h(), hw));
+    return Ten(pg);
+  };
+  struct Cache { Ten g[6]; Ten p; };
+  auto cache = std::make_shared<Cache>();
+  auto back = [=](int which) {
+    return [=](const Ten& p, Variable& o) {
+      if (!(cache->p.defined() && cache->p.h() == p.h() && cache->g[which].defined())) {
+        bool need[6];
+        for (int i = 0; i < 6; i++) need[i] = want[i];
+        need[which] = true;
+        six(planes_of(p), need, cache->g);
+        cache->p = p;
+      }
+      Ten g = cache->g[which];
+      cache->g[which] = Ten();
+      bool any = false;
+      for (int i = 0; i < 6; i++) any = any || cache->g[i].defined();
+      if (!any) cache->p = Ten();
+      o.accumulate(ops::reshape(g, o.shape()), true);
+    };
+  };
+  op->params.push_back({input, back(0)});
+  op->params.push_back({weight, back(1)});
+  op->params.push_back({bias, back(2)});
+  op->params.push_back({input2, back(3)});
+  op->params.push_back({weight2, back(4)});
+  op->params.push_back({bias2, back(5)});
+  op->reset = [cache] { for (auto& t : cache->g) t = Ten(); cache->p = Ten(); };
+  // (raw pointers: the node's params hold the six variables for as long as the node lives)
+  Variable* vars[6] = {input.get(), weight.get(), bias.get(), input2.get(), weight2.get(), bias2.get()};
+  op->pooled_input_grad = [=](const Ten& plane_grad) {
+    Ten g[6];
+    six(plane_grad, want, g);
+    for (int i = 0; i < 6; i++)
+      if (want[i] && g[i].defined()) vars[i]->accumulate(ops::reshape(g[i], vars[i]->shape()), true);
+  };
   return make_result(op, out);
 }
 bool conv_of_batch_norm_relu_2d_pays(const Var& input, const Var& weight, int64_t stride, int64_t padding, int64_t dilation, int64_t groups) {

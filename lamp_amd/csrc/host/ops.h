@@ -73,6 +73,9 @@ Var conv_of_batch_norm_relu_2d(const Var& input, const Var& bnWeight, const Var&
                                const std::vector<int64_t>& dilation, int64_t groups);
 Var batch_norm2_add_relu_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum, double eps,
                             const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2, const Ten& runningVar2, double momentum2,
+                            double eps2);
+Var batch_norm2_add_relu_pool_log_softmax_2d(const Var& input, const Var& weight, const Var& bias, const Ten& runningMean, const Ten& runningVar, double momentum, double eps,
+                            const Var& input2, const Var& weight2, const Var& bias2, const Ten& runningMean2, const Ten& runningVar2, double momentum2,
                             double eps2);   // relu(bn(input) + bn2(input2)), training mode, one op
 Var layer_norm(const Var& input, const Var& weight /*nullable*/, const Var& bias /*nullable*/, const std::vector<int64_t>& normalizedShape,
                double eps);

@@ -286,7 +286,11 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
                                                         T* __restrict__ save_mean, T* __restrict__ save_invstd, T* running_mean, T* running_var,
                                                         double momentum, double eps, const T* __restrict__ w, const T* __restrict__ b, int64_t N,
                                                         int64_t C, int64_t HW, int nblk, int vec, int relu, const T* __restrict__ addend,
-                                                        BnSecond<T> second) {
+                                                        BnSecond<T> second, T* __restrict__ pooled = nullptr) {
+  // pooled (round 6, vec path, HW / W a power of two <= 64): the output is consumed by a global average pool and by nothing else (the last
+  // block of Cnn.resnet in front of AvgPool2D -> Flatten -> LogSoftMax, cnn.scala:129-136): y is NOT written; the HW / W lanes that hold a
+  // plane sum their rounded outputs in gap_lsm_fwd_kernel's order (eight values per lane, then the butterfly) and pooled[n][c] gets that
+  // kernel's rounded mean - bitwise what the pool would have read back from y
   using A = acc_t<T>;
   constexpr int W = 16 / sizeof(T);
   __shared__ A stat[2], stat2[2];
@@ -324,7 +328,13 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
         if (relu && load_as<A>(o) < A(0)) o = store_as<T>(A(0));
         pk.v[k] = o;
       }
-      *reinterpret_cast<Vec<T, W>*>(y + base) = pk;
+      if (pooled) {
+        A sum = 0;
+#pragma unroll
+        for (int k = 0; k < W; k++) sum += load_as<A>(pk.v[k]);
+        for (int off = (int)vpp >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (v == 0) pooled[n * C + c] = store_as<T>((A)(sum / (A)HW));
+      } else *reinterpret_cast<Vec<T, W>*>(y + base) = pk;
     }
   } else {
     const int64_t total = N * HW;
@@ -1446,10 +1456,14 @@ struct BnSecondArgs {
 };
 static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
                            lamp_tensor* running_mean, lamp_tensor* running_var, int training, double momentum, double eps, int relu,
-                           const lamp_tensor* addend = nullptr, BnSecondArgs* second = nullptr, bool table_only = false) {
+                           const lamp_tensor* addend = nullptr, BnSecondArgs* second = nullptr, bool table_only = false, bool* pooled = nullptr) {
+  // pooled (in: asked for, out: done): out3[0] = the [N, C] plane means of the output instead of the output (bn_apply2_kernel), where the
+  // two-batch-norm form runs its vector path over planes of a power-of-two number of packets; otherwise *pooled = false and out3[0] is the output
   LAMP_API_BEGIN
   check_device_tensor(x, "input");
   BnGeom g = bn_geom(x);
+  const bool want_pooled = pooled && *pooled;
+  if (pooled) *pooled = false;
   LAMP_CHECK(!table_only || (training && !addend && !second && x->dtype != kF64), "the batch norm table exists in training mode, as an f32 table for f32 / f16 / bf16 inputs");
   Hold addc, x2c, mean2, invstd2;
   if (second) {
@@ -1473,6 +1487,7 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   Hold xc(contiguous(x));
   int64_t cs[1] = {g.C}, ts[2] = {g.C, 4};
   Hold y(table_only ? new_tensor(ts, 2, kF32, x->device()) : new_like(xc.get()));   // table_only: out3[0] is the [C, 4] table, x is never normalised here
+  Hold pooled_t;
   Hold mean(new_tensor(cs, 1, x->dtype, x->device())), invstd(new_tensor(cs, 1, x->dtype, x->device()));
   hipStream_t st = current_stream(x->device());
   const int64_t total = x->numel();
@@ -1535,11 +1550,20 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
         LAMP_LAUNCH_CHECK();
       } else if (!col && total > 0) {
         // finalize folded into the channel-aligned normalise
-        KernelTimer kt("bn_fwd_apply", 0, (second ? 3.0 : addc.get() ? 3.0 : 2.0) * (double)total * sizeof(T), st);
+        const int vec2 = (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0;
+        const int64_t vpp = g.HW / (int64_t)(16 / sizeof(T));
+        T* poolp = nullptr;
+        if (want_pooled && second && vec2 && vpp >= 1 && vpp <= 64 && (vpp & (vpp - 1)) == 0) {
+          int64_t ps[2] = {g.N, g.C};
+          pooled_t = Hold(new_tensor(ps, 2, x->dtype, x->device()));
+          poolp = pooled_t->ptr<T>();
+          *pooled = true;
+        }
+        KernelTimer kt("bn_fwd_apply", 0, ((second ? 3.0 : addc.get() ? 3.0 : 2.0) - (poolp ? 1.0 : 0.0)) * (double)total * sizeof(T), st);
         hipLaunchKernelGGL((bn_apply2_kernel<T>), dim3((unsigned)g.C, nsplit), dim3(256), 0, st, static_cast<const Tensor*>(xc.get())->ptr<T>(), y->ptr<T>(),
                            static_cast<const Tensor*>(partial.get())->ptr<A>(), have_stats ? -npart : npart,
                            mean->ptr<T>(), invstd->ptr<T>(), rm, rv, momentum, eps, wp, bp, g.N, g.C, g.HW, nsplit,
-                           (vec && (!addc.get() || ((uintptr_t)addc->data() & 15) == 0)) ? 1 : 0, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr, sec);
+                           vec2, relu, addc.get() ? addc->ptr<T>() : (const T*)nullptr, sec, poolp);
         LAMP_LAUNCH_CHECK();
       } else {
         hipLaunchKernelGGL((bn_finalize_kernel<T>), dim3((unsigned)((g.C * 64 + 255) / 256)), dim3(256), 0, st, partial->ptr<A>(), g.C, nsplit,
@@ -1572,7 +1596,7 @@ static int bn_forward_impl(lamp_tensor* out3[3], const lamp_tensor* x, const lam
   if (!training) {
     // ATen returns empty save tensors in eval mode; keep handles valid but zero-sized semantics are not needed by lamp
   }
-  out3[0] = y.take(); out3[1] = mean.take(); out3[2] = invstd.take();
+  out3[0] = pooled_t.get() ? pooled_t.take() : y.take(); out3[1] = mean.take(); out3[2] = invstd.take();
   if (second) { second->save_mean = mean2.take(); second->save_invstd = invstd2.take(); }
   LAMP_API_END
 }
@@ -1737,6 +1761,31 @@ int lamp_native_batch_norm2_add_relu(lamp_tensor* out5[5], const lamp_tensor* x,
   const int rc = bn_forward_impl(o3, x, weight, bias, running_mean, running_var, 1, momentum, eps, 1, nullptr, &sec);
   if (rc != 0) return rc;
   out5[0] = o3[0]; out5[1] = o3[1]; out5[2] = o3[2]; out5[3] = sec.save_mean; out5[4] = sec.save_invstd;
+  return 0;
+}
+// ... -> AvgPool2D over the whole map -> Flatten -> LogSoftMax: the LAST block of Cnn.resnet with the network's tail (cnn.scala:129-136).  The
+// block's output has one reader, the pool - it is never written: bn_apply2_kernel leaves its plane means [N, C] (bitwise the pool's), the
+// LogSoftMax runs on those.  out5[0] = the log-probabilities [N, C]; the other four as lamp_native_batch_norm2_add_relu.  Where the pooled
+// form does not apply (planes that are no power-of-two number of 16-byte packets, unaligned views) the two calls run one after the other.
+int lamp_native_batch_norm2_add_relu_pool_log_softmax(lamp_tensor* out5[5], const lamp_tensor* x, const lamp_tensor* weight, const lamp_tensor* bias,
+                                                      lamp_tensor* running_mean, lamp_tensor* running_var, const lamp_tensor* x2, const lamp_tensor* weight2,
+                                                      const lamp_tensor* bias2, lamp_tensor* running_mean2, lamp_tensor* running_var2, double momentum,
+                                                      double momentum2, double eps, double eps2) {
+  for (int i = 0; i < 5; i++) out5[i] = nullptr;
+  if (!x2) { ::lamp::set_last_error("lamp_native_batch_norm2_add_relu_pool_log_softmax: the second input is null"); return 1; }
+  BnSecondArgs sec{x2, weight2, bias2, running_mean2, running_var2, momentum2, eps2};
+  lamp_tensor* o3[3] = {nullptr, nullptr, nullptr};
+  bool pooled = true;
+  const int rc = bn_forward_impl(o3, x, weight, bias, running_mean, running_var, 1, momentum, eps, 1, nullptr, &sec, false, &pooled);
+  if (rc != 0) return rc;
+  lamp_tensor* o = nullptr;
+  const int rc2 = pooled ? lamp_log_softmax(&o, o3[0], 1) : lamp_global_avg_pool_log_softmax(&o, o3[0]);
+  (void)lamp_tensor_release(o3[0]);
+  if (rc2 != 0) {
+    (void)lamp_tensor_release(o3[1]); (void)lamp_tensor_release(o3[2]); (void)lamp_tensor_release(sec.save_mean); (void)lamp_tensor_release(sec.save_invstd);
+    return rc2;
+  }
+  out5[0] = o; out5[1] = o3[1]; out5[2] = o3[2]; out5[3] = sec.save_mean; out5[4] = sec.save_invstd;
   return 0;
 }
 int lamp_native_batch_norm2_add_relu_backward(lamp_tensor* out6[6], const lamp_tensor* grad_out, const lamp_tensor* x, const lamp_tensor* weight,

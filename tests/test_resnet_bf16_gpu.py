@@ -203,6 +203,28 @@ def test_computing_the_tail_gradient_in_the_loss_launch_changes_no_bit(gpu, batc
     assert digests["0"] == digests["1"]
 
 
+@pytest.mark.parametrize("batch", ["64", "1024"])
+def test_the_last_block_with_the_tail_as_one_node_changes_no_bit(gpu, batch):
+    """Round 6: Sequential's look-ahead (nn.cpp) hands the network's tail - AvgPool2D -> Flatten -> LogSoftMax, cnn.scala:129-136 - to the last
+    residual block, whose two batch norms + add + relu then leave plane means instead of the block's output (read by the pool only; never written)
+    and whose backward takes the loss tail's plane gradient directly (LAMP_FUSE_BLOCK_TAIL=0: the two nodes).  Loss, all 37 gradients and every
+    running statistic of a training step are BITWISE the same."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, LAMP_FUSE_BLOCK_TAIL=flag, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, batch], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[flag] = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert digests["0"] == digests["1"]
+    # ... and with the loss tail's short cut off the node's own closures do the work (p -> plane values -> the paired backward): still no bit
+    env = dict(os.environ, LAMP_FUSE_BLOCK_TAIL="1", LAMP_FUSE_LOSS_TAIL="0", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", _STEP_DIGEST, batch], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][0] == digests["0"]
+
+
 def test_running_a_block_s_two_first_convolutions_as_one_launch_changes_no_bit(gpu):
     """Residual's rewrite (nn.cpp): both branches of every block of Cnn.resnet start with a Conv2D on the block's input (cnn.scala:38-45,
     64-72); F::convolution_pair runs the 3x3 and the 1x1 of res3 / res4 in one launch of the eight-image kernel (B >= 1024).  Loss, all 37
