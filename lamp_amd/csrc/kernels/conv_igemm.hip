@@ -1759,21 +1759,35 @@ __device__ unsigned int g_wg8h_stamps[1024 * 8 * 8];
 #ifndef LAMP_WG8H_DMA
 #define LAMP_WG8H_DMA 1          // SHIFT_DY = 2: the dY tiles arrive by LDS-DMA (0: through registers and ds_write, the A/B form)
 #endif
+// A SECOND PROBLEM in the same launch (round 6, igemm_wgrad_group; wgs0 = 0: none): workgroups [0, wgs0) belong to the kernel's own arguments,
+// [wgs0, gridDim.x) to this one - another layer's weight gradient of the same batch.  Two layers share the CUs, so each workgroup walks twice as
+// many images and each layer leaves HALF the partial sums (they are the kernel's store phase and the reduction's whole input: EXPERIMENTS 73).
+struct WgSecondProblem { const bf16_t* dy; const bf16_t* x; float* partial; int CO, CI, CIP, images_per_split, ntile; const float4* affine; int wgs0; };
 template <int SHIFT_DY, bool PAIR = false, bool DMA = (LAMP_WG8H_DMA != 0)>
-__global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                         int N, int CO, int CI, int CIP, int images_per_split, int ntile, const float4* __restrict__ affine,
-                                                         int stream_out, const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2) {
+__global__ __launch_bounds__(512) void ig_wgrad8h_kernel(const bf16_t* __restrict__ dy_, const bf16_t* __restrict__ x_, float* __restrict__ partial_,
+                                                         int N, int CO_, int CI_, int CIP_, int images_per_split_, int ntile_, const float4* __restrict__ affine_,
+                                                         int stream_out, const bf16_t* __restrict__ dy2, float* __restrict__ partial2, int CO2,
+                                                         const WgSecondProblem sp) {
   static_assert(!PAIR || SHIFT_DY == 2, "the pair uses the LDS of the shifted X copies");
+  const bool second_problem = !PAIR && sp.wgs0 > 0 && (int)blockIdx.x >= sp.wgs0;          // (uniform per workgroup)
+  const bf16_t* __restrict__ dy = second_problem ? sp.dy : dy_;
+  const bf16_t* __restrict__ x = second_problem ? sp.x : x_;
+  float* __restrict__ partial = second_problem ? sp.partial : partial_;
+  const int CO = second_problem ? sp.CO : CO_, CI = second_problem ? sp.CI : CI_, CIP = second_problem ? sp.CIP : CIP_;
+  const int images_per_split = second_problem ? sp.images_per_split : images_per_split_, ntile = second_problem ? sp.ntile : ntile_;
+  const float4* __restrict__ affine = second_problem ? sp.affine : affine_;
+  const int wg_index = second_problem ? (int)blockIdx.x - sp.wgs0 : (int)blockIdx.x;
+  const int wg_count = second_problem ? (int)gridDim.x - sp.wgs0 : ((!PAIR && sp.wgs0 > 0) ? sp.wgs0 : (int)gridDim.x);
   // stage layout: [dY tile | X copies ...] or, PAIR, [dY tile | dY2 tile | X]; XC = offset of the unshifted X copy
   constexpr int XC = PAIR ? 2 * IG_WTILE : IG_WTILE + WG_XCOPY;
   constexpr int STG = PAIR ? 2 * IG_WTILE + WG_XCOPY + 512 : WG_STAGE;
   constexpr int ZSLOT = STG - 512;                          // 16 zero bytes per image stage (in the padding; SHIFT_DY = 2 reads them for dY rows outside the image)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 3, RS = 9, PAD = 1;
-  const int nsplit = gridDim.x / ntile;
+  const int nsplit = wg_count / ntile;
   int tile, split;
   {                                                           // XCD-aware: the tiles of one image range share an L2 (see ig_wgrad8v2_kernel)
-    const int b = blockIdx.x;
+    const int b = wg_index;                                   // (host: wgs0 a multiple of 8 - the XCD of a workgroup is blockIdx.x % 8 for both problems)
     if ((nsplit & 7) == 0) { const int xcd = b & 7, slot = b >> 3; tile = slot % ntile; split = xcd + 8 * (slot / ntile); }
     else { tile = b % ntile; split = b / ntile; }
   }
@@ -2592,9 +2606,161 @@ static int wgrad_min_ips(int64_t N) {
   static const int v = [] { const char* e = getenv("LAMP_WGRAD_MIN_IPS"); return e ? std::max(2, atoi(e)) : 0; }();
   return v ? v : (N <= 512 ? 2 : 8);
 }
+// ---- the eight-wave weight-gradient kernel: one launch for one layer (optionally with its sibling 1x1: `second`) or for TWO layers (round 6) ----
+struct SecondWgradConv;
+struct Wg8hProblem { const Tensor* dy; const Tensor* x; Tensor* dw; ConvGeom g; const Tensor* affine; };
+static void wg8h_launch(const Wg8hProblem& a, const Wg8hProblem* b, hipStream_t st, const SecondWgradConv* second);
+// Two layers in one launch.  A layer's launch leaves (256 workgroups) x (its accumulators) of partial sums - 33 MB written by the kernel and read
+// again by the batched reduction, whatever the layer's size; with two layers' workgroups side by side each layer is walked by half the workgroups,
+// twice as many images each, and leaves half of that.  Nothing in backprop waits for a weight gradient (only the optimiser reads it), so a layer
+// that qualifies is PARKED here - its tensors retained, its gradient's storage marked pending like a deferred reduction's - until the next one
+// arrives (res4's second convolution waits for res3's, three kernels later) or anything flushes: the end of backprop, a read of the gradient
+// (Tensor::raw -> resolve_deferred), a stream / device synchronisation, the end of a graph capture.  LAMP_WGRAD_GROUP=0: every layer at once.
+namespace {
+struct ParkedWgrad { Tensor* dy; Tensor* x; Tensor* dw; ConvGeom g; Tensor* affine; hipStream_t st; int device; uint64_t vdy, vx; };
+std::mutex g_wgpark_mu;
+std::vector<ParkedWgrad> g_wgpark;
+void wgpark_release(ParkedWgrad& p) { release(p.dy); release(p.x); release(p.dw); if (p.affine) release(p.affine); }
+void wgpark_check(const ParkedWgrad& p) {
+  // (x is a forward activation: nothing writes it during backprop, but the batch-norm backward that runs meanwhile takes its pointer through the
+  // mutable accessor, which counts as a write - only the gradient's version is held to its value at parking)
+  LAMP_CHECK(p.dy->st->version.load(std::memory_order_relaxed) == p.vdy, "internal: the output gradient of a parked weight gradient was written before its launch");
+}
+}  // namespace
+// every parked layer, alone (called with nothing of this file's locks held; any thread may flush any entry: the launch goes to the entry's stream)
+void igemm_wgrad_flush_parked() {
+  std::vector<ParkedWgrad> v;
+  { std::lock_guard<std::mutex> lk(g_wgpark_mu); v.swap(g_wgpark); }
+  for (auto& p : v) {
+    struct Rel { ParkedWgrad& p; ~Rel() { wgpark_release(p); } } rel{p};
+    wgpark_check(p);
+    const int prev = current_device();
+    if (prev != p.device) set_device(p.device);
+    struct Back { int prev, dev; ~Back() { if (prev != dev) set_device(prev); } } back{prev, p.device};
+    Wg8hProblem a{p.dy, p.x, p.dw, p.g, p.affine};
+    wg8h_launch(a, nullptr, p.st, nullptr);
+  }
+}
+static bool wg8h_group_defer(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine) {
+  static const bool on = [] { const char* e = getenv("LAMP_WGRAD_GROUP"); return !(e && e[0] == '0'); }();
+  static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();
+  // large batches only (a workgroup still walks >= 16 images with half the workgroups), gradients the library owns (the pending flag is honoured
+  // by every reader that goes through Tensor::raw), deferred reductions on
+  if (!on || shift_dy < 2 || !wgrad_reduce_deferred() || !dw->st->owned || g.N < 8 * (int64_t)num_cus()) return false;
+  ParkedWgrad mate{};
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> lk(g_wgpark_mu);
+    for (size_t i = 0; i < g_wgpark.size(); i++)
+      if (g_wgpark[i].st == st && g_wgpark[i].device == dw->device() && g_wgpark[i].g.N == g.N && g_wgpark[i].dw->st != dw->st) {
+        mate = g_wgpark[i]; g_wgpark.erase(g_wgpark.begin() + i); have = true; break;
+      }
+    if (!have) {
+      ParkedWgrad p{retain(const_cast<Tensor*>(dy)), retain(const_cast<Tensor*>(x)), retain(dw), g, affine ? retain(const_cast<Tensor*>(affine)) : nullptr, st,
+                    dw->device(), dy->st->version.load(std::memory_order_relaxed), x->st->version.load(std::memory_order_relaxed)};
+      g_wgpark.push_back(p);
+      dw->st->version.fetch_add(1, std::memory_order_relaxed);  // a writer like any other
+      dw->st->pending.store(1, std::memory_order_release);
+      return true;
+    }
+  }
+  struct Rel { ParkedWgrad& p; ~Rel() { wgpark_release(p); } } rel{mate};
+  wgpark_check(mate);
+  Wg8hProblem a{mate.dy, mate.x, mate.dw, mate.g, mate.affine}, b{dy, x, dw, g, affine};
+  wg8h_launch(a, &b, st, nullptr);
+  return true;
+}
 // second (optional, the eight-wave kernel only): the output gradient of a sibling 1x1 convolution of the same x and the tensor that receives ITS
 // weight gradient - both from the one launch (igemm_conv_wgrad_pair checks the conditions first)
 struct SecondWgradConv { const Tensor* dy; Tensor* dw; const ConvGeom* g; };
+static void wg8h_launch(const Wg8hProblem& pa, const Wg8hProblem* pb, hipStream_t st, const SecondWgradConv* second) {
+  const bool pair = second != nullptr;
+  LAMP_CHECK(!(pair && pb), "internal: the sibling pair and the two-layer group do not combine");
+  const int RS = 9;
+  const int cus = num_cus();
+  struct Plan { int ntile, CIP, ips, nsplit, wgs; Hold partial; };
+  auto plan = [&](const Wg8hProblem& p, int wg_budget) {
+    Plan q;
+    q.ntile = (int)((p.g.Cin + WG_CI - 1) / WG_CI);
+    q.CIP = q.ntile * WG_CI;
+    const int target = std::max(1, wg_budget / q.ntile);
+    q.ips = (int)std::max<int64_t>(1, (p.g.N + target - 1) / target);
+    if (q.ips < wgrad_min_ips(p.g.N) && p.g.N >= wgrad_min_ips(p.g.N)) q.ips = wgrad_min_ips(p.g.N);
+    q.nsplit = (int)((p.g.N + q.ips - 1) / q.ips);
+    q.wgs = q.ntile * q.nsplit;
+    int64_t ps[1] = {(int64_t)q.nsplit * RS * IG_M * q.CIP};
+    q.partial = Hold(new_tensor(ps, 1, kF32, p.x->device()));
+    return q;
+  };
+  // two layers: half the CUs' workgroups each, the first problem's count a multiple of 8 (the kernel's XCD mapping)
+  Plan A = plan(pa, pb ? cus / 2 : cus), B;
+  if (pb) {
+    B = plan(*pb, cus / 2);
+    if (A.wgs % 8 != 0) {                                     // (a ragged first problem would shift the second one's XCDs: not grouped)
+      Wg8hProblem a1 = pa, b1 = *pb;
+      wg8h_launch(a1, nullptr, st, nullptr);
+      wg8h_launch(b1, nullptr, st, nullptr);
+      return;
+    }
+  }
+  static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();   // 0: off, 1: dY rows, 2: + X columns in registers
+  LAMP_CHECK(!(pair || pb) || shift_dy >= 2, "internal: the weight-gradient pair / group needs the register-shifted X fragments");
+  Hold partial2;
+  if (pair) { int64_t ps2[1] = {(int64_t)A.nsplit * IG_M * A.CIP}; partial2 = Hold(new_tensor(ps2, 1, kF32, pa.x->device())); }
+  const size_t lds = pair ? 4 * (size_t)(2 * IG_WTILE + WG_XCOPY + 512) : 4 * (size_t)WG_STAGE;
+  {
+    const double sec_fl = pair ? conv_flops(*second->g) : pb ? conv_flops(pb->g) : 0.0;
+    const double sec_by = pair ? conv_bytes(*second->g, 2) - (double)pa.g.N * pa.g.Cin * 64 * 2 : pb ? conv_bytes(pb->g, 2) : 0.0;   // (pair: x is the one already counted)
+    KernelTimer kt("conv_wgrad_igemm", conv_flops(pa.g) + sec_fl, conv_bytes(pa.g, 2) + sec_by, st);
+    const bf16_t* dy2p = pair ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
+    float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
+    const int co2 = pair ? (int)second->g->Cout : 0;
+    const float4* affp = pa.affine ? reinterpret_cast<const float4*>(pa.affine->ptr<float>()) : (const float4*)nullptr;
+    WgSecondProblem sp{};
+    if (pb) {
+      sp.dy = pb->dy->ptr<bf16_t>(); sp.x = pb->x->ptr<bf16_t>(); sp.partial = B.partial->ptr<float>();
+      sp.CO = (int)pb->g.Cout; sp.CI = (int)pb->g.Cin; sp.CIP = B.CIP; sp.images_per_split = B.ips; sp.ntile = B.ntile;
+      sp.affine = pb->affine ? reinterpret_cast<const float4*>(pb->affine->ptr<float>()) : (const float4*)nullptr;
+      sp.wgs0 = A.wgs;
+    }
+    static const bool wg_stagger = [] { const char* e = getenv("LAMP_WGRAD_STAGGER"); return !(e && e[0] == '0'); }();
+    static const bool wg_prio = [] { const char* e = getenv("LAMP_WGRAD_PRIO"); return !(e && e[0] == '0'); }();
+    // LAMP_WG8H_DMA=0 (run time): the dY tiles through registers and ds_write instead of LDS-DMA - the same arithmetic in the same order, kept
+    // as the fallback and the bitwise A/B of the hand-counted vmcnt waits (tests/test_ops_gpu.py)
+    static const bool wg_dma = [] { const char* e = getenv("LAMP_WG8H_DMA"); return e ? e[0] != '0' : (LAMP_WG8H_DMA != 0); }();
+    const int grid = A.wgs + (pb ? B.wgs : 0);
+#define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
+  do {                                                                                                                                      \
+    if (M_ == 2 && !wg_dma) { IG_LAUNCH_WG8H_(M_, P_, false); } else { IG_LAUNCH_WG8H_(M_, P_, true); }                                       \
+  } while (0)
+#define IG_LAUNCH_WG8H_(M_, P_, D_)                                                                                                         \
+  do {                                                                                                                                      \
+    allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_, D_>);                                                                             \
+    hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_, D_>), dim3(grid), dim3(512), lds, st, pa.dy->ptr<bf16_t>(), pa.x->ptr<bf16_t>(),          \
+                       A.partial->ptr<float>(), (int)pa.g.N, (int)pa.g.Cout, (int)pa.g.Cin, A.CIP, A.ips, A.ntile, affp,                    \
+                       (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2) | (wg_prio ? 4 : 0), dy2p, p2p, co2, sp);                   \
+  } while (0)
+    if (pair) IG_LAUNCH_WG8H(2, true);
+    else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
+#undef IG_LAUNCH_WG8H
+#undef IG_LAUNCH_WG8H_
+    LAMP_LAUNCH_CHECK();
+  }
+  auto enqueue = [&](const Wg8hProblem& p, Plan& q) {
+    const int64_t cols = (int64_t)RS * IG_M * q.CIP / 4;
+    WgradReduceArgs ra{};
+    ra.kind = 0; ra.CO = (int)p.g.Cout; ra.CI = (int)p.g.Cin; ra.CIP = q.CIP; ra.COP = IG_M; ra.RS = RS; ra.nsplit = q.nsplit; ra.blocks = (int)((cols + 31) / 32);
+    wgrad_reduce_enqueue(ra, q.partial.get(), p.dw, st);
+  };
+  enqueue(pa, A);
+  if (pb) enqueue(*pb, B);
+  if (pair) {
+    const int64_t cols2 = (int64_t)IG_M * A.CIP / 4;
+    WgradReduceArgs rb{};
+    rb.kind = 0; rb.CO = (int)second->g->Cout; rb.CI = (int)pa.g.Cin; rb.CIP = A.CIP; rb.COP = IG_M; rb.RS = 1; rb.nsplit = A.nsplit; rb.blocks = (int)((cols2 + 31) / 32);
+    wgrad_reduce_enqueue(rb, partial2.get(), second->dw, st);
+  }
+}
 static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw, const ConvGeom& g, hipStream_t st, const Tensor* affine,
                                   const SecondWgradConv* second) {
   if (!ig_qualifies(g, x->dtype)) return false;
@@ -2604,59 +2770,9 @@ static bool igemm_conv_wgrad_impl(const Tensor* dy, const Tensor* x, Tensor* dw,
   if (affine && !ig_wgrad_folds_affine(g, x->dtype)) return false;
   if (wide_on && KS == 3 && g.Cin > WG_CI && g.Cout > 64) {
     // eight-wave kernel: the v2 decomposition (32-channel slice of Cin, image range) with two waves per SIMD
-    const int ntile = (int)((g.Cin + WG_CI - 1) / WG_CI);
-    const int CIP = ntile * WG_CI;
-    int target = std::max(1, num_cus() / ntile);
-    int ips = (int)std::max<int64_t>(1, (g.N + target - 1) / target);
-    if (ips < wgrad_min_ips(g.N) && g.N >= wgrad_min_ips(g.N)) ips = wgrad_min_ips(g.N);
-    const int nsplit = (int)((g.N + ips - 1) / ips);
-    int64_t ps[1] = {(int64_t)nsplit * RS * IG_M * CIP};
-    Hold partial(new_tensor(ps, 1, kF32, x->device()));
-    static const int shift_dy = [] { const char* e = getenv("LAMP_WGRAD_SHIFT_DY"); return e ? atoi(e) : 2; }();   // 0: off, 1: dY rows, 2: + X columns in registers
-    const bool pair = second != nullptr;
-    LAMP_CHECK(!pair || shift_dy >= 2, "internal: the weight-gradient pair needs the register-shifted X fragments");
-    Hold partial2;
-    if (pair) { int64_t ps2[1] = {(int64_t)nsplit * IG_M * CIP}; partial2 = Hold(new_tensor(ps2, 1, kF32, x->device())); }
-    const size_t lds = pair ? 4 * (size_t)(2 * IG_WTILE + WG_XCOPY + 512) : 4 * (size_t)WG_STAGE;
-    {
-      const double sec_fl = pair ? conv_flops(*second->g) : 0.0;
-      const double sec_by = pair ? conv_bytes(*second->g, 2) - (double)g.N * g.Cin * 64 * 2 : 0.0;          // (x is the one already counted)
-      KernelTimer kt("conv_wgrad_igemm", conv_flops(g) + sec_fl, conv_bytes(g, 2) + sec_by, st);
-      const bf16_t* dy2p = pair ? second->dy->ptr<bf16_t>() : (const bf16_t*)nullptr;
-      float* p2p = pair ? partial2->ptr<float>() : (float*)nullptr;
-      const int co2 = pair ? (int)second->g->Cout : 0;
-      static const bool wg_stagger = [] { const char* e = getenv("LAMP_WGRAD_STAGGER"); return !(e && e[0] == '0'); }();
-      static const bool wg_prio = [] { const char* e = getenv("LAMP_WGRAD_PRIO"); return !(e && e[0] == '0'); }();
-      // LAMP_WG8H_DMA=0 (run time): the dY tiles through registers and ds_write instead of LDS-DMA - the same arithmetic in the same order, kept
-      // as the fallback and the bitwise A/B of the hand-counted vmcnt waits (tests/test_ops_gpu.py)
-      static const bool wg_dma = [] { const char* e = getenv("LAMP_WG8H_DMA"); return e ? e[0] != '0' : (LAMP_WG8H_DMA != 0); }();
-#define IG_LAUNCH_WG8H(M_, P_)                                                                                                              \
-  do {                                                                                                                                      \
-    if (M_ == 2 && !wg_dma) { IG_LAUNCH_WG8H_(M_, P_, false); } else { IG_LAUNCH_WG8H_(M_, P_, true); }                                       \
-  } while (0)
-#define IG_LAUNCH_WG8H_(M_, P_, D_)                                                                                                         \
-  do {                                                                                                                                      \
-    allow_big_lds((const void*)ig_wgrad8h_kernel<M_, P_, D_>);                                                                             \
-    hipLaunchKernelGGL((ig_wgrad8h_kernel<M_, P_, D_>), dim3(ntile * nsplit), dim3(512), lds, st, dy->ptr<bf16_t>(), x->ptr<bf16_t>(),      \
-                       partial->ptr<float>(), (int)g.N, (int)g.Cout, (int)g.Cin, CIP, ips, ntile, affp,                                     \
-                       (wgrad_reduce_deferred() ? 1 : 0) | (wg_stagger ? 0 : 2) | (wg_prio ? 4 : 0), dy2p, p2p, co2);                                                                                                                                            \
-  } while (0)
-      if (pair) IG_LAUNCH_WG8H(2, true);
-      else if (shift_dy >= 2) IG_LAUNCH_WG8H(2, false); else if (shift_dy == 1) IG_LAUNCH_WG8H(1, false); else IG_LAUNCH_WG8H(0, false);
-#undef IG_LAUNCH_WG8H
-#undef IG_LAUNCH_WG8H_
-      LAMP_LAUNCH_CHECK();
-    }
-    const int64_t cols = (int64_t)RS * IG_M * CIP / 4;
-    WgradReduceArgs ra{};
-    ra.kind = 0; ra.CO = (int)g.Cout; ra.CI = (int)g.Cin; ra.CIP = CIP; ra.COP = IG_M; ra.RS = RS; ra.nsplit = nsplit; ra.blocks = (int)((cols + 31) / 32);
-    wgrad_reduce_enqueue(ra, partial.get(), dw, st);
-    if (pair) {
-      const int64_t cols2 = (int64_t)IG_M * CIP / 4;
-      WgradReduceArgs rb{};
-      rb.kind = 0; rb.CO = (int)second->g->Cout; rb.CI = (int)g.Cin; rb.CIP = CIP; rb.COP = IG_M; rb.RS = 1; rb.nsplit = nsplit; rb.blocks = (int)((cols2 + 31) / 32);
-      wgrad_reduce_enqueue(rb, partial2.get(), second->dw, st);
-    }
+    if (!second && wg8h_group_defer(dy, x, dw, g, st, affine)) return true;      // launched with the next such layer's, or by the flush (below)
+    Wg8hProblem a{dy, x, dw, g, affine};
+    wg8h_launch(a, nullptr, st, second);
     return true;
   }
   {

@@ -1638,6 +1638,68 @@ def test_weight_gradient_reductions_are_deferred_and_batched(gpu):
         assert torch.equal(a, f)
 
 
+def test_two_layers_weight_gradients_share_one_launch(gpu):
+    """Round 6: at large batches the eight-wave weight-gradient kernel takes TWO layers in one launch - a layer that qualifies is parked (its gradient
+    marked pending) until the next one arrives, each then gets half the workgroups, twice the images per workgroup and leaves half the partial
+    sums (igemm_wgrad_group; LAMP_WGRAD_GROUP=0: every layer at once).  The gradients are those of the f64 convolution within bf16 tolerance and
+    within the summation-order noise of the separate launches; a layer that stays alone is launched by the flush or by the first read of its
+    gradient; the launch count says which happened."""
+    import os, subprocess, sys
+    dt = torch.bfloat16
+    N = 2048
+    layers = [(100, 100, 7), (128, 128, 11), (128, 100, 13)]
+
+    def wgrad(cin, cout, seed):
+        x = closed_form((N, cin, 8, 8), seed, 2.0, dt)
+        w = closed_form((cout, cin, 3, 3), 17, 1.0, dt)
+        gy = closed_form((N, cout, 8, 8), seed + 16, 1.0, dt)
+        out3 = (C.c_void_p * 3)()
+        lib.lamp_convolution_backward(out3, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0,
+                                      i64_array([0, 0]), 1, (C.c_uint8 * 3)(0, 1, 0))
+        ref = aten.convolution_backward(gy.double(), x.double(), w.double(), [0], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return S.STen(out3[1]), ref
+
+    def launches():
+        buf = C.create_string_buffer(1 << 16)
+        lib.lamp_kernel_timer_report(buf, len(buf))
+        return {l.split()[0]: int(l.split()[1]) for l in buf.value.decode().splitlines() if l.strip()}
+
+    lib.lamp_device_synchronize()
+    lib.lamp_kernel_timer_enable(1)
+    hs = [wgrad(*l) for l in layers]                       # layers 0 and 1 in one launch; layer 2 parked
+    mid = launches().get("conv_wgrad_igemm", 0)
+    got2 = to_torch(hs[2][0])                              # the read launches it alone
+    after = launches()
+    lib.lamp_kernel_timer_enable(0)
+    assert mid == 1 and after.get("conv_wgrad_igemm", 0) == 1, (mid, after)        # (the report starts a new count)
+    got = [to_torch(hs[0][0]), to_torch(hs[1][0]), got2]
+    for g, (_, ref) in zip(got, hs):
+        assert_close(g, ref, 2.0 ** -7, "grouped weight gradient against the f64 convolution")
+    # ... and against the separate launches (another process: the switch is read once): only the order of the image ranges' f32 sums differs
+    code = ("import sys, torch, ctypes as C\n"
+            "from tests.test_ops_gpu import *\n"
+            "from tests.test_ops_gpu import _out3\n"
+            "import numpy as np\n"
+            "outs = []\n"
+            "for (cin, cout, seed) in %r:\n"
+            "    x = closed_form((%d, cin, 8, 8), seed, 2.0, torch.bfloat16); w = closed_form((cout, cin, 3, 3), 17, 1.0, torch.bfloat16); gy = closed_form((%d, cout, 8, 8), seed + 16, 1.0, torch.bfloat16)\n"
+            "    out3 = (C.c_void_p * 3)()\n"
+            "    lib.lamp_convolution_backward(out3, to_sten(gy), to_sten(x), to_sten(w), i64_array([1, 1]), i64_array([1, 1]), i64_array([1, 1]), 2, 0, i64_array([0, 0]), 1, (C.c_uint8 * 3)(0, 1, 0))\n"
+            "    outs.append(to_torch(S.STen(out3[1])).float().numpy())\n"
+            "np.savez(sys.argv[1], *outs)\n") % (layers, N, N)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "alone.npz")
+        out = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, LAMP_WGRAD_GROUP="0", PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        alone = np.load(f)
+        for i, g in enumerate(got):
+            a = torch.from_numpy(alone[f"arr_{i}"]).double()
+            assert_close(g, a, 2.0 ** -7, "grouped against separate launches")
+            assert (g.double() - a).abs().gt(0).float().mean().item() < 0.25, "more than a quarter of the elements changed their rounding"
+
+
 @pytest.mark.parametrize("cin,cout,k,N", [(128, 128, 3, 64), (64, 64, 3, 64), (32, 64, 1, 64), (128, 100, 3, 64),
                                          (128, 128, 3, 1024), (16, 16, 3, 1024), (128, 100, 1, 1024)])   # N = 1024: the eight-image kernel, one triple per workgroup
 def test_batch_norm_takes_its_statistics_from_the_convolution(gpu, cin, cout, k, N):
