@@ -31,6 +31,7 @@
 #include "device_utils.h"
 #include "conv_geom.h"
 #include "wgrad_reduce.h"
+#include <thread>
 #include "conv_narrow_pack.h"
 
 namespace lamp {
@@ -2617,7 +2618,7 @@ static void wg8h_launch(const Wg8hProblem& a, const Wg8hProblem* b, hipStream_t 
 // arrives (res4's second convolution waits for res3's, three kernels later) or anything flushes: the end of backprop, a read of the gradient
 // (Tensor::raw -> resolve_deferred), a stream / device synchronisation, the end of a graph capture.  LAMP_WGRAD_GROUP=0: every layer at once.
 namespace {
-struct ParkedWgrad { Tensor* dy; Tensor* x; Tensor* dw; ConvGeom g; Tensor* affine; hipStream_t st; int device; uint64_t vdy, vx; };
+struct ParkedWgrad { Tensor* dy; Tensor* x; Tensor* dw; ConvGeom g; Tensor* affine; hipStream_t st; int device; uint64_t vdy, vx; std::thread::id owner; };
 std::mutex g_wgpark_mu;
 std::vector<ParkedWgrad> g_wgpark;
 void wgpark_release(ParkedWgrad& p) { release(p.dy); release(p.x); release(p.dw); if (p.affine) release(p.affine); }
@@ -2627,10 +2628,21 @@ void wgpark_check(const ParkedWgrad& p) {
   LAMP_CHECK(p.dy->st->version.load(std::memory_order_relaxed) == p.vdy, "internal: the output gradient of a parked weight gradient was written before its launch");
 }
 }  // namespace
-// every parked layer, alone (called with nothing of this file's locks held; any thread may flush any entry: the launch goes to the entry's stream)
-void igemm_wgrad_flush_parked() {
+// the parked layers, each alone (called with nothing of this file's locks held).  An entry belongs to the thread that parked it, like a deferred
+// reduction: flush_deferred() launches the CALLER's (all = false) - a replica thread of the single-process data-parallel step must not launch
+// another's half-finished pass early -, a read of a pending gradient (resolve_deferred) launches everybody's: the launch goes to the entry's stream
+void igemm_wgrad_flush_parked(bool all) {
   std::vector<ParkedWgrad> v;
-  { std::lock_guard<std::mutex> lk(g_wgpark_mu); v.swap(g_wgpark); }
+  {
+    std::lock_guard<std::mutex> lk(g_wgpark_mu);
+    const std::thread::id me = std::this_thread::get_id();
+    size_t keep = 0;
+    for (size_t i = 0; i < g_wgpark.size(); i++) {
+      if (all || g_wgpark[i].owner == me) v.push_back(g_wgpark[i]);
+      else g_wgpark[keep++] = g_wgpark[i];
+    }
+    g_wgpark.resize(keep);
+  }
   for (auto& p : v) {
     struct Rel { ParkedWgrad& p; ~Rel() { wgpark_release(p); } } rel{p};
     wgpark_check(p);
@@ -2651,13 +2663,14 @@ static bool wg8h_group_defer(const Tensor* dy, const Tensor* x, Tensor* dw, cons
   bool have = false;
   {
     std::lock_guard<std::mutex> lk(g_wgpark_mu);
+    const std::thread::id me = std::this_thread::get_id();
     for (size_t i = 0; i < g_wgpark.size(); i++)
-      if (g_wgpark[i].st == st && g_wgpark[i].device == dw->device() && g_wgpark[i].g.N == g.N && g_wgpark[i].dw->st != dw->st) {
+      if (g_wgpark[i].owner == me && g_wgpark[i].st == st && g_wgpark[i].device == dw->device() && g_wgpark[i].g.N == g.N && g_wgpark[i].dw->st != dw->st) {
         mate = g_wgpark[i]; g_wgpark.erase(g_wgpark.begin() + i); have = true; break;
       }
     if (!have) {
       ParkedWgrad p{retain(const_cast<Tensor*>(dy)), retain(const_cast<Tensor*>(x)), retain(dw), g, affine ? retain(const_cast<Tensor*>(affine)) : nullptr, st,
-                    dw->device(), dy->st->version.load(std::memory_order_relaxed), x->st->version.load(std::memory_order_relaxed)};
+                    dw->device(), dy->st->version.load(std::memory_order_relaxed), x->st->version.load(std::memory_order_relaxed), me};
       g_wgpark.push_back(p);
       dw->st->version.fetch_add(1, std::memory_order_relaxed);  // a writer like any other
       dw->st->pending.store(1, std::memory_order_release);

@@ -94,16 +94,16 @@ void flush_owner_locked(std::thread::id owner) {
 }
 }  // namespace
 
-void igemm_wgrad_flush_parked();     // conv_igemm.hip: weight-gradient LAUNCHES that wait for a second layer to share the chip with (they register their reductions here)
+void igemm_wgrad_flush_parked(bool all);     // conv_igemm.hip: weight-gradient LAUNCHES that wait for a second layer to share the chip with (they register their reductions here)
 void flush_deferred() {
-  igemm_wgrad_flush_parked();
+  igemm_wgrad_flush_parked(false);
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_pending.empty()) return;
   flush_owner_locked(std::this_thread::get_id());
 }
 
 void resolve_deferred(Storage* st) {
-  igemm_wgrad_flush_parked();
+  igemm_wgrad_flush_parked(true);
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& p : g_pending)
     if (p.dw->st == st) { flush_owner_locked(p.owner); return; }
